@@ -1,0 +1,112 @@
+/*
+ * include/nsx.h -- C ABI of libnsx.so, the MI355X (gfx950) native library for the
+ * NeRSemble per-sample hot path.
+ *
+ * The reference (tobias-kirschstein/nersemble) is pure Python and reaches its native
+ * code through three third-party Python packages; this library supplies those native
+ * entry points.  Every function documents the reference interface it replaces as
+ * file:line relative to the reference repository root.
+ *
+ * Conventions
+ *   - extern "C", plain pointers + sizes, no torch / C++ types.
+ *   - All data pointers are DEVICE pointers owned by the caller (borrowed for the call,
+ *     never retained or freed); `stream` is a hipStream_t passed as void*.
+ *   - Return value: 0 = NSX_OK, negative = error; nsx_last_error() returns a
+ *     thread-local human readable message.  No exceptions cross the ABI.
+ *   - Kernels are enqueued on `stream`; no hidden synchronisation unless stated.
+ *   - fp16 buffers are IEEE binary16 bit patterns (uint16_t storage).
+ */
+#ifndef NSX_H
+#define NSX_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NSX_OK 0
+#define NSX_ERR_INVALID (-1)
+#define NSX_ERR_HIP (-2)
+#define NSX_ERR_UNSUPPORTED (-3)
+
+#define NSX_MAX_LEVELS 32
+#define NSX_VERSION 100
+
+typedef uint16_t nsx_half;
+
+/* Multi-resolution hash-grid geometry.  Replaces the tcnn HashGrid constructor reached
+ * from hash_ensemble.py:41-50 (TCNNHashEncodingConfig.setup). */
+typedef struct nsx_grid_geom {
+    int32_t  n_levels;
+    int32_t  log2_hashmap_size;
+    int32_t  base_resolution;
+    float    per_level_scale;
+    float    scale[NSX_MAX_LEVELS];      /* exp2f(l*log2f(s))*base - 1                       */
+    uint32_t res[NSX_MAX_LEVELS];        /* ceilf(scale)+1                                   */
+    uint32_t size[NSX_MAX_LEVELS];       /* entries of the level                             */
+    uint32_t offset[NSX_MAX_LEVELS + 1]; /* first entry of each level; [n_levels] = total    */
+    uint32_t hashed[NSX_MAX_LEVELS];     /* 1: coherent-prime hash & (size-1); 0: dense walk */
+} nsx_grid_geom;
+
+int         nsx_version(void);
+const char* nsx_last_error(void);
+
+/* Host-only.  hash_ensemble.py:31-50. */
+int nsx_grid_geometry(int n_levels, float per_level_scale, int base_resolution,
+                      int log2_hashmap_size, nsx_grid_geom* out);
+
+/* Padded number of grids used by the interleaved layout (next power of two >= H). */
+int nsx_padded_grids(int H);
+
+/* ---- parameter layout conversion (checkpoint compatibility) --------------------------------
+ * tcnn layout  : C = ceil(2H/8) encodings, each [total_entries][F_enc] (F_enc = 8, or 2H if
+ *                2H < 8), feature j = p*2+f of encoding c belongs to logical grid h = c*P+p
+ *                (hash_ensemble.py:84-112; state-dict keys
+ *                field.hash_ensemble.hash_encodings.{c}.params).
+ * native layout: [total_entries][2][Hp] fp16 -- all grids of one entry are contiguous
+ *                (Hp = nsx_padded_grids(H); one entry = 4*Hp bytes = one 128-B line at H=32).
+ * src/dst tcnn buffers are fp32 (the reference keeps fp32 master params). */
+int nsx_tables_from_tcnn(const float* tcnn_params, int H, const nsx_grid_geom* g,
+                         nsx_half* native_f16, float* native_master_f32 /* may be NULL */,
+                         void* stream);
+int nsx_tables_to_tcnn(const float* native_master_f32, int H, const nsx_grid_geom* g,
+                       float* tcnn_params, void* stream);
+/* fp32 native gradient/master -> tcnn layout is the same permutation (use nsx_tables_to_tcnn). */
+
+/* ---- HashEnsemble ---------------------------------------------------------------------------
+ * Replaces HashEnsemble.forward (hash_ensemble.py:93-158): the C tcnn HashGrid launches
+ * (:102-104), torch.stack (:106), einops rearrange (:112), grid window (:133-138) and the
+ * blend einsum (:155-156) as ONE kernel that never materialises [B, 32, H].
+ *   x          [B][3] fp32 in [0,1)  (the field zeroes out-of-box samples first,
+ *              nersemble_nerfacto_field.py:268-269)
+ *   tables     native layout fp16
+ *   code       fp32 rows of H values; row of sample b = code[(code_index ? code_index[b] : b) * code_stride]
+ *              (code_index lets the caller pass the [T][H] time embedding + per-sample timestep instead
+ *              of the gathered [B][H] copy, nersemble_instant_ngp.py:310-312)
+ *   window     [H] fp32 or NULL: per-grid window multiplied onto the code (hash_ensemble.py:133-138)
+ *   out        [B][2*n_levels] fp16
+ */
+int nsx_hash_ensemble_fwd(const float* x, int64_t B, const nsx_half* tables, int H,
+                          const nsx_grid_geom* g, const float* code, int64_t code_stride,
+                          const int32_t* code_index, const float* window, nsx_half* out,
+                          void* stream);
+
+/* Backward of the above (tcnn kernel_grid_backward + kernel_grid_backward_input + einsum/rearrange
+ * backward, reached through autograd from hash_ensemble.py:102-156).
+ *   dout       [B][2*n_levels] fp32 (upstream gradient, already loss-scaled by the caller if desired)
+ *   dtables    native layout fp32, ACCUMULATED into with atomics (caller zeroes); may be NULL
+ *   dcode      [B][H] fp32: gradient w.r.t. the (windowed) per-sample code row; may be NULL
+ *   dx         [B][3] fp32; may be NULL
+ */
+int nsx_hash_ensemble_bwd(const float* x, int64_t B, const nsx_half* tables, int H,
+                          const nsx_grid_geom* g, const float* code, int64_t code_stride,
+                          const int32_t* code_index, const float* window, const float* dout,
+                          float* dtables, float* dcode, float* dx, void* stream);
+
+/* Debug/parity helper: the 8 level-local entry indices per (sample, level), uint32 [B][L][8].
+ * Integer outputs are held bit-exact to the oracle. */
+int nsx_hash_indices(const float* x, int64_t B, const nsx_grid_geom* g, uint32_t* idx, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,103 @@
+"""ctypes binding of csrc/libnsx.so (C ABI: include/nsx.h).  Fails loudly when the library is absent."""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "csrc", "libnsx.so")
+NSX_MAX_LEVELS = 32
+
+c_void_p, c_int, c_int64, c_float = C.c_void_p, C.c_int, C.c_int64, C.c_float
+
+
+class GridGeom(C.Structure):
+    """Mirror of ``nsx_grid_geom`` (include/nsx.h)."""
+    _fields_ = [
+        ("n_levels", C.c_int32),
+        ("log2_hashmap_size", C.c_int32),
+        ("base_resolution", C.c_int32),
+        ("per_level_scale", C.c_float),
+        ("scale", C.c_float * NSX_MAX_LEVELS),
+        ("res", C.c_uint32 * NSX_MAX_LEVELS),
+        ("size", C.c_uint32 * NSX_MAX_LEVELS),
+        ("offset", C.c_uint32 * (NSX_MAX_LEVELS + 1)),
+        ("hashed", C.c_uint32 * NSX_MAX_LEVELS),
+    ]
+
+    @property
+    def total_entries(self) -> int:
+        return int(self.offset[self.n_levels])
+
+
+_GEOM_P = C.POINTER(GridGeom)
+
+# name -> (restype, argtypes); must list every symbol include/nsx.h declares (tests check this)
+SIGNATURES = {
+    "nsx_version": (c_int, []),
+    "nsx_last_error": (C.c_char_p, []),
+    "nsx_grid_geometry": (c_int, [c_int, c_float, c_int, c_int, _GEOM_P]),
+    "nsx_padded_grids": (c_int, [c_int]),
+    "nsx_tables_from_tcnn": (c_int, [c_void_p, c_int, _GEOM_P, c_void_p, c_void_p, c_void_p]),
+    "nsx_tables_to_tcnn": (c_int, [c_void_p, c_int, _GEOM_P, c_void_p, c_void_p]),
+    "nsx_hash_ensemble_fwd": (c_int, [c_void_p, c_int64, c_void_p, c_int, _GEOM_P, c_void_p, c_int64, c_void_p,
+                                      c_void_p, c_void_p, c_void_p]),
+    "nsx_hash_ensemble_bwd": (c_int, [c_void_p, c_int64, c_void_p, c_int, _GEOM_P, c_void_p, c_int64, c_void_p,
+                                      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "nsx_hash_indices": (c_int, [c_void_p, c_int64, _GEOM_P, c_void_p, c_void_p]),
+}
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Loads libnsx.so.  No fallback: a missing library is an error (build with __graft_entry__.build())."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise RuntimeError(
+                f"nersemble_amd: native library {SO_PATH} not found. Build it with "
+                f"`python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc). There is no CPU fallback.")
+        handle = C.CDLL(SO_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = lib().nsx_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"libnsx {what} failed (rc={rc}): {msg}")
+
+
+def ptr(t, dtype=None) -> c_void_p:
+    """Raw device pointer of a contiguous CUDA(HIP) tensor; None -> NULL."""
+    if t is None:
+        return c_void_p(0)
+    if not t.is_cuda:
+        raise RuntimeError("nersemble_amd native ops need device tensors (cuda/HIP); got a CPU tensor. "
+                           "There is no CPU fallback.")
+    if not t.is_contiguous():
+        raise RuntimeError("nersemble_amd native ops need contiguous tensors")
+    if dtype is not None and t.dtype != dtype:
+        raise RuntimeError(f"expected dtype {dtype}, got {t.dtype}")
+    return c_void_p(t.data_ptr())
+
+
+def stream() -> c_void_p:
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def grid_geometry(n_levels=16, per_level_scale=1.4472692012786865, base_resolution=16,
+                  log2_hashmap_size=19) -> GridGeom:
+    g = GridGeom()
+    check(lib().nsx_grid_geometry(n_levels, per_level_scale, base_resolution, log2_hashmap_size, C.byref(g)),
+          "nsx_grid_geometry")
+    return g
+
+
+def padded_grids(H: int) -> int:
+    return int(lib().nsx_padded_grids(H))

@@ -1,0 +1,540 @@
+// hash_ensemble.hip -- fused HashEnsemble forward / backward for gfx950 (CDNA4).
+//
+// Replaces, as ONE kernel each way, what the reference does in HashEnsemble.forward
+// (src/nersemble/nerfstudio/field_components/hash_ensemble.py:93-158): C separate tcnn HashGrid
+// launches (:102-104), torch.stack (:106), einops rearrange (:112), grid window (:133-138) and the
+// blend einsum 'bdh,bh->bd' (:155-156) -- without ever materialising the [B, 32, H] product.
+//
+// MI355X design
+//   * native table layout [entry][f][h] fp16: all H grids of one entry are contiguous, 4*H bytes
+//     (H=32: exactly one 128-B line per trilinear corner).  All C tcnn encodings share geometry
+//     (hash_ensemble.py:84-85), so the corner index is computed once and shared by every grid.
+//   * lane mapping: LPE = H/4 lanes cover one entry with one 16-B load each, so a wave-instruction
+//     fetches 64/LPE whole entries (H=32: 8 full 128-B lines, fully coalesced per line).
+//     lane = (sample s, chunk q); the wave walks the 8 corners with 8 independent loads in flight,
+//     accumulates w_k * <features, code> with v_dot2c_f32_f16 (fp32 accumulate), then reduces the
+//     LPE/2 lanes of each feature with cross-lane xor shuffles.
+//   * the per-sample code row is read once per sample (optionally through an index into the [T][H]
+//     time embedding -- no [B][H] gather is materialised), rounded to fp16 like the reference does
+//     (hash_ensemble.py:155) and kept packed in registers.
+//   * per-level results are staged through a tiny LDS tile so the [B][32] fp16 output is written
+//     with coalesced dword stores.
+// Roofline: HBM-bound; algorithmic bytes per sample = 512*H (8 corners x 16 levels x 4H B) + 80.
+#include "nsx_common.h"
+
+namespace nsx {
+
+template <int H>
+struct EnsCfg {
+    static_assert(H == 1 || H == 2 || H == 4 || H == 8 || H == 16 || H == 32, "padded grid count");
+    static constexpr int ROW_BYTES = 4 * H;                          // 2 features x H grids x fp16
+    static constexpr int LANE_BYTES = ROW_BYTES < 16 ? ROW_BYTES : 16;
+    static constexpr int NDW = LANE_BYTES / 4;                       // dwords per lane load
+    static constexpr int LPE = ROW_BYTES / LANE_BYTES;               // lanes per entry
+    static constexpr int SPW = kWave / LPE;                          // samples per wave step
+    static constexpr int DPF = H >= 2 ? H / 2 : 1;                   // dwords per feature plane
+};
+
+template <int NDW> struct LaneVec;
+template <> struct LaneVec<1> { uint32_t d[1]; };
+template <> struct LaneVec<2> { uint32_t d[2]; };
+template <> struct LaneVec<4> { uint32_t d[4]; };
+
+template <int NDW>
+__device__ __forceinline__ LaneVec<NDW> load_lane(const uint8_t* p) {
+    LaneVec<NDW> r;
+    if constexpr (NDW == 4) {
+        uint4 v = *reinterpret_cast<const uint4*>(p);
+        r.d[0] = v.x; r.d[1] = v.y; r.d[2] = v.z; r.d[3] = v.w;
+    } else if constexpr (NDW == 2) {
+        uint2 v = *reinterpret_cast<const uint2*>(p);
+        r.d[0] = v.x; r.d[1] = v.y;
+    } else {
+        r.d[0] = *reinterpret_cast<const uint32_t*>(p);
+    }
+    return r;
+}
+
+struct Cell {
+    uint32_t cx, cy, cz;
+    float wx, wy, wz;
+};
+
+__device__ __forceinline__ Cell cell_of(float scale, float px, float py, float pz) {
+    Cell c;
+    float p = __fmaf_rn(scale, px, 0.5f); float f = floorf(p); c.cx = (uint32_t)(int32_t)f; c.wx = p - f;
+    p = __fmaf_rn(scale, py, 0.5f); f = floorf(p); c.cy = (uint32_t)(int32_t)f; c.wy = p - f;
+    p = __fmaf_rn(scale, pz, 0.5f); f = floorf(p); c.cz = (uint32_t)(int32_t)f; c.wz = p - f;
+    return c;
+}
+
+// Level-local entry indices of the 8 corners (k bit0 = x, bit1 = y, bit2 = z).
+__device__ __forceinline__ void corner_indices(const Cell& c, uint32_t res, uint32_t size, bool hashed,
+                                               uint32_t idx[8]) {
+    if (hashed) {
+        const uint32_t mask = size - 1u;
+        const uint32_t y0 = c.cy * 2654435761u, y1 = (c.cy + 1u) * 2654435761u;
+        const uint32_t z0 = c.cz * 805459861u, z1 = (c.cz + 1u) * 805459861u;
+        const uint32_t x0 = c.cx, x1 = c.cx + 1u;
+        idx[0] = (x0 ^ y0 ^ z0) & mask; idx[1] = (x1 ^ y0 ^ z0) & mask;
+        idx[2] = (x0 ^ y1 ^ z0) & mask; idx[3] = (x1 ^ y1 ^ z0) & mask;
+        idx[4] = (x0 ^ y0 ^ z1) & mask; idx[5] = (x1 ^ y0 ^ z1) & mask;
+        idx[6] = (x0 ^ y1 ^ z1) & mask; idx[7] = (x1 ^ y1 ^ z1) & mask;
+    } else {
+        const float inv = 1.0f / (float)size;
+        const uint32_t r2 = res * res;
+        const uint32_t y0 = c.cy * res, y1 = y0 + res;
+        const uint32_t z0 = c.cz * r2, z1 = z0 + r2;
+        const uint32_t x0 = c.cx, x1 = c.cx + 1u;
+        idx[0] = umod(x0 + y0 + z0, size, inv); idx[1] = umod(x1 + y0 + z0, size, inv);
+        idx[2] = umod(x0 + y1 + z0, size, inv); idx[3] = umod(x1 + y1 + z0, size, inv);
+        idx[4] = umod(x0 + y0 + z1, size, inv); idx[5] = umod(x1 + y0 + z1, size, inv);
+        idx[6] = umod(x0 + y1 + z1, size, inv); idx[7] = umod(x1 + y1 + z1, size, inv);
+    }
+}
+
+__device__ __forceinline__ void corner_weights(const Cell& c, float w[8]) {
+    const float ax = 1.0f - c.wx, ay = 1.0f - c.wy, az = 1.0f - c.wz;
+    const float yz00 = ay * az, yz10 = c.wy * az, yz01 = ay * c.wz, yz11 = c.wy * c.wz;
+    w[0] = ax * yz00; w[1] = c.wx * yz00; w[2] = ax * yz10; w[3] = c.wx * yz10;
+    w[4] = ax * yz01; w[5] = c.wx * yz01; w[6] = ax * yz11; w[7] = c.wx * yz11;
+}
+
+// Packed fp16 code for this lane's dwords (code * window, rounded to fp16 once).
+template <int H>
+__device__ __forceinline__ void load_code(const float* __restrict__ row, const float* __restrict__ window,
+                                          int Hreal, int q, half2_t cw[EnsCfg<H>::NDW]) {
+    using C = EnsCfg<H>;
+    if constexpr (H == 1) {
+        float c0 = row[0] * (window ? window[0] : 1.0f);
+        cw[0] = half2_t{(half_t)c0, (half_t)c0};
+    } else {
+#pragma unroll
+        for (int j = 0; j < C::NDW; ++j) {
+            const int pair = (q * C::NDW + j) % C::DPF;
+            const int h0 = 2 * pair, h1 = h0 + 1;
+            float c0 = 0.f, c1 = 0.f;
+            if (h0 < Hreal) c0 = row[h0] * (window ? window[h0] : 1.0f);
+            if (h1 < Hreal) c1 = row[h1] * (window ? window[h1] : 1.0f);
+            cw[j] = half2_t{(half_t)c0, (half_t)c1};
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------
+template <int H, int WAVES>
+__global__ __launch_bounds__(WAVES * kWave) void ens_fwd_kernel(
+    const float* __restrict__ x, int64_t B, const uint8_t* __restrict__ tab, const nsx_grid_geom g,
+    const float* __restrict__ code, int64_t code_stride, const int32_t* __restrict__ code_index,
+    const float* __restrict__ window, int Hreal, uint32_t* __restrict__ out, int64_t n_tiles) {
+    using C = EnsCfg<H>;
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];   // [WAVES][SPW][L + 4] dwords
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x / kWave;
+    const int L = g.n_levels;
+    const int row_dw = L + 4;                       // +16 B pad: conflict-free 8-row column writes
+    uint32_t* stage = smem + (size_t)wave * C::SPW * row_dw;
+    half_t* stage_h = reinterpret_cast<half_t*>(stage);
+    const int s = lane / C::LPE, q = lane % C::LPE;
+    const int64_t wave_global = (int64_t)blockIdx.x * WAVES + wave;
+    const int64_t wave_count = (int64_t)gridDim.x * WAVES;
+
+    for (int64_t tile = wave_global; tile < n_tiles; tile += wave_count) {
+        const int64_t b_raw = tile * C::SPW + s;
+        const int64_t b = b_raw < B ? b_raw : B - 1;
+        const float px = x[b * 3 + 0], py = x[b * 3 + 1], pz = x[b * 3 + 2];
+        half2_t cw[C::NDW];
+        {
+            const int64_t r = code_index ? (int64_t)code_index[b] : b;
+            load_code<H>(code + r * code_stride, window, Hreal, q, cw);
+        }
+        for (int l = 0; l < L; ++l) {
+            const float scale = g.scale[l];
+            const uint32_t res = g.res[l], size = g.size[l], off = g.offset[l];
+            const bool hashed = g.hashed[l] != 0;
+            const Cell c = cell_of(scale, px, py, pz);
+            uint32_t idx[8];
+            float w[8];
+            corner_indices(c, res, size, hashed, idx);
+            corner_weights(c, w);
+            LaneVec<C::NDW> v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const uint8_t* p = tab + (size_t)(off + idx[k]) * C::ROW_BYTES + q * C::LANE_BYTES;
+                v[k] = load_lane<C::NDW>(p);
+            }
+            float acc0 = 0.f, acc1 = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if constexpr (H == 1) {
+                    const half2_t t = as_half2(v[k].d[0]);
+                    acc0 = __fmaf_rn(w[k], (float)t.x * (float)cw[0].x, acc0);
+                    acc1 = __fmaf_rn(w[k], (float)t.y * (float)cw[0].x, acc1);
+                } else if constexpr (C::NDW > C::DPF) {     // H = 2, 4: both features in one lane
+                    float t0 = 0.f, t1 = 0.f;
+#pragma unroll
+                    for (int j = 0; j < C::DPF; ++j) {
+                        t0 = dot2(v[k].d[j], cw[j], t0);
+                        t1 = dot2(v[k].d[C::DPF + j], cw[C::DPF + j], t1);
+                    }
+                    acc0 = __fmaf_rn(w[k], t0, acc0);
+                    acc1 = __fmaf_rn(w[k], t1, acc1);
+                } else {                                    // H >= 8: one feature per lane
+                    float t = 0.f;
+#pragma unroll
+                    for (int j = 0; j < C::NDW; ++j) t = dot2(v[k].d[j], cw[j], t);
+                    acc0 = __fmaf_rn(w[k], t, acc0);
+                }
+            }
+            if constexpr (C::LPE >= 2) {
+                // lanes [0, LPE/2) of a sample hold feature 0 partials, [LPE/2, LPE) feature 1
+#pragma unroll
+                for (int m = 1; m < C::LPE / 2; m <<= 1) acc0 += __shfl_xor(acc0, m);
+                if ((q & (C::LPE / 2 - 1)) == 0) {
+                    const int f = q / (C::LPE / 2);
+                    stage_h[(s * row_dw + l) * 2 + f] = (half_t)acc0;
+                }
+            } else {
+                stage[s * row_dw + l] = as_u32(half2_t{(half_t)acc0, (half_t)acc1});
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // coalesced dword stores of the [SPW][L] tile
+        const int64_t base_row = tile * C::SPW;
+        for (int i = lane; i < C::SPW * L; i += kWave) {
+            const int r = i / L, cdw = i - r * L;
+            if (base_row + r < B) out[(base_row + r) * L + cdw] = stage[r * row_dw + cdw];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward: table gradient (fp32 atomics into the native layout), code gradient, position gradient
+// ------------------------------------------------------------------------------------------------
+template <int H, int WAVES>
+__global__ __launch_bounds__(WAVES * kWave) void ens_bwd_kernel(
+    const float* __restrict__ x, int64_t B, const uint8_t* __restrict__ tab, const nsx_grid_geom g,
+    const float* __restrict__ code, int64_t code_stride, const int32_t* __restrict__ code_index,
+    const float* __restrict__ window, int Hreal, const float* __restrict__ dout,
+    float* __restrict__ dtab, float* __restrict__ dcode, float* __restrict__ dx, int64_t n_tiles) {
+    using C = EnsCfg<H>;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x / kWave;
+    const int L = g.n_levels;
+    const int s = lane / C::LPE, q = lane % C::LPE;
+    const int64_t wave_global = (int64_t)blockIdx.x * WAVES + wave;
+    const int64_t wave_count = (int64_t)gridDim.x * WAVES;
+    constexpr int NH = 2 * C::NDW;   // fp16 values per lane load
+
+    for (int64_t tile = wave_global; tile < n_tiles; tile += wave_count) {
+        const int64_t b_raw = tile * C::SPW + s;
+        const bool valid = b_raw < B;
+        const int64_t b = valid ? b_raw : B - 1;
+        const float px = x[b * 3 + 0], py = x[b * 3 + 1], pz = x[b * 3 + 2];
+        half2_t cw[C::NDW];
+        {
+            const int64_t r = code_index ? (int64_t)code_index[b] : b;
+            load_code<H>(code + r * code_stride, window, Hreal, q, cw);
+        }
+        float dc[NH];
+#pragma unroll
+        for (int i = 0; i < NH; ++i) dc[i] = 0.f;
+        float dxa = 0.f, dya = 0.f, dza = 0.f;
+        const float* drow = dout + b * (2 * L);
+
+        for (int l = 0; l < L; ++l) {
+            const float scale = g.scale[l];
+            const uint32_t res = g.res[l], size = g.size[l], off = g.offset[l];
+            const bool hashed = g.hashed[l] != 0;
+            float g0 = drow[2 * l], g1 = drow[2 * l + 1];
+            if (!valid) { g0 = 0.f; g1 = 0.f; }
+            const Cell c = cell_of(scale, px, py, pz);
+            uint32_t idx[8];
+            float w[8];
+            corner_indices(c, res, size, hashed, idx);
+            corner_weights(c, w);
+            LaneVec<C::NDW> v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const uint8_t* p = tab + (size_t)(off + idx[k]) * C::ROW_BYTES + q * C::LANE_BYTES;
+                v[k] = load_lane<C::NDW>(p);
+            }
+            // per-lane feature selector for H >= 8 (one feature plane per lane)
+            const float gl = (C::LPE >= 2) ? ((q / (C::LPE / 2 > 0 ? C::LPE / 2 : 1)) ? g1 : g0) : 0.f;
+            const float ax = 1.0f - c.wx, ay = 1.0f - c.wy, az = 1.0f - c.wz;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                // blended_k = sum_f g_f * sum_h table[f][h] * code[h]  (this lane's share)
+                float blended = 0.f;
+                float* gdst = dtab ? dtab + ((size_t)(off + idx[k]) * C::ROW_BYTES + q * C::LANE_BYTES) / 2 : nullptr;
+                if constexpr (H == 1) {
+                    const half2_t t = as_half2(v[k].d[0]);
+                    const float cf = (float)cw[0].x;
+                    blended = (g0 * (float)t.x + g1 * (float)t.y) * cf;
+                    dc[0] = __fmaf_rn(w[k], g0 * (float)t.x + g1 * (float)t.y, dc[0]);
+                    if (gdst) {
+                        atomicAdd(gdst + 0, w[k] * g0 * cf);
+                        atomicAdd(gdst + 1, w[k] * g1 * cf);
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < C::NDW; ++j) {
+                        float gf;
+                        if constexpr (C::NDW > C::DPF) gf = (j >= C::DPF) ? g1 : g0;
+                        else gf = gl;
+                        const half2_t t = as_half2(v[k].d[j]);
+                        const float wg = w[k] * gf;
+                        blended = __fmaf_rn(gf, dot2(v[k].d[j], cw[j], 0.f), blended);
+                        dc[2 * j + 0] = __fmaf_rn(wg, (float)t.x, dc[2 * j + 0]);
+                        dc[2 * j + 1] = __fmaf_rn(wg, (float)t.y, dc[2 * j + 1]);
+                        if (gdst) {
+                            atomicAdd(gdst + 2 * j + 0, wg * (float)cw[j].x);
+                            atomicAdd(gdst + 2 * j + 1, wg * (float)cw[j].y);
+                        }
+                    }
+                }
+                // d w_k / d pos_d = sign * product of the other two weights
+                const float ox = (k & 2 ? c.wy : ay) * (k & 4 ? c.wz : az);
+                const float oy = (k & 1 ? c.wx : ax) * (k & 4 ? c.wz : az);
+                const float oz = (k & 1 ? c.wx : ax) * (k & 2 ? c.wy : ay);
+                const float sb = scale * blended;
+                dxa = __fmaf_rn((k & 1) ? sb : -sb, ox, dxa);
+                dya = __fmaf_rn((k & 2) ? sb : -sb, oy, dya);
+                dza = __fmaf_rn((k & 4) ? sb : -sb, oz, dza);
+            }
+        }
+        // position gradient: reduce over the LPE lanes of the sample
+        if (dx) {
+#pragma unroll
+            for (int m = 1; m < C::LPE; m <<= 1) {
+                dxa += __shfl_xor(dxa, m); dya += __shfl_xor(dya, m); dza += __shfl_xor(dza, m);
+            }
+            if (q == 0 && valid) { dx[b * 3 + 0] = dxa; dx[b * 3 + 1] = dya; dx[b * 3 + 2] = dza; }
+        }
+        // code gradient: grid h receives contributions of both feature planes
+        if (dcode) {
+            if constexpr (H == 1) {
+                if (valid) dcode[b] = dc[0];
+            } else if constexpr (C::NDW > C::DPF) {   // H = 2, 4: features are dwords [0,DPF) and [DPF,2DPF)
+#pragma unroll
+                for (int j = 0; j < C::DPF; ++j) {
+                    const int h0 = 2 * j;
+                    const float a = dc[2 * j] + dc[2 * (C::DPF + j)];
+                    const float bq = dc[2 * j + 1] + dc[2 * (C::DPF + j) + 1];
+                    if (valid && h0 < Hreal) dcode[b * Hreal + h0] = a;
+                    if (valid && h0 + 1 < Hreal) dcode[b * Hreal + h0 + 1] = bq;
+                }
+            } else {                                   // H >= 8: partner lane q ^ (LPE/2) holds the other plane
+#pragma unroll
+                for (int i = 0; i < NH; ++i) dc[i] += __shfl_xor(dc[i], C::LPE / 2);
+                if (valid && q < C::LPE / 2) {
+#pragma unroll
+                    for (int j = 0; j < C::NDW; ++j) {
+                        const int pair = (q * C::NDW + j) % C::DPF;
+                        const int h0 = 2 * pair;
+                        if (h0 < Hreal) dcode[b * Hreal + h0] = dc[2 * j];
+                        if (h0 + 1 < Hreal) dcode[b * Hreal + h0 + 1] = dc[2 * j + 1];
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// layout conversion + index dump
+// ------------------------------------------------------------------------------------------------
+__global__ void tables_from_tcnn_kernel(const float* __restrict__ src, int H, int Hp, int F_enc, int P,
+                                        uint64_t total, half_t* __restrict__ dst16, float* __restrict__ dst32) {
+    // one thread per native element (e, f, h)
+    const uint64_t n = total * 2ull * (uint64_t)Hp;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const int h = (int)(i % Hp);
+        const int f = (int)((i / Hp) & 1);
+        const uint64_t e = i / (2ull * Hp);
+        float v = 0.f;
+        if (h < H) {
+            const int c = h / P, p = h % P;
+            v = src[((uint64_t)c * total + e) * F_enc + p * 2 + f];
+        }
+        dst16[i] = (half_t)v;
+        if (dst32) dst32[i] = v;
+    }
+}
+
+__global__ void tables_to_tcnn_kernel(const float* __restrict__ src, int H, int Hp, int F_enc, int P,
+                                      uint64_t total, float* __restrict__ dst) {
+    const uint64_t n = total * 2ull * (uint64_t)H;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const int h = (int)(i % H);
+        const int f = (int)((i / H) & 1);
+        const uint64_t e = i / (2ull * H);
+        const int c = h / P, p = h % P;
+        dst[((uint64_t)c * total + e) * F_enc + p * 2 + f] = src[(e * 2ull + f) * Hp + h];
+    }
+}
+
+__global__ void hash_indices_kernel(const float* __restrict__ x, int64_t B, const nsx_grid_geom g,
+                                    uint32_t* __restrict__ out) {
+    const int L = g.n_levels;
+    const int64_t n = B * L;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = i / L;
+        const int l = (int)(i - b * L);
+        const Cell c = cell_of(g.scale[l], x[b * 3], x[b * 3 + 1], x[b * 3 + 2]);
+        uint32_t idx[8];
+        corner_indices(c, g.res[l], g.size[l], g.hashed[l] != 0, idx);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) out[i * 8 + k] = idx[k];
+    }
+}
+
+static int ens_layout(int H, int* F_enc, int* P) {
+    const int total = 2 * H;
+    *F_enc = total >= 8 ? 8 : total;
+    *P = total >= 8 ? 4 : H;
+    return (total + 7) / 8;
+}
+
+template <int H>
+static int launch_fwd(const float* x, int64_t B, const nsx_half* tables, int Hreal, const nsx_grid_geom* g,
+                      const float* code, int64_t code_stride, const int32_t* code_index, const float* window,
+                      nsx_half* out, hipStream_t st) {
+    using C = EnsCfg<H>;
+    constexpr int WAVES = 4;
+    const int64_t n_tiles = (B + C::SPW - 1) / C::SPW;
+    int64_t blocks = (n_tiles + WAVES - 1) / WAVES;
+    const int64_t cap = (int64_t)num_cus() * 8;
+    if (blocks > cap) blocks = cap;
+    const size_t smem = (size_t)WAVES * C::SPW * (g->n_levels + 4) * sizeof(uint32_t);
+    hipLaunchKernelGGL((ens_fwd_kernel<H, WAVES>), dim3((unsigned)blocks), dim3(WAVES * kWave), smem, st, x, B,
+                       reinterpret_cast<const uint8_t*>(tables), *g, code, code_stride, code_index, window, Hreal,
+                       reinterpret_cast<uint32_t*>(out), n_tiles);
+    NSX_LAUNCH_CHECK("nsx_hash_ensemble_fwd launch");
+    return NSX_OK;
+}
+
+template <int H>
+static int launch_bwd(const float* x, int64_t B, const nsx_half* tables, int Hreal, const nsx_grid_geom* g,
+                      const float* code, int64_t code_stride, const int32_t* code_index, const float* window,
+                      const float* dout, float* dtables, float* dcode, float* dx, hipStream_t st) {
+    using C = EnsCfg<H>;
+    constexpr int WAVES = 4;
+    const int64_t n_tiles = (B + C::SPW - 1) / C::SPW;
+    int64_t blocks = (n_tiles + WAVES - 1) / WAVES;
+    const int64_t cap = (int64_t)num_cus() * 8;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL((ens_bwd_kernel<H, WAVES>), dim3((unsigned)blocks), dim3(WAVES * kWave), 0, st, x, B,
+                       reinterpret_cast<const uint8_t*>(tables), *g, code, code_stride, code_index, window, Hreal,
+                       dout, dtables, dcode, dx, n_tiles);
+    NSX_LAUNCH_CHECK("nsx_hash_ensemble_bwd launch");
+    return NSX_OK;
+}
+
+static int check_geom(const nsx_grid_geom* g, int Hp, const char* who) {
+    NSX_REQUIRE(g != nullptr, "%s: geometry is NULL", who);
+    NSX_REQUIRE(g->n_levels >= 1 && g->n_levels <= NSX_MAX_LEVELS, "%s: bad n_levels %d", who, g->n_levels);
+    const uint64_t bytes = (uint64_t)g->offset[g->n_levels] * 4ull * (uint64_t)Hp;
+    NSX_REQUIRE(bytes > 0, "%s: empty geometry", who);
+    return NSX_OK;
+}
+
+}  // namespace nsx
+
+using namespace nsx;
+
+extern "C" {
+
+int nsx_tables_from_tcnn(const float* tcnn_params, int H, const nsx_grid_geom* g, nsx_half* native_f16,
+                         float* native_master_f32, void* stream) {
+    NSX_REQUIRE(tcnn_params && native_f16 && g, "nsx_tables_from_tcnn: NULL argument");
+    NSX_REQUIRE(H >= 1 && H <= 32, "nsx_tables_from_tcnn: H=%d not in [1,32]", H);
+    NSX_REQUIRE(2 * H <= 8 || (2 * H) % 8 == 0, "nsx_tables_from_tcnn: 2H must be <= 8 or a multiple of 8 "
+                "(hash_ensemble.py:80-82)");
+    int F_enc, P;
+    ens_layout(H, &F_enc, &P);
+    const int Hp = nsx_padded_grids(H);
+    const uint64_t total = g->offset[g->n_levels];
+    hipLaunchKernelGGL(tables_from_tcnn_kernel, dim3(num_cus() * 8), dim3(256), 0, (hipStream_t)stream, tcnn_params, H,
+                       Hp, F_enc, P, total, reinterpret_cast<half_t*>(native_f16), native_master_f32);
+    NSX_LAUNCH_CHECK("nsx_tables_from_tcnn launch");
+    return NSX_OK;
+}
+
+int nsx_tables_to_tcnn(const float* native_master_f32, int H, const nsx_grid_geom* g, float* tcnn_params,
+                       void* stream) {
+    NSX_REQUIRE(tcnn_params && native_master_f32 && g, "nsx_tables_to_tcnn: NULL argument");
+    NSX_REQUIRE(H >= 1 && H <= 32, "nsx_tables_to_tcnn: H=%d not in [1,32]", H);
+    NSX_REQUIRE(2 * H <= 8 || (2 * H) % 8 == 0, "nsx_tables_to_tcnn: 2H must be <= 8 or a multiple of 8");
+    int F_enc, P;
+    ens_layout(H, &F_enc, &P);
+    const int Hp = nsx_padded_grids(H);
+    const uint64_t total = g->offset[g->n_levels];
+    hipLaunchKernelGGL(tables_to_tcnn_kernel, dim3(num_cus() * 8), dim3(256), 0, (hipStream_t)stream,
+                       native_master_f32, H, Hp, F_enc, P, total, tcnn_params);
+    NSX_LAUNCH_CHECK("nsx_tables_to_tcnn launch");
+    return NSX_OK;
+}
+
+int nsx_hash_ensemble_fwd(const float* x, int64_t B, const nsx_half* tables, int H, const nsx_grid_geom* g,
+                          const float* code, int64_t code_stride, const int32_t* code_index,
+                          const float* window, nsx_half* out, void* stream) {
+    NSX_REQUIRE(B >= 0, "nsx_hash_ensemble_fwd: negative batch");
+    if (B == 0) return NSX_OK;
+    NSX_REQUIRE(x && tables && code && out, "nsx_hash_ensemble_fwd: NULL argument");
+    NSX_REQUIRE(H >= 1 && H <= 32, "nsx_hash_ensemble_fwd: H=%d not in [1,32]", H);
+    const int Hp = nsx_padded_grids(H);
+    if (int rc = check_geom(g, Hp, "nsx_hash_ensemble_fwd")) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    switch (Hp) {
+        case 1: return launch_fwd<1>(x, B, tables, H, g, code, code_stride, code_index, window, out, st);
+        case 2: return launch_fwd<2>(x, B, tables, H, g, code, code_stride, code_index, window, out, st);
+        case 4: return launch_fwd<4>(x, B, tables, H, g, code, code_stride, code_index, window, out, st);
+        case 8: return launch_fwd<8>(x, B, tables, H, g, code, code_stride, code_index, window, out, st);
+        case 16: return launch_fwd<16>(x, B, tables, H, g, code, code_stride, code_index, window, out, st);
+        case 32: return launch_fwd<32>(x, B, tables, H, g, code, code_stride, code_index, window, out, st);
+    }
+    set_error("nsx_hash_ensemble_fwd: unsupported H=%d", H);
+    return NSX_ERR_UNSUPPORTED;
+}
+
+int nsx_hash_ensemble_bwd(const float* x, int64_t B, const nsx_half* tables, int H, const nsx_grid_geom* g,
+                          const float* code, int64_t code_stride, const int32_t* code_index,
+                          const float* window, const float* dout, float* dtables, float* dcode, float* dx,
+                          void* stream) {
+    NSX_REQUIRE(B >= 0, "nsx_hash_ensemble_bwd: negative batch");
+    if (B == 0) return NSX_OK;
+    NSX_REQUIRE(x && tables && code && dout, "nsx_hash_ensemble_bwd: NULL argument");
+    NSX_REQUIRE(H >= 1 && H <= 32, "nsx_hash_ensemble_bwd: H=%d not in [1,32]", H);
+    const int Hp = nsx_padded_grids(H);
+    if (int rc = check_geom(g, Hp, "nsx_hash_ensemble_bwd")) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    switch (Hp) {
+        case 1: return launch_bwd<1>(x, B, tables, H, g, code, code_stride, code_index, window, dout, dtables, dcode, dx, st);
+        case 2: return launch_bwd<2>(x, B, tables, H, g, code, code_stride, code_index, window, dout, dtables, dcode, dx, st);
+        case 4: return launch_bwd<4>(x, B, tables, H, g, code, code_stride, code_index, window, dout, dtables, dcode, dx, st);
+        case 8: return launch_bwd<8>(x, B, tables, H, g, code, code_stride, code_index, window, dout, dtables, dcode, dx, st);
+        case 16: return launch_bwd<16>(x, B, tables, H, g, code, code_stride, code_index, window, dout, dtables, dcode, dx, st);
+        case 32: return launch_bwd<32>(x, B, tables, H, g, code, code_stride, code_index, window, dout, dtables, dcode, dx, st);
+    }
+    set_error("nsx_hash_ensemble_bwd: unsupported H=%d", H);
+    return NSX_ERR_UNSUPPORTED;
+}
+
+int nsx_hash_indices(const float* x, int64_t B, const nsx_grid_geom* g, uint32_t* idx, void* stream) {
+    NSX_REQUIRE(B >= 0, "nsx_hash_indices: negative batch");
+    if (B == 0) return NSX_OK;
+    NSX_REQUIRE(x && g && idx, "nsx_hash_indices: NULL argument");
+    hipLaunchKernelGGL(hash_indices_kernel, dim3(num_cus() * 8), dim3(256), 0, (hipStream_t)stream, x, B, *g, idx);
+    NSX_LAUNCH_CHECK("nsx_hash_indices launch");
+    return NSX_OK;
+}
+
+}  // extern "C"

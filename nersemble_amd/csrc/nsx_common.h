@@ -1,0 +1,59 @@
+// nsx_common.h -- shared helpers of libnsx.so (error reporting, launch checks, device utils).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "nsx.h"
+
+namespace nsx {
+
+void set_error(const char* fmt, ...);
+int hip_fail(hipError_t e, const char* what);
+
+#define NSX_REQUIRE(cond, ...)                         \
+    do {                                               \
+        if (!(cond)) {                                 \
+            ::nsx::set_error(__VA_ARGS__);             \
+            return NSX_ERR_INVALID;                    \
+        }                                              \
+    } while (0)
+
+#define NSX_LAUNCH_CHECK(what)                                         \
+    do {                                                               \
+        hipError_t e__ = hipGetLastError();                            \
+        if (e__ != hipSuccess) return ::nsx::hip_fail(e__, what);      \
+    } while (0)
+
+constexpr int kWave = 64;   // CDNA wavefront
+
+typedef _Float16 half_t;
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ half2_t as_half2(uint32_t u) { return __builtin_bit_cast(half2_t, u); }
+__device__ __forceinline__ uint32_t as_u32(half2_t h) { return __builtin_bit_cast(uint32_t, h); }
+__device__ __forceinline__ float dot2(uint32_t a, half2_t b, float c) {
+    // v_dot2c_f32_f16: c + a.lo*b.lo + a.hi*b.hi, fp32 accumulate
+    return __builtin_amdgcn_fdot2(as_half2(a), b, c, false);
+}
+
+// exact idx % size for any uint32 idx, size >= 2 (dense hash-grid levels; size is level-uniform)
+__device__ __forceinline__ uint32_t umod(uint32_t idx, uint32_t size, float inv_size) {
+    uint32_t q = (uint32_t)(__uint2float_rz(idx) * inv_size);
+    int32_t r = (int32_t)(idx - q * size);
+    if (r < 0) r += (int32_t)size;
+    if ((uint32_t)r >= size) r -= (int32_t)size;
+    return (uint32_t)r;
+}
+
+inline int num_cus() {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t p;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess)
+            cus = p.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+    }
+    return cus;
+}
+
+}  // namespace nsx

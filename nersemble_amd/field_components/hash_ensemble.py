@@ -1,0 +1,178 @@
+"""HashEnsemble -- host-side mirror of the reference's
+``src/nersemble/nerfstudio/field_components/hash_ensemble.py`` (same class / config names, argument
+meaning, assertions and state-dict keys), backed by ONE fused gfx950 kernel instead of C tcnn
+HashGrid launches + stack + rearrange + window + einsum.
+
+Storage is MI355X-native: one interleaved table ``[total_entries, 2, Hp]`` (fp32 master parameter
+``tables`` + fp16 working copy), see include/nsx.h.  ``state_dict()`` / ``load_state_dict()`` speak the
+reference's tcnn layout (``hash_encodings.{c}.params``) through a lossless permutation.
+"""
+from collections import defaultdict
+from dataclasses import dataclass, field
+from math import ceil
+from typing import Dict, List, Literal, Optional
+
+import torch
+from torch import nn
+
+from .. import _lib
+from .. import functional as F
+
+
+def posenc_window(windows_param: float, min_bands: float, max_bands: float, dim_encoding: int) -> torch.Tensor:
+    """Cosine-eased window (reference hash_ensemble.py:12-28)."""
+    bands = torch.linspace(min_bands, max_bands, dim_encoding)
+    x = torch.clamp(windows_param - bands, 0, 1)
+    return 0.5 * (1 - torch.cos(torch.pi * x))
+
+
+@dataclass
+class TCNNHashEncodingConfig:
+    """Same fields/defaults as the reference (hash_ensemble.py:31-39)."""
+    n_dims_to_encode: int = 3
+    n_levels: int = 16
+    n_features_per_level: int = 2
+    log2_hashmap_size: int = 19
+    base_resolution: int = 16
+    per_level_scale: float = 1.4472692012786865
+    interpolation: Literal['Linear', 'Nearest', 'Smoothstep'] = 'Linear'
+
+    def geometry(self) -> _lib.GridGeom:
+        if self.n_dims_to_encode != 3 or self.n_features_per_level != 2 or self.interpolation != 'Linear':
+            raise NotImplementedError("native HashEnsemble supports the configuration NeRSemble trains with: "
+                                      "3-D input, 2 features per level, Linear interpolation")
+        return _lib.grid_geometry(self.n_levels, self.per_level_scale, self.base_resolution, self.log2_hashmap_size)
+
+
+@dataclass
+class HashEnsembleConfig:
+    """Same fields/defaults as the reference (hash_ensemble.py:53-66)."""
+    n_hash_encodings: int
+    hash_encoding_config: TCNNHashEncodingConfig = field(default_factory=TCNNHashEncodingConfig)
+    disable_initial_hash_ensemble: bool = False
+    use_soft_transition: bool = False
+
+
+class HashEnsemble(nn.Module):
+
+    def __init__(self, config: HashEnsembleConfig, seed: int = 1337):
+        super().__init__()
+        self.n_hash_encodings = config.n_hash_encodings
+        self.hash_encoding_config = config.hash_encoding_config
+        self.disable_initial_hash_ensemble = config.disable_initial_hash_ensemble
+        self.use_soft_transition = config.use_soft_transition
+
+        n_total_features = config.n_hash_encodings * config.hash_encoding_config.n_features_per_level
+        assert n_total_features <= 8 \
+               or n_total_features % 8 == 0, \
+            "Number of features in hashtables must either be smaller than 8 or a multiple of 8!"
+        assert config.n_hash_encodings <= 32, "native layout supports up to 32 hash grids"
+        self.n_tcnn_encodings = ceil(n_total_features / 8)
+        self.geom = config.hash_encoding_config.geometry()
+        self.Hp = _lib.padded_grids(self.n_hash_encodings)
+        self.n_output_dims = config.hash_encoding_config.n_levels * config.hash_encoding_config.n_features_per_level
+
+        total = self.geom.total_entries
+        # tcnn initialises grid parameters U(-1e-4, 1e-4)
+        gen = torch.Generator().manual_seed(seed)
+        master = torch.zeros((total, 2, self.Hp), dtype=torch.float32)
+        master[:, :, :self.n_hash_encodings] = \
+            (torch.rand((total, 2, self.n_hash_encodings), generator=gen) * 2 - 1) * 1e-4
+        self.tables = nn.Parameter(master)                                   # fp32 master, native layout
+        self.register_buffer("tables_f16", master.to(torch.float16), persistent=False)
+        self._f16_version = None
+        self._register_state_dict_hook(self._export_tcnn_keys)
+        self._register_load_state_dict_pre_hook(self._import_tcnn_keys)
+
+    # ---- working copy management --------------------------------------------------------------
+    def half_tables(self) -> torch.Tensor:
+        """fp16 working copy; refreshed lazily whenever the fp32 master changed (any optimizer works)."""
+        v = (self.tables._version, self.tables.data_ptr())
+        if self._f16_version != v:
+            if self.tables_f16.device != self.tables.device:
+                self.tables_f16 = torch.empty_like(self.tables, dtype=torch.float16)
+            self.tables_f16.copy_(self.tables.detach())
+            self._f16_version = v
+        return self.tables_f16
+
+    def mark_half_synced(self):
+        """Called by the fused Adam step, which writes master and working copy together."""
+        self._f16_version = (self.tables._version, self.tables.data_ptr())
+
+    # ---- reference state-dict layout -----------------------------------------------------------
+    def _tcnn_keys(self, prefix):
+        return [f"{prefix}hash_encodings.{c}.params" for c in range(self.n_tcnn_encodings)]
+
+    @staticmethod
+    def _export_tcnn_keys(module, state_dict, prefix, local_metadata):
+        native = state_dict.pop(prefix + "tables")
+        if native.is_cuda:
+            tc = F.tables_to_tcnn(native, module.n_hash_encodings, module.geom)
+        else:
+            tc = module._permute_to_tcnn_cpu(native)
+        for c, key in enumerate(module._tcnn_keys(prefix)):
+            state_dict[key] = tc[c].reshape(-1)
+        return state_dict
+
+    def _import_tcnn_keys(self, state_dict, prefix, *args):
+        keys = self._tcnn_keys(prefix)
+        if all(k in state_dict for k in keys):
+            tc = torch.stack([state_dict.pop(k).reshape(self.geom.total_entries, -1) for k in keys])
+            state_dict[prefix + "tables"] = self._permute_from_tcnn_cpu(tc.float().cpu()).to(tc.device)
+            self._f16_version = None
+
+    def _permute_to_tcnn_cpu(self, native: torch.Tensor) -> torch.Tensor:
+        # host-side restatement of the permutation (used only for CPU state dicts): [e,f,h] -> [c,e,p*2+f]
+        H = self.n_hash_encodings
+        P = 4 if 2 * H >= 8 else H
+        t = native[:, :, :H].reshape(native.shape[0], 2, self.n_tcnn_encodings, P)   # e f c p
+        return t.permute(2, 0, 3, 1).reshape(self.n_tcnn_encodings, native.shape[0], P * 2).contiguous()
+
+    def _permute_from_tcnn_cpu(self, tc: torch.Tensor) -> torch.Tensor:
+        H = self.n_hash_encodings
+        P = 4 if 2 * H >= 8 else H
+        total = tc.shape[1]
+        t = tc.reshape(self.n_tcnn_encodings, total, P, 2).permute(1, 3, 0, 2).reshape(total, 2, H)
+        out = torch.zeros((total, 2, self.Hp), dtype=torch.float32)
+        out[:, :, :H] = t
+        return out
+
+    # ---- forward -----------------------------------------------------------------------------------
+    def forward(self,
+                in_tensor: torch.Tensor,
+                conditioning_code: torch.Tensor,
+                windows_param: Optional[float] = None,
+                window_hash_encodings: Optional[float] = None,
+                code_index: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Same contract as the reference (hash_ensemble.py:93-158): in_tensor [B,3] in [0,1),
+        conditioning_code [B,H] -> blended features [B, 32] fp16.
+
+        ``code_index`` (native extension): if given, ``conditioning_code`` is a ``[T,H]`` table and row
+        ``code_index[b]`` is sample b's code -- avoids materialising the gathered ``[B,H]`` tensor."""
+        if windows_param is not None:
+            raise NotImplementedError("per-level window (hash_ensemble.py:141-149) is unused by NeRSemble configs")
+        assert conditioning_code.shape[-1] == self.n_hash_encodings, \
+            "If blend mixing type is chosen, conditioning code needs to have as many dimensions as there are " \
+            "hashtables in the encoding"
+
+        window = None
+        if window_hash_encodings is not None:
+            if window_hash_encodings == 1 and self.disable_initial_hash_ensemble:
+                conditioning_code = torch.ones_like(conditioning_code)
+            elif self.use_soft_transition and window_hash_encodings < 2:
+                alpha = window_hash_encodings - 1
+                first = torch.zeros_like(conditioning_code)
+                first[:, 0] = (1 - alpha) * 1
+                conditioning_code = alpha * conditioning_code + first
+            window = posenc_window(window_hash_encodings, 0, self.n_hash_encodings - 1, self.n_hash_encodings)
+
+        return F.hash_ensemble(in_tensor, self.tables, self.half_tables(), conditioning_code,
+                               self.n_hash_encodings, self.geom, code_index=code_index, window=window)
+
+    def get_out_dim(self) -> int:
+        return self.n_output_dims
+
+    def get_param_groups(self) -> Dict[str, List[nn.Parameter]]:
+        param_groups = defaultdict(list)
+        param_groups["fields"] = [self.tables]
+        return param_groups

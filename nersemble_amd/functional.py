@@ -1,0 +1,116 @@
+"""torch.autograd glue over the C ABI of libnsx.so (include/nsx.h).
+
+Every function here hands raw device pointers to the native library; there is no eager/CPU
+fallback.  Gradients between kernels travel in fp32 (they are a negligible fraction of the gather
+traffic), activations in fp16 like the reference's tcnn path.
+"""
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import GridGeom, check, lib, ptr, stream
+
+
+# ------------------------------------------------------------------------------------------------
+# table layout conversion (checkpoint compatibility with the reference's tcnn state dict)
+# ------------------------------------------------------------------------------------------------
+def tcnn_param_shape(H: int, geom: GridGeom):
+    total = 2 * H
+    f_enc = 8 if total >= 8 else total
+    c = (total + 7) // 8
+    return c, geom.total_entries, f_enc
+
+
+def tables_from_tcnn(tcnn_params: torch.Tensor, H: int, geom: GridGeom, want_master: bool = True):
+    """tcnn layout fp32 ``[C, total, F_enc]`` -> native ``[total, 2, Hp]`` (fp16 working copy, fp32 master)."""
+    c, total, f_enc = tcnn_param_shape(H, geom)
+    assert tcnn_params.numel() == c * total * f_enc, "tcnn params have the wrong size"
+    src = tcnn_params.detach().to(torch.float32).contiguous()
+    Hp = _lib.padded_grids(H)
+    f16 = torch.empty((total, 2, Hp), dtype=torch.float16, device=src.device)
+    master = torch.empty((total, 2, Hp), dtype=torch.float32, device=src.device) if want_master else None
+    check(lib().nsx_tables_from_tcnn(ptr(src), H, C.byref(geom), ptr(f16), ptr(master), stream()),
+          "nsx_tables_from_tcnn")
+    return f16, master
+
+
+def tables_to_tcnn(native_f32: torch.Tensor, H: int, geom: GridGeom) -> torch.Tensor:
+    c, total, f_enc = tcnn_param_shape(H, geom)
+    out = torch.empty((c, total, f_enc), dtype=torch.float32, device=native_f32.device)
+    check(lib().nsx_tables_to_tcnn(ptr(native_f32.detach().contiguous(), torch.float32), H, C.byref(geom), ptr(out),
+                                   stream()), "nsx_tables_to_tcnn")
+    return out
+
+
+def hash_indices(x: torch.Tensor, geom: GridGeom) -> torch.Tensor:
+    """uint32 level-local entry indices ``[B, L, 8]`` (returned as int64 for convenience)."""
+    x = x.detach().to(torch.float32).contiguous()
+    out = torch.empty((x.shape[0], geom.n_levels, 8), dtype=torch.int32, device=x.device)
+    check(lib().nsx_hash_indices(ptr(x), x.shape[0], C.byref(geom), ptr(out), stream()), "nsx_hash_indices")
+    return out.to(torch.int64) & 0xFFFFFFFF
+
+
+# ------------------------------------------------------------------------------------------------
+# HashEnsemble
+# ------------------------------------------------------------------------------------------------
+def _hash_ensemble_fwd_raw(x, tables_f16, H, geom, code, code_index, window):
+    B = x.shape[0]
+    out = torch.empty((B, 2 * geom.n_levels), dtype=torch.float16, device=x.device)
+    check(lib().nsx_hash_ensemble_fwd(ptr(x, torch.float32), B, ptr(tables_f16, torch.float16), H, C.byref(geom),
+                                      ptr(code, torch.float32), code.stride(0), ptr(code_index, torch.int32),
+                                      ptr(window, torch.float32), ptr(out), stream()), "nsx_hash_ensemble_fwd")
+    return out
+
+
+class _HashEnsembleFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, tables_master, tables_f16, code, code_index, window, H, geom):
+        x = x.detach().to(torch.float32).contiguous()
+        code_c = code.detach().to(torch.float32).contiguous()
+        out = _hash_ensemble_fwd_raw(x, tables_f16, H, geom, code_c, code_index, window)
+        ctx.save_for_backward(x, tables_f16, code_c, code_index, window)
+        ctx.H, ctx.geom = H, geom
+        ctx.master_shape = tables_master.shape
+        ctx.code_rows = code.shape[0]
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, tables_f16, code, code_index, window = ctx.saved_tensors
+        H, geom = ctx.H, ctx.geom
+        B = x.shape[0]
+        need_x, need_tab, _, need_code = ctx.needs_input_grad[0], ctx.needs_input_grad[1], None, ctx.needs_input_grad[3]
+        dout = dout.to(torch.float32).contiguous()
+        dtab = torch.zeros(ctx.master_shape, dtype=torch.float32, device=x.device) if need_tab else None
+        dcode_s = torch.empty((B, H), dtype=torch.float32, device=x.device) if need_code else None
+        dx = torch.empty((B, 3), dtype=torch.float32, device=x.device) if need_x else None
+        check(lib().nsx_hash_ensemble_bwd(ptr(x), B, ptr(tables_f16), H, C.byref(geom), ptr(code), code.stride(0),
+                                          ptr(code_index), ptr(window), ptr(dout), ptr(dtab), ptr(dcode_s), ptr(dx),
+                                          stream()), "nsx_hash_ensemble_bwd")
+        dcode = None
+        if need_code:
+            if window is not None:
+                dcode_s = dcode_s * window[None, :]
+            if code_index is not None:
+                dcode = torch.zeros((ctx.code_rows, H), dtype=torch.float32, device=x.device)
+                dcode.index_add_(0, code_index.to(torch.int64), dcode_s)
+            else:
+                dcode = dcode_s
+        return dx, dtab, None, dcode, None, None, None, None
+
+
+def hash_ensemble(x: torch.Tensor, tables_master: torch.Tensor, tables_f16: torch.Tensor, code: torch.Tensor,
+                  H: int, geom: GridGeom, code_index: Optional[torch.Tensor] = None,
+                  window: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Fused HashEnsemble forward (hash_ensemble.py:93-158), differentiable w.r.t. x, tables_master, code.
+
+    x [B,3] fp32 in [0,1); code fp32 rows of H values (row b, or row code_index[b]); window [H] fp32 or None.
+    Returns [B, 2*n_levels] fp16.
+    """
+    if code_index is not None:
+        code_index = code_index.to(torch.int32).contiguous()
+    if window is not None:
+        window = window.to(device=x.device, dtype=torch.float32).contiguous()
+    return _HashEnsembleFn.apply(x, tables_master, tables_f16, code, code_index, window, H, geom)

@@ -1,0 +1,356 @@
+"""Generates tests/golden/*.npz by importing the REFERENCE's own Python (read-only, /root/reference)
+in this container.  Only the resulting small fixtures travel; the reference source never does.
+
+Run:  python tests/golden/make_golden.py          (needs /root/reference; CPU only)
+
+What is pinned (reference-owned code, executed for real):
+  * HashEnsemble.forward  (hash_ensemble.py:93-158): rearrange map (c,p)->h, disable-initial (w==1),
+    soft transition (1<w<2), cosine grid window, blend einsum -- with a stub ``tinycudann.Encoding``
+    whose output is the oracle's tcnn HashGrid restatement on seeded tables.
+  * posenc_window (hash_ensemble.py:12-28)
+  * WindowedNeRFEncoding.forward (windowed_nerf_encoding.py:33-74)
+  * se3_exp_map (util/pytorch3d.py:107-191)
+  * SE3DeformationField.compute_offsets (deformation_field.py:148-166) with a tiny seeded config
+  * GenericScheduler (engine/generic_scheduler.py), chunked (util/chunker.py)
+  * BaseModel.get_dist_loss sample selection / midpoint construction (models/base.py:224-249) with a
+    stub flatten_eff_distloss that records its arguments.
+Stubs (third-party packages that are not installed): tinycudann, nerfstudio.*, jaxtyping,
+torch_efficient_distloss.  The nerfstudio MLP / NeRFEncoding / SceneBox stubs restate nerfstudio 0.3.1
+ -> that sub-part stays "parity unpinned".
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+from torch import nn
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, "/root/reference/src")
+
+import oracle  # noqa: E402
+from oracle import hashgrid as ohg  # noqa: E402
+from tests.helpers import make_tcnn_tables, SMALL_GEOM_KW  # noqa: E402
+
+
+# ------------------------------------------------------------------------------------------------
+# stubs
+# ------------------------------------------------------------------------------------------------
+def _mod(name):
+    m = types.ModuleType(name)
+    sys.modules[name] = m
+    return m
+
+
+_ENC_COUNTER = {"n": 0}
+_ENC_CTX = {}
+
+
+class StubEncoding(nn.Module):
+    """tinycudann.Encoding stand-in: HashGrid output = oracle restatement on seeded tables."""
+
+    def __init__(self, n_input_dims, encoding_config, **kw):
+        super().__init__()
+        self.cfg = encoding_config
+        self.n_input_dims = n_input_dims
+        if encoding_config["otype"] == "HashGrid":
+            self.geom = oracle.grid_geometry(encoding_config["n_levels"], encoding_config["per_level_scale"],
+                                             encoding_config["base_resolution"], encoding_config["log2_hashmap_size"])
+            self.f_enc = encoding_config["n_features_per_level"]
+            self.n_output_dims = encoding_config["n_levels"] * self.f_enc
+            c = _ENC_COUNTER["n"]
+            _ENC_COUNTER["n"] += 1
+            tables = _ENC_CTX["tables"]          # [C, total, F_enc] float32, prepared by the caller
+            self.params = nn.Parameter(torch.from_numpy(tables[c].reshape(-1).copy()))
+        else:
+            self.n_output_dims = n_input_dims
+
+    def forward(self, x):
+        if self.cfg["otype"] != "HashGrid":
+            return x.half()
+        tab = self.params.detach().numpy().astype(np.float16).reshape(self.geom.total_entries, self.f_enc)
+        out = ohg.hashgrid_fwd(x.detach().numpy(), tab.view(np.uint16), self.geom)
+        return torch.from_numpy(out.copy())
+
+
+tcnn = _mod("tinycudann")
+tcnn.Encoding = StubEncoding
+
+jax = _mod("jaxtyping")
+
+
+class _Sub:
+    def __getitem__(self, item):
+        return torch.Tensor
+
+
+jax.Shaped = _Sub()
+jax.Float = _Sub()
+
+ns = _mod("nerfstudio")
+for sub in ["cameras", "cameras.rays", "data", "data.scene_box", "field_components", "field_components.encodings",
+            "utils", "utils.math"]:
+    _mod("nerfstudio." + sub)
+
+
+class RaySamples:  # only the name is needed by deformation_field.py's annotations
+    pass
+
+
+sys.modules["nerfstudio.cameras.rays"].RaySamples = RaySamples
+
+
+class SceneBox:
+    @staticmethod
+    def get_normalized_positions(positions, aabb):
+        aabb_lengths = aabb[1] - aabb[0]
+        return (positions - aabb[0]) / aabb_lengths
+
+
+sys.modules["nerfstudio.data.scene_box"].SceneBox = SceneBox
+
+
+class MLP(nn.Module):
+    """Restatement of nerfstudio 0.3.1 field_components.MLP."""
+
+    def __init__(self, in_dim, num_layers, layer_width, out_dim=None, skip_connections=None,
+                 activation=nn.ReLU(), out_activation=None):
+        super().__init__()
+        self.in_dim = in_dim
+        self.out_dim = out_dim if out_dim is not None else layer_width
+        self.num_layers = num_layers
+        self.layer_width = layer_width
+        self.skip_connections = skip_connections
+        self._skip = set(skip_connections) if skip_connections else set()
+        self.activation = activation
+        self.out_activation = out_activation
+        layers = []
+        if num_layers == 1:
+            layers.append(nn.Linear(in_dim, self.out_dim))
+        else:
+            for i in range(num_layers - 1):
+                if i == 0:
+                    assert i not in self._skip
+                    layers.append(nn.Linear(in_dim, layer_width))
+                elif i in self._skip:
+                    layers.append(nn.Linear(layer_width + in_dim, layer_width))
+                else:
+                    layers.append(nn.Linear(layer_width, layer_width))
+            layers.append(nn.Linear(layer_width, self.out_dim))
+        self.layers = nn.ModuleList(layers)
+
+    def forward(self, in_tensor):
+        x = in_tensor
+        for i, layer in enumerate(self.layers):
+            if i in self._skip:
+                x = torch.cat([in_tensor, x], -1)
+            x = layer(x)
+            if self.activation is not None and i < len(self.layers) - 1:
+                x = self.activation(x)
+        if self.out_activation is not None:
+            x = self.out_activation(x)
+        return x
+
+
+sys.modules["nerfstudio.field_components"].MLP = MLP
+
+
+class NeRFEncoding(nn.Module):
+    def __init__(self, in_dim, num_frequencies, min_freq_exp, max_freq_exp, include_input=False):
+        super().__init__()
+        self.in_dim = in_dim
+        self.num_frequencies = num_frequencies
+        self.include_input = include_input
+
+    def get_out_dim(self):
+        out = self.in_dim * self.num_frequencies * 2
+        if self.include_input:
+            out += self.in_dim
+        return out
+
+
+sys.modules["nerfstudio.field_components.encodings"].NeRFEncoding = NeRFEncoding
+sys.modules["nerfstudio.utils.math"].expected_sin = lambda x, v: torch.exp(-0.5 * v) * torch.sin(x)
+
+
+# ------------------------------------------------------------------------------------------------
+def gen_hash_ensemble(out):
+    from nersemble.nerfstudio.field_components.hash_ensemble import (HashEnsemble, HashEnsembleConfig,
+                                                                     TCNNHashEncodingConfig, posenc_window)
+    rng = np.random.default_rng(20240501)
+    B = 96
+    x = rng.random((B, 3), dtype=np.float32)
+    x[0] = [0.0, 0.0, 0.0]
+    x[1] = [0.999999, 0.999999, 0.999999]
+    x[2] = [0.5, 0.25, 0.75]
+    out["he_x"] = x
+    geom = oracle.grid_geometry(**SMALL_GEOM_KW)
+    for H in (1, 2, 4, 8, 16, 32):
+        tables = make_tcnn_tables(H, geom, seed=100 + H, amplitude=0.5)      # [C,total,F_enc] fp32
+        _ENC_COUNTER["n"] = 0
+        _ENC_CTX["tables"] = tables
+        cfg = HashEnsembleConfig(n_hash_encodings=H,
+                                 hash_encoding_config=TCNNHashEncodingConfig(
+                                     n_levels=SMALL_GEOM_KW["n_levels"],
+                                     log2_hashmap_size=SMALL_GEOM_KW["log2_hashmap_size"],
+                                     base_resolution=SMALL_GEOM_KW["base_resolution"],
+                                     per_level_scale=SMALL_GEOM_KW["per_level_scale"]),
+                                 disable_initial_hash_ensemble=True, use_soft_transition=True)
+        he = HashEnsemble(cfg)
+        assert len(he.hash_encodings) == tables.shape[0]
+        code = (rng.standard_normal((B, H)) * 0.7).astype(np.float32)
+        out[f"he_code_H{H}"] = code
+        windows = [None, 1, 1.5, 3.25, float(H)]
+        for wi, w in enumerate(windows):
+            with torch.no_grad():
+                y = he(torch.from_numpy(x), torch.from_numpy(code.copy()), window_hash_encodings=w)
+            assert y.dtype == torch.float16 and y.shape == (B, 2 * SMALL_GEOM_KW["n_levels"])
+            out[f"he_out_H{H}_w{wi}"] = y.numpy()
+        out[f"he_windows_H{H}"] = np.array([np.nan if w is None else w for w in windows], dtype=np.float64)
+    # posenc_window known answers
+    for i, (w, n) in enumerate([(3.25, 32), (0.0, 32), (1.0, 32), (32.0, 32), (7.5, 16), (0.4, 1)]):
+        out[f"pw_{i}"] = posenc_window(w, 0, n - 1, n).numpy()
+        out[f"pw_{i}_args"] = np.array([w, n], dtype=np.float64)
+
+
+def gen_deformation(out):
+    from nersemble.nerfstudio.field_components.windowed_nerf_encoding import WindowedNeRFEncoding
+    from nersemble.nerfstudio.field_components.deformation_field import (SE3DeformationField,
+                                                                          SE3DeformationFieldConfig)
+    from nersemble.util.pytorch3d import se3_exp_map
+    rng = np.random.default_rng(77)
+    # windowed PE
+    enc = WindowedNeRFEncoding(in_dim=3, num_frequencies=7, min_freq_exp=0.0, max_freq_exp=6.0, include_input=True)
+    xp = rng.random((40, 3), dtype=np.float32)
+    xp[0] = [0.1, 0.2, 0.3]
+    out["pe_x"] = xp
+    for i, w in enumerate([None, 0.0, 3.5, 7.0, 0.25]):
+        with torch.no_grad():
+            out[f"pe_out_{i}"] = enc(torch.from_numpy(xp), windows_param=w).numpy()
+    out["pe_windows"] = np.array([np.nan, 0.0, 3.5, 7.0, 0.25])
+    # se3 exp map: random + edge cases (zero rotation -> eps clamp, tiny, large angle)
+    screw = (rng.standard_normal((64, 6)) * 0.5).astype(np.float32)
+    screw[0] = 0
+    screw[1, 3:] = 0
+    screw[2, 3:] = [1e-4, 0, 0]
+    screw[3, 3:] = [3.0, 0.1, -0.2]
+    screw[4, 3:] = [0, 6.0, 0]
+    screw[5] = [1, 2, 3, 1e-3, 1e-3, 1e-3]
+    out["se3_in"] = screw
+    out["se3_out"] = se3_exp_map(torch.from_numpy(screw)).numpy()
+    # tiny deformation field, fp32
+    torch.manual_seed(1234)
+    cfg = SE3DeformationFieldConfig(warp_code_dim=8, mlp_num_layers=6, mlp_layer_width=32)
+    aabb = torch.tensor([[-2.5, -1.8, -2.5], [2.2, 1.8, 2.0]])
+    df = SE3DeformationField(aabb, cfg, max_n_samples_per_batch=17)
+    # make the heads non-trivial so the SE(3) part is exercised (reference init is ~identity)
+    with torch.no_grad():
+        df.se3_field.mlp_r.layers[-1].weight.mul_(2e4)
+        df.se3_field.mlp_v.layers[-1].weight.mul_(2e4)
+    pos = (torch.rand(50, 3) * (aabb[1] - aabb[0]) + aabb[0])
+    codes = torch.randn(50, 8) * 0.3
+    out["df_pos"] = pos.numpy()
+    out["df_code"] = codes.numpy()
+    for k, v in df.state_dict().items():
+        out["df_sd_" + k] = v.numpy()
+    for i, w in enumerate([None, 0.0, 2.75, 7.0]):
+        with torch.no_grad():
+            out[f"df_off_{i}"] = df.compute_offsets(pos, codes, w).numpy()
+    out["df_windows"] = np.array([np.nan, 0.0, 2.75, 7.0])
+
+
+def gen_misc(out):
+    from nersemble.nerfstudio.engine.generic_scheduler import GenericScheduler
+    from nersemble.util.chunker import chunked
+    s = GenericScheduler(init_value=1, final_value=32, begin_step=40000, end_step=80000)
+    steps = np.array([0, 39999, 40000, 40001, 50000, 60000, 79999, 80000, 80001, 300000])
+    vals = []
+    for st in steps:
+        s.update(int(st))
+        vals.append(s.get_value())
+    out["sched_steps"] = steps
+    out["sched_vals"] = np.array(vals, dtype=np.float64)
+    s.eval()
+    out["sched_eval"] = np.array([s.get_value()], dtype=np.float64)
+    a = torch.arange(10)
+    b = torch.arange(20).reshape(10, 2)
+    sizes = []
+    for ca, cn, cb in chunked(4, a, None, b):
+        assert cn is None
+        sizes.append([len(ca), len(cb), int(ca[0]), int(cb[0, 0])])
+    out["chunk_sizes"] = np.array(sizes)
+    single = [len(c) for c in chunked(3, a)]
+    out["chunk_single"] = np.array(single)
+
+
+def gen_distloss_selection(out):
+    # stubs for the model base class imports
+    for sub in ["engine", "engine.callbacks", "models", "models.base_model"]:
+        _mod("nerfstudio." + sub)
+    cb = sys.modules["nerfstudio.engine.callbacks"]
+    cb.TrainingCallbackAttributes = cb.TrainingCallback = cb.TrainingCallbackLocation = object
+    bm = sys.modules["nerfstudio.models.base_model"]
+
+    class Model(nn.Module):
+        pass
+
+    class ModelConfig:
+        pass
+
+    bm.Model, bm.ModelConfig = Model, ModelConfig
+    sys.modules["nerfstudio.utils"].writer = types.SimpleNamespace()
+    rec = {}
+    ted = _mod("torch_efficient_distloss")
+
+    def flatten_eff_distloss(w, m, interval, ray_id):
+        rec["w"], rec["m"], rec["interval"], rec["ray_id"] = w, m, interval, ray_id
+        return torch.tensor(2.0)
+
+    ted.flatten_eff_distloss = flatten_eff_distloss
+    from nersemble.nerfstudio.models.base import BaseModel, BaseModelConfig
+    model = BaseModel.__new__(BaseModel)
+    nn.Module.__init__(model)
+    cfg = BaseModelConfig.__new__(BaseModelConfig)
+    cfg.lambda_dist_loss = 1e-4
+    cfg.dist_loss_max_rays = 5
+    model.config = cfg
+    rng = np.random.default_rng(5)
+    counts = np.array([3, 0, 4, 2, 0, 1, 5, 2])
+    ray_idx = np.repeat(np.arange(len(counts)), counts)
+    S = len(ray_idx)
+    starts = np.sort(rng.random(S).astype(np.float32)) * 3
+    ends = starts + 0.011
+    weights = rng.random((S, 1)).astype(np.float32)
+    fr = types.SimpleNamespace(starts=torch.from_numpy(starts)[:, None], ends=torch.from_numpy(ends.astype(np.float32))[:, None])
+    rs = types.SimpleNamespace(frustums=fr)
+    loss = model.get_dist_loss(rs, torch.from_numpy(ray_idx), torch.from_numpy(weights))
+    out["dl_ray_idx"] = ray_idx
+    out["dl_starts"] = starts
+    out["dl_ends"] = ends.astype(np.float32)
+    out["dl_weights"] = weights
+    out["dl_sel_w"] = rec["w"].numpy()
+    out["dl_sel_m"] = rec["m"].numpy()
+    out["dl_sel_interval"] = rec["interval"].numpy()
+    out["dl_sel_ray_id"] = rec["ray_id"].numpy()
+    out["dl_loss"] = np.array([float(loss)])      # = lambda * stub value
+
+
+def main():
+    torch.set_num_threads(4)
+    a, b, c = {}, {}, {}
+    gen_hash_ensemble(a)
+    np.savez_compressed(os.path.join(HERE, "hash_ensemble.npz"), **a)
+    gen_deformation(b)
+    np.savez_compressed(os.path.join(HERE, "deformation.npz"), **b)
+    gen_misc(c)
+    gen_distloss_selection(c)
+    np.savez_compressed(os.path.join(HERE, "misc.npz"), **c)
+    for f in ("hash_ensemble.npz", "deformation.npz", "misc.npz"):
+        print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")
+
+
+if __name__ == "__main__":
+    main()

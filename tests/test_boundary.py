@@ -1,0 +1,96 @@
+"""CPU: the C-ABI library loads, exports every symbol include/nsx.h declares, and the product never
+touches the oracle (no CPU fallback)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    syms = set()
+    inc = os.path.join(ROOT, "include")
+    for f in os.listdir(inc):
+        if f.endswith(".h"):
+            txt = open(os.path.join(inc, f)).read()
+            txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+            syms |= set(re.findall(r"\b(nsx_[a-z0-9_]+)\s*\(", txt))
+    return syms
+
+
+def test_library_exports_every_declared_symbol():
+    from nersemble_amd import _lib
+    handle = _lib.lib()
+    declared = _declared_symbols()
+    assert len(declared) >= 9
+    for s in declared:
+        assert hasattr(handle, s), f"libnsx.so does not export {s}"
+    # the ctypes signature table covers exactly the header
+    assert set(_lib.SIGNATURES) == declared
+    assert handle.nsx_version() >= 100
+
+
+def test_error_reporting_across_abi():
+    from nersemble_amd import _lib
+    g = _lib.GridGeom()
+    rc = _lib.lib().nsx_grid_geometry(99, 1.5, 16, 19, ctypes.byref(g))
+    assert rc != 0
+    assert b"n_levels" in _lib.lib().nsx_last_error()
+    with pytest.raises(RuntimeError, match="n_levels"):
+        _lib.check(rc, "nsx_grid_geometry")
+
+
+def test_native_geometry_equals_oracle_geometry():
+    import oracle
+    from nersemble_amd import _lib
+    from tests.helpers import REF_GEOM_KW, SMALL_GEOM_KW
+    for kw in (REF_GEOM_KW, SMALL_GEOM_KW, dict(n_levels=8, per_level_scale=2.0, base_resolution=4, log2_hashmap_size=10)):
+        a, b = _lib.grid_geometry(**kw), oracle.grid_geometry(**kw)
+        for l in range(kw["n_levels"]):
+            assert a.scale[l] == b.scale[l] and a.res[l] == b.res[l]
+            assert a.size[l] == b.size[l] and a.offset[l] == b.offset[l]
+        assert a.total_entries == b.total_entries
+
+
+def test_product_never_imports_oracle_or_reference():
+    pkg = os.path.join(ROOT, "nersemble_amd")
+    bad = []
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dp, f)).read()
+                if re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M) or "nsx_oracle" in txt \
+                        or "/root/reference" in txt:
+                    bad.append(os.path.join(dp, f))
+    assert not bad, f"product code references the oracle/reference: {bad}"
+
+
+def test_native_ops_refuse_cpu_tensors():
+    import torch
+    from nersemble_amd.field_components.hash_ensemble import HashEnsemble, HashEnsembleConfig, TCNNHashEncodingConfig
+    he = HashEnsemble(HashEnsembleConfig(2, TCNNHashEncodingConfig(n_levels=2, log2_hashmap_size=8)))
+    with pytest.raises(RuntimeError, match="no CPU fallback|device tensors"):
+        he(torch.rand(4, 3), torch.rand(4, 2))
+
+
+def test_hash_ensemble_state_dict_uses_reference_keys():
+    import numpy as np
+    import torch
+    from nersemble_amd.field_components.hash_ensemble import HashEnsemble, HashEnsembleConfig, TCNNHashEncodingConfig
+    cfg = HashEnsembleConfig(16, TCNNHashEncodingConfig(n_levels=3, log2_hashmap_size=9))
+    he = HashEnsemble(cfg)
+    sd = he.state_dict()
+    assert sorted(sd) == [f"hash_encodings.{c}.params" for c in range(4)]
+    total = he.geom.total_entries
+    assert all(v.shape == (total * 8,) for v in sd.values())
+    # tcnn feature j = p*2+f of encoding c is logical grid h = c*4+p  (hash_ensemble.py:107-112)
+    tc = torch.stack([sd[f"hash_encodings.{c}.params"].reshape(total, 8) for c in range(4)])
+    for h in (0, 5, 15):
+        c, p = divmod(h, 4)
+        for f in (0, 1):
+            assert torch.equal(tc[c, :, p * 2 + f], he.tables[:, f, h])
+    he2 = HashEnsemble(cfg, seed=99)
+    he2.load_state_dict(sd)
+    assert torch.equal(he2.tables, he.tables)

@@ -1,0 +1,198 @@
+"""GPU parity: fused HashEnsemble HIP kernels (through the C ABI) vs the CPU oracle and the reference
+golden vectors.  Integer outputs bit-exact; fp outputs within the stated tolerances."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from oracle import hashgrid as ohg
+from tests.helpers import SMALL_GEOM_KW, REF_GEOM_KW, make_tcnn_tables
+
+pytestmark = pytest.mark.gpu
+FP16_EPS = 2.0 ** -10
+
+
+def _native_geom(kw):
+    from nersemble_amd import _lib
+    return _lib.grid_geometry(**kw)
+
+
+def _setup(H, kw, seed, B, cuda, amplitude=0.5):
+    from nersemble_amd import functional as F
+    go = oracle.grid_geometry(**kw)
+    gn = _native_geom(kw)
+    tabs = make_tcnn_tables(H, go, seed, amplitude)
+    f16, master = F.tables_from_tcnn(torch.from_numpy(tabs).to(cuda), H, gn)
+    rng = np.random.default_rng(seed + 1)
+    x = rng.random((B, 3), dtype=np.float32)
+    if B >= 3:
+        x[0] = 0.0
+        x[1] = 0.999999
+        x[2] = [0.5, 0.25, 0.75]
+    code = (rng.standard_normal((B, H)) * 0.7).astype(np.float32)
+    return go, gn, tabs, f16, master, x, code
+
+
+@pytest.mark.parametrize("kw", [SMALL_GEOM_KW, REF_GEOM_KW])
+def test_indices_bit_exact(kw, cuda):
+    from nersemble_amd import functional as F
+    go, gn = oracle.grid_geometry(**kw), _native_geom(kw)
+    rng = np.random.default_rng(5)
+    x = rng.random((4099, 3), dtype=np.float32)
+    x[:4] = [[0, 0, 0], [0.999999, 0.999999, 0.999999], [1.0, 1.0, 1.0], [0.5, 0.5, 0.5]]
+    # out-of-contract inputs must still agree (uint32 wrap + modulo), the field zeroes them in practice
+    x[4] = [-0.25, 1.5, 3.0]
+    want, _ = ohg.indices(x, go)
+    got = F.hash_indices(torch.from_numpy(x).to(cuda), gn).cpu().numpy().astype(np.uint32)
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("H", [1, 2, 4, 8, 16, 32])
+def test_layout_roundtrip_and_permutation(H, cuda):
+    from nersemble_amd import functional as F
+    go, gn, tabs, f16, master, _, _ = _setup(H, SMALL_GEOM_KW, 40 + H, 8, cuda)
+    back = F.tables_to_tcnn(master, H, gn).cpu().numpy()
+    assert np.array_equal(back, tabs)
+    P = 4 if 2 * H >= 8 else H
+    m = master.cpu().numpy()
+    for h in sorted({0, H - 1, H // 2}):
+        c, p = divmod(h, P)
+        for f in (0, 1):
+            assert np.array_equal(m[:, f, h], tabs[c, :, p * 2 + f])
+    assert np.array_equal(f16.cpu().numpy().astype(np.float32), m)
+
+
+@pytest.mark.parametrize("H", [1, 2, 4, 8, 16, 32])
+@pytest.mark.parametrize("B", [1, 7, 96, 1031])
+def test_forward_matches_oracle(H, B, cuda):
+    from nersemble_amd import functional as F
+    go, gn, tabs, f16, master, x, code = _setup(H, SMALL_GEOM_KW, 100 + H, B, cuda)
+    out = F.hash_ensemble(torch.from_numpy(x).to(cuda), master, f16, torch.from_numpy(code).to(cuda), H, gn)
+    assert out.dtype == torch.float16 and out.shape == (B, 32)
+    want = ohg.ensemble_fwd(x, tabs.astype(np.float16).view(np.uint16), H, go, code).astype(np.float32)
+    got = out.float().cpu().numpy()
+    # fp32 accumulation in a different order + one fp16 rounding: <= 1 fp16 ulp of the value
+    tol = FP16_EPS * np.abs(want) + 1e-6
+    assert (np.abs(got - want) <= tol).all(), float(np.abs(got - want).max())
+    assert (got == want).mean() > 0.98
+
+
+@pytest.mark.parametrize("H", [1, 2, 4, 8, 16, 32])
+def test_forward_matches_reference_golden(H, cuda, golden_dir):
+    """HIP kernel vs outputs of the reference's own HashEnsemble.forward (module-level API, windows incl.)."""
+    from nersemble_amd.field_components.hash_ensemble import HashEnsemble, HashEnsembleConfig, TCNNHashEncodingConfig
+    z = np.load(f"{golden_dir}/hash_ensemble.npz")
+    kw = SMALL_GEOM_KW
+    cfg = HashEnsembleConfig(H, TCNNHashEncodingConfig(n_levels=kw["n_levels"], log2_hashmap_size=kw["log2_hashmap_size"],
+                                                       base_resolution=kw["base_resolution"],
+                                                       per_level_scale=kw["per_level_scale"]),
+                             disable_initial_hash_ensemble=True, use_soft_transition=True)
+    he = HashEnsemble(cfg)
+    go = oracle.grid_geometry(**kw)
+    tabs = make_tcnn_tables(H, go, 100 + H)
+    he.load_state_dict({f"hash_encodings.{c}.params": torch.from_numpy(tabs[c].reshape(-1)) for c in range(tabs.shape[0])})
+    he = he.to(cuda)
+    x = torch.from_numpy(z["he_x"]).to(cuda)
+    code = torch.from_numpy(z[f"he_code_H{H}"]).to(cuda)
+    for wi, w in enumerate(z[f"he_windows_H{H}"]):
+        w = None if np.isnan(w) else float(w)
+        with torch.no_grad():
+            out = he(x, code.clone(), window_hash_encodings=w).float().cpu().numpy()
+        ref = z[f"he_out_H{H}_w{wi}"].astype(np.float32)
+        tol = 2.0 * FP16_EPS * np.abs(ref).max() + 1e-6
+        assert np.abs(out - ref).max() <= tol, (H, w, float(np.abs(out - ref).max()))
+
+
+def test_code_index_path_equals_gathered_codes(cuda):
+    from nersemble_amd import functional as F
+    H, B, T = 16, 517, 9
+    go, gn, tabs, f16, master, x, _ = _setup(H, SMALL_GEOM_KW, 9, B, cuda)
+    rng = np.random.default_rng(2)
+    emb = torch.from_numpy((rng.standard_normal((T, H)) * 0.5).astype(np.float32)).to(cuda)
+    ts = torch.from_numpy(rng.integers(0, T, B).astype(np.int32)).to(cuda)
+    win = torch.from_numpy(ohg.posenc_window(5.5, 0, H - 1, H)).to(cuda)
+    xt = torch.from_numpy(x).to(cuda)
+    a = F.hash_ensemble(xt, master, f16, emb, H, gn, code_index=ts, window=win)
+    b = F.hash_ensemble(xt, master, f16, emb[ts.long()].contiguous(), H, gn, window=win)
+    assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("H", [1, 2, 4, 8, 16, 32])
+def test_backward_matches_oracle(H, cuda):
+    from nersemble_amd import functional as F
+    B = 203
+    go, gn, tabs, f16, master, x, code = _setup(H, SMALL_GEOM_KW, 300 + H, B, cuda)
+    rng = np.random.default_rng(8)
+    dout = rng.standard_normal((B, 32)).astype(np.float32)
+    xt = torch.from_numpy(x).to(cuda).requires_grad_(True)
+    ct = torch.from_numpy(code).to(cuda).requires_grad_(True)
+    mt = master.clone().requires_grad_(True)
+    out = F.hash_ensemble(xt, mt, f16, ct, H, gn)
+    out.backward(torch.from_numpy(dout).to(cuda).to(out.dtype).float())
+    dtab_o, dcode_o, dx_o = ohg.ensemble_bwd(x, tabs.astype(np.float16).view(np.uint16), H, go, code, dout)
+    # table gradient: compare in the reference's tcnn layout (tests the permutation of the grad as well)
+    dtab = F.tables_to_tcnn(mt.grad, H, gn).cpu().numpy()
+    scale = np.abs(dtab_o).max()
+    assert np.abs(dtab - dtab_o).max() <= 2e-5 * scale + 1e-7, float(np.abs(dtab - dtab_o).max())
+    dcode = ct.grad.cpu().numpy()
+    assert np.abs(dcode - dcode_o).max() <= 2e-5 * np.abs(dcode_o).max() + 1e-7
+    dx = xt.grad.cpu().numpy()
+    assert np.abs(dx - dx_o).max() <= 5e-5 * np.abs(dx_o).max() + 1e-6
+
+
+def test_backward_with_code_index_and_window(cuda):
+    from nersemble_amd import functional as F
+    H, B, T = 32, 311, 5
+    go, gn, tabs, f16, master, x, _ = _setup(H, SMALL_GEOM_KW, 77, B, cuda)
+    rng = np.random.default_rng(12)
+    emb = (rng.standard_normal((T, H)) * 0.5).astype(np.float32)
+    ts = rng.integers(0, T, B).astype(np.int32)
+    win = ohg.posenc_window(20.3, 0, H - 1, H)
+    dout = rng.standard_normal((B, 32)).astype(np.float32)
+    et = torch.from_numpy(emb).to(cuda).requires_grad_(True)
+    out = F.hash_ensemble(torch.from_numpy(x).to(cuda), master, f16, et, H, gn,
+                          code_index=torch.from_numpy(ts).to(cuda), window=torch.from_numpy(win).to(cuda))
+    out.backward(torch.from_numpy(dout).to(cuda))
+    codew = emb[ts] * win[None]
+    _, dcw, _ = ohg.ensemble_bwd(x, tabs.astype(np.float16).view(np.uint16), H, go, codew, dout, want_table=False)
+    want = np.zeros_like(emb)
+    np.add.at(want, ts, dcw * win[None])
+    assert np.abs(et.grad.cpu().numpy() - want).max() <= 1e-4 * np.abs(want).max() + 1e-6
+
+
+def test_empty_batch(cuda):
+    from nersemble_amd import functional as F
+    H = 4
+    go, gn, tabs, f16, master, _, _ = _setup(H, SMALL_GEOM_KW, 1, 4, cuda)
+    out = F.hash_ensemble(torch.zeros((0, 3), device=cuda), master, f16, torch.zeros((0, H), device=cuda), H, gn)
+    assert out.shape == (0, 32)
+
+
+def test_full_size_properties_h32(cuda):
+    """BASELINE-size run (reference geometry, H=32, 2^20 samples): properties that need no oracle pass:
+    linearity in the code, agreement with the oracle on a random subsample, determinism."""
+    from nersemble_amd import functional as F
+    H, B = 32, 1 << 20
+    gn = _native_geom(REF_GEOM_KW)
+    go = oracle.grid_geometry(**REF_GEOM_KW)
+    gen = torch.Generator(device=cuda).manual_seed(3)
+    total = gn.total_entries
+    master = (torch.rand((total, 2, H), device=cuda, generator=gen) - 0.5)
+    f16 = master.half()
+    master = f16.float()
+    x = torch.rand((B, 3), device=cuda, generator=gen)
+    c1 = torch.randn((B, H), device=cuda, generator=gen) * 0.5
+    c2 = torch.randn((B, H), device=cuda, generator=gen) * 0.5
+    c1, c2 = c1.half().float(), c2.half().float()
+    o1 = F.hash_ensemble(x, master, f16, c1, H, gn).float()
+    o2 = F.hash_ensemble(x, master, f16, c2, H, gn).float()
+    o12 = F.hash_ensemble(x, master, f16, (c1 + c2).half().float(), H, gn).float()
+    lin = (o1 + o2 - o12).abs().max().item()
+    assert lin <= 8 * FP16_EPS * max(1.0, o12.abs().max().item())
+    assert torch.equal(o1, F.hash_ensemble(x, master, f16, c1, H, gn).float())
+    # oracle on a subsample of 2048 samples (tables converted back to the reference layout)
+    sel = torch.randperm(B, device=cuda, generator=gen)[:2048]
+    tc = F.tables_to_tcnn(master, H, gn).cpu().numpy().astype(np.float16)
+    want = ohg.ensemble_fwd(x[sel].cpu().numpy(), tc.view(np.uint16), H, go, c1[sel].cpu().numpy()).astype(np.float32)
+    got = o1[sel].cpu().numpy()
+    assert (np.abs(got - want) <= FP16_EPS * np.abs(want) + 1e-6).all()
