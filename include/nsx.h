@@ -29,6 +29,7 @@ extern "C" {
 #define NSX_ERR_UNSUPPORTED (-3)
 
 #define NSX_MAX_LEVELS 32
+#define NSX_MAX_SLOTS 64
 #define NSX_VERSION 100
 
 typedef uint16_t nsx_half;
@@ -101,6 +102,23 @@ int nsx_hash_ensemble_bwd(const float* x, int64_t B, const nsx_half* tables, int
                           const nsx_grid_geom* g, const float* code, int64_t code_stride,
                           const int32_t* code_index, const float* window, const float* dout,
                           float* dtables, float* dcode, float* dx, void* stream);
+
+/* Factored table gradient -- the MI355X-native backward used when the per-sample code is a row of a SMALL
+ * table (the <= 24 distinct time codes of a training batch, nersemble_instant_ngp.py:310-312).  Since
+ *   dL/dtable[e][f][h] = sum_slot G[e][slot][f] * code'[slot][h],   G[e][slot][f] = sum_{b in slot} w_b * dout_b[f],
+ * the kernel scatters 2 scalars per (sample, level, corner) into G instead of 2H table values (32x fewer
+ * atomics at H=32); nsx_hash_grad_expand then produces the native-layout fp32 table gradient.
+ *   code_table [n_slots][code_stride] fp32, code_slot [B] int32 in [0, n_slots), n_slots <= NSX_MAX_SLOTS
+ *   G          [total_entries][n_slots][2] fp32, ACCUMULATED into with atomics (caller zeroes); may be NULL
+ *   dcode      [B][H] fp32 per-sample gradient w.r.t. the windowed code row; may be NULL.  dx [B][3]; may be NULL */
+int nsx_hash_ensemble_bwd_factored(const float* x, int64_t B, const nsx_half* tables, int H,
+                                   const nsx_grid_geom* g, const float* code_table, int64_t code_stride,
+                                   int n_slots, const int32_t* code_slot, const float* window,
+                                   const float* dout, float* G, float* dcode, float* dx, void* stream);
+/* dtables (native fp32) = (accumulate ? dtables : 0) + expand(G, code_table*window). */
+int nsx_hash_grad_expand(const float* G, int n_slots, const float* code_table, int64_t code_stride,
+                         const float* window, int H, const nsx_grid_geom* g, float* dtables, int accumulate,
+                         void* stream);
 
 /* Debug/parity helper: the 8 level-local entry indices per (sample, level), uint32 [B][L][8].
  * Integer outputs are held bit-exact to the oracle. */

@@ -7,6 +7,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "csrc", "libnsx.so")
 NSX_MAX_LEVELS = 32
+NSX_MAX_SLOTS = 64
 
 c_void_p, c_int, c_int64, c_float = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
@@ -44,6 +45,11 @@ SIGNATURES = {
                                       c_void_p, c_void_p, c_void_p]),
     "nsx_hash_ensemble_bwd": (c_int, [c_void_p, c_int64, c_void_p, c_int, _GEOM_P, c_void_p, c_int64, c_void_p,
                                       c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "nsx_hash_ensemble_bwd_factored": (c_int, [c_void_p, c_int64, c_void_p, c_int, _GEOM_P, c_void_p, c_int64, c_int,
+                                               c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                               c_void_p]),
+    "nsx_hash_grad_expand": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_void_p, c_int, _GEOM_P, c_void_p, c_int,
+                                     c_void_p]),
     "nsx_hash_indices": (c_int, [c_void_p, c_int64, _GEOM_P, c_void_p, c_void_p]),
 }
 

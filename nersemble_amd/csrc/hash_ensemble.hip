@@ -218,12 +218,17 @@ __global__ __launch_bounds__(WAVES * kWave) void ens_fwd_kernel(
 // ------------------------------------------------------------------------------------------------
 // backward: table gradient (fp32 atomics into the native layout), code gradient, position gradient
 // ------------------------------------------------------------------------------------------------
-template <int H, int WAVES>
+// FACTORED: the per-sample code is row code_index[b] of a SMALL table (n_slots rows), so
+//   dL/dtable[e][f][h] = sum_slot G[e][slot][f] * code'[slot][h],  G[e][slot][f] = sum_{b in slot} w * dout_f.
+// The kernel then scatters only 2 scalars per (sample, level, corner) into G (one corner per lane) instead of
+// 2*H values; nsx_hash_grad_expand turns G into the table gradient with a tiny dense contraction.
+template <int H, int WAVES, bool FACTORED>
 __global__ __launch_bounds__(WAVES * kWave) void ens_bwd_kernel(
     const float* __restrict__ x, int64_t B, const uint8_t* __restrict__ tab, const nsx_grid_geom g,
     const float* __restrict__ code, int64_t code_stride, const int32_t* __restrict__ code_index,
     const float* __restrict__ window, int Hreal, const float* __restrict__ dout,
-    float* __restrict__ dtab, float* __restrict__ dcode, float* __restrict__ dx, int64_t n_tiles) {
+    float* __restrict__ dtab, float* __restrict__ dcode, float* __restrict__ dx, int64_t n_tiles,
+    int n_slots) {
     using C = EnsCfg<H>;
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x / kWave;
@@ -239,10 +244,8 @@ __global__ __launch_bounds__(WAVES * kWave) void ens_bwd_kernel(
         const int64_t b = valid ? b_raw : B - 1;
         const float px = x[b * 3 + 0], py = x[b * 3 + 1], pz = x[b * 3 + 2];
         half2_t cw[C::NDW];
-        {
-            const int64_t r = code_index ? (int64_t)code_index[b] : b;
-            load_code<H>(code + r * code_stride, window, Hreal, q, cw);
-        }
+        const int64_t crow = code_index ? (int64_t)code_index[b] : b;
+        load_code<H>(code + crow * code_stride, window, Hreal, q, cw);
         float dc[NH];
 #pragma unroll
         for (int i = 0; i < NH; ++i) dc[i] = 0.f;
@@ -273,7 +276,8 @@ __global__ __launch_bounds__(WAVES * kWave) void ens_bwd_kernel(
             for (int k = 0; k < 8; ++k) {
                 // blended_k = sum_f g_f * sum_h table[f][h] * code[h]  (this lane's share)
                 float blended = 0.f;
-                float* gdst = dtab ? dtab + ((size_t)(off + idx[k]) * C::ROW_BYTES + q * C::LANE_BYTES) / 2 : nullptr;
+                float* gdst = (!FACTORED && dtab)
+                                  ? dtab + ((size_t)(off + idx[k]) * C::ROW_BYTES + q * C::LANE_BYTES) / 2 : nullptr;
                 if constexpr (H == 1) {
                     const half2_t t = as_half2(v[k].d[0]);
                     const float cf = (float)cw[0].x;
@@ -308,6 +312,23 @@ __global__ __launch_bounds__(WAVES * kWave) void ens_bwd_kernel(
                 dxa = __fmaf_rn((k & 1) ? sb : -sb, ox, dxa);
                 dya = __fmaf_rn((k & 2) ? sb : -sb, oy, dya);
                 dza = __fmaf_rn((k & 4) ? sb : -sb, oz, dza);
+            }
+            if constexpr (FACTORED) {
+                if (dtab) {
+                    // lane q of the sample owns corners q, q+LPE, ...: 2 scalar atomics per corner
+#pragma unroll
+                    for (int k0 = 0; k0 < 8; k0 += C::LPE) {
+                        uint32_t ik = idx[k0];
+                        float wk = w[k0];
+#pragma unroll
+                        for (int j = 1; j < C::LPE; ++j) {
+                            if (q == j) { ik = idx[k0 + j]; wk = w[k0 + j]; }
+                        }
+                        float* gp = dtab + ((size_t)(off + ik) * (size_t)n_slots + (size_t)crow) * 2;
+                        atomicAdd(gp + 0, wk * g0);
+                        atomicAdd(gp + 1, wk * g1);
+                    }
+                }
             }
         }
         // position gradient: reduce over the LPE lanes of the sample
@@ -381,6 +402,45 @@ __global__ void tables_to_tcnn_kernel(const float* __restrict__ src, int H, int 
     }
 }
 
+// dtables[e][f][h] (+)= sum_slot G[e][slot][f] * code'[slot][h]   (code' = fp16(code*window), as in the forward)
+template <int HP>
+__global__ __launch_bounds__(256) void grad_expand_kernel(const float* __restrict__ G, int n_slots,
+                                                          const float* __restrict__ code, int64_t code_stride,
+                                                          const float* __restrict__ window, int Hreal,
+                                                          uint64_t total, float* __restrict__ dtab, int accumulate) {
+    extern __shared__ float cs[];     // [n_slots][HP]
+    for (int i = threadIdx.x; i < n_slots * HP; i += blockDim.x) {
+        const int sl = i / HP, h = i % HP;
+        float c = 0.f;
+        if (h < Hreal) c = code[sl * code_stride + h] * (window ? window[h] : 1.0f);
+        cs[i] = (float)(half_t)c;
+    }
+    __syncthreads();
+    // one thread per (entry, f, h-quad): 2*HP/4 threads per entry (HP>=4) -> coalesced float4 stores
+    constexpr int HQ = HP >= 4 ? HP / 4 : 1;
+    constexpr int HV = HP >= 4 ? 4 : HP;
+    const uint64_t n = total * 2ull * HQ;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const int hq = (int)(i % HQ);
+        const int f = (int)((i / HQ) & 1);
+        const uint64_t e = i / (2ull * HQ);
+        const float* gr = G + e * (uint64_t)n_slots * 2ull + f;
+        float acc[HV];
+#pragma unroll
+        for (int v = 0; v < HV; ++v) acc[v] = 0.f;
+        for (int sl = 0; sl < n_slots; ++sl) {
+            const float gv = gr[sl * 2];
+            if (gv != 0.f) {
+#pragma unroll
+                for (int v = 0; v < HV; ++v) acc[v] = __fmaf_rn(gv, cs[sl * HP + hq * HV + v], acc[v]);
+            }
+        }
+        float* dst = dtab + (e * 2ull + f) * HP + hq * HV;
+#pragma unroll
+        for (int v = 0; v < HV; ++v) dst[v] = accumulate ? dst[v] + acc[v] : acc[v];
+    }
+}
+
 __global__ void hash_indices_kernel(const float* __restrict__ x, int64_t B, const nsx_grid_geom g,
                                     uint32_t* __restrict__ out) {
     const int L = g.n_levels;
@@ -424,16 +484,22 @@ static int launch_fwd(const float* x, int64_t B, const nsx_half* tables, int Hre
 template <int H>
 static int launch_bwd(const float* x, int64_t B, const nsx_half* tables, int Hreal, const nsx_grid_geom* g,
                       const float* code, int64_t code_stride, const int32_t* code_index, const float* window,
-                      const float* dout, float* dtables, float* dcode, float* dx, hipStream_t st) {
+                      const float* dout, float* dtables, float* dcode, float* dx, hipStream_t st,
+                      int n_slots = 0) {
     using C = EnsCfg<H>;
     constexpr int WAVES = 4;
     const int64_t n_tiles = (B + C::SPW - 1) / C::SPW;
     int64_t blocks = (n_tiles + WAVES - 1) / WAVES;
     const int64_t cap = (int64_t)num_cus() * 8;
     if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL((ens_bwd_kernel<H, WAVES>), dim3((unsigned)blocks), dim3(WAVES * kWave), 0, st, x, B,
-                       reinterpret_cast<const uint8_t*>(tables), *g, code, code_stride, code_index, window, Hreal,
-                       dout, dtables, dcode, dx, n_tiles);
+    if (n_slots > 0)
+        hipLaunchKernelGGL((ens_bwd_kernel<H, WAVES, true>), dim3((unsigned)blocks), dim3(WAVES * kWave), 0, st, x, B,
+                           reinterpret_cast<const uint8_t*>(tables), *g, code, code_stride, code_index, window,
+                           Hreal, dout, dtables, dcode, dx, n_tiles, n_slots);
+    else
+        hipLaunchKernelGGL((ens_bwd_kernel<H, WAVES, false>), dim3((unsigned)blocks), dim3(WAVES * kWave), 0, st, x,
+                           B, reinterpret_cast<const uint8_t*>(tables), *g, code, code_stride, code_index, window,
+                           Hreal, dout, dtables, dcode, dx, n_tiles, 0);
     NSX_LAUNCH_CHECK("nsx_hash_ensemble_bwd launch");
     return NSX_OK;
 }
@@ -443,6 +509,16 @@ static int check_geom(const nsx_grid_geom* g, int Hp, const char* who) {
     NSX_REQUIRE(g->n_levels >= 1 && g->n_levels <= NSX_MAX_LEVELS, "%s: bad n_levels %d", who, g->n_levels);
     const uint64_t bytes = (uint64_t)g->offset[g->n_levels] * 4ull * (uint64_t)Hp;
     NSX_REQUIRE(bytes > 0, "%s: empty geometry", who);
+    return NSX_OK;
+}
+
+template <int HP>
+static int launch_expand(const float* G, int n_slots, const float* code, int64_t code_stride, const float* window,
+                         int H, uint64_t total, float* dtables, int accumulate, hipStream_t st) {
+    const size_t smem = (size_t)n_slots * HP * sizeof(float);
+    hipLaunchKernelGGL((grad_expand_kernel<HP>), dim3(num_cus() * 8), dim3(256), smem, st, G, n_slots, code,
+                       code_stride, window, H, total, dtables, accumulate);
+    NSX_LAUNCH_CHECK("nsx_hash_grad_expand launch");
     return NSX_OK;
 }
 
@@ -525,6 +601,52 @@ int nsx_hash_ensemble_bwd(const float* x, int64_t B, const nsx_half* tables, int
         case 32: return launch_bwd<32>(x, B, tables, H, g, code, code_stride, code_index, window, dout, dtables, dcode, dx, st);
     }
     set_error("nsx_hash_ensemble_bwd: unsupported H=%d", H);
+    return NSX_ERR_UNSUPPORTED;
+}
+
+int nsx_hash_ensemble_bwd_factored(const float* x, int64_t B, const nsx_half* tables, int H,
+                                   const nsx_grid_geom* g, const float* code_table, int64_t code_stride,
+                                   int n_slots, const int32_t* code_slot, const float* window,
+                                   const float* dout, float* G, float* dcode, float* dx, void* stream) {
+    NSX_REQUIRE(B >= 0, "nsx_hash_ensemble_bwd_factored: negative batch");
+    if (B == 0) return NSX_OK;
+    NSX_REQUIRE(x && tables && code_table && code_slot && dout, "nsx_hash_ensemble_bwd_factored: NULL argument");
+    NSX_REQUIRE(H >= 1 && H <= 32, "nsx_hash_ensemble_bwd_factored: H=%d not in [1,32]", H);
+    NSX_REQUIRE(n_slots >= 1 && n_slots <= NSX_MAX_SLOTS, "nsx_hash_ensemble_bwd_factored: n_slots=%d not in [1,%d]",
+                n_slots, NSX_MAX_SLOTS);
+    const int Hp = nsx_padded_grids(H);
+    if (int rc = check_geom(g, Hp, "nsx_hash_ensemble_bwd_factored")) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    switch (Hp) {
+        case 1: return launch_bwd<1>(x, B, tables, H, g, code_table, code_stride, code_slot, window, dout, G, dcode, dx, st, n_slots);
+        case 2: return launch_bwd<2>(x, B, tables, H, g, code_table, code_stride, code_slot, window, dout, G, dcode, dx, st, n_slots);
+        case 4: return launch_bwd<4>(x, B, tables, H, g, code_table, code_stride, code_slot, window, dout, G, dcode, dx, st, n_slots);
+        case 8: return launch_bwd<8>(x, B, tables, H, g, code_table, code_stride, code_slot, window, dout, G, dcode, dx, st, n_slots);
+        case 16: return launch_bwd<16>(x, B, tables, H, g, code_table, code_stride, code_slot, window, dout, G, dcode, dx, st, n_slots);
+        case 32: return launch_bwd<32>(x, B, tables, H, g, code_table, code_stride, code_slot, window, dout, G, dcode, dx, st, n_slots);
+    }
+    set_error("nsx_hash_ensemble_bwd_factored: unsupported H=%d", H);
+    return NSX_ERR_UNSUPPORTED;
+}
+
+int nsx_hash_grad_expand(const float* G, int n_slots, const float* code_table, int64_t code_stride,
+                         const float* window, int H, const nsx_grid_geom* g, float* dtables, int accumulate,
+                         void* stream) {
+    NSX_REQUIRE(G && code_table && dtables && g, "nsx_hash_grad_expand: NULL argument");
+    NSX_REQUIRE(H >= 1 && H <= 32, "nsx_hash_grad_expand: H=%d not in [1,32]", H);
+    NSX_REQUIRE(n_slots >= 1 && n_slots <= NSX_MAX_SLOTS, "nsx_hash_grad_expand: n_slots=%d not in [1,%d]", n_slots,
+                NSX_MAX_SLOTS);
+    const uint64_t total = g->offset[g->n_levels];
+    hipStream_t st = (hipStream_t)stream;
+    switch (nsx_padded_grids(H)) {
+        case 1: return launch_expand<1>(G, n_slots, code_table, code_stride, window, H, total, dtables, accumulate, st);
+        case 2: return launch_expand<2>(G, n_slots, code_table, code_stride, window, H, total, dtables, accumulate, st);
+        case 4: return launch_expand<4>(G, n_slots, code_table, code_stride, window, H, total, dtables, accumulate, st);
+        case 8: return launch_expand<8>(G, n_slots, code_table, code_stride, window, H, total, dtables, accumulate, st);
+        case 16: return launch_expand<16>(G, n_slots, code_table, code_stride, window, H, total, dtables, accumulate, st);
+        case 32: return launch_expand<32>(G, n_slots, code_table, code_stride, window, H, total, dtables, accumulate, st);
+    }
+    set_error("nsx_hash_grad_expand: unsupported H=%d", H);
     return NSX_ERR_UNSUPPORTED;
 }
 

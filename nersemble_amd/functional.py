@@ -83,12 +83,29 @@ class _HashEnsembleFn(torch.autograd.Function):
         B = x.shape[0]
         need_x, need_tab, _, need_code = ctx.needs_input_grad[0], ctx.needs_input_grad[1], None, ctx.needs_input_grad[3]
         dout = dout.to(torch.float32).contiguous()
-        dtab = torch.zeros(ctx.master_shape, dtype=torch.float32, device=x.device) if need_tab else None
         dcode_s = torch.empty((B, H), dtype=torch.float32, device=x.device) if need_code else None
         dx = torch.empty((B, 3), dtype=torch.float32, device=x.device) if need_x else None
-        check(lib().nsx_hash_ensemble_bwd(ptr(x), B, ptr(tables_f16), H, C.byref(geom), ptr(code), code.stride(0),
-                                          ptr(code_index), ptr(window), ptr(dout), ptr(dtab), ptr(dcode_s), ptr(dx),
-                                          stream()), "nsx_hash_ensemble_bwd")
+        n_rows = code.shape[0]
+        if code_index is not None and n_rows <= _lib.NSX_MAX_SLOTS:
+            # factored table gradient: scatter 2 scalars per corner into G[e][slot][f], then expand with the codes
+            dtab = None
+            G = None
+            if need_tab:
+                G = torch.zeros((geom.total_entries, n_rows, 2), dtype=torch.float32, device=x.device)
+            check(lib().nsx_hash_ensemble_bwd_factored(ptr(x), B, ptr(tables_f16), H, C.byref(geom), ptr(code),
+                                                       code.stride(0), n_rows, ptr(code_index), ptr(window),
+                                                       ptr(dout), ptr(G), ptr(dcode_s), ptr(dx), stream()),
+                  "nsx_hash_ensemble_bwd_factored")
+            if need_tab:
+                dtab = torch.empty(ctx.master_shape, dtype=torch.float32, device=x.device)
+                check(lib().nsx_hash_grad_expand(ptr(G), n_rows, ptr(code), code.stride(0), ptr(window), H,
+                                                 C.byref(geom), ptr(dtab), 0, stream()), "nsx_hash_grad_expand")
+                del G
+        else:
+            dtab = torch.zeros(ctx.master_shape, dtype=torch.float32, device=x.device) if need_tab else None
+            check(lib().nsx_hash_ensemble_bwd(ptr(x), B, ptr(tables_f16), H, C.byref(geom), ptr(code),
+                                              code.stride(0), ptr(code_index), ptr(window), ptr(dout), ptr(dtab),
+                                              ptr(dcode_s), ptr(dx), stream()), "nsx_hash_ensemble_bwd")
         dcode = None
         if need_code:
             if window is not None:

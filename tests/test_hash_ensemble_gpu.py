@@ -123,12 +123,13 @@ def test_backward_matches_oracle(H, cuda):
     B = 203
     go, gn, tabs, f16, master, x, code = _setup(H, SMALL_GEOM_KW, 300 + H, B, cuda)
     rng = np.random.default_rng(8)
-    dout = rng.standard_normal((B, 32)).astype(np.float32)
+    # the upstream gradient of an fp16 activation arrives in fp16 (AMP semantics, as in the reference)
+    dout = rng.standard_normal((B, 32)).astype(np.float16).astype(np.float32)
     xt = torch.from_numpy(x).to(cuda).requires_grad_(True)
     ct = torch.from_numpy(code).to(cuda).requires_grad_(True)
     mt = master.clone().requires_grad_(True)
     out = F.hash_ensemble(xt, mt, f16, ct, H, gn)
-    out.backward(torch.from_numpy(dout).to(cuda).to(out.dtype).float())
+    out.backward(torch.from_numpy(dout).to(cuda).half())
     dtab_o, dcode_o, dx_o = ohg.ensemble_bwd(x, tabs.astype(np.float16).view(np.uint16), H, go, code, dout)
     # table gradient: compare in the reference's tcnn layout (tests the permutation of the grad as well)
     dtab = F.tables_to_tcnn(mt.grad, H, gn).cpu().numpy()
@@ -140,24 +141,32 @@ def test_backward_matches_oracle(H, cuda):
     assert np.abs(dx - dx_o).max() <= 5e-5 * np.abs(dx_o).max() + 1e-6
 
 
-def test_backward_with_code_index_and_window(cuda):
+@pytest.mark.parametrize("H,T", [(32, 5), (16, 24), (4, 64), (1, 3), (8, 200)])
+def test_backward_with_code_index_and_window(H, T, cuda):
+    """Indexed codes: T <= 64 rows takes the factored table-gradient path (G scatter + expand), T = 200 the
+    generic atomics path; both must equal the oracle (table, code-table, position gradients)."""
     from nersemble_amd import functional as F
-    H, B, T = 32, 311, 5
-    go, gn, tabs, f16, master, x, _ = _setup(H, SMALL_GEOM_KW, 77, B, cuda)
+    B = 311
+    go, gn, tabs, f16, master, x, _ = _setup(H, SMALL_GEOM_KW, 77 + H, B, cuda)
     rng = np.random.default_rng(12)
     emb = (rng.standard_normal((T, H)) * 0.5).astype(np.float32)
     ts = rng.integers(0, T, B).astype(np.int32)
-    win = ohg.posenc_window(20.3, 0, H - 1, H)
-    dout = rng.standard_normal((B, 32)).astype(np.float32)
+    win = ohg.posenc_window(0.63 * H + 0.2, 0, H - 1, H)
+    dout = rng.standard_normal((B, 32)).astype(np.float16).astype(np.float32)
     et = torch.from_numpy(emb).to(cuda).requires_grad_(True)
-    out = F.hash_ensemble(torch.from_numpy(x).to(cuda), master, f16, et, H, gn,
+    mt = master.clone().requires_grad_(True)
+    xt = torch.from_numpy(x).to(cuda).requires_grad_(True)
+    out = F.hash_ensemble(xt, mt, f16, et, H, gn,
                           code_index=torch.from_numpy(ts).to(cuda), window=torch.from_numpy(win).to(cuda))
-    out.backward(torch.from_numpy(dout).to(cuda))
+    out.backward(torch.from_numpy(dout).to(cuda).half())
     codew = emb[ts] * win[None]
-    _, dcw, _ = ohg.ensemble_bwd(x, tabs.astype(np.float16).view(np.uint16), H, go, codew, dout, want_table=False)
+    dtab_o, dcw, dx_o = ohg.ensemble_bwd(x, tabs.astype(np.float16).view(np.uint16), H, go, codew, dout)
     want = np.zeros_like(emb)
     np.add.at(want, ts, dcw * win[None])
     assert np.abs(et.grad.cpu().numpy() - want).max() <= 1e-4 * np.abs(want).max() + 1e-6
+    dtab = F.tables_to_tcnn(mt.grad, H, gn).cpu().numpy()
+    assert np.abs(dtab - dtab_o).max() <= 2e-5 * np.abs(dtab_o).max() + 1e-7
+    assert np.abs(xt.grad.cpu().numpy() - dx_o).max() <= 5e-5 * np.abs(dx_o).max() + 1e-6
 
 
 def test_empty_batch(cuda):

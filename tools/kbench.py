@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--H", type=int, default=32)
     ap.add_argument("--log2B", type=int, default=20)
     ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--generic", action="store_true", help="also time the generic (2H atomics per corner) backward")
     ap.add_argument("--coherent", action="store_true", help="ray-like spatially coherent samples instead of uniform")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -45,7 +46,7 @@ def main():
         x = ((o + d * t) % 1.0).reshape(-1, 3).contiguous()
     else:
         x = torch.rand((B, 3), device=dev, generator=gen)
-    T = 100
+    T = 24
     emb = torch.randn((T, H), device=dev, generator=gen)
     ts = torch.randint(0, T, (B,), device=dev, generator=gen, dtype=torch.int32)
     dout = torch.randn((B, 32), device=dev, generator=gen)
@@ -64,11 +65,23 @@ def main():
         _lib.check(_lib.lib().nsx_hash_ensemble_bwd(_lib.ptr(x), B, _lib.ptr(f16), H, C.byref(g), _lib.ptr(emb),
                                                     emb.stride(0), _lib.ptr(ts), None, _lib.ptr(dout), _lib.ptr(dt),
                                                     _lib.ptr(dcode), _lib.ptr(dx), _lib.stream()))
-    ms = timeit(bwd, max(3, a.iters // 2))
-    res["bwd_ms"] = ms
-    res["bwd_GBps"] = B * (1024 * H + 76) / ms / 1e6
+    if a.generic:
+        ms = timeit(bwd, 2, 1)
+        res["bwd_generic_ms"] = ms
     ms = timeit(lambda: bwd(None), max(3, a.iters // 2))
     res["bwd_notable_ms"] = ms
+    G = torch.zeros((g.total_entries, T, 2), device=dev)
+
+    def bwdf(Gp=G):
+        _lib.check(_lib.lib().nsx_hash_ensemble_bwd_factored(_lib.ptr(x), B, _lib.ptr(f16), H, C.byref(g),
+                                                             _lib.ptr(emb), emb.stride(0), T, _lib.ptr(ts), None,
+                                                             _lib.ptr(dout), _lib.ptr(Gp), _lib.ptr(dcode),
+                                                             _lib.ptr(dx), _lib.stream()))
+    res["bwd_factored_ms"] = timeit(bwdf, a.iters)
+    res["bwd_factored_GBps"] = B * (1024 * H + 76) / res["bwd_factored_ms"] / 1e6
+    res["expand_ms"] = timeit(lambda: _lib.check(_lib.lib().nsx_hash_grad_expand(
+        _lib.ptr(G), T, _lib.ptr(emb), emb.stride(0), None, H, C.byref(g), _lib.ptr(dtab), 0, _lib.stream())), a.iters)
+    res["memsetG_ms"] = timeit(lambda: G.zero_(), a.iters)
     print(json.dumps(res))
 
 
