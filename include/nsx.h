@@ -120,6 +120,33 @@ int nsx_hash_grad_expand(const float* G, int n_slots, const float* code_table, i
                          const float* window, int H, const nsx_grid_geom* g, float* dtables, int accumulate,
                          void* stream);
 
+/* ---- fully fused MLPs (tcnn FullyFusedMLP equivalents) ---------------------------------------------------
+ * Replaces tcnn.NetworkWithInputEncoding (Identity encoding) / tcnn.Network as built at
+ * nersemble_nerfacto_field.py:142-153 (mlp_base: 32 -> 64 -> 16, no output activation) and :162-172
+ * (mlp_head: 18 -> 64 -> 64 -> 3, Sigmoid), called at :285 and :377.
+ *   weights   fp16, tcnn flat layout: W0 [64][32] | (Wh [64][64] if n_hidden_mats == 1) | Wo [16][64],
+ *             row-major [out][in], no biases, input zero-padded to 32, output padded to 16.
+ *   input of sample b = [ a[b][0..a_dim) * a_mul + a_add  (fp32 source),
+ *                         b[b][b_off .. b_off + b_dim)      (fp16 source), zero padding ]
+ *             -- the two segments let mlp_head read (dir+1)/2 (nersemble_nerfacto_field.py:313) and the 15
+ *             geometry features straight from mlp_base's output without materialising the torch.cat (:371-375).
+ *   out       [B][out_stride] fp16, columns [0, n_out) written; out_act 0 = None, 1 = Sigmoid.
+ * nsx_mlp_bwd recomputes the forward (no saved activations) and produces
+ *   dweights  fp32 [nsx_mlp_param_count], ACCUMULATED into (caller zeroes)
+ *   da        fp32 [B][a_dim] (may be NULL), db fp16 written at b's layout [B][b_stride] cols b_off.. (may be NULL)
+ * from dout fp16 [B][dout_stride] (AMP semantics: gradients of fp16 activations are fp16, loss-scaled by the caller). */
+int nsx_mlp_param_count(int n_hidden_mats);
+int nsx_mlp_fwd(const nsx_half* weights, int n_hidden_mats, int64_t B,
+                const float* a, int64_t a_stride, int a_dim, float a_mul, float a_add,
+                const nsx_half* b, int64_t b_stride, int b_off, int b_dim,
+                int n_out, int out_act, nsx_half* out, int64_t out_stride, void* stream);
+int nsx_mlp_bwd(const nsx_half* weights, int n_hidden_mats, int64_t B,
+                const float* a, int64_t a_stride, int a_dim, float a_mul, float a_add,
+                const nsx_half* b, int64_t b_stride, int b_off, int b_dim,
+                int n_out, int out_act, const nsx_half* dout, int64_t dout_stride,
+                float* dweights, float* da, nsx_half* db, void* stream);
+int nsx_f32_to_f16(const float* src, nsx_half* dst, int64_t n, void* stream);
+
 /* Debug/parity helper: the 8 level-local entry indices per (sample, level), uint32 [B][L][8].
  * Integer outputs are held bit-exact to the oracle. */
 int nsx_hash_indices(const float* x, int64_t B, const nsx_grid_geom* g, uint32_t* idx, void* stream);

@@ -50,6 +50,12 @@ SIGNATURES = {
                                                c_void_p]),
     "nsx_hash_grad_expand": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_void_p, c_int, _GEOM_P, c_void_p, c_int,
                                      c_void_p]),
+    "nsx_mlp_param_count": (c_int, [c_int]),
+    "nsx_mlp_fwd": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_int64, c_int, c_float, c_float, c_void_p, c_int64,
+                            c_int, c_int, c_int, c_int, c_void_p, c_int64, c_void_p]),
+    "nsx_mlp_bwd": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_int64, c_int, c_float, c_float, c_void_p, c_int64,
+                            c_int, c_int, c_int, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "nsx_f32_to_f16": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "nsx_hash_indices": (c_int, [c_void_p, c_int64, _GEOM_P, c_void_p, c_void_p]),
 }
 

@@ -1,0 +1,516 @@
+// mlp.hip -- fully fused small MLPs (tcnn FullyFusedMLP equivalents) on gfx950 MFMA.
+//
+// Replaces tcnn.NetworkWithInputEncoding / tcnn.Network as used by the reference field
+// (src/nersemble/nerfstudio/fields/nersemble_nerfacto_field.py:142-153 `mlp_base` 32->64->16, :162-172
+// `mlp_head` 18(pad 32)->64->64->3(pad 16) Sigmoid; calls at :285 and :377).
+//
+// Semantics (tcnn FullyFusedMLP, restated from the published design): fp16 weights without
+// biases, row-major [out][in] matrices stored back to back in one flat parameter vector (first layer
+// [64][in_pad], hidden [64][64], last [16][64]); input zero-padded to 32, output padded to 16; ReLU hidden
+// activations stored in fp16; output activation None / Sigmoid.  Accumulation here is fp32 in the MFMA
+// (tcnn accumulates in fp16 on tensor cores) -> ~1e-2 relative agreement is the stated tolerance.
+//
+// MI355X design
+//   * v_mfma_f32_32x32x16_f16, D[neuron][sample] = W[neuron][k] * X[k][sample]: one wave owns a tile of 32
+//     samples; lane = (sample n = lane&31, k-half = lane>>5).  The accumulator layout of layer l (lane holds
+//     16 neurons of ONE sample) is exactly the B-operand layout of layer l+1 up to a permutation of k, and
+//     k is a contraction index -> the weight fragments are stored pre-permuted in LDS and the activations
+//     never leave registers between layers (no LDS/HBM round trip, no cross-lane traffic).
+//   * backward recomputes the forward in-register (inputs are 64 B/sample; saving [B][64] activations like
+//     tcnn would triple the HBM traffic), chains dZ through W^T fragments the same way, and forms weight
+//     gradients with samples as the contraction index: dZ and H tiles are transposed through a padded
+//     (conflict-free) per-wave LDS tile, multiplied on MFMA, accumulated in registers across all tiles of
+//     the wave and reduced block-wide before one fp32 atomic per parameter per block.
+//   * these kernels are memory/latency bound (<= 16 MFMAs per 32 samples): MFMA time is noise next to the
+//     hash gather, so the design optimises bytes and launches, not matrix-core utilisation.
+#include "nsx_common.h"
+
+namespace nsx {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int MLP_W = 64;        // hidden width
+constexpr int MLP_IN = 32;       // padded input width
+constexpr int MLP_OUT = 16;      // padded output width
+constexpr int MLP_WAVES = 4;
+
+struct MlpIO {
+    // input vector of sample b = [ a[b][0..a_dim) * a_mul + a_add  (fp32 source),  bsrc[b][b_off .. b_off+b_dim) (fp16 source), 0... ]
+    const float* a; int64_t a_stride; int a_dim; float a_mul, a_add;
+    const half_t* b; int64_t b_stride; int b_off; int b_dim;
+};
+
+__device__ __forceinline__ f32x16 mfma(f16x8 a, f16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 zero16() {
+    f32x16 z;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) z[i] = 0.f;
+    return z;
+}
+// accumulator register r of lane-half `half` holds row:
+__device__ __host__ __forceinline__ int acc_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
+// k-permutation when the accumulator tile mt of the previous layer is used as B operand:
+// K-step t = 2*mt + tt uses registers 8*tt .. 8*tt+7 -> actual neuron index
+__device__ __host__ __forceinline__ int kmap_chain(int t, int kb, int j) {
+    return 32 * (t >> 1) + acc_row(8 * (t & 1) + j, kb);
+}
+__device__ __host__ __forceinline__ int kmap_natural(int t, int kb, int j) { return 16 * t + 8 * kb + j; }
+
+// ---- LDS weight fragments ----------------------------------------------------------------------
+// Fragment (mt, t) of a matrix product D = Wm * Xm with Wm[M][K]: lane (i = lane&31, kb = lane>>5) element j
+// holds Wm[32*mt + i][kmap(t, kb, j)] (zero outside the matrix).
+struct FragPlan {
+    // forward
+    int w0;          // [2 mt][2 t]    W0 [64][32], natural k
+    int wh;          // [2 mt][4 t]    Wh [64][64], chained k        (only if NH == 1)
+    int wo;          // [1 mt][4 t]    Wo [16->32][64], chained k
+    // backward (transposed matrices, K = output neurons in chained order)
+    int woT;         // [2 mt][1 t]    Wo^T [64][16->(K-step 0 only)]
+    int whT;         // [2 mt][4 t]    Wh^T [64][64]
+    int w0T;         // [1 mt][4 t]    W0^T [32][64]
+    int total;
+};
+__device__ __host__ inline FragPlan make_plan(int NH, bool bwd) {
+    FragPlan p{};
+    int n = 0;
+    p.w0 = n; n += 4;
+    p.wh = n; if (NH) n += 8;
+    p.wo = n; n += 4;
+    if (bwd) {
+        p.woT = n; n += 2;
+        p.whT = n; if (NH) n += 8;
+        p.w0T = n; n += 4;
+    }
+    p.total = n;
+    return p;
+}
+
+template <int NH>
+__device__ void stage_weights(const half_t* __restrict__ W, int in_pad_unused, f16x8* frags, bool bwd) {
+    // flat parameter layout: W0 [64][32], (Wh [64][64]), Wo [16][64]
+    const half_t* W0 = W;
+    const half_t* Wh = W + MLP_W * MLP_IN;
+    const half_t* Wo = Wh + (NH ? MLP_W * MLP_W : 0);
+    const FragPlan p = make_plan(NH, bwd);
+    for (int e = threadIdx.x; e < p.total * kWave; e += blockDim.x) {
+        const int fi = e / kWave, ll = e % kWave;
+        const int i = ll & 31, kb = ll >> 5;
+        f16x8 v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            half_t x = (half_t)0.f;
+            if (fi < p.wh) {                       // W0: mt = (fi-p.w0)/2, t = %2, natural k
+                const int mt = (fi - p.w0) >> 1, t = (fi - p.w0) & 1;
+                x = W0[(32 * mt + i) * MLP_IN + kmap_natural(t, kb, j)];
+            } else if (fi < p.wo) {                // Wh
+                const int mt = (fi - p.wh) >> 2, t = (fi - p.wh) & 3;
+                x = Wh[(32 * mt + i) * MLP_W + kmap_chain(t, kb, j)];
+            } else if (!bwd || fi < p.woT) {       // Wo (rows >= 16 are zero padding)
+                const int t = fi - p.wo;
+                if (i < MLP_OUT) x = Wo[i * MLP_W + kmap_chain(t, kb, j)];
+            } else if (fi < p.whT) {               // Wo^T: M = hidden neuron (2 tiles), K-step 0 of chained out neurons
+                const int mt = fi - p.woT;
+                const int o = kmap_chain(0, kb, j);          // rows 0..3,8..11 / 4..7,12..15
+                if (o < MLP_OUT) x = Wo[o * MLP_W + 32 * mt + i];
+            } else if (fi < p.w0T) {               // Wh^T
+                const int mt = (fi - p.whT) >> 2, t = (fi - p.whT) & 3;
+                x = Wh[kmap_chain(t, kb, j) * MLP_W + 32 * mt + i];
+            } else {                               // W0^T: M = input feature (1 tile), K = 64 hidden chained
+                const int t = fi - p.w0T;
+                x = W0[kmap_chain(t, kb, j) * MLP_IN + i];
+            }
+            v[j] = x;
+        }
+        frags[e] = v;
+    }
+}
+
+// ---- input fragments (orientation: lane = sample) ------------------------------------------------
+__device__ __forceinline__ half_t input_elem(const MlpIO& io, int64_t b, int k) {
+    if (k < io.a_dim) return (half_t)__fmaf_rn(io.a[b * io.a_stride + k], io.a_mul, io.a_add);
+    k -= io.a_dim;
+    if (k < io.b_dim) return io.b[b * io.b_stride + io.b_off + k];
+    return (half_t)0.f;
+}
+
+__device__ __forceinline__ void load_input(const MlpIO& io, int64_t b, int kb, bool fast, f16x8 x[2]) {
+    if (fast) {
+        const f16x8* row = reinterpret_cast<const f16x8*>(io.b + b * io.b_stride);
+        x[0] = row[kb];
+        x[1] = row[2 + kb];
+    } else {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[t][j] = input_elem(io, b, kmap_natural(t, kb, j));
+    }
+}
+
+__device__ __forceinline__ void relu_pack(const f32x16& d, f16x8& lo, f16x8& hi) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        lo[j] = (half_t)fmaxf(d[j], 0.f);
+        hi[j] = (half_t)fmaxf(d[8 + j], 0.f);
+    }
+}
+
+// forward chain for one tile; keeps hidden activations (fp16 fragments, chained-k order)
+template <int NH>
+__device__ __forceinline__ f32x16 forward_tile(const f16x8* frags, const FragPlan& p, int lane, const f16x8 x[2],
+                                               f16x8 h1[4], f16x8 h2[4]) {
+    f32x16 z[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        z[mt] = zero16();
+#pragma unroll
+        for (int t = 0; t < 2; ++t) z[mt] = mfma(frags[(p.w0 + mt * 2 + t) * kWave + lane], x[t], z[mt]);
+        relu_pack(z[mt], h1[2 * mt], h1[2 * mt + 1]);
+    }
+    const f16x8* hl = h1;
+    if constexpr (NH == 1) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            z[mt] = zero16();
+#pragma unroll
+            for (int t = 0; t < 4; ++t) z[mt] = mfma(frags[(p.wh + mt * 4 + t) * kWave + lane], h1[t], z[mt]);
+            relu_pack(z[mt], h2[2 * mt], h2[2 * mt + 1]);
+        }
+        hl = h2;
+    }
+    f32x16 o = zero16();
+#pragma unroll
+    for (int t = 0; t < 4; ++t) o = mfma(frags[(p.wo + t) * kWave + lane], hl[t], o);
+    return o;
+}
+
+__device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + __expf(-v)); }
+
+// ------------------------------------------------------------------------------------------------
+template <int NH>
+__global__ __launch_bounds__(MLP_WAVES * kWave) void mlp_fwd_kernel(const half_t* __restrict__ W, MlpIO io, int64_t B,
+                                                                   int n_out, int out_act, half_t* __restrict__ out,
+                                                                   int64_t out_stride, int64_t n_tiles) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem_raw[];
+    f16x8* frags = reinterpret_cast<f16x8*>(smem_raw);
+    stage_weights<NH>(W, MLP_IN, frags, false);
+    __syncthreads();
+    const FragPlan p = make_plan(NH, false);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = lane & 31, kb = lane >> 5;
+    const bool fast = io.a_dim == 0 && io.b_off == 0 && io.b_dim == MLP_IN && (io.b_stride % 8) == 0;
+    for (int64_t tile = (int64_t)blockIdx.x * MLP_WAVES + wave; tile < n_tiles; tile += (int64_t)gridDim.x * MLP_WAVES) {
+        const int64_t b_raw = tile * 32 + n;
+        const int64_t b = b_raw < B ? b_raw : B - 1;
+        f16x8 x[2], h1[4], h2[4];
+        load_input(io, b, kb, fast, x);
+        f32x16 o = forward_tile<NH>(frags, p, lane, x, h1, h2);
+        if (b_raw < B) {
+            // rows held by this lane: r = 0..7 -> neurons (r&3) + 8*(r>>2) + 4*kb  (two runs of 4 consecutive)
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int m = acc_row(r, kb);
+                if (m < n_out) {
+                    float v = o[r];
+                    if (out_act == 1) v = sigmoidf_(v);
+                    out[b * out_stride + m] = (half_t)v;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward
+// ------------------------------------------------------------------------------------------------
+constexpr int TP = 40;   // transposed tile pitch in halfs (32 samples + 8 pad = 80 B: conflict-free b128 row reads)
+
+// write accumulator-layout values (lane = sample, regs = 16 rows of tile mt) transposed into T[neuron][sample]
+__device__ __forceinline__ void stage_T(half_t* T, int mt, int n, int kb, const f16x8& lo, const f16x8& hi) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        T[(32 * mt + acc_row(j, kb)) * TP + n] = lo[j];
+        T[(32 * mt + acc_row(8 + j, kb)) * TP + n] = hi[j];
+    }
+}
+__device__ __forceinline__ f16x8 read_T(const half_t* T, int row, int t, int kb) {
+    return *reinterpret_cast<const f16x8*>(T + row * TP + 16 * t + 8 * kb);
+}
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int NH>
+__global__ __launch_bounds__(MLP_WAVES * kWave) void mlp_bwd_kernel(
+    const half_t* __restrict__ W, MlpIO io, int64_t B, int n_out, int out_act, const half_t* __restrict__ dout,
+    int64_t dout_stride, float* __restrict__ dW, float* __restrict__ dA, half_t* __restrict__ dBsrc, int64_t n_tiles) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem_raw[];
+    const FragPlan p = make_plan(NH, true);
+    f16x8* frags = reinterpret_cast<f16x8*>(smem_raw);
+    half_t* tbase = reinterpret_cast<half_t*>(smem_raw + (size_t)p.total * kWave * sizeof(f16x8));
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    half_t* Zt = tbase + (size_t)wave * 2 * MLP_W * TP;     // dZ^T tile  [64][TP]
+    half_t* Ht = Zt + MLP_W * TP;                           // H^T  tile  [64][TP]
+    stage_weights<NH>(W, MLP_IN, frags, true);
+    __syncthreads();
+    const int n = lane & 31, kb = lane >> 5;
+    const bool fast = io.a_dim == 0 && io.b_off == 0 && io.b_dim == MLP_IN && (io.b_stride % 8) == 0;
+
+    // weight-gradient accumulators (D[o][i] tiles): Wo: 1x2, Wh: 2x2, W0: 2x1
+    f32x16 gWo[2], gWh[2][2], gW0[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { gWo[i] = zero16(); gW0[i] = zero16(); gWh[i][0] = zero16(); gWh[i][1] = zero16(); }
+
+    for (int64_t tile = (int64_t)blockIdx.x * MLP_WAVES + wave; tile < n_tiles; tile += (int64_t)gridDim.x * MLP_WAVES) {
+        const int64_t b_raw = tile * 32 + n;
+        const bool valid = b_raw < B;
+        const int64_t b = valid ? b_raw : B - 1;
+        f16x8 x[2], h1[4], h2[4];
+        load_input(io, b, kb, fast, x);
+        if (!valid) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { x[0][j] = (half_t)0.f; x[1][j] = (half_t)0.f; }
+        }
+        const f32x16 o = forward_tile<NH>(frags, p, lane, x, h1, h2);
+        // dZ_out (rows 0..15 live in regs 0..7)
+        f16x8 dzo;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int m = acc_row(r, kb);
+            float gv = 0.f;
+            if (valid && m < n_out) {
+                gv = (float)dout[b * dout_stride + m];
+                if (out_act == 1) { const float y = sigmoidf_(o[r]); gv *= y * (1.0f - y); }
+            }
+            dzo[r] = (half_t)gv;
+        }
+        const f16x8* hl = (NH == 1) ? h2 : h1;
+        // ---- dWo += dZo * Hl^T ----
+        f16x8 zero8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) zero8[j] = (half_t)0.f;
+        stage_T(Zt, 0, n, kb, dzo, zero8);
+        stage_T(Ht, 0, n, kb, hl[0], hl[1]);
+        stage_T(Ht, 1, n, kb, hl[2], hl[3]);
+        wave_lds_sync();
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const f16x8 a = read_T(Zt, n, t, kb);                       // rows = out neuron (lane&31)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) gWo[nt] = mfma(a, read_T(Ht, 32 * nt + n, t, kb), gWo[nt]);
+        }
+        wave_lds_sync();
+        // ---- dHl = Wo^T dZo ; dZl = dHl * relu'(Hl) ----
+        f16x8 dz[4];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            f32x16 d = mfma(frags[(p.woT + mt) * kWave + lane], dzo, zero16());
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                dz[2 * mt][j] = ((float)hl[2 * mt][j] > 0.f) ? (half_t)d[j] : (half_t)0.f;
+                dz[2 * mt + 1][j] = ((float)hl[2 * mt + 1][j] > 0.f) ? (half_t)d[8 + j] : (half_t)0.f;
+            }
+        }
+        if constexpr (NH == 1) {
+            // ---- dWh += dZ2 * H1^T ----
+            stage_T(Zt, 0, n, kb, dz[0], dz[1]);
+            stage_T(Zt, 1, n, kb, dz[2], dz[3]);
+            stage_T(Ht, 0, n, kb, h1[0], h1[1]);
+            stage_T(Ht, 1, n, kb, h1[2], h1[3]);
+            wave_lds_sync();
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    const f16x8 a = read_T(Zt, 32 * mt + n, t, kb);
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) gWh[mt][nt] = mfma(a, read_T(Ht, 32 * nt + n, t, kb), gWh[mt][nt]);
+                }
+            wave_lds_sync();
+            // ---- dH1 = Wh^T dZ2 ; dZ1 ----
+            f16x8 dz1[4];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                f32x16 d = zero16();
+#pragma unroll
+                for (int t = 0; t < 4; ++t) d = mfma(frags[(p.whT + mt * 4 + t) * kWave + lane], dz[t], d);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    dz1[2 * mt][j] = ((float)h1[2 * mt][j] > 0.f) ? (half_t)d[j] : (half_t)0.f;
+                    dz1[2 * mt + 1][j] = ((float)h1[2 * mt + 1][j] > 0.f) ? (half_t)d[8 + j] : (half_t)0.f;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) dz[i] = dz1[i];
+        }
+        // ---- dW0 += dZ1 * X^T  (X is in natural k order: write rows k directly) ----
+        stage_T(Zt, 0, n, kb, dz[0], dz[1]);
+        stage_T(Zt, 1, n, kb, dz[2], dz[3]);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) Ht[kmap_natural(t, kb, j) * TP + n] = x[t][j];
+        wave_lds_sync();
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const f16x8 bx = read_T(Ht, n, t, kb);                     // rows = input feature (lane&31)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) gW0[mt] = mfma(read_T(Zt, 32 * mt + n, t, kb), bx, gW0[mt]);
+        }
+        wave_lds_sync();
+        // ---- dX = W0^T dZ1 ----
+        if (dA || dBsrc) {
+            f32x16 d = zero16();
+#pragma unroll
+            for (int t = 0; t < 4; ++t) d = mfma(frags[(p.w0T + t) * kWave + lane], dz[t], d);
+            if (valid) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    int k = acc_row(r, kb);                              // input feature index
+                    if (k < io.a_dim) {
+                        if (dA) dA[b * io.a_dim + k] = d[r] * io.a_mul;
+                    } else if (k - io.a_dim < io.b_dim) {
+                        if (dBsrc) dBsrc[b * io.b_stride + io.b_off + (k - io.a_dim)] = (half_t)d[r];
+                    }
+                }
+            }
+        }
+    }
+    // ---- reduce weight gradients over the block's waves, then one atomic per parameter ----
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem_raw);         // reuse LDS: n_params floats
+    const int n_params = MLP_W * MLP_IN + (NH ? MLP_W * MLP_W : 0) + MLP_OUT * MLP_W;
+    for (int i = threadIdx.x; i < n_params; i += blockDim.x) red[i] = 0.f;
+    __syncthreads();
+    float* r0 = red;
+    float* rh = red + MLP_W * MLP_IN;
+    float* ro = rh + (NH ? MLP_W * MLP_W : 0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = acc_row(r, kb);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) atomicAdd(&r0[(32 * mt + row) * MLP_IN + n], gW0[mt][r]);
+        if constexpr (NH == 1) {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) atomicAdd(&rh[(32 * mt + row) * MLP_W + 32 * nt + n], gWh[mt][nt][r]);
+        }
+        if (row < MLP_OUT) {
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) atomicAdd(&ro[row * MLP_W + 32 * nt + n], gWo[nt][r]);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n_params; i += blockDim.x) {
+        const float v = red[i];
+        if (v != 0.f) atomicAdd(&dW[i], v);
+    }
+}
+
+__global__ void f32_to_f16_kernel(const float* __restrict__ src, half_t* __restrict__ dst, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        dst[i] = (half_t)src[i];
+}
+
+static size_t fwd_smem(int NH) { return (size_t)make_plan(NH, false).total * kWave * sizeof(f16x8); }
+static size_t bwd_smem(int NH) {
+    size_t frag = (size_t)make_plan(NH, true).total * kWave * sizeof(f16x8);
+    size_t tiles = (size_t)MLP_WAVES * 2 * MLP_W * TP * sizeof(half_t);
+    size_t red = (size_t)(MLP_W * MLP_IN + (NH ? MLP_W * MLP_W : 0) + MLP_OUT * MLP_W) * sizeof(float);
+    size_t s = frag + tiles;
+    return s > red ? s : red;
+}
+
+}  // namespace nsx
+
+using namespace nsx;
+
+extern "C" {
+
+int nsx_mlp_param_count(int n_hidden_mats) {
+    return MLP_W * MLP_IN + (n_hidden_mats ? MLP_W * MLP_W : 0) + MLP_OUT * MLP_W;
+}
+
+static int check_io(const char* who, int n_hidden_mats, int a_dim, int b_dim, int n_out, int out_act,
+                    const void* a, const void* b) {
+    NSX_REQUIRE(n_hidden_mats == 0 || n_hidden_mats == 1, "%s: n_hidden_mats must be 0 or 1 (got %d)", who, n_hidden_mats);
+    NSX_REQUIRE(a_dim >= 0 && b_dim >= 0 && a_dim + b_dim >= 1 && a_dim + b_dim <= MLP_IN,
+                "%s: input width %d+%d not in [1,%d]", who, a_dim, b_dim, MLP_IN);
+    NSX_REQUIRE(n_out >= 1 && n_out <= MLP_OUT, "%s: n_out=%d not in [1,%d]", who, n_out, MLP_OUT);
+    NSX_REQUIRE(out_act == 0 || out_act == 1, "%s: out_act must be 0 (None) or 1 (Sigmoid)", who);
+    NSX_REQUIRE((a_dim == 0 || a) && (b_dim == 0 || b), "%s: NULL input segment", who);
+    return NSX_OK;
+}
+
+int nsx_mlp_fwd(const nsx_half* weights, int n_hidden_mats, int64_t B,
+                const float* a, int64_t a_stride, int a_dim, float a_mul, float a_add,
+                const nsx_half* b, int64_t b_stride, int b_off, int b_dim,
+                int n_out, int out_act, nsx_half* out, int64_t out_stride, void* stream) {
+    NSX_REQUIRE(B >= 0, "nsx_mlp_fwd: negative batch");
+    if (B == 0) return NSX_OK;
+    NSX_REQUIRE(weights && out, "nsx_mlp_fwd: NULL argument");
+    if (int rc = check_io("nsx_mlp_fwd", n_hidden_mats, a_dim, b_dim, n_out, out_act, a, b)) return rc;
+    MlpIO io{a, a_stride, a_dim, a_mul, a_add, reinterpret_cast<const half_t*>(b), b_stride, b_off, b_dim};
+    const int64_t n_tiles = (B + 31) / 32;
+    int64_t blocks = (n_tiles + MLP_WAVES - 1) / MLP_WAVES;
+    const int64_t cap = (int64_t)num_cus() * 4;
+    if (blocks > cap) blocks = cap;
+    hipStream_t st = (hipStream_t)stream;
+    const half_t* W = reinterpret_cast<const half_t*>(weights);
+    half_t* o = reinterpret_cast<half_t*>(out);
+    if (n_hidden_mats == 0)
+        hipLaunchKernelGGL((mlp_fwd_kernel<0>), dim3((unsigned)blocks), dim3(MLP_WAVES * kWave), fwd_smem(0), st, W, io, B,
+                           n_out, out_act, o, out_stride, n_tiles);
+    else
+        hipLaunchKernelGGL((mlp_fwd_kernel<1>), dim3((unsigned)blocks), dim3(MLP_WAVES * kWave), fwd_smem(1), st, W, io, B,
+                           n_out, out_act, o, out_stride, n_tiles);
+    NSX_LAUNCH_CHECK("nsx_mlp_fwd launch");
+    return NSX_OK;
+}
+
+int nsx_mlp_bwd(const nsx_half* weights, int n_hidden_mats, int64_t B,
+                const float* a, int64_t a_stride, int a_dim, float a_mul, float a_add,
+                const nsx_half* b, int64_t b_stride, int b_off, int b_dim,
+                int n_out, int out_act, const nsx_half* dout, int64_t dout_stride,
+                float* dweights, float* da, nsx_half* db, void* stream) {
+    NSX_REQUIRE(B >= 0, "nsx_mlp_bwd: negative batch");
+    if (B == 0) return NSX_OK;
+    NSX_REQUIRE(weights && dout && dweights, "nsx_mlp_bwd: NULL argument");
+    if (int rc = check_io("nsx_mlp_bwd", n_hidden_mats, a_dim, b_dim, n_out, out_act, a, b)) return rc;
+    MlpIO io{a, a_stride, a_dim, a_mul, a_add, reinterpret_cast<const half_t*>(b), b_stride, b_off, b_dim};
+    const int64_t n_tiles = (B + 31) / 32;
+    int64_t blocks = (n_tiles + MLP_WAVES - 1) / MLP_WAVES;
+    const int64_t cap = (int64_t)num_cus() * 2;
+    if (blocks > cap) blocks = cap;
+    hipStream_t st = (hipStream_t)stream;
+    const half_t* W = reinterpret_cast<const half_t*>(weights);
+    if (n_hidden_mats == 0)
+        hipLaunchKernelGGL((mlp_bwd_kernel<0>), dim3((unsigned)blocks), dim3(MLP_WAVES * kWave), bwd_smem(0), st, W, io, B,
+                           n_out, out_act, reinterpret_cast<const half_t*>(dout), dout_stride, dweights, da,
+                           reinterpret_cast<half_t*>(db), n_tiles);
+    else
+        hipLaunchKernelGGL((mlp_bwd_kernel<1>), dim3((unsigned)blocks), dim3(MLP_WAVES * kWave), bwd_smem(1), st, W, io, B,
+                           n_out, out_act, reinterpret_cast<const half_t*>(dout), dout_stride, dweights, da,
+                           reinterpret_cast<half_t*>(db), n_tiles);
+    NSX_LAUNCH_CHECK("nsx_mlp_bwd launch");
+    return NSX_OK;
+}
+
+int nsx_f32_to_f16(const float* src, nsx_half* dst, int64_t n, void* stream) {
+    NSX_REQUIRE(n >= 0, "nsx_f32_to_f16: negative size");
+    if (n == 0) return NSX_OK;
+    NSX_REQUIRE(src && dst, "nsx_f32_to_f16: NULL argument");
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > num_cus() * 8) blocks = num_cus() * 8;
+    hipLaunchKernelGGL(f32_to_f16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src,
+                       reinterpret_cast<half_t*>(dst), n);
+    NSX_LAUNCH_CHECK("nsx_f32_to_f16 launch");
+    return NSX_OK;
+}
+
+}  // extern "C"

@@ -131,3 +131,68 @@ def hash_ensemble(x: torch.Tensor, tables_master: torch.Tensor, tables_f16: torc
     if window is not None:
         window = window.to(device=x.device, dtype=torch.float32).contiguous()
     return _HashEnsembleFn.apply(x, tables_master, tables_f16, code, code_index, window, H, geom)
+
+
+# ------------------------------------------------------------------------------------------------
+# fully fused MLPs (tcnn FullyFusedMLP equivalents)
+# ------------------------------------------------------------------------------------------------
+def mlp_param_count(n_hidden_mats: int) -> int:
+    return int(lib().nsx_mlp_param_count(n_hidden_mats))
+
+
+def _seg(t, width_dtype):
+    return t
+
+
+class _FusedMLPFn(torch.autograd.Function):
+    """out = MLP([a * a_mul + a_add (fp32 segment), b[:, b_off:b_off+b_dim] (fp16 segment)]); see include/nsx.h."""
+
+    @staticmethod
+    def forward(ctx, params, a, b, n_hidden_mats, a_mul, a_add, b_off, b_dim, n_out, out_act):
+        dev = params.device
+        w16 = torch.empty(params.numel(), dtype=torch.float16, device=dev)
+        check(lib().nsx_f32_to_f16(ptr(params.detach().contiguous(), torch.float32), ptr(w16), params.numel(), stream()),
+              "nsx_f32_to_f16")
+        a_c = a.detach().to(torch.float32).contiguous() if a is not None else None
+        b_c = b.detach().to(torch.float16).contiguous() if b is not None else None
+        B = a_c.shape[0] if a_c is not None else b_c.shape[0]
+        a_dim = a_c.shape[1] if a_c is not None else 0
+        out = torch.empty((B, n_out), dtype=torch.float16, device=dev)
+        check(lib().nsx_mlp_fwd(ptr(w16), n_hidden_mats, B,
+                                ptr(a_c), a_c.stride(0) if a_c is not None else 0, a_dim, a_mul, a_add,
+                                ptr(b_c), b_c.stride(0) if b_c is not None else 0, b_off, b_dim if b_c is not None else 0,
+                                n_out, out_act, ptr(out), out.stride(0), stream()), "nsx_mlp_fwd")
+        ctx.save_for_backward(w16, a_c, b_c)
+        ctx.cfg = (n_hidden_mats, a_mul, a_add, b_off, b_dim, n_out, out_act, a_dim)
+        ctx.b_shape = b.shape if b is not None else None
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        w16, a_c, b_c = ctx.saved_tensors
+        n_hidden_mats, a_mul, a_add, b_off, b_dim, n_out, out_act, a_dim = ctx.cfg
+        dev = w16.device
+        dout = dout.to(torch.float16).contiguous()
+        B = dout.shape[0]
+        dW = torch.zeros(w16.numel(), dtype=torch.float32, device=dev)
+        need_a = a_c is not None and ctx.needs_input_grad[1]
+        need_b = b_c is not None and ctx.needs_input_grad[2]
+        da = torch.empty((B, a_dim), dtype=torch.float32, device=dev) if need_a else None
+        db = torch.zeros(ctx.b_shape, dtype=torch.float16, device=dev) if need_b else None
+        check(lib().nsx_mlp_bwd(ptr(w16), n_hidden_mats, B,
+                                ptr(a_c), a_c.stride(0) if a_c is not None else 0, a_dim, a_mul, a_add,
+                                ptr(b_c), b_c.stride(0) if b_c is not None else 0, b_off, b_dim if b_c is not None else 0,
+                                n_out, out_act, ptr(dout), dout.stride(0), ptr(dW), ptr(da), ptr(db), stream()),
+              "nsx_mlp_bwd")
+        return dW, da, db, None, None, None, None, None, None, None
+
+
+def fused_mlp(params: torch.Tensor, n_hidden_mats: int, n_out: int, out_act: int = 0,
+              a: Optional[torch.Tensor] = None, a_mul: float = 1.0, a_add: float = 0.0,
+              b: Optional[torch.Tensor] = None, b_off: int = 0, b_dim: Optional[int] = None) -> torch.Tensor:
+    """tcnn FullyFusedMLP equivalent (width 64, 1 + n_hidden_mats hidden layers, no biases).
+    params: flat fp32 [W0 | Wh | Wo]; returns [B, n_out] fp16."""
+    if b is not None and b_dim is None:
+        b_dim = b.shape[1] - b_off
+    return _FusedMLPFn.apply(params, a, b, n_hidden_mats, float(a_mul), float(a_add), int(b_off),
+                             int(b_dim or 0), int(n_out), int(out_act))

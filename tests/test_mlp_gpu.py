@@ -1,0 +1,92 @@
+"""GPU parity: fused MFMA MLP kernels (mlp_base / mlp_head shapes) vs the numpy oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import mlp as omlp
+
+pytestmark = pytest.mark.gpu
+
+
+def _params(nh, seed, scale=1.0):
+    rng = np.random.default_rng(seed)
+    n = omlp.param_count(nh)
+    # asymmetric, transpose-detecting weights
+    p = (rng.standard_normal(n) * 0.25 * scale).astype(np.float32)
+    return p.astype(np.float16).astype(np.float32)
+
+
+@pytest.mark.parametrize("nh,in_dim,n_out,act", [(0, 32, 16, 0), (1, 32, 3, 1), (1, 18, 3, 1), (0, 7, 5, 0), (1, 32, 16, 0)])
+@pytest.mark.parametrize("B", [1, 31, 32, 33, 1000])
+def test_mlp_forward(nh, in_dim, n_out, act, B, cuda):
+    from nersemble_amd import functional as F
+    p = _params(nh, 10 * nh + in_dim)
+    rng = np.random.default_rng(B)
+    x = rng.standard_normal((B, in_dim)).astype(np.float16)
+    want = omlp.mlp_fwd(x, p, nh, n_out, act).astype(np.float32)
+    out = F.fused_mlp(torch.from_numpy(p).to(cuda), nh, n_out, act, b=torch.from_numpy(x).to(cuda))
+    got = out.float().cpu().numpy()
+    assert got.shape == (B, n_out)
+    # fp32 MFMA accumulation + fp16 rounding of hidden activations: a flipped rounding in a hidden unit moves
+    # an output by ~2^-11 * |w| -> a few fp16 ulps of the output scale
+    tol = 4 * 2.0 ** -10 * max(1.0, np.abs(want).max())
+    assert np.abs(got - want).max() <= tol, float(np.abs(got - want).max())
+
+
+def test_mlp_head_two_segment_input(cuda):
+    """mlp_head reads (dir+1)/2 (fp32) and 15 geo features out of mlp_base's [B,16] output (cols 1..15)."""
+    from nersemble_amd import functional as F
+    B = 517
+    p = _params(1, 5)
+    rng = np.random.default_rng(1)
+    dirs = rng.standard_normal((B, 3)).astype(np.float32)
+    dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    base = rng.standard_normal((B, 16)).astype(np.float16)
+    x = np.concatenate([((dirs + 1) / 2).astype(np.float16), base[:, 1:]], axis=1)
+    want = omlp.mlp_fwd(x, p, 1, 3, 1).astype(np.float32)
+    out = F.fused_mlp(torch.from_numpy(p).to(cuda), 1, 3, 1, a=torch.from_numpy(dirs).to(cuda), a_mul=0.5, a_add=0.5,
+                      b=torch.from_numpy(base).to(cuda), b_off=1, b_dim=15)
+    assert np.abs(out.float().cpu().numpy() - want).max() <= 4 * 2.0 ** -10
+
+
+@pytest.mark.parametrize("nh,in_dim,n_out,act", [(0, 32, 16, 0), (1, 18, 3, 1), (1, 32, 16, 0)])
+@pytest.mark.parametrize("B", [5, 64, 777])
+def test_mlp_backward(nh, in_dim, n_out, act, B, cuda):
+    from nersemble_amd import functional as F
+    p = _params(nh, 3 + nh)
+    rng = np.random.default_rng(B + 1)
+    x = rng.standard_normal((B, in_dim)).astype(np.float16)
+    dout = rng.standard_normal((B, n_out)).astype(np.float16)
+    dW_o, dx_o = omlp.mlp_bwd(x, p, nh, n_out, act, dout.astype(np.float64))
+    pt = torch.from_numpy(p).to(cuda).requires_grad_(True)
+    xt = torch.from_numpy(x).to(cuda).requires_grad_(True)
+    out = F.fused_mlp(pt, nh, n_out, act, b=xt)
+    out.backward(torch.from_numpy(dout).to(cuda))
+    dW = pt.grad.cpu().numpy()
+    dx = xt.grad.float().cpu().numpy()
+    # HIP rounds dZ to fp16 between layers (like tcnn); oracle keeps float64 -> ~1e-3 relative to the scale
+    assert np.abs(dW - dW_o).max() <= 3e-3 * np.abs(dW_o).max() + 1e-6, float(np.abs(dW - dW_o).max() / np.abs(dW_o).max())
+    assert np.abs(dx - dx_o[:, :in_dim]).max() <= 3e-3 * np.abs(dx_o).max() + 1e-6
+
+
+def test_mlp_head_backward_segments(cuda):
+    from nersemble_amd import functional as F
+    B = 300
+    p = _params(1, 9)
+    rng = np.random.default_rng(2)
+    dirs = rng.standard_normal((B, 3)).astype(np.float32)
+    base = rng.standard_normal((B, 16)).astype(np.float16)
+    dout = rng.standard_normal((B, 3)).astype(np.float16)
+    x = np.concatenate([((dirs + 1) / 2).astype(np.float16), base[:, 1:]], axis=1)
+    dW_o, dx_o = omlp.mlp_bwd(x, p, 1, 3, 1, dout.astype(np.float64))
+    pt = torch.from_numpy(p).to(cuda).requires_grad_(True)
+    bt = torch.from_numpy(base).to(cuda).requires_grad_(True)
+    dt = torch.from_numpy(dirs).to(cuda).requires_grad_(True)
+    out = F.fused_mlp(pt, 1, 3, 1, a=dt, a_mul=0.5, a_add=0.5, b=bt, b_off=1, b_dim=15)
+    out.backward(torch.from_numpy(dout).to(cuda))
+    sc = np.abs(dx_o).max()
+    db = bt.grad.float().cpu().numpy()
+    assert np.all(db[:, 0] == 0)
+    assert np.abs(db[:, 1:] - dx_o[:, 3:18]).max() <= 3e-3 * sc
+    assert np.abs(dt.grad.cpu().numpy() - 0.5 * dx_o[:, :3]).max() <= 3e-3 * sc
+    assert np.abs(pt.grad.cpu().numpy() - dW_o).max() <= 3e-3 * np.abs(dW_o).max()
