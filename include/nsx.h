@@ -147,6 +147,50 @@ int nsx_mlp_bwd(const nsx_half* weights, int n_hidden_mats, int64_t B,
                 float* dweights, float* da, nsx_half* db, void* stream);
 int nsx_f32_to_f16(const float* src, nsx_half* dst, int64_t n, void* stream);
 
+/* ---- occupancy-grid ray marching (nerfacc 0.5.2 traverse_grids equivalent) -----------------------------
+ * Replaces the native part of OccGridEstimator.sampling called at nersemble_volumetric_sampler.py:95-108:
+ * ray/AABB slab test + DDA through ONE res^3 boolean grid level (grid_levels=1, train_nersemble.py:100) +
+ * fixed-step lattice anchored at the per-ray near plane; a sample [t, t+step] is emitted iff its midpoint
+ * lies in an occupied voxel.  aabb is a HOST pointer to 6 floats (min xyz, max xyz); binary is a device
+ * uint8/bool [res][res][res]; near is a device [R] (near plane, already jittered when stratified).
+ * Two passes like nerfacc: nsx_march_count -> nsx_pack_info (device scan; caller reads *total back) ->
+ * nsx_march_fill.  Counts, ray indices, cell ids and t values are bit-exact against the oracle. */
+int nsx_march_count(const float* rays_o, const float* rays_d, int64_t R, const float* aabb_host,
+                    const uint8_t* binary, int res, const float* near, float far_plane, float step,
+                    int64_t* counts, void* stream);
+int nsx_pack_info(const int64_t* counts, int64_t R, int64_t* packed_info /* [R][2] start,count */,
+                  int64_t* total /* device scalar */, void* stream);
+int nsx_march_fill(const float* rays_o, const float* rays_d, int64_t R, const float* aabb_host,
+                   const uint8_t* binary, int res, const float* near, float far_plane, float step,
+                   const int64_t* packed_info, float* t_starts, float* t_ends, int64_t* ray_indices,
+                   int32_t* cells /* may be NULL */, void* stream);
+/* counts[r] += #samples with ray index r (nerfacc.pack_info, nersemble_instant_ngp.py:325); caller zeroes counts. */
+int nsx_ray_histogram(const int64_t* ray_indices, int64_t S, int64_t R, int64_t* counts_zeroed, void* stream);
+
+/* ---- per-ray scans on packed samples ----------------------------------------------------------------------
+ * nerfacc.render_weight_from_density (nersemble_instant_ngp.py:326-331) and render_visibility_from_density
+ * (inside sampling): T_i = exp(-sum_{j<i} sigma_j dt_j), alpha_i = 1-exp(-sigma_i dt_i), w_i = T_i alpha_i,
+ * visibility = T >= early_stop_eps && (alpha_thre <= 0 || alpha >= alpha_thre).  Any output may be NULL. */
+int nsx_render_weights_fwd(const float* t_starts, const float* t_ends, const float* sigmas,
+                           const int64_t* packed_info, int64_t R, float* weights, float* trans, float* alphas,
+                           uint8_t* visibility, float early_stop_eps, float alpha_thre, void* stream);
+int nsx_render_weights_bwd(const float* t_starts, const float* t_ends, const float* sigmas,
+                           const int64_t* packed_info, int64_t R, const float* grad_weights, float* grad_sigmas,
+                           void* stream);
+/* nerfacc.accumulate_along_rays (renderers at nersemble_instant_ngp.py:334-343, nersemble_deformation_renderer.py:22-25):
+ * out[r][c] = sum_i w_i * values[i][c]; values NULL => C = 1, out = sum_i w_i.  C in {1, 3}. */
+int nsx_accumulate_fwd(const float* weights, const float* values, int C, const int64_t* packed_info, int64_t R,
+                       float* out, void* stream);
+int nsx_accumulate_bwd(const float* weights, const float* values, int C, const int64_t* ray_indices, int64_t S,
+                       const float* grad_out, float* grad_weights /* may be NULL */,
+                       float* grad_values /* may be NULL */, void* stream);
+/* torch_efficient_distloss.flatten_eff_distloss (models/base.py:245-247): per-ray loss terms
+ * ray_loss[r] = (sum_i 1/3 interval_i w_i^2 + 2 w_i (m_i Wpre_i - WMpre_i)) / n_rays for rays r < max_ray (0 otherwise,
+ * base.py:235) and grad_weights = grad_scale * dloss/dw.  ray_loss / grad_weights may be NULL. */
+int nsx_distloss(const float* weights, const float* midpoints, const float* intervals, const int64_t* packed_info,
+                 int64_t R, int64_t max_ray, int64_t n_rays, float grad_scale, float* ray_loss, float* grad_weights,
+                 void* stream);
+
 /* Debug/parity helper: the 8 level-local entry indices per (sample, level), uint32 [B][L][8].
  * Integer outputs are held bit-exact to the oracle. */
 int nsx_hash_indices(const float* x, int64_t B, const nsx_grid_geom* g, uint32_t* idx, void* stream);

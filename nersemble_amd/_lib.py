@@ -56,13 +56,73 @@ SIGNATURES = {
     "nsx_mlp_bwd": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_int64, c_int, c_float, c_float, c_void_p, c_int64,
                             c_int, c_int, c_int, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "nsx_f32_to_f16": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "nsx_march_count": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_void_p, c_float, c_float,
+                                c_void_p, c_void_p]),
+    "nsx_pack_info": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
+    "nsx_march_fill": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_void_p, c_float, c_float,
+                               c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "nsx_ray_histogram": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p]),
+    "nsx_render_weights_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p,
+                                       c_void_p, c_float, c_float, c_void_p]),
+    "nsx_render_weights_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
+    "nsx_accumulate_fwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int64, c_void_p, c_void_p]),
+    "nsx_accumulate_bwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p,
+                                   c_void_p]),
+    "nsx_distloss": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_float, c_void_p,
+                             c_void_p, c_void_p]),
     "nsx_hash_indices": (c_int, [c_void_p, c_int64, _GEOM_P, c_void_p, c_void_p]),
 }
 
 _lib = None
 
 
-def lib() -> C.CDLL:
+class KernelProfiler:
+    """Optional HIP-event timing of every native call (used by bench.py for the live roofline numbers).
+    Events are recorded on torch's current stream -- the stream the kernels are enqueued on."""
+
+    def __init__(self):
+        self.enabled = False
+        self.records = []          # (name, start_event, end_event, int_args)
+
+    def reset(self):
+        self.records = []
+
+    def summary(self):
+        """name -> dict(calls, total_ms, avg_ms, samples); call after torch.cuda.synchronize()."""
+        out = {}
+        for name, s, e, ints in self.records:
+            d = out.setdefault(name, {"calls": 0, "total_ms": 0.0, "units": 0})
+            d["calls"] += 1
+            d["total_ms"] += s.elapsed_time(e)
+            d["units"] += ints[0] if ints else 0
+        for d in out.values():
+            d["avg_ms"] = d["total_ms"] / max(d["calls"], 1)
+        return out
+
+
+profiler = KernelProfiler()
+
+
+class _LibProxy:
+    def __init__(self, handle):
+        self._h = handle
+
+    def __getattr__(self, name):
+        fn = getattr(self._h, name)
+        if not profiler.enabled or not name.startswith("nsx_"):
+            return fn
+
+        def timed(*args):
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            rc = fn(*args)
+            e.record()
+            profiler.records.append((name, s, e, [a for a in args if isinstance(a, int)]))
+            return rc
+        return timed
+
+
+def lib():
     """Loads libnsx.so.  No fallback: a missing library is an error (build with __graft_entry__.build())."""
     global _lib
     if _lib is None:
@@ -75,7 +135,7 @@ def lib() -> C.CDLL:
             fn = getattr(handle, name)
             fn.restype = res
             fn.argtypes = args
-        _lib = handle
+        _lib = _LibProxy(handle)
     return _lib
 
 

@@ -1,0 +1,254 @@
+// march.hip -- occupancy-grid ray marching (nerfacc traverse_grids equivalent) for gfx950.
+//
+// Replaces OccGridEstimator.sampling's native part as called from the reference sampler
+// (src/nersemble/nerfstudio/model_components/nersemble_volumetric_sampler.py:95-108): ray/AABB slab test,
+// 3-D DDA through the res^3 boolean grid, fixed-step lattice anchored at the (jittered) near plane; a sample
+// [t, t+step] is emitted iff its midpoint lies in an occupied voxel.  Two passes (count -> pack -> fill), as
+// nerfacc does, with the single host read-back of the total between them.
+//
+// Integer outputs (per-ray counts, ray indices, cell ids) AND the t values are bit-exact against the CPU
+// oracle: everything is plain fp32 with contraction disabled (no fused multiply-add), IEEE division.
+//
+// Cost model: <= ~700 lattice steps + <= 3*res voxel steps per ray, 4096 rays -> ~0.1 ms; the hash gather is
+// 20-100x larger, so this stays one lane per ray (64-lane blocks spread over 64 CUs) in round 1.
+#include "nsx_common.h"
+#pragma clang fp contract(off)
+
+namespace nsx {
+
+struct Aabb { float v[6]; };
+
+__device__ __forceinline__ bool ray_aabb(const float o[3], const float d[3], const Aabb& bb, float& tmin_o,
+                                         float& tmax_o) {
+    const float ix = 1.0f / d[0], iy = 1.0f / d[1], iz = 1.0f / d[2];
+    float tmin, tmax, tmin_t, tmax_t;
+    if (ix >= 0) { tmin = (bb.v[0] - o[0]) * ix; tmax = (bb.v[3] - o[0]) * ix; }
+    else         { tmin = (bb.v[3] - o[0]) * ix; tmax = (bb.v[0] - o[0]) * ix; }
+    if (iy >= 0) { tmin_t = (bb.v[1] - o[1]) * iy; tmax_t = (bb.v[4] - o[1]) * iy; }
+    else         { tmin_t = (bb.v[4] - o[1]) * iy; tmax_t = (bb.v[1] - o[1]) * iy; }
+    if (tmin > tmax_t || tmin_t > tmax) return false;
+    if (tmin_t > tmin) tmin = tmin_t;
+    if (tmax_t < tmax) tmax = tmax_t;
+    if (iz >= 0) { tmin_t = (bb.v[2] - o[2]) * iz; tmax_t = (bb.v[5] - o[2]) * iz; }
+    else         { tmin_t = (bb.v[5] - o[2]) * iz; tmax_t = (bb.v[2] - o[2]) * iz; }
+    if (tmin > tmax_t || tmin_t > tmax) return false;
+    if (tmin_t > tmin) tmin = tmin_t;
+    if (tmax_t < tmax) tmax = tmax_t;
+    if (tmax <= 0) return false;
+    tmin_o = tmin; tmax_o = tmax;
+    return true;
+}
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+template <bool FILL>
+__device__ __forceinline__ int64_t march_ray(const float o[3], const float d[3], const Aabb& bb,
+                                             const uint8_t* __restrict__ binary, int res, float near_plane,
+                                             float far_plane, float step, float* __restrict__ t0,
+                                             float* __restrict__ t1, int32_t* __restrict__ cells) {
+    const float eps = 1e-6f;
+    float tmin, tmax;
+    if (!ray_aabb(o, d, bb, tmin, tmax)) return 0;
+    const float this_tmin = fmaxf(tmin, near_plane);
+    const float this_tmax = fminf(tmax, far_plane);
+    if (this_tmin >= this_tmax) return 0;
+    float t_last = near_plane;
+    int64_t n = 0;
+    for (;;) {
+        if (t_last + step * 0.5f >= this_tmin) break;
+        t_last += step;
+    }
+    float inv[3], voxel[3], tdist[3], delta[3];
+    int cur[3], fin[3], stepi[3], over[3];
+    const float ts = this_tmin + eps, te = this_tmax - eps;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        inv[a] = 1.0f / d[a];
+        voxel[a] = (bb.v[3 + a] - bb.v[a]) / (float)res;
+        const float rs = o[a] + d[a] * ts;
+        const float re = o[a] + d[a] * te;
+        cur[a] = clampi((int)(((rs - bb.v[a]) / (bb.v[3 + a] - bb.v[a])) * (float)res), 0, res - 1);
+        fin[a] = clampi((int)(((re - bb.v[a]) / (bb.v[3 + a] - bb.v[a])) * (float)res), 0, res - 1);
+        const int idelta = d[a] > 0 ? 1 : 0;
+        const float start = (float)(cur[a] + idelta);
+        const float tmx = ((bb.v[a] + ((start * voxel[a]) - rs)) * inv[a]) + this_tmin;
+        tdist[a] = (d[a] == 0.0f) ? this_tmax : tmx;
+        const float sf = (d[a] == 0.0f) ? 0.0f : (d[a] > 0.0f ? 1.0f : -1.0f);
+        stepi[a] = (int)sf;
+        const float dtmp = voxel[a] * inv[a] * sf;
+        delta[a] = (d[a] == 0.0f) ? this_tmax : dtmp;
+        over[a] = fin[a] + stepi[a];
+    }
+    for (;;) {
+        float t_trav = fminf(tdist[0], fminf(tdist[1], tdist[2]));
+        t_trav = fminf(t_trav, this_tmax);
+        const int32_t cell = (cur[0] * res + cur[1]) * res + cur[2];
+        if (!binary[cell]) {
+            for (;;) {
+                if (t_last + step * 0.5f >= t_trav) break;
+                t_last += step;
+            }
+        } else {
+            for (;;) {
+                if (t_last + step * 0.5f >= t_trav) break;
+                const float t_next = t_last + step;
+                if (FILL) {
+                    t0[n] = t_last; t1[n] = t_next;
+                    if (cells) cells[n] = cell;
+                }
+                n++;
+                t_last = t_next;
+                if (t_next >= t_trav) break;
+            }
+        }
+        if (tdist[0] < tdist[1] && tdist[0] < tdist[2]) {
+            cur[0] += stepi[0]; tdist[0] += delta[0];
+            if (cur[0] == over[0]) break;
+        } else if (tdist[1] < tdist[2]) {
+            cur[1] += stepi[1]; tdist[1] += delta[1];
+            if (cur[1] == over[1]) break;
+        } else {
+            cur[2] += stepi[2]; tdist[2] += delta[2];
+            if (cur[2] == over[2]) break;
+        }
+    }
+    return n;
+}
+
+__global__ __launch_bounds__(64) void march_count_kernel(const float* __restrict__ rays_o,
+                                                         const float* __restrict__ rays_d, int64_t R, Aabb bb,
+                                                         const uint8_t* __restrict__ binary, int res,
+                                                         const float* __restrict__ near, float far_plane, float step,
+                                                         int64_t* __restrict__ counts) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    const float o[3] = {rays_o[3 * r], rays_o[3 * r + 1], rays_o[3 * r + 2]};
+    const float d[3] = {rays_d[3 * r], rays_d[3 * r + 1], rays_d[3 * r + 2]};
+    counts[r] = march_ray<false>(o, d, bb, binary, res, near[r], far_plane, step, nullptr, nullptr, nullptr);
+}
+
+__global__ __launch_bounds__(64) void march_fill_kernel(const float* __restrict__ rays_o,
+                                                        const float* __restrict__ rays_d, int64_t R, Aabb bb,
+                                                        const uint8_t* __restrict__ binary, int res,
+                                                        const float* __restrict__ near, float far_plane, float step,
+                                                        const int64_t* __restrict__ packed, float* __restrict__ t0,
+                                                        float* __restrict__ t1, int64_t* __restrict__ ray_idx,
+                                                        int32_t* __restrict__ cells) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    const int64_t s = packed[2 * r], cnt = packed[2 * r + 1];
+    if (cnt == 0) return;
+    const float o[3] = {rays_o[3 * r], rays_o[3 * r + 1], rays_o[3 * r + 2]};
+    const float d[3] = {rays_d[3 * r], rays_d[3 * r + 1], rays_d[3 * r + 2]};
+    const int64_t n = march_ray<true>(o, d, bb, binary, res, near[r], far_plane, step, t0 + s, t1 + s,
+                                      cells ? cells + s : nullptr);
+    for (int64_t i = 0; i < n; ++i) ray_idx[s + i] = r;
+}
+
+// packed_info[r] = (exclusive prefix of counts, counts[r]); total written to total[0].  Single block.
+__global__ __launch_bounds__(1024) void pack_info_kernel(const int64_t* __restrict__ counts, int64_t R,
+                                                         int64_t* __restrict__ packed, int64_t* __restrict__ total) {
+    __shared__ int64_t wsum[16];
+    __shared__ int64_t carry_s;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (int64_t base = 0; base < R; base += blockDim.x) {
+        const int64_t i = base + threadIdx.x;
+        const int64_t c = i < R ? counts[i] : 0;
+        int64_t v = c;
+#pragma unroll
+        for (int dlt = 1; dlt < 64; dlt <<= 1) {
+            const int64_t t = __shfl_up(v, dlt);
+            if (lane >= dlt) v += t;
+        }
+        if (lane == 63) wsum[wave] = v;
+        __syncthreads();
+        int64_t woff = 0;
+        for (int w = 0; w < wave; ++w) woff += wsum[w];
+        const int64_t carry = carry_s;
+        if (i < R) { packed[2 * i] = carry + woff + v - c; packed[2 * i + 1] = c; }
+        __syncthreads();
+        if (threadIdx.x == blockDim.x - 1) carry_s = carry + woff + v;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) total[0] = carry_s;
+}
+
+// counts from sorted ray indices (nerfacc.pack_info): histogram with one atomic per sample
+__global__ void ray_hist_kernel(const int64_t* __restrict__ ray_idx, int64_t S, int64_t R,
+                                unsigned long long* __restrict__ counts) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < S; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = ray_idx[i];
+        if (r >= 0 && r < R) atomicAdd(&counts[r], 1ull);
+    }
+}
+
+}  // namespace nsx
+
+using namespace nsx;
+
+extern "C" {
+
+static int check_march(const char* who, const float* rays_o, const float* rays_d, const float* aabb,
+                       const uint8_t* binary, int res, const float* near, float step) {
+    NSX_REQUIRE(rays_o && rays_d && aabb && binary && near, "%s: NULL argument", who);
+    NSX_REQUIRE(res >= 1 && res <= 1024, "%s: resolution %d out of range", who, res);
+    NSX_REQUIRE(step > 0.0f, "%s: render_step_size must be > 0", who);
+    return NSX_OK;
+}
+
+int nsx_march_count(const float* rays_o, const float* rays_d, int64_t R, const float* aabb_host,
+                    const uint8_t* binary, int res, const float* near, float far_plane, float step,
+                    int64_t* counts, void* stream) {
+    NSX_REQUIRE(R >= 0, "nsx_march_count: negative ray count");
+    if (R == 0) return NSX_OK;
+    if (int rc = check_march("nsx_march_count", rays_o, rays_d, aabb_host, binary, res, near, step)) return rc;
+    NSX_REQUIRE(counts, "nsx_march_count: NULL counts");
+    Aabb bb;
+    for (int i = 0; i < 6; ++i) bb.v[i] = aabb_host[i];
+    hipLaunchKernelGGL(march_count_kernel, dim3((unsigned)((R + 63) / 64)), dim3(64), 0, (hipStream_t)stream, rays_o,
+                       rays_d, R, bb, binary, res, near, far_plane, step, counts);
+    NSX_LAUNCH_CHECK("nsx_march_count launch");
+    return NSX_OK;
+}
+
+int nsx_pack_info(const int64_t* counts, int64_t R, int64_t* packed_info, int64_t* total, void* stream) {
+    NSX_REQUIRE(R >= 0, "nsx_pack_info: negative ray count");
+    NSX_REQUIRE(total, "nsx_pack_info: NULL total");
+    NSX_REQUIRE(R == 0 || (counts && packed_info), "nsx_pack_info: NULL argument");
+    hipLaunchKernelGGL(pack_info_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, counts, R, packed_info, total);
+    NSX_LAUNCH_CHECK("nsx_pack_info launch");
+    return NSX_OK;
+}
+
+int nsx_march_fill(const float* rays_o, const float* rays_d, int64_t R, const float* aabb_host,
+                   const uint8_t* binary, int res, const float* near, float far_plane, float step,
+                   const int64_t* packed_info, float* t_starts, float* t_ends, int64_t* ray_indices,
+                   int32_t* cells, void* stream) {
+    NSX_REQUIRE(R >= 0, "nsx_march_fill: negative ray count");
+    if (R == 0) return NSX_OK;
+    if (int rc = check_march("nsx_march_fill", rays_o, rays_d, aabb_host, binary, res, near, step)) return rc;
+    NSX_REQUIRE(packed_info && t_starts && t_ends && ray_indices, "nsx_march_fill: NULL argument");
+    Aabb bb;
+    for (int i = 0; i < 6; ++i) bb.v[i] = aabb_host[i];
+    hipLaunchKernelGGL(march_fill_kernel, dim3((unsigned)((R + 63) / 64)), dim3(64), 0, (hipStream_t)stream, rays_o,
+                       rays_d, R, bb, binary, res, near, far_plane, step, packed_info, t_starts, t_ends, ray_indices,
+                       cells);
+    NSX_LAUNCH_CHECK("nsx_march_fill launch");
+    return NSX_OK;
+}
+
+int nsx_ray_histogram(const int64_t* ray_indices, int64_t S, int64_t R, int64_t* counts_zeroed, void* stream) {
+    NSX_REQUIRE(S >= 0 && R >= 0, "nsx_ray_histogram: negative size");
+    if (S == 0) return NSX_OK;
+    NSX_REQUIRE(ray_indices && counts_zeroed, "nsx_ray_histogram: NULL argument");
+    int64_t blocks = (S + 255) / 256;
+    if (blocks > num_cus() * 8) blocks = num_cus() * 8;
+    hipLaunchKernelGGL(ray_hist_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, ray_indices, S, R,
+                       reinterpret_cast<unsigned long long*>(counts_zeroed));
+    NSX_LAUNCH_CHECK("nsx_ray_histogram launch");
+    return NSX_OK;
+}
+
+}  // extern "C"

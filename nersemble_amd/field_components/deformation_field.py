@@ -1,0 +1,131 @@
+"""SE(3) deformation field -- mirror of the reference's field_components/deformation_field.py:15-166.
+
+``SE3WarpingField``: windowed positional encoding (45) + warp code -> 6x128 MLP with a skip into layer 4
+(nerfstudio ``MLP`` semantics) -> two linear heads (rotation r, translation v) -> screw axis
+[v, r] -> se3_exp_map -> homogeneous transform of the NORMALISED position, NaN fallback.
+``SE3DeformationField.compute_offsets`` returns ``warped - normalised`` (deformation_field.py:148-166).
+Parameter names follow the reference's state dict (``se3_field.mlp_stem.layers.{i}.weight`` ...).
+"""
+from dataclasses import dataclass
+from typing import Optional, Tuple
+
+import torch
+from torch import nn
+
+from ..rays import RaySamples, SceneBox
+from ..util.chunker import chunked
+from ..util.se3 import se3_exp_map
+from .windowed_nerf_encoding import WindowedNeRFEncoding
+
+
+@dataclass
+class SE3DeformationFieldConfig:
+    n_freq_pos = 7
+    warp_code_dim: int = 8
+    mlp_num_layers: int = 6
+    mlp_layer_width: int = 128
+    skip_connections: Tuple[int] = (4,)
+
+
+class MLP(nn.Module):
+    """nerfstudio 0.3.1 ``field_components.MLP``: ``num_layers`` Linear layers, layer i in ``skip_connections``
+    takes cat([input, x]); activation after all but the last layer; ``out_activation`` after the last."""
+
+    def __init__(self, in_dim, num_layers, layer_width, out_dim=None, skip_connections=None,
+                 activation=nn.ReLU(), out_activation=None):
+        super().__init__()
+        self.in_dim = in_dim
+        self.out_dim = out_dim if out_dim is not None else layer_width
+        self.num_layers, self.layer_width = num_layers, layer_width
+        self._skip = set(skip_connections) if skip_connections else set()
+        self.activation, self.out_activation = activation, out_activation
+        layers = []
+        if num_layers == 1:
+            layers.append(nn.Linear(in_dim, self.out_dim))
+        else:
+            for i in range(num_layers - 1):
+                if i == 0:
+                    assert i not in self._skip, "Skip connection at layer 0 doesn't make sense."
+                    layers.append(nn.Linear(in_dim, layer_width))
+                elif i in self._skip:
+                    layers.append(nn.Linear(layer_width + in_dim, layer_width))
+                else:
+                    layers.append(nn.Linear(layer_width, layer_width))
+            layers.append(nn.Linear(layer_width, self.out_dim))
+        self.layers = nn.ModuleList(layers)
+
+    def forward(self, in_tensor):
+        x = in_tensor
+        for i, layer in enumerate(self.layers):
+            if i in self._skip:
+                x = torch.cat([in_tensor, x], -1)
+            x = layer(x)
+            if self.activation is not None and i < len(self.layers) - 1:
+                x = self.activation(x)
+        if self.out_activation is not None:
+            x = self.out_activation(x)
+        return x
+
+
+class SE3WarpingField(nn.Module):
+    def __init__(self, config: SE3DeformationFieldConfig) -> None:
+        super().__init__()
+        self.position_encoding = WindowedNeRFEncoding(in_dim=3, num_frequencies=config.n_freq_pos, min_freq_exp=0.0,
+                                                      max_freq_exp=config.n_freq_pos - 1, include_input=True)
+        in_dim = self.position_encoding.get_out_dim() + config.warp_code_dim
+        self.mlp_stem = MLP(in_dim=in_dim, out_dim=config.mlp_layer_width, num_layers=config.mlp_num_layers,
+                            layer_width=config.mlp_layer_width, skip_connections=config.skip_connections,
+                            out_activation=nn.ReLU())
+        self.mlp_r = MLP(in_dim=config.mlp_layer_width, out_dim=3, num_layers=1, layer_width=config.mlp_layer_width)
+        self.mlp_v = MLP(in_dim=config.mlp_layer_width, out_dim=3, num_layers=1, layer_width=config.mlp_layer_width)
+        # start close to the identity transformation (deformation_field.py:71-75)
+        for head in (self.mlp_r, self.mlp_v):
+            nn.init.uniform_(head.layers[-1].weight, a=-1e-5, b=1e-5)
+            nn.init.zeros_(head.layers[-1].bias)
+
+    def get_transform(self, positions, warp_code, windows_param=None):
+        encoded_xyz = self.position_encoding(positions, windows_param=windows_param)
+        feat = self.mlp_stem(torch.cat([encoded_xyz, warp_code], dim=-1))
+        r = self.mlp_r(feat).reshape(-1, 3)
+        v = self.mlp_v(feat).reshape(-1, 3)
+        screw_axis = torch.concat([v, r], dim=-1).to(positions.dtype)
+        return se3_exp_map(screw_axis).permute(0, 2, 1)
+
+    def apply_transform(self, positions, transforms):
+        p = positions.reshape(-1, 3)
+        ph = torch.concat([p, torch.ones_like(p[..., :1])], dim=-1)
+        wh = (transforms @ ph.unsqueeze(-1)).squeeze(-1)
+        warped = (wh[..., :3] / wh[..., -1:]).to(positions.dtype)
+        warped = torch.where(warped.isnan(), p, warped)          # NaN deformation -> keep the original point
+        return warped.reshape(*positions.shape[: positions.ndim - 1], 3)
+
+    def forward(self, positions, warp_code=None, windows_param=None):
+        if warp_code is None:
+            return None
+        return self.apply_transform(positions, self.get_transform(positions, warp_code, windows_param))
+
+
+class SE3DeformationField(nn.Module):
+    def __init__(self, aabb: torch.Tensor, deformation_field_config: SE3DeformationFieldConfig,
+                 max_n_samples_per_batch: int = -1):
+        super().__init__()
+        self.aabb = nn.Parameter(aabb, requires_grad=False)
+        self.se3_field = SE3WarpingField(deformation_field_config)
+        self.max_n_samples_per_batch = max_n_samples_per_batch
+
+    def forward(self, ray_samples: RaySamples, warp_code: Optional[torch.Tensor] = None,
+                windows_param: Optional[float] = None) -> RaySamples:
+        assert ray_samples.frustums.offsets is None or (
+                ray_samples.frustums.offsets == 0).all(), "ray samples have already been warped"
+        positions = ray_samples.frustums.get_positions()
+        ray_samples.frustums.set_offsets(self.compute_offsets(positions, warp_code, windows_param))
+        return ray_samples
+
+    def compute_offsets(self, positions, warp_code=None, windows_param=None):
+        max_chunk = len(positions) if self.max_n_samples_per_batch == -1 else self.max_n_samples_per_batch
+        offsets = []
+        for pos_c, code_c in chunked(max(max_chunk, 1), positions, warp_code):
+            pos_n = SceneBox.get_normalized_positions(pos_c, self.aabb)
+            warped = self.se3_field(pos_n, warp_code=code_c, windows_param=windows_param)
+            offsets.append(warped - pos_n)
+        return torch.cat(offsets, dim=0) if offsets else positions.new_zeros((0, 3))

@@ -1,0 +1,153 @@
+"""NeRSembleNeRFactoField -- host-side mirror of the reference's fields/nersemble_nerfacto_field.py:30-402 for
+the configuration NeRSemble trains (hash ensemble on, Identity direction encoding, no appearance / transient /
+semantic / normal heads -- those are dead code in the reference's configs).
+
+Same public surface: ``get_density(ray_samples, window_hash_encodings) -> (density [S,1] fp32, embedding [S,15])``,
+``get_outputs(ray_samples, density_embedding) -> {FieldHeadNames.RGB: [S,3] fp32}``, ``forward``, ``density_fn``;
+same state-dict names (``hash_ensemble.hash_encodings.{c}.params``, ``mlp_base.params``, ``mlp_head.params``,
+``aabb`` ...).  Compute is three native kernels: fused HashEnsemble, mlp_base, mlp_head (which reads the shifted
+directions and the 15 geometry features in place -- no torch.cat, no Identity-encoding launch).
+"""
+import enum
+from typing import Dict, Optional, Tuple
+
+import torch
+from torch import nn, Tensor
+
+from .. import functional as F
+from .. import tcnn
+from ..field_components.hash_ensemble import HashEnsemble, HashEnsembleConfig
+from ..rays import Frustums, RaySamples, SceneBox
+from ..util.chunker import chunked
+
+
+class FieldHeadNames(enum.Enum):
+    """nerfstudio.field_components.field_heads.FieldHeadNames (the members the path produces)."""
+    RGB = "rgb"
+    DENSITY = "density"
+
+
+class _TruncExp(torch.autograd.Function):
+    """nerfstudio ``trunc_exp``: forward exp(x), backward g * exp(clamp(x, -15, 15))."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.save_for_backward(x)
+        return torch.exp(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        return g * torch.exp(x.clamp(-15, 15))
+
+
+trunc_exp = _TruncExp.apply
+
+
+def shift_directions_for_tcnn(directions: Tensor) -> Tensor:
+    return (directions + 1.0) / 2.0
+
+
+class NeRSembleNeRFactoField(nn.Module):
+
+    def __init__(self, aabb: Tensor, num_images: int, num_layers: int = 2, hidden_dim: int = 64,
+                 geo_feat_dim: int = 15, num_levels: int = 16, max_res: int = 2048, log2_hashmap_size: int = 19,
+                 num_layers_color: int = 3, hidden_dim_color: int = 64, spatial_distortion=None,
+                 use_appearance_embedding: bool = False, spherical_harmonics_degree: int = 0,
+                 use_hash_ensemble: bool = True, hash_ensemble_config: Optional[HashEnsembleConfig] = None,
+                 max_n_samples_per_batch: int = -1, **unused_nerfacto_kwargs) -> None:
+        super().__init__()
+        if spatial_distortion is not None or use_appearance_embedding or spherical_harmonics_degree > 0 \
+                or not use_hash_ensemble:
+            raise NotImplementedError("native field covers the NeRSemble training configuration: no scene "
+                                      "contraction, no appearance embedding, SH degree 0, hash ensemble on")
+        self.register_buffer("aabb", aabb)
+        self.geo_feat_dim = geo_feat_dim
+        self.register_buffer("max_res", torch.tensor(max_res))
+        self.register_buffer("num_levels", torch.tensor(num_levels))
+        self.register_buffer("log2_hashmap_size", torch.tensor(log2_hashmap_size))
+        self.num_images = num_images
+        self.use_hash_ensemble = use_hash_ensemble
+        self.max_n_samples_per_batch = max_n_samples_per_batch
+
+        self.direction_encoding = tcnn.Encoding(n_input_dims=3, encoding_config={"otype": "Identity"})
+        self.hash_ensemble = HashEnsemble(hash_ensemble_config)
+        self.mlp_base = tcnn.NetworkWithInputEncoding(
+            n_input_dims=self.hash_ensemble.get_out_dim(), n_output_dims=1 + self.geo_feat_dim,
+            encoding_config={"otype": "Identity", "n_dims_to_encode": self.hash_ensemble.get_out_dim()},
+            network_config={"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": "None",
+                            "n_neurons": hidden_dim, "n_hidden_layers": num_layers - 1}, seed=1338)
+        self.mlp_head = tcnn.Network(
+            n_input_dims=self.direction_encoding.n_output_dims + self.geo_feat_dim, n_output_dims=3,
+            network_config={"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": "Sigmoid",
+                            "n_neurons": hidden_dim_color, "n_hidden_layers": num_layers_color - 1}, seed=1339)
+
+    # ---- density -----------------------------------------------------------------------------------
+    def density_fn(self, positions: Tensor, times: Optional[Tensor] = None,
+                   window_hash_encodings: Optional[float] = None, time_codes: Optional[Tensor] = None,
+                   time_code_index: Optional[Tensor] = None) -> Tensor:
+        """Occupancy / sigma_fn entry (nersemble_nerfacto_field.py:228-248)."""
+        del times
+        ray_samples = RaySamples(
+            frustums=Frustums(origins=positions, directions=torch.ones_like(positions),
+                              starts=torch.zeros_like(positions[..., :1]), ends=torch.zeros_like(positions[..., :1]),
+                              pixel_area=torch.ones_like(positions[..., :1])),
+            metadata={"time_codes": time_codes, "time_code_index": time_code_index})
+        density, _ = self.get_density(ray_samples, window_hash_encodings=window_hash_encodings)
+        return density
+
+    def get_density(self, ray_samples: RaySamples, window_hash_encodings: Optional[float]) -> Tuple[Tensor, Tensor]:
+        positions = SceneBox.get_normalized_positions(ray_samples.frustums.get_positions(), self.aabb)
+        max_chunk = len(positions) if self.max_n_samples_per_batch == -1 else self.max_n_samples_per_batch
+        md = ray_samples.metadata or {}
+        time_codes = md.get("time_codes")
+        code_index = md.get("time_code_index")        # native extension: time_codes is a [T,H] table
+        densities, base_outs = [], []
+        if code_index is None:
+            chunks = chunked(max(max_chunk, 1), positions, time_codes, None)
+        else:
+            chunks = ((p, time_codes, ci) for p, ci in chunked(max(max_chunk, 1), positions, code_index))
+        for pos_c, codes_c, idx_c in chunks:
+            # tcnn needs inputs in [0,1): zero the samples outside the scene box (:268-269)
+            selector = ((pos_c > 0.0) & (pos_c < 1.0)).all(dim=-1)
+            pos_c = pos_c * selector[..., None]
+            feats = self.hash_ensemble(pos_c.view(-1, 3), conditioning_code=codes_c,
+                                       window_hash_encodings=window_hash_encodings, code_index=idx_c)
+            h = self.mlp_base(feats).view(*pos_c.shape[:-1], -1)          # [S, 16] fp16
+            density_before_activation = h[..., :1]
+            density = trunc_exp(density_before_activation.to(pos_c)) * selector[..., None]
+            densities.append(density)
+            base_outs.append(h)
+        density = torch.cat(densities, dim=0)
+        base_out = torch.cat(base_outs, dim=0)
+        self._base_out = base_out                      # full [S,16] tensor for the fused head read
+        return density, base_out[..., 1:]
+
+    # ---- colour ------------------------------------------------------------------------------------
+    def get_outputs(self, ray_samples: RaySamples, density_embedding: Optional[Tensor] = None,
+                    base_out: Optional[Tensor] = None) -> Dict[FieldHeadNames, Tensor]:
+        assert density_embedding is not None or base_out is not None
+        if ray_samples.camera_indices is None:
+            raise AttributeError("Camera indices are not provided.")
+        directions = ray_samples.frustums.directions.reshape(-1, 3)
+        max_chunk = len(ray_samples) if self.max_n_samples_per_batch == -1 else self.max_n_samples_per_batch
+        if base_out is None:
+            # generic path (reference signature): rebuild a [S,16] tensor with an empty density column
+            base_out = torch.cat([torch.zeros_like(density_embedding[..., :1]), density_embedding], dim=-1)
+        rgbs = []
+        for dir_c, base_c in chunked(max(max_chunk, 1), directions, base_out):
+            # mlp_head input = [(d+1)/2 (3), geo features (15)], read in place by the kernel (:313, :371-377)
+            rgb = F.fused_mlp(self.mlp_head.params, self.mlp_head.n_hidden_mats, 3, self.mlp_head.out_act,
+                              a=dir_c, a_mul=0.5, a_add=0.5, b=base_c, b_off=1, b_dim=self.geo_feat_dim)
+            rgbs.append(rgb.to(directions))
+        return {FieldHeadNames.RGB: torch.cat(rgbs, dim=0)}
+
+    def forward(self, ray_samples: RaySamples, compute_normals: bool = False,
+                window_hash_encodings: Optional[float] = None) -> Dict[FieldHeadNames, Tensor]:
+        if compute_normals:
+            raise NotImplementedError("normals are not part of the NeRSemble training path")
+        density, density_embedding = self.get_density(ray_samples, window_hash_encodings=window_hash_encodings)
+        field_outputs = self.get_outputs(ray_samples, density_embedding=density_embedding, base_out=self._base_out)
+        self._base_out = None
+        field_outputs[FieldHeadNames.DENSITY] = density
+        return field_outputs

@@ -1,0 +1,329 @@
+"""NeRSembleNGPModel -- host-side mirror of the reference's nerfstudio/models/nersemble_instant_ngp.py:40-516
+(config fields, module names, ``get_outputs`` dict, loss / metric dicts, param groups, occupancy + window
+callbacks), running the hot path on libnsx kernels.
+
+MI355X-native changes that do not alter results:
+  * time codes are never gathered per sample: the batch's distinct timesteps are compacted once per step
+    (<= 24 rows) and the kernels index the small ``[Tb,H]`` table per sample (nersemble_instant_ngp.py:300-318
+    materialises ``[S,H]`` and ``[S,128]`` fp32 tensors instead);
+  * ``packed_info`` is computed once and shared by the weight / accumulation / distortion kernels.
+"""
+from dataclasses import dataclass, field
+from math import sqrt
+from typing import Callable, Dict, List, Optional, Tuple
+
+import torch
+from torch import nn, Tensor
+from torch.nn import Parameter, init
+
+from .. import nerfacc
+from ..engine.generic_scheduler import GenericScheduler
+from ..field_components.deformation_field import SE3DeformationField, SE3DeformationFieldConfig
+from ..field_components.hash_ensemble import HashEnsembleConfig
+from ..fields.nersemble_nerfacto_field import FieldHeadNames, NeRSembleNeRFactoField
+from ..model_components.nersemble_volumetric_sampler import NeRSembleVolumetricSampler
+from ..model_components.renderers import AccumulationRenderer, DeformationRenderer, DepthRenderer, RGBRenderer
+from ..rays import RayBundle, RaySamples, SceneBox
+from .base import BaseModel, BaseModelConfig
+
+
+@dataclass
+class NeRSembleNGPModelConfig(BaseModelConfig):
+    # nerfstudio InstantNGPModelConfig fields the reference relies on
+    grid_resolution: int = 128
+    grid_levels: int = 1
+    max_res: int = 2048
+    log2_hashmap_size: int = 19
+    alpha_thre: float = 0.01
+    cone_angle: float = 0.004
+    render_step_size: Optional[float] = None
+    near_plane: float = 0.05
+    far_plane: float = 1e3
+    use_appearance_embedding: bool = False
+    background_color: str = "random"
+    disable_scene_contraction: bool = False
+    eval_num_rays_per_chunk: int = 4096
+    # NeRSemble additions (nersemble_instant_ngp.py:44-77)
+    n_timesteps: int = 1
+    latent_dim_time: int = 128
+    spherical_harmonics_degree: int = 0
+    use_hash_ensemble: bool = False
+    hash_ensemble_config: Optional[HashEnsembleConfig] = None
+    use_deformation_field: bool = False
+    deformation_field_config: Optional[SE3DeformationFieldConfig] = None
+    use_separate_deformation_time_embedding: bool = True
+    window_deform_begin: int = 0
+    window_deform_end: int = 0
+    window_hash_encodings_begin: int = 0
+    window_hash_encodings_end: int = 1
+    early_stop_eps: float = 1e-4
+    occ_thre: float = 1e-2
+    disable_occupancy_grid: bool = False
+    occupancy_grid_ema_decay: float = 0.95
+    occupancy_grid_warmup_steps: int = 256
+    max_n_samples_per_batch: int = -1
+    use_view_frustum_culling: bool = False
+    view_frustum_culling: int = 2
+
+
+@dataclass
+class TrainingCallback:
+    """Minimal stand-in for nerfstudio's TrainingCallback (BEFORE_TRAIN_ITERATION only)."""
+    func: Callable
+    update_every_num_iters: int = 1
+    args: Tuple = ()
+
+    def run(self, step: int) -> None:
+        if step % self.update_every_num_iters == 0:
+            self.func(*self.args, step=step)
+
+
+def psnr(pred: Tensor, target: Tensor) -> Tensor:
+    """torchmetrics.PeakSignalNoiseRatio(data_range=1.0): 10 log10(1 / MSE)."""
+    return 10.0 * torch.log10(1.0 / torch.mean((pred - target) ** 2))
+
+
+class NeRSembleNGPModel(BaseModel):
+    config: NeRSembleNGPModelConfig
+
+    def __init__(self, config: NeRSembleNGPModelConfig, scene_box: SceneBox, num_train_data: int,
+                 metadata: Optional[Dict] = None, occ_seed: int = 0):
+        super().__init__()
+        self.config = config
+        self.scene_box = scene_box
+        self.num_train_data = num_train_data
+        self.kwargs = {"metadata": metadata or {}}
+        self._occ_seed = occ_seed
+        self._occ_generator = None
+        self.populate_modules()
+
+    # ---- construction (nersemble_instant_ngp.py:81-179) ---------------------------------------------
+    def populate_modules(self):
+        super().populate_modules()
+        cfg = self.config
+        if not cfg.disable_scene_contraction:
+            raise NotImplementedError("NeRSemble trains with disable_scene_contraction=True (train_nersemble.py:196)")
+        self.field = NeRSembleNeRFactoField(
+            aabb=self.scene_box.aabb, num_images=self.num_train_data, log2_hashmap_size=cfg.log2_hashmap_size,
+            max_res=cfg.max_res, spatial_distortion=None, spherical_harmonics_degree=cfg.spherical_harmonics_degree,
+            use_hash_ensemble=cfg.use_hash_ensemble, hash_ensemble_config=cfg.hash_ensemble_config,
+            use_appearance_embedding=cfg.use_appearance_embedding,
+            max_n_samples_per_batch=cfg.max_n_samples_per_batch)
+
+        self.deformation_field = None
+        if cfg.use_deformation_field:
+            self.deformation_field = SE3DeformationField(self.scene_box.aabb.clone(), cfg.deformation_field_config,
+                                                         max_n_samples_per_batch=cfg.max_n_samples_per_batch)
+        self.time_embedding = None
+        self.time_embedding_deformation = None
+        if cfg.use_deformation_field or cfg.use_hash_ensemble:
+            self.time_embedding = nn.Embedding(cfg.n_timesteps, cfg.latent_dim_time)
+            init.normal_(self.time_embedding.weight, mean=0., std=0.01 / sqrt(cfg.latent_dim_time))
+            if cfg.use_separate_deformation_time_embedding and cfg.deformation_field_config is not None:
+                self.time_embedding_deformation = nn.Embedding(cfg.n_timesteps, cfg.deformation_field_config.warp_code_dim)
+                init.normal_(self.time_embedding_deformation.weight, mean=0.,
+                             std=0.01 / sqrt(cfg.deformation_field_config.warp_code_dim))
+
+        self.scene_aabb = Parameter(self.scene_box.aabb.flatten().clone(), requires_grad=False)
+        if cfg.render_step_size is None:
+            cfg.render_step_size = ((self.scene_aabb[3:] - self.scene_aabb[:3]) ** 2).sum().sqrt().item() / 1000
+        self.occupancy_grid = nerfacc.OccGridEstimator(roi_aabb=self.scene_aabb.detach(), resolution=cfg.grid_resolution,
+                                                       levels=cfg.grid_levels)
+        self.sampler = NeRSembleVolumetricSampler(
+            occupancy_grid=self.occupancy_grid, density_fn=self.field_density_fn, scene_aabb=self.scene_box.aabb,
+            camera_frustums=self.kwargs["metadata"].get("camera_frustums"),
+            view_frustum_culling=cfg.view_frustum_culling if cfg.use_view_frustum_culling else None)
+
+        self.renderer_rgb = RGBRenderer(background_color=cfg.background_color)
+        self.renderer_accumulation = AccumulationRenderer()
+        self.renderer_depth = DepthRenderer(method="expected")
+        self.renderer_deformation = DeformationRenderer()
+
+        self.sched_window_deform = None
+        if cfg.window_deform_end >= 1:
+            self.sched_window_deform = GenericScheduler(init_value=0, final_value=cfg.deformation_field_config.n_freq_pos,
+                                                        begin_step=cfg.window_deform_begin, end_step=cfg.window_deform_end)
+        self.sched_window_hash_encodings = None
+        if cfg.use_hash_ensemble and cfg.window_hash_encodings_end > 0:
+            self.sched_window_hash_encodings = GenericScheduler(
+                init_value=1, final_value=cfg.hash_ensemble_config.n_hash_encodings,
+                begin_step=cfg.window_hash_encodings_begin, end_step=cfg.window_hash_encodings_end)
+
+    # ---- callbacks (:181-233) ---------------------------------------------------------------------
+    def _random_times(self, n: int, device) -> Tensor:
+        T = self.config.n_timesteps
+        if self._occ_generator is None or self._occ_generator.device != torch.device(device):
+            # seeded generator shared by all data-parallel ranks: identical grids without communication
+            self._occ_generator = torch.Generator(device=device).manual_seed(self._occ_seed)
+        ts = torch.randint(0, T, (n, 1), dtype=torch.int, device=device, generator=self._occ_generator)
+        if T == 1:
+            return torch.zeros((n, 1), device=device)       # the reference divides by T-1 = 0 here; time is 0
+        return ts / (T - 1)
+
+    def update_occupancy_grid(self, step: int):
+        cfg = self.config
+        self._random_times(1, self.occupancy_grid.device)          # make sure the shared generator exists
+        self.occupancy_grid.update_every_n_steps(
+            step=step,
+            occ_eval_fn=lambda x: self.field_density_fn(x, self._random_times(x.shape[0], x.device)).reshape(-1, 1)
+            * cfg.render_step_size,
+            n=16, occ_thre=cfg.occ_thre, ema_decay=cfg.occupancy_grid_ema_decay,
+            warmup_steps=cfg.occupancy_grid_warmup_steps, generator=self._occ_generator)
+
+    def get_training_callbacks(self) -> List[TrainingCallback]:
+        callbacks = [TrainingCallback(func=lambda step: self.update_occupancy_grid(step))]
+
+        def update_window_param(sched: GenericScheduler, name: str, step: int):
+            sched.update(step)
+
+        for sched, name in ((self.sched_window_deform, "sched_window_deform"),
+                            (self.sched_window_hash_encodings, "sched_window_hash_encodings"),
+                            (self.sched_eps_depth, "sched_eps_depth")):
+            if sched is not None:
+                callbacks.append(TrainingCallback(func=update_window_param, args=(sched, name)))
+        return callbacks
+
+    # ---- time codes ----------------------------------------------------------------------------------
+    def _timesteps(self, times: Tensor) -> Tensor:
+        return (times * (self.config.n_timesteps - 1)).round().int().reshape(-1)
+
+    # ---- density for sigma_fn / occupancy grid (:235-266) ------------------------------------------
+    def field_density_fn(self, positions: Tensor, times: Optional[Tensor]) -> Tensor:
+        cfg = self.config
+        if cfg.disable_occupancy_grid:
+            return torch.ones((positions.shape[0],), dtype=positions.dtype, device=positions.device)
+        window_hash = self.sched_window_hash_encodings.value if self.sched_window_hash_encodings is not None else None
+        window_deform = self.sched_window_deform.value if self.sched_window_deform is not None else None
+        time_codes = time_codes_deformation = timesteps = None
+        if self.time_embedding is not None:
+            assert times is not None, "Times need to be provided to NeRSemble's density_fn"
+            timesteps = self._timesteps(times)
+            if self.time_embedding_deformation is not None:
+                time_codes_deformation = self.time_embedding_deformation(timesteps)
+        if cfg.use_deformation_field:
+            if self.time_embedding_deformation is None:
+                time_codes_deformation = self.time_embedding(timesteps)
+            # normalised-space offset added to the world-space position, exactly as the reference does (:257-259)
+            offsets = self.deformation_field.compute_offsets(positions, time_codes_deformation, window_deform)
+            positions = positions + offsets
+        return self.field.density_fn(positions, times, window_hash_encodings=window_hash,
+                                     time_codes=self.time_embedding.weight if self.time_embedding is not None else None,
+                                     time_code_index=timesteps)
+
+    def warp_ray_samples(self, ray_samples: RaySamples, time_codes: Optional[Tensor] = None) -> RaySamples:
+        window_deform = self.sched_window_deform.value if self.sched_window_deform is not None else None
+        if self.deformation_field is not None:
+            assert ray_samples.frustums.offsets is None, "ray samples have already been warped"
+            self.deformation_field(ray_samples, warp_code=time_codes, windows_param=window_deform)
+        return ray_samples
+
+    # ---- forward (:280-364) --------------------------------------------------------------------------
+    def get_outputs(self, ray_bundle: RayBundle):
+        cfg = self.config
+        window_hash = self.sched_window_hash_encodings.value if self.sched_window_hash_encodings is not None else None
+        num_rays = len(ray_bundle)
+        with torch.no_grad():
+            ray_samples, ray_indices = self.sampler(
+                ray_bundle=ray_bundle, near_plane=cfg.near_plane, far_plane=cfg.far_plane,
+                render_step_size=cfg.render_step_size, alpha_thre=cfg.alpha_thre, cone_angle=cfg.cone_angle,
+                early_stop_eps=cfg.early_stop_eps)
+        if ray_samples.metadata is None:
+            ray_samples.metadata = dict()
+
+        if ray_bundle.times is not None:
+            ray_timesteps = self._timesteps(ray_bundle.times)
+        elif "timesteps" in ray_bundle.metadata:
+            ray_timesteps = ray_bundle.metadata["timesteps"].reshape(-1).int()
+        else:
+            ray_timesteps = torch.zeros((num_rays,), dtype=torch.int, device=ray_indices.device)
+
+        time_codes_deformation = None
+        if self.time_embedding is not None:
+            # compact the batch's distinct timesteps (<= 24 images per batch) -> small code tables + per-sample slot
+            uniq, inv = torch.unique(ray_timesteps, return_inverse=True)
+            slot = inv.to(torch.int32)[ray_indices]
+            ray_samples.metadata["time_codes"] = self.time_embedding(uniq)              # [Tb, H]
+            ray_samples.metadata["time_code_index"] = slot                              # [S]
+            if self.time_embedding_deformation is not None:
+                time_codes_deformation = self.time_embedding_deformation(uniq)[slot.long()]
+            elif cfg.use_deformation_field:
+                time_codes_deformation = ray_samples.metadata["time_codes"][slot.long()]
+
+        ray_samples = self.warp_ray_samples(ray_samples, time_codes_deformation)
+        field_outputs = self.field(ray_samples, window_hash_encodings=window_hash)
+
+        packed_info = nerfacc.pack_info(ray_indices, num_rays)
+        weights = nerfacc.render_weight_from_density(
+            t_starts=ray_samples.frustums.starts[..., 0], t_ends=ray_samples.frustums.ends[..., 0],
+            sigmas=field_outputs[FieldHeadNames.DENSITY][..., 0], packed_info=packed_info)[0]
+        weights = weights[..., None]
+
+        rgb = self.renderer_rgb(rgb=field_outputs[FieldHeadNames.RGB], weights=weights, ray_indices=ray_indices,
+                                num_rays=num_rays, packed_info=packed_info)
+        depth = self.renderer_depth(weights=weights, ray_samples=ray_samples, ray_indices=ray_indices,
+                                    num_rays=num_rays, packed_info=packed_info)
+        accumulation = self.renderer_accumulation(weights=weights, ray_indices=ray_indices, num_rays=num_rays,
+                                                  packed_info=packed_info)
+        outputs = {
+            "rgb": rgb, "accumulation": accumulation, "depth": depth, "num_samples_per_ray": packed_info[:, 1],
+            # 1-tuples: not per-ray image outputs (:351-356)
+            "ray_samples": (ray_samples,), "ray_indices": (ray_indices,), "weights": (weights,),
+            "packed_info": (packed_info,),
+        }
+        if ray_samples.frustums.offsets is not None:
+            with torch.no_grad():
+                outputs["deformation"] = self.renderer_deformation(weights=weights.detach(), ray_samples=ray_samples,
+                                                                   ray_indices=ray_indices, num_rays=num_rays,
+                                                                   packed_info=packed_info)
+        return outputs
+
+    def forward(self, ray_bundle: RayBundle):
+        return self.get_outputs(ray_bundle)
+
+    # ---- losses / metrics (:366-422) ---------------------------------------------------------------
+    def get_loss_dict(self, outputs, batch, metrics_dict=None) -> Dict[str, Tensor]:
+        loss_dict = dict()
+        accumulation = outputs["accumulation"]
+        depths = outputs["depth"]
+        ray_samples = outputs["ray_samples"][0]
+        ray_indices = outputs["ray_indices"][0]
+        weights = outputs["weights"][0]
+        loss_dict["rgb_loss"] = self.get_masked_rgb_loss(batch, outputs["rgb"])
+        if "alpha_map" in batch:
+            alpha_loss = self.get_alpha_loss(batch, accumulation)
+            if alpha_loss is not None:
+                loss_dict["alpha_loss"] = alpha_loss
+        if "depth_maps" in batch:
+            near_loss, empty_loss = self.get_near_and_empty_loss(batch, ray_samples, ray_indices, weights, accumulation)
+            depth_loss = self.get_depth_loss(batch, depths)
+            if near_loss is not None:
+                loss_dict["near_loss"] = near_loss
+            if empty_loss is not None:
+                loss_dict["empty_loss"] = empty_loss
+            if depth_loss is not None:
+                loss_dict["depth_loss"] = depth_loss
+        dist_loss = self.get_dist_loss(ray_samples, ray_indices, weights, num_rays=accumulation.shape[0],
+                                       packed_info=outputs["packed_info"][0])
+        if dist_loss is not None:
+            loss_dict["dist_loss"] = dist_loss
+        return loss_dict
+
+    def get_metrics_dict(self, outputs, batch) -> Dict[str, Tensor]:
+        rgb = outputs["rgb"]
+        image = batch["image"].to(rgb.device)
+        metrics = {"psnr": psnr(rgb, image), "num_samples_per_batch": outputs["num_samples_per_ray"].sum()}
+        if "alpha_map" in batch:
+            mask = batch["alpha_map"].squeeze(1) > 127
+            if mask.any():
+                metrics["psnr_masked"] = psnr(rgb[mask], image[mask])
+        return metrics
+
+    def get_param_groups(self) -> Dict[str, List[Parameter]]:
+        groups = {"fields": list(self.field.parameters())}
+        if self.time_embedding is not None:
+            groups["embeddings"] = list(self.time_embedding.parameters())
+            if self.time_embedding_deformation is not None:
+                groups["embeddings"].extend(list(self.time_embedding_deformation.parameters()))
+        if self.config.use_deformation_field:
+            groups["deformation_field"] = [p for p in self.deformation_field.parameters() if p.requires_grad]
+        return groups

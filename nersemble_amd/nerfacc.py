@@ -1,0 +1,275 @@
+"""nerfacc-shaped operators backed by libnsx.so (include/nsx.h).
+
+Mirrors the part of nerfacc 0.5.2 the reference imports: ``OccGridEstimator`` (``sampling``,
+``update_every_n_steps``, attributes ``binaries`` / ``occs`` / ``aabbs`` / ``resolution``), ``pack_info``,
+``render_weight_from_density``, ``render_visibility_from_density``, ``accumulate_along_rays``.
+Call sites in the reference: nersemble_volumetric_sampler.py:95-108, nersemble_instant_ngp.py:133-137,
+:185-196, :325-331, nersemble_deformation_renderer.py:22-25.  The traversal and the per-ray scans are HIP
+kernels; only random cell selection / EMA bookkeeping of the grid update is torch glue.
+"""
+import ctypes as C
+from typing import Callable, Optional, Tuple
+
+import torch
+from torch import nn, Tensor
+
+from ._lib import check, lib, ptr, stream
+
+
+# ------------------------------------------------------------------------------------------------
+# packed-ray helpers
+# ------------------------------------------------------------------------------------------------
+def pack_info(ray_indices: Tensor, n_rays: Optional[int] = None) -> Tensor:
+    """[n_rays, 2] int64 (start, count) from sorted ray indices (nerfacc.pack_info)."""
+    assert ray_indices.dim() == 1
+    ray_indices = ray_indices.to(torch.int64).contiguous()
+    if n_rays is None:
+        n_rays = int(ray_indices.max().item()) + 1 if ray_indices.numel() else 0
+    dev = ray_indices.device
+    counts = torch.zeros((n_rays,), dtype=torch.int64, device=dev)
+    check(lib().nsx_ray_histogram(ptr(ray_indices), ray_indices.numel(), n_rays, ptr(counts), stream()),
+          "nsx_ray_histogram")
+    packed = torch.empty((n_rays, 2), dtype=torch.int64, device=dev)
+    total = torch.empty((1,), dtype=torch.int64, device=dev)
+    check(lib().nsx_pack_info(ptr(counts), n_rays, ptr(packed), ptr(total), stream()), "nsx_pack_info")
+    return packed
+
+
+def _packed(packed_info, ray_indices, n_rays):
+    if packed_info is not None:
+        return packed_info.to(torch.int64).contiguous()
+    assert ray_indices is not None and n_rays is not None, "need packed_info or (ray_indices, n_rays)"
+    return pack_info(ray_indices, n_rays)
+
+
+class _RenderWeights(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, t_starts, t_ends, sigmas, packed):
+        t0 = t_starts.detach().to(torch.float32).contiguous()
+        t1 = t_ends.detach().to(torch.float32).contiguous()
+        sg = sigmas.detach().to(torch.float32).contiguous()
+        w, T, a = torch.empty_like(sg), torch.empty_like(sg), torch.empty_like(sg)
+        if sg.numel() > 0:
+            check(lib().nsx_render_weights_fwd(ptr(t0), ptr(t1), ptr(sg), ptr(packed), packed.shape[0], ptr(w), ptr(T),
+                                               ptr(a), None, 0.0, 0.0, stream()), "nsx_render_weights_fwd")
+        ctx.save_for_backward(t0, t1, sg, packed)
+        ctx.mark_non_differentiable(T, a)
+        return w, T, a
+
+    @staticmethod
+    def backward(ctx, gw, gT, ga):
+        t0, t1, sg, packed = ctx.saved_tensors
+        gw = gw.to(torch.float32).contiguous()
+        ds = torch.zeros_like(sg)
+        check(lib().nsx_render_weights_bwd(ptr(t0), ptr(t1), ptr(sg), ptr(packed), packed.shape[0], ptr(gw), ptr(ds),
+                                           stream()), "nsx_render_weights_bwd")
+        return None, None, ds, None
+
+
+def render_weight_from_density(t_starts: Tensor, t_ends: Tensor, sigmas: Tensor, packed_info: Optional[Tensor] = None,
+                               ray_indices: Optional[Tensor] = None, n_rays: Optional[int] = None
+                               ) -> Tuple[Tensor, Tensor, Tensor]:
+    """(weights, transmittance, alphas) for packed samples; differentiable w.r.t. sigmas (through weights)."""
+    return _RenderWeights.apply(t_starts, t_ends, sigmas, _packed(packed_info, ray_indices, n_rays))
+
+
+@torch.no_grad()
+def render_visibility_from_density(t_starts: Tensor, t_ends: Tensor, sigmas: Tensor,
+                                   packed_info: Optional[Tensor] = None, ray_indices: Optional[Tensor] = None,
+                                   n_rays: Optional[int] = None, early_stop_eps: float = 1e-4,
+                                   alpha_thre: float = 0.0) -> Tensor:
+    packed = _packed(packed_info, ray_indices, n_rays)
+    t0, t1 = t_starts.to(torch.float32).contiguous(), t_ends.to(torch.float32).contiguous()
+    sg = sigmas.to(torch.float32).contiguous()
+    vis = torch.empty(sg.shape, dtype=torch.uint8, device=sg.device)
+    if sg.numel() == 0:
+        return vis.bool()
+    check(lib().nsx_render_weights_fwd(ptr(t0), ptr(t1), ptr(sg), ptr(packed), packed.shape[0], None, None, None,
+                                       ptr(vis), float(early_stop_eps), float(alpha_thre), stream()),
+          "nsx_render_weights_fwd")
+    return vis.bool()
+
+
+class _Accumulate(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, weights, values, packed, ray_indices):
+        w = weights.detach().to(torch.float32).contiguous()
+        v = values.detach().to(torch.float32).contiguous() if values is not None else None
+        Cc = v.shape[1] if v is not None else 1
+        out = torch.empty((packed.shape[0], Cc), dtype=torch.float32, device=w.device)
+        check(lib().nsx_accumulate_fwd(ptr(w), ptr(v), Cc, ptr(packed), packed.shape[0], ptr(out), stream()),
+              "nsx_accumulate_fwd")
+        ctx.save_for_backward(w, v, ray_indices)
+        ctx.Cc = Cc
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        w, v, ray_indices = ctx.saved_tensors
+        g = g.to(torch.float32).contiguous()
+        dw = torch.empty_like(w) if ctx.needs_input_grad[0] else None
+        dv = torch.empty_like(v) if (v is not None and ctx.needs_input_grad[1]) else None
+        check(lib().nsx_accumulate_bwd(ptr(w), ptr(v), ctx.Cc, ptr(ray_indices), w.numel(), ptr(g), ptr(dw), ptr(dv),
+                                       stream()), "nsx_accumulate_bwd")
+        return dw, dv, None, None
+
+
+def accumulate_along_rays(weights: Tensor, values: Optional[Tensor] = None, ray_indices: Optional[Tensor] = None,
+                          n_rays: Optional[int] = None, packed_info: Optional[Tensor] = None) -> Tensor:
+    """out[r] = sum_{i in ray r} weights[i] * values[i] (values None -> sum of weights); weights [S], values [S, C]."""
+    assert weights.dim() == 1, "packed weights must be [S]"
+    assert ray_indices is not None, "packed mode needs ray_indices"
+    ray_indices = ray_indices.to(torch.int64).contiguous()
+    packed = _packed(packed_info, ray_indices, n_rays)
+    if values is not None and values.shape[1] not in (1, 3):
+        # generic channel count: split into supported widths
+        outs = [accumulate_along_rays(weights, values[:, c:c + 1].contiguous(), ray_indices, n_rays, packed)
+                for c in range(values.shape[1])]
+        return torch.cat(outs, dim=1)
+    return _Accumulate.apply(weights, values, packed, ray_indices)
+
+
+# ------------------------------------------------------------------------------------------------
+# occupancy grid
+# ------------------------------------------------------------------------------------------------
+def _meshgrid3d(res: Tensor, device="cpu") -> Tensor:
+    return torch.stack(torch.meshgrid([torch.arange(int(r), device=device) for r in res], indexing="ij"), dim=-1).long()
+
+
+class OccGridEstimator(nn.Module):
+    """Occupancy grid (single level) with nerfacc 0.5.2's interface; traversal runs in libnsx."""
+
+    DIM: int = 3
+
+    def __init__(self, roi_aabb, resolution=128, levels: int = 1):
+        super().__init__()
+        if isinstance(resolution, int):
+            resolution = [resolution] * self.DIM
+        resolution = torch.as_tensor(resolution, dtype=torch.int32)
+        roi_aabb = torch.as_tensor(roi_aabb, dtype=torch.float32).flatten()
+        assert resolution.shape[0] == self.DIM and roi_aabb.shape[0] == 2 * self.DIM
+        if levels != 1 or len(set(resolution.tolist())) != 1:
+            raise NotImplementedError("native traversal supports grid_levels=1 and cubic resolution "
+                                      "(the configuration NeRSemble trains with, train_nersemble.py:100)")
+        center, half = (roi_aabb[:3] + roi_aabb[3:]) / 2, (roi_aabb[3:] - roi_aabb[:3]) / 2
+        aabbs = torch.stack([torch.cat([center - half * 2 ** i, center + half * 2 ** i]) for i in range(levels)])
+        self.cells_per_lvl = int(resolution.prod().item())
+        self.levels = levels
+        self.register_buffer("resolution", resolution)
+        self.register_buffer("aabbs", aabbs)
+        self.register_buffer("occs", torch.zeros(self.levels * self.cells_per_lvl))
+        self.register_buffer("binaries", torch.zeros([levels] + resolution.tolist(), dtype=torch.bool))
+        grid_coords = _meshgrid3d(resolution).reshape(self.cells_per_lvl, self.DIM)
+        self.register_buffer("grid_coords", grid_coords, persistent=False)
+        self.register_buffer("grid_indices", torch.arange(self.cells_per_lvl), persistent=False)
+        self._aabb_host = (C.c_float * 6)(*[float(v) for v in aabbs[0].tolist()])
+
+    @property
+    def device(self) -> torch.device:
+        return self.occs.device
+
+    # ---- traversal -------------------------------------------------------------------------------
+    @torch.no_grad()
+    def traverse(self, rays_o: Tensor, rays_d: Tensor, near_planes: Tensor, far_plane: float, step: float,
+                 want_cells: bool = False):
+        """Two-pass marching; returns (ray_indices int64 [S], t_starts, t_ends, packed_info [R,2], cells|None)."""
+        rays_o = rays_o.to(torch.float32).contiguous()
+        rays_d = rays_d.to(torch.float32).contiguous()
+        near_planes = near_planes.to(torch.float32).contiguous()
+        R = rays_o.shape[0]
+        dev = rays_o.device
+        binary = self.binaries[0].contiguous().view(torch.uint8)
+        res = int(self.resolution[0])
+        counts = torch.empty((R,), dtype=torch.int64, device=dev)
+        packed = torch.empty((R, 2), dtype=torch.int64, device=dev)
+        total = torch.zeros((1,), dtype=torch.int64, device=dev)
+        check(lib().nsx_march_count(ptr(rays_o), ptr(rays_d), R, self._aabb_host, ptr(binary), res, ptr(near_planes),
+                                    float(far_plane), float(step), ptr(counts), stream()), "nsx_march_count")
+        check(lib().nsx_pack_info(ptr(counts), R, ptr(packed), ptr(total), stream()), "nsx_pack_info")
+        S = int(total.item())                       # the one host read-back (as in nerfacc's two-pass design)
+        t0 = torch.empty((S,), dtype=torch.float32, device=dev)
+        t1 = torch.empty((S,), dtype=torch.float32, device=dev)
+        ri = torch.empty((S,), dtype=torch.int64, device=dev)
+        cells = torch.empty((S,), dtype=torch.int32, device=dev) if want_cells else None
+        if S > 0:
+            check(lib().nsx_march_fill(ptr(rays_o), ptr(rays_d), R, self._aabb_host, ptr(binary), res,
+                                       ptr(near_planes), float(far_plane), float(step), ptr(packed), ptr(t0), ptr(t1),
+                                       ptr(ri), ptr(cells), stream()), "nsx_march_fill")
+        return ri, t0, t1, packed, cells
+
+    @torch.no_grad()
+    def sampling(self, rays_o: Tensor, rays_d: Tensor, sigma_fn: Optional[Callable] = None,
+                 alpha_fn: Optional[Callable] = None, near_plane: float = 0.0, far_plane: float = 1e10,
+                 t_min: Optional[Tensor] = None, t_max: Optional[Tensor] = None, render_step_size: float = 1e-3,
+                 early_stop_eps: float = 1e-4, alpha_thre: float = 0.0, stratified: bool = False,
+                 cone_angle: float = 0.0) -> Tuple[Tensor, Tensor, Tensor]:
+        """Same contract as nerfacc 0.5.2 ``OccGridEstimator.sampling``: (ray_indices, t_starts, t_ends)."""
+        if cone_angle != 0.0:
+            raise NotImplementedError("cone_angle != 0 is not used by NeRSemble (train_nersemble.py:97)")
+        if alpha_fn is not None:
+            raise NotImplementedError("alpha_fn is not used by NeRSemble")
+        near_planes = torch.full_like(rays_o[..., 0], fill_value=near_plane)
+        far = float(far_plane)
+        if t_min is not None:
+            near_planes = torch.clamp(near_planes, min=t_min)
+        if t_max is not None:
+            raise NotImplementedError("per-ray t_max is not used by NeRSemble (ray bundles carry no fars)")
+        if stratified:
+            near_planes = near_planes + torch.rand_like(near_planes) * render_step_size
+        ray_indices, t_starts, t_ends, packed, _ = self.traverse(rays_o, rays_d, near_planes, far, render_step_size)
+        if (alpha_thre > 0.0 or early_stop_eps > 0.0) and sigma_fn is not None:
+            alpha_thre = min(alpha_thre, self.occs.mean().item())
+            if t_starts.shape[0] != 0:
+                sigmas = sigma_fn(t_starts, t_ends, ray_indices)
+            else:
+                sigmas = torch.empty((0,), device=t_starts.device)
+            assert sigmas.shape == t_starts.shape, "sigmas must have shape of (N,)! Got {}".format(sigmas.shape)
+            masks = render_visibility_from_density(t_starts, t_ends, sigmas, packed_info=packed,
+                                                   early_stop_eps=early_stop_eps, alpha_thre=alpha_thre)
+            ray_indices, t_starts, t_ends = ray_indices[masks], t_starts[masks], t_ends[masks]
+        return ray_indices, t_starts, t_ends
+
+    # ---- grid update (nerfacc _update; torch glue around the density evaluation) ----------------
+    @torch.no_grad()
+    def _get_all_cells(self):
+        return [self.grid_indices] * self.levels
+
+    @torch.no_grad()
+    def _sample_uniform_and_occupied_cells(self, n: int, generator=None):
+        lvl_indices = []
+        for lvl in range(self.levels):
+            uniform_indices = torch.randint(self.cells_per_lvl, (n,), device=self.device, generator=generator)
+            occupied_indices = torch.nonzero(self.binaries[lvl].flatten())[:, 0]
+            if n < len(occupied_indices):
+                selector = torch.randint(len(occupied_indices), (n,), device=self.device, generator=generator)
+                occupied_indices = occupied_indices[selector]
+            lvl_indices.append(torch.cat([uniform_indices, occupied_indices], dim=0))
+        return lvl_indices
+
+    @torch.no_grad()
+    def update_every_n_steps(self, step: int, occ_eval_fn: Callable, occ_thre: float = 1e-2, ema_decay: float = 0.95,
+                             warmup_steps: int = 256, n: int = 16, generator=None) -> None:
+        if not self.training:
+            raise RuntimeError("You should only call this function only during training. "
+                               "Please call _update() directly if you want to update the field during inference.")
+        if step % n == 0 and self.training:
+            self._update(step=step, occ_eval_fn=occ_eval_fn, occ_thre=occ_thre, ema_decay=ema_decay,
+                         warmup_steps=warmup_steps, generator=generator)
+
+    @torch.no_grad()
+    def _update(self, step: int, occ_eval_fn: Callable, occ_thre: float = 0.01, ema_decay: float = 0.95,
+                warmup_steps: int = 256, generator=None) -> None:
+        if step < warmup_steps:
+            cells = self._get_all_cells()
+        else:
+            cells = self._sample_uniform_and_occupied_cells(self.cells_per_lvl // 4, generator=generator)
+        for lvl, indices in enumerate(cells):
+            grid_coords = self.grid_coords[indices]
+            jitter = torch.rand(grid_coords.shape, dtype=torch.float32, device=grid_coords.device, generator=generator)
+            x = (grid_coords + jitter) / self.resolution
+            x = self.aabbs[lvl, :3] + x * (self.aabbs[lvl, 3:] - self.aabbs[lvl, :3])
+            occ = occ_eval_fn(x).squeeze(-1)
+            cell_ids = lvl * self.cells_per_lvl + indices
+            self.occs[cell_ids] = torch.maximum(self.occs[cell_ids] * ema_decay, occ.to(self.occs.dtype))
+        thre = torch.clamp(self.occs[self.occs >= 0].mean(), max=occ_thre)
+        self.binaries = (self.occs > thre).view(self.binaries.shape)

@@ -1,0 +1,80 @@
+"""tcnn-shaped operator layer (``tinycudann`` Python API subset the reference imports):
+``Network``, ``NetworkWithInputEncoding``, ``Encoding`` with ``.params`` (flat fp32 ``nn.Parameter``),
+``.n_output_dims`` and fp16 outputs -- backed by the MFMA kernels of libnsx.so.
+
+Reference call sites: nersemble_nerfacto_field.py:98-112 (direction encoding), :142-153 (mlp_base),
+:162-172 (mlp_head).  Supported configurations are the ones the reference instantiates on the hot path:
+FullyFusedMLP, 64 neurons, ReLU, 1-2 hidden layers, output None/Sigmoid, Identity encoding.
+"""
+import math
+
+import torch
+from torch import nn
+
+from . import functional as F
+
+_ACT = {"None": 0, "Sigmoid": 1}
+
+
+def _xavier_flat(shapes, gen) -> torch.Tensor:
+    parts = []
+    for fan_out, fan_in in shapes:
+        bound = math.sqrt(6.0 / (fan_in + fan_out))
+        parts.append(((torch.rand(fan_out * fan_in, generator=gen) * 2 - 1) * bound))
+    return torch.cat(parts)
+
+
+class Network(nn.Module):
+    """``tcnn.Network(n_input_dims, n_output_dims, network_config)`` (FullyFusedMLP)."""
+
+    def __init__(self, n_input_dims: int, n_output_dims: int, network_config: dict, seed: int = 1337):
+        super().__init__()
+        if network_config.get("otype", "FullyFusedMLP") != "FullyFusedMLP":
+            raise NotImplementedError("only FullyFusedMLP is provided")
+        if network_config.get("n_neurons", 64) != 64 or network_config.get("activation", "ReLU") != "ReLU":
+            raise NotImplementedError("native FullyFusedMLP: 64 neurons, ReLU (the reference's configuration)")
+        n_hidden = int(network_config.get("n_hidden_layers", 1))
+        if n_hidden not in (1, 2):
+            raise NotImplementedError("native FullyFusedMLP supports 1 or 2 hidden layers")
+        if n_input_dims > 32 or n_output_dims > 16:
+            raise NotImplementedError("native FullyFusedMLP: n_input_dims <= 32, n_output_dims <= 16")
+        self.n_input_dims, self.n_output_dims = n_input_dims, n_output_dims
+        self.n_hidden_mats = n_hidden - 1
+        self.out_act = _ACT[network_config.get("output_activation", "None")]
+        gen = torch.Generator().manual_seed(seed)
+        shapes = [(64, 32)] + [(64, 64)] * self.n_hidden_mats + [(16, 64)]
+        self.params = nn.Parameter(_xavier_flat(shapes, gen))
+        assert self.params.numel() == 64 * 32 + self.n_hidden_mats * 64 * 64 + 16 * 64
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """x [B, n_input_dims] (fp16 or fp32) -> [B, n_output_dims] fp16."""
+        x2 = x.reshape(-1, self.n_input_dims)
+        if x2.dtype == torch.float16:
+            return F.fused_mlp(self.params, self.n_hidden_mats, self.n_output_dims, self.out_act, b=x2)
+        return F.fused_mlp(self.params, self.n_hidden_mats, self.n_output_dims, self.out_act, a=x2.float())
+
+
+class NetworkWithInputEncoding(Network):
+    """``tcnn.NetworkWithInputEncoding`` with the Identity encoding the reference uses for mlp_base when the
+    HashEnsemble is enabled (nersemble_nerfacto_field.py:123-129)."""
+
+    def __init__(self, n_input_dims: int, n_output_dims: int, encoding_config: dict, network_config: dict,
+                 seed: int = 1337):
+        if encoding_config.get("otype") != "Identity":
+            raise NotImplementedError("native NetworkWithInputEncoding: Identity encoding (use HashEnsemble for grids)")
+        super().__init__(n_input_dims, n_output_dims, network_config, seed)
+
+
+class Encoding(nn.Module):
+    """``tcnn.Encoding`` -- Identity only (direction encoding with spherical_harmonics_degree = 0, the default of
+    every shipped NeRSemble config, nersemble_instant_ngp.py:46)."""
+
+    def __init__(self, n_input_dims: int, encoding_config: dict):
+        super().__init__()
+        if encoding_config.get("otype") != "Identity":
+            raise NotImplementedError(f"native Encoding: Identity only (got {encoding_config.get('otype')}); "
+                                      "hash grids go through HashEnsemble")
+        self.n_input_dims = self.n_output_dims = n_input_dims
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return x.to(torch.float16)

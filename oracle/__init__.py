@@ -7,4 +7,4 @@ status (third-party kernels "parity unpinned"; reference-owned glue pinned by
 tests/golden/).
 """
 from .capi import lib, build, GridGeom, grid_geometry  # noqa: F401
-from . import hashgrid  # noqa: F401
+from . import hashgrid, march, mlp  # noqa: F401

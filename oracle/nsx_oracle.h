@@ -68,6 +68,21 @@ void nsxo_ensemble_bwd(const float* x, int64_t B, const uint16_t* tables, int H,
                        const nsxo_grid_geom* g, const float* codew, const float* dout,
                        float* dtable, float* dcodew, float* dx);
 
+/* ---- ray marching / per-ray scans (oracle/march.c) ---- */
+void nsxo_march_count(const float* rays_o, const float* rays_d, int64_t R, const float* aabb,
+                      const uint8_t* binary, int res, const float* near, float far_plane, float step,
+                      int64_t* counts);
+void nsxo_march_fill(const float* rays_o, const float* rays_d, int64_t R, const float* aabb,
+                     const uint8_t* binary, int res, const float* near, float far_plane, float step,
+                     const int64_t* starts, float* t0, float* t1, int64_t* ray_idx, int32_t* cells);
+void nsxo_render_weights(const float* t0, const float* t1, const float* sigma, const int64_t* packed,
+                         int64_t R, float* weights, float* trans, float* alphas);
+void nsxo_render_weights_bwd(const float* t0, const float* t1, const float* sigma, const int64_t* packed,
+                             int64_t R, const float* gw, float* dsigma);
+void nsxo_accumulate(const float* w, const float* v, int C, const int64_t* packed, int64_t R, float* out);
+double nsxo_distloss(const float* w, const float* m, const float* interval, const int64_t* packed, int64_t R,
+                     int64_t n_rays, float* grad_w);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,69 @@
+"""CPU: reference-owned glue mirrored in nersemble_amd (pure torch parts) vs golden vectors produced by the
+reference's own Python (tests/golden/make_golden.py)."""
+import numpy as np
+import torch
+
+
+def test_se3_exp_map_matches_reference(golden_dir):
+    from nersemble_amd.util.se3 import se3_exp_map
+    z = np.load(f"{golden_dir}/deformation.npz")
+    got = se3_exp_map(torch.from_numpy(z["se3_in"])).numpy()
+    assert np.abs(got - z["se3_out"]).max() <= 2e-6
+
+
+def test_windowed_encoding_matches_reference(golden_dir):
+    from nersemble_amd.field_components.windowed_nerf_encoding import WindowedNeRFEncoding
+    z = np.load(f"{golden_dir}/deformation.npz")
+    enc = WindowedNeRFEncoding(3, 7, 0.0, 6.0, include_input=True)
+    assert enc.get_out_dim() == 45
+    for i, w in enumerate(z["pe_windows"]):
+        w = None if np.isnan(w) else float(w)
+        got = enc(torch.from_numpy(z["pe_x"]), windows_param=w).numpy()
+        assert np.abs(got - z[f"pe_out_{i}"]).max() <= 1e-6
+    out = enc(torch.tensor([[0.1, 0.2, 0.3]]), windows_param=3.5)[0]
+    assert torch.allclose(out[-3:], torch.tensor([0.6283, 1.2566, 1.8850]), atol=1e-4)   # SURVEY 8c known answer
+
+
+def test_deformation_offsets_match_reference(golden_dir):
+    from nersemble_amd.field_components.deformation_field import SE3DeformationField, SE3DeformationFieldConfig
+    z = np.load(f"{golden_dir}/deformation.npz")
+    cfg = SE3DeformationFieldConfig(warp_code_dim=8, mlp_num_layers=6, mlp_layer_width=32)
+    aabb = torch.tensor([[-2.5, -1.8, -2.5], [2.2, 1.8, 2.0]])
+    df = SE3DeformationField(aabb, cfg, max_n_samples_per_batch=17)
+    sd = {k[len("df_sd_"):]: torch.from_numpy(z[k]) for k in z.files if k.startswith("df_sd_")}
+    assert set(sd) == set(df.state_dict())            # same state-dict keys as the reference module
+    df.load_state_dict(sd)
+    shapes = [tuple(l.weight.shape) for l in df.se3_field.mlp_stem.layers]
+    assert shapes == [(32, 53), (32, 32), (32, 32), (32, 32), (32, 85), (32, 32)]
+    for i, w in enumerate(z["df_windows"]):
+        w = None if np.isnan(w) else float(w)
+        with torch.no_grad():
+            got = df.compute_offsets(torch.from_numpy(z["df_pos"]), torch.from_numpy(z["df_code"]), w).numpy()
+        assert np.abs(got - z[f"df_off_{i}"]).max() <= 5e-6, i
+
+
+def test_scheduler_and_chunker_match_reference(golden_dir):
+    from nersemble_amd.engine.generic_scheduler import GenericScheduler
+    from nersemble_amd.util.chunker import chunked
+    z = np.load(f"{golden_dir}/misc.npz")
+    s = GenericScheduler(init_value=1, final_value=32, begin_step=40000, end_step=80000)
+    vals = []
+    for st in z["sched_steps"]:
+        s.update(int(st))
+        vals.append(s.get_value())
+    assert np.array_equal(np.array(vals, dtype=np.float64), z["sched_vals"])
+    s.eval()
+    assert s.get_value() == z["sched_eval"][0]
+    a, b = torch.arange(10), torch.arange(20).reshape(10, 2)
+    sizes = [[len(ca), len(cb), int(ca[0]), int(cb[0, 0])] for ca, cn, cb in chunked(4, a, None, b)]
+    assert np.array_equal(np.array(sizes), z["chunk_sizes"])
+    assert [len(c) for c in chunked(3, a)] == z["chunk_single"].tolist()
+
+
+def test_full_size_deformation_shapes():
+    from nersemble_amd.field_components.deformation_field import SE3DeformationField, SE3DeformationFieldConfig
+    cfg = SE3DeformationFieldConfig(warp_code_dim=128, mlp_num_layers=6, mlp_layer_width=128)
+    df = SE3DeformationField(torch.tensor([[-2.5, -1.8, -2.5], [2.2, 1.8, 2.0]]), cfg)
+    shapes = [tuple(l.weight.shape) for l in df.se3_field.mlp_stem.layers]
+    assert shapes == [(128, 173), (128, 128), (128, 128), (128, 128), (128, 301), (128, 128)]
+    assert sum(p.numel() for p in df.parameters()) == 127756

@@ -1,0 +1,187 @@
+"""GPU parity: ray marching (bit-exact), per-ray scans, accumulation, distortion loss vs the C oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import march as om
+
+pytestmark = pytest.mark.gpu
+
+P30 = np.array([-2.5, -1.8, -2.5, 2.2, 1.8, 2.0], np.float32)
+P97 = np.array([-2.2, -2.8, -2.5, 2.2, 2.2, 2.0], np.float32)
+
+
+def _rays(R, seed, axis_aligned=False):
+    rng = np.random.default_rng(seed)
+    o = rng.standard_normal((R, 3)).astype(np.float32)
+    o = o / np.linalg.norm(o, axis=1, keepdims=True) * 9
+    tgt = (rng.random((R, 3)).astype(np.float32) - 0.5) * 3
+    d = tgt - o
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    if axis_aligned:                      # zero direction components + rays that miss the box
+        d[:8] = 0
+        d[:8, 0] = 1
+        o[:8] = [-9, 0.1, 0.2]
+        o[8:16] = [50, 50, 50]
+    return o, d.astype(np.float32)
+
+
+def _grid(res, kind, seed=0):
+    if kind == "ones":
+        return np.ones((res, res, res), bool)
+    if kind == "empty":
+        return np.zeros((res, res, res), bool)
+    g = np.stack(np.meshgrid(*[np.linspace(0, 1, res, endpoint=False) + 0.5 / res] * 3, indexing="ij"), -1)
+    if kind == "shell":
+        r = np.linalg.norm((g - 0.5) / [0.25, 0.3, 0.3], axis=-1)
+        return (r < 1.0) & (r > 0.8)
+    return np.random.default_rng(seed).random((res, res, res)) < 0.07
+
+
+def _est(aabb, binary, cuda):
+    from nersemble_amd.nerfacc import OccGridEstimator
+    est = OccGridEstimator(torch.from_numpy(aabb), resolution=binary.shape[0], levels=1).to(cuda)
+    est.binaries = torch.from_numpy(binary)[None].to(cuda)
+    return est
+
+
+@pytest.mark.parametrize("kind,aabb,res", [("ones", P97, 128), ("shell", P30, 128), ("random", P30, 64),
+                                           ("empty", P30, 32), ("shell", P30, 96)])
+def test_march_bit_exact(kind, aabb, res, cuda):
+    R = 1024
+    o, d = _rays(R, 3, axis_aligned=True)
+    binary = _grid(res, kind)
+    rng = np.random.default_rng(9)
+    near = (0.2 + rng.random(R).astype(np.float32) * np.float32(0.011)).astype(np.float32)   # stratified near planes
+    ri_o, t0_o, t1_o, packed_o, cells_o = om.march(o, d, aabb, binary, near, 1e3, 0.011, want_cells=True)
+    est = _est(aabb, binary, cuda)
+    ri, t0, t1, packed, cells = est.traverse(torch.from_numpy(o).to(cuda), torch.from_numpy(d).to(cuda),
+                                             torch.from_numpy(near).to(cuda), 1e3, 0.011, want_cells=True)
+    assert np.array_equal(packed.cpu().numpy(), packed_o)            # per-ray sample counts + offsets
+    assert np.array_equal(ri.cpu().numpy(), ri_o)                    # ray indices
+    assert np.array_equal(cells.cpu().numpy(), cells_o)              # occupancy-grid cell ids
+    assert np.array_equal(t0.cpu().numpy().view(np.uint32), t0_o.view(np.uint32))   # t values, bitwise
+    assert np.array_equal(t1.cpu().numpy().view(np.uint32), t1_o.view(np.uint32))
+    if kind == "empty":
+        assert ri.numel() == 0
+    if kind == "ones":
+        assert ri.numel() > 200 * (R - 16)
+
+
+def test_sampling_contract_and_visibility(cuda):
+    """OccGridEstimator.sampling: sigma_fn filtering == oracle transmittance/alpha thresholds."""
+    R = 512
+    o, d = _rays(R, 5)
+    binary = _grid(128, "shell")
+    est = _est(P30, binary, cuda)
+    est.occs.fill_(0.5)                     # occs.mean() > alpha_thre -> alpha_thre stays 1e-2
+    ot, dt = torch.from_numpy(o).to(cuda), torch.from_numpy(d).to(cuda)
+
+    def sigma_fn(t0, t1, ri):
+        p = ot[ri] + dt[ri] * ((t0 + t1) / 2)[:, None]
+        return 40.0 * torch.exp(-(p ** 2).sum(-1))
+
+    ri, t0, t1 = est.sampling(ot, dt, sigma_fn=sigma_fn, near_plane=0.2, far_plane=1e3, render_step_size=0.011,
+                              early_stop_eps=0.0, alpha_thre=1e-2, stratified=False)
+    near = np.full(R, 0.2, np.float32)
+    ri_o, t0_o, t1_o, packed_o = om.march(o, d, P30, binary, near, 1e3, 0.011)
+    p = o[ri_o] + d[ri_o] * ((t0_o + t1_o) / 2)[:, None]
+    sig = (40.0 * np.exp(-(p.astype(np.float64) ** 2).sum(-1))).astype(np.float32)
+    w, T, a = om.render_weights(t0_o, t1_o, sig, packed_o)
+    keep = (T >= 0.0) & (a >= 1e-2)
+    # samples whose alpha sits within fp32 noise of the threshold may legitimately differ
+    border = np.abs(a - 1e-2) < 1e-6
+    got = set(zip(ri.cpu().numpy().tolist(), t0.cpu().numpy().view(np.uint32).tolist()))
+    want = set(zip(ri_o[keep].tolist(), t0_o[keep].view(np.uint32).tolist()))
+    amb = set(zip(ri_o[border].tolist(), t0_o[border].view(np.uint32).tolist()))
+    assert (got ^ want) <= amb
+    assert len(got) > 1000
+
+
+def _packed_case(seed, R=300, maxn=300, cuda=None):
+    rng = np.random.default_rng(seed)
+    counts = rng.integers(0, maxn, R)
+    counts[::7] = 0
+    counts[5] = 1
+    counts[6] = 64
+    counts[8] = 65
+    ray_idx = np.repeat(np.arange(R), counts).astype(np.int64)
+    S = len(ray_idx)
+    t0 = np.concatenate([np.sort(rng.random(c)) * 3 + 0.2 for c in counts]).astype(np.float32) if S else np.zeros(0, np.float32)
+    t1 = (t0 + 0.011).astype(np.float32)
+    sigma = (rng.random(S) ** 3 * 30).astype(np.float32)
+    packed = om.pack_info(ray_idx, R)
+    return ray_idx, t0, t1, sigma, packed
+
+
+def test_pack_info_and_render_weights(cuda):
+    from nersemble_amd import nerfacc as nf
+    ray_idx, t0, t1, sigma, packed_o = _packed_case(1)
+    R = packed_o.shape[0]
+    ri = torch.from_numpy(ray_idx).to(cuda)
+    packed = nf.pack_info(ri, R)
+    assert np.array_equal(packed.cpu().numpy(), packed_o)
+    sg = torch.from_numpy(sigma).to(cuda).requires_grad_(True)
+    w, T, a = nf.render_weight_from_density(torch.from_numpy(t0).to(cuda), torch.from_numpy(t1).to(cuda), sg,
+                                            packed_info=packed)
+    w_o, T_o, a_o = om.render_weights(t0, t1, sigma, packed_o)
+    assert np.abs(w.detach().cpu().numpy() - w_o).max() <= 2e-6
+    assert np.abs(T.cpu().numpy() - T_o).max() <= 2e-6
+    assert np.abs(a.cpu().numpy() - a_o).max() <= 2e-6
+    gw = np.random.default_rng(3).standard_normal(len(sigma)).astype(np.float32)
+    w.backward(torch.from_numpy(gw).to(cuda))
+    ds_o = om.render_weights_bwd(t0, t1, sigma, packed_o, gw)
+    assert np.abs(sg.grad.cpu().numpy() - ds_o).max() <= 1e-5 * max(1.0, np.abs(ds_o).max())
+
+
+@pytest.mark.parametrize("Cc", [None, 1, 3])
+def test_accumulate_along_rays(Cc, cuda):
+    from nersemble_amd import nerfacc as nf
+    ray_idx, t0, t1, sigma, packed_o = _packed_case(2)
+    R = packed_o.shape[0]
+    rng = np.random.default_rng(4)
+    w = rng.random(len(ray_idx)).astype(np.float32)
+    v = rng.standard_normal((len(ray_idx), Cc)).astype(np.float32) if Cc else None
+    wt = torch.from_numpy(w).to(cuda).requires_grad_(True)
+    vt = torch.from_numpy(v).to(cuda).requires_grad_(True) if Cc else None
+    out = nf.accumulate_along_rays(wt, vt, ray_indices=torch.from_numpy(ray_idx).to(cuda), n_rays=R)
+    want = om.accumulate(w, v, packed_o)
+    assert np.abs(out.detach().cpu().numpy() - want).max() <= 1e-5 * max(1.0, np.abs(want).max())
+    g = rng.standard_normal(want.shape).astype(np.float32)
+    out.backward(torch.from_numpy(g).to(cuda))
+    vv = v if Cc else np.ones((len(w), 1), np.float32)
+    dw = (vv * g[ray_idx]).sum(1)
+    assert np.abs(wt.grad.cpu().numpy() - dw).max() <= 1e-5 * max(1.0, np.abs(dw).max())
+    if Cc:
+        assert np.abs(vt.grad.cpu().numpy() - w[:, None] * g[ray_idx]).max() <= 1e-6
+
+
+def test_flatten_eff_distloss(cuda):
+    from nersemble_amd.distloss import flatten_eff_distloss
+    ray_idx, t0, t1, sigma, packed_o = _packed_case(6)
+    # torch_efficient_distloss semantics: n_rays = ray_id.max()+1
+    n_rays = int(ray_idx.max()) + 1
+    w_o, _, _ = om.render_weights(t0, t1, sigma, packed_o)
+    m, iv = ((t0 + t1) * 0.5).astype(np.float32), (t1 - t0).astype(np.float32)
+    loss_o, g_o = om.distloss(w_o, m, iv, om.pack_info(ray_idx, n_rays), n_rays)
+    wt = torch.from_numpy(w_o).to(cuda).requires_grad_(True)
+    loss = flatten_eff_distloss(wt, torch.from_numpy(m).to(cuda), torch.from_numpy(iv).to(cuda),
+                                torch.from_numpy(ray_idx).to(cuda))
+    assert abs(loss.item() - loss_o) <= 1e-5 * max(1e-3, abs(loss_o))
+    (loss * 3.0).backward()
+    assert np.abs(wt.grad.cpu().numpy() - 3.0 * g_o).max() <= 2e-5 * max(1e-3, np.abs(g_o).max() * 3)
+
+
+def test_distloss_selection_matches_reference_golden(cuda, golden_dir):
+    """BaseModel.get_dist_loss sample selection (ray_indices < max_rays), midpoints, intervals: golden from the
+    reference's own models/base.py:224-249 with a recording stub."""
+    from nersemble_amd.models.base import select_dist_loss_samples
+    z = np.load(f"{golden_dir}/misc.npz")
+    ri = torch.from_numpy(z["dl_ray_idx"]).to(cuda)
+    w, m, iv, rid = select_dist_loss_samples(ri, torch.from_numpy(z["dl_weights"]).to(cuda),
+                                             torch.from_numpy(z["dl_starts"]).to(cuda)[:, None],
+                                             torch.from_numpy(z["dl_ends"]).to(cuda)[:, None], max_rays=5)
+    assert np.array_equal(rid.cpu().numpy(), z["dl_sel_ray_id"])
+    assert np.array_equal(w.cpu().numpy(), z["dl_sel_w"])
+    assert np.array_equal(m.cpu().numpy(), z["dl_sel_m"])
+    assert np.array_equal(iv.cpu().numpy(), z["dl_sel_interval"])
