@@ -147,6 +147,34 @@ int nsx_mlp_bwd(const nsx_half* weights, int n_hidden_mats, int64_t B,
                 float* dweights, float* da, nsx_half* db, void* stream);
 int nsx_f32_to_f16(const float* src, nsx_half* dst, int64_t n, void* stream);
 
+/* ---- fused SE(3) deformation field -------------------------------------------------------------------------
+ * Replaces SE3DeformationField.compute_offsets (deformation_field.py:148-166): WindowedNeRFEncoding
+ * (windowed_nerf_encoding.py:33-74) + torch.cat with the warp code + 6x128 MLP with a skip into layer 4 + the
+ * two 128->3 heads (8 nn.Linear GEMMs under fp16 autocast, deformation_field.py:50-69,85-88) + se3_exp_map
+ * (util/pytorch3d.py:107-191) + homogeneous warp with NaN fallback (:96-102), as one MFMA kernel.
+ *   params     flat fp32 [nsx_deform_param_count()]:  W0[128][173] b0 | W1 b1 | W2 b2 | W3 b3 | W4[128][301] b4 |
+ *              W5 b5 | Wr[3][128] br | Wv[3][128] bv   (the reference's mlp_stem.layers.{0..5}, mlp_r, mlp_v)
+ *   packed     device scratch of nsx_deform_pack_bytes(): fp16 MFMA weight fragments + fp16-rounded biases,
+ *              refreshed with nsx_deform_pack whenever the parameters change
+ *   positions  [S][3] fp32 WORLD positions; aabb_host = 6 host floats; offsets are in NORMALISED space
+ *              (warped - normalised, deformation_field.py:162)
+ *   code / code_slot: warp code rows (fp32, stride code_stride); row of sample s = code_slot ? code_slot[s] : s
+ *   window7_host: 7 per-frequency window weights (host), NULL = no window (windows_param None)
+ * Backward (recomputes the forward; scratch of nsx_deform_scratch_bytes(S)): grad_params fp32 [param_count] and
+ * grad_code_table fp32 [n_code_rows][128] (needs code_slot, n_code_rows <= 128) are ACCUMULATED into (caller
+ * zeroes); grad_code_samples fp32 [S][128] (per-sample code gradient, written) -- either may be NULL. */
+int     nsx_deform_param_count(void);
+int64_t nsx_deform_pack_bytes(void);
+int64_t nsx_deform_scratch_bytes(int64_t S);
+int nsx_deform_pack(const float* params, void* packed, void* stream);
+int nsx_deform_fwd(const void* packed, const float* positions, int64_t S, const float* aabb_host, const float* code,
+                   int64_t code_stride, const int32_t* code_slot, const float* window7_host, float* offsets,
+                   void* stream);
+int nsx_deform_bwd(const void* packed, const float* positions, int64_t S, const float* aabb_host, const float* code,
+                   int64_t code_stride, const int32_t* code_slot, int n_code_rows, const float* window7_host,
+                   const float* grad_offsets, void* scratch, float* grad_params, float* grad_code_table,
+                   float* grad_code_samples, void* stream);
+
 /* ---- occupancy-grid ray marching (nerfacc 0.5.2 traverse_grids equivalent) -----------------------------
  * Replaces the native part of OccGridEstimator.sampling called at nersemble_volumetric_sampler.py:95-108:
  * ray/AABB slab test + DDA through ONE res^3 boolean grid level (grid_levels=1, train_nersemble.py:100) +

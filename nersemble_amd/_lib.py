@@ -56,6 +56,14 @@ SIGNATURES = {
     "nsx_mlp_bwd": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_int64, c_int, c_float, c_float, c_void_p, c_int64,
                             c_int, c_int, c_int, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "nsx_f32_to_f16": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "nsx_deform_param_count": (c_int, []),
+    "nsx_deform_pack_bytes": (c_int64, []),
+    "nsx_deform_scratch_bytes": (c_int64, [c_int64]),
+    "nsx_deform_pack": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "nsx_deform_fwd": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p,
+                               c_void_p]),
+    "nsx_deform_bwd": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int, c_void_p,
+                               c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "nsx_march_count": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_void_p, c_float, c_float,
                                 c_void_p, c_void_p]),
     "nsx_pack_info": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),

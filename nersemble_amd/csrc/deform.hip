@@ -1,0 +1,707 @@
+// deform.hip -- fused SE(3) deformation field for gfx950: windowed positional encoding + 6x128 MLP (skip into
+// layer 4) + rotation/translation heads + SE(3) exponential map + warp, forward and backward, on MFMA.
+//
+// Replaces SE3DeformationField.compute_offsets / SE3WarpingField.forward of the reference
+// (src/nersemble/nerfstudio/field_components/deformation_field.py:77-116,148-166), which runs
+// WindowedNeRFEncoding (windowed_nerf_encoding.py:33-74), torch.cat with the per-sample warp code, eight
+// nn.Linear GEMMs under fp16 autocast (nerfstudio MLP), se3_exp_map (util/pytorch3d.py:107-191) and a batched
+// 4x4 matmul as ~50 separate launches.  Numerics follow the autocast path: inputs / weights / biases rounded to
+// fp16, fp32 accumulation, every layer output rounded to fp16, exponential map and warp in fp32.
+//
+// MI355X design
+//   * v_mfma_f32_32x32x16_f16 with D[neuron][sample]: a wave owns 32 samples; the accumulator layout of one
+//     layer is the B-operand layout of the next up to a k-permutation that is folded into pre-packed weight
+//     fragments, so the 6 layers + heads chain entirely in registers (same trick as mlp.hip, 4 M-tiles wide).
+//   * the warp code is never gathered to [S,128]: each sample carries a slot into the batch's small code table
+//     (nersemble_instant_ngp.py:310-316 materialises the gather; its backward was a 46 ms index_put).
+//   * weights are packed once per step into MFMA fragment order (fp16) and streamed from L2.
+//   * backward recomputes the forward (only ReLU bit masks are kept), chains dZ through W^T fragments, and
+//     writes dZ / activation tiles in [neuron][sample] order; weight, bias and code-table gradients are then
+//     sample-contracted GEMMs (deform_wgrad_kernel) -- the only form in which K = #samples fits MFMA.
+#include "nsx_common.h"
+
+namespace nsx {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int DFW = 128;        // layer width
+constexpr int DF_PE = 45;       // 42 windowed sin/cos + 3 scaled inputs
+constexpr int DF_CODE = 128;    // warp code width
+constexpr int DF_IN = DF_PE + DF_CODE;      // 173
+constexpr int DF_TIN = 11;
+constexpr int DF_TW = 8;
+constexpr int DF_W4 = DF_IN + DFW;          // 301
+
+// flat fp32 parameter layout (host packs the nn.Linear tensors in this order)
+constexpr int P_W0 = 0;
+constexpr int P_B0 = P_W0 + DFW * DF_IN;
+constexpr int P_W1 = P_B0 + DFW;
+constexpr int P_B1 = P_W1 + DFW * DFW;
+constexpr int P_W2 = P_B1 + DFW;
+constexpr int P_B2 = P_W2 + DFW * DFW;
+constexpr int P_W3 = P_B2 + DFW;
+constexpr int P_B3 = P_W3 + DFW * DFW;
+constexpr int P_W4 = P_B3 + DFW;
+constexpr int P_B4 = P_W4 + DFW * DF_W4;
+constexpr int P_W5 = P_B4 + DFW;
+constexpr int P_B5 = P_W5 + DFW * DFW;
+constexpr int P_WR = P_B5 + DFW;            // [3][128]
+constexpr int P_BR = P_WR + 3 * DFW;
+constexpr int P_WV = P_BR + 3;
+constexpr int P_BV = P_WV + 3 * DFW;
+constexpr int P_TOTAL = P_BV + 3;           // 127 750
+
+// fragment groups (each fragment = 64 lanes x 8 halfs)
+constexpr int F0 = 0;                       // [4][11]
+constexpr int F1 = F0 + 44, F2 = F1 + 32, F3 = F2 + 32;
+constexpr int F4 = F3 + 32;                 // [4][19]
+constexpr int F5 = F4 + 76;
+constexpr int FH = F5 + 32;                 // [1][8]
+constexpr int N_FWD_FRAGS = FH + 8;         // 256
+constexpr int BH = N_FWD_FRAGS;             // [4][1]
+constexpr int B5 = BH + 4, B4X = B5 + 32, B4C = B4X + 32, B3 = B4C + 32, B2 = B3 + 32, B1 = B2 + 32;
+constexpr int B0C = B1 + 32;
+constexpr int N_FRAGS = B0C + 32;           // 484
+constexpr int N_BIAS = 6 * DFW + 8;         // + heads (6, padded to 8)
+
+__device__ __host__ __forceinline__ int acc_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
+__device__ __host__ __forceinline__ int kchain(int t, int kb, int j) { return 32 * (t >> 1) + acc_row(8 * (t & 1) + j, kb); }
+__device__ __forceinline__ f32x16 mfma(f16x8 a, f16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 zero16() {
+    f32x16 z;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) z[i] = 0.f;
+    return z;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// weight packing: fp32 nn.Linear parameters -> fp16 MFMA fragments (+ fp16-rounded biases as fp32)
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float pack_source(const float* __restrict__ P, int fi, int i, int kb, int j) {
+    auto lin = [&](int wbase, int ld, int row, int col) { return P[wbase + row * ld + col]; };
+    if (fi < F1) {                                   // W0 natural k
+        const int mt = (fi - F0) / DF_TIN, t = (fi - F0) % DF_TIN, k = 16 * t + 8 * kb + j;
+        return k < DF_IN ? lin(P_W0, DF_IN, 32 * mt + i, k) : 0.f;
+    }
+    if (fi < F4) {                                   // W1..W3
+        const int l = (fi - F1) / 32, r = (fi - F1) % 32, mt = r / DF_TW, t = r % DF_TW;
+        const int base = l == 0 ? P_W1 : (l == 1 ? P_W2 : P_W3);
+        return lin(base, DFW, 32 * mt + i, kchain(t, kb, j));
+    }
+    if (fi < F5) {                                   // W4: 11 natural steps over the input, 8 chained over x
+        const int mt = (fi - F4) / 19, t = (fi - F4) % 19;
+        if (t < DF_TIN) {
+            const int k = 16 * t + 8 * kb + j;
+            return k < DF_IN ? lin(P_W4, DF_W4, 32 * mt + i, k) : 0.f;
+        }
+        return lin(P_W4, DF_W4, 32 * mt + i, DF_IN + kchain(t - DF_TIN, kb, j));
+    }
+    if (fi < FH) {                                   // W5
+        const int mt = (fi - F5) / DF_TW, t = (fi - F5) % DF_TW;
+        return lin(P_W5, DFW, 32 * mt + i, kchain(t, kb, j));
+    }
+    if (fi < BH) {                                   // heads: rows 0..2 = r, 3..5 = v
+        const int t = fi - FH, k = kchain(t, kb, j);
+        if (i < 3) return lin(P_WR, DFW, i, k);
+        if (i < 6) return lin(P_WV, DFW, i - 3, k);
+        return 0.f;
+    }
+    if (fi < B5) {                                   // heads^T: M = hidden neuron, K-step 0 over head rows
+        const int mt = fi - BH, o = kchain(0, kb, j);
+        if (o < 3) return lin(P_WR, DFW, o, 32 * mt + i);
+        if (o < 6) return lin(P_WV, DFW, o - 3, 32 * mt + i);
+        return 0.f;
+    }
+    const int g = (fi - B5) / 32, r = (fi - B5) % 32, mt = r / DF_TW, t = r % DF_TW, o = kchain(t, kb, j);
+    switch (g) {
+        case 0: return lin(P_W5, DFW, o, 32 * mt + i);                 // B5
+        case 1: return lin(P_W4, DF_W4, o, DF_IN + 32 * mt + i);       // B4x
+        case 2: return lin(P_W4, DF_W4, o, DF_PE + 32 * mt + i);       // B4c (code columns)
+        case 3: return lin(P_W3, DFW, o, 32 * mt + i);
+        case 4: return lin(P_W2, DFW, o, 32 * mt + i);
+        case 5: return lin(P_W1, DFW, o, 32 * mt + i);
+        default: return lin(P_W0, DF_IN, o, DF_PE + 32 * mt + i);      // B0c
+    }
+}
+
+__global__ void deform_pack_kernel(const float* __restrict__ P, f16x8* __restrict__ frags, float* __restrict__ bias) {
+    const int total = N_FRAGS * 64;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        const int fi = e / 64, ll = e % 64, i = ll & 31, kb = ll >> 5;
+        f16x8 v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (half_t)pack_source(P, fi, i, kb, j);
+        frags[e] = v;
+    }
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < N_BIAS; e += gridDim.x * blockDim.x) {
+        float b = 0.f;
+        if (e < 6 * DFW) {
+            const int l = e / DFW, n = e % DFW;
+            const int base = l == 0 ? P_B0 : l == 1 ? P_B1 : l == 2 ? P_B2 : l == 3 ? P_B3 : l == 4 ? P_B4 : P_B5;
+            b = P[base + n];
+        } else {
+            const int o = e - 6 * DFW;
+            if (o < 3) b = P[P_BR + o];
+            else if (o < 6) b = P[P_BV + o - 3];
+        }
+        bias[e] = (float)(half_t)b;            // autocast rounds the bias to fp16
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// shared device pieces
+// ---------------------------------------------------------------------------------------------------------
+struct DeformArgs {
+    const float* pos;            // [S][3] world positions
+    const float* code;           // code rows (fp32)
+    int64_t code_stride;
+    const int32_t* slot;         // [S] row per sample, or nullptr -> row = sample
+    float aabb_min[3], aabb_inv[3], aabb_ext[3];
+    float window[7];             // per-frequency window (all ones when windows_param is None)
+    const f16x8* frags;
+    const float* bias;
+    int64_t S;
+};
+
+// input fragments of sample b for lane half kb, natural k order (k = 16 t + 8 kb + j):
+//   k <  21 : w[f] * sin(2 pi pn_d 2^f)          (k = 7 d + f)        windowed_nerf_encoding.py:47-70
+//   k <  42 : w[f] * sin(2 pi pn_d 2^f + pi/2)
+//   k <  45 : 2 pi pn_d                           (the 2 pi-SCALED input is appended, :72-73)
+//   k < 173 : warp code
+// sin(2 pi x) is the native v_sin_f32 (input in revolutions, range-reduced in hardware).
+__device__ __forceinline__ void build_input(const DeformArgs& A, int64_t b, int kb, float pn[3], f16x8 x[DF_TIN]) {
+#pragma unroll
+    for (int d = 0; d < 3; ++d) pn[d] = (A.pos[b * 3 + d] - A.aabb_min[d]) / A.aabb_ext[d];
+    const float* crow = A.code + (A.slot ? (int64_t)A.slot[b] : b) * A.code_stride;
+    // k depends on the lane half only through + 8 kb: evaluate both compile-time variants and select, so that the
+    // frequency / axis / window indices are constants (no dynamically indexed kernel-argument arrays)
+    auto pe_value = [&](int k) -> float {
+        if (k < 42) {
+            const int kk = k < 21 ? k : k - 21;
+            const int d = kk / 7, f = kk - 7 * d;
+            const float rev = pn[d] * (float)(1 << f) + (k >= 21 ? 0.25f : 0.f);
+            return A.window[f] * __builtin_amdgcn_sinf(rev);
+        }
+        if (k < DF_PE) return 6.283185307179586f * pn[k - 42];
+        return 0.f;                                   // code part handled by the caller
+    };
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k0 = 16 * t + j, k1 = k0 + 8;
+            float v0 = k0 < DF_PE ? pe_value(k0) : 0.f;
+            float v1 = k1 < DF_PE ? pe_value(k1) : 0.f;
+            float v = kb ? v1 : v0;
+            const int k = k0 + 8 * kb;
+            if (k1 >= DF_PE) {                         // at least the kb = 1 variant is a code element
+                const int kc = k - DF_PE;
+                const float cv = crow[kc < 0 ? 0 : kc];
+                if (k >= DF_PE) v = cv;
+            }
+            x[t][j] = (half_t)v;
+        }
+    }
+#pragma unroll
+    for (int t = 3; t < DF_TIN; ++t) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = 16 * t + 8 * kb + j;
+            x[t][j] = (k < DF_IN) ? (half_t)crow[k - DF_PE] : (half_t)0.f;
+        }
+    }
+}
+
+// acc (+bias) -> relu -> fp16 fragments (chained k order) ; returns a 64-bit mask of positive units (bit 8 t + j)
+__device__ __forceinline__ uint64_t finish_layer(const f32x16 acc[4], const float* __restrict__ bias, int kb,
+                                                 f16x8 h[DF_TW]) {
+    uint64_t mask = 0;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float v = acc[mt][r] + bias[32 * mt + acc_row(r, kb)];
+            const half_t hv = (half_t)v;                       // Linear output in fp16 ...
+            const half_t rl = (float)hv <= 0.f ? (half_t)0.f : hv;  // ... then ReLU (NaN propagates like torch.relu)
+            h[2 * mt + (r >> 3)][r & 7] = rl;
+            if ((float)hv > 0.f) mask |= (1ull << (8 * (2 * mt + (r >> 3)) + (r & 7)));
+        }
+    }
+    return mask;
+}
+
+// acc[mt] += sum_t W_frag(group, mt, t) * in[t].  Weight fragments stream from L2 with a one-step software
+// prefetch; the compiler barrier keeps it from hoisting a whole layer of fragment loads into registers.
+// one weight fragment: uniform (scalar) base + 16 B per lane -> global_load_dwordx4 with an SGPR base address
+__device__ __forceinline__ f16x8 load_frag(const f16x8* __restrict__ frags, int fi, uint32_t voff) {
+    const char* ub = reinterpret_cast<const char*>(frags) + (size_t)fi * 1024;
+    return *reinterpret_cast<const f16x8*>(ub + voff);
+}
+
+template <int KT>
+__device__ __forceinline__ void gemm_layer(const f16x8* __restrict__ frags, int group, int lane, const f16x8* in,
+                                           f32x16 acc[4], int t_off = 0, int kt_total = KT) {
+    const uint32_t voff = (uint32_t)lane * 16u;
+    const int g0 = group + t_off;
+    f16x8 a[4], nx[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) a[mt] = load_frag(frags, g0 + mt * kt_total, voff);
+#pragma unroll
+    for (int t = 0; t < KT; ++t) {
+        if (t + 1 < KT) {
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) nx[mt] = load_frag(frags, g0 + mt * kt_total + t + 1, voff);
+        }
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) acc[mt] = mfma(a[mt], in[t], acc[mt]);
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) a[mt] = nx[mt];
+    }
+}
+
+struct Fwd {
+    f16x8 x[DF_TIN];
+    f16x8 h[DF_TW];              // current activation
+    uint64_t m1, m2, m3, m4, m5, m6;
+    float pn[3];
+    float r[3], v[3];            // head outputs (fp16-rounded), valid on both lanes of a sample
+};
+
+// store fragments (chained k order) as a [neuron][32 samples] fp16 tile
+__device__ __forceinline__ void store_tile_chain(half_t* __restrict__ tile, int n, int kb, const f16x8 h[DF_TW]) {
+#pragma unroll
+    for (int t = 0; t < DF_TW; ++t)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) tile[kchain(t, kb, j) * 32 + n] = h[t][j];
+}
+
+// forward of one tile; when tiles != nullptr also writes a0..a6 as [neuron][sample] tiles for the wgrad GEMMs
+// Loop-invariant-code motion would hoist every bias value and fragment address (hundreds of VGPRs) out of the
+// persistent tile loop; laundering the uniform base pointers once per tile keeps them as in-loop loads.
+template <typename T>
+__device__ __forceinline__ const T* launder(const T* p) {
+    asm volatile("" : "+s"(p));
+    return p;
+}
+
+__device__ __forceinline__ void forward_tile(const DeformArgs& A0, int64_t b, int lane, Fwd& F, half_t* a_tiles) {
+    DeformArgs A = A0;
+    A.frags = launder(A0.frags);
+    A.bias = launder(A0.bias);
+    const int n = lane & 31, kb = lane >> 5;
+    build_input(A, b, kb, F.pn, F.x);
+    if (a_tiles) {
+#pragma unroll
+        for (int t = 0; t < DF_TIN; ++t)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a_tiles[(16 * t + 8 * kb + j) * 32 + n] = F.x[t][j];
+    }
+    f32x16 acc[4];
+    // L0
+    for (int i = 0; i < 4; ++i) acc[i] = zero16();
+    gemm_layer<DF_TIN>(A.frags, F0, lane, F.x, acc);
+    F.m1 = finish_layer(acc, A.bias + 0 * DFW, kb, F.h);
+    if (a_tiles) store_tile_chain(a_tiles + 192 * 32 + 0 * DFW * 32, n, kb, F.h);
+    // L1..L3 (the input fragments are dead once the layer's MFMAs are issued: the output overwrites them)
+#pragma unroll 1
+    for (int l = 1; l <= 3; ++l) {
+        for (int i = 0; i < 4; ++i) acc[i] = zero16();
+        gemm_layer<DF_TW>(A.frags, l == 1 ? F1 : (l == 2 ? F2 : F3), lane, F.h, acc);
+        const uint64_t m = finish_layer(acc, A.bias + l * DFW, kb, F.h);
+        if (l == 1) F.m2 = m; else if (l == 2) F.m3 = m; else F.m4 = m;
+        if (a_tiles) store_tile_chain(a_tiles + 192 * 32 + l * DFW * 32, n, kb, F.h);
+    }
+    // L4: cat[input, x]
+    for (int i = 0; i < 4; ++i) acc[i] = zero16();
+    gemm_layer<DF_TIN>(A.frags, F4, lane, F.x, acc, 0, 19);
+    gemm_layer<DF_TW>(A.frags, F4, lane, F.h, acc, DF_TIN, 19);
+    F.m5 = finish_layer(acc, A.bias + 4 * DFW, kb, F.h);
+    if (a_tiles) store_tile_chain(a_tiles + 192 * 32 + 4 * DFW * 32, n, kb, F.h);
+    // L5 (+ out_activation ReLU)
+    for (int i = 0; i < 4; ++i) acc[i] = zero16();
+    gemm_layer<DF_TW>(A.frags, F5, lane, F.h, acc);
+    F.m6 = finish_layer(acc, A.bias + 5 * DFW, kb, F.h);
+    if (a_tiles) store_tile_chain(a_tiles + 192 * 32 + 5 * DFW * 32, n, kb, F.h);
+    // heads (one M-tile, rows 0..5)
+    f32x16 o = zero16();
+#pragma unroll
+    for (int t = 0; t < DF_TW; ++t) o = mfma(load_frag(A.frags, FH + t, (uint32_t)lane * 16u), F.h[t], o);
+    float own[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) own[r] = (float)(half_t)(o[r] + A.bias[6 * DFW + acc_row(r, kb)]);
+    float oth[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) oth[r] = __shfl_xor(own[r], 32);
+    // rows 0..3 live on kb = 0, rows 4..7 on kb = 1
+    const float r0 = kb ? oth[0] : own[0], r1 = kb ? oth[1] : own[1], r2 = kb ? oth[2] : own[2];
+    const float v0 = kb ? oth[3] : own[3], v1 = kb ? own[0] : oth[0], v2 = kb ? own[1] : oth[1];
+    F.r[0] = r0; F.r[1] = r1; F.r[2] = r2;
+    F.v[0] = v0; F.v[1] = v1; F.v[2] = v2;
+}
+
+__device__ __forceinline__ void cross3(const float a[3], const float b[3], float c[3]) {
+    c[0] = a[1] * b[2] - a[2] * b[1];
+    c[1] = a[2] * b[0] - a[0] * b[2];
+    c[2] = a[0] * b[1] - a[1] * b[0];
+}
+__device__ __forceinline__ float dot3(const float a[3], const float b[3]) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+
+struct Se3Coef { float theta, a, b, c; bool clamped; };
+
+__device__ __forceinline__ Se3Coef se3_coef(const float r[3]) {
+    Se3Coef q;
+    const float nr = dot3(r, r);
+    q.clamped = nr < 1e-4f;
+    q.theta = sqrtf(fmaxf(nr, 1e-4f));
+    const float inv = 1.0f / q.theta, s = sinf(q.theta), co = cosf(q.theta);
+    q.a = inv * s;
+    q.b = inv * inv * (1.0f - co);
+    q.c = (q.theta - s) / (q.theta * q.theta * q.theta);
+    return q;
+}
+
+// warped = R p + V v  (Rodrigues with K^2 = r r^T - |r|^2 I)
+__device__ __forceinline__ void se3_apply(const float r[3], const float v[3], const float p[3], float out[3]) {
+    const Se3Coef q = se3_coef(r);
+    float u1[3], u2[3], w1[3], w2[3];
+    cross3(r, p, u1); cross3(r, u1, u2);
+    cross3(r, v, w1); cross3(r, w1, w2);
+#pragma unroll
+    for (int d = 0; d < 3; ++d) out[d] = p[d] + q.a * u1[d] + q.b * u2[d] + v[d] + q.b * w1[d] + q.c * w2[d];
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// forward kernel
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void deform_fwd_kernel(DeformArgs A, float* __restrict__ offsets, int64_t n_tiles) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
+        const int64_t b_raw = tile * 32 + (lane & 31);
+        const int64_t b = b_raw < A.S ? b_raw : A.S - 1;
+        Fwd F;
+        forward_tile(A, b, lane, F, nullptr);
+        float w[3];
+        se3_apply(F.r, F.v, F.pn, w);
+        if (b_raw < A.S && (lane >> 5) == 0) {
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                const float wd = (w[d] != w[d]) ? F.pn[d] : w[d];          // NaN deformation -> keep the point
+                offsets[b * 3 + d] = wd - F.pn[d];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// backward chain kernel: writes per-tile a0..a6, dZ0..dZ5, dZheads, dCode tiles
+// ---------------------------------------------------------------------------------------------------------
+// per sample-tile scratch layout (halfs): a0 [192][32] | a1..a6 [6][128][32] | dZ0..dZ5 [6][128][32] | dZh [32][32] | dC [128][32]
+constexpr int64_t TILE_A0 = 0;
+constexpr int64_t TILE_A = 192 * 32;
+constexpr int64_t TILE_DZ = TILE_A + 6 * DFW * 32;
+constexpr int64_t TILE_DZH = TILE_DZ + 6 * DFW * 32;
+constexpr int64_t TILE_DC = TILE_DZH + 32 * 32;
+constexpr int64_t TILE_HALFS = TILE_DC + DFW * 32;        // 60 416 halfs = 118 KB per 32 samples
+
+__device__ __forceinline__ void mask_pack(const f32x16 d[4], uint64_t mask, f16x8 dz[DF_TW]) {
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int t = 2 * mt + (r >> 3), j = r & 7;
+            dz[t][j] = ((mask >> (8 * t + j)) & 1ull) ? (half_t)d[mt][r] : (half_t)0.f;
+        }
+}
+
+__global__ __launch_bounds__(256, 1) void deform_bwd_kernel(DeformArgs A, const float* __restrict__ goff,
+                                                         half_t* __restrict__ scratch, int64_t n_tiles,
+                                                         float* __restrict__ gcode_samples) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = lane & 31, kb = lane >> 5;
+    for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
+        const int64_t b_raw = tile * 32 + n;
+        const bool valid = b_raw < A.S;
+        const int64_t b = valid ? b_raw : A.S - 1;
+        half_t* T = scratch + tile * TILE_HALFS;
+        Fwd F;
+        forward_tile(A, b, lane, F, T);
+        const f16x8* frags_l = launder(A.frags);
+        // ---- SE(3) backward (fp32): g = dL/dwarped ----
+        float g[3] = {0.f, 0.f, 0.f};
+        if (valid) { g[0] = goff[b * 3]; g[1] = goff[b * 3 + 1]; g[2] = goff[b * 3 + 2]; }
+        float wchk[3];
+        se3_apply(F.r, F.v, F.pn, wchk);
+#pragma unroll
+        for (int d = 0; d < 3; ++d) if (wchk[d] != wchk[d]) g[d] = 0.f;       // NaN fallback branch has no gradient
+        const Se3Coef q = se3_coef(F.r);
+        const float* r = F.r; const float* v = F.v; const float* p = F.pn;
+        float u1[3], u2[3], w1[3], w2[3], t1[3], t2[3];
+        cross3(r, p, u1); cross3(r, u1, u2); cross3(r, v, w1); cross3(r, w1, w2);
+        float dv[3], dr[3];
+        // dL/dv = V^T g = g - b (r x g) + c (r x (r x g))
+        cross3(r, g, t1); cross3(r, t1, t2);
+#pragma unroll
+        for (int d = 0; d < 3; ++d) dv[d] = g[d] - q.b * t1[d] + q.c * t2[d];
+        const float th = q.theta, s = sinf(th), co = cosf(th);
+        const float dLa = dot3(g, u1), dLb = dot3(g, u2) + dot3(g, w1), dLc = dot3(g, w2);
+        const float da = (th * co - s) / (th * th);
+        const float db = (th * s - 2.0f * (1.0f - co)) / (th * th * th);
+        const float dc = (3.0f * s - 2.0f * th - th * co) / (th * th * th * th);
+        const float dth = q.clamped ? 0.f : (dLa * da + dLb * db + dLc * dc) / th;
+        float pxg[3], vxg[3];
+        cross3(p, g, pxg); cross3(v, g, vxg);
+        const float rp = dot3(r, p), gr = dot3(g, r), gp = dot3(g, p), rv = dot3(r, v), gv = dot3(g, v);
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+            dr[d] = dth * r[d] + q.a * pxg[d] + q.b * (g[d] * rp + p[d] * gr - 2.0f * r[d] * gp) + q.b * vxg[d]
+                    + q.c * (g[d] * rv + v[d] * gr - 2.0f * r[d] * gv);
+        // head gradient fragment (K-step 0, chained rows): kb=0 -> rows 0..3 = dr0,dr1,dr2,dv0 ; kb=1 -> rows 4..7 = dv1,dv2,0,0
+        f16x8 dzh;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dzh[j] = (half_t)0.f;
+        if (kb == 0) { dzh[0] = (half_t)dr[0]; dzh[1] = (half_t)dr[1]; dzh[2] = (half_t)dr[2]; dzh[3] = (half_t)dv[0]; }
+        else         { dzh[0] = (half_t)dv[1]; dzh[1] = (half_t)dv[2]; }
+        {   // dZh tile [32 rows][32 samples] (rows >= 6 zero)
+            half_t* Z = T + TILE_DZH;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                Z[acc_row(j, kb) * 32 + n] = dzh[j];
+                Z[acc_row(8 + j, kb) * 32 + n] = (half_t)0.f;
+            }
+        }
+        // ---- chain ----
+        f32x16 d[4];
+        f16x8 dz[DF_TW];
+        // dA6 = heads^T dzh ; dZ5 = dA6 * relu'(a6)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) d[mt] = mfma(load_frag(frags_l, BH + mt, (uint32_t)lane * 16u), dzh, zero16());
+        mask_pack(d, F.m6, dz);
+        store_tile_chain(T + TILE_DZ + 5 * DFW * 32, n, kb, dz);
+        // dA5 = W5^T dZ5 ; dZ4
+        for (int i = 0; i < 4; ++i) d[i] = zero16();
+        gemm_layer<DF_TW>(frags_l, B5, lane, dz, d);
+        mask_pack(d, F.m5, dz);
+        store_tile_chain(T + TILE_DZ + 4 * DFW * 32, n, kb, dz);
+        // keep dZ4 for the code gradient (dC = W4[:, code]^T dZ4 + W0[:, code]^T dZ0), formed at the end
+        f16x8 dz4[DF_TW];
+#pragma unroll
+        for (int t = 0; t < DF_TW; ++t) dz4[t] = dz[t];
+        // dA4 = W4[:, x]^T dZ4 ; dZ3
+        for (int i = 0; i < 4; ++i) d[i] = zero16();
+        gemm_layer<DF_TW>(frags_l, B4X, lane, dz, d);
+        mask_pack(d, F.m4, dz);
+        store_tile_chain(T + TILE_DZ + 3 * DFW * 32, n, kb, dz);
+        // L3 -> L2 -> L1
+        for (int i = 0; i < 4; ++i) d[i] = zero16();
+        gemm_layer<DF_TW>(frags_l, B3, lane, dz, d);
+        mask_pack(d, F.m3, dz);
+        store_tile_chain(T + TILE_DZ + 2 * DFW * 32, n, kb, dz);
+        for (int i = 0; i < 4; ++i) d[i] = zero16();
+        gemm_layer<DF_TW>(frags_l, B2, lane, dz, d);
+        mask_pack(d, F.m2, dz);
+        store_tile_chain(T + TILE_DZ + 1 * DFW * 32, n, kb, dz);
+        for (int i = 0; i < 4; ++i) d[i] = zero16();
+        gemm_layer<DF_TW>(frags_l, B1, lane, dz, d);
+        mask_pack(d, F.m1, dz);
+        store_tile_chain(T + TILE_DZ + 0 * DFW * 32, n, kb, dz);
+        f32x16 dcode[4];
+        for (int i = 0; i < 4; ++i) dcode[i] = zero16();
+        gemm_layer<DF_TW>(frags_l, B0C, lane, dz, dcode);
+        gemm_layer<DF_TW>(frags_l, B4C, lane, dz4, dcode);
+        {
+            half_t* Cc = T + TILE_DC;       // natural code index: row = 32 mt + acc_row(r, kb)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int rr = 0; rr < 16; ++rr)
+                    Cc[(32 * mt + acc_row(rr, kb)) * 32 + n] = valid ? (half_t)dcode[mt][rr] : (half_t)0.f;
+            if (gcode_samples && valid) {
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int rr = 0; rr < 16; ++rr)
+                        gcode_samples[b * DF_CODE + 32 * mt + acc_row(rr, kb)] = dcode[mt][rr];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// sample-contracted GEMMs: C[M][N] += sum_tiles A_tile[M][32] * B_tile[N][32]^T  (fp16 tiles, fp32 atomics)
+// ---------------------------------------------------------------------------------------------------------
+struct WgradJob {
+    int64_t a_off;       // offset (halfs) of the A tile inside a sample-tile scratch block; -1 => one-hot of slot
+    int64_t b_off;       // offset of the B tile
+    int m_rows;          // valid rows of A (<= 128)
+    int n_rows;          // valid rows of B
+    int ldc;             // leading dimension of C
+    int64_t c_off;       // offset (floats) into the flat gradient buffer (or the code-table gradient for one-hot)
+    int64_t bias_off;    // >= 0: also accumulate row sums of A there
+    int n_tile0;         // first 32-row block of B handled by job instance (set per launch)
+};
+
+__global__ __launch_bounds__(256) void deform_wgrad_kernel(const half_t* __restrict__ scratch, int64_t n_tiles,
+                                                           WgradJob job, int n_ntiles, const int32_t* __restrict__ slot,
+                                                           int64_t S, float* __restrict__ C, int chunks) {
+    // block = 4 waves; wave w handles n-tile (blockIdx.x * 4 + w) % n_ntiles ... simpler: grid.x = n_ntiles, grid.y = chunks
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 31, kb = lane >> 5;
+    const int nt = blockIdx.x;
+    const int chunk = blockIdx.y * 4 + wave;
+    const int total_chunks = chunks * 4;
+    const int64_t per = (n_tiles + total_chunks - 1) / total_chunks;
+    const int64_t t_begin = (int64_t)chunk * per, t_end = (t_begin + per < n_tiles) ? t_begin + per : n_tiles;
+    const int m_tiles = (job.m_rows + 31) / 32;
+    f32x16 acc[4];
+    for (int q = 0; q < 4; ++q) acc[q] = zero16();
+    float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int64_t tile = t_begin; tile < t_end; ++tile) {
+        const half_t* T = scratch + tile * TILE_HALFS;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const f16x8 bf = *reinterpret_cast<const f16x8*>(T + job.b_off + (int64_t)(32 * nt + i) * 32 + 16 * t + 8 * kb);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                if (mt < m_tiles) {
+                    f16x8 af;
+                    if (job.a_off >= 0) {
+                        af = *reinterpret_cast<const f16x8*>(T + job.a_off + (int64_t)(32 * mt + i) * 32 + 16 * t + 8 * kb);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const int64_t sidx = tile * 32 + 16 * t + 8 * kb + j;
+                            af[j] = (sidx < S && slot[sidx] == 32 * mt + i) ? (half_t)1.f : (half_t)0.f;
+                        }
+                    }
+                    acc[mt] = mfma(af, bf, acc[mt]);
+                    if (job.bias_off >= 0 && nt == 0) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) bsum[mt] += (float)af[j];
+                    }
+                }
+            }
+        }
+    }
+    // D[o][n]: lane col = n-row (32 nt + i), reg r -> row o = 32 mt + acc_row(r, kb)
+    const int col = 32 * nt + i;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        if (mt >= m_tiles) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = 32 * mt + acc_row(r, kb);
+            const float v = acc[mt][r];
+            if (row < job.m_rows && col < job.n_rows && v != 0.f) atomicAdd(&C[job.c_off + (int64_t)row * job.ldc + col], v);
+        }
+        if (job.bias_off >= 0 && nt == 0) {
+            const float s = bsum[mt] + __shfl_xor(bsum[mt], 32);
+            const int row = 32 * mt + i;
+            if (kb == 0 && row < job.m_rows && s != 0.f) atomicAdd(&C[job.bias_off + row], s);
+        }
+    }
+}
+
+static void fill_args(DeformArgs& A, const float* pos, int64_t S, const float* aabb, const float* code,
+                      int64_t code_stride, const int32_t* slot, const float* window7, const void* frags,
+                      const float* bias) {
+    A.pos = pos; A.code = code; A.code_stride = code_stride; A.slot = slot; A.S = S;
+    for (int d = 0; d < 3; ++d) {
+        A.aabb_min[d] = aabb[d];
+        A.aabb_ext[d] = aabb[3 + d] - aabb[d];
+        A.aabb_inv[d] = 1.0f / A.aabb_ext[d];
+    }
+    for (int f = 0; f < 7; ++f) A.window[f] = window7 ? window7[f] : 1.0f;
+    A.frags = reinterpret_cast<const f16x8*>(frags);
+    A.bias = bias;
+}
+
+}  // namespace nsx
+
+using namespace nsx;
+
+extern "C" {
+
+int nsx_deform_param_count(void) { return P_TOTAL; }
+int64_t nsx_deform_pack_bytes(void) { return (int64_t)N_FRAGS * 64 * 16 + (int64_t)N_BIAS * 4; }
+int64_t nsx_deform_scratch_bytes(int64_t S) { return ((S + 31) / 32) * TILE_HALFS * 2; }
+
+int nsx_deform_pack(const float* params, void* packed, void* stream) {
+    NSX_REQUIRE(params && packed, "nsx_deform_pack: NULL argument");
+    f16x8* frags = reinterpret_cast<f16x8*>(packed);
+    float* bias = reinterpret_cast<float*>(reinterpret_cast<uint8_t*>(packed) + (size_t)N_FRAGS * 64 * 16);
+    hipLaunchKernelGGL(deform_pack_kernel, dim3(64), dim3(256), 0, (hipStream_t)stream, params, frags, bias);
+    NSX_LAUNCH_CHECK("nsx_deform_pack launch");
+    return NSX_OK;
+}
+
+int nsx_deform_fwd(const void* packed, const float* positions, int64_t S, const float* aabb_host, const float* code,
+                   int64_t code_stride, const int32_t* code_slot, const float* window7_host, float* offsets,
+                   void* stream) {
+    NSX_REQUIRE(S >= 0, "nsx_deform_fwd: negative sample count");
+    if (S == 0) return NSX_OK;
+    NSX_REQUIRE(packed && positions && aabb_host && code && offsets, "nsx_deform_fwd: NULL argument");
+    DeformArgs A;
+    const float* bias = reinterpret_cast<const float*>(reinterpret_cast<const uint8_t*>(packed) + (size_t)N_FRAGS * 64 * 16);
+    fill_args(A, positions, S, aabb_host, code, code_stride, code_slot, window7_host, packed, bias);
+    const int64_t n_tiles = (S + 31) / 32;
+    int64_t blocks = (n_tiles + 3) / 4;
+    if (blocks > num_cus() * 2) blocks = num_cus() * 2;
+    hipLaunchKernelGGL(deform_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, A, offsets, n_tiles);
+    NSX_LAUNCH_CHECK("nsx_deform_fwd launch");
+    return NSX_OK;
+}
+
+int nsx_deform_bwd(const void* packed, const float* positions, int64_t S, const float* aabb_host, const float* code,
+                   int64_t code_stride, const int32_t* code_slot, int n_code_rows, const float* window7_host,
+                   const float* grad_offsets, void* scratch, float* grad_params, float* grad_code_table,
+                   float* grad_code_samples, void* stream) {
+    NSX_REQUIRE(S >= 0, "nsx_deform_bwd: negative sample count");
+    if (S == 0) return NSX_OK;
+    NSX_REQUIRE(packed && positions && aabb_host && code && grad_offsets && scratch && grad_params,
+                "nsx_deform_bwd: NULL argument");
+    NSX_REQUIRE(!grad_code_table || (code_slot && n_code_rows >= 1 && n_code_rows <= 128),
+                "nsx_deform_bwd: grad_code_table needs code_slot and n_code_rows in [1,128] (got %d)", n_code_rows);
+    DeformArgs A;
+    const float* bias = reinterpret_cast<const float*>(reinterpret_cast<const uint8_t*>(packed) + (size_t)N_FRAGS * 64 * 16);
+    fill_args(A, positions, S, aabb_host, code, code_stride, code_slot, window7_host, packed, bias);
+    const int64_t n_tiles = (S + 31) / 32;
+    int64_t blocks = (n_tiles + 3) / 4;
+    if (blocks > num_cus() * 2) blocks = num_cus() * 2;
+    hipStream_t st = (hipStream_t)stream;
+    half_t* sc = reinterpret_cast<half_t*>(scratch);
+    hipLaunchKernelGGL(deform_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, st, A, grad_offsets, sc, n_tiles,
+                       grad_code_samples);
+    NSX_LAUNCH_CHECK("nsx_deform_bwd chain launch");
+    // weight / bias / code-table gradients
+    int chunks = (int)((n_tiles + 255) / 256);
+    if (chunks < 1) chunks = 1;
+    if (chunks > 32) chunks = 32;
+    auto run = [&](WgradJob job, float* Cbuf) {
+        const int n_ntiles = (job.n_rows + 31) / 32;
+        hipLaunchKernelGGL(deform_wgrad_kernel, dim3(n_ntiles, chunks), dim3(256), 0, st, sc, n_tiles, job, n_ntiles,
+                           code_slot, S, Cbuf, chunks);
+    };
+    const int64_t A_of[7] = {TILE_A0, TILE_A + 0 * DFW * 32, TILE_A + 1 * DFW * 32, TILE_A + 2 * DFW * 32,
+                             TILE_A + 3 * DFW * 32, TILE_A + 4 * DFW * 32, TILE_A + 5 * DFW * 32};
+    auto dz = [&](int l) { return TILE_DZ + (int64_t)l * DFW * 32; };
+    run(WgradJob{dz(0), A_of[0], DFW, DF_IN, DF_IN, P_W0, P_B0, 0}, grad_params);
+    run(WgradJob{dz(1), A_of[1], DFW, DFW, DFW, P_W1, P_B1, 0}, grad_params);
+    run(WgradJob{dz(2), A_of[2], DFW, DFW, DFW, P_W2, P_B2, 0}, grad_params);
+    run(WgradJob{dz(3), A_of[3], DFW, DFW, DFW, P_W3, P_B3, 0}, grad_params);
+    run(WgradJob{dz(4), A_of[0], DFW, DF_IN, DF_W4, P_W4, P_B4, 0}, grad_params);
+    run(WgradJob{dz(4), A_of[4], DFW, DFW, DF_W4, P_W4 + DF_IN, -1, 0}, grad_params);
+    run(WgradJob{dz(5), A_of[5], DFW, DFW, DFW, P_W5, P_B5, 0}, grad_params);
+    // heads: rows 0..2 -> Wr / br, rows 3..5 -> Wv / bv: contiguous in the flat layout except for the bias slots
+    run(WgradJob{TILE_DZH, A_of[6], 3, DFW, DFW, P_WR, P_BR, 0}, grad_params);
+    run(WgradJob{TILE_DZH + 3 * 32, A_of[6], 3, DFW, DFW, P_WV, P_BV, 0}, grad_params);
+    if (grad_code_table)
+        run(WgradJob{-1, TILE_DC, n_code_rows, DF_CODE, DF_CODE, 0, -1, 0}, grad_code_table);
+    NSX_LAUNCH_CHECK("nsx_deform_bwd wgrad launch");
+    return NSX_OK;
+}
+
+}  // extern "C"

@@ -12,6 +12,9 @@ from typing import Optional, Tuple
 import torch
 from torch import nn
 
+import ctypes
+
+from .. import functional as F
 from ..rays import RaySamples, SceneBox
 from ..util.chunker import chunked
 from ..util.se3 import se3_exp_map
@@ -114,14 +117,54 @@ class SE3DeformationField(nn.Module):
         self.max_n_samples_per_batch = max_n_samples_per_batch
 
     def forward(self, ray_samples: RaySamples, warp_code: Optional[torch.Tensor] = None,
-                windows_param: Optional[float] = None) -> RaySamples:
+                windows_param: Optional[float] = None, code_index: Optional[torch.Tensor] = None) -> RaySamples:
         assert ray_samples.frustums.offsets is None or (
                 ray_samples.frustums.offsets == 0).all(), "ray samples have already been warped"
         positions = ray_samples.frustums.get_positions()
-        ray_samples.frustums.set_offsets(self.compute_offsets(positions, warp_code, windows_param))
+        ray_samples.frustums.set_offsets(self.compute_offsets(positions, warp_code, windows_param, code_index))
         return ray_samples
 
-    def compute_offsets(self, positions, warp_code=None, windows_param=None):
+    # ---- native path -------------------------------------------------------------------------------
+    def native_supported(self) -> bool:
+        st = self.se3_field.mlp_stem
+        return (len(st.layers) == 6 and st.layer_width == 128 and st._skip == {4} and st.in_dim == 173)
+
+    def flat_params(self) -> torch.Tensor:
+        """The 16 nn.Linear tensors in include/nsx.h order (autograd routes the flat gradient back)."""
+        L = self.se3_field
+        parts = []
+        for lyr in L.mlp_stem.layers:
+            parts += [lyr.weight.reshape(-1), lyr.bias]
+        parts += [L.mlp_r.layers[0].weight.reshape(-1), L.mlp_r.layers[0].bias,
+                  L.mlp_v.layers[0].weight.reshape(-1), L.mlp_v.layers[0].bias]
+        return torch.cat([p.float() for p in parts])
+
+    def _aabb6(self):
+        if getattr(self, "_aabb6_cache", None) is None:
+            self._aabb6_cache = (ctypes.c_float * 6)(*[float(v) for v in self.aabb.detach().flatten().tolist()])
+        return self._aabb6_cache
+
+    def compute_offsets(self, positions, warp_code=None, windows_param=None, code_index=None):
+        """``code_index`` (native extension): ``warp_code`` is a code TABLE and ``code_index[s]`` the row of sample s."""
+        if positions.is_cuda:
+            if not self.native_supported():
+                raise NotImplementedError("native deformation kernel: 6x128 MLP, skip at 4, warp_code_dim 128 "
+                                          "(the configuration of train_nersemble.py:84-91)")
+            if warp_code is None:
+                return None
+            max_chunk = len(positions) if self.max_n_samples_per_batch == -1 else self.max_n_samples_per_batch
+            flat = self.flat_params()
+            outs = []
+            if code_index is None:
+                for pos_c, code_c in chunked(max(max_chunk, 1), positions, warp_code):
+                    outs.append(F.deform_offsets(flat, pos_c, code_c, self._aabb6(), windows_param))
+            else:
+                for pos_c, idx_c in chunked(max(max_chunk, 1), positions, code_index):
+                    outs.append(F.deform_offsets(flat, pos_c, warp_code, self._aabb6(), windows_param, idx_c))
+            return torch.cat(outs, dim=0) if outs else positions.new_zeros((0, 3))
+        # CPU tensors: plain torch restatement (used to pin the glue against the reference's goldens)
+        if code_index is not None:
+            warp_code = warp_code[code_index.long()]
         max_chunk = len(positions) if self.max_n_samples_per_batch == -1 else self.max_n_samples_per_batch
         offsets = []
         for pos_c, code_c in chunked(max(max_chunk, 1), positions, warp_code):

@@ -196,3 +196,78 @@ def fused_mlp(params: torch.Tensor, n_hidden_mats: int, n_out: int, out_act: int
         b_dim = b.shape[1] - b_off
     return _FusedMLPFn.apply(params, a, b, n_hidden_mats, float(a_mul), float(a_add), int(b_off),
                              int(b_dim or 0), int(n_out), int(out_act))
+
+
+# ------------------------------------------------------------------------------------------------
+# fused SE(3) deformation field
+# ------------------------------------------------------------------------------------------------
+def deform_param_count() -> int:
+    return int(lib().nsx_deform_param_count())
+
+
+def deform_window7(windows_param, n_freq: int = 7):
+    """Per-frequency cosine window (windowed_nerf_encoding.py:76-92) as a host float array; None -> no window."""
+    if windows_param is None:
+        return None
+    import numpy as np
+    bands = np.linspace(0.0, n_freq - 1, n_freq, dtype=np.float32)
+    x = np.clip(np.float32(windows_param) - bands, 0, 1)
+    w = (0.5 * (1 - np.cos(np.float32(np.pi) * x))).astype(np.float32)
+    return (C.c_float * 7)(*[float(v) for v in w])
+
+
+class _DeformFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, flat_params, code, positions, code_slot, aabb6, window7):
+        dev = positions.device
+        params = flat_params.detach().to(torch.float32).contiguous()
+        packed = torch.empty(int(lib().nsx_deform_pack_bytes()), dtype=torch.uint8, device=dev)
+        check(lib().nsx_deform_pack(ptr(params), ptr(packed), stream()), "nsx_deform_pack")
+        pos = positions.detach().to(torch.float32).contiguous()
+        code_c = code.detach().to(torch.float32).contiguous()
+        S = pos.shape[0]
+        off = torch.empty((S, 3), dtype=torch.float32, device=dev)
+        check(lib().nsx_deform_fwd(ptr(packed), ptr(pos), S, aabb6, ptr(code_c), code_c.stride(0), ptr(code_slot),
+                                   window7, ptr(off), stream()), "nsx_deform_fwd")
+        ctx.save_for_backward(packed, pos, code_c, code_slot)
+        ctx.aabb6, ctx.window7 = aabb6, window7
+        ctx.n_params = params.numel()
+        return off
+
+    @staticmethod
+    def backward(ctx, goff):
+        packed, pos, code_c, code_slot = ctx.saved_tensors
+        dev = pos.device
+        S = pos.shape[0]
+        goff = goff.to(torch.float32).contiguous()
+        gparams = torch.zeros(ctx.n_params, dtype=torch.float32, device=dev)
+        need_code = ctx.needs_input_grad[1]
+        gtable = gsamples = None
+        if need_code:
+            if code_slot is not None and code_c.shape[0] <= 128:
+                gtable = torch.zeros_like(code_c)
+            else:
+                gsamples = torch.empty((S, 128), dtype=torch.float32, device=dev)
+        scratch = torch.empty(int(lib().nsx_deform_scratch_bytes(S)), dtype=torch.uint8, device=dev)
+        check(lib().nsx_deform_bwd(ptr(packed), ptr(pos), S, ctx.aabb6, ptr(code_c), code_c.stride(0), ptr(code_slot),
+                                   code_c.shape[0] if gtable is not None else 0, ctx.window7, ptr(goff), ptr(scratch),
+                                   ptr(gparams), ptr(gtable), ptr(gsamples), stream()), "nsx_deform_bwd")
+        gcode = None
+        if need_code:
+            if gtable is not None:
+                gcode = gtable
+            elif code_slot is not None:
+                gcode = torch.zeros_like(code_c).index_add_(0, code_slot.long(), gsamples)
+            else:
+                gcode = gsamples
+        return gparams, gcode, None, None, None, None
+
+
+def deform_offsets(flat_params: torch.Tensor, positions: torch.Tensor, code: torch.Tensor, aabb6,
+                   windows_param=None, code_slot: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Fused SE(3) deformation (deformation_field.py:148-166): offsets [S,3] fp32 in normalised space.
+    flat_params: the 16 nn.Linear tensors concatenated in include/nsx.h order; code: [S,128] per-sample codes, or a
+    code table with per-sample row indices ``code_slot``; aabb6: ctypes float[6] (host)."""
+    if code_slot is not None:
+        code_slot = code_slot.to(torch.int32).contiguous()
+    return _DeformFn.apply(flat_params, code, positions, code_slot, aabb6, deform_window7(windows_param))

@@ -198,23 +198,23 @@ class NeRSembleNGPModel(BaseModel):
         if self.time_embedding is not None:
             assert times is not None, "Times need to be provided to NeRSemble's density_fn"
             timesteps = self._timesteps(times)
-            if self.time_embedding_deformation is not None:
-                time_codes_deformation = self.time_embedding_deformation(timesteps)
         if cfg.use_deformation_field:
-            if self.time_embedding_deformation is None:
-                time_codes_deformation = self.time_embedding(timesteps)
-            # normalised-space offset added to the world-space position, exactly as the reference does (:257-259)
-            offsets = self.deformation_field.compute_offsets(positions, time_codes_deformation, window_deform)
+            emb = self.time_embedding_deformation if self.time_embedding_deformation is not None else self.time_embedding
+            # normalised-space offset added to the world-space position, exactly as the reference does (:257-259);
+            # the kernel indexes the embedding table per sample instead of gathering [N,128] codes
+            offsets = self.deformation_field.compute_offsets(positions, emb.weight, window_deform, code_index=timesteps)
             positions = positions + offsets
         return self.field.density_fn(positions, times, window_hash_encodings=window_hash,
                                      time_codes=self.time_embedding.weight if self.time_embedding is not None else None,
                                      time_code_index=timesteps)
 
-    def warp_ray_samples(self, ray_samples: RaySamples, time_codes: Optional[Tensor] = None) -> RaySamples:
+    def warp_ray_samples(self, ray_samples: RaySamples, time_codes: Optional[Tensor] = None,
+                         code_index: Optional[Tensor] = None) -> RaySamples:
         window_deform = self.sched_window_deform.value if self.sched_window_deform is not None else None
         if self.deformation_field is not None:
             assert ray_samples.frustums.offsets is None, "ray samples have already been warped"
-            self.deformation_field(ray_samples, warp_code=time_codes, windows_param=window_deform)
+            self.deformation_field(ray_samples, warp_code=time_codes, windows_param=window_deform,
+                                   code_index=code_index)
         return ray_samples
 
     # ---- forward (:280-364) --------------------------------------------------------------------------
@@ -237,7 +237,7 @@ class NeRSembleNGPModel(BaseModel):
         else:
             ray_timesteps = torch.zeros((num_rays,), dtype=torch.int, device=ray_indices.device)
 
-        time_codes_deformation = None
+        time_codes_deformation = deform_slot = None
         if self.time_embedding is not None:
             # compact the batch's distinct timesteps (<= 24 images per batch) -> small code tables + per-sample slot
             uniq, inv = torch.unique(ray_timesteps, return_inverse=True)
@@ -245,11 +245,13 @@ class NeRSembleNGPModel(BaseModel):
             ray_samples.metadata["time_codes"] = self.time_embedding(uniq)              # [Tb, H]
             ray_samples.metadata["time_code_index"] = slot                              # [S]
             if self.time_embedding_deformation is not None:
-                time_codes_deformation = self.time_embedding_deformation(uniq)[slot.long()]
+                time_codes_deformation = self.time_embedding_deformation(uniq)            # [Tb, 128] table
             elif cfg.use_deformation_field:
-                time_codes_deformation = ray_samples.metadata["time_codes"][slot.long()]
+                time_codes_deformation = ray_samples.metadata["time_codes"]
+            deform_slot = slot
 
-        ray_samples = self.warp_ray_samples(ray_samples, time_codes_deformation)
+        ray_samples = self.warp_ray_samples(ray_samples, time_codes_deformation,
+                                            deform_slot if time_codes_deformation is not None else None)
         field_outputs = self.field(ray_samples, window_hash_encodings=window_hash)
 
         packed_info = nerfacc.pack_info(ray_indices, num_rays)
