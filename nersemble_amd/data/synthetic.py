@@ -14,6 +14,7 @@ from typing import Dict, Tuple
 
 import torch
 
+from ..engine.parallel import shard_seed
 from ..model_components.frustum import TorchFrustum
 from ..rays import RayBundle
 
@@ -38,7 +39,7 @@ class SyntheticNeRSembleData:
         self.scene_box = scene_box.float()
         self.n_timesteps, self.n_rays, self.n_images = n_timesteps, n_rays, n_images_per_batch
         self.width, self.height, self.focal = width, height, focal
-        self.gen = torch.Generator(device=self.device).manual_seed(seed + 7919 * rank)
+        self.gen = torch.Generator(device=self.device).manual_seed(shard_seed(seed, rank))
         center = (self.scene_box[0] + self.scene_box[1]) / 2
         angles = torch.linspace(-50.0, 50.0, n_cameras) * math.pi / 180.0
         elev = torch.tensor([0.15, -0.15]).repeat(n_cameras // 2 + 1)[:n_cameras]

@@ -12,6 +12,7 @@ import torch
 import torch.distributed as dist
 
 from ..models.nersemble_instant_ngp import NeRSembleNGPModel
+from .parallel import all_reduce_gradients
 from ..rays import RayBundle
 
 
@@ -51,20 +52,8 @@ class NeRSembleTrainer:
     def _all_reduce_grads(self) -> None:
         if self.world_size <= 1:
             return
-        handles = []
-        for group in self.optimizers.values():
-            for pg in group.param_groups:
-                for p in pg["params"]:
-                    if p.grad is None:
-                        p.grad = torch.zeros_like(p)          # every rank must join every collective
-                    handles.append(dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, async_op=True))
-        for h in handles:
-            h.wait()
-        inv = 1.0 / self.world_size
-        for group in self.optimizers.values():
-            for pg in group.param_groups:
-                for p in pg["params"]:
-                    p.grad.mul_(inv)
+        params = [p for opt in self.optimizers.values() for pg in opt.param_groups for p in pg["params"]]
+        all_reduce_gradients(params, self.world_size)
 
     def train_iteration(self, step: int, ray_bundle: RayBundle, batch: Dict[str, torch.Tensor]
                         ) -> Tuple[torch.Tensor, Dict[str, torch.Tensor], Dict[str, torch.Tensor]]:
