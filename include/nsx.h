@@ -219,6 +219,23 @@ int nsx_distloss(const float* weights, const float* midpoints, const float* inte
                  int64_t R, int64_t max_ray, int64_t n_rays, float grad_scale, float* ray_loss, float* grad_weights,
                  void* stream);
 
+/* ---- optimizer step for the hash tables --------------------------------------------------------------------
+ * Replaces, for the 403 M-parameter `fields` group, torch.optim.Adam(lr 5e-3, eps 1e-15)
+ * (train_nersemble.py:243-246) + GradScaler unscale / inf check / conditional step (nersemble_trainer.py:185-186,
+ * 199-203) + tcnn's per-call fp32 -> fp16 parameter cast, in ONE pass over the parameters.
+ * torch.optim.Adam semantics (no amsgrad, no weight decay); `step` is the 1-based step count; inv_scale /
+ * found_inf are DEVICE scalars (may be NULL): gradients are multiplied by *inv_scale and the whole update is
+ * skipped when *found_inf != 0.  nsx_adam_hash_factored forms the gradient on the fly from the factored
+ * gradient G (see nsx_hash_ensemble_bwd_factored) -- the dense table gradient is never materialised. */
+int nsx_check_finite(const float* x, int64_t n, float* found_inf /* set to 1 if any non-finite */, void* stream);
+int nsx_adam_hash_factored(const float* G, int n_slots, const float* code_table, int64_t code_stride,
+                           const float* window, int H, const nsx_grid_geom* g, float* master, float* exp_avg,
+                           float* exp_avg_sq, nsx_half* tables_f16, float lr, float beta1, float beta2, float eps,
+                           int64_t step, const float* inv_scale, const float* found_inf, void* stream);
+int nsx_adam_dense(const float* grad, int64_t n, float* master, float* exp_avg, float* exp_avg_sq,
+                   nsx_half* params_f16 /* may be NULL */, float lr, float beta1, float beta2, float eps,
+                   int64_t step, const float* inv_scale, const float* found_inf, void* stream);
+
 /* Debug/parity helper: the 8 level-local entry indices per (sample, level), uint32 [B][L][8].
  * Integer outputs are held bit-exact to the oracle. */
 int nsx_hash_indices(const float* x, int64_t B, const nsx_grid_geom* g, uint32_t* idx, void* stream);

@@ -1,0 +1,174 @@
+// adam.hip -- fused Adam for the hash tables (403 M fp32 master parameters at H = 32) on gfx950.
+//
+// Replaces, for the `fields` parameter group, what the reference does per step through torch
+// (scripts/train/train_nersemble.py:243-246 Adam(lr 5e-3, eps 1e-15); nersemble_trainer.py:185-186
+// GradScaler unscale + inf check + optimizer step) plus tcnn's per-call fp32->fp16 parameter cast:
+//   torch:  unscale pass (r+w grad) + ~8 multi-tensor passes over param/grad/m/v  + cast pass   ~ 60 B/param
+//   here :  ONE pass: grad is formed on the fly from the factored gradient G (nsx_hash_ensemble_bwd_factored)
+//           and the <= 64 code rows (the 1.6 GB table gradient is never materialised), unscaled, the moments and
+//           the master weights updated and the fp16 working copy written:  ~ 29 B/param.
+// Semantics are torch.optim.Adam's (no amsgrad / weight decay): m.lerp_(g, 1-b1); v = b2 v + (1-b2) g^2;
+// p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps); skipped entirely when *found_inf != 0 (GradScaler).
+#include "nsx_common.h"
+
+namespace nsx {
+
+struct AdamHyper {
+    float lr, beta1, beta2, eps, bc1, bc2_sqrt;     // bc1 = 1 - b1^t ; bc2_sqrt = sqrt(1 - b2^t)
+};
+
+__device__ __forceinline__ void adam_update(float g, float& p, float& m, float& v, const AdamHyper& h) {
+    m = m + (g - m) * (1.0f - h.beta1);
+    v = v * h.beta2 + (1.0f - h.beta2) * g * g;
+    const float denom = sqrtf(v) / h.bc2_sqrt + h.eps;
+    p = p - (h.lr / h.bc1) * (m / denom);
+}
+
+__global__ __launch_bounds__(256) void check_finite_kernel(const float* __restrict__ x, int64_t n,
+                                                           float* __restrict__ found_inf) {
+    bool bad = false;
+    const int64_t n4 = n / 4;
+    const float4* x4 = reinterpret_cast<const float4*>(x);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const float4 v = x4[i];
+        bad |= !(isfinite(v.x) && isfinite(v.y) && isfinite(v.z) && isfinite(v.w));
+    }
+    for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        bad |= !isfinite(x[i]);
+    if (__any(bad) && (threadIdx.x & 63) == 0) found_inf[0] = 1.0f;
+}
+
+// one thread per (entry, f, 4 consecutive grids)
+template <int HP>
+__global__ __launch_bounds__(256) void adam_hash_factored_kernel(
+    const float* __restrict__ G, int n_slots, const float* __restrict__ code, int64_t code_stride,
+    const float* __restrict__ window, int Hreal, uint64_t total, float* __restrict__ master, float* __restrict__ m,
+    float* __restrict__ v, half_t* __restrict__ f16, AdamHyper hy, const float* __restrict__ inv_scale,
+    const float* __restrict__ found_inf) {
+    if (found_inf && found_inf[0] != 0.f) return;
+    extern __shared__ float cs[];     // [n_slots][HP] fp16-rounded windowed codes (as in the forward)
+    for (int i = threadIdx.x; i < n_slots * HP; i += blockDim.x) {
+        const int sl = i / HP, h = i % HP;
+        float c = 0.f;
+        if (h < Hreal) c = code[sl * code_stride + h] * (window ? window[h] : 1.0f);
+        cs[i] = (float)(half_t)c;
+    }
+    __syncthreads();
+    const float is = inv_scale ? inv_scale[0] : 1.0f;
+    constexpr int HQ = HP >= 4 ? HP / 4 : 1;
+    constexpr int HV = HP >= 4 ? 4 : HP;
+    const uint64_t n = total * 2ull * HQ;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const int hq = (int)(i % HQ);
+        const int f = (int)((i / HQ) & 1);
+        const uint64_t e = i / (2ull * HQ);
+        const float* gr = G + e * (uint64_t)n_slots * 2ull + f;
+        float g[HV];
+#pragma unroll
+        for (int k = 0; k < HV; ++k) g[k] = 0.f;
+        for (int sl = 0; sl < n_slots; ++sl) {
+            const float gv = gr[sl * 2];
+            if (gv != 0.f) {
+#pragma unroll
+                for (int k = 0; k < HV; ++k) g[k] = __fmaf_rn(gv, cs[sl * HP + hq * HV + k], g[k]);
+            }
+        }
+        const uint64_t at = (e * 2ull + f) * HP + hq * HV;
+        float pp[HV], mm[HV], vv[HV];
+#pragma unroll
+        for (int k = 0; k < HV; ++k) { pp[k] = master[at + k]; mm[k] = m[at + k]; vv[k] = v[at + k]; }
+#pragma unroll
+        for (int k = 0; k < HV; ++k) {
+            if (hq * HV + k < Hreal) adam_update(g[k] * is, pp[k], mm[k], vv[k], hy);
+        }
+#pragma unroll
+        for (int k = 0; k < HV; ++k) { master[at + k] = pp[k]; m[at + k] = mm[k]; v[at + k] = vv[k]; f16[at + k] = (half_t)pp[k]; }
+    }
+}
+
+__global__ __launch_bounds__(256) void adam_dense_kernel(const float* __restrict__ grad, int64_t n,
+                                                         float* __restrict__ master, float* __restrict__ m,
+                                                         float* __restrict__ v, half_t* __restrict__ f16, AdamHyper hy,
+                                                         const float* __restrict__ inv_scale,
+                                                         const float* __restrict__ found_inf) {
+    if (found_inf && found_inf[0] != 0.f) return;
+    const float is = inv_scale ? inv_scale[0] : 1.0f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float p = master[i], mm = m[i], vv = v[i];
+        adam_update(grad[i] * is, p, mm, vv, hy);
+        master[i] = p; m[i] = mm; v[i] = vv;
+        if (f16) f16[i] = (half_t)p;
+    }
+}
+
+static AdamHyper make_hyper(float lr, float beta1, float beta2, float eps, int64_t step) {
+    AdamHyper h;
+    h.lr = lr; h.beta1 = beta1; h.beta2 = beta2; h.eps = eps;
+    h.bc1 = (float)(1.0 - pow((double)beta1, (double)step));
+    h.bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step));
+    return h;
+}
+
+template <int HP>
+static int launch_adam_factored(const float* G, int n_slots, const float* code, int64_t code_stride, const float* window,
+                                int H, uint64_t total, float* master, float* m, float* v, nsx_half* f16, AdamHyper hy,
+                                const float* inv_scale, const float* found_inf, hipStream_t st) {
+    const size_t smem = (size_t)n_slots * HP * sizeof(float);
+    hipLaunchKernelGGL((adam_hash_factored_kernel<HP>), dim3(num_cus() * 8), dim3(256), smem, st, G, n_slots, code,
+                       code_stride, window, H, total, master, m, v, reinterpret_cast<half_t*>(f16), hy, inv_scale,
+                       found_inf);
+    NSX_LAUNCH_CHECK("nsx_adam_hash_factored launch");
+    return NSX_OK;
+}
+
+}  // namespace nsx
+
+using namespace nsx;
+
+extern "C" {
+
+int nsx_check_finite(const float* x, int64_t n, float* found_inf, void* stream) {
+    NSX_REQUIRE(n >= 0, "nsx_check_finite: negative size");
+    if (n == 0) return NSX_OK;
+    NSX_REQUIRE(x && found_inf, "nsx_check_finite: NULL argument");
+    hipLaunchKernelGGL(check_finite_kernel, dim3(num_cus() * 8), dim3(256), 0, (hipStream_t)stream, x, n, found_inf);
+    NSX_LAUNCH_CHECK("nsx_check_finite launch");
+    return NSX_OK;
+}
+
+int nsx_adam_hash_factored(const float* G, int n_slots, const float* code_table, int64_t code_stride,
+                           const float* window, int H, const nsx_grid_geom* g, float* master, float* exp_avg,
+                           float* exp_avg_sq, nsx_half* tables_f16, float lr, float beta1, float beta2, float eps,
+                           int64_t step, const float* inv_scale, const float* found_inf, void* stream) {
+    NSX_REQUIRE(G && code_table && g && master && exp_avg && exp_avg_sq && tables_f16, "nsx_adam_hash_factored: NULL argument");
+    NSX_REQUIRE(H >= 1 && H <= 32, "nsx_adam_hash_factored: H=%d not in [1,32]", H);
+    NSX_REQUIRE(n_slots >= 1 && n_slots <= NSX_MAX_SLOTS, "nsx_adam_hash_factored: n_slots=%d not in [1,%d]", n_slots, NSX_MAX_SLOTS);
+    NSX_REQUIRE(step >= 1, "nsx_adam_hash_factored: step must be >= 1");
+    const uint64_t total = g->offset[g->n_levels];
+    const AdamHyper hy = make_hyper(lr, beta1, beta2, eps, step);
+    hipStream_t st = (hipStream_t)stream;
+#define NSX_ADAM_CASE(HP) case HP: return launch_adam_factored<HP>(G, n_slots, code_table, code_stride, window, H, total, \
+        master, exp_avg, exp_avg_sq, tables_f16, hy, inv_scale, found_inf, st);
+    switch (nsx_padded_grids(H)) {
+        NSX_ADAM_CASE(1) NSX_ADAM_CASE(2) NSX_ADAM_CASE(4) NSX_ADAM_CASE(8) NSX_ADAM_CASE(16) NSX_ADAM_CASE(32)
+    }
+#undef NSX_ADAM_CASE
+    set_error("nsx_adam_hash_factored: unsupported H=%d", H);
+    return NSX_ERR_UNSUPPORTED;
+}
+
+int nsx_adam_dense(const float* grad, int64_t n, float* master, float* exp_avg, float* exp_avg_sq,
+                   nsx_half* params_f16, float lr, float beta1, float beta2, float eps, int64_t step,
+                   const float* inv_scale, const float* found_inf, void* stream) {
+    NSX_REQUIRE(n >= 0, "nsx_adam_dense: negative size");
+    if (n == 0) return NSX_OK;
+    NSX_REQUIRE(grad && master && exp_avg && exp_avg_sq, "nsx_adam_dense: NULL argument");
+    NSX_REQUIRE(step >= 1, "nsx_adam_dense: step must be >= 1");
+    const AdamHyper hy = make_hyper(lr, beta1, beta2, eps, step);
+    hipLaunchKernelGGL(adam_dense_kernel, dim3(num_cus() * 8), dim3(256), 0, (hipStream_t)stream, grad, n, master,
+                       exp_avg, exp_avg_sq, reinterpret_cast<half_t*>(params_f16), hy, inv_scale, found_inf);
+    NSX_LAUNCH_CHECK("nsx_adam_dense launch");
+    return NSX_OK;
+}
+
+}  // extern "C"

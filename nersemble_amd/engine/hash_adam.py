@@ -1,0 +1,119 @@
+"""Native optimizer step for the hash tables + a device-side GradScaler.
+
+``HashTableAdam`` is torch.optim.Adam (no amsgrad / weight decay; reference hyper-parameters
+scripts/train/train_nersemble.py:243-246) for ``HashEnsemble.tables`` as ONE libnsx kernel that forms the table
+gradient on the fly from the factored gradient (``functional.FactoredGradSink``), unscales it, updates the moments
+and the fp32 master and writes the fp16 working copy.  ``NativeGradScaler`` keeps torch.amp.GradScaler's algorithm
+(scale 65536, x2 every 2000 clean steps, x0.5 on inf/NaN; per-optimizer skip; nersemble_trainer.py:185-203) but holds
+scale / found_inf on the device so the table gradient never needs its own unscale pass.
+"""
+import ctypes as C
+from typing import Dict, List, Optional
+
+import torch
+
+from .. import _lib
+from .. import functional as F
+from .._lib import check, lib, ptr, stream
+from ..field_components.hash_ensemble import HashEnsemble
+
+
+class HashTableAdam(torch.optim.Optimizer):
+    def __init__(self, hash_ensemble: HashEnsemble, lr: float = 5e-3, betas=(0.9, 0.999), eps: float = 1e-15,
+                 factored: bool = True):
+        self.he = hash_ensemble
+        super().__init__([hash_ensemble.tables], dict(lr=lr, betas=betas, eps=eps))
+        self.factored = factored
+        if factored:
+            hash_ensemble.grad_sink = F.FactoredGradSink()
+
+    def _state(self):
+        p = self.he.tables
+        st = self.state[p]
+        if len(st) == 0:
+            st["step"] = 0
+            st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+        return st
+
+    @torch.no_grad()
+    def check_finite(self, found_inf: torch.Tensor) -> None:
+        """found_inf[0] = 1 if the pending table gradient holds an inf/NaN."""
+        sink = self.he.grad_sink
+        if sink is not None:
+            for e in sink.entries:
+                check(lib().nsx_check_finite(ptr(e["G"]), e["G"].numel(), ptr(found_inf), stream()), "nsx_check_finite")
+        g = self.he.tables.grad
+        if g is not None:
+            check(lib().nsx_check_finite(ptr(g.contiguous()), g.numel(), ptr(found_inf), stream()), "nsx_check_finite")
+
+    @torch.no_grad()
+    def step(self, found_inf: Optional[torch.Tensor] = None, inv_scale: Optional[torch.Tensor] = None):
+        he, p = self.he, self.he.tables
+        group = self.param_groups[0]
+        sink = he.grad_sink
+        entries = sink.entries if sink is not None else []
+        if not entries and p.grad is None:
+            return
+        st = self._state()
+        st["step"] += 1
+        b1, b2 = group["betas"]
+        f16 = he.half_tables()            # make sure the working copy exists on the right device
+        if len(entries) == 1 and p.grad is None:
+            e = entries[0]
+            check(lib().nsx_adam_hash_factored(ptr(e["G"]), e["n_rows"], ptr(e["code"]), e["code"].stride(0),
+                                               ptr(e["window"]), he.n_hash_encodings, C.byref(he.geom), ptr(p.data),
+                                               ptr(st["exp_avg"]), ptr(st["exp_avg_sq"]), ptr(f16), group["lr"], b1, b2,
+                                               group["eps"], st["step"], ptr(inv_scale), ptr(found_inf), stream()),
+                  "nsx_adam_hash_factored")
+        else:
+            grad = p.grad.contiguous() if p.grad is not None else torch.zeros_like(p)
+            for e in entries:      # several code tables in one step: expand each into the dense gradient
+                check(lib().nsx_hash_grad_expand(ptr(e["G"]), e["n_rows"], ptr(e["code"]), e["code"].stride(0),
+                                                 ptr(e["window"]), he.n_hash_encodings, C.byref(he.geom), ptr(grad), 1,
+                                                 stream()), "nsx_hash_grad_expand")
+            check(lib().nsx_adam_dense(ptr(grad), grad.numel(), ptr(p.data), ptr(st["exp_avg"]), ptr(st["exp_avg_sq"]),
+                                       ptr(f16), group["lr"], b1, b2, group["eps"], st["step"], ptr(inv_scale),
+                                       ptr(found_inf), stream()), "nsx_adam_dense")
+        if sink is not None:
+            sink.clear()
+        p._version_bump = None
+        he.mark_half_synced()
+
+    def zero_grad(self, set_to_none: bool = True):
+        super().zero_grad(set_to_none=set_to_none)
+        if self.he.grad_sink is not None:
+            self.he.grad_sink.clear()
+
+
+class NativeGradScaler:
+    """torch.amp.GradScaler's algorithm with device-resident state and explicit found_inf plumbing."""
+
+    def __init__(self, device, init_scale: float = 65536.0, growth_factor: float = 2.0, backoff_factor: float = 0.5,
+                 growth_interval: int = 2000, enabled: bool = True):
+        self.enabled = enabled
+        self.growth_factor, self.backoff_factor, self.growth_interval = growth_factor, backoff_factor, growth_interval
+        self._scale = torch.full((), init_scale if enabled else 1.0, dtype=torch.float32, device=device)
+        self._growth_tracker = torch.full((), 0, dtype=torch.int32, device=device)
+
+    def scale(self, loss: torch.Tensor) -> torch.Tensor:
+        return loss * self._scale if self.enabled else loss
+
+    def inv_scale(self) -> torch.Tensor:
+        return self._scale.double().reciprocal().float().reshape(1)
+
+    def unscale_and_check(self, grads: List[torch.Tensor], found_inf: torch.Tensor, inv_scale: torch.Tensor) -> None:
+        if grads:
+            torch._amp_foreach_non_finite_check_and_unscale_(grads, found_inf, inv_scale)
+
+    def update(self, found_infs: List[torch.Tensor]) -> None:
+        if not self.enabled:
+            return
+        total = found_infs[0].clone()
+        for f in found_infs[1:]:
+            total += f
+        torch._amp_update_scale_(self._scale, self._growth_tracker, total.reshape(()), self.growth_factor,
+                                 self.backoff_factor, self.growth_interval)
+
+    def get_scale(self) -> float:
+        return float(self._scale.item())

@@ -12,6 +12,7 @@ import torch
 import torch.distributed as dist
 
 from ..models.nersemble_instant_ngp import NeRSembleNGPModel
+from .hash_adam import HashTableAdam, NativeGradScaler
 from .parallel import all_reduce_gradients
 from ..rays import RayBundle
 
@@ -35,17 +36,28 @@ class NeRSembleTrainer:
         self.cfg = opt_cfg or OptimizerConfig()
         self.mixed_precision = mixed_precision
         self.world_size = world_size
+        device = next(model.parameters()).device
         groups = model.get_param_groups()
         lrs = {"fields": self.cfg.lr_main, "deformation_field": self.cfg.lr_deformation_field,
                "embeddings": self.cfg.lr_embeddings}
         gammas = {"fields": self.cfg.gamma_fields, "deformation_field": self.cfg.gamma_deformation_field,
                   "embeddings": self.cfg.gamma_embeddings}
-        self.optimizers, self.schedulers = {}, {}
+        self.optimizers, self.schedulers, self.group_of = {}, {}, {}
+        fused = device.type == "cuda"
+        tables = model.field.hash_ensemble.tables
         for name, params in groups.items():
-            self.optimizers[name] = torch.optim.Adam(params, lr=lrs[name], eps=self.cfg.eps, weight_decay=0)
-            self.schedulers[name] = torch.optim.lr_scheduler.StepLR(self.optimizers[name], step_size=self.cfg.step_size,
-                                                                    gamma=gammas[name])
-        self.grad_scaler = torch.amp.GradScaler("cuda", enabled=mixed_precision)
+            small = [p for p in params if p is not tables]
+            self.optimizers[name] = torch.optim.Adam(small, lr=lrs[name], eps=self.cfg.eps, weight_decay=0, fused=fused)
+            self.group_of[name] = name
+            if len(small) != len(params):
+                # the 403 M-parameter hash tables: native fused step; the dense gradient is only materialised for DP
+                self.optimizers[name + "/tables"] = HashTableAdam(model.field.hash_ensemble, lr=lrs[name],
+                                                                  eps=self.cfg.eps, factored=(world_size == 1))
+                self.group_of[name + "/tables"] = name
+        for key, opt in self.optimizers.items():
+            self.schedulers[key] = torch.optim.lr_scheduler.StepLR(opt, step_size=self.cfg.step_size,
+                                                                   gamma=gammas[self.group_of[key]])
+        self.grad_scaler = NativeGradScaler(device, enabled=mixed_precision)
         self.callbacks = model.get_training_callbacks()
 
     # ---- data-parallel gradient averaging ------------------------------------------------------------
@@ -54,6 +66,35 @@ class NeRSembleTrainer:
             return
         params = [p for opt in self.optimizers.values() for pg in opt.param_groups for p in pg["params"]]
         all_reduce_gradients(params, self.world_size)
+
+    def _optimizer_step_all(self):
+        """GradScaler semantics (nersemble_trainer.py:186): unscale + inf check per optimizer group, skip the step of
+        a group whose gradients hold inf/NaN, then one scale update from all groups."""
+        scaler = self.grad_scaler
+        inv_scale = scaler.inv_scale()
+        dev = inv_scale.device
+        found = {g: torch.zeros((1,), dtype=torch.float32, device=dev) for g in set(self.group_of.values())}
+        for key, opt in self.optimizers.items():
+            f = found[self.group_of[key]]
+            if isinstance(opt, HashTableAdam):
+                opt.check_finite(f)
+            else:
+                grads = [p.grad for pg in opt.param_groups for p in pg["params"] if p.grad is not None]
+                scaler.unscale_and_check(grads, f, inv_scale)
+        for key, opt in self.optimizers.items():
+            f = found[self.group_of[key]]
+            if isinstance(opt, HashTableAdam):
+                opt.step(found_inf=f, inv_scale=inv_scale)
+            elif any(p.grad is not None for pg in opt.param_groups for p in pg["params"]):
+                if opt.defaults.get("fused"):
+                    opt.found_inf, opt.grad_scale = f.reshape(()), None
+                    opt.step()
+                    del opt.found_inf, opt.grad_scale
+                elif f.item() == 0:
+                    opt.step()
+        founds = list(found.values())
+        scaler.update(founds)
+        return founds
 
     def train_iteration(self, step: int, ray_bundle: RayBundle, batch: Dict[str, torch.Tensor]
                         ) -> Tuple[torch.Tensor, Dict[str, torch.Tensor], Dict[str, torch.Tensor]]:
@@ -70,11 +111,9 @@ class NeRSembleTrainer:
             loss = functools.reduce(torch.add, loss_dict.values())
         self.grad_scaler.scale(loss).backward()
         self._all_reduce_grads()
-        for opt in self.optimizers.values():
-            self.grad_scaler.step(opt)
-        scale = self.grad_scaler.get_scale()
-        self.grad_scaler.update()
-        if scale <= self.grad_scaler.get_scale():
+        founds = self._optimizer_step_all()
+        # the reference skips the LR step when the scale dropped, i.e. when an inf/NaN was found (:199-203)
+        if sum(f.item() for f in founds) == 0:
             for sch in self.schedulers.values():
                 sch.step()
         return loss, loss_dict, metrics_dict

@@ -81,6 +81,9 @@ class HashEnsemble(nn.Module):
         self.tables = nn.Parameter(master)                                   # fp32 master, native layout
         self.register_buffer("tables_f16", master.to(torch.float16), persistent=False)
         self._f16_version = None
+        # set by engine.hash_adam.HashTableAdam: factored-gradient sink (no dense table gradient is materialised)
+        self.grad_sink = None
+        self._window_cache = {}
         self._register_state_dict_hook(self._export_tcnn_keys)
         self._register_load_state_dict_pre_hook(self._import_tcnn_keys)
 
@@ -164,10 +167,17 @@ class HashEnsemble(nn.Module):
                 first = torch.zeros_like(conditioning_code)
                 first[:, 0] = (1 - alpha) * 1
                 conditioning_code = alpha * conditioning_code + first
-            window = posenc_window(window_hash_encodings, 0, self.n_hash_encodings - 1, self.n_hash_encodings)
+            # one device tensor per window value (chunks / passes of a step share it)
+            wkey = (float(window_hash_encodings), str(in_tensor.device))
+            window = self._window_cache.get(wkey)
+            if window is None:
+                window = posenc_window(window_hash_encodings, 0, self.n_hash_encodings - 1,
+                                       self.n_hash_encodings).to(device=in_tensor.device, dtype=torch.float32)
+                self._window_cache = {wkey: window}
 
+        sink = self.grad_sink if (self.grad_sink is not None and torch.is_grad_enabled()) else None
         return F.hash_ensemble(in_tensor, self.tables, self.half_tables(), conditioning_code,
-                               self.n_hash_encodings, self.geom, code_index=code_index, window=window)
+                               self.n_hash_encodings, self.geom, code_index=code_index, window=window, sink=sink)
 
     def get_out_dim(self) -> int:
         return self.n_output_dims

@@ -64,9 +64,38 @@ def _hash_ensemble_fwd_raw(x, tables_f16, H, geom, code, code_index, window):
     return out
 
 
+class FactoredGradSink:
+    """Collects the factored table gradient G[e][slot][f] (+ the code rows it factors through) instead of a dense
+    1.6 GB table gradient; consumed by ``engine.hash_adam.HashTableAdam`` which forms the gradient on the fly.
+    Backward calls of one step that share the code table (the chunks of a step) accumulate into one G."""
+
+    def __init__(self):
+        self.entries = []            # dicts: G, code, window, n_rows, key
+        self._cache = {}
+
+    def buffer_for(self, code: torch.Tensor, window: Optional[torch.Tensor], n_rows: int, total_entries: int):
+        key = (code.data_ptr(), n_rows, None if window is None else window.data_ptr())
+        for e in self.entries:
+            if e["key"] == key:
+                return e["G"]
+        G = self._cache.get(n_rows)
+        if G is None or G.device != code.device:
+            G = torch.empty((total_entries, n_rows, 2), dtype=torch.float32, device=code.device)
+            self._cache = {n_rows: G}          # keep at most one persistent buffer
+        if any(e["G"] is G for e in self.entries):
+            G = torch.empty_like(G)
+        G.zero_()
+        self.entries.append({"G": G, "code": code, "window": window, "n_rows": n_rows, "key": key})
+        return G
+
+    def clear(self):
+        self.entries = []
+
+
 class _HashEnsembleFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, tables_master, tables_f16, code, code_index, window, H, geom):
+    def forward(ctx, x, tables_master, tables_f16, code, code_index, window, H, geom, sink=None):
+        ctx.sink = sink
         x = x.detach().to(torch.float32).contiguous()
         code_c = code.detach().to(torch.float32).contiguous()
         out = _hash_ensemble_fwd_raw(x, tables_f16, H, geom, code_c, code_index, window)
@@ -90,13 +119,16 @@ class _HashEnsembleFn(torch.autograd.Function):
             # factored table gradient: scatter 2 scalars per corner into G[e][slot][f], then expand with the codes
             dtab = None
             G = None
-            if need_tab:
+            use_sink = ctx.sink is not None and need_tab
+            if use_sink:
+                G = ctx.sink.buffer_for(code, window, n_rows, geom.total_entries)
+            elif need_tab:
                 G = torch.zeros((geom.total_entries, n_rows, 2), dtype=torch.float32, device=x.device)
             check(lib().nsx_hash_ensemble_bwd_factored(ptr(x), B, ptr(tables_f16), H, C.byref(geom), ptr(code),
                                                        code.stride(0), n_rows, ptr(code_index), ptr(window),
                                                        ptr(dout), ptr(G), ptr(dcode_s), ptr(dx), stream()),
                   "nsx_hash_ensemble_bwd_factored")
-            if need_tab:
+            if need_tab and not use_sink:
                 dtab = torch.empty(ctx.master_shape, dtype=torch.float32, device=x.device)
                 check(lib().nsx_hash_grad_expand(ptr(G), n_rows, ptr(code), code.stride(0), ptr(window), H,
                                                  C.byref(geom), ptr(dtab), 0, stream()), "nsx_hash_grad_expand")
@@ -115,12 +147,12 @@ class _HashEnsembleFn(torch.autograd.Function):
                 dcode.index_add_(0, code_index.to(torch.int64), dcode_s)
             else:
                 dcode = dcode_s
-        return dx, dtab, None, dcode, None, None, None, None
+        return dx, dtab, None, dcode, None, None, None, None, None
 
 
 def hash_ensemble(x: torch.Tensor, tables_master: torch.Tensor, tables_f16: torch.Tensor, code: torch.Tensor,
                   H: int, geom: GridGeom, code_index: Optional[torch.Tensor] = None,
-                  window: Optional[torch.Tensor] = None) -> torch.Tensor:
+                  window: Optional[torch.Tensor] = None, sink: Optional[FactoredGradSink] = None) -> torch.Tensor:
     """Fused HashEnsemble forward (hash_ensemble.py:93-158), differentiable w.r.t. x, tables_master, code.
 
     x [B,3] fp32 in [0,1); code fp32 rows of H values (row b, or row code_index[b]); window [H] fp32 or None.
@@ -130,7 +162,7 @@ def hash_ensemble(x: torch.Tensor, tables_master: torch.Tensor, tables_f16: torc
         code_index = code_index.to(torch.int32).contiguous()
     if window is not None:
         window = window.to(device=x.device, dtype=torch.float32).contiguous()
-    return _HashEnsembleFn.apply(x, tables_master, tables_f16, code, code_index, window, H, geom)
+    return _HashEnsembleFn.apply(x, tables_master, tables_f16, code, code_index, window, H, geom, sink)
 
 
 # ------------------------------------------------------------------------------------------------

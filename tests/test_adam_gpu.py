@@ -1,0 +1,87 @@
+"""GPU parity: native hash-table Adam (factored + dense) vs torch.optim.Adam on the materialised gradient, and the
+GradScaler skip semantics."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _he(H, cuda, seed=0):
+    from nersemble_amd.field_components.hash_ensemble import HashEnsemble, HashEnsembleConfig, TCNNHashEncodingConfig
+    cfg = HashEnsembleConfig(H, TCNNHashEncodingConfig(n_levels=6, log2_hashmap_size=11), True, True)
+    he = HashEnsemble(cfg, seed=seed).to(cuda)
+    with torch.no_grad():
+        he.tables.mul_(3000)          # non-trivial values
+    return he
+
+
+@pytest.mark.parametrize("H", [1, 4, 32])
+def test_factored_adam_equals_torch_adam(H, cuda):
+    from nersemble_amd.engine.hash_adam import HashTableAdam
+    B, T = 4000, 7
+    g = torch.Generator(device=cuda).manual_seed(1)
+    x = torch.rand((B, 3), device=cuda, generator=g)
+    emb = torch.randn((T, H), device=cuda, generator=g)
+    slot = torch.randint(0, T, (B,), device=cuda, generator=g, dtype=torch.int32)
+    dout = torch.randn((B, 12), device=cuda, generator=g).half()
+    scale = 1024.0
+    # reference: dense gradient + torch Adam (+ manual unscale)
+    ref = _he(H, cuda)
+    opt_ref = torch.optim.Adam([ref.tables], lr=5e-3, eps=1e-15)
+    nat = _he(H, cuda)
+    opt_nat = HashTableAdam(nat, lr=5e-3, eps=1e-15, factored=True)
+    inv = torch.tensor([1.0 / scale], device=cuda)
+    found = torch.zeros(1, device=cuda)
+    for it in range(3):
+        win = 0.5 * H + it * 0.3
+        opt_ref.zero_grad()
+        ref(x, emb, window_hash_encodings=win, code_index=slot).backward(dout * scale)
+        ref.tables.grad.mul_(1.0 / scale)
+        opt_ref.step()
+        opt_nat.zero_grad()
+        nat(x, emb, window_hash_encodings=win, code_index=slot).backward(dout * scale)
+        assert nat.tables.grad is None and len(nat.grad_sink.entries) == 1
+        opt_nat.check_finite(found)
+        opt_nat.step(found_inf=found, inv_scale=inv)
+        assert found.item() == 0
+        d = (nat.tables - ref.tables).abs().max().item()
+        # Adam with eps = 1e-15 is scale-free: on entries whose gradient is pure cancellation noise the update is
+        # lr * (noise ratio), so the atomics' summation order shows up at ~1e-5 (lr = 5e-3); everything else ~1e-7
+        assert d <= 5e-5, (it, d)
+        assert (nat.tables - ref.tables).abs().mean().item() <= 1e-7
+        # the fp16 working copy is refreshed by the kernel
+        assert torch.equal(nat.half_tables(), nat.tables.detach().half())
+        ref._f16_version = None
+
+
+def test_adam_skips_on_inf_and_dense_path(cuda):
+    from nersemble_amd.engine.hash_adam import HashTableAdam, NativeGradScaler
+    H = 4
+    he = _he(H, cuda)
+    opt = HashTableAdam(he, lr=5e-3, eps=1e-15, factored=False)          # dense (data-parallel) mode
+    ref = _he(H, cuda)
+    opt_ref = torch.optim.Adam([ref.tables], lr=5e-3, eps=1e-15)
+    g = torch.Generator(device=cuda).manual_seed(2)
+    grad = torch.randn(he.tables.shape, device=cuda, generator=g)
+    he.tables.grad = grad.clone()
+    ref.tables.grad = grad.clone()
+    found = torch.zeros(1, device=cuda)
+    opt.check_finite(found)
+    opt.step(found_inf=found, inv_scale=None)
+    opt_ref.step()
+    assert (he.tables - ref.tables).abs().max().item() <= 1e-6
+    before = he.tables.detach().clone()
+    he.tables.grad = grad.clone()
+    he.tables.grad[5, 1, 2] = float("inf")
+    found = torch.zeros(1, device=cuda)
+    opt.check_finite(found)
+    assert found.item() == 1
+    opt.step(found_inf=found, inv_scale=None)
+    assert torch.equal(he.tables.detach(), before)                       # skipped
+    sc = NativeGradScaler(cuda)
+    s0 = sc.get_scale()
+    sc.update([found])
+    assert sc.get_scale() == s0 * 0.5
+    sc.update([torch.zeros(1, device=cuda)])
+    assert sc.get_scale() == s0 * 0.5
