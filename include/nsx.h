@@ -109,7 +109,7 @@ int nsx_hash_ensemble_bwd(const float* x, int64_t B, const nsx_half* tables, int
  * the kernel scatters 2 scalars per (sample, level, corner) into G instead of 2H table values (32x fewer
  * atomics at H=32); nsx_hash_grad_expand then produces the native-layout fp32 table gradient.
  *   code_table [n_slots][code_stride] fp32, code_slot [B] int32 in [0, n_slots), n_slots <= NSX_MAX_SLOTS
- *   G          [total_entries][n_slots][2] fp32, ACCUMULATED into with atomics (caller zeroes); may be NULL
+ *   G          [n_slots][total_entries][2] fp32, ACCUMULATED into with atomics (caller zeroes); may be NULL
  *   dcode      [B][H] fp32 per-sample gradient w.r.t. the windowed code row; may be NULL.  dx [B][3]; may be NULL */
 int nsx_hash_ensemble_bwd_factored(const float* x, int64_t B, const nsx_half* tables, int H,
                                    const nsx_grid_geom* g, const float* code_table, int64_t code_stride,

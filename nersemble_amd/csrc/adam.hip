@@ -62,12 +62,12 @@ __global__ __launch_bounds__(256) void adam_hash_factored_kernel(
         const int hq = (int)(i % HQ);
         const int f = (int)((i / HQ) & 1);
         const uint64_t e = i / (2ull * HQ);
-        const float* gr = G + e * (uint64_t)n_slots * 2ull + f;
+        const float* gr = G + e * 2ull + f;                 // G is [slot][entry][f]
         float g[HV];
 #pragma unroll
         for (int k = 0; k < HV; ++k) g[k] = 0.f;
         for (int sl = 0; sl < n_slots; ++sl) {
-            const float gv = gr[sl * 2];
+            const float gv = gr[(uint64_t)sl * total * 2ull];
             if (gv != 0.f) {
 #pragma unroll
                 for (int k = 0; k < HV; ++k) g[k] = __fmaf_rn(gv, cs[sl * HP + hq * HV + k], g[k]);

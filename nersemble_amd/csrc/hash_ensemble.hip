@@ -215,6 +215,22 @@ __global__ __launch_bounds__(WAVES * kWave) void ens_fwd_kernel(
     }
 }
 
+// DPP row_shl:J -- lane i receives the value of lane i+J of its 16-lane row (0 when out of the row)
+template <int J>
+__device__ __forceinline__ int dpp_row_shl(int x) { return __builtin_amdgcn_update_dpp(0, x, 0x100 + J, 0xf, 0xf, true); }
+
+// sum of `val` over the run of equal keys that starts at this lane (runs live inside aligned 8-lane groups)
+template <int J, int N>
+__device__ __forceinline__ void run_merge(uint32_t key, float val, int s7, bool& alive, float& sum) {
+    if constexpr (J < N) {
+        const uint32_t nk = (uint32_t)dpp_row_shl<J>((int)key);
+        const float nv = __builtin_bit_cast(float, dpp_row_shl<J>(__builtin_bit_cast(int, val)));
+        alive = alive && (s7 + J < 8) && (nk == key);
+        if (alive) sum += nv;
+        run_merge<J + 1, N>(key, val, s7, alive, sum);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // backward: table gradient (fp32 atomics into the native layout), code gradient, position gradient
 // ------------------------------------------------------------------------------------------------
@@ -233,10 +249,13 @@ __global__ __launch_bounds__(WAVES * kWave) void ens_bwd_kernel(
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x / kWave;
     const int L = g.n_levels;
-    const int s = lane / C::LPE, q = lane % C::LPE;
+    // backward lane mapping: lane = q * SPW + s (chunk-major) so the samples of a tile sit in ADJACENT lanes --
+    // consecutive samples of a ray share coarse cells, and duplicates are merged with DPP before the atomics
+    const int s = lane % C::SPW, q = lane / C::SPW;
     const int64_t wave_global = (int64_t)blockIdx.x * WAVES + wave;
     const int64_t wave_count = (int64_t)gridDim.x * WAVES;
     constexpr int NH = 2 * C::NDW;   // fp16 values per lane load
+    const size_t g_total = g.offset[L];
 
     for (int64_t tile = wave_global; tile < n_tiles; tile += wave_count) {
         const int64_t b_raw = tile * C::SPW + s;
@@ -315,18 +334,34 @@ __global__ __launch_bounds__(WAVES * kWave) void ens_bwd_kernel(
             }
             if constexpr (FACTORED) {
                 if (dtab) {
-                    // lane q of the sample owns corners q, q+LPE, ...: 2 scalar atomics per corner
+                    // 16 (corner, feature) items per sample and level, LPE lanes per sample -> 16/LPE instructions.
+                    // item = i*LPE + q: bit0 = feature, bit1 = x, bit2 = y, bit3 = z.  With G stored [slot][entry][f]
+                    // the 4 items (f0,f1) x (x0,x1) of one (y,z) are 16 contiguous bytes whenever entry(x1) =
+                    // entry(x0)+1 (always on dense levels, for even x on hashed levels): the memory system charges
+                    // per distinct 32-B sector per instruction (measured ~20 G sectors/s), so they cost ONE request.
+                    constexpr int NI = 16 / C::LPE;
 #pragma unroll
-                    for (int k0 = 0; k0 < 8; k0 += C::LPE) {
-                        uint32_t ik = idx[k0];
-                        float wk = w[k0];
+                    for (int i = 0; i < NI; ++i) {
+                        const int item = i * C::LPE + q;
+                        const int f = item & 1, c = (item >> 1) & 7;
+                        uint32_t ik = idx[0];
+                        float wk = w[0];
 #pragma unroll
-                        for (int j = 1; j < C::LPE; ++j) {
-                            if (q == j) { ik = idx[k0 + j]; wk = w[k0 + j]; }
+                        for (int cc = 1; cc < 8; ++cc) {
+                            if (c == cc) { ik = idx[cc]; wk = w[cc]; }
                         }
-                        float* gp = dtab + ((size_t)(off + ik) * (size_t)n_slots + (size_t)crow) * 2;
-                        atomicAdd(gp + 0, wk * g0);
-                        atomicAdd(gp + 1, wk * g1);
+                        float val = wk * (f ? g1 : g0);
+                        const uint32_t key = ((off + ik) << 6) | (uint32_t)crow;      // entry < 2^23, slot < 64
+                        // merge runs of equal keys over the adjacent sample lanes (only the run head issues)
+                        float sum = val;
+                        bool alive = true;
+                        run_merge<1, 8>(key, val, s & 7, alive, sum);
+                        const uint32_t pk = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)key, 0x111, 0xf, 0xf, true);
+                        const bool head = ((s & 7) == 0) || (pk != key);
+                        if (head && sum != 0.f) {
+                            float* gp = dtab + (((size_t)crow * g_total + (size_t)(off + ik)) * 2 + f);
+                            atomicAdd(gp, sum);
+                        }
                     }
                 }
             }
@@ -335,7 +370,7 @@ __global__ __launch_bounds__(WAVES * kWave) void ens_bwd_kernel(
         if (dx) {
 #pragma unroll
             for (int m = 1; m < C::LPE; m <<= 1) {
-                dxa += __shfl_xor(dxa, m); dya += __shfl_xor(dya, m); dza += __shfl_xor(dza, m);
+                dxa += __shfl_xor(dxa, m * C::SPW); dya += __shfl_xor(dya, m * C::SPW); dza += __shfl_xor(dza, m * C::SPW);
             }
             if (q == 0 && valid) { dx[b * 3 + 0] = dxa; dx[b * 3 + 1] = dya; dx[b * 3 + 2] = dza; }
         }
@@ -354,7 +389,7 @@ __global__ __launch_bounds__(WAVES * kWave) void ens_bwd_kernel(
                 }
             } else {                                   // H >= 8: partner lane q ^ (LPE/2) holds the other plane
 #pragma unroll
-                for (int i = 0; i < NH; ++i) dc[i] += __shfl_xor(dc[i], C::LPE / 2);
+                for (int i = 0; i < NH; ++i) dc[i] += __shfl_xor(dc[i], (C::LPE / 2) * C::SPW);
                 if (valid && q < C::LPE / 2) {
 #pragma unroll
                     for (int j = 0; j < C::NDW; ++j) {
@@ -424,12 +459,12 @@ __global__ __launch_bounds__(256) void grad_expand_kernel(const float* __restric
         const int hq = (int)(i % HQ);
         const int f = (int)((i / HQ) & 1);
         const uint64_t e = i / (2ull * HQ);
-        const float* gr = G + e * (uint64_t)n_slots * 2ull + f;
+        const float* gr = G + e * 2ull + f;                 // G is [slot][entry][f]
         float acc[HV];
 #pragma unroll
         for (int v = 0; v < HV; ++v) acc[v] = 0.f;
         for (int sl = 0; sl < n_slots; ++sl) {
-            const float gv = gr[sl * 2];
+            const float gv = gr[(uint64_t)sl * total * 2ull];
             if (gv != 0.f) {
 #pragma unroll
                 for (int v = 0; v < HV; ++v) acc[v] = __fmaf_rn(gv, cs[sl * HP + hq * HV + v], acc[v]);

@@ -80,7 +80,7 @@ class FactoredGradSink:
                 return e["G"]
         G = self._cache.get(n_rows)
         if G is None or G.device != code.device:
-            G = torch.empty((total_entries, n_rows, 2), dtype=torch.float32, device=code.device)
+            G = torch.empty((n_rows, total_entries, 2), dtype=torch.float32, device=code.device)
             self._cache = {n_rows: G}          # keep at most one persistent buffer
         if any(e["G"] is G for e in self.entries):
             G = torch.empty_like(G)
@@ -123,7 +123,7 @@ class _HashEnsembleFn(torch.autograd.Function):
             if use_sink:
                 G = ctx.sink.buffer_for(code, window, n_rows, geom.total_entries)
             elif need_tab:
-                G = torch.zeros((geom.total_entries, n_rows, 2), dtype=torch.float32, device=x.device)
+                G = torch.zeros((n_rows, geom.total_entries, 2), dtype=torch.float32, device=x.device)
             check(lib().nsx_hash_ensemble_bwd_factored(ptr(x), B, ptr(tables_f16), H, C.byref(geom), ptr(code),
                                                        code.stride(0), n_rows, ptr(code_index), ptr(window),
                                                        ptr(dout), ptr(G), ptr(dcode_s), ptr(dx), stream()),

@@ -70,7 +70,7 @@ def main():
         res["bwd_generic_ms"] = ms
     ms = timeit(lambda: bwd(None), max(3, a.iters // 2))
     res["bwd_notable_ms"] = ms
-    G = torch.zeros((g.total_entries, T, 2), device=dev)
+    G = torch.zeros((T, g.total_entries, 2), device=dev)
 
     def bwdf(Gp=G):
         _lib.check(_lib.lib().nsx_hash_ensemble_bwd_factored(_lib.ptr(x), B, _lib.ptr(f16), H, C.byref(g),
