@@ -544,13 +544,23 @@ struct WgradJob {
     int n_tile0;         // first 32-row block of B handled by job instance (set per launch)
 };
 
+constexpr int MAX_WGRAD_JOBS = 12;
+struct WgradJobs {
+    WgradJob job[MAX_WGRAD_JOBS];
+    float* out[MAX_WGRAD_JOBS];
+    int n;
+};
+
+// grid = (max n-tiles, chunks, jobs): every weight / bias / code-table gradient GEMM of the step in ONE launch
 __global__ __launch_bounds__(256) void deform_wgrad_kernel(const half_t* __restrict__ scratch, int64_t n_tiles,
-                                                           WgradJob job, int n_ntiles, const int32_t* __restrict__ slot,
-                                                           int64_t S, float* __restrict__ C, int chunks) {
-    // block = 4 waves; wave w handles n-tile (blockIdx.x * 4 + w) % n_ntiles ... simpler: grid.x = n_ntiles, grid.y = chunks
+                                                           WgradJobs jobs, const int32_t* __restrict__ slot,
+                                                           int64_t S, int chunks) {
+    const WgradJob job = jobs.job[blockIdx.z];
+    float* __restrict__ C = jobs.out[blockIdx.z];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 31, kb = lane >> 5;
     const int nt = blockIdx.x;
+    if (nt * 32 >= job.n_rows) return;
     const int chunk = blockIdx.y * 4 + wave;
     const int total_chunks = chunks * 4;
     const int64_t per = (n_tiles + total_chunks - 1) / total_chunks;
@@ -677,13 +687,18 @@ int nsx_deform_bwd(const void* packed, const float* positions, int64_t S, const 
                        grad_code_samples);
     NSX_LAUNCH_CHECK("nsx_deform_bwd chain launch");
     // weight / bias / code-table gradients
-    int chunks = (int)((n_tiles + 255) / 256);
+    int chunks = (int)((n_tiles + 63) / 64);       // >= 16 sample tiles per wave
     if (chunks < 1) chunks = 1;
-    if (chunks > 32) chunks = 32;
+    if (chunks > 64) chunks = 64;
+    WgradJobs jobs;
+    jobs.n = 0;
+    int max_ntiles = 1;
     auto run = [&](WgradJob job, float* Cbuf) {
         const int n_ntiles = (job.n_rows + 31) / 32;
-        hipLaunchKernelGGL(deform_wgrad_kernel, dim3(n_ntiles, chunks), dim3(256), 0, st, sc, n_tiles, job, n_ntiles,
-                           code_slot, S, Cbuf, chunks);
+        if (n_ntiles > max_ntiles) max_ntiles = n_ntiles;
+        jobs.job[jobs.n] = job;
+        jobs.out[jobs.n] = Cbuf;
+        jobs.n++;
     };
     const int64_t A_of[7] = {TILE_A0, TILE_A + 0 * DFW * 32, TILE_A + 1 * DFW * 32, TILE_A + 2 * DFW * 32,
                              TILE_A + 3 * DFW * 32, TILE_A + 4 * DFW * 32, TILE_A + 5 * DFW * 32};
@@ -700,6 +715,8 @@ int nsx_deform_bwd(const void* packed, const float* positions, int64_t S, const 
     run(WgradJob{TILE_DZH + 3 * 32, A_of[6], 3, DFW, DFW, P_WV, P_BV, 0}, grad_params);
     if (grad_code_table)
         run(WgradJob{-1, TILE_DC, n_code_rows, DF_CODE, DF_CODE, 0, -1, 0}, grad_code_table);
+    hipLaunchKernelGGL(deform_wgrad_kernel, dim3(max_ntiles, chunks, jobs.n), dim3(256), 0, st, sc, n_tiles, jobs,
+                       code_slot, S, chunks);
     NSX_LAUNCH_CHECK("nsx_deform_bwd wgrad launch");
     return NSX_OK;
 }
