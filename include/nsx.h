@@ -201,7 +201,9 @@ int nsx_ray_histogram(const int64_t* ray_indices, int64_t S, int64_t R, int64_t*
  * visibility = T >= early_stop_eps && (alpha_thre <= 0 || alpha >= alpha_thre).  Any output may be NULL. */
 int nsx_render_weights_fwd(const float* t_starts, const float* t_ends, const float* sigmas,
                            const int64_t* packed_info, int64_t R, float* weights, float* trans, float* alphas,
-                           uint8_t* visibility, float early_stop_eps, float alpha_thre, void* stream);
+                           uint8_t* visibility, float early_stop_eps, float alpha_thre,
+                           const float* alpha_thre_dev /* device scalar overriding alpha_thre; may be NULL */,
+                           void* stream);
 int nsx_render_weights_bwd(const float* t_starts, const float* t_ends, const float* sigmas,
                            const int64_t* packed_info, int64_t R, const float* grad_weights, float* grad_sigmas,
                            void* stream);

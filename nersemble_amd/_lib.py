@@ -71,7 +71,7 @@ SIGNATURES = {
                                c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "nsx_ray_histogram": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p]),
     "nsx_render_weights_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p,
-                                       c_void_p, c_float, c_float, c_void_p]),
+                                       c_void_p, c_float, c_float, c_void_p, c_void_p]),
     "nsx_render_weights_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "nsx_accumulate_fwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int64, c_void_p, c_void_p]),
     "nsx_accumulate_bwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p,

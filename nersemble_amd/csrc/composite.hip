@@ -42,7 +42,9 @@ __device__ __forceinline__ float wave_sum(float v) {
 __global__ __launch_bounds__(CW * 64) void render_weights_kernel(
     const float* __restrict__ t0, const float* __restrict__ t1, const float* __restrict__ sigma,
     const int64_t* __restrict__ packed, int64_t R, float* __restrict__ weights, float* __restrict__ trans,
-    float* __restrict__ alphas, uint8_t* __restrict__ vis, float early_stop_eps, float alpha_thre) {
+    float* __restrict__ alphas, uint8_t* __restrict__ vis, float early_stop_eps, float alpha_thre,
+    const float* __restrict__ alpha_thre_dev) {
+    if (alpha_thre_dev) alpha_thre = alpha_thre_dev[0];
     const int lane = threadIdx.x & 63;
     const int64_t r = (int64_t)blockIdx.x * CW + (threadIdx.x >> 6);
     if (r >= R) return;
@@ -204,13 +206,14 @@ extern "C" {
 
 int nsx_render_weights_fwd(const float* t_starts, const float* t_ends, const float* sigmas,
                            const int64_t* packed_info, int64_t R, float* weights, float* trans, float* alphas,
-                           uint8_t* visibility, float early_stop_eps, float alpha_thre, void* stream) {
+                           uint8_t* visibility, float early_stop_eps, float alpha_thre, const float* alpha_thre_dev,
+                           void* stream) {
     NSX_REQUIRE(R >= 0, "nsx_render_weights_fwd: negative ray count");
     if (R == 0) return NSX_OK;
     NSX_REQUIRE(t_starts && t_ends && sigmas && packed_info, "nsx_render_weights_fwd: NULL argument");
     hipLaunchKernelGGL(render_weights_kernel, dim3((unsigned)((R + CW - 1) / CW)), dim3(CW * 64), 0, (hipStream_t)stream,
                        t_starts, t_ends, sigmas, packed_info, R, weights, trans, alphas, visibility, early_stop_eps,
-                       alpha_thre);
+                       alpha_thre, alpha_thre_dev);
     NSX_LAUNCH_CHECK("nsx_render_weights_fwd launch");
     return NSX_OK;
 }

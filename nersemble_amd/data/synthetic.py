@@ -110,7 +110,11 @@ class SyntheticNeRSembleData:
         rgb, alpha, depth = self.render_ground_truth(origins, directions, times)
         bundle = RayBundle(origins=origins, directions=directions, pixel_area=torch.ones_like(origins[:, :1]),
                            camera_indices=cam_ids[:, None], times=times[:, None],
-                           metadata={"timesteps": timesteps[:, None].int(), "cam_ids": cam_ids[:, None]})
+                           metadata={"timesteps": timesteps[:, None].int(), "cam_ids": cam_ids[:, None],
+                                     # which of the batch's images each ray comes from + the images' timesteps: the
+                                     # pixel sampler already has both (nersemble_pixel_sampler.py:51-64 gathers
+                                     # per-image attributes by the image index c); the model uses them as code slots
+                                     "image_index": which[:, None].int(), "_image_timesteps": img_ts.int()})
         batch = {"image": rgb, "alpha_map": alpha, "depth_maps": depth,
                  "indices": torch.stack([which, ys.long(), xs.long()], -1)}
         return bundle, batch

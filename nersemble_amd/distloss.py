@@ -35,4 +35,5 @@ def flatten_eff_distloss(w: torch.Tensor, m: torch.Tensor, interval: torch.Tenso
     n_rays_t = ray_id.max() + 1                                   # stays on device (no sync)
     if packed_info is None:
         packed_info = pack_info(ray_id, int(n_rays_t.item()))
+    # a caller-provided packed_info may cover more (empty) rays than ray_id.max()+1: they contribute nothing
     return _FlattenEffDistLoss.apply(w, m, interval, packed_info.contiguous()) / n_rays_t

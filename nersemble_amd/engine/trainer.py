@@ -113,7 +113,7 @@ class NeRSembleTrainer:
         self._all_reduce_grads()
         founds = self._optimizer_step_all()
         # the reference skips the LR step when the scale dropped, i.e. when an inf/NaN was found (:199-203)
-        if sum(f.item() for f in founds) == 0:
+        if torch.stack(founds).sum().item() == 0:
             for sch in self.schedulers.values():
                 sch.step()
         return loss, loss_dict, metrics_dict

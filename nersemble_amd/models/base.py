@@ -29,6 +29,12 @@ class BaseModelConfig:
     dist_loss_max_rays: int = 5000
 
 
+def _masked_mean(values: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
+    """mean of values[mask] (0 when the mask is empty) without materialising the selection."""
+    m = mask.to(values.dtype)
+    return (values * m).sum() / m.sum().clamp(min=1.0)
+
+
 def select_dist_loss_samples(ray_indices, weights, starts, ends, max_rays: int):
     """models/base.py:233-243: keep samples of rays with index < max_rays; midpoints and intervals."""
     w = weights.squeeze(1)
@@ -65,7 +71,8 @@ class BaseModel(nn.Module):
         image = batch["image"].to(rgb_pred.device)
         if self.config.use_masked_rgb_loss and "alpha_map" in batch:
             mask = self.get_alpha_per_ray(batch) > self.config.alpha_mask_threshold
-            return torch.nn.functional.mse_loss(image[mask], rgb_pred[mask])
+            # == MSELoss()(image[mask], rgb_pred[mask]) without the boolean-index copy and its host sync
+            return _masked_mean(((image - rgb_pred) ** 2).mean(dim=-1), mask)
         return torch.nn.functional.mse_loss(image, rgb_pred)
 
     def get_alpha_loss(self, batch, accumulation: torch.Tensor) -> Optional[torch.Tensor]:
@@ -74,9 +81,9 @@ class BaseModel(nn.Module):
         acc = accumulation.squeeze(1)
         alpha = self.get_alpha_per_ray(batch)
         bg = alpha < 1
-        if not bg.any():
-            return None
-        return (acc[bg] - alpha[bg]).abs().mean() * self.config.lambda_alpha_loss
+        # the reference returns None when no background ray is present (:129); the masked mean is 0 then, which
+        # leaves the summed loss unchanged and needs no host synchronisation
+        return _masked_mean((acc - alpha).abs(), bg) * self.config.lambda_alpha_loss
 
     def get_near_and_empty_loss(self, batch, ray_samples: RaySamples, ray_indices, weights, accumulation
                                 ) -> Tuple[Optional[torch.Tensor], Optional[torch.Tensor]]:
@@ -91,22 +98,19 @@ class BaseModel(nn.Module):
             w = weights.squeeze(1)
             if self.config.lambda_empty_loss > 0:
                 very_near = (target > 0) & (midpoints < target - eps)
-                if very_near.any():
-                    empty_loss = self.config.lambda_empty_loss * (w[very_near] ** 2).mean()
+                empty_loss = self.config.lambda_empty_loss * _masked_mean(w ** 2, very_near)
             if self.config.lambda_near_loss > 0:
                 near = (target > 0) & (target - eps <= midpoints) & (midpoints <= target + eps)
-                if near.any():
-                    # accumulated weight up to and including each sample, per ray (base.py:176-190 does this with a
-                    # global cumsum minus the value at each ray's head)
-                    csum = w.cumsum(dim=0)
-                    is_head = torch.ones_like(ray_indices, dtype=torch.bool)
-                    is_head[1:] = ray_indices[1:] != ray_indices[:-1]
-                    head_pos = torch.where(is_head)[0]
-                    seg = torch.cumsum(is_head.long(), 0) - 1
-                    head_idx = head_pos[seg]
-                    accumulated = csum - csum[head_idx] + w[head_idx]
-                    expected = Normal(0, (eps / 3) ** 2).cdf(midpoints - target)     # sigma = (eps/3)^2 as in :162
-                    near_loss = self.config.lambda_near_loss * ((accumulated[near] - expected[near]) ** 2).mean()
+                # accumulated weight up to and including each sample, per ray (base.py:176-190 does this with a
+                # global cumsum minus the value at each ray's head); heads found with a running maximum, no sync
+                csum = w.cumsum(dim=0)
+                is_head = torch.ones_like(ray_indices, dtype=torch.bool)
+                is_head[1:] = ray_indices[1:] != ray_indices[:-1]
+                pos = torch.arange(w.shape[0], device=w.device)
+                head_idx = torch.cummax(torch.where(is_head, pos, torch.zeros_like(pos)), dim=0).values
+                accumulated = csum - csum[head_idx] + w[head_idx]
+                expected = Normal(0, (eps / 3) ** 2).cdf(midpoints - target)     # sigma = (eps/3)^2 as in :162
+                near_loss = self.config.lambda_near_loss * _masked_mean((accumulated - expected) ** 2, near)
         return near_loss, empty_loss
 
     def get_depth_loss(self, batch, depths: torch.Tensor) -> Optional[torch.Tensor]:
@@ -115,9 +119,7 @@ class BaseModel(nn.Module):
         target = batch["depth_maps"]
         pred = depths.squeeze()
         mask = target > 0
-        if not mask.any():
-            return None
-        return ((target[mask] - pred[mask]) ** 2).mean() * self.config.lambda_depth_loss
+        return _masked_mean((target - pred) ** 2, mask) * self.config.lambda_depth_loss
 
     def get_dist_loss(self, ray_samples: RaySamples, ray_indices, weights, num_rays: Optional[int] = None,
                       packed_info: Optional[torch.Tensor] = None):
@@ -129,7 +131,8 @@ class BaseModel(nn.Module):
             w = weights.squeeze(1)
             s = ray_samples.frustums.starts.squeeze(-1)
             e = ray_samples.frustums.ends.squeeze(-1)
-            return self.config.lambda_dist_loss * flatten_eff_distloss(w, (e + s) * 0.5, e - s, ray_indices)
+            return self.config.lambda_dist_loss * flatten_eff_distloss(w, (e + s) * 0.5, e - s, ray_indices,
+                                                                       packed_info=packed_info)
         w, m, iv, rid = select_dist_loss_samples(ray_indices, weights, ray_samples.frustums.starts,
                                                  ray_samples.frustums.ends, max_rays)
         return self.config.lambda_dist_loss * flatten_eff_distloss(w, m, iv, rid)

@@ -239,8 +239,13 @@ class NeRSembleNGPModel(BaseModel):
 
         time_codes_deformation = deform_slot = None
         if self.time_embedding is not None:
-            # compact the batch's distinct timesteps (<= 24 images per batch) -> small code tables + per-sample slot
-            uniq, inv = torch.unique(ray_timesteps, return_inverse=True)
+            # small code tables + per-sample slot instead of [S,H] / [S,128] gathers.  The datamanager knows the <= 24
+            # images of the batch (image index per ray + per-image timestep); otherwise compact the distinct timesteps.
+            if "image_index" in ray_bundle.metadata and "_image_timesteps" in ray_bundle.metadata:
+                uniq = ray_bundle.metadata["_image_timesteps"].reshape(-1).int()
+                inv = ray_bundle.metadata["image_index"].reshape(-1)
+            else:
+                uniq, inv = torch.unique(ray_timesteps, return_inverse=True)
             slot = inv.to(torch.int32)[ray_indices]
             ray_samples.metadata["time_codes"] = self.time_embedding(uniq)              # [Tb, H]
             ray_samples.metadata["time_code_index"] = slot                              # [S]
@@ -315,9 +320,9 @@ class NeRSembleNGPModel(BaseModel):
         image = batch["image"].to(rgb.device)
         metrics = {"psnr": psnr(rgb, image), "num_samples_per_batch": outputs["num_samples_per_ray"].sum()}
         if "alpha_map" in batch:
-            mask = batch["alpha_map"].squeeze(1) > 127
-            if mask.any():
-                metrics["psnr_masked"] = psnr(rgb[mask], image[mask])
+            mask = (batch["alpha_map"].squeeze(1) > 127).to(rgb.dtype)
+            mse = (((rgb - image) ** 2).mean(-1) * mask).sum() / mask.sum().clamp(min=1.0)
+            metrics["psnr_masked"] = 10.0 * torch.log10(1.0 / mse)
         return metrics
 
     def get_param_groups(self) -> Dict[str, List[Parameter]]:

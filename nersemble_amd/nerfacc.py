@@ -51,7 +51,7 @@ class _RenderWeights(torch.autograd.Function):
         w, T, a = torch.empty_like(sg), torch.empty_like(sg), torch.empty_like(sg)
         if sg.numel() > 0:
             check(lib().nsx_render_weights_fwd(ptr(t0), ptr(t1), ptr(sg), ptr(packed), packed.shape[0], ptr(w), ptr(T),
-                                               ptr(a), None, 0.0, 0.0, stream()), "nsx_render_weights_fwd")
+                                                   ptr(a), None, 0.0, 0.0, None, stream()), "nsx_render_weights_fwd")
         ctx.save_for_backward(t0, t1, sg, packed)
         ctx.mark_non_differentiable(T, a)
         return w, T, a
@@ -77,15 +77,18 @@ def render_weight_from_density(t_starts: Tensor, t_ends: Tensor, sigmas: Tensor,
 def render_visibility_from_density(t_starts: Tensor, t_ends: Tensor, sigmas: Tensor,
                                    packed_info: Optional[Tensor] = None, ray_indices: Optional[Tensor] = None,
                                    n_rays: Optional[int] = None, early_stop_eps: float = 1e-4,
-                                   alpha_thre: float = 0.0) -> Tensor:
+                                   alpha_thre=0.0) -> Tensor:
+    """``alpha_thre`` may be a float or a 1-element device tensor."""
     packed = _packed(packed_info, ray_indices, n_rays)
     t0, t1 = t_starts.to(torch.float32).contiguous(), t_ends.to(torch.float32).contiguous()
     sg = sigmas.to(torch.float32).contiguous()
     vis = torch.empty(sg.shape, dtype=torch.uint8, device=sg.device)
     if sg.numel() == 0:
         return vis.bool()
+    thre_dev = alpha_thre if isinstance(alpha_thre, Tensor) else None
     check(lib().nsx_render_weights_fwd(ptr(t0), ptr(t1), ptr(sg), ptr(packed), packed.shape[0], None, None, None,
-                                       ptr(vis), float(early_stop_eps), float(alpha_thre), stream()),
+                                       ptr(vis), float(early_stop_eps), 0.0 if thre_dev is not None else float(alpha_thre),
+                                       ptr(thre_dev), stream()),
           "nsx_render_weights_fwd")
     return vis.bool()
 
@@ -218,7 +221,8 @@ class OccGridEstimator(nn.Module):
             near_planes = near_planes + torch.rand_like(near_planes) * render_step_size
         ray_indices, t_starts, t_ends, packed, _ = self.traverse(rays_o, rays_d, near_planes, far, render_step_size)
         if (alpha_thre > 0.0 or early_stop_eps > 0.0) and sigma_fn is not None:
-            alpha_thre = min(alpha_thre, self.occs.mean().item())
+            # nerfacc: alpha_thre = min(alpha_thre, occs.mean().item()); kept on the device (no host sync)
+            alpha_thre = torch.clamp(self.occs.mean(), max=alpha_thre).reshape(1).float()
             if t_starts.shape[0] != 0:
                 sigmas = sigma_fn(t_starts, t_ends, ray_indices)
             else:

@@ -64,8 +64,10 @@ class RayBundle:
     def __getitem__(self, idx) -> "RayBundle":
         def sl(t):
             return t[idx] if isinstance(t, Tensor) else t
+        # metadata keys starting with "_" are per-batch (not per-ray) entries and are passed through unsliced
+        md = {k: (v if k.startswith("_") else sl(v)) for k, v in self.metadata.items()}
         return RayBundle(sl(self.origins), sl(self.directions), sl(self.pixel_area), sl(self.camera_indices),
-                         sl(self.nears), sl(self.fars), {k: sl(v) for k, v in self.metadata.items()}, sl(self.times))
+                         sl(self.nears), sl(self.fars), md, sl(self.times))
 
 
 @dataclass
