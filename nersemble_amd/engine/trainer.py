@@ -31,7 +31,7 @@ class OptimizerConfig:
 
 class NeRSembleTrainer:
     def __init__(self, model: NeRSembleNGPModel, opt_cfg: Optional[OptimizerConfig] = None,
-                 mixed_precision: bool = True, world_size: int = 1):
+                 mixed_precision: bool = True, world_size: int = 1, factored_table_grad: Optional[bool] = None):
         self.model = model
         self.cfg = opt_cfg or OptimizerConfig()
         self.mixed_precision = mixed_precision
@@ -52,7 +52,9 @@ class NeRSembleTrainer:
             if len(small) != len(params):
                 # the 403 M-parameter hash tables: native fused step; the dense gradient is only materialised for DP
                 self.optimizers[name + "/tables"] = HashTableAdam(model.field.hash_ensemble, lr=lrs[name],
-                                                                  eps=self.cfg.eps, factored=(world_size == 1))
+                                                                  eps=self.cfg.eps,
+                                                                  factored=(world_size == 1) if factored_table_grad is None
+                                                                  else factored_table_grad)
                 self.group_of[name + "/tables"] = name
         for key, opt in self.optimizers.items():
             self.schedulers[key] = torch.optim.lr_scheduler.StepLR(opt, step_size=self.cfg.step_size,

@@ -1,0 +1,74 @@
+"""GPU: end-to-end training iterations on the native path (small tables): loss decreases, the factored-gradient
+optimizer path (single GPU) and the dense-gradient path (what data-parallel ranks run before the all-reduce) give the
+same trajectory, checkpoints use the reference's state-dict keys and round-trip."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(factored, steps=6, seed=0, workload="p030_h16"):
+    from nersemble_amd.workloads import build_workload
+    torch.manual_seed(seed)
+    trainer, data, info = build_workload(workload, device="cuda:0", small=True, n_rays=512, factored_table_grad=factored)
+    losses = []
+    for step in range(steps):
+        bundle, batch = data.next_train(step)
+        loss, loss_dict, metrics = trainer.train_iteration(step, bundle, batch)
+        losses.append(loss.item())
+    return trainer, losses, metrics
+
+
+def test_training_loss_decreases_and_paths_agree(cuda):
+    t_f, l_f, m_f = _run(True, steps=12)
+    t_d, l_d, m_d = _run(False, steps=12)
+    assert all(np.isfinite(l_f)) and all(np.isfinite(l_d))
+    assert l_f[-1] < l_f[0] * 0.8
+    # identical data, identical init: factored-on-the-fly Adam == expand + dense Adam up to atomics order
+    assert np.allclose(l_f, l_d, rtol=2e-3, atol=1e-5), (l_f, l_d)
+    # after ONE step the tables agree entry by entry; later steps diverge chaotically on a few entries (Adam with
+    # eps = 1e-15 turns summation-order noise of cancelling gradients into +-lr steps, and density changes near the
+    # pruning threshold change the sample set), which is why the long run is compared through the loss only
+    t1, _, _ = _run(True, steps=1)
+    t2, _, _ = _run(False, steps=1)
+    a = t1.model.field.hash_ensemble.tables.detach()
+    b = t2.model.field.hash_ensemble.tables.detach()
+    d = (a - b).abs()
+    assert (d <= 1e-5).float().mean().item() >= 0.9999
+    assert d.mean().item() <= 1e-7
+
+
+def test_static_h1_config_runs(cuda):
+    """BASELINE configs[0]-like: single timestep, one hash grid (the reference divides by n_timesteps-1 = 0 in the
+    occupancy callback, nersemble_instant_ngp.py:189-190; here time == 0)."""
+    trainer, losses, metrics = _run(None, steps=4, workload="static_h1")
+    assert all(np.isfinite(losses))
+
+
+def test_checkpoint_roundtrip_reference_keys(cuda):
+    from nersemble_amd.workloads import build_workload
+    torch.manual_seed(3)
+    trainer, data, _ = build_workload("p030_h16", device="cuda:0", small=True, n_rays=256)
+    for step in range(2):
+        trainer.train_iteration(step, *data.next_train(step))
+    sd = trainer.model.state_dict()
+    for k in ("field.hash_ensemble.hash_encodings.0.params", "field.hash_ensemble.hash_encodings.3.params",
+              "field.mlp_base.params", "field.mlp_head.params", "time_embedding.weight",
+              "time_embedding_deformation.weight", "deformation_field.se3_field.mlp_stem.layers.4.weight",
+              "deformation_field.aabb", "scene_aabb", "occupancy_grid.occs", "occupancy_grid.binaries"):
+        assert k in sd, k
+    assert "field.hash_ensemble.tables" not in sd
+    torch.manual_seed(4)
+    trainer2, data2, _ = build_workload("p030_h16", device="cuda:0", small=True, n_rays=256)
+    trainer2.model.load_state_dict(sd)
+    # window schedulers are run-time state, not checkpoint state (as in the reference): bring them to the same step
+    for cb in trainer2.callbacks[1:]:
+        cb.run(1)
+    trainer.model.eval(); trainer2.model.eval()
+    bundle, batch, hw = data.eval_image_rays(cam=3, timestep=5, downscale=64)
+    with torch.no_grad():
+        o1 = trainer.model(bundle)["rgb"]
+        o2 = trainer2.model(bundle)["rgb"]
+    assert torch.equal(o1, o2)
+    assert o1.shape[0] == hw[0] * hw[1] and float(o1.min()) >= 0 and float(o1.max()) <= 1     # eval mode clamps
