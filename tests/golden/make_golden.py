@@ -14,6 +14,7 @@ What is pinned (reference-owned code, executed for real):
   * GenericScheduler (engine/generic_scheduler.py), chunked (util/chunker.py)
   * BaseModel.get_dist_loss sample selection / midpoint construction (models/base.py:224-249) with a
     stub flatten_eff_distloss that records its arguments.
+  * BaseModel masked-RGB / alpha / empty / near / depth losses (models/base.py:90-222) on a synthetic packed batch.
 Stubs (third-party packages that are not installed): tinycudann, nerfstudio.*, jaxtyping,
 torch_efficient_distloss.  The nerfstudio MLP / NeRFEncoding / SceneBox stubs restate nerfstudio 0.3.1
  -> that sub-part stays "parity unpinned".
@@ -338,6 +339,62 @@ def gen_distloss_selection(out):
     out["dl_loss"] = np.array([float(loss)])      # = lambda * stub value
 
 
+def gen_losses(out):
+    """BaseModel losses (models/base.py:90-222) on a synthetic packed batch: masked RGB MSE, alpha L1, empty / near
+    (cumsum bookkeeping, Normal CDF with sigma=(eps/3)^2) and depth losses."""
+    from nersemble.nerfstudio.models.base import BaseModel, BaseModelConfig
+    from nersemble.nerfstudio.engine.generic_scheduler import GenericScheduler
+    model = BaseModel.__new__(BaseModel)
+    nn.Module.__init__(model)
+    cfg = BaseModelConfig.__new__(BaseModelConfig)
+    cfg.use_masked_rgb_loss = True
+    cfg.alpha_mask_threshold = 0
+    cfg.lambda_alpha_loss = 1e-2
+    cfg.lambda_empty_loss = 1e-2
+    cfg.lambda_near_loss = 1e-4
+    cfg.lambda_depth_loss = 1e-4
+    cfg.lambda_dist_loss = 0
+    cfg.dist_loss_max_rays = 5000
+    model.config = cfg
+    model.rgb_loss = nn.MSELoss()
+    model._dummy = nn.Parameter(torch.zeros(1))
+    type(model).device = property(lambda self: torch.device("cpu"))
+    model.sched_eps_depth = GenericScheduler(init_value=0.9, final_value=0.01, begin_step=0, end_step=10000)
+    model.sched_eps_depth.update(2500)
+    model.train()
+    rng = np.random.default_rng(11)
+    R = 40
+    counts = rng.integers(1, 30, R)              # the reference's bookkeeping needs every ray to own >= 1 sample
+    ray_idx = np.repeat(np.arange(R), counts)
+    S = len(ray_idx)
+    starts = np.concatenate([8.0 + np.sort(rng.random(c)) * 2.0 for c in counts]).astype(np.float32)
+    ends = (starts + 0.011).astype(np.float32)
+    weights = (rng.random((S, 1)) * 0.1).astype(np.float32)
+    depth = (8.5 + rng.random(R) * 1.0).astype(np.float32)
+    depth[::5] = 0                                # rays without depth information
+    alpha = rng.integers(0, 256, (R, 1)).astype(np.uint8)
+    alpha[::3] = 255
+    alpha[1::7] = 0
+    image = rng.random((R, 3)).astype(np.float32)
+    rgb_pred = rng.random((R, 3)).astype(np.float32)
+    w_t = torch.from_numpy(weights)
+    acc = torch.zeros(R).index_add_(0, torch.from_numpy(ray_idx), w_t[:, 0])[:, None]
+    depth_pred = torch.from_numpy((8.4 + rng.random((R, 1))).astype(np.float32))
+    batch = {"image": torch.from_numpy(image), "alpha_map": torch.from_numpy(alpha), "depth_maps": torch.from_numpy(depth)}
+    fr = types.SimpleNamespace(starts=torch.from_numpy(starts)[:, None], ends=torch.from_numpy(ends)[:, None])
+    rs = types.SimpleNamespace(frustums=fr)
+    near, empty = model.get_near_and_empty_loss(batch, rs, torch.from_numpy(ray_idx), w_t, acc)
+    out["ls_ray_idx"], out["ls_starts"], out["ls_ends"], out["ls_weights"] = ray_idx, starts, ends, weights
+    out["ls_depth"], out["ls_alpha"], out["ls_image"], out["ls_rgb_pred"] = depth, alpha, image, rgb_pred
+    out["ls_acc"], out["ls_depth_pred"] = acc.numpy(), depth_pred.numpy()
+    out["ls_eps"] = np.array([model.sched_eps_depth.value], dtype=np.float64)
+    out["ls_near"] = np.array([float(near)])
+    out["ls_empty"] = np.array([float(empty)])
+    out["ls_rgb"] = np.array([float(model.get_masked_rgb_loss(batch, torch.from_numpy(rgb_pred)))])
+    out["ls_alpha_loss"] = np.array([float(model.get_alpha_loss(batch, acc))])
+    out["ls_depth_loss"] = np.array([float(model.get_depth_loss(batch, depth_pred))])
+
+
 def main():
     torch.set_num_threads(4)
     a, b, c = {}, {}, {}
@@ -347,6 +404,7 @@ def main():
     np.savez_compressed(os.path.join(HERE, "deformation.npz"), **b)
     gen_misc(c)
     gen_distloss_selection(c)
+    gen_losses(c)
     np.savez_compressed(os.path.join(HERE, "misc.npz"), **c)
     for f in ("hash_ensemble.npz", "deformation.npz", "misc.npz"):
         print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")

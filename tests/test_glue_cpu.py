@@ -67,3 +67,34 @@ def test_full_size_deformation_shapes():
     shapes = [tuple(l.weight.shape) for l in df.se3_field.mlp_stem.layers]
     assert shapes == [(128, 173), (128, 128), (128, 128), (128, 128), (128, 301), (128, 128)]
     assert sum(p.numel() for p in df.parameters()) == 127756
+
+
+def test_base_model_losses_match_reference(golden_dir):
+    """Masked RGB MSE, alpha L1, empty / near (per-ray accumulated weights, Normal CDF with sigma=(eps/3)^2) and depth
+    losses vs values computed by the reference's own BaseModel (models/base.py:90-222)."""
+    import types
+    from nersemble_amd.models.base import BaseModel, BaseModelConfig
+    from nersemble_amd.engine.generic_scheduler import GenericScheduler
+    z = np.load(f"{golden_dir}/misc.npz")
+    m = BaseModel.__new__(BaseModel)
+    torch.nn.Module.__init__(m)
+    m.config = BaseModelConfig(use_masked_rgb_loss=True, alpha_mask_threshold=0, lambda_alpha_loss=1e-2,
+                               lambda_empty_loss=1e-2, lambda_near_loss=1e-4, lambda_depth_loss=1e-4)
+    m.sched_eps_depth = GenericScheduler(init_value=0.9, final_value=0.01, begin_step=0, end_step=10000)
+    m.sched_eps_depth.update(2500)
+    assert m.sched_eps_depth.value == z["ls_eps"][0]
+    m.train()
+    batch = {"image": torch.from_numpy(z["ls_image"]), "alpha_map": torch.from_numpy(z["ls_alpha"]),
+             "depth_maps": torch.from_numpy(z["ls_depth"])}
+    fr = types.SimpleNamespace(starts=torch.from_numpy(z["ls_starts"])[:, None], ends=torch.from_numpy(z["ls_ends"])[:, None])
+    rs = types.SimpleNamespace(frustums=fr)
+    near, empty = m.get_near_and_empty_loss(batch, rs, torch.from_numpy(z["ls_ray_idx"]),
+                                            torch.from_numpy(z["ls_weights"]), torch.from_numpy(z["ls_acc"]))
+    assert abs(float(near) - z["ls_near"][0]) <= 1e-6 * abs(z["ls_near"][0]) + 1e-12
+    assert abs(float(empty) - z["ls_empty"][0]) <= 1e-6 * abs(z["ls_empty"][0]) + 1e-12
+    rgb = m.get_masked_rgb_loss(batch, torch.from_numpy(z["ls_rgb_pred"]))
+    assert abs(float(rgb) - z["ls_rgb"][0]) <= 1e-6
+    al = m.get_alpha_loss(batch, torch.from_numpy(z["ls_acc"]))
+    assert abs(float(al) - z["ls_alpha_loss"][0]) <= 1e-7
+    dl = m.get_depth_loss(batch, torch.from_numpy(z["ls_depth_pred"]))
+    assert abs(float(dl) - z["ls_depth_loss"][0]) <= 1e-8
