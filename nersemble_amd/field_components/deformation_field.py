@@ -117,11 +117,12 @@ class SE3DeformationField(nn.Module):
         self.max_n_samples_per_batch = max_n_samples_per_batch
 
     def forward(self, ray_samples: RaySamples, warp_code: Optional[torch.Tensor] = None,
-                windows_param: Optional[float] = None, code_index: Optional[torch.Tensor] = None) -> RaySamples:
-        assert ray_samples.frustums.offsets is None or (
-                ray_samples.frustums.offsets == 0).all(), "ray samples have already been warped"
+                windows_param: Optional[float] = None, code_index: Optional[torch.Tensor] = None,
+                precomputed_offsets: Optional[torch.Tensor] = None) -> RaySamples:
+        assert ray_samples.frustums.offsets is None, "ray samples have already been warped"
         positions = ray_samples.frustums.get_positions()
-        ray_samples.frustums.set_offsets(self.compute_offsets(positions, warp_code, windows_param, code_index))
+        ray_samples.frustums.set_offsets(self.compute_offsets(positions, warp_code, windows_param, code_index,
+                                                              precomputed_offsets))
         return ray_samples
 
     # ---- native path -------------------------------------------------------------------------------
@@ -144,8 +145,10 @@ class SE3DeformationField(nn.Module):
             self._aabb6_cache = (ctypes.c_float * 6)(*[float(v) for v in self.aabb.detach().flatten().tolist()])
         return self._aabb6_cache
 
-    def compute_offsets(self, positions, warp_code=None, windows_param=None, code_index=None):
-        """``code_index`` (native extension): ``warp_code`` is a code TABLE and ``code_index[s]`` the row of sample s."""
+    def compute_offsets(self, positions, warp_code=None, windows_param=None, code_index=None, precomputed=None):
+        """``code_index`` (native extension): ``warp_code`` is a code TABLE and ``code_index[s]`` the row of sample s.
+        ``precomputed``: offsets of the same samples from the step's no-grad sigma_fn pass (forward is skipped, the
+        backward still runs the native kernel)."""
         if positions.is_cuda:
             if not self.native_supported():
                 raise NotImplementedError("native deformation kernel: 6x128 MLP, skip at 4, warp_code_dim 128 "
@@ -156,11 +159,11 @@ class SE3DeformationField(nn.Module):
             flat = self.flat_params()
             outs = []
             if code_index is None:
-                for pos_c, code_c in chunked(max(max_chunk, 1), positions, warp_code):
-                    outs.append(F.deform_offsets(flat, pos_c, code_c, self._aabb6(), windows_param))
+                for pos_c, code_c, pre_c in chunked(max(max_chunk, 1), positions, warp_code, precomputed):
+                    outs.append(F.deform_offsets(flat, pos_c, code_c, self._aabb6(), windows_param, None, pre_c))
             else:
-                for pos_c, idx_c in chunked(max(max_chunk, 1), positions, code_index):
-                    outs.append(F.deform_offsets(flat, pos_c, warp_code, self._aabb6(), windows_param, idx_c))
+                for pos_c, idx_c, pre_c in chunked(max(max_chunk, 1), positions, code_index, precomputed):
+                    outs.append(F.deform_offsets(flat, pos_c, warp_code, self._aabb6(), windows_param, idx_c, pre_c))
             return torch.cat(outs, dim=0) if outs else positions.new_zeros((0, 3))
         # CPU tensors: plain torch restatement (used to pin the glue against the reference's goldens)
         if code_index is not None:

@@ -146,7 +146,8 @@ class HashEnsemble(nn.Module):
                 conditioning_code: torch.Tensor,
                 windows_param: Optional[float] = None,
                 window_hash_encodings: Optional[float] = None,
-                code_index: Optional[torch.Tensor] = None) -> torch.Tensor:
+                code_index: Optional[torch.Tensor] = None,
+                precomputed: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Same contract as the reference (hash_ensemble.py:93-158): in_tensor [B,3] in [0,1),
         conditioning_code [B,H] -> blended features [B, 32] fp16.
 
@@ -177,7 +178,8 @@ class HashEnsemble(nn.Module):
 
         sink = self.grad_sink if (self.grad_sink is not None and torch.is_grad_enabled()) else None
         return F.hash_ensemble(in_tensor, self.tables, self.half_tables(), conditioning_code,
-                               self.n_hash_encodings, self.geom, code_index=code_index, window=window, sink=sink)
+                               self.n_hash_encodings, self.geom, code_index=code_index, window=window, sink=sink,
+                               precomputed=precomputed)
 
     def get_out_dim(self) -> int:
         return self.n_output_dims

@@ -69,6 +69,9 @@ class NeRSembleNeRFactoField(nn.Module):
         self.num_images = num_images
         self.use_hash_ensemble = use_hash_ensemble
         self.max_n_samples_per_batch = max_n_samples_per_batch
+        # set by the model around the sampler's sigma_fn pass: keep hash features / base-MLP outputs for reuse
+        self.keep_density_intermediates = False
+        self.last_hash_features = self.last_base_out = None
 
         self.direction_encoding = tcnn.Encoding(n_input_dims=3, encoding_config={"otype": "Identity"})
         self.hash_ensemble = HashEnsemble(hash_ensemble_config)
@@ -102,25 +105,34 @@ class NeRSembleNeRFactoField(nn.Module):
         md = ray_samples.metadata or {}
         time_codes = md.get("time_codes")
         code_index = md.get("time_code_index")        # native extension: time_codes is a [T,H] table
-        densities, base_outs = [], []
+        pre_feats = md.get("precomputed_hash_features")       # from the step's sigma_fn pass (same samples, same params)
+        pre_base = md.get("precomputed_base_out")
+        densities, base_outs, feats_all = [], [], []
         if code_index is None:
-            chunks = chunked(max(max_chunk, 1), positions, time_codes, None)
+            chunks = ((p, c, None, f, b) for p, c, f, b in chunked(max(max_chunk, 1), positions, time_codes, pre_feats, pre_base))
         else:
-            chunks = ((p, time_codes, ci) for p, ci in chunked(max(max_chunk, 1), positions, code_index))
-        for pos_c, codes_c, idx_c in chunks:
+            chunks = ((p, time_codes, ci, f, b) for p, ci, f, b in chunked(max(max_chunk, 1), positions, code_index,
+                                                                          pre_feats, pre_base))
+        for pos_c, codes_c, idx_c, pre_f, pre_b in chunks:
             # tcnn needs inputs in [0,1): zero the samples outside the scene box (:268-269)
             selector = ((pos_c > 0.0) & (pos_c < 1.0)).all(dim=-1)
             pos_c = pos_c * selector[..., None]
             feats = self.hash_ensemble(pos_c.view(-1, 3), conditioning_code=codes_c,
-                                       window_hash_encodings=window_hash_encodings, code_index=idx_c)
-            h = self.mlp_base(feats).view(*pos_c.shape[:-1], -1)          # [S, 16] fp16
+                                       window_hash_encodings=window_hash_encodings, code_index=idx_c, precomputed=pre_f)
+            h = F.fused_mlp(self.mlp_base.params, self.mlp_base.n_hidden_mats, self.mlp_base.n_output_dims,
+                            self.mlp_base.out_act, b=feats, precomputed=pre_b).view(*pos_c.shape[:-1], -1)   # [S,16] fp16
+            if self.keep_density_intermediates:
+                feats_all.append(feats)
             density_before_activation = h[..., :1]
             density = trunc_exp(density_before_activation.to(pos_c)) * selector[..., None]
             densities.append(density)
             base_outs.append(h)
-        density = torch.cat(densities, dim=0)
-        base_out = torch.cat(base_outs, dim=0)
+        density = densities[0] if len(densities) == 1 else torch.cat(densities, dim=0)
+        base_out = base_outs[0] if len(base_outs) == 1 else torch.cat(base_outs, dim=0)
         self._base_out = base_out                      # full [S,16] tensor for the fused head read
+        if self.keep_density_intermediates:
+            self.last_hash_features = feats_all[0] if len(feats_all) == 1 else torch.cat(feats_all, dim=0)
+            self.last_base_out = base_out
         return density, base_out[..., 1:]
 
     # ---- colour ------------------------------------------------------------------------------------

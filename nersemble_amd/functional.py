@@ -94,11 +94,15 @@ class FactoredGradSink:
 
 class _HashEnsembleFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, tables_master, tables_f16, code, code_index, window, H, geom, sink=None):
+    def forward(ctx, x, tables_master, tables_f16, code, code_index, window, H, geom, sink=None, precomputed=None):
         ctx.sink = sink
         x = x.detach().to(torch.float32).contiguous()
         code_c = code.detach().to(torch.float32).contiguous()
-        out = _hash_ensemble_fwd_raw(x, tables_f16, H, geom, code_c, code_index, window)
+        if precomputed is not None:
+            # forward value already produced by the no-grad sigma_fn pass of the same step on the same inputs
+            out = precomputed.detach().clone() if precomputed.requires_grad else precomputed.detach()
+        else:
+            out = _hash_ensemble_fwd_raw(x, tables_f16, H, geom, code_c, code_index, window)
         ctx.save_for_backward(x, tables_f16, code_c, code_index, window)
         ctx.H, ctx.geom = H, geom
         ctx.master_shape = tables_master.shape
@@ -147,12 +151,13 @@ class _HashEnsembleFn(torch.autograd.Function):
                 dcode.index_add_(0, code_index.to(torch.int64), dcode_s)
             else:
                 dcode = dcode_s
-        return dx, dtab, None, dcode, None, None, None, None, None
+        return dx, dtab, None, dcode, None, None, None, None, None, None
 
 
 def hash_ensemble(x: torch.Tensor, tables_master: torch.Tensor, tables_f16: torch.Tensor, code: torch.Tensor,
                   H: int, geom: GridGeom, code_index: Optional[torch.Tensor] = None,
-                  window: Optional[torch.Tensor] = None, sink: Optional[FactoredGradSink] = None) -> torch.Tensor:
+                  window: Optional[torch.Tensor] = None, sink: Optional[FactoredGradSink] = None,
+                  precomputed: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Fused HashEnsemble forward (hash_ensemble.py:93-158), differentiable w.r.t. x, tables_master, code.
 
     x [B,3] fp32 in [0,1); code fp32 rows of H values (row b, or row code_index[b]); window [H] fp32 or None.
@@ -162,7 +167,7 @@ def hash_ensemble(x: torch.Tensor, tables_master: torch.Tensor, tables_f16: torc
         code_index = code_index.to(torch.int32).contiguous()
     if window is not None:
         window = window.to(device=x.device, dtype=torch.float32).contiguous()
-    return _HashEnsembleFn.apply(x, tables_master, tables_f16, code, code_index, window, H, geom, sink)
+    return _HashEnsembleFn.apply(x, tables_master, tables_f16, code, code_index, window, H, geom, sink, precomputed)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -180,7 +185,7 @@ class _FusedMLPFn(torch.autograd.Function):
     """out = MLP([a * a_mul + a_add (fp32 segment), b[:, b_off:b_off+b_dim] (fp16 segment)]); see include/nsx.h."""
 
     @staticmethod
-    def forward(ctx, params, a, b, n_hidden_mats, a_mul, a_add, b_off, b_dim, n_out, out_act):
+    def forward(ctx, params, a, b, n_hidden_mats, a_mul, a_add, b_off, b_dim, n_out, out_act, precomputed=None):
         dev = params.device
         w16 = torch.empty(params.numel(), dtype=torch.float16, device=dev)
         check(lib().nsx_f32_to_f16(ptr(params.detach().contiguous(), torch.float32), ptr(w16), params.numel(), stream()),
@@ -189,11 +194,15 @@ class _FusedMLPFn(torch.autograd.Function):
         b_c = b.detach().to(torch.float16).contiguous() if b is not None else None
         B = a_c.shape[0] if a_c is not None else b_c.shape[0]
         a_dim = a_c.shape[1] if a_c is not None else 0
-        out = torch.empty((B, n_out), dtype=torch.float16, device=dev)
-        check(lib().nsx_mlp_fwd(ptr(w16), n_hidden_mats, B,
-                                ptr(a_c), a_c.stride(0) if a_c is not None else 0, a_dim, a_mul, a_add,
-                                ptr(b_c), b_c.stride(0) if b_c is not None else 0, b_off, b_dim if b_c is not None else 0,
-                                n_out, out_act, ptr(out), out.stride(0), stream()), "nsx_mlp_fwd")
+        if precomputed is not None:
+            out = precomputed.detach()
+        else:
+            out = torch.empty((B, n_out), dtype=torch.float16, device=dev)
+            check(lib().nsx_mlp_fwd(ptr(w16), n_hidden_mats, B,
+                                    ptr(a_c), a_c.stride(0) if a_c is not None else 0, a_dim, a_mul, a_add,
+                                    ptr(b_c), b_c.stride(0) if b_c is not None else 0, b_off,
+                                    b_dim if b_c is not None else 0, n_out, out_act, ptr(out), out.stride(0), stream()),
+                  "nsx_mlp_fwd")
         ctx.save_for_backward(w16, a_c, b_c)
         ctx.cfg = (n_hidden_mats, a_mul, a_add, b_off, b_dim, n_out, out_act, a_dim)
         ctx.b_shape = b.shape if b is not None else None
@@ -216,18 +225,19 @@ class _FusedMLPFn(torch.autograd.Function):
                                 ptr(b_c), b_c.stride(0) if b_c is not None else 0, b_off, b_dim if b_c is not None else 0,
                                 n_out, out_act, ptr(dout), dout.stride(0), ptr(dW), ptr(da), ptr(db), stream()),
               "nsx_mlp_bwd")
-        return dW, da, db, None, None, None, None, None, None, None
+        return dW, da, db, None, None, None, None, None, None, None, None
 
 
 def fused_mlp(params: torch.Tensor, n_hidden_mats: int, n_out: int, out_act: int = 0,
               a: Optional[torch.Tensor] = None, a_mul: float = 1.0, a_add: float = 0.0,
-              b: Optional[torch.Tensor] = None, b_off: int = 0, b_dim: Optional[int] = None) -> torch.Tensor:
+              b: Optional[torch.Tensor] = None, b_off: int = 0, b_dim: Optional[int] = None,
+              precomputed: Optional[torch.Tensor] = None) -> torch.Tensor:
     """tcnn FullyFusedMLP equivalent (width 64, 1 + n_hidden_mats hidden layers, no biases).
     params: flat fp32 [W0 | Wh | Wo]; returns [B, n_out] fp16."""
     if b is not None and b_dim is None:
         b_dim = b.shape[1] - b_off
     return _FusedMLPFn.apply(params, a, b, n_hidden_mats, float(a_mul), float(a_add), int(b_off),
-                             int(b_dim or 0), int(n_out), int(out_act))
+                             int(b_dim or 0), int(n_out), int(out_act), precomputed)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -250,17 +260,20 @@ def deform_window7(windows_param, n_freq: int = 7):
 
 class _DeformFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, flat_params, code, positions, code_slot, aabb6, window7):
+    def forward(ctx, flat_params, code, positions, code_slot, aabb6, window7, precomputed=None):
         dev = positions.device
         params = flat_params.detach().to(torch.float32).contiguous()
-        packed = torch.empty(int(lib().nsx_deform_pack_bytes()), dtype=torch.uint8, device=dev)
+        packed = torch.empty(_deform_pack_bytes(), dtype=torch.uint8, device=dev)
         check(lib().nsx_deform_pack(ptr(params), ptr(packed), stream()), "nsx_deform_pack")
         pos = positions.detach().to(torch.float32).contiguous()
         code_c = code.detach().to(torch.float32).contiguous()
         S = pos.shape[0]
-        off = torch.empty((S, 3), dtype=torch.float32, device=dev)
-        check(lib().nsx_deform_fwd(ptr(packed), ptr(pos), S, aabb6, ptr(code_c), code_c.stride(0), ptr(code_slot),
-                                   window7, ptr(off), stream()), "nsx_deform_fwd")
+        if precomputed is not None:
+            off = precomputed.detach()
+        else:
+            off = torch.empty((S, 3), dtype=torch.float32, device=dev)
+            check(lib().nsx_deform_fwd(ptr(packed), ptr(pos), S, aabb6, ptr(code_c), code_c.stride(0), ptr(code_slot),
+                                       window7, ptr(off), stream()), "nsx_deform_fwd")
         ctx.save_for_backward(packed, pos, code_c, code_slot)
         ctx.aabb6, ctx.window7 = aabb6, window7
         ctx.n_params = params.numel()
@@ -292,14 +305,25 @@ class _DeformFn(torch.autograd.Function):
                 gcode = torch.zeros_like(code_c).index_add_(0, code_slot.long(), gsamples)
             else:
                 gcode = gsamples
-        return gparams, gcode, None, None, None, None
+        return gparams, gcode, None, None, None, None, None
+
+
+_PACK_BYTES = None
+
+
+def _deform_pack_bytes() -> int:
+    global _PACK_BYTES
+    if _PACK_BYTES is None:
+        _PACK_BYTES = int(lib().nsx_deform_pack_bytes())
+    return _PACK_BYTES
 
 
 def deform_offsets(flat_params: torch.Tensor, positions: torch.Tensor, code: torch.Tensor, aabb6,
-                   windows_param=None, code_slot: Optional[torch.Tensor] = None) -> torch.Tensor:
+                   windows_param=None, code_slot: Optional[torch.Tensor] = None,
+                   precomputed: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Fused SE(3) deformation (deformation_field.py:148-166): offsets [S,3] fp32 in normalised space.
     flat_params: the 16 nn.Linear tensors concatenated in include/nsx.h order; code: [S,128] per-sample codes, or a
     code table with per-sample row indices ``code_slot``; aabb6: ctypes float[6] (host)."""
     if code_slot is not None:
         code_slot = code_slot.to(torch.int32).contiguous()
-    return _DeformFn.apply(flat_params, code, positions, code_slot, aabb6, deform_window7(windows_param))
+    return _DeformFn.apply(flat_params, code, positions, code_slot, aabb6, deform_window7(windows_param), precomputed)

@@ -95,6 +95,9 @@ class NeRSembleNGPModel(BaseModel):
         self.kwargs = {"metadata": metadata or {}}
         self._occ_seed = occ_seed
         self._occ_generator = None
+        self._sigma_cache = None
+        # reuse the forward values of the sampler's no-grad density pass in the main pass (exact; see get_outputs)
+        self.reuse_sigma_pass = True
         self.populate_modules()
 
     # ---- construction (nersemble_instant_ngp.py:81-179) ---------------------------------------------
@@ -204,17 +207,23 @@ class NeRSembleNGPModel(BaseModel):
             # the kernel indexes the embedding table per sample instead of gathering [N,128] codes
             offsets = self.deformation_field.compute_offsets(positions, emb.weight, window_deform, code_index=timesteps)
             positions = positions + offsets
-        return self.field.density_fn(positions, times, window_hash_encodings=window_hash,
-                                     time_codes=self.time_embedding.weight if self.time_embedding is not None else None,
-                                     time_code_index=timesteps)
+        density = self.field.density_fn(positions, times, window_hash_encodings=window_hash,
+                                        time_codes=self.time_embedding.weight if self.time_embedding is not None else None,
+                                        time_code_index=timesteps)
+        if self.field.keep_density_intermediates:
+            # same samples, same parameters, same step as the main pass: its forward values are reused there
+            self._sigma_cache = {"n": positions.shape[0],
+                                 "offsets": offsets if cfg.use_deformation_field else None,
+                                 "features": self.field.last_hash_features, "base_out": self.field.last_base_out}
+        return density
 
     def warp_ray_samples(self, ray_samples: RaySamples, time_codes: Optional[Tensor] = None,
-                         code_index: Optional[Tensor] = None) -> RaySamples:
+                         code_index: Optional[Tensor] = None, precomputed_offsets: Optional[Tensor] = None) -> RaySamples:
         window_deform = self.sched_window_deform.value if self.sched_window_deform is not None else None
         if self.deformation_field is not None:
             assert ray_samples.frustums.offsets is None, "ray samples have already been warped"
             self.deformation_field(ray_samples, warp_code=time_codes, windows_param=window_deform,
-                                   code_index=code_index)
+                                   code_index=code_index, precomputed_offsets=precomputed_offsets)
         return ray_samples
 
     # ---- forward (:280-364) --------------------------------------------------------------------------
@@ -222,13 +231,27 @@ class NeRSembleNGPModel(BaseModel):
         cfg = self.config
         window_hash = self.sched_window_hash_encodings.value if self.sched_window_hash_encodings is not None else None
         num_rays = len(ray_bundle)
+        self._sigma_cache = None
+        self.field.keep_density_intermediates = self.reuse_sigma_pass and self.training and torch.is_grad_enabled()
         with torch.no_grad():
             ray_samples, ray_indices = self.sampler(
                 ray_bundle=ray_bundle, near_plane=cfg.near_plane, far_plane=cfg.far_plane,
                 render_step_size=cfg.render_step_size, alpha_thre=cfg.alpha_thre, cone_angle=cfg.cone_angle,
                 early_stop_eps=cfg.early_stop_eps)
+        self.field.keep_density_intermediates = False
         if ray_samples.metadata is None:
             ray_samples.metadata = dict()
+        # forward values of the sigma_fn pass for the samples that survived the visibility test (exact reuse: the
+        # reference evaluates deformation + hash ensemble + mlp_base twice per step on identical inputs)
+        cache, keep = self._sigma_cache, self.occupancy_grid.last_keep_index
+        pre_offsets = None
+        if cache is not None and keep is not None and cache["n"] == self.occupancy_grid.last_n_marched \
+                and keep.shape[0] == ray_indices.shape[0] and cache["features"] is not None:
+            ray_samples.metadata["precomputed_hash_features"] = cache["features"].index_select(0, keep)
+            ray_samples.metadata["precomputed_base_out"] = cache["base_out"].index_select(0, keep)
+            if cache["offsets"] is not None:
+                pre_offsets = cache["offsets"].index_select(0, keep)
+        self._sigma_cache = None
 
         if ray_bundle.times is not None:
             ray_timesteps = self._timesteps(ray_bundle.times)
@@ -256,7 +279,7 @@ class NeRSembleNGPModel(BaseModel):
             deform_slot = slot
 
         ray_samples = self.warp_ray_samples(ray_samples, time_codes_deformation,
-                                            deform_slot if time_codes_deformation is not None else None)
+                                            deform_slot if time_codes_deformation is not None else None, pre_offsets)
         field_outputs = self.field(ray_samples, window_hash_encodings=window_hash)
 
         packed_info = nerfacc.pack_info(ray_indices, num_rays)

@@ -219,6 +219,7 @@ class OccGridEstimator(nn.Module):
             raise NotImplementedError("per-ray t_max is not used by NeRSemble (ray bundles carry no fars)")
         if stratified:
             near_planes = near_planes + torch.rand_like(near_planes) * render_step_size
+        self.last_keep_index, self.last_n_marched = None, -1
         ray_indices, t_starts, t_ends, packed, _ = self.traverse(rays_o, rays_d, near_planes, far, render_step_size)
         if (alpha_thre > 0.0 or early_stop_eps > 0.0) and sigma_fn is not None:
             # nerfacc: alpha_thre = min(alpha_thre, occs.mean().item()); kept on the device (no host sync)
@@ -230,7 +231,9 @@ class OccGridEstimator(nn.Module):
             assert sigmas.shape == t_starts.shape, "sigmas must have shape of (N,)! Got {}".format(sigmas.shape)
             masks = render_visibility_from_density(t_starts, t_ends, sigmas, packed_info=packed,
                                                    early_stop_eps=early_stop_eps, alpha_thre=alpha_thre)
-            ray_indices, t_starts, t_ends = ray_indices[masks], t_starts[masks], t_ends[masks]
+            keep = masks.nonzero(as_tuple=True)[0]             # one host sync for all three selections
+            self.last_keep_index, self.last_n_marched = keep, masks.shape[0]
+            ray_indices, t_starts, t_ends = ray_indices[keep], t_starts[keep], t_ends[keep]
         return ray_indices, t_starts, t_ends
 
     # ---- grid update (nerfacc _update; torch glue around the density evaluation) ----------------

@@ -72,3 +72,33 @@ def test_checkpoint_roundtrip_reference_keys(cuda):
         o2 = trainer2.model(bundle)["rgb"]
     assert torch.equal(o1, o2)
     assert o1.shape[0] == hw[0] * hw[1] and float(o1.min()) >= 0 and float(o1.max()) <= 1     # eval mode clamps
+
+
+def test_sigma_pass_reuse_is_exact(cuda):
+    """The main pass reuses offsets / hash features / mlp_base outputs computed by the sampler's no-grad density pass
+    for the samples that survive pruning: outputs must be BIT-identical to recomputing them, gradients equal up to
+    atomics order."""
+    from nersemble_amd.workloads import build_workload
+    torch.manual_seed(5)
+    trainer, data, _ = build_workload("p030_h16", device="cuda:0", small=True, n_rays=512, factored_table_grad=False)
+    model = trainer.model
+    for step in range(3):
+        trainer.train_iteration(step, *data.next_train(step))
+    bundle, batch = data.next_train(7)
+    res = {}
+    for reuse in (True, False):
+        model.reuse_sigma_pass = reuse
+        model.zero_grad(set_to_none=True)
+        torch.manual_seed(123)                       # same stratified jitter
+        with torch.autocast("cuda", dtype=torch.float16, cache_enabled=False):
+            out = model(bundle)
+            loss = sum(model.get_loss_dict(out, batch).values())
+        (loss * 1024.0).backward()
+        res[reuse] = (out["rgb"].detach().clone(), out["weights"][0].detach().clone(), loss.item(),
+                      model.field.mlp_head.params.grad.clone(), model.field.hash_ensemble.tables.grad.clone(),
+                      model.time_embedding_deformation.weight.grad.clone())
+    a, b = res[True], res[False]
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and a[2] == b[2]
+    for i in (3, 4, 5):
+        d = (a[i] - b[i]).abs().max().item()
+        assert d <= 1e-4 * max(b[i].abs().max().item(), 1e-12), (i, d)
