@@ -214,6 +214,19 @@ int nsx_accumulate_fwd(const float* weights, const float* values, int C, const i
 int nsx_accumulate_bwd(const float* weights, const float* values, int C, const int64_t* ray_indices, int64_t S,
                        const float* grad_out, float* grad_weights /* may be NULL */,
                        float* grad_values /* may be NULL */, void* stream);
+/* Fused compositing of nersemble_instant_ngp.py:325-343,359-362 (render_weight_from_density + RGBRenderer(white|black
+ * background) + AccumulationRenderer + DepthRenderer("expected", clipped to [min, max] sample midpoint) + the
+ * DeformationRenderer accumulation of `aux`) in one pass; nsx_composite_bwd returns dL/dsigma and dL/drgb from the
+ * gradients of all four outputs (any gradient pointer may be NULL). */
+int nsx_composite_fwd(const float* t_starts, const float* t_ends, const float* sigmas, const float* rgb,
+                      const float* aux /* [S][3] or NULL */, const int64_t* packed_info, int64_t R, float background,
+                      float* clip_workspace /* device float[2]: receives min/max sample midpoint */, float* weights,
+                      float* rgb_ray, float* acc_ray, float* depth_ray, float* aux_ray, void* stream);
+int nsx_composite_bwd(const float* t_starts, const float* t_ends, const float* sigmas, const float* rgb,
+                      const int64_t* packed_info, int64_t R, float background, const float* clip_workspace,
+                      const float* acc_ray, const float* depth_ray, const float* grad_weights, const float* grad_rgb_ray,
+                      const float* grad_acc_ray, const float* grad_depth_ray, float* grad_sigmas, float* grad_rgb,
+                      void* stream);
 /* torch_efficient_distloss.flatten_eff_distloss (models/base.py:245-247): per-ray loss terms
  * ray_loss[r] = (sum_i 1/3 interval_i w_i^2 + 2 w_i (m_i Wpre_i - WMpre_i)) / n_rays for rays r < max_ray (0 otherwise,
  * base.py:235) and grad_weights = grad_scale * dloss/dw.  ray_loss / grad_weights may be NULL. */

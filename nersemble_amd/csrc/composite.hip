@@ -198,6 +198,148 @@ __global__ __launch_bounds__(CW * 64) void distloss_kernel(const float* __restri
     if (lane == 0 && ray_loss) ray_loss[r] = loss * inv_n_rays;
 }
 
+// ------------------------------------------------------------------------------------------------
+// fused compositing: weights + RGB / accumulation / expected depth (+ optional aux accumulation) in one pass
+// ------------------------------------------------------------------------------------------------
+__global__ void minmax_init_kernel(float* __restrict__ mm) {
+    mm[0] = __builtin_inff();
+    mm[1] = -__builtin_inff();
+}
+
+// global min / max of the sample midpoints (DepthRenderer clips to [steps.min(), steps.max()]); t > 0 and sorted per ray
+__global__ __launch_bounds__(256) void minmax_mid_kernel(const float* __restrict__ t0, const float* __restrict__ t1,
+                                                         const int64_t* __restrict__ packed, int64_t R,
+                                                         float* __restrict__ mm) {
+    float lo = __builtin_inff(), hi = -__builtin_inff();
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < R; r += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t s = packed[2 * r], n = packed[2 * r + 1];
+        // midpoints are not guaranteed monotone after fp32 rounding only in pathological cases; scan ends + guard
+        for (int64_t i = 0; i < n; i += (n > 1 ? n - 1 : 1)) {
+            const float m = (t0[s + i] + t1[s + i]) / 2;
+            lo = fminf(lo, m); hi = fmaxf(hi, m);
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { lo = fminf(lo, __shfl_xor(lo, d)); hi = fmaxf(hi, __shfl_xor(hi, d)); }
+    if ((threadIdx.x & 63) == 0) {
+        // positive floats order like their bit patterns as ints; signed handling via two-way atomics
+        if (lo >= 0) atomicMin(reinterpret_cast<int*>(mm), __float_as_int(lo));
+        else atomicMax(reinterpret_cast<unsigned int*>(mm), __float_as_uint(lo));
+        if (hi >= 0) atomicMax(reinterpret_cast<int*>(mm) + 1, __float_as_int(hi));
+        else atomicMin(reinterpret_cast<unsigned int*>(mm) + 1, __float_as_uint(hi));
+    }
+}
+
+__global__ __launch_bounds__(CW * 64) void composite_fwd_kernel(
+    const float* __restrict__ t0, const float* __restrict__ t1, const float* __restrict__ sigma,
+    const float* __restrict__ rgb, const float* __restrict__ aux, const int64_t* __restrict__ packed, int64_t R,
+    float bg, const float* __restrict__ clip, float* __restrict__ weights, float* __restrict__ rgb_ray,
+    float* __restrict__ acc_ray, float* __restrict__ depth_ray, float* __restrict__ aux_ray) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * CW + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const int64_t s = packed[2 * r], n = packed[2 * r + 1];
+    float carry = 0.f, c0 = 0.f, c1 = 0.f, c2 = 0.f, A = 0.f, D = 0.f, a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    for (int64_t base = 0; base < n; base += 64) {
+        const int64_t i = base + lane;
+        const bool ok = i < n;
+        const float ta = ok ? t0[s + i] : 0.f, tb = ok ? t1[s + i] : 0.f;
+        const float sdt = ok ? sigma[s + i] * (tb - ta) : 0.f;
+        const float incl = wave_incl_scan(sdt, lane);
+        const float T = __expf(-(carry + incl - sdt));
+        const float w = ok ? T * (1.0f - __expf(-sdt)) : 0.f;
+        if (ok) {
+            weights[s + i] = w;
+            c0 += w * rgb[(s + i) * 3 + 0]; c1 += w * rgb[(s + i) * 3 + 1]; c2 += w * rgb[(s + i) * 3 + 2];
+            A += w;
+            D += w * ((ta + tb) / 2);
+            if (aux) { a0 += w * aux[(s + i) * 3 + 0]; a1 += w * aux[(s + i) * 3 + 1]; a2 += w * aux[(s + i) * 3 + 2]; }
+        }
+        carry += __shfl(incl, 63);
+    }
+    c0 = wave_sum(c0); c1 = wave_sum(c1); c2 = wave_sum(c2); A = wave_sum(A); D = wave_sum(D);
+    if (aux) { a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2); }
+    if (lane == 0) {
+        rgb_ray[r * 3 + 0] = c0 + bg * (1.0f - A);
+        rgb_ray[r * 3 + 1] = c1 + bg * (1.0f - A);
+        rgb_ray[r * 3 + 2] = c2 + bg * (1.0f - A);
+        acc_ray[r] = A;
+        const float d = D / (A + 1e-10f);
+        depth_ray[r] = fminf(fmaxf(d, clip[0]), clip[1]);
+        if (aux_ray) { aux_ray[r * 3 + 0] = a0; aux_ray[r * 3 + 1] = a1; aux_ray[r * 3 + 2] = a2; }
+    }
+}
+
+// gradients of (weights, rgb_ray, acc_ray, depth_ray) w.r.t. sigma and per-sample rgb
+__global__ __launch_bounds__(CW * 64) void composite_bwd_kernel(
+    const float* __restrict__ t0, const float* __restrict__ t1, const float* __restrict__ sigma,
+    const float* __restrict__ rgb, const int64_t* __restrict__ packed, int64_t R, float bg,
+    const float* __restrict__ clip, const float* __restrict__ acc_ray, const float* __restrict__ depth_ray,
+    const float* __restrict__ g_w, const float* __restrict__ g_rgb, const float* __restrict__ g_acc,
+    const float* __restrict__ g_depth, float* __restrict__ dsigma, float* __restrict__ drgb) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * CW + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const int64_t s = packed[2 * r], n = packed[2 * r + 1];
+    if (n == 0) return;
+    const float gr0 = g_rgb ? g_rgb[r * 3 + 0] : 0.f, gr1 = g_rgb ? g_rgb[r * 3 + 1] : 0.f, gr2 = g_rgb ? g_rgb[r * 3 + 2] : 0.f;
+    const float ga = g_acc ? g_acc[r] : 0.f;
+    float gd = g_depth ? g_depth[r] : 0.f;
+    const float A = acc_ray[r];
+    // un-clipped expected depth is not stored: recompute d = D / (A + eps) on the fly in pass 1
+    float tot = 0.f, Dsum = 0.f;
+    for (int64_t base = 0; base < n; base += 64) {
+        const int64_t i = base + lane;
+        tot += (i < n) ? sigma[s + i] * (t1[s + i] - t0[s + i]) : 0.f;
+    }
+    tot = wave_sum(tot);
+    // D needs the weights: forward-order scan (cheap: the ray's samples are L2 resident)
+    {
+        float carry = 0.f;
+        for (int64_t base = 0; base < n; base += 64) {
+            const int64_t i = base + lane;
+            const bool ok = i < n;
+            const float ta = ok ? t0[s + i] : 0.f, tb = ok ? t1[s + i] : 0.f;
+            const float sdt = ok ? sigma[s + i] * (tb - ta) : 0.f;
+            const float incl = wave_incl_scan(sdt, lane);
+            const float T = __expf(-(carry + incl - sdt));
+            Dsum += ok ? T * (1.0f - __expf(-sdt)) * ((ta + tb) / 2) : 0.f;
+            carry += __shfl(incl, 63);
+        }
+        Dsum = wave_sum(Dsum);
+    }
+    const float dval = Dsum / (A + 1e-10f);
+    if (!(dval >= clip[0] && dval <= clip[1])) gd = 0.f;          // clamp backward
+    const float gd_scaled = gd / (A + 1e-10f);
+    float suffix_carry = 0.f, after = 0.f;
+    const int64_t nchunks = (n + 63) / 64;
+    for (int64_t c = nchunks - 1; c >= 0; --c) {
+        const int64_t i = c * 64 + lane;
+        const bool ok = i < n;
+        const float ta = ok ? t0[s + i] : 0.f, tb = ok ? t1[s + i] : 0.f;
+        const float dt = tb - ta;
+        const float sdt = ok ? sigma[s + i] * dt : 0.f;
+        const float incl = wave_incl_scan(sdt, lane);
+        const float chunk_sum = __shfl(incl, 63);
+        const float excl = (tot - after - chunk_sum) + incl - sdt;
+        const float T = __expf(-excl), Tn = __expf(-(excl + sdt));
+        const float w = T * (1.0f - __expf(-sdt));
+        float g = 0.f;
+        if (ok) {
+            const float q0 = rgb[(s + i) * 3 + 0], q1 = rgb[(s + i) * 3 + 1], q2 = rgb[(s + i) * 3 + 2];
+            g = (g_w ? g_w[s + i] : 0.f) + gr0 * (q0 - bg) + gr1 * (q1 - bg) + gr2 * (q2 - bg) + ga
+                + gd_scaled * ((ta + tb) / 2 - dval);
+            if (drgb) { drgb[(s + i) * 3 + 0] = w * gr0; drgb[(s + i) * 3 + 1] = w * gr1; drgb[(s + i) * 3 + 2] = w * gr2; }
+        }
+        const float gwv = g * w;
+        const float sincl = wave_incl_scan_rev(gwv, lane);
+        const float suffix = suffix_carry + sincl - gwv;
+        if (ok) dsigma[s + i] = dt * (g * Tn - suffix);
+        suffix_carry += __shfl(sincl, 0);
+        after += chunk_sum;
+    }
+}
+
 }  // namespace nsx
 
 using namespace nsx;
@@ -262,6 +404,42 @@ int nsx_accumulate_bwd(const float* weights, const float* values, int C, const i
         hipLaunchKernelGGL((accumulate_bwd_kernel<3>), dim3((unsigned)blocks), dim3(256), 0, st, weights, values,
                            ray_indices, S, grad_out, grad_weights, grad_values);
     NSX_LAUNCH_CHECK("nsx_accumulate_bwd launch");
+    return NSX_OK;
+}
+
+int nsx_composite_fwd(const float* t_starts, const float* t_ends, const float* sigmas, const float* rgb,
+                      const float* aux /* [S][3] or NULL */, const int64_t* packed_info, int64_t R, float background,
+                      float* clip_workspace /* device float[2]: receives min/max sample midpoint */, float* weights,
+                      float* rgb_ray, float* acc_ray, float* depth_ray, float* aux_ray, void* stream) {
+    NSX_REQUIRE(R >= 0, "nsx_composite_fwd: negative ray count");
+    if (R == 0) return NSX_OK;
+    NSX_REQUIRE(t_starts && t_ends && sigmas && rgb && packed_info && clip_workspace && weights && rgb_ray && acc_ray && depth_ray,
+                "nsx_composite_fwd: NULL argument");
+    NSX_REQUIRE(!aux || aux_ray, "nsx_composite_fwd: aux given without aux_ray");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(minmax_init_kernel, dim3(1), dim3(1), 0, st, clip_workspace);
+    hipLaunchKernelGGL(minmax_mid_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, st, t_starts, t_ends,
+                       packed_info, R, clip_workspace);
+    hipLaunchKernelGGL(composite_fwd_kernel, dim3((unsigned)((R + CW - 1) / CW)), dim3(CW * 64), 0, st, t_starts, t_ends,
+                       sigmas, rgb, aux, packed_info, R, background, clip_workspace, weights, rgb_ray, acc_ray, depth_ray,
+                       aux_ray);
+    NSX_LAUNCH_CHECK("nsx_composite_fwd launch");
+    return NSX_OK;
+}
+
+int nsx_composite_bwd(const float* t_starts, const float* t_ends, const float* sigmas, const float* rgb,
+                      const int64_t* packed_info, int64_t R, float background, const float* clip_workspace,
+                      const float* acc_ray, const float* depth_ray, const float* grad_weights, const float* grad_rgb_ray,
+                      const float* grad_acc_ray, const float* grad_depth_ray, float* grad_sigmas, float* grad_rgb,
+                      void* stream) {
+    NSX_REQUIRE(R >= 0, "nsx_composite_bwd: negative ray count");
+    if (R == 0) return NSX_OK;
+    NSX_REQUIRE(t_starts && t_ends && sigmas && rgb && packed_info && clip_workspace && acc_ray && depth_ray && grad_sigmas,
+                "nsx_composite_bwd: NULL argument");
+    hipLaunchKernelGGL(composite_bwd_kernel, dim3((unsigned)((R + CW - 1) / CW)), dim3(CW * 64), 0, (hipStream_t)stream,
+                       t_starts, t_ends, sigmas, rgb, packed_info, R, background, clip_workspace, acc_ray, depth_ray,
+                       grad_weights, grad_rgb_ray, grad_acc_ray, grad_depth_ray, grad_sigmas, grad_rgb);
+    NSX_LAUNCH_CHECK("nsx_composite_bwd launch");
     return NSX_OK;
 }
 

@@ -283,28 +283,24 @@ class NeRSembleNGPModel(BaseModel):
         field_outputs = self.field(ray_samples, window_hash_encodings=window_hash)
 
         packed_info = nerfacc.pack_info(ray_indices, num_rays)
-        weights = nerfacc.render_weight_from_density(
-            t_starts=ray_samples.frustums.starts[..., 0], t_ends=ray_samples.frustums.ends[..., 0],
-            sigmas=field_outputs[FieldHeadNames.DENSITY][..., 0], packed_info=packed_info)[0]
+        # one fused pass for render_weight_from_density + the RGB / accumulation / depth / deformation renderers
+        # (:326-343, :359-362); the renderer modules keep the reference's separate-operator form
+        weights, rgb, accumulation, depth, deformation = nerfacc.composite(
+            ray_samples.frustums.starts[..., 0], ray_samples.frustums.ends[..., 0],
+            field_outputs[FieldHeadNames.DENSITY][..., 0], field_outputs[FieldHeadNames.RGB], packed_info,
+            background=1.0 if cfg.background_color == "white" else 0.0,
+            aux=ray_samples.frustums.offsets.detach() if ray_samples.frustums.offsets is not None else None)
         weights = weights[..., None]
-
-        rgb = self.renderer_rgb(rgb=field_outputs[FieldHeadNames.RGB], weights=weights, ray_indices=ray_indices,
-                                num_rays=num_rays, packed_info=packed_info)
-        depth = self.renderer_depth(weights=weights, ray_samples=ray_samples, ray_indices=ray_indices,
-                                    num_rays=num_rays, packed_info=packed_info)
-        accumulation = self.renderer_accumulation(weights=weights, ray_indices=ray_indices, num_rays=num_rays,
-                                                  packed_info=packed_info)
+        if not self.training:
+            rgb = torch.clamp(rgb, min=0.0, max=1.0)
         outputs = {
             "rgb": rgb, "accumulation": accumulation, "depth": depth, "num_samples_per_ray": packed_info[:, 1],
             # 1-tuples: not per-ray image outputs (:351-356)
             "ray_samples": (ray_samples,), "ray_indices": (ray_indices,), "weights": (weights,),
             "packed_info": (packed_info,),
         }
-        if ray_samples.frustums.offsets is not None:
-            with torch.no_grad():
-                outputs["deformation"] = self.renderer_deformation(weights=weights.detach(), ray_samples=ray_samples,
-                                                                   ray_indices=ray_indices, num_rays=num_rays,
-                                                                   packed_info=packed_info)
+        if deformation is not None:
+            outputs["deformation"] = deformation
         return outputs
 
     def forward(self, ray_bundle: RayBundle):

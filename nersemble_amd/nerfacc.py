@@ -132,6 +132,53 @@ def accumulate_along_rays(weights: Tensor, values: Optional[Tensor] = None, ray_
     return _Accumulate.apply(weights, values, packed, ray_indices)
 
 
+class _Composite(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, t_starts, t_ends, sigmas, rgb, aux, packed, background):
+        t0 = t_starts.detach().to(torch.float32).contiguous()
+        t1 = t_ends.detach().to(torch.float32).contiguous()
+        sg = sigmas.detach().to(torch.float32).contiguous()
+        c = rgb.detach().to(torch.float32).contiguous()
+        ax = aux.detach().to(torch.float32).contiguous() if aux is not None else None
+        R, dev = packed.shape[0], sg.device
+        w = torch.empty_like(sg)
+        rgb_ray = torch.empty((R, 3), dtype=torch.float32, device=dev)
+        acc = torch.empty((R, 1), dtype=torch.float32, device=dev)
+        depth = torch.empty((R, 1), dtype=torch.float32, device=dev)
+        aux_ray = torch.empty((R, 3), dtype=torch.float32, device=dev) if ax is not None else None
+        clip = torch.empty((2,), dtype=torch.float32, device=dev)
+        if sg.numel() > 0:
+            check(lib().nsx_composite_fwd(ptr(t0), ptr(t1), ptr(sg), ptr(c), ptr(ax), ptr(packed), R, float(background),
+                                          ptr(clip), ptr(w), ptr(rgb_ray), ptr(acc), ptr(depth), ptr(aux_ray), stream()),
+                  "nsx_composite_fwd")
+        ctx.save_for_backward(t0, t1, sg, c, packed, clip, acc, depth)
+        ctx.background = float(background)
+        if aux_ray is not None:
+            ctx.mark_non_differentiable(aux_ray)
+        return w, rgb_ray, acc, depth, aux_ray
+
+    @staticmethod
+    def backward(ctx, g_w, g_rgb, g_acc, g_depth, g_aux):
+        t0, t1, sg, c, packed, clip, acc, depth = ctx.saved_tensors
+        def prep(g):
+            return g.to(torch.float32).contiguous() if g is not None else None
+        g_w, g_rgb, g_acc, g_depth = prep(g_w), prep(g_rgb), prep(g_acc), prep(g_depth)
+        ds = torch.zeros_like(sg)
+        dc = torch.zeros_like(c) if ctx.needs_input_grad[3] else None
+        if sg.numel() > 0:
+            check(lib().nsx_composite_bwd(ptr(t0), ptr(t1), ptr(sg), ptr(c), ptr(packed), packed.shape[0], ctx.background,
+                                          ptr(clip), ptr(acc), ptr(depth), ptr(g_w), ptr(g_rgb), ptr(g_acc), ptr(g_depth),
+                                          ptr(ds), ptr(dc), stream()), "nsx_composite_bwd")
+        return None, None, ds, dc, None, None, None
+
+
+def composite(t_starts: Tensor, t_ends: Tensor, sigmas: Tensor, rgb: Tensor, packed_info: Tensor,
+              background: float = 1.0, aux: Optional[Tensor] = None):
+    """Fused render_weight_from_density + RGB / accumulation / expected-depth renderers (+ aux accumulation):
+    returns (weights [S], rgb [R,3], accumulation [R,1], depth [R,1], aux [R,3] | None)."""
+    return _Composite.apply(t_starts, t_ends, sigmas, rgb, aux, packed_info.to(torch.int64).contiguous(), background)
+
+
 # ------------------------------------------------------------------------------------------------
 # occupancy grid
 # ------------------------------------------------------------------------------------------------

@@ -185,3 +185,49 @@ def test_distloss_selection_matches_reference_golden(cuda, golden_dir):
     assert np.array_equal(w.cpu().numpy(), z["dl_sel_w"])
     assert np.array_equal(m.cpu().numpy(), z["dl_sel_m"])
     assert np.array_equal(iv.cpu().numpy(), z["dl_sel_interval"])
+
+
+def test_fused_composite_equals_separate_operators(cuda):
+    """nsx_composite_fwd/bwd == render_weight_from_density + RGB(white bg) / accumulation / depth('expected', clipped)
+    renderers built from the separate nerfacc-shaped operators (values and gradients)."""
+    from nersemble_amd import nerfacc as nf
+    from nersemble_amd.model_components.renderers import AccumulationRenderer, DepthRenderer, RGBRenderer
+    from nersemble_amd.rays import Frustums, RaySamples
+    ray_idx, t0, t1, sigma, packed_o = _packed_case(9)
+    R, S = packed_o.shape[0], len(ray_idx)
+    rng = np.random.default_rng(10)
+    rgbv = rng.random((S, 3)).astype(np.float32)
+    aux = rng.standard_normal((S, 3)).astype(np.float32)
+    ri = torch.from_numpy(ray_idx).to(cuda)
+    packed = nf.pack_info(ri, R)
+    t0t, t1t = torch.from_numpy(t0).to(cuda), torch.from_numpy(t1).to(cuda)
+    g_rgb = torch.from_numpy(rng.standard_normal((R, 3)).astype(np.float32)).to(cuda)
+    g_acc = torch.from_numpy(rng.standard_normal((R, 1)).astype(np.float32)).to(cuda)
+    g_dep = torch.from_numpy(rng.standard_normal((R, 1)).astype(np.float32)).to(cuda)
+    g_w = torch.from_numpy(rng.standard_normal(S).astype(np.float32)).to(cuda)
+
+    def run(fused):
+        sg = torch.from_numpy(sigma).to(cuda).requires_grad_(True)
+        c = torch.from_numpy(rgbv).to(cuda).requires_grad_(True)
+        if fused:
+            w, rgb, acc, dep, ax = nf.composite(t0t, t1t, sg, c, packed, background=1.0, aux=torch.from_numpy(aux).to(cuda))
+        else:
+            w = nf.render_weight_from_density(t0t, t1t, sg, packed_info=packed)[0]
+            rs = RaySamples(Frustums(None, None, t0t[:, None], t1t[:, None], None))
+            rgb = RGBRenderer("white").train()(c, w[:, None], ri, R, packed)
+            acc = AccumulationRenderer()(w[:, None], ri, R, packed)
+            dep = DepthRenderer()(w[:, None], rs, ri, R, packed)
+            ax = nf.accumulate_along_rays(w.detach(), torch.from_numpy(aux).to(cuda), ri, R, packed)
+        ((rgb * g_rgb).sum() + (acc * g_acc).sum() + (dep * g_dep).sum() + (w * g_w).sum()).backward()
+        return [t.detach() for t in (w, rgb, acc, dep, ax, sg.grad, c.grad)]
+
+    a, b = run(True), run(False)
+    names = ["weights", "rgb", "acc", "depth", "aux", "dsigma", "drgb"]
+    for n, x, y in zip(names, a, b):
+        tol = 2e-5 * max(1.0, y.abs().max().item())
+        assert (x - y).abs().max().item() <= tol, (n, (x - y).abs().max().item(), tol)
+    # oracle cross-check of the forward
+    w_o, _, _ = om.render_weights(t0, t1, sigma, packed_o)
+    assert np.abs(a[0].cpu().numpy() - w_o).max() <= 2e-6
+    acc_o = om.accumulate(w_o, None, packed_o)
+    assert np.abs(a[2].cpu().numpy() - acc_o).max() <= 1e-5
