@@ -227,6 +227,18 @@ int nsx_composite_bwd(const float* t_starts, const float* t_ends, const float* s
                       const float* acc_ray, const float* depth_ray, const float* grad_weights, const float* grad_rgb_ray,
                       const float* grad_acc_ray, const float* grad_depth_ray, float* grad_sigmas, float* grad_rgb,
                       void* stream);
+/* Fused per-sample losses of one step: distortion (models/base.py:224-249, rays < max_ray), empty and near losses
+ * (models/base.py:136-202; Normal CDF with sigma = (eps/3)^2, accumulated weights per ray) in one segmented-scan pass.
+ *   per_ray   [R][5] = { dist term, sum w^2 over "very near" samples, their count, sum (A - cdf)^2 over "near"
+ *             samples, their count }; the caller sums over rays:  dist = S0 / n_rays, empty = S1 / max(S2,1),
+ *             near = S3 / max(S4,1).
+ *   bwd: sums = the 5 column sums (device), grads = dL/d{dist, empty, near} (device float[3]); writes dL/dw. */
+int nsx_sample_losses_fwd(const float* weights, const float* t_starts, const float* t_ends, const int64_t* packed_info,
+                          int64_t R, const float* depth_targets /* [R] or NULL */, float eps, int64_t max_ray,
+                          float* per_ray, void* stream);
+int nsx_sample_losses_bwd(const float* weights, const float* t_starts, const float* t_ends, const int64_t* packed_info,
+                          int64_t R, const float* depth_targets, float eps, int64_t max_ray, int64_t n_rays,
+                          const float* sums, const float* grads, float* grad_weights, void* stream);
 /* torch_efficient_distloss.flatten_eff_distloss (models/base.py:245-247): per-ray loss terms
  * ray_loss[r] = (sum_i 1/3 interval_i w_i^2 + 2 w_i (m_i Wpre_i - WMpre_i)) / n_rays for rays r < max_ray (0 otherwise,
  * base.py:235) and grad_weights = grad_scale * dloss/dw.  ray_loss / grad_weights may be NULL. */

@@ -80,6 +80,10 @@ SIGNATURES = {
                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "nsx_composite_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_void_p, c_void_p,
                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "nsx_sample_losses_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_float, c_int64, c_void_p,
+                                      c_void_p]),
+    "nsx_sample_losses_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_float, c_int64, c_int64,
+                                      c_void_p, c_void_p, c_void_p, c_void_p]),
     "nsx_distloss": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_float, c_void_p,
                              c_void_p, c_void_p]),
     "nsx_check_finite": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),

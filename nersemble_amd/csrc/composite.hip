@@ -340,6 +340,110 @@ __global__ __launch_bounds__(CW * 64) void composite_bwd_kernel(
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// fused per-sample losses: distortion (models/base.py:224-249) + empty + near (models/base.py:136-202)
+// per_ray[r] = { dist, empty_sum, empty_cnt, near_sum, near_cnt }
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float normal_cdf(float x, float sigma) {
+    return 0.5f * (1.0f + erff(x / (sigma * 1.4142135623730951f)));
+}
+
+__global__ __launch_bounds__(CW * 64) void sample_losses_fwd_kernel(
+    const float* __restrict__ w, const float* __restrict__ t0, const float* __restrict__ t1,
+    const int64_t* __restrict__ packed, int64_t R, const float* __restrict__ depth_target, float eps, int64_t max_ray,
+    float* __restrict__ per_ray) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * CW + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const int64_t s = packed[2 * r], n = packed[2 * r + 1];
+    const float target = depth_target ? depth_target[r] : 0.f;
+    const float sigma = (eps / 3.0f) * (eps / 3.0f);
+    const bool do_dist = r < max_ray;
+    float cw = 0.f, cwm = 0.f, dist = 0.f, es = 0.f, ec = 0.f, ns = 0.f, nc = 0.f;
+    for (int64_t base = 0; base < n; base += 64) {
+        const int64_t i = base + lane;
+        const bool ok = i < n;
+        const float wi = ok ? w[s + i] : 0.f;
+        const float a = ok ? t0[s + i] : 0.f, b = ok ? t1[s + i] : 0.f;
+        const float mi = (a + b) * 0.5f, iv = b - a, wm = wi * mi;
+        const float iw = wave_incl_scan(wi, lane), iwm = wave_incl_scan(wm, lane);
+        const float wpre = cw + iw - wi, wmpre = cwm + iwm - wm;
+        if (do_dist) dist += (1.0f / 3.0f) * iv * wi * wi + 2.0f * wi * (mi * wpre - wmpre);
+        if (ok && target > 0.f) {
+            if (mi < target - eps) { es += wi * wi; ec += 1.f; }
+            if (target - eps <= mi && mi <= target + eps) {
+                const float diff = (cw + iw) - normal_cdf(mi - target, sigma);      // accumulated incl. this sample
+                ns += diff * diff; nc += 1.f;
+            }
+        }
+        cw += __shfl(iw, 63);
+        cwm += __shfl(iwm, 63);
+    }
+    dist = wave_sum(dist); es = wave_sum(es); ec = wave_sum(ec); ns = wave_sum(ns); nc = wave_sum(nc);
+    if (lane == 0) {
+        per_ray[r * 5 + 0] = dist; per_ray[r * 5 + 1] = es; per_ray[r * 5 + 2] = ec;
+        per_ray[r * 5 + 3] = ns; per_ray[r * 5 + 4] = nc;
+    }
+}
+
+// grad_w = g[0]/n_rays * d dist/dw + g[1]/max(Ce,1) * d empty_sum/dw + g[2]/max(Cn,1) * d near_sum/dw
+__global__ __launch_bounds__(CW * 64) void sample_losses_bwd_kernel(
+    const float* __restrict__ w, const float* __restrict__ t0, const float* __restrict__ t1,
+    const int64_t* __restrict__ packed, int64_t R, const float* __restrict__ depth_target, float eps, int64_t max_ray,
+    float inv_n_rays, const float* __restrict__ sums, const float* __restrict__ g, float* __restrict__ grad_w) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * CW + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const int64_t s = packed[2 * r], n = packed[2 * r + 1];
+    if (n == 0) return;
+    const float target = depth_target ? depth_target[r] : 0.f;
+    const float sigma = (eps / 3.0f) * (eps / 3.0f);
+    const float cd = (r < max_ray) ? g[0] * inv_n_rays : 0.f;
+    const float ce = g[1] / fmaxf(sums[2], 1.0f);
+    const float cn = g[2] / fmaxf(sums[4], 1.0f);
+    // pass 1: ray totals (W, WM) and the total of the near residuals
+    float W = 0.f, WM = 0.f, cw = 0.f, near_tot = 0.f;
+    for (int64_t base = 0; base < n; base += 64) {
+        const int64_t i = base + lane;
+        const bool ok = i < n;
+        const float wi = ok ? w[s + i] : 0.f;
+        const float mi = ok ? (t0[s + i] + t1[s + i]) * 0.5f : 0.f;
+        const float iw = wave_incl_scan(wi, lane);
+        W += wi; WM += wi * mi;
+        if (ok && target > 0.f && target - eps <= mi && mi <= target + eps)
+            near_tot += 2.0f * ((cw + iw) - normal_cdf(mi - target, sigma));
+        cw += __shfl(iw, 63);
+    }
+    W = wave_sum(W); WM = wave_sum(WM); near_tot = wave_sum(near_tot);
+    // pass 2: forward order; suffix of the near residuals = total - exclusive prefix
+    float cwm = 0.f, near_pre = 0.f;
+    cw = 0.f;
+    for (int64_t base = 0; base < n; base += 64) {
+        const int64_t i = base + lane;
+        const bool ok = i < n;
+        const float wi = ok ? w[s + i] : 0.f;
+        const float a = ok ? t0[s + i] : 0.f, b = ok ? t1[s + i] : 0.f;
+        const float mi = (a + b) * 0.5f, iv = b - a, wm = wi * mi;
+        const float iw = wave_incl_scan(wi, lane), iwm = wave_incl_scan(wm, lane);
+        const float wpre = cw + iw - wi, wmpre = cwm + iwm - wm;
+        float nr = 0.f;
+        const bool isnear = ok && target > 0.f && target - eps <= mi && mi <= target + eps;
+        if (isnear) nr = 2.0f * ((cw + iw) - normal_cdf(mi - target, sigma));
+        const float inr = wave_incl_scan(nr, lane);
+        const float near_suffix = near_tot - (near_pre + inr - nr);          // sum over j >= i
+        if (ok) {
+            const float wsuf = W - wpre - wi, wmsuf = WM - wmpre - wm;
+            float gi = cd * ((2.0f / 3.0f) * iv * wi + 2.0f * (mi * (wpre - wsuf) + (wmsuf - wmpre)));
+            if (target > 0.f && mi < target - eps) gi += ce * 2.0f * wi;
+            gi += cn * near_suffix;
+            grad_w[s + i] = gi;
+        }
+        cw += __shfl(iw, 63);
+        cwm += __shfl(iwm, 63);
+        near_pre += __shfl(inr, 63);
+    }
+}
+
 }  // namespace nsx
 
 using namespace nsx;
@@ -440,6 +544,33 @@ int nsx_composite_bwd(const float* t_starts, const float* t_ends, const float* s
                        t_starts, t_ends, sigmas, rgb, packed_info, R, background, clip_workspace, acc_ray, depth_ray,
                        grad_weights, grad_rgb_ray, grad_acc_ray, grad_depth_ray, grad_sigmas, grad_rgb);
     NSX_LAUNCH_CHECK("nsx_composite_bwd launch");
+    return NSX_OK;
+}
+
+int nsx_sample_losses_fwd(const float* weights, const float* t_starts, const float* t_ends, const int64_t* packed_info,
+                          int64_t R, const float* depth_targets, float eps, int64_t max_ray, float* per_ray,
+                          void* stream) {
+    NSX_REQUIRE(R >= 0, "nsx_sample_losses_fwd: negative ray count");
+    if (R == 0) return NSX_OK;
+    NSX_REQUIRE(weights && t_starts && t_ends && packed_info && per_ray, "nsx_sample_losses_fwd: NULL argument");
+    hipLaunchKernelGGL(sample_losses_fwd_kernel, dim3((unsigned)((R + CW - 1) / CW)), dim3(CW * 64), 0,
+                       (hipStream_t)stream, weights, t_starts, t_ends, packed_info, R, depth_targets, eps, max_ray, per_ray);
+    NSX_LAUNCH_CHECK("nsx_sample_losses_fwd launch");
+    return NSX_OK;
+}
+
+int nsx_sample_losses_bwd(const float* weights, const float* t_starts, const float* t_ends, const int64_t* packed_info,
+                          int64_t R, const float* depth_targets, float eps, int64_t max_ray, int64_t n_rays,
+                          const float* sums, const float* grads, float* grad_weights, void* stream) {
+    NSX_REQUIRE(R >= 0, "nsx_sample_losses_bwd: negative ray count");
+    if (R == 0) return NSX_OK;
+    NSX_REQUIRE(weights && t_starts && t_ends && packed_info && sums && grads && grad_weights,
+                "nsx_sample_losses_bwd: NULL argument");
+    NSX_REQUIRE(n_rays >= 1, "nsx_sample_losses_bwd: n_rays must be >= 1");
+    hipLaunchKernelGGL(sample_losses_bwd_kernel, dim3((unsigned)((R + CW - 1) / CW)), dim3(CW * 64), 0,
+                       (hipStream_t)stream, weights, t_starts, t_ends, packed_info, R, depth_targets, eps, max_ray,
+                       1.0f / (float)n_rays, sums, grads, grad_weights);
+    NSX_LAUNCH_CHECK("nsx_sample_losses_bwd launch");
     return NSX_OK;
 }
 

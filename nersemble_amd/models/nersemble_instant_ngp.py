@@ -319,6 +319,27 @@ class NeRSembleNGPModel(BaseModel):
             alpha_loss = self.get_alpha_loss(batch, accumulation)
             if alpha_loss is not None:
                 loss_dict["alpha_loss"] = alpha_loss
+        cfg = self.config
+        num_rays = accumulation.shape[0]
+        fuse = (self.training and ray_indices.is_cuda and "depth_maps" in batch and cfg.lambda_dist_loss > 0
+                and cfg.lambda_near_loss > 0 and cfg.lambda_empty_loss > 0 and num_rays <= cfg.dist_loss_max_rays)
+        if fuse:
+            # distortion + empty + near losses in one segmented-scan kernel (same definitions as models/base.py;
+            # n_rays of the distortion loss = ray_id.max()+1 as in torch_efficient_distloss)
+            from ..distloss import fused_sample_losses
+            n_rays_d = int(num_rays)
+            trio = fused_sample_losses(weights[..., 0], ray_samples.frustums.starts[..., 0],
+                                       ray_samples.frustums.ends[..., 0], outputs["packed_info"][0],
+                                       batch["depth_maps"], self.sched_eps_depth.value, cfg.dist_loss_max_rays, n_rays_d)
+            # torch_efficient_distloss divides by ray_id.max()+1 (not by num_rays): rescale on the device
+            n_eff = (ray_indices.max() + 1).to(trio.dtype)
+            loss_dict["dist_loss"] = cfg.lambda_dist_loss * trio[0] * (n_rays_d / n_eff)
+            loss_dict["empty_loss"] = cfg.lambda_empty_loss * trio[1]
+            loss_dict["near_loss"] = cfg.lambda_near_loss * trio[2]
+            depth_loss = self.get_depth_loss(batch, depths)
+            if depth_loss is not None:
+                loss_dict["depth_loss"] = depth_loss
+            return loss_dict
         if "depth_maps" in batch:
             near_loss, empty_loss = self.get_near_and_empty_loss(batch, ray_samples, ray_indices, weights, accumulation)
             depth_loss = self.get_depth_loss(batch, depths)

@@ -231,3 +231,43 @@ def test_fused_composite_equals_separate_operators(cuda):
     assert np.abs(a[0].cpu().numpy() - w_o).max() <= 2e-6
     acc_o = om.accumulate(w_o, None, packed_o)
     assert np.abs(a[2].cpu().numpy() - acc_o).max() <= 1e-5
+
+
+def test_fused_sample_losses_match_reference_golden_and_separate_ops(cuda, golden_dir):
+    """Fused dist + empty + near kernel vs (1) the values the reference's BaseModel produced for the golden batch and
+    (2) the separate mirrored implementations incl. gradients w.r.t. the weights."""
+    from nersemble_amd import nerfacc as nf
+    from nersemble_amd.distloss import fused_sample_losses, flatten_eff_distloss
+    z = np.load(f"{golden_dir}/misc.npz")
+    ri = torch.from_numpy(z["ls_ray_idx"]).to(cuda)
+    R = int(z["ls_depth"].shape[0])
+    packed = nf.pack_info(ri, R)
+    t0, t1 = torch.from_numpy(z["ls_starts"]).to(cuda), torch.from_numpy(z["ls_ends"]).to(cuda)
+    w = torch.from_numpy(z["ls_weights"][:, 0]).to(cuda).requires_grad_(True)
+    depth = torch.from_numpy(z["ls_depth"]).to(cuda)
+    eps = float(z["ls_eps"][0])
+    trio = fused_sample_losses(w, t0, t1, packed, depth, eps, 5000, R)
+    assert abs(1e-2 * trio[1].item() - z["ls_empty"][0]) <= 1e-5 * abs(z["ls_empty"][0])
+    assert abs(1e-4 * trio[2].item() - z["ls_near"][0]) <= 1e-4 * abs(z["ls_near"][0])
+    gsel = torch.tensor([0.7, -1.3, 2.1], device=cuda)
+    (trio * gsel).sum().backward()
+    g_fused = w.grad.clone()
+    # separate implementations
+    import types
+    from nersemble_amd.models.base import BaseModel, BaseModelConfig
+    from nersemble_amd.engine.generic_scheduler import GenericScheduler
+    m = BaseModel.__new__(BaseModel)
+    torch.nn.Module.__init__(m)
+    m.config = BaseModelConfig(lambda_empty_loss=1.0, lambda_near_loss=1.0, lambda_dist_loss=1.0)
+    m.sched_eps_depth = GenericScheduler(0.9, 0.01, 0, 10000)
+    m.sched_eps_depth.update(2500)
+    m.train()
+    w2 = torch.from_numpy(z["ls_weights"][:, 0]).to(cuda).requires_grad_(True)
+    rs = types.SimpleNamespace(frustums=types.SimpleNamespace(starts=t0[:, None], ends=t1[:, None]))
+    near, empty = m.get_near_and_empty_loss({"depth_maps": depth}, rs, ri, w2[:, None], None)
+    dist = flatten_eff_distloss(w2, (t0 + t1) * 0.5, t1 - t0, ri)
+    assert abs(trio[0].item() - dist.item()) <= 1e-5 * abs(dist.item())
+    assert abs(trio[1].item() - empty.item()) <= 1e-5 * abs(empty.item())
+    assert abs(trio[2].item() - near.item()) <= 1e-4 * abs(near.item())
+    (0.7 * dist - 1.3 * empty + 2.1 * near).backward()
+    assert (g_fused - w2.grad).abs().max().item() <= 1e-4 * w2.grad.abs().max().item()
