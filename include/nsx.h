@@ -147,6 +147,25 @@ int nsx_mlp_bwd(const nsx_half* weights, int n_hidden_mats, int64_t B,
                 float* dweights, float* da, nsx_half* db, void* stream);
 int nsx_f32_to_f16(const float* src, nsx_half* dst, int64_t n, void* stream);
 
+/* ---- field glue (elementwise, fused) ------------------------------------------------------------------------
+ * nsx_sample_positions: pos = o + (d * (t0 + t1)) / 2 (+ offsets) -- Frustums.get_positions (nerfstudio) and the
+ *   sampler's sigma_fn positions; o/d are per sample [S][3], or [R][3] gathered through ray_indices.  With
+ *   t_starts == NULL pos = o (+ offsets).  Optionally also the scene-box normalisation, in-box selector and
+ *   masking of nersemble_nerfacto_field.py:257,268-269 (pos_normalised = normalised * selector, selector u8).
+ * nsx_normalise_bwd: dL/dpos_world = dL/dpos_normalised * selector / extent.
+ * nsx_density_fwd/bwd: density = trunc_exp(float(h0)) * selector (nersemble_nerfacto_field.py:286-293); backward
+ *   g * selector * exp(clamp(h0, -15, 15)) written as fp16 into column 0 of a caller-zeroed [S][stride] buffer. */
+int nsx_sample_positions(const float* origins, const float* directions, const int64_t* ray_indices,
+                         const float* t_starts, const float* t_ends, const float* offsets, int64_t S,
+                         const float* aabb_host, float* pos_world, float* pos_normalised, uint8_t* selector,
+                         void* stream);
+int nsx_normalise_bwd(const float* grad_pos_normalised, const uint8_t* selector, int64_t S, const float* aabb_host,
+                      float* grad_pos_world, void* stream);
+int nsx_density_fwd(const nsx_half* base_out, int64_t stride, const uint8_t* selector, int64_t S, float* density,
+                    void* stream);
+int nsx_density_bwd(const nsx_half* base_out, int64_t stride, const uint8_t* selector, const float* grad_density,
+                    int64_t S, nsx_half* grad_base_out_zeroed, void* stream);
+
 /* ---- fused SE(3) deformation field -------------------------------------------------------------------------
  * Replaces SE3DeformationField.compute_offsets (deformation_field.py:148-166): WindowedNeRFEncoding
  * (windowed_nerf_encoding.py:33-74) + torch.cat with the warp code + 6x128 MLP with a skip into layer 4 + the

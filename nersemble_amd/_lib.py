@@ -56,6 +56,11 @@ SIGNATURES = {
     "nsx_mlp_bwd": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_int64, c_int, c_float, c_float, c_void_p, c_int64,
                             c_int, c_int, c_int, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "nsx_f32_to_f16": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "nsx_sample_positions": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p,
+                                     c_void_p, c_void_p, c_void_p, c_void_p]),
+    "nsx_normalise_bwd": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
+    "nsx_density_fwd": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p]),
+    "nsx_density_bwd": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "nsx_deform_param_count": (c_int, []),
     "nsx_deform_pack_bytes": (c_int64, []),
     "nsx_deform_scratch_bytes": (c_int64, [c_int64]),

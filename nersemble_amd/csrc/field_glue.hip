@@ -1,0 +1,145 @@
+// field_glue.hip -- the elementwise glue around the field kernels, fused: sample positions, scene-box
+// normalisation + in-box selector, and the trunc_exp density epilogue.
+//
+// Replaces the ~30 tiny torch launches per pass of
+//   Frustums.get_positions                      origins + directions * (starts + ends) / 2 (+ offsets)      (nerfstudio)
+//   VolumetricSampler.get_sigma_fn              origins[ray_idx] + dirs[ray_idx] * (t0 + t1)[:, None] / 2    (nerfstudio)
+//   SceneBox.get_normalized_positions + selector + mask   nersemble_nerfacto_field.py:257, :268-269
+//   split / trunc_exp / selector mask           nersemble_nerfacto_field.py:286-293
+// Arithmetic follows torch's op order with contraction off, so results are bit-identical to the unfused form.
+#include "nsx_common.h"
+#pragma clang fp contract(off)
+
+namespace nsx {
+
+struct Box { float lo[3], ext[3]; };
+
+// pos = o + (d * (t0 + t1)) / 2 (+ off);  o/d either per sample [S][3] or gathered through ray_idx from [R][3]
+__global__ __launch_bounds__(256) void sample_positions_kernel(
+    const float* __restrict__ o, const float* __restrict__ d, const int64_t* __restrict__ ray_idx,
+    const float* __restrict__ t0, const float* __restrict__ t1, const float* __restrict__ off, int64_t S, Box box,
+    float* __restrict__ pos_world, float* __restrict__ pos_n, uint8_t* __restrict__ sel) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < S; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = ray_idx ? ray_idx[i] : i;
+        const float tt = t0 ? (t0[i] + t1[i]) : 0.f;
+        float p[3];
+        bool inside = true;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            float v = t0 ? o[r * 3 + a] + (d[r * 3 + a] * tt) / 2.0f : o[r * 3 + a];
+            if (off) v = v + off[i * 3 + a];
+            p[a] = v;
+        }
+        if (pos_world) { pos_world[i * 3] = p[0]; pos_world[i * 3 + 1] = p[1]; pos_world[i * 3 + 2] = p[2]; }
+        if (pos_n) {
+            float q[3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                q[a] = (p[a] - box.lo[a]) / box.ext[a];
+                inside = inside && (q[a] > 0.0f) && (q[a] < 1.0f);
+            }
+            const float m = inside ? 1.0f : 0.0f;
+            pos_n[i * 3] = q[0] * m; pos_n[i * 3 + 1] = q[1] * m; pos_n[i * 3 + 2] = q[2] * m;
+            if (sel) sel[i] = inside ? 1 : 0;
+        }
+    }
+}
+
+// d pos = g * sel / ext
+__global__ __launch_bounds__(256) void normalise_bwd_kernel(const float* __restrict__ g, const uint8_t* __restrict__ sel,
+                                                            int64_t S, Box box, float* __restrict__ dpos) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < S; i += (int64_t)gridDim.x * blockDim.x) {
+        const float m = sel[i] ? 1.0f : 0.0f;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) dpos[i * 3 + a] = (g[i * 3 + a] * m) / box.ext[a];
+    }
+}
+
+// density = exp(float(h0)) * sel
+__global__ __launch_bounds__(256) void density_fwd_kernel(const half_t* __restrict__ base, int64_t stride,
+                                                          const uint8_t* __restrict__ sel, int64_t S,
+                                                          float* __restrict__ density) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < S; i += (int64_t)gridDim.x * blockDim.x)
+        density[i] = expf((float)base[i * stride]) * (sel[i] ? 1.0f : 0.0f);
+}
+
+// trunc_exp backward: d h0 = g * sel * exp(clamp(h0, -15, 15)), written as fp16 into column 0 of a zeroed [S][stride]
+__global__ __launch_bounds__(256) void density_bwd_kernel(const half_t* __restrict__ base, int64_t stride,
+                                                          const uint8_t* __restrict__ sel, const float* __restrict__ g,
+                                                          int64_t S, half_t* __restrict__ dbase) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < S; i += (int64_t)gridDim.x * blockDim.x) {
+        const float h = (float)base[i * stride];
+        const float gd = g[i] * (sel[i] ? 1.0f : 0.0f);
+        dbase[i * stride] = (half_t)(gd * expf(fminf(fmaxf(h, -15.0f), 15.0f)));
+    }
+}
+
+static Box make_box(const float* aabb) {
+    Box b;
+    for (int a = 0; a < 3; ++a) { b.lo[a] = aabb ? aabb[a] : 0.f; b.ext[a] = aabb ? aabb[3 + a] - aabb[a] : 1.f; }
+    return b;
+}
+static unsigned grid_for(int64_t n) {
+    int64_t b = (n + 255) / 256;
+    const int64_t cap = (int64_t)num_cus() * 8;
+    return (unsigned)(b > cap ? cap : (b < 1 ? 1 : b));
+}
+
+}  // namespace nsx
+
+using namespace nsx;
+
+extern "C" {
+
+int nsx_sample_positions(const float* origins, const float* directions, const int64_t* ray_indices,
+                         const float* t_starts, const float* t_ends, const float* offsets, int64_t S,
+                         const float* aabb_host, float* pos_world, float* pos_normalised, uint8_t* selector,
+                         void* stream) {
+    NSX_REQUIRE(S >= 0, "nsx_sample_positions: negative sample count");
+    if (S == 0) return NSX_OK;
+    NSX_REQUIRE(origins, "nsx_sample_positions: NULL origins");
+    NSX_REQUIRE((t_starts == nullptr) == (t_ends == nullptr), "nsx_sample_positions: t_starts/t_ends must come together");
+    NSX_REQUIRE(!t_starts || directions, "nsx_sample_positions: directions required with t_starts");
+    NSX_REQUIRE(pos_world || pos_normalised, "nsx_sample_positions: no output requested");
+    NSX_REQUIRE(!pos_normalised || aabb_host, "nsx_sample_positions: aabb required for normalised positions");
+    hipLaunchKernelGGL(sample_positions_kernel, dim3(grid_for(S)), dim3(256), 0, (hipStream_t)stream, origins, directions,
+                       ray_indices, t_starts, t_ends, offsets, S, make_box(aabb_host), pos_world, pos_normalised, selector);
+    NSX_LAUNCH_CHECK("nsx_sample_positions launch");
+    return NSX_OK;
+}
+
+int nsx_normalise_bwd(const float* grad_pos_normalised, const uint8_t* selector, int64_t S, const float* aabb_host,
+                      float* grad_pos_world, void* stream) {
+    NSX_REQUIRE(S >= 0, "nsx_normalise_bwd: negative sample count");
+    if (S == 0) return NSX_OK;
+    NSX_REQUIRE(grad_pos_normalised && selector && aabb_host && grad_pos_world, "nsx_normalise_bwd: NULL argument");
+    hipLaunchKernelGGL(normalise_bwd_kernel, dim3(grid_for(S)), dim3(256), 0, (hipStream_t)stream, grad_pos_normalised,
+                       selector, S, make_box(aabb_host), grad_pos_world);
+    NSX_LAUNCH_CHECK("nsx_normalise_bwd launch");
+    return NSX_OK;
+}
+
+int nsx_density_fwd(const nsx_half* base_out, int64_t stride, const uint8_t* selector, int64_t S, float* density,
+                    void* stream) {
+    NSX_REQUIRE(S >= 0, "nsx_density_fwd: negative sample count");
+    if (S == 0) return NSX_OK;
+    NSX_REQUIRE(base_out && selector && density, "nsx_density_fwd: NULL argument");
+    hipLaunchKernelGGL(density_fwd_kernel, dim3(grid_for(S)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const half_t*>(base_out), stride, selector, S, density);
+    NSX_LAUNCH_CHECK("nsx_density_fwd launch");
+    return NSX_OK;
+}
+
+int nsx_density_bwd(const nsx_half* base_out, int64_t stride, const uint8_t* selector, const float* grad_density,
+                    int64_t S, nsx_half* grad_base_out_zeroed, void* stream) {
+    NSX_REQUIRE(S >= 0, "nsx_density_bwd: negative sample count");
+    if (S == 0) return NSX_OK;
+    NSX_REQUIRE(base_out && selector && grad_density && grad_base_out_zeroed, "nsx_density_bwd: NULL argument");
+    hipLaunchKernelGGL(density_bwd_kernel, dim3(grid_for(S)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const half_t*>(base_out), stride, selector, grad_density, S,
+                       reinterpret_cast<half_t*>(grad_base_out_zeroed));
+    NSX_LAUNCH_CHECK("nsx_density_bwd launch");
+    return NSX_OK;
+}
+
+}  // extern "C"

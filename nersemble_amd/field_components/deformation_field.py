@@ -120,7 +120,9 @@ class SE3DeformationField(nn.Module):
                 windows_param: Optional[float] = None, code_index: Optional[torch.Tensor] = None,
                 precomputed_offsets: Optional[torch.Tensor] = None) -> RaySamples:
         assert ray_samples.frustums.offsets is None, "ray samples have already been warped"
-        positions = ray_samples.frustums.get_positions()
+        fr = ray_samples.frustums
+        positions = F.sample_positions(fr.origins, fr.directions, fr.starts, fr.ends) if fr.origins.is_cuda \
+            else fr.get_positions()
         ray_samples.frustums.set_offsets(self.compute_offsets(positions, warp_code, windows_param, code_index,
                                                               precomputed_offsets))
         return ray_samples

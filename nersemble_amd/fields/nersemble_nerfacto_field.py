@@ -91,40 +91,65 @@ class NeRSembleNeRFactoField(nn.Module):
                    time_code_index: Optional[Tensor] = None) -> Tensor:
         """Occupancy / sigma_fn entry (nersemble_nerfacto_field.py:228-248)."""
         del times
-        ray_samples = RaySamples(
-            frustums=Frustums(origins=positions, directions=torch.ones_like(positions),
-                              starts=torch.zeros_like(positions[..., :1]), ends=torch.zeros_like(positions[..., :1]),
-                              pixel_area=torch.ones_like(positions[..., :1])),
-            metadata={"time_codes": time_codes, "time_code_index": time_code_index})
-        density, _ = self.get_density(ray_samples, window_hash_encodings=window_hash_encodings)
+        # the reference wraps the positions into dummy Frustums (starts = ends = 0) whose get_positions() returns them
+        # unchanged (:236-246); the wrapper is skipped here
+        density, _ = self._density_from_positions(positions, None, {"time_codes": time_codes,
+                                                                    "time_code_index": time_code_index},
+                                                  window_hash_encodings)
         return density
 
+    def _aabb6(self):
+        if getattr(self, "_aabb6_cache", None) is None:
+            import ctypes
+            self._aabb6_cache = (ctypes.c_float * 6)(*[float(v) for v in self.aabb.detach().flatten().tolist()])
+        return self._aabb6_cache
+
     def get_density(self, ray_samples: RaySamples, window_hash_encodings: Optional[float]) -> Tuple[Tensor, Tensor]:
-        positions = SceneBox.get_normalized_positions(ray_samples.frustums.get_positions(), self.aabb)
+        fr = ray_samples.frustums
+        if fr.origins.is_cuda:
+            base = F.sample_positions(fr.origins, fr.directions, fr.starts, fr.ends)      # offsets added in-kernel below
+            return self._density_from_positions(base, fr.offsets, ray_samples.metadata or {}, window_hash_encodings)
+        return self._density_from_positions(fr.get_positions(), None, ray_samples.metadata or {}, window_hash_encodings)
+
+    def _density_from_positions(self, positions_world: Tensor, offsets: Optional[Tensor], md: Dict,
+                                window_hash_encodings: Optional[float]) -> Tuple[Tensor, Tensor]:
+        """positions (+ offsets) -> scene-box normalisation, selector (:257, :268-269) -> HashEnsemble -> mlp_base ->
+        trunc_exp density (:286-293)."""
+        if positions_world.is_cuda:
+            positions, selector_all = F.normalised_positions(positions_world, offsets, self._aabb6())
+        else:
+            if offsets is not None:
+                positions_world = positions_world + offsets
+            positions = SceneBox.get_normalized_positions(positions_world, self.aabb)
+            selector_all = None
         max_chunk = len(positions) if self.max_n_samples_per_batch == -1 else self.max_n_samples_per_batch
-        md = ray_samples.metadata or {}
         time_codes = md.get("time_codes")
         code_index = md.get("time_code_index")        # native extension: time_codes is a [T,H] table
         pre_feats = md.get("precomputed_hash_features")       # from the step's sigma_fn pass (same samples, same params)
         pre_base = md.get("precomputed_base_out")
         densities, base_outs, feats_all = [], [], []
         if code_index is None:
-            chunks = ((p, c, None, f, b) for p, c, f, b in chunked(max(max_chunk, 1), positions, time_codes, pre_feats, pre_base))
+            chunks = ((p, c, None, f, b, sl) for p, c, f, b, sl in chunked(max(max_chunk, 1), positions, time_codes,
+                                                                          pre_feats, pre_base, selector_all))
         else:
-            chunks = ((p, time_codes, ci, f, b) for p, ci, f, b in chunked(max(max_chunk, 1), positions, code_index,
-                                                                          pre_feats, pre_base))
-        for pos_c, codes_c, idx_c, pre_f, pre_b in chunks:
-            # tcnn needs inputs in [0,1): zero the samples outside the scene box (:268-269)
-            selector = ((pos_c > 0.0) & (pos_c < 1.0)).all(dim=-1)
-            pos_c = pos_c * selector[..., None]
+            chunks = ((p, time_codes, ci, f, b, sl) for p, ci, f, b, sl in chunked(max(max_chunk, 1), positions, code_index,
+                                                                                  pre_feats, pre_base, selector_all))
+        for pos_c, codes_c, idx_c, pre_f, pre_b, sel_c in chunks:
+            if sel_c is None:
+                # tcnn needs inputs in [0,1): zero the samples outside the scene box (:268-269)
+                selector = ((pos_c > 0.0) & (pos_c < 1.0)).all(dim=-1)
+                pos_c = pos_c * selector[..., None]
             feats = self.hash_ensemble(pos_c.view(-1, 3), conditioning_code=codes_c,
                                        window_hash_encodings=window_hash_encodings, code_index=idx_c, precomputed=pre_f)
             h = F.fused_mlp(self.mlp_base.params, self.mlp_base.n_hidden_mats, self.mlp_base.n_output_dims,
                             self.mlp_base.out_act, b=feats, precomputed=pre_b).view(*pos_c.shape[:-1], -1)   # [S,16] fp16
             if self.keep_density_intermediates:
                 feats_all.append(feats)
-            density_before_activation = h[..., :1]
-            density = trunc_exp(density_before_activation.to(pos_c)) * selector[..., None]
+            if sel_c is not None:
+                density = F.density_from_base(h, sel_c)
+            else:
+                density_before_activation = h[..., :1]
+                density = trunc_exp(density_before_activation.to(pos_c)) * selector[..., None]
             densities.append(density)
             base_outs.append(h)
         density = densities[0] if len(densities) == 1 else torch.cat(densities, dim=0)

@@ -327,3 +327,83 @@ def deform_offsets(flat_params: torch.Tensor, positions: torch.Tensor, code: tor
     if code_slot is not None:
         code_slot = code_slot.to(torch.int32).contiguous()
     return _DeformFn.apply(flat_params, code, positions, code_slot, aabb6, deform_window7(windows_param), precomputed)
+
+
+# ------------------------------------------------------------------------------------------------
+# field glue: sample positions, scene-box normalisation + selector, trunc_exp density epilogue
+# ------------------------------------------------------------------------------------------------
+def sample_positions(origins: torch.Tensor, directions: Optional[torch.Tensor], t_starts: Optional[torch.Tensor],
+                     t_ends: Optional[torch.Tensor], ray_indices: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """World-space sample midpoints origins + directions * (t_starts + t_ends) / 2 (no gradient: rays are data)."""
+    S = t_starts.shape[0] if t_starts is not None else origins.shape[0]
+    o = origins.detach().to(torch.float32).contiguous()
+    d = directions.detach().to(torch.float32).contiguous() if directions is not None else None
+    t0 = t_starts.detach().reshape(-1).to(torch.float32).contiguous() if t_starts is not None else None
+    t1 = t_ends.detach().reshape(-1).to(torch.float32).contiguous() if t_ends is not None else None
+    ri = ray_indices.to(torch.int64).contiguous() if ray_indices is not None else None
+    out = torch.empty((S, 3), dtype=torch.float32, device=o.device)
+    check(lib().nsx_sample_positions(ptr(o), ptr(d), ptr(ri), ptr(t0), ptr(t1), None, S, None, ptr(out), None, None,
+                                     stream()), "nsx_sample_positions")
+    return out
+
+
+class _NormalisedPositionsFn(torch.autograd.Function):
+    """(positions [+ offsets]) -> scene-box-normalised positions masked by the in-box selector, and the selector."""
+
+    @staticmethod
+    def forward(ctx, positions, offsets, aabb6):
+        p = positions.detach().to(torch.float32).contiguous()
+        off = offsets.detach().to(torch.float32).contiguous() if offsets is not None else None
+        S = p.shape[0]
+        pn = torch.empty((S, 3), dtype=torch.float32, device=p.device)
+        sel = torch.empty((S,), dtype=torch.uint8, device=p.device)
+        check(lib().nsx_sample_positions(ptr(p), None, None, None, None, ptr(off), S, aabb6, None, ptr(pn), ptr(sel),
+                                         stream()), "nsx_sample_positions")
+        ctx.save_for_backward(sel)
+        ctx.aabb6 = aabb6
+        ctx.has_off = offsets is not None
+        ctx.mark_non_differentiable(sel)
+        return pn, sel
+
+    @staticmethod
+    def backward(ctx, g, _gsel):
+        (sel,) = ctx.saved_tensors
+        need_p, need_o = ctx.needs_input_grad[0], ctx.has_off and ctx.needs_input_grad[1]
+        if not (need_p or need_o):
+            return None, None, None
+        g = g.to(torch.float32).contiguous()
+        dpos = torch.empty_like(g)
+        check(lib().nsx_normalise_bwd(ptr(g), ptr(sel), g.shape[0], ctx.aabb6, ptr(dpos), stream()), "nsx_normalise_bwd")
+        return (dpos if need_p else None), (dpos if need_o else None), None
+
+
+def normalised_positions(positions: torch.Tensor, offsets: Optional[torch.Tensor], aabb6):
+    return _NormalisedPositionsFn.apply(positions, offsets, aabb6)
+
+
+class _DensityFn(torch.autograd.Function):
+    """density = trunc_exp(base_out[:, 0].float()) * selector."""
+
+    @staticmethod
+    def forward(ctx, base_out, sel):
+        b = base_out.detach()
+        assert b.dtype == torch.float16 and b.stride(1) == 1
+        S = b.shape[0]
+        dens = torch.empty((S, 1), dtype=torch.float32, device=b.device)
+        check(lib().nsx_density_fwd(ptr(b) if b.is_contiguous() else C.c_void_p(b.data_ptr()), b.stride(0), ptr(sel), S,
+                                    ptr(dens), stream()), "nsx_density_fwd")
+        ctx.save_for_backward(b, sel)
+        return dens
+
+    @staticmethod
+    def backward(ctx, g):
+        b, sel = ctx.saved_tensors
+        g = g.reshape(-1).to(torch.float32).contiguous()
+        db = torch.zeros(b.shape, dtype=torch.float16, device=b.device)
+        check(lib().nsx_density_bwd(C.c_void_p(b.data_ptr()), b.stride(0), ptr(sel), ptr(g), b.shape[0], ptr(db),
+                                    stream()), "nsx_density_bwd")
+        return db, None
+
+
+def density_from_base(base_out: torch.Tensor, selector: torch.Tensor) -> torch.Tensor:
+    return _DensityFn.apply(base_out, selector)

@@ -7,6 +7,7 @@ from typing import Callable, List, Optional, Tuple
 import torch
 from torch import nn, Tensor
 
+from .. import functional as F
 from ..nerfacc import OccGridEstimator
 from ..rays import Frustums, RayBundle, RaySamples
 from .frustum import TorchFrustum, visibility_grid
@@ -35,9 +36,10 @@ class NeRSembleVolumetricSampler(nn.Module):
         density_fn = self.density_fn
 
         def sigma_fn(t_starts, t_ends, ray_indices):
-            t_origins = origins[ray_indices]
-            t_dirs = directions[ray_indices]
-            positions = t_origins + t_dirs * (t_starts + t_ends)[:, None] / 2.0
+            if origins.is_cuda:
+                positions = F.sample_positions(origins, directions, t_starts, t_ends, ray_indices)
+            else:
+                positions = origins[ray_indices] + directions[ray_indices] * (t_starts + t_ends)[:, None] / 2.0
             if times is None:
                 return density_fn(positions).squeeze(-1)
             return density_fn(positions, times[ray_indices]).squeeze(-1)
