@@ -38,7 +38,10 @@ __global__ __launch_bounds__(256) void check_finite_kernel(const float* __restri
     if (__any(bad) && (threadIdx.x & 63) == 0) found_inf[0] = 1.0f;
 }
 
-// one thread per (entry, f, 4 consecutive grids)
+// Block = 256 threads = a tile of 2048/(2*HP) entries (32 at H = 32).  The tile's slice of G ([slot][entry][f], i.e.
+// one contiguous run per slot) is staged through LDS with coalesced loads; every thread then owns 4 consecutive
+// parameters (float4 streams of master / m / v, half4 store of the working copy) and forms their gradient from the
+// LDS-resident G values and code rows.
 template <int HP>
 __global__ __launch_bounds__(256) void adam_hash_factored_kernel(
     const float* __restrict__ G, int n_slots, const float* __restrict__ code, int64_t code_stride,
@@ -46,28 +49,40 @@ __global__ __launch_bounds__(256) void adam_hash_factored_kernel(
     float* __restrict__ v, half_t* __restrict__ f16, AdamHyper hy, const float* __restrict__ inv_scale,
     const float* __restrict__ found_inf) {
     if (found_inf && found_inf[0] != 0.f) return;
-    extern __shared__ float cs[];     // [n_slots][HP] fp16-rounded windowed codes (as in the forward)
+    constexpr int HV = HP >= 4 ? 4 : HP;                 // parameters per thread (vector width)
+    constexpr int TPE = 2 * HP / HV;                     // threads per entry
+    constexpr int EPB = 256 / TPE;                       // entries per block tile
+    extern __shared__ float smem[];
+    float* cs = smem;                                    // [n_slots][HP] fp16-rounded windowed codes
+    float* gs = smem + n_slots * HP;                     // [n_slots][EPB * 2]
     for (int i = threadIdx.x; i < n_slots * HP; i += blockDim.x) {
         const int sl = i / HP, h = i % HP;
         float c = 0.f;
         if (h < Hreal) c = code[sl * code_stride + h] * (window ? window[h] : 1.0f);
         cs[i] = (float)(half_t)c;
     }
-    __syncthreads();
     const float is = inv_scale ? inv_scale[0] : 1.0f;
-    constexpr int HQ = HP >= 4 ? HP / 4 : 1;
-    constexpr int HV = HP >= 4 ? 4 : HP;
-    const uint64_t n = total * 2ull * HQ;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
-        const int hq = (int)(i % HQ);
-        const int f = (int)((i / HQ) & 1);
-        const uint64_t e = i / (2ull * HQ);
-        const float* gr = G + e * 2ull + f;                 // G is [slot][entry][f]
+    const uint64_t n_tiles = (total + EPB - 1) / EPB;
+    const int le = threadIdx.x / TPE;                    // entry within the tile
+    const int part = threadIdx.x % TPE;
+    const int f = part / (TPE / 2);
+    const int hq = part % (TPE / 2);
+    for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const uint64_t e0 = tile * EPB;
+        __syncthreads();
+        for (int i = threadIdx.x; i < n_slots * EPB * 2; i += blockDim.x) {
+            const int sl = i / (EPB * 2), j = i % (EPB * 2);
+            const uint64_t ge = e0 * 2ull + j;
+            gs[i] = (ge < total * 2ull) ? G[(uint64_t)sl * total * 2ull + ge] : 0.f;
+        }
+        __syncthreads();
+        const uint64_t e = e0 + le;
+        if (e >= total) continue;
         float g[HV];
 #pragma unroll
         for (int k = 0; k < HV; ++k) g[k] = 0.f;
         for (int sl = 0; sl < n_slots; ++sl) {
-            const float gv = gr[(uint64_t)sl * total * 2ull];
+            const float gv = gs[sl * (EPB * 2) + le * 2 + f];
             if (gv != 0.f) {
 #pragma unroll
                 for (int k = 0; k < HV; ++k) g[k] = __fmaf_rn(gv, cs[sl * HP + hq * HV + k], g[k]);
@@ -113,7 +128,9 @@ template <int HP>
 static int launch_adam_factored(const float* G, int n_slots, const float* code, int64_t code_stride, const float* window,
                                 int H, uint64_t total, float* master, float* m, float* v, nsx_half* f16, AdamHyper hy,
                                 const float* inv_scale, const float* found_inf, hipStream_t st) {
-    const size_t smem = (size_t)n_slots * HP * sizeof(float);
+    constexpr int HV = HP >= 4 ? 4 : HP;
+    constexpr int EPB = 256 / (2 * HP / HV);
+    const size_t smem = ((size_t)n_slots * HP + (size_t)n_slots * EPB * 2) * sizeof(float);
     hipLaunchKernelGGL((adam_hash_factored_kernel<HP>), dim3(num_cus() * 8), dim3(256), smem, st, G, n_slots, code,
                        code_stride, window, H, total, master, m, v, reinterpret_cast<half_t*>(f16), hy, inv_scale,
                        found_inf);
