@@ -263,6 +263,37 @@ __device__ __forceinline__ void gemm_layer(const f16x8* __restrict__ frags, int 
     }
 }
 
+// ---- LDS-staged weights: the 4 waves of a block walk the layers in lock-step; each layer's fragment group is copied
+// once from L2 into LDS and read by all waves (4x less L2 traffic than every wave streaming its own fragments) ----
+constexpr int LDS_FRAGS = 76;                               // largest group: W4 (4 M-tiles x 19 K-steps)
+
+__device__ __forceinline__ void stage_group(const f16x8* __restrict__ frags, int first, int count, f16x8* lds) {
+    __syncthreads();                                        // previous group fully consumed
+    const f16x8* src = frags + (size_t)first * 64;
+    for (int i = threadIdx.x; i < count * 64; i += blockDim.x) lds[i] = src[i];
+    __syncthreads();
+}
+
+template <int KT>
+__device__ __forceinline__ void gemm_layer_lds(const f16x8* lds, int local, int lane, const f16x8* in, f32x16 acc[4],
+                                               int t_off = 0, int kt_total = KT) {
+    const f16x8* base = lds + (size_t)(local + t_off) * 64 + lane;
+    f16x8 a[4], nx[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) a[mt] = base[(mt * kt_total) * 64];
+#pragma unroll
+    for (int t = 0; t < KT; ++t) {
+        if (t + 1 < KT) {
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) nx[mt] = base[(mt * kt_total + t + 1) * 64];
+        }
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) acc[mt] = mfma(a[mt], in[t], acc[mt]);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) a[mt] = nx[mt];
+    }
+}
+
 struct Fwd {
     f16x8 x[DF_TIN];
     f16x8 h[DF_TW];              // current activation
@@ -288,7 +319,8 @@ __device__ __forceinline__ const T* launder(const T* p) {
     return p;
 }
 
-__device__ __forceinline__ void forward_tile(const DeformArgs& A0, int64_t b, int lane, Fwd& F, half_t* a_tiles) {
+__device__ __forceinline__ void forward_tile(const DeformArgs& A0, int64_t b, int lane, Fwd& F, half_t* a_tiles,
+                                             f16x8* lds) {
     DeformArgs A = A0;
     A.frags = launder(A0.frags);
     A.bias = launder(A0.bias);
@@ -302,34 +334,38 @@ __device__ __forceinline__ void forward_tile(const DeformArgs& A0, int64_t b, in
     }
     f32x16 acc[4];
     // L0
+    stage_group(A.frags, F0, 44, lds);
     for (int i = 0; i < 4; ++i) acc[i] = zero16();
-    gemm_layer<DF_TIN>(A.frags, F0, lane, F.x, acc);
+    gemm_layer_lds<DF_TIN>(lds, 0, lane, F.x, acc);
     F.m1 = finish_layer(acc, A.bias + 0 * DFW, kb, F.h);
     if (a_tiles) store_tile_chain(a_tiles + 192 * 32 + 0 * DFW * 32, n, kb, F.h);
     // L1..L3 (the input fragments are dead once the layer's MFMAs are issued: the output overwrites them)
 #pragma unroll 1
     for (int l = 1; l <= 3; ++l) {
+        stage_group(A.frags, l == 1 ? F1 : (l == 2 ? F2 : F3), 32, lds);
         for (int i = 0; i < 4; ++i) acc[i] = zero16();
-        gemm_layer<DF_TW>(A.frags, l == 1 ? F1 : (l == 2 ? F2 : F3), lane, F.h, acc);
+        gemm_layer_lds<DF_TW>(lds, 0, lane, F.h, acc);
         const uint64_t m = finish_layer(acc, A.bias + l * DFW, kb, F.h);
         if (l == 1) F.m2 = m; else if (l == 2) F.m3 = m; else F.m4 = m;
         if (a_tiles) store_tile_chain(a_tiles + 192 * 32 + l * DFW * 32, n, kb, F.h);
     }
     // L4: cat[input, x]
+    stage_group(A.frags, F4, 76, lds);
     for (int i = 0; i < 4; ++i) acc[i] = zero16();
-    gemm_layer<DF_TIN>(A.frags, F4, lane, F.x, acc, 0, 19);
-    gemm_layer<DF_TW>(A.frags, F4, lane, F.h, acc, DF_TIN, 19);
+    gemm_layer_lds<DF_TIN>(lds, 0, lane, F.x, acc, 0, 19);
+    gemm_layer_lds<DF_TW>(lds, 0, lane, F.h, acc, DF_TIN, 19);
     F.m5 = finish_layer(acc, A.bias + 4 * DFW, kb, F.h);
     if (a_tiles) store_tile_chain(a_tiles + 192 * 32 + 4 * DFW * 32, n, kb, F.h);
-    // L5 (+ out_activation ReLU)
+    // L5 (+ out_activation ReLU) and the heads share one staged group (F5 | FH are contiguous)
+    stage_group(A.frags, F5, 40, lds);
     for (int i = 0; i < 4; ++i) acc[i] = zero16();
-    gemm_layer<DF_TW>(A.frags, F5, lane, F.h, acc);
+    gemm_layer_lds<DF_TW>(lds, 0, lane, F.h, acc);
     F.m6 = finish_layer(acc, A.bias + 5 * DFW, kb, F.h);
     if (a_tiles) store_tile_chain(a_tiles + 192 * 32 + 5 * DFW * 32, n, kb, F.h);
     // heads (one M-tile, rows 0..5)
     f32x16 o = zero16();
 #pragma unroll
-    for (int t = 0; t < DF_TW; ++t) o = mfma(load_frag(A.frags, FH + t, (uint32_t)lane * 16u), F.h[t], o);
+    for (int t = 0; t < DF_TW; ++t) o = mfma(lds[(32 + t) * 64 + lane], F.h[t], o);
     float own[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) own[r] = (float)(half_t)(o[r] + A.bias[6 * DFW + acc_row(r, kb)]);
@@ -378,12 +414,15 @@ __device__ __forceinline__ void se3_apply(const float r[3], const float v[3], co
 // forward kernel
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256, 2) void deform_fwd_kernel(DeformArgs A, float* __restrict__ offsets, int64_t n_tiles) {
+    __shared__ __attribute__((aligned(16))) f16x8 lds[LDS_FRAGS * 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
+    const int64_t n_groups = (n_tiles + 3) / 4;
+    for (int64_t grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {        // all 4 waves iterate together
+        const int64_t tile = grp * 4 + wave;
         const int64_t b_raw = tile * 32 + (lane & 31);
         const int64_t b = b_raw < A.S ? b_raw : A.S - 1;
         Fwd F;
-        forward_tile(A, b, lane, F, nullptr);
+        forward_tile(A, b, lane, F, nullptr, lds);
         float w[3];
         se3_apply(F.r, F.v, F.pn, w);
         if (b_raw < A.S && (lane >> 5) == 0) {
@@ -420,15 +459,21 @@ __device__ __forceinline__ void mask_pack(const f32x16 d[4], uint64_t mask, f16x
 __global__ __launch_bounds__(256, 1) void deform_bwd_kernel(DeformArgs A, const float* __restrict__ goff,
                                                          half_t* __restrict__ scratch, int64_t n_tiles,
                                                          float* __restrict__ gcode_samples) {
+    __shared__ __attribute__((aligned(16))) f16x8 lds[LDS_FRAGS * 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n = lane & 31, kb = lane >> 5;
-    for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
+    const int64_t n_groups = (n_tiles + 3) / 4;
+    for (int64_t grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {        // all 4 waves iterate together
+        const int64_t tile_raw = grp * 4 + wave;
+        const bool tile_ok = tile_raw < n_tiles;
+        const int64_t tile = tile_ok ? tile_raw : n_tiles - 1;
         const int64_t b_raw = tile * 32 + n;
-        const bool valid = b_raw < A.S;
-        const int64_t b = valid ? b_raw : A.S - 1;
-        half_t* T = scratch + tile * TILE_HALFS;
+        const bool valid = tile_ok && b_raw < A.S;
+        const int64_t b = (b_raw < A.S) ? b_raw : A.S - 1;
+        // waves past the last tile still walk the layers (barriers) but write into the block-private dummy tile
+        half_t* T = scratch + (tile_ok ? tile : n_tiles + (int64_t)blockIdx.x * 4 + wave) * TILE_HALFS;
         Fwd F;
-        forward_tile(A, b, lane, F, T);
+        forward_tile(A, b, lane, F, T, lds);
         const f16x8* frags_l = launder(A.frags);
         // ---- SE(3) backward (fp32): g = dL/dwarped ----
         float g[3] = {0.f, 0.f, 0.f};
@@ -477,13 +522,14 @@ __global__ __launch_bounds__(256, 1) void deform_bwd_kernel(DeformArgs A, const 
         f32x16 d[4];
         f16x8 dz[DF_TW];
         // dA6 = heads^T dzh ; dZ5 = dA6 * relu'(a6)
+        stage_group(frags_l, BH, 36, lds);                   // heads^T (4) | W5^T (32) are contiguous
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) d[mt] = mfma(load_frag(frags_l, BH + mt, (uint32_t)lane * 16u), dzh, zero16());
+        for (int mt = 0; mt < 4; ++mt) d[mt] = mfma(lds[mt * 64 + lane], dzh, zero16());
         mask_pack(d, F.m6, dz);
         store_tile_chain(T + TILE_DZ + 5 * DFW * 32, n, kb, dz);
         // dA5 = W5^T dZ5 ; dZ4
         for (int i = 0; i < 4; ++i) d[i] = zero16();
-        gemm_layer<DF_TW>(frags_l, B5, lane, dz, d);
+        gemm_layer_lds<DF_TW>(lds, 4, lane, dz, d);
         mask_pack(d, F.m5, dz);
         store_tile_chain(T + TILE_DZ + 4 * DFW * 32, n, kb, dz);
         // keep dZ4 for the code gradient (dC = W4[:, code]^T dZ4 + W0[:, code]^T dZ0), formed at the end
@@ -492,26 +538,32 @@ __global__ __launch_bounds__(256, 1) void deform_bwd_kernel(DeformArgs A, const 
         for (int t = 0; t < DF_TW; ++t) dz4[t] = dz[t];
         // dA4 = W4[:, x]^T dZ4 ; dZ3
         for (int i = 0; i < 4; ++i) d[i] = zero16();
-        gemm_layer<DF_TW>(frags_l, B4X, lane, dz, d);
+        stage_group(frags_l, B4X, 32, lds);
+        gemm_layer_lds<DF_TW>(lds, 0, lane, dz, d);
         mask_pack(d, F.m4, dz);
         store_tile_chain(T + TILE_DZ + 3 * DFW * 32, n, kb, dz);
         // L3 -> L2 -> L1
         for (int i = 0; i < 4; ++i) d[i] = zero16();
-        gemm_layer<DF_TW>(frags_l, B3, lane, dz, d);
+        stage_group(frags_l, B3, 32, lds);
+        gemm_layer_lds<DF_TW>(lds, 0, lane, dz, d);
         mask_pack(d, F.m3, dz);
         store_tile_chain(T + TILE_DZ + 2 * DFW * 32, n, kb, dz);
         for (int i = 0; i < 4; ++i) d[i] = zero16();
-        gemm_layer<DF_TW>(frags_l, B2, lane, dz, d);
+        stage_group(frags_l, B2, 32, lds);
+        gemm_layer_lds<DF_TW>(lds, 0, lane, dz, d);
         mask_pack(d, F.m2, dz);
         store_tile_chain(T + TILE_DZ + 1 * DFW * 32, n, kb, dz);
         for (int i = 0; i < 4; ++i) d[i] = zero16();
-        gemm_layer<DF_TW>(frags_l, B1, lane, dz, d);
+        stage_group(frags_l, B1, 32, lds);
+        gemm_layer_lds<DF_TW>(lds, 0, lane, dz, d);
         mask_pack(d, F.m1, dz);
         store_tile_chain(T + TILE_DZ + 0 * DFW * 32, n, kb, dz);
         f32x16 dcode[4];
         for (int i = 0; i < 4; ++i) dcode[i] = zero16();
-        gemm_layer<DF_TW>(frags_l, B0C, lane, dz, dcode);
-        gemm_layer<DF_TW>(frags_l, B4C, lane, dz4, dcode);
+        stage_group(frags_l, B0C, 32, lds);
+        gemm_layer_lds<DF_TW>(lds, 0, lane, dz, dcode);
+        stage_group(frags_l, B4C, 32, lds);
+        gemm_layer_lds<DF_TW>(lds, 0, lane, dz4, dcode);
         {
             half_t* Cc = T + TILE_DC;       // natural code index: row = 32 mt + acc_row(r, kb)
 #pragma unroll
@@ -637,7 +689,8 @@ extern "C" {
 
 int nsx_deform_param_count(void) { return P_TOTAL; }
 int64_t nsx_deform_pack_bytes(void) { return (int64_t)N_FRAGS * 64 * 16 + (int64_t)N_BIAS * 4; }
-int64_t nsx_deform_scratch_bytes(int64_t S) { return ((S + 31) / 32) * TILE_HALFS * 2; }
+// + one private dummy tile per possible wave of the launch (tail waves of the lock-stepped blocks write there)
+int64_t nsx_deform_scratch_bytes(int64_t S) { return (((S + 31) / 32) + (int64_t)num_cus() * 2 * 4) * TILE_HALFS * 2; }
 
 int nsx_deform_pack(const float* params, void* packed, void* stream) {
     NSX_REQUIRE(params && packed, "nsx_deform_pack: NULL argument");
