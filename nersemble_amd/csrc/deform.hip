@@ -302,15 +302,47 @@ struct Fwd {
     float r[3], v[3];            // head outputs (fp16-rounded), valid on both lanes of a sample
 };
 
-// store fragments (chained k order) as a [neuron][32 samples] fp16 tile
-__device__ __forceinline__ void store_tile_chain(half_t* __restrict__ tile, int n, int kb, const f16x8 h[DF_TW]) {
-#pragma unroll
-    for (int t = 0; t < DF_TW; ++t)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) tile[kchain(t, kb, j) * 32 + n] = h[t][j];
+// ---- transposed tiles for the sample-contracted GEMMs ---------------------------------------------------------
+// The weight-gradient GEMMs contract over SAMPLES, so they need operands with lane = neuron and 8 samples per lane --
+// the transpose of the chain's fragments (lane = sample, 8 neurons).  The transpose is done on the matrix core:
+// D[sample][c] = sum_k X[sample][k] * I[k][c] with the fragment as A operand and a 16x32 selector (identity placed
+// in columns 0..15 or 16..31) as B: two K-steps fill one 32-column tile, exactly (products with 1.0, fp32
+// accumulation).  The accumulator layout (lane = column/neuron, 16 samples in registers) is stored as is: 32 B per
+// lane, fully coalesced -- instead of 64 two-byte stores per activation.
+// Tile p of an activation = [64 lanes][16 halfs]; lane (c = lane&31, half), element r <-> sample acc_row(r, half);
+// column c of tile p is neuron 32p + c for natural-order inputs and tile_neuron_chain(p, c) for chained fragments.
+__device__ __host__ __forceinline__ int tile_neuron_chain(int p, int c) {
+    return 32 * p + (c & 3) + 8 * (2 * (c >> 4) + ((c & 7) >> 2)) + 4 * ((c >> 3) & 1);
 }
 
-// forward of one tile; when tiles != nullptr also writes a0..a6 as [neuron][sample] tiles for the wgrad GEMMs
+struct TSel { f16x8 lo, hi; };
+
+__device__ __forceinline__ TSel make_tsel(int lane) {
+    TSel s;
+    const int n = lane & 31, kb = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        s.lo[j] = (n == 8 * kb + j) ? (half_t)1.f : (half_t)0.f;
+        s.hi[j] = (n == 16 + 8 * kb + j) ? (half_t)1.f : (half_t)0.f;
+    }
+    return s;
+}
+
+template <int NF>
+__device__ __forceinline__ void store_tile_T(half_t* __restrict__ dst, int lane, const f16x8* frags, const TSel& sel) {
+#pragma unroll
+    for (int p = 0; p < (NF + 1) / 2; ++p) {
+        f32x16 d = mfma(frags[2 * p], sel.lo, zero16());
+        if (2 * p + 1 < NF) d = mfma(frags[2 * p + 1], sel.hi, d);
+        f16x8 o0, o1;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { o0[r] = (half_t)d[r]; o1[r] = (half_t)d[8 + r]; }
+        f16x8* out = reinterpret_cast<f16x8*>(dst + ((size_t)p * 64 + lane) * 16);
+        out[0] = o0;
+        out[1] = o1;
+    }
+}
+
 // Loop-invariant-code motion would hoist every bias value and fragment address (hundreds of VGPRs) out of the
 // persistent tile loop; laundering the uniform base pointers once per tile keeps them as in-loop loads.
 template <typename T>
@@ -326,11 +358,10 @@ __device__ __forceinline__ void forward_tile(const DeformArgs& A0, int64_t b, in
     A.bias = launder(A0.bias);
     const int n = lane & 31, kb = lane >> 5;
     build_input(A, b, kb, F.pn, F.x);
+    TSel tsel;
     if (a_tiles) {
-#pragma unroll
-        for (int t = 0; t < DF_TIN; ++t)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) a_tiles[(16 * t + 8 * kb + j) * 32 + n] = F.x[t][j];
+        tsel = make_tsel(lane);
+        store_tile_T<DF_TIN>(a_tiles, lane, F.x, tsel);
     }
     f32x16 acc[4];
     // L0
@@ -338,7 +369,7 @@ __device__ __forceinline__ void forward_tile(const DeformArgs& A0, int64_t b, in
     for (int i = 0; i < 4; ++i) acc[i] = zero16();
     gemm_layer_lds<DF_TIN>(lds, 0, lane, F.x, acc);
     F.m1 = finish_layer(acc, A.bias + 0 * DFW, kb, F.h);
-    if (a_tiles) store_tile_chain(a_tiles + 192 * 32 + 0 * DFW * 32, n, kb, F.h);
+    if (a_tiles) store_tile_T<DF_TW>(a_tiles + 192 * 32 + 0 * DFW * 32, lane, F.h, tsel);
     // L1..L3 (the input fragments are dead once the layer's MFMAs are issued: the output overwrites them)
 #pragma unroll 1
     for (int l = 1; l <= 3; ++l) {
@@ -347,7 +378,7 @@ __device__ __forceinline__ void forward_tile(const DeformArgs& A0, int64_t b, in
         gemm_layer_lds<DF_TW>(lds, 0, lane, F.h, acc);
         const uint64_t m = finish_layer(acc, A.bias + l * DFW, kb, F.h);
         if (l == 1) F.m2 = m; else if (l == 2) F.m3 = m; else F.m4 = m;
-        if (a_tiles) store_tile_chain(a_tiles + 192 * 32 + l * DFW * 32, n, kb, F.h);
+        if (a_tiles) store_tile_T<DF_TW>(a_tiles + 192 * 32 + l * DFW * 32, lane, F.h, tsel);
     }
     // L4: cat[input, x]
     stage_group(A.frags, F4, 76, lds);
@@ -355,13 +386,13 @@ __device__ __forceinline__ void forward_tile(const DeformArgs& A0, int64_t b, in
     gemm_layer_lds<DF_TIN>(lds, 0, lane, F.x, acc, 0, 19);
     gemm_layer_lds<DF_TW>(lds, 0, lane, F.h, acc, DF_TIN, 19);
     F.m5 = finish_layer(acc, A.bias + 4 * DFW, kb, F.h);
-    if (a_tiles) store_tile_chain(a_tiles + 192 * 32 + 4 * DFW * 32, n, kb, F.h);
+    if (a_tiles) store_tile_T<DF_TW>(a_tiles + 192 * 32 + 4 * DFW * 32, lane, F.h, tsel);
     // L5 (+ out_activation ReLU) and the heads share one staged group (F5 | FH are contiguous)
     stage_group(A.frags, F5, 40, lds);
     for (int i = 0; i < 4; ++i) acc[i] = zero16();
     gemm_layer_lds<DF_TW>(lds, 0, lane, F.h, acc);
     F.m6 = finish_layer(acc, A.bias + 5 * DFW, kb, F.h);
-    if (a_tiles) store_tile_chain(a_tiles + 192 * 32 + 5 * DFW * 32, n, kb, F.h);
+    if (a_tiles) store_tile_T<DF_TW>(a_tiles + 192 * 32 + 5 * DFW * 32, lane, F.h, tsel);
     // heads (one M-tile, rows 0..5)
     f32x16 o = zero16();
 #pragma unroll
@@ -510,14 +541,8 @@ __global__ __launch_bounds__(256, 1) void deform_bwd_kernel(DeformArgs A, const 
         for (int j = 0; j < 8; ++j) dzh[j] = (half_t)0.f;
         if (kb == 0) { dzh[0] = (half_t)dr[0]; dzh[1] = (half_t)dr[1]; dzh[2] = (half_t)dr[2]; dzh[3] = (half_t)dv[0]; }
         else         { dzh[0] = (half_t)dv[1]; dzh[1] = (half_t)dv[2]; }
-        {   // dZh tile [32 rows][32 samples] (rows >= 6 zero)
-            half_t* Z = T + TILE_DZH;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                Z[acc_row(j, kb) * 32 + n] = dzh[j];
-                Z[acc_row(8 + j, kb) * 32 + n] = (half_t)0.f;
-            }
-        }
+        const TSel tsel = make_tsel(lane);
+        store_tile_T<1>(T + TILE_DZH, lane, &dzh, tsel);       // head rows (only columns < 16 are populated)
         // ---- chain ----
         f32x16 d[4];
         f16x8 dz[DF_TW];
@@ -526,12 +551,12 @@ __global__ __launch_bounds__(256, 1) void deform_bwd_kernel(DeformArgs A, const 
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) d[mt] = mfma(lds[mt * 64 + lane], dzh, zero16());
         mask_pack(d, F.m6, dz);
-        store_tile_chain(T + TILE_DZ + 5 * DFW * 32, n, kb, dz);
+        store_tile_T<DF_TW>(T + TILE_DZ + 5 * DFW * 32, lane, dz, tsel);
         // dA5 = W5^T dZ5 ; dZ4
         for (int i = 0; i < 4; ++i) d[i] = zero16();
         gemm_layer_lds<DF_TW>(lds, 4, lane, dz, d);
         mask_pack(d, F.m5, dz);
-        store_tile_chain(T + TILE_DZ + 4 * DFW * 32, n, kb, dz);
+        store_tile_T<DF_TW>(T + TILE_DZ + 4 * DFW * 32, lane, dz, tsel);
         // keep dZ4 for the code gradient (dC = W4[:, code]^T dZ4 + W0[:, code]^T dZ0), formed at the end
         f16x8 dz4[DF_TW];
 #pragma unroll
@@ -541,23 +566,23 @@ __global__ __launch_bounds__(256, 1) void deform_bwd_kernel(DeformArgs A, const 
         stage_group(frags_l, B4X, 32, lds);
         gemm_layer_lds<DF_TW>(lds, 0, lane, dz, d);
         mask_pack(d, F.m4, dz);
-        store_tile_chain(T + TILE_DZ + 3 * DFW * 32, n, kb, dz);
+        store_tile_T<DF_TW>(T + TILE_DZ + 3 * DFW * 32, lane, dz, tsel);
         // L3 -> L2 -> L1
         for (int i = 0; i < 4; ++i) d[i] = zero16();
         stage_group(frags_l, B3, 32, lds);
         gemm_layer_lds<DF_TW>(lds, 0, lane, dz, d);
         mask_pack(d, F.m3, dz);
-        store_tile_chain(T + TILE_DZ + 2 * DFW * 32, n, kb, dz);
+        store_tile_T<DF_TW>(T + TILE_DZ + 2 * DFW * 32, lane, dz, tsel);
         for (int i = 0; i < 4; ++i) d[i] = zero16();
         stage_group(frags_l, B2, 32, lds);
         gemm_layer_lds<DF_TW>(lds, 0, lane, dz, d);
         mask_pack(d, F.m2, dz);
-        store_tile_chain(T + TILE_DZ + 1 * DFW * 32, n, kb, dz);
+        store_tile_T<DF_TW>(T + TILE_DZ + 1 * DFW * 32, lane, dz, tsel);
         for (int i = 0; i < 4; ++i) d[i] = zero16();
         stage_group(frags_l, B1, 32, lds);
         gemm_layer_lds<DF_TW>(lds, 0, lane, dz, d);
         mask_pack(d, F.m1, dz);
-        store_tile_chain(T + TILE_DZ + 0 * DFW * 32, n, kb, dz);
+        store_tile_T<DF_TW>(T + TILE_DZ + 0 * DFW * 32, lane, dz, tsel);
         f32x16 dcode[4];
         for (int i = 0; i < 4; ++i) dcode[i] = zero16();
         stage_group(frags_l, B0C, 32, lds);
@@ -565,12 +590,14 @@ __global__ __launch_bounds__(256, 1) void deform_bwd_kernel(DeformArgs A, const 
         stage_group(frags_l, B4C, 32, lds);
         gemm_layer_lds<DF_TW>(lds, 0, lane, dz4, dcode);
         {
-            half_t* Cc = T + TILE_DC;       // natural code index: row = 32 mt + acc_row(r, kb)
+            // code-gradient tile: accumulators -> chained fragments (code index kchain(t, kb, j)) -> transposed tile
+            f16x8 dcf[DF_TW];
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
                 for (int rr = 0; rr < 16; ++rr)
-                    Cc[(32 * mt + acc_row(rr, kb)) * 32 + n] = valid ? (half_t)dcode[mt][rr] : (half_t)0.f;
+                    dcf[2 * mt + (rr >> 3)][rr & 7] = valid ? (half_t)dcode[mt][rr] : (half_t)0.f;
+            store_tile_T<DF_TW>(T + TILE_DC, lane, dcf, tsel);
             if (gcode_samples && valid) {
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt)
@@ -586,14 +613,16 @@ __global__ __launch_bounds__(256, 1) void deform_bwd_kernel(DeformArgs A, const 
 // sample-contracted GEMMs: C[M][N] += sum_tiles A_tile[M][32] * B_tile[N][32]^T  (fp16 tiles, fp32 atomics)
 // ---------------------------------------------------------------------------------------------------------
 struct WgradJob {
-    int64_t a_off;       // offset (halfs) of the A tile inside a sample-tile scratch block; -1 => one-hot of slot
-    int64_t b_off;       // offset of the B tile
-    int m_rows;          // valid rows of A (<= 128)
+    int64_t a_off;       // offset (halfs) of the A activation tiles inside a sample-tile scratch block; -1 => one-hot of slot
+    int64_t b_off;       // offset of the B activation tiles
+    int a_tile0, b_tile0;// first 32-column tile of A / B used by the job
+    int m_rows;          // valid rows of A
     int n_rows;          // valid rows of B
+    int a_natural, b_natural;   // neuron index map of the tile columns: natural (32p + c) or chained
     int ldc;             // leading dimension of C
-    int64_t c_off;       // offset (floats) into the flat gradient buffer (or the code-table gradient for one-hot)
+    int64_t c_off;       // offset (floats) into the gradient buffer
     int64_t bias_off;    // >= 0: also accumulate row sums of A there
-    int n_tile0;         // first 32-row block of B handled by job instance (set per launch)
+    int heads;           // rows 0..2 -> Wr / br, rows 3..5 -> Wv / bv (c_off / bias_off unused)
 };
 
 constexpr int MAX_WGRAD_JOBS = 12;
@@ -603,7 +632,9 @@ struct WgradJobs {
     int n;
 };
 
-// grid = (max n-tiles, chunks, jobs): every weight / bias / code-table gradient GEMM of the step in ONE launch
+// grid = (max n-tiles, chunks, jobs): every weight / bias / code-table gradient GEMM of the step in ONE launch.
+// C[row][col] += sum over sample tiles and samples of A[row][sample] * B[col][sample]; operands are the transposed
+// tiles written by the chain kernel (16-B coalesced fragment loads, sample order acc_row(8 tt + j, kb) on both sides).
 __global__ __launch_bounds__(256) void deform_wgrad_kernel(const half_t* __restrict__ scratch, int64_t n_tiles,
                                                            WgradJobs jobs, const int32_t* __restrict__ slot,
                                                            int64_t S, int chunks) {
@@ -623,46 +654,59 @@ __global__ __launch_bounds__(256) void deform_wgrad_kernel(const half_t* __restr
     float bsum[4] = {0.f, 0.f, 0.f, 0.f};
     for (int64_t tile = t_begin; tile < t_end; ++tile) {
         const half_t* T = scratch + tile * TILE_HALFS;
+        const half_t* Bt = T + job.b_off + ((size_t)(job.b_tile0 + nt) * 64 + lane) * 16;
+        const f16x8 b0 = reinterpret_cast<const f16x8*>(Bt)[0], b1 = reinterpret_cast<const f16x8*>(Bt)[1];
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const f16x8 bf = *reinterpret_cast<const f16x8*>(T + job.b_off + (int64_t)(32 * nt + i) * 32 + 16 * t + 8 * kb);
+        for (int mt = 0; mt < 4; ++mt) {
+            if (mt < m_tiles) {
+                f16x8 a0, a1;
+                if (job.a_off >= 0) {
+                    const half_t* At = T + job.a_off + ((size_t)(job.a_tile0 + mt) * 64 + lane) * 16;
+                    a0 = reinterpret_cast<const f16x8*>(At)[0];
+                    a1 = reinterpret_cast<const f16x8*>(At)[1];
+                } else {
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-                if (mt < m_tiles) {
-                    f16x8 af;
-                    if (job.a_off >= 0) {
-                        af = *reinterpret_cast<const f16x8*>(T + job.a_off + (int64_t)(32 * mt + i) * 32 + 16 * t + 8 * kb);
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) {
-                            const int64_t sidx = tile * 32 + 16 * t + 8 * kb + j;
-                            af[j] = (sidx < S && slot[sidx] == 32 * mt + i) ? (half_t)1.f : (half_t)0.f;
-                        }
+                    for (int j = 0; j < 8; ++j) {
+                        const int64_t s0 = tile * 32 + acc_row(j, kb), s1 = tile * 32 + acc_row(8 + j, kb);
+                        a0[j] = (s0 < S && slot[s0] == 32 * mt + i) ? (half_t)1.f : (half_t)0.f;
+                        a1[j] = (s1 < S && slot[s1] == 32 * mt + i) ? (half_t)1.f : (half_t)0.f;
                     }
-                    acc[mt] = mfma(af, bf, acc[mt]);
-                    if (job.bias_off >= 0 && nt == 0) {
+                }
+                acc[mt] = mfma(a0, b0, acc[mt]);
+                acc[mt] = mfma(a1, b1, acc[mt]);
+                if ((job.bias_off >= 0 || job.heads) && nt == 0) {
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) bsum[mt] += (float)af[j];
-                    }
+                    for (int j = 0; j < 8; ++j) bsum[mt] += (float)a0[j] + (float)a1[j];
                 }
             }
         }
     }
-    // D[o][n]: lane col = n-row (32 nt + i), reg r -> row o = 32 mt + acc_row(r, kb)
-    const int col = 32 * nt + i;
+    // accumulator element r of lane (col i, half kb): A-side row index acc_row(r, kb) of tile mt, B-side column i of tile nt
+    const int col = job.b_natural ? 32 * nt + i : tile_neuron_chain(nt, i);
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
         if (mt >= m_tiles) continue;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int row = 32 * mt + acc_row(r, kb);
+            const int ar = acc_row(r, kb);
+            const int row = job.a_natural ? 32 * mt + ar : tile_neuron_chain(mt, ar);
             const float v = acc[mt][r];
-            if (row < job.m_rows && col < job.n_rows && v != 0.f) atomicAdd(&C[job.c_off + (int64_t)row * job.ldc + col], v);
+            if (row < job.m_rows && col < job.n_rows && v != 0.f && (job.a_natural || ar < 16 || !job.heads)) {
+                if (job.heads) {
+                    const int64_t off = row < 3 ? (int64_t)P_WR + (int64_t)row * DFW : (int64_t)P_WV + (int64_t)(row - 3) * DFW;
+                    atomicAdd(&C[off + col], v);
+                } else {
+                    atomicAdd(&C[job.c_off + (int64_t)row * job.ldc + col], v);
+                }
+            }
         }
-        if (job.bias_off >= 0 && nt == 0) {
-            const float s = bsum[mt] + __shfl_xor(bsum[mt], 32);
-            const int row = 32 * mt + i;
-            if (kb == 0 && row < job.m_rows && s != 0.f) atomicAdd(&C[job.bias_off + row], s);
+        if ((job.bias_off >= 0 || job.heads) && nt == 0) {
+            const float sb = bsum[mt] + __shfl_xor(bsum[mt], 32);
+            const int row = job.a_natural ? 32 * mt + i : tile_neuron_chain(mt, i);
+            if (kb == 0 && row < job.m_rows && sb != 0.f && (!job.heads || i < 16)) {
+                if (job.heads) atomicAdd(&C[row < 3 ? P_BR + row : P_BV + row - 3], sb);
+                else atomicAdd(&C[job.bias_off + row], sb);
+            }
         }
     }
 }
@@ -756,18 +800,17 @@ int nsx_deform_bwd(const void* packed, const float* positions, int64_t S, const 
     const int64_t A_of[7] = {TILE_A0, TILE_A + 0 * DFW * 32, TILE_A + 1 * DFW * 32, TILE_A + 2 * DFW * 32,
                              TILE_A + 3 * DFW * 32, TILE_A + 4 * DFW * 32, TILE_A + 5 * DFW * 32};
     auto dz = [&](int l) { return TILE_DZ + (int64_t)l * DFW * 32; };
-    run(WgradJob{dz(0), A_of[0], DFW, DF_IN, DF_IN, P_W0, P_B0, 0}, grad_params);
-    run(WgradJob{dz(1), A_of[1], DFW, DFW, DFW, P_W1, P_B1, 0}, grad_params);
-    run(WgradJob{dz(2), A_of[2], DFW, DFW, DFW, P_W2, P_B2, 0}, grad_params);
-    run(WgradJob{dz(3), A_of[3], DFW, DFW, DFW, P_W3, P_B3, 0}, grad_params);
-    run(WgradJob{dz(4), A_of[0], DFW, DF_IN, DF_W4, P_W4, P_B4, 0}, grad_params);
-    run(WgradJob{dz(4), A_of[4], DFW, DFW, DF_W4, P_W4 + DF_IN, -1, 0}, grad_params);
-    run(WgradJob{dz(5), A_of[5], DFW, DFW, DFW, P_W5, P_B5, 0}, grad_params);
-    // heads: rows 0..2 -> Wr / br, rows 3..5 -> Wv / bv: contiguous in the flat layout except for the bias slots
-    run(WgradJob{TILE_DZH, A_of[6], 3, DFW, DFW, P_WR, P_BR, 0}, grad_params);
-    run(WgradJob{TILE_DZH + 3 * 32, A_of[6], 3, DFW, DFW, P_WV, P_BV, 0}, grad_params);
+    // {a_off, b_off, a_tile0, b_tile0, m_rows, n_rows, a_natural, b_natural, ldc, c_off, bias_off, heads}
+    run(WgradJob{dz(0), A_of[0], 0, 0, DFW, DF_IN, 0, 1, DF_IN, P_W0, P_B0, 0}, grad_params);
+    run(WgradJob{dz(1), A_of[1], 0, 0, DFW, DFW, 0, 0, DFW, P_W1, P_B1, 0}, grad_params);
+    run(WgradJob{dz(2), A_of[2], 0, 0, DFW, DFW, 0, 0, DFW, P_W2, P_B2, 0}, grad_params);
+    run(WgradJob{dz(3), A_of[3], 0, 0, DFW, DFW, 0, 0, DFW, P_W3, P_B3, 0}, grad_params);
+    run(WgradJob{dz(4), A_of[0], 0, 0, DFW, DF_IN, 0, 1, DF_W4, P_W4, P_B4, 0}, grad_params);
+    run(WgradJob{dz(4), A_of[4], 0, 0, DFW, DFW, 0, 0, DF_W4, P_W4 + DF_IN, -1, 0}, grad_params);
+    run(WgradJob{dz(5), A_of[5], 0, 0, DFW, DFW, 0, 0, DFW, P_W5, P_B5, 0}, grad_params);
+    run(WgradJob{TILE_DZH, A_of[6], 0, 0, 6, DFW, 0, 0, DFW, 0, -1, 1}, grad_params);        // both heads
     if (grad_code_table)
-        run(WgradJob{-1, TILE_DC, n_code_rows, DF_CODE, DF_CODE, 0, -1, 0}, grad_code_table);
+        run(WgradJob{-1, TILE_DC, 0, 0, n_code_rows, DF_CODE, 1, 0, DF_CODE, 0, -1, 0}, grad_code_table);
     hipLaunchKernelGGL(deform_wgrad_kernel, dim3(max_ntiles, chunks, jobs.n), dim3(256), 0, st, sc, n_tiles, jobs,
                        code_slot, S, chunks);
     NSX_LAUNCH_CHECK("nsx_deform_bwd wgrad launch");
