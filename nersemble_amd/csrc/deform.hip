@@ -487,7 +487,7 @@ __device__ __forceinline__ void mask_pack(const f32x16 d[4], uint64_t mask, f16x
         }
 }
 
-__global__ __launch_bounds__(256, 1) void deform_bwd_kernel(DeformArgs A, const float* __restrict__ goff,
+__global__ __launch_bounds__(256, 2) void deform_bwd_kernel(DeformArgs A, const float* __restrict__ goff,
                                                          half_t* __restrict__ scratch, int64_t n_tiles,
                                                          float* __restrict__ gcode_samples) {
     __shared__ __attribute__((aligned(16))) f16x8 lds[LDS_FRAGS * 64];
@@ -614,18 +614,18 @@ __global__ __launch_bounds__(256, 1) void deform_bwd_kernel(DeformArgs A, const 
 // ---------------------------------------------------------------------------------------------------------
 struct WgradJob {
     int64_t a_off;       // offset (halfs) of the A activation tiles inside a sample-tile scratch block; -1 => one-hot of slot
-    int64_t b_off;       // offset of the B activation tiles
+    int64_t b_off;       // offset of the B activation tiles; -2 => B = ones (row sums of A: bias gradients)
     int a_tile0, b_tile0;// first 32-column tile of A / B used by the job
     int m_rows;          // valid rows of A
     int n_rows;          // valid rows of B
     int a_natural, b_natural;   // neuron index map of the tile columns: natural (32p + c) or chained
     int ldc;             // leading dimension of C
     int64_t c_off;       // offset (floats) into the gradient buffer
-    int64_t bias_off;    // >= 0: also accumulate row sums of A there
-    int heads;           // rows 0..2 -> Wr / br, rows 3..5 -> Wv / bv (c_off / bias_off unused)
+    int64_t bias_off;    // unused (bias gradients are their own jobs with b_off = -2)
+    int heads;           // 1: rows 0..2 -> Wr, 3..5 -> Wv ; 2: the head biases br / bv
 };
 
-constexpr int MAX_WGRAD_JOBS = 12;
+constexpr int MAX_WGRAD_JOBS = 20;
 struct WgradJobs {
     WgradJob job[MAX_WGRAD_JOBS];
     float* out[MAX_WGRAD_JOBS];
@@ -635,7 +635,7 @@ struct WgradJobs {
 // grid = (max n-tiles, chunks, jobs): every weight / bias / code-table gradient GEMM of the step in ONE launch.
 // C[row][col] += sum over sample tiles and samples of A[row][sample] * B[col][sample]; operands are the transposed
 // tiles written by the chain kernel (16-B coalesced fragment loads, sample order acc_row(8 tt + j, kb) on both sides).
-__global__ __launch_bounds__(256) void deform_wgrad_kernel(const half_t* __restrict__ scratch, int64_t n_tiles,
+__global__ __launch_bounds__(256, 2) void deform_wgrad_kernel(const half_t* __restrict__ scratch, int64_t n_tiles,
                                                            WgradJobs jobs, const int32_t* __restrict__ slot,
                                                            int64_t S, int chunks) {
     const WgradJob job = jobs.job[blockIdx.z];
@@ -651,35 +651,57 @@ __global__ __launch_bounds__(256) void deform_wgrad_kernel(const half_t* __restr
     const int m_tiles = (job.m_rows + 31) / 32;
     f32x16 acc[4];
     for (int q = 0; q < 4; ++q) acc[q] = zero16();
-    float bsum[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int64_t tile = t_begin; tile < t_end; ++tile) {
-        const half_t* T = scratch + tile * TILE_HALFS;
-        const half_t* Bt = T + job.b_off + ((size_t)(job.b_tile0 + nt) * 64 + lane) * 16;
-        const f16x8 b0 = reinterpret_cast<const f16x8*>(Bt)[0], b1 = reinterpret_cast<const f16x8*>(Bt)[1];
+    const bool b_ones = job.b_off < 0;        // bias job: B = ones -> every column of D is the row sum of A
+    // per-lane operand pointers (advance by one scratch block per sample tile)
+    const half_t* bp = scratch + t_begin * TILE_HALFS + (b_ones ? 0 : job.b_off) + ((size_t)(job.b_tile0 + nt) * 64 + lane) * 16;
+    const half_t* ap = (job.a_off >= 0)
+                           ? scratch + t_begin * TILE_HALFS + job.a_off + ((size_t)job.a_tile0 * 64 + lane) * 16
+                           : nullptr;
+    auto load_tile = [&](const half_t* a, const half_t* b, f16x8 af[4][2], f16x8 bf[2], int64_t tile) {
+        if (b_ones) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { bf[0][j] = (half_t)1.f; bf[1][j] = (half_t)1.f; }
+        } else {
+            bf[0] = reinterpret_cast<const f16x8*>(b)[0];
+            bf[1] = reinterpret_cast<const f16x8*>(b)[1];
+        }
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
             if (mt < m_tiles) {
-                f16x8 a0, a1;
-                if (job.a_off >= 0) {
-                    const half_t* At = T + job.a_off + ((size_t)(job.a_tile0 + mt) * 64 + lane) * 16;
-                    a0 = reinterpret_cast<const f16x8*>(At)[0];
-                    a1 = reinterpret_cast<const f16x8*>(At)[1];
+                if (a) {
+                    af[mt][0] = reinterpret_cast<const f16x8*>(a + (size_t)mt * 1024)[0];
+                    af[mt][1] = reinterpret_cast<const f16x8*>(a + (size_t)mt * 1024)[1];
                 } else {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
                         const int64_t s0 = tile * 32 + acc_row(j, kb), s1 = tile * 32 + acc_row(8 + j, kb);
-                        a0[j] = (s0 < S && slot[s0] == 32 * mt + i) ? (half_t)1.f : (half_t)0.f;
-                        a1[j] = (s1 < S && slot[s1] == 32 * mt + i) ? (half_t)1.f : (half_t)0.f;
+                        af[mt][0][j] = (s0 < S && slot[s0] == 32 * mt + i) ? (half_t)1.f : (half_t)0.f;
+                        af[mt][1][j] = (s1 < S && slot[s1] == 32 * mt + i) ? (half_t)1.f : (half_t)0.f;
                     }
-                }
-                acc[mt] = mfma(a0, b0, acc[mt]);
-                acc[mt] = mfma(a1, b1, acc[mt]);
-                if ((job.bias_off >= 0 || job.heads) && nt == 0) {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) bsum[mt] += (float)a0[j] + (float)a1[j];
                 }
             }
         }
+    };
+    f16x8 af[4][2], bf[2], afn[4][2], bfn[2];
+    if (t_begin < t_end) load_tile(ap, bp, af, bf, t_begin);
+    for (int64_t tile = t_begin; tile < t_end; ++tile) {
+        // software prefetch of the next sample tile's operands
+        const bool more = tile + 1 < t_end;
+        if (more) load_tile(ap ? ap + TILE_HALFS : nullptr, bp + TILE_HALFS, afn, bfn, tile + 1);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            if (mt < m_tiles) {
+                acc[mt] = mfma(af[mt][0], bf[0], acc[mt]);
+                acc[mt] = mfma(af[mt][1], bf[1], acc[mt]);
+            }
+        }
+        if (more) {
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) { af[mt][0] = afn[mt][0]; af[mt][1] = afn[mt][1]; }
+            bf[0] = bfn[0]; bf[1] = bfn[1];
+        }
+        if (ap) ap += TILE_HALFS;
+        bp += TILE_HALFS;
     }
     // accumulator element r of lane (col i, half kb): A-side row index acc_row(r, kb) of tile mt, B-side column i of tile nt
     const int col = job.b_natural ? 32 * nt + i : tile_neuron_chain(nt, i);
@@ -692,20 +714,14 @@ __global__ __launch_bounds__(256) void deform_wgrad_kernel(const half_t* __restr
             const int row = job.a_natural ? 32 * mt + ar : tile_neuron_chain(mt, ar);
             const float v = acc[mt][r];
             if (row < job.m_rows && col < job.n_rows && v != 0.f && (job.a_natural || ar < 16 || !job.heads)) {
-                if (job.heads) {
+                if (job.heads == 2) {                    // head biases (B = ones, column 0)
+                    atomicAdd(&C[row < 3 ? P_BR + row : P_BV + row - 3], v);
+                } else if (job.heads) {
                     const int64_t off = row < 3 ? (int64_t)P_WR + (int64_t)row * DFW : (int64_t)P_WV + (int64_t)(row - 3) * DFW;
                     atomicAdd(&C[off + col], v);
                 } else {
                     atomicAdd(&C[job.c_off + (int64_t)row * job.ldc + col], v);
                 }
-            }
-        }
-        if ((job.bias_off >= 0 || job.heads) && nt == 0) {
-            const float sb = bsum[mt] + __shfl_xor(bsum[mt], 32);
-            const int row = job.a_natural ? 32 * mt + i : tile_neuron_chain(mt, i);
-            if (kb == 0 && row < job.m_rows && sb != 0.f && (!job.heads || i < 16)) {
-                if (job.heads) atomicAdd(&C[row < 3 ? P_BR + row : P_BV + row - 3], sb);
-                else atomicAdd(&C[job.bias_off + row], sb);
             }
         }
     }
@@ -801,14 +817,18 @@ int nsx_deform_bwd(const void* packed, const float* positions, int64_t S, const 
                              TILE_A + 3 * DFW * 32, TILE_A + 4 * DFW * 32, TILE_A + 5 * DFW * 32};
     auto dz = [&](int l) { return TILE_DZ + (int64_t)l * DFW * 32; };
     // {a_off, b_off, a_tile0, b_tile0, m_rows, n_rows, a_natural, b_natural, ldc, c_off, bias_off, heads}
-    run(WgradJob{dz(0), A_of[0], 0, 0, DFW, DF_IN, 0, 1, DF_IN, P_W0, P_B0, 0}, grad_params);
-    run(WgradJob{dz(1), A_of[1], 0, 0, DFW, DFW, 0, 0, DFW, P_W1, P_B1, 0}, grad_params);
-    run(WgradJob{dz(2), A_of[2], 0, 0, DFW, DFW, 0, 0, DFW, P_W2, P_B2, 0}, grad_params);
-    run(WgradJob{dz(3), A_of[3], 0, 0, DFW, DFW, 0, 0, DFW, P_W3, P_B3, 0}, grad_params);
-    run(WgradJob{dz(4), A_of[0], 0, 0, DFW, DF_IN, 0, 1, DF_W4, P_W4, P_B4, 0}, grad_params);
+    run(WgradJob{dz(0), A_of[0], 0, 0, DFW, DF_IN, 0, 1, DF_IN, P_W0, -1, 0}, grad_params);
+    run(WgradJob{dz(1), A_of[1], 0, 0, DFW, DFW, 0, 0, DFW, P_W1, -1, 0}, grad_params);
+    run(WgradJob{dz(2), A_of[2], 0, 0, DFW, DFW, 0, 0, DFW, P_W2, -1, 0}, grad_params);
+    run(WgradJob{dz(3), A_of[3], 0, 0, DFW, DFW, 0, 0, DFW, P_W3, -1, 0}, grad_params);
+    run(WgradJob{dz(4), A_of[0], 0, 0, DFW, DF_IN, 0, 1, DF_W4, P_W4, -1, 0}, grad_params);
     run(WgradJob{dz(4), A_of[4], 0, 0, DFW, DFW, 0, 0, DF_W4, P_W4 + DF_IN, -1, 0}, grad_params);
-    run(WgradJob{dz(5), A_of[5], 0, 0, DFW, DFW, 0, 0, DFW, P_W5, P_B5, 0}, grad_params);
+    run(WgradJob{dz(5), A_of[5], 0, 0, DFW, DFW, 0, 0, DFW, P_W5, -1, 0}, grad_params);
     run(WgradJob{TILE_DZH, A_of[6], 0, 0, 6, DFW, 0, 0, DFW, 0, -1, 1}, grad_params);        // both heads
+    // bias gradients: row sums of dZ (B = ones, one column)
+    const int64_t pb[6] = {P_B0, P_B1, P_B2, P_B3, P_B4, P_B5};
+    for (int l = 0; l < 6; ++l) run(WgradJob{dz(l), -2, 0, 0, DFW, 1, 0, 1, 1, pb[l], -1, 0}, grad_params);
+    run(WgradJob{TILE_DZH, -2, 0, 0, 6, 1, 0, 1, 1, 0, -1, 2}, grad_params);
     if (grad_code_table)
         run(WgradJob{-1, TILE_DC, 0, 0, n_code_rows, DF_CODE, 1, 0, DF_CODE, 0, -1, 0}, grad_code_table);
     hipLaunchKernelGGL(deform_wgrad_kernel, dim3(max_ntiles, chunks, jobs.n), dim3(256), 0, st, sc, n_tiles, jobs,
