@@ -26,13 +26,34 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (~6.3 TB/s achievable)
 
 
-def algorithmic_bytes(name: str, units: int, H: int) -> float:
-    """per-sample algorithmic bytes of the hash kernels."""
-    if name == "nsx_hash_ensemble_fwd":
-        return units * (512.0 * H + 80.0)
-    if name in ("nsx_hash_ensemble_bwd_factored", "nsx_hash_ensemble_bwd"):
-        return units * (1024.0 * H + 76.0)
-    return 0.0
+MFMA_PEAK_TFLOPS = 2500.0       # dense fp16 MFMA peak (MI355X_MICROARCH.md)
+DEFORM_FWD_FLOPS = 253952.0     # 2 * 126 976 MAC per sample
+
+
+def kernel_model(name: str, ints, H: int, total_entries: int):
+    """(bound, work per launch) for the kernels with a stated algorithmic cost.
+    `ints` = the integer arguments of the C-ABI call as recorded by the profiler."""
+    if name == "nsx_hash_ensemble_fwd":                       # (B, H, code_stride)
+        return "hbm", ints[0] * (512.0 * H + 80.0)
+    if name == "nsx_hash_ensemble_bwd_factored":              # (B, H, code_stride, n_slots)
+        # table gather for dL/dcode and dL/dx (512 H) + read-modify-write of G (128 corners x 2 floats x 2) + fp16
+        # dout (64) + dcode (4 H) + x, dx, slot (28): the factored gradient moves FEWER bytes than SURVEY's dense
+        # count 1024 H + 76 -- the kernel is priced against what it has to move
+        return "hbm", ints[0] * (512.0 * H + 2048.0 + 64.0 + 4.0 * H + 28.0)
+    if name == "nsx_hash_ensemble_bwd":
+        return "hbm", ints[0] * (1024.0 * H + 76.0)
+    if name == "nsx_adam_hash_factored":                      # (n_slots, code_stride, H, step)
+        Hp = 1
+        while Hp < H:
+            Hp *= 2
+        params = total_entries * 2.0 * Hp
+        # master, m, v read + written (24 B) + fp16 copy written (2 B) per parameter + G read once
+        return "hbm", params * 26.0 + ints[0] * total_entries * 8.0
+    if name == "nsx_deform_fwd":                              # (S, code_stride)
+        return "mfma", ints[0] * DEFORM_FWD_FLOPS
+    if name == "nsx_deform_bwd":                              # recompute fwd + dX chain + weight gradients = 3x fwd
+        return "mfma", ints[0] * DEFORM_FWD_FLOPS * 3.0
+    return None, 0.0
 
 
 def cpu_baseline(H: int, seconds_budget: float = 15.0):
@@ -123,17 +144,40 @@ def main():
 
     if rank == 0:
         prof = _lib.profiler.summary()
-        hash_kernels = {k: v for k, v in prof.items() if algorithmic_bytes(k, 1, H) > 0}
-        dom_name = max(hash_kernels, key=lambda k: hash_kernels[k]["total_ms"]) if hash_kernels else None
-        roofline = None
-        if dom_name:
-            d = hash_kernels[dom_name]
-            per_launch_bytes = algorithmic_bytes(dom_name, d["units"], H) / d["calls"]
-            achieved = per_launch_bytes / (d["avg_ms"] * 1e-3) / 1e9
-            roofline = {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
-                        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
-                        "avg_launch_ms": round(d["avg_ms"], 4), "launches": d["calls"],
-                        "algorithmic_bytes_per_launch": per_launch_bytes}
+        total_entries = trainer.model.field.hash_ensemble.geom.total_entries
+        work = {}
+        for name, st, en, ints in _lib.profiler.records:
+            bound, w = kernel_model(name, ints, H, total_entries)
+            if bound:
+                d = work.setdefault(name, {"bound": bound, "work": 0.0})
+                d["work"] += w
+        rooflines = {}
+        for name, d in work.items():
+            p = prof[name]
+            per_launch = d["work"] / p["calls"]
+            if d["bound"] == "hbm":
+                ach = per_launch / (p["avg_ms"] * 1e-3) / 1e9
+                rooflines[name] = {"bound": "hbm", "kernel": name, "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS,
+                                   "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": None,
+                                   "avg_launch_ms": round(p["avg_ms"], 4), "launches": p["calls"],
+                                   "algorithmic_bytes_per_launch": per_launch}
+            else:
+                ach = per_launch / (p["avg_ms"] * 1e-3) / 1e12
+                rooflines[name] = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS,
+                                   "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                                   "avg_launch_ms": round(p["avg_ms"], 4), "launches": p["calls"],
+                                   "algorithmic_flops_per_launch": per_launch}
+        # the dominant kernel = the modelled kernel with the largest total time in the timed region
+        dom_name = max(rooflines, key=lambda k: prof[k]["total_ms"]) if rooflines else None
+        roofline = rooflines.get(dom_name)
+        pmc_path = os.path.join(ROOT, "profiles", "pmc", "latest.json")
+        if roofline and os.path.exists(pmc_path):
+            try:
+                pmc = json.load(open(pmc_path)).get("per_launch_hbm_bytes", {})
+                if dom_name in pmc:
+                    roofline["traffic"] = pmc[dom_name]       # from the committed rocprofv3 --pmc pass of this command
+            except Exception:
+                pass
         kernels = {k: {"calls": v["calls"], "total_ms": round(v["total_ms"], 3), "avg_ms": round(v["avg_ms"], 4)}
                    for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])}
         out = {
@@ -147,7 +191,7 @@ def main():
                        "parallelism": f"dp{world}", "params": info["params"]},
             "rays_per_sec": world * info["rays"] * a.steps / dt_max,
             "psnr_last": float(metrics["psnr"].detach()), "loss_last": float(loss.detach()),
-            "roofline": roofline, "native_kernel_ms": kernels,
+            "roofline": roofline, "rooflines": rooflines, "native_kernel_ms": kernels,
             "native_ms_per_step": sum(v["total_ms"] for v in prof.values()) / a.steps,
         }
         if not a.no_cpu_baseline and world == 1:

@@ -120,6 +120,17 @@ int nsx_hash_grad_expand(const float* G, int n_slots, const float* code_table, i
                          const float* window, int H, const nsx_grid_geom* g, float* dtables, int accumulate,
                          void* stream);
 
+/* ---- plain tcnn-shaped HashGrid encoding (compatibility path) -------------------------------------------------
+ * tcnn.Encoding(3, {"otype": "HashGrid", n_levels, n_features_per_level F in {2,4,8}, log2_hashmap_size,
+ * base_resolution, per_level_scale, "Linear"}) as instantiated at hash_ensemble.py:42-50 and called at :102-104:
+ * table fp16 [total_entries][F] (tcnn AoS), out fp16 [B][n_levels*F].  Backward: dtable fp32 (same shape,
+ * ACCUMULATED, may be NULL), dx fp32 [B][3] ACCUMULATED into a caller-zeroed buffer (may be NULL).  Lets the
+ * reference's own HashEnsemble module run on this library; the fused kernels above are the fast path. */
+int nsx_hashgrid_fwd(const float* x, int64_t B, const nsx_half* table, int F, const nsx_grid_geom* g, nsx_half* out,
+                     void* stream);
+int nsx_hashgrid_bwd(const float* x, int64_t B, const nsx_half* table, int F, const nsx_grid_geom* g,
+                     const nsx_half* dout, float* dtable, float* dx_zeroed, void* stream);
+
 /* ---- fully fused MLPs (tcnn FullyFusedMLP equivalents) ---------------------------------------------------
  * Replaces tcnn.NetworkWithInputEncoding (Identity encoding) / tcnn.Network as built at
  * nersemble_nerfacto_field.py:142-153 (mlp_base: 32 -> 64 -> 16, no output activation) and :162-172

@@ -50,6 +50,8 @@ SIGNATURES = {
                                                c_void_p]),
     "nsx_hash_grad_expand": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_void_p, c_int, _GEOM_P, c_void_p, c_int,
                                      c_void_p]),
+    "nsx_hashgrid_fwd": (c_int, [c_void_p, c_int64, c_void_p, c_int, _GEOM_P, c_void_p, c_void_p]),
+    "nsx_hashgrid_bwd": (c_int, [c_void_p, c_int64, c_void_p, c_int, _GEOM_P, c_void_p, c_void_p, c_void_p, c_void_p]),
     "nsx_mlp_param_count": (c_int, [c_int]),
     "nsx_mlp_fwd": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_int64, c_int, c_float, c_float, c_void_p, c_int64,
                             c_int, c_int, c_int, c_int, c_void_p, c_int64, c_void_p]),
@@ -118,10 +120,9 @@ class KernelProfiler:
         """name -> dict(calls, total_ms, avg_ms, samples); call after torch.cuda.synchronize()."""
         out = {}
         for name, s, e, ints in self.records:
-            d = out.setdefault(name, {"calls": 0, "total_ms": 0.0, "units": 0})
+            d = out.setdefault(name, {"calls": 0, "total_ms": 0.0})
             d["calls"] += 1
             d["total_ms"] += s.elapsed_time(e)
-            d["units"] += ints[0] if ints else 0
         for d in out.values():
             d["avg_ms"] = d["total_ms"] / max(d["calls"], 1)
         return out

@@ -407,3 +407,34 @@ class _DensityFn(torch.autograd.Function):
 
 def density_from_base(base_out: torch.Tensor, selector: torch.Tensor) -> torch.Tensor:
     return _DensityFn.apply(base_out, selector)
+
+
+# ------------------------------------------------------------------------------------------------
+# plain tcnn-shaped HashGrid encoding (compatibility path for the reference's own HashEnsemble module)
+# ------------------------------------------------------------------------------------------------
+class _HashGridFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, params, F_enc, geom):
+        xx = x.detach().to(torch.float32).contiguous()
+        t16 = params.detach().to(torch.float16).contiguous()
+        B = xx.shape[0]
+        out = torch.empty((B, geom.n_levels * F_enc), dtype=torch.float16, device=xx.device)
+        check(lib().nsx_hashgrid_fwd(ptr(xx), B, ptr(t16), F_enc, C.byref(geom), ptr(out), stream()), "nsx_hashgrid_fwd")
+        ctx.save_for_backward(xx, t16)
+        ctx.F_enc, ctx.geom = F_enc, geom
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        xx, t16 = ctx.saved_tensors
+        d = dout.to(torch.float16).contiguous()
+        dtab = torch.zeros(t16.shape, dtype=torch.float32, device=xx.device) if ctx.needs_input_grad[1] else None
+        dx = torch.zeros_like(xx) if ctx.needs_input_grad[0] else None
+        check(lib().nsx_hashgrid_bwd(ptr(xx), xx.shape[0], ptr(t16), ctx.F_enc, C.byref(ctx.geom), ptr(d), ptr(dtab),
+                                     ptr(dx), stream()), "nsx_hashgrid_bwd")
+        return dx, dtab, None, None
+
+
+def hashgrid_encoding(x: torch.Tensor, params: torch.Tensor, F_enc: int, geom: GridGeom) -> torch.Tensor:
+    """x [B,3] in [0,1), params flat fp32 (tcnn layout [total][F_enc]) -> [B, n_levels*F_enc] fp16."""
+    return _HashGridFn.apply(x, params, F_enc, geom)

@@ -66,15 +66,36 @@ class NetworkWithInputEncoding(Network):
 
 
 class Encoding(nn.Module):
-    """``tcnn.Encoding`` -- Identity only (direction encoding with spherical_harmonics_degree = 0, the default of
-    every shipped NeRSemble config, nersemble_instant_ngp.py:46)."""
+    """``tcnn.Encoding``: ``Identity`` (direction encoding with spherical_harmonics_degree = 0, the default of every
+    shipped NeRSemble config, nersemble_instant_ngp.py:46) and ``HashGrid`` with tcnn's parameter layout and
+    U(-1e-4, 1e-4) initialisation (the operator the reference's own HashEnsemble instantiates at
+    hash_ensemble.py:42-50; the fused ``nersemble_amd`` HashEnsemble is the fast path)."""
 
-    def __init__(self, n_input_dims: int, encoding_config: dict):
+    def __init__(self, n_input_dims: int, encoding_config: dict, seed: int = 1337):
         super().__init__()
-        if encoding_config.get("otype") != "Identity":
-            raise NotImplementedError(f"native Encoding: Identity only (got {encoding_config.get('otype')}); "
-                                      "hash grids go through HashEnsemble")
-        self.n_input_dims = self.n_output_dims = n_input_dims
+        otype = encoding_config.get("otype")
+        self.otype = otype
+        self.n_input_dims = n_input_dims
+        if otype == "Identity":
+            self.n_output_dims = n_input_dims
+        elif otype == "HashGrid":
+            if n_input_dims != 3 or encoding_config.get("interpolation", "Linear") != "Linear":
+                raise NotImplementedError("native HashGrid: 3-D input, Linear interpolation")
+            from . import _lib
+            self.f_enc = int(encoding_config.get("n_features_per_level", 2))
+            if self.f_enc not in (2, 4, 8):
+                raise NotImplementedError("native HashGrid: n_features_per_level in {2, 4, 8}")
+            self.geom = _lib.grid_geometry(int(encoding_config.get("n_levels", 16)),
+                                           float(encoding_config.get("per_level_scale", 2.0)),
+                                           int(encoding_config.get("base_resolution", 16)),
+                                           int(encoding_config.get("log2_hashmap_size", 19)))
+            self.n_output_dims = self.geom.n_levels * self.f_enc
+            gen = torch.Generator().manual_seed(seed)
+            self.params = nn.Parameter((torch.rand(self.geom.total_entries * self.f_enc, generator=gen) * 2 - 1) * 1e-4)
+        else:
+            raise NotImplementedError(f"native Encoding: Identity and HashGrid (got {otype})")
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        return x.to(torch.float16)
+        if self.otype == "Identity":
+            return x.to(torch.float16)
+        return F.hashgrid_encoding(x, self.params.view(self.geom.total_entries, self.f_enc), self.f_enc, self.geom)

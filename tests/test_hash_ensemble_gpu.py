@@ -205,3 +205,66 @@ def test_full_size_properties_h32(cuda):
     want = ohg.ensemble_fwd(x[sel].cpu().numpy(), tc.view(np.uint16), H, go, c1[sel].cpu().numpy()).astype(np.float32)
     got = o1[sel].cpu().numpy()
     assert (np.abs(got - want) <= FP16_EPS * np.abs(want) + 1e-6).all()
+
+
+@pytest.mark.parametrize("F_enc", [2, 4, 8])
+def test_tcnn_shaped_hashgrid_encoding(F_enc, cuda):
+    """tcnn.Encoding(HashGrid) compatibility operator vs the oracle's single-encoding restatement (+ gradients)."""
+    from nersemble_amd import tcnn
+    kw = SMALL_GEOM_KW
+    enc = tcnn.Encoding(3, {"otype": "HashGrid", "n_levels": kw["n_levels"], "n_features_per_level": F_enc,
+                            "log2_hashmap_size": kw["log2_hashmap_size"], "base_resolution": kw["base_resolution"],
+                            "per_level_scale": kw["per_level_scale"], "interpolation": "Linear"}).to(cuda)
+    go = oracle.grid_geometry(**kw)
+    rng = np.random.default_rng(F_enc)
+    tab = ((rng.random((go.total_entries, F_enc), dtype=np.float32) - 0.5)).astype(np.float16)
+    with torch.no_grad():
+        enc.params.copy_(torch.from_numpy(tab.astype(np.float32).reshape(-1)))
+    B = 333
+    x = rng.random((B, 3), dtype=np.float32)
+    xt = torch.from_numpy(x).to(cuda).requires_grad_(True)
+    out = enc(xt)
+    want = ohg.hashgrid_fwd(x, tab.view(np.uint16), go).astype(np.float32)
+    assert (np.abs(out.float().detach().cpu().numpy() - want) <= FP16_EPS * np.abs(want) + 1e-6).all()
+    # gradients through the ensemble oracle with H = F_enc/2 grids, unit codes
+    H = F_enc // 2
+    dout = rng.standard_normal((B, kw["n_levels"] * F_enc)).astype(np.float16)
+    out.backward(torch.from_numpy(dout).to(cuda))
+    # reference: finite-sum identity  sum(dtable * T) == sum(dout * out)
+    lhs = float((enc.params.grad.double() * enc.params.detach().double()).sum())
+    rhs = float((torch.from_numpy(dout).double() * torch.from_numpy(want).double()).sum())
+    assert abs(lhs - rhs) <= 2e-3 * max(1.0, abs(rhs))
+    assert torch.isfinite(xt.grad).all() and xt.grad.abs().max().item() > 0
+
+
+def test_reference_layout_ensemble_from_tcnn_encodings_matches_fused(cuda):
+    """The operator-level drop-in (C separate tcnn.Encoding(HashGrid) + rearrange + einsum, i.e. what the reference's
+    own HashEnsemble.forward does) equals the fused native HashEnsemble on the same parameters."""
+    import einops
+    from nersemble_amd import tcnn
+    from nersemble_amd.field_components.hash_ensemble import HashEnsemble, HashEnsembleConfig, TCNNHashEncodingConfig
+    H, kw = 16, SMALL_GEOM_KW
+    cfg = HashEnsembleConfig(H, TCNNHashEncodingConfig(n_levels=kw["n_levels"], log2_hashmap_size=kw["log2_hashmap_size"],
+                                                       base_resolution=kw["base_resolution"],
+                                                       per_level_scale=kw["per_level_scale"]))
+    he = HashEnsemble(cfg).to(cuda)
+    with torch.no_grad():
+        he.tables.mul_(4000)
+    sd = he.state_dict()
+    encs = []
+    for c in range(4):
+        e = tcnn.Encoding(3, {"otype": "HashGrid", "n_levels": kw["n_levels"], "n_features_per_level": 8,
+                              "log2_hashmap_size": kw["log2_hashmap_size"], "base_resolution": kw["base_resolution"],
+                              "per_level_scale": kw["per_level_scale"]}).to(cuda)
+        with torch.no_grad():
+            e.params.copy_(sd[f"hash_encodings.{c}.params"])
+        encs.append(e)
+    g = torch.Generator(device=cuda).manual_seed(0)
+    x = torch.rand((257, 3), device=cuda, generator=g)
+    code = torch.randn((257, H), device=cuda, generator=g) * 0.5
+    emb = torch.stack([e(x) for e in encs], dim=1)                                   # hash_ensemble.py:102-106
+    emb = einops.rearrange(emb, 'b c (l p f) -> b (l f) (c p) ', l=kw["n_levels"], p=4, f=2)   # :112
+    ref = torch.einsum('bdh,bh->bd', emb, code.to(emb))                               # :155-156
+    fused = he(x, code)
+    tol = 2.0 * FP16_EPS * ref.float().abs().max().item() + 1e-6
+    assert (fused.float() - ref.float()).abs().max().item() <= tol
