@@ -88,6 +88,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="p030_h32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true",
+                    help="do not record HIP events around the native calls (no roofline block; measures their overhead)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -111,27 +113,45 @@ def main():
     batches = [data.next_train(s) for s in range(a.warmup + a.steps)]
     torch.cuda.synchronize()
 
-    def run(n_steps, first_step):
+    step_marks = []                          # (event at step start, device-side sample count) per timed step
+
+    def run(n_steps, first_step, mark=False):
         samples = 0
         for s in range(first_step, first_step + n_steps):
+            if mark:
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record()
             bundle, batch = batches[s]
             loss, loss_dict, metrics = trainer.train_iteration(s, bundle, batch)
             samples += metrics["num_samples_per_batch"]
+            if mark:
+                step_marks.append((ev, metrics["num_samples_per_batch"]))
         return samples, loss, metrics
 
     run(a.warmup, 0)
+    # HIP events only around the calls that are priced against a roofline (+ the other large kernels), allocated
+    # before the timed region
+    _lib.profiler.watch = {"nsx_hash_ensemble_fwd", "nsx_hash_ensemble_bwd_factored", "nsx_hash_ensemble_bwd",
+                           "nsx_adam_hash_factored", "nsx_adam_dense", "nsx_deform_fwd", "nsx_deform_bwd",
+                           "nsx_mlp_fwd", "nsx_mlp_bwd", "nsx_check_finite", "nsx_march_count", "nsx_march_fill",
+                           "nsx_hash_grad_expand"}
+    if not a.no_kernel_events:
+        _lib.profiler.prewarm(2 * 16 * a.steps + 64)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     _lib.profiler.reset()
-    _lib.profiler.enabled = True
+    _lib.profiler.enabled = not a.no_kernel_events
     t0 = time.perf_counter()
-    samples, loss, metrics = run(a.steps, a.warmup)
+    samples, loss, metrics = run(a.steps, a.warmup, mark=True)
+    end_mark = torch.cuda.Event(enable_timing=True)
+    end_mark.record()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    trainer.flush_scheduler_step()
     _lib.profiler.enabled = False
     samples = int(samples)
 
@@ -193,6 +213,11 @@ def main():
             "psnr_last": float(metrics["psnr"].detach()), "loss_last": float(loss.detach()),
             "roofline": roofline, "rooflines": rooflines, "native_kernel_ms": kernels,
             "native_ms_per_step": sum(v["total_ms"] for v in prof.values()) / a.steps,
+            # device-timeline duration and marched samples of every timed step (the occupancy grid refines over the
+            # first steps, so the sample count -- and with it the step time -- falls during the run)
+            "per_step": [{"ms": round(step_marks[i][0].elapsed_time(
+                              step_marks[i + 1][0] if i + 1 < len(step_marks) else end_mark), 3),
+                          "samples": int(step_marks[i][1])} for i in range(len(step_marks))],
         }
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(H)

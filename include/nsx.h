@@ -269,6 +269,47 @@ int nsx_sample_losses_fwd(const float* weights, const float* t_starts, const flo
 int nsx_sample_losses_bwd(const float* weights, const float* t_starts, const float* t_ends, const int64_t* packed_info,
                           int64_t R, const float* depth_targets, float eps, int64_t max_ray, int64_t n_rays,
                           const float* sums, const float* grads, float* grad_weights, void* stream);
+/* The per-ray loss terms of one training step, their reduction over rays, the summed loss and the training metrics
+ * (models/base.py:90-133,204-215 get_masked_rgb_loss / get_alpha_loss / get_depth_loss; the reductions of the
+ * distortion / empty / near losses, base.py:136-202,224-249; nersemble_instant_ngp.py:409-422 get_metrics_dict;
+ * nersemble_trainer.py:184 reduce(add, loss_dict.values())) in ONE single-block kernel instead of ~110 element-wise
+ * launches on [R] tensors.  All pointers are device pointers; out is float[NSX_LOSS_OUT]:
+ *   out[NSX_LOSS_RGB]   = masked ? sum_{alpha>thr} mean_c (img-rgb)^2 / max(#,1) : MSE(img, rgb)
+ *   out[NSX_LOSS_ALPHA] = lambda_alpha * sum_{alpha<1} |acc - alpha| / max(#,1)        (alpha = alpha_map / 255; 0 if NULL)
+ *   out[NSX_LOSS_DEPTH] = lambda_depth * sum_{t>0} (t - depth)^2 / max(#,1)           (0 if depth_targets NULL)
+ *   out[NSX_LOSS_DIST / EMPTY / NEAR] from per_ray_sample = nsx_sample_losses_fwd's [R][5] (0 if NULL):
+ *       lambda_dist * S0 / n_eff (n_eff = last ray with samples + 1, as torch_efficient_distloss divides by
+ *       ray_id.max()+1), lambda_empty * S1 / max(S2,1), lambda_near * S3 / max(S4,1)
+ *   out[NSX_LOSS_TOTAL] = ((((rgb + alpha) + dist) + empty) + near) + depth
+ *   out[NSX_LOSS_PSNR], out[NSX_LOSS_PSNR_MASKED] (alpha_map > 127), out[NSX_LOSS_NUM_SAMPLES] = sum packed_info[:,1]
+ *   out[NSX_LOSS_SAMPLE_SUMS ..+4] = S0..S4 (the `sums` argument of nsx_sample_losses_bwd), ..+5..+8 = denominators.
+ * bwd: grad_out = dL/d out (float[NSX_LOSS_OUT], device; entries of TOTAL and of the individual terms add up);
+ * writes dL/d rgb [R][3], dL/d accumulation [R], dL/d depth [R] and sample_grads float[3] = the `grads` argument of
+ * nsx_sample_losses_bwd (launch it afterwards on the same stream with n_rays and out + NSX_LOSS_SAMPLE_SUMS). */
+#define NSX_LOSS_OUT 24
+#define NSX_LOSS_RGB 0
+#define NSX_LOSS_ALPHA 1
+#define NSX_LOSS_DEPTH 2
+#define NSX_LOSS_DIST 3
+#define NSX_LOSS_EMPTY 4
+#define NSX_LOSS_NEAR 5
+#define NSX_LOSS_TOTAL 6
+#define NSX_LOSS_PSNR 7
+#define NSX_LOSS_PSNR_MASKED 8
+#define NSX_LOSS_NUM_SAMPLES 9
+#define NSX_LOSS_SAMPLE_SUMS 10
+int nsx_ray_losses_fwd(const float* rgb, const float* accumulation, const float* depth, const float* image,
+                       const uint8_t* alpha_map /* [R] or NULL */, const float* depth_targets /* [R] or NULL */,
+                       const float* per_ray_sample /* [R][5] or NULL */, const int64_t* packed_info /* or NULL */,
+                       int64_t R, int use_masked_rgb, float alpha_mask_threshold, float lambda_alpha,
+                       float lambda_depth, float lambda_dist, float lambda_empty, float lambda_near, float* out,
+                       void* stream);
+int nsx_ray_losses_bwd(const float* rgb, const float* accumulation, const float* depth, const float* image,
+                       const uint8_t* alpha_map, const float* depth_targets, int64_t R, int use_masked_rgb,
+                       float alpha_mask_threshold, float lambda_alpha, float lambda_depth, float lambda_dist,
+                       float lambda_empty, float lambda_near, int64_t n_rays, const float* out, const float* grad_out,
+                       float* grad_rgb, float* grad_accumulation, float* grad_depth, float* sample_grads /* or NULL */,
+                       void* stream);
 /* torch_efficient_distloss.flatten_eff_distloss (models/base.py:245-247): per-ray loss terms
  * ray_loss[r] = (sum_i 1/3 interval_i w_i^2 + 2 w_i (m_i Wpre_i - WMpre_i)) / n_rays for rays r < max_ray (0 otherwise,
  * base.py:235) and grad_weights = grad_scale * dloss/dw.  ray_loss / grad_weights may be NULL. */

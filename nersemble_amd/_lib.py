@@ -91,6 +91,11 @@ SIGNATURES = {
                                       c_void_p]),
     "nsx_sample_losses_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_float, c_int64, c_int64,
                                       c_void_p, c_void_p, c_void_p, c_void_p]),
+    "nsx_ray_losses_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
+                                   c_int, c_float, c_float, c_float, c_float, c_float, c_float, c_void_p, c_void_p]),
+    "nsx_ray_losses_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float,
+                                   c_float, c_float, c_float, c_float, c_float, c_int64, c_void_p, c_void_p, c_void_p,
+                                   c_void_p, c_void_p, c_void_p, c_void_p]),
     "nsx_distloss": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_float, c_void_p,
                              c_void_p, c_void_p]),
     "nsx_check_finite": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
@@ -111,10 +116,23 @@ class KernelProfiler:
 
     def __init__(self):
         self.enabled = False
+        self.watch = None          # optional set of entry-point names to time (None = all)
         self.records = []          # (name, start_event, end_event, int_args)
+        self._pool = []
 
     def reset(self):
         self.records = []
+
+    def prewarm(self, n: int):
+        """Create (and record once) n events up front: the first record of an event allocates it in the runtime,
+        which must not happen inside a timed region."""
+        for _ in range(n):
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            self._pool.append(e)
+
+    def event(self):
+        return self._pool.pop() if self._pool else torch.cuda.Event(enable_timing=True)
 
     def summary(self):
         """name -> dict(calls, total_ms, avg_ms, samples); call after torch.cuda.synchronize()."""
@@ -137,11 +155,12 @@ class _LibProxy:
 
     def __getattr__(self, name):
         fn = getattr(self._h, name)
-        if not profiler.enabled or not name.startswith("nsx_"):
+        if not profiler.enabled or not name.startswith("nsx_") or (profiler.watch is not None
+                                                                   and name not in profiler.watch):
             return fn
 
         def timed(*args):
-            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s, e = profiler.event(), profiler.event()
             s.record()
             rc = fn(*args)
             e.record()

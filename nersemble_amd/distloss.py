@@ -75,3 +75,74 @@ def fused_sample_losses(weights: torch.Tensor, t_starts: torch.Tensor, t_ends: t
     """Returns a [3] tensor (dist, empty, near) -- un-weighted (the caller multiplies by the lambdas)."""
     return _SampleLosses.apply(weights, t_starts, t_ends, packed_info.to(torch.int64).contiguous(), depth_targets, eps,
                                max_ray, n_rays)
+
+
+# ---- all loss terms + metrics of a training step in two launches (csrc/losses.hip) --------------------------------
+LOSS_OUT = 24
+(LOSS_RGB, LOSS_ALPHA, LOSS_DEPTH, LOSS_DIST, LOSS_EMPTY, LOSS_NEAR, LOSS_TOTAL, LOSS_PSNR, LOSS_PSNR_MASKED,
+ LOSS_NUM_SAMPLES, LOSS_SAMPLE_SUMS) = range(11)
+
+
+class _StepLosses(torch.autograd.Function):
+    """out[LOSS_OUT] = every loss term of models/base.py + nersemble_instant_ngp.py:366-407, their sum and the
+    metrics of :409-422.  cfg = (use_masked_rgb, alpha_thr, l_alpha, l_depth, l_dist, l_empty, l_near, eps, max_ray)."""
+
+    @staticmethod
+    def forward(ctx, rgb, accumulation, depth, weights, t0, t1, packed, image, alpha_map, depth_targets, cfg):
+        f32 = torch.float32
+        rgbf = rgb.detach().to(f32).contiguous()
+        accf = accumulation.detach().to(f32).reshape(-1).contiguous()
+        depf = depth.detach().to(f32).reshape(-1).contiguous()
+        img = image.detach().to(f32).contiguous()
+        am = alpha_map.reshape(-1).contiguous() if alpha_map is not None else None
+        dt = depth_targets.detach().to(f32).reshape(-1).contiguous() if depth_targets is not None else None
+        wf = weights.detach().to(f32).reshape(-1).contiguous()
+        a = t0.detach().to(f32).reshape(-1).contiguous()
+        b = t1.detach().to(f32).reshape(-1).contiguous()
+        R = rgbf.shape[0]
+        use_masked, thr, l_alpha, l_depth, l_dist, l_empty, l_near, eps, max_ray = cfg
+        per_ray = torch.empty((R, 5), dtype=f32, device=rgbf.device)
+        check(lib().nsx_sample_losses_fwd(ptr(wf), ptr(a), ptr(b), ptr(packed), R, ptr(dt), float(eps), int(max_ray),
+                                          ptr(per_ray), stream()), "nsx_sample_losses_fwd")
+        out = torch.empty((LOSS_OUT,), dtype=f32, device=rgbf.device)
+        check(lib().nsx_ray_losses_fwd(ptr(rgbf), ptr(accf), ptr(depf), ptr(img), ptr(am), ptr(dt), ptr(per_ray),
+                                       ptr(packed), R, int(use_masked), float(thr), float(l_alpha), float(l_depth),
+                                       float(l_dist), float(l_empty), float(l_near), ptr(out), stream()),
+              "nsx_ray_losses_fwd")
+        ctx.save_for_backward(rgbf, accf, depf, img, am, dt, wf, a, b, packed, out)
+        ctx.cfg = cfg
+        ctx.shapes = (rgb.shape, accumulation.shape, depth.shape, weights.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        rgbf, accf, depf, img, am, dt, wf, a, b, packed, out = ctx.saved_tensors
+        use_masked, thr, l_alpha, l_depth, l_dist, l_empty, l_near, eps, max_ray = ctx.cfg
+        R = rgbf.shape[0]
+        g = g.to(torch.float32).contiguous()
+        g_rgb, g_acc, g_dep = torch.empty_like(rgbf), torch.empty_like(accf), torch.empty_like(depf)
+        g3 = torch.empty((3,), dtype=torch.float32, device=rgbf.device)
+        check(lib().nsx_ray_losses_bwd(ptr(rgbf), ptr(accf), ptr(depf), ptr(img), ptr(am), ptr(dt), R, int(use_masked),
+                                       float(thr), float(l_alpha), float(l_depth), float(l_dist), float(l_empty),
+                                       float(l_near), R, ptr(out), ptr(g), ptr(g_rgb), ptr(g_acc), ptr(g_dep), ptr(g3),
+                                       stream()), "nsx_ray_losses_bwd")
+        gw = torch.empty_like(wf)
+        if wf.numel() > 0:
+            sums = out[LOSS_SAMPLE_SUMS:LOSS_SAMPLE_SUMS + 5]
+            check(lib().nsx_sample_losses_bwd(ptr(wf), ptr(a), ptr(b), ptr(packed), R, ptr(dt), float(eps), int(max_ray),
+                                              R, ptr(sums), ptr(g3), ptr(gw), stream()), "nsx_sample_losses_bwd")
+        s_rgb, s_acc, s_dep, s_w = ctx.shapes
+        return (g_rgb.reshape(s_rgb), g_acc.reshape(s_acc), g_dep.reshape(s_dep), gw.reshape(s_w),
+                None, None, None, None, None, None, None)
+
+
+def fused_step_losses(rgb, accumulation, depth, weights, t_starts, t_ends, packed_info, image, alpha_map, depth_targets,
+                      *, use_masked_rgb: bool, alpha_mask_threshold: float, lambda_alpha: float, lambda_depth: float,
+                      lambda_dist: float, lambda_empty: float, lambda_near: float, eps: float, max_ray: int
+                      ) -> torch.Tensor:
+    """Returns the [LOSS_OUT] vector of ``nsx_ray_losses_fwd`` (index constants LOSS_* above); differentiable w.r.t.
+    rgb, accumulation, depth and weights."""
+    cfg = (bool(use_masked_rgb), float(alpha_mask_threshold), float(lambda_alpha or 0.0), float(lambda_depth or 0.0),
+           float(lambda_dist), float(lambda_empty), float(lambda_near), float(eps), int(max_ray))
+    return _StepLosses.apply(rgb, accumulation, depth, weights, t_starts, t_ends,
+                             packed_info.to(torch.int64).contiguous(), image, alpha_map, depth_targets, cfg)

@@ -106,14 +106,15 @@ class NativeGradScaler:
         if grads:
             torch._amp_foreach_non_finite_check_and_unscale_(grads, found_inf, inv_scale)
 
-    def update(self, found_infs: List[torch.Tensor]) -> None:
-        if not self.enabled:
-            return
+    def update(self, found_infs: List[torch.Tensor]) -> torch.Tensor:
+        """One scale update from the found_inf flags of all groups; returns their sum (device, shape [1])."""
         total = found_infs[0].clone()
         for f in found_infs[1:]:
             total += f
-        torch._amp_update_scale_(self._scale, self._growth_tracker, total.reshape(()), self.growth_factor,
-                                 self.backoff_factor, self.growth_interval)
+        if self.enabled:
+            torch._amp_update_scale_(self._scale, self._growth_tracker, total.reshape(()), self.growth_factor,
+                                     self.backoff_factor, self.growth_interval)
+        return total
 
     def get_scale(self) -> float:
         return float(self._scale.item())

@@ -61,6 +61,7 @@ class NeRSembleTrainer:
                                                                    gamma=gammas[self.group_of[key]])
         self.grad_scaler = NativeGradScaler(device, enabled=mixed_precision)
         self.callbacks = model.get_training_callbacks()
+        self._pending, self._found_host, self._found_event = None, None, None
 
     # ---- data-parallel gradient averaging ------------------------------------------------------------
     def _all_reduce_grads(self) -> None:
@@ -72,6 +73,7 @@ class NeRSembleTrainer:
     def _optimizer_step_all(self):
         """GradScaler semantics (nersemble_trainer.py:186): unscale + inf check per optimizer group, skip the step of
         a group whose gradients hold inf/NaN, then one scale update from all groups."""
+        self.flush_scheduler_step()        # the learning rates of this step depend on the previous step's outcome
         scaler = self.grad_scaler
         inv_scale = scaler.inv_scale()
         dev = inv_scale.device
@@ -94,9 +96,7 @@ class NeRSembleTrainer:
                     del opt.found_inf, opt.grad_scale
                 elif f.item() == 0:
                     opt.step()
-        founds = list(found.values())
-        scaler.update(founds)
-        return founds
+        return scaler.update(list(found.values()))
 
     def train_iteration(self, step: int, ray_bundle: RayBundle, batch: Dict[str, torch.Tensor]
                         ) -> Tuple[torch.Tensor, Dict[str, torch.Tensor], Dict[str, torch.Tensor]]:
@@ -110,12 +110,41 @@ class NeRSembleTrainer:
             outputs = self.model(ray_bundle)
             metrics_dict = self.model.get_metrics_dict(outputs, batch)
             loss_dict = self.model.get_loss_dict(outputs, batch, metrics_dict)
-            loss = functools.reduce(torch.add, loss_dict.values())
+            loss = getattr(loss_dict, "total", None)
+            if loss is None:
+                loss = functools.reduce(torch.add, loss_dict.values())
         self.grad_scaler.scale(loss).backward()
         self._all_reduce_grads()
-        founds = self._optimizer_step_all()
-        # the reference skips the LR step when the scale dropped, i.e. when an inf/NaN was found (:199-203)
-        if torch.stack(founds).sum().item() == 0:
+        found_any = self._optimizer_step_all()
+        # the reference skips the LR step when the scale dropped, i.e. when an inf/NaN was found (:199-203).  Reading
+        # the flag here would drain the GPU queue at the end of every step; it is copied to pinned memory instead
+        # and consulted right before the learning rates are next used (flush_scheduler_step).
+        self._defer_scheduler_step(found_any)
+        return loss, loss_dict, metrics_dict
+
+    def _defer_scheduler_step(self, found_any: torch.Tensor) -> None:
+        if not found_any.is_cuda:
+            self._pending = ("host", found_any)
+            return
+        if self._found_host is None:
+            self._found_host = torch.empty((1,), dtype=torch.float32).pin_memory()
+            self._found_event = torch.cuda.Event()
+        self._found_host.copy_(found_any.reshape(1), non_blocking=True)
+        self._found_event.record()
+        self._pending = ("pinned", None)
+
+    def flush_scheduler_step(self) -> None:
+        """Applies the LR-scheduler step of the last finished iteration (skipped if that iteration found inf/NaN).
+        Called automatically before the next optimizer step; call it once after the last iteration."""
+        if self._pending is None:
+            return
+        kind, val = self._pending
+        self._pending = None
+        if kind == "pinned":
+            self._found_event.synchronize()
+            bad = float(self._found_host[0]) != 0.0
+        else:
+            bad = float(val.sum()) != 0.0
+        if not bad:
             for sch in self.schedulers.values():
                 sch.step()
-        return loss, loss_dict, metrics_dict

@@ -78,6 +78,12 @@ class TrainingCallback:
             self.func(*self.args, step=step)
 
 
+class LossDict(dict):
+    """loss_dict whose sum over the values is already available as ``total`` (computed in the loss kernel in the
+    order of functools.reduce(torch.add, values)); a plain dict for every other purpose."""
+    total: Optional[Tensor] = None
+
+
 def psnr(pred: Tensor, target: Tensor) -> Tensor:
     """torchmetrics.PeakSignalNoiseRatio(data_range=1.0): 10 log10(1 / MSE)."""
     return 10.0 * torch.log10(1.0 / torch.mean((pred - target) ** 2))
@@ -98,6 +104,8 @@ class NeRSembleNGPModel(BaseModel):
         self._sigma_cache = None
         # reuse the forward values of the sampler's no-grad density pass in the main pass (exact; see get_outputs)
         self.reuse_sigma_pass = True
+        # all loss terms + metrics from csrc/losses.hip when the configuration allows (see _fused_step_losses)
+        self.fuse_step_losses = True
         self.populate_modules()
 
     # ---- construction (nersemble_instant_ngp.py:81-179) ---------------------------------------------
@@ -307,6 +315,34 @@ class NeRSembleNGPModel(BaseModel):
         return self.get_outputs(ray_bundle)
 
     # ---- losses / metrics (:366-422) ---------------------------------------------------------------
+    def _fused_step_losses(self, outputs, batch):
+        """All loss terms + metrics of the step from csrc/losses.hip (2 launches instead of ~110 element-wise ones),
+        or None when the configuration is not the one the fused kernels cover.  Cached in ``outputs``."""
+        if "_step_losses" in outputs:
+            return outputs["_step_losses"]
+        cfg = self.config
+        res = None
+        ray_indices = outputs["ray_indices"][0]
+        num_rays = outputs["accumulation"].shape[0]
+        alpha_map = batch.get("alpha_map")
+        ok = (self.fuse_step_losses and self.training and ray_indices.is_cuda and "depth_maps" in batch
+              and cfg.lambda_dist_loss > 0 and cfg.lambda_near_loss > 0 and cfg.lambda_empty_loss > 0
+              and num_rays <= cfg.dist_loss_max_rays
+              and (alpha_map is None or (alpha_map.dtype == torch.uint8 and alpha_map.numel() == num_rays)))
+        if ok:
+            from ..distloss import fused_step_losses
+            ray_samples = outputs["ray_samples"][0]
+            res = fused_step_losses(
+                outputs["rgb"], outputs["accumulation"], outputs["depth"], outputs["weights"][0],
+                ray_samples.frustums.starts, ray_samples.frustums.ends, outputs["packed_info"][0],
+                batch["image"], alpha_map, batch["depth_maps"],
+                use_masked_rgb=cfg.use_masked_rgb_loss, alpha_mask_threshold=cfg.alpha_mask_threshold,
+                lambda_alpha=cfg.lambda_alpha_loss, lambda_depth=cfg.lambda_depth_loss if self.training else 0.0,
+                lambda_dist=cfg.lambda_dist_loss, lambda_empty=cfg.lambda_empty_loss, lambda_near=cfg.lambda_near_loss,
+                eps=self.sched_eps_depth.value, max_ray=cfg.dist_loss_max_rays)
+        outputs["_step_losses"] = res
+        return res
+
     def get_loss_dict(self, outputs, batch, metrics_dict=None) -> Dict[str, Tensor]:
         loss_dict = dict()
         accumulation = outputs["accumulation"]
@@ -314,12 +350,27 @@ class NeRSembleNGPModel(BaseModel):
         ray_samples = outputs["ray_samples"][0]
         ray_indices = outputs["ray_indices"][0]
         weights = outputs["weights"][0]
+        cfg = self.config
+        fused = self._fused_step_losses(outputs, batch)
+        if fused is not None:
+            from .. import distloss as dl
+            loss_dict = LossDict()
+            loss_dict["rgb_loss"] = fused[dl.LOSS_RGB]
+            if "alpha_map" in batch and cfg.lambda_alpha_loss is not None and cfg.lambda_alpha_loss > 0:
+                loss_dict["alpha_loss"] = fused[dl.LOSS_ALPHA]
+            loss_dict["dist_loss"] = fused[dl.LOSS_DIST]
+            loss_dict["empty_loss"] = fused[dl.LOSS_EMPTY]
+            loss_dict["near_loss"] = fused[dl.LOSS_NEAR]
+            if cfg.lambda_depth_loss > 0:
+                loss_dict["depth_loss"] = fused[dl.LOSS_DEPTH]
+            # == reduce(torch.add, loss_dict.values()), summed in the kernel in the same order
+            loss_dict.total = fused[dl.LOSS_TOTAL]
+            return loss_dict
         loss_dict["rgb_loss"] = self.get_masked_rgb_loss(batch, outputs["rgb"])
         if "alpha_map" in batch:
             alpha_loss = self.get_alpha_loss(batch, accumulation)
             if alpha_loss is not None:
                 loss_dict["alpha_loss"] = alpha_loss
-        cfg = self.config
         num_rays = accumulation.shape[0]
         fuse = (self.training and ray_indices.is_cuda and "depth_maps" in batch and cfg.lambda_dist_loss > 0
                 and cfg.lambda_near_loss > 0 and cfg.lambda_empty_loss > 0 and num_rays <= cfg.dist_loss_max_rays)
@@ -356,6 +407,14 @@ class NeRSembleNGPModel(BaseModel):
         return loss_dict
 
     def get_metrics_dict(self, outputs, batch) -> Dict[str, Tensor]:
+        fused = self._fused_step_losses(outputs, batch)
+        if fused is not None:
+            from .. import distloss as dl
+            m = fused.detach()
+            metrics = {"psnr": m[dl.LOSS_PSNR], "num_samples_per_batch": m[dl.LOSS_NUM_SAMPLES]}
+            if "alpha_map" in batch:
+                metrics["psnr_masked"] = m[dl.LOSS_PSNR_MASKED]
+            return metrics
         rgb = outputs["rgb"]
         image = batch["image"].to(rgb.device)
         metrics = {"psnr": psnr(rgb, image), "num_samples_per_batch": outputs["num_samples_per_ray"].sum()}
