@@ -55,8 +55,9 @@ constexpr int P_TOTAL = P_BV + 3;           // 127 750
 // fragment groups (each fragment = 64 lanes x 8 halfs)
 constexpr int F0 = 0;                       // [4][11]
 constexpr int F1 = F0 + 44, F2 = F1 + 32, F3 = F2 + 32;
-constexpr int F4 = F3 + 32;                 // [4][19]
-constexpr int F5 = F4 + 76;
+constexpr int F4 = F3 + 32;                 // W4 over the input: [4][11]
+constexpr int F4X = F4 + 44;                // W4 over x:         [4][8]
+constexpr int F5 = F4X + 32;
 constexpr int FH = F5 + 32;                 // [1][8]
 constexpr int N_FWD_FRAGS = FH + 8;         // 256
 constexpr int BH = N_FWD_FRAGS;             // [4][1]
@@ -91,13 +92,13 @@ __device__ __forceinline__ float pack_source(const float* __restrict__ P, int fi
         const int base = l == 0 ? P_W1 : (l == 1 ? P_W2 : P_W3);
         return lin(base, DFW, 32 * mt + i, kchain(t, kb, j));
     }
-    if (fi < F5) {                                   // W4: 11 natural steps over the input, 8 chained over x
-        const int mt = (fi - F4) / 19, t = (fi - F4) % 19;
-        if (t < DF_TIN) {
-            const int k = 16 * t + 8 * kb + j;
-            return k < DF_IN ? lin(P_W4, DF_W4, 32 * mt + i, k) : 0.f;
-        }
-        return lin(P_W4, DF_W4, 32 * mt + i, DF_IN + kchain(t - DF_TIN, kb, j));
+    if (fi < F4X) {                                  // W4, 11 natural steps over the input
+        const int mt = (fi - F4) / DF_TIN, t = (fi - F4) % DF_TIN, k = 16 * t + 8 * kb + j;
+        return k < DF_IN ? lin(P_W4, DF_W4, 32 * mt + i, k) : 0.f;
+    }
+    if (fi < F5) {                                   // W4, 8 chained steps over x
+        const int mt = (fi - F4X) / DF_TW, t = (fi - F4X) % DF_TW;
+        return lin(P_W4, DF_W4, 32 * mt + i, DF_IN + kchain(t, kb, j));
     }
     if (fi < FH) {                                   // W5
         const int mt = (fi - F5) / DF_TW, t = (fi - F5) % DF_TW;
@@ -215,77 +216,114 @@ __device__ __forceinline__ void build_input(const DeformArgs& A, int64_t b, int 
     }
 }
 
-// acc (+bias) -> relu -> fp16 fragments (chained k order) ; returns a 64-bit mask of positive units (bit 8 t + j)
-__device__ __forceinline__ uint64_t finish_layer(const f32x16 acc[4], const float* __restrict__ bias, int kb,
-                                                 f16x8 h[DF_TW]) {
-    uint64_t mask = 0;
+// Packed epilogue helpers.  Two accumulator values -> one dword of two halfs (v_cvt_pk_f16_f32, round-to-nearest-even).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ uint32_t cvt_pk(float a, float b) {
+    f32x2 v; v[0] = a; v[1] = b;
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2));
+}
+
+// acc (bias already in the accumulator) -> fp16 -> relu -> fragments (chained k order).
+// ReLU on the packed halfs is gfx950's v_pk_maximum3_f16(x, 0, 0): the IEEE-754-2019 maximum, which -- unlike
+// v_pk_max_f16 -- propagates NaN exactly as torch.relu does (the reference relies on that: a NaN deformation falls back
+// to the undeformed point, deformation_field.py:101-102).
+// With MASK, also the positions of the non-zero outputs, 1 bit per unit in TWO words per lane: word (D >> 4), bit
+// (D & 15) for the low half and 16 + (D & 15) for the high half of fragment dword D = 4 t + j / 2.
+template <bool MASK>
+__device__ __forceinline__ u32x2 finish_layer(const f32x16 acc[4], f16x8 h[DF_TW]) {
+    u32x2 mask; mask[0] = 0u; mask[1] = 0u;
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
+    for (int t = 0; t < DF_TW; ++t) {
+        u32x4 hv;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float v = acc[mt][r] + bias[32 * mt + acc_row(r, kb)];
-            const half_t hv = (half_t)v;                       // Linear output in fp16 ...
-            const half_t rl = (float)hv <= 0.f ? (half_t)0.f : hv;  // ... then ReLU (NaN propagates like torch.relu)
-            h[2 * mt + (r >> 3)][r & 7] = rl;
-            if ((float)hv > 0.f) mask |= (1ull << (8 * (2 * mt + (r >> 3)) + (r & 7)));
+        for (int q = 0; q < 4; ++q) {
+            const int mt = t >> 1, r = 8 * (t & 1) + 2 * q;
+            const uint32_t p = cvt_pk(acc[mt][r], acc[mt][r + 1]);
+            uint32_t rl;
+            asm("v_pk_maximum3_f16 %0, %1, 0, 0" : "=v"(rl) : "v"(p));
+            hv[q] = rl;
+            if (MASK) {
+                uint32_t nz;                                   // 1 per non-zero half (the compiler would expand a
+                asm("v_pk_min_u16 %0, %1, %2" : "=v"(nz) : "v"(rl), "v"(0x00010001u));   // vector min into cmp + select)
+                const int D = 4 * t + q;
+                mask[D >> 4] |= nz << (D & 15);
+            }
         }
+        h[t] = __builtin_bit_cast(f16x8, hv);
     }
     return mask;
 }
 
-// acc[mt] += sum_t W_frag(group, mt, t) * in[t].  Weight fragments stream from L2 with a one-step software
-// prefetch; the compiler barrier keeps it from hoisting a whole layer of fragment loads into registers.
-// one weight fragment: uniform (scalar) base + 16 B per lane -> global_load_dwordx4 with an SGPR base address
-__device__ __forceinline__ f16x8 load_frag(const f16x8* __restrict__ frags, int fi, uint32_t voff) {
-    const char* ub = reinterpret_cast<const char*>(frags) + (size_t)fi * 1024;
-    return *reinterpret_cast<const f16x8*>(ub + voff);
+// ---- weight pipeline: the 8 waves of a block walk the layers in lock-step.  Each layer's fragment group ("stage",
+// <= 44 KB) is copied L2 -> LDS by the LDS-DMA path (global_load_lds_dwordx4: one 1-KB fragment per wave-instruction,
+// no VGPR round trip) into the buffer that is NOT being read, while the MFMAs of the current stage run; one barrier
+// per stage.  A stage is consumed by 8 x 32 samples, so the weights cross L2 -> CU once per 256 samples. ----
+constexpr int NW = 8;                                       // waves per block (one block per CU, 2 waves per SIMD)
+constexpr int STAGE_FRAGS = 44;                             // largest stage: W0 / W4-input (4 M-tiles x 11 K-steps)
+
+struct DeformLds {
+    f16x8 w[2][STAGE_FRAGS * 64];
+    float bias[N_BIAS];
+};
+
+__device__ __forceinline__ void stage_issue(const f16x8* __restrict__ frags, int first, int count, f16x8* buf) {
+    // wave-uniform fragment base (SGPR) + 16 B per lane: the copy needs no per-stage address VGPRs
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t voff = (threadIdx.x & 63u) * 16u;
+    const char* base = reinterpret_cast<const char*>(frags) + (size_t)first * 1024;
+    for (int f = wave; f < count; f += NW)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + (size_t)f * 1024 + voff),
+                                         (__attribute__((address_space(3))) void*)(buf + f * 64), 16, 0, 0);
 }
 
-template <int KT>
-__device__ __forceinline__ void gemm_layer(const f16x8* __restrict__ frags, int group, int lane, const f16x8* in,
-                                           f32x16 acc[4], int t_off = 0, int kt_total = KT) {
-    const uint32_t voff = (uint32_t)lane * 16u;
-    const int g0 = group + t_off;
-    f16x8 a[4], nx[4];
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) a[mt] = load_frag(frags, g0 + mt * kt_total, voff);
-#pragma unroll
-    for (int t = 0; t < KT; ++t) {
-        if (t + 1 < KT) {
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) nx[mt] = load_frag(frags, g0 + mt * kt_total + t + 1, voff);
-        }
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) acc[mt] = mfma(a[mt], in[t], acc[mt]);
-        asm volatile("" ::: "memory");
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) a[mt] = nx[mt];
-    }
-}
-
-// ---- LDS-staged weights: the 4 waves of a block walk the layers in lock-step; each layer's fragment group is copied
-// once from L2 into LDS and read by all waves (4x less L2 traffic than every wave streaming its own fragments) ----
-constexpr int LDS_FRAGS = 76;                               // largest group: W4 (4 M-tiles x 19 K-steps)
-
-__device__ __forceinline__ void stage_group(const f16x8* __restrict__ frags, int first, int count, f16x8* lds) {
-    __syncthreads();                                        // previous group fully consumed
-    const f16x8* src = frags + (size_t)first * 64;
-    for (int i = threadIdx.x; i < count * 64; i += blockDim.x) lds[i] = src[i];
+// own LDS-DMA copies landed (vmcnt(0)) + everybody finished reading the other buffer
+__device__ __forceinline__ void stage_flip(int& cur) {
     __syncthreads();
+    cur ^= 1;
 }
 
+typedef __attribute__((address_space(3))) const float lds_cfloat;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) const f32x4 lds_cfloat4;
+
+// The bias block never changes after the prologue, so loop-invariant-code motion would hoist every bias read of every
+// layer (hundreds of VGPRs) out of the persistent tile loop; laundering the LDS address once per tile keeps them as
+// in-loop ds_reads.
+__device__ __forceinline__ lds_cfloat* launder_lds(const float* p) {
+    lds_cfloat* q = (lds_cfloat*)p;
+    asm volatile("" : "+s"(q));
+    return q;
+}
+
+// accumulators start at the (fp16-rounded) bias: rows acc_row(r, kb) of tile mt are 4 runs of 4 consecutive neurons
+__device__ __forceinline__ void acc_init(f32x16 acc[4], lds_cfloat* bias_lds, int kb) {
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 v = *reinterpret_cast<lds_cfloat4*>(bias_lds + 32 * mt + 8 * q + 4 * kb);
+            acc[mt][4 * q + 0] = v.x; acc[mt][4 * q + 1] = v.y; acc[mt][4 * q + 2] = v.z; acc[mt][4 * q + 3] = v.w;
+        }
+}
+
+// acc[mt] += sum_t W_frag(stage-local index local + mt * KT + t) * in[t], fragments read from LDS one K-step ahead
 template <int KT>
-__device__ __forceinline__ void gemm_layer_lds(const f16x8* lds, int local, int lane, const f16x8* in, f32x16 acc[4],
-                                               int t_off = 0, int kt_total = KT) {
-    const f16x8* base = lds + (size_t)(local + t_off) * 64 + lane;
+__device__ __forceinline__ void gemm_layer_lds(const f16x8* lds, int local, int lane, const f16x8* in, f32x16 acc[4]) {
+    const f16x8* base = lds + (size_t)local * 64 + lane;
     f16x8 a[4], nx[4];
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) a[mt] = base[(mt * kt_total) * 64];
+    for (int mt = 0; mt < 4; ++mt) a[mt] = base[(mt * KT) * 64];
 #pragma unroll
     for (int t = 0; t < KT; ++t) {
         if (t + 1 < KT) {
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) nx[mt] = base[(mt * kt_total + t + 1) * 64];
+            for (int mt = 0; mt < 4; ++mt) nx[mt] = base[(mt * KT + t + 1) * 64];
         }
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) acc[mt] = mfma(a[mt], in[t], acc[mt]);
@@ -297,7 +335,7 @@ __device__ __forceinline__ void gemm_layer_lds(const f16x8* lds, int local, int 
 struct Fwd {
     f16x8 x[DF_TIN];
     f16x8 h[DF_TW];              // current activation
-    uint64_t m1, m2, m3, m4, m5, m6;
+    u32x2 m1, m2, m3, m4, m5, m6;   // positions of the positive units of each layer (layout: finish_layer)
     float pn[3];
     float r[3], v[3];            // head outputs (fp16-rounded), valid on both lanes of a sample
 };
@@ -334,72 +372,71 @@ __device__ __forceinline__ void store_tile_T(half_t* __restrict__ dst, int lane,
     for (int p = 0; p < (NF + 1) / 2; ++p) {
         f32x16 d = mfma(frags[2 * p], sel.lo, zero16());
         if (2 * p + 1 < NF) d = mfma(frags[2 * p + 1], sel.hi, d);
-        f16x8 o0, o1;
+        u32x4 o0, o1;
 #pragma unroll
-        for (int r = 0; r < 8; ++r) { o0[r] = (half_t)d[r]; o1[r] = (half_t)d[8 + r]; }
-        f16x8* out = reinterpret_cast<f16x8*>(dst + ((size_t)p * 64 + lane) * 16);
+        for (int r = 0; r < 4; ++r) { o0[r] = cvt_pk(d[2 * r], d[2 * r + 1]); o1[r] = cvt_pk(d[8 + 2 * r], d[9 + 2 * r]); }
+        u32x4* out = reinterpret_cast<u32x4*>(dst + ((size_t)p * 64 + lane) * 16);
         out[0] = o0;
         out[1] = o1;
     }
 }
 
-// Loop-invariant-code motion would hoist every bias value and fragment address (hundreds of VGPRs) out of the
-// persistent tile loop; laundering the uniform base pointers once per tile keeps them as in-loop loads.
-template <typename T>
-__device__ __forceinline__ const T* launder(const T* p) {
-    asm volatile("" : "+s"(p));
-    return p;
-}
-
-__device__ __forceinline__ void forward_tile(const DeformArgs& A0, int64_t b, int lane, Fwd& F, half_t* a_tiles,
-                                             f16x8* lds) {
-    DeformArgs A = A0;
-    A.frags = launder(A0.frags);
-    A.bias = launder(A0.bias);
-    const int n = lane & 31, kb = lane >> 5;
+// One 32-sample tile through the 6 layers + heads.  On entry stage F0 is resident in L.w[cur]; on exit the stage
+// `next_first` (the first stage of whatever follows: F0 of the next tile, or the first backward stage) is resident in
+// L.w[cur].  BWD: also keeps the ReLU masks and writes the transposed layer-input tiles for the weight gradients.
+template <bool BWD>
+__device__ __forceinline__ void forward_tile(const DeformArgs& A, int64_t b, int lane, Fwd& F, half_t* a_tiles,
+                                             DeformLds& L, int& cur, int next_first, int next_count) {
+    const int kb = lane >> 5;
+    lds_cfloat* bias = launder_lds(L.bias);
     build_input(A, b, kb, F.pn, F.x);
     TSel tsel;
-    if (a_tiles) {
+    if (BWD) {
         tsel = make_tsel(lane);
         store_tile_T<DF_TIN>(a_tiles, lane, F.x, tsel);
     }
     f32x16 acc[4];
     // L0
-    stage_group(A.frags, F0, 44, lds);
-    for (int i = 0; i < 4; ++i) acc[i] = zero16();
-    gemm_layer_lds<DF_TIN>(lds, 0, lane, F.x, acc);
-    F.m1 = finish_layer(acc, A.bias + 0 * DFW, kb, F.h);
-    if (a_tiles) store_tile_T<DF_TW>(a_tiles + 192 * 32 + 0 * DFW * 32, lane, F.h, tsel);
+    stage_issue(A.frags, F1, 32, L.w[cur ^ 1]);
+    acc_init(acc, bias + 0 * DFW, kb);
+    gemm_layer_lds<DF_TIN>(L.w[cur], 0, lane, F.x, acc);
+    F.m1 = finish_layer<BWD>(acc, F.h);
+    if (BWD) store_tile_T<DF_TW>(a_tiles + 192 * 32 + 0 * DFW * 32, lane, F.h, tsel);
+    stage_flip(cur);
     // L1..L3 (the input fragments are dead once the layer's MFMAs are issued: the output overwrites them)
 #pragma unroll 1
     for (int l = 1; l <= 3; ++l) {
-        stage_group(A.frags, l == 1 ? F1 : (l == 2 ? F2 : F3), 32, lds);
-        for (int i = 0; i < 4; ++i) acc[i] = zero16();
-        gemm_layer_lds<DF_TW>(lds, 0, lane, F.h, acc);
-        const uint64_t m = finish_layer(acc, A.bias + l * DFW, kb, F.h);
+        stage_issue(A.frags, l == 1 ? F2 : (l == 2 ? F3 : F4), l == 3 ? 44 : 32, L.w[cur ^ 1]);
+        acc_init(acc, bias + l * DFW, kb);
+        gemm_layer_lds<DF_TW>(L.w[cur], 0, lane, F.h, acc);
+        const u32x2 m = finish_layer<BWD>(acc, F.h);
         if (l == 1) F.m2 = m; else if (l == 2) F.m3 = m; else F.m4 = m;
-        if (a_tiles) store_tile_T<DF_TW>(a_tiles + 192 * 32 + l * DFW * 32, lane, F.h, tsel);
+        if (BWD) store_tile_T<DF_TW>(a_tiles + 192 * 32 + l * DFW * 32, lane, F.h, tsel);
+        stage_flip(cur);
     }
-    // L4: cat[input, x]
-    stage_group(A.frags, F4, 76, lds);
-    for (int i = 0; i < 4; ++i) acc[i] = zero16();
-    gemm_layer_lds<DF_TIN>(lds, 0, lane, F.x, acc, 0, 19);
-    gemm_layer_lds<DF_TW>(lds, 0, lane, F.h, acc, DF_TIN, 19);
-    F.m5 = finish_layer(acc, A.bias + 4 * DFW, kb, F.h);
-    if (a_tiles) store_tile_T<DF_TW>(a_tiles + 192 * 32 + 4 * DFW * 32, lane, F.h, tsel);
-    // L5 (+ out_activation ReLU) and the heads share one staged group (F5 | FH are contiguous)
-    stage_group(A.frags, F5, 40, lds);
-    for (int i = 0; i < 4; ++i) acc[i] = zero16();
-    gemm_layer_lds<DF_TW>(lds, 0, lane, F.h, acc);
-    F.m6 = finish_layer(acc, A.bias + 5 * DFW, kb, F.h);
-    if (a_tiles) store_tile_T<DF_TW>(a_tiles + 192 * 32 + 5 * DFW * 32, lane, F.h, tsel);
+    // L4: cat[input, x] -- two stages, one accumulator
+    stage_issue(A.frags, F4X, 32, L.w[cur ^ 1]);
+    acc_init(acc, bias + 4 * DFW, kb);
+    gemm_layer_lds<DF_TIN>(L.w[cur], 0, lane, F.x, acc);
+    stage_flip(cur);
+    stage_issue(A.frags, F5, 40, L.w[cur ^ 1]);
+    gemm_layer_lds<DF_TW>(L.w[cur], 0, lane, F.h, acc);
+    F.m5 = finish_layer<BWD>(acc, F.h);
+    if (BWD) store_tile_T<DF_TW>(a_tiles + 192 * 32 + 4 * DFW * 32, lane, F.h, tsel);
+    stage_flip(cur);
+    // L5 (+ out_activation ReLU) and the heads share one stage (F5 | FH are contiguous)
+    stage_issue(A.frags, next_first, next_count, L.w[cur ^ 1]);
+    acc_init(acc, bias + 5 * DFW, kb);
+    gemm_layer_lds<DF_TW>(L.w[cur], 0, lane, F.h, acc);
+    F.m6 = finish_layer<BWD>(acc, F.h);
+    if (BWD) store_tile_T<DF_TW>(a_tiles + 192 * 32 + 5 * DFW * 32, lane, F.h, tsel);
     // heads (one M-tile, rows 0..5)
     f32x16 o = zero16();
 #pragma unroll
-    for (int t = 0; t < DF_TW; ++t) o = mfma(lds[(32 + t) * 64 + lane], F.h[t], o);
+    for (int t = 0; t < DF_TW; ++t) o = mfma(L.w[cur][(32 + t) * 64 + lane], F.h[t], o);
     float own[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) own[r] = (float)(half_t)(o[r] + A.bias[6 * DFW + acc_row(r, kb)]);
+    for (int r = 0; r < 4; ++r) own[r] = (float)(half_t)(o[r] + bias[6 * DFW + acc_row(r, kb)]);
     float oth[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) oth[r] = __shfl_xor(own[r], 32);
@@ -408,6 +445,7 @@ __device__ __forceinline__ void forward_tile(const DeformArgs& A0, int64_t b, in
     const float v0 = kb ? oth[3] : own[3], v1 = kb ? own[0] : oth[0], v2 = kb ? own[1] : oth[1];
     F.r[0] = r0; F.r[1] = r1; F.r[2] = r2;
     F.v[0] = v0; F.v[1] = v1; F.v[2] = v2;
+    stage_flip(cur);
 }
 
 __device__ __forceinline__ void cross3(const float a[3], const float b[3], float c[3]) {
@@ -444,16 +482,24 @@ __device__ __forceinline__ void se3_apply(const float r[3], const float v[3], co
 // ---------------------------------------------------------------------------------------------------------
 // forward kernel
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 2) void deform_fwd_kernel(DeformArgs A, float* __restrict__ offsets, int64_t n_tiles) {
-    __shared__ __attribute__((aligned(16))) f16x8 lds[LDS_FRAGS * 64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t n_groups = (n_tiles + 3) / 4;
-    for (int64_t grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {        // all 4 waves iterate together
-        const int64_t tile = grp * 4 + wave;
+__device__ __forceinline__ void lds_prologue(const DeformArgs& A, DeformLds& L, int first, int count) {
+    for (int i = threadIdx.x; i < N_BIAS; i += blockDim.x) L.bias[i] = A.bias[i];
+    stage_issue(A.frags, first, count, L.w[0]);
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(NW * 64, 1) void deform_fwd_kernel(DeformArgs A, float* __restrict__ offsets, int64_t n_tiles) {
+    __shared__ __attribute__((aligned(16))) DeformLds L;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t n_groups = (n_tiles + NW - 1) / NW;
+    lds_prologue(A, L, F0, 44);
+    int cur = 0;
+    for (int64_t grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {        // all waves iterate together
+        const int64_t tile = grp * NW + wave;
         const int64_t b_raw = tile * 32 + (lane & 31);
         const int64_t b = b_raw < A.S ? b_raw : A.S - 1;
         Fwd F;
-        forward_tile(A, b, lane, F, nullptr, lds);
+        forward_tile<false>(A, b, lane, F, nullptr, L, cur, F0, 44);
         float w[3];
         se3_apply(F.r, F.v, F.pn, w);
         if (b_raw < A.S && (lane >> 5) == 0) {
@@ -477,35 +523,42 @@ constexpr int64_t TILE_DZH = TILE_DZ + 6 * DFW * 32;
 constexpr int64_t TILE_DC = TILE_DZH + 32 * 32;
 constexpr int64_t TILE_HALFS = TILE_DC + DFW * 32;        // 60 416 halfs = 118 KB per 32 samples
 
-__device__ __forceinline__ void mask_pack(const f32x16 d[4], uint64_t mask, f16x8 dz[DF_TW]) {
+// dZ = dA * relu'(a): accumulators -> packed halfs, AND-ed with 0xFFFF per positive unit (mask layout: finish_layer)
+__device__ __forceinline__ void mask_pack(const f32x16 d[4], u32x2 mask, f16x8 dz[DF_TW]) {
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
+    for (int t = 0; t < DF_TW; ++t) {
+        u32x4 v;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int t = 2 * mt + (r >> 3), j = r & 7;
-            dz[t][j] = ((mask >> (8 * t + j)) & 1ull) ? (half_t)d[mt][r] : (half_t)0.f;
+        for (int q = 0; q < 4; ++q) {
+            const int mt = t >> 1, r = 8 * (t & 1) + 2 * q, D = 4 * t + q;
+            const uint32_t p = cvt_pk(d[mt][r], d[mt][r + 1]);
+            const uint32_t bits = (mask[D >> 4] >> (D & 15)) & 0x10001u;
+            v[q] = p & (bits * 0xFFFFu);
         }
+        dz[t] = __builtin_bit_cast(f16x8, v);
+    }
 }
 
-__global__ __launch_bounds__(256, 2) void deform_bwd_kernel(DeformArgs A, const float* __restrict__ goff,
-                                                         half_t* __restrict__ scratch, int64_t n_tiles,
-                                                         float* __restrict__ gcode_samples) {
-    __shared__ __attribute__((aligned(16))) f16x8 lds[LDS_FRAGS * 64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+__global__ __launch_bounds__(NW * 64, 1) void deform_bwd_kernel(DeformArgs A, const float* __restrict__ goff,
+                                                              half_t* __restrict__ scratch, int64_t n_tiles,
+                                                              float* __restrict__ gcode_samples) {
+    __shared__ __attribute__((aligned(16))) DeformLds L;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int n = lane & 31, kb = lane >> 5;
-    const int64_t n_groups = (n_tiles + 3) / 4;
-    for (int64_t grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {        // all 4 waves iterate together
-        const int64_t tile_raw = grp * 4 + wave;
+    const int64_t n_groups = (n_tiles + NW - 1) / NW;
+    lds_prologue(A, L, F0, 44);
+    int cur = 0;
+    for (int64_t grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {        // all waves iterate together
+        const int64_t tile_raw = grp * NW + wave;
         const bool tile_ok = tile_raw < n_tiles;
         const int64_t tile = tile_ok ? tile_raw : n_tiles - 1;
         const int64_t b_raw = tile * 32 + n;
         const bool valid = tile_ok && b_raw < A.S;
         const int64_t b = (b_raw < A.S) ? b_raw : A.S - 1;
         // waves past the last tile still walk the layers (barriers) but write into the block-private dummy tile
-        half_t* T = scratch + (tile_ok ? tile : n_tiles + (int64_t)blockIdx.x * 4 + wave) * TILE_HALFS;
+        half_t* T = scratch + (tile_ok ? tile : n_tiles + (int64_t)blockIdx.x * NW + wave) * TILE_HALFS;
         Fwd F;
-        forward_tile(A, b, lane, F, T, lds);
-        const f16x8* frags_l = launder(A.frags);
+        forward_tile<true>(A, b, lane, F, T, L, cur, BH, 36);
         // ---- SE(3) backward (fp32): g = dL/dwarped ----
         float g[3] = {0.f, 0.f, 0.f};
         if (valid) { g[0] = goff[b * 3]; g[1] = goff[b * 3 + 1]; g[2] = goff[b * 3 + 2]; }
@@ -543,52 +596,58 @@ __global__ __launch_bounds__(256, 2) void deform_bwd_kernel(DeformArgs A, const 
         else         { dzh[0] = (half_t)dv[1]; dzh[1] = (half_t)dv[2]; }
         const TSel tsel = make_tsel(lane);
         store_tile_T<1>(T + TILE_DZH, lane, &dzh, tsel);       // head rows (only columns < 16 are populated)
-        // ---- chain ----
+        // ---- chain (stage BH | B5 is resident in L.w[cur]) ----
         f32x16 d[4];
         f16x8 dz[DF_TW];
         // dA6 = heads^T dzh ; dZ5 = dA6 * relu'(a6)
-        stage_group(frags_l, BH, 36, lds);                   // heads^T (4) | W5^T (32) are contiguous
+        stage_issue(A.frags, B4X, 32, L.w[cur ^ 1]);
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) d[mt] = mfma(lds[mt * 64 + lane], dzh, zero16());
+        for (int mt = 0; mt < 4; ++mt) d[mt] = mfma(L.w[cur][mt * 64 + lane], dzh, zero16());
         mask_pack(d, F.m6, dz);
         store_tile_T<DF_TW>(T + TILE_DZ + 5 * DFW * 32, lane, dz, tsel);
         // dA5 = W5^T dZ5 ; dZ4
         for (int i = 0; i < 4; ++i) d[i] = zero16();
-        gemm_layer_lds<DF_TW>(lds, 4, lane, dz, d);
+        gemm_layer_lds<DF_TW>(L.w[cur], 4, lane, dz, d);
         mask_pack(d, F.m5, dz);
         store_tile_T<DF_TW>(T + TILE_DZ + 4 * DFW * 32, lane, dz, tsel);
         // keep dZ4 for the code gradient (dC = W4[:, code]^T dZ4 + W0[:, code]^T dZ0), formed at the end
         f16x8 dz4[DF_TW];
 #pragma unroll
         for (int t = 0; t < DF_TW; ++t) dz4[t] = dz[t];
+        stage_flip(cur);
         // dA4 = W4[:, x]^T dZ4 ; dZ3
+        stage_issue(A.frags, B3, 32, L.w[cur ^ 1]);
         for (int i = 0; i < 4; ++i) d[i] = zero16();
-        stage_group(frags_l, B4X, 32, lds);
-        gemm_layer_lds<DF_TW>(lds, 0, lane, dz, d);
+        gemm_layer_lds<DF_TW>(L.w[cur], 0, lane, dz, d);
         mask_pack(d, F.m4, dz);
         store_tile_T<DF_TW>(T + TILE_DZ + 3 * DFW * 32, lane, dz, tsel);
+        stage_flip(cur);
         // L3 -> L2 -> L1
+        stage_issue(A.frags, B2, 32, L.w[cur ^ 1]);
         for (int i = 0; i < 4; ++i) d[i] = zero16();
-        stage_group(frags_l, B3, 32, lds);
-        gemm_layer_lds<DF_TW>(lds, 0, lane, dz, d);
+        gemm_layer_lds<DF_TW>(L.w[cur], 0, lane, dz, d);
         mask_pack(d, F.m3, dz);
         store_tile_T<DF_TW>(T + TILE_DZ + 2 * DFW * 32, lane, dz, tsel);
+        stage_flip(cur);
+        stage_issue(A.frags, B1, 32, L.w[cur ^ 1]);
         for (int i = 0; i < 4; ++i) d[i] = zero16();
-        stage_group(frags_l, B2, 32, lds);
-        gemm_layer_lds<DF_TW>(lds, 0, lane, dz, d);
+        gemm_layer_lds<DF_TW>(L.w[cur], 0, lane, dz, d);
         mask_pack(d, F.m2, dz);
         store_tile_T<DF_TW>(T + TILE_DZ + 1 * DFW * 32, lane, dz, tsel);
+        stage_flip(cur);
+        stage_issue(A.frags, B0C, 32, L.w[cur ^ 1]);
         for (int i = 0; i < 4; ++i) d[i] = zero16();
-        stage_group(frags_l, B1, 32, lds);
-        gemm_layer_lds<DF_TW>(lds, 0, lane, dz, d);
+        gemm_layer_lds<DF_TW>(L.w[cur], 0, lane, dz, d);
         mask_pack(d, F.m1, dz);
         store_tile_T<DF_TW>(T + TILE_DZ + 0 * DFW * 32, lane, dz, tsel);
+        stage_flip(cur);
         f32x16 dcode[4];
         for (int i = 0; i < 4; ++i) dcode[i] = zero16();
-        stage_group(frags_l, B0C, 32, lds);
-        gemm_layer_lds<DF_TW>(lds, 0, lane, dz, dcode);
-        stage_group(frags_l, B4C, 32, lds);
-        gemm_layer_lds<DF_TW>(lds, 0, lane, dz4, dcode);
+        stage_issue(A.frags, B4C, 32, L.w[cur ^ 1]);
+        gemm_layer_lds<DF_TW>(L.w[cur], 0, lane, dz, dcode);
+        stage_flip(cur);
+        stage_issue(A.frags, F0, 44, L.w[cur ^ 1]);           // first stage of the next tile
+        gemm_layer_lds<DF_TW>(L.w[cur], 0, lane, dz4, dcode);
         {
             // code-gradient tile: accumulators -> chained fragments (code index kchain(t, kb, j)) -> transposed tile
             f16x8 dcf[DF_TW];
@@ -606,6 +665,7 @@ __global__ __launch_bounds__(256, 2) void deform_bwd_kernel(DeformArgs A, const 
                         gcode_samples[b * DF_CODE + 32 * mt + acc_row(rr, kb)] = dcode[mt][rr];
             }
         }
+        stage_flip(cur);
     }
 }
 
@@ -750,7 +810,7 @@ extern "C" {
 int nsx_deform_param_count(void) { return P_TOTAL; }
 int64_t nsx_deform_pack_bytes(void) { return (int64_t)N_FRAGS * 64 * 16 + (int64_t)N_BIAS * 4; }
 // + one private dummy tile per possible wave of the launch (tail waves of the lock-stepped blocks write there)
-int64_t nsx_deform_scratch_bytes(int64_t S) { return (((S + 31) / 32) + (int64_t)num_cus() * 2 * 4) * TILE_HALFS * 2; }
+int64_t nsx_deform_scratch_bytes(int64_t S) { return (((S + 31) / 32) + (int64_t)num_cus() * NW) * TILE_HALFS * 2; }
 
 int nsx_deform_pack(const float* params, void* packed, void* stream) {
     NSX_REQUIRE(params && packed, "nsx_deform_pack: NULL argument");
@@ -771,9 +831,9 @@ int nsx_deform_fwd(const void* packed, const float* positions, int64_t S, const 
     const float* bias = reinterpret_cast<const float*>(reinterpret_cast<const uint8_t*>(packed) + (size_t)N_FRAGS * 64 * 16);
     fill_args(A, positions, S, aabb_host, code, code_stride, code_slot, window7_host, packed, bias);
     const int64_t n_tiles = (S + 31) / 32;
-    int64_t blocks = (n_tiles + 3) / 4;
-    if (blocks > num_cus() * 2) blocks = num_cus() * 2;
-    hipLaunchKernelGGL(deform_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, A, offsets, n_tiles);
+    int64_t blocks = (n_tiles + NW - 1) / NW;
+    if (blocks > num_cus()) blocks = num_cus();
+    hipLaunchKernelGGL(deform_fwd_kernel, dim3((unsigned)blocks), dim3(NW * 64), 0, (hipStream_t)stream, A, offsets, n_tiles);
     NSX_LAUNCH_CHECK("nsx_deform_fwd launch");
     return NSX_OK;
 }
@@ -792,11 +852,11 @@ int nsx_deform_bwd(const void* packed, const float* positions, int64_t S, const 
     const float* bias = reinterpret_cast<const float*>(reinterpret_cast<const uint8_t*>(packed) + (size_t)N_FRAGS * 64 * 16);
     fill_args(A, positions, S, aabb_host, code, code_stride, code_slot, window7_host, packed, bias);
     const int64_t n_tiles = (S + 31) / 32;
-    int64_t blocks = (n_tiles + 3) / 4;
-    if (blocks > num_cus() * 2) blocks = num_cus() * 2;
+    int64_t blocks = (n_tiles + NW - 1) / NW;
+    if (blocks > num_cus()) blocks = num_cus();
     hipStream_t st = (hipStream_t)stream;
     half_t* sc = reinterpret_cast<half_t*>(scratch);
-    hipLaunchKernelGGL(deform_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, st, A, grad_offsets, sc, n_tiles,
+    hipLaunchKernelGGL(deform_bwd_kernel, dim3((unsigned)blocks), dim3(NW * 64), 0, st, A, grad_offsets, sc, n_tiles,
                        grad_code_samples);
     NSX_LAUNCH_CHECK("nsx_deform_bwd chain launch");
     // weight / bias / code-table gradients
