@@ -375,9 +375,11 @@ __device__ __forceinline__ void store_tile_T(half_t* __restrict__ dst, int lane,
         u32x4 o0, o1;
 #pragma unroll
         for (int r = 0; r < 4; ++r) { o0[r] = cvt_pk(d[2 * r], d[2 * r + 1]); o1[r] = cvt_pk(d[8 + 2 * r], d[9 + 2 * r]); }
-        u32x4* out = reinterpret_cast<u32x4*>(dst + ((size_t)p * 64 + lane) * 16);
+        // tile p = [2 K-steps][64 lanes][8 halfs]: each store instruction writes one contiguous KB, and the weight-gradient
+        // kernel can copy the tile into LDS linearly and read it back conflict-free as MFMA operand fragments
+        u32x4* out = reinterpret_cast<u32x4*>(dst + (size_t)p * 1024 + (size_t)lane * 8);
         out[0] = o0;
-        out[1] = o1;
+        out[64] = o1;
     }
 }
 
@@ -670,121 +672,200 @@ __global__ __launch_bounds__(NW * 64, 1) void deform_bwd_kernel(DeformArgs A, co
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// sample-contracted GEMMs: C[M][N] += sum_tiles A_tile[M][32] * B_tile[N][32]^T  (fp16 tiles, fp32 atomics)
+// sample-contracted GEMMs: C[M][N] += sum over samples X[M][s] * Y[N][s]  (fp16 tiles, fp32 accumulation)
 // ---------------------------------------------------------------------------------------------------------
-struct WgradJob {
-    int64_t a_off;       // offset (halfs) of the A activation tiles inside a sample-tile scratch block; -1 => one-hot of slot
-    int64_t b_off;       // offset of the B activation tiles; -2 => B = ones (row sums of A: bias gradients)
-    int a_tile0, b_tile0;// first 32-column tile of A / B used by the job
-    int m_rows;          // valid rows of A
-    int n_rows;          // valid rows of B
-    int a_natural, b_natural;   // neuron index map of the tile columns: natural (32p + c) or chained
-    int ldc;             // leading dimension of C
-    int64_t c_off;       // offset (floats) into the gradient buffer
-    int64_t bias_off;    // unused (bias gradients are their own jobs with b_off = -2)
-    int heads;           // 1: rows 0..2 -> Wr, 3..5 -> Wv ; 2: the head biases br / bv
+// Every weight / bias / code-table gradient of the step in ONE launch that reads each scratch byte (almost) once.
+// grid = (block type, sample chunk).  A block type owns a group of gradient GEMMs whose operands it copies, one
+// 32-sample tile per pipeline stage, from the scratch into a 4-deep LDS ring with the LDS-DMA path (3 stages in
+// flight: the kernel is HBM-bound, ~30 KB per stage and CU); its 8 waves then each own ONE 32-row tile of X and all
+// (<= 6) column tiles of Y, so a full 128 x 128..192 gradient lives in the block's accumulators for the whole chunk
+// and is added to the gradient buffer with fp32 atomics at the end.
+//   type 0: dW0 = dZ0 a0^T, db0 | dW4[:, :173] = dZ4 a0^T, db4       stage = dZ0 dZ4 a0            (28 KB)
+//   type 1: dW1 = dZ1 a1^T, db1 | dW2 = dZ2 a2^T, db2                stage = dZ1 a1 dZ2 a2         (32 KB)
+//   type 2: dW3 = dZ3 a3^T, db3 | dW4[:, 173:] = dZ4 a4^T            stage = dZ3 a3 dZ4 a4         (32 KB)
+//   type 3: dW5 = dZ5 a5^T, db5 | heads: dZh a6^T, dbr, dbv          stage = dZ5 a5 dZh a6         (26 KB)
+//   type 4: code table: onehot(slot) dC^T                            stage = dC + the 32 slots     ( 9 KB)
+// Bias gradients are the row sums of dZ: the same X fragments against an all-ones operand.
+constexpr int WG_K = 4;                         // LDS-DMA copies per wave and stage
+constexpr int WG_PIECES = NW * WG_K;            // 32 one-KB pieces per stage
+constexpr int WG_NS = 4;                        // ring depth
+constexpr int WG_TYPES = 5;
+constexpr int TILE_KB = (int)(TILE_HALFS * 2 / 1024);                    // 118
+constexpr int KB_A0 = 0, KB_A = (int)(TILE_A * 2 / 1024), KB_DZ = (int)(TILE_DZ * 2 / 1024);
+constexpr int KB_DZH = (int)(TILE_DZH * 2 / 1024), KB_DC = (int)(TILE_DC * 2 / 1024);
+static_assert(TILE_HALFS * 2 % 1024 == 0 && TILE_A * 2 % 1024 == 0 && TILE_DZ * 2 % 1024 == 0 &&
+              TILE_DZH * 2 % 1024 == 0 && TILE_DC * 2 % 1024 == 0, "scratch regions must be KB-aligned");
+
+// piece q of a stage of block type `type`: source KB offset inside the scratch tile (-1: the slot piece); pieces past
+// the end repeat earlier ones (same bytes to the same place) so that every wave issues exactly WG_K copies per stage
+__device__ __forceinline__ int wg_piece_src(int type, int q, int& dst_kb, bool with_slots) {
+    auto a_kb = [](int l) { return l == 0 ? KB_A0 : KB_A + 8 * (l - 1); };   // input of layer l (l = 6: input of the heads)
+    auto dz_kb = [](int l) { return KB_DZ + 8 * l; };
+    int total, src = 0;
+    switch (type) {
+        case 0: total = 28; break;
+        case 1: case 2: total = 32; break;
+        case 3: total = 26; break;
+        default: total = with_slots ? 9 : 8; break;
+    }
+    q = q % total;
+    dst_kb = q;
+    switch (type) {
+        case 0: src = q < 8 ? dz_kb(0) + q : (q < 16 ? dz_kb(4) + q - 8 : a_kb(0) + q - 16); break;
+        case 1: src = q < 8 ? dz_kb(1) + q : (q < 16 ? a_kb(1) + q - 8 : (q < 24 ? dz_kb(2) + q - 16 : a_kb(2) + q - 24)); break;
+        case 2: src = q < 8 ? dz_kb(3) + q : (q < 16 ? a_kb(3) + q - 8 : (q < 24 ? dz_kb(4) + q - 16 : a_kb(4) + q - 24)); break;
+        case 3: src = q < 8 ? dz_kb(5) + q : (q < 16 ? a_kb(5) + q - 8 : (q < 18 ? KB_DZH + q - 16 : a_kb(6) + q - 18)); break;
+        default: src = q < 8 ? KB_DC + q : -1; break;
+    }
+    return src;
+}
+
+struct WgRole {            // what one wave of a block accumulates
+    int x_kb;              // LDS KB offset of its X tile (2 KB); -1: one-hot of the code slot
+    int y_kb, n_y;         // first Y tile, number of Y tiles (0: the wave only helps copying)
+    int bias;              // also accumulate X * ones
+    int x_tile;            // index of the X tile inside its activation (row block)
+    int job;               // output mapping, see wg_store
 };
 
-constexpr int MAX_WGRAD_JOBS = 20;
-struct WgradJobs {
-    WgradJob job[MAX_WGRAD_JOBS];
-    float* out[MAX_WGRAD_JOBS];
-    int n;
-};
+__device__ __forceinline__ WgRole wg_role(int type, int wave, int n_code_rows) {
+    WgRole r{0, 0, 0, 0, wave & 3, -1};
+    const int hi = wave >> 2;
+    switch (type) {
+        case 0: r.x_kb = 8 * hi + 2 * (wave & 3); r.y_kb = 16; r.n_y = 6; r.bias = 1; r.job = hi ? 4 : 0; break;
+        case 1: r.x_kb = 16 * hi + 2 * (wave & 3); r.y_kb = 8 + 16 * hi; r.n_y = 4; r.bias = 1; r.job = hi ? 2 : 1; break;
+        case 2: r.x_kb = 16 * hi + 2 * (wave & 3); r.y_kb = 8 + 16 * hi; r.n_y = 4; r.bias = hi ? 0 : 1; r.job = hi ? 5 : 3; break;
+        case 3:
+            if (!hi) { r.x_kb = 2 * wave; r.y_kb = 8; r.n_y = 4; r.bias = 1; r.job = 6; }
+            else if (wave == 4) { r.x_kb = 16; r.y_kb = 18; r.n_y = 4; r.bias = 1; r.x_tile = 0; r.job = 7; }
+            break;
+        default:
+            if (!hi && 32 * wave < n_code_rows) { r.x_kb = -1; r.y_kb = 0; r.n_y = 4; r.job = 8; }
+            break;
+    }
+    return r;
+}
 
-// grid = (max n-tiles, chunks, jobs): every weight / bias / code-table gradient GEMM of the step in ONE launch.
-// C[row][col] += sum over sample tiles and samples of A[row][sample] * B[col][sample]; operands are the transposed
-// tiles written by the chain kernel (16-B coalesced fragment loads, sample order acc_row(8 tt + j, kb) on both sides).
-__global__ __launch_bounds__(256, 2) void deform_wgrad_kernel(const half_t* __restrict__ scratch, int64_t n_tiles,
-                                                           WgradJobs jobs, const int32_t* __restrict__ slot,
-                                                           int64_t S, int chunks) {
-    const WgradJob job = jobs.job[blockIdx.z];
-    float* __restrict__ C = jobs.out[blockIdx.z];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+// accumulator element r of lane (i, kb) of output tile (x tile mt, y tile nt): X-side row acc_row(r, kb), Y-side column i
+__device__ __forceinline__ void wg_store(const f32x16& acc, int job, int mt, int nt, bool is_bias, int lane,
+                                         float* __restrict__ gp, float* __restrict__ gcode, int n_code_rows) {
     const int i = lane & 31, kb = lane >> 5;
-    const int nt = blockIdx.x;
-    if (nt * 32 >= job.n_rows) return;
-    const int chunk = blockIdx.y * 4 + wave;
-    const int total_chunks = chunks * 4;
-    const int64_t per = (n_tiles + total_chunks - 1) / total_chunks;
-    const int64_t t_begin = (int64_t)chunk * per, t_end = (t_begin + per < n_tiles) ? t_begin + per : n_tiles;
-    const int m_tiles = (job.m_rows + 31) / 32;
-    f32x16 acc[4];
-    for (int q = 0; q < 4; ++q) acc[q] = zero16();
-    const bool b_ones = job.b_off < 0;        // bias job: B = ones -> every column of D is the row sum of A
-    // per-lane operand pointers (advance by one scratch block per sample tile)
-    const half_t* bp = scratch + t_begin * TILE_HALFS + (b_ones ? 0 : job.b_off) + ((size_t)(job.b_tile0 + nt) * 64 + lane) * 16;
-    const half_t* ap = (job.a_off >= 0)
-                           ? scratch + t_begin * TILE_HALFS + job.a_off + ((size_t)job.a_tile0 * 64 + lane) * 16
-                           : nullptr;
-    auto load_tile = [&](const half_t* a, const half_t* b, f16x8 af[4][2], f16x8 bf[2], int64_t tile) {
-        if (b_ones) {
+    if (is_bias && i != 0) return;                          // every column of X * ones holds the row sum
+    const int64_t w_off[7] = {P_W0, P_W1, P_W2, P_W3, P_W4, P_W4 + DF_IN, P_W5};
+    const int64_t b_off[7] = {P_B0, P_B1, P_B2, P_B3, P_B4, -1, P_B5};
+    const int ldc[7] = {DF_IN, DFW, DFW, DFW, DF_W4, DF_W4, DFW};
+    const bool y_natural = (job == 0 || job == 4);          // a0 tiles are in natural column order
+    const int n_cols = y_natural ? DF_IN : DFW;
+    const int col = y_natural ? 32 * nt + i : tile_neuron_chain(nt, i);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { bf[0][j] = (half_t)1.f; bf[1][j] = (half_t)1.f; }
-        } else {
-            bf[0] = reinterpret_cast<const f16x8*>(b)[0];
-            bf[1] = reinterpret_cast<const f16x8*>(b)[1];
+    for (int r = 0; r < 16; ++r) {
+        const float v = acc[r];
+        if (v == 0.f) continue;
+        const int ar = acc_row(r, kb);
+        if (job <= 6) {
+            const int row = tile_neuron_chain(mt, ar);
+            if (is_bias) atomicAdd(&gp[b_off[job] + row], v);
+            else if (col < n_cols) atomicAdd(&gp[w_off[job] + (int64_t)row * ldc[job] + col], v);
+        } else if (job == 7) {                               // heads: rows 0..2 -> Wr / br, 3..5 -> Wv / bv
+            if (ar >= 16) continue;                          // only the first 16 columns of the dZh tile are populated
+            const int row = tile_neuron_chain(0, ar);
+            if (row >= 6) continue;
+            if (is_bias) atomicAdd(&gp[row < 3 ? P_BR + row : P_BV + row - 3], v);
+            else atomicAdd(&gp[(row < 3 ? (int64_t)P_WR + (int64_t)row * DFW : (int64_t)P_WV + (int64_t)(row - 3) * DFW) + col], v);
+        } else {                                             // code table rows (natural), code columns (chained)
+            const int row = 32 * mt + ar;
+            if (row < n_code_rows) atomicAdd(&gcode[(int64_t)row * DF_CODE + col], v);
         }
+    }
+}
+
+__global__ __launch_bounds__(NW * 64, 1) void deform_wgrad_kernel(const half_t* __restrict__ scratch, int64_t n_tiles,
+                                                                 const int32_t* __restrict__ slot, int64_t S,
+                                                                 float* __restrict__ grad_params,
+                                                                 float* __restrict__ grad_code, int n_code_rows) {
+    __shared__ __attribute__((aligned(16))) char ring[WG_NS * WG_PIECES * 1024];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int i = lane & 31, kb = lane >> 5;
+    const int type = blockIdx.x;
+    const int64_t per = (n_tiles + gridDim.y - 1) / gridDim.y;
+    const int64_t t_begin = (int64_t)blockIdx.y * per, t_end = (t_begin + per < n_tiles) ? t_begin + per : n_tiles;
+    if (t_begin >= t_end) return;                            // whole block
+    const bool with_slots = (type == 4);
+    const WgRole role = wg_role(type, wave, n_code_rows);
+    // this wave's WG_K copies per stage
+    int src_kb[WG_K], dst_kb[WG_K];
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-            if (mt < m_tiles) {
-                if (a) {
-                    af[mt][0] = reinterpret_cast<const f16x8*>(a + (size_t)mt * 1024)[0];
-                    af[mt][1] = reinterpret_cast<const f16x8*>(a + (size_t)mt * 1024)[1];
-                } else {
+    for (int k = 0; k < WG_K; ++k) src_kb[k] = wg_piece_src(type, wave + NW * k, dst_kb[k], with_slots);
+    const char* sbytes = reinterpret_cast<const char*>(scratch);
+    auto issue = [&](int64_t tile, int ring_slot) {
+        const int64_t tc = tile < n_tiles ? tile : n_tiles - 1;      // past the end: harmless re-copy (uniform vmcnt)
+        char* stage = ring + (size_t)ring_slot * (WG_PIECES * 1024);
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const int64_t s0 = tile * 32 + acc_row(j, kb), s1 = tile * 32 + acc_row(8 + j, kb);
-                        af[mt][0][j] = (s0 < S && slot[s0] == 32 * mt + i) ? (half_t)1.f : (half_t)0.f;
-                        af[mt][1][j] = (s1 < S && slot[s1] == 32 * mt + i) ? (half_t)1.f : (half_t)0.f;
-                    }
-                }
+        for (int k = 0; k < WG_K; ++k) {
+            if (src_kb[k] >= 0) {
+                const char* g = sbytes + (size_t)tc * (TILE_KB * 1024) + (size_t)src_kb[k] * 1024 + (size_t)lane * 16;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                                 (__attribute__((address_space(3))) void*)(stage + dst_kb[k] * 1024), 16, 0, 0);
+            } else {                                                  // the tile's 32 code slots (+ 32 of the next tile)
+                int64_t si = tc * 32 + lane;
+                if (si >= S) si = S - 1;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(slot + si),
+                                                 (__attribute__((address_space(3))) void*)(stage + dst_kb[k] * 1024), 4, 0, 0);
             }
         }
     };
-    f16x8 af[4][2], bf[2], afn[4][2], bfn[2];
-    if (t_begin < t_end) load_tile(ap, bp, af, bf, t_begin);
-    for (int64_t tile = t_begin; tile < t_end; ++tile) {
-        // software prefetch of the next sample tile's operands
-        const bool more = tile + 1 < t_end;
-        if (more) load_tile(ap ? ap + TILE_HALFS : nullptr, bp + TILE_HALFS, afn, bfn, tile + 1);
+    f32x16 acc[7];
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-            if (mt < m_tiles) {
-                acc[mt] = mfma(af[mt][0], bf[0], acc[mt]);
-                acc[mt] = mfma(af[mt][1], bf[1], acc[mt]);
-            }
-        }
-        if (more) {
+    for (int q = 0; q < 7; ++q) acc[q] = zero16();
+    f16x8 ones;
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) { af[mt][0] = afn[mt][0]; af[mt][1] = afn[mt][1]; }
-            bf[0] = bfn[0]; bf[1] = bfn[1];
-        }
-        if (ap) ap += TILE_HALFS;
-        bp += TILE_HALFS;
-    }
-    // accumulator element r of lane (col i, half kb): A-side row index acc_row(r, kb) of tile mt, B-side column i of tile nt
-    const int col = job.b_natural ? 32 * nt + i : tile_neuron_chain(nt, i);
+    for (int j = 0; j < 8; ++j) ones[j] = (half_t)1.f;
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-        if (mt >= m_tiles) continue;
+    for (int p = 0; p < WG_NS - 1; ++p) issue(t_begin + p, p);
+    int cur = 0;
+    for (int64_t t = t_begin; t < t_end; ++t) {
+        // stage t landed: at most the copies of the WG_NS - 2 younger stages may still be in flight
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WG_K * (WG_NS - 2)) : "memory");
+        __builtin_amdgcn_s_barrier();
+        issue(t + WG_NS - 1, (cur + WG_NS - 1) % WG_NS);     // into the slot everybody finished reading before the barrier
+        if (role.n_y > 0) {
+            const char* stage = ring + (size_t)cur * (WG_PIECES * 1024);
+            f16x8 x0, x1;
+            if (role.x_kb >= 0) {
+                x0 = *reinterpret_cast<const f16x8*>(stage + role.x_kb * 1024 + lane * 16);
+                x1 = *reinterpret_cast<const f16x8*>(stage + role.x_kb * 1024 + 1024 + lane * 16);
+            } else {
+                const int32_t* sl = reinterpret_cast<const int32_t*>(stage + 8 * 1024);
+                const int row = 32 * wave + i;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int ar = acc_row(r, kb);
-            const int row = job.a_natural ? 32 * mt + ar : tile_neuron_chain(mt, ar);
-            const float v = acc[mt][r];
-            if (row < job.m_rows && col < job.n_rows && v != 0.f && (job.a_natural || ar < 16 || !job.heads)) {
-                if (job.heads == 2) {                    // head biases (B = ones, column 0)
-                    atomicAdd(&C[row < 3 ? P_BR + row : P_BV + row - 3], v);
-                } else if (job.heads) {
-                    const int64_t off = row < 3 ? (int64_t)P_WR + (int64_t)row * DFW : (int64_t)P_WV + (int64_t)(row - 3) * DFW;
-                    atomicAdd(&C[off + col], v);
-                } else {
-                    atomicAdd(&C[job.c_off + (int64_t)row * job.ldc + col], v);
+                for (int j = 0; j < 8; ++j) {
+                    const int s0 = acc_row(j, kb), s1 = acc_row(8 + j, kb);
+                    x0[j] = (t * 32 + s0 < S && sl[s0] == row) ? (half_t)1.f : (half_t)0.f;
+                    x1[j] = (t * 32 + s1 < S && sl[s1] == row) ? (half_t)1.f : (half_t)0.f;
                 }
             }
+#pragma unroll
+            for (int q = 0; q < 6; ++q) {
+                if (q < role.n_y) {
+                    const f16x8 y0 = *reinterpret_cast<const f16x8*>(stage + (role.y_kb + 2 * q) * 1024 + lane * 16);
+                    const f16x8 y1 = *reinterpret_cast<const f16x8*>(stage + (role.y_kb + 2 * q + 1) * 1024 + lane * 16);
+                    acc[q] = mfma(x0, y0, acc[q]);
+                    acc[q] = mfma(x1, y1, acc[q]);
+                }
+            }
+            if (role.bias) {
+                acc[6] = mfma(x0, ones, acc[6]);
+                acc[6] = mfma(x1, ones, acc[6]);
+            }
         }
+        cur = (cur + 1) % WG_NS;
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // no LDS-DMA write may outlive the block
+    if (role.n_y == 0) return;
+#pragma unroll
+    for (int q = 0; q < 6; ++q)
+        if (q < role.n_y) wg_store(acc[q], role.job, role.x_tile, q, false, lane, grad_params, grad_code, n_code_rows);
+    if (role.bias) wg_store(acc[6], role.job, role.x_tile, 0, true, lane, grad_params, grad_code, n_code_rows);
 }
 
 static void fill_args(DeformArgs& A, const float* pos, int64_t S, const float* aabb, const float* code,
@@ -860,39 +941,13 @@ int nsx_deform_bwd(const void* packed, const float* positions, int64_t S, const 
                        grad_code_samples);
     NSX_LAUNCH_CHECK("nsx_deform_bwd chain launch");
     // weight / bias / code-table gradients
-    int chunks = (int)((n_tiles + 63) / 64);       // >= 16 sample tiles per wave
+    const int n_types = grad_code_table ? WG_TYPES : WG_TYPES - 1;
+    int chunks = num_cus() / n_types;                 // one block per CU
+    const int64_t max_chunks = (n_tiles + 3) / 4;     // >= 4 sample tiles per block
+    if (chunks > max_chunks) chunks = (int)max_chunks;
     if (chunks < 1) chunks = 1;
-    if (chunks > 64) chunks = 64;
-    WgradJobs jobs;
-    jobs.n = 0;
-    int max_ntiles = 1;
-    auto run = [&](WgradJob job, float* Cbuf) {
-        const int n_ntiles = (job.n_rows + 31) / 32;
-        if (n_ntiles > max_ntiles) max_ntiles = n_ntiles;
-        jobs.job[jobs.n] = job;
-        jobs.out[jobs.n] = Cbuf;
-        jobs.n++;
-    };
-    const int64_t A_of[7] = {TILE_A0, TILE_A + 0 * DFW * 32, TILE_A + 1 * DFW * 32, TILE_A + 2 * DFW * 32,
-                             TILE_A + 3 * DFW * 32, TILE_A + 4 * DFW * 32, TILE_A + 5 * DFW * 32};
-    auto dz = [&](int l) { return TILE_DZ + (int64_t)l * DFW * 32; };
-    // {a_off, b_off, a_tile0, b_tile0, m_rows, n_rows, a_natural, b_natural, ldc, c_off, bias_off, heads}
-    run(WgradJob{dz(0), A_of[0], 0, 0, DFW, DF_IN, 0, 1, DF_IN, P_W0, -1, 0}, grad_params);
-    run(WgradJob{dz(1), A_of[1], 0, 0, DFW, DFW, 0, 0, DFW, P_W1, -1, 0}, grad_params);
-    run(WgradJob{dz(2), A_of[2], 0, 0, DFW, DFW, 0, 0, DFW, P_W2, -1, 0}, grad_params);
-    run(WgradJob{dz(3), A_of[3], 0, 0, DFW, DFW, 0, 0, DFW, P_W3, -1, 0}, grad_params);
-    run(WgradJob{dz(4), A_of[0], 0, 0, DFW, DF_IN, 0, 1, DF_W4, P_W4, -1, 0}, grad_params);
-    run(WgradJob{dz(4), A_of[4], 0, 0, DFW, DFW, 0, 0, DF_W4, P_W4 + DF_IN, -1, 0}, grad_params);
-    run(WgradJob{dz(5), A_of[5], 0, 0, DFW, DFW, 0, 0, DFW, P_W5, -1, 0}, grad_params);
-    run(WgradJob{TILE_DZH, A_of[6], 0, 0, 6, DFW, 0, 0, DFW, 0, -1, 1}, grad_params);        // both heads
-    // bias gradients: row sums of dZ (B = ones, one column)
-    const int64_t pb[6] = {P_B0, P_B1, P_B2, P_B3, P_B4, P_B5};
-    for (int l = 0; l < 6; ++l) run(WgradJob{dz(l), -2, 0, 0, DFW, 1, 0, 1, 1, pb[l], -1, 0}, grad_params);
-    run(WgradJob{TILE_DZH, -2, 0, 0, 6, 1, 0, 1, 1, 0, -1, 2}, grad_params);
-    if (grad_code_table)
-        run(WgradJob{-1, TILE_DC, 0, 0, n_code_rows, DF_CODE, 1, 0, DF_CODE, 0, -1, 0}, grad_code_table);
-    hipLaunchKernelGGL(deform_wgrad_kernel, dim3(max_ntiles, chunks, jobs.n), dim3(256), 0, st, sc, n_tiles, jobs,
-                       code_slot, S, chunks);
+    hipLaunchKernelGGL(deform_wgrad_kernel, dim3(n_types, chunks), dim3(NW * 64), 0, st, sc, n_tiles, code_slot, S,
+                       grad_params, grad_code_table, grad_code_table ? n_code_rows : 0);
     NSX_LAUNCH_CHECK("nsx_deform_bwd wgrad launch");
     return NSX_OK;
 }

@@ -66,7 +66,7 @@ def test_deform_nan_fallback_and_identity_init(cuda):
     assert torch.all(off[3] == 0) and torch.isfinite(off).all()
 
 
-@pytest.mark.parametrize("S,T", [(700, 9), (64, 1)])
+@pytest.mark.parametrize("S,T", [(700, 9), (64, 1), (3000, 70)])
 def test_deform_backward(S, T, cuda):
     df = _field(2)
     g = torch.Generator().manual_seed(S)
