@@ -110,11 +110,16 @@ int nsx_hash_ensemble_bwd(const float* x, int64_t B, const nsx_half* tables, int
  * atomics at H=32); nsx_hash_grad_expand then produces the native-layout fp32 table gradient.
  *   code_table [n_slots][code_stride] fp32, code_slot [B] int32 in [0, n_slots), n_slots <= NSX_MAX_SLOTS
  *   G          [n_slots][total_entries][2] fp32, ACCUMULATED into with atomics (caller zeroes); may be NULL
- *   dcode      [B][H] fp32 per-sample gradient w.r.t. the windowed code row; may be NULL.  dx [B][3]; may be NULL */
+ *   dcode      [B][H] fp32 per-sample gradient w.r.t. the windowed code row; may be NULL.  dx [B][3]; may be NULL
+ *   nonfinite  device float, set to 1 when a value added to G was inf/NaN (never cleared here); may be NULL.
+ *              This is GradScaler's inf check on the table gradient (nersemble_trainer.py:186) without a pass over G:
+ *              G holds a non-finite value iff one was added to it (sums of finite fp32 terms of this size cannot
+ *              overflow: |dout| <= 65504 * w, w <= 1, <= 2^23 terms). */
 int nsx_hash_ensemble_bwd_factored(const float* x, int64_t B, const nsx_half* tables, int H,
                                    const nsx_grid_geom* g, const float* code_table, int64_t code_stride,
                                    int n_slots, const int32_t* code_slot, const float* window,
-                                   const float* dout, float* G, float* dcode, float* dx, void* stream);
+                                   const float* dout, float* G, float* dcode, float* dx, float* nonfinite,
+                                   void* stream);
 /* dtables (native fp32) = (accumulate ? dtables : 0) + expand(G, code_table*window). */
 int nsx_hash_grad_expand(const float* G, int n_slots, const float* code_table, int64_t code_stride,
                          const float* window, int H, const nsx_grid_geom* g, float* dtables, int accumulate,

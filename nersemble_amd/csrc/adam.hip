@@ -69,15 +69,33 @@ __global__ __launch_bounds__(256) void adam_hash_factored_kernel(
     const int hq = part % (TPE / 2);
     for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const uint64_t e0 = tile * EPB;
-        __syncthreads();
-        for (int i = threadIdx.x; i < n_slots * EPB * 2; i += blockDim.x) {
-            const int sl = i / (EPB * 2), j = i % (EPB * 2);
-            const uint64_t ge = e0 * 2ull + j;
-            gs[i] = (ge < total * 2ull) ? G[(uint64_t)sl * total * 2ull + ge] : 0.f;
+        const uint64_t e = e0 + le;
+        const bool live = e < total;
+        const uint64_t at = (e * 2ull + f) * HP + hq * HV;
+        // the three parameter streams are requested first: their HBM latency overlaps the staging of G below
+        float pp[HV], mm[HV], vv[HV];
+        if (live) {
+#pragma unroll
+            for (int k = 0; k < HV; ++k) { pp[k] = master[at + k]; mm[k] = m[at + k]; vv[k] = v[at + k]; }
         }
         __syncthreads();
-        const uint64_t e = e0 + le;
-        if (e >= total) continue;
+        {
+            // one slot's run of the tile is EPB * 2 contiguous floats (a multiple of 4 for every HP): float4 pieces
+            static_assert((EPB * 2) % 4 == 0, "tile run must be float4-divisible");
+            constexpr int Q = EPB * 2 / 4;
+            for (int i = threadIdx.x; i < n_slots * Q; i += blockDim.x) {
+                const int sl = i / Q, j = (i % Q) * 4;
+                const uint64_t ge = e0 * 2ull + j;
+                const float* src = G + (uint64_t)sl * total * 2ull + ge;
+                float4 g4;
+                if (ge + 3 < total * 2ull) g4 = *reinterpret_cast<const float4*>(src);
+                else g4 = make_float4(ge < total * 2ull ? src[0] : 0.f, ge + 1 < total * 2ull ? src[1] : 0.f,
+                                      ge + 2 < total * 2ull ? src[2] : 0.f, 0.f);
+                *reinterpret_cast<float4*>(gs + sl * (EPB * 2) + j) = g4;
+            }
+        }
+        __syncthreads();
+        if (!live) continue;
         float g[HV];
 #pragma unroll
         for (int k = 0; k < HV; ++k) g[k] = 0.f;
@@ -88,10 +106,6 @@ __global__ __launch_bounds__(256) void adam_hash_factored_kernel(
                 for (int k = 0; k < HV; ++k) g[k] = __fmaf_rn(gv, cs[sl * HP + hq * HV + k], g[k]);
             }
         }
-        const uint64_t at = (e * 2ull + f) * HP + hq * HV;
-        float pp[HV], mm[HV], vv[HV];
-#pragma unroll
-        for (int k = 0; k < HV; ++k) { pp[k] = master[at + k]; mm[k] = m[at + k]; vv[k] = v[at + k]; }
 #pragma unroll
         for (int k = 0; k < HV; ++k) {
             if (hq * HV + k < Hreal) adam_update(g[k] * is, pp[k], mm[k], vv[k], hy);

@@ -244,8 +244,9 @@ __global__ __launch_bounds__(WAVES * kWave) void ens_bwd_kernel(
     const float* __restrict__ code, int64_t code_stride, const int32_t* __restrict__ code_index,
     const float* __restrict__ window, int Hreal, const float* __restrict__ dout,
     float* __restrict__ dtab, float* __restrict__ dcode, float* __restrict__ dx, int64_t n_tiles,
-    int n_slots) {
+    int n_slots, float* __restrict__ nonfinite) {
     using C = EnsCfg<H>;
+    bool bad = false;                 // a non-finite value was added to the factored gradient
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x / kWave;
     const int L = g.n_levels;
@@ -361,6 +362,7 @@ __global__ __launch_bounds__(WAVES * kWave) void ens_bwd_kernel(
                         if (head && sum != 0.f) {
                             float* gp = dtab + (((size_t)crow * g_total + (size_t)(off + ik)) * 2 + f);
                             atomicAdd(gp, sum);
+                            bad |= !isfinite(sum);
                         }
                     }
                 }
@@ -402,6 +404,7 @@ __global__ __launch_bounds__(WAVES * kWave) void ens_bwd_kernel(
             }
         }
     }
+    if (nonfinite && __any(bad) && lane == 0) nonfinite[0] = 1.0f;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -520,7 +523,7 @@ template <int H>
 static int launch_bwd(const float* x, int64_t B, const nsx_half* tables, int Hreal, const nsx_grid_geom* g,
                       const float* code, int64_t code_stride, const int32_t* code_index, const float* window,
                       const float* dout, float* dtables, float* dcode, float* dx, hipStream_t st,
-                      int n_slots = 0) {
+                      int n_slots = 0, float* nonfinite = nullptr) {
     using C = EnsCfg<H>;
     constexpr int WAVES = 4;
     const int64_t n_tiles = (B + C::SPW - 1) / C::SPW;
@@ -530,11 +533,11 @@ static int launch_bwd(const float* x, int64_t B, const nsx_half* tables, int Hre
     if (n_slots > 0)
         hipLaunchKernelGGL((ens_bwd_kernel<H, WAVES, true>), dim3((unsigned)blocks), dim3(WAVES * kWave), 0, st, x, B,
                            reinterpret_cast<const uint8_t*>(tables), *g, code, code_stride, code_index, window,
-                           Hreal, dout, dtables, dcode, dx, n_tiles, n_slots);
+                           Hreal, dout, dtables, dcode, dx, n_tiles, n_slots, nonfinite);
     else
         hipLaunchKernelGGL((ens_bwd_kernel<H, WAVES, false>), dim3((unsigned)blocks), dim3(WAVES * kWave), 0, st, x,
                            B, reinterpret_cast<const uint8_t*>(tables), *g, code, code_stride, code_index, window,
-                           Hreal, dout, dtables, dcode, dx, n_tiles, 0);
+                           Hreal, dout, dtables, dcode, dx, n_tiles, 0, nullptr);
     NSX_LAUNCH_CHECK("nsx_hash_ensemble_bwd launch");
     return NSX_OK;
 }
@@ -642,7 +645,8 @@ int nsx_hash_ensemble_bwd(const float* x, int64_t B, const nsx_half* tables, int
 int nsx_hash_ensemble_bwd_factored(const float* x, int64_t B, const nsx_half* tables, int H,
                                    const nsx_grid_geom* g, const float* code_table, int64_t code_stride,
                                    int n_slots, const int32_t* code_slot, const float* window,
-                                   const float* dout, float* G, float* dcode, float* dx, void* stream) {
+                                   const float* dout, float* G, float* dcode, float* dx, float* nonfinite,
+                                   void* stream) {
     NSX_REQUIRE(B >= 0, "nsx_hash_ensemble_bwd_factored: negative batch");
     if (B == 0) return NSX_OK;
     NSX_REQUIRE(x && tables && code_table && code_slot && dout, "nsx_hash_ensemble_bwd_factored: NULL argument");
@@ -653,12 +657,12 @@ int nsx_hash_ensemble_bwd_factored(const float* x, int64_t B, const nsx_half* ta
     if (int rc = check_geom(g, Hp, "nsx_hash_ensemble_bwd_factored")) return rc;
     hipStream_t st = (hipStream_t)stream;
     switch (Hp) {
-        case 1: return launch_bwd<1>(x, B, tables, H, g, code_table, code_stride, code_slot, window, dout, G, dcode, dx, st, n_slots);
-        case 2: return launch_bwd<2>(x, B, tables, H, g, code_table, code_stride, code_slot, window, dout, G, dcode, dx, st, n_slots);
-        case 4: return launch_bwd<4>(x, B, tables, H, g, code_table, code_stride, code_slot, window, dout, G, dcode, dx, st, n_slots);
-        case 8: return launch_bwd<8>(x, B, tables, H, g, code_table, code_stride, code_slot, window, dout, G, dcode, dx, st, n_slots);
-        case 16: return launch_bwd<16>(x, B, tables, H, g, code_table, code_stride, code_slot, window, dout, G, dcode, dx, st, n_slots);
-        case 32: return launch_bwd<32>(x, B, tables, H, g, code_table, code_stride, code_slot, window, dout, G, dcode, dx, st, n_slots);
+        case 1: return launch_bwd<1>(x, B, tables, H, g, code_table, code_stride, code_slot, window, dout, G, dcode, dx, st, n_slots, nonfinite);
+        case 2: return launch_bwd<2>(x, B, tables, H, g, code_table, code_stride, code_slot, window, dout, G, dcode, dx, st, n_slots, nonfinite);
+        case 4: return launch_bwd<4>(x, B, tables, H, g, code_table, code_stride, code_slot, window, dout, G, dcode, dx, st, n_slots, nonfinite);
+        case 8: return launch_bwd<8>(x, B, tables, H, g, code_table, code_stride, code_slot, window, dout, G, dcode, dx, st, n_slots, nonfinite);
+        case 16: return launch_bwd<16>(x, B, tables, H, g, code_table, code_stride, code_slot, window, dout, G, dcode, dx, st, n_slots, nonfinite);
+        case 32: return launch_bwd<32>(x, B, tables, H, g, code_table, code_stride, code_slot, window, dout, G, dcode, dx, st, n_slots, nonfinite);
     }
     set_error("nsx_hash_ensemble_bwd_factored: unsupported H=%d", H);
     return NSX_ERR_UNSUPPORTED;

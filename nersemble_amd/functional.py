@@ -72,12 +72,17 @@ class FactoredGradSink:
     def __init__(self):
         self.entries = []            # dicts: G, code, window, n_rows, key
         self._cache = {}
+        self.nonfinite = None        # device float: set by the backward kernel when it adds an inf/NaN to a G
 
     def buffer_for(self, code: torch.Tensor, window: Optional[torch.Tensor], n_rows: int, total_entries: int):
         key = (code.data_ptr(), n_rows, None if window is None else window.data_ptr())
         for e in self.entries:
             if e["key"] == key:
                 return e["G"]
+        if self.nonfinite is None or self.nonfinite.device != code.device:
+            self.nonfinite = torch.zeros((1,), dtype=torch.float32, device=code.device)
+        elif not self.entries:
+            self.nonfinite.zero_()             # first backward of a step
         G = self._cache.get(n_rows)
         if G is None or G.device != code.device:
             G = torch.empty((n_rows, total_entries, 2), dtype=torch.float32, device=code.device)
@@ -130,7 +135,8 @@ class _HashEnsembleFn(torch.autograd.Function):
                 G = torch.zeros((n_rows, geom.total_entries, 2), dtype=torch.float32, device=x.device)
             check(lib().nsx_hash_ensemble_bwd_factored(ptr(x), B, ptr(tables_f16), H, C.byref(geom), ptr(code),
                                                        code.stride(0), n_rows, ptr(code_index), ptr(window),
-                                                       ptr(dout), ptr(G), ptr(dcode_s), ptr(dx), stream()),
+                                                       ptr(dout), ptr(G), ptr(dcode_s), ptr(dx),
+                                                       ptr(ctx.sink.nonfinite) if use_sink else None, stream()),
                   "nsx_hash_ensemble_bwd_factored")
             if need_tab and not use_sink:
                 dtab = torch.empty(ctx.master_shape, dtype=torch.float32, device=x.device)

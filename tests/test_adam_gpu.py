@@ -85,3 +85,34 @@ def test_adam_skips_on_inf_and_dense_path(cuda):
     assert sc.get_scale() == s0 * 0.5
     sc.update([torch.zeros(1, device=cuda)])
     assert sc.get_scale() == s0 * 0.5
+
+
+@pytest.mark.parametrize("bad", [float("inf"), float("nan")])
+def test_factored_backward_flags_nonfinite_gradient(bad, cuda):
+    """GradScaler's inf check on the table gradient: the backward kernel flags a non-finite value it adds to G, and the
+    optimizer skips the step exactly like a check over the whole buffer would."""
+    from nersemble_amd.engine.hash_adam import HashTableAdam
+    from nersemble_amd._lib import check, lib, ptr, stream
+    B, T, H = 3000, 5, 8
+    g = torch.Generator(device=cuda).manual_seed(2)
+    x = torch.rand((B, 3), device=cuda, generator=g)
+    emb = torch.randn((T, H), device=cuda, generator=g)
+    slot = torch.randint(0, T, (B,), device=cuda, generator=g, dtype=torch.int32)
+    dout = torch.randn((B, 12), device=cuda, generator=g).half()
+    he = _he(H, cuda)
+    opt = HashTableAdam(he, lr=5e-3, eps=1e-15, factored=True)
+    for poisoned in (False, True, False):          # the flag must clear again on the next clean step
+        d = dout.clone()
+        if poisoned:
+            d[1234, 7] = bad
+        before = he.tables.detach().clone()
+        opt.zero_grad()
+        he(x, emb, window_hash_encodings=4.0, code_index=slot).backward(d)
+        G = he.grad_sink.entries[0]["G"]
+        brute = torch.zeros(1, device=cuda)
+        check(lib().nsx_check_finite(ptr(G), G.numel(), ptr(brute), stream()), "nsx_check_finite")
+        found = torch.zeros(1, device=cuda)
+        opt.check_finite(found)
+        assert found.item() == brute.item() == (1.0 if poisoned else 0.0)
+        opt.step(found_inf=found, inv_scale=None)
+        assert torch.equal(he.tables.detach(), before) == poisoned
