@@ -4,7 +4,8 @@ acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for path in sys.argv[1:]:
     with open(path) as f:
         for r in csv.DictReader(f):
-            k = r["Kernel_Name"].split("(")[0][-60:]
+            full = r["Kernel_Name"].split("(")[0]
+            k = full if len(full) <= 70 else full[:70]
             acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, d in acc.items():
     if "nsx" not in k and "deform" not in k and "ens_" not in k:
