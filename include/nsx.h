@@ -339,6 +339,19 @@ int nsx_adam_dense(const float* grad, int64_t n, float* master, float* exp_avg, 
                    nsx_half* params_f16 /* may be NULL */, float lr, float beta1, float beta2, float eps,
                    int64_t step, const float* inv_scale, const float* found_inf, void* stream);
 
+/* ---- data-parallel optimizer step for the hash tables (no reference counterpart: train_nersemble.py:272-274 is
+ * single-GPU).  Each rank expands its factored gradient to a dense fp16 gradient scaled by 1/world
+ * (tcnn's own table gradients are fp16), RCCL reduce-scatters it, the rank that owns a 1/world shard of the master
+ * weights / Adam moments checks the shard for inf/NaN, runs Adam on it and writes the shard of the fp16 working
+ * tables, which RCCL all-gathers.  (engine/sharded_adam.py) */
+int nsx_hash_grad_expand_f16(const float* G, int n_slots, const float* code_table, int64_t code_stride,
+                             const float* window, int H, const nsx_grid_geom* g, nsx_half* dtables_f16, float scale,
+                             int accumulate, void* stream);
+int nsx_check_finite_f16(const nsx_half* x, int64_t n, float* found_inf /* set to 1 if any inf/NaN */, void* stream);
+int nsx_adam_dense_f16grad(const nsx_half* grad, int64_t n, float* master, float* exp_avg, float* exp_avg_sq,
+                           nsx_half* params_f16 /* may be NULL */, float lr, float beta1, float beta2, float eps,
+                           int64_t step, const float* inv_scale, const float* found_inf, void* stream);
+
 /* Debug/parity helper: the 8 level-local entry indices per (sample, level), uint32 [B][L][8].
  * Integer outputs are held bit-exact to the oracle. */
 int nsx_hash_indices(const float* x, int64_t B, const nsx_grid_geom* g, uint32_t* idx, void* stream);

@@ -99,6 +99,11 @@ SIGNATURES = {
     "nsx_distloss": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_float, c_void_p,
                              c_void_p, c_void_p]),
     "nsx_check_finite": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
+    "nsx_check_finite_f16": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
+    "nsx_adam_dense_f16grad": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_float,
+                                       c_float, c_int64, c_void_p, c_void_p, c_void_p]),
+    "nsx_hash_grad_expand_f16": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_void_p, c_int, _GEOM_P, c_void_p, c_float,
+                                         c_int, c_void_p]),
     "nsx_adam_hash_factored": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_void_p, c_int, _GEOM_P, c_void_p, c_void_p,
                                        c_void_p, c_void_p, c_float, c_float, c_float, c_float, c_int64, c_void_p,
                                        c_void_p, c_void_p]),

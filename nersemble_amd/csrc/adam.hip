@@ -130,6 +130,129 @@ __global__ __launch_bounds__(256) void adam_dense_kernel(const float* __restrict
     }
 }
 
+// ---- data-parallel pieces (engine/sharded_adam.py): fp16 dense gradient for the reduce-scatter, inf check and Adam
+// on the rank's shard ----
+__global__ __launch_bounds__(256) void check_finite_f16_kernel(const half_t* __restrict__ x, int64_t n,
+                                                               float* __restrict__ found_inf) {
+    bool bad = false;
+    // fp16 inf / NaN <=> exponent field all ones
+    const int64_t n8 = n / 8;
+    const uint4* x8 = reinterpret_cast<const uint4*>(x);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+        const uint4 v = x8[i];
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) bad |= ((w[k] & 0x7C00u) == 0x7C00u) || ((w[k] & 0x7C000000u) == 0x7C000000u);
+    }
+    const uint16_t* xs = reinterpret_cast<const uint16_t*>(x);
+    for (int64_t i = n8 * 8 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        bad |= (xs[i] & 0x7C00u) == 0x7C00u;
+    if (__any(bad) && (threadIdx.x & 63) == 0) found_inf[0] = 1.0f;
+}
+
+__global__ __launch_bounds__(256) void adam_dense_f16grad_kernel(const half_t* __restrict__ grad, int64_t n,
+                                                                 float* __restrict__ master, float* __restrict__ m,
+                                                                 float* __restrict__ v, half_t* __restrict__ f16,
+                                                                 AdamHyper hy, const float* __restrict__ inv_scale,
+                                                                 const float* __restrict__ found_inf) {
+    if (found_inf && found_inf[0] != 0.f) return;
+    const float is = inv_scale ? inv_scale[0] : 1.0f;
+    const int64_t n4 = n / 4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const float4 p4 = reinterpret_cast<const float4*>(master)[i];
+        const float4 m4 = reinterpret_cast<const float4*>(m)[i];
+        const float4 v4 = reinterpret_cast<const float4*>(v)[i];
+        const uint2 g2 = reinterpret_cast<const uint2*>(grad)[i];
+        float p[4] = {p4.x, p4.y, p4.z, p4.w}, mm[4] = {m4.x, m4.y, m4.z, m4.w}, vv[4] = {v4.x, v4.y, v4.z, v4.w};
+        const half2_t ga = __builtin_bit_cast(half2_t, g2.x), gb = __builtin_bit_cast(half2_t, g2.y);
+        const float g[4] = {(float)ga.x, (float)ga.y, (float)gb.x, (float)gb.y};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) adam_update(g[k] * is, p[k], mm[k], vv[k], hy);
+        reinterpret_cast<float4*>(master)[i] = make_float4(p[0], p[1], p[2], p[3]);
+        reinterpret_cast<float4*>(m)[i] = make_float4(mm[0], mm[1], mm[2], mm[3]);
+        reinterpret_cast<float4*>(v)[i] = make_float4(vv[0], vv[1], vv[2], vv[3]);
+        if (f16) {
+            half2_t oa, ob;
+            oa.x = (half_t)p[0]; oa.y = (half_t)p[1]; ob.x = (half_t)p[2]; ob.y = (half_t)p[3];
+            reinterpret_cast<uint2*>(f16)[i] = make_uint2(__builtin_bit_cast(uint32_t, oa), __builtin_bit_cast(uint32_t, ob));
+        }
+    }
+    for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float p = master[i], mm = m[i], vv = v[i];
+        adam_update((float)grad[i] * is, p, mm, vv, hy);
+        master[i] = p; m[i] = mm; v[i] = vv;
+        if (f16) f16[i] = (half_t)p;
+    }
+}
+
+// out[e][f][h] (+)= scale * sum_slot G[slot][e][f] * code'[slot][h], written as fp16 (same tile staging as the fused
+// Adam kernel: G crosses HBM once)
+template <int HP>
+__global__ __launch_bounds__(256) void expand_f16_kernel(
+    const float* __restrict__ G, int n_slots, const float* __restrict__ code, int64_t code_stride,
+    const float* __restrict__ window, int Hreal, uint64_t total, half_t* __restrict__ out, float scale, int accumulate) {
+    constexpr int HV = HP >= 4 ? 4 : HP;
+    constexpr int TPE = 2 * HP / HV;
+    constexpr int EPB = 256 / TPE;
+    extern __shared__ float smem[];
+    float* cs = smem;
+    float* gs = smem + n_slots * HP;
+    for (int i = threadIdx.x; i < n_slots * HP; i += blockDim.x) {
+        const int sl = i / HP, h = i % HP;
+        float c = 0.f;
+        if (h < Hreal) c = code[sl * code_stride + h] * (window ? window[h] : 1.0f);
+        cs[i] = (float)(half_t)c;
+    }
+    const uint64_t n_tiles = (total + EPB - 1) / EPB;
+    const int le = threadIdx.x / TPE, part = threadIdx.x % TPE, f = part / (TPE / 2), hq = part % (TPE / 2);
+    for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const uint64_t e0 = tile * EPB;
+        __syncthreads();
+        constexpr int Q = EPB * 2 / 4;
+        for (int i = threadIdx.x; i < n_slots * Q; i += blockDim.x) {
+            const int sl = i / Q, j = (i % Q) * 4;
+            const uint64_t ge = e0 * 2ull + j;
+            const float* src = G + (uint64_t)sl * total * 2ull + ge;
+            float4 g4;
+            if (ge + 3 < total * 2ull) g4 = *reinterpret_cast<const float4*>(src);
+            else g4 = make_float4(ge < total * 2ull ? src[0] : 0.f, ge + 1 < total * 2ull ? src[1] : 0.f,
+                                  ge + 2 < total * 2ull ? src[2] : 0.f, 0.f);
+            *reinterpret_cast<float4*>(gs + sl * (EPB * 2) + j) = g4;
+        }
+        __syncthreads();
+        const uint64_t e = e0 + le;
+        if (e >= total) continue;
+        float g[HV];
+#pragma unroll
+        for (int k = 0; k < HV; ++k) g[k] = 0.f;
+        for (int sl = 0; sl < n_slots; ++sl) {
+            const float gv = gs[sl * (EPB * 2) + le * 2 + f];
+            if (gv != 0.f) {
+#pragma unroll
+                for (int k = 0; k < HV; ++k) g[k] = __fmaf_rn(gv, cs[sl * HP + hq * HV + k], g[k]);
+            }
+        }
+        const uint64_t at = (e * 2ull + f) * HP + hq * HV;
+#pragma unroll
+        for (int k = 0; k < HV; ++k) {
+            const float prev = accumulate ? (float)out[at + k] : 0.f;
+            out[at + k] = (half_t)(prev + scale * g[k]);
+        }
+    }
+}
+
+template <int HP>
+static int launch_expand_f16(const float* G, int n_slots, const float* code, int64_t code_stride, const float* window,
+                             int H, uint64_t total, nsx_half* out, float scale, int accumulate, hipStream_t st) {
+    constexpr int HV = HP >= 4 ? 4 : HP;
+    constexpr int EPB = 256 / (2 * HP / HV);
+    const size_t smem = ((size_t)n_slots * HP + (size_t)n_slots * EPB * 2) * sizeof(float);
+    hipLaunchKernelGGL((expand_f16_kernel<HP>), dim3(num_cus() * 8), dim3(256), smem, st, G, n_slots, code, code_stride,
+                       window, H, total, reinterpret_cast<half_t*>(out), scale, accumulate);
+    NSX_LAUNCH_CHECK("nsx_hash_grad_expand_f16 launch");
+    return NSX_OK;
+}
+
 static AdamHyper make_hyper(float lr, float beta1, float beta2, float eps, int64_t step) {
     AdamHyper h;
     h.lr = lr; h.beta1 = beta1; h.beta2 = beta2; h.eps = eps;
@@ -200,6 +323,55 @@ int nsx_adam_dense(const float* grad, int64_t n, float* master, float* exp_avg, 
                        exp_avg, exp_avg_sq, reinterpret_cast<half_t*>(params_f16), hy, inv_scale, found_inf);
     NSX_LAUNCH_CHECK("nsx_adam_dense launch");
     return NSX_OK;
+}
+
+int nsx_check_finite_f16(const nsx_half* x, int64_t n, float* found_inf, void* stream) {
+    NSX_REQUIRE(n >= 0, "nsx_check_finite_f16: negative size");
+    if (n == 0) return NSX_OK;
+    NSX_REQUIRE(x && found_inf, "nsx_check_finite_f16: NULL argument");
+    NSX_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0, "nsx_check_finite_f16: x must be 16-byte aligned");
+    hipLaunchKernelGGL(check_finite_f16_kernel, dim3(num_cus() * 8), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const half_t*>(x), n, found_inf);
+    NSX_LAUNCH_CHECK("nsx_check_finite_f16 launch");
+    return NSX_OK;
+}
+
+int nsx_adam_dense_f16grad(const nsx_half* grad, int64_t n, float* master, float* exp_avg, float* exp_avg_sq,
+                           nsx_half* params_f16, float lr, float beta1, float beta2, float eps, int64_t step,
+                           const float* inv_scale, const float* found_inf, void* stream) {
+    NSX_REQUIRE(n >= 0, "nsx_adam_dense_f16grad: negative size");
+    if (n == 0) return NSX_OK;
+    NSX_REQUIRE(grad && master && exp_avg && exp_avg_sq, "nsx_adam_dense_f16grad: NULL argument");
+    NSX_REQUIRE(step >= 1, "nsx_adam_dense_f16grad: step must be >= 1");
+    NSX_REQUIRE(((reinterpret_cast<uintptr_t>(grad) | reinterpret_cast<uintptr_t>(params_f16)) & 7) == 0 &&
+                ((reinterpret_cast<uintptr_t>(master) | reinterpret_cast<uintptr_t>(exp_avg) |
+                  reinterpret_cast<uintptr_t>(exp_avg_sq)) & 15) == 0,
+                "nsx_adam_dense_f16grad: buffers must be 16-byte (fp32) / 8-byte (fp16) aligned");
+    const AdamHyper hy = make_hyper(lr, beta1, beta2, eps, step);
+    hipLaunchKernelGGL(adam_dense_f16grad_kernel, dim3(num_cus() * 8), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const half_t*>(grad), n, master, exp_avg, exp_avg_sq,
+                       reinterpret_cast<half_t*>(params_f16), hy, inv_scale, found_inf);
+    NSX_LAUNCH_CHECK("nsx_adam_dense_f16grad launch");
+    return NSX_OK;
+}
+
+int nsx_hash_grad_expand_f16(const float* G, int n_slots, const float* code_table, int64_t code_stride,
+                             const float* window, int H, const nsx_grid_geom* g, nsx_half* dtables_f16, float scale,
+                             int accumulate, void* stream) {
+    NSX_REQUIRE(G && code_table && dtables_f16 && g, "nsx_hash_grad_expand_f16: NULL argument");
+    NSX_REQUIRE(H >= 1 && H <= 32, "nsx_hash_grad_expand_f16: H=%d not in [1,32]", H);
+    NSX_REQUIRE(n_slots >= 1 && n_slots <= NSX_MAX_SLOTS, "nsx_hash_grad_expand_f16: n_slots=%d not in [1,%d]", n_slots,
+                NSX_MAX_SLOTS);
+    const uint64_t total = g->offset[g->n_levels];
+    hipStream_t st = (hipStream_t)stream;
+#define NSX_EXP_CASE(HP) case HP: return launch_expand_f16<HP>(G, n_slots, code_table, code_stride, window, H, total, \
+        dtables_f16, scale, accumulate, st);
+    switch (nsx_padded_grids(H)) {
+        NSX_EXP_CASE(1) NSX_EXP_CASE(2) NSX_EXP_CASE(4) NSX_EXP_CASE(8) NSX_EXP_CASE(16) NSX_EXP_CASE(32)
+    }
+#undef NSX_EXP_CASE
+    set_error("nsx_hash_grad_expand_f16: unsupported H=%d", H);
+    return NSX_ERR_UNSUPPORTED;
 }
 
 }  // extern "C"

@@ -80,6 +80,12 @@ class HashTableAdam(torch.optim.Optimizer):
         p._version_bump = None
         he.mark_half_synced()
 
+    def rollback_step(self) -> None:
+        """The last ``step()`` was skipped on the device (inf/NaN): it must not count (torch.optim.Adam semantics)."""
+        st = self.state.get(self.he.tables)
+        if st:
+            st["step"] = max(0, st["step"] - 1)
+
     def zero_grad(self, set_to_none: bool = True):
         super().zero_grad(set_to_none=set_to_none)
         if self.he.grad_sink is not None:

@@ -14,6 +14,7 @@ import torch.distributed as dist
 from ..models.nersemble_instant_ngp import NeRSembleNGPModel
 from .hash_adam import HashTableAdam, NativeGradScaler
 from .parallel import all_reduce_gradients
+from .sharded_adam import ShardedTableAdam
 from ..rays import RayBundle
 
 
@@ -31,11 +32,13 @@ class OptimizerConfig:
 
 class NeRSembleTrainer:
     def __init__(self, model: NeRSembleNGPModel, opt_cfg: Optional[OptimizerConfig] = None,
-                 mixed_precision: bool = True, world_size: int = 1, factored_table_grad: Optional[bool] = None):
+                 mixed_precision: bool = True, world_size: int = 1, factored_table_grad: Optional[bool] = None,
+                 rank: Optional[int] = None, sharded_table_adam: Optional[bool] = None):
         self.model = model
         self.cfg = opt_cfg or OptimizerConfig()
         self.mixed_precision = mixed_precision
         self.world_size = world_size
+        self.rank = (dist.get_rank() if dist.is_initialized() else 0) if rank is None else rank
         device = next(model.parameters()).device
         groups = model.get_param_groups()
         lrs = {"fields": self.cfg.lr_main, "deformation_field": self.cfg.lr_deformation_field,
@@ -50,11 +53,20 @@ class NeRSembleTrainer:
             self.optimizers[name] = torch.optim.Adam(small, lr=lrs[name], eps=self.cfg.eps, weight_decay=0, fused=fused)
             self.group_of[name] = name
             if len(small) != len(params):
-                # the 403 M-parameter hash tables: native fused step; the dense gradient is only materialised for DP
-                self.optimizers[name + "/tables"] = HashTableAdam(model.field.hash_ensemble, lr=lrs[name],
-                                                                  eps=self.cfg.eps,
-                                                                  factored=(world_size == 1) if factored_table_grad is None
-                                                                  else factored_table_grad)
+                # the 403 M-parameter hash tables: native fused step on the factored gradient.  Data-parallel runs
+                # shard the optimizer state and exchange fp16 (reduce-scatter / all-gather, engine/sharded_adam.py);
+                # factored_table_grad=False keeps the dense fp32 gradient + all-reduce path.
+                sharded = (world_size > 1 and factored_table_grad is not False) if sharded_table_adam is None \
+                    else sharded_table_adam
+                if sharded:
+                    self.optimizers[name + "/tables"] = ShardedTableAdam(model.field.hash_ensemble, lr=lrs[name],
+                                                                         eps=self.cfg.eps, world_size=world_size,
+                                                                         rank=self.rank)
+                else:
+                    self.optimizers[name + "/tables"] = HashTableAdam(model.field.hash_ensemble, lr=lrs[name],
+                                                                      eps=self.cfg.eps,
+                                                                      factored=(world_size == 1) if factored_table_grad is None
+                                                                      else factored_table_grad)
                 self.group_of[name + "/tables"] = name
         for key, opt in self.optimizers.items():
             self.schedulers[key] = torch.optim.lr_scheduler.StepLR(opt, step_size=self.cfg.step_size,
@@ -62,12 +74,15 @@ class NeRSembleTrainer:
         self.grad_scaler = NativeGradScaler(device, enabled=mixed_precision)
         self.callbacks = model.get_training_callbacks()
         self._pending, self._found_host, self._found_event = None, None, None
+        self._found_groups = []
 
     # ---- data-parallel gradient averaging ------------------------------------------------------------
     def _all_reduce_grads(self) -> None:
         if self.world_size <= 1:
             return
-        params = [p for opt in self.optimizers.values() for pg in opt.param_groups for p in pg["params"]]
+        # (the sharded table optimizer runs its own reduce-scatter; its parameter has no dense gradient)
+        params = [p for opt in self.optimizers.values() if not isinstance(opt, ShardedTableAdam)
+                  for pg in opt.param_groups for p in pg["params"]]
         all_reduce_gradients(params, self.world_size)
 
     def _optimizer_step_all(self):
@@ -77,17 +92,22 @@ class NeRSembleTrainer:
         scaler = self.grad_scaler
         inv_scale = scaler.inv_scale()
         dev = inv_scale.device
-        found = {g: torch.zeros((1,), dtype=torch.float32, device=dev) for g in set(self.group_of.values())}
+        groups = sorted(set(self.group_of.values()))
+        found_all = torch.zeros((len(groups),), dtype=torch.float32, device=dev)
+        found = {g: found_all[i:i + 1] for i, g in enumerate(groups)}
         for key, opt in self.optimizers.items():
             f = found[self.group_of[key]]
-            if isinstance(opt, HashTableAdam):
+            if isinstance(opt, (HashTableAdam, ShardedTableAdam)):
                 opt.check_finite(f)
             else:
                 grads = [p.grad for pg in opt.param_groups for p in pg["params"] if p.grad is not None]
                 scaler.unscale_and_check(grads, f, inv_scale)
+        if self.world_size > 1:
+            # a step is skipped on every rank or on none: the shard-level checks of the table gradient differ per rank
+            dist.all_reduce(found_all, op=dist.ReduceOp.MAX)
         for key, opt in self.optimizers.items():
             f = found[self.group_of[key]]
-            if isinstance(opt, HashTableAdam):
+            if isinstance(opt, (HashTableAdam, ShardedTableAdam)):
                 opt.step(found_inf=f, inv_scale=inv_scale)
             elif any(p.grad is not None for pg in opt.param_groups for p in pg["params"]):
                 if opt.defaults.get("fused"):
@@ -96,7 +116,9 @@ class NeRSembleTrainer:
                     del opt.found_inf, opt.grad_scale
                 elif f.item() == 0:
                     opt.step()
-        return scaler.update(list(found.values()))
+        scaler.update(list(found.values()))
+        self._found_groups = groups
+        return found_all
 
     def train_iteration(self, step: int, ray_bundle: RayBundle, batch: Dict[str, torch.Tensor]
                         ) -> Tuple[torch.Tensor, Dict[str, torch.Tensor], Dict[str, torch.Tensor]]:
@@ -115,23 +137,30 @@ class NeRSembleTrainer:
                 loss = functools.reduce(torch.add, loss_dict.values())
         self.grad_scaler.scale(loss).backward()
         self._all_reduce_grads()
-        found_any = self._optimizer_step_all()
+        found_all = self._optimizer_step_all()
         # the reference skips the LR step when the scale dropped, i.e. when an inf/NaN was found (:199-203).  Reading
-        # the flag here would drain the GPU queue at the end of every step; it is copied to pinned memory instead
+        # the flags here would drain the GPU queue at the end of every step; they are copied to pinned memory instead
         # and consulted right before the learning rates are next used (flush_scheduler_step).
-        self._defer_scheduler_step(found_any)
+        self._defer_scheduler_step(found_all)
         return loss, loss_dict, metrics_dict
 
-    def _defer_scheduler_step(self, found_any: torch.Tensor) -> None:
-        if not found_any.is_cuda:
-            self._pending = ("host", found_any)
+    def _defer_scheduler_step(self, found_all: torch.Tensor) -> None:
+        """found_all: one inf/NaN flag per parameter group (device)."""
+        if not found_all.is_cuda:
+            self._pending = ("host", found_all.clone())
             return
-        if self._found_host is None:
-            self._found_host = torch.empty((1,), dtype=torch.float32).pin_memory()
+        if self._found_host is None or self._found_host.numel() != found_all.numel():
+            self._found_host = torch.empty((found_all.numel(),), dtype=torch.float32).pin_memory()
             self._found_event = torch.cuda.Event()
-        self._found_host.copy_(found_any.reshape(1), non_blocking=True)
+        self._found_host.copy_(found_all, non_blocking=True)
         self._found_event.record()
         self._pending = ("pinned", None)
+
+    def consolidate(self) -> None:
+        """Data-parallel runs: rebuild the full fp32 master tables on every rank (before ``model.state_dict()``)."""
+        for opt in self.optimizers.values():
+            if isinstance(opt, ShardedTableAdam):
+                opt.gather_master()
 
     def flush_scheduler_step(self) -> None:
         """Applies the LR-scheduler step of the last finished iteration (skipped if that iteration found inf/NaN).
@@ -142,9 +171,15 @@ class NeRSembleTrainer:
         self._pending = None
         if kind == "pinned":
             self._found_event.synchronize()
-            bad = float(self._found_host[0]) != 0.0
+            flags = self._found_host.tolist()
         else:
-            bad = float(val.sum()) != 0.0
-        if not bad:
+            flags = val.tolist()
+        # the native table optimizers count their step on the host before the device decides to skip it: take the
+        # count back for the groups that skipped (torch's fused Adam does the same with _foreach_sub_(steps, found_inf))
+        for key, opt in self.optimizers.items():
+            if isinstance(opt, (HashTableAdam, ShardedTableAdam)) and \
+                    flags[self._found_groups.index(self.group_of[key])] != 0.0:
+                opt.rollback_step()
+        if not any(f != 0.0 for f in flags):
             for sch in self.schedulers.values():
                 sch.step()

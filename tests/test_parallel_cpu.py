@@ -53,3 +53,107 @@ def test_gradient_allreduce_and_ray_sharding_world2(tmp_path):
     assert r0["ok"] and r1["ok"]
     assert torch.equal(r0["c2w"], r1["c2w"])                         # same camera rig
     assert not torch.equal(r0["dirs"], r1["dirs"])                   # different rays per rank
+
+
+# ---- sharded table optimizer: reduce-scatter -> Adam on the shard -> all-gather ------------------------------------
+class _TorchTableOps:
+    """torch restatement of the three libnsx kernels of engine/sharded_adam.py, so that its collective plumbing runs
+    on CPU tensors under gloo (test infrastructure only)."""
+
+    @staticmethod
+    def dense(he, entry):
+        H = he.n_hash_encodings
+        code = entry["code"][:entry["n_rows"], :H].float()
+        if entry["window"] is not None:
+            code = code * entry["window"][:H]
+        code = code.half().float()
+        out = torch.zeros(he.tables.shape, dtype=torch.float32)
+        out[:, :, :H] = torch.einsum("sef,sh->efh", entry["G"].float(), code)
+        return out
+
+    def expand_f16(self, he, entry, out, scale, accumulate):
+        d = (self.dense(he, entry) * scale).reshape(-1)
+        n = d.numel()
+        out[:n] = (out[:n].float() + d).half() if accumulate else d.half()
+
+    @staticmethod
+    def check_finite_f16(x, found_inf):
+        if not torch.isfinite(x.float()).all():
+            found_inf.fill_(1.0)
+
+    @staticmethod
+    def adam_f16grad(grad, n, master, exp_avg, exp_avg_sq, f16_out, lr, b1, b2, eps, step, inv_scale, found_inf):
+        if found_inf is not None and float(found_inf) != 0:
+            return
+        g = grad[:n].float() * (float(inv_scale) if inv_scale is not None else 1.0)
+        m, v = exp_avg[:n], exp_avg_sq[:n]
+        m.lerp_(g, 1 - b1)
+        v.mul_(b2).addcmul_(g, g, value=1 - b2)
+        bc1, bc2 = 1 - b1 ** step, 1 - b2 ** step
+        master.sub_((lr / bc1) * m / (v.sqrt() / bc2 ** 0.5 + eps))
+        f16_out[:n] = master.half()
+
+
+def _fake_entry(he, seed, n_rows=3, poison=False):
+    g = torch.Generator().manual_seed(seed)
+    G = torch.randn((n_rows, he.geom.total_entries, 2), generator=g) * 1e-2
+    G[torch.rand(G.shape, generator=g) < 0.5] = 0.0
+    if poison:
+        G[1, 7, 0] = float("inf")
+    code = torch.randn((n_rows, he.n_hash_encodings), generator=g)
+    return {"G": G, "code": code, "window": None, "n_rows": n_rows, "key": seed}
+
+
+def _sharded_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from nersemble_amd.engine.sharded_adam import ShardedTableAdam
+    from nersemble_amd.field_components.hash_ensemble import HashEnsemble, HashEnsembleConfig, TCNNHashEncodingConfig
+    he = HashEnsemble(HashEnsembleConfig(3, TCNNHashEncodingConfig(n_levels=3, log2_hashmap_size=8), True, True), seed=5)
+    with torch.no_grad():
+        he.tables.mul_(1e3)
+    opt = ShardedTableAdam(he, lr=5e-3, eps=1e-15, world_size=world, rank=rank, ops=_TorchTableOps())
+    inv = torch.tensor([1.0 / 64.0])
+    log = []
+    for it in range(4):
+        poison = (it == 2 and rank == 1)                 # only ONE rank produces an inf: everybody must skip
+        he.grad_sink.entries = [_fake_entry(he, 100 * it + rank, poison=poison)]
+        he.grad_sink.nonfinite = torch.zeros(1)
+        found = torch.zeros(1)
+        opt.check_finite(found)
+        dist.all_reduce(found, op=dist.ReduceOp.MAX)
+        opt.step(found_inf=found, inv_scale=inv)
+        if float(found) != 0:
+            opt.rollback_step()                          # what the trainer does once it has read the flag
+        log.append(float(found))
+    f16 = he.tables_f16.detach().clone()
+    opt.gather_master()
+    torch.save({"log": log, "f16": f16, "master": he.tables.detach().clone(), "shard": opt.shard, "n": opt.n},
+               os.path.join(out_dir, f"s{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_table_adam_world2_matches_single_process(tmp_path):
+    port = _free_port()
+    mp.spawn(_sharded_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0 = torch.load(tmp_path / "s0.pt")
+    r1 = torch.load(tmp_path / "s1.pt")
+    assert r0["log"] == r1["log"] == [0.0, 0.0, 1.0, 0.0]              # the poisoned step is skipped on BOTH ranks
+    assert torch.equal(r0["f16"], r1["f16"]) and torch.equal(r0["master"], r1["master"])
+    assert torch.equal(r0["f16"], r0["master"].half())
+    assert r0["shard"] % 1024 == 0 and 2 * r0["shard"] >= r0["n"]
+    # single-process reference: torch Adam on the fp16-rounded average of the two ranks' dense gradients
+    from nersemble_amd.field_components.hash_ensemble import HashEnsemble, HashEnsembleConfig, TCNNHashEncodingConfig
+    he = HashEnsemble(HashEnsembleConfig(3, TCNNHashEncodingConfig(n_levels=3, log2_hashmap_size=8), True, True), seed=5)
+    with torch.no_grad():
+        he.tables.mul_(1e3)
+    opt = torch.optim.Adam([he.tables], lr=5e-3, eps=1e-15)
+    ops = _TorchTableOps()
+    for it in (0, 1, 3):
+        g = sum((ops.dense(he, _fake_entry(he, 100 * it + r)) * 0.5).half().float() for r in range(2))
+        he.tables.grad = g.half().float() / 64.0
+        opt.step()
+    d = (he.tables.detach() - r0["master"]).abs().max().item()
+    assert d <= 2e-5, d                                   # fp16 summation order inside the reduce-scatter

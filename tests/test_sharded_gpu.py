@@ -1,0 +1,146 @@
+"""GPU: the data-parallel table optimizer (engine/sharded_adam.py) -- its three kernels against torch, and the whole
+reduce-scatter / sharded Adam / all-gather step through a real (single-rank) RCCL process group against the
+single-GPU fused optimizer.  The two-rank collective plumbing itself is covered on CPU (tests/test_parallel_cpu.py)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+
+pytestmark = pytest.mark.gpu
+
+
+def _he(H, cuda, seed=0):
+    from nersemble_amd.field_components.hash_ensemble import HashEnsemble, HashEnsembleConfig, TCNNHashEncodingConfig
+    cfg = HashEnsembleConfig(H, TCNNHashEncodingConfig(n_levels=6, log2_hashmap_size=11), True, True)
+    he = HashEnsemble(cfg, seed=seed).to(cuda)
+    with torch.no_grad():
+        he.tables.mul_(3000)
+    return he
+
+
+@pytest.fixture(scope="module")
+def single_rank_group():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    yield
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("H", [1, 8, 32])
+def test_expand_f16_matches_fp32_expand(H, cuda):
+    import ctypes as C
+    from nersemble_amd._lib import check, lib, ptr, stream
+    he = _he(H, cuda)
+    g = torch.Generator(device=cuda).manual_seed(H)
+    T = 5
+    G = torch.randn((T, he.geom.total_entries, 2), device=cuda, generator=g) * 1e-2
+    G[torch.rand(G.shape, device=cuda, generator=g) < 0.5] = 0
+    code = torch.randn((T, H), device=cuda, generator=g)
+    win = torch.rand((H,), device=cuda, generator=g)
+    dense = torch.empty_like(he.tables)
+    check(lib().nsx_hash_grad_expand(ptr(G), T, ptr(code), code.stride(0), ptr(win), H, C.byref(he.geom), ptr(dense), 0,
+                                     stream()), "expand")
+    out = torch.zeros(he.tables.numel() + 64, dtype=torch.float16, device=cuda)
+    check(lib().nsx_hash_grad_expand_f16(ptr(G), T, ptr(code), code.stride(0), ptr(win), H, C.byref(he.geom), ptr(out),
+                                         0.5, 0, stream()), "expand_f16")
+    assert torch.equal(out[:dense.numel()], (dense.reshape(-1) * 0.5).half())
+    assert out[dense.numel():].abs().max().item() == 0
+    check(lib().nsx_hash_grad_expand_f16(ptr(G), T, ptr(code), code.stride(0), ptr(win), H, C.byref(he.geom), ptr(out),
+                                         0.5, 1, stream()), "expand_f16 accumulate")
+    want = ((dense.reshape(-1) * 0.5).half().float() + dense.reshape(-1) * 0.5).half()
+    assert torch.equal(out[:dense.numel()], want)
+
+
+def test_check_finite_f16_and_f16grad_adam(cuda):
+    from nersemble_amd._lib import check, lib, ptr, stream
+    n = 100_003
+    g = torch.Generator(device=cuda).manual_seed(0)
+    for pos, val in ((None, 0.0), (0, float("inf")), (n - 1, float("nan")), (54321, float("-inf"))):
+        x = torch.randn(n + 5, device=cuda, generator=g).half()[:n + 5]
+        x = x[:n] if x.data_ptr() % 16 == 0 else x
+        if pos is not None:
+            x[pos] = val
+        found = torch.zeros(1, device=cuda)
+        check(lib().nsx_check_finite_f16(ptr(x), n, ptr(found), stream()), "check")
+        assert found.item() == (0.0 if pos is None else 1.0)
+    # Adam on an fp16 gradient == torch Adam on the same gradient in fp32
+    p0 = torch.randn(n, device=cuda, generator=g)
+    ref = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([ref], lr=5e-3, eps=1e-15)
+    master, m, v = p0.clone(), torch.zeros(n, device=cuda), torch.zeros(n, device=cuda)
+    f16 = torch.empty(n, dtype=torch.float16, device=cuda)
+    inv = torch.tensor([1.0 / 128], device=cuda)
+    zero = torch.zeros(1, device=cuda)
+    for step in range(1, 4):
+        grad = (torch.randn(n, device=cuda, generator=g) * 3).half()
+        ref.grad = grad.float() / 128
+        opt.step()
+        check(lib().nsx_adam_dense_f16grad(ptr(grad), n, ptr(master), ptr(m), ptr(v), ptr(f16), 5e-3, 0.9, 0.999, 1e-15,
+                                           step, ptr(inv), ptr(zero), stream()), "adam")
+        assert (master - ref.detach()).abs().max().item() <= 2e-6
+        assert torch.equal(f16, master.half())
+    before = master.clone()
+    one = torch.ones(1, device=cuda)
+    check(lib().nsx_adam_dense_f16grad(ptr(grad), n, ptr(master), ptr(m), ptr(v), ptr(f16), 5e-3, 0.9, 0.999, 1e-15, 4,
+                                       ptr(inv), ptr(one), stream()), "adam skip")
+    assert torch.equal(master, before)
+
+
+def test_sharded_step_through_rccl_equals_fused_adam(cuda, single_rank_group):
+    from nersemble_amd.engine.hash_adam import HashTableAdam
+    from nersemble_amd.engine.sharded_adam import ShardedTableAdam
+    B, T, H = 4000, 7, 8
+    g = torch.Generator(device=cuda).manual_seed(1)
+    x = torch.rand((B, 3), device=cuda, generator=g)
+    emb = torch.randn((T, H), device=cuda, generator=g)
+    slot = torch.randint(0, T, (B,), device=cuda, generator=g, dtype=torch.int32)
+    dout = torch.randn((B, 12), device=cuda, generator=g).half()
+    scale = 1024.0
+    a, b = _he(H, cuda), _he(H, cuda)
+    opt_a = HashTableAdam(a, lr=5e-3, eps=1e-15, factored=True)
+    opt_b = ShardedTableAdam(b, lr=5e-3, eps=1e-15, world_size=1, rank=0)
+    inv = torch.tensor([1.0 / scale], device=cuda)
+    for it in range(3):
+        for he, opt in ((a, opt_a), (b, opt_b)):
+            found = torch.zeros(1, device=cuda)
+            opt.zero_grad()
+            he(x, emb, window_hash_encodings=3.0 + it, code_index=slot).backward(dout * scale)
+            opt.check_finite(found)
+            opt.step(found_inf=found, inv_scale=inv)
+            assert found.item() == 0
+        d = (a.tables - b.tables).abs()
+        # the exchanged gradient is fp16: entries whose gradient is cancellation noise move by +-lr either way
+        assert d.mean().item() <= 2e-6 and (d <= 1e-4).float().mean().item() >= 0.999, (it, d.max().item())
+        assert torch.equal(b.half_tables(), b.tables.detach().half())
+    before = b.tables.detach().clone()
+    opt_b.gather_master()
+    assert torch.equal(b.tables.detach(), before)
+
+
+def test_training_with_sharded_table_adam(cuda, single_rank_group):
+    """Trainer integration: the sharded optimizer (world of one) follows the fused single-GPU optimizer's losses."""
+    from nersemble_amd.workloads import build_workload
+
+    def run(sharded):
+        torch.manual_seed(0)
+        trainer, data, _ = build_workload("p030_h16", device="cuda:0", small=True, n_rays=512, sharded_table_adam=sharded)
+        losses = []
+        for step in range(8):
+            loss, _, _ = trainer.train_iteration(step, *data.next_train(step))
+            losses.append(loss.item())
+        trainer.flush_scheduler_step()
+        trainer.consolidate()
+        return losses
+
+    l_s, l_f = run(True), run(False)
+    assert all(np.isfinite(l_s)) and l_s[-1] < l_s[0]
+    assert np.allclose(l_s, l_f, rtol=5e-3, atol=1e-5), (l_s, l_f)
