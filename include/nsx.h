@@ -125,6 +125,14 @@ int nsx_hash_grad_expand(const float* G, int n_slots, const float* code_table, i
                          const float* window, int H, const nsx_grid_geom* g, float* dtables, int accumulate,
                          void* stream);
 
+/* Eval-time fast path (no reference counterpart -- hash_ensemble.py:155-158 blends per sample):
+ * all rays of an evaluation image share one time code, so  blended[e][f] = fp16(sum_h fp16(code_h window_h) *
+ * tables[e][f][h])  is formed once per image (reads the 0.8 GB tables once) and the image is rendered with
+ * nsx_hashgrid_fwd(F = 2) on the 25 MB result: 32x less gather traffic.  Linear in the tables, so it equals the
+ * per-sample blend up to fp16 rounding order (blend-then-interpolate instead of interpolate-then-blend). */
+int nsx_tables_preblend(const nsx_half* tables, int H, const nsx_grid_geom* g, const float* code_row /* [H] */,
+                        const float* window /* [H] or NULL */, nsx_half* blended /* [total_entries][2] */, void* stream);
+
 /* ---- plain tcnn-shaped HashGrid encoding (compatibility path) -------------------------------------------------
  * tcnn.Encoding(3, {"otype": "HashGrid", n_levels, n_features_per_level F in {2,4,8}, log2_hashmap_size,
  * base_resolution, per_level_scale, "Linear"}) as instantiated at hash_ensemble.py:42-50 and called at :102-104:

@@ -479,6 +479,45 @@ __global__ __launch_bounds__(256) void grad_expand_kernel(const float* __restric
     }
 }
 
+// Eval-time pre-blend: every ray of an evaluation image carries the same time code, so the blend over the H grids can
+// be applied to the TABLES once -- out[e][f] = fp16( sum_h fp16(code_h * window_h) * table[e][f][h] ) -- and the image
+// rendered from one plain 2-feature hash grid (hashgrid_compat.hip): 4 B instead of 128 B per corner.
+template <int HP>
+__global__ __launch_bounds__(256) void preblend_kernel(const half_t* __restrict__ tab, uint64_t total,
+                                                       const float* __restrict__ code, const float* __restrict__ window,
+                                                       int Hreal, half_t* __restrict__ out) {
+    __shared__ float cs[HP];
+    if (threadIdx.x < HP) {
+        const int h = threadIdx.x;
+        float c = 0.f;
+        if (h < Hreal) c = code[h] * (window ? window[h] : 1.0f);
+        cs[h] = (float)(half_t)c;
+    }
+    __syncthreads();
+    const uint64_t n = total * 2ull;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const half_t* row = tab + i * HP;
+        float acc = 0.f;
+        if constexpr (HP >= 8) {
+#pragma unroll
+            for (int v = 0; v < HP / 8; ++v) {
+                const uint4 q = reinterpret_cast<const uint4*>(row)[v];
+                const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const half2_t t = as_half2(w[k]);
+                    acc = __fmaf_rn((float)t.x, cs[8 * v + 2 * k], acc);
+                    acc = __fmaf_rn((float)t.y, cs[8 * v + 2 * k + 1], acc);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int h = 0; h < HP; ++h) acc = __fmaf_rn((float)row[h], cs[h], acc);
+        }
+        out[i] = (half_t)acc;
+    }
+}
+
 __global__ void hash_indices_kernel(const float* __restrict__ x, int64_t B, const nsx_grid_geom g,
                                     uint32_t* __restrict__ out) {
     const int L = g.n_levels;
@@ -594,6 +633,25 @@ int nsx_tables_to_tcnn(const float* native_master_f32, int H, const nsx_grid_geo
     hipLaunchKernelGGL(tables_to_tcnn_kernel, dim3(num_cus() * 8), dim3(256), 0, (hipStream_t)stream,
                        native_master_f32, H, Hp, F_enc, P, total, tcnn_params);
     NSX_LAUNCH_CHECK("nsx_tables_to_tcnn launch");
+    return NSX_OK;
+}
+
+int nsx_tables_preblend(const nsx_half* tables, int H, const nsx_grid_geom* g, const float* code_row,
+                        const float* window, nsx_half* blended, void* stream) {
+    NSX_REQUIRE(tables && g && code_row && blended, "nsx_tables_preblend: NULL argument");
+    NSX_REQUIRE(H >= 1 && H <= 32, "nsx_tables_preblend: H=%d not in [1,32]", H);
+    const uint64_t total = g->offset[g->n_levels];
+    hipStream_t st = (hipStream_t)stream;
+    const half_t* tab = reinterpret_cast<const half_t*>(tables);
+    half_t* out = reinterpret_cast<half_t*>(blended);
+#define NSX_PB_CASE(HP) case HP: hipLaunchKernelGGL((preblend_kernel<HP>), dim3(num_cus() * 8), dim3(256), 0, st, tab, \
+        total, code_row, window, H, out); break;
+    switch (nsx_padded_grids(H)) {
+        NSX_PB_CASE(1) NSX_PB_CASE(2) NSX_PB_CASE(4) NSX_PB_CASE(8) NSX_PB_CASE(16) NSX_PB_CASE(32)
+        default: set_error("nsx_tables_preblend: unsupported H=%d", H); return NSX_ERR_UNSUPPORTED;
+    }
+#undef NSX_PB_CASE
+    NSX_LAUNCH_CHECK("nsx_tables_preblend launch");
     return NSX_OK;
 }
 

@@ -140,6 +140,41 @@ class HashEnsemble(nn.Module):
         out[:, :, :H] = t
         return out
 
+    # ---- eval fast path: one time code for a whole image ---------------------------------------------
+    def _conditioned(self, conditioning_code: torch.Tensor, window_hash_encodings: Optional[float], device):
+        """The code transformations and the window of forward() (hash_ensemble.py:112-139)."""
+        window = None
+        if window_hash_encodings is not None:
+            if window_hash_encodings == 1 and self.disable_initial_hash_ensemble:
+                conditioning_code = torch.ones_like(conditioning_code)
+            elif self.use_soft_transition and window_hash_encodings < 2:
+                alpha = window_hash_encodings - 1
+                first = torch.zeros_like(conditioning_code)
+                first[:, 0] = (1 - alpha) * 1
+                conditioning_code = alpha * conditioning_code + first
+            # one device tensor per window value (chunks / passes of a step share it)
+            wkey = (float(window_hash_encodings), str(device))
+            window = self._window_cache.get(wkey)
+            if window is None:
+                window = posenc_window(window_hash_encodings, 0, self.n_hash_encodings - 1,
+                                       self.n_hash_encodings).to(device=device, dtype=torch.float32)
+                self._window_cache = {wkey: window}
+        return conditioning_code, window
+
+    @torch.no_grad()
+    def preblend(self, conditioning_code: torch.Tensor, window_hash_encodings: Optional[float] = None) -> torch.Tensor:
+        """Eval fast path: blend the H tables with ONE code row ([H] or [1,H]) into a single 2-feature
+        grid ``[total_entries, 2]`` fp16.  ``forward_preblended`` then costs 4 B per corner instead of 128 B.  Equal to
+        forward() with that code on every sample up to fp16 rounding order (the blend is linear in the tables)."""
+        code = conditioning_code.reshape(1, -1)
+        assert code.shape[-1] == self.n_hash_encodings
+        code, window = self._conditioned(code, window_hash_encodings, self.tables.device)
+        return F.tables_preblend(self.half_tables(), self.n_hash_encodings, self.geom, code[0], window)
+
+    @torch.no_grad()
+    def forward_preblended(self, in_tensor: torch.Tensor, blended: torch.Tensor) -> torch.Tensor:
+        return F.hashgrid_fwd_f16(in_tensor, blended, 2, self.geom)
+
     # ---- forward -----------------------------------------------------------------------------------
     def forward(self,
                 in_tensor: torch.Tensor,
@@ -159,22 +194,7 @@ class HashEnsemble(nn.Module):
             "If blend mixing type is chosen, conditioning code needs to have as many dimensions as there are " \
             "hashtables in the encoding"
 
-        window = None
-        if window_hash_encodings is not None:
-            if window_hash_encodings == 1 and self.disable_initial_hash_ensemble:
-                conditioning_code = torch.ones_like(conditioning_code)
-            elif self.use_soft_transition and window_hash_encodings < 2:
-                alpha = window_hash_encodings - 1
-                first = torch.zeros_like(conditioning_code)
-                first[:, 0] = (1 - alpha) * 1
-                conditioning_code = alpha * conditioning_code + first
-            # one device tensor per window value (chunks / passes of a step share it)
-            wkey = (float(window_hash_encodings), str(in_tensor.device))
-            window = self._window_cache.get(wkey)
-            if window is None:
-                window = posenc_window(window_hash_encodings, 0, self.n_hash_encodings - 1,
-                                       self.n_hash_encodings).to(device=in_tensor.device, dtype=torch.float32)
-                self._window_cache = {wkey: window}
+        conditioning_code, window = self._conditioned(conditioning_code, window_hash_encodings, in_tensor.device)
 
         sink = self.grad_sink if (self.grad_sink is not None and torch.is_grad_enabled()) else None
         return F.hash_ensemble(in_tensor, self.tables, self.half_tables(), conditioning_code,

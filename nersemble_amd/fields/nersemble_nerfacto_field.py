@@ -88,13 +88,14 @@ class NeRSembleNeRFactoField(nn.Module):
     # ---- density -----------------------------------------------------------------------------------
     def density_fn(self, positions: Tensor, times: Optional[Tensor] = None,
                    window_hash_encodings: Optional[float] = None, time_codes: Optional[Tensor] = None,
-                   time_code_index: Optional[Tensor] = None) -> Tensor:
+                   time_code_index: Optional[Tensor] = None, preblended_table: Optional[Tensor] = None) -> Tensor:
         """Occupancy / sigma_fn entry (nersemble_nerfacto_field.py:228-248)."""
         del times
         # the reference wraps the positions into dummy Frustums (starts = ends = 0) whose get_positions() returns them
         # unchanged (:236-246); the wrapper is skipped here
         density, _ = self._density_from_positions(positions, None, {"time_codes": time_codes,
-                                                                    "time_code_index": time_code_index},
+                                                                    "time_code_index": time_code_index,
+                                                                    "preblended_table": preblended_table},
                                                   window_hash_encodings)
         return density
 
@@ -125,6 +126,7 @@ class NeRSembleNeRFactoField(nn.Module):
         max_chunk = len(positions) if self.max_n_samples_per_batch == -1 else self.max_n_samples_per_batch
         time_codes = md.get("time_codes")
         code_index = md.get("time_code_index")        # native extension: time_codes is a [T,H] table
+        blended = md.get("preblended_table")           # eval fast path: one time code for every sample of the image
         pre_feats = md.get("precomputed_hash_features")       # from the step's sigma_fn pass (same samples, same params)
         pre_base = md.get("precomputed_base_out")
         densities, base_outs, feats_all = [], [], []
@@ -139,8 +141,12 @@ class NeRSembleNeRFactoField(nn.Module):
                 # tcnn needs inputs in [0,1): zero the samples outside the scene box (:268-269)
                 selector = ((pos_c > 0.0) & (pos_c < 1.0)).all(dim=-1)
                 pos_c = pos_c * selector[..., None]
-            feats = self.hash_ensemble(pos_c.view(-1, 3), conditioning_code=codes_c,
-                                       window_hash_encodings=window_hash_encodings, code_index=idx_c, precomputed=pre_f)
+            if blended is not None:
+                feats = self.hash_ensemble.forward_preblended(pos_c.view(-1, 3), blended)
+            else:
+                feats = self.hash_ensemble(pos_c.view(-1, 3), conditioning_code=codes_c,
+                                           window_hash_encodings=window_hash_encodings, code_index=idx_c,
+                                           precomputed=pre_f)
             h = F.fused_mlp(self.mlp_base.params, self.mlp_base.n_hidden_mats, self.mlp_base.n_output_dims,
                             self.mlp_base.out_act, b=feats, precomputed=pre_b).view(*pos_c.shape[:-1], -1)   # [S,16] fp16
             if self.keep_density_intermediates:

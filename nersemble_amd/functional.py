@@ -441,6 +441,29 @@ class _HashGridFn(torch.autograd.Function):
         return dx, dtab, None, None
 
 
+@torch.no_grad()
+def tables_preblend(tables_f16: torch.Tensor, H: int, geom: GridGeom, code_row: torch.Tensor,
+                    window: Optional[torch.Tensor]) -> torch.Tensor:
+    """[total,2,Hp] fp16 tables x one [H] code row (x window) -> [total,2] fp16 blended grid (eval fast path)."""
+    out = torch.empty((geom.total_entries, 2), dtype=torch.float16, device=tables_f16.device)
+    code = code_row.detach().to(torch.float32).reshape(-1).contiguous()
+    check(lib().nsx_tables_preblend(ptr(tables_f16), H, C.byref(geom), ptr(code), ptr(window), ptr(out), stream()),
+          "nsx_tables_preblend")
+    return out
+
+
+@torch.no_grad()
+def hashgrid_fwd_f16(x: torch.Tensor, table_f16: torch.Tensor, F_enc: int, geom: GridGeom) -> torch.Tensor:
+    """Forward only, on an fp16 table in tcnn layout [total][F_enc] (no conversion, no autograd)."""
+    xx = x.detach().to(torch.float32).contiguous()
+    B = xx.shape[0]
+    out = torch.empty((B, geom.n_levels * F_enc), dtype=torch.float16, device=xx.device)
+    if B > 0:
+        check(lib().nsx_hashgrid_fwd(ptr(xx), B, ptr(table_f16), F_enc, C.byref(geom), ptr(out), stream()),
+              "nsx_hashgrid_fwd")
+    return out
+
+
 def hashgrid_encoding(x: torch.Tensor, params: torch.Tensor, F_enc: int, geom: GridGeom) -> torch.Tensor:
     """x [B,3] in [0,1), params flat fp32 (tcnn layout [total][F_enc]) -> [B, n_levels*F_enc] fp16."""
     return _HashGridFn.apply(x, params, F_enc, geom)

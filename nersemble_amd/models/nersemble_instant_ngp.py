@@ -106,6 +106,11 @@ class NeRSembleNGPModel(BaseModel):
         self.reuse_sigma_pass = True
         # all loss terms + metrics from csrc/losses.hip when the configuration allows (see _fused_step_losses)
         self.fuse_step_losses = True
+        # evaluation fast path: when every ray of a bundle carries the same timestep the H hash tables
+        # are blended once per image into one 2-feature grid (HashEnsemble.preblend)
+        self.eval_preblend = True
+        self._eval_blend = None
+        self._eval_blend_cache = (None, None)
         self.populate_modules()
 
     # ---- construction (nersemble_instant_ngp.py:81-179) ---------------------------------------------
@@ -217,7 +222,7 @@ class NeRSembleNGPModel(BaseModel):
             positions = positions + offsets
         density = self.field.density_fn(positions, times, window_hash_encodings=window_hash,
                                         time_codes=self.time_embedding.weight if self.time_embedding is not None else None,
-                                        time_code_index=timesteps)
+                                        time_code_index=timesteps, preblended_table=self._eval_blend)
         if self.field.keep_density_intermediates:
             # same samples, same parameters, same step as the main pass: its forward values are reused there
             self._sigma_cache = {"n": positions.shape[0],
@@ -234,13 +239,42 @@ class NeRSembleNGPModel(BaseModel):
                                    code_index=code_index, precomputed_offsets=precomputed_offsets)
         return ray_samples
 
+    def _eval_blend_table(self, ray_timesteps: Tensor) -> Optional[Tensor]:
+        """The pre-blended grid for this bundle, or None (training, gradients on, several timesteps, no time codes)."""
+        if (self.training or torch.is_grad_enabled() or not self.eval_preblend or self.time_embedding is None
+                or not self.config.use_hash_ensemble or ray_timesteps.numel() == 0 or not ray_timesteps.is_cuda):
+            return None
+        t0 = int(ray_timesteps[0])                              # evaluation only: a host read per bundle is fine
+        if not bool((ray_timesteps == t0).all()):
+            return None
+        he = self.field.hash_ensemble
+        window = self.sched_window_hash_encodings.value if self.sched_window_hash_encodings is not None else None
+        key = (t0, window, he.tables._version, he.tables.data_ptr(), he._f16_version, self.time_embedding.weight._version)
+        if self._eval_blend_cache[0] != key:
+            self._eval_blend_cache = (key, he.preblend(self.time_embedding.weight[t0], window))
+        return self._eval_blend_cache[1]
+
     # ---- forward (:280-364) --------------------------------------------------------------------------
     def get_outputs(self, ray_bundle: RayBundle):
+        try:
+            return self._get_outputs(ray_bundle)
+        finally:
+            self._eval_blend = None
+
+    def _get_outputs(self, ray_bundle: RayBundle):
         cfg = self.config
         window_hash = self.sched_window_hash_encodings.value if self.sched_window_hash_encodings is not None else None
         num_rays = len(ray_bundle)
         self._sigma_cache = None
-        self.field.keep_density_intermediates = self.reuse_sigma_pass and self.training and torch.is_grad_enabled()
+        # (training with autograd, or inference without: the reused values are exactly what the second evaluation returns)
+        self.field.keep_density_intermediates = self.reuse_sigma_pass and (self.training == torch.is_grad_enabled())
+        if ray_bundle.times is not None:
+            ray_timesteps = self._timesteps(ray_bundle.times)
+        elif "timesteps" in ray_bundle.metadata:
+            ray_timesteps = ray_bundle.metadata["timesteps"].reshape(-1).int()
+        else:
+            ray_timesteps = torch.zeros((num_rays,), dtype=torch.int, device=ray_bundle.origins.device)
+        self._eval_blend = self._eval_blend_table(ray_timesteps)
         with torch.no_grad():
             ray_samples, ray_indices = self.sampler(
                 ray_bundle=ray_bundle, near_plane=cfg.near_plane, far_plane=cfg.far_plane,
@@ -261,13 +295,6 @@ class NeRSembleNGPModel(BaseModel):
                 pre_offsets = cache["offsets"].index_select(0, keep)
         self._sigma_cache = None
 
-        if ray_bundle.times is not None:
-            ray_timesteps = self._timesteps(ray_bundle.times)
-        elif "timesteps" in ray_bundle.metadata:
-            ray_timesteps = ray_bundle.metadata["timesteps"].reshape(-1).int()
-        else:
-            ray_timesteps = torch.zeros((num_rays,), dtype=torch.int, device=ray_indices.device)
-
         time_codes_deformation = deform_slot = None
         if self.time_embedding is not None:
             # small code tables + per-sample slot instead of [S,H] / [S,128] gathers.  The datamanager knows the <= 24
@@ -280,6 +307,8 @@ class NeRSembleNGPModel(BaseModel):
             slot = inv.to(torch.int32)[ray_indices]
             ray_samples.metadata["time_codes"] = self.time_embedding(uniq)              # [Tb, H]
             ray_samples.metadata["time_code_index"] = slot                              # [S]
+            if self._eval_blend is not None:
+                ray_samples.metadata["preblended_table"] = self._eval_blend
             if self.time_embedding_deformation is not None:
                 time_codes_deformation = self.time_embedding_deformation(uniq)            # [Tb, 128] table
             elif cfg.use_deformation_field:

@@ -15,8 +15,10 @@ What is pinned (reference-owned code, executed for real):
   * BaseModel.get_dist_loss sample selection / midpoint construction (models/base.py:224-249) with a
     stub flatten_eff_distloss that records its arguments.
   * BaseModel masked-RGB / alpha / empty / near / depth losses (models/base.py:90-222) on a synthetic packed batch.
+  * extract_top_k_connected_component / filter_occupancy_grid (util/connected_components.py:28-139) on a synthetic
+    40^3 grid (numpy + scipy.ndimage for real; cc3d.largest_k stubbed with scipy.ndimage.label).
 Stubs (third-party packages that are not installed): tinycudann, nerfstudio.*, jaxtyping,
-torch_efficient_distloss.  The nerfstudio MLP / NeRFEncoding / SceneBox stubs restate nerfstudio 0.3.1
+torch_efficient_distloss, cc3d, nerfacc.  The nerfstudio MLP / NeRFEncoding / SceneBox stubs restate nerfstudio 0.3.1
  -> that sub-part stays "parity unpinned".
 """
 import os
@@ -395,18 +397,86 @@ def gen_losses(out):
     out["ls_depth_loss"] = np.array([float(model.get_depth_loss(batch, depth_pred))])
 
 
+def gen_occupancy_filter(out):
+    """filter_occupancy_grid / extract_top_k_connected_component (util/connected_components.py:28-139), run for real
+    with numpy + scipy.ndimage.  Stub: ``cc3d.largest_k`` (not installed) = largest 6-connected component via
+    scipy.ndimage.label -> the connected-component step itself stays "parity unpinned"."""
+    import scipy.ndimage as ndi
+
+    def largest_k(arr, k=1, connectivity=6, delta=0, return_N=False):
+        assert k == 1 and connectivity == 6
+        lab, n = ndi.label(arr > 0)                      # default structure = 6-connectivity in 3-D
+        res = np.zeros(arr.shape, dtype=np.uint32)
+        if n > 0:
+            counts = np.bincount(lab.ravel())[1:]
+            res[lab == (int(np.argmax(counts)) + 1)] = 1
+        return (res, min(n, 1)) if return_N else res
+
+    cc3d = _mod("cc3d")
+    cc3d.largest_k = largest_k
+    if "nerfacc" not in sys.modules:
+        _mod("nerfacc")
+    sys.modules["nerfacc"].OccGridEstimator = object
+    from nersemble.util.connected_components import extract_top_k_connected_component, filter_occupancy_grid
+
+    rng = np.random.default_rng(4242)
+    R = 40
+    zz, yy, xx = np.meshgrid(np.arange(R), np.arange(R), np.arange(R), indexing="ij")
+
+    def blob(c, r, amp):
+        d2 = (xx - c[0]) ** 2 + (yy - c[1]) ** 2 + (zz - c[2]) ** 2
+        return amp * np.exp(-d2 / (2.0 * r * r))
+
+    occs = blob((20, 19, 21), 7.0, 6.0) + blob((6, 7, 30), 2.5, 5.0) + blob((33, 31, 8), 2.0, 7.0)   # head + 2 floaters
+    occs[19:21, 19:21, 6:16] += 4.0                       # a thin bridge towards a floater (cut by the thinning blur)
+    occs += rng.random((R, R, R)) * 0.4                   # noise floor
+    occs = occs.astype(np.float32)
+    out["occ_in"] = occs
+    for i, (thr, s_thin, s_ero) in enumerate([(0.6, 1, 5), (0.6, 1, 2), (0.8, 2, 3)]):
+        m = extract_top_k_connected_component(occs.copy(), threshold=thr, sigma_thinning=s_thin, sigma_erosion=s_ero)[0]
+        out[f"occ_mask_{i}"] = np.packbits(m.astype(bool).ravel())
+        out[f"occ_args_{i}"] = np.array([thr, s_thin, s_ero], dtype=np.float64)
+
+    class FakeGrid:
+        resolution = torch.tensor([R, R, R])
+        device = "cpu"
+
+    g = FakeGrid()
+    g.occs = torch.from_numpy(occs.reshape(-1).copy())
+    g.binaries = torch.from_numpy(rng.random((1, R, R, R)) < 0.7)
+    out["occ_binaries_in"] = np.packbits(g.binaries.numpy().ravel())
+    filter_occupancy_grid(g, threshold=0.6, sigma_erosion=5)
+    out["occ_binaries_out"] = np.packbits(g.binaries.numpy().ravel())
+
+
 def main():
+    """python tests/golden/make_golden.py [hash_ensemble] [deformation] [misc] [occupancy_filter]   (default: all)"""
     torch.set_num_threads(4)
-    a, b, c = {}, {}, {}
-    gen_hash_ensemble(a)
-    np.savez_compressed(os.path.join(HERE, "hash_ensemble.npz"), **a)
-    gen_deformation(b)
-    np.savez_compressed(os.path.join(HERE, "deformation.npz"), **b)
-    gen_misc(c)
-    gen_distloss_selection(c)
-    gen_losses(c)
-    np.savez_compressed(os.path.join(HERE, "misc.npz"), **c)
-    for f in ("hash_ensemble.npz", "deformation.npz", "misc.npz"):
+    which = set(sys.argv[1:]) or {"hash_ensemble", "deformation", "misc", "occupancy_filter"}
+    written = []
+    if "hash_ensemble" in which:
+        a = {}
+        gen_hash_ensemble(a)
+        np.savez_compressed(os.path.join(HERE, "hash_ensemble.npz"), **a)
+        written.append("hash_ensemble.npz")
+    if "deformation" in which:
+        b = {}
+        gen_deformation(b)
+        np.savez_compressed(os.path.join(HERE, "deformation.npz"), **b)
+        written.append("deformation.npz")
+    if "misc" in which:
+        c = {}
+        gen_misc(c)
+        gen_distloss_selection(c)
+        gen_losses(c)
+        np.savez_compressed(os.path.join(HERE, "misc.npz"), **c)
+        written.append("misc.npz")
+    if "occupancy_filter" in which:
+        d = {}
+        gen_occupancy_filter(d)
+        np.savez_compressed(os.path.join(HERE, "occupancy_filter.npz"), **d)
+        written.append("occupancy_filter.npz")
+    for f in written:
         print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")
 
 

@@ -268,3 +268,25 @@ def test_reference_layout_ensemble_from_tcnn_encodings_matches_fused(cuda):
     fused = he(x, code)
     tol = 2.0 * FP16_EPS * ref.float().abs().max().item() + 1e-6
     assert (fused.float() - ref.float()).abs().max().item() <= tol
+
+
+@pytest.mark.parametrize("H", [1, 4, 16, 32])
+@pytest.mark.parametrize("win", [None, 1.0, 1.5, 5.25])
+def test_preblended_eval_grid_matches_ensemble_forward(H, win, cuda):
+    """Eval fast path: blending the tables with one time code and sampling the resulting 2-feature grid
+    equals the per-sample blend up to fp16 rounding order (blend-then-interpolate vs interpolate-then-blend)."""
+    from nersemble_amd.field_components.hash_ensemble import HashEnsemble, HashEnsembleConfig, TCNNHashEncodingConfig
+    cfg = HashEnsembleConfig(H, TCNNHashEncodingConfig(n_levels=8, log2_hashmap_size=13), True, True)
+    he = HashEnsemble(cfg, seed=3).to(cuda)
+    with torch.no_grad():
+        he.tables.mul_(5000)
+    g = torch.Generator(device=cuda).manual_seed(H)
+    x = torch.rand((5000, 3), device=cuda, generator=g)
+    code = torch.randn((1, H), device=cuda, generator=g)
+    with torch.no_grad():
+        want = he(x, code.expand(x.shape[0], H).contiguous(), window_hash_encodings=win).float()
+        table = he.preblend(code, window_hash_encodings=win)
+        got = he.forward_preblended(x, table).float()
+    assert table.shape == (he.geom.total_entries, 2) and table.dtype == torch.float16
+    scale = want.abs().max().item() + 1e-12
+    assert (got - want).abs().max().item() <= 4e-3 * scale, (got - want).abs().max().item() / scale

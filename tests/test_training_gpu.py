@@ -176,3 +176,36 @@ def test_deferred_scheduler_step_matches_immediate(cuda):
     trainer.flush_scheduler_step()
     for sch in trainer.schedulers.values():
         assert sch.last_epoch == 4
+
+
+def test_eval_preblend_fast_path_matches_per_sample_blend(cuda):
+    """Rendering an evaluation image (one timestep for all rays) through the pre-blended grid gives the image of the
+    regular path: same samples, colours within fp16 blend-order noise."""
+    from nersemble_amd.workloads import build_workload
+    torch.manual_seed(2)
+    trainer, data, _ = build_workload("p030_h16", device="cuda:0", small=True, n_rays=512)
+    for step in range(6):
+        trainer.train_iteration(step, *data.next_train(step))
+    model = trainer.model
+    model.eval()
+    bundle, _, _ = data.eval_image_rays(cam=1, timestep=3, downscale=64)
+    outs = {}
+    with torch.no_grad():
+        for fast in (False, True):
+            model.eval_preblend = fast
+            torch.manual_seed(7)
+            outs[fast] = model(bundle)
+            assert (model._eval_blend_cache[0] is not None) == fast or fast is False
+    a, b = outs[False], outs[True]
+    n_a, n_b = a["num_samples_per_ray"].sum().item(), b["num_samples_per_ray"].sum().item()
+    assert abs(n_a - n_b) <= 0.01 * max(n_a, 1)           # a density at the alpha threshold may flip a sample
+    assert (a["rgb"] - b["rgb"]).abs().max().item() <= 2e-2
+    assert (a["rgb"] - b["rgb"]).abs().mean().item() <= 2e-3
+    assert (a["accumulation"] - b["accumulation"]).abs().mean().item() <= 2e-3
+    # a bundle with several timesteps must not take the fast path
+    model.eval_preblend = True
+    tb, _ = data.next_train(99)
+    with torch.no_grad():
+        model(tb)
+    assert model._eval_blend is None
+    model.train()
