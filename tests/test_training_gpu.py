@@ -209,3 +209,12 @@ def test_eval_preblend_fast_path_matches_per_sample_blend(cuda):
         model(tb)
     assert model._eval_blend is None
     model.train()
+
+
+def test_dense_march_config_runs(cuda):
+    """BASELINE configs[3]-like: --disable_occupancy_grid --lambda_dist_loss 0 (every cell occupied, density_fn == 1 for
+    the visibility pass, no distortion loss -> the operator-by-operator loss path)."""
+    trainer, losses, metrics = _run(None, steps=4, workload="p097_dense")
+    assert all(np.isfinite(losses))
+    assert trainer.model.config.disable_occupancy_grid and trainer.model.occupancy_grid.binaries.all()
+    assert float(metrics["num_samples_per_batch"]) > 0
