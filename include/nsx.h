@@ -183,6 +183,13 @@ int nsx_sample_positions(const float* origins, const float* directions, const in
                          const float* t_starts, const float* t_ends, const float* offsets, int64_t S,
                          const float* aabb_host, float* pos_world, float* pos_normalised, uint8_t* selector,
                          void* stream);
+/* dsts[a][i][:] = srcs[a][index[i]][:] for n_arrays <= NSX_MAX_GATHER device arrays in one launch (row_bytes[a] a
+ * multiple of 4; srcs / row_bytes / dsts are HOST arrays of device pointers / sizes).  Replaces the index_select /
+ * advanced-indexing launches after the visibility test: nerfacc's ray_indices[keep], t_starts[keep], t_ends[keep]
+ * (inside OccGridEstimator.sampling) and the compaction of the sigma-pass values that the main pass reuses. */
+#define NSX_MAX_GATHER 8
+int nsx_gather_rows(int n_arrays, const void* const* srcs, const int64_t* row_bytes, void* const* dsts,
+                    const int64_t* index, int64_t n, void* stream);
 int nsx_normalise_bwd(const float* grad_pos_normalised, const uint8_t* selector, int64_t S, const float* aabb_host,
                       float* grad_pos_world, void* stream);
 int nsx_density_fwd(const nsx_half* base_out, int64_t stride, const uint8_t* selector, int64_t S, float* density,

@@ -8,6 +8,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "csrc", "libnsx.so")
 NSX_MAX_LEVELS = 32
 NSX_MAX_SLOTS = 64
+NSX_MAX_GATHER = 8
 
 c_void_p, c_int, c_int64, c_float = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
@@ -61,6 +62,7 @@ SIGNATURES = {
     "nsx_f32_to_f16": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "nsx_sample_positions": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p,
                                      c_void_p, c_void_p, c_void_p, c_void_p]),
+    "nsx_gather_rows": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "nsx_normalise_bwd": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "nsx_density_fwd": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p]),
     "nsx_density_bwd": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),

@@ -518,7 +518,7 @@ __global__ __launch_bounds__(NW * 64, 1) void deform_fwd_kernel(DeformArgs A, fl
 // backward chain kernel: writes per-tile a0..a6, dZ0..dZ5, dZheads, dCode tiles
 // ---------------------------------------------------------------------------------------------------------
 // per sample-tile scratch layout (halfs): a0 [192][32] | a1..a6 [6][128][32] | dZ0..dZ5 [6][128][32] | dZh [32][32] | dC [128][32]
-constexpr int64_t TILE_A0 = 0;
+// TILE_A0 = 0: the 192-column input tile comes first
 constexpr int64_t TILE_A = 192 * 32;
 constexpr int64_t TILE_DZ = TILE_A + 6 * DFW * 32;
 constexpr int64_t TILE_DZH = TILE_DZ + 6 * DFW * 32;

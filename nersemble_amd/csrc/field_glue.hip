@@ -74,6 +74,37 @@ __global__ __launch_bounds__(256) void density_bwd_kernel(const half_t* __restri
     }
 }
 
+// dst_a[i][:] = src_a[index[i]][:] for up to NSX_MAX_GATHER arrays in ONE launch (rows of 4-byte words; 16-byte pieces
+// when every row is a multiple of 16 B)
+struct GatherArgs {
+    const uint8_t* src[NSX_MAX_GATHER];
+    uint8_t* dst[NSX_MAX_GATHER];
+    int words[NSX_MAX_GATHER];       // row length in pieces (uint32 or uint4)
+    int vec[NSX_MAX_GATHER];         // 1: uint4 pieces, 0: uint32 pieces
+    int n_arrays;
+};
+
+__global__ __launch_bounds__(256) void gather_rows_kernel(GatherArgs A, const int64_t* __restrict__ index, int64_t n) {
+    const int a = blockIdx.y;
+    const int64_t words = A.words[a];
+    const int64_t total = n * words;
+    if (A.vec[a]) {
+        const uint4* src = reinterpret_cast<const uint4*>(A.src[a]);
+        uint4* dst = reinterpret_cast<uint4*>(A.dst[a]);
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+            const int64_t row = i / words, w = i - row * words;
+            dst[i] = src[index[row] * words + w];
+        }
+    } else {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(A.src[a]);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(A.dst[a]);
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+            const int64_t row = i / words, w = i - row * words;
+            dst[i] = src[index[row] * words + w];
+        }
+    }
+}
+
 static Box make_box(const float* aabb) {
     Box b;
     for (int a = 0; a < 3; ++a) { b.lo[a] = aabb ? aabb[a] : 0.f; b.ext[a] = aabb ? aabb[3 + a] - aabb[a] : 1.f; }
@@ -105,6 +136,33 @@ int nsx_sample_positions(const float* origins, const float* directions, const in
     hipLaunchKernelGGL(sample_positions_kernel, dim3(grid_for(S)), dim3(256), 0, (hipStream_t)stream, origins, directions,
                        ray_indices, t_starts, t_ends, offsets, S, make_box(aabb_host), pos_world, pos_normalised, selector);
     NSX_LAUNCH_CHECK("nsx_sample_positions launch");
+    return NSX_OK;
+}
+
+int nsx_gather_rows(int n_arrays, const void* const* srcs, const int64_t* row_bytes, void* const* dsts,
+                    const int64_t* index, int64_t n, void* stream) {
+    NSX_REQUIRE(n >= 0, "nsx_gather_rows: negative row count");
+    NSX_REQUIRE(n_arrays >= 1 && n_arrays <= NSX_MAX_GATHER, "nsx_gather_rows: n_arrays=%d not in [1,%d]", n_arrays,
+                NSX_MAX_GATHER);
+    if (n == 0) return NSX_OK;
+    NSX_REQUIRE(srcs && row_bytes && dsts && index, "nsx_gather_rows: NULL argument");
+    GatherArgs A;
+    A.n_arrays = n_arrays;
+    int64_t max_pieces = 1;
+    for (int a = 0; a < n_arrays; ++a) {
+        NSX_REQUIRE(srcs[a] && dsts[a] && row_bytes[a] > 0 && row_bytes[a] % 4 == 0,
+                    "nsx_gather_rows: array %d: NULL pointer or row size %lld not a positive multiple of 4 bytes", a,
+                    (long long)row_bytes[a]);
+        A.src[a] = reinterpret_cast<const uint8_t*>(srcs[a]);
+        A.dst[a] = reinterpret_cast<uint8_t*>(dsts[a]);
+        const bool vec = row_bytes[a] % 16 == 0 && (reinterpret_cast<uintptr_t>(srcs[a]) & 15) == 0 &&
+                         (reinterpret_cast<uintptr_t>(dsts[a]) & 15) == 0;
+        A.vec[a] = vec ? 1 : 0;
+        A.words[a] = (int)(row_bytes[a] / (vec ? 16 : 4));
+        if (n * A.words[a] > max_pieces) max_pieces = n * A.words[a];
+    }
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for(max_pieces), n_arrays), dim3(256), 0, (hipStream_t)stream, A, index, n);
+    NSX_LAUNCH_CHECK("nsx_gather_rows launch");
     return NSX_OK;
 }
 

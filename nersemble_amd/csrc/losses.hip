@@ -12,7 +12,6 @@
 
 namespace nsx {
 
-constexpr int NL_OUT = NSX_LOSS_OUT;
 constexpr int NL_THREADS = 1024;
 
 struct LossCfg {

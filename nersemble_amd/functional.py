@@ -442,6 +442,25 @@ class _HashGridFn(torch.autograd.Function):
 
 
 @torch.no_grad()
+def gather_rows(index: torch.Tensor, *tensors: torch.Tensor):
+    """[t[index] for t in tensors] (rows along dim 0) in one native launch; no autograd (values only)."""
+    idx = index.to(torch.int64).contiguous()
+    n = idx.shape[0]
+    srcs = [t.detach().contiguous() for t in tensors]
+    outs = [torch.empty((n,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device) for t in srcs]
+    k = len(srcs)
+    if n > 0 and k > 0:
+        rb = [t[0].numel() * t.element_size() if t.shape[0] > 0 else 4 for t in srcs]
+        if any(b % 4 for b in rb) or k > _lib.NSX_MAX_GATHER:
+            return tuple(t.index_select(0, idx) for t in srcs)
+        src_arr = (C.c_void_p * k)(*[t.data_ptr() for t in srcs])
+        dst_arr = (C.c_void_p * k)(*[t.data_ptr() for t in outs])
+        rb_arr = (C.c_int64 * k)(*rb)
+        check(lib().nsx_gather_rows(k, src_arr, rb_arr, dst_arr, ptr(idx), n, stream()), "nsx_gather_rows")
+    return tuple(outs)
+
+
+@torch.no_grad()
 def tables_preblend(tables_f16: torch.Tensor, H: int, geom: GridGeom, code_row: torch.Tensor,
                     window: Optional[torch.Tensor]) -> torch.Tensor:
     """[total,2,Hp] fp16 tables x one [H] code row (x window) -> [total,2] fp16 blended grid (eval fast path)."""

@@ -289,10 +289,13 @@ class NeRSembleNGPModel(BaseModel):
         pre_offsets = None
         if cache is not None and keep is not None and cache["n"] == self.occupancy_grid.last_n_marched \
                 and keep.shape[0] == ray_indices.shape[0] and cache["features"] is not None:
-            ray_samples.metadata["precomputed_hash_features"] = cache["features"].index_select(0, keep)
-            ray_samples.metadata["precomputed_base_out"] = cache["base_out"].index_select(0, keep)
+            from ..functional import gather_rows
+            vals = [cache["features"], cache["base_out"]] + ([cache["offsets"]] if cache["offsets"] is not None else [])
+            got = gather_rows(keep, *vals)                                                # one launch
+            ray_samples.metadata["precomputed_hash_features"] = got[0]
+            ray_samples.metadata["precomputed_base_out"] = got[1]
             if cache["offsets"] is not None:
-                pre_offsets = cache["offsets"].index_select(0, keep)
+                pre_offsets = got[2]
         self._sigma_cache = None
 
         time_codes_deformation = deform_slot = None

@@ -280,7 +280,11 @@ class OccGridEstimator(nn.Module):
                                                    early_stop_eps=early_stop_eps, alpha_thre=alpha_thre)
             keep = masks.nonzero(as_tuple=True)[0]             # one host sync for all three selections
             self.last_keep_index, self.last_n_marched = keep, masks.shape[0]
-            ray_indices, t_starts, t_ends = ray_indices[keep], t_starts[keep], t_ends[keep]
+            if keep.is_cuda:
+                from .functional import gather_rows
+                ray_indices, t_starts, t_ends = gather_rows(keep, ray_indices, t_starts, t_ends)      # one launch
+            else:
+                ray_indices, t_starts, t_ends = ray_indices[keep], t_starts[keep], t_ends[keep]
         return ray_indices, t_starts, t_ends
 
     # ---- grid update (nerfacc _update; torch glue around the density evaluation) ----------------

@@ -271,3 +271,20 @@ def test_fused_sample_losses_match_reference_golden_and_separate_ops(cuda, golde
     assert abs(trio[2].item() - near.item()) <= 1e-4 * abs(near.item())
     (0.7 * dist - 1.3 * empty + 2.1 * near).backward()
     assert (g_fused - w2.grad).abs().max().item() <= 1e-4 * w2.grad.abs().max().item()
+
+
+def test_gather_rows_matches_indexing(cuda):
+    """nsx_gather_rows: several arrays of different row widths compacted by one index in one launch (bit-exact)."""
+    from nersemble_amd.functional import gather_rows
+    g = torch.Generator(device=cuda).manual_seed(0)
+    n_src = 10_001
+    a = torch.randn((n_src, 32), device=cuda, generator=g).half()          # 64-B rows -> 16-B pieces
+    b = torch.randn((n_src, 3), device=cuda, generator=g)                  # 12-B rows -> 4-B pieces
+    c = torch.randint(0, 1 << 40, (n_src,), device=cuda, generator=g)      # int64
+    d = torch.randn((n_src,), device=cuda, generator=g)
+    e = torch.randn((n_src, 16), device=cuda, generator=g).half()[1:]      # misaligned base (32-B rows, 4-B pieces)
+    for n in (0, 1, 7777):
+        idx = torch.randint(0, n_src - 1, (n,), device=cuda, generator=g)
+        got = gather_rows(idx, a, b, c, d, e)
+        for t, o in zip((a, b, c, d, e), got):
+            assert o.dtype == t.dtype and torch.equal(o, t[idx])
