@@ -142,6 +142,12 @@ def main():
         return samples, loss, metrics
 
     run(a.warmup, 0)
+    # Python's cyclic garbage collector pauses the host for tens of ms whenever its generation-2 threshold trips
+    # (sporadic 70-100 ms steps); training loops collect at controlled points instead (NeRSembleTrainer.gc_every)
+    import gc
+    gc.collect()
+    gc.freeze()
+    gc.disable()
     # HIP events only around the calls that are priced against a roofline (+ the other large kernels), allocated
     # before the timed region
     _lib.profiler.watch = {"nsx_hash_ensemble_fwd", "nsx_hash_ensemble_bwd_factored", "nsx_hash_ensemble_bwd",

@@ -76,7 +76,11 @@ __global__ __launch_bounds__(256) void adam_hash_factored_kernel(
         float pp[HV], mm[HV], vv[HV];
         if (live) {
 #pragma unroll
-            for (int k = 0; k < HV; ++k) { pp[k] = master[at + k]; mm[k] = m[at + k]; vv[k] = v[at + k]; }
+            for (int k = 0; k < HV; ++k) {          // streamed once per step: keep them out of the way of G in L2
+                pp[k] = __builtin_nontemporal_load(master + at + k);
+                mm[k] = __builtin_nontemporal_load(m + at + k);
+                vv[k] = __builtin_nontemporal_load(v + at + k);
+            }
         }
         __syncthreads();
         {
@@ -111,7 +115,12 @@ __global__ __launch_bounds__(256) void adam_hash_factored_kernel(
             if (hq * HV + k < Hreal) adam_update(g[k] * is, pp[k], mm[k], vv[k], hy);
         }
 #pragma unroll
-        for (int k = 0; k < HV; ++k) { master[at + k] = pp[k]; m[at + k] = mm[k]; v[at + k] = vv[k]; f16[at + k] = (half_t)pp[k]; }
+        for (int k = 0; k < HV; ++k) {
+            __builtin_nontemporal_store(pp[k], master + at + k);
+            __builtin_nontemporal_store(mm[k], m + at + k);
+            __builtin_nontemporal_store(vv[k], v + at + k);
+            f16[at + k] = (half_t)pp[k];                  // read again by the next forward pass
+        }
     }
 }
 
