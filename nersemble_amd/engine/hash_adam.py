@@ -48,13 +48,35 @@ class HashTableAdam(torch.optim.Optimizer):
             check(lib().nsx_check_finite(ptr(g.contiguous()), g.numel(), ptr(found_inf), stream()), "nsx_check_finite")
 
     @torch.no_grad()
-    def step(self, found_inf: Optional[torch.Tensor] = None, inv_scale: Optional[torch.Tensor] = None):
+    def step(self, found_inf: Optional[torch.Tensor] = None, inv_scale: Optional[torch.Tensor] = None,
+             side_stream: Optional["torch.cuda.Stream"] = None):
+        """``side_stream``: run the 12 GB pass there instead of on the current stream.  Nothing after it in the step
+        depends on the tables (the other groups' optimizers, the scaler update, the next step's ray marching), so the
+        current stream carries on; ``HashEnsemble.wait_tables`` orders the next reader of the tables after it."""
         he, p = self.he, self.he.tables
-        group = self.param_groups[0]
         sink = he.grad_sink
         entries = sink.entries if sink is not None else []
         if not entries and p.grad is None:
             return
+        if side_stream is None or not p.is_cuda:
+            return self._step_now(found_inf, inv_scale)
+        he.wait_tables()
+        side_stream.wait_stream(torch.cuda.current_stream(p.device))
+        keep = [t for e in entries for t in (e["code"], e["window"]) if t is not None]
+        keep += [t for t in (found_inf, inv_scale, p.grad) if t is not None]
+        with torch.cuda.stream(side_stream):
+            self._step_now(found_inf, inv_scale)
+            done = torch.cuda.Event()
+            done.record(side_stream)
+        for t in keep:                        # allocated on the main stream, still being read on the side stream
+            t.record_stream(side_stream)
+        he._tables_ready = done
+
+    def _step_now(self, found_inf, inv_scale):
+        he, p = self.he, self.he.tables
+        group = self.param_groups[0]
+        sink = he.grad_sink
+        entries = sink.entries if sink is not None else []
         st = self._state()
         st["step"] += 1
         b1, b2 = group["betas"]

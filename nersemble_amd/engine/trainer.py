@@ -33,7 +33,8 @@ class OptimizerConfig:
 class NeRSembleTrainer:
     def __init__(self, model: NeRSembleNGPModel, opt_cfg: Optional[OptimizerConfig] = None,
                  mixed_precision: bool = True, world_size: int = 1, factored_table_grad: Optional[bool] = None,
-                 rank: Optional[int] = None, sharded_table_adam: Optional[bool] = None):
+                 rank: Optional[int] = None, sharded_table_adam: Optional[bool] = None,
+                 overlap_table_adam: bool = True):
         self.model = model
         self.cfg = opt_cfg or OptimizerConfig()
         self.mixed_precision = mixed_precision
@@ -74,6 +75,8 @@ class NeRSembleTrainer:
         self.grad_scaler = NativeGradScaler(device, enabled=mixed_precision)
         self.callbacks = model.get_training_callbacks()
         self._pending, self._found_host, self._found_event = None, None, None
+        # the table optimizer's 12 GB pass runs beside the rest of the step's tail and the next step's ray marching
+        self._opt_stream = torch.cuda.Stream(device) if (overlap_table_adam and device.type == "cuda") else None
         self._found_groups = []
 
     # ---- data-parallel gradient averaging ------------------------------------------------------------
@@ -107,7 +110,9 @@ class NeRSembleTrainer:
             dist.all_reduce(found_all, op=dist.ReduceOp.MAX)
         for key, opt in self.optimizers.items():
             f = found[self.group_of[key]]
-            if isinstance(opt, (HashTableAdam, ShardedTableAdam)):
+            if isinstance(opt, HashTableAdam):
+                opt.step(found_inf=f, inv_scale=inv_scale, side_stream=self._opt_stream)
+            elif isinstance(opt, ShardedTableAdam):
                 opt.step(found_inf=f, inv_scale=inv_scale)
             elif any(p.grad is not None for pg in opt.param_groups for p in pg["params"]):
                 if opt.defaults.get("fused"):

@@ -81,6 +81,8 @@ class HashEnsemble(nn.Module):
         self.tables = nn.Parameter(master)                                   # fp32 master, native layout
         self.register_buffer("tables_f16", master.to(torch.float16), persistent=False)
         self._f16_version = None
+        # set by HashTableAdam when its step runs on a side stream: the first reader of the tables waits for it
+        self._tables_ready = None
         # set by engine.hash_adam.HashTableAdam: factored-gradient sink (no dense table gradient is materialised)
         self.grad_sink = None
         self._window_cache = {}
@@ -90,6 +92,7 @@ class HashEnsemble(nn.Module):
     # ---- working copy management --------------------------------------------------------------
     def half_tables(self) -> torch.Tensor:
         """fp16 working copy; refreshed lazily whenever the fp32 master changed (any optimizer works)."""
+        self.wait_tables()
         v = (self.tables._version, self.tables.data_ptr())
         if self._f16_version != v:
             if self.tables_f16.device != self.tables.device:
@@ -97,6 +100,13 @@ class HashEnsemble(nn.Module):
             self.tables_f16.copy_(self.tables.detach())
             self._f16_version = v
         return self.tables_f16
+
+    def wait_tables(self) -> None:
+        """Order the current stream after an optimizer step that is still running on its own stream."""
+        ev = self._tables_ready
+        if ev is not None:
+            torch.cuda.current_stream(self.tables.device).wait_event(ev)
+            self._tables_ready = None
 
     def mark_half_synced(self):
         """Called by the fused Adam step, which writes master and working copy together."""
@@ -108,6 +118,7 @@ class HashEnsemble(nn.Module):
 
     @staticmethod
     def _export_tcnn_keys(module, state_dict, prefix, local_metadata):
+        module.wait_tables()
         native = state_dict.pop(prefix + "tables")
         if native.is_cuda:
             tc = F.tables_to_tcnn(native, module.n_hash_encodings, module.geom)
