@@ -175,12 +175,23 @@ __global__ __launch_bounds__(1024) void pack_info_kernel(const int64_t* __restri
     if (threadIdx.x == 0) total[0] = carry_s;
 }
 
-// counts from sorted ray indices (nerfacc.pack_info): histogram with one atomic per sample
-__global__ void ray_hist_kernel(const int64_t* __restrict__ ray_idx, int64_t S, int64_t R,
-                                unsigned long long* __restrict__ counts) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < S; i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t r = ray_idx[i];
-        if (r >= 0 && r < R) atomicAdd(&counts[r], 1ull);
+// counts per ray (nerfacc.pack_info).  Ray indices arrive sorted, ~200 samples per ray: each wave merges its runs of
+// equal indices and issues ONE atomic per run (correct for unsorted input too, which merely merges less).
+__global__ __launch_bounds__(256) void ray_hist_kernel(const int64_t* __restrict__ ray_idx, int64_t S, int64_t R,
+                                                       unsigned long long* __restrict__ counts) {
+    const int lane = threadIdx.x & 63;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t base = (int64_t)blockIdx.x * blockDim.x + (threadIdx.x - lane); base < S; base += stride) {
+        const int64_t i = base + lane;
+        const int64_t r = i < S ? ray_idx[i] : -1;
+        const int64_t prev = __shfl_up(r, 1);
+        const bool head = lane == 0 || prev != r;
+        const unsigned long long heads = __ballot(head);
+        if (head && r >= 0 && r < R) {
+            const unsigned long long rest = lane == 63 ? 0ull : heads >> (lane + 1);
+            const int len = rest ? __ffsll((long long)rest) : 64 - lane;
+            atomicAdd(&counts[r], (unsigned long long)len);
+        }
     }
 }
 
