@@ -14,10 +14,14 @@
 //     fragments, so the 6 layers + heads chain entirely in registers (same trick as mlp.hip, 4 M-tiles wide).
 //   * the warp code is never gathered to [S,128]: each sample carries a slot into the batch's small code table
 //     (nersemble_instant_ngp.py:310-316 materialises the gather; its backward was a 46 ms index_put).
-//   * weights are packed once per step into MFMA fragment order (fp16) and streamed from L2.
+//   * weights are packed once per step into MFMA fragment order (fp16); one 8-wave block per CU walks the layers in
+//     lock-step while the next layer's fragments are copied L2 -> LDS by LDS-DMA (global_load_lds_dwordx4) into the
+//     buffer that is not being read -- one barrier per layer, weights cross L2 -> CU once per 256 samples.
 //   * backward recomputes the forward (only ReLU bit masks are kept), chains dZ through W^T fragments, and
-//     writes dZ / activation tiles in [neuron][sample] order; weight, bias and code-table gradients are then
-//     sample-contracted GEMMs (deform_wgrad_kernel) -- the only form in which K = #samples fits MFMA.
+//     writes dZ / activation tiles in [neuron][sample] order (transposed in registers by an identity-operand MFMA);
+//     weight, bias and code-table gradients are then sample-contracted GEMMs (deform_wgrad_kernel: operands staged
+//     through a 4-deep LDS ring by LDS-DMA, each scratch byte read once) -- the only form in which K = #samples fits
+//     MFMA.
 #include "nsx_common.h"
 
 namespace nsx {
