@@ -17,10 +17,6 @@ import os
 import sys
 import time
 
-# the marcher's sample count changes every step; growing a cached block in place (instead of a fresh hipMalloc of every
-# sample-sized tensor whenever a new maximum is reached, ~100 ms each time) keeps the step time flat
-os.environ.setdefault("PYTORCH_HIP_ALLOC_CONF", "expandable_segments:True")
-
 import torch
 import torch.distributed as dist
 
