@@ -19,6 +19,8 @@ from ..field_components.hash_ensemble import HashEnsemble
 
 
 class HashTableAdam(torch.optim.Optimizer):
+    writes_half_tables = True      # HashEnsemble keeps its fp16 working copy; this optimizer refreshes it itself
+
     def __init__(self, hash_ensemble: HashEnsemble, lr: float = 5e-3, betas=(0.9, 0.999), eps: float = 1e-15,
                  factored: bool = True):
         self.he = hash_ensemble

@@ -54,6 +54,8 @@ class NativeTableOps:
 
 class ShardedTableAdam(torch.optim.Optimizer):
     """torch.optim.Adam (no amsgrad / weight decay) for ``HashEnsemble.tables`` with the state sharded over the ranks."""
+    writes_half_tables = True      # HashEnsemble keeps its fp16 working copy; this optimizer refreshes it itself
+
 
     def __init__(self, hash_ensemble: HashEnsemble, lr: float = 5e-3, betas=(0.9, 0.999), eps: float = 1e-15,
                  world_size: int = 1, rank: int = 0, group=None, ops=None):

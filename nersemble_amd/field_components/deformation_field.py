@@ -19,6 +19,18 @@ from ..rays import RaySamples, SceneBox
 from ..util.chunker import chunked
 from ..util.se3 import se3_exp_map
 from .windowed_nerf_encoding import WindowedNeRFEncoding
+from torch.optim.optimizer import register_optimizer_step_post_hook
+
+# any torch.optim step anywhere invalidates cached parameter packs (SE3DeformationField.packed_params)
+_OPTIMIZER_STEPS = [0]
+
+
+def _count_optimizer_step(*_args, **_kwargs):
+    _OPTIMIZER_STEPS[0] += 1
+
+
+register_optimizer_step_post_hook(_count_optimizer_step)
+
 
 
 @dataclass
@@ -132,15 +144,30 @@ class SE3DeformationField(nn.Module):
         st = self.se3_field.mlp_stem
         return (len(st.layers) == 6 and st.layer_width == 128 and st._skip == {4} and st.in_dim == 173)
 
-    def flat_params(self) -> torch.Tensor:
-        """The 16 nn.Linear tensors in include/nsx.h order (autograd routes the flat gradient back)."""
+    def ordered_params(self):
+        """The 16 nn.Linear tensors in include/nsx.h order."""
         L = self.se3_field
         parts = []
         for lyr in L.mlp_stem.layers:
-            parts += [lyr.weight.reshape(-1), lyr.bias]
-        parts += [L.mlp_r.layers[0].weight.reshape(-1), L.mlp_r.layers[0].bias,
-                  L.mlp_v.layers[0].weight.reshape(-1), L.mlp_v.layers[0].bias]
-        return torch.cat([p.float() for p in parts])
+            parts += [lyr.weight, lyr.bias]
+        parts += [L.mlp_r.layers[0].weight, L.mlp_r.layers[0].bias, L.mlp_v.layers[0].weight, L.mlp_v.layers[0].bias]
+        return parts
+
+    def flat_params(self) -> torch.Tensor:
+        """All parameters as one flat fp32 tensor in include/nsx.h order."""
+        return torch.cat([p.float().reshape(-1) for p in self.ordered_params()])
+
+    def packed_params(self) -> torch.Tensor:
+        """MFMA weight fragments of the current parameter values, packed once per optimizer step (every pass of a step
+        -- occupancy update, sigma_fn pass, main pass -- shares them)."""
+        params = self.ordered_params()
+        # fused optimizers update parameters without touching Tensor._version: count optimizer steps as well
+        key = (_OPTIMIZER_STEPS[0],) + tuple((p._version, p.data_ptr()) for p in params)
+        if getattr(self, "_packed_key", None) != key:
+            with torch.no_grad():
+                self._packed = F.deform_pack(self.flat_params())
+            self._packed_key = key
+        return self._packed
 
     def _aabb6(self):
         if getattr(self, "_aabb6_cache", None) is None:
@@ -158,14 +185,17 @@ class SE3DeformationField(nn.Module):
             if warp_code is None:
                 return None
             max_chunk = len(positions) if self.max_n_samples_per_batch == -1 else self.max_n_samples_per_batch
-            flat = self.flat_params()
+            params, packed = self.ordered_params(), self.packed_params()
             outs = []
             if code_index is None:
                 for pos_c, code_c, pre_c in chunked(max(max_chunk, 1), positions, warp_code, precomputed):
-                    outs.append(F.deform_offsets(flat, pos_c, code_c, self._aabb6(), windows_param, None, pre_c))
+                    outs.append(F.deform_offsets(params, packed, pos_c, code_c, self._aabb6(), windows_param, None, pre_c))
             else:
                 for pos_c, idx_c, pre_c in chunked(max(max_chunk, 1), positions, code_index, precomputed):
-                    outs.append(F.deform_offsets(flat, pos_c, warp_code, self._aabb6(), windows_param, idx_c, pre_c))
+                    outs.append(F.deform_offsets(params, packed, pos_c, warp_code, self._aabb6(), windows_param, idx_c,
+                                                 pre_c))
+            if len(outs) == 1:
+                return outs[0]
             return torch.cat(outs, dim=0) if outs else positions.new_zeros((0, 3))
         # CPU tensors: plain torch restatement (used to pin the glue against the reference's goldens)
         if code_index is not None:

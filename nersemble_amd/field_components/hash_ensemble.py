@@ -86,6 +86,20 @@ class HashEnsemble(nn.Module):
         # set by engine.hash_adam.HashTableAdam: factored-gradient sink (no dense table gradient is materialised)
         self.grad_sink = None
         self._window_cache = {}
+        # torch's fused optimizers update parameters in place WITHOUT bumping Tensor._version: if one of them steps the
+        # tables, the fp16 working copy must be rebuilt (the native table optimizers write it themselves)
+        import weakref
+        from torch.optim.optimizer import register_optimizer_step_post_hook
+        ref = weakref.ref(self)
+
+        def _after_optimizer_step(optimizer, *_a, **_k):
+            me = ref()
+            if me is None or getattr(optimizer, "writes_half_tables", False):
+                return
+            if any(p is me.tables for g in optimizer.param_groups for p in g["params"]):
+                me._f16_version = None
+
+        self._opt_hook = register_optimizer_step_post_hook(_after_optimizer_step)
         self._register_state_dict_hook(self._export_tcnn_keys)
         self._register_load_state_dict_pre_hook(self._import_tcnn_keys)
 

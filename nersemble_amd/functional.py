@@ -265,12 +265,12 @@ def deform_window7(windows_param, n_freq: int = 7):
 
 
 class _DeformFn(torch.autograd.Function):
+    """packed: the fp16 MFMA fragments of the 16 nn.Linear tensors (deform_pack); params: those tensors themselves, in
+    include/nsx.h order -- inputs only so that autograd routes their gradients (views of one flat buffer) back."""
+
     @staticmethod
-    def forward(ctx, flat_params, code, positions, code_slot, aabb6, window7, precomputed=None):
+    def forward(ctx, packed, code, positions, code_slot, aabb6, window7, precomputed, *params):
         dev = positions.device
-        params = flat_params.detach().to(torch.float32).contiguous()
-        packed = torch.empty(_deform_pack_bytes(), dtype=torch.uint8, device=dev)
-        check(lib().nsx_deform_pack(ptr(params), ptr(packed), stream()), "nsx_deform_pack")
         pos = positions.detach().to(torch.float32).contiguous()
         code_c = code.detach().to(torch.float32).contiguous()
         S = pos.shape[0]
@@ -282,7 +282,7 @@ class _DeformFn(torch.autograd.Function):
                                        window7, ptr(off), stream()), "nsx_deform_fwd")
         ctx.save_for_backward(packed, pos, code_c, code_slot)
         ctx.aabb6, ctx.window7 = aabb6, window7
-        ctx.n_params = params.numel()
+        ctx.param_shapes = [tuple(p.shape) for p in params]
         return off
 
     @staticmethod
@@ -291,7 +291,8 @@ class _DeformFn(torch.autograd.Function):
         dev = pos.device
         S = pos.shape[0]
         goff = goff.to(torch.float32).contiguous()
-        gparams = torch.zeros(ctx.n_params, dtype=torch.float32, device=dev)
+        n_params = int(lib().nsx_deform_param_count())
+        gparams = torch.zeros(n_params, dtype=torch.float32, device=dev)
         need_code = ctx.needs_input_grad[1]
         gtable = gsamples = None
         if need_code:
@@ -311,7 +312,23 @@ class _DeformFn(torch.autograd.Function):
                 gcode = torch.zeros_like(code_c).index_add_(0, code_slot.long(), gsamples)
             else:
                 gcode = gsamples
-        return gparams, gcode, None, None, None, None, None
+        grads, off = [], 0
+        for shp in ctx.param_shapes:                      # views of the flat gradient, nsx.h order
+            n = 1
+            for d in shp:
+                n *= d
+            grads.append(gparams[off:off + n].view(shp))
+            off += n
+        assert off == n_params
+        return (None, gcode, None, None, None, None, None, *grads)
+
+
+def deform_pack(flat_params: torch.Tensor) -> torch.Tensor:
+    """fp32 flat parameters (include/nsx.h order) -> packed fp16 MFMA fragments + fp16-rounded biases (device buffer)."""
+    params = flat_params.detach().to(torch.float32).contiguous()
+    packed = torch.empty(_deform_pack_bytes(), dtype=torch.uint8, device=params.device)
+    check(lib().nsx_deform_pack(ptr(params), ptr(packed), stream()), "nsx_deform_pack")
+    return packed
 
 
 _PACK_BYTES = None
@@ -324,15 +341,17 @@ def _deform_pack_bytes() -> int:
     return _PACK_BYTES
 
 
-def deform_offsets(flat_params: torch.Tensor, positions: torch.Tensor, code: torch.Tensor, aabb6,
+def deform_offsets(params, packed: torch.Tensor, positions: torch.Tensor, code: torch.Tensor, aabb6,
                    windows_param=None, code_slot: Optional[torch.Tensor] = None,
                    precomputed: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Fused SE(3) deformation (deformation_field.py:148-166): offsets [S,3] fp32 in normalised space.
-    flat_params: the 16 nn.Linear tensors concatenated in include/nsx.h order; code: [S,128] per-sample codes, or a
-    code table with per-sample row indices ``code_slot``; aabb6: ctypes float[6] (host)."""
+    params: the 16 nn.Linear tensors in include/nsx.h order (gradient routing); packed: ``deform_pack`` of their
+    current values; code: [S,128] per-sample codes, or a code table with per-sample row indices ``code_slot``;
+    aabb6: ctypes float[6] (host)."""
     if code_slot is not None:
         code_slot = code_slot.to(torch.int32).contiguous()
-    return _DeformFn.apply(flat_params, code, positions, code_slot, aabb6, deform_window7(windows_param), precomputed)
+    return _DeformFn.apply(packed, code, positions, code_slot, aabb6, deform_window7(windows_param), precomputed,
+                           *params)
 
 
 # ------------------------------------------------------------------------------------------------

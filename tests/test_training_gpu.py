@@ -218,3 +218,38 @@ def test_dense_march_config_runs(cuda):
     assert all(np.isfinite(losses))
     assert trainer.model.config.disable_occupancy_grid and trainer.model.occupancy_grid.binaries.all()
     assert float(metrics["num_samples_per_batch"]) > 0
+
+
+def test_cached_parameter_packs_follow_fused_optimizers(cuda):
+    """torch's fused optimizers update parameters without bumping Tensor._version; the cached fp16 working tables and
+    the cached deformation weight fragments must still follow them."""
+    from nersemble_amd.field_components.deformation_field import SE3DeformationField, SE3DeformationFieldConfig
+    from nersemble_amd.field_components.hash_ensemble import HashEnsemble, HashEnsembleConfig, TCNNHashEncodingConfig
+    aabb = torch.tensor([[-2.5, -1.8, -2.5], [2.2, 1.8, 2.0]])
+    torch.manual_seed(0)
+    df = SE3DeformationField(aabb, SE3DeformationFieldConfig(warp_code_dim=128)).to(cuda)
+    pos = (torch.rand(200, 3) * (aabb[1] - aabb[0]) + aabb[0]).to(cuda)
+    codes = torch.randn(200, 128, device=cuda) * 0.3
+    opt = torch.optim.Adam(df.parameters(), lr=1e-2, fused=True)
+    off0 = df.compute_offsets(pos, codes, None)
+    off0.square().sum().backward()
+    opt.step()
+    with torch.no_grad():
+        off1 = df.compute_offsets(pos, codes, None)
+        fresh = SE3DeformationField(aabb, SE3DeformationFieldConfig(warp_code_dim=128)).to(cuda)
+        fresh.load_state_dict(df.state_dict())
+        off_fresh = fresh.compute_offsets(pos, codes, None)
+    assert not torch.equal(off0.detach(), off1) and torch.equal(off1, off_fresh)
+
+    he = HashEnsemble(HashEnsembleConfig(4, TCNNHashEncodingConfig(n_levels=4, log2_hashmap_size=10), True, True)).to(cuda)
+    with torch.no_grad():
+        he.tables.mul_(1000)
+    x = torch.rand((500, 3), device=cuda)
+    code = torch.randn((500, 4), device=cuda)
+    opt = torch.optim.Adam([he.tables], lr=1e-2, fused=True)
+    y0 = he(x, code)
+    y0.float().square().sum().backward()
+    opt.step()
+    with torch.no_grad():
+        y1 = he(x, code)
+    assert torch.equal(he.half_tables(), he.tables.detach().half()) and not torch.equal(y0.detach(), y1)
