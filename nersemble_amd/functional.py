@@ -312,14 +312,15 @@ class _DeformFn(torch.autograd.Function):
                 gcode = torch.zeros_like(code_c).index_add_(0, code_slot.long(), gsamples)
             else:
                 gcode = gsamples
-        grads, off = [], 0
-        for shp in ctx.param_shapes:                      # views of the flat gradient, nsx.h order
+        sizes = []
+        for shp in ctx.param_shapes:
             n = 1
             for d in shp:
                 n *= d
-            grads.append(gparams[off:off + n].view(shp))
-            off += n
-        assert off == n_params
+            sizes.append(n)
+        assert sum(sizes) == n_params
+        # views of the flat gradient, nsx.h order (one split dispatch; biases are already 1-D)
+        grads = [g if len(shp) == 1 else g.view(shp) for g, shp in zip(torch.split(gparams, sizes), ctx.param_shapes)]
         return (None, gcode, None, None, None, None, None, *grads)
 
 
