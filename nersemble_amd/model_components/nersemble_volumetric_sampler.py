@@ -46,45 +46,46 @@ class NeRSembleVolumetricSampler(nn.Module):
 
         return sigma_fn
 
+    def _cull_to_camera_frusta(self) -> None:
+        """Cells seen by fewer than ``view_frustum_culling`` training cameras never hold samples (reference :90-93)."""
+        grid = self.camera_frustum_grid
+        if grid is None:
+            return
+        binaries = self.occupancy_grid.binaries
+        if grid.device != binaries.device:
+            grid = self.camera_frustum_grid = grid.to(binaries.device)
+        binaries[0] = binaries[0] & grid
+
+    @staticmethod
+    def _packed_samples(bundle: RayBundle, o: Tensor, d: Tensor, ray_indices: Tensor, t0: Tensor, t1: Tensor
+                        ) -> RaySamples:
+        """One RaySamples row per marched interval, rays gathered through ``ray_indices`` (flattened / packed layout)."""
+        cams = bundle.camera_indices
+        samples = RaySamples(
+            frustums=Frustums(origins=o[ray_indices], directions=d[ray_indices], starts=t0[..., None], ends=t1[..., None],
+                              pixel_area=torch.zeros((ray_indices.shape[0], 1), dtype=o.dtype, device=o.device)),
+            camera_indices=cams.contiguous()[ray_indices] if cams is not None else None)
+        if bundle.times is not None:
+            samples.times = bundle.times[ray_indices]
+        return samples
+
     def forward(self, ray_bundle: RayBundle, render_step_size: float, near_plane: float = 0.0,
                 far_plane: Optional[float] = None, alpha_thre: float = 0.01, cone_angle: float = 0.0,
                 early_stop_eps: float = 1e-4) -> Tuple[RaySamples, Tensor]:
-        rays_o = ray_bundle.origins.contiguous()
-        rays_d = ray_bundle.directions.contiguous()
-        times = ray_bundle.times
-        t_min = t_max = None
+        o, d = ray_bundle.origins.contiguous(), ray_bundle.directions.contiguous()
+        per_ray_near = per_ray_far = None
         if ray_bundle.nears is not None and ray_bundle.fars is not None:
-            t_min = ray_bundle.nears.contiguous().reshape(-1)
-            t_max = ray_bundle.fars.contiguous().reshape(-1)
-        if far_plane is None:
-            far_plane = 1e10
-        camera_indices = ray_bundle.camera_indices.contiguous() if ray_bundle.camera_indices is not None else None
-
-        if self.camera_frustum_grid is not None:
-            if self.camera_frustum_grid.device != self.occupancy_grid.binaries.device:
-                self.camera_frustum_grid = self.camera_frustum_grid.to(self.occupancy_grid.binaries.device)
-            # view-frustum culling only on the coarsest level (:90-93)
-            self.occupancy_grid.binaries[0] = self.occupancy_grid.binaries[0] & self.camera_frustum_grid
-
-        ray_indices, starts, ends = self.occupancy_grid.sampling(
-            rays_o=rays_o, rays_d=rays_d, t_min=t_min, t_max=t_max,
-            sigma_fn=self.get_sigma_fn(rays_o, rays_d, times), render_step_size=render_step_size,
-            near_plane=near_plane, far_plane=far_plane, stratified=self.training, cone_angle=cone_angle,
-            alpha_thre=alpha_thre, early_stop_eps=early_stop_eps)
-        if starts.shape[0] == 0:
-            # a single fake sample so downstream shapes stay valid (:109-115)
-            ray_indices = torch.zeros((1,), dtype=torch.long, device=rays_o.device)
-            starts = torch.ones((1,), dtype=starts.dtype, device=rays_o.device)
-            ends = torch.ones((1,), dtype=ends.dtype, device=rays_o.device)
-
-        origins = rays_o[ray_indices]
-        dirs = rays_d[ray_indices]
-        if camera_indices is not None:
-            camera_indices = camera_indices[ray_indices]
-        ray_samples = RaySamples(
-            frustums=Frustums(origins=origins, directions=dirs, starts=starts[..., None], ends=ends[..., None],
-                              pixel_area=torch.zeros_like(origins[:, :1])),
-            camera_indices=camera_indices)
-        if ray_bundle.times is not None:
-            ray_samples.times = ray_bundle.times[ray_indices]
-        return ray_samples, ray_indices
+            per_ray_near = ray_bundle.nears.contiguous().reshape(-1)
+            per_ray_far = ray_bundle.fars.contiguous().reshape(-1)
+        self._cull_to_camera_frusta()
+        ray_indices, t0, t1 = self.occupancy_grid.sampling(
+            rays_o=o, rays_d=d, t_min=per_ray_near, t_max=per_ray_far,
+            sigma_fn=self.get_sigma_fn(o, d, ray_bundle.times), render_step_size=render_step_size,
+            near_plane=near_plane, far_plane=1e10 if far_plane is None else far_plane, stratified=self.training,
+            cone_angle=cone_angle, alpha_thre=alpha_thre, early_stop_eps=early_stop_eps)
+        if t0.shape[0] == 0:
+            # nothing survived: one dummy interval on ray 0 keeps every downstream shape valid (reference :109-115)
+            ray_indices = torch.zeros((1,), dtype=torch.long, device=o.device)
+            t0 = torch.ones((1,), dtype=t0.dtype, device=o.device)
+            t1 = torch.ones((1,), dtype=t1.dtype, device=o.device)
+        return self._packed_samples(ray_bundle, o, d, ray_indices, t0, t1), ray_indices
