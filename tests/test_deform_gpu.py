@@ -119,3 +119,35 @@ def test_deform_backward_per_sample_codes(cuda):
     cc = codes.to(cuda).requires_grad_(True)
     dfc.compute_offsets(pos.to(cuda), cc, None).backward(goff.to(cuda))
     assert (cc.grad.cpu().double() - c64.grad).abs().max().item() <= 3e-2 * c64.grad.abs().max().item()
+
+
+def test_deform_kernels_are_race_free(cuda):
+    """The LDS-DMA pipelines (weight stages in the chain kernels, the operand ring of the weight-gradient kernel) are
+    ordered by counted waits and barriers only: a mis-ordered stage would show up as run-to-run differences.  The forward
+    and the per-sample code gradient involve no atomics and must be bit-identical across runs; the atomically
+    accumulated gradients may differ in summation order only."""
+    df = _field(5).to(cuda)
+    S = 40_000
+    g = torch.Generator(device=cuda).manual_seed(9)
+    pos = torch.rand((S, 3), device=cuda, generator=g) * (AABB[1] - AABB[0]).to(cuda) + AABB[0].to(cuda)
+    codes = torch.randn((S, 128), device=cuda, generator=g) * 0.3
+    goff = torch.randn((S, 3), device=cuda, generator=g)
+    table = torch.randn((24, 128), device=cuda, generator=g) * 0.3
+    slot = torch.randint(0, 24, (S,), device=cuda, generator=g, dtype=torch.int32)
+    ref_off = ref_gc = ref_gw = ref_gt = None
+    for it in range(6):
+        for p in df.parameters():
+            p.grad = None
+        c = codes.clone().requires_grad_(True)
+        off = df.compute_offsets(pos, c, 2.0)
+        off.backward(goff)
+        t = table.clone().requires_grad_(True)
+        df.compute_offsets(pos, t, 2.0, code_index=slot).backward(goff)
+        gw = torch.cat([p.grad.reshape(-1) for p in _ordered_params(df)])
+        if it == 0:
+            ref_off, ref_gc, ref_gw, ref_gt = off.detach().clone(), c.grad.clone(), gw.clone(), t.grad.clone()
+        else:
+            assert torch.equal(off.detach(), ref_off)
+            assert torch.equal(c.grad, ref_gc)
+            assert (gw - ref_gw).abs().max().item() <= 1e-4 * ref_gw.abs().max().item()
+            assert (t.grad - ref_gt).abs().max().item() <= 1e-4 * ref_gt.abs().max().item()
