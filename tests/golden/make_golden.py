@@ -15,6 +15,8 @@ What is pinned (reference-owned code, executed for real):
   * BaseModel.get_dist_loss sample selection / midpoint construction (models/base.py:224-249) with a
     stub flatten_eff_distloss that records its arguments.
   * BaseModel masked-RGB / alpha / empty / near / depth losses (models/base.py:90-222) on a synthetic packed batch.
+  * NeRSemblePixelSampler.collate_image_dataset_batch (data/nersemble_pixel_sampler.py:23-69) under a fixed seed
+    (nerfstudio's PixelSampler base restated as a stub).
   * extract_top_k_connected_component / filter_occupancy_grid (util/connected_components.py:28-139) on a synthetic
     40^3 grid (numpy + scipy.ndimage for real; cc3d.largest_k stubbed with scipy.ndimage.label).
 Stubs (third-party packages that are not installed): tinycudann, nerfstudio.*, jaxtyping,
@@ -449,10 +451,56 @@ def gen_occupancy_filter(out):
     out["occ_binaries_out"] = np.packbits(g.binaries.numpy().ravel())
 
 
+def gen_pixel_sampler(out):
+    """NeRSemblePixelSampler.collate_image_dataset_batch (data/nersemble_pixel_sampler.py:23-69), run for real on a
+    synthetic image batch under a fixed torch seed.  Stub: nerfstudio's PixelSampler base class (constructor +
+    uniform ``sample_method``, restated from nerfstudio 0.3.1)."""
+    ps = _mod("nerfstudio.data.pixel_samplers") if "nerfstudio.data.pixel_samplers" not in sys.modules \
+        else sys.modules["nerfstudio.data.pixel_samplers"]
+    if "nerfstudio.data" not in sys.modules:
+        _mod("nerfstudio.data")
+
+    class PixelSampler:
+        def __init__(self, num_rays_per_batch, keep_full_image=False, **kwargs):
+            self.num_rays_per_batch = num_rays_per_batch
+            self.keep_full_image = keep_full_image
+
+        def sample_method(self, batch_size, num_images, image_height, image_width, mask=None, device="cpu"):
+            if isinstance(mask, torch.Tensor):
+                nonzero_indices = torch.nonzero(mask[..., 0], as_tuple=False)
+                chosen = torch.randint(0, nonzero_indices.shape[0], (batch_size,))
+                return nonzero_indices[chosen]
+            return torch.floor(torch.rand((batch_size, 3), device=device)
+                               * torch.tensor([num_images, image_height, image_width], device=device)).long()
+
+    ps.PixelSampler = PixelSampler
+    from nersemble.nerfstudio.data.nersemble_pixel_sampler import NeRSemblePixelSampler
+    g = torch.Generator().manual_seed(11)
+    N, Hh, Ww = 5, 12, 9
+    batch = {"image": torch.rand((N, Hh, Ww, 3), generator=g),
+             "alpha_map": (torch.rand((N, Hh, Ww, 1), generator=g) * 255).to(torch.uint8),
+             "depth_map": torch.rand((N, Hh, Ww), generator=g),
+             "timesteps": torch.tensor([3, 3, 17, 0, 42]), "cam_ids": torch.tensor([0, 5, 2, 2, 7]),
+             "image_idx": torch.tensor([10, 11, 25, 4, 31])}
+    for k, v in batch.items():
+        out[f"px_in_{k}"] = v.numpy()
+    sampler = NeRSemblePixelSampler(64, additional_metadata=["depth_map", "timesteps", "cam_ids"])
+    torch.manual_seed(2024)
+    col = sampler.collate_image_dataset_batch({k: v.clone() for k, v in batch.items()}, 64)
+    for k, v in col.items():
+        out[f"px_out_{k}"] = v.numpy()
+    mask = (torch.rand((N, Hh, Ww, 1), generator=g) > 0.6)
+    torch.manual_seed(2025)
+    colm = sampler.collate_image_dataset_batch({**{k: v.clone() for k, v in batch.items()}, "mask": mask}, 32)
+    out["px_mask"] = mask.numpy()
+    for k, v in colm.items():
+        out[f"px_outm_{k}"] = v.numpy()
+
+
 def main():
     """python tests/golden/make_golden.py [hash_ensemble] [deformation] [misc] [occupancy_filter]   (default: all)"""
     torch.set_num_threads(4)
-    which = set(sys.argv[1:]) or {"hash_ensemble", "deformation", "misc", "occupancy_filter"}
+    which = set(sys.argv[1:]) or {"hash_ensemble", "deformation", "misc", "occupancy_filter", "pixel_sampler"}
     written = []
     if "hash_ensemble" in which:
         a = {}
@@ -476,6 +524,11 @@ def main():
         gen_occupancy_filter(d)
         np.savez_compressed(os.path.join(HERE, "occupancy_filter.npz"), **d)
         written.append("occupancy_filter.npz")
+    if "pixel_sampler" in which:
+        e = {}
+        gen_pixel_sampler(e)
+        np.savez_compressed(os.path.join(HERE, "pixel_sampler.npz"), **e)
+        written.append("pixel_sampler.npz")
     for f in written:
         print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")
 
