@@ -238,7 +238,9 @@ __device__ __forceinline__ void run_merge(uint32_t key, float val, int s7, bool&
 //   dL/dtable[e][f][h] = sum_slot G[e][slot][f] * code'[slot][h],  G[e][slot][f] = sum_{b in slot} w * dout_f.
 // The kernel then scatters only 2 scalars per (sample, level, corner) into G (one corner per lane) instead of
 // 2*H values; nsx_hash_grad_expand turns G into the table gradient with a tiny dense contraction.
-template <int H, int WAVES, bool FACTORED>
+// DCODE = false: the caller wants no code gradient (e.g. while the coarse-to-fine window pins the code to ones,
+// hash_ensemble.py:114-115): the per-grid accumulation -- a fifth of the kernel's VALU work -- is compiled out.
+template <int H, int WAVES, bool FACTORED, bool DCODE>
 __global__ __launch_bounds__(WAVES * kWave) void ens_bwd_kernel(
     const float* __restrict__ x, int64_t B, const uint8_t* __restrict__ tab, const nsx_grid_geom g,
     const float* __restrict__ code, int64_t code_stride, const int32_t* __restrict__ code_index,
@@ -302,7 +304,7 @@ __global__ __launch_bounds__(WAVES * kWave) void ens_bwd_kernel(
                     const half2_t t = as_half2(v[k].d[0]);
                     const float cf = (float)cw[0].x;
                     blended = (g0 * (float)t.x + g1 * (float)t.y) * cf;
-                    dc[0] = __fmaf_rn(w[k], g0 * (float)t.x + g1 * (float)t.y, dc[0]);
+                    if constexpr (DCODE) dc[0] = __fmaf_rn(w[k], g0 * (float)t.x + g1 * (float)t.y, dc[0]);
                     if (gdst) {
                         atomicAdd(gdst + 0, w[k] * g0 * cf);
                         atomicAdd(gdst + 1, w[k] * g1 * cf);
@@ -316,8 +318,10 @@ __global__ __launch_bounds__(WAVES * kWave) void ens_bwd_kernel(
                         const half2_t t = as_half2(v[k].d[j]);
                         const float wg = w[k] * gf;
                         blended = __fmaf_rn(gf, dot2(v[k].d[j], cw[j], 0.f), blended);
-                        dc[2 * j + 0] = __fmaf_rn(wg, (float)t.x, dc[2 * j + 0]);
-                        dc[2 * j + 1] = __fmaf_rn(wg, (float)t.y, dc[2 * j + 1]);
+                        if constexpr (DCODE) {
+                            dc[2 * j + 0] = __fmaf_rn(wg, (float)t.x, dc[2 * j + 0]);
+                            dc[2 * j + 1] = __fmaf_rn(wg, (float)t.y, dc[2 * j + 1]);
+                        }
                         if (gdst) {
                             atomicAdd(gdst + 2 * j + 0, wg * (float)cw[j].x);
                             atomicAdd(gdst + 2 * j + 1, wg * (float)cw[j].y);
@@ -377,7 +381,7 @@ __global__ __launch_bounds__(WAVES * kWave) void ens_bwd_kernel(
             if (q == 0 && valid) { dx[b * 3 + 0] = dxa; dx[b * 3 + 1] = dya; dx[b * 3 + 2] = dza; }
         }
         // code gradient: grid h receives contributions of both feature planes
-        if (dcode) {
+        if (DCODE && dcode) {
             if constexpr (H == 1) {
                 if (valid) dcode[b] = dc[0];
             } else if constexpr (C::NDW > C::DPF) {   // H = 2, 4: features are dwords [0,DPF) and [DPF,2DPF)
@@ -569,14 +573,18 @@ static int launch_bwd(const float* x, int64_t B, const nsx_half* tables, int Hre
     int64_t blocks = (n_tiles + WAVES - 1) / WAVES;
     const int64_t cap = (int64_t)num_cus() * 8;
     if (blocks > cap) blocks = cap;
-    if (n_slots > 0)
-        hipLaunchKernelGGL((ens_bwd_kernel<H, WAVES, true>), dim3((unsigned)blocks), dim3(WAVES * kWave), 0, st, x, B,
-                           reinterpret_cast<const uint8_t*>(tables), *g, code, code_stride, code_index, window,
-                           Hreal, dout, dtables, dcode, dx, n_tiles, n_slots, nonfinite);
-    else
-        hipLaunchKernelGGL((ens_bwd_kernel<H, WAVES, false>), dim3((unsigned)blocks), dim3(WAVES * kWave), 0, st, x,
-                           B, reinterpret_cast<const uint8_t*>(tables), *g, code, code_stride, code_index, window,
-                           Hreal, dout, dtables, dcode, dx, n_tiles, 0, nullptr);
+#define NSX_BWD_LAUNCH(FACT, DC, NS, NF)                                                                            \
+    hipLaunchKernelGGL((ens_bwd_kernel<H, WAVES, FACT, DC>), dim3((unsigned)blocks), dim3(WAVES * kWave), 0, st, x, B, \
+                       reinterpret_cast<const uint8_t*>(tables), *g, code, code_stride, code_index, window, Hreal,    \
+                       dout, dtables, dcode, dx, n_tiles, NS, NF)
+    if (n_slots > 0) {
+        if (dcode) NSX_BWD_LAUNCH(true, true, n_slots, nonfinite);
+        else NSX_BWD_LAUNCH(true, false, n_slots, nonfinite);
+    } else {
+        if (dcode) NSX_BWD_LAUNCH(false, true, 0, nullptr);
+        else NSX_BWD_LAUNCH(false, false, 0, nullptr);
+    }
+#undef NSX_BWD_LAUNCH
     NSX_LAUNCH_CHECK("nsx_hash_ensemble_bwd launch");
     return NSX_OK;
 }
