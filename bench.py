@@ -49,6 +49,8 @@ def kernel_model(name: str, ints, H: int, total_entries: int):
         params = total_entries * 2.0 * Hp
         # master, m, v read + written (24 B) + fp16 copy written (2 B) per parameter + G read once
         return "hbm", params * 26.0 + ints[0] * total_entries * 8.0
+    if name == "nsx_adam_dense_f16grad":                      # (n, step): the rank's shard in data-parallel runs
+        return "hbm", ints[0] * 28.0                          # fp16 gradient + master / m / v read + written + fp16 copy
     if name == "nsx_deform_fwd":                              # (S, code_stride)
         return "mfma", ints[0] * DEFORM_FWD_FLOPS
     if name == "nsx_deform_bwd":                              # recompute fwd + dX chain + weight gradients = 3x fwd
@@ -88,6 +90,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="p030_h32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to exercise the "
+                                                      "multi-rank control flow where RCCL cannot run)")
+    ap.add_argument("--ranks-share-gpu0", action="store_true",
+                    help="testing aid: every rank uses cuda:0 (several ranks on a 1-GPU box, with --backend gloo)")
     ap.add_argument("--reserve-gb", type=float, default=24.0,
                     help="allocator warm-up: device memory handed to torch's caching allocator before the first step")
     ap.add_argument("--no-kernel-events", action="store_true",
@@ -97,10 +103,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.ranks_share_gpu0:
+        local_rank = 0
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        if a.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        else:
+            dist.init_process_group(backend=a.backend)
     assert a.gpus == world, f"--gpus {a.gpus} but WORLD_SIZE={world}"
     dev = f"cuda:{local_rank}"
     torch.cuda.set_device(local_rank)
@@ -149,7 +160,8 @@ def main():
     _lib.profiler.watch = {"nsx_hash_ensemble_fwd", "nsx_hash_ensemble_bwd_factored", "nsx_hash_ensemble_bwd",
                            "nsx_adam_hash_factored", "nsx_adam_dense", "nsx_deform_fwd", "nsx_deform_bwd",
                            "nsx_mlp_fwd", "nsx_mlp_bwd", "nsx_check_finite", "nsx_march_count", "nsx_march_fill",
-                           "nsx_hash_grad_expand"}
+                           "nsx_hash_grad_expand", "nsx_hash_grad_expand_f16", "nsx_adam_dense_f16grad",
+                           "nsx_check_finite_f16"}
     if not a.no_kernel_events:
         _lib.profiler.prewarm(2 * 16 * a.steps + 64)
     if world > 1:

@@ -144,3 +144,47 @@ def test_training_with_sharded_table_adam(cuda, single_rank_group):
     l_s, l_f = run(True), run(False)
     assert all(np.isfinite(l_s)) and l_s[-1] < l_s[0]
     assert np.allclose(l_s, l_f, rtol=5e-3, atol=1e-5), (l_s, l_f)
+
+
+def _two_rank_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)         # both ranks on cuda:0: RCCL cannot, gloo can
+    from nersemble_amd.engine.sharded_adam import ShardedTableAdam
+    from nersemble_amd.workloads import build_workload
+    torch.manual_seed(19980801)                                          # identical initial weights
+    trainer, data, _ = build_workload("p030_h16", device="cuda:0", small=True, n_rays=256, rank=rank, world_size=world)
+    assert any(isinstance(o, ShardedTableAdam) for o in trainer.optimizers.values())
+    losses = []
+    for step in range(4):
+        loss, _, _ = trainer.train_iteration(step, *data.next_train(step))
+        losses.append(loss.item())
+    trainer.flush_scheduler_step()
+    model = trainer.model
+    f16 = model.field.hash_ensemble.half_tables().detach().cpu()
+    small = torch.cat([p.detach().reshape(-1).cpu() for n, p in model.named_parameters() if "tables" not in n])
+    trainer.consolidate()
+    master = model.field.hash_ensemble.tables.detach().cpu()
+    torch.save({"losses": losses, "f16": f16, "small": small, "master": master,
+                "rays": data.next_train(99)[0].directions.cpu()}, os.path.join(out_dir, f"r{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_training_on_one_gpu(cuda, tmp_path):
+    """The data-parallel step with the REAL kernels and world_size 2: two processes share the GPU (gloo moves the
+    collectives).  Replicas must stay identical; the sharded fp32 master, gathered, must round to the working tables."""
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_two_rank_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = torch.load(tmp_path / "r0.pt"), torch.load(tmp_path / "r1.pt")
+    assert all(np.isfinite(r0["losses"])) and all(np.isfinite(r1["losses"]))
+    assert r0["losses"] != r1["losses"] and not torch.equal(r0["rays"], r1["rays"])      # different rays per rank
+    assert torch.equal(r0["f16"], r1["f16"])                                               # identical replicas
+    assert torch.equal(r0["small"], r1["small"])
+    assert torch.equal(r0["master"], r1["master"]) and torch.equal(r0["master"].half(), r0["f16"])
+    init = r0["master"].numel()
+    assert (r0["f16"].float() - r0["master"]).abs().max().item() < 1e-3 and init > 0
