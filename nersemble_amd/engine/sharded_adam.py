@@ -117,7 +117,26 @@ class ShardedTableAdam(torch.optim.Optimizer):
             torch.maximum(found_inf, sink.nonfinite.to(found_inf.dtype), out=found_inf)
 
     @torch.no_grad()
-    def step(self, found_inf: Optional[torch.Tensor] = None, inv_scale: Optional[torch.Tensor] = None):
+    def step(self, found_inf: Optional[torch.Tensor] = None, inv_scale: Optional[torch.Tensor] = None,
+             side_stream: Optional["torch.cuda.Stream"] = None):
+        """Adam on the shard + all-gather of the working tables.  ``side_stream``: run both there -- nothing else in the
+        step's tail nor the next step's ray marching needs the tables; ``HashEnsemble.wait_tables`` orders the next
+        reader after the all-gather (same scheme as HashTableAdam.step)."""
+        he = self.he
+        if side_stream is None or not he.tables.is_cuda:
+            return self._step_now(found_inf, inv_scale)
+        he.wait_tables()
+        side_stream.wait_stream(torch.cuda.current_stream(he.tables.device))
+        with torch.cuda.stream(side_stream):
+            self._step_now(found_inf, inv_scale)
+            done = torch.cuda.Event()
+            done.record(side_stream)
+        for t in (found_inf, inv_scale):
+            if t is not None:
+                t.record_stream(side_stream)
+        he._tables_ready = done
+
+    def _step_now(self, found_inf, inv_scale):
         he, b = self.he, self._buffers()
         group = self.param_groups[0]
         self._step += 1
@@ -144,6 +163,7 @@ class ShardedTableAdam(torch.optim.Optimizer):
     @torch.no_grad()
     def gather_master(self) -> None:
         """Rebuild the full fp32 master tables on every rank from the shards (call before ``state_dict()``)."""
+        self.he.wait_tables()                    # a step may still be running on the optimizer stream
         p = self.he.tables
         full = torch.zeros((self.shard * self.world_size,), dtype=torch.float32, device=p.device)
         mine = full[self.lo:self.lo + self.shard]

@@ -113,7 +113,7 @@ class NeRSembleTrainer:
             if isinstance(opt, HashTableAdam):
                 opt.step(found_inf=f, inv_scale=inv_scale, side_stream=self._opt_stream)
             elif isinstance(opt, ShardedTableAdam):
-                opt.step(found_inf=f, inv_scale=inv_scale)
+                opt.step(found_inf=f, inv_scale=inv_scale, side_stream=self._opt_stream)
             elif any(p.grad is not None for pg in opt.param_groups for p in pg["params"]):
                 if opt.defaults.get("fused"):
                     opt.found_inf, opt.grad_scale = f.reshape(()), None
