@@ -20,7 +20,10 @@ class AccumulationRenderer(nn.Module):
 class RGBRenderer(nn.Module):
     def __init__(self, background_color="white"):
         super().__init__()
-        assert background_color in ("white", "black"), "synthetic NeRSemble path uses a constant background"
+        if background_color not in ("white", "black"):
+            raise NotImplementedError(f"background_color={background_color!r}: NeRSemble trains with a constant background "
+                                      "(scripts/train/train_nersemble.py:193 sets 'white'); nerfstudio's 'random' / "
+                                      "'last_sample' modes are not part of the path")
         self.background_color = background_color
 
     def forward(self, rgb: Tensor, weights: Tensor, ray_indices: Tensor, num_rays: int,
