@@ -215,7 +215,8 @@ def ptr(t, dtype=None) -> c_void_p:
 
 
 def stream() -> c_void_p:
-    return c_void_p(torch.cuda.current_stream().cuda_stream)
+    """The raw HIP stream torch is currently enqueueing on (what every native call launches into)."""
+    return c_void_p(torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))
 
 
 def grid_geometry(n_levels=16, per_level_scale=1.4472692012786865, base_resolution=16,
