@@ -253,15 +253,25 @@ def deform_param_count() -> int:
     return int(lib().nsx_deform_param_count())
 
 
+_WINDOW7_CACHE = {}
+
+
 def deform_window7(windows_param, n_freq: int = 7):
     """Per-frequency cosine window (windowed_nerf_encoding.py:76-92) as a host float array; None -> no window."""
     if windows_param is None:
         return None
+    key = (float(windows_param), n_freq)
+    hit = _WINDOW7_CACHE.get(key)
+    if hit is not None:
+        return hit
     import numpy as np
     bands = np.linspace(0.0, n_freq - 1, n_freq, dtype=np.float32)
     x = np.clip(np.float32(windows_param) - bands, 0, 1)
     w = (0.5 * (1 - np.cos(np.float32(np.pi) * x))).astype(np.float32)
-    return (C.c_float * 7)(*[float(v) for v in w])
+    if len(_WINDOW7_CACHE) > 64:
+        _WINDOW7_CACHE.clear()
+    _WINDOW7_CACHE[key] = (C.c_float * 7)(*[float(v) for v in w])
+    return _WINDOW7_CACHE[key]
 
 
 class _DeformFn(torch.autograd.Function):
