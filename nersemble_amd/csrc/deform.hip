@@ -382,8 +382,8 @@ __device__ __forceinline__ void store_tile_T(half_t* __restrict__ dst, int lane,
         // tile p = [2 K-steps][64 lanes][8 halfs]: each store instruction writes one contiguous KB, and the weight-gradient
         // kernel can copy the tile into LDS linearly and read it back conflict-free as MFMA operand fragments
         u32x4* out = reinterpret_cast<u32x4*>(dst + (size_t)p * 1024 + (size_t)lane * 8);
-        out[0] = o0;
-        out[64] = o1;
+        __builtin_nontemporal_store(o0, out);            // written once, read once by the weight-gradient kernel
+        __builtin_nontemporal_store(o1, out + 64);
     }
 }
 
