@@ -53,7 +53,7 @@ class SyntheticNeRSembleData:
         self.center = center.to(self.device)
         self.semi_axes = torch.tensor([0.9, 1.1, 1.2], device=self.device)
         self.camera_frustums = [TorchFrustum.from_camera(self.c2w[c].cpu(), focal, focal, width / 2, height / 2, width,
-                                                         height, near=0.2, far=1e3) for c in range(n_cameras)]
+                                                         height) for c in range(n_cameras)]
 
     # ---- analytic scene ---------------------------------------------------------------------------
     def _rotation(self, times: torch.Tensor) -> torch.Tensor:

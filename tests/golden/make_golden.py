@@ -19,6 +19,8 @@ What is pinned (reference-owned code, executed for real):
     (nerfstudio's PixelSampler base restated as a stub).
   * extract_top_k_connected_component / filter_occupancy_grid (util/connected_components.py:28-139) on a synthetic
     40^3 grid (numpy + scipy.ndimage for real; cc3d.largest_k stubbed with scipy.ndimage.label).
+  * Frustum.contains / contains_points (model_components/frustum.py) and Quantizer / DepthQuantizer / NormalsQuantizer
+    (util/quantization.py): imported and run as they are (numpy only) -> dataformat.npz.
 Stubs (third-party packages that are not installed): tinycudann, nerfstudio.*, jaxtyping,
 torch_efficient_distloss, cc3d, nerfacc.  The nerfstudio MLP / NeRFEncoding / SceneBox stubs restate nerfstudio 0.3.1
  -> that sub-part stays "parity unpinned".
@@ -497,10 +499,61 @@ def gen_pixel_sampler(out):
         out[f"px_outm_{k}"] = v.numpy()
 
 
+def gen_dataformat(out):
+    """Frustum / HalfSpaceCollection (model_components/frustum.py:17-26,60-100,148-193 -- the numpy twin of the
+    TorchFrustum the dataparser builds, which needs ``.cuda()``) and the depth / normal codecs
+    (util/quantization.py:33-120), all imported and run for real: no stubs."""
+    from nersemble.nerfstudio.model_components.frustum import Frustum
+    from nersemble.util.quantization import DepthQuantizer, NormalsQuantizer, Quantizer
+    rng = np.random.default_rng(77)
+    poses, ks, masks, singles = [], [], [], []
+    pts = rng.uniform(-3.0, 3.0, size=(4096, 3))
+    dims = (1100, 1604)
+    for i in range(4):
+        # random OpenCV pose looking roughly at the origin from ~9 units away
+        eye = rng.normal(size=3)
+        eye = 9.0 * eye / np.linalg.norm(eye)
+        fwd = -eye / np.linalg.norm(eye) + 0.05 * rng.normal(size=3)
+        fwd /= np.linalg.norm(fwd)
+        right = np.cross(fwd, np.array([0.0, 0.0, 1.0]) if abs(fwd[2]) < 0.9 else np.array([0.0, 1.0, 0.0]))
+        right /= np.linalg.norm(right)
+        down = np.cross(fwd, right)
+        pose = np.eye(4)
+        pose[:3, 0], pose[:3, 1], pose[:3, 2], pose[:3, 3] = right, down, fwd, eye
+        k = np.array([[2200.0 + 50 * i, 0.0, 550.0 + 3 * i], [0.0, 2190.0 - 20 * i, 802.0 - 5 * i], [0.0, 0.0, 1.0]])
+        fr = Frustum(pose, k, dims)
+        poses.append(pose), ks.append(k)
+        masks.append(fr.contains_points(pts))
+        singles.append(np.array([fr.contains(p) for p in pts[:16]]))
+    out["fr_pose"], out["fr_k"], out["fr_dims"] = np.stack(poses), np.stack(ks), np.array(dims)
+    out["fr_points"], out["fr_mask"], out["fr_single"] = pts, np.stack(masks), np.stack(singles)
+
+    depth = rng.uniform(0.0, 2.4, size=(48, 40)).astype(np.float32)
+    depth[rng.random(depth.shape) < 0.2] = 0
+    out["dq_in"] = depth.copy()
+    dq = DepthQuantizer()
+    codes = dq.encode(depth.copy())
+    out["dq_codes"], out["dq_decoded"] = codes, dq.decode(codes)
+    known = np.array([[0, 1, 2, 32768, 65535]], dtype=np.uint16)
+    out["dq_known_codes"], out["dq_known"] = known, dq.decode(known)
+    q8 = Quantizer(min_values=-1.0, max_values=3.0, bits=8, separate_mask=False)
+    vals = rng.uniform(-1.0, 3.0, size=(17, 5))
+    out["q8_in"], out["q8_codes"] = vals, q8.encode(vals.copy())
+    out["q8_decoded"] = q8.decode(out["q8_codes"])
+    normals = rng.normal(size=(24, 20, 3))
+    normals /= np.linalg.norm(normals, axis=-1, keepdims=True)
+    normals[..., 2] = -np.abs(normals[..., 2]) * 0.4          # camera-facing: theta within [pi/3, pi]
+    normals /= np.linalg.norm(normals, axis=-1, keepdims=True)
+    normals[rng.random(normals.shape[:2]) < 0.25] = 0
+    nq = NormalsQuantizer()
+    ncodes = nq.encode(normals.copy())
+    out["nq_in"], out["nq_codes"], out["nq_decoded"] = normals, ncodes, nq.decode(ncodes)
+
+
 def main():
-    """python tests/golden/make_golden.py [hash_ensemble] [deformation] [misc] [occupancy_filter]   (default: all)"""
+    """python tests/golden/make_golden.py [hash_ensemble] [deformation] [misc] [occupancy_filter] [pixel_sampler] [dataformat]   (default: all)"""
     torch.set_num_threads(4)
-    which = set(sys.argv[1:]) or {"hash_ensemble", "deformation", "misc", "occupancy_filter", "pixel_sampler"}
+    which = set(sys.argv[1:]) or {"hash_ensemble", "deformation", "misc", "occupancy_filter", "pixel_sampler", "dataformat"}
     written = []
     if "hash_ensemble" in which:
         a = {}
@@ -529,6 +582,11 @@ def main():
         gen_pixel_sampler(e)
         np.savez_compressed(os.path.join(HERE, "pixel_sampler.npz"), **e)
         written.append("pixel_sampler.npz")
+    if "dataformat" in which:
+        f_ = {}
+        gen_dataformat(f_)
+        np.savez_compressed(os.path.join(HERE, "dataformat.npz"), **f_)
+        written.append("dataformat.npz")
     for f in written:
         print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")
 

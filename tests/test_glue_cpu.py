@@ -98,3 +98,65 @@ def test_base_model_losses_match_reference(golden_dir):
     assert abs(float(al) - z["ls_alpha_loss"][0]) <= 1e-7
     dl = m.get_depth_loss(batch, torch.from_numpy(z["ls_depth_pred"]))
     assert abs(float(dl) - z["ls_depth_loss"][0]) <= 1e-8
+
+
+def test_frustum_matches_reference(golden_dir):
+    """TorchFrustum(cam_to_world, intrinsics, image_dimensions) vs the reference's numpy Frustum on 4 random OpenCV
+    poses x 4096 points: identical containment masks, single-point ``contains`` and the >=k-views culling count."""
+    from nersemble_amd.model_components.frustum import TorchFrustum, visibility_grid
+    z = np.load(f"{golden_dir}/dataformat.npz")
+    pts = torch.from_numpy(z["fr_points"])
+    dims = tuple(int(v) for v in z["fr_dims"])
+    frusta = [TorchFrustum(torch.from_numpy(p), torch.from_numpy(k), dims) for p, k in zip(z["fr_pose"], z["fr_k"])]
+    for i, fr in enumerate(frusta):
+        assert fr.normals.dtype == torch.float64 and torch.allclose(fr.normals.norm(dim=1), torch.ones(4).double())
+        assert np.array_equal(fr.contains_points(pts).numpy(), z["fr_mask"][i])
+        assert [fr.contains(p) for p in pts[:16]] == z["fr_single"][i].tolist()
+        # float32 points are promoted to the planes' float64 exactly like the reference's ``points - offsets``
+        d32 = fr.signed_distances(pts.float())
+        assert d32.dtype == torch.float64
+    # an OpenGL pose (camera looks along -z, y up) through the convenience constructor == its OpenCV twin
+    gl = torch.from_numpy(z["fr_pose"][0]).clone()
+    gl[:3, 1:3] = -gl[:3, 1:3]
+    k = z["fr_k"][0]
+    twin = TorchFrustum.from_camera(gl, k[0, 0], k[1, 1], k[0, 2], k[1, 2], *dims)
+    assert np.array_equal(twin.contains_points(pts).numpy(), z["fr_mask"][0])
+    # the sampler's culling lattice: linspace end points included, >= 2 views
+    aabb = torch.tensor([[-3.0, -3.0, -3.0], [3.0, 3.0, 3.0]])
+    grid = visibility_grid(frusta, aabb, (9, 8, 7), 2, "cpu")
+    lin = [torch.linspace(-3, 3, n) for n in (9, 8, 7)]
+    lattice = torch.stack(torch.meshgrid(*lin, indexing="ij"), -1).reshape(-1, 3)
+    want = sum(f.contains_points(lattice).int() for f in frusta) >= 2
+    assert grid.shape == (9, 8, 7) and torch.equal(grid.reshape(-1), want)
+
+
+def test_quantizers_match_reference(golden_dir):
+    """Depth / normal map codecs (data format on the input side of the path) vs the reference's util/quantization.py:
+    bit-identical codes, identical decoded float32 values, known answers for the reserved mask code."""
+    from nersemble_amd.util.quantization import DepthQuantizer, NormalsQuantizer, Quantizer
+    z = np.load(f"{golden_dir}/dataformat.npz")
+    dq = DepthQuantizer()
+    depth = z["dq_in"].copy()
+    codes = dq.encode(depth)
+    assert codes.dtype == np.uint16 and np.array_equal(codes, z["dq_codes"])
+    assert (depth[z["dq_in"] > 2] == 0).all()                      # outliers masked in place, like the reference
+    dec = dq.decode(codes)
+    assert dec.dtype == z["dq_decoded"].dtype and np.array_equal(dec, z["dq_decoded"])
+    assert np.array_equal(dq.decode(z["dq_known_codes"]), z["dq_known"])
+    assert dq.decode(np.array([[0, 1, 65535]], dtype=np.uint16)).tolist() == [[0.0, 0.0, 2.0]]
+    q8 = Quantizer(min_values=-1.0, max_values=3.0, bits=8, separate_mask=False)
+    c8 = q8.encode(z["q8_in"].copy())
+    assert c8.dtype == np.uint8 and np.array_equal(c8, z["q8_codes"])
+    assert np.array_equal(q8.decode(c8), z["q8_decoded"])
+    nq = NormalsQuantizer()
+    nc = nq.encode(z["nq_in"].copy())
+    assert np.array_equal(nc, z["nq_codes"])
+    nd = nq.decode(nc)
+    assert np.array_equal(nd, z["nq_decoded"])
+    present = (z["nq_in"] != 0).any(-1)
+    assert np.abs(nd[present] - z["nq_in"][present]).max() < 0.03  # 8-bit angles
+    assert (nd[~present] == 0).all()
+    try:
+        dq.encode(np.array([[-0.0, 1.0], [2.0, 5.0]], dtype=np.float32))   # > max is masked, not an error
+    except AssertionError:
+        raise AssertionError("DepthQuantizer must mask out-of-range depth")
