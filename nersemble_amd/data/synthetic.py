@@ -96,6 +96,28 @@ class SyntheticNeRSembleData:
         dirs_w = dirs_w / dirs_w.norm(dim=-1, keepdim=True)
         return c2w[:, :3, 3].contiguous(), dirs_w.contiguous()
 
+    def eval_cameras(self, timesteps, downscale: int = 16):
+        """``Cameras`` of the 4 held-out views x the given timesteps (what nerfstudio's eval dataloader iterates)."""
+        from ..cameras import Cameras
+        cams = self.eval_cams.repeat(len(timesteps))
+        times = torch.tensor([t / max(self.n_timesteps - 1, 1) for t in timesteps for _ in self.eval_cams])
+        cameras = Cameras(self.c2w[cams].cpu(), self.focal, self.focal, self.width / 2, self.height / 2, self.width,
+                          self.height, times=times)
+        cameras.rescale_output_resolution(1.0 / downscale)
+        return cameras
+
+    def eval_views(self, timesteps, downscale: int = 16):
+        """(camera_ray_bundle [H, W], batch) per held-out view, like ``fixed_indices_eval_dataloader``: ``batch`` has
+        ``image [H,W,3]``, ``alpha_map [H,W,1] uint8``, ``depth_maps [H,W]`` and ``cam_ids`` = index of the eval cam."""
+        cameras = self.eval_cameras(timesteps, downscale).to(self.device)
+        for i in range(cameras.size):
+            bundle = cameras.generate_rays(i)
+            h, w = bundle.shape
+            flat = bundle.flatten()
+            rgb, alpha, depth = self.render_ground_truth(flat.origins, flat.directions, flat.times.reshape(-1))
+            yield bundle, {"image": rgb.view(h, w, 3), "alpha_map": alpha.view(h, w, 1), "depth_maps": depth.view(h, w),
+                           "cam_ids": torch.tensor(i % len(self.eval_cams))}
+
     def next_train(self, step: int) -> Tuple[RayBundle, Dict[str, torch.Tensor]]:
         g, dev = self.gen, self.device
         img_cams = self.train_cams[torch.randint(0, len(self.train_cams), (self.n_images,), device=dev, generator=g)]

@@ -155,6 +155,15 @@ class NeRSembleNGPModel(BaseModel):
         self.renderer_depth = DepthRenderer(method="expected")
         self.renderer_deformation = DeformationRenderer()
 
+        # image metrics of the evaluation path (:158-160)
+        from ..util.metrics import (LearnedPerceptualImagePatchSimilarity, PeakSignalNoiseRatio,
+                                    structural_similarity_index_measure)
+        self.psnr = PeakSignalNoiseRatio(data_range=1.0)
+        self.ssim = structural_similarity_index_measure
+        self.rgb_loss = nn.MSELoss()
+        # kept out of the module tree: its (learned, externally supplied) weights are not part of a checkpoint
+        self.__dict__["lpips"] = LearnedPerceptualImagePatchSimilarity(normalize=True)
+
         self.sched_window_deform = None
         if cfg.window_deform_end >= 1:
             self.sched_window_deform = GenericScheduler(init_value=0, final_value=cfg.deformation_field_config.n_freq_pos,
@@ -345,6 +354,58 @@ class NeRSembleNGPModel(BaseModel):
 
     def forward(self, ray_bundle: RayBundle):
         return self.get_outputs(ray_bundle)
+
+    @torch.no_grad()
+    def get_outputs_for_camera_ray_bundle(self, camera_ray_bundle: RayBundle) -> Dict[str, Tensor]:
+        """Render one full image: the image-shaped bundle ``[H, W, ...]`` is walked in row-major chunks of
+        ``config.eval_num_rays_per_chunk`` rays and every tensor output is stitched back to ``[H, W, C]``
+        (nerfstudio ``Model.get_outputs_for_camera_ray_bundle``, UPSTREAM; the caller the reference's
+        ``evaluate_nersemble.py:141`` and ``util/render.py:39`` use).  Tuple-wrapped per-sample outputs are dropped,
+        as upstream drops everything that is not a tensor."""
+        height, width = camera_ray_bundle.shape[:2]
+        flat = camera_ray_bundle.flatten()
+        step = int(self.config.eval_num_rays_per_chunk)
+        pieces: Dict[str, List[Tensor]] = {}
+        for begin in range(0, len(flat), step):
+            for name, value in self.forward(flat[begin:begin + step]).items():
+                if torch.is_tensor(value):
+                    pieces.setdefault(name, []).append(value)
+        return {name: torch.cat(chunks).view(height, width, -1) for name, chunks in pieces.items()}
+
+    def get_image_metrics_and_images(self, outputs: Dict[str, Tensor], batch: Dict[str, Tensor]
+                                     ) -> Tuple[Dict[str, float], Dict[str, Tensor]]:
+        """Per-image evaluation (:424-500): PSNR / SSIM / LPIPS / MSE of the rendered ``[H, W, 3]`` image against
+        ``batch["image"]``, the same four on the alpha-composited-onto-white pair when the batch has an ``alpha_map``
+        (uint8 ``[H, W, 1]``), plus the side-by-side / colour-mapped images the trainer logs."""
+        from ..util import colormaps
+        image = batch["image"].to(self.device)
+        rgb = outputs["rgb"]
+        squared_error = ((rgb - image) ** 2).mean(dim=-1, keepdim=True)
+        images_dict = {
+            "img": torch.cat([image, rgb], dim=1),
+            "accumulation": colormaps.apply_colormap(outputs["accumulation"]),
+            "depth": colormaps.apply_depth_colormap(outputs["depth"], accumulation=outputs["accumulation"]),
+            "error": colormaps.apply_colormap(squared_error, colormaps.ColormapOptions(colormap="turbo")),
+        }
+        if "deformation" in outputs:
+            images_dict["deformation"] = colormaps.apply_scene_flow_colormap(outputs["deformation"])
+
+        def scores(target_hwc: Tensor, pred_hwc: Tensor, suffix: str) -> Dict[str, float]:
+            t = torch.moveaxis(target_hwc, -1, 0)[None]            # [1, C, H, W]
+            p = torch.moveaxis(pred_hwc, -1, 0)[None]
+            return {"psnr" + suffix: float(self.psnr(t, p)), "ssim" + suffix: float(self.ssim(t, p)),
+                    "lpips" + suffix: float(self.lpips(t, p)), "mse" + suffix: float(self.rgb_loss(t, p))}
+
+        metrics_dict = scores(image, rgb, "")
+        # the trainer keys its image logging on the camera id, which has to travel as a float (:457-458)
+        metrics_dict["cam_id"] = float(batch["cam_ids"])
+        if "alpha_map" in batch:
+            alpha = torch.as_tensor(batch["alpha_map"]).to(rgb) / 255.0
+            image_masked = alpha * image + (1 - alpha)
+            rgb_masked = alpha * rgb + (1 - alpha)
+            metrics_dict.update(scores(image_masked, rgb_masked, "_masked"))
+            images_dict["img_masked"] = torch.cat([image_masked, rgb_masked], dim=1)
+        return metrics_dict, images_dict
 
     # ---- losses / metrics (:366-422) ---------------------------------------------------------------
     def _fused_step_losses(self, outputs, batch):

@@ -53,7 +53,29 @@ class RayBundle:
     times: Optional[Tensor] = None
 
     def __len__(self) -> int:
-        return self.origins.shape[0]
+        return self.origins.numel() // self.origins.shape[-1]
+
+    @property
+    def shape(self):
+        return tuple(self.origins.shape[:-1])
+
+    def _map(self, fn) -> "RayBundle":
+        def ap(t):
+            return fn(t) if isinstance(t, Tensor) else t
+        # metadata keys starting with "_" are per-batch (not per-ray) entries and are passed through untouched
+        md = {k: (v if k.startswith("_") else ap(v)) for k, v in self.metadata.items()}
+        return RayBundle(ap(self.origins), ap(self.directions), ap(self.pixel_area), ap(self.camera_indices),
+                         ap(self.nears), ap(self.fars), md, ap(self.times))
+
+    def flatten(self) -> "RayBundle":
+        """Image-shaped bundle [H, W, ...] -> [H*W, ...] (row-major), nerfstudio's ``RayBundle.flatten``."""
+        lead = len(self.shape)
+        return self._map(lambda t: t.reshape(-1, *t.shape[lead:]))
+
+    def get_row_major_sliced_ray_bundle(self, start_idx: int, end_idx: int) -> "RayBundle":
+        """Rays ``start_idx:end_idx`` of the flattened bundle (nerfstudio API used by
+        ``Model.get_outputs_for_camera_ray_bundle``)."""
+        return self.flatten()[start_idx:end_idx]
 
     def to(self, device) -> "RayBundle":
         def mv(t):

@@ -1,0 +1,277 @@
+"""Evaluation-side callers of the path: image metrics, full-image rendering, result aggregation,
+trajectory rendering.  CPU tests use a stand-in model; the GPU test renders through libnsx."""
+import math
+import os
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+
+def _ssim_numpy(p, t, sigma=1.5, k1=0.01, k2=0.03, data_range=None):
+    """Independent float64 SSIM: separable Gaussian moments with scipy, valid region only."""
+    from scipy.ndimage import correlate1d
+    r = int(3.5 * sigma + 0.5)
+    x = np.arange(-r, r + 1, dtype=np.float64)
+    g = np.exp(-0.5 * (x / sigma) ** 2)
+    g /= g.sum()
+
+    def blur(a):
+        a = correlate1d(a, g, axis=-2, mode="constant")
+        a = correlate1d(a, g, axis=-1, mode="constant")
+        return a[..., r:-r, r:-r]
+    p, t = p.astype(np.float64), t.astype(np.float64)
+    if data_range is None:
+        data_range = max(p.max() - p.min(), t.max() - t.min())
+    c1, c2 = (k1 * data_range) ** 2, (k2 * data_range) ** 2
+    mp, mt = blur(p), blur(t)
+    vp, vt, cov = blur(p * p) - mp * mp, blur(t * t) - mt * mt, blur(p * t) - mp * mt
+    idx = ((2 * mp * mt + c1) * (2 * cov + c2)) / ((mp * mp + mt * mt + c1) * (vp + vt + c2))
+    return idx.reshape(idx.shape[0], -1).mean(-1).mean()
+
+
+def test_psnr_and_ssim_against_independent_computation():
+    from nersemble_amd.util.metrics import PeakSignalNoiseRatio, structural_similarity_index_measure as ssim
+    g = torch.Generator().manual_seed(0)
+    t = torch.rand((2, 3, 40, 33), generator=g)
+    p = (t + 0.1 * torch.randn(t.shape, generator=g)).clamp(0, 1)
+    psnr = PeakSignalNoiseRatio(data_range=1.0)
+    assert abs(float(psnr(p, t)) - 10 * math.log10(1 / float(((p - t) ** 2).mean()))) < 1e-5
+    assert abs(float(psnr(torch.full((1, 3, 4, 4), 0.5), torch.full((1, 3, 4, 4), 0.6))) - 20.0) < 1e-4
+    got = float(ssim(p, t))
+    want = _ssim_numpy(p.numpy(), t.numpy())
+    assert abs(got - want) < 2e-5, (got, want)
+    assert abs(float(ssim(p, t, data_range=1.0)) - _ssim_numpy(p.numpy(), t.numpy(), data_range=1.0)) < 2e-5
+    assert abs(float(ssim(t, t)) - 1.0) < 1e-6
+    assert float(ssim(p, t)) == float(ssim(p.clone(), t.clone()))
+    assert 0 < got < 1
+    # float64 inputs reproduce the float64 oracle to rounding
+    assert abs(float(ssim(p.double(), t.double())) - _ssim_numpy(p.double().numpy(), t.double().numpy())) < 1e-12
+    with pytest.raises(ValueError):
+        ssim(torch.rand(1, 3, 8, 8), torch.rand(1, 3, 8, 8))            # smaller than the 11 x 11 window
+
+
+def test_lpips_needs_weights_and_is_a_distance_with_them():
+    from nersemble_amd.util.metrics import LearnedPerceptualImagePatchSimilarity as LPIPS
+    a, b = torch.rand(1, 3, 64, 64), torch.rand(1, 3, 64, 64)
+    m = LPIPS(normalize=True)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        assert math.isnan(float(m(a, b))) and math.isnan(float(m(a, b)))
+    assert len(w) == 1 and len(list(m.parameters())) == 0              # warns once, holds no trunk until weights come
+    g = torch.Generator().manual_seed(3)
+    state = {}
+    for k, (idx, i, o, ks, _, _) in enumerate(LPIPS._CONVS):
+        state[f"features.{idx}.weight"] = torch.randn((o, i, ks, ks), generator=g) * (2.0 / (i * ks * ks)) ** 0.5
+        state[f"features.{idx}.bias"] = torch.zeros(o)
+        state[f"lin{k}.model.1.weight"] = torch.rand((1, o, 1, 1), generator=g)
+    m.load_weights(state)
+    assert float(m(a, a)) == 0.0 and float(m(a, b)) > 0
+    assert abs(float(m(a, b)) - float(m(b, a))) < 1e-6
+    assert float(m(a, (a + 0.02 * torch.randn(a.shape, generator=g)).clamp(0, 1))) < float(m(a, b))
+
+
+def test_colormaps():
+    from nersemble_amd.util import colormaps as cm
+    x = torch.linspace(0, 1, 12).reshape(3, 4, 1)
+    turbo = cm.apply_colormap(x)
+    assert turbo.shape == (3, 4, 3) and 0 <= float(turbo.min()) and float(turbo.max()) <= 1
+    assert torch.equal(cm.apply_colormap(x, cm.ColormapOptions(colormap="gray")), x.expand(3, 4, 3))
+    inv = cm.apply_colormap(x, cm.ColormapOptions(colormap="turbo", invert=True))
+    assert torch.allclose(inv.flip(0).flip(1), turbo, atol=1e-6)
+    rgb = torch.rand(3, 4, 3)
+    assert cm.apply_colormap(rgb) is rgb
+    assert torch.equal(cm.apply_colormap(x > 0.5)[..., 0], (x > 0.5)[..., 0].float())
+    depth = torch.rand(3, 4, 1) * 5 + 7
+    acc = torch.zeros(3, 4, 1)
+    assert torch.equal(cm.apply_depth_colormap(depth, accumulation=acc), torch.ones(3, 4, 3))   # empty rays -> white
+    d = cm.apply_depth_colormap(depth, near_plane=7.2, far_plane=10.8)
+    assert d.shape == (3, 4, 3)
+    flow = cm.apply_scene_flow_colormap(torch.zeros(2, 2, 3))
+    assert torch.equal(flow, torch.full((2, 2, 3), 0.5))
+
+
+def test_cameras_generate_image_shaped_rays():
+    from nersemble_amd.cameras import Cameras
+    c2w = torch.eye(4)[None, :3].repeat(2, 1, 1)
+    c2w[1, :, 3] = torch.tensor([1.0, 2.0, 3.0])
+    cams = Cameras(c2w, fx=100.0, fy=100.0, cx=8.0, cy=6.0, width=16, height=12, times=torch.tensor([0.0, 0.5]))
+    assert cams.size == 2 and len(cams) == 2
+    b = cams.generate_rays(camera_indices=1)
+    assert b.shape == (12, 16) and len(b) == 192
+    assert torch.allclose(b.directions.norm(dim=-1), torch.ones(12, 16), atol=1e-6)
+    assert torch.equal(b.origins[3, 5], torch.tensor([1.0, 2.0, 3.0])) and float(b.times[0, 0]) == 0.5
+    # OpenGL camera: looks along -z, x right, y up; pixel centres at +0.5
+    d = b.directions[0, 0]
+    want = torch.tensor([(0.5 - 8) / 100, -(0.5 - 6) / 100, -1.0])
+    assert torch.allclose(d, want / want.norm(), atol=1e-6)
+    assert float(b.directions[5, 7, 2]) < -0.99 and (b.pixel_area > 0).all()
+    flat = b.flatten()
+    assert flat.origins.shape == (192, 3) and torch.equal(flat.directions[16 + 2], b.directions[1, 2])
+    sl = b.get_row_major_sliced_ray_bundle(10, 40)
+    assert len(sl) == 30 and torch.equal(sl.directions, flat.directions[10:40])
+    cams.rescale_output_resolution(0.5)
+    assert cams.generate_rays(0).shape == (6, 8) and float(cams.fx[0]) == 50.0
+
+
+class _FakeModel:
+    """Renders ``image * gain`` -- enough to drive the evaluation loop without a GPU."""
+    device = torch.device("cpu")
+
+    def __init__(self, images, gain=0.9):
+        from nersemble_amd.util.metrics import (LearnedPerceptualImagePatchSimilarity, PeakSignalNoiseRatio,
+                                                structural_similarity_index_measure)
+        self.images, self.gain, self.calls = images, gain, 0
+        self.psnr, self.ssim = PeakSignalNoiseRatio(1.0), structural_similarity_index_measure
+        self.lpips, self.rgb_loss = LearnedPerceptualImagePatchSimilarity(), torch.nn.MSELoss()
+        self.config = type("C", (), {"eval_num_rays_per_chunk": 64})()
+
+    def get_outputs_for_camera_ray_bundle(self, bundle):
+        h, w = bundle.shape
+        img = self.images[int(bundle.camera_indices[0, 0, 0])]
+        self.calls += 1
+        return {"rgb": img * self.gain, "accumulation": torch.ones(h, w, 1), "depth": torch.full((h, w, 1), 9.0)}
+
+    def get_image_metrics_and_images(self, outputs, batch):
+        from nersemble_amd.models.nersemble_instant_ngp import NeRSembleNGPModel
+        return NeRSembleNGPModel.get_image_metrics_and_images(self, outputs, batch)
+
+
+def _fake_views(n_cams=2, timesteps=(0, 1, 2, 3), T=4, h=16, w=20):
+    from nersemble_amd.cameras import Cameras
+    g = torch.Generator().manual_seed(1)
+    n = n_cams * len(timesteps)
+    images = [torch.rand((h, w, 3), generator=g) for _ in range(n)]
+    times = torch.tensor([t / (T - 1) for t in timesteps for _ in range(n_cams)])
+    cams = Cameras(torch.eye(4)[None, :3].repeat(n, 1, 1), 50.0, 50.0, w / 2, h / 2, w, h, times=times)
+    views = []
+    for i in range(n):
+        alpha = (torch.rand((h, w, 1), generator=g) * 255).to(torch.uint8)
+        views.append((cams.generate_rays(i), {"image": images[i], "alpha_map": alpha,
+                                               "cam_ids": torch.tensor(i % n_cams)}))
+    return images, cams, views
+
+
+def test_evaluation_loop_aggregates_like_the_reference_script():
+    from nersemble_amd import evaluation as ev
+    images, cams, views = _fake_views()
+    model = _FakeModel(images)
+
+    class FakeJod:
+        def __init__(self):
+            self.calls = []
+
+        def predict(self, test, ref, dim_order, frames_per_second):
+            assert dim_order == "FHWC" and test.dtype == np.uint8 and test.shape == ref.shape and test.ndim == 4
+            self.calls.append((test.shape[0], frames_per_second))
+            return torch.tensor(10.0 - np.abs(test.astype(float) - ref).mean() / 25.5), None
+
+    jod = FakeJod()
+    seen = []
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        res = ev.evaluate_novel_views(model, views, time_to_timestep=lambda t: round(t * 3), skip_timesteps=2,
+                                      jod_evaluator=jod, frames_per_second=2.0, cam_names=["camA", "camB"],
+                                      on_image=lambda c, t, img: seen.append((c, t, img.shape)))
+    # timesteps 0 and 2 survive the skip: 2 cams x 2 frames
+    assert model.calls == 4 and sorted(seen) == [(0, 0, (16, 20, 3)), (0, 2, (16, 20, 3)), (1, 0, (16, 20, 3)),
+                                                 (1, 2, (16, 20, 3))]
+    assert set(res.per_cam) == {"camA", "camB"}
+    assert jod.calls == [(2, 4.1)] * 4                                  # regular + masked clip per camera, fps floor
+    per_image_mse = [float(((images[i] * 0.9 - images[i]) ** 2).mean()) for i in (0, 1, 4, 5)]
+    assert abs(res.mean.regular.mse - sum(per_image_mse) / 4) < 1e-7
+    assert abs(res.per_cam["camA"].regular.mse - (per_image_mse[0] + per_image_mse[2]) / 2) < 1e-7
+    assert abs(res.mean.regular.psnr - np.mean([10 * math.log10(1 / m) for m in per_image_mse])) < 1e-4
+    assert math.isnan(res.mean.regular.lpips) and 0 < res.mean.regular.ssim < 1
+    assert res.mean.masked.mse < res.mean.regular.mse                   # blending both onto white shrinks the error
+    assert abs(res.mean.regular.jod - (res.per_cam["camA"].regular.jod + res.per_cam["camB"].regular.jod) / 2) < 1e-9
+    assert res.to_json()["per_cam"]["camB"]["masked"]["psnr"] == res.per_cam["camB"].masked.psnr
+    # without an evaluator the JOD fields stay empty; default names are the rig's held-out serials
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        res2 = ev.evaluate_novel_views(_FakeModel(images), views, time_to_timestep=lambda t: round(t * 3))
+    assert res2.mean.regular.jod is None and set(res2.per_cam) == {"222200040", "220700191"}
+    with pytest.raises(ValueError):
+        ev.evaluate_novel_views(model, [], time_to_timestep=lambda t: 0)
+
+
+def test_alpha_blending_and_jod_rate_known_answers():
+    from nersemble_amd import evaluation as ev
+    img = np.array([[[0, 128, 255]]], dtype=np.uint8)
+    assert ev.perform_alpha_blending(img, np.array([[[255]]], dtype=np.uint8)).tolist() == [[[0, 128, 255]]]
+    assert ev.perform_alpha_blending(img, np.array([[[0]]], dtype=np.uint8)).tolist() == [[[255, 255, 255]]]
+    half = ev.perform_alpha_blending(img, np.array([[[128]]], dtype=np.uint8))
+    a = 128 / 255
+    assert half.tolist() == [[[int((a * 0 + (1 - a)) * 255), int((a * 128 / 255 + (1 - a)) * 255), 255]]]
+    with pytest.raises(AssertionError):
+        ev.perform_alpha_blending(img.astype(np.float32), np.array([[[0]]], dtype=np.uint8))
+    assert ev.jod_frames_per_second(73, 3, 150, 15, None) == pytest.approx(max(4.1, 73 / 3 / 10))
+    assert ev.jod_frames_per_second(73, 1, 150, 15, 5) == pytest.approx(73 / 5)
+    assert ev.jod_frames_per_second(73, 1, 150, -1, None) == 73
+
+
+def test_render_trajectory_writes_one_stream_per_channel(tmp_path):
+    from nersemble_amd.util.render import render_trajectory_video
+    images, cams, _ = _fake_views(n_cams=3, timesteps=(0,), T=2)
+    model = _FakeModel(images, gain=1.0)
+    out = render_trajectory_video(model, cams, str(tmp_path / "traj_{r}.mp4"), rendered_resolution_scaling_factor=1.0,
+                                  render_channels=["rgb", "depth", "accumulation"], seconds=1.5)
+    assert model.calls == 3 and len(out) == 3
+    try:
+        import mediapy  # noqa: F401
+        return
+    except ImportError:
+        pass
+    from PIL import Image
+    for channel in ("rgb", "depth", "accumulation"):
+        folder = tmp_path / f"traj_{channel}"
+        frames = sorted(f for f in os.listdir(folder) if f.endswith(".png"))
+        assert frames == ["frame_00000.png", "frame_00001.png", "frame_00002.png"]
+        assert float(open(folder / "fps.txt").read()) == pytest.approx(2.0)
+        assert np.asarray(Image.open(folder / frames[0])).shape == (16, 20, 3)
+    first = np.asarray(Image.open(tmp_path / "traj_rgb" / "frame_00000.png"))
+    assert np.abs(first.astype(float) - images[0].numpy() * 255).max() <= 0.5 + 1e-6
+    with pytest.raises(KeyError):
+        render_trajectory_video(model, cams, str(tmp_path / "x_{r}.mp4"), render_channels=["normals"])
+
+
+@pytest.mark.gpu
+def test_full_image_evaluation_through_the_kernels(cuda, tmp_path):
+    """Held-out views rendered through libnsx in chunks == the same rays rendered in one go; metrics and the
+    aggregated result are finite and consistent."""
+    from nersemble_amd import evaluation as ev
+    from nersemble_amd.util.render import render_trajectory_video
+    from nersemble_amd.workloads import build_workload
+    torch.manual_seed(5)
+    trainer, data, _ = build_workload("p030_h16", device="cuda:0", small=True, n_rays=512)
+    for step in range(8):
+        trainer.train_iteration(step, *data.next_train(step))
+    model = trainer.model
+    model.eval()
+    model.config.eval_num_rays_per_chunk = 128
+    views = list(data.eval_views(timesteps=[0, 2], downscale=64))
+    assert len(views) == 8
+    bundle, batch = views[1]
+    h, w = bundle.shape
+    out = model.get_outputs_for_camera_ray_bundle(bundle)
+    assert out["rgb"].shape == (h, w, 3) and out["depth"].shape == (h, w, 1) and out["deformation"].shape == (h, w, 3)
+    assert out["num_samples_per_ray"].shape == (h, w, 1)
+    with torch.no_grad():
+        whole = model(bundle.flatten())
+    assert torch.equal(out["num_samples_per_ray"].reshape(-1), whole["num_samples_per_ray"].reshape(-1))
+    assert (out["rgb"].reshape(-1, 3) - whole["rgb"]).abs().max().item() <= 2e-2   # chunking changes fp16 blend order only
+    metrics, images = model.get_image_metrics_and_images(out, batch)
+    assert {"psnr", "ssim", "lpips", "mse", "cam_id", "psnr_masked", "ssim_masked", "lpips_masked",
+            "mse_masked"} == set(metrics)
+    assert math.isfinite(metrics["psnr"]) and 0 <= metrics["ssim"] <= 1 and math.isnan(metrics["lpips"])
+    assert abs(metrics["psnr"] - 10 * math.log10(1 / metrics["mse"])) < 1e-3
+    assert images["img"].shape == (h, 2 * w, 3) and images["img_masked"].shape == (h, 2 * w, 3)
+    assert images["depth"].shape == (h, w, 3) and images["deformation"].shape == (h, w, 3)
+    res = ev.evaluate_novel_views(model, views, time_to_timestep=lambda t: round(t * (data.n_timesteps - 1)))
+    assert len(res.per_cam) == 4 and math.isfinite(res.mean.regular.psnr) and res.mean.regular.jod is None
+    assert abs(res.mean.regular.mse - np.mean([b.regular.mse for b in res.per_cam.values()])) < 1e-6
+    paths = render_trajectory_video(model, data.eval_cameras([1], downscale=64), str(tmp_path / "t_{r}.mp4"),
+                                    render_channels=["rgb", "depth"])
+    assert len(paths) == 2
+    model.train()
