@@ -9,8 +9,10 @@
 // Integer outputs (per-ray counts, ray indices, cell ids) AND the t values are bit-exact against the CPU
 // oracle: everything is plain fp32 with contraction disabled (no fused multiply-add), IEEE division.
 //
-// Cost model: <= ~700 lattice steps + <= 3*res voxel steps per ray, 4096 rays -> ~0.1 ms; the hash gather is
-// 20-100x larger, so this stays one lane per ray (64-lane blocks spread over 64 CUs) in round 1.
+// Cost model: <= ~700 lattice steps + <= 3*res voxel steps per ray.  One lane per ray (the lattice and DDA
+// recurrences are serial fp32 additions that must keep their order to stay bit-exact), so the walk is bound by
+// the LATENCY of the occupancy loads, not by bandwidth: the voxel walk runs 8 voxels ahead so that 8 loads are in
+// flight per lane, and rays are spread 16 to a wave (256 waves instead of 64) to cut the divergence tail.
 #include "nsx_common.h"
 #pragma clang fp contract(off)
 
@@ -38,6 +40,8 @@ __device__ __forceinline__ bool ray_aabb(const float o[3], const float d[3], con
     tmin_o = tmin; tmax_o = tmax;
     return true;
 }
+
+constexpr int kRaysPerBlock = 16;   // one partially filled wave per block: 4096 rays -> 256 waves, one per CU
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
@@ -79,37 +83,64 @@ __device__ __forceinline__ int64_t march_ray(const float o[3], const float d[3],
         delta[a] = (d[a] == 0.0f) ? this_tmax : dtmp;
         over[a] = fin[a] + stepi[a];
     }
-    for (;;) {
-        float t_trav = fminf(tdist[0], fminf(tdist[1], tdist[2]));
-        t_trav = fminf(t_trav, this_tmax);
-        const int32_t cell = (cur[0] * res + cur[1]) * res + cur[2];
-        if (!binary[cell]) {
-            for (;;) {
-                if (t_last + step * 0.5f >= t_trav) break;
-                t_last += step;
-            }
-        } else {
-            for (;;) {
-                if (t_last + step * 0.5f >= t_trav) break;
-                const float t_next = t_last + step;
-                if (FILL) {
-                    t0[n] = t_last; t1[n] = t_next;
-                    if (cells) cells[n] = cell;
+    // The DDA recurrence (cur / tdist) never depends on the grid's contents, so the voxel walk runs NB voxels ahead
+    // of the lattice walk: NB cell ids + exit times are produced first, their occupancy bytes are fetched with NB
+    // independent loads (one L2 round trip instead of NB dependent ones -- the walk is latency-bound: one lane per
+    // ray), then the lattice steps of those voxels are emitted in order.  Every floating-point recurrence keeps its
+    // operation order, so the outputs stay bit-identical to the one-voxel-at-a-time formulation.
+    constexpr int NB = 8;
+    bool walking = true;
+    while (walking) {
+        float t_exit[NB];
+        int32_t cell_id[NB];
+        int nb = 0;
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            t_exit[i] = 0.f;
+            cell_id[i] = 0;
+            if (walking) {
+                float t_trav = fminf(tdist[0], fminf(tdist[1], tdist[2]));
+                t_exit[i] = fminf(t_trav, this_tmax);
+                cell_id[i] = (cur[0] * res + cur[1]) * res + cur[2];
+                nb = i + 1;
+                if (tdist[0] < tdist[1] && tdist[0] < tdist[2]) {
+                    cur[0] += stepi[0]; tdist[0] += delta[0];
+                    walking = cur[0] != over[0];
+                } else if (tdist[1] < tdist[2]) {
+                    cur[1] += stepi[1]; tdist[1] += delta[1];
+                    walking = cur[1] != over[1];
+                } else {
+                    cur[2] += stepi[2]; tdist[2] += delta[2];
+                    walking = cur[2] != over[2];
                 }
-                n++;
-                t_last = t_next;
-                if (t_next >= t_trav) break;
             }
         }
-        if (tdist[0] < tdist[1] && tdist[0] < tdist[2]) {
-            cur[0] += stepi[0]; tdist[0] += delta[0];
-            if (cur[0] == over[0]) break;
-        } else if (tdist[1] < tdist[2]) {
-            cur[1] += stepi[1]; tdist[1] += delta[1];
-            if (cur[1] == over[1]) break;
-        } else {
-            cur[2] += stepi[2]; tdist[2] += delta[2];
-            if (cur[2] == over[2]) break;
+        uint8_t occupied[NB];
+#pragma unroll
+        for (int i = 0; i < NB; ++i) occupied[i] = binary[cell_id[i]];
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            if (i < nb) {
+                const float t_trav = t_exit[i];
+                if (!occupied[i]) {
+                    for (;;) {
+                        if (t_last + step * 0.5f >= t_trav) break;
+                        t_last += step;
+                    }
+                } else {
+                    for (;;) {
+                        if (t_last + step * 0.5f >= t_trav) break;
+                        const float t_next = t_last + step;
+                        if (FILL) {
+                            t0[n] = t_last; t1[n] = t_next;
+                            if (cells) cells[n] = cell_id[i];
+                        }
+                        n++;
+                        t_last = t_next;
+                        if (t_next >= t_trav) break;
+                    }
+                }
+            }
         }
     }
     return n;
@@ -218,7 +249,7 @@ int nsx_march_count(const float* rays_o, const float* rays_d, int64_t R, const f
     NSX_REQUIRE(counts, "nsx_march_count: NULL counts");
     Aabb bb;
     for (int i = 0; i < 6; ++i) bb.v[i] = aabb_host[i];
-    hipLaunchKernelGGL(march_count_kernel, dim3((unsigned)((R + 63) / 64)), dim3(64), 0, (hipStream_t)stream, rays_o,
+    hipLaunchKernelGGL(march_count_kernel, dim3((unsigned)((R + kRaysPerBlock - 1) / kRaysPerBlock)), dim3(kRaysPerBlock), 0, (hipStream_t)stream, rays_o,
                        rays_d, R, bb, binary, res, near, far_plane, step, counts);
     NSX_LAUNCH_CHECK("nsx_march_count launch");
     return NSX_OK;
@@ -243,7 +274,7 @@ int nsx_march_fill(const float* rays_o, const float* rays_d, int64_t R, const fl
     NSX_REQUIRE(packed_info && t_starts && t_ends && ray_indices, "nsx_march_fill: NULL argument");
     Aabb bb;
     for (int i = 0; i < 6; ++i) bb.v[i] = aabb_host[i];
-    hipLaunchKernelGGL(march_fill_kernel, dim3((unsigned)((R + 63) / 64)), dim3(64), 0, (hipStream_t)stream, rays_o,
+    hipLaunchKernelGGL(march_fill_kernel, dim3((unsigned)((R + kRaysPerBlock - 1) / kRaysPerBlock)), dim3(kRaysPerBlock), 0, (hipStream_t)stream, rays_o,
                        rays_d, R, bb, binary, res, near, far_plane, step, packed_info, t_starts, t_ends, ray_indices,
                        cells);
     NSX_LAUNCH_CHECK("nsx_march_fill launch");
