@@ -41,7 +41,13 @@ __device__ __forceinline__ bool ray_aabb(const float o[3], const float d[3], con
     return true;
 }
 
-constexpr int kRaysPerBlock = 16;   // one partially filled wave per block: 4096 rays -> 256 waves, one per CU
+#ifndef NSX_MARCH_RPB
+#define NSX_MARCH_RPB 16
+#endif
+#ifndef NSX_MARCH_NB
+#define NSX_MARCH_NB 8
+#endif
+constexpr int kRaysPerBlock = NSX_MARCH_RPB;   // one partially filled wave per block: 4096 rays -> 256 waves, one per CU
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
@@ -88,7 +94,8 @@ __device__ __forceinline__ int64_t march_ray(const float o[3], const float d[3],
     // independent loads (one L2 round trip instead of NB dependent ones -- the walk is latency-bound: one lane per
     // ray), then the lattice steps of those voxels are emitted in order.  Every floating-point recurrence keeps its
     // operation order, so the outputs stay bit-identical to the one-voxel-at-a-time formulation.
-    constexpr int NB = 8;
+    constexpr int NB = NSX_MARCH_NB;
+    const float half_step = step * 0.5f;
     bool walking = true;
     while (walking) {
         float t_exit[NB];
@@ -99,46 +106,50 @@ __device__ __forceinline__ int64_t march_ray(const float o[3], const float d[3],
             t_exit[i] = 0.f;
             cell_id[i] = 0;
             if (walking) {
-                float t_trav = fminf(tdist[0], fminf(tdist[1], tdist[2]));
+                const float t_trav = fminf(tdist[0], fminf(tdist[1], tdist[2]));
                 t_exit[i] = fminf(t_trav, this_tmax);
                 cell_id[i] = (cur[0] * res + cur[1]) * res + cur[2];
                 nb = i + 1;
-                if (tdist[0] < tdist[1] && tdist[0] < tdist[2]) {
-                    cur[0] += stepi[0]; tdist[0] += delta[0];
-                    walking = cur[0] != over[0];
-                } else if (tdist[1] < tdist[2]) {
-                    cur[1] += stepi[1]; tdist[1] += delta[1];
-                    walking = cur[1] != over[1];
-                } else {
-                    cur[2] += stepi[2]; tdist[2] += delta[2];
-                    walking = cur[2] != over[2];
-                }
+                // branch-free axis step (the three-way branch diverges on every voxel): the chosen axis moves by
+                // its step / delta, the others add 0 / +0.0f, which leaves their values bit-identical
+                const bool ax0 = tdist[0] < tdist[1] && tdist[0] < tdist[2];
+                const bool ax1 = !ax0 && tdist[1] < tdist[2];
+                const bool ax2 = !ax0 && !ax1;
+                cur[0] += ax0 ? stepi[0] : 0;
+                cur[1] += ax1 ? stepi[1] : 0;
+                cur[2] += ax2 ? stepi[2] : 0;
+                tdist[0] += ax0 ? delta[0] : 0.0f;
+                tdist[1] += ax1 ? delta[1] : 0.0f;
+                tdist[2] += ax2 ? delta[2] : 0.0f;
+                walking = !((ax0 && cur[0] == over[0]) || (ax1 && cur[1] == over[1]) || (ax2 && cur[2] == over[2]));
             }
         }
-        uint8_t occupied[NB];
+        // All NB occupancy bytes are folded into one mask BEFORE any sample of this batch is stored: vmcnt retires
+        // loads and stores in issue order, so a load consumed after the emit loop of an earlier voxel would also wait
+        // for that voxel's stores to be acknowledged (a full L2 round trip per voxel once HBM is busy).
+        uint32_t occupied = 0;
 #pragma unroll
-        for (int i = 0; i < NB; ++i) occupied[i] = binary[cell_id[i]];
+        for (int i = 0; i < NB; ++i) occupied |= (uint32_t)(binary[cell_id[i]] != 0) << i;
+        asm volatile("" : "+v"(occupied));
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             if (i < nb) {
+                // one loop for empty and occupied voxels: both advance the same lattice recurrence, an occupied
+                // voxel also emits.  (Leaving as soon as t_next >= t_exit would only skip a test that the next
+                // iteration's exit check repeats: fl(t_next + step/2) >= t_next >= t_exit.)
                 const float t_trav = t_exit[i];
-                if (!occupied[i]) {
-                    for (;;) {
-                        if (t_last + step * 0.5f >= t_trav) break;
-                        t_last += step;
-                    }
-                } else {
-                    for (;;) {
-                        if (t_last + step * 0.5f >= t_trav) break;
-                        const float t_next = t_last + step;
+                const bool emit = (occupied >> i) & 1u;
+                for (;;) {
+                    if (t_last + half_step >= t_trav) break;
+                    const float t_next = t_last + step;
+                    if (emit) {
                         if (FILL) {
-                            t0[n] = t_last; t1[n] = t_next;
+                            t0[n] = t_last;          // t1[n] = t0[n] + step: written by the caller, coalesced
                             if (cells) cells[n] = cell_id[i];
                         }
                         n++;
-                        t_last = t_next;
-                        if (t_next >= t_trav) break;
                     }
+                    t_last = t_next;
                 }
             }
         }
@@ -165,15 +176,47 @@ __global__ __launch_bounds__(64) void march_fill_kernel(const float* __restrict_
                                                         const int64_t* __restrict__ packed, float* __restrict__ t0,
                                                         float* __restrict__ t1, int64_t* __restrict__ ray_idx,
                                                         int32_t* __restrict__ cells) {
-    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= R) return;
-    const int64_t s = packed[2 * r], cnt = packed[2 * r + 1];
-    if (cnt == 0) return;
-    const float o[3] = {rays_o[3 * r], rays_o[3 * r + 1], rays_o[3 * r + 2]};
-    const float d[3] = {rays_d[3 * r], rays_d[3 * r + 1], rays_d[3 * r + 2]};
-    const int64_t n = march_ray<true>(o, d, bb, binary, res, near[r], far_plane, step, t0 + s, t1 + s,
-                                      cells ? cells + s : nullptr);
-    for (int64_t i = 0; i < n; ++i) ray_idx[s + i] = r;
+    // One wave per block: lanes 0..kRaysPerBlock-1 each walk a ray, all 64 lanes share the coalesced passes.
+    const int lane = threadIdx.x;
+    const int64_t r_first = (int64_t)blockIdx.x * kRaysPerBlock;
+    const int64_t r = r_first + lane;
+    const bool has_ray = lane < kRaysPerBlock && r < R;
+    long long s = 0, cnt = 0;
+    if (has_ray) { s = packed[2 * r]; cnt = packed[2 * r + 1]; }
+    const int n_rays = (int)((R - r_first) < kRaysPerBlock ? (R - r_first) : kRaysPerBlock);
+    // ray indices first: the block's rays own one contiguous run of the output and their counts are already known,
+    // so all 64 lanes write it with coalesced stores (one lane per ray would scatter 8-byte stores from a serial loop)
+    for (int k = 0; k < n_rays; ++k) {
+        const long long sk = __shfl(s, k), nk = __shfl(cnt, k);
+        for (long long i = lane; i < nk; i += kWave) ray_idx[sk + i] = r_first + k;
+    }
+    if (has_ray && cnt != 0) {
+        const float o[3] = {rays_o[3 * r], rays_o[3 * r + 1], rays_o[3 * r + 2]};
+        const float d[3] = {rays_d[3 * r], rays_d[3 * r + 1], rays_d[3 * r + 2]};
+        march_ray<true>(o, d, bb, binary, res, near[r], far_plane, step, t0 + s, t1 + s, cells ? cells + s : nullptr);
+    }
+    // interval ends: every emitted sample is [t, fl(t + step)] by construction, so the ends are one coalesced
+    // read-add-write over the block's run of starts instead of a second scattered store per lattice step
+    // (kPost independent loads in flight per lane: a dependent load -> store per iteration would pay the HBM
+    // latency once per 64 samples)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    const long long run_begin = __shfl(s, 0), run_end = __shfl(s + cnt, n_rays - 1);
+    constexpr int kPost = 8;
+    for (long long base = run_begin + lane; base < run_end; base += (long long)kWave * kPost) {
+        float v[kPost];
+#pragma unroll
+        for (int u = 0; u < kPost; ++u) {
+            const long long i = base + (long long)u * kWave;
+            v[u] = i < run_end ? __hip_atomic_load(t0 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < kPost; ++u) {
+            const long long i = base + (long long)u * kWave;
+            if (i < run_end) t1[i] = v[u] + step;
+        }
+    }
 }
 
 // packed_info[r] = (exclusive prefix of counts, counts[r]); total written to total[0].  Single block.
@@ -274,7 +317,7 @@ int nsx_march_fill(const float* rays_o, const float* rays_d, int64_t R, const fl
     NSX_REQUIRE(packed_info && t_starts && t_ends && ray_indices, "nsx_march_fill: NULL argument");
     Aabb bb;
     for (int i = 0; i < 6; ++i) bb.v[i] = aabb_host[i];
-    hipLaunchKernelGGL(march_fill_kernel, dim3((unsigned)((R + kRaysPerBlock - 1) / kRaysPerBlock)), dim3(kRaysPerBlock), 0, (hipStream_t)stream, rays_o,
+    hipLaunchKernelGGL(march_fill_kernel, dim3((unsigned)((R + kRaysPerBlock - 1) / kRaysPerBlock)), dim3(kWave), 0, (hipStream_t)stream, rays_o,
                        rays_d, R, bb, binary, res, near, far_plane, step, packed_info, t_starts, t_ends, ray_indices,
                        cells);
     NSX_LAUNCH_CHECK("nsx_march_fill launch");
