@@ -122,11 +122,14 @@ def main():
     # is re-requested each step with a different size; whenever the marcher reaches a new maximum the caching allocator
     # has to go to hipMalloc, which on a fresh box costs ~100 ms per step it happens in.  One block allocated and
     # released here stays in the allocator's cache and is carved up instead (288 GB of HBM: the reserve is free).
+    # (After the model is built: the trainer picks the physical placement of the table-optimizer streams from fresh
+    # allocations and returns the losers with empty_cache(), engine/placement.py -- arrays carved out of one big
+    # cached block are always at the slow end of the placement spread.)
+    torch.manual_seed(19980801)            # identical initial weights on every rank
+    trainer, data, info = build_workload(a.workload, device=dev, rank=rank, world_size=world)
     if a.reserve_gb > 0:
         reserve = torch.empty(int(a.reserve_gb * 2 ** 30), dtype=torch.uint8, device=dev)
         del reserve
-    torch.manual_seed(19980801)            # identical initial weights on every rank
-    trainer, data, info = build_workload(a.workload, device=dev, rank=rank, world_size=world)
     H = WORKLOADS[a.workload]["H"]
 
     # synthetic inputs are generated up front: they are resident in HBM when the timed region starts
@@ -246,6 +249,8 @@ def main():
                               step_marks[i + 1][0] if i + 1 < len(step_marks) else end_mark), 3),
                           "samples": int(step_marks[i][1])} for i in range(len(step_marks))],
         }
+        if trainer.placement_report is not None:
+            out["table_placement"] = trainer.placement_report       # one-off, before the warm-up (engine/placement.py)
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(H)
         print(json.dumps(out))

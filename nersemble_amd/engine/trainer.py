@@ -62,7 +62,7 @@ class NeRSembleTrainer:
     def __init__(self, model: NeRSembleNGPModel, opt_cfg: Optional[OptimizerConfig] = None,
                  mixed_precision: bool = True, world_size: int = 1, factored_table_grad: Optional[bool] = None,
                  rank: Optional[int] = None, sharded_table_adam: Optional[bool] = None,
-                 overlap_table_adam: bool = True):
+                 overlap_table_adam: bool = True, calibrate_table_placement: bool = True):
         self.model = model
         self.cfg = opt_cfg or OptimizerConfig()
         self.mixed_precision = mixed_precision
@@ -105,6 +105,16 @@ class NeRSembleTrainer:
         # the table optimizer's 12 GB pass runs beside the rest of the step's tail and the next step's ray marching
         self._opt_stream = torch.cuda.Stream(device) if (overlap_table_adam and device.type == "cuda") else None
         self._found_groups = []
+        # where the table optimizer's streams live in HBM changes the pass by up to 20 % (engine/placement.py)
+        self.placement_report = None
+        table_opt = self.optimizers.get(self.group_of_tables())
+        if calibrate_table_placement and isinstance(table_opt, HashTableAdam):
+            from .placement import calibrate_table_placement as _calibrate
+            self.placement_report = _calibrate(model.field.hash_ensemble, table_opt)
+
+    def group_of_tables(self) -> Optional[str]:
+        """Key of the optimizer that owns the hash tables (``"<group>/tables"``), if there is one."""
+        return next((k for k in self.optimizers if k.endswith("/tables")), None)
 
     # ---- data-parallel gradient averaging ------------------------------------------------------------
     def _all_reduce_grads(self) -> None:

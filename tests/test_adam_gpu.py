@@ -116,3 +116,38 @@ def test_factored_backward_flags_nonfinite_gradient(bad, cuda):
         assert found.item() == brute.item() == (1.0 if poisoned else 0.0)
         opt.step(found_inf=found, inv_scale=None)
         assert torch.equal(he.tables.detach(), before) == poisoned
+
+
+def test_placement_calibration_keeps_values_and_installs_state(cuda):
+    """engine/placement.py: after trying candidate placements the tables, their fp16 copy and the (zero) Adam moments
+    hold exactly what they held before; the optimizer steps from the chosen buffers like an uncalibrated twin."""
+    from nersemble_amd.engine.hash_adam import HashTableAdam
+    from nersemble_amd.engine.placement import calibrate_table_placement
+    H, B, T = 8, 4000, 5
+    he, twin = _he(H, cuda), _he(H, cuda)
+    opt, opt_twin = HashTableAdam(he, lr=5e-3, eps=1e-15), HashTableAdam(twin, lr=5e-3, eps=1e-15)
+    before, before16 = he.tables.detach().clone(), he.half_tables().clone()
+    assert calibrate_table_placement(he, opt) is None                      # small tables: nothing to gain, untouched
+    rep = calibrate_table_placement(he, opt, candidates=4, iters=2, min_params=0)
+    assert rep is not None and len(rep["candidate_ms"]) == 4 and rep["chosen_ms"] == min(rep["candidate_ms"])
+    assert torch.equal(he.tables.detach(), before) and torch.equal(he.half_tables(), before16)
+    st = opt.state[he.tables]
+    assert st["step"] == 0 and not st["exp_avg"].any() and not st["exp_avg_sq"].any()
+    assert st["exp_avg"].data_ptr() != st["exp_avg_sq"].data_ptr() != he.tables.data_ptr()
+    assert calibrate_table_placement(he, opt, min_params=0) is None        # optimizer already holds state
+
+    g = torch.Generator(device=cuda).manual_seed(1)
+    x = torch.rand((B, 3), device=cuda, generator=g)
+    emb = torch.randn((T, H), device=cuda, generator=g)
+    slot = torch.randint(0, T, (B,), device=cuda, generator=g, dtype=torch.int32)
+    dout = torch.randn((B, 12), device=cuda, generator=g).half()
+    for it in range(3):
+        for h, o in ((he, opt), (twin, opt_twin)):
+            o.zero_grad()
+            h(x, emb, window_hash_encodings=4.0, code_index=slot).backward(dout)
+            o.step()
+    assert opt.state[he.tables]["step"] == 3 and opt.state[he.tables]["exp_avg"].any()
+    # (fp32 atomics accumulate G in arbitrary order: equal up to that, see test_factored_adam_equals_torch_adam)
+    assert (he.tables - twin.tables).abs().max().item() <= 5e-5
+    assert (he.tables.detach() - before).abs().max().item() > 1e-3          # it did train
+    assert torch.equal(he.half_tables(), he.tables.detach().half())
