@@ -218,6 +218,15 @@ class OccGridEstimator(nn.Module):
     def device(self) -> torch.device:
         return self.occs.device
 
+    def _occs_mean(self) -> Tensor:
+        """``occs.mean()`` as a device scalar, recomputed only when ``occs`` was written (every 16 steps, or by a
+        caller that edits the grid): a 2 M-element reduction otherwise launched in front of every sampling call."""
+        key = (self.occs._version, self.occs.data_ptr())
+        if getattr(self, "_occs_mean_key", None) != key:
+            self._occs_mean_value = self.occs.mean()
+            self._occs_mean_key = key
+        return self._occs_mean_value
+
     # ---- traversal -------------------------------------------------------------------------------
     @torch.no_grad()
     def traverse(self, rays_o: Tensor, rays_d: Tensor, near_planes: Tensor, far_plane: float, step: float,
@@ -270,7 +279,7 @@ class OccGridEstimator(nn.Module):
         ray_indices, t_starts, t_ends, packed, _ = self.traverse(rays_o, rays_d, near_planes, far, render_step_size)
         if (alpha_thre > 0.0 or early_stop_eps > 0.0) and sigma_fn is not None:
             # nerfacc: alpha_thre = min(alpha_thre, occs.mean().item()); kept on the device (no host sync)
-            alpha_thre = torch.clamp(self.occs.mean(), max=alpha_thre).reshape(1).float()
+            alpha_thre = torch.clamp(self._occs_mean(), max=alpha_thre).reshape(1).float()
             if t_starts.shape[0] != 0:
                 sigmas = sigma_fn(t_starts, t_ends, ray_indices)
             else:
