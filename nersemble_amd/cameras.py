@@ -51,25 +51,48 @@ class Cameras:
         self.width = (self.width * scaling_factor).to(torch.int64)
         self.height = (self.height * scaling_factor).to(torch.int64)
 
-    def _directions(self, i: int, ys: Tensor, xs: Tensor) -> Tensor:
-        d = torch.stack([(xs - self.cx[i, 0]) / self.fx[i, 0], -(ys - self.cy[i, 0]) / self.fy[i, 0],
-                         -torch.ones_like(xs)], dim=-1)
-        return d @ self.camera_to_worlds[i, :, :3].T
-
-    def generate_rays(self, camera_indices: int) -> RayBundle:
-        """All rays of camera ``camera_indices`` as an image-shaped bundle ``[H, W, ...]`` (row-major)."""
+    def generate_rays(self, camera_indices, coords: Optional[Tensor] = None) -> RayBundle:
+        """``generate_rays(i)``: all rays of camera ``i`` as an image-shaped bundle ``[H, W, ...]`` (row-major).
+        ``generate_rays(camera_indices [N, 1], coords [N, 2])``: one ray per row, ``coords`` = (y, x) in pixels with
+        the pixel centre already added (what nerfstudio's ``RayGenerator`` passes)."""
+        if coords is not None:
+            cams = torch.as_tensor(camera_indices, device=self.device).reshape(-1).long()
+            return self._rays_at(cams, coords[:, 0].to(self.device), coords[:, 1].to(self.device))
         i = int(camera_indices)
         h, w = int(self.height[i, 0]), int(self.width[i, 0])
         dev = self.device
         ys, xs = torch.meshgrid(torch.arange(h, device=dev, dtype=torch.float32) + 0.5,
                                 torch.arange(w, device=dev, dtype=torch.float32) + 0.5, indexing="ij")
-        raw = self._directions(i, ys, xs)
-        directions = raw / raw.norm(dim=-1, keepdim=True)
-        right = self._directions(i, ys, xs + 1)
-        down = self._directions(i, ys + 1, xs)
-        dx = (directions - right / right.norm(dim=-1, keepdim=True)).norm(dim=-1, keepdim=True)
-        dy = (directions - down / down.norm(dim=-1, keepdim=True)).norm(dim=-1, keepdim=True)
-        origins = self.camera_to_worlds[i, :, 3].expand(h, w, 3).contiguous()
-        times = None if self.times is None else self.times[i].expand(h, w, 1).contiguous()
-        return RayBundle(origins=origins, directions=directions.contiguous(), pixel_area=dx * dy,
-                         camera_indices=torch.full((h, w, 1), i, device=dev, dtype=torch.long), times=times)
+        flat = self._rays_at(torch.full((h * w,), i, device=dev, dtype=torch.long), ys.reshape(-1), xs.reshape(-1))
+        return RayBundle(origins=flat.origins.view(h, w, 3), directions=flat.directions.view(h, w, 3),
+                         pixel_area=flat.pixel_area.view(h, w, 1), camera_indices=flat.camera_indices.view(h, w, 1),
+                         times=None if flat.times is None else flat.times.view(h, w, 1))
+
+    def _rays_at(self, cams: Tensor, ys: Tensor, xs: Tensor) -> RayBundle:
+        rot = self.camera_to_worlds[cams, :, :3]                       # [N, 3, 3]
+        fx, fy, cx, cy = (t[cams, 0] for t in (self.fx, self.fy, self.cx, self.cy))
+
+        def unit_dirs(y, x):
+            d = torch.stack([(x - cx) / fx, -(y - cy) / fy, -torch.ones_like(x)], dim=-1)
+            d = torch.einsum("nij,nj->ni", rot, d)
+            return d / d.norm(dim=-1, keepdim=True)
+
+        directions = unit_dirs(ys, xs)
+        dx = (directions - unit_dirs(ys, xs + 1)).norm(dim=-1, keepdim=True)
+        dy = (directions - unit_dirs(ys + 1, xs)).norm(dim=-1, keepdim=True)
+        times = None if self.times is None else self.times[cams]
+        return RayBundle(origins=self.camera_to_worlds[cams, :, 3].contiguous(), directions=directions.contiguous(),
+                         pixel_area=dx * dy, camera_indices=cams[:, None], times=times)
+
+
+class RayGenerator:
+    """nerfstudio's ``RayGenerator``: (camera, y, x) pixel indices -> ``RayBundle`` (pixel centres at +0.5); the
+    module the datamanager calls on the pixel sampler's ``indices`` (``VanillaDataManager.next_train``, UPSTREAM)."""
+
+    def __init__(self, cameras: Cameras):
+        self.cameras = cameras
+
+    def __call__(self, ray_indices: Tensor) -> RayBundle:
+        c, y, x = ray_indices[:, 0], ray_indices[:, 1], ray_indices[:, 2]
+        coords = torch.stack([y, x], dim=-1).to(torch.float32) + 0.5
+        return self.cameras.generate_rays(camera_indices=c.unsqueeze(-1), coords=coords)

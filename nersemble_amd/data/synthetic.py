@@ -106,6 +106,35 @@ class SyntheticNeRSembleData:
         cameras.rescale_output_resolution(1.0 / downscale)
         return cameras
 
+    def image_dataset(self, images, downscale: int = 16, max_cached_items: int = -1,
+                      use_cache_compression: bool = False):
+        """``InMemoryInputDataset`` over the given (camera, timestep) images of the rig, rendered analytically on first
+        use: the stand-in for the reference's ``NeRSembleInputDataset`` (whose loader decodes the gated dataset's files).
+        Item keys as there: ``image``, ``alpha_map`` (uint8), ``depth_maps`` (per pixel), ``timesteps`` / ``cam_ids``
+        (per image), ``image_idx``; one camera per image."""
+        from ..cameras import Cameras
+        from .dataset import InMemoryInputDataset
+        images = [(int(c), int(t)) for c, t in images]
+        cams = torch.tensor([c for c, _ in images], device=self.c2w.device)
+        times = torch.tensor([t / max(self.n_timesteps - 1, 1) for _, t in images])
+        cameras = Cameras(self.c2w[cams].cpu(), self.focal, self.focal, self.width / 2, self.height / 2, self.width,
+                          self.height, times=times)
+        cameras.rescale_output_resolution(1.0 / downscale)
+        on_device = cameras.to(self.device)
+
+        def load(image_idx: int):
+            bundle = on_device.generate_rays(image_idx)
+            h, w = bundle.shape
+            flat = bundle.flatten()
+            rgb, alpha, depth = self.render_ground_truth(flat.origins, flat.directions, flat.times.reshape(-1))
+            cam, timestep = images[image_idx]
+            return {"image_idx": image_idx, "image": rgb.view(h, w, 3), "alpha_map": alpha.view(h, w, 1),
+                    "depth_maps": depth.view(h, w), "timesteps": timestep, "cam_ids": cam}
+
+        return InMemoryInputDataset(load, cameras, max_cached_items=max_cached_items,
+                                    use_cache_compression=use_cache_compression,
+                                    metadata={"camera_frustums": self.camera_frustums})
+
     def eval_views(self, timesteps, downscale: int = 16):
         """(camera_ray_bundle [H, W], batch) per held-out view, like ``fixed_indices_eval_dataloader``: ``batch`` has
         ``image [H,W,3]``, ``alpha_map [H,W,1] uint8``, ``depth_maps [H,W]`` and ``cam_ids`` = index of the eval cam."""
