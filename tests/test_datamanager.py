@@ -130,7 +130,7 @@ def test_training_and_evaluation_through_the_datamanager(cuda):
     for step in range(10):
         bundle, batch = dm.next_train(step)
         assert bundle.origins.is_cuda and batch["image"].is_cuda and bundle.metadata["_image_timesteps"].numel() == 6
-        loss = float(trainer.train_iteration(step, bundle, batch)[0])
+        loss = float(trainer.train_iteration(step, bundle, batch)[0].detach())
         assert math.isfinite(loss)
         first = loss if first is None else first
         last = loss
