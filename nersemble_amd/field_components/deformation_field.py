@@ -135,6 +135,7 @@ class SE3DeformationField(nn.Module):
         fr = ray_samples.frustums
         positions = F.sample_positions(fr.origins, fr.directions, fr.starts, fr.ends) if fr.origins.is_cuda \
             else fr.get_positions()
+        fr.base_positions = positions          # un-warped sample positions: the field's density pass starts from them
         ray_samples.frustums.set_offsets(self.compute_offsets(positions, warp_code, windows_param, code_index,
                                                               precomputed_offsets))
         return ray_samples

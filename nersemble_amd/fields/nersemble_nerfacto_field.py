@@ -108,7 +108,10 @@ class NeRSembleNeRFactoField(nn.Module):
     def get_density(self, ray_samples: RaySamples, window_hash_encodings: Optional[float]) -> Tuple[Tensor, Tensor]:
         fr = ray_samples.frustums
         if fr.origins.is_cuda:
-            base = F.sample_positions(fr.origins, fr.directions, fr.starts, fr.ends)      # offsets added in-kernel below
+            base = getattr(fr, "base_positions", None)            # left by the deformation field for these samples
+            if base is None or base.shape[0] != fr.origins.shape[0]:
+                base = F.sample_positions(fr.origins, fr.directions, fr.starts, fr.ends)
+            # (offsets are added in the normalisation kernel below)
             return self._density_from_positions(base, fr.offsets, ray_samples.metadata or {}, window_hash_encodings)
         return self._density_from_positions(fr.get_positions(), None, ray_samples.metadata or {}, window_hash_encodings)
 

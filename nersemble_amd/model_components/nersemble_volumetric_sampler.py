@@ -56,17 +56,38 @@ class NeRSembleVolumetricSampler(nn.Module):
             grid = self.camera_frustum_grid = grid.to(binaries.device)
         binaries[0] = binaries[0] & grid
 
-    @staticmethod
-    def _packed_samples(bundle: RayBundle, o: Tensor, d: Tensor, ray_indices: Tensor, t0: Tensor, t1: Tensor
+    # per-ray entries of ``ray_bundle.metadata`` that the model wants per sample (gathered in the same launch)
+    sample_metadata_keys = ("image_index",)
+
+    def _packed_samples(self, bundle: RayBundle, o: Tensor, d: Tensor, ray_indices: Tensor, t0: Tensor, t1: Tensor
                         ) -> RaySamples:
-        """One RaySamples row per marched interval, rays gathered through ``ray_indices`` (flattened / packed layout)."""
-        cams = bundle.camera_indices
-        samples = RaySamples(
-            frustums=Frustums(origins=o[ray_indices], directions=d[ray_indices], starts=t0[..., None], ends=t1[..., None],
-                              pixel_area=torch.zeros((ray_indices.shape[0], 1), dtype=o.dtype, device=o.device)),
-            camera_indices=cams.contiguous()[ray_indices] if cams is not None else None)
+        """One RaySamples row per marched interval, rays gathered through ``ray_indices`` (flattened / packed layout).
+        All per-ray arrays (origins, directions, camera indices, times, requested metadata) go through ONE gather
+        launch on the device (the reference issues one advanced-indexing op per field, :117-134)."""
+        named = [("origins", o), ("directions", d)]
+        if bundle.camera_indices is not None:
+            named.append(("camera_indices", bundle.camera_indices.contiguous()))
         if bundle.times is not None:
-            samples.times = bundle.times[ray_indices]
+            named.append(("times", bundle.times))
+        for key in self.sample_metadata_keys:
+            value = bundle.metadata.get(key) if bundle.metadata else None
+            if isinstance(value, Tensor) and value.shape[0] == o.shape[0]:
+                named.append(("metadata:" + key, value))
+        if o.is_cuda:
+            rows = F.gather_rows(ray_indices, *[t for _, t in named])
+        else:
+            rows = [t[ray_indices] for _, t in named]
+        got = dict(zip([n for n, _ in named], rows))
+        samples = RaySamples(
+            frustums=Frustums(origins=got["origins"], directions=got["directions"], starts=t0[..., None],
+                              ends=t1[..., None],
+                              pixel_area=torch.zeros((ray_indices.shape[0], 1), dtype=o.dtype, device=o.device)),
+            camera_indices=got.get("camera_indices"))
+        if "times" in got:
+            samples.times = got["times"]
+        extra = {n[len("metadata:"):]: v for n, v in got.items() if n.startswith("metadata:")}
+        if extra:
+            samples.metadata = extra
         return samples
 
     def forward(self, ray_bundle: RayBundle, render_step_size: float, near_plane: float = 0.0,

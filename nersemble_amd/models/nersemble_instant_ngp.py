@@ -316,7 +316,9 @@ class NeRSembleNGPModel(BaseModel):
                 inv = ray_bundle.metadata["image_index"].reshape(-1)
             else:
                 uniq, inv = torch.unique(ray_timesteps, return_inverse=True)
-            slot = inv.to(torch.int32)[ray_indices]
+            slot = ray_samples.metadata.get("image_index")                               # gathered by the sampler
+            slot = inv.to(torch.int32)[ray_indices] if slot is None or slot.shape[0] != ray_indices.shape[0] \
+                else slot.reshape(-1).to(torch.int32)
             ray_samples.metadata["time_codes"] = self.time_embedding(uniq)              # [Tb, H]
             ray_samples.metadata["time_code_index"] = slot                              # [S]
             if self._eval_blend is not None:

@@ -18,6 +18,7 @@ class Frustums:
     ends: Tensor               # [..., 1]
     pixel_area: Tensor         # [..., 1]
     offsets: Optional[Tensor] = None
+    base_positions: Optional[Tensor] = None     # cache: origins + directions * (starts + ends) / 2, without offsets
 
     def get_positions(self) -> Tensor:
         pos = self.origins + self.directions * (self.starts + self.ends) / 2
