@@ -58,7 +58,7 @@ class ShardedTableAdam(torch.optim.Optimizer):
 
 
     def __init__(self, hash_ensemble: HashEnsemble, lr: float = 5e-3, betas=(0.9, 0.999), eps: float = 1e-15,
-                 world_size: int = 1, rank: int = 0, group=None, ops=None):
+                 world_size: int = 1, rank: int = 0, group=None, ops=None, overlap_reduce: bool = True):
         self.he = hash_ensemble
         super().__init__([hash_ensemble.tables], dict(lr=lr, betas=betas, eps=eps))
         self.world_size, self.rank, self.group = int(world_size), int(rank), group
@@ -71,6 +71,12 @@ class ShardedTableAdam(torch.optim.Optimizer):
         self.n_local = max(0, min(self.shard, self.n - self.lo))          # the last shards may be short or empty
         self._buf = None
         self._step = 0
+        # the reduce-scatter starts inside the backward, as soon as the HashEnsemble's backward has completed G: it
+        # then runs beside the deformation field's backward (which comes later in the graph) instead of after it
+        self._early = None            # handle of a reduce-scatter already started for this step ("done" = finished)
+        self._comm_stream = None
+        if overlap_reduce:
+            hash_ensemble.grad_sink.on_complete = self._start_reduce
 
     # ---- buffers ------------------------------------------------------------------------------------------------
     def _buffers(self):
@@ -107,14 +113,47 @@ class ShardedTableAdam(torch.optim.Optimizer):
         if he.tables.grad is not None:
             raise RuntimeError("ShardedTableAdam consumes the factored gradient; a dense .grad on the tables means the "
                                "HashEnsemble ran without time_code_index (not a data-parallel training configuration)")
-        if not entries:
-            b["grad_dense"][:self.n].zero_()                     # every rank joins every collective
-        for i, e in enumerate(entries):
-            self.ops.expand_f16(he, e, b["grad_dense"], 1.0 / self.world_size, i > 0)
-        dist.reduce_scatter_tensor(b["grad_shard"], b["grad_dense"], op=dist.ReduceOp.SUM, group=self.group)
+        early, self._early = self._early, None
+        if early is None:
+            self._expand_and_reduce(async_op=False)              # not started from the backward: do it here
+        elif early != "done":
+            early.wait()                                         # the current stream waits for the collective
         self.ops.check_finite_f16(b["grad_shard"], found_inf)
         if entries and sink.nonfinite is not None:
             torch.maximum(found_inf, sink.nonfinite.to(found_inf.dtype), out=found_inf)
+
+    def _expand_and_reduce(self, async_op: bool):
+        """Dense fp16 gradient / world from the factored one, then the reduce-scatter (every rank joins, with zeros
+        if it has no gradient)."""
+        he, b = self.he, self._buffers()
+        entries = he.grad_sink.entries if he.grad_sink is not None else []
+        if not entries:
+            b["grad_dense"][:self.n].zero_()
+        for i, e in enumerate(entries):
+            self.ops.expand_f16(he, e, b["grad_dense"], 1.0 / self.world_size, i > 0)
+        return dist.reduce_scatter_tensor(b["grad_shard"], b["grad_dense"], op=dist.ReduceOp.SUM, group=self.group,
+                                          async_op=async_op)
+
+    @torch.no_grad()
+    def _start_reduce(self) -> None:
+        """``FactoredGradSink.on_complete``: called from the HashEnsemble's backward when G holds the whole step."""
+        he = self.he
+        self._buffers()
+        if not he.tables.is_cuda:
+            self._expand_and_reduce(async_op=False)
+            self._early = "done"
+            return
+        dev = he.tables.device
+        if self._comm_stream is None:
+            self._comm_stream = torch.cuda.Stream(dev)
+        comm = self._comm_stream
+        comm.wait_stream(torch.cuda.current_stream(dev))         # G is complete on the backward's stream
+        with torch.cuda.stream(comm):
+            self._early = self._expand_and_reduce(async_op=True)
+        for e in he.grad_sink.entries:                           # allocated on the main stream, read on this one
+            for t in (e["G"], e["code"], e["window"]):
+                if t is not None:
+                    t.record_stream(comm)
 
     @torch.no_grad()
     def step(self, found_inf: Optional[torch.Tensor] = None, inv_scale: Optional[torch.Tensor] = None,
@@ -156,6 +195,9 @@ class ShardedTableAdam(torch.optim.Optimizer):
 
     def zero_grad(self, set_to_none: bool = True):
         super().zero_grad(set_to_none=set_to_none)
+        early, self._early = self._early, None
+        if early is not None and early != "done":
+            early.wait()                          # a reduce-scatter nobody consumed: let it finish before G is reused
         if self.he.grad_sink is not None:
             self.he.grad_sink.clear()
 

@@ -73,6 +73,19 @@ class FactoredGradSink:
         self.entries = []            # dicts: G, code, window, n_rows, key
         self._cache = {}
         self.nonfinite = None        # device float: set by the backward kernel when it adds an inf/NaN to a G
+        self.pending = 0             # forwards recorded for autograd whose backward has not run yet
+        self.on_complete = None      # called inside the backward once the LAST pending one has added its share to G
+
+    def expect(self) -> None:
+        self.pending += 1
+
+    def arrived(self) -> None:
+        """One recorded forward has scattered its gradient; the table gradient of the step is complete when none is
+        left (the data-parallel optimizer starts its reduce-scatter from here, beside the rest of the backward)."""
+        if self.pending > 0:
+            self.pending -= 1
+        if self.pending == 0 and self.on_complete is not None and self.entries:
+            self.on_complete()
 
     def buffer_for(self, code: torch.Tensor, window: Optional[torch.Tensor], n_rows: int, total_entries: int):
         key = (code.data_ptr(), n_rows, None if window is None else window.data_ptr())
@@ -95,6 +108,7 @@ class FactoredGradSink:
 
     def clear(self):
         self.entries = []
+        self.pending = 0
 
 
 class _HashEnsembleFn(torch.autograd.Function):
@@ -112,6 +126,11 @@ class _HashEnsembleFn(torch.autograd.Function):
         ctx.H, ctx.geom = H, geom
         ctx.master_shape = tables_master.shape
         ctx.code_rows = code.shape[0]
+        # a forward whose backward will add to the sink's G (the sink counts them to know when G is complete)
+        ctx.announced = (sink is not None and ctx.needs_input_grad[1] and code_index is not None
+                         and code.shape[0] <= _lib.NSX_MAX_SLOTS)
+        if ctx.announced:
+            sink.expect()
         return out
 
     @staticmethod
@@ -138,6 +157,8 @@ class _HashEnsembleFn(torch.autograd.Function):
                                                        ptr(dout), ptr(G), ptr(dcode_s), ptr(dx),
                                                        ptr(ctx.sink.nonfinite) if use_sink else None, stream()),
                   "nsx_hash_ensemble_bwd_factored")
+            if use_sink and ctx.announced:
+                ctx.sink.arrived()
             if need_tab and not use_sink:
                 dtab = torch.empty(ctx.master_shape, dtype=torch.float32, device=x.device)
                 check(lib().nsx_hash_grad_expand(ptr(G), n_rows, ptr(code), code.stride(0), ptr(window), H,

@@ -121,7 +121,16 @@ def _sharded_worker(rank, world, port, out_dir):
         he.grad_sink.entries = [_fake_entry(he, 100 * it + rank, poison=poison)]
         he.grad_sink.nonfinite = torch.zeros(1)
         found = torch.zeros(1)
+        if it % 2 == 1:
+            # the route a real backward takes: the sink announces completion and the optimizer reduce-scatters at once
+            he.grad_sink.expect()
+            he.grad_sink.expect()
+            he.grad_sink.arrived()
+            assert opt._early is None                          # one backward still pending
+            he.grad_sink.arrived()
+            assert opt._early == "done"
         opt.check_finite(found)
+        assert opt._early is None
         dist.all_reduce(found, op=dist.ReduceOp.MAX)
         opt.step(found_inf=found, inv_scale=inv)
         if float(found) != 0:
