@@ -8,11 +8,10 @@ and the fp32 master and writes the fp16 working copy.  ``NativeGradScaler`` keep
 scale / found_inf on the device so the table gradient never needs its own unscale pass.
 """
 import ctypes as C
-from typing import Dict, List, Optional
+from typing import List, Optional
 
 import torch
 
-from .. import _lib
 from .. import functional as F
 from .._lib import check, lib, ptr, stream
 from ..field_components.hash_ensemble import HashEnsemble

@@ -5,7 +5,7 @@ independent until the loss mean, so each rank draws its own rays and holds a ful
 the sum of gradients.  Large buffers (the 1.6 GB hash-table gradient) go out as their own
 collective; small tensors are flattened into one bucket so a step issues O(1) collectives.
 """
-from typing import Iterable, List
+from typing import Iterable
 
 import torch
 import torch.distributed as dist

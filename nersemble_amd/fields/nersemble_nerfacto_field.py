@@ -17,7 +17,7 @@ from torch import nn, Tensor
 from .. import functional as F
 from .. import tcnn
 from ..field_components.hash_ensemble import HashEnsemble, HashEnsembleConfig
-from ..rays import Frustums, RaySamples, SceneBox
+from ..rays import RaySamples, SceneBox
 from ..util.chunker import chunked
 
 

@@ -8,7 +8,7 @@ MI355X-native changes that do not alter results:
     materialises ``[S,H]`` and ``[S,128]`` fp32 tensors instead);
   * ``packed_info`` is computed once and shared by the weight / accumulation / distortion kernels.
 """
-from dataclasses import dataclass, field
+from dataclasses import dataclass
 from math import sqrt
 from typing import Callable, Dict, List, Optional, Tuple
 

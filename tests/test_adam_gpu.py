@@ -1,6 +1,5 @@
 """GPU parity: native hash-table Adam (factored + dense) vs torch.optim.Adam on the materialised gradient, and the
 GradScaler skip semantics."""
-import numpy as np
 import pytest
 import torch
 

@@ -1,5 +1,5 @@
 """Development aid: time / profile the fused deformation kernels alone (S samples, 24 code slots)."""
-import argparse, os, sys, json
+import argparse, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from nersemble_amd.field_components.deformation_field import SE3DeformationField, SE3DeformationFieldConfig
