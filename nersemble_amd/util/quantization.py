@@ -1,17 +1,21 @@
 """Fixed-point codecs of the dataset's depth / normal maps -- the data format on the input side of the path
 (``batch["depth_maps"]`` reaches ``get_depth_loss`` / ``get_near_and_empty_loss`` decoded by these).
 
-Mirror of the reference's ``util/quantization.py`` (``Quantizer :33-72``, ``DepthQuantizer :75-87``,
+API mirror of the reference's ``util/quantization.py`` (``Quantizer :33-72``, ``DepthQuantizer :75-87``,
 ``NormalsQuantizer :90-120``, ``to_spherical / to_cartesian :6-30``): same class names, constructor arguments and
-``encode`` / ``decode`` results on numpy arrays.  Code 0 is reserved for "no measurement" when ``separate_mask`` is
-set, so B bits hold 2^B - 2 value steps between ``min_values`` and ``max_values``:
+``encode`` / ``decode`` results on numpy arrays, bit for bit (``tests/test_glue_cpu.py::test_quantizers_match_reference``
+against ``tests/golden/dataformat.npz``, produced by the reference's own classes).
 
-    encode(v) = round(max(0, v - min) * s) + off      (0 where v is the mask value)       s = (2^B - 1 - off)/(max - min)
-    decode(q) = (float32(q) - off) / s + min          (mask value where q is the mask value)
+The code: B bits give 2^B levels; when ``separate_mask`` is set level 0 means "no measurement" and the value range
+[min, max] is spread over the remaining 2^B - 2 steps:
 
-Host-side numpy, like the reference -- it runs once per image in the data loader, not per sample.
-Pinned by ``tests/test_glue_cpu.py::test_quantizers_match_reference`` (``tests/golden/dataformat.npz``).
+    level(v) = round(max(0, v - min) * gain) + first        gain = (2^B - 1 - first) / (max - min), first = 0 or 1
+    value(q) = (float32(q) - first) / gain + min
+
+Pixels equal to ``mask_value`` (all channels, for multi-channel maps) are stored as level 0 / restored as
+``mask_value``.  Host-side numpy like the reference: it runs once per image in the data loader, not per sample.
 """
+from dataclasses import dataclass
 from typing import Union
 
 import numpy as np
@@ -19,72 +23,93 @@ import numpy as np
 ArrayOrFloat = Union[np.ndarray, float]
 
 
+# ---- spherical coordinates of unit normals ---------------------------------------------------------------------------
 def to_spherical(cartesian_points: np.ndarray) -> np.ndarray:
-    """[...,3] xyz -> [...,3] (radius, polar angle from +z, azimuth in the xy plane)."""
-    x, y, z = (cartesian_points[..., i] for i in range(3))
-    return np.stack([np.linalg.norm(cartesian_points, axis=-1, ord=2), np.arctan2(np.sqrt(x * x + y * y), z),
-                     np.arctan2(y, x)], axis=-1)
+    """[..., 3] xyz -> [..., 3] (radius, polar angle measured from +z, azimuth in the xy plane)."""
+    px, py, pz = np.moveaxis(cartesian_points, -1, 0)
+    planar = np.sqrt(px * px + py * py)
+    return np.stack((np.linalg.norm(cartesian_points, axis=-1, ord=2), np.arctan2(planar, pz), np.arctan2(py, px)), -1)
 
 
 def to_cartesian(spherical_coordinates: np.ndarray) -> np.ndarray:
-    radius, theta, phi = (spherical_coordinates[..., i] for i in range(3))
-    ring = np.sin(theta)
-    return np.stack([radius * np.cos(phi) * ring, radius * np.sin(phi) * ring, radius * np.cos(theta)], axis=-1)
+    rad, polar, azimuth = np.moveaxis(spherical_coordinates, -1, 0)
+    ring = np.sin(polar)
+    return np.stack((rad * np.cos(azimuth) * ring, rad * np.sin(azimuth) * ring, rad * np.cos(polar)), -1)
 
 
-def _pixel_mask(flags: np.ndarray, reduce) -> np.ndarray:
-    """Multi-channel maps ([H,W,C]) are masked per pixel, single-channel ones per element."""
-    return reduce(flags, axis=-1) if flags.ndim > 2 else flags
+def _per_pixel(flags: np.ndarray, combine) -> np.ndarray:
+    """Masks of [H, W, C] maps are per pixel (over the channels); [H, W] maps are masked element-wise."""
+    return combine(flags, axis=-1) if flags.ndim > 2 else flags
+
+
+@dataclass
+class _LinearCode:
+    """The affine value <-> level map shared by all codecs."""
+    lowest: ArrayOrFloat
+    highest: ArrayOrFloat
+    bits: int
+    first_level: int                       # 1 when level 0 is reserved for "no measurement"
+
+    @property
+    def levels(self) -> int:
+        return 1 << self.bits
+
+    @property
+    def gain(self) -> ArrayOrFloat:
+        return (self.levels - 1 - self.first_level) / (self.highest - self.lowest)
+
+    def to_levels(self, values: np.ndarray, measured: np.ndarray) -> np.ndarray:
+        real = np.maximum(0, values - self.lowest) * self.gain + self.first_level
+        if real.min() < self.first_level or real.max() >= self.levels:
+            raise AssertionError("value outside the quantiser's range")
+        real[~measured] = 0
+        return real.round().astype(np.uint8 if self.bits == 8 else np.uint16)
+
+    def to_values(self, levels: np.ndarray) -> np.ndarray:
+        return (levels.astype(np.float32) - self.first_level) / self.gain + self.lowest
 
 
 class Quantizer:
     def __init__(self, min_values: ArrayOrFloat, max_values: ArrayOrFloat, bits: int, mask_value: ArrayOrFloat = 0,
                  separate_mask: bool = True):
-        self._min_values, self._max_values = min_values, max_values
-        self._bits, self._mask_value, self._separate_mask = bits, mask_value, separate_mask
-        self._mask_offset = int(bool(separate_mask))
-        self._n_buckets = 1 << bits
-        self._scale_factor = (self._n_buckets - 1 - self._mask_offset) / (max_values - min_values)
+        self._code = _LinearCode(min_values, max_values, bits, 1 if separate_mask else 0)
+        self._mask_value = mask_value
+        # the reference's attribute names, for code that reads them
+        self._min_values, self._max_values, self._bits, self._separate_mask = min_values, max_values, bits, separate_mask
+        self._mask_offset, self._n_buckets, self._scale_factor = self._code.first_level, self._code.levels, self._code.gain
 
     def encode(self, values: np.ndarray) -> np.ndarray:
-        valid = _pixel_mask(values != self._mask_value, np.any)
-        codes = np.maximum(0, values - self._min_values) * self._scale_factor + self._mask_offset
-        if codes.min() < self._mask_offset or codes.max() >= self._n_buckets:
-            raise AssertionError("value outside the quantiser's range")
-        codes[~valid] = 0
-        return codes.round().astype(np.uint8 if self._bits == 8 else np.uint16)
+        return self._code.to_levels(values, _per_pixel(values != self._mask_value, np.any))
 
     def decode(self, quantized_values: np.ndarray) -> np.ndarray:
-        empty = _pixel_mask(quantized_values == self._mask_value, np.all)
-        values = (quantized_values.astype(np.float32) - self._mask_offset) / self._scale_factor + self._min_values
-        values[empty] = self._mask_value
-        return values
+        restored = self._code.to_values(quantized_values)
+        restored[_per_pixel(quantized_values == self._mask_value, np.all)] = self._mask_value
+        return restored
 
 
 class DepthQuantizer(Quantizer):
     """16-bit depth in metres over [0, 2]; anything farther is an outlier and is stored as "no measurement"."""
 
     def __init__(self, min_values: float = 0, max_values: float = 2, bits: int = 16, separate_mask: bool = True):
-        super().__init__(min_values=min_values, max_values=max_values, bits=bits, separate_mask=separate_mask)
+        super().__init__(min_values, max_values, bits, separate_mask=separate_mask)
 
     def encode(self, values: np.ndarray) -> np.ndarray:
-        values[values > self._max_values] = self._mask_value        # in place, as the reference does
+        np.putmask(values, values > self._max_values, self._mask_value)      # in place, as the reference does
         return super().encode(values)
 
 
 class NormalsQuantizer(Quantizer):
-    """Unit normals as 8-bit spherical coordinates (radius, theta in [pi/3, pi], phi in [-pi, pi])."""
+    """Unit normals as 8-bit spherical coordinates (radius, polar angle in [pi/3, pi], azimuth in [-pi, pi])."""
 
     def __init__(self):
-        super().__init__(min_values=np.array([0, 1 / 3 * np.pi, -np.pi]), max_values=np.array([1, np.pi, np.pi]),
-                         bits=8)
+        super().__init__(np.array([0, 1 / 3 * np.pi, -np.pi]), np.array([1, np.pi, np.pi]), 8)
 
     def encode(self, values: np.ndarray) -> np.ndarray:
         return super().encode(to_spherical(values))
 
     def decode(self, quantized_values: np.ndarray) -> np.ndarray:
-        present = _pixel_mask(quantized_values != 0, np.any)
-        spherical = super().decode(quantized_values)
-        normals = np.zeros_like(spherical)
-        normals[present] = to_cartesian(spherical[present])
+        angles = super().decode(quantized_values)
+        present = _per_pixel(quantized_values != 0, np.any)
+        normals = np.zeros_like(angles)
+        normals[present] = to_cartesian(angles[present])
         return normals
