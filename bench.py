@@ -221,7 +221,9 @@ def main():
         dom_name = max(rooflines, key=lambda k: prof[k]["total_ms"]) if rooflines else None
         roofline = rooflines.get(dom_name)
         pmc_path = os.path.join(ROOT, "profiles", "pmc", "latest.json")
-        if roofline and os.path.exists(pmc_path):
+        # the committed counter passes were taken on the default workload at one rank: their per-launch bytes say
+        # nothing about another table size / sample count, so any other run reports traffic = null
+        if roofline and os.path.exists(pmc_path) and a.workload == "p030_h32" and world == 1:
             try:
                 pmc = json.load(open(pmc_path)).get("per_launch_hbm_bytes", {})
                 if dom_name in pmc:
