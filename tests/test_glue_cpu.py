@@ -160,3 +160,56 @@ def test_quantizers_match_reference(golden_dir):
         dq.encode(np.array([[-0.0, 1.0], [2.0, 5.0]], dtype=np.float32))   # > max is masked, not an error
     except AssertionError:
         raise AssertionError("DepthQuantizer must mask out-of-range depth")
+
+
+def test_step_lr_matches_torch_scheduler():
+    """The trainer's four-line StepLR follows torch.optim.lr_scheduler.StepLR (train_nersemble.py:243-256: 20 k-step
+    stairs, gamma 0.8 / 0.5) exactly, including after a state-dict round trip."""
+    from nersemble_amd.engine.trainer import StepLR
+    for gamma, size in ((0.8, 20), (0.5, 7)):
+        pa, pb = torch.nn.Parameter(torch.zeros(1)), torch.nn.Parameter(torch.zeros(1))
+        oa, ob = torch.optim.Adam([pa], lr=5e-3), torch.optim.Adam([pb], lr=5e-3)
+        mine, ref = StepLR(oa, step_size=size, gamma=gamma), torch.optim.lr_scheduler.StepLR(ob, size, gamma)
+        for step in range(65):
+            oa.step(), ob.step()
+            mine.step(), ref.step()
+            assert abs(mine.get_last_lr()[0] - ref.get_last_lr()[0]) <= 1e-12 * 5e-3 + 1e-18, (step, gamma)
+            if step == 30:
+                state = mine.state_dict()
+                oa = torch.optim.Adam([pa], lr=5e-3)
+                mine = StepLR(oa, step_size=size, gamma=gamma)
+                mine.load_state_dict(state)
+        assert mine.last_epoch == 65
+
+
+def test_native_grad_scaler_follows_torch_gradscaler():
+    """NativeGradScaler (device-resident scale / growth tracker, flags summed over the parameter groups) against
+    torch.amp.GradScaler's rule (nersemble_trainer.py:185-203): x0.5 on a step with inf/NaN, x2 after growth_interval
+    clean steps, 65536 to start with."""
+    from nersemble_amd.engine.hash_adam import NativeGradScaler
+    sc = NativeGradScaler("cpu", growth_interval=5)
+    assert sc.get_scale() == 65536.0
+    want, clean = 65536.0, 0
+    pattern = [0, 0, 0, 0, 0, 0, 1, 0, 0, 2, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1]
+    for flag in pattern:
+        groups = [torch.tensor([float(flag > 0)]), torch.tensor([float(flag > 1)]), torch.zeros(1)]
+        total = sc.update(groups)
+        assert float(total) == float(flag)
+        if flag:
+            want, clean = want * 0.5, 0
+        else:
+            clean += 1
+            if clean == 5:
+                want, clean = want * 2.0, 0
+        assert sc.get_scale() == want
+    loss = torch.tensor(0.25)
+    assert float(sc.scale(loss)) == 0.25 * want
+    assert float(sc.inv_scale()) == pytest_approx(1.0 / want)
+    off = NativeGradScaler("cpu", enabled=False)
+    off.update([torch.ones(1)])
+    assert off.get_scale() == 1.0 and float(off.scale(loss)) == 0.25
+
+
+def pytest_approx(v):
+    import pytest
+    return pytest.approx(v, rel=1e-7)
