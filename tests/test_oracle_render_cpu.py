@@ -103,3 +103,50 @@ def test_static_render_stages_agree_with_their_own_oracles():
     assert np.allclose(out["weights"][m], T * alpha, atol=1e-6)
     assert np.allclose(out["rgb"][r], (T * alpha) @ out["rgb_samples"][m].astype(np.float64) + (1 - (T * alpha).sum()),
                        atol=1e-5)
+
+
+def test_dynamic_render_reduces_to_static_and_follows_time():
+    """render_dynamic with H = 1, a constant code of 1 and no deformation field IS render_static; with a deformation
+    field whose last layers are zero the offsets vanish; different timesteps give different images."""
+    from oracle import deform
+    g, tables, base, head, binary = _scene(2)
+    o, d = _camera_rays(12)
+    R = o.shape[0]
+    static = render.render_static(o, d, AABB, binary, tables, g, base, head)
+    one = np.ones((3, 1), np.float32)
+    dyn = render.render_dynamic(o, d, np.full(R, 0.5, np.float32), AABB, binary, tables, 1, g, base, head, one, 3)
+    for k in ("rgb", "depth", "accumulation", "num_samples_per_ray"):
+        assert np.array_equal(static[k], dyn[k]), k
+    assert (dyn["timesteps"] == 1).all() and not dyn["offsets"].any() and not dyn["deformation"].any()
+
+    # H = 4 grids blended with per-timestep codes; deformation field with zero rotation / translation heads
+    rng = np.random.default_rng(3)
+    H, T = 4, 5
+    f_enc, _, c = hashgrid.ens_layout(H)
+    tables4 = rng.uniform(-0.5, 0.5, size=(c, g.total_entries, f_enc)).astype(np.float16).view(np.uint16)
+    codes = rng.normal(0, 0.5, size=(T, H)).astype(np.float32)
+    dcodes = rng.normal(0, 0.1, size=(T, 128)).astype(np.float32)
+    lay, total = deform.flat_layout()
+    flat = (rng.uniform(-1, 1, size=total) * 0.05).astype(np.float32)
+    for name in ("Wr", "br", "Wv", "bv"):
+        off, shp = lay[name]
+        flat[off:off + int(np.prod(shp))] = 0.0
+    times = np.where(np.arange(R) % 2 == 0, 0.0, 1.0).astype(np.float32)
+    kw = dict(time_embedding=codes, n_timesteps=T, deform_embedding=dcodes, window_hash=float(H), window_deform=7.0)
+    a = render.render_dynamic(o, d, times, AABB, binary, tables4, H, g, base, head, deform_params=flat, **kw)
+    assert set(np.unique(a["timesteps"]).tolist()) <= {0, T - 1}
+    assert np.abs(a["offsets"]).max() <= 1e-6                      # zero screw axis -> identity warp
+    b = render.render_dynamic(o, d, times, AABB, binary, tables4, H, g, base, head, deform_params=None, **kw)
+    assert np.allclose(a["rgb"], b["rgb"], atol=1e-5)
+    # the same rays at the other timestep see another blend of the grids
+    c_ = render.render_dynamic(o, d, 1.0 - times, AABB, binary, tables4, H, g, base, head, deform_params=None, **kw)
+    hit = a["num_samples_per_ray"] > 0
+    assert np.array_equal(a["num_samples_per_ray"], c_["num_samples_per_ray"])      # marching ignores time
+    assert np.abs(a["rgb"][hit] - c_["rgb"][hit]).max() > 1e-3
+    # a live deformation field moves the samples and is reported by the deformation renderer
+    flat2 = flat.copy()
+    off, shp = lay["bv"]
+    flat2[off:off + 3] = np.array([0.01, -0.02, 0.005], np.float32)
+    e = render.render_dynamic(o, d, times, AABB, binary, tables4, H, g, base, head, deform_params=flat2, **kw)
+    assert np.allclose(e["offsets"], np.array([0.01, -0.02, 0.005]), atol=2e-5)     # pure translation (fp16 bias)
+    assert np.allclose(e["deformation"][hit], e["accumulation"][hit] * np.array([0.01, -0.02, 0.005]), atol=1e-4)
