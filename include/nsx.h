@@ -55,7 +55,8 @@ const char* nsx_last_error(void);
 int nsx_grid_geometry(int n_levels, float per_level_scale, int base_resolution,
                       int log2_hashmap_size, nsx_grid_geom* out);
 
-/* Padded number of grids used by the interleaved layout (next power of two >= H). */
+/* Padded number of grids used by the interleaved layout (next power of two >= H; the reference's H is any value with
+ * 2H <= 8 or 2H a multiple of 8, hash_ensemble.py:80-82). */
 int nsx_padded_grids(int H);
 
 /* ---- parameter layout conversion (checkpoint compatibility) --------------------------------
@@ -120,7 +121,9 @@ int nsx_hash_ensemble_bwd_factored(const float* x, int64_t B, const nsx_half* ta
                                    int n_slots, const int32_t* code_slot, const float* window,
                                    const float* dout, float* G, float* dcode, float* dx, float* nonfinite,
                                    void* stream);
-/* dtables (native fp32) = (accumulate ? dtables : 0) + expand(G, code_table*window). */
+/* dtables (native fp32) = (accumulate ? dtables : 0) + expand(G, code_table*window): the dense table gradient that
+ * autograd would have produced through hash_ensemble.py:155-156 (einsum) and the tcnn encodings' backward; only for
+ * callers that want a materialised .grad (torch optimizers, the dense all-reduce path). */
 int nsx_hash_grad_expand(const float* G, int n_slots, const float* code_table, int64_t code_stride,
                          const float* window, int H, const nsx_grid_geom* g, float* dtables, int accumulate,
                          void* stream);
@@ -186,7 +189,9 @@ int nsx_sample_positions(const float* origins, const float* directions, const in
 /* dsts[a][i][:] = srcs[a][index[i]][:] for n_arrays <= NSX_MAX_GATHER device arrays in one launch (row_bytes[a] a
  * multiple of 4; srcs / row_bytes / dsts are HOST arrays of device pointers / sizes).  Replaces the index_select /
  * advanced-indexing launches after the visibility test: nerfacc's ray_indices[keep], t_starts[keep], t_ends[keep]
- * (inside OccGridEstimator.sampling) and the compaction of the sigma-pass values that the main pass reuses. */
+ * (inside OccGridEstimator.sampling, called at nersemble_volumetric_sampler.py:95-108), the per-field gathers that build
+ * the packed RaySamples (nersemble_volumetric_sampler.py:117-134) and the compaction of the sigma-pass values that the
+ * main pass reuses. */
 #define NSX_MAX_GATHER 8
 int nsx_gather_rows(int n_arrays, const void* const* srcs, const int64_t* row_bytes, void* const* dsts,
                     const int64_t* index, int64_t n, void* stream);
@@ -367,8 +372,9 @@ int nsx_adam_dense_f16grad(const nsx_half* grad, int64_t n, float* master, float
                            nsx_half* params_f16 /* may be NULL */, float lr, float beta1, float beta2, float eps,
                            int64_t step, const float* inv_scale, const float* found_inf, void* stream);
 
-/* Debug/parity helper: the 8 level-local entry indices per (sample, level), uint32 [B][L][8].
- * Integer outputs are held bit-exact to the oracle. */
+/* Debug/parity helper: the 8 level-local entry indices per (sample, level), uint32 [B][L][8] -- what tcnn's HashGrid
+ * (instantiated at hash_ensemble.py:42-50; algorithm: SURVEY.md A.1) computes internally.  Integer outputs are held
+ * bit-exact to the oracle. */
 int nsx_hash_indices(const float* x, int64_t B, const nsx_grid_geom* g, uint32_t* idx, void* stream);
 
 #ifdef __cplusplus
