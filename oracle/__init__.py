@@ -2,7 +2,7 @@
 
 TEST INFRASTRUCTURE ONLY.  Only tests/, __graft_entry__.smoke() and bench.py's
 ``cpu_baseline`` leg may import this package; nothing under nersemble_amd/ does
-(tests/test_layout_rules.py checks that).  See oracle/nsx_oracle.h for the parity
+(tests/test_boundary.py checks that).  See oracle/nsx_oracle.h for the parity
 status (third-party kernels "parity unpinned"; reference-owned glue pinned by
 tests/golden/).
 """

@@ -1,21 +1,33 @@
 """CPU restatement of the SE(3) deformation field (reference deformation_field.py:77-166,
-windowed_nerf_encoding.py:33-74, util/pytorch3d.py:107-191) with the fp16-autocast numerics the reference
-trains with (train_nersemble.py:160 mixed_precision=True): Linear inputs / weights / biases rounded to fp16,
-wide accumulation, outputs rounded to fp16; PE, exponential map and warp in fp32/64.  TEST INFRASTRUCTURE ONLY.
+windowed_nerf_encoding.py:33-74, util/pytorch3d.py:107-191).  TEST INFRASTRUCTURE ONLY.
 
-The fp32 (no rounding) mode of this file is checked against nersemble_amd's torch mirror, which is itself pinned
-by goldens from the reference's own module (tests/test_glue_cpu.py)."""
+Two numeric modes:
+  * ``half=False``: every operation in ``dtype`` (fp64 by default), no rounding.  This mode is PINNED: it is compared
+    with the outputs of the reference's own ``SE3DeformationField.compute_offsets`` (fp32, CPU) in
+    tests/test_oracle_deform_cpu.py -- the tiny W = 32 / code 8 module of tests/golden/deformation.npz and the
+    full-size W = 128 / code 128 module of tests/golden/deformation_full.npz (forward and autograd gradients).
+  * ``half=True``: the fp16-autocast numerics the reference trains with (train_nersemble.py:160
+    mixed_precision=True): Linear inputs / weights / biases rounded to fp16, wide accumulation, outputs rounded to
+    fp16; PE, exponential map and warp in fp32/64.  Same code path, plus the roundings: this is the mode the HIP
+    kernels (csrc/deform.hip) are held to.
+
+Width ``W`` and warp-code dimension are parameters (6 layers, skip into layer 4 are the reference's fixed
+architecture, deformation_field.py:15-21, :50-69); the flat parameter vector is in include/nsx.h order.
+"""
 import numpy as np
 import torch
 
-W, PE, CODE = 128, 45, 128
+PE = 45                      # 3 x 7 frequencies x (sin, cos) + the 2*pi-scaled input (windowed_nerf_encoding.py:48,72)
+W, CODE = 128, 128           # the training configuration (train_nersemble.py:84-91)
 IN = PE + CODE
 
 
-def flat_layout():
-    sizes = [("W0", (W, IN)), ("b0", (W,)), ("W1", (W, W)), ("b1", (W,)), ("W2", (W, W)), ("b2", (W,)),
-             ("W3", (W, W)), ("b3", (W,)), ("W4", (W, IN + W)), ("b4", (W,)), ("W5", (W, W)), ("b5", (W,)),
-             ("Wr", (3, W)), ("br", (3,)), ("Wv", (3, W)), ("bv", (3,))]
+def flat_layout(width: int = W, code_dim: int = CODE):
+    n_in = PE + code_dim
+    sizes = [("W0", (width, n_in)), ("b0", (width,)), ("W1", (width, width)), ("b1", (width,)),
+             ("W2", (width, width)), ("b2", (width,)), ("W3", (width, width)), ("b3", (width,)),
+             ("W4", (width, n_in + width)), ("b4", (width,)), ("W5", (width, width)), ("b5", (width,)),
+             ("Wr", (3, width)), ("br", (3,)), ("Wv", (3, width)), ("bv", (3,))]
     off, out = 0, {}
     for name, shp in sizes:
         n = int(np.prod(shp))
@@ -24,9 +36,19 @@ def flat_layout():
     return out, off
 
 
-def unflatten(flat: torch.Tensor):
-    lay, total = flat_layout()
-    assert flat.numel() == total
+STATE_DICT_ORDER = [f"se3_field.mlp_stem.layers.{i}.{k}" for i in range(6) for k in ("weight", "bias")] + \
+    ["se3_field.mlp_r.layers.0.weight", "se3_field.mlp_r.layers.0.bias",
+     "se3_field.mlp_v.layers.0.weight", "se3_field.mlp_v.layers.0.bias"]
+
+
+def flat_from_state_dict(sd) -> torch.Tensor:
+    """The reference module's state dict (deformation_field.py:50-69 names) -> flat vector in include/nsx.h order."""
+    return torch.cat([torch.as_tensor(sd[k]).reshape(-1).to(torch.float64) for k in STATE_DICT_ORDER])
+
+
+def unflatten(flat: torch.Tensor, width: int = W, code_dim: int = CODE):
+    lay, total = flat_layout(width, code_dim)
+    assert flat.numel() == total, (flat.numel(), total)
     return {k: flat[o:o + int(np.prod(s))].reshape(s) for k, (o, s) in lay.items()}
 
 
@@ -55,6 +77,9 @@ def encode(pn: torch.Tensor, windows_param) -> torch.Tensor:
 
 
 def se3_warp(r, v, p, eps=1e-4):
+    """exp([v, r]) applied to p in closed form: R p + V v with the Rodrigues coefficients of util/pytorch3d.py:10-39
+    (_so3_exp_map: theta = sqrt(clamp(|r|^2, eps))) and :78-105 (_se3_V_matrix); equal to the reference's 4x4
+    homogeneous product (deformation_field.py:93-100; its w component is exactly 1)."""
     nr = (r * r).sum(-1)
     theta = torch.clamp(nr, min=eps).sqrt()
     a = torch.sin(theta) / theta
@@ -65,9 +90,14 @@ def se3_warp(r, v, p, eps=1e-4):
     return p + a[:, None] * u1 + b[:, None] * u2 + v + b[:, None] * w1 + c[:, None] * w2
 
 
-def compute_offsets(pos_world, codes, flat_params, aabb, windows_param, half=True, dtype=torch.float64):
-    """pos_world [S,3], codes [S,128], flat_params [127750] -> offsets [S,3] (normalised space)."""
-    P = unflatten(flat_params.to(dtype))
+def compute_offsets(pos_world, codes, flat_params, aabb, windows_param, half=True, dtype=torch.float64,
+                    width: int = None):
+    """pos_world [S,3], codes [S,code_dim], flat_params (include/nsx.h order) -> offsets [S,3] (normalised space).
+    ``width`` defaults to 128 unless the parameter count says otherwise (solved from the layout)."""
+    code_dim = codes.shape[1]
+    if width is None:
+        width = next(w for w in (128, 32, 64, 16, 256) if flat_layout(w, code_dim)[1] == flat_params.numel())
+    P = unflatten(flat_params.to(dtype), width, code_dim)
     rnd = _r16 if half else (lambda t: t)
     aabb = aabb.to(dtype)
     pn = (pos_world.to(dtype) - aabb[0]) / (aabb[1] - aabb[0])

@@ -10,7 +10,8 @@ What is pinned (reference-owned code, executed for real):
   * posenc_window (hash_ensemble.py:12-28)
   * WindowedNeRFEncoding.forward (windowed_nerf_encoding.py:33-74)
   * se3_exp_map (util/pytorch3d.py:107-191)
-  * SE3DeformationField.compute_offsets (deformation_field.py:148-166) with a tiny seeded config
+  * SE3DeformationField.compute_offsets (deformation_field.py:148-166) with a tiny seeded config, and at the
+    training size (6 x 128, code 128) with forward outputs + autograd gradients -> deformation_full.npz
   * GenericScheduler (engine/generic_scheduler.py), chunked (util/chunker.py)
   * BaseModel.get_dist_loss sample selection / midpoint construction (models/base.py:224-249) with a
     stub flatten_eff_distloss that records its arguments.
@@ -267,6 +268,43 @@ def gen_deformation(out):
         with torch.no_grad():
             out[f"df_off_{i}"] = df.compute_offsets(pos, codes, w).numpy()
     out["df_windows"] = np.array([np.nan, 0.0, 2.75, 7.0])
+
+
+def gen_deformation_full(out):
+    """The reference's own SE3DeformationField at the TRAINING size (6 x 128, warp code 128, train_nersemble.py:84-91),
+    fp32 on CPU: offsets for four window values and, for one of them, the autograd gradients w.r.t. the warp codes,
+    the positions' normalised encoding input (through the codes only -- positions are data) and every parameter.
+    The weights come from tests/helpers.make_deform_state_dict (numpy PCG64, seed in the fixture), so the fixture
+    holds inputs and outputs only."""
+    from nersemble.nerfstudio.field_components.deformation_field import (SE3DeformationField,
+                                                                          SE3DeformationFieldConfig)
+    from tests.helpers import make_deform_state_dict, DEFORM_KEYS
+    seed = 4711
+    cfg = SE3DeformationFieldConfig(warp_code_dim=128, mlp_num_layers=6, mlp_layer_width=128)
+    aabb = torch.tensor([[-2.5, -1.8, -2.5], [2.2, 1.8, 2.0]])
+    df = SE3DeformationField(aabb, cfg, max_n_samples_per_batch=29)
+    sd = {k: torch.from_numpy(v) for k, v in make_deform_state_dict(seed).items()}
+    sd["aabb"] = aabb
+    assert set(sd) == set(df.state_dict())
+    df.load_state_dict(sd)
+    rng = np.random.default_rng(seed + 1)
+    pos = (rng.random((64, 3), dtype=np.float32) * (aabb[1] - aabb[0]).numpy() + aabb[0].numpy()).astype(np.float32)
+    pos[0] = [3.0, 0.0, 0.0]                                   # outside the box: the field extrapolates, no clamp
+    codes = (rng.standard_normal((64, 128)) * 0.3).astype(np.float32)
+    gw = rng.standard_normal((64, 3)).astype(np.float32)
+    out["dff_seed"] = np.array([seed])
+    out["dff_pos"], out["dff_code"], out["dff_gw"] = pos, codes, gw
+    wins = [None, 0.0, 2.75, 7.0]
+    out["dff_windows"] = np.array([np.nan, 0.0, 2.75, 7.0])
+    for i, w in enumerate(wins):
+        with torch.no_grad():
+            out[f"dff_off_{i}"] = df.compute_offsets(torch.from_numpy(pos), torch.from_numpy(codes), w).numpy()
+    c = torch.from_numpy(codes).requires_grad_(True)
+    off = df.compute_offsets(torch.from_numpy(pos), c, 2.75)
+    (off * torch.from_numpy(gw)).sum().backward()
+    out["dff_gcode"] = c.grad.numpy()
+    named = dict(df.named_parameters())
+    out["dff_gparams"] = torch.cat([named[k].grad.reshape(-1) for k in DEFORM_KEYS]).numpy()
 
 
 def gen_misc(out):
@@ -551,9 +589,9 @@ def gen_dataformat(out):
 
 
 def main():
-    """python tests/golden/make_golden.py [hash_ensemble] [deformation] [misc] [occupancy_filter] [pixel_sampler] [dataformat]   (default: all)"""
+    """python tests/golden/make_golden.py [hash_ensemble] [deformation] [deformation_full] [misc] [occupancy_filter] [pixel_sampler] [dataformat]   (default: all)"""
     torch.set_num_threads(4)
-    which = set(sys.argv[1:]) or {"hash_ensemble", "deformation", "misc", "occupancy_filter", "pixel_sampler", "dataformat"}
+    which = set(sys.argv[1:]) or {"hash_ensemble", "deformation", "deformation_full", "misc", "occupancy_filter", "pixel_sampler", "dataformat"}
     written = []
     if "hash_ensemble" in which:
         a = {}
@@ -565,6 +603,11 @@ def main():
         gen_deformation(b)
         np.savez_compressed(os.path.join(HERE, "deformation.npz"), **b)
         written.append("deformation.npz")
+    if "deformation_full" in which:
+        b2 = {}
+        gen_deformation_full(b2)
+        np.savez_compressed(os.path.join(HERE, "deformation_full.npz"), **b2)
+        written.append("deformation_full.npz")
     if "misc" in which:
         c = {}
         gen_misc(c)

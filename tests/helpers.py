@@ -20,3 +20,27 @@ def make_tcnn_tables(H: int, geom, seed: int, amplitude: float = 0.5) -> np.ndar
     rng = np.random.default_rng(seed)
     t = (rng.random((c, geom.total_entries, f_enc), dtype=np.float32) * 2 - 1) * amplitude
     return t.astype(np.float16).astype(np.float32)
+
+
+DEFORM_KEYS = [f"se3_field.mlp_stem.layers.{i}.{k}" for i in range(6) for k in ("weight", "bias")] + \
+    ["se3_field.mlp_r.layers.0.weight", "se3_field.mlp_r.layers.0.bias",
+     "se3_field.mlp_v.layers.0.weight", "se3_field.mlp_v.layers.0.bias"]
+
+
+def make_deform_state_dict(seed: int, width: int = 128, code_dim: int = 128, head_scale: float = 0.05) -> dict:
+    """Seeded fp32 state dict of an SE3DeformationField (reference key names, deformation_field.py:50-69) with
+    nn.Linear-like magnitudes U(+-1/sqrt(fan_in)) and rotation / translation heads large enough to exercise the SE(3)
+    exponential (the reference initialises them at +-1e-5, i.e. the identity).  numpy's PCG64 stream: the same
+    arrays wherever this runs, so the goldens made from them need not store 127 756 weights."""
+    rng = np.random.default_rng(seed)
+    n_in = 45 + code_dim
+    shapes = [(width, n_in), (width, width), (width, width), (width, width), (width, n_in + width), (width, width)]
+    sd = {}
+    for i, (o, k) in enumerate(shapes):
+        bound = 1.0 / np.sqrt(k)
+        sd[f"se3_field.mlp_stem.layers.{i}.weight"] = rng.uniform(-bound, bound, (o, k)).astype(np.float32)
+        sd[f"se3_field.mlp_stem.layers.{i}.bias"] = rng.uniform(-bound, bound, (o,)).astype(np.float32)
+    for head in ("mlp_r", "mlp_v"):
+        sd[f"se3_field.{head}.layers.0.weight"] = rng.uniform(-head_scale, head_scale, (3, width)).astype(np.float32)
+        sd[f"se3_field.{head}.layers.0.bias"] = rng.uniform(-head_scale, head_scale, (3,)).astype(np.float32)
+    return sd
