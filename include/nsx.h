@@ -377,6 +377,37 @@ int nsx_adam_dense_f16grad(const nsx_half* grad, int64_t n, float* master, float
  * bit-exact to the oracle. */
 int nsx_hash_indices(const float* x, int64_t B, const nsx_grid_geom* g, uint32_t* idx, void* stream);
 
+/* ---- occupancy-grid update (csrc/occ_grid.hip) ------------------------------------------------------------------
+ * Replaces nerfacc 0.5.2 OccGridEstimator._update / _sample_uniform_and_occupied_cells as the reference reaches them
+ * through the update_occupancy_grid callback, nersemble_instant_ngp.py:184-196 (every 16 steps: all cells while
+ * step < 256, then N/4 uniform draws + the occupied cells (N/4 draws from them when there are more); jittered cell
+ * positions; density at a random timestep x render step; occs = max(occs * 0.95, occ); binaries = occs > min(mean,
+ * occ_thre)).  Random numbers come from Philox4x32-10 keyed by `seed` with counter (slot, purpose, step): identical
+ * on every data-parallel rank and in the CPU oracle (oracle/occgrid.c), which states the conventions.
+ * The density query between nsx_occ_sample_cells and nsx_occ_update is the caller's (deformation + HashEnsemble +
+ * mlp_base kernels of this library on `positions` / `timesteps`). */
+
+/* Bytes of the scratch buffer shared by the three calls below; the caller zeroes it ONCE after allocation (the calls
+ * leave it zeroed again). */
+int64_t nsx_occ_scratch_bytes(int64_t n_cells);
+
+/* Ascending list of the occupied cells (`occupied`, capacity n_cells, int32) and their number (*n_occ, device). */
+int nsx_occ_compact(const uint8_t* binaries, int64_t n_cells, int32_t* occupied, int32_t* n_occ, void* scratch,
+                    void* stream);
+
+/* Slot s of the update -> cell id, jittered world position, random timestep and its normalised time t / (T - 1).
+ * warmup != 0: slot s is cell s (M = res^3).  Otherwise M = N/4 + min(N/4, n_occ) with n_occ read back by the caller
+ * from nsx_occ_compact (the one 4-byte read-back of the update; nerfacc's boolean indexing syncs three times). */
+int nsx_occ_sample_cells(int res, const float* aabb_host, int warmup, const int32_t* occupied, int64_t n_occ,
+                         uint64_t seed, int64_t step, int n_timesteps, int64_t M, int32_t* cell_ids, float* positions,
+                         int32_t* timesteps, float* times, void* stream);
+
+/* occs[c] = max(occs[c] * ema_decay, max over the slots of cell c of occ_values) for every cell named in cell_ids,
+ * then binaries = occs > min(mean(occs[occs >= 0]), occ_thre) (mean accumulated in double).  threshold_out (device,
+ * may be NULL) receives the threshold. */
+int nsx_occ_update(float* occs, uint8_t* binaries, int64_t n_cells, const int32_t* cell_ids, const float* occ_values,
+                   int64_t M, float ema_decay, float occ_thre, void* scratch, float* threshold_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -113,6 +113,12 @@ SIGNATURES = {
     "nsx_adam_dense": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_float,
                                c_float, c_int64, c_void_p, c_void_p, c_void_p]),
     "nsx_hash_indices": (c_int, [c_void_p, c_int64, _GEOM_P, c_void_p, c_void_p]),
+    "nsx_occ_scratch_bytes": (c_int64, [c_int64]),
+    "nsx_occ_compact": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "nsx_occ_sample_cells": (c_int, [c_int, c_void_p, c_int, c_void_p, c_int64, C.c_uint64, c_int64, c_int, c_int64,
+                                     c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "nsx_occ_update": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_float, c_float, c_void_p,
+                               c_void_p, c_void_p]),
 }
 
 _lib = None

@@ -100,7 +100,6 @@ class NeRSembleNGPModel(BaseModel):
         self.num_train_data = num_train_data
         self.kwargs = {"metadata": metadata or {}}
         self._occ_seed = occ_seed
-        self._occ_generator = None
         self._sigma_cache = None
         # reuse the forward values of the sampler's no-grad density pass in the main pass (exact; see get_outputs)
         self.reuse_sigma_pass = True
@@ -175,25 +174,19 @@ class NeRSembleNGPModel(BaseModel):
                 begin_step=cfg.window_hash_encodings_begin, end_step=cfg.window_hash_encodings_end)
 
     # ---- callbacks (:181-233) ---------------------------------------------------------------------
-    def _random_times(self, n: int, device) -> Tensor:
-        T = self.config.n_timesteps
-        if self._occ_generator is None or self._occ_generator.device != torch.device(device):
-            # seeded generator shared by all data-parallel ranks: identical grids without communication
-            self._occ_generator = torch.Generator(device=device).manual_seed(self._occ_seed)
-        ts = torch.randint(0, T, (n, 1), dtype=torch.int, device=device, generator=self._occ_generator)
-        if T == 1:
-            return torch.zeros((n, 1), device=device)       # the reference divides by T-1 = 0 here; time is 0
-        return ts / (T - 1)
-
     def update_occupancy_grid(self, step: int):
+        """nersemble_instant_ngp.py:184-196: every 16 steps the grid is refreshed from the density at jittered cell
+        positions and a random timestep per query.  The random timesteps come from the estimator's counter-based
+        stream (seed shared by all data-parallel ranks: identical grids without communication) instead of
+        ``torch.randint``; with a single timestep the time is 0 (the reference divides by T - 1 = 0 there)."""
         cfg = self.config
-        self._random_times(1, self.occupancy_grid.device)          # make sure the shared generator exists
-        self.occupancy_grid.update_every_n_steps(
+        grid = self.occupancy_grid
+        grid.rng_seed, grid.n_timesteps = self._occ_seed, cfg.n_timesteps
+        grid.update_every_n_steps(
             step=step,
-            occ_eval_fn=lambda x: self.field_density_fn(x, self._random_times(x.shape[0], x.device)).reshape(-1, 1)
-            * cfg.render_step_size,
+            occ_eval_fn=lambda x: self.field_density_fn(x, grid.sample_times).reshape(-1, 1) * cfg.render_step_size,
             n=16, occ_thre=cfg.occ_thre, ema_decay=cfg.occupancy_grid_ema_decay,
-            warmup_steps=cfg.occupancy_grid_warmup_steps, generator=self._occ_generator)
+            warmup_steps=cfg.occupancy_grid_warmup_steps)
 
     def get_training_callbacks(self) -> List[TrainingCallback]:
         callbacks = [TrainingCallback(func=lambda step: self.update_occupancy_grid(step))]

@@ -4,8 +4,8 @@ Mirrors the part of nerfacc 0.5.2 the reference imports: ``OccGri
 ``update_every_n_steps``, attributes ``binaries`` / ``occs`` / ``aabbs`` / ``resolution``), ``pack_info``,
 ``render_weight_from_density``, ``render_visibility_from_density``, ``accumulate_along_rays``.
 Call sites in the reference: nersemble_volumetric_sampler.py:95-108, nersemble_instant_ngp.py:133-137,
-:185-196, :325-331, nersemble_deformation_renderer.py:22-25.  The traversal and the per-ray scans are HIP
-kernels; only random cell selection / EMA bookkeeping of the grid update is torch glue.
+:185-196, :325-331, nersemble_deformation_renderer.py:22-25.  The traversal, the per-ray scans and the grid
+update (cell selection, jitter, EMA-max, threshold) are HIP kernels.
 """
 import ctypes as C
 from typing import Callable, Optional, Tuple
@@ -182,10 +182,6 @@ def composite(t_starts: Tensor, t_ends: Tensor, sigmas: Tensor, rgb: Tensor, pac
 # ------------------------------------------------------------------------------------------------
 # occupancy grid
 # ------------------------------------------------------------------------------------------------
-def _meshgrid3d(res: Tensor, device="cpu") -> Tensor:
-    return torch.stack(torch.meshgrid([torch.arange(int(r), device=device) for r in res], indexing="ij"), dim=-1).long()
-
-
 class OccGridEstimator(nn.Module):
     """Occupancy grid (single level) with nerfacc 0.5.2's interface; traversal runs in libnsx."""
 
@@ -209,14 +205,21 @@ class OccGridEstimator(nn.Module):
         self.register_buffer("aabbs", aabbs)
         self.register_buffer("occs", torch.zeros(self.levels * self.cells_per_lvl))
         self.register_buffer("binaries", torch.zeros([levels] + resolution.tolist(), dtype=torch.bool))
-        grid_coords = _meshgrid3d(resolution).reshape(self.cells_per_lvl, self.DIM)
-        self.register_buffer("grid_coords", grid_coords, persistent=False)
-        self.register_buffer("grid_indices", torch.arange(self.cells_per_lvl), persistent=False)
-        self._aabb_host = (C.c_float * 6)(*[float(v) for v in aabbs[0].tolist()])
+        self._res = int(resolution[0])               # host copy (the buffer lives on the device)
+        self._aabb_host_key = None
 
     @property
     def device(self) -> torch.device:
         return self.occs.device
+
+    def _aabb6(self):
+        """Host copy of ``aabbs[0]`` for the kernels' by-value box argument, rebuilt whenever the buffer was replaced or
+        written (``load_state_dict``, ``.to()``): the kernels always march the box the state dict reports."""
+        key = (self.aabbs.data_ptr(), self.aabbs._version)
+        if self._aabb_host_key != key:
+            self._aabb_host = (C.c_float * 6)(*[float(v) for v in self.aabbs[0].tolist()])
+            self._aabb_host_key = key
+        return self._aabb_host
 
     def _occs_mean(self) -> Tensor:
         """``occs.mean()`` as a device scalar, recomputed only when ``occs`` was written (every 16 steps, or by a
@@ -238,11 +241,11 @@ class OccGridEstimator(nn.Module):
         R = rays_o.shape[0]
         dev = rays_o.device
         binary = self.binaries[0].contiguous().view(torch.uint8)
-        res = int(self.resolution[0])
+        res = self._res
         counts = torch.empty((R,), dtype=torch.int64, device=dev)
         packed = torch.empty((R, 2), dtype=torch.int64, device=dev)
         total = torch.zeros((1,), dtype=torch.int64, device=dev)
-        check(lib().nsx_march_count(ptr(rays_o), ptr(rays_d), R, self._aabb_host, ptr(binary), res, ptr(near_planes),
+        check(lib().nsx_march_count(ptr(rays_o), ptr(rays_d), R, self._aabb6(), ptr(binary), res, ptr(near_planes),
                                     float(far_plane), float(step), ptr(counts), stream()), "nsx_march_count")
         check(lib().nsx_pack_info(ptr(counts), R, ptr(packed), ptr(total), stream()), "nsx_pack_info")
         S = int(total.item())                       # the one host read-back (as in nerfacc's two-pass design)
@@ -251,7 +254,7 @@ class OccGridEstimator(nn.Module):
         ri = torch.empty((S,), dtype=torch.int64, device=dev)
         cells = torch.empty((S,), dtype=torch.int32, device=dev) if want_cells else None
         if S > 0:
-            check(lib().nsx_march_fill(ptr(rays_o), ptr(rays_d), R, self._aabb_host, ptr(binary), res,
+            check(lib().nsx_march_fill(ptr(rays_o), ptr(rays_d), R, self._aabb6(), ptr(binary), res,
                                        ptr(near_planes), float(far_plane), float(step), ptr(packed), ptr(t0), ptr(t1),
                                        ptr(ri), ptr(cells), stream()), "nsx_march_fill")
         return ri, t0, t1, packed, cells
@@ -296,47 +299,83 @@ class OccGridEstimator(nn.Module):
                 ray_indices, t_starts, t_ends = ray_indices[keep], t_starts[keep], t_ends[keep]
         return ray_indices, t_starts, t_ends
 
-    # ---- grid update (nerfacc _update; torch glue around the density evaluation) ----------------
-    @torch.no_grad()
-    def _get_all_cells(self):
-        return [self.grid_indices] * self.levels
+    # ---- grid update (native: csrc/occ_grid.hip) ----------------------------------------------------
+    # nerfacc 0.5.2 ``update_every_n_steps`` / ``_update`` as the reference reaches them from its
+    # ``update_occupancy_grid`` callback (nersemble_instant_ngp.py:184-196).  Cell selection, jitter, the EMA-max and
+    # the threshold are kernels (include/nsx.h "occupancy-grid update"); only ``occ_eval_fn`` -- the model's density
+    # query -- is called in between.  Randomness is counter-based (seed, step, slot), so every data-parallel rank and
+    # the CPU oracle (oracle/occgrid.c) draw the same cells.
+    rng_seed: int = 0            # key of the update's Philox stream (set by the model; shared by all ranks)
+    n_timesteps: int = 1         # range of the per-query random timestep (``sample_times`` / ``sample_timesteps``)
+
+    def _occ_scratch(self) -> Tensor:
+        buf = getattr(self, "_occ_scratch_buf", None)
+        if buf is None or buf.device != self.occs.device:
+            nbytes = int(lib().nsx_occ_scratch_bytes(self.levels * self.cells_per_lvl))
+            buf = self._occ_scratch_buf = torch.zeros((nbytes,), dtype=torch.uint8, device=self.occs.device)
+            self._occupied_buf = torch.empty((self.cells_per_lvl,), dtype=torch.int32, device=self.occs.device)
+            self._n_occ_buf = torch.zeros((1,), dtype=torch.int32, device=self.occs.device)
+        return buf
 
     @torch.no_grad()
-    def _sample_uniform_and_occupied_cells(self, n: int, generator=None):
-        lvl_indices = []
-        for lvl in range(self.levels):
-            uniform_indices = torch.randint(self.cells_per_lvl, (n,), device=self.device, generator=generator)
-            occupied_indices = torch.nonzero(self.binaries[lvl].flatten())[:, 0]
-            if n < len(occupied_indices):
-                selector = torch.randint(len(occupied_indices), (n,), device=self.device, generator=generator)
-                occupied_indices = occupied_indices[selector]
-            lvl_indices.append(torch.cat([uniform_indices, occupied_indices], dim=0))
-        return lvl_indices
+    def sample_cells(self, step: int, warmup: bool):
+        """The density queries of the update at ``step``: (cell_ids int32 [M], positions [M,3], timesteps int32 [M],
+        times [M,1] = timestep / (T - 1)).  Warm-up: every cell once; afterwards N/4 uniform draws followed by the
+        occupied cells (N/4 draws from them when there are more than N/4)."""
+        dev = self.occs.device
+        N = self.cells_per_lvl
+        scratch = self._occ_scratch()
+        n_occ = 0
+        if warmup:
+            M = N
+        else:
+            binary = self.binaries[0].contiguous().view(torch.uint8)
+            check(lib().nsx_occ_compact(ptr(binary), N, ptr(self._occupied_buf), ptr(self._n_occ_buf), ptr(scratch),
+                                        stream()), "nsx_occ_compact")
+            n_occ = int(self._n_occ_buf.item())            # the update's one read-back (nerfacc's nonzero() syncs too)
+            M = N // 4 + min(N // 4, n_occ)
+        cells = torch.empty((M,), dtype=torch.int32, device=dev)
+        positions = torch.empty((M, 3), dtype=torch.float32, device=dev)
+        timesteps = torch.empty((M,), dtype=torch.int32, device=dev)
+        times = torch.empty((M, 1), dtype=torch.float32, device=dev)
+        check(lib().nsx_occ_sample_cells(self._res, self._aabb6(), 1 if warmup else 0,
+                                         ptr(self._occupied_buf), n_occ, int(self.rng_seed) & (2 ** 64 - 1), int(step),
+                                         int(self.n_timesteps), M, ptr(cells), ptr(positions), ptr(timesteps),
+                                         ptr(times), stream()), "nsx_occ_sample_cells")
+        return cells, positions, timesteps, times
+
+    @torch.no_grad()
+    def apply_update(self, cell_ids: Tensor, occ: Tensor, occ_thre: float, ema_decay: float) -> None:
+        """occs <- max(occs * ema_decay, occ) on ``cell_ids`` (duplicates: their maximum), binaries <- occs > min(mean,
+        occ_thre).  In place: ``binaries`` / ``occs`` keep their storage (callers hold views of them)."""
+        occ = occ.reshape(-1).to(torch.float32).contiguous()
+        assert occ.shape[0] == cell_ids.shape[0]
+        if not self.binaries.is_contiguous():
+            self.binaries = self.binaries.contiguous()
+        check(lib().nsx_occ_update(ptr(self.occs), ptr(self.binaries.view(torch.uint8)), self.levels * self.cells_per_lvl,
+                                   ptr(cell_ids), ptr(occ), cell_ids.shape[0], float(ema_decay), float(occ_thre),
+                                   ptr(self._occ_scratch()), None, stream()), "nsx_occ_update")
+        self._occs_mean_key = None                  # occs was written behind torch's back: drop the cached mean
 
     @torch.no_grad()
     def update_every_n_steps(self, step: int, occ_eval_fn: Callable, occ_thre: float = 1e-2, ema_decay: float = 0.95,
-                             warmup_steps: int = 256, n: int = 16, generator=None) -> None:
+                             warmup_steps: int = 256, n: int = 16) -> None:
+        """nerfacc's entry point: runs ``_update`` on every n-th step; a training-time operation."""
         if not self.training:
-            raise RuntimeError("You should only call this function only during training. "
-                               "Please call _update() directly if you want to update the field during inference.")
-        if step % n == 0 and self.training:
+            raise RuntimeError("OccGridEstimator.update_every_n_steps() belongs to training; in evaluation mode call "
+                               "_update() yourself if the grid really has to change.")
+        if step % n == 0:
             self._update(step=step, occ_eval_fn=occ_eval_fn, occ_thre=occ_thre, ema_decay=ema_decay,
-                         warmup_steps=warmup_steps, generator=generator)
+                         warmup_steps=warmup_steps)
 
     @torch.no_grad()
     def _update(self, step: int, occ_eval_fn: Callable, occ_thre: float = 0.01, ema_decay: float = 0.95,
-                warmup_steps: int = 256, generator=None) -> None:
-        if step < warmup_steps:
-            cells = self._get_all_cells()
-        else:
-            cells = self._sample_uniform_and_occupied_cells(self.cells_per_lvl // 4, generator=generator)
-        for lvl, indices in enumerate(cells):
-            grid_coords = self.grid_coords[indices]
-            jitter = torch.rand(grid_coords.shape, dtype=torch.float32, device=grid_coords.device, generator=generator)
-            x = (grid_coords + jitter) / self.resolution
-            x = self.aabbs[lvl, :3] + x * (self.aabbs[lvl, 3:] - self.aabbs[lvl, :3])
-            occ = occ_eval_fn(x).squeeze(-1)
-            cell_ids = lvl * self.cells_per_lvl + indices
-            self.occs[cell_ids] = torch.maximum(self.occs[cell_ids] * ema_decay, occ.to(self.occs.dtype))
-        thre = torch.clamp(self.occs[self.occs >= 0].mean(), max=occ_thre)
-        self.binaries = (self.occs > thre).view(self.binaries.shape)
+                warmup_steps: int = 256) -> None:
+        cell_ids, positions, timesteps, times = self.sample_cells(step, warmup=step < warmup_steps)
+        # the query's random timesteps, for an occ_eval_fn that conditions on time (the model's does)
+        self.sample_timesteps, self.sample_times = timesteps, times
+        try:
+            occ = occ_eval_fn(positions)
+        finally:
+            self.sample_timesteps = self.sample_times = None
+        self.apply_update(cell_ids, occ, occ_thre, ema_decay)

@@ -83,6 +83,15 @@ void nsxo_accumulate(const float* w, const float* v, int C, const int64_t* packe
 double nsxo_distloss(const float* w, const float* m, const float* interval, const int64_t* packed, int64_t R,
                      int64_t n_rays, float* grad_w);
 
+/* ---- occupancy-grid update (oracle/occgrid.c) ---- */
+void nsxo_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+int64_t nsxo_occ_num_slots(int64_t n_cells, int64_t n_occ, int warmup);
+int64_t nsxo_occ_sample_cells(const uint8_t* binaries, int res, const float* aabb, int warmup, uint64_t seed,
+                              int64_t step, int n_timesteps, int32_t* cell_ids, float* positions,
+                              int32_t* timesteps, float* times);
+float nsxo_occ_update(float* occs, uint8_t* binaries, int64_t n_cells, const int32_t* cell_ids,
+                      const float* occ_values, int64_t M, float ema_decay, float occ_thre);
+
 #ifdef __cplusplus
 }
 #endif

@@ -55,6 +55,15 @@ def test_static_config_renders_64x64_in_256_ray_batches():
     assert rgb.shape == (4096, 3) and acc.shape == (4096, 1) and depth.shape == (4096, 1)
     # one 4096-ray batch gives the same image bit for bit (rays are independent; the packed layout is per batch)
     whole = render.render_static(o, d, *args)
+    # (a batch in which no ray hits the grid carries the reference's one fake zero-length sample on its ray 0,
+    # nersemble_volumetric_sampler.py:109-115: count 1, weight 0 -- it renders as background)
+    fake = np.zeros(4096, dtype=bool)
+    for k, b in enumerate(batches):
+        if b["num_samples_per_ray"].sum() == 1 and b["t_starts"][0] == b["t_ends"][0] == 1.0:
+            assert b["weights"][0] == 0.0 and np.array_equal(b["rgb"][0], np.ones(3, np.float32))
+            fake[k * 256] = True
+    assert fake.any()
+    counts = np.where(fake, 0, counts)
     assert np.array_equal(whole["num_samples_per_ray"], counts)
     assert np.array_equal(whole["rgb"], rgb) and np.array_equal(whole["accumulation"], acc)
     # packed layout: sorted ray indices, counts = histogram, samples of a ray are consecutive lattice steps
