@@ -217,6 +217,10 @@ def ptr(t, dtype=None) -> c_void_p:
         raise RuntimeError("nersemble_amd native ops need contiguous tensors")
     if dtype is not None and t.dtype != dtype:
         raise RuntimeError(f"expected dtype {dtype}, got {t.dtype}")
+    if t.device.index != torch._C._cuda_getDevice():
+        # stream() hands the kernels the CURRENT device's stream: a tensor of another device would be dereferenced there
+        raise RuntimeError(f"nersemble_amd native ops launch on the current device (cuda:{torch._C._cuda_getDevice()}); "
+                           f"got a tensor on {t.device}. Use torch.cuda.set_device / torch.cuda.device.")
     return c_void_p(t.data_ptr())
 
 

@@ -63,7 +63,9 @@ class HashTableAdam(torch.optim.Optimizer):
             return self._step_now(found_inf, inv_scale)
         he.wait_tables()
         side_stream.wait_stream(torch.cuda.current_stream(p.device))
-        keep = [t for e in entries for t in (e["code"], e["window"]) if t is not None]
+        # (every G as well: a second G of a step comes from the caching allocator on the main stream and is dropped by
+        # sink.clear() right after the launch -- without the record the allocator could hand it out while it is read)
+        keep = [t for e in entries for t in (e["G"], e["code"], e["window"]) if t is not None]
         keep += [t for t in (found_inf, inv_scale, p.grad) if t is not None]
         with torch.cuda.stream(side_stream):
             self._step_now(found_inf, inv_scale)
@@ -109,6 +111,21 @@ class HashTableAdam(torch.optim.Optimizer):
         if st:
             st["step"] = max(0, st["step"] - 1)
 
+    # ---- checkpointing: moments in the reference's parameter layout (one flat tensor per tcnn encoding) -------------
+    def table_state(self) -> dict:
+        self.he.wait_tables()
+        st = self._state()
+        return {"step": int(st["step"]), "lr": float(self.param_groups[0]["lr"]),
+                "exp_avg": self.he.to_tcnn_layout(st["exp_avg"]), "exp_avg_sq": self.he.to_tcnn_layout(st["exp_avg_sq"])}
+
+    def load_table_state(self, state: dict) -> None:
+        self.he.wait_tables()
+        st = self._state()
+        st["step"] = int(state["step"])
+        self.param_groups[0]["lr"] = float(state.get("lr", self.param_groups[0]["lr"]))
+        st["exp_avg"].copy_(self.he.from_tcnn_layout(state["exp_avg"]))
+        st["exp_avg_sq"].copy_(self.he.from_tcnn_layout(state["exp_avg_sq"]))
+
     def zero_grad(self, set_to_none: bool = True):
         super().zero_grad(set_to_none=set_to_none)
         if self.he.grad_sink is not None:
@@ -147,3 +164,15 @@ class NativeGradScaler:
 
     def get_scale(self) -> float:
         return float(self._scale.item())
+
+    def state_dict(self) -> dict:
+        """torch.amp.GradScaler.state_dict()'s keys."""
+        return {"scale": self.get_scale(), "growth_factor": self.growth_factor, "backoff_factor": self.backoff_factor,
+                "growth_interval": self.growth_interval, "_growth_tracker": int(self._growth_tracker.item())}
+
+    def load_state_dict(self, state: dict) -> None:
+        self._scale.fill_(float(state["scale"]))
+        self._growth_tracker.fill_(int(state.get("_growth_tracker", 0)))
+        self.growth_factor = state.get("growth_factor", self.growth_factor)
+        self.backoff_factor = state.get("backoff_factor", self.backoff_factor)
+        self.growth_interval = state.get("growth_interval", self.growth_interval)

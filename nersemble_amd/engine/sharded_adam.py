@@ -202,6 +202,39 @@ class ShardedTableAdam(torch.optim.Optimizer):
             self.he.grad_sink.clear()
 
     # ---- checkpointing ------------------------------------------------------------------------------------------
+    def _gather_shards(self, mine_local: torch.Tensor) -> torch.Tensor:
+        """All ranks' shards of one fp32 per-parameter array -> the full array, shaped like ``tables``."""
+        p = self.he.tables
+        full = torch.zeros((self.shard * self.world_size,), dtype=torch.float32, device=p.device)
+        mine = full[self.lo:self.lo + self.shard]
+        mine[:self.n_local].copy_(mine_local[:self.n_local])
+        dist.all_gather_into_tensor(full, mine, group=self.group)
+        return full[:self.n].view(p.shape)
+
+    @torch.no_grad()
+    def table_state(self) -> dict:
+        """Collective (every rank calls it): the moments of ALL shards in the reference's parameter layout, the step
+        count and the learning rate -- what ``HashTableAdam.table_state`` returns on one GPU."""
+        self.he.wait_tables()
+        b = self._buffers()
+        return {"step": int(self._step), "lr": float(self.param_groups[0]["lr"]),
+                "exp_avg": self.he.to_tcnn_layout(self._gather_shards(b["exp_avg"])),
+                "exp_avg_sq": self.he.to_tcnn_layout(self._gather_shards(b["exp_avg_sq"]))}
+
+    @torch.no_grad()
+    def load_table_state(self, state: dict) -> None:
+        self.he.wait_tables()
+        b = self._buffers()
+        self._step = int(state["step"])
+        self.param_groups[0]["lr"] = float(state.get("lr", self.param_groups[0]["lr"]))
+        for key in ("exp_avg", "exp_avg_sq"):
+            full = self.he.from_tcnn_layout(state[key]).reshape(-1)
+            b[key].zero_()
+            b[key][:self.n_local].copy_(full[self.lo:self.lo + self.n_local])
+        # the working tables / master shard follow the (already loaded) model parameters
+        b["f16"][:self.n].copy_(self.he.tables.detach().reshape(-1))
+        self.he.mark_half_synced()
+
     @torch.no_grad()
     def gather_master(self) -> None:
         """Rebuild the full fp32 master tables on every rank from the shards (call before ``state_dict()``)."""

@@ -205,6 +205,36 @@ class NeRSembleTrainer:
             if isinstance(opt, ShardedTableAdam):
                 opt.gather_master()
 
+    # ---- checkpointing of the training state (nerfstudio's checkpoints carry "optimizers" and "scalers") -------------
+    def state_dict(self) -> Dict:
+        """Everything a resumed run needs besides the model: Adam moments + step counts of every group (the table
+        moments in the reference's tcnn parameter layout, gathered from all ranks in data-parallel runs -- a
+        collective there), StepLR counters, the loss scale and its growth tracker.  Call ``consolidate()`` first in
+        data-parallel runs so that ``model.state_dict()`` is complete as well."""
+        self.flush_scheduler_step()
+        opts = {}
+        for key, opt in self.optimizers.items():
+            if isinstance(opt, (HashTableAdam, ShardedTableAdam)):
+                opts[key] = {"native_table_adam": opt.table_state()}
+            else:
+                opts[key] = opt.state_dict()
+        return {"optimizers": opts, "schedulers": {k: s.state_dict() for k, s in self.schedulers.items()},
+                "scalers": self.grad_scaler.state_dict()}
+
+    def load_state_dict(self, state: Dict) -> None:
+        self.flush_scheduler_step()
+        for key, opt in self.optimizers.items():
+            saved = state["optimizers"][key]
+            if isinstance(opt, (HashTableAdam, ShardedTableAdam)):
+                opt.load_table_state(saved["native_table_adam"])
+            else:
+                opt.load_state_dict(saved)
+        for key, sch in self.schedulers.items():
+            if key in state.get("schedulers", {}):
+                sch.load_state_dict(state["schedulers"][key])
+        if "scalers" in state:
+            self.grad_scaler.load_state_dict(state["scalers"])
+
     def flush_scheduler_step(self) -> None:
         """Applies the LR-scheduler step of the last finished iteration (skipped if that iteration found inf/NaN).
         Called automatically before the next optimizer step; call it once after the last iteration."""

@@ -171,8 +171,11 @@ class SE3DeformationField(nn.Module):
         return self._packed
 
     def _aabb6(self):
-        if getattr(self, "_aabb6_cache", None) is None:
+        """Host copy of ``aabb`` for the kernels' by-value box argument; follows ``load_state_dict`` / ``.to()``."""
+        key = (self.aabb.data_ptr(), self.aabb._version)
+        if getattr(self, "_aabb6_key", None) != key:
             self._aabb6_cache = (ctypes.c_float * 6)(*[float(v) for v in self.aabb.detach().flatten().tolist()])
+            self._aabb6_key = key
         return self._aabb6_cache
 
     def compute_offsets(self, positions, warp_code=None, windows_param=None, code_index=None, precomputed=None):

@@ -165,6 +165,17 @@ class HashEnsemble(nn.Module):
         out[:, :, :H] = t
         return out
 
+    def to_tcnn_layout(self, native: torch.Tensor) -> List[torch.Tensor]:
+        """A tensor shaped like ``tables`` (master, gradient, optimizer moment) as one flat fp32 tensor per tcnn
+        encoding -- the layout of the reference's ``hash_encodings.{c}.params``."""
+        tc = F.tables_to_tcnn(native, self.n_hash_encodings, self.geom) if native.is_cuda \
+            else self._permute_to_tcnn_cpu(native)
+        return [tc[c].reshape(-1).clone() for c in range(self.n_tcnn_encodings)]
+
+    def from_tcnn_layout(self, per_encoding: List[torch.Tensor]) -> torch.Tensor:
+        tc = torch.stack([t.reshape(self.geom.total_entries, -1).float().cpu() for t in per_encoding])
+        return self._permute_from_tcnn_cpu(tc).to(self.tables.device)
+
     # ---- eval fast path: one time code for a whole image ---------------------------------------------
     def _conditioned(self, conditioning_code: torch.Tensor, window_hash_encodings: Optional[float], device):
         """The code transformations and the window of forward() (hash_ensemble.py:112-139)."""

@@ -100,9 +100,12 @@ class NeRSembleNeRFactoField(nn.Module):
         return density
 
     def _aabb6(self):
-        if getattr(self, "_aabb6_cache", None) is None:
+        """Host copy of ``aabb`` for the kernels' by-value box argument; follows ``load_state_dict`` / ``.to()``."""
+        key = (self.aabb.data_ptr(), self.aabb._version)
+        if getattr(self, "_aabb6_key", None) != key:
             import ctypes
             self._aabb6_cache = (ctypes.c_float * 6)(*[float(v) for v in self.aabb.detach().flatten().tolist()])
+            self._aabb6_key = key
         return self._aabb6_cache
 
     def get_density(self, ray_samples: RaySamples, window_hash_encodings: Optional[float]) -> Tuple[Tensor, Tensor]:

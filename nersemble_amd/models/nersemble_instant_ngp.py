@@ -18,7 +18,7 @@ from torch.nn import Parameter, init
 
 from .. import nerfacc
 from ..engine.generic_scheduler import GenericScheduler
-from ..field_components.deformation_field import SE3DeformationField, SE3DeformationFieldConfig
+from ..field_components.deformation_field import SE3DeformationField, SE3DeformationFieldConfig, _OPTIMIZER_STEPS
 from ..field_components.hash_ensemble import HashEnsembleConfig
 from ..fields.nersemble_nerfacto_field import FieldHeadNames, NeRSembleNeRFactoField
 from ..model_components.nersemble_volumetric_sampler import NeRSembleVolumetricSampler
@@ -251,7 +251,10 @@ class NeRSembleNGPModel(BaseModel):
             return None
         he = self.field.hash_ensemble
         window = self.sched_window_hash_encodings.value if self.sched_window_hash_encodings is not None else None
-        key = (t0, window, he.tables._version, he.tables.data_ptr(), he._f16_version, self.time_embedding.weight._version)
+        # the native table optimizers write through raw pointers and torch's fused Adam does not bump Tensor._version:
+        # the count of optimizer steps taken anywhere is what says "the tables / codes may have changed"
+        key = (t0, window, he.tables._version, he.tables.data_ptr(), he._f16_version, self.time_embedding.weight._version,
+               self.time_embedding.weight.data_ptr(), _OPTIMIZER_STEPS[0])
         if self._eval_blend_cache[0] != key:
             self._eval_blend_cache = (key, he.preblend(self.time_embedding.weight[t0], window))
         return self._eval_blend_cache[1]
@@ -349,6 +352,10 @@ class NeRSembleNGPModel(BaseModel):
 
     def forward(self, ray_bundle: RayBundle):
         return self.get_outputs(ray_bundle)
+
+    def train(self, mode: bool = True):
+        self._eval_blend_cache = (None, None)           # a pre-blended grid never survives a change of mode
+        return super().train(mode)
 
     @torch.no_grad()
     def get_outputs_for_camera_ray_bundle(self, camera_ray_bundle: RayBundle) -> Dict[str, Tensor]:

@@ -45,7 +45,22 @@ def load_nerfstudio_checkpoint(checkpoint: Union[str, Dict], model: torch.nn.Mod
     return int(checkpoint.get("step", -1)), missing, list(result.unexpected_keys)
 
 
-def nerfstudio_checkpoint_from_model(model: torch.nn.Module, step: int) -> Dict:
-    """The inverse: a dict in nerfstudio's checkpoint format (model part only) that the reference's loader accepts."""
-    return {"step": int(step), "pipeline": {MODEL_PREFIX + k: v for k, v in model.state_dict().items()},
-            "optimizers": {}, "scalers": {}}
+def nerfstudio_checkpoint_from_model(model: torch.nn.Module, step: int, trainer=None) -> Dict:
+    """The inverse: a dict in nerfstudio's checkpoint format that the reference's loader accepts.  With ``trainer``
+    (``engine.trainer.NeRSembleTrainer``) the ``optimizers`` / ``scalers`` entries carry the training state (Adam moments,
+    step counts, loss scale) so that a run can resume; data-parallel runs gather the sharded table state first."""
+    training = {"optimizers": {}, "scalers": {}}
+    if trainer is not None:
+        trainer.consolidate()
+        full = trainer.state_dict()
+        training = {"optimizers": full["optimizers"], "scalers": full["scalers"], "schedulers": full["schedulers"]}
+    return {"step": int(step), "pipeline": {MODEL_PREFIX + k: v for k, v in model.state_dict().items()}, **training}
+
+
+def resume_trainer_from_checkpoint(checkpoint: Dict, trainer) -> int:
+    """Model weights + training state from a checkpoint written by ``nerfstudio_checkpoint_from_model(..., trainer)``."""
+    step, _, _ = load_nerfstudio_checkpoint(checkpoint, trainer.model, strict=True)
+    if checkpoint.get("optimizers"):
+        trainer.load_state_dict({"optimizers": checkpoint["optimizers"], "scalers": checkpoint.get("scalers", {}),
+                                 "schedulers": checkpoint.get("schedulers", {})})
+    return step

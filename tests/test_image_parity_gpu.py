@@ -4,7 +4,7 @@ reference's key names and tcnn table layout -- at the reference table size (16 l
 
 Per case:  per-ray sample counts, ray indices and the fp32 interval bounds BIT-EXACT (evaluation mode; in training mode
 up to samples whose alpha sits on the pruning threshold);  rgb / depth / accumulation / rendered deformation within the
-tolerances stated at the asserts;  PSNR of both renders against the synthetic ground truth, |dPSNR| <= 0.05 dB
+tolerances stated at the asserts (measured: max |d rgb| 4e-6 .. 2e-4, PSNR between the two renders 104 .. 131 dB);  PSNR of both renders against the synthetic ground truth, |dPSNR| <= 0.05 dB
 (BASELINE.json north_star), printed.
 
 Cases:  BASELINE configs[0] (static, one grid), configs[1] (H = 16), configs[2] (H = 32), configs[3] (dense march,
@@ -64,7 +64,7 @@ def _oracle_render(model, W, w, o, d, times, binary, **kw):
                                  background=1.0, clamp_rgb=not model.training, **kw)
 
 
-def _compare(out, ref, gt, label, rgb_max=2e-2, rgb_mean=1.5e-3, exact_samples=True):
+def _compare(out, ref, gt, label, rgb_max=2e-3, rgb_mean=1e-4, exact_samples=True):
     ri = out["ray_indices"][0].cpu().numpy()
     rs = out["ray_samples"][0]
     t0 = rs.frustums.starts[:, 0].detach().cpu().numpy()
@@ -92,7 +92,7 @@ def _compare(out, ref, gt, label, rgb_max=2e-2, rgb_mean=1.5e-3, exact_samples=T
           f"PSNR(oracle, gt) {p_ref:.4f} dB, |dPSNR| {abs(p_gpu - p_ref):.5f} dB, PSNR(HIP, oracle) {p_x:.2f} dB, "
           f"max |d rgb| {d_rgb.max():.2e}")
     assert abs(p_gpu - p_ref) <= 0.05, (label, p_gpu, p_ref)                        # north_star: within 0.05 dB
-    assert p_x >= 45.0, (label, p_x)
+    assert p_x >= (70.0 if exact_samples else 45.0), (label, p_x)
     return p_gpu, p_ref
 
 
@@ -147,18 +147,18 @@ def test_eval_fast_path_single_timestep_image(cuda):
                          bundle.times.cpu().numpy(), binary)
     gt = batch["image"].cpu().numpy()
     _compare(slow, ref, gt, "p030_h16 eval image, per-sample blend")
-    _compare(out, ref, gt, "p030_h16 eval image, pre-blended tables", rgb_max=3e-2, rgb_mean=3e-3)
+    _compare(out, ref, gt, "p030_h16 eval image, pre-blended tables", rgb_max=5e-3, rgb_mean=5e-4)
 
 
 def test_training_mode_forward_matches_oracle(cuda):
     """Training-mode forward: jittered near planes (the same U[0,1) draws on both sides) and sigma_fn visibility
-    pruning with alpha_thre = min(1e-2, occs.mean()) = 0.008.  Samples whose alpha lies within 3 % of the threshold may be
+    pruning with alpha_thre = min(1e-2, occs.mean()).  Samples whose alpha lies within 3 % of the threshold may be
     kept on one side only (their weight is <= 1e-2); every other sample agrees bit for bit."""
     model, data, w = _build("p030_h16", cuda)
     W = randomise_model(model, 21, oracle.grid_geometry(**REF_GEOM_KW))
     binary = _ellipsoid_grid(W["aabb"])
     model.occupancy_grid.binaries.copy_(torch.from_numpy(binary)[None].to(cuda))
-    model.occupancy_grid.occs.fill_(0.008)                        # occs.mean() < alpha_thre -> threshold 0.008
+    model.occupancy_grid.occs.fill_(0.5)                          # alpha_thre = min(1e-2, occs.mean()) = 1e-2
     model.sched_window_deform.update(9000)
     model.sched_window_hash_encodings.update(50000)
     model.train()
@@ -174,7 +174,7 @@ def test_training_mode_forward_matches_oracle(cuda):
                          alpha_thre=model.config.alpha_thre, early_stop_eps=model.config.early_stop_eps,
                          occs_mean=float(model.occupancy_grid.occs.mean()))
     info = ref["sampling"]
-    assert abs(info["alpha_thre"] - 0.008) < 1e-7
+    assert abs(info["alpha_thre"] - 0.01) < 1e-7
     # the marched (pre-pruning) sample set is bit-exact: the traversal saw the same near planes
     assert model.occupancy_grid.last_n_marched == info["n_marched"]
     ri = out["ray_indices"][0].cpu().numpy()
@@ -189,7 +189,8 @@ def test_training_mode_forward_matches_oracle(cuda):
     assert 0.05 < keep.mean() < 0.999 and len(got) > 5000          # the pruning does remove samples
     print(f"[image parity] training-mode pruning: marched {info['n_marched']}, kept {len(got)} (oracle {len(want)}), "
           f"on-threshold {len(got ^ want)}")
-    _compare(out, ref, gt.cpu().numpy(), "p030_h16 training-mode forward", rgb_max=3e-2, exact_samples=(got == want))
+    _compare(out, ref, gt.cpu().numpy(), "p030_h16 training-mode forward", rgb_max=2e-3 if got == want else 3e-2,
+             rgb_mean=1e-4 if got == want else 1e-3, exact_samples=(got == want))
 
 
 @pytest.mark.parametrize("name,steps", [("static_h1", 200), ("p030_h16", 300)])

@@ -58,7 +58,7 @@ def test_ema_max_threshold_bit_exact(res, scale, cuda):
     o2, b2, thre = og.update(o1, b1, cells, vals, 0.95, 0.01)
     assert np.array_equal(est.occs.cpu().numpy(), o2)
     assert np.array_equal(est.binaries.cpu().numpy().reshape(-1), b2)
-    assert (thre < 0.01) == (scale < 0.01) and 0.0 < b2.mean() < 1.0
+    assert (thre < np.float32(0.01)) == (scale < 0.01) and 0.0 < b2.mean() < 1.0
 
 
 def _model(cuda, res=32):

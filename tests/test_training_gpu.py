@@ -253,3 +253,69 @@ def test_cached_parameter_packs_follow_fused_optimizers(cuda):
     with torch.no_grad():
         y1 = he(x, code)
     assert torch.equal(he.half_tables(), he.tables.detach().half()) and not torch.equal(y0.detach(), y1)
+
+
+def test_eval_preblend_cache_follows_training(cuda):
+    """eval(t0) -> train k steps -> eval(t0): the pre-blended grid must be rebuilt (the table optimizers write through
+    raw pointers and torch's fused Adam leaves Tensor._version alone, so the cache keys on the optimizer-step count)."""
+    from nersemble_amd.workloads import build_workload
+    torch.manual_seed(5)
+    trainer, data, _ = build_workload("p030_h16", device="cuda:0", small=True, n_rays=512)
+    model = trainer.model
+    model.sched_window_hash_encodings.update(90000)          # window saturated: only the weights change below
+    for step in range(3):
+        trainer.train_iteration(step, *data.next_train(step))
+    bundle, _, _ = data.eval_image_rays(cam=1, timestep=3, downscale=64)
+
+    def render(fast):
+        model.eval()
+        model.eval_preblend = fast
+        with torch.no_grad():
+            return model(bundle)["rgb"].clone()
+
+    first = render(True)
+    blend_before = model._eval_blend_cache[1].clone()
+    model.train()
+    for step in range(3, 40):
+        trainer.train_iteration(step, *data.next_train(step))
+    fast, slow = render(True), render(False)
+    assert not torch.equal(model._eval_blend_cache[1], blend_before)          # rebuilt from the trained tables
+    assert (fast - slow).abs().mean().item() <= 2e-3 and (fast - slow).abs().max().item() <= 2e-2
+    assert (fast - first).abs().mean().item() > 5 * (fast - slow).abs().mean().item()   # training did move the image
+    model.train()
+
+
+def test_resume_from_checkpoint_continues_the_run(cuda):
+    """Model + training state (Adam moments of all groups -- the table moments in the reference's tcnn layout --, step
+    counts, StepLR counters, loss scale) through the nerfstudio checkpoint dict; the resumed run takes the same steps."""
+    from nersemble_amd.util.checkpoint import nerfstudio_checkpoint_from_model, resume_trainer_from_checkpoint
+    from nersemble_amd.workloads import build_workload
+    torch.manual_seed(8)
+    a, data, _ = build_workload("p030_h16", device="cuda:0", small=True, n_rays=512)
+    batches = [data.next_train(s) for s in range(7)]
+    for step in range(4):
+        a.train_iteration(step, *batches[step])
+    ckpt = nerfstudio_checkpoint_from_model(a.model, 4, trainer=a)
+    assert set(ckpt) >= {"step", "pipeline", "optimizers", "scalers"}
+    tab = ckpt["optimizers"]["fields/tables"]["native_table_adam"]
+    he = a.model.field.hash_ensemble
+    assert tab["step"] == 4 and len(tab["exp_avg"]) == he.n_tcnn_encodings
+    assert tab["exp_avg"][0].numel() == ckpt["pipeline"]["_model.field.hash_ensemble.hash_encodings.0.params"].numel()
+    assert float(sum(t.abs().sum() for t in tab["exp_avg_sq"])) > 0
+    occ_a = (a.model.occupancy_grid.occs.clone(), a.model.occupancy_grid.binaries.clone())
+    losses_a = [a.train_iteration(step, *batches[step])[0].item() for step in range(4, 7)]
+
+    torch.manual_seed(1234)                                   # different initial weights: everything comes from the file
+    b, _, _ = build_workload("p030_h16", device="cuda:0", small=True, n_rays=512)
+    assert resume_trainer_from_checkpoint(ckpt, b) == 4
+    assert torch.equal(b.model.occupancy_grid.occs, occ_a[0]) and torch.equal(b.model.occupancy_grid.binaries, occ_a[1])
+    assert b.grad_scaler.get_scale() == ckpt["scalers"]["scale"]
+    for sched in (b.model.sched_window_deform, b.model.sched_window_hash_encodings):
+        sched.update(3)                                       # (window schedules are functions of the step)
+    losses_b = [b.train_iteration(step, *batches[step])[0].item() for step in range(4, 7)]
+    # same data, same weights, same moments: the runs agree up to the order of the fp32 atomics (and the random near-
+    # plane jitter of the marcher, which draws from torch's global generator)
+    assert np.allclose(losses_a, losses_b, rtol=5e-2), (losses_a, losses_b)
+    sa = a.optimizers["fields/tables"].state[a.model.field.hash_ensemble.tables]["step"]
+    sb = b.optimizers["fields/tables"].state[b.model.field.hash_ensemble.tables]["step"]
+    assert sa == sb == 7
