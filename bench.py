@@ -9,7 +9,16 @@ deformation -> HashEnsemble -> mlp_base -> mlp_head -> weights / compositing -> 
 
 Prints ONE JSON line on rank 0.  `value` = ray samples processed by all ranks / max-over-ranks wall time.
 `roofline` is measured live with HIP events on the kernels' stream over the timed region for the dominant
-kernel; `cpu_baseline` times the CPU oracle ("port") of the fused HashEnsemble forward on the host cores.
+kernel; `kernels_alone` times the priced kernels one at a time on 2^20 uniformly random samples right after the timed
+region (no co-running stream, no cache-friendly ray order); `cpu_baseline` times the PyTorch-CPU restatement of the
+encoder path (oracle/torch_cpu.py) on the host cores.
+
+Occupancy grid (`--grid`): the grid refines itself every 16 steps, so the samples a 4096-ray batch yields fall from
+~2^20 at the start of training to ~10^5 once the volume is pruned, and with them the step time.  The metric is quoted
+on "4096 rays x 2^20 samples": by default (`--grid frozen`) the grid state reached at the end of the warm-up is kept for
+the timed region -- the update callback STILL RUNS on schedule with all its work (cell selection, density queries,
+EMA, threshold), only its result is not adopted -- so every timed step processes the same kind of batch.  `--grid live`
+lets it evolve (what round 1 reported).
 """
 import argparse
 import json
@@ -58,29 +67,126 @@ def kernel_model(name: str, ints, H: int, total_entries: int):
     return None, 0.0
 
 
-def cpu_baseline(H: int, seconds_budget: float = 15.0):
-    """CPU oracle (C restatement, OpenMP on all host cores) of the fused HashEnsemble forward on a bounded
-    sample of the same workload: reference geometry, H grids, uniformly random positions."""
-    import numpy as np
+def cpu_baseline(H: int, seconds_budget: float = 25.0):
+    """the PyTorch-CPU restatement of the encoder path (HashEnsemble forward + mlp_base,
+    oracle/torch_cpu.py -- gathers + einsum, held to the C oracle in tests/test_oracle_hash.py) on all host cores,
+    swept over S = 2^16, 2^18, 2^20 uniformly random samples at the reference geometry (bounded by the time budget).
+    The reference has no CPU encoder of its own (tinycudann is CUDA-only): kind = "port"."""
     import oracle
-    from oracle import hashgrid as ohg
-    g = oracle.grid_geometry()
-    rng = np.random.default_rng(0)
-    f_enc, p, c = ohg.ens_layout(H)
-    tabs = rng.integers(0, 2 ** 16, size=(c, g.total_entries, f_enc), dtype=np.uint16) & np.uint16(0x3BFF)
-    B = 1 << 14
-    x = rng.random((B, 3), dtype=np.float32)
-    code = rng.standard_normal((B, H)).astype(np.float32)
-    ohg.ensemble_fwd(x[:256], tabs, H, g, code[:256])           # warm up / page in
-    t0 = time.time()
-    n = 0
-    while time.time() - t0 < seconds_budget:
-        ohg.ensemble_fwd(x, tabs, H, g, code)
-        n += B
-    dt = time.time() - t0
-    return {"value": n / dt, "unit": "ray-samples/s (HashEnsemble forward only)", "cores": os.cpu_count(),
-            "kind": "port", "sample": f"{n} samples of the H={H} fused HashEnsemble forward (oracle/nsx_oracle.c, "
-                                      f"OpenMP), reference geometry 16 levels x 2^19, {dt:.1f} s"}
+    from oracle import torch_cpu
+    cores = os.cpu_count() or 1
+    sweep, threads = torch_cpu.time_encoder_sweep(H, oracle.grid_geometry(), budget_s=seconds_budget, threads=cores)
+    best = max(sweep, key=lambda r: r["samples_per_s"])
+    total_s = sum(r["seconds"] for r in sweep)
+    return {"value": best["samples_per_s"], "unit": "ray-samples/s (encoder forward: HashEnsemble + mlp_base)",
+            "cores": threads, "kind": "port",
+            "sample": f"PyTorch-CPU encoder (oracle/torch_cpu.py), H={H}, 16 levels x 2^19, uniformly random samples, "
+                      f"S = {', '.join(str(r['samples']) for r in sweep)} ({total_s:.1f} s in total); value = best S",
+            "sweep": sweep}
+
+
+def kernels_alone(trainer, H: int, log2_s: int = 20, iters: int = 10):
+    """The priced kernels ONE AT A TIME on S = 2^20 uniformly random samples (seed 0) with the run's own tables and
+    weights: no optimizer stream beside them, no ray-coherent sample order that would serve the coarse levels from L2 /
+    Infinity Cache.  These are the numbers to hold against BASELINE.json's ">= 70 % of the HBM roofline on the 32-grid
+    HashEnsemble"; `rooflines` above are the same kernels as they run inside the step."""
+    import ctypes as C
+    from nersemble_amd import _lib, functional as F
+    from nersemble_amd._lib import check, lib, ptr, stream
+    model = trainer.model
+    he = model.field.hash_ensemble
+    dev = he.tables.device
+    g, S, T = he.geom, 1 << log2_s, 24
+    gen = torch.Generator(device=dev).manual_seed(0)
+    x = torch.rand((S, 3), device=dev, generator=gen)
+    code = torch.randn((T, H), device=dev, generator=gen) * 0.5
+    slot = torch.randint(0, T, (S,), device=dev, generator=gen, dtype=torch.int32)
+    dout = torch.randn((S, 2 * g.n_levels), device=dev, generator=gen)
+    f16 = he.half_tables()
+    torch.cuda.synchronize()
+
+    def timeit(fn, n=iters, warm=2):
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(n):
+            fn()
+        e.record()
+        torch.cuda.synchronize()
+        return s.elapsed_time(e) / n
+
+    out = {}
+
+    def entry(name, ms, bound, work):
+        if bound == "hbm":
+            ach = work / (ms * 1e-3) / 1e9
+            out[name] = {"bound": "hbm", "ms": round(ms, 4), "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS,
+                         "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4), "algorithmic_bytes": work,
+                         "samples_per_s": S / (ms * 1e-3)}
+        else:
+            ach = work / (ms * 1e-3) / 1e12
+            out[name] = {"bound": "mfma", "ms": round(ms, 4), "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "algorithmic_flops": work,
+                         "samples_per_s": S / (ms * 1e-3)}
+
+    entry("nsx_hash_ensemble_fwd", timeit(lambda: F._hash_ensemble_fwd_raw(x, f16, H, g, code, slot, None)), "hbm",
+          kernel_model("nsx_hash_ensemble_fwd", [S], H, g.total_entries)[1])
+    G = torch.zeros((T, g.total_entries, 2), device=dev)
+    dcode = torch.empty((S, H), device=dev)
+    dx = torch.empty((S, 3), device=dev)
+
+    def bwd():
+        check(lib().nsx_hash_ensemble_bwd_factored(ptr(x), S, ptr(f16), H, C.byref(g), ptr(code), code.stride(0), T,
+                                                   ptr(slot), None, ptr(dout), ptr(G), ptr(dcode), ptr(dx), None,
+                                                   stream()), "nsx_hash_ensemble_bwd_factored")
+    entry("nsx_hash_ensemble_bwd_factored", timeit(bwd), "hbm",
+          kernel_model("nsx_hash_ensemble_bwd_factored", [S], H, g.total_entries)[1])
+    # table Adam on the run's own state, value-preserving (lr 0 keeps master / working copy; the moments only decay)
+    opt = trainer.optimizers.get(trainer.group_of_tables())
+    from nersemble_amd.engine.hash_adam import HashTableAdam
+    if isinstance(opt, HashTableAdam):
+        he.wait_tables()
+        st = opt._state()
+        G.zero_()
+        one = torch.ones((1,), device=dev)
+        zero = torch.zeros((1,), device=dev)
+
+        def adam():
+            check(lib().nsx_adam_hash_factored(ptr(G), T, ptr(code), code.stride(0), None, H, C.byref(g), ptr(he.tables.data),
+                                               ptr(st["exp_avg"]), ptr(st["exp_avg_sq"]), ptr(f16), 0.0, 0.9, 0.999, 1e-15,
+                                               max(int(st["step"]), 1), ptr(one), ptr(zero), stream()),
+                  "nsx_adam_hash_factored")
+        entry("nsx_adam_hash_factored", timeit(adam), "hbm",
+              kernel_model("nsx_adam_hash_factored", [T], H, g.total_entries)[1])
+    del G
+    df = model.deformation_field
+    if df is not None:
+        box = model.scene_box.aabb.to(dev)
+        pos = x * (box[1] - box[0]) + box[0]
+        dcode_t = torch.randn((T, 128), device=dev, generator=gen) * 0.1
+        packed = df.packed_params()
+        aabb6 = df._aabb6()
+        w7 = F.deform_window7(3.5)
+        off = torch.empty((S, 3), device=dev)
+
+        def dfwd():
+            check(lib().nsx_deform_fwd(ptr(packed), ptr(pos), S, aabb6, ptr(dcode_t), dcode_t.stride(0), ptr(slot), w7,
+                                       ptr(off), stream()), "nsx_deform_fwd")
+        entry("nsx_deform_fwd", timeit(dfwd), "mfma", S * DEFORM_FWD_FLOPS)
+        goff = torch.randn((S, 3), device=dev, generator=gen)
+        gparams = torch.zeros(int(lib().nsx_deform_param_count()), device=dev)
+        gtable = torch.zeros_like(dcode_t)
+        scratch = torch.empty(int(lib().nsx_deform_scratch_bytes(S)), dtype=torch.uint8, device=dev)
+
+        def dbwd():
+            check(lib().nsx_deform_bwd(ptr(packed), ptr(pos), S, aabb6, ptr(dcode_t), dcode_t.stride(0), ptr(slot), T, w7,
+                                       ptr(goff), ptr(scratch), ptr(gparams), ptr(gtable), None, stream()),
+                  "nsx_deform_bwd")
+        entry("nsx_deform_bwd", timeit(dbwd, n=max(3, iters // 2)), "mfma", S * DEFORM_FWD_FLOPS * 3.0)
+    return {"samples": S, "sampling": "uniform random positions in the scene box, 24 time-code slots, seed 0",
+            "kernels": out}
 
 
 def main():
@@ -98,6 +204,13 @@ def main():
                     help="allocator warm-up: device memory handed to torch's caching allocator before the first step")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="do not record HIP events around the native calls (no roofline block; measures their overhead)")
+    ap.add_argument("--grid", choices=("frozen", "live"), default="frozen",
+                    help="frozen: the occupancy-grid state at the end of the warm-up is kept for the timed region (the "
+                         "update still runs with all its work, its result is not adopted); live: the grid evolves")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak: 4096 rays per rank; strong: the 4096-ray batch is sliced 4096/N rays per rank with global "
+                         "loss normalisers (SURVEY.md 8e)")
+    ap.add_argument("--no-kernels-alone", action="store_true", help="skip the stand-alone kernel timings after the run")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -126,7 +239,11 @@ def main():
     # allocations and returns the losers with empty_cache(), engine/placement.py -- arrays carved out of one big
     # cached block are always at the slow end of the placement spread.)
     torch.manual_seed(19980801)            # identical initial weights on every rank
-    trainer, data, info = build_workload(a.workload, device=dev, rank=rank, world_size=world)
+    n_rays = None
+    if a.scaling == "strong" and world > 1:
+        n_rays = WORKLOADS[a.workload]["rays"] // world
+    trainer, data, info = build_workload(a.workload, device=dev, rank=rank, world_size=world, n_rays=n_rays,
+                                         global_loss_normalisers=(a.scaling == "strong" and world > 1))
     if a.reserve_gb > 0:
         reserve = torch.empty(int(a.reserve_gb * 2 ** 30), dtype=torch.uint8, device=dev)
         del reserve
@@ -152,6 +269,18 @@ def main():
         return samples, loss, metrics
 
     run(a.warmup, 0)
+    if a.grid == "frozen":
+        grid = trainer.model.occupancy_grid
+        adopt = grid.apply_update
+
+        def run_update_without_adopting(cell_ids, occ, occ_thre, ema_decay):
+            held = (grid.occs.clone(), grid.binaries.clone())
+            adopt(cell_ids, occ, occ_thre, ema_decay)           # the full update: scatter-max, EMA, mean, threshold
+            grid.occs.copy_(held[0])
+            grid.binaries.copy_(held[1])
+            grid._occs_mean_key = None
+
+        grid.apply_update = run_update_without_adopting
     # Python's cyclic garbage collector pauses the host for tens of ms whenever its generation-2 threshold trips
     # (sporadic 70-100 ms steps); training loops collect at controlled points instead (NeRSembleTrainer.gc_every)
     import gc
@@ -211,6 +340,13 @@ def main():
                                    "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": None,
                                    "avg_launch_ms": round(p["avg_ms"], 4), "launches": p["calls"],
                                    "algorithmic_bytes_per_launch": per_launch}
+                if ach > HBM_PEAK_GBPS:
+                    # ray-ordered samples: the coarse levels are served from L2 / Infinity Cache, so the algorithmic
+                    # byte count is not HBM traffic here -- not a roofline fraction (see kernels_alone for one)
+                    rooflines[name]["frac"] = None
+                    rooflines[name]["note"] = ("algorithmic bytes per second exceed the HBM peak: cache hits on "
+                                               "ray-coherent samples; the HBM-roofline fraction of this kernel is "
+                                               "kernels_alone's (uniform samples)")
             else:
                 ach = per_launch / (p["avg_ms"] * 1e-3) / 1e12
                 rooflines[name] = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS,
@@ -218,16 +354,21 @@ def main():
                                    "avg_launch_ms": round(p["avg_ms"], 4), "launches": p["calls"],
                                    "algorithmic_flops_per_launch": per_launch}
         # the dominant kernel = the modelled kernel with the largest total time in the timed region
-        dom_name = max(rooflines, key=lambda k: prof[k]["total_ms"]) if rooflines else None
-        roofline = rooflines.get(dom_name)
+        priced = [k for k in rooflines if rooflines[k]["frac"] is not None]
+        dom_name = max(priced, key=lambda k: prof[k]["total_ms"]) if priced else None
+        roofline = dict(rooflines[dom_name]) if dom_name else None
         pmc_path = os.path.join(ROOT, "profiles", "pmc", "latest.json")
         # the committed counter passes were taken on the default workload at one rank: their per-launch bytes say
         # nothing about another table size / sample count, so any other run reports traffic = null
         if roofline and os.path.exists(pmc_path) and a.workload == "p030_h32" and world == 1:
             try:
-                pmc = json.load(open(pmc_path)).get("per_launch_hbm_bytes", {})
+                pmc_doc = json.load(open(pmc_path))
+                pmc = pmc_doc.get("per_launch_hbm_bytes", {})
                 if dom_name in pmc:
-                    roofline["traffic"] = pmc[dom_name]       # from the committed rocprofv3 --pmc pass of this command
+                    # NOT a counter of this run: the committed rocprofv3 --pmc passes of this command (counters need
+                    # their own passes; gpurun refuses --pmc together with tracing)
+                    roofline["traffic"] = pmc[dom_name]
+                    roofline["traffic_source"] = "profiles/pmc/latest.json <- " + str(pmc_doc.get("source", "?"))
             except Exception:
                 pass
         kernels = {k: {"calls": v["calls"], "total_ms": round(v["total_ms"], 3), "avg_ms": round(v["avg_ms"], 4)}
@@ -235,12 +376,15 @@ def main():
         out = {
             "metric": "ray-samples/sec training, 4096 rays x 2^20 samples", "value": total_samples / dt_max,
             "unit": "ray-samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": dt_max / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": dt_max / a.steps * 1e3, "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None,
             "dtype": "f16", "data": "synthetic",
             "config": {"workload": a.workload, "participant": info["participant"], "n_hash_encodings": H,
                        "rays_per_gpu": info["rays"], "max_n_samples_per_batch": "2^20",
                        "samples_per_step_per_gpu": samples / a.steps, "n_timesteps": info["n_timesteps"],
-                       "parallelism": f"dp{world}", "params": info["params"]},
+                       "parallelism": f"dp{world}", "params": info["params"],
+                       "occupancy_grid": "state at the end of the warm-up kept for the timed region; the update runs on "
+                                         "schedule, its result is not adopted" if a.grid == "frozen" else "live",
+                       "rccl_ranks": world if (world > 1 and a.backend == "nccl") else 0},
             "rays_per_sec": world * info["rays"] * a.steps / dt_max,
             "psnr_last": float(metrics["psnr"].detach()), "loss_last": float(loss.detach()),
             "roofline": roofline, "rooflines": rooflines, "native_kernel_ms": kernels,
@@ -253,6 +397,10 @@ def main():
         }
         if trainer.placement_report is not None:
             out["table_placement"] = trainer.placement_report       # one-off, before the warm-up (engine/placement.py)
+        spp = [p["samples"] for p in out["per_step"]]
+        out["samples_per_step_min_max"] = [min(spp), max(spp)] if spp else None
+        if not a.no_kernels_alone and world == 1:
+            out["kernels_alone"] = kernels_alone(trainer, H)
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(H)
         print(json.dumps(out))

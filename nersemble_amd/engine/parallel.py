@@ -43,6 +43,40 @@ def all_reduce_gradients(params: Iterable[torch.nn.Parameter], world_size: int, 
             off += n
 
 
+def global_normaliser_scales(local_counts: torch.Tensor, n_eff_local: torch.Tensor, n_rays_local: int,
+                             world_size: int, rank: int, group=None) -> torch.Tensor:
+    """Strong scaling of ONE ray batch sliced over the ranks: the reference's loss terms are masked means
+    whose denominators count rays / samples of the WHOLE batch (models/base.py:110-113 masked MSE, :120-134 alpha,
+    :158-202 empty / near, :206-222 depth) and the distortion loss divides by ``ray_id.max() + 1`` of the whole batch
+    (:235-247).  A rank only sees its slice, so every term ``sum_local / count_local`` is re-weighted by
+
+        scale = world * count_local / count_global          (count clamped to >= 1 like the reference's empty-mask case)
+
+    after which the usual gradient AVERAGE over the ranks (all-reduce sum / world) yields exactly the gradient of the
+    single-process loss on the union batch, and the mean of the ranks' losses is that loss.
+
+    local_counts [K] fp32: the raw local denominators of the K masked means; n_eff_local: this rank's raw
+    ``ray_id.max() + 1`` (0 when the slice has no samples); the slices are consecutive blocks of ``n_rays_local`` rays in
+    rank order.  Returns [K + 1] scales (the last one for the distortion term).  One small all-gather."""
+    k = local_counts.numel()
+    mine = torch.cat([local_counts.reshape(-1).to(torch.float32), n_eff_local.reshape(1).to(torch.float32)])
+    if world_size > 1:
+        everyone = torch.empty((world_size * (k + 1),), dtype=torch.float32, device=mine.device)
+        dist.all_gather_into_tensor(everyone, mine.contiguous(), group=group)
+        everyone = everyone.view(world_size, k + 1)
+    else:
+        everyone = mine.view(1, k + 1)
+    one = torch.ones((), dtype=torch.float32, device=mine.device)
+    count_global = torch.maximum(everyone[:, :k].sum(dim=0), one)
+    count_local = torch.maximum(mine[:k], one)
+    # index + 1 of the last ray of the WHOLE batch that carries samples (slices without samples do not take part)
+    offsets = torch.arange(world_size, device=mine.device, dtype=torch.float32) * float(n_rays_local)
+    last = torch.where(everyone[:, k] > 0, offsets + everyone[:, k], torch.zeros_like(offsets))
+    n_eff_global = torch.maximum(last.max(), one)
+    return torch.cat([world_size * count_local / count_global,
+                      (world_size * torch.maximum(mine[k], one) / n_eff_global).reshape(1)])
+
+
 def shard_seed(base_seed: int, rank: int) -> int:
     """Rank-specific RNG stream for ray sampling (identical model init comes from the un-sharded base seed)."""
     return base_seed + 7919 * rank

@@ -62,12 +62,17 @@ class NeRSembleTrainer:
     def __init__(self, model: NeRSembleNGPModel, opt_cfg: Optional[OptimizerConfig] = None,
                  mixed_precision: bool = True, world_size: int = 1, factored_table_grad: Optional[bool] = None,
                  rank: Optional[int] = None, sharded_table_adam: Optional[bool] = None,
-                 overlap_table_adam: bool = True, calibrate_table_placement: bool = True):
+                 overlap_table_adam: bool = True, calibrate_table_placement: bool = True,
+                 global_loss_normalisers: bool = False):
+        """``global_loss_normalisers``: the ranks hold consecutive slices of ONE ray batch (strong scaling)
+        -- loss denominators are made global so that the step equals the single-process step on the union batch."""
         self.model = model
         self.cfg = opt_cfg or OptimizerConfig()
         self.mixed_precision = mixed_precision
         self.world_size = world_size
         self.rank = (dist.get_rank() if dist.is_initialized() else 0) if rank is None else rank
+        model.global_loss_normalisers = dict(world_size=world_size, rank=self.rank) \
+            if (global_loss_normalisers and world_size > 1) else None
         device = next(model.parameters()).device
         groups = model.get_param_groups()
         lrs = {"fields": self.cfg.lr_main, "deformation_field": self.cfg.lr_deformation_field,

@@ -108,6 +108,10 @@ class NeRSembleNGPModel(BaseModel):
         # evaluation fast path: when every ray of a bundle carries the same timestep the H hash tables
         # are blended once per image into one 2-feature grid (HashEnsemble.preblend)
         self.eval_preblend = True
+        # data-parallel STRONG scaling (one ray batch sliced over the ranks): dict(world_size, rank, group) makes the loss
+        # denominators those of the whole batch (engine.parallel.global_normaliser_scales); None: every rank's batch is
+        # its own (weak scaling, single GPU)
+        self.global_loss_normalisers = None
         self._eval_blend = None
         self._eval_blend_cache = (None, None)
         self.populate_modules()
@@ -460,7 +464,12 @@ class NeRSembleNGPModel(BaseModel):
                 loss_dict["depth_loss"] = fused[dl.LOSS_DEPTH]
             # == reduce(torch.add, loss_dict.values()), summed in the kernel in the same order
             loss_dict.total = fused[dl.LOSS_TOTAL]
+            if self.global_loss_normalisers is not None:
+                self._apply_global_normalisers(loss_dict, fused, accumulation.shape[0])
             return loss_dict
+        if self.global_loss_normalisers is not None:
+            raise NotImplementedError("global loss normalisers (ray batch sliced over the ranks) are implemented on the "
+                                      "fused loss path: distortion, near, empty and depth terms on, <= 5000 rays")
         loss_dict["rgb_loss"] = self.get_masked_rgb_loss(batch, outputs["rgb"])
         if "alpha_map" in batch:
             alpha_loss = self.get_alpha_loss(batch, accumulation)
@@ -500,6 +509,30 @@ class NeRSembleNGPModel(BaseModel):
         if dist_loss is not None:
             loss_dict["dist_loss"] = dist_loss
         return loss_dict
+
+    def _apply_global_normalisers(self, loss_dict: "LossDict", fused: Tensor, n_rays_local: int) -> None:
+        """Re-weights the terms of a fused loss vector so that their denominators are those of the whole (sliced) batch;
+        ``loss_dict.total`` becomes the re-weighted sum (same association as the kernel's)."""
+        from .. import distloss as dl
+        from ..engine.parallel import global_normaliser_scales
+        dp = self.global_loss_normalisers
+        f = fused.detach()
+        sums = dl.LOSS_SAMPLE_SUMS
+        # raw local denominators: masked rgb rays, background rays, depth rays, empty-mask samples, near-mask samples
+        if self.config.use_masked_rgb_loss:
+            n_rgb = f[sums + 5]
+        else:
+            n_rgb = torch.full((), float(n_rays_local), device=f.device)
+        counts = torch.stack([n_rgb, f[sums + 6], f[sums + 7], f[sums + 2], f[sums + 4]])
+        n_eff_raw = torch.where(f[dl.LOSS_NUM_SAMPLES] > 0, f[sums + 8], torch.zeros_like(f[sums + 8]))
+        sc = global_normaliser_scales(counts, n_eff_raw, n_rays_local, dp["world_size"], dp["rank"], dp.get("group"))
+        scale_of = {"rgb_loss": sc[0], "alpha_loss": sc[1], "depth_loss": sc[2], "empty_loss": sc[3], "near_loss": sc[4],
+                    "dist_loss": sc[5]}
+        total = None
+        for name in list(loss_dict.keys()):
+            loss_dict[name] = loss_dict[name] * scale_of[name]
+            total = loss_dict[name] if total is None else total + loss_dict[name]
+        loss_dict.total = total
 
     def get_metrics_dict(self, outputs, batch) -> Dict[str, Tensor]:
         fused = self._fused_step_losses(outputs, batch)

@@ -49,8 +49,8 @@ def build_model_config(w: dict, max_n_samples_per_batch: int = 20, small: bool =
 
 
 def build_workload(name: str, device="cuda:0", small: bool = False, rank: int = 0, world_size: int = 1,
-                   n_rays: int = None, factored_table_grad=None, sharded_table_adam=None
-                   ) -> Tuple[NeRSembleTrainer, SyntheticNeRSembleData, dict]:
+                   n_rays: int = None, factored_table_grad=None, sharded_table_adam=None,
+                   global_loss_normalisers: bool = False) -> Tuple[NeRSembleTrainer, SyntheticNeRSembleData, dict]:
     w = WORKLOADS[name]
     box = torch.tensor(SCENE_BOXES[w["pid"]], dtype=torch.float32)
     rays = n_rays if n_rays is not None else w["rays"]
@@ -63,7 +63,7 @@ def build_workload(name: str, device="cuda:0", small: bool = False, rank: int = 
         model.occupancy_grid.occs.fill_(1.0)
     trainer = NeRSembleTrainer(model, OptimizerConfig(), mixed_precision=True, world_size=world_size,
                                factored_table_grad=factored_table_grad, rank=rank,
-                               sharded_table_adam=sharded_table_adam)
+                               sharded_table_adam=sharded_table_adam, global_loss_normalisers=global_loss_normalisers)
     info = dict(workload=name, participant=w["pid"], n_hash_encodings=w["H"], n_timesteps=w["T"], rays=rays,
                 params=sum(p.numel() for p in model.parameters()))
     return trainer, data, info

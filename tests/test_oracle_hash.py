@@ -158,3 +158,26 @@ def test_ensemble_bwd_matches_finite_differences():
     lhs = float((dtab.astype(np.float64) * t64).sum())
     rhs = loss(x, code.astype(np.float64), t64)
     assert abs(lhs - rhs) <= 1e-4 * max(1.0, abs(rhs))
+
+
+def test_torch_cpu_encoder_restatement_matches_the_c_oracle():
+    """oracle/torch_cpu.py (the PyTorch-CPU encoder bench.py times as ``cpu_baseline``) against the C oracle."""
+    import torch
+    from oracle import torch_cpu, mlp as omlp
+    for H, kw in ((4, SMALL_GEOM_KW), (16, SMALL_GEOM_KW), (32, SMALL_GEOM_KW)):
+        g = oracle.grid_geometry(**kw)
+        tabs = make_tcnn_tables(H, g, 3 + H)
+        rng = np.random.default_rng(H)
+        x = rng.random((2000, 3), dtype=np.float32)
+        code = (rng.standard_normal((2000, H)) * 0.7).astype(np.float32)
+        want = ohg.ensemble_fwd(x, tabs.astype(np.float16).view(np.uint16), H, g, code).astype(np.float32)
+        got = torch_cpu.hash_ensemble_forward(torch.from_numpy(x), torch.from_numpy(tabs).to(torch.float16),
+                                              torch.from_numpy(code), g, H)
+        err = np.abs(got.float().numpy() - want)
+        # per-encoding fp16 rounding before the blend (what the reference's C tcnn encodings do) vs the fused oracle's
+        # single rounding: a few fp16 ulp of the blended value's scale
+        assert np.quantile(err, 0.999) <= 2.0 ** -8 * max(1.0, np.abs(want).max()), (H, float(err.max()))
+        params = (rng.standard_normal(omlp.param_count(0)) * 0.25).astype(np.float32)
+        base = torch_cpu.mlp_base_forward(got, torch.from_numpy(params)).float().numpy()
+        want_b = omlp.mlp_fwd(got.float().numpy(), params, 0, 16, 0).astype(np.float32)
+        assert np.abs(base - want_b).max() <= 4 * 2.0 ** -10 * max(1.0, np.abs(want_b).max())

@@ -166,3 +166,87 @@ def test_sharded_table_adam_world2_matches_single_process(tmp_path):
         opt.step()
     d = (he.tables.detach() - r0["master"]).abs().max().item()
     assert d <= 2e-5, d                                   # fp16 summation order inside the reduce-scatter
+
+
+# ---- strong scaling: one ray batch sliced over the ranks, loss denominators made global -------------------------------
+def _union_batch(seed=0, R=64):
+    """Per-ray / per-sample quantities of a synthetic 64-ray batch with the reference's masked-mean structure
+    (models/base.py:90-249): masked rgb rays, background rays, depth rays, empty / near sample masks, per-ray distortion
+    sums; the last 9 rays carry no samples (so ``ray_id.max() + 1`` < R and the second slice ends early)."""
+    g = torch.Generator().manual_seed(seed)
+    counts = torch.randint(0, 9, (R,), generator=g)
+    counts[-9:] = 0
+    d = {"w_rgb": torch.rand(R, generator=g).requires_grad_(True), "m_rgb": torch.rand(R, generator=g) < 0.6,
+         "w_alpha": torch.rand(R, generator=g).requires_grad_(True), "m_bg": torch.rand(R, generator=g) < 0.4,
+         "w_depth": torch.rand(R, generator=g).requires_grad_(True), "m_depth": torch.rand(R, generator=g) < 0.7,
+         "w_dist": torch.rand(R, generator=g).requires_grad_(True), "counts": counts}
+    S = int(counts.sum())
+    d["ray_of"] = torch.repeat_interleave(torch.arange(R), counts)
+    d["w_empty"] = torch.rand(S, generator=g).requires_grad_(True)
+    d["m_empty"] = torch.rand(S, generator=g) < 0.5
+    d["w_near"] = torch.rand(S, generator=g).requires_grad_(True)
+    d["m_near"] = torch.rand(S, generator=g) < 0.3
+    return d
+
+
+def _masked_mean(v, m):
+    m = m.to(v.dtype)
+    return (v * m).sum() / m.sum().clamp(min=1.0)
+
+
+def _loss_terms(d, rays, samples):
+    """The six terms on a slice: (terms [6], raw counts [5], raw n_eff)."""
+    has = d["counts"][rays] > 0
+    n_eff = (torch.nonzero(has).max() + 1).float() if has.any() else torch.zeros(())
+    terms = torch.stack([_masked_mean(d["w_rgb"][rays] ** 2, d["m_rgb"][rays]),
+                         _masked_mean(d["w_alpha"][rays].abs(), d["m_bg"][rays]),
+                         _masked_mean(d["w_depth"][rays] ** 2, d["m_depth"][rays]),
+                         _masked_mean(d["w_empty"][samples] ** 2, d["m_empty"][samples]),
+                         _masked_mean(d["w_near"][samples] ** 2, d["m_near"][samples]),
+                         (d["w_dist"][rays] * has).sum() / n_eff.clamp(min=1.0)])
+    counts = torch.stack([d["m_rgb"][rays].sum(), d["m_bg"][rays].sum(), d["m_depth"][rays].sum(),
+                          d["m_empty"][samples].sum(), d["m_near"][samples].sum()]).float()
+    return terms, counts, n_eff
+
+
+def _normaliser_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from nersemble_amd.engine.parallel import all_reduce_gradients, global_normaliser_scales
+    d = _union_batch()
+    R = d["counts"].shape[0]
+    per = R // world
+    rays = torch.arange(rank * per, (rank + 1) * per)
+    samples = torch.nonzero((d["ray_of"] >= rank * per) & (d["ray_of"] < (rank + 1) * per))[:, 0]
+    terms, counts, n_eff = _loss_terms(d, rays, samples)
+    scales = global_normaliser_scales(counts, n_eff, per, world, rank)
+    loss = (terms * scales).sum()
+    leaves = [d[k] for k in ("w_rgb", "w_alpha", "w_depth", "w_dist", "w_empty", "w_near")]
+    loss.backward()
+    all_reduce_gradients(leaves, world)                       # the trainer's gradient average
+    torch.save({"loss": loss.detach(), "grads": [p.grad for p in leaves]}, os.path.join(out_dir, f"n{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_global_loss_normalisers_world2_equal_the_union_batch(tmp_path):
+    """Two ranks on half-batches with ``global_normaliser_scales`` reproduce the single-process loss and gradient on the
+    union batch: mean of the ranks' losses == the loss, averaged gradients == its gradient."""
+    port = _free_port()
+    mp.spawn(_normaliser_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    d = _union_batch()
+    R = d["counts"].shape[0]
+    terms, _, n_eff = _loss_terms(d, torch.arange(R), torch.arange(d["ray_of"].shape[0]))
+    assert n_eff == R - 9
+    loss = terms.sum()
+    loss.backward()
+    r0, r1 = torch.load(tmp_path / "n0.pt"), torch.load(tmp_path / "n1.pt")
+    assert torch.allclose((r0["loss"] + r1["loss"]) / 2, loss.detach(), rtol=1e-6)
+    for k, name in enumerate(("w_rgb", "w_alpha", "w_depth", "w_dist", "w_empty", "w_near")):
+        assert torch.allclose(r0["grads"][k], d[name].grad, rtol=1e-5, atol=1e-8), name
+        assert torch.equal(r0["grads"][k], r1["grads"][k])
+    # without the re-weighting the halves do NOT add up (different mask counts per half)
+    h0, c0, _ = _loss_terms(d, torch.arange(R // 2), torch.nonzero(d["ray_of"] < R // 2)[:, 0])
+    h1, c1, _ = _loss_terms(d, torch.arange(R // 2, R), torch.nonzero(d["ray_of"] >= R // 2)[:, 0])
+    assert not torch.allclose((h0.sum() + h1.sum()) / 2, loss.detach(), rtol=1e-3)

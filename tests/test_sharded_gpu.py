@@ -188,3 +188,96 @@ def test_two_rank_training_on_one_gpu(cuda, tmp_path):
     assert torch.equal(r0["master"], r1["master"]) and torch.equal(r0["master"].half(), r0["f16"])
     init = r0["master"].numel()
     assert (r0["f16"].float() - r0["master"]).abs().max().item() < 1e-3 and init > 0
+
+
+# ---- strong scaling: ONE ray batch sliced over the ranks == the single-process step on the union batch ----
+def _no_jitter(trainer):
+    """The marcher's near-plane jitter draws from torch's global generator (one draw per ray of the local batch): switch
+    it off so that the union batch and its halves march the same samples."""
+    grid = trainer.model.occupancy_grid
+    orig = grid.sampling
+
+    def sampling(*args, **kw):
+        kw["stratified"] = False
+        return orig(*args, **kw)
+
+    grid.sampling = sampling
+
+
+def _union_data(n_rays_total):
+    from nersemble_amd.data.synthetic import SyntheticNeRSembleData
+    from nersemble_amd.workloads import SCENE_BOXES
+    box = torch.tensor(SCENE_BOXES[30], dtype=torch.float32)
+    return SyntheticNeRSembleData(box, n_timesteps=100, n_rays=n_rays_total, device="cuda:0", rank=0)
+
+
+def _slice_batch(bundle, batch, lo, hi):
+    return bundle[lo:hi], {k: v[lo:hi] for k, v in batch.items()}
+
+
+def _strong_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from nersemble_amd.workloads import build_workload
+    per = 256
+    bundle, batch = _union_data(per * world).next_train(0)
+    res = {}
+    for mode, kw in (("dense", dict(factored_table_grad=False, sharded_table_adam=False)), ("sharded", dict())):
+        torch.manual_seed(19980801)
+        trainer, _, _ = build_workload("p030_h16", device="cuda:0", small=True, n_rays=per, rank=rank, world_size=world,
+                                       global_loss_normalisers=True, **kw)
+        _no_jitter(trainer)
+        loss, loss_dict, _ = trainer.train_iteration(0, *_slice_batch(bundle, batch, rank * per, (rank + 1) * per))
+        trainer.flush_scheduler_step()
+        trainer.consolidate()
+        model = trainer.model
+        res[mode] = {"loss": loss.item(), "terms": {k: v.item() for k, v in loss_dict.items()},
+                     "tables": model.field.hash_ensemble.tables.detach().cpu(),
+                     "small": torch.cat([p.detach().reshape(-1).cpu() for n, p in model.named_parameters()
+                                         if "tables" not in n])}
+        del trainer
+        torch.cuda.empty_cache()
+    torch.save(res, os.path.join(out_dir, f"s{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_on_half_batches_equal_one_process_on_the_union_batch(cuda, tmp_path):
+    """Real kernels, world_size 2 (two processes share the GPU, gloo moves the collectives), the 512-ray batch sliced
+    256 + 256 with global loss normalisers: loss, every loss term, the small parameters and the hash tables after one
+    optimizer step equal the single-process step on the whole batch -- with the dense fp32 gradient all-reduce to fp32
+    noise, with the sharded fp16 reduce-scatter to fp16-gradient noise."""
+    import torch.multiprocessing as mp
+    from nersemble_amd.workloads import build_workload
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_strong_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = torch.load(tmp_path / "s0.pt"), torch.load(tmp_path / "s1.pt")
+    bundle, batch = _union_data(512).next_train(0)
+    torch.manual_seed(19980801)
+    single, _, _ = build_workload("p030_h16", device="cuda:0", small=True, n_rays=512)
+    init_tables = single.model.field.hash_ensemble.tables.detach().cpu().clone()
+    _no_jitter(single)
+    loss, loss_dict, _ = single.train_iteration(0, bundle, batch)
+    single.flush_scheduler_step()
+    tables = single.model.field.hash_ensemble.tables.detach().cpu()
+    small = torch.cat([p.detach().reshape(-1).cpu() for n, p in single.model.named_parameters() if "tables" not in n])
+    moved = (tables - init_tables).abs() > 1e-4                    # entries the step touched (+-lr at step 1)
+    assert moved.float().mean().item() > 1e-3
+    for mode, tol_frac in (("dense", 0.9995), ("sharded", 0.995)):
+        a, b = r0[mode], r1[mode]
+        assert torch.equal(a["tables"], b["tables"]) and torch.equal(a["small"], b["small"])     # identical replicas
+        # the mean of the ranks' losses is the union loss, term by term
+        assert np.isclose((a["loss"] + b["loss"]) / 2, loss.item(), rtol=2e-4), (mode, a["loss"], b["loss"], loss.item())
+        for k, v in loss_dict.items():
+            assert np.isclose((a["terms"][k] + b["terms"][k]) / 2, v.item(), rtol=2e-3, atol=1e-9), (mode, k)
+        assert a["loss"] != b["loss"]                              # the halves differ; only their mean is the loss
+        d = (a["tables"] - tables).abs()
+        # Adam at step 1 moves every touched entry by +-lr: an entry agrees unless its (tiny) gradient changed sign or
+        # vanished in the other summation order / in fp16
+        assert (d[moved] <= 1e-5).float().mean().item() >= tol_frac, (mode, (d[moved] <= 1e-5).float().mean().item())
+        ds = (a["small"] - small).abs()
+        assert (ds <= 1e-5).float().mean().item() >= 0.99, (mode, (ds <= 1e-5).float().mean().item())
