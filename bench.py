@@ -399,6 +399,8 @@ def main():
             out["table_placement"] = trainer.placement_report       # one-off, before the warm-up (engine/placement.py)
         spp = [p["samples"] for p in out["per_step"]]
         out["samples_per_step_min_max"] = [min(spp), max(spp)] if spp else None
+        if len(out["per_step"]) > 40:                            # long runs: every k-th step is enough to see the trend
+            out["per_step"] = out["per_step"][::len(out["per_step"]) // 40]
         if not a.no_kernels_alone and world == 1:
             out["kernels_alone"] = kernels_alone(trainer, H)
         if not a.no_cpu_baseline and world == 1:
