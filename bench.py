@@ -13,12 +13,14 @@ kernel; `kernels_alone` times the priced kernels one at a time on 2^20 uniformly
 region (no co-running stream, no cache-friendly ray order); `cpu_baseline` times the PyTorch-CPU restatement of the
 encoder path (oracle/torch_cpu.py) on the host cores.
 
-Occupancy grid (`--grid`): the grid refines itself every 16 steps, so the samples a 4096-ray batch yields fall from
-~2^20 at the start of training to ~10^5 once the volume is pruned, and with them the step time.  The metric is quoted
-on "4096 rays x 2^20 samples": by default (`--grid frozen`) the grid state reached at the end of the warm-up is kept for
-the timed region -- the update callback STILL RUNS on schedule with all its work (cell selection, density queries,
-EMA, threshold), only its result is not adopted -- so every timed step processes the same kind of batch.  `--grid live`
-lets it evolve (what round 1 reported).
+Which steps are timed matters: the samples a 4096-ray batch keeps fall from ~2^20 at the start of training to ~10^5
+once the model has learnt where the volume is empty (the occupancy grid prunes the marcher, the sigma_fn visibility test
+prunes what it marched), and with them the step time, while the table optimizer's 12 GB pass per step stays.  The timed
+region is the W warm-up + K steps the caller asks for, from a fresh model (as in round 1).  Two stationary readings are
+added to the same line: `steady_state` -- training continues to step `--steady-after` (600) and 100 more steps are
+timed there -- and, on request, `--preroll N` moves the whole timed region behind N untimed steps.  `--grid frozen`
+keeps the occupancy grid of the end of the warm-up (its update still runs with all its work, the result is not adopted);
+measured, that alone does not hold the sample count (the visibility pruning follows the model, not the grid).
 """
 import argparse
 import json
@@ -39,6 +41,9 @@ MFMA_PEAK_TFLOPS = 2500.0       # dense fp16 MFMA peak (MI355X_MICROARCH.md)
 DEFORM_FWD_FLOPS = 253952.0     # 2 * 126 976 MAC per sample
 
 
+SPLIT_SCATTER = True            # set in main() from the trainer's gradient sink: the factored backward runs as two kernels
+
+
 def kernel_model(name: str, ints, H: int, total_entries: int):
     """(bound, work per launch) for the kernels with a stated algorithmic cost.
     `ints` = the integer arguments of the C-ABI call as recorded by the profiler."""
@@ -48,7 +53,13 @@ def kernel_model(name: str, ints, H: int, total_entries: int):
         # table gather for dL/dcode and dL/dx (512 H) + read-modify-write of G (128 corners x 2 floats x 2) + fp16
         # dout (64) + dcode (4 H) + x, dx, slot (28): the factored gradient moves FEWER bytes than SURVEY's dense
         # count 1024 H + 76 -- the kernel is priced against what it has to move
+        if SPLIT_SCATTER:                                     # gather half only: table reads + dout + dcode + x, dx, slot
+            return "hbm", ints[0] * (512.0 * H + 64.0 + 4.0 * H + 28.0)
         return "hbm", ints[0] * (512.0 * H + 2048.0 + 64.0 + 4.0 * H + 28.0)
+    if name == "nsx_hash_ensemble_bwd_scatter":               # (B, n_slots, blocks_per_cu): read-modify-write of G + dout
+        # + x + slot.  Priced against HBM for uniformity; what bounds it is the rate of memory-side fp32 atomics
+        # (measured ~14-20 G 32-B sectors/s; 64 sector requests per sample without duplicate merging)
+        return "hbm", ints[0] * (2048.0 + 128.0 + 12.0 + 4.0)
     if name == "nsx_hash_ensemble_bwd":
         return "hbm", ints[0] * (1024.0 * H + 76.0)
     if name == "nsx_adam_hash_factored":                      # (n_slots, code_stride, H, step)
@@ -67,22 +78,68 @@ def kernel_model(name: str, ints, H: int, total_entries: int):
     return None, 0.0
 
 
-def cpu_baseline(H: int, seconds_budget: float = 25.0):
-    """the PyTorch-CPU restatement of the encoder path (HashEnsemble forward + mlp_base,
-    oracle/torch_cpu.py -- gathers + einsum, held to the C oracle in tests/test_oracle_hash.py) on all host cores,
-    swept over S = 2^16, 2^18, 2^20 uniformly random samples at the reference geometry (bounded by the time budget).
-    The reference has no CPU encoder of its own (tinycudann is CUDA-only): kind = "port"."""
+def cpu_baseline(H: int, seconds_budget: float = 30.0):
+    """The encoder path on the host cores, two restatements, each bounded in time:
+      * SURVEY.md 8(d)'s PyTorch-CPU encoder (oracle/torch_cpu.py: HashEnsemble forward + mlp_base as gathers + einsum,
+        held to the C oracle in tests/test_oracle_hash.py), swept over S = 2^16, 2^18, 2^20 uniformly random samples at
+        the reference geometry as far as the budget allows, intra-op threads calibrated first;
+      * the C oracle (oracle/nsx_oracle.c, OpenMP over all cores) on the fused HashEnsemble forward.
+    The reference has no CPU encoder of its own (tinycudann is CUDA-only): kind = "port".  `value` is the faster of the
+    two -- a baseline, not a target."""
+    import numpy as np
     import oracle
-    from oracle import torch_cpu
+    from oracle import hashgrid as ohg, torch_cpu
     cores = os.cpu_count() or 1
-    sweep, threads = torch_cpu.time_encoder_sweep(H, oracle.grid_geometry(), budget_s=seconds_budget, threads=cores)
+    g = oracle.grid_geometry()
+    sweep, threads = torch_cpu.time_encoder_sweep(H, g, budget_s=0.6 * seconds_budget, max_threads=cores)
     best = max(sweep, key=lambda r: r["samples_per_s"])
-    total_s = sum(r["seconds"] for r in sweep)
-    return {"value": best["samples_per_s"], "unit": "ray-samples/s (encoder forward: HashEnsemble + mlp_base)",
-            "cores": threads, "kind": "port",
-            "sample": f"PyTorch-CPU encoder (oracle/torch_cpu.py), H={H}, 16 levels x 2^19, uniformly random samples, "
-                      f"S = {', '.join(str(r['samples']) for r in sweep)} ({total_s:.1f} s in total); value = best S",
-            "sweep": sweep}
+    rng = np.random.default_rng(0)
+    f_enc, p, c = ohg.ens_layout(H)
+    tabs = rng.integers(0, 2 ** 16, size=(c, g.total_entries, f_enc), dtype=np.uint16) & np.uint16(0x3BFF)
+    B = 1 << 16
+    x = rng.random((B, 3), dtype=np.float32)
+    code = rng.standard_normal((B, H)).astype(np.float32)
+    ohg.ensemble_fwd(x[:256], tabs, H, g, code[:256])           # warm up / page in
+    t0, n = time.time(), 0
+    while time.time() - t0 < 0.3 * seconds_budget:
+        ohg.ensemble_fwd(x, tabs, H, g, code)
+        n += B
+    c_rate = n / (time.time() - t0)
+    torch_wins = best["samples_per_s"] >= c_rate
+    return {"value": max(best["samples_per_s"], c_rate),
+            "unit": "ray-samples/s (encoder forward on the host: HashEnsemble" + (" + mlp_base)" if torch_wins else ")"),
+            "cores": threads if torch_wins else cores, "kind": "port",
+            "sample": (f"H={H}, 16 levels x 2^19, uniformly random samples; PyTorch-CPU encoder (oracle/torch_cpu.py, "
+                       f"{threads} intra-op threads of {cores} cores) S = {', '.join(str(r['samples']) for r in sweep)}: "
+                       f"{best['samples_per_s']:.0f} samples/s at best; C oracle (OpenMP, {cores} threads) {n} samples: "
+                       f"{c_rate:.0f} samples/s; value = the faster"),
+            "torch_cpu_sweep": sweep, "c_port_samples_per_s": c_rate}
+
+
+def steady_state(trainer, data, first_step: int, settle_at: int, rays: int, n_timed: int = 100):
+    """Continues the run to step `settle_at` (untimed), then times `n_timed` steps: by then the occupancy grid and the
+    visibility pruning have settled and every step sees about the same number of samples."""
+    import gc
+    step = first_step
+    while step < settle_at:
+        trainer.train_iteration(step, *data.next_train(step))
+        step += 1
+    batches = [data.next_train(step + i) for i in range(n_timed)]
+    gc.collect()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    samples, counts = 0, []
+    for i in range(n_timed):
+        _, _, metrics = trainer.train_iteration(step + i, *batches[i])
+        counts.append(metrics["num_samples_per_batch"])
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    trainer.flush_scheduler_step()
+    counts = [int(c) for c in counts]
+    samples = sum(counts)
+    return {"from_step": step, "steps": n_timed, "ms_per_step": dt / n_timed * 1e3, "value": samples / dt,
+            "unit": "ray-samples/s", "rays_per_sec": rays * n_timed / dt, "samples_per_step_min_max": [min(counts), max(counts)],
+            "psnr": float(metrics["psnr"].detach())}
 
 
 def kernels_alone(trainer, H: int, log2_s: int = 20, iters: int = 10):
@@ -141,8 +198,20 @@ def kernels_alone(trainer, H: int, log2_s: int = 20, iters: int = 10):
         check(lib().nsx_hash_ensemble_bwd_factored(ptr(x), S, ptr(f16), H, C.byref(g), ptr(code), code.stride(0), T,
                                                    ptr(slot), None, ptr(dout), ptr(G), ptr(dcode), ptr(dx), None,
                                                    stream()), "nsx_hash_ensemble_bwd_factored")
-    entry("nsx_hash_ensemble_bwd_factored", timeit(bwd), "hbm",
-          kernel_model("nsx_hash_ensemble_bwd_factored", [S], H, g.total_entries)[1])
+    def gather():
+        check(lib().nsx_hash_ensemble_bwd_factored(ptr(x), S, ptr(f16), H, C.byref(g), ptr(code), code.stride(0), T,
+                                                   ptr(slot), None, ptr(dout), None, ptr(dcode), ptr(dx), None,
+                                                   stream()), "nsx_hash_ensemble_bwd_factored")
+
+    def scatter():
+        check(lib().nsx_hash_ensemble_bwd_scatter(ptr(x), S, C.byref(g), T, ptr(slot), ptr(dout), ptr(G), None, 8,
+                                                  stream()), "nsx_hash_ensemble_bwd_scatter")
+    entry("nsx_hash_ensemble_bwd_factored (fused gather + scatter)", timeit(bwd), "hbm",
+          S * (512.0 * H + 2048.0 + 64.0 + 4.0 * H + 28.0))
+    entry("nsx_hash_ensemble_bwd_factored (gather half)", timeit(gather), "hbm", S * (512.0 * H + 64.0 + 4.0 * H + 28.0))
+    entry("nsx_hash_ensemble_bwd_scatter", timeit(scatter), "hbm", S * (2048.0 + 128.0 + 12.0 + 4.0))
+    out["nsx_hash_ensemble_bwd_scatter"]["note"] = ("bound by memory-side fp32 atomics, not by bandwidth: uniform samples "
+                                                    "share no cells, 64 sector requests per sample")
     # table Adam on the run's own state, value-preserving (lr 0 keeps master / working copy; the moments only decay)
     opt = trainer.optimizers.get(trainer.group_of_tables())
     from nersemble_amd.engine.hash_adam import HashTableAdam
@@ -204,13 +273,19 @@ def main():
                     help="allocator warm-up: device memory handed to torch's caching allocator before the first step")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="do not record HIP events around the native calls (no roofline block; measures their overhead)")
-    ap.add_argument("--grid", choices=("frozen", "live"), default="frozen",
+    ap.add_argument("--grid", choices=("frozen", "live"), default="live",
                     help="frozen: the occupancy-grid state at the end of the warm-up is kept for the timed region (the "
                          "update still runs with all its work, its result is not adopted); live: the grid evolves")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="weak: 4096 rays per rank; strong: the 4096-ray batch is sliced 4096/N rays per rank with global "
                          "loss normalisers (SURVEY.md 8e)")
     ap.add_argument("--no-kernels-alone", action="store_true", help="skip the stand-alone kernel timings after the run")
+    ap.add_argument("--preroll", type=int, default=0,
+                    help="untimed training steps BEFORE the warm-up (e.g. 600: the occupancy grid and the visibility "
+                         "pruning have settled, the timed window is stationary)")
+    ap.add_argument("--steady-after", type=int, default=600,
+                    help="after the timed region, training continues to this step and 100 more steps are timed as the "
+                         "`steady_state` block (0: skip)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -249,8 +324,10 @@ def main():
         del reserve
     H = WORKLOADS[a.workload]["H"]
 
+    for s in range(a.preroll):                                   # optional: start the measurement from a settled state
+        trainer.train_iteration(s, *data.next_train(s))
     # synthetic inputs are generated up front: they are resident in HBM when the timed region starts
-    batches = [data.next_train(s) for s in range(a.warmup + a.steps)]
+    batches = [data.next_train(a.preroll + s) for s in range(a.warmup + a.steps)]
     torch.cuda.synchronize()
 
     step_marks = []                          # (event at step start, device-side sample count) per timed step
@@ -262,7 +339,7 @@ def main():
                 ev = torch.cuda.Event(enable_timing=True)
                 ev.record()
             bundle, batch = batches[s]
-            loss, loss_dict, metrics = trainer.train_iteration(s, bundle, batch)
+            loss, loss_dict, metrics = trainer.train_iteration(a.preroll + s, bundle, batch)
             samples += metrics["num_samples_per_batch"]
             if mark:
                 step_marks.append((ev, metrics["num_samples_per_batch"]))
@@ -289,7 +366,11 @@ def main():
     gc.disable()
     # HIP events only around the calls that are priced against a roofline (+ the other large kernels), allocated
     # before the timed region
+    global SPLIT_SCATTER
+    sink = trainer.model.field.hash_ensemble.grad_sink
+    SPLIT_SCATTER = bool(sink is not None and sink.split_scatter)
     _lib.profiler.watch = {"nsx_hash_ensemble_fwd", "nsx_hash_ensemble_bwd_factored", "nsx_hash_ensemble_bwd",
+                           "nsx_hash_ensemble_bwd_scatter",
                            "nsx_adam_hash_factored", "nsx_adam_dense", "nsx_deform_fwd", "nsx_deform_bwd",
                            "nsx_mlp_fwd", "nsx_mlp_bwd", "nsx_check_finite", "nsx_march_count", "nsx_march_fill",
                            "nsx_hash_grad_expand", "nsx_hash_grad_expand_f16", "nsx_adam_dense_f16grad",
@@ -397,6 +478,8 @@ def main():
         }
         if trainer.placement_report is not None:
             out["table_placement"] = trainer.placement_report       # one-off, before the warm-up (engine/placement.py)
+        if a.steady_after > 0 and world == 1:
+            out["steady_state"] = steady_state(trainer, data, a.preroll + a.warmup + a.steps, a.steady_after, info["rays"])
         spp = [p["samples"] for p in out["per_step"]]
         out["samples_per_step_min_max"] = [min(spp), max(spp)] if spp else None
         if len(out["per_step"]) > 40:                            # long runs: every k-th step is enough to see the trend

@@ -121,6 +121,18 @@ int nsx_hash_ensemble_bwd_factored(const float* x, int64_t B, const nsx_half* ta
                                    int n_slots, const int32_t* code_slot, const float* window,
                                    const float* dout, float* G, float* dcode, float* dx, float* nonfinite,
                                    void* stream);
+/* The two halves of the factored backward as separate launches, so that they can run on separate streams:
+ *   nsx_hash_ensemble_bwd_factored(..., G = NULL, ...)   the GATHER half: dcode and dx only (bandwidth-bound table reads)
+ *   nsx_hash_ensemble_bwd_scatter                        the SCATTER half: G only.  It needs neither the tables nor the
+ *                                                        codes (the gradient factors through the code slot), is bound by
+ *                                                        the rate of memory-side fp32 atomics and uses ~1/3 of the fused
+ *                                                        kernel's registers, so it overlaps the gather half and the
+ *                                                        deformation field's backward (which needs only the gather's dx).
+ * Same sums as the fused kernel up to the order of the atomics.  blocks_per_cu caps the persistent grid (<= 0: 8) --
+ * a small value leaves the CU's registers to the kernels it runs beside. */
+int nsx_hash_ensemble_bwd_scatter(const float* x, int64_t B, const nsx_grid_geom* g, int n_slots,
+                                  const int32_t* code_slot, const float* dout, float* G, float* nonfinite,
+                                  int blocks_per_cu, void* stream);
 /* dtables (native fp32) = (accumulate ? dtables : 0) + expand(G, code_table*window): the dense table gradient that
  * autograd would have produced through hash_ensemble.py:155-156 (einsum) and the tcnn encodings' backward; only for
  * callers that want a materialised .grad (torch optimizers, the dense all-reduce path). */

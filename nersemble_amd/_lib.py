@@ -49,6 +49,8 @@ SIGNATURES = {
     "nsx_hash_ensemble_bwd_factored": (c_int, [c_void_p, c_int64, c_void_p, c_int, _GEOM_P, c_void_p, c_int64, c_int,
                                                c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                                c_void_p, c_void_p]),
+    "nsx_hash_ensemble_bwd_scatter": (c_int, [c_void_p, c_int64, _GEOM_P, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                              c_int, c_void_p]),
     "nsx_tables_preblend": (c_int, [c_void_p, c_int, _GEOM_P, c_void_p, c_void_p, c_void_p, c_void_p]),
     "nsx_hash_grad_expand": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_void_p, c_int, _GEOM_P, c_void_p, c_int,
                                      c_void_p]),

@@ -240,7 +240,10 @@ __device__ __forceinline__ void run_merge(uint32_t key, float val, int s7, bool&
 // 2*H values; nsx_hash_grad_expand turns G into the table gradient with a tiny dense contraction.
 // DCODE = false: the caller wants no code gradient (e.g. while the coarse-to-fine window pins the code to ones,
 // hash_ensemble.py:114-115): the per-grid accumulation -- a fifth of the kernel's VALU work -- is compiled out.
-template <int H, int WAVES, bool FACTORED, bool DCODE>
+// MODE: BWD_DENSE (2H atomics per corner into the table gradient), BWD_FACTORED (gather + G scatter in one kernel),
+// BWD_GATHER (dL/dcode and dL/dx only: the table gradient is scattered by ens_scatter_kernel on another stream).
+constexpr int BWD_DENSE = 0, BWD_FACTORED = 1, BWD_GATHER = 2;
+template <int H, int WAVES, int MODE, bool DCODE>
 __global__ __launch_bounds__(WAVES * kWave) void ens_bwd_kernel(
     const float* __restrict__ x, int64_t B, const uint8_t* __restrict__ tab, const nsx_grid_geom g,
     const float* __restrict__ code, int64_t code_stride, const int32_t* __restrict__ code_index,
@@ -298,7 +301,7 @@ __global__ __launch_bounds__(WAVES * kWave) void ens_bwd_kernel(
             for (int k = 0; k < 8; ++k) {
                 // blended_k = sum_f g_f * sum_h table[f][h] * code[h]  (this lane's share)
                 float blended = 0.f;
-                float* gdst = (!FACTORED && dtab)
+                float* gdst = (MODE == BWD_DENSE && dtab)
                                   ? dtab + ((size_t)(off + idx[k]) * C::ROW_BYTES + q * C::LANE_BYTES) / 2 : nullptr;
                 if constexpr (H == 1) {
                     const half2_t t = as_half2(v[k].d[0]);
@@ -337,7 +340,7 @@ __global__ __launch_bounds__(WAVES * kWave) void ens_bwd_kernel(
                 dya = __fmaf_rn((k & 2) ? sb : -sb, oy, dya);
                 dza = __fmaf_rn((k & 4) ? sb : -sb, oz, dza);
             }
-            if constexpr (FACTORED) {
+            if constexpr (MODE == BWD_FACTORED) {
                 if (dtab) {
                     // 16 (corner, feature) items per sample and level, LPE lanes per sample -> 16/LPE instructions.
                     // item = i*LPE + q: bit0 = feature, bit1 = x, bit2 = y, bit3 = z.  With G stored [slot][entry][f]
@@ -356,7 +359,7 @@ __global__ __launch_bounds__(WAVES * kWave) void ens_bwd_kernel(
                             if (c == cc) { ik = idx[cc]; wk = w[cc]; }
                         }
                         float val = wk * (f ? g1 : g0);
-                        const uint32_t key = ((off + ik) << 6) | (uint32_t)crow;      // entry < 2^23, slot < 64
+                        const uint32_t key = ((off + ik) << 6) | (uint32_t)crow;      // entry < 2^26 (checked at launch), slot < 64
                         // merge runs of equal keys over the adjacent sample lanes (only the run head issues)
                         float sum = val;
                         bool alive = true;
@@ -404,6 +407,82 @@ __global__ __launch_bounds__(WAVES * kWave) void ens_bwd_kernel(
                         if (h0 < Hreal) dcode[b * Hreal + h0] = dc[2 * j];
                         if (h0 + 1 < Hreal) dcode[b * Hreal + h0 + 1] = dc[2 * j + 1];
                     }
+                }
+            }
+        }
+    }
+    if (nonfinite && __any(bad) && lane == 0) nonfinite[0] = 1.0f;
+}
+
+// ------------------------------------------------------------------------------------------------
+// factored table gradient alone: G[slot][entry][f] += w_corner * dout_f
+// ------------------------------------------------------------------------------------------------
+// The scatter half of the factored backward as its own kernel.  It touches neither the tables nor the codes (the
+// gradient factors through the code slot), so it is independent of H, needs ~1/3 of the fused kernel's registers and
+// -- being bound by the rate of the memory-side fp32 atomics, not by bandwidth -- runs on its own stream BESIDE the
+// bandwidth-bound rest of the backward (the gather half, then the deformation field's backward, which only needs the
+// gather's dL/dx).  Same lane mapping, same merging of equal cells over 8 adjacent samples (DPP run-length sums) and
+// the same sector grouping of the (f, x) neighbours as ens_bwd_kernel<BWD_FACTORED>: the two produce the same sums up
+// to the order of the atomics.
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * kWave) void ens_scatter_kernel(
+    const float* __restrict__ x, int64_t B, const nsx_grid_geom g, const int32_t* __restrict__ code_index,
+    const float* __restrict__ dout, float* __restrict__ G, int64_t n_tiles, float* __restrict__ nonfinite) {
+    constexpr int SPW = 8, LPE = 8;                   // 8 samples per wave step, 8 lanes (2 items each) per sample
+    bool bad = false;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x / kWave;
+    const int L = g.n_levels;
+    const int s = lane % SPW, q = lane / SPW;
+    const int64_t wave_global = (int64_t)blockIdx.x * WAVES + wave;
+    const int64_t wave_count = (int64_t)gridDim.x * WAVES;
+    const size_t g_total = g.offset[L];
+    // this lane's two items: item = i * LPE + q, bit0 = feature, bits 1-3 = corner (x, y, z)
+    const int f = q & 1, c0 = (q >> 1) & 3;           // corner of item 0 (z = 0); item 1 is the same (x, y) at z = 1
+    for (int64_t tile = wave_global; tile < n_tiles; tile += wave_count) {
+        const int64_t b_raw = tile * SPW + s;
+        const bool valid = b_raw < B;
+        const int64_t b = valid ? b_raw : B - 1;
+        const float px = x[b * 3 + 0], py = x[b * 3 + 1], pz = x[b * 3 + 2];
+        const uint32_t crow = (uint32_t)code_index[b];
+        const float* drow = dout + b * (2 * L);
+        float* gslot = G + (size_t)crow * g_total * 2 + f;
+        for (int l = 0; l < L; ++l) {
+            const float scale = g.scale[l];
+            const uint32_t res = g.res[l], size = g.size[l], off = g.offset[l];
+            const bool hashed = g.hashed[l] != 0;
+            const float gf = valid ? drow[2 * l + f] : 0.f;
+            const Cell c = cell_of(scale, px, py, pz);
+            // the two corners of this lane: (x, y) from c0, z = 0 / 1
+            const uint32_t cx = c.cx + (uint32_t)(c0 & 1), cy = c.cy + (uint32_t)(c0 >> 1);
+            uint32_t ik[2];
+            if (hashed) {
+                const uint32_t mask = size - 1u, hxy = cx ^ (cy * 2654435761u);
+                ik[0] = (hxy ^ (c.cz * 805459861u)) & mask;
+                ik[1] = (hxy ^ ((c.cz + 1u) * 805459861u)) & mask;
+            } else {
+                const float inv = 1.0f / (float)size;
+                const uint32_t r2 = res * res, bxy = cx + cy * res;
+                ik[0] = umod(bxy + c.cz * r2, size, inv);
+                ik[1] = umod(bxy + (c.cz + 1u) * r2, size, inv);
+            }
+            // corner weight in ens_bwd_kernel's association: w = wx * (wy * wz)
+            const float wyz0 = ((c0 >> 1) ? c.wy : 1.0f - c.wy) * (1.0f - c.wz);
+            const float wyz1 = ((c0 >> 1) ? c.wy : 1.0f - c.wy) * c.wz;
+            const float wx = (c0 & 1) ? c.wx : 1.0f - c.wx;
+            const float val2[2] = {(wx * wyz0) * gf, (wx * wyz1) * gf};
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const float val = val2[i];
+                const uint32_t key = ((off + ik[i]) << 6) | crow;                      // entry < 2^26, slot < 64
+                float sum = val;
+                bool alive = true;
+                run_merge<1, 8>(key, val, s, alive, sum);
+                const uint32_t pk = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)key, 0x111, 0xf, 0xf, true);
+                const bool head = (s == 0) || (pk != key);
+                if (head && sum != 0.f) {
+                    atomicAdd(gslot + (size_t)(off + ik[i]) * 2, sum);
+                    bad |= !isfinite(sum);
                 }
             }
         }
@@ -573,16 +652,19 @@ static int launch_bwd(const float* x, int64_t B, const nsx_half* tables, int Hre
     int64_t blocks = (n_tiles + WAVES - 1) / WAVES;
     const int64_t cap = (int64_t)num_cus() * 8;
     if (blocks > cap) blocks = cap;
-#define NSX_BWD_LAUNCH(FACT, DC, NS, NF)                                                                            \
-    hipLaunchKernelGGL((ens_bwd_kernel<H, WAVES, FACT, DC>), dim3((unsigned)blocks), dim3(WAVES * kWave), 0, st, x, B, \
+#define NSX_BWD_LAUNCH(MODE, DC, NS, NF)                                                                            \
+    hipLaunchKernelGGL((ens_bwd_kernel<H, WAVES, MODE, DC>), dim3((unsigned)blocks), dim3(WAVES * kWave), 0, st, x, B, \
                        reinterpret_cast<const uint8_t*>(tables), *g, code, code_stride, code_index, window, Hreal,    \
                        dout, dtables, dcode, dx, n_tiles, NS, NF)
-    if (n_slots > 0) {
-        if (dcode) NSX_BWD_LAUNCH(true, true, n_slots, nonfinite);
-        else NSX_BWD_LAUNCH(true, false, n_slots, nonfinite);
+    if (n_slots > 0 && dtables) {
+        if (dcode) NSX_BWD_LAUNCH(BWD_FACTORED, true, n_slots, nonfinite);
+        else NSX_BWD_LAUNCH(BWD_FACTORED, false, n_slots, nonfinite);
+    } else if (n_slots > 0 || !dtables) {              // no table gradient asked of THIS kernel: the gather half alone
+        if (dcode) NSX_BWD_LAUNCH(BWD_GATHER, true, 0, nullptr);
+        else NSX_BWD_LAUNCH(BWD_GATHER, false, 0, nullptr);
     } else {
-        if (dcode) NSX_BWD_LAUNCH(false, true, 0, nullptr);
-        else NSX_BWD_LAUNCH(false, false, 0, nullptr);
+        if (dcode) NSX_BWD_LAUNCH(BWD_DENSE, true, 0, nullptr);
+        else NSX_BWD_LAUNCH(BWD_DENSE, false, 0, nullptr);
     }
 #undef NSX_BWD_LAUNCH
     NSX_LAUNCH_CHECK("nsx_hash_ensemble_bwd launch");
@@ -721,6 +803,9 @@ int nsx_hash_ensemble_bwd_factored(const float* x, int64_t B, const nsx_half* ta
                 n_slots, NSX_MAX_SLOTS);
     const int Hp = nsx_padded_grids(H);
     if (int rc = check_geom(g, Hp, "nsx_hash_ensemble_bwd_factored")) return rc;
+    // the duplicate-merging key packs (entry, slot) into 32 bits: ((offset + index) << 6) | slot
+    NSX_REQUIRE(!G || g->offset[g->n_levels] < (1u << 26), "nsx_hash_ensemble_bwd_factored: %u table entries exceed the "
+                "2^26 the run-merge key can address", g->offset[g->n_levels]);
     hipStream_t st = (hipStream_t)stream;
     switch (Hp) {
         case 1: return launch_bwd<1>(x, B, tables, H, g, code_table, code_stride, code_slot, window, dout, G, dcode, dx, st, n_slots, nonfinite);
@@ -732,6 +817,30 @@ int nsx_hash_ensemble_bwd_factored(const float* x, int64_t B, const nsx_half* ta
     }
     set_error("nsx_hash_ensemble_bwd_factored: unsupported H=%d", H);
     return NSX_ERR_UNSUPPORTED;
+}
+
+int nsx_hash_ensemble_bwd_scatter(const float* x, int64_t B, const nsx_grid_geom* g, int n_slots,
+                                  const int32_t* code_slot, const float* dout, float* G, float* nonfinite,
+                                  int blocks_per_cu, void* stream) {
+    NSX_REQUIRE(B >= 0, "nsx_hash_ensemble_bwd_scatter: negative batch");
+    if (B == 0) return NSX_OK;
+    NSX_REQUIRE(x && code_slot && dout && G, "nsx_hash_ensemble_bwd_scatter: NULL argument");
+    NSX_REQUIRE(n_slots >= 1 && n_slots <= NSX_MAX_SLOTS, "nsx_hash_ensemble_bwd_scatter: n_slots=%d not in [1,%d]",
+                n_slots, NSX_MAX_SLOTS);
+    if (int rc = check_geom(g, 1, "nsx_hash_ensemble_bwd_scatter")) return rc;
+    // the duplicate-merging key packs (entry, slot) into 32 bits
+    NSX_REQUIRE(g->offset[g->n_levels] < (1u << 26), "nsx_hash_ensemble_bwd_scatter: %u table entries exceed the 2^26 "
+                "the run-merge key can address", g->offset[g->n_levels]);
+    constexpr int WAVES = 4;
+    const int64_t n_tiles = (B + 7) / 8;
+    int64_t blocks = (n_tiles + WAVES - 1) / WAVES;
+    if (blocks_per_cu < 1) blocks_per_cu = 8;
+    const int64_t cap = (int64_t)num_cus() * blocks_per_cu;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL((ens_scatter_kernel<WAVES>), dim3((unsigned)blocks), dim3(WAVES * kWave), 0, (hipStream_t)stream, x,
+                       B, *g, code_slot, dout, G, n_tiles, nonfinite);
+    NSX_LAUNCH_CHECK("nsx_hash_ensemble_bwd_scatter launch");
+    return NSX_OK;
 }
 
 int nsx_hash_grad_expand(const float* G, int n_slots, const float* code_table, int64_t code_stride,

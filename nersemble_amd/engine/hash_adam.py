@@ -42,6 +42,7 @@ class HashTableAdam(torch.optim.Optimizer):
         """found_inf[0] = 1 if the pending table gradient holds an inf/NaN."""
         sink = self.he.grad_sink
         if sink is not None and sink.entries:
+            sink.wait_scatter()            # G and the flag are complete once the scatter stream has caught up
             # the backward kernel flagged every non-finite value it added to G: no pass over the 1.2 GB buffer
             torch.maximum(found_inf, sink.nonfinite.to(found_inf.dtype), out=found_inf)
         g = self.he.tables.grad
@@ -59,6 +60,8 @@ class HashTableAdam(torch.optim.Optimizer):
         entries = sink.entries if sink is not None else []
         if not entries and p.grad is None:
             return
+        if sink is not None and p.is_cuda:
+            sink.wait_scatter()
         if side_stream is None or not p.is_cuda:
             return self._step_now(found_inf, inv_scale)
         he.wait_tables()

@@ -115,6 +115,8 @@ class ShardedTableAdam(torch.optim.Optimizer):
                                "HashEnsemble ran without time_code_index (not a data-parallel training configuration)")
         early, self._early = self._early, None
         if early is None:
+            if sink is not None and he.tables.is_cuda:
+                sink.wait_scatter()
             self._expand_and_reduce(async_op=False)              # not started from the backward: do it here
         elif early != "done":
             early.wait()                                         # the current stream waits for the collective
@@ -147,7 +149,8 @@ class ShardedTableAdam(torch.optim.Optimizer):
         if self._comm_stream is None:
             self._comm_stream = torch.cuda.Stream(dev)
         comm = self._comm_stream
-        comm.wait_stream(torch.cuda.current_stream(dev))         # G is complete on the backward's stream
+        comm.wait_stream(torch.cuda.current_stream(dev))         # codes / flags are ready on the backward's stream
+        he.grad_sink.wait_scatter(comm)                          # G is complete on the scatter's stream
         with torch.cuda.stream(comm):
             self._early = self._expand_and_reduce(async_op=True)
         for e in he.grad_sink.entries:                           # allocated on the main stream, read on this one

@@ -5,6 +5,7 @@ fallback.  Gradients between kernels travel in fp32 (they are a negligible fract
 traffic), activations in fp16 like the reference's tcnn path.
 """
 import ctypes as C
+import os
 from typing import Optional
 
 import torch
@@ -75,6 +76,20 @@ class FactoredGradSink:
         self.nonfinite = None        # device float: set by the backward kernel when it adds an inf/NaN to a G
         self.pending = 0             # forwards recorded for autograd whose backward has not run yet
         self.on_complete = None      # called inside the backward once the LAST pending one has added its share to G
+        # The scatter into G is bound by the rate of memory-side fp32 atomics, everything else in the backward by
+        # bandwidth / MFMA: the scatter runs as its own kernel on its own stream beside the gather half of the
+        # HashEnsemble backward and the deformation field's backward (which only needs the gather's dL/dx).
+        # Consumers of G / ``nonfinite`` call ``wait_scatter()``.
+        self.split_scatter = os.environ.get("NSX_SPLIT_SCATTER", "1") != "0"
+        self.scatter_blocks_per_cu = int(os.environ.get("NSX_SCATTER_BLOCKS", "2"))   # leaves the CU's registers to others
+        self.scatter_stream = None
+        self.scatter_done = None
+
+    def wait_scatter(self, stream=None) -> None:
+        """Order ``stream`` (default: the current one) after the scatter kernels launched so far."""
+        ev = self.scatter_done
+        if ev is not None:
+            (stream if stream is not None else torch.cuda.current_stream()).wait_event(ev)
 
     def expect(self) -> None:
         self.pending += 1
@@ -87,7 +102,11 @@ class FactoredGradSink:
         if self.pending == 0 and self.on_complete is not None and self.entries:
             self.on_complete()
 
-    def buffer_for(self, code: torch.Tensor, window: Optional[torch.Tensor], n_rows: int, total_entries: int):
+    def buffer_for(self, code: torch.Tensor, window: Optional[torch.Tensor], n_rows: int, total_entries: int,
+                   zero: bool = True):
+        """The G this backward adds to.  ``zero=False``: a NEW buffer is returned un-cleared with ``fresh`` set in its
+        entry -- the caller clears it right in front of its scatter, on the scatter's stream (freshly written zero lines
+        are what the atomics then hit in the Infinity Cache)."""
         key = (code.data_ptr(), n_rows, None if window is None else window.data_ptr())
         for e in self.entries:
             if e["key"] == key:
@@ -102,13 +121,15 @@ class FactoredGradSink:
             self._cache = {n_rows: G}          # keep at most one persistent buffer
         if any(e["G"] is G for e in self.entries):
             G = torch.empty_like(G)
-        G.zero_()
-        self.entries.append({"G": G, "code": code, "window": window, "n_rows": n_rows, "key": key})
+        if zero:
+            G.zero_()
+        self.entries.append({"G": G, "code": code, "window": window, "n_rows": n_rows, "key": key, "fresh": not zero})
         return G
 
     def clear(self):
         self.entries = []
         self.pending = 0
+        self.scatter_done = None
 
 
 class _HashEnsembleFn(torch.autograd.Function):
@@ -148,14 +169,35 @@ class _HashEnsembleFn(torch.autograd.Function):
             dtab = None
             G = None
             use_sink = ctx.sink is not None and need_tab
+            split = use_sink and ctx.sink.split_scatter and x.is_cuda
             if use_sink:
-                G = ctx.sink.buffer_for(code, window, n_rows, geom.total_entries)
+                G = ctx.sink.buffer_for(code, window, n_rows, geom.total_entries, zero=not split)
             elif need_tab:
                 G = torch.zeros((n_rows, geom.total_entries, 2), dtype=torch.float32, device=x.device)
+            if split:
+                sink = ctx.sink
+                if sink.scatter_stream is None or sink.scatter_stream.device != x.device:
+                    sink.scatter_stream = torch.cuda.Stream(x.device)
+                side, cur = sink.scatter_stream, torch.cuda.current_stream(x.device)
+                side.wait_stream(cur)                                   # dout / x / nonfinite are ready on `cur`
+                entry = next(e for e in sink.entries if e["G"] is G)
+                with torch.cuda.stream(side):
+                    if entry["fresh"]:
+                        G.zero_()
+                        entry["fresh"] = False
+                    check(lib().nsx_hash_ensemble_bwd_scatter(ptr(x), B, C.byref(geom), n_rows, ptr(code_index), ptr(dout),
+                                                              ptr(G), ptr(sink.nonfinite), sink.scatter_blocks_per_cu,
+                                                              stream()), "nsx_hash_ensemble_bwd_scatter")
+                    sink.scatter_done = torch.cuda.Event()
+                    sink.scatter_done.record(side)
+                for t in (x, dout, code_index, G):                      # allocated on `cur`, read on `side`
+                    t.record_stream(side)
+                G = None                                                # the gather half below adds nothing to G
             check(lib().nsx_hash_ensemble_bwd_factored(ptr(x), B, ptr(tables_f16), H, C.byref(geom), ptr(code),
                                                        code.stride(0), n_rows, ptr(code_index), ptr(window),
                                                        ptr(dout), ptr(G), ptr(dcode_s), ptr(dx),
-                                                       ptr(ctx.sink.nonfinite) if use_sink else None, stream()),
+                                                       ptr(ctx.sink.nonfinite) if (use_sink and not split) else None,
+                                                       stream()),
                   "nsx_hash_ensemble_bwd_factored")
             if use_sink and ctx.announced:
                 ctx.sink.arrived()

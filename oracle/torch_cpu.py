@@ -75,28 +75,50 @@ def mlp_base_forward(feats: torch.Tensor, params: torch.Tensor) -> torch.Tensor:
     return (h @ wo.T).to(torch.float16)
 
 
-def time_encoder_sweep(H: int, geom, sizes=(1 << 16, 1 << 18, 1 << 20), budget_s: float = 25.0, threads=None, seed=0):
-    """Times hash_ensemble_forward + mlp_base_forward on uniformly random samples; returns a list of
-    dict(samples, seconds, samples_per_s) (stops early when the time budget is used up) and the thread count."""
+def _time_once(S, tables, params, geom, H, g):
     import time
-    if threads:
-        torch.set_num_threads(int(threads))
-    n_threads = torch.get_num_threads()
+    x = torch.rand((S, 3), generator=g)
+    code = torch.randn((S, H), generator=g)
+    t0 = time.time()
+    mlp_base_forward(hash_ensemble_forward(x, tables, code, geom, H), params)
+    return time.time() - t0
+
+
+def time_encoder_sweep(H: int, geom, sizes=(1 << 16, 1 << 18, 1 << 20), budget_s: float = 25.0, max_threads=None, seed=0):
+    """Times hash_ensemble_forward + mlp_base_forward on uniformly random samples.  The intra-op thread count is chosen
+    by a short calibration on 4096 samples (torch's CPU gathers do not scale to hundreds of threads); every size is
+    only started if its projected time fits the remaining budget.  Returns (list of dict(samples, seconds,
+    samples_per_s), threads used)."""
+    import time
+    t_begin = time.time()
     g = torch.Generator().manual_seed(seed)
     F = 8 if 2 * H >= 8 else 2 * H
     C = (2 * H + 7) // 8
     tables = ((torch.rand((C, geom.total_entries, F), generator=g) - 0.5)).to(torch.float16)
     params = (torch.rand((64 * 32 + 16 * 64,), generator=g) - 0.5) * 0.5
-    out, t_begin = [], time.time()
-    for S in sizes:
-        x = torch.rand((S, 3), generator=g)
-        code = torch.randn((S, H), generator=g)
-        if not out:
-            mlp_base_forward(hash_ensemble_forward(x[:4096], tables, code[:4096], geom, H), params)     # warm up
-        t0 = time.time()
-        mlp_base_forward(hash_ensemble_forward(x, tables, code, geom, H), params)
-        dt = time.time() - t0
-        out.append({"samples": S, "seconds": round(dt, 3), "samples_per_s": S / dt})
-        if time.time() - t_begin + 4.5 * dt > budget_s:          # the next size costs ~4x
+    max_threads = int(max_threads or torch.get_num_threads())
+    best_t, best_rate = None, 0.0
+    # ascending: few threads are quick to try; hundreds of threads on these small ops can be 20x slower
+    for t in sorted({min(max_threads, 8), min(max_threads, 16), min(max_threads, 32), min(max_threads, 64), max_threads}):
+        torch.set_num_threads(t)
+        _time_once(1024, tables, params, geom, H, g)                       # warm up this thread-pool size
+        dt = _time_once(4096, tables, params, geom, H, g)
+        if 4096 / dt > best_rate:
+            best_t, best_rate = t, 4096 / dt
+        elif 4096 / dt < 0.5 * best_rate:                                  # clearly past the optimum
             break
-    return out, n_threads
+        if time.time() - t_begin > 0.3 * budget_s:
+            break
+    torch.set_num_threads(best_t)
+    out = []
+    rate = best_rate
+    for S in sizes:
+        left = budget_s - (time.time() - t_begin)
+        if out and S / rate > left:                                      # would not fit: stop the sweep here
+            break
+        if not out and S / rate > left:                                  # even the first size is too slow: shrink it
+            S = max(4096, int(rate * left * 0.8) // 4096 * 4096)
+        dt = _time_once(S, tables, params, geom, H, g)
+        rate = S / dt
+        out.append({"samples": S, "seconds": round(dt, 3), "samples_per_s": rate})
+    return out, best_t

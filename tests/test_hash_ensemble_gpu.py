@@ -290,3 +290,58 @@ def test_preblended_eval_grid_matches_ensemble_forward(H, win, cuda):
     assert table.shape == (he.geom.total_entries, 2) and table.dtype == torch.float16
     scale = want.abs().max().item() + 1e-12
     assert (got - want).abs().max().item() <= 4e-3 * scale, (got - want).abs().max().item() / scale
+
+
+@pytest.mark.parametrize("H", [4, 16, 32])
+@pytest.mark.parametrize("coherent", [False, True])
+def test_split_backward_equals_fused(H, coherent, cuda):
+    """The factored backward as two launches (gather half: dcode / dx; scatter half: G, no tables, no codes) against the
+    fused kernel: dcode and dx BIT-equal (same code path, the scatter compiled out), G up to the order of the fp32
+    atomics.  ``coherent``: consecutive samples along rays, so that the duplicate-cell merging is exercised."""
+    import ctypes as C
+    from nersemble_amd._lib import check, lib, ptr, stream
+    B, T = 5003, 13
+    go, gn, tabs, f16, master, x, code = _setup(H, SMALL_GEOM_KW, 300 + H, B, cuda)
+    rng = np.random.default_rng(H)
+    if coherent:
+        o = rng.random((50, 1, 3), dtype=np.float32) * 0.5 + 0.1
+        d = rng.standard_normal((50, 1, 3)).astype(np.float32)
+        d /= np.linalg.norm(d, axis=-1, keepdims=True)
+        t = (np.arange(101, dtype=np.float32) * 0.0023)[None, :, None]
+        x = np.clip((o + d * t).reshape(-1, 3)[:B], 0.0, 0.999).astype(np.float32)
+        B = x.shape[0]
+    xt = torch.from_numpy(x).to(cuda)
+    table = torch.from_numpy((rng.standard_normal((T, H)) * 0.6).astype(np.float32)).to(cuda)
+    slot = torch.from_numpy(np.sort(rng.integers(0, T, B)).astype(np.int32)).to(cuda)
+    dout = torch.from_numpy(rng.standard_normal((B, 32)).astype(np.float32)).to(cuda)
+    total = gn.total_entries
+
+    def run(G, dc, dx, nf):
+        check(lib().nsx_hash_ensemble_bwd_factored(ptr(xt), B, ptr(f16), H, C.byref(gn), ptr(table), table.stride(0), T,
+                                                   ptr(slot), None, ptr(dout), ptr(G), ptr(dc), ptr(dx), ptr(nf), stream()),
+              "nsx_hash_ensemble_bwd_factored")
+
+    G_f = torch.zeros((T, total, 2), device=cuda)
+    dc_f, dx_f = torch.empty((B, H), device=cuda), torch.empty((B, 3), device=cuda)
+    nf = torch.zeros((1,), device=cuda)
+    run(G_f, dc_f, dx_f, nf)
+    dc_g, dx_g = torch.empty((B, H), device=cuda), torch.empty((B, 3), device=cuda)
+    run(None, dc_g, dx_g, None)                                                     # gather half
+    assert torch.equal(dc_g, dc_f) and torch.equal(dx_g, dx_f)
+    for blocks in (1, 8):
+        G_s = torch.zeros((T, total, 2), device=cuda)
+        nf_s = torch.zeros((1,), device=cuda)
+        check(lib().nsx_hash_ensemble_bwd_scatter(ptr(xt), B, C.byref(gn), T, ptr(slot), ptr(dout), ptr(G_s), ptr(nf_s),
+                                                  blocks, stream()), "nsx_hash_ensemble_bwd_scatter")
+        sc = G_f.abs().max().item()
+        assert sc > 0 and (G_s - G_f).abs().max().item() <= 2e-5 * sc
+        assert torch.equal((G_s != 0), (G_f != 0)) and nf_s.item() == 0
+    # a non-finite upstream gradient raises the flag (GradScaler's inf check on the table gradient)
+    dout[B // 2, 7] = float("inf")
+    nf_s = torch.zeros((1,), device=cuda)
+    check(lib().nsx_hash_ensemble_bwd_scatter(ptr(xt), B, C.byref(gn), T, ptr(slot), ptr(dout), ptr(torch.zeros_like(G_f)),
+                                              ptr(nf_s), 2, stream()), "nsx_hash_ensemble_bwd_scatter")
+    assert nf_s.item() == 1
+    # empty batch: no launch, no error
+    check(lib().nsx_hash_ensemble_bwd_scatter(ptr(xt), 0, C.byref(gn), T, ptr(slot), ptr(dout), ptr(G_f), None, 2,
+                                              stream()), "nsx_hash_ensemble_bwd_scatter")

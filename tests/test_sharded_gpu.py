@@ -233,6 +233,9 @@ def _strong_worker(rank, world, port, out_dir):
         trainer.consolidate()
         model = trainer.model
         res[mode] = {"loss": loss.item(), "terms": {k: v.item() for k, v in loss_dict.items()},
+                     # gradients of the small parameters as the optimizers saw them (unscaled, averaged over the ranks)
+                     "grads": {n: p.grad.detach().float().cpu() for n, p in model.named_parameters()
+                               if "tables" not in n and p.grad is not None},
                      "tables": model.field.hash_ensemble.tables.detach().cpu(),
                      "small": torch.cat([p.detach().reshape(-1).cpu() for n, p in model.named_parameters()
                                          if "tables" not in n])}
@@ -264,7 +267,8 @@ def test_two_ranks_on_half_batches_equal_one_process_on_the_union_batch(cuda, tm
     loss, loss_dict, _ = single.train_iteration(0, bundle, batch)
     single.flush_scheduler_step()
     tables = single.model.field.hash_ensemble.tables.detach().cpu()
-    small = torch.cat([p.detach().reshape(-1).cpu() for n, p in single.model.named_parameters() if "tables" not in n])
+    grads = {n: p.grad.detach().float().cpu() for n, p in single.model.named_parameters()
+             if "tables" not in n and p.grad is not None}
     moved = (tables - init_tables).abs() > 1e-4                    # entries the step touched (+-lr at step 1)
     assert moved.float().mean().item() > 1e-3
     for mode, tol_frac in (("dense", 0.9995), ("sharded", 0.995)):
@@ -279,5 +283,13 @@ def test_two_ranks_on_half_batches_equal_one_process_on_the_union_batch(cuda, tm
         # Adam at step 1 moves every touched entry by +-lr: an entry agrees unless its (tiny) gradient changed sign or
         # vanished in the other summation order / in fp16
         assert (d[moved] <= 1e-5).float().mean().item() >= tol_frac, (mode, (d[moved] <= 1e-5).float().mean().item())
-        ds = (a["small"] - small).abs()
-        assert (ds <= 1e-5).float().mean().item() >= 0.99, (mode, (ds <= 1e-5).float().mean().item())
+        # small parameter groups: the averaged gradients ARE the union-batch gradients (what Adam does with them at
+        # step 1 is +-lr per element, i.e. a sign test of values that can be pure summation noise -- compare upstream)
+        assert set(a["grads"]) == set(grads)
+        for name, g_ref in grads.items():
+            sc = g_ref.abs().max().item()
+            if sc == 0.0:
+                assert a["grads"][name].abs().max().item() == 0.0, (mode, name)
+                continue
+            err = (a["grads"][name] - g_ref).abs().max().item()
+            assert err <= 2e-3 * sc, (mode, name, err / sc)

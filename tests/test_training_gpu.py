@@ -278,8 +278,9 @@ def test_eval_preblend_cache_follows_training(cuda):
     model.train()
     for step in range(3, 40):
         trainer.train_iteration(step, *data.next_train(step))
-    fast, slow = render(True), render(False)
+    fast = render(True)
     assert not torch.equal(model._eval_blend_cache[1], blend_before)          # rebuilt from the trained tables
+    slow = render(False)
     assert (fast - slow).abs().mean().item() <= 2e-3 and (fast - slow).abs().max().item() <= 2e-2
     assert (fast - first).abs().mean().item() > 5 * (fast - slow).abs().mean().item()   # training did move the image
     model.train()
@@ -303,7 +304,14 @@ def test_resume_from_checkpoint_continues_the_run(cuda):
     assert tab["exp_avg"][0].numel() == ckpt["pipeline"]["_model.field.hash_ensemble.hash_encodings.0.params"].numel()
     assert float(sum(t.abs().sum() for t in tab["exp_avg_sq"])) > 0
     occ_a = (a.model.occupancy_grid.occs.clone(), a.model.occupancy_grid.binaries.clone())
-    losses_a = [a.train_iteration(step, *batches[step])[0].item() for step in range(4, 7)]
+    def three_more_steps(trainer):
+        out = []
+        for step in range(4, 7):
+            torch.manual_seed(100 + step)                     # the marcher's near-plane jitter draws from the global generator
+            out.append(trainer.train_iteration(step, *batches[step])[0].item())
+        return out
+
+    losses_a = three_more_steps(a)
 
     torch.manual_seed(1234)                                   # different initial weights: everything comes from the file
     b, _, _ = build_workload("p030_h16", device="cuda:0", small=True, n_rays=512)
@@ -312,10 +320,9 @@ def test_resume_from_checkpoint_continues_the_run(cuda):
     assert b.grad_scaler.get_scale() == ckpt["scalers"]["scale"]
     for sched in (b.model.sched_window_deform, b.model.sched_window_hash_encodings):
         sched.update(3)                                       # (window schedules are functions of the step)
-    losses_b = [b.train_iteration(step, *batches[step])[0].item() for step in range(4, 7)]
-    # same data, same weights, same moments: the runs agree up to the order of the fp32 atomics (and the random near-
-    # plane jitter of the marcher, which draws from torch's global generator)
-    assert np.allclose(losses_a, losses_b, rtol=5e-2), (losses_a, losses_b)
+    losses_b = three_more_steps(b)
+    # same data, same jitter, same weights, same moments: the runs agree up to the order of the fp32 atomics
+    assert np.allclose(losses_a, losses_b, rtol=1e-2), (losses_a, losses_b)
     sa = a.optimizers["fields/tables"].state[a.model.field.hash_ensemble.tables]["step"]
     sb = b.optimizers["fields/tables"].state[b.model.field.hash_ensemble.tables]["step"]
     assert sa == sb == 7
