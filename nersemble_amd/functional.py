@@ -76,12 +76,14 @@ class FactoredGradSink:
         self.nonfinite = None        # device float: set by the backward kernel when it adds an inf/NaN to a G
         self.pending = 0             # forwards recorded for autograd whose backward has not run yet
         self.on_complete = None      # called inside the backward once the LAST pending one has added its share to G
-        # The scatter into G is bound by the rate of memory-side fp32 atomics, everything else in the backward by
-        # bandwidth / MFMA: the scatter runs as its own kernel on its own stream beside the gather half of the
-        # HashEnsemble backward and the deformation field's backward (which only needs the gather's dL/dx).
-        # Consumers of G / ``nonfinite`` call ``wait_scatter()``.
-        self.split_scatter = os.environ.get("NSX_SPLIT_SCATTER", "1") != "0"
-        self.scatter_blocks_per_cu = int(os.environ.get("NSX_SCATTER_BLOCKS", "2"))   # leaves the CU's registers to others
+        # Optional (NSX_SPLIT_SCATTER=1): the scatter into G as its own kernel on its own stream beside the gather half of
+        # the HashEnsemble backward and the deformation field's backward (which only needs the gather's dL/dx).
+        # MEASURED SLOWER than the fused kernel (9.3-9.5 vs 8.7 ms per step): the memory-side atomics
+        # that bound the scatter also slow every bandwidth-bound kernel that runs beside them, and the fused kernel
+        # already hides its table reads under them.  Kept for the stand-alone timings of the two halves (bench.py
+        # kernels_alone) and as a tested entry point.  Consumers of G / ``nonfinite`` call ``wait_scatter()``.
+        self.split_scatter = os.environ.get("NSX_SPLIT_SCATTER", "0") == "1"
+        self.scatter_blocks_per_cu = int(os.environ.get("NSX_SCATTER_BLOCKS", "8"))
         self.scatter_stream = None
         self.scatter_done = None
 

@@ -304,6 +304,21 @@ def test_resume_from_checkpoint_continues_the_run(cuda):
     assert tab["exp_avg"][0].numel() == ckpt["pipeline"]["_model.field.hash_ensemble.hash_encodings.0.params"].numel()
     assert float(sum(t.abs().sum() for t in tab["exp_avg_sq"])) > 0
     occ_a = (a.model.occupancy_grid.occs.clone(), a.model.occupancy_grid.binaries.clone())
+
+    def snapshot(tr):
+        """Every tensor the next step depends on."""
+        snap = {"p:" + n: p.detach().clone() for n, p in tr.model.named_parameters()}
+        snap["f16"] = tr.model.field.hash_ensemble.half_tables().clone()
+        for key, opt in tr.optimizers.items():
+            for i, (p, st) in enumerate(opt.state.items()):
+                for k, v in st.items():
+                    snap[f"o:{key}:{i}:{k}"] = v.detach().clone() if torch.is_tensor(v) else torch.tensor(float(v))
+            snap[f"lr:{key}"] = torch.tensor([g["lr"] for g in opt.param_groups])
+        snap["scale"] = tr.grad_scaler._scale.clone()
+        snap["growth"] = tr.grad_scaler._growth_tracker.clone()
+        return snap
+
+    snap_a = snapshot(a)
     def three_more_steps(trainer):
         out = []
         for step in range(4, 7):
@@ -318,6 +333,10 @@ def test_resume_from_checkpoint_continues_the_run(cuda):
     assert resume_trainer_from_checkpoint(ckpt, b) == 4
     assert torch.equal(b.model.occupancy_grid.occs, occ_a[0]) and torch.equal(b.model.occupancy_grid.binaries, occ_a[1])
     assert b.grad_scaler.get_scale() == ckpt["scalers"]["scale"]
+    snap_b = snapshot(b)
+    assert set(snap_a) == set(snap_b), set(snap_a) ^ set(snap_b)
+    for k in snap_a:
+        assert torch.equal(snap_a[k].cpu().float(), snap_b[k].cpu().float()), k
     for sched in (b.model.sched_window_deform, b.model.sched_window_hash_encodings):
         sched.update(3)                                       # (window schedules are functions of the step)
     losses_b = three_more_steps(b)
@@ -326,3 +345,24 @@ def test_resume_from_checkpoint_continues_the_run(cuda):
     sa = a.optimizers["fields/tables"].state[a.model.field.hash_ensemble.tables]["step"]
     sb = b.optimizers["fields/tables"].state[b.model.field.hash_ensemble.tables]["step"]
     assert sa == sb == 7
+
+
+def test_split_scatter_backward_trains_like_the_fused_one(cuda):
+    """NSX_SPLIT_SCATTER path (scatter half of the factored backward on its own stream, consumers ordered by
+    ``FactoredGradSink.wait_scatter``): same trajectory as the fused kernel up to the order of the atomics."""
+    from nersemble_amd.workloads import build_workload
+    runs = {}
+    for split in (False, True):
+        torch.manual_seed(4)
+        trainer, data, _ = build_workload("p030_h16", device="cuda:0", small=True, n_rays=512)
+        sink = trainer.model.field.hash_ensemble.grad_sink
+        sink.split_scatter, sink.scatter_blocks_per_cu = split, 2
+        losses = []
+        for step in range(6):
+            torch.manual_seed(50 + step)
+            losses.append(trainer.train_iteration(step, *data.next_train(step))[0].item())
+        trainer.flush_scheduler_step()
+        assert (sink.scatter_stream is not None) == split
+        runs[split] = (losses, trainer.model.field.hash_ensemble.tables.detach().clone())
+    assert np.allclose(runs[True][0][:4], runs[False][0][:4], rtol=2e-3), runs
+    assert np.allclose(runs[True][0], runs[False][0], rtol=3e-2), runs
