@@ -54,7 +54,20 @@ def nerfstudio_checkpoint_from_model(model: torch.nn.Module, step: int, trainer=
         trainer.consolidate()
         full = trainer.state_dict()
         training = {"optimizers": full["optimizers"], "scalers": full["scalers"], "schedulers": full["schedulers"]}
-    return {"step": int(step), "pipeline": {MODEL_PREFIX + k: v for k, v in model.state_dict().items()}, **training}
+    # a SNAPSHOT: ``state_dict()`` hands out views of the live parameters / optimizer moments, which the next training
+    # step would rewrite under the checkpoint
+    return _snapshot({"step": int(step), "pipeline": {MODEL_PREFIX + k: v for k, v in model.state_dict().items()},
+                      **training})
+
+
+def _snapshot(obj):
+    if torch.is_tensor(obj):
+        return obj.detach().clone()
+    if isinstance(obj, dict):
+        return {k: _snapshot(v) for k, v in obj.items()}
+    if isinstance(obj, (list, tuple)):
+        return type(obj)(_snapshot(v) for v in obj)
+    return obj
 
 
 def resume_trainer_from_checkpoint(checkpoint: Dict, trainer) -> int:
