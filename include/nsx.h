@@ -384,6 +384,31 @@ int nsx_adam_dense_f16grad(const nsx_half* grad, int64_t n, float* master, float
                            nsx_half* params_f16 /* may be NULL */, float lr, float beta1, float beta2, float eps,
                            int64_t step, const float* inv_scale, const float* found_inf, void* stream);
 
+/* The small parameter groups (mlp_base / mlp_head, the two time embeddings, the 16 deformation tensors) in ONE launch
+ * each: GradScaler.unscale_ + inf check (nersemble_trainer.py:185-186: found_inf[group] = 1 if any element of a
+ * group's gradients is non-finite; gradients multiplied by *inv_scale in place) and torch.optim.Adam's update per group
+ * (train_nersemble.py:247-256; skipped for a group whose found_inf is set, and for tensors without a gradient).
+ * Tensor references are HOST arrays of device pointers (fp32, contiguous); at most NSX_MAX_TENSORS / NSX_MAX_GROUPS. */
+#define NSX_MAX_TENSORS 64
+#define NSX_MAX_GROUPS 8
+typedef struct nsx_tensor_ref {
+    void*   param;
+    void*   grad;         /* NULL: no gradient this step */
+    void*   exp_avg;
+    void*   exp_avg_sq;
+    int64_t n;
+    int32_t group;
+    int32_t reserved;
+} nsx_tensor_ref;
+typedef struct nsx_adam_group {
+    float   lr, beta1, beta2, eps;
+    int64_t step;         /* 1-based step count of the group */
+} nsx_adam_group;
+int nsx_multi_unscale_check(const nsx_tensor_ref* tensors_host, int n_tensors, int n_groups, const float* inv_scale,
+                            float* found_inf /* [n_groups] */, void* stream);
+int nsx_multi_adam(const nsx_tensor_ref* tensors_host, int n_tensors, const nsx_adam_group* groups_host, int n_groups,
+                   const float* found_inf /* [n_groups], may be NULL */, void* stream);
+
 /* Debug/parity helper: the 8 level-local entry indices per (sample, level), uint32 [B][L][8] -- what tcnn's HashGrid
  * (instantiated at hash_ensemble.py:42-50; algorithm: SURVEY.md A.1) computes internally.  Integer outputs are held
  * bit-exact to the oracle. */

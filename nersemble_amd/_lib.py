@@ -33,6 +33,20 @@ class GridGeom(C.Structure):
 
 
 _GEOM_P = C.POINTER(GridGeom)
+NSX_MAX_TENSORS = 64
+NSX_MAX_GROUPS = 8
+
+
+class TensorRef(C.Structure):
+    """Mirror of ``nsx_tensor_ref``."""
+    _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
+                ("n", C.c_int64), ("group", C.c_int32), ("reserved", C.c_int32)]
+
+
+class AdamGroup(C.Structure):
+    """Mirror of ``nsx_adam_group``."""
+    _fields_ = [("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float), ("step", C.c_int64)]
+
 
 # name -> (restype, argtypes); must list every symbol include/nsx.h declares (tests check this)
 SIGNATURES = {
@@ -115,6 +129,8 @@ SIGNATURES = {
     "nsx_adam_dense": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_float,
                                c_float, c_int64, c_void_p, c_void_p, c_void_p]),
     "nsx_hash_indices": (c_int, [c_void_p, c_int64, _GEOM_P, c_void_p, c_void_p]),
+    "nsx_multi_unscale_check": (c_int, [C.POINTER(TensorRef), c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "nsx_multi_adam": (c_int, [C.POINTER(TensorRef), c_int, C.POINTER(AdamGroup), c_int, c_void_p, c_void_p]),
     "nsx_occ_scratch_bytes": (c_int64, [c_int64]),
     "nsx_occ_compact": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "nsx_occ_sample_cells": (c_int, [c_int, c_void_p, c_int, c_void_p, c_int64, C.c_uint64, c_int64, c_int, c_int64,

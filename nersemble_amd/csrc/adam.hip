@@ -262,6 +262,52 @@ static int launch_expand_f16(const float* G, int n_slots, const float* code, int
     return NSX_OK;
 }
 
+// ---- the small parameter groups (two fused MLPs, two embeddings, 16 deformation tensors: ~0.27 M parameters) -----------
+// torch.optim.Adam(fused=True) per group costs ~0.15 ms of host time per group and step (optimizer hooks, _foreach_add_
+// of the step tensors, profiler ranges) plus one _amp_foreach_non_finite_check_and_unscale_ each -- in steady state the
+// step is host-bound, so the three groups' unscale + inf check and their Adam updates are ONE launch each over a
+// by-value table of tensor references.  blockIdx.y = tensor, blockIdx.x strides over its elements.
+struct TensorTable {
+    nsx_tensor_ref t[NSX_MAX_TENSORS];
+    int n;
+};
+struct GroupHyper {
+    AdamHyper h[NSX_MAX_GROUPS];
+};
+
+// GradScaler.unscale_ (torch._amp_foreach_non_finite_check_and_unscale_): found_inf[group] = 1 if any gradient element
+// is non-finite (checked on the scaled value), every element multiplied by *inv_scale in place.
+__global__ __launch_bounds__(256) void multi_unscale_check_kernel(TensorTable T, const float* __restrict__ inv_scale,
+                                                                  float* __restrict__ found_inf) {
+    const nsx_tensor_ref r = T.t[blockIdx.y];
+    float* g = reinterpret_cast<float*>(r.grad);
+    if (!g) return;
+    const float is = inv_scale ? inv_scale[0] : 1.0f;
+    bool bad = false;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < r.n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float v = g[i];
+        bad |= !isfinite(v);
+        g[i] = is == 1.0f ? v : v * is;
+    }
+    if (__any(bad) && (threadIdx.x & 63) == 0) found_inf[r.group] = 1.0f;
+}
+
+__global__ __launch_bounds__(256) void multi_adam_kernel(TensorTable T, GroupHyper H, const float* __restrict__ found_inf) {
+    const nsx_tensor_ref r = T.t[blockIdx.y];
+    const float* g = reinterpret_cast<const float*>(r.grad);
+    if (!g) return;                                          // no gradient this step: torch skips the parameter
+    if (found_inf && found_inf[r.group] != 0.f) return;      // GradScaler: the whole group's step is skipped
+    const AdamHyper hy = H.h[r.group];
+    float* p = reinterpret_cast<float*>(r.param);
+    float* m = reinterpret_cast<float*>(r.exp_avg);
+    float* v = reinterpret_cast<float*>(r.exp_avg_sq);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < r.n; i += (int64_t)gridDim.x * blockDim.x) {
+        float pp = p[i], mm = m[i], vv = v[i];
+        adam_update(g[i], pp, mm, vv, hy);
+        p[i] = pp; m[i] = mm; v[i] = vv;
+    }
+}
+
 static AdamHyper make_hyper(float lr, float beta1, float beta2, float eps, int64_t step) {
     AdamHyper h;
     h.lr = lr; h.beta1 = beta1; h.beta2 = beta2; h.eps = eps;
@@ -383,6 +429,62 @@ int nsx_hash_grad_expand_f16(const float* G, int n_slots, const float* code_tabl
 #undef NSX_EXP_CASE
     set_error("nsx_hash_grad_expand_f16: unsupported H=%d", H);
     return NSX_ERR_UNSUPPORTED;
+}
+
+static int fill_table(const nsx_tensor_ref* tensors, int n_tensors, int n_groups, TensorTable& T, int64_t& n_max,
+                      const char* who) {
+    NSX_REQUIRE(tensors && n_tensors >= 1 && n_tensors <= NSX_MAX_TENSORS, "%s: n_tensors=%d not in [1,%d]", who, n_tensors,
+                NSX_MAX_TENSORS);
+    NSX_REQUIRE(n_groups >= 1 && n_groups <= NSX_MAX_GROUPS, "%s: n_groups=%d not in [1,%d]", who, n_groups, NSX_MAX_GROUPS);
+    T.n = n_tensors;
+    n_max = 0;
+    for (int i = 0; i < n_tensors; ++i) {
+        NSX_REQUIRE(tensors[i].n >= 0 && tensors[i].group >= 0 && tensors[i].group < n_groups,
+                    "%s: tensor %d: bad size or group", who, i);
+        NSX_REQUIRE(!tensors[i].grad || tensors[i].n == 0 || tensors[i].param, "%s: tensor %d: NULL parameter", who, i);
+        T.t[i] = tensors[i];
+        if (tensors[i].grad && tensors[i].n > n_max) n_max = tensors[i].n;
+    }
+    return NSX_OK;
+}
+
+int nsx_multi_unscale_check(const nsx_tensor_ref* tensors_host, int n_tensors, int n_groups, const float* inv_scale,
+                            float* found_inf, void* stream) {
+    NSX_REQUIRE(found_inf, "nsx_multi_unscale_check: NULL found_inf");
+    TensorTable T;
+    int64_t n_max = 0;
+    if (int rc = fill_table(tensors_host, n_tensors, n_groups, T, n_max, "nsx_multi_unscale_check")) return rc;
+    if (n_max == 0) return NSX_OK;
+    int64_t bx = (n_max + 1023) / 1024;
+    if (bx > 64) bx = 64;
+    hipLaunchKernelGGL(multi_unscale_check_kernel, dim3((unsigned)bx, (unsigned)n_tensors), dim3(256), 0, (hipStream_t)stream,
+                       T, inv_scale, found_inf);
+    NSX_LAUNCH_CHECK("nsx_multi_unscale_check launch");
+    return NSX_OK;
+}
+
+int nsx_multi_adam(const nsx_tensor_ref* tensors_host, int n_tensors, const nsx_adam_group* groups_host, int n_groups,
+                   const float* found_inf, void* stream) {
+    NSX_REQUIRE(groups_host, "nsx_multi_adam: NULL groups");
+    TensorTable T;
+    int64_t n_max = 0;
+    if (int rc = fill_table(tensors_host, n_tensors, n_groups, T, n_max, "nsx_multi_adam")) return rc;
+    if (n_max == 0) return NSX_OK;
+    GroupHyper H;
+    for (int k = 0; k < n_groups; ++k) {
+        NSX_REQUIRE(groups_host[k].step >= 1, "nsx_multi_adam: group %d: step must be >= 1", k);
+        H.h[k] = make_hyper(groups_host[k].lr, groups_host[k].beta1, groups_host[k].beta2, groups_host[k].eps,
+                            groups_host[k].step);
+    }
+    for (int i = 0; i < n_tensors; ++i)
+        NSX_REQUIRE(!tensors_host[i].grad || tensors_host[i].n == 0 || (tensors_host[i].exp_avg && tensors_host[i].exp_avg_sq),
+                    "nsx_multi_adam: tensor %d: NULL moments", i);
+    int64_t bx = (n_max + 1023) / 1024;
+    if (bx > 64) bx = 64;
+    hipLaunchKernelGGL(multi_adam_kernel, dim3((unsigned)bx, (unsigned)n_tensors), dim3(256), 0, (hipStream_t)stream, T, H,
+                       found_inf);
+    NSX_LAUNCH_CHECK("nsx_multi_adam launch");
+    return NSX_OK;
 }
 
 }  // extern "C"

@@ -15,6 +15,7 @@ from ..models.nersemble_instant_ngp import NeRSembleNGPModel
 from .hash_adam import HashTableAdam, NativeGradScaler
 from .parallel import all_reduce_gradients
 from .sharded_adam import ShardedTableAdam
+from .small_adam import SmallGroupAdam, adam_groups, unscale_and_check_groups
 from ..rays import RayBundle
 
 
@@ -84,7 +85,11 @@ class NeRSembleTrainer:
         tables = model.field.hash_ensemble.tables
         for name, params in groups.items():
             small = [p for p in params if p is not tables]
-            self.optimizers[name] = torch.optim.Adam(small, lr=lrs[name], eps=self.cfg.eps, weight_decay=0, fused=fused)
+            if fused:
+                # all small groups step together in two native launches (engine/small_adam.py)
+                self.optimizers[name] = SmallGroupAdam(small, lr=lrs[name], eps=self.cfg.eps)
+            else:
+                self.optimizers[name] = torch.optim.Adam(small, lr=lrs[name], eps=self.cfg.eps, weight_decay=0)
             self.group_of[name] = name
             if len(small) != len(params):
                 # the 403 M-parameter hash tables: native fused step on the factored gradient.  Data-parallel runs
@@ -140,11 +145,16 @@ class NeRSembleTrainer:
         groups = sorted(set(self.group_of.values()))
         found_all = torch.zeros((len(groups),), dtype=torch.float32, device=dev)
         found = {g: found_all[i:i + 1] for i, g in enumerate(groups)}
+        native_small = [(key, opt) for key, opt in self.optimizers.items() if isinstance(opt, SmallGroupAdam)]
+        small_groups = [groups.index(self.group_of[key]) for key, _ in native_small]
+        table = None
+        if native_small:
+            table = unscale_and_check_groups([o for _, o in native_small], small_groups, len(groups), found_all, inv_scale)
         for key, opt in self.optimizers.items():
             f = found[self.group_of[key]]
             if isinstance(opt, (HashTableAdam, ShardedTableAdam)):
                 opt.check_finite(f)
-            else:
+            elif not isinstance(opt, SmallGroupAdam):
                 grads = [p.grad for pg in opt.param_groups for p in pg["params"] if p.grad is not None]
                 scaler.unscale_and_check(grads, f, inv_scale)
         if self.world_size > 1:
@@ -156,6 +166,8 @@ class NeRSembleTrainer:
                 opt.step(found_inf=f, inv_scale=inv_scale, side_stream=self._opt_stream)
             elif isinstance(opt, ShardedTableAdam):
                 opt.step(found_inf=f, inv_scale=inv_scale, side_stream=self._opt_stream)
+            elif isinstance(opt, SmallGroupAdam):
+                continue
             elif any(p.grad is not None for pg in opt.param_groups for p in pg["params"]):
                 if opt.defaults.get("fused"):
                     opt.found_inf, opt.grad_scale = f.reshape(()), None
@@ -163,6 +175,8 @@ class NeRSembleTrainer:
                     del opt.found_inf, opt.grad_scale
                 elif f.item() == 0:
                     opt.step()
+        if native_small:
+            adam_groups([o for _, o in native_small], small_groups, len(groups), table, found_all)
         scaler.update(list(found.values()))
         self._found_groups = groups
         return found_all
@@ -255,7 +269,7 @@ class NeRSembleTrainer:
         # the native table optimizers count their step on the host before the device decides to skip it: take the
         # count back for the groups that skipped (torch's fused Adam does the same with _foreach_sub_(steps, found_inf))
         for key, opt in self.optimizers.items():
-            if isinstance(opt, (HashTableAdam, ShardedTableAdam)) and \
+            if isinstance(opt, (HashTableAdam, ShardedTableAdam, SmallGroupAdam)) and \
                     flags[self._found_groups.index(self.group_of[key])] != 0.0:
                 opt.rollback_step()
         if not any(f != 0.0 for f in flags):

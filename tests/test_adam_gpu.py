@@ -150,3 +150,62 @@ def test_placement_calibration_keeps_values_and_installs_state(cuda):
     assert (he.tables - twin.tables).abs().max().item() <= 5e-5
     assert (he.tables.detach() - before).abs().max().item() > 1e-3          # it did train
     assert torch.equal(he.half_tables(), he.tables.detach().half())
+
+
+def test_small_group_adam_equals_torch_adam_with_gradscaler_semantics(cuda):
+    """engine/small_adam.py (two launches for all small groups) against torch.optim.Adam per group + GradScaler's
+    unscale / inf check / per-group skip (nersemble_trainer.py:185-203): identical parameters and moments to fp32
+    rounding, a poisoned group is skipped and its step count does not advance, tensors without a gradient are left
+    alone."""
+    from nersemble_amd.engine.small_adam import SmallGroupAdam, adam_groups, unscale_and_check_groups
+    g = torch.Generator(device=cuda).manual_seed(0)
+    shapes = [[(64, 32), (16, 64), (64, 64)], [(100, 32), (100, 128)], [(128, 173), (128,), (3, 128), (3,), (7, 5, 3)]]
+    lrs, eps = [5e-3, 5e-3, 1e-3], 1e-15
+
+    def make():
+        gg = torch.Generator(device=cuda).manual_seed(1)
+        return [[torch.nn.Parameter(torch.randn(s, device=cuda, generator=gg)) for s in grp] for grp in shapes]
+
+    ref_params, nat_params = make(), make()
+    ref_opts = [torch.optim.Adam(p, lr=lr, eps=eps) for p, lr in zip(ref_params, lrs)]
+    nat_opts = [SmallGroupAdam(p, lr=lr, eps=eps) for p, lr in zip(nat_params, lrs)]
+    scale = 1024.0
+    inv = torch.tensor([1.0 / scale], device=cuda)
+    for it in range(5):
+        poisoned = 1 if it == 2 else -1
+        skip_tensor = (2, 4)                                     # group 2's last tensor gets no gradient at all
+        for gi, (rp, np_) in enumerate(zip(ref_params, nat_params)):
+            for ti, (a, b) in enumerate(zip(rp, np_)):
+                if (gi, ti) == skip_tensor:
+                    a.grad = b.grad = None
+                    continue
+                grad = torch.randn(a.shape, device=cuda, generator=g)
+                if gi == poisoned and ti == 0:
+                    grad.view(-1)[3] = float("inf")
+                a.grad = grad.clone()                            # reference: unscaled gradient
+                b.grad = grad * scale                            # native: scaled, as backward() of the scaled loss leaves it
+        found = torch.zeros(3, device=cuda)
+        table = unscale_and_check_groups(nat_opts, [0, 1, 2], 3, found, inv)
+        assert found.tolist() == [1.0 if k == poisoned else 0.0 for k in range(3)]
+        adam_groups(nat_opts, [0, 1, 2], 3, table, found)
+        for k, opt in enumerate(ref_opts):
+            if k != poisoned:
+                opt.step()
+            else:
+                nat_opts[k].rollback_step()                      # what the trainer does once it has read the flag
+        for gi, (rp, np_) in enumerate(zip(ref_params, nat_params)):
+            for ti, (a, b) in enumerate(zip(rp, np_)):
+                assert torch.allclose(a, b, rtol=1e-5, atol=1e-7), (it, gi, ti, (a - b).abs().max().item())
+                if (gi, ti) != skip_tensor and gi != poisoned:
+                    assert torch.allclose(b.grad, a.grad, rtol=1e-6)         # unscaled in place
+    assert [o.step_count for o in nat_opts] == [5, 4, 5]
+    for ro, no in zip(ref_opts, nat_opts):
+        for (pa, sa), (pb, sb) in zip(ro.state.items(), no.state.items()):
+            assert torch.allclose(sa["exp_avg"], sb["exp_avg"], rtol=1e-5, atol=1e-8)
+            assert torch.allclose(sa["exp_avg_sq"], sb["exp_avg_sq"], rtol=1e-5, atol=1e-10)
+    # torch-shaped state dict round trip
+    sd = nat_opts[0].state_dict()
+    assert int(sd["state"][0]["step"]) == 5 and "exp_avg" in sd["state"][0]
+    fresh = SmallGroupAdam(make()[0], lr=5e-3, eps=eps)
+    fresh.load_state_dict(sd)
+    assert fresh.step_count == 5
