@@ -234,6 +234,9 @@ int     nsx_deform_param_count(void);
 int64_t nsx_deform_pack_bytes(void);
 int64_t nsx_deform_scratch_bytes(int64_t S);
 int nsx_deform_pack(const float* params, void* packed, void* stream);
+/* The same from the 16 nn.Linear tensors where they live (host array of 16 device pointers, fp32 contiguous, in the
+ * order W0 b0 W1 b1 W2 b2 W3 b3 W4 b4 W5 b5 Wr br Wv bv): no concatenation of the parameters per optimizer step. */
+int nsx_deform_pack_tensors(const void* const* tensors16_host, void* packed, void* stream);
 int nsx_deform_fwd(const void* packed, const float* positions, int64_t S, const float* aabb_host, const float* code,
                    int64_t code_stride, const int32_t* code_slot, const float* window7_host, float* offsets,
                    void* stream);

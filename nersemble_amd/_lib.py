@@ -86,6 +86,7 @@ SIGNATURES = {
     "nsx_deform_pack_bytes": (c_int64, []),
     "nsx_deform_scratch_bytes": (c_int64, [c_int64]),
     "nsx_deform_pack": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "nsx_deform_pack_tensors": (c_int, [C.POINTER(c_void_p), c_void_p, c_void_p]),
     "nsx_deform_fwd": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p,
                                c_void_p]),
     "nsx_deform_bwd": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int, c_void_p,

@@ -85,8 +85,24 @@ __device__ __forceinline__ f32x16 zero16() {
 // ---------------------------------------------------------------------------------------------------------
 // weight packing: fp32 nn.Linear parameters -> fp16 MFMA fragments (+ fp16-rounded biases as fp32)
 // ---------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float pack_source(const float* __restrict__ P, int fi, int i, int kb, int j) {
-    auto lin = [&](int wbase, int ld, int row, int col) { return P[wbase + row * ld + col]; };
+// The 16 nn.Linear tensors either as ONE flat fp32 vector in the P_* order above or as 16 separate device tensors (what
+// nn.Module holds: no torch.cat of the parameters per step).
+struct DeformParamSrc {
+    const float* flat;          // non-NULL: flat vector
+    const float* t[16];         // else: W0 b0 W1 b1 W2 b2 W3 b3 W4 b4 W5 b5 Wr br Wv bv
+    __device__ __forceinline__ float at(int flat_index) const {
+        if (flat) return flat[flat_index];
+        constexpr int starts[17] = {P_W0, P_B0, P_W1, P_B1, P_W2, P_B2, P_W3, P_B3, P_W4, P_B4, P_W5, P_B5,
+                                    P_WR, P_BR, P_WV, P_BV, P_TOTAL};
+        int k = 0;
+#pragma unroll
+        for (int q = 1; q < 16; ++q) k += (flat_index >= starts[q]) ? 1 : 0;
+        return t[k][flat_index - starts[k]];
+    }
+};
+
+__device__ __forceinline__ float pack_source(const DeformParamSrc& P, int fi, int i, int kb, int j) {
+    auto lin = [&](int wbase, int ld, int row, int col) { return P.at(wbase + row * ld + col); };
     if (fi < F1) {                                   // W0 natural k
         const int mt = (fi - F0) / DF_TIN, t = (fi - F0) % DF_TIN, k = 16 * t + 8 * kb + j;
         return k < DF_IN ? lin(P_W0, DF_IN, 32 * mt + i, k) : 0.f;
@@ -132,7 +148,7 @@ __device__ __forceinline__ float pack_source(const float* __restrict__ P, int fi
     }
 }
 
-__global__ void deform_pack_kernel(const float* __restrict__ P, f16x8* __restrict__ frags, float* __restrict__ bias) {
+__global__ void deform_pack_kernel(DeformParamSrc P, f16x8* __restrict__ frags, float* __restrict__ bias) {
     const int total = N_FRAGS * 64;
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
         const int fi = e / 64, ll = e % 64, i = ll & 31, kb = ll >> 5;
@@ -146,11 +162,11 @@ __global__ void deform_pack_kernel(const float* __restrict__ P, f16x8* __restric
         if (e < 6 * DFW) {
             const int l = e / DFW, n = e % DFW;
             const int base = l == 0 ? P_B0 : l == 1 ? P_B1 : l == 2 ? P_B2 : l == 3 ? P_B3 : l == 4 ? P_B4 : P_B5;
-            b = P[base + n];
+            b = P.at(base + n);
         } else {
             const int o = e - 6 * DFW;
-            if (o < 3) b = P[P_BR + o];
-            else if (o < 6) b = P[P_BV + o - 3];
+            if (o < 3) b = P.at(P_BR + o);
+            else if (o < 6) b = P.at(P_BV + o - 3);
         }
         bias[e] = (float)(half_t)b;            // autocast rounds the bias to fp16
     }
@@ -901,8 +917,26 @@ int nsx_deform_pack(const float* params, void* packed, void* stream) {
     NSX_REQUIRE(params && packed, "nsx_deform_pack: NULL argument");
     f16x8* frags = reinterpret_cast<f16x8*>(packed);
     float* bias = reinterpret_cast<float*>(reinterpret_cast<uint8_t*>(packed) + (size_t)N_FRAGS * 64 * 16);
-    hipLaunchKernelGGL(deform_pack_kernel, dim3(64), dim3(256), 0, (hipStream_t)stream, params, frags, bias);
+    DeformParamSrc src;
+    src.flat = params;
+    for (int k = 0; k < 16; ++k) src.t[k] = nullptr;
+    hipLaunchKernelGGL(deform_pack_kernel, dim3(64), dim3(256), 0, (hipStream_t)stream, src, frags, bias);
     NSX_LAUNCH_CHECK("nsx_deform_pack launch");
+    return NSX_OK;
+}
+
+int nsx_deform_pack_tensors(const void* const* tensors16_host, void* packed, void* stream) {
+    NSX_REQUIRE(tensors16_host && packed, "nsx_deform_pack_tensors: NULL argument");
+    DeformParamSrc src;
+    src.flat = nullptr;
+    for (int k = 0; k < 16; ++k) {
+        NSX_REQUIRE(tensors16_host[k], "nsx_deform_pack_tensors: tensor %d is NULL", k);
+        src.t[k] = reinterpret_cast<const float*>(tensors16_host[k]);
+    }
+    f16x8* frags = reinterpret_cast<f16x8*>(packed);
+    float* bias = reinterpret_cast<float*>(reinterpret_cast<uint8_t*>(packed) + (size_t)N_FRAGS * 64 * 16);
+    hipLaunchKernelGGL(deform_pack_kernel, dim3(64), dim3(256), 0, (hipStream_t)stream, src, frags, bias);
+    NSX_LAUNCH_CHECK("nsx_deform_pack_tensors launch");
     return NSX_OK;
 }
 

@@ -191,9 +191,13 @@ class NeRSembleTrainer:
             opt.zero_grad(set_to_none=True)
         dev_type = ray_bundle.origins.device.type
         with torch.autocast(device_type=dev_type, dtype=torch.float16, enabled=self.mixed_precision, cache_enabled=False):
-            outputs = self.model(ray_bundle)
-            metrics_dict = self.model.get_metrics_dict(outputs, batch)
-            loss_dict = self.model.get_loss_dict(outputs, batch, metrics_dict)
+            fast = self.model.fused_train_forward(ray_bundle, batch) if self.mixed_precision else None
+            if fast is not None:
+                loss_dict, metrics_dict, outputs = fast
+            else:
+                outputs = self.model(ray_bundle)
+                metrics_dict = self.model.get_metrics_dict(outputs, batch)
+                loss_dict = self.model.get_loss_dict(outputs, batch, metrics_dict)
             loss = getattr(loss_dict, "total", None)
             if loss is None:
                 loss = functools.reduce(torch.add, loss_dict.values())

@@ -166,7 +166,7 @@ class SE3DeformationField(nn.Module):
         key = (_OPTIMIZER_STEPS[0],) + tuple((p._version, p.data_ptr()) for p in params)
         if getattr(self, "_packed_key", None) != key:
             with torch.no_grad():
-                self._packed = F.deform_pack(self.flat_params())
+                self._packed = F.deform_pack_tensors(params)
             self._packed_key = key
         return self._packed
 

@@ -154,7 +154,8 @@ class NeRSembleNeRFactoField(nn.Module):
                                            window_hash_encodings=window_hash_encodings, code_index=idx_c,
                                            precomputed=pre_f)
             h = F.fused_mlp(self.mlp_base.params, self.mlp_base.n_hidden_mats, self.mlp_base.n_output_dims,
-                            self.mlp_base.out_act, b=feats, precomputed=pre_b).view(*pos_c.shape[:-1], -1)   # [S,16] fp16
+                            self.mlp_base.out_act, b=feats, precomputed=pre_b,
+                            w16=self.mlp_base.half_weights()).view(*pos_c.shape[:-1], -1)   # [S,16] fp16
             if self.keep_density_intermediates:
                 feats_all.append(feats)
             if sel_c is not None:
@@ -187,7 +188,8 @@ class NeRSembleNeRFactoField(nn.Module):
         for dir_c, base_c in chunked(max(max_chunk, 1), directions, base_out):
             # mlp_head input = [(d+1)/2 (3), geo features (15)], read in place by the kernel (:313, :371-377)
             rgb = F.fused_mlp(self.mlp_head.params, self.mlp_head.n_hidden_mats, 3, self.mlp_head.out_act,
-                              a=dir_c, a_mul=0.5, a_add=0.5, b=base_c, b_off=1, b_dim=self.geo_feat_dim)
+                              a=dir_c, a_mul=0.5, a_add=0.5, b=base_c, b_off=1, b_dim=self.geo_feat_dim,
+                              w16=self.mlp_head.half_weights())
             rgbs.append(rgb.to(directions))
         return {FieldHeadNames.RGB: torch.cat(rgbs, dim=0)}
 

@@ -252,15 +252,23 @@ def _seg(t, width_dtype):
     return t
 
 
+def f32_to_f16(params: torch.Tensor) -> torch.Tensor:
+    """Flat fp32 parameters -> fp16 (round to nearest even), one launch."""
+    src = params.detach().contiguous()
+    w16 = torch.empty(src.numel(), dtype=torch.float16, device=src.device)
+    check(lib().nsx_f32_to_f16(ptr(src, torch.float32), ptr(w16), src.numel(), stream()), "nsx_f32_to_f16")
+    return w16
+
+
 class _FusedMLPFn(torch.autograd.Function):
     """out = MLP([a * a_mul + a_add (fp32 segment), b[:, b_off:b_off+b_dim] (fp16 segment)]); see include/nsx.h."""
 
     @staticmethod
-    def forward(ctx, params, a, b, n_hidden_mats, a_mul, a_add, b_off, b_dim, n_out, out_act, precomputed=None):
+    def forward(ctx, params, a, b, n_hidden_mats, a_mul, a_add, b_off, b_dim, n_out, out_act, precomputed=None,
+                w16=None):
         dev = params.device
-        w16 = torch.empty(params.numel(), dtype=torch.float16, device=dev)
-        check(lib().nsx_f32_to_f16(ptr(params.detach().contiguous(), torch.float32), ptr(w16), params.numel(), stream()),
-              "nsx_f32_to_f16")
+        if w16 is None:
+            w16 = f32_to_f16(params)
         a_c = a.detach().to(torch.float32).contiguous() if a is not None else None
         b_c = b.detach().to(torch.float16).contiguous() if b is not None else None
         B = a_c.shape[0] if a_c is not None else b_c.shape[0]
@@ -296,19 +304,19 @@ class _FusedMLPFn(torch.autograd.Function):
                                 ptr(b_c), b_c.stride(0) if b_c is not None else 0, b_off, b_dim if b_c is not None else 0,
                                 n_out, out_act, ptr(dout), dout.stride(0), ptr(dW), ptr(da), ptr(db), stream()),
               "nsx_mlp_bwd")
-        return dW, da, db, None, None, None, None, None, None, None, None
+        return dW, da, db, None, None, None, None, None, None, None, None, None
 
 
 def fused_mlp(params: torch.Tensor, n_hidden_mats: int, n_out: int, out_act: int = 0,
               a: Optional[torch.Tensor] = None, a_mul: float = 1.0, a_add: float = 0.0,
               b: Optional[torch.Tensor] = None, b_off: int = 0, b_dim: Optional[int] = None,
-              precomputed: Optional[torch.Tensor] = None) -> torch.Tensor:
+              precomputed: Optional[torch.Tensor] = None, w16: Optional[torch.Tensor] = None) -> torch.Tensor:
     """tcnn FullyFusedMLP equivalent (width 64, 1 + n_hidden_mats hidden layers, no biases).
-    params: flat fp32 [W0 | Wh | Wo]; returns [B, n_out] fp16."""
+    params: flat fp32 [W0 | Wh | Wo]; ``w16``: their fp16 copy if the caller already has it; returns [B, n_out] fp16."""
     if b is not None and b_dim is None:
         b_dim = b.shape[1] - b_off
     return _FusedMLPFn.apply(params, a, b, n_hidden_mats, float(a_mul), float(a_add), int(b_off),
-                             int(b_dim or 0), int(n_out), int(out_act), precomputed)
+                             int(b_dim or 0), int(n_out), int(out_act), precomputed, w16)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -404,6 +412,19 @@ def deform_pack(flat_params: torch.Tensor) -> torch.Tensor:
     params = flat_params.detach().to(torch.float32).contiguous()
     packed = torch.empty(_deform_pack_bytes(), dtype=torch.uint8, device=params.device)
     check(lib().nsx_deform_pack(ptr(params), ptr(packed), stream()), "nsx_deform_pack")
+    return packed
+
+
+def deform_pack_tensors(params16) -> torch.Tensor:
+    """As ``deform_pack`` but straight from the 16 parameter tensors (include/nsx.h order), without concatenating."""
+    assert len(params16) == 16
+    tensors = [p.detach() for p in params16]
+    for t in tensors:
+        if t.dtype != torch.float32 or not t.is_contiguous():
+            return deform_pack(torch.cat([p.detach().float().reshape(-1) for p in params16]))
+    packed = torch.empty(_deform_pack_bytes(), dtype=torch.uint8, device=tensors[0].device)
+    arr = (C.c_void_p * 16)(*[ptr(t).value for t in tensors])
+    check(lib().nsx_deform_pack_tensors(arr, ptr(packed), stream()), "nsx_deform_pack_tensors")
     return packed
 
 

@@ -105,6 +105,8 @@ class NeRSembleNGPModel(BaseModel):
         self.reuse_sigma_pass = True
         # all loss terms + metrics from csrc/losses.hip when the configuration allows (see _fused_step_losses)
         self.fuse_step_losses = True
+        # the kept samples' main pass of a training step as one autograd node (fused_train_forward; host-side saving)
+        self.fuse_main_pass = True
         # evaluation fast path: when every ray of a bundle carries the same timestep the H hash tables
         # are blended once per image into one 2-feature grid (HashEnsemble.preblend)
         self.eval_preblend = True
@@ -353,6 +355,116 @@ class NeRSembleNGPModel(BaseModel):
         if deformation is not None:
             outputs["deformation"] = deformation
         return outputs
+
+    # ---- training fast path: the main pass as one autograd node (engine/fused_pass.py) --------------------------
+    def fused_train_forward(self, ray_bundle: RayBundle, batch: Dict[str, Tensor]):
+        """``get_outputs`` + ``get_loss_dict`` + ``get_metrics_dict`` of a training step with the kept samples' main pass
+        run as ONE autograd Function (same kernels, same order, same results as the modular path).  Returns
+        ``(loss_dict, metrics_dict, outputs)`` -- or ``None`` when the configuration is outside what the fast path covers
+        (then the caller takes the modular path).  Training mode with autograd on only."""
+        cfg = self.config
+        if not (self.fuse_main_pass and self.training and torch.is_grad_enabled() and ray_bundle.origins.is_cuda
+                and cfg.use_hash_ensemble and cfg.use_deformation_field and self.time_embedding is not None
+                and self.deformation_field.native_supported() and cfg.background_color in ("white", "black")
+                and not cfg.disable_occupancy_grid and "depth_maps" in batch and cfg.lambda_dist_loss > 0
+                and cfg.lambda_near_loss > 0 and cfg.lambda_empty_loss > 0 and len(ray_bundle) <= cfg.dist_loss_max_rays):
+            return None
+        alpha_map = batch.get("alpha_map")
+        num_rays = len(ray_bundle)
+        if alpha_map is not None and not (alpha_map.dtype == torch.uint8 and alpha_map.numel() == num_rays):
+            return None
+        from ..engine.fused_pass import MainPassInputs, main_pass
+        from .. import distloss as dl
+        from .. import functional as Fn
+        window_hash = self.sched_window_hash_encodings.value if self.sched_window_hash_encodings is not None else None
+        window_deform = self.sched_window_deform.value if self.sched_window_deform is not None else None
+        self._sigma_cache = None
+        self.field.keep_density_intermediates = self.reuse_sigma_pass
+        try:
+            with torch.no_grad():
+                ray_samples, ray_indices = self.sampler(
+                    ray_bundle=ray_bundle, near_plane=cfg.near_plane, far_plane=cfg.far_plane,
+                    render_step_size=cfg.render_step_size, alpha_thre=cfg.alpha_thre, cone_angle=cfg.cone_angle,
+                    early_stop_eps=cfg.early_stop_eps)
+        finally:
+            self.field.keep_density_intermediates = False
+        S = ray_indices.shape[0]
+        max_chunk = cfg.max_n_samples_per_batch
+        if max_chunk != -1 and S > max_chunk:
+            self._sigma_cache = None
+            return None                                  # several chunks: the modular path walks them
+        md = ray_bundle.metadata
+        if "image_index" in md and "_image_timesteps" in md:
+            uniq = md["_image_timesteps"].reshape(-1).int()
+            slot = (ray_samples.metadata or {}).get("image_index")
+            if slot is None or slot.shape[0] != S:
+                slot = md["image_index"].reshape(-1).to(torch.int32)[ray_indices]
+        else:
+            ray_timesteps = self._timesteps(ray_bundle.times) if ray_bundle.times is not None \
+                else md["timesteps"].reshape(-1).int()
+            uniq, inv = torch.unique(ray_timesteps, return_inverse=True)
+            slot = inv.to(torch.int32)[ray_indices]
+        slot = slot.reshape(-1).to(torch.int32).contiguous()
+        if uniq.shape[0] > 64:
+            return None
+        # forward values of the sampler's sigma_fn pass for the kept samples (exact reuse)
+        cache, keep = self._sigma_cache, self.occupancy_grid.last_keep_index
+        self._sigma_cache = None
+        pre = (None, None, None)
+        if cache is not None and keep is not None and cache["n"] == self.occupancy_grid.last_n_marched \
+                and keep.shape[0] == S and cache["features"] is not None and cache["offsets"] is not None:
+            pre = Fn.gather_rows(keep, cache["offsets"], cache["features"], cache["base_out"])
+        he = self.field.hash_ensemble
+        code_hash, window = he._conditioned(self.time_embedding(uniq), window_hash, ray_indices.device)
+        emb_d = self.time_embedding_deformation if self.time_embedding_deformation is not None else self.time_embedding
+        code_deform = emb_d(uniq)
+        fr = ray_samples.frustums
+        inp = MainPassInputs()
+        inp.origins, inp.directions = fr.origins.contiguous(), fr.directions.contiguous()
+        inp.t0, inp.t1 = fr.starts.reshape(-1).contiguous(), fr.ends.reshape(-1).contiguous()
+        inp.ray_indices, inp.slot, inp.n_rays = ray_indices, slot, num_rays
+        inp.packed = nerfacc.pack_info(ray_indices, num_rays)
+        inp.pre_offsets, inp.pre_features, inp.pre_base = pre
+        inp.image = batch["image"].to(torch.float32).contiguous()
+        inp.alpha_map = alpha_map.reshape(-1).contiguous() if alpha_map is not None else None
+        inp.depth_targets = batch["depth_maps"].to(torch.float32).reshape(-1).contiguous()
+        inp.he, inp.window = he, window
+        inp.field_aabb6 = self.field._aabb6()
+        inp.deform_packed = self.deformation_field.packed_params()
+        inp.deform_aabb6 = self.deformation_field._aabb6()
+        inp.deform_window7 = Fn.deform_window7(window_deform)
+        mb, mh = self.field.mlp_base, self.field.mlp_head
+        inp.base_hidden, inp.base_out_dim, inp.base_act = mb.n_hidden_mats, mb.n_output_dims, mb.out_act
+        inp.head_hidden, inp.head_act, inp.geo_dim = mh.n_hidden_mats, mh.out_act, self.field.geo_feat_dim
+        inp.base_w16, inp.head_w16 = mb.half_weights(), mh.half_weights()
+        inp.background = 1.0 if cfg.background_color == "white" else 0.0
+        inp.loss_cfg = (bool(cfg.use_masked_rgb_loss), float(cfg.alpha_mask_threshold), float(cfg.lambda_alpha_loss or 0.0),
+                        float(cfg.lambda_depth_loss or 0.0), float(cfg.lambda_dist_loss), float(cfg.lambda_empty_loss),
+                        float(cfg.lambda_near_loss), float(self.sched_eps_depth.value), int(cfg.dist_loss_max_rays))
+        fused = main_pass(inp, he.tables, mb.params, mh.params, code_hash, code_deform,
+                          self.deformation_field.ordered_params())
+        loss_dict = LossDict()
+        loss_dict["rgb_loss"] = fused[dl.LOSS_RGB]
+        if alpha_map is not None and cfg.lambda_alpha_loss is not None and cfg.lambda_alpha_loss > 0:
+            loss_dict["alpha_loss"] = fused[dl.LOSS_ALPHA]
+        loss_dict["dist_loss"] = fused[dl.LOSS_DIST]
+        loss_dict["empty_loss"] = fused[dl.LOSS_EMPTY]
+        loss_dict["near_loss"] = fused[dl.LOSS_NEAR]
+        if cfg.lambda_depth_loss > 0:
+            loss_dict["depth_loss"] = fused[dl.LOSS_DEPTH]
+        loss_dict.total = fused[dl.LOSS_TOTAL]
+        if self.global_loss_normalisers is not None:
+            self._apply_global_normalisers(loss_dict, fused, num_rays)
+        m = fused.detach()
+        metrics = {"psnr": m[dl.LOSS_PSNR], "num_samples_per_batch": m[dl.LOSS_NUM_SAMPLES]}
+        if alpha_map is not None:
+            metrics["psnr_masked"] = m[dl.LOSS_PSNR_MASKED]
+        aux = inp.aux
+        fr.set_offsets(aux["offsets"])
+        outputs = {"rgb": aux["rgb"], "accumulation": aux["accumulation"], "depth": aux["depth"],
+                   "num_samples_per_ray": inp.packed[:, 1], "ray_samples": (ray_samples,), "ray_indices": (ray_indices,),
+                   "weights": (aux["weights"][..., None],), "packed_info": (inp.packed,), "deformation": aux["deformation"]}
+        return loss_dict, metrics, outputs
 
     def forward(self, ray_bundle: RayBundle):
         return self.get_outputs(ray_bundle)

@@ -46,6 +46,18 @@ class Network(nn.Module):
         self.params = nn.Parameter(_xavier_flat(shapes, gen))
         assert self.params.numel() == 64 * 32 + self.n_hidden_mats * 64 * 64 + 16 * 64
 
+    def half_weights(self) -> torch.Tensor:
+        """fp16 copy of ``params`` (what the kernels read), made once per optimizer step instead of once per call (tcnn
+        itself casts its fp32 master parameters to fp16 on every step).  Fused optimizers update parameters without
+        bumping ``Tensor._version``, hence the optimizer-step counter in the key."""
+        from .field_components.deformation_field import _OPTIMIZER_STEPS
+        p = self.params
+        key = (p._version, p.data_ptr(), _OPTIMIZER_STEPS[0])
+        if getattr(self, "_w16_key", None) != key:
+            self._w16 = F.f32_to_f16(p.detach())
+            self._w16_key = key
+        return self._w16
+
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         """x [B, n_input_dims] (fp16 or fp32) -> [B, n_output_dims] fp16."""
         x2 = x.reshape(-1, self.n_input_dims)

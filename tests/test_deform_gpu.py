@@ -151,3 +151,12 @@ def test_deform_kernels_are_race_free(cuda):
             assert torch.equal(c.grad, ref_gc)
             assert (gw - ref_gw).abs().max().item() <= 1e-4 * ref_gw.abs().max().item()
             assert (t.grad - ref_gt).abs().max().item() <= 1e-4 * ref_gt.abs().max().item()
+
+
+def test_pack_from_separate_tensors_equals_pack_of_the_flat_vector(cuda):
+    """nsx_deform_pack_tensors (16 nn.Linear tensors where they live) == nsx_deform_pack (their concatenation)."""
+    from nersemble_amd import functional as F
+    df = _field(5).to(cuda)
+    a = F.deform_pack(df.flat_params())
+    b = F.deform_pack_tensors(df.ordered_params())
+    assert torch.equal(a, b)

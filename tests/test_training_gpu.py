@@ -366,3 +366,47 @@ def test_split_scatter_backward_trains_like_the_fused_one(cuda):
         runs[split] = (losses, trainer.model.field.hash_ensemble.tables.detach().clone())
     assert np.allclose(runs[True][0][:4], runs[False][0][:4], rtol=2e-3), runs
     assert np.allclose(runs[True][0], runs[False][0], rtol=3e-2), runs
+
+
+def test_fused_main_pass_equals_modular_path(cuda):
+    """engine/fused_pass.py (the kept samples' main pass as ONE autograd node) against the modular path (nine autograd
+    Functions): the same kernels in the same order, so the loss vector is equal bit for bit and the gradients agree up
+    to the order of the fp32 atomics; with and without reuse of the sigma_fn pass's forward values."""
+    from nersemble_amd.workloads import build_workload
+    for reuse in (True, False):
+        res = {}
+        for fused in (False, True):
+            torch.manual_seed(6)
+            trainer, data, _ = build_workload("p030_h16", device="cuda:0", small=True, n_rays=512)
+            model = trainer.model
+            model.fuse_main_pass, model.reuse_sigma_pass = fused, reuse
+            calls = []
+            orig = model.fused_train_forward
+
+            def counted(*a, _orig=orig, _calls=calls, **k):
+                r = _orig(*a, **k)
+                _calls.append(r is not None)
+                return r
+
+            model.fused_train_forward = counted
+            losses, terms = [], None
+            for step in range(5):
+                torch.manual_seed(70 + step)                      # same near-plane jitter on both sides
+                loss, loss_dict, metrics = trainer.train_iteration(step, *data.next_train(step))
+                losses.append(loss.item())
+                if step == 0:
+                    terms = {k: v.item() for k, v in loss_dict.items()}
+                    terms.update({"m:" + k: float(v) for k, v in metrics.items()})
+                    grads = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+            trainer.flush_scheduler_step()
+            assert all(calls) == fused and len(calls) == 5
+            res[fused] = (losses, terms, grads, model.field.hash_ensemble.tables.detach().clone())
+        (l_m, t_m, g_m, tab_m), (l_f, t_f, g_f, tab_f) = res[False], res[True]
+        assert l_m[0] == l_f[0] and t_m == t_f, (reuse, l_m[0], l_f[0], t_m, t_f)     # forward: bit for bit
+        assert set(g_m) == set(g_f)
+        for name in g_m:
+            sc = g_m[name].abs().max().item()
+            assert (g_m[name] - g_f[name]).abs().max().item() <= 1e-4 * sc + 1e-12, (reuse, name)
+        assert np.allclose(l_m, l_f, rtol=2e-3), (reuse, l_m, l_f)
+        d = (tab_m - tab_f).abs()
+        assert (d <= 1e-5).float().mean().item() >= 0.999
