@@ -285,7 +285,11 @@ def test_two_ranks_on_half_batches_equal_one_process_on_the_union_batch(cuda, tm
         assert (d[moved] <= 1e-5).float().mean().item() >= tol_frac, (mode, (d[moved] <= 1e-5).float().mean().item())
         # small parameter groups: the averaged gradients ARE the union-batch gradients (what Adam does with them at
         # step 1 is +-lr per element, i.e. a sign test of values that can be pure summation noise -- compare upstream)
-        assert set(a["grads"]) == set(grads)
+        # (the data-parallel gradient average gives parameters without a gradient -- the time codes while the hash window
+        # pins them to ones -- an explicit zero; the single process leaves them at None)
+        assert set(a["grads"]) >= set(grads)
+        for name in set(a["grads"]) - set(grads):
+            assert a["grads"][name].abs().max().item() == 0.0, (mode, name)
         for name, g_ref in grads.items():
             sc = g_ref.abs().max().item()
             if sc == 0.0:

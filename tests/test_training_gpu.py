@@ -355,6 +355,7 @@ def test_split_scatter_backward_trains_like_the_fused_one(cuda):
     for split in (False, True):
         torch.manual_seed(4)
         trainer, data, _ = build_workload("p030_h16", device="cuda:0", small=True, n_rays=512)
+        trainer.model.fuse_main_pass = False                 # the split lives in the modular path's HashEnsemble backward
         sink = trainer.model.field.hash_ensemble.grad_sink
         sink.split_scatter, sink.scatter_blocks_per_cu = split, 2
         losses = []
@@ -398,9 +399,11 @@ def test_fused_main_pass_equals_modular_path(cuda):
                     terms = {k: v.item() for k, v in loss_dict.items()}
                     terms.update({"m:" + k: float(v) for k, v in metrics.items()})
                     grads = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+                    model.field.hash_ensemble.wait_tables()
+                    tables = model.field.hash_ensemble.tables.detach().clone()       # after ONE optimizer step
             trainer.flush_scheduler_step()
             assert all(calls) == fused and len(calls) == 5
-            res[fused] = (losses, terms, grads, model.field.hash_ensemble.tables.detach().clone())
+            res[fused] = (losses, terms, grads, tables)
         (l_m, t_m, g_m, tab_m), (l_f, t_f, g_f, tab_f) = res[False], res[True]
         assert l_m[0] == l_f[0] and t_m == t_f, (reuse, l_m[0], l_f[0], t_m, t_f)     # forward: bit for bit
         assert set(g_m) == set(g_f)
@@ -408,5 +411,7 @@ def test_fused_main_pass_equals_modular_path(cuda):
             sc = g_m[name].abs().max().item()
             assert (g_m[name] - g_f[name]).abs().max().item() <= 1e-4 * sc + 1e-12, (reuse, name)
         assert np.allclose(l_m, l_f, rtol=2e-3), (reuse, l_m, l_f)
+        # one Adam step (+-lr per touched entry): equal unless a cancelling gradient changed sign with the atomics' order;
+        # later steps diverge chaotically from there, which is why the long run is compared through the loss
         d = (tab_m - tab_f).abs()
-        assert (d <= 1e-5).float().mean().item() >= 0.999
+        assert (d <= 1e-5).float().mean().item() >= 0.9995

@@ -1,0 +1,59 @@
+"""rocprofv3 --pmc counter_collection CSVs -> per-kernel means and per-launch HBM bytes of the C-ABI entry points.
+
+    python tools/pmc_to_json.py <fetch_dir> <write_dir> <out.json> "<source note>"
+
+FETCH_SIZE / WRITE_SIZE are reported in KB per dispatch.  Correction (MI355X_MICROARCH.md, HBM section): on gfx950
+FETCH_SIZE tallies the 128-B requests of wide coalesced reads at 64 B -> x2; WRITE_SIZE as reported."""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+ENTRY_OF = {            # kernel-name prefix -> C-ABI entry point it belongs to
+    "nsx::ens_fwd_kernel": "nsx_hash_ensemble_fwd",
+    "nsx::ens_bwd_kernel": "nsx_hash_ensemble_bwd_factored",
+    "nsx::ens_scatter_kernel": "nsx_hash_ensemble_bwd_scatter",
+    "nsx::adam_hash_factored_kernel": "nsx_adam_hash_factored",
+    "nsx::deform_bwd_kernel": "nsx_deform_bwd",
+    "nsx::deform_wgrad_kernel": "nsx_deform_bwd",
+    "nsx::deform_fwd_kernel": "nsx_deform_fwd",
+}
+
+
+def means(directory, counter):
+    acc = collections.defaultdict(list)
+    for path in glob.glob(os.path.join(directory, "**", "*counter_collection.csv"), recursive=True):
+        with open(path) as f:
+            for r in csv.DictReader(f):
+                if r["Counter_Name"] != counter:
+                    continue
+                name = r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0].strip()
+                acc[name].append(float(r["Counter_Value"]))
+    return {k: {"mean_kb": sum(v) / len(v), "dispatches": len(v)} for k, v in acc.items()}
+
+
+def main():
+    fetch_dir, write_dir, out, note = sys.argv[1:5]
+    fetch, write = means(fetch_dir, "FETCH_SIZE"), means(write_dir, "WRITE_SIZE")
+    per_launch = collections.defaultdict(float)
+    for name, entry in ENTRY_OF.items():
+        if name in fetch:
+            per_launch[entry] += fetch[name]["mean_kb"] * 1024.0 * 2.0
+        if name in write:
+            per_launch[entry] += write[name]["mean_kb"] * 1024.0
+    doc = {"source": note,
+           "correction": "MI355X_MICROARCH.md HBM section: FETCH_SIZE counts half the bytes of 16-B/lane coalesced reads on "
+                         "gfx950 -> x2; WRITE_SIZE as reported; KB -> x1024; per launch = mean over the dispatches of the "
+                         "run (a C-ABI call that launches two kernels sums them)",
+           "per_launch_hbm_bytes": dict(per_launch),
+           "kernels_fetch_kb": {k: v for k, v in sorted(fetch.items()) if k.startswith("nsx::")},
+           "kernels_write_kb": {k: v for k, v in sorted(write.items()) if k.startswith("nsx::")}}
+    with open(out, "w") as f:
+        json.dump(doc, f, indent=1)
+    print(json.dumps(doc["per_launch_hbm_bytes"], indent=1))
+
+
+if __name__ == "__main__":
+    main()
