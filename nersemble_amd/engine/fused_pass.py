@@ -189,7 +189,9 @@ class _MainPass(torch.autograd.Function):
                                                ptr(dx), ptr(sink.nonfinite) if (sink is not None and need_tab) else None,
                                                st), "nsx_hash_ensemble_bwd_factored")
         if sink is not None and need_tab and ctx.announced:
-            sink.arrived()
+            # G is complete, and so are the gradients of the two fused MLPs (the rest of the tables' optimizer group):
+            # the table optimizer may start its 12 GB pass now, beside the deformation backward below
+            sink.arrived(group_grads=[d_base, d_head])
         if need_tab and sink is None:
             dtab = torch.empty(ctx.shapes[0], dtype=f32, device=dev)
             check(L.nsx_hash_grad_expand(ptr(G), n_rows, ptr(code_h), code_h.stride(0), ptr(inp.window), H, C.byref(geom),

@@ -27,6 +27,41 @@ class HashTableAdam(torch.optim.Optimizer):
         self.factored = factored
         if factored:
             hash_ensemble.grad_sink = F.FactoredGradSink()
+        # early step (armed by the trainer for one backward): see arm_early_step
+        self._early = None
+        self.stepped_early = False
+
+    # ---- the step started from inside the backward -----------------------------------------------------------
+    def arm_early_step(self, found_inf: torch.Tensor, inv_scale: torch.Tensor, side_stream) -> None:
+        """For the coming backward: as soon as the HashEnsemble's backward has completed G -- and handed over the
+        gradients of the rest of this optimizer's group (``FactoredGradSink.arrived(group_grads=...)``) -- check them for
+        inf / NaN into ``found_inf`` and launch the table step on ``side_stream``, i.e. BESIDE the deformation field's
+        backward and the small groups' optimizer work instead of after them.  GradScaler semantics are kept: the group is
+        skipped as a whole iff any of its gradients is non-finite (the trainer merges ``found_inf`` into the flags the
+        small-group kernels and the scale update read)."""
+        sink = self.he.grad_sink
+        if sink is None:
+            return
+        self._early = (found_inf, inv_scale, side_stream)
+        self.stepped_early = False
+        sink.on_complete = self._early_step
+
+    def disarm_early_step(self) -> None:
+        self._early = None
+        if self.he.grad_sink is not None:
+            self.he.grad_sink.on_complete = None
+
+    @torch.no_grad()
+    def _early_step(self) -> None:
+        sink = self.he.grad_sink
+        if self._early is None or sink.group_grads is None or self.he.tables.grad is not None or len(sink.entries) != 1:
+            return                                           # not everything is known here: the trainer steps later
+        found_inf, inv_scale, side_stream = self._early
+        for g in sink.group_grads:
+            check(lib().nsx_check_finite(ptr(g), g.numel(), ptr(found_inf), stream()), "nsx_check_finite")
+        self.check_finite(found_inf)
+        self.step(found_inf=found_inf, inv_scale=inv_scale, side_stream=side_stream)
+        self.stepped_early = True
 
     def _state(self):
         p = self.he.tables

@@ -135,16 +135,42 @@ class NeRSembleTrainer:
                   for pg in opt.param_groups for p in pg["params"]]
         all_reduce_gradients(params, self.world_size)
 
-    def _optimizer_step_all(self):
+    def _arm_early_table_step(self):
+        """Single GPU, fused main pass: let the table optimizer start from inside the backward (HashTableAdam.
+        arm_early_step).  Returns (found_all, inv_scale) for ``_optimizer_step_all`` or None."""
+        key = self.group_of_tables()
+        opt = self.optimizers.get(key) if key else None
+        if self.world_size != 1 or not isinstance(opt, HashTableAdam) or opt.he.grad_sink is None \
+                or self._opt_stream is None:
+            return None
+        self.flush_scheduler_step()        # the learning rates of this step depend on the previous step's outcome
+        inv_scale = self.grad_scaler.inv_scale()
+        groups = sorted(set(self.group_of.values()))
+        found_all = torch.zeros((len(groups),), dtype=torch.float32, device=inv_scale.device)
+        i = groups.index(self.group_of[key])
+        opt.arm_early_step(found_all[i:i + 1], inv_scale, self._opt_stream)
+        return found_all, inv_scale
+
+    def _optimizer_step_all(self, early=None):
         """GradScaler semantics (nersemble_trainer.py:186): unscale + inf check per optimizer group, skip the step of
-        a group whose gradients hold inf/NaN, then one scale update from all groups."""
+        a group whose gradients hold inf/NaN, then one scale update from all groups.  ``early``: (found_all, inv_scale)
+        of a step whose table optimizer was armed to start inside the backward."""
         self.flush_scheduler_step()        # the learning rates of this step depend on the previous step's outcome
         scaler = self.grad_scaler
-        inv_scale = scaler.inv_scale()
-        dev = inv_scale.device
         groups = sorted(set(self.group_of.values()))
-        found_all = torch.zeros((len(groups),), dtype=torch.float32, device=dev)
+        if early is not None:
+            found_all, inv_scale = early
+            dev = inv_scale.device
+        else:
+            inv_scale = scaler.inv_scale()
+            dev = inv_scale.device
+            found_all = torch.zeros((len(groups),), dtype=torch.float32, device=dev)
         found = {g: found_all[i:i + 1] for i, g in enumerate(groups)}
+        table_opt = self.optimizers.get(self.group_of_tables() or "")
+        stepped_early = isinstance(table_opt, HashTableAdam) and table_opt.stepped_early
+        if isinstance(table_opt, HashTableAdam):
+            table_opt.disarm_early_step()
+            table_opt.stepped_early = False
         native_small = [(key, opt) for key, opt in self.optimizers.items() if isinstance(opt, SmallGroupAdam)]
         small_groups = [groups.index(self.group_of[key]) for key, _ in native_small]
         table = None
@@ -153,7 +179,8 @@ class NeRSembleTrainer:
         for key, opt in self.optimizers.items():
             f = found[self.group_of[key]]
             if isinstance(opt, (HashTableAdam, ShardedTableAdam)):
-                opt.check_finite(f)
+                if not (stepped_early and opt is table_opt):
+                    opt.check_finite(f)
             elif not isinstance(opt, SmallGroupAdam):
                 grads = [p.grad for pg in opt.param_groups for p in pg["params"] if p.grad is not None]
                 scaler.unscale_and_check(grads, f, inv_scale)
@@ -163,7 +190,8 @@ class NeRSembleTrainer:
         for key, opt in self.optimizers.items():
             f = found[self.group_of[key]]
             if isinstance(opt, HashTableAdam):
-                opt.step(found_inf=f, inv_scale=inv_scale, side_stream=self._opt_stream)
+                if not (stepped_early and opt is table_opt):
+                    opt.step(found_inf=f, inv_scale=inv_scale, side_stream=self._opt_stream)
             elif isinstance(opt, ShardedTableAdam):
                 opt.step(found_inf=f, inv_scale=inv_scale, side_stream=self._opt_stream)
             elif isinstance(opt, SmallGroupAdam):
@@ -201,9 +229,10 @@ class NeRSembleTrainer:
             loss = getattr(loss_dict, "total", None)
             if loss is None:
                 loss = functools.reduce(torch.add, loss_dict.values())
+        early = self._arm_early_table_step() if fast is not None else None
         self.grad_scaler.scale(loss).backward()
         self._all_reduce_grads()
-        found_all = self._optimizer_step_all()
+        found_all = self._optimizer_step_all(early)
         # the reference skips the LR step when the scale dropped, i.e. when an inf/NaN was found (:199-203).  Reading
         # the flags here would drain the GPU queue at the end of every step; they are copied to pinned memory instead
         # and consulted right before the learning rates are next used (flush_scheduler_step).

@@ -86,6 +86,7 @@ class FactoredGradSink:
         self.scatter_blocks_per_cu = int(os.environ.get("NSX_SCATTER_BLOCKS", "8"))
         self.scatter_stream = None
         self.scatter_done = None
+        self.group_grads = None
 
     def wait_scatter(self, stream=None) -> None:
         """Order ``stream`` (default: the current one) after the scatter kernels launched so far."""
@@ -96,11 +97,15 @@ class FactoredGradSink:
     def expect(self) -> None:
         self.pending += 1
 
-    def arrived(self) -> None:
+    def arrived(self, group_grads=None) -> None:
         """One recorded forward has scattered its gradient; the table gradient of the step is complete when none is
-        left (the data-parallel optimizer starts its reduce-scatter from here, beside the rest of the backward)."""
+        left (the data-parallel optimizer starts its reduce-scatter from here, the single-GPU one its whole step --
+        beside the rest of the backward).  ``group_grads``: the (scaled) gradients of the OTHER parameters of the
+        tables' optimizer group if the caller has them already (GradScaler skips a group as a whole); without them the
+        completion hook must not step on its own."""
         if self.pending > 0:
             self.pending -= 1
+        self.group_grads = group_grads if self.pending == 0 else None
         if self.pending == 0 and self.on_complete is not None and self.entries:
             self.on_complete()
 

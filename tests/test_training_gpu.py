@@ -415,3 +415,40 @@ def test_fused_main_pass_equals_modular_path(cuda):
         # later steps diverge chaotically from there, which is why the long run is compared through the loss
         d = (tab_m - tab_f).abs()
         assert (d <= 1e-5).float().mean().item() >= 0.9995
+
+
+def test_early_table_step_keeps_gradscaler_skip_semantics(cuda):
+    """The table optimizer launched from inside the backward (HashTableAdam.arm_early_step) still skips its group as a
+    whole when the scaled gradients overflow: tables, fused-MLP parameters and all moments untouched, the scale halves,
+    the step count does not advance; the next (finite) step goes through."""
+    from nersemble_amd.workloads import build_workload
+    torch.manual_seed(9)
+    trainer, data, _ = build_workload("p030_h16", device="cuda:0", small=True, n_rays=512)
+    model = trainer.model
+    he = model.field.hash_ensemble
+    trainer.train_iteration(0, *data.next_train(0))                     # a normal step first (moments exist)
+    trainer.flush_scheduler_step()
+    he.wait_tables()
+    opt = trainer.optimizers["fields/tables"]
+    before = {"tables": he.tables.detach().clone(), "f16": he.half_tables().clone(),
+              "m": opt.state[he.tables]["exp_avg"].clone(), "base": model.field.mlp_base.params.detach().clone(),
+              "deform": model.deformation_field.se3_field.mlp_stem.layers[0].weight.detach().clone()}
+    trainer.grad_scaler._scale.fill_(2.0 ** 60)                          # every fp16 gradient overflows
+    armed = []
+    orig = opt._early_step
+    opt._early_step = lambda: (orig(), armed.append(opt.stepped_early))[0]
+    trainer.train_iteration(1, *data.next_train(1))
+    trainer.flush_scheduler_step()
+    he.wait_tables()
+    assert armed == [True]                                               # the early path was taken ...
+    assert torch.equal(he.tables, before["tables"]) and torch.equal(he.half_tables(), before["f16"])   # ... and skipped
+    assert torch.equal(opt.state[he.tables]["exp_avg"], before["m"])
+    assert torch.equal(model.field.mlp_base.params, before["base"])
+    assert opt.state[he.tables]["step"] == 1 and trainer.optimizers["fields"].step_count == 1
+    assert trainer.grad_scaler.get_scale() == 2.0 ** 59
+    trainer.grad_scaler._scale.fill_(65536.0)
+    trainer.train_iteration(2, *data.next_train(2))
+    trainer.flush_scheduler_step()
+    he.wait_tables()
+    assert not torch.equal(he.tables, before["tables"]) and opt.state[he.tables]["step"] == 2
+    assert not torch.equal(model.field.mlp_base.params, before["base"])
