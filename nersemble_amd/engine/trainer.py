@@ -64,10 +64,14 @@ class NeRSembleTrainer:
                  mixed_precision: bool = True, world_size: int = 1, factored_table_grad: Optional[bool] = None,
                  rank: Optional[int] = None, sharded_table_adam: Optional[bool] = None,
                  overlap_table_adam: bool = True, calibrate_table_placement: bool = True,
-                 global_loss_normalisers: bool = False):
+                 global_loss_normalisers: bool = False, early_table_step: bool = False):
         """``global_loss_normalisers``: the ranks hold consecutive slices of ONE ray batch (strong scaling)
         -- loss denominators are made global so that the step equals the single-process step on the union batch."""
         self.model = model
+        # start the table optimizer from inside the backward (HashTableAdam.arm_early_step).  OFF by default: measured
+        # slower (8.8 vs 8.3 ms per step early in training, 4.85 vs 4.25 ms in steady state) -- the 12 GB pass next to
+        # the deformation backward triples the latter (both are HBM-bound) and crowds the step's tail off the CUs
+        self.early_table_step = early_table_step
         self.cfg = opt_cfg or OptimizerConfig()
         self.mixed_precision = mixed_precision
         self.world_size = world_size
@@ -140,8 +144,8 @@ class NeRSembleTrainer:
         arm_early_step).  Returns (found_all, inv_scale) for ``_optimizer_step_all`` or None."""
         key = self.group_of_tables()
         opt = self.optimizers.get(key) if key else None
-        if self.world_size != 1 or not isinstance(opt, HashTableAdam) or opt.he.grad_sink is None \
-                or self._opt_stream is None:
+        if not self.early_table_step or self.world_size != 1 or not isinstance(opt, HashTableAdam) \
+                or opt.he.grad_sink is None or self._opt_stream is None:
             return None
         self.flush_scheduler_step()        # the learning rates of this step depend on the previous step's outcome
         inv_scale = self.grad_scaler.inv_scale()

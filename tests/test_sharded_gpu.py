@@ -291,9 +291,9 @@ def test_two_ranks_on_half_batches_equal_one_process_on_the_union_batch(cuda, tm
         for name in set(a["grads"]) - set(grads):
             assert a["grads"][name].abs().max().item() == 0.0, (mode, name)
         for name, g_ref in grads.items():
+            # (absolute floor: at initialisation the deformation gradients sit at the fp16 underflow threshold of the
+            # chain's dZ -- the ranks' per-sample upstream gradients are world x larger, so a value that flushes to zero in
+            # the single process can survive, ~1e-13, on the ranks)
             sc = g_ref.abs().max().item()
-            if sc == 0.0:
-                assert a["grads"][name].abs().max().item() == 0.0, (mode, name)
-                continue
             err = (a["grads"][name] - g_ref).abs().max().item()
-            assert err <= 2e-3 * sc, (mode, name, err / sc)
+            assert err <= 2e-3 * sc + 1e-9, (mode, name, err, sc)

@@ -424,6 +424,7 @@ def test_early_table_step_keeps_gradscaler_skip_semantics(cuda):
     from nersemble_amd.workloads import build_workload
     torch.manual_seed(9)
     trainer, data, _ = build_workload("p030_h16", device="cuda:0", small=True, n_rays=512)
+    trainer.early_table_step = True                                      # opt-in (measured slower, see the trainer)
     model = trainer.model
     he = model.field.hash_ensemble
     trainer.train_iteration(0, *data.next_train(0))                     # a normal step first (moments exist)
