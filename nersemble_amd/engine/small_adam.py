@@ -70,9 +70,12 @@ def _table(optimizers: Sequence[SmallGroupAdam], group_of: Sequence[int]):
             if g is not None and not g.is_contiguous():
                 p.grad = g = g.contiguous()
             m, v = opt._moments(p)
+            if not (p.is_cuda and p.is_contiguous()):
+                raise RuntimeError("SmallGroupAdam: contiguous device parameters only")
             r = refs[n]
-            r.param, r.exp_avg, r.exp_avg_sq = ptr(p.data).value, ptr(m).value, ptr(v).value
-            r.grad = ptr(g).value if g is not None else None
+            # raw pointers without a dispatch per tensor (Tensor.data / detach() are torch ops)
+            r.param, r.exp_avg, r.exp_avg_sq = p.data_ptr(), m.data_ptr(), v.data_ptr()
+            r.grad = g.data_ptr() if g is not None else None
             r.n, r.group = p.numel(), grp
             n += 1
     return refs, n

@@ -423,12 +423,11 @@ def deform_pack(flat_params: torch.Tensor) -> torch.Tensor:
 def deform_pack_tensors(params16) -> torch.Tensor:
     """As ``deform_pack`` but straight from the 16 parameter tensors (include/nsx.h order), without concatenating."""
     assert len(params16) == 16
-    tensors = [p.detach() for p in params16]
-    for t in tensors:
-        if t.dtype != torch.float32 or not t.is_contiguous():
+    for t in params16:
+        if t.dtype != torch.float32 or not t.is_contiguous() or not t.is_cuda:
             return deform_pack(torch.cat([p.detach().float().reshape(-1) for p in params16]))
-    packed = torch.empty(_deform_pack_bytes(), dtype=torch.uint8, device=tensors[0].device)
-    arr = (C.c_void_p * 16)(*[ptr(t).value for t in tensors])
+    packed = torch.empty(_deform_pack_bytes(), dtype=torch.uint8, device=params16[0].device)
+    arr = (C.c_void_p * 16)(*[t.data_ptr() for t in params16])
     check(lib().nsx_deform_pack_tensors(arr, ptr(packed), stream()), "nsx_deform_pack_tensors")
     return packed
 
@@ -567,11 +566,16 @@ def gather_rows(index: torch.Tensor, *tensors: torch.Tensor):
     """[t[index] for t in tensors] (rows along dim 0) in one native launch; no autograd (values only)."""
     idx = index.to(torch.int64).contiguous()
     n = idx.shape[0]
-    srcs = [t.detach().contiguous() for t in tensors]
+    srcs = [(t.detach() if t.requires_grad else t).contiguous() for t in tensors]
     outs = [torch.empty((n,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device) for t in srcs]
     k = len(srcs)
     if n > 0 and k > 0:
-        rb = [t[0].numel() * t.element_size() if t.shape[0] > 0 else 4 for t in srcs]
+        rb = []
+        for t in srcs:                                   # bytes per row (no tensor op: shapes only)
+            row = t.element_size()
+            for d in t.shape[1:]:
+                row *= int(d)
+            rb.append(row)
         if any(b % 4 for b in rb) or k > _lib.NSX_MAX_GATHER:
             return tuple(t.index_select(0, idx) for t in srcs)
         src_arr = (C.c_void_p * k)(*[t.data_ptr() for t in srcs])
