@@ -588,10 +588,103 @@ def gen_dataformat(out):
     out["nq_in"], out["nq_codes"], out["nq_decoded"] = normals, ncodes, nq.decode(ncodes)
 
 
+def gen_config_yml(path):
+    """A run's ``config.yml`` as the reference writes it (``model_manager/base.py:44-46``: ``yaml.dump(config)`` of the
+    ``NeRSembleTrainerConfig`` built in ``scripts/train/train_nersemble.py:146-262``).  The config CLASSES live in packages
+    that are not installed (nerfstudio) or import them (nersemble.nerfstudio.*), so the objects dumped here are instances of
+    dynamically created classes that carry the reference's module paths and class names -- PyYAML's dumper only writes
+    ``cls.__module__ + "." + cls.__name__`` -- and the reference's own FIELD NAMES and DEFAULTS, read from its source files
+    with ``ast`` (no import); nerfstudio's inherited fields are the ones SURVEY.md A.3 lists.  Values as in
+    ``train_nersemble.py`` for participant 30 with 16 hash grids."""
+    import ast
+    import pathlib
+    import yaml
+    ref = pathlib.Path("/root/reference/src/nersemble")
+
+    def fields_of(rel, cls_name):
+        tree = ast.parse((ref / rel).read_text())
+        out = {}
+        for node in ast.walk(tree):
+            if isinstance(node, ast.ClassDef) and node.name == cls_name:
+                for st in node.body:
+                    if isinstance(st, ast.AnnAssign) and isinstance(st.target, ast.Name) and st.value is not None:
+                        try:
+                            out[st.target.id] = ast.literal_eval(st.value)
+                        except Exception:
+                            out[st.target.id] = None
+        return out
+
+    def make(module, name, **values):
+        cls = type(name, (), {"__module__": module})
+        obj = cls()
+        obj.__dict__.update(values)
+        return obj
+
+    def cls_ref(module, name):
+        return type(name, (), {"__module__": module})
+
+    enc = make("nersemble.nerfstudio.field_components.hash_ensemble", "TCNNHashEncodingConfig",
+               **fields_of("nerfstudio/field_components/hash_ensemble.py", "TCNNHashEncodingConfig"))
+    he_f = fields_of("nerfstudio/field_components/hash_ensemble.py", "HashEnsembleConfig")
+    he_f.update(n_hash_encodings=16, hash_encoding_config=enc, disable_initial_hash_ensemble=True, use_soft_transition=True)
+    he = make("nersemble.nerfstudio.field_components.hash_ensemble", "HashEnsembleConfig", **he_f)
+    df_f = fields_of("nerfstudio/field_components/deformation_field.py", "SE3DeformationFieldConfig")
+    df_f.update(warp_code_dim=128, mlp_num_layers=6, mlp_layer_width=128)
+    df = make("nersemble.nerfstudio.field_components.deformation_field", "SE3DeformationFieldConfig", **df_f)
+    model_f = {  # nerfstudio 0.3.1 ModelConfig + InstantNGPModelConfig (UPSTREAM, SURVEY.md A.3)
+        "_target": cls_ref("nersemble.nerfstudio.models.nersemble_instant_ngp", "NeRSembleNGPModel"),
+        "enable_collider": False, "collider_params": None, "loss_coefficients": {"rgb_loss_coarse": 1.0, "rgb_loss_fine": 1.0},
+        "eval_num_rays_per_chunk": 4096, "grid_resolution": 128, "grid_levels": 1, "max_res": 2048,
+        "log2_hashmap_size": 19, "alpha_thre": 0.01, "cone_angle": 0.0, "render_step_size": 0.011, "near_plane": 0.2,
+        "far_plane": 1000.0, "use_appearance_embedding": False, "background_color": "white",
+        "disable_scene_contraction": True}
+    model_f.update(fields_of("nerfstudio/models/base.py", "BaseModelConfig"))
+    own = fields_of("nerfstudio/models/nersemble_instant_ngp.py", "NeRSembleNGPModelConfig")
+    own.pop("_target", None)
+    model_f.update(own)
+    model_f.update(early_stop_eps=0, occ_thre=0.01, max_n_samples_per_batch=2 ** 20, n_timesteps=100, latent_dim_time=16,
+                   use_masked_rgb_loss=True, alpha_mask_threshold=0, lambda_alpha_loss=1e-2, lambda_near_loss=1e-4,
+                   lambda_empty_loss=1e-2, lambda_depth_loss=1e-4, lambda_dist_loss=1e-4, use_hash_ensemble=True,
+                   hash_ensemble_config=he, use_deformation_field=True, use_separate_deformation_time_embedding=True,
+                   deformation_field_config=df, disable_occupancy_grid=False, window_hash_encodings_begin=40000,
+                   window_hash_encodings_end=80000, window_deform_begin=0, window_deform_end=20000,
+                   use_view_frustum_culling=False, view_frustum_culling=2)
+    model = make("nersemble.nerfstudio.models.nersemble_instant_ngp", "NeRSembleNGPModelConfig", **model_f)
+    dataparser = make("nersemble.nerfstudio.dataparser.nersemble_dataparser", "NeRSembleDataParserConfig",
+                      _target=cls_ref("nersemble.nerfstudio.dataparser.nersemble_dataparser", "NeRSembleDataParser"),
+                      participant_id=30, sequence_name="EXP-2-eyes", start_timestep=0, n_timesteps=100, skip_timesteps=3,
+                      scale_factor=9, scene_box=torch.tensor([[-2.5, -1.8, -2.5], [2.2, 1.8, 2.0]]))
+    datamanager = make("nersemble.nerfstudio.datamanager.nersemble_datamanager", "NeRSembleVanillaDataManagerConfig",
+                       _target=cls_ref("nersemble.nerfstudio.datamanager.nersemble_datamanager", "NeRSembleVanillaDataManager"),
+                       dataparser=dataparser, train_num_rays_per_batch=4096, eval_num_rays_per_batch=1024,
+                       train_num_images_to_sample_from=24, train_num_times_to_repeat_images=20,
+                       eval_num_images_to_sample_from=36, use_cache_compression=False, max_cached_items=10000)
+    pipeline = make("nerfstudio.pipelines.base_pipeline", "VanillaPipelineConfig",
+                    _target=cls_ref("nerfstudio.pipelines.base_pipeline", "VanillaPipeline"), datamanager=datamanager,
+                    model=model)
+
+    def opt(lr, gamma):
+        return {"optimizer": make("nerfstudio.engine.optimizers", "AdamOptimizerConfig",
+                                  _target=torch.optim.Adam, lr=lr, eps=1e-15, max_norm=None, weight_decay=0),
+                "scheduler": make("nersemble.nerfstudio.engine.step_lr_scheduler", "StepLRSchedulerConfig",
+                                  step_size=20000, gamma=gamma)}
+
+    config = make("nersemble.nerfstudio.config.nersemble_trainer_config", "NeRSembleTrainerConfig",
+                  _target=cls_ref("nersemble.nerfstudio.engine.nersemble_trainer", "NeRSembleTrainer"),
+                  output_dir=pathlib.PosixPath("/models/nersemble"), method_name="nersemble", experiment_name="NERS-9999",
+                  project_name="nersemble", run_name="NERS-9999", relative_model_dir=pathlib.PosixPath("checkpoints/"),
+                  steps_per_save=50000, steps_per_eval_batch=500, steps_per_eval_image=500,
+                  steps_per_eval_all_images=50000, max_num_iterations=300001, mixed_precision=True,
+                  save_only_latest_checkpoint=True, load_dir=None, load_step=None, log_gradients=False, vis="wandb",
+                  pipeline=pipeline,
+                  optimizers={"fields": opt(5e-3, 0.8), "deformation_field": opt(1e-3, 0.5), "embeddings": opt(5e-3, 0.8)})
+    pathlib.Path(path).write_text(yaml.dump(config))
+
+
 def main():
     """python tests/golden/make_golden.py [hash_ensemble] [deformation] [deformation_full] [misc] [occupancy_filter] [pixel_sampler] [dataformat]   (default: all)"""
     torch.set_num_threads(4)
-    which = set(sys.argv[1:]) or {"hash_ensemble", "deformation", "deformation_full", "misc", "occupancy_filter", "pixel_sampler", "dataformat"}
+    which = set(sys.argv[1:]) or {"hash_ensemble", "deformation", "deformation_full", "config_yml", "misc", "occupancy_filter", "pixel_sampler", "dataformat"}
     written = []
     if "hash_ensemble" in which:
         a = {}
@@ -630,6 +723,9 @@ def main():
         gen_dataformat(f_)
         np.savez_compressed(os.path.join(HERE, "dataformat.npz"), **f_)
         written.append("dataformat.npz")
+    if "config_yml" in which:
+        gen_config_yml(os.path.join(HERE, "config.yml"))
+        written.append("config.yml")
     for f in written:
         print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")
 

@@ -46,3 +46,66 @@ def test_rejects_foreign_files():
     with pytest.raises(KeyError):
         load_nerfstudio_checkpoint({"pipeline": {"datamanager.x": torch.zeros(1)}}, torch.nn.Linear(1, 1))
     assert model_state_from_pipeline({"_model.a": 1, "module._model.b": 2, "other": 3}) == {"a": 1, "b": 2}
+
+
+def test_run_folder_config_yml_and_checkpoint_lookup(tmp_path, golden_dir):
+    """SURVEY 8 f3 -- a run as the reference stores it: ``config.yml`` (yaml.dump of the trainer config: python-object tags
+    of nerfstudio / nersemble classes that are not installed here, a pickled torch scene box, PosixPaths) next to
+    ``checkpoints/step-*.ckpt``.  ``nersemble_eval_setup`` (util/setup.py:14-71 in the reference) reads the config without
+    those packages, builds the model from ``pipeline.model``, picks the newest checkpoint and loads it.
+    The fixture is produced by tests/golden/make_golden.py::gen_config_yml from the reference's own field names."""
+    import torch
+    from nersemble_amd.models.nersemble_instant_ngp import NeRSembleNGPModel
+    from nersemble_amd.rays import SceneBox
+    from nersemble_amd.util.checkpoint import nerfstudio_checkpoint_from_model
+    from nersemble_amd.util.setup import (find_checkpoint, model_config_from_nerfstudio, nersemble_eval_setup,
+                                          try_load_config)
+    cfg_path = f"{golden_dir}/config.yml"
+    config = try_load_config(cfg_path)
+    assert type(config).__name__ == "NeRSembleTrainerConfig" and config.run_name == "NERS-9999"
+    assert config.pipeline.datamanager.dataparser.participant_id == 30
+    assert torch.equal(config.pipeline.datamanager.dataparser.scene_box,
+                       torch.tensor([[-2.5, -1.8, -2.5], [2.2, 1.8, 2.0]]))
+    assert str(config.relative_model_dir) == "checkpoints" and config.optimizers["deformation_field"]["optimizer"].lr == 1e-3
+    model_cfg, unknown = model_config_from_nerfstudio(config.pipeline.model)
+    # every field of the reference's model config has a place here; what is reported belongs to nerfstudio's collider /
+    # loss-coefficient plumbing, which the path does not use
+    assert sorted(unknown) == ["model.collider_params", "model.enable_collider", "model.loss_coefficients"]
+    assert model_cfg.n_timesteps == 100 and model_cfg.latent_dim_time == 16 and model_cfg.max_n_samples_per_batch == 2 ** 20
+    assert model_cfg.hash_ensemble_config.n_hash_encodings == 16
+    assert model_cfg.hash_ensemble_config.hash_encoding_config.log2_hashmap_size == 19
+    assert model_cfg.deformation_field_config.warp_code_dim == 128 and model_cfg.deformation_field_config.skip_connections == (4,)
+    assert model_cfg.window_hash_encodings_end == 80000 and model_cfg.lambda_dist_loss == 1e-4
+
+    # a small twin of that run (2^12-entry tables keep the CPU test quick): write two checkpoints, load the newest.
+    # The loaded config dumps back to the tags it was read from (what the reference's save_config does with the real classes)
+    config.pipeline.model.hash_ensemble_config.hash_encoding_config.log2_hashmap_size = 12
+    import yaml
+    run = tmp_path / "NERS-9999"
+    (run / "checkpoints").mkdir(parents=True)
+    text = yaml.dump(config)
+    assert "!!python/object:nersemble.nerfstudio.models.nersemble_instant_ngp.NeRSembleNGPModelConfig" in text
+    (run / "config.yml").write_text(text)
+    small_cfg, _ = model_config_from_nerfstudio(config.pipeline.model)
+    torch.manual_seed(0)
+    src = NeRSembleNGPModel(small_cfg, SceneBox(config.pipeline.datamanager.dataparser.scene_box), num_train_data=1)
+    torch.save(nerfstudio_checkpoint_from_model(src, 50000), run / "checkpoints" / "step-000050000.ckpt")
+    with torch.no_grad():
+        src.time_embedding.weight.add_(1.0)
+        src.field.hash_ensemble.tables.mul_(3.0)
+    torch.save(nerfstudio_checkpoint_from_model(src, 300000), run / "checkpoints" / "step-000300000.ckpt")
+    assert find_checkpoint(run / "checkpoints")[1] == 300000 and find_checkpoint(run / "checkpoints", 50000)[1] == 50000
+    loaded_cfg, model, path, step = nersemble_eval_setup(run / "config.yml", run / "checkpoints", eval_num_rays_per_chunk=2048,
+                                                          device="cpu")
+    assert step == 300000 and path.name == "step-000300000.ckpt" and not model.training
+    assert model.config.eval_num_rays_per_chunk == 2048
+    want = src.state_dict()
+    got = model.state_dict()
+    assert set(got) == set(want)
+    for k in want:
+        assert torch.equal(got[k], want[k]), k
+    older = nersemble_eval_setup(run / "config.yml", run / "checkpoints", checkpoint=50000, device="cpu")[1]
+    assert not torch.equal(older.time_embedding.weight, model.time_embedding.weight)
+    import pytest
+    with pytest.raises(FileNotFoundError):
+        find_checkpoint(run / "checkpoints", 123)
