@@ -55,6 +55,16 @@ const char* nsx_last_error(void);
 int nsx_grid_geometry(int n_levels, float per_level_scale, int base_resolution,
                       int log2_hashmap_size, nsx_grid_geom* out);
 
+/* Device-side element counts.  The number of samples a step keeps after visibility pruning is known on the device long
+ * before the host could read it back; between nsx_device_count_begin(n_device, capacity) and nsx_device_count_end() every
+ * per-sample entry point of this library that is called with a sample count EQUAL TO `capacity` (buffers are allocated
+ * for `capacity` rows) processes only the first *n_device rows -- *n_device is read by the kernels when they run, so the
+ * calls can be enqueued without a host synchronisation.  Applies to: nsx_sample_positions, nsx_normalise_bwd,
+ * nsx_density_fwd/bwd, nsx_gather_rows, nsx_hash_ensemble_fwd/bwd(_factored), nsx_mlp_fwd/bwd, nsx_deform_fwd/bwd,
+ * nsx_ray_histogram (per-ray entry points follow through packed_info).  Thread-local, not nestable; host-only state. */
+int nsx_device_count_begin(const int64_t* n_device, int64_t capacity);
+int nsx_device_count_end(void);
+
 /* Padded number of grids used by the interleaved layout (next power of two >= H; the reference's H is any value with
  * 2H <= 8 or 2H a multiple of 8, hash_ensemble.py:80-82). */
 int nsx_padded_grids(int H);

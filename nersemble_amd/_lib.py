@@ -54,6 +54,8 @@ SIGNATURES = {
     "nsx_last_error": (C.c_char_p, []),
     "nsx_grid_geometry": (c_int, [c_int, c_float, c_int, c_int, _GEOM_P]),
     "nsx_padded_grids": (c_int, [c_int]),
+    "nsx_device_count_begin": (c_int, [c_void_p, c_int64]),
+    "nsx_device_count_end": (c_int, []),
     "nsx_tables_from_tcnn": (c_int, [c_void_p, c_int, _GEOM_P, c_void_p, c_void_p, c_void_p]),
     "nsx_tables_to_tcnn": (c_int, [c_void_p, c_int, _GEOM_P, c_void_p, c_void_p]),
     "nsx_hash_ensemble_fwd": (c_int, [c_void_p, c_int64, c_void_p, c_int, _GEOM_P, c_void_p, c_int64, c_void_p,
@@ -217,6 +219,27 @@ def lib():
             fn.argtypes = args
         _lib = _LibProxy(handle)
     return _lib
+
+
+class device_count:
+    """``with device_count(n_dev, capacity): ...`` -- native per-sample calls made with a sample count equal to
+    ``capacity`` process only the first ``n_dev[0]`` rows (include/nsx.h, nsx_device_count_begin).  ``n_dev``: int64 device
+    tensor with one element, or None (then the block runs unchanged)."""
+
+    def __init__(self, n_dev, capacity: int):
+        self.n_dev, self.capacity = n_dev, int(capacity)
+
+    def __enter__(self):
+        if self.n_dev is not None:
+            if self.n_dev.dtype != torch.int64 or self.n_dev.numel() != 1:
+                raise RuntimeError("device_count: n_dev must be one int64 on the device")
+            check(lib().nsx_device_count_begin(ptr(self.n_dev), self.capacity), "nsx_device_count_begin")
+        return self
+
+    def __exit__(self, *exc):
+        if self.n_dev is not None:
+            lib().nsx_device_count_end()
+        return False
 
 
 def check(rc: int, what: str = "") -> None:

@@ -510,7 +510,9 @@ __device__ __forceinline__ void lds_prologue(const DeformArgs& A, DeformLds& L, 
     __syncthreads();
 }
 
-__global__ __launch_bounds__(NW * 64, 1) void deform_fwd_kernel(DeformArgs A, float* __restrict__ offsets, int64_t n_tiles) {
+__global__ __launch_bounds__(NW * 64, 1) void deform_fwd_kernel(DeformArgs A, float* __restrict__ offsets, int64_t n_tiles,
+                                                              const int64_t* __restrict__ n_dev) {
+    NSX_DEVICE_COUNT(A.S, n_tiles, 32, n_dev);
     __shared__ __attribute__((aligned(16))) DeformLds L;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int64_t n_groups = (n_tiles + NW - 1) / NW;
@@ -563,7 +565,9 @@ __device__ __forceinline__ void mask_pack(const f32x16 d[4], u32x2 mask, f16x8 d
 
 __global__ __launch_bounds__(NW * 64, 1) void deform_bwd_kernel(DeformArgs A, const float* __restrict__ goff,
                                                               half_t* __restrict__ scratch, int64_t n_tiles,
-                                                              float* __restrict__ gcode_samples) {
+                                                              float* __restrict__ gcode_samples,
+                                                              const int64_t* __restrict__ n_dev) {
+    NSX_DEVICE_COUNT(A.S, n_tiles, 32, n_dev);
     __shared__ __attribute__((aligned(16))) DeformLds L;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int n = lane & 31, kb = lane >> 5;
@@ -802,7 +806,9 @@ __device__ __forceinline__ void wg_store(const f32x16& acc, int job, int mt, int
 __global__ __launch_bounds__(NW * 64, 1) void deform_wgrad_kernel(const half_t* __restrict__ scratch, int64_t n_tiles,
                                                                  const int32_t* __restrict__ slot, int64_t S,
                                                                  float* __restrict__ grad_params,
-                                                                 float* __restrict__ grad_code, int n_code_rows) {
+                                                                 float* __restrict__ grad_code, int n_code_rows,
+                                                                 const int64_t* __restrict__ n_dev) {
+    NSX_DEVICE_COUNT(S, n_tiles, 32, n_dev);
     __shared__ __attribute__((aligned(16))) char ring[WG_NS * WG_PIECES * 1024];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int i = lane & 31, kb = lane >> 5;
@@ -952,7 +958,8 @@ int nsx_deform_fwd(const void* packed, const float* positions, int64_t S, const 
     const int64_t n_tiles = (S + 31) / 32;
     int64_t blocks = (n_tiles + NW - 1) / NW;
     if (blocks > num_cus()) blocks = num_cus();
-    hipLaunchKernelGGL(deform_fwd_kernel, dim3((unsigned)blocks), dim3(NW * 64), 0, (hipStream_t)stream, A, offsets, n_tiles);
+    hipLaunchKernelGGL(deform_fwd_kernel, dim3((unsigned)blocks), dim3(NW * 64), 0, (hipStream_t)stream, A, offsets, n_tiles,
+                       count_for(S));
     NSX_LAUNCH_CHECK("nsx_deform_fwd launch");
     return NSX_OK;
 }
@@ -976,7 +983,7 @@ int nsx_deform_bwd(const void* packed, const float* positions, int64_t S, const 
     hipStream_t st = (hipStream_t)stream;
     half_t* sc = reinterpret_cast<half_t*>(scratch);
     hipLaunchKernelGGL(deform_bwd_kernel, dim3((unsigned)blocks), dim3(NW * 64), 0, st, A, grad_offsets, sc, n_tiles,
-                       grad_code_samples);
+                       grad_code_samples, count_for(S));
     NSX_LAUNCH_CHECK("nsx_deform_bwd chain launch");
     // weight / bias / code-table gradients
     const int n_types = grad_code_table ? WG_TYPES : WG_TYPES - 1;
@@ -985,7 +992,7 @@ int nsx_deform_bwd(const void* packed, const float* positions, int64_t S, const 
     if (chunks > max_chunks) chunks = (int)max_chunks;
     if (chunks < 1) chunks = 1;
     hipLaunchKernelGGL(deform_wgrad_kernel, dim3(n_types, chunks), dim3(NW * 64), 0, st, sc, n_tiles, code_slot, S,
-                       grad_params, grad_code_table, grad_code_table ? n_code_rows : 0);
+                       grad_params, grad_code_table, grad_code_table ? n_code_rows : 0, count_for(S));
     NSX_LAUNCH_CHECK("nsx_deform_bwd wgrad launch");
     return NSX_OK;
 }

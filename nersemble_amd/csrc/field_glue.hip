@@ -18,7 +18,10 @@ struct Box { float lo[3], ext[3]; };
 __global__ __launch_bounds__(256) void sample_positions_kernel(
     const float* __restrict__ o, const float* __restrict__ d, const int64_t* __restrict__ ray_idx,
     const float* __restrict__ t0, const float* __restrict__ t1, const float* __restrict__ off, int64_t S, Box box,
-    float* __restrict__ pos_world, float* __restrict__ pos_n, uint8_t* __restrict__ sel) {
+    float* __restrict__ pos_world, float* __restrict__ pos_n, uint8_t* __restrict__ sel,
+    const int64_t* __restrict__ n_dev) {
+    int64_t unused_tiles = 0;
+    NSX_DEVICE_COUNT(S, unused_tiles, 1, n_dev);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < S; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t r = ray_idx ? ray_idx[i] : i;
         const float tt = t0 ? (t0[i] + t1[i]) : 0.f;
@@ -47,7 +50,10 @@ __global__ __launch_bounds__(256) void sample_positions_kernel(
 
 // d pos = g * sel / ext
 __global__ __launch_bounds__(256) void normalise_bwd_kernel(const float* __restrict__ g, const uint8_t* __restrict__ sel,
-                                                            int64_t S, Box box, float* __restrict__ dpos) {
+                                                            int64_t S, Box box, float* __restrict__ dpos,
+                                                            const int64_t* __restrict__ n_dev) {
+    int64_t unused_tiles = 0;
+    NSX_DEVICE_COUNT(S, unused_tiles, 1, n_dev);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < S; i += (int64_t)gridDim.x * blockDim.x) {
         const float m = sel[i] ? 1.0f : 0.0f;
 #pragma unroll
@@ -58,7 +64,9 @@ __global__ __launch_bounds__(256) void normalise_bwd_kernel(const float* __restr
 // density = exp(float(h0)) * sel
 __global__ __launch_bounds__(256) void density_fwd_kernel(const half_t* __restrict__ base, int64_t stride,
                                                           const uint8_t* __restrict__ sel, int64_t S,
-                                                          float* __restrict__ density) {
+                                                          float* __restrict__ density, const int64_t* __restrict__ n_dev) {
+    int64_t unused_tiles = 0;
+    NSX_DEVICE_COUNT(S, unused_tiles, 1, n_dev);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < S; i += (int64_t)gridDim.x * blockDim.x)
         density[i] = expf((float)base[i * stride]) * (sel[i] ? 1.0f : 0.0f);
 }
@@ -66,7 +74,10 @@ __global__ __launch_bounds__(256) void density_fwd_kernel(const half_t* __restri
 // trunc_exp backward: d h0 = g * sel * exp(clamp(h0, -15, 15)), written as fp16 into column 0 of a zeroed [S][stride]
 __global__ __launch_bounds__(256) void density_bwd_kernel(const half_t* __restrict__ base, int64_t stride,
                                                           const uint8_t* __restrict__ sel, const float* __restrict__ g,
-                                                          int64_t S, half_t* __restrict__ dbase) {
+                                                          int64_t S, half_t* __restrict__ dbase,
+                                                          const int64_t* __restrict__ n_dev) {
+    int64_t unused_tiles = 0;
+    NSX_DEVICE_COUNT(S, unused_tiles, 1, n_dev);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < S; i += (int64_t)gridDim.x * blockDim.x) {
         const float h = (float)base[i * stride];
         const float gd = g[i] * (sel[i] ? 1.0f : 0.0f);
@@ -84,7 +95,10 @@ struct GatherArgs {
     int n_arrays;
 };
 
-__global__ __launch_bounds__(256) void gather_rows_kernel(GatherArgs A, const int64_t* __restrict__ index, int64_t n) {
+__global__ __launch_bounds__(256) void gather_rows_kernel(GatherArgs A, const int64_t* __restrict__ index, int64_t n,
+                                                          const int64_t* __restrict__ n_dev) {
+    int64_t unused_tiles = 0;
+    NSX_DEVICE_COUNT(n, unused_tiles, 1, n_dev);
     const int a = blockIdx.y;
     const int64_t words = A.words[a];
     const int64_t total = n * words;
@@ -134,7 +148,8 @@ int nsx_sample_positions(const float* origins, const float* directions, const in
     NSX_REQUIRE(pos_world || pos_normalised, "nsx_sample_positions: no output requested");
     NSX_REQUIRE(!pos_normalised || aabb_host, "nsx_sample_positions: aabb required for normalised positions");
     hipLaunchKernelGGL(sample_positions_kernel, dim3(grid_for(S)), dim3(256), 0, (hipStream_t)stream, origins, directions,
-                       ray_indices, t_starts, t_ends, offsets, S, make_box(aabb_host), pos_world, pos_normalised, selector);
+                       ray_indices, t_starts, t_ends, offsets, S, make_box(aabb_host), pos_world, pos_normalised, selector,
+                       count_for(S));
     NSX_LAUNCH_CHECK("nsx_sample_positions launch");
     return NSX_OK;
 }
@@ -161,7 +176,8 @@ int nsx_gather_rows(int n_arrays, const void* const* srcs, const int64_t* row_by
         A.words[a] = (int)(row_bytes[a] / (vec ? 16 : 4));
         if (n * A.words[a] > max_pieces) max_pieces = n * A.words[a];
     }
-    hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for(max_pieces), n_arrays), dim3(256), 0, (hipStream_t)stream, A, index, n);
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for(max_pieces), n_arrays), dim3(256), 0, (hipStream_t)stream, A, index, n,
+                       count_for(n));
     NSX_LAUNCH_CHECK("nsx_gather_rows launch");
     return NSX_OK;
 }
@@ -172,7 +188,7 @@ int nsx_normalise_bwd(const float* grad_pos_normalised, const uint8_t* selector,
     if (S == 0) return NSX_OK;
     NSX_REQUIRE(grad_pos_normalised && selector && aabb_host && grad_pos_world, "nsx_normalise_bwd: NULL argument");
     hipLaunchKernelGGL(normalise_bwd_kernel, dim3(grid_for(S)), dim3(256), 0, (hipStream_t)stream, grad_pos_normalised,
-                       selector, S, make_box(aabb_host), grad_pos_world);
+                       selector, S, make_box(aabb_host), grad_pos_world, count_for(S));
     NSX_LAUNCH_CHECK("nsx_normalise_bwd launch");
     return NSX_OK;
 }
@@ -183,7 +199,7 @@ int nsx_density_fwd(const nsx_half* base_out, int64_t stride, const uint8_t* sel
     if (S == 0) return NSX_OK;
     NSX_REQUIRE(base_out && selector && density, "nsx_density_fwd: NULL argument");
     hipLaunchKernelGGL(density_fwd_kernel, dim3(grid_for(S)), dim3(256), 0, (hipStream_t)stream,
-                       reinterpret_cast<const half_t*>(base_out), stride, selector, S, density);
+                       reinterpret_cast<const half_t*>(base_out), stride, selector, S, density, count_for(S));
     NSX_LAUNCH_CHECK("nsx_density_fwd launch");
     return NSX_OK;
 }
@@ -195,7 +211,7 @@ int nsx_density_bwd(const nsx_half* base_out, int64_t stride, const uint8_t* sel
     NSX_REQUIRE(base_out && selector && grad_density && grad_base_out_zeroed, "nsx_density_bwd: NULL argument");
     hipLaunchKernelGGL(density_bwd_kernel, dim3(grid_for(S)), dim3(256), 0, (hipStream_t)stream,
                        reinterpret_cast<const half_t*>(base_out), stride, selector, grad_density, S,
-                       reinterpret_cast<half_t*>(grad_base_out_zeroed));
+                       reinterpret_cast<half_t*>(grad_base_out_zeroed), count_for(S));
     NSX_LAUNCH_CHECK("nsx_density_bwd launch");
     return NSX_OK;
 }

@@ -128,8 +128,10 @@ template <int H, int WAVES>
 __global__ __launch_bounds__(WAVES * kWave) void ens_fwd_kernel(
     const float* __restrict__ x, int64_t B, const uint8_t* __restrict__ tab, const nsx_grid_geom g,
     const float* __restrict__ code, int64_t code_stride, const int32_t* __restrict__ code_index,
-    const float* __restrict__ window, int Hreal, uint32_t* __restrict__ out, int64_t n_tiles) {
+    const float* __restrict__ window, int Hreal, uint32_t* __restrict__ out, int64_t n_tiles,
+    const int64_t* __restrict__ n_dev) {
     using C = EnsCfg<H>;
+    NSX_DEVICE_COUNT(B, n_tiles, C::SPW, n_dev);
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];   // [WAVES][SPW][L + 4] dwords
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x / kWave;
@@ -249,8 +251,9 @@ __global__ __launch_bounds__(WAVES * kWave) void ens_bwd_kernel(
     const float* __restrict__ code, int64_t code_stride, const int32_t* __restrict__ code_index,
     const float* __restrict__ window, int Hreal, const float* __restrict__ dout,
     float* __restrict__ dtab, float* __restrict__ dcode, float* __restrict__ dx, int64_t n_tiles,
-    int n_slots, float* __restrict__ nonfinite) {
+    int n_slots, float* __restrict__ nonfinite, const int64_t* __restrict__ n_dev) {
     using C = EnsCfg<H>;
+    NSX_DEVICE_COUNT(B, n_tiles, C::SPW, n_dev);
     bool bad = false;                 // a non-finite value was added to the factored gradient
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x / kWave;
@@ -636,7 +639,7 @@ static int launch_fwd(const float* x, int64_t B, const nsx_half* tables, int Hre
     const size_t smem = (size_t)WAVES * C::SPW * (g->n_levels + 4) * sizeof(uint32_t);
     hipLaunchKernelGGL((ens_fwd_kernel<H, WAVES>), dim3((unsigned)blocks), dim3(WAVES * kWave), smem, st, x, B,
                        reinterpret_cast<const uint8_t*>(tables), *g, code, code_stride, code_index, window, Hreal,
-                       reinterpret_cast<uint32_t*>(out), n_tiles);
+                       reinterpret_cast<uint32_t*>(out), n_tiles, count_for(B));
     NSX_LAUNCH_CHECK("nsx_hash_ensemble_fwd launch");
     return NSX_OK;
 }
@@ -655,7 +658,7 @@ static int launch_bwd(const float* x, int64_t B, const nsx_half* tables, int Hre
 #define NSX_BWD_LAUNCH(MODE, DC, NS, NF)                                                                            \
     hipLaunchKernelGGL((ens_bwd_kernel<H, WAVES, MODE, DC>), dim3((unsigned)blocks), dim3(WAVES * kWave), 0, st, x, B, \
                        reinterpret_cast<const uint8_t*>(tables), *g, code, code_stride, code_index, window, Hreal,    \
-                       dout, dtables, dcode, dx, n_tiles, NS, NF)
+                       dout, dtables, dcode, dx, n_tiles, NS, NF, count_for(B))
     if (n_slots > 0 && dtables) {
         if (dcode) NSX_BWD_LAUNCH(BWD_FACTORED, true, n_slots, nonfinite);
         else NSX_BWD_LAUNCH(BWD_FACTORED, false, n_slots, nonfinite);

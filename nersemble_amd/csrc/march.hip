@@ -252,7 +252,10 @@ __global__ __launch_bounds__(1024) void pack_info_kernel(const int64_t* __restri
 // counts per ray (nerfacc.pack_info).  Ray indices arrive sorted, ~200 samples per ray: each wave merges its runs of
 // equal indices and issues ONE atomic per run (correct for unsorted input too, which merely merges less).
 __global__ __launch_bounds__(256) void ray_hist_kernel(const int64_t* __restrict__ ray_idx, int64_t S, int64_t R,
-                                                       unsigned long long* __restrict__ counts) {
+                                                       unsigned long long* __restrict__ counts,
+                                                       const int64_t* __restrict__ n_dev) {
+    int64_t unused_tiles = 0;
+    NSX_DEVICE_COUNT(S, unused_tiles, 1, n_dev);
     const int lane = threadIdx.x & 63;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t base = (int64_t)blockIdx.x * blockDim.x + (threadIdx.x - lane); base < S; base += stride) {
@@ -331,7 +334,7 @@ int nsx_ray_histogram(const int64_t* ray_indices, int64_t S, int64_t R, int64_t*
     int64_t blocks = (S + 255) / 256;
     if (blocks > num_cus() * 8) blocks = num_cus() * 8;
     hipLaunchKernelGGL(ray_hist_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, ray_indices, S, R,
-                       reinterpret_cast<unsigned long long*>(counts_zeroed));
+                       reinterpret_cast<unsigned long long*>(counts_zeroed), count_for(S));
     NSX_LAUNCH_CHECK("nsx_ray_histogram launch");
     return NSX_OK;
 }

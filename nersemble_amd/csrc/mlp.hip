@@ -192,7 +192,9 @@ __device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + __ex
 template <int NH>
 __global__ __launch_bounds__(MLP_WAVES * kWave) void mlp_fwd_kernel(const half_t* __restrict__ W, MlpIO io, int64_t B,
                                                                    int n_out, int out_act, half_t* __restrict__ out,
-                                                                   int64_t out_stride, int64_t n_tiles) {
+                                                                   int64_t out_stride, int64_t n_tiles,
+                                                                   const int64_t* __restrict__ n_dev) {
+    NSX_DEVICE_COUNT(B, n_tiles, 32, n_dev);
     extern __shared__ __attribute__((aligned(16))) uint8_t smem_raw[];
     f16x8* frags = reinterpret_cast<f16x8*>(smem_raw);
     stage_weights<NH>(W, MLP_IN, frags, false);
@@ -247,7 +249,9 @@ __device__ __forceinline__ void wave_lds_sync() {
 template <int NH>
 __global__ __launch_bounds__(MLP_WAVES * kWave) void mlp_bwd_kernel(
     const half_t* __restrict__ W, MlpIO io, int64_t B, int n_out, int out_act, const half_t* __restrict__ dout,
-    int64_t dout_stride, float* __restrict__ dW, float* __restrict__ dA, half_t* __restrict__ dBsrc, int64_t n_tiles) {
+    int64_t dout_stride, float* __restrict__ dW, float* __restrict__ dA, half_t* __restrict__ dBsrc, int64_t n_tiles,
+    const int64_t* __restrict__ n_dev) {
+    NSX_DEVICE_COUNT(B, n_tiles, 32, n_dev);
     extern __shared__ __attribute__((aligned(16))) uint8_t smem_raw[];
     const FragPlan p = make_plan(NH, true);
     f16x8* frags = reinterpret_cast<f16x8*>(smem_raw);
@@ -465,10 +469,10 @@ int nsx_mlp_fwd(const nsx_half* weights, int n_hidden_mats, int64_t B,
     half_t* o = reinterpret_cast<half_t*>(out);
     if (n_hidden_mats == 0)
         hipLaunchKernelGGL((mlp_fwd_kernel<0>), dim3((unsigned)blocks), dim3(MLP_WAVES * kWave), fwd_smem(0), st, W, io, B,
-                           n_out, out_act, o, out_stride, n_tiles);
+                           n_out, out_act, o, out_stride, n_tiles, count_for(B));
     else
         hipLaunchKernelGGL((mlp_fwd_kernel<1>), dim3((unsigned)blocks), dim3(MLP_WAVES * kWave), fwd_smem(1), st, W, io, B,
-                           n_out, out_act, o, out_stride, n_tiles);
+                           n_out, out_act, o, out_stride, n_tiles, count_for(B));
     NSX_LAUNCH_CHECK("nsx_mlp_fwd launch");
     return NSX_OK;
 }
@@ -492,11 +496,11 @@ int nsx_mlp_bwd(const nsx_half* weights, int n_hidden_mats, int64_t B,
     if (n_hidden_mats == 0)
         hipLaunchKernelGGL((mlp_bwd_kernel<0>), dim3((unsigned)blocks), dim3(MLP_WAVES * kWave), bwd_smem(0), st, W, io, B,
                            n_out, out_act, reinterpret_cast<const half_t*>(dout), dout_stride, dweights, da,
-                           reinterpret_cast<half_t*>(db), n_tiles);
+                           reinterpret_cast<half_t*>(db), n_tiles, count_for(B));
     else
         hipLaunchKernelGGL((mlp_bwd_kernel<1>), dim3((unsigned)blocks), dim3(MLP_WAVES * kWave), bwd_smem(1), st, W, io, B,
                            n_out, out_act, reinterpret_cast<const half_t*>(dout), dout_stride, dweights, da,
-                           reinterpret_cast<half_t*>(db), n_tiles);
+                           reinterpret_cast<half_t*>(db), n_tiles, count_for(B));
     NSX_LAUNCH_CHECK("nsx_mlp_bwd launch");
     return NSX_OK;
 }

@@ -25,6 +25,21 @@ int hip_fail(hipError_t e, const char* what);
 
 constexpr int kWave = 64;   // CDNA wavefront
 
+// Device-side element counts (nsx_device_count_begin / _end, include/nsx.h): the registered device pointer when a
+// per-sample entry point is called with exactly the registered capacity, else NULL.
+const int64_t* count_for(int64_t n);
+
+// First statement of a per-sample kernel: shrink the element count (and the tile count derived from it) to the value in
+// device memory, if one is attached; nothing to do -> the whole grid returns.
+#define NSX_DEVICE_COUNT(B, n_tiles, per_tile, n_dev)                                              \
+    do {                                                                                           \
+        if (n_dev) {                                                                               \
+            const int64_t n__ = *(n_dev);                                                          \
+            if (n__ < (B)) { (B) = n__ < 0 ? 0 : n__; (n_tiles) = ((B) + (per_tile) - 1) / (per_tile); } \
+        }                                                                                          \
+        if ((B) <= 0) return;                                                                      \
+    } while (0)
+
 typedef _Float16 half_t;
 typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
 

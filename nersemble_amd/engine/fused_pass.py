@@ -23,7 +23,7 @@ import torch
 from .. import _lib
 from .. import distloss as dl
 from .. import functional as F
-from .._lib import check, lib, ptr, stream
+from .._lib import check, device_count, lib, ptr, stream
 
 
 class MainPassInputs:
@@ -32,12 +32,19 @@ class MainPassInputs:
                  "pre_offsets", "pre_features", "pre_base", "image", "alpha_map", "depth_targets",
                  "he", "window", "field_aabb6", "deform_packed", "deform_aabb6", "deform_window7",
                  "base_hidden", "base_out_dim", "base_act", "base_w16", "head_hidden", "head_act", "head_w16", "geo_dim",
-                 "background", "loss_cfg", "aux")
+                 "background", "loss_cfg", "aux", "n_dev")
 
 
 class _MainPass(torch.autograd.Function):
     @staticmethod
     def forward(ctx, inp: MainPassInputs, tables_master, base_params, head_params, code_hash, code_deform, *deform_params):
+        # inp.n_dev (optional): the number of valid samples lives on the device; the arrays have capacity rows
+        with device_count(inp.n_dev, inp.t0.shape[0]):
+            return _MainPass._forward(ctx, inp, tables_master, base_params, head_params, code_hash, code_deform,
+                                      *deform_params)
+
+    @staticmethod
+    def _forward(ctx, inp: MainPassInputs, tables_master, base_params, head_params, code_hash, code_deform, *deform_params):
         L = lib()
         st = stream()
         dev = inp.origins.device
@@ -123,6 +130,11 @@ class _MainPass(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_out):
+        with device_count(ctx.inp.n_dev, ctx.inp.t0.shape[0]):
+            return _MainPass._backward(ctx, g_out)
+
+    @staticmethod
+    def _backward(ctx, g_out):
         (pos, pn, sel, feats, base_out, density, rgb_s, w, rgb, acc1, dep1, clip, out, base_w, head_w, code_h, code_d,
          tables_f16) = ctx.saved_tensors
         inp: MainPassInputs = ctx.inp
@@ -182,7 +194,8 @@ class _MainPass(torch.autograd.Function):
                 G = sink.buffer_for(code_h, inp.window, n_rows, geom.total_entries)
             else:
                 G = torch.zeros((n_rows, geom.total_entries, 2), dtype=f32, device=dev)
-        dcode_s = torch.empty((S, H), dtype=f32, device=dev) if need_code else None
+        dcode_s = (torch.zeros if inp.n_dev is not None else torch.empty)((S, H), dtype=f32, device=dev) \
+            if need_code else None
         dx = torch.empty((S, 3), dtype=f32, device=dev)
         check(L.nsx_hash_ensemble_bwd_factored(ptr(pn), S, ptr(tables_f16), H, C.byref(geom), ptr(code_h), code_h.stride(0),
                                                n_rows, ptr(inp.slot), ptr(inp.window), ptr(dout), ptr(G), ptr(dcode_s),

@@ -562,12 +562,14 @@ class _HashGridFn(torch.autograd.Function):
 
 
 @torch.no_grad()
-def gather_rows(index: torch.Tensor, *tensors: torch.Tensor):
-    """[t[index] for t in tensors] (rows along dim 0) in one native launch; no autograd (values only)."""
+def gather_rows(index: torch.Tensor, *tensors: torch.Tensor, zero_fill: bool = False):
+    """[t[index] for t in tensors] (rows along dim 0) in one native launch; no autograd (values only).
+    ``zero_fill``: outputs start as zeros (under ``_lib.device_count`` only the first ``n`` rows are written)."""
     idx = index.to(torch.int64).contiguous()
     n = idx.shape[0]
     srcs = [(t.detach() if t.requires_grad else t).contiguous() for t in tensors]
-    outs = [torch.empty((n,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device) for t in srcs]
+    alloc = torch.zeros if zero_fill else torch.empty
+    outs = [alloc((n,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device) for t in srcs]
     k = len(srcs)
     if n > 0 and k > 0:
         rb = []

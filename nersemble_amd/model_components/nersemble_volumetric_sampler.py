@@ -59,8 +59,8 @@ class NeRSembleVolumetricSampler(nn.Module):
     # per-ray entries of ``ray_bundle.metadata`` that the model wants per sample (gathered in the same launch)
     sample_metadata_keys = ("image_index",)
 
-    def _packed_samples(self, bundle: RayBundle, o: Tensor, d: Tensor, ray_indices: Tensor, t0: Tensor, t1: Tensor
-                        ) -> RaySamples:
+    def _packed_samples(self, bundle: RayBundle, o: Tensor, d: Tensor, ray_indices: Tensor, t0: Tensor, t1: Tensor,
+                        n_dev: Optional[Tensor] = None) -> RaySamples:
         """One RaySamples row per marched interval, rays gathered through ``ray_indices`` (flattened / packed layout).
         All per-ray arrays (origins, directions, camera indices, times, requested metadata) go through ONE gather
         launch on the device (the reference issues one advanced-indexing op per field, :117-134)."""
@@ -74,7 +74,9 @@ class NeRSembleVolumetricSampler(nn.Module):
             if isinstance(value, Tensor) and value.shape[0] == o.shape[0]:
                 named.append(("metadata:" + key, value))
         if o.is_cuda:
-            rows = F.gather_rows(ray_indices, *[t for _, t in named])
+            from .._lib import device_count
+            with device_count(n_dev, ray_indices.shape[0]):          # (n_dev None: every row)
+                rows = F.gather_rows(ray_indices, *[t for _, t in named], zero_fill=n_dev is not None)
         else:
             rows = [t[ray_indices] for _, t in named]
         got = dict(zip([n for n, _ in named], rows))
@@ -92,7 +94,9 @@ class NeRSembleVolumetricSampler(nn.Module):
 
     def forward(self, ray_bundle: RayBundle, render_step_size: float, near_plane: float = 0.0,
                 far_plane: Optional[float] = None, alpha_thre: float = 0.01, cone_angle: float = 0.0,
-                early_stop_eps: float = 1e-4) -> Tuple[RaySamples, Tensor]:
+                early_stop_eps: float = 1e-4, device_counts: bool = False) -> Tuple[RaySamples, Tensor]:
+        """``device_counts`` (native extension, training fast path): see ``OccGridEstimator.sampling`` -- the returned
+        arrays keep the marched capacity, ``self.occupancy_grid.last_n_kept`` holds the number of valid rows."""
         o, d = ray_bundle.origins.contiguous(), ray_bundle.directions.contiguous()
         per_ray_near = per_ray_far = None
         if ray_bundle.nears is not None and ray_bundle.fars is not None:
@@ -103,7 +107,10 @@ class NeRSembleVolumetricSampler(nn.Module):
             rays_o=o, rays_d=d, t_min=per_ray_near, t_max=per_ray_far,
             sigma_fn=self.get_sigma_fn(o, d, ray_bundle.times), render_step_size=render_step_size,
             near_plane=near_plane, far_plane=1e10 if far_plane is None else far_plane, stratified=self.training,
-            cone_angle=cone_angle, alpha_thre=alpha_thre, early_stop_eps=early_stop_eps)
+            cone_angle=cone_angle, alpha_thre=alpha_thre, early_stop_eps=early_stop_eps, device_counts=device_counts)
+        n_dev = self.occupancy_grid.last_n_kept if device_counts else None
+        if n_dev is not None:
+            return self._packed_samples(ray_bundle, o, d, ray_indices, t0, t1, n_dev), ray_indices
         if t0.shape[0] == 0:
             # nothing survived: one dummy interval on ray 0 keeps every downstream shape valid (reference :109-115)
             ray_indices = torch.zeros((1,), dtype=torch.long, device=o.device)

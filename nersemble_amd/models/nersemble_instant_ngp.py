@@ -107,6 +107,8 @@ class NeRSembleNGPModel(BaseModel):
         self.fuse_step_losses = True
         # the kept samples' main pass of a training step as one autograd node (fused_train_forward; host-side saving)
         self.fuse_main_pass = True
+        # ... with the number of kept samples left on the device (no host read-back after the marcher's own count)
+        self.device_sample_counts = True
         # evaluation fast path: when every ray of a bundle carries the same timestep the H hash tables
         # are blended once per image into one 2-feature grid (HashEnsemble.preblend)
         self.eval_preblend = True
@@ -380,24 +382,31 @@ class NeRSembleNGPModel(BaseModel):
         window_deform = self.sched_window_deform.value if self.sched_window_deform is not None else None
         self._sigma_cache = None
         self.field.keep_density_intermediates = self.reuse_sigma_pass
+        md = ray_bundle.metadata
+        # the kept-sample count can stay on the device when the per-sample code slot comes with the batch (it is gathered
+        # with the other per-ray fields) and the sigma_fn pass's forward values are reused
+        on_device = (self.device_sample_counts and self.reuse_sigma_pass and "image_index" in md
+                     and "_image_timesteps" in md and (cfg.alpha_thre > 0 or cfg.early_stop_eps > 0))
         try:
             with torch.no_grad():
                 ray_samples, ray_indices = self.sampler(
                     ray_bundle=ray_bundle, near_plane=cfg.near_plane, far_plane=cfg.far_plane,
                     render_step_size=cfg.render_step_size, alpha_thre=cfg.alpha_thre, cone_angle=cfg.cone_angle,
-                    early_stop_eps=cfg.early_stop_eps)
+                    early_stop_eps=cfg.early_stop_eps, device_counts=on_device)
         finally:
             self.field.keep_density_intermediates = False
+        n_dev = self.occupancy_grid.last_n_kept if on_device else None
         S = ray_indices.shape[0]
         max_chunk = cfg.max_n_samples_per_batch
         if max_chunk != -1 and S > max_chunk:
             self._sigma_cache = None
             return None                                  # several chunks: the modular path walks them
-        md = ray_bundle.metadata
         if "image_index" in md and "_image_timesteps" in md:
             uniq = md["_image_timesteps"].reshape(-1).int()
             slot = (ray_samples.metadata or {}).get("image_index")
             if slot is None or slot.shape[0] != S:
+                if n_dev is not None:
+                    raise RuntimeError("device-side sample counts need the sampler to gather the code slots")
                 slot = md["image_index"].reshape(-1).to(torch.int32)[ray_indices]
         else:
             ray_timesteps = self._timesteps(ray_bundle.times) if ray_bundle.times is not None \
@@ -413,7 +422,12 @@ class NeRSembleNGPModel(BaseModel):
         pre = (None, None, None)
         if cache is not None and keep is not None and cache["n"] == self.occupancy_grid.last_n_marched \
                 and keep.shape[0] == S and cache["features"] is not None and cache["offsets"] is not None:
-            pre = Fn.gather_rows(keep, cache["offsets"], cache["features"], cache["base_out"])
+            from .._lib import device_count
+            with device_count(n_dev, S):
+                pre = Fn.gather_rows(keep, cache["offsets"], cache["features"], cache["base_out"],
+                                     zero_fill=n_dev is not None)
+        elif n_dev is not None:
+            raise RuntimeError("device-side sample counts: the sigma_fn pass left no forward values to reuse")
         he = self.field.hash_ensemble
         code_hash, window = he._conditioned(self.time_embedding(uniq), window_hash, ray_indices.device)
         emb_d = self.time_embedding_deformation if self.time_embedding_deformation is not None else self.time_embedding
@@ -422,8 +436,10 @@ class NeRSembleNGPModel(BaseModel):
         inp = MainPassInputs()
         inp.origins, inp.directions = fr.origins.contiguous(), fr.directions.contiguous()
         inp.t0, inp.t1 = fr.starts.reshape(-1).contiguous(), fr.ends.reshape(-1).contiguous()
-        inp.ray_indices, inp.slot, inp.n_rays = ray_indices, slot, num_rays
-        inp.packed = nerfacc.pack_info(ray_indices, num_rays)
+        inp.ray_indices, inp.slot, inp.n_rays, inp.n_dev = ray_indices, slot, num_rays, n_dev
+        from .._lib import device_count
+        with device_count(n_dev, S):
+            inp.packed = nerfacc.pack_info(ray_indices, num_rays)
         inp.pre_offsets, inp.pre_features, inp.pre_base = pre
         inp.image = batch["image"].to(torch.float32).contiguous()
         inp.alpha_map = alpha_map.reshape(-1).contiguous() if alpha_map is not None else None

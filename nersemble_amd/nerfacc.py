@@ -264,8 +264,13 @@ class OccGridEstimator(nn.Module):
                  alpha_fn: Optional[Callable] = None, near_plane: float = 0.0, far_plane: float = 1e10,
                  t_min: Optional[Tensor] = None, t_max: Optional[Tensor] = None, render_step_size: float = 1e-3,
                  early_stop_eps: float = 1e-4, alpha_thre: float = 0.0, stratified: bool = False,
-                 cone_angle: float = 0.0) -> Tuple[Tensor, Tensor, Tensor]:
-        """Same contract as nerfacc 0.5.2 ``OccGridEstimator.sampling``: (ray_indices, t_starts, t_ends)."""
+                 cone_angle: float = 0.0, device_counts: bool = False) -> Tuple[Tensor, Tensor, Tensor]:
+        """Same contract as nerfacc 0.5.2 ``OccGridEstimator.sampling``: (ray_indices, t_starts, t_ends).
+
+        ``device_counts`` (native extension): the number of samples that survive the visibility test stays ON THE DEVICE --
+        the outputs keep the marched samples' capacity, their first ``self.last_n_kept[0]`` rows are the kept samples
+        (compacted in order), and the caller runs the per-sample kernels under ``_lib.device_count(self.last_n_kept,
+        capacity)``.  No host synchronisation after the marcher's own count."""
         if cone_angle != 0.0:
             raise NotImplementedError("cone_angle != 0 is not used by NeRSemble (train_nersemble.py:97)")
         if alpha_fn is not None:
@@ -278,7 +283,7 @@ class OccGridEstimator(nn.Module):
             raise NotImplementedError("per-ray t_max is not used by NeRSemble (ray bundles carry no fars)")
         if stratified:
             near_planes = near_planes + torch.rand_like(near_planes) * render_step_size
-        self.last_keep_index, self.last_n_marched = None, -1
+        self.last_keep_index, self.last_n_marched, self.last_n_kept = None, -1, None
         ray_indices, t_starts, t_ends, packed, _ = self.traverse(rays_o, rays_d, near_planes, far, render_step_size)
         if (alpha_thre > 0.0 or early_stop_eps > 0.0) and sigma_fn is not None:
             # nerfacc: alpha_thre = min(alpha_thre, occs.mean().item()); kept on the device (no host sync)
@@ -290,6 +295,21 @@ class OccGridEstimator(nn.Module):
             assert sigmas.shape == t_starts.shape, "sigmas must have shape of (N,)! Got {}".format(sigmas.shape)
             masks = render_visibility_from_density(t_starts, t_ends, sigmas, packed_info=packed,
                                                    early_stop_eps=early_stop_eps, alpha_thre=alpha_thre)
+            n_marched = masks.shape[0]
+            if device_counts and masks.is_cuda and n_marched > 0:
+                # stream compaction on the device: ascending indices of the visible samples + their number
+                from ._lib import device_count
+                from .functional import gather_rows
+                keep32 = torch.zeros((n_marched,), dtype=torch.int32, device=masks.device)
+                n32 = torch.zeros((1,), dtype=torch.int32, device=masks.device)
+                scratch = torch.empty((int(lib().nsx_occ_scratch_bytes(n_marched)),), dtype=torch.uint8, device=masks.device)
+                check(lib().nsx_occ_compact(ptr(masks.view(torch.uint8)), n_marched, ptr(keep32), ptr(n32), ptr(scratch),
+                                            stream()), "nsx_occ_compact")
+                keep, n_kept = keep32.to(torch.int64), n32.to(torch.int64)
+                self.last_keep_index, self.last_n_marched, self.last_n_kept = keep, n_marched, n_kept
+                with device_count(n_kept, n_marched):
+                    ray_indices, t_starts, t_ends = gather_rows(keep, ray_indices, t_starts, t_ends, zero_fill=True)
+                return ray_indices, t_starts, t_ends
             keep = masks.nonzero(as_tuple=True)[0]             # one host sync for all three selections
             self.last_keep_index, self.last_n_marched = keep, masks.shape[0]
             if keep.is_cuda:

@@ -453,3 +453,66 @@ def test_early_table_step_keeps_gradscaler_skip_semantics(cuda):
     he.wait_tables()
     assert not torch.equal(he.tables, before["tables"]) and opt.state[he.tables]["step"] == 2
     assert not torch.equal(model.field.mlp_base.params, before["base"])
+
+
+def test_device_side_sample_counts_equal_host_side_counts(cuda):
+    """The training fast path with the kept-sample count left on the device (one host read-back per step: the marcher's
+    own) against the same path with the count read back (``nonzero``): the kernels process the same rows, so the loss
+    vector is equal bit for bit, the gradients up to the order of atomics; the padded tails never leak into a result."""
+    import ctypes as C
+    from nersemble_amd import _lib
+    from nersemble_amd.workloads import build_workload
+    res = {}
+    for on_device in (False, True):
+        torch.manual_seed(12)
+        trainer, data, _ = build_workload("p030_h16", device="cuda:0", small=True, n_rays=512)
+        model = trainer.model
+        model.device_sample_counts = on_device
+        model.occupancy_grid.occs.fill_(0.5)                      # visibility threshold at its cap: pruning does bite
+        losses, kept = [], []
+        for step in range(6):
+            torch.manual_seed(90 + step)
+            loss, loss_dict, metrics = trainer.train_iteration(step, *data.next_train(step))
+            losses.append(loss.item())
+            kept.append(int(metrics["num_samples_per_batch"]))
+            if step == 0:
+                terms = {k: v.item() for k, v in loss_dict.items()}
+                grads = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+                n_marched = model.occupancy_grid.last_n_marched
+        trainer.flush_scheduler_step()
+        assert (model.occupancy_grid.last_n_kept is not None) == on_device
+        res[on_device] = (losses, kept, terms, grads, n_marched)
+    (l_h, k_h, t_h, g_h, m_h), (l_d, k_d, t_d, g_d, m_d) = res[False], res[True]
+    assert m_h == m_d and k_h[0] == k_d[0] and 0 < k_h[0] < m_h        # same marched set, same kept count, some pruned
+    assert l_h[0] == l_d[0] and t_h == t_d                              # forward: bit for bit
+    for name in g_h:
+        sc = g_h[name].abs().max().item()
+        assert (g_h[name] - g_d[name]).abs().max().item() <= 1e-4 * sc + 1e-12, name
+    assert np.allclose(l_h, l_d, rtol=2e-3) and k_h[:3] == k_d[:3], (l_h, l_d, k_h, k_d)
+
+
+def test_device_count_scope_of_the_c_abi(cuda):
+    """nsx_device_count_begin / _end: a per-sample entry point called with the registered capacity touches only the first
+    *n rows; other sizes and calls outside the scope are unaffected; the scope does not nest."""
+    from nersemble_amd import _lib, functional as F
+    from nersemble_amd._lib import device_count
+    src = torch.arange(40, device=cuda, dtype=torch.float32).reshape(10, 4)
+    idx = torch.tensor([9, 8, 7, 6, 5, 4, 3, 2, 1, 0], device=cuda)
+    n = torch.tensor([3], device=cuda, dtype=torch.int64)
+    with device_count(n, 10):
+        (part,) = F.gather_rows(idx, src, zero_fill=True)
+        (other,) = F.gather_rows(idx[:5], src, zero_fill=True)              # size != capacity: every row
+        with pytest.raises(RuntimeError):
+            with device_count(n, 10):
+                pass
+    (full,) = F.gather_rows(idx, src)
+    assert torch.equal(part[:3], src[idx[:3]]) and bool((part[3:] == 0).all())
+    assert torch.equal(other, src[idx[:5]]) and torch.equal(full, src[idx])
+    n.fill_(0)
+    with device_count(n, 10):
+        (none,) = F.gather_rows(idx, src, zero_fill=True)
+    assert bool((none == 0).all())
+    n.fill_(25)                                                               # more than the capacity: capped
+    with device_count(n, 10):
+        (capped,) = F.gather_rows(idx, src, zero_fill=True)
+    assert torch.equal(capped, src[idx])
