@@ -469,26 +469,28 @@ def test_device_side_sample_counts_equal_host_side_counts(cuda):
         model = trainer.model
         model.device_sample_counts = on_device
         model.occupancy_grid.occs.fill_(0.5)                      # visibility threshold at its cap: pruning does bite
-        losses, kept = [], []
-        for step in range(6):
+        losses, kept, marched = [], [], []
+        for step in range(24):
             torch.manual_seed(90 + step)
             loss, loss_dict, metrics = trainer.train_iteration(step, *data.next_train(step))
             losses.append(loss.item())
             kept.append(int(metrics["num_samples_per_batch"]))
+            marched.append(model.occupancy_grid.last_n_marched)
             if step == 0:
                 terms = {k: v.item() for k, v in loss_dict.items()}
                 grads = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
-                n_marched = model.occupancy_grid.last_n_marched
         trainer.flush_scheduler_step()
         assert (model.occupancy_grid.last_n_kept is not None) == on_device
-        res[on_device] = (losses, kept, terms, grads, n_marched)
+        res[on_device] = (losses, kept, terms, grads, marched)
     (l_h, k_h, t_h, g_h, m_h), (l_d, k_d, t_d, g_d, m_d) = res[False], res[True]
-    assert m_h == m_d and k_h[0] == k_d[0] and 0 < k_h[0] < m_h        # same marched set, same kept count, some pruned
+    assert m_h[0] == m_d[0] and k_h[0] == k_d[0] and 0 < k_h[0] <= m_h[0]      # same marched set, same kept count
+    assert any(k < m for k, m in zip(k_d, m_d)), (k_d, m_d)                  # the visibility test does prune on the way
     assert l_h[0] == l_d[0] and t_h == t_d                              # forward: bit for bit
     for name in g_h:
         sc = g_h[name].abs().max().item()
         assert (g_h[name] - g_d[name]).abs().max().item() <= 1e-4 * sc + 1e-12, name
-    assert np.allclose(l_h, l_d, rtol=2e-3) and k_h[:3] == k_d[:3], (l_h, l_d, k_h, k_d)
+    assert np.allclose(l_h[:6], l_d[:6], rtol=2e-3) and k_h[:3] == k_d[:3], (l_h, l_d, k_h, k_d)
+    assert np.allclose(l_h, l_d, rtol=5e-2)
 
 
 def test_device_count_scope_of_the_c_abi(cuda):
