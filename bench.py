@@ -124,13 +124,13 @@ def steady_state(trainer, data, first_step: int, settle_at: int, rays: int, n_ti
     while step < settle_at:
         trainer.train_iteration(step, *data.next_train(step))
         step += 1
-    batches = [data.next_train(step + i) for i in range(n_timed)]
+    batches = [data.next_train(step + i) for i in range(n_timed + 1)]      # (+1: the loader is one batch ahead)
     gc.collect()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     samples, counts = 0, []
     for i in range(n_timed):
-        _, _, metrics = trainer.train_iteration(step + i, *batches[i])
+        _, _, metrics = trainer.train_iteration(step + i, *batches[i], next_ray_bundle=batches[i + 1][0])
         counts.append(metrics["num_samples_per_batch"])
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
@@ -323,11 +323,17 @@ def main():
         reserve = torch.empty(int(a.reserve_gb * 2 ** 30), dtype=torch.uint8, device=dev)
         del reserve
     H = WORKLOADS[a.workload]["H"]
+    if os.environ.get("NSX_EARLY_TABLE_STEP") == "1":            # experiment knobs (engine/trainer.py)
+        trainer.early_table_step = True
+    if os.environ.get("NSX_PREFETCH_MARCH") == "0":
+        trainer.prefetch_march = False
 
     for s in range(a.preroll):                                   # optional: start the measurement from a settled state
         trainer.train_iteration(s, *data.next_train(s))
     # synthetic inputs are generated up front: they are resident in HBM when the timed region starts
-    batches = [data.next_train(a.preroll + s) for s in range(a.warmup + a.steps)]
+    # (one more than is trained on: like a loader, the loop knows the next batch, and the trainer starts the counting pass
+    # of its ray marching one step ahead -- every timed step issues exactly one such pass)
+    batches = [data.next_train(a.preroll + s) for s in range(a.warmup + a.steps + 1)]
     torch.cuda.synchronize()
 
     step_marks = []                          # (event at step start, device-side sample count) per timed step
@@ -339,7 +345,8 @@ def main():
                 ev = torch.cuda.Event(enable_timing=True)
                 ev.record()
             bundle, batch = batches[s]
-            loss, loss_dict, metrics = trainer.train_iteration(a.preroll + s, bundle, batch)
+            loss, loss_dict, metrics = trainer.train_iteration(a.preroll + s, bundle, batch,
+                                                               next_ray_bundle=batches[s + 1][0])
             samples += metrics["num_samples_per_batch"]
             if mark:
                 step_marks.append((ev, metrics["num_samples_per_batch"]))
@@ -465,7 +472,9 @@ def main():
                        "parallelism": f"dp{world}", "params": info["params"],
                        "occupancy_grid": "state at the end of the warm-up kept for the timed region; the update runs on "
                                          "schedule, its result is not adopted" if a.grid == "frozen" else "live",
-                       "rccl_ranks": world if (world > 1 and a.backend == "nccl") else 0},
+                       "rccl_ranks": world if (world > 1 and a.backend == "nccl") else 0,
+                       "early_table_step": bool(trainer.early_table_step),
+                       "march_count_one_step_ahead": bool(trainer.prefetch_march)},
             "rays_per_sec": world * info["rays"] * a.steps / dt_max,
             "psnr_last": float(metrics["psnr"].detach()), "loss_last": float(loss.detach()),
             "roofline": roofline, "rooflines": rooflines, "native_kernel_ms": kernels,

@@ -72,6 +72,7 @@ class NeRSembleTrainer:
         # slower (8.8 vs 8.3 ms per step early in training, 4.85 vs 4.25 ms in steady state) -- the 12 GB pass next to
         # the deformation backward triples the latter (both are HBM-bound) and crowds the step's tail off the CUs
         self.early_table_step = early_table_step
+        self.prefetch_march = True                # use train_iteration's next_ray_bundle (off: for A/B measurements)
         self.cfg = opt_cfg or OptimizerConfig()
         self.mixed_precision = mixed_precision
         self.world_size = world_size
@@ -213,12 +214,19 @@ class NeRSembleTrainer:
         self._found_groups = groups
         return found_all
 
-    def train_iteration(self, step: int, ray_bundle: RayBundle, batch: Dict[str, torch.Tensor]
+    def train_iteration(self, step: int, ray_bundle: RayBundle, batch: Dict[str, torch.Tensor],
+                        next_ray_bundle: Optional[RayBundle] = None
                         ) -> Tuple[torch.Tensor, Dict[str, torch.Tensor], Dict[str, torch.Tensor]]:
+        """One optimisation step.  ``next_ray_bundle`` (optional): the rays of step ``step + 1`` if the loader has them
+        already -- the counting pass of their ray marching then runs beside this step (``prefetch_sampling``), and the
+        next call finds the sample count on the host instead of waiting for the device.  It must be the very bundle
+        object passed to that next call; anything else is simply not used."""
         if not self.model.training:               # (nn.Module.train() walks all ~100 sub-modules)
             self.model.train()
         for cb in self.callbacks:
             cb.run(step)
+        if next_ray_bundle is not None and self.prefetch_march:
+            self.model.prefetch_sampling(next_ray_bundle, step + 1)
         for opt in self.optimizers.values():
             opt.zero_grad(set_to_none=True)
         dev_type = ray_bundle.origins.device.type

@@ -54,7 +54,11 @@ class NeRSembleVolumetricSampler(nn.Module):
         binaries = self.occupancy_grid.binaries
         if grid.device != binaries.device:
             grid = self.camera_frustum_grid = grid.to(binaries.device)
+        stamp = (binaries.data_ptr(), binaries._version)
+        if getattr(self, "_culled_stamp", None) == stamp:
+            return                                   # nobody wrote the grid since it was culled: the AND is idempotent
         binaries[0] = binaries[0] & grid
+        self._culled_stamp = (binaries.data_ptr(), binaries._version)
 
     # per-ray entries of ``ray_bundle.metadata`` that the model wants per sample (gathered in the same launch)
     sample_metadata_keys = ("image_index",)
@@ -92,16 +96,33 @@ class NeRSembleVolumetricSampler(nn.Module):
             samples.metadata = extra
         return samples
 
-    def forward(self, ray_bundle: RayBundle, render_step_size: float, near_plane: float = 0.0,
-                far_plane: Optional[float] = None, alpha_thre: float = 0.01, cone_angle: float = 0.0,
-                early_stop_eps: float = 1e-4, device_counts: bool = False) -> Tuple[RaySamples, Tensor]:
-        """``device_counts`` (native extension, training fast path): see ``OccGridEstimator.sampling`` -- the returned
-        arrays keep the marched capacity, ``self.occupancy_grid.last_n_kept`` holds the number of valid rows."""
+    @staticmethod
+    def _march_inputs(ray_bundle: RayBundle):
         o, d = ray_bundle.origins.contiguous(), ray_bundle.directions.contiguous()
         per_ray_near = per_ray_far = None
         if ray_bundle.nears is not None and ray_bundle.fars is not None:
             per_ray_near = ray_bundle.nears.contiguous().reshape(-1)
             per_ray_far = ray_bundle.fars.contiguous().reshape(-1)
+        return o, d, per_ray_near, per_ray_far
+
+    def prefetch(self, ray_bundle: RayBundle, render_step_size: float, near_plane: float = 0.0,
+                 far_plane: Optional[float] = None) -> bool:
+        """Start the traversal's counting pass for a later ``forward`` on this very bundle with these arguments
+        (``OccGridEstimator.prefetch_march``).  False when there is nothing to gain (CPU, per-ray far planes)."""
+        o, d, per_ray_near, per_ray_far = self._march_inputs(ray_bundle)
+        if per_ray_far is not None or not o.is_cuda:
+            return False
+        self._cull_to_camera_frusta()
+        return self.occupancy_grid.prefetch_march(o, d, near_plane=near_plane,
+                                                  far_plane=1e10 if far_plane is None else far_plane, t_min=per_ray_near,
+                                                  render_step_size=render_step_size, stratified=self.training)
+
+    def forward(self, ray_bundle: RayBundle, render_step_size: float, near_plane: float = 0.0,
+                far_plane: Optional[float] = None, alpha_thre: float = 0.01, cone_angle: float = 0.0,
+                early_stop_eps: float = 1e-4, device_counts: bool = False) -> Tuple[RaySamples, Tensor]:
+        """``device_counts`` (native extension, training fast path): see ``OccGridEstimator.sampling`` -- the returned
+        arrays keep the marched capacity, ``self.occupancy_grid.last_n_kept`` holds the number of valid rows."""
+        o, d, per_ray_near, per_ray_far = self._march_inputs(ray_bundle)
         self._cull_to_camera_frusta()
         ray_indices, t0, t1 = self.occupancy_grid.sampling(
             rays_o=o, rays_d=d, t_min=per_ray_near, t_max=per_ray_far,

@@ -196,6 +196,17 @@ class NeRSembleNGPModel(BaseModel):
             n=16, occ_thre=cfg.occ_thre, ema_decay=cfg.occupancy_grid_ema_decay,
             warmup_steps=cfg.occupancy_grid_warmup_steps)
 
+    def prefetch_sampling(self, ray_bundle: RayBundle, step: int) -> bool:
+        """Tell the model which ray bundle training step ``step`` will use (native extension, called one step ahead by
+        ``NeRSembleTrainer.train_iteration``): the counting pass of that step's ray marching starts now, on a side
+        stream.  Nothing is done when the grid is refreshed before that step (it would march the stale grid; the
+        estimator would discard the result anyway)."""
+        if self.config.disable_occupancy_grid or not self.training or step % 16 == 0:
+            return False
+        cfg = self.config
+        return self.sampler.prefetch(ray_bundle, render_step_size=cfg.render_step_size, near_plane=cfg.near_plane,
+                                     far_plane=cfg.far_plane)
+
     def get_training_callbacks(self) -> List[TrainingCallback]:
         callbacks = [TrainingCallback(func=lambda step: self.update_occupancy_grid(step))]
 

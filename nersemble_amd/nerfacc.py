@@ -231,10 +231,73 @@ class OccGridEstimator(nn.Module):
         return self._occs_mean_value
 
     # ---- traversal -------------------------------------------------------------------------------
+    @staticmethod
+    def _near_planes(rays_o: Tensor, near_plane: float, t_min: Optional[Tensor], render_step_size: float,
+                     stratified: bool) -> Tensor:
+        near_planes = torch.full_like(rays_o[..., 0], fill_value=near_plane)
+        if t_min is not None:
+            near_planes = torch.clamp(near_planes, min=t_min)
+        if stratified:
+            near_planes = near_planes + torch.rand_like(near_planes) * render_step_size
+        return near_planes
+
+    def _march_key(self, rays_o, rays_d, near_plane, far_plane, render_step_size, stratified, t_min):
+        return (rays_o.data_ptr(), rays_d.data_ptr(), rays_o.shape[0], float(near_plane), float(far_plane),
+                float(render_step_size), bool(stratified), None if t_min is None else t_min.data_ptr(),
+                self.binaries.data_ptr(), self.binaries._version)
+
+    @torch.no_grad()
+    def prefetch_march(self, rays_o: Tensor, rays_d: Tensor, near_plane: float = 0.0, far_plane: float = 1e10,
+                       t_min: Optional[Tensor] = None, render_step_size: float = 1e-3, stratified: bool = False) -> bool:
+        """Pass 1 of the two-pass traversal for a LATER ``sampling()`` call on the same rays: the (jittered) near planes,
+        the per-ray sample counts, their prefix sums, and the copy of the total into pinned host memory -- on a side
+        stream, beside whatever the device is doing.  Marching depends on the rays and on the occupancy grid only, not
+        on the model's weights, so a training loop that knows its next ray batch (a loader always does) issues this one
+        step ahead; the later ``sampling()`` finds the count on the host and never waits for the device.  The result is
+        used only if rays, arguments and the grid (same storage, same version) are exactly those of the later call."""
+        if not rays_o.is_cuda:
+            return False
+        rays_o = rays_o.to(torch.float32).contiguous()
+        rays_d = rays_d.to(torch.float32).contiguous()
+        if t_min is not None:
+            t_min = t_min.contiguous()
+        R, dev = rays_o.shape[0], rays_o.device
+        main = torch.cuda.current_stream(dev)
+        side = getattr(self, "_prefetch_stream", None)
+        if side is None or side.device != dev:
+            side = self._prefetch_stream = torch.cuda.Stream(dev, priority=-1)
+        key = self._march_key(rays_o, rays_d, near_plane, far_plane, render_step_size, stratified, t_min)
+        binary = self.binaries[0].contiguous().view(torch.uint8)
+        total_host = torch.empty((1,), dtype=torch.int64, pin_memory=True)
+        side.wait_stream(main)                               # rays and grid were written on the caller's stream
+        with torch.cuda.stream(side):
+            near_planes = self._near_planes(rays_o, near_plane, t_min, render_step_size, stratified)
+            counts = torch.empty((R,), dtype=torch.int64, device=dev)
+            packed = torch.empty((R, 2), dtype=torch.int64, device=dev)
+            total = torch.zeros((1,), dtype=torch.int64, device=dev)
+            check(lib().nsx_march_count(ptr(rays_o), ptr(rays_d), R, self._aabb6(), ptr(binary), self._res,
+                                        ptr(near_planes), float(far_plane), float(render_step_size), ptr(counts),
+                                        stream()), "nsx_march_count")
+            check(lib().nsx_pack_info(ptr(counts), R, ptr(packed), ptr(total), stream()), "nsx_pack_info")
+            total_host.copy_(total, non_blocking=True)
+            done = torch.cuda.Event()
+            done.record(side)
+        for t in (near_planes, packed, binary):               # consumed on the caller's stream later
+            t.record_stream(main)
+        self._prefetched = {"key": key, "rays": (rays_o, rays_d, t_min), "near_planes": near_planes, "packed": packed,
+                            "total_host": total_host, "done": done, "keep": (counts, total)}
+        return True
+
+    def _take_prefetched(self, key):
+        pre = getattr(self, "_prefetched", None)
+        self._prefetched = None
+        return pre if (pre is not None and pre["key"] == key) else None
+
     @torch.no_grad()
     def traverse(self, rays_o: Tensor, rays_d: Tensor, near_planes: Tensor, far_plane: float, step: float,
-                 want_cells: bool = False):
-        """Two-pass marching; returns (ray_indices int64 [S], t_starts, t_ends, packed_info [R,2], cells|None)."""
+                 want_cells: bool = False, counted: Optional[dict] = None):
+        """Two-pass marching; returns (ray_indices int64 [S], t_starts, t_ends, packed_info [R,2], cells|None).
+        ``counted``: pass 1 already done by ``prefetch_march`` (its near planes must be the ones passed in)."""
         rays_o = rays_o.to(torch.float32).contiguous()
         rays_d = rays_d.to(torch.float32).contiguous()
         near_planes = near_planes.to(torch.float32).contiguous()
@@ -242,13 +305,19 @@ class OccGridEstimator(nn.Module):
         dev = rays_o.device
         binary = self.binaries[0].contiguous().view(torch.uint8)
         res = self._res
-        counts = torch.empty((R,), dtype=torch.int64, device=dev)
-        packed = torch.empty((R, 2), dtype=torch.int64, device=dev)
-        total = torch.zeros((1,), dtype=torch.int64, device=dev)
-        check(lib().nsx_march_count(ptr(rays_o), ptr(rays_d), R, self._aabb6(), ptr(binary), res, ptr(near_planes),
-                                    float(far_plane), float(step), ptr(counts), stream()), "nsx_march_count")
-        check(lib().nsx_pack_info(ptr(counts), R, ptr(packed), ptr(total), stream()), "nsx_pack_info")
-        S = int(total.item())                       # the one host read-back (as in nerfacc's two-pass design)
+        if counted is not None:
+            packed = counted["packed"]
+            torch.cuda.current_stream(dev).wait_event(counted["done"])
+            counted["done"].synchronize()                     # long complete when issued a step ahead
+            S = int(counted["total_host"][0])
+        else:
+            counts = torch.empty((R,), dtype=torch.int64, device=dev)
+            packed = torch.empty((R, 2), dtype=torch.int64, device=dev)
+            total = torch.zeros((1,), dtype=torch.int64, device=dev)
+            check(lib().nsx_march_count(ptr(rays_o), ptr(rays_d), R, self._aabb6(), ptr(binary), res, ptr(near_planes),
+                                        float(far_plane), float(step), ptr(counts), stream()), "nsx_march_count")
+            check(lib().nsx_pack_info(ptr(counts), R, ptr(packed), ptr(total), stream()), "nsx_pack_info")
+            S = int(total.item())                       # the one host read-back (as in nerfacc's two-pass design)
         t0 = torch.empty((S,), dtype=torch.float32, device=dev)
         t1 = torch.empty((S,), dtype=torch.float32, device=dev)
         ri = torch.empty((S,), dtype=torch.int64, device=dev)
@@ -275,16 +344,21 @@ class OccGridEstimator(nn.Module):
             raise NotImplementedError("cone_angle != 0 is not used by NeRSemble (train_nersemble.py:97)")
         if alpha_fn is not None:
             raise NotImplementedError("alpha_fn is not used by NeRSemble")
-        near_planes = torch.full_like(rays_o[..., 0], fill_value=near_plane)
         far = float(far_plane)
-        if t_min is not None:
-            near_planes = torch.clamp(near_planes, min=t_min)
         if t_max is not None:
             raise NotImplementedError("per-ray t_max is not used by NeRSemble (ray bundles carry no fars)")
-        if stratified:
-            near_planes = near_planes + torch.rand_like(near_planes) * render_step_size
+        counted = None
+        if getattr(self, "_prefetched", None) is not None:
+            counted = self._take_prefetched(self._march_key(rays_o, rays_d, near_plane, far, render_step_size, stratified,
+                                                            t_min))
+        if counted is not None:
+            near_planes = counted["near_planes"]
+        else:
+            near_planes = self._near_planes(rays_o, near_plane, t_min, render_step_size, stratified)
         self.last_keep_index, self.last_n_marched, self.last_n_kept = None, -1, None
-        ray_indices, t_starts, t_ends, packed, _ = self.traverse(rays_o, rays_d, near_planes, far, render_step_size)
+        self.last_march_prefetched = counted is not None
+        ray_indices, t_starts, t_ends, packed, _ = self.traverse(rays_o, rays_d, near_planes, far, render_step_size,
+                                                                 counted=counted)
         if (alpha_thre > 0.0 or early_stop_eps > 0.0) and sigma_fn is not None:
             # nerfacc: alpha_thre = min(alpha_thre, occs.mean().item()); kept on the device (no host sync)
             alpha_thre = torch.clamp(self._occs_mean(), max=alpha_thre).reshape(1).float()
@@ -375,7 +449,11 @@ class OccGridEstimator(nn.Module):
         check(lib().nsx_occ_update(ptr(self.occs), ptr(self.binaries.view(torch.uint8)), self.levels * self.cells_per_lvl,
                                    ptr(cell_ids), ptr(occ), cell_ids.shape[0], float(ema_decay), float(occ_thre),
                                    ptr(self._occ_scratch()), None, stream()), "nsx_occ_update")
-        self._occs_mean_key = None                  # occs was written behind torch's back: drop the cached mean
+        # both buffers were written through raw pointers: tell torch (version-keyed caches -- the cached occs mean, a
+        # prefetched march, the sampler's frustum culling -- must see the change)
+        torch.autograd.graph.increment_version(self.occs)
+        torch.autograd.graph.increment_version(self.binaries)
+        self._occs_mean_key = None
 
     @torch.no_grad()
     def update_every_n_steps(self, step: int, occ_eval_fn: Callable, occ_thre: float = 1e-2, ema_decay: float = 0.95,

@@ -518,3 +518,71 @@ def test_device_count_scope_of_the_c_abi(cuda):
     with device_count(n, 10):
         (capped,) = F.gather_rows(idx, src, zero_fill=True)
     assert torch.equal(capped, src[idx])
+
+
+def test_march_counted_one_step_ahead_is_the_same_march(cuda):
+    """``OccGridEstimator.prefetch_march`` (the counting pass of the traversal on a side stream, one step ahead) followed
+    by ``sampling`` == ``sampling`` alone, bit for bit, when the jitter draws the same random numbers; a grid update in
+    between discards the prefetched pass."""
+    from nersemble_amd.workloads import build_workload
+    torch.manual_seed(21)
+    trainer, data, _ = build_workload("p030_h16", device="cuda:0", small=True, n_rays=512)
+    for step in range(3):
+        trainer.train_iteration(step, *data.next_train(step))
+    model = trainer.model
+    grid, cfg = model.occupancy_grid, model.config
+    bundle, _ = data.next_train(3)
+    o, d = bundle.origins.contiguous(), bundle.directions.contiguous()
+    kw = dict(near_plane=cfg.near_plane, far_plane=cfg.far_plane, render_step_size=cfg.render_step_size, stratified=True)
+
+    def sample():
+        out = grid.sampling(rays_o=o, rays_d=d, sigma_fn=None, alpha_thre=0.0, early_stop_eps=0.0, **kw)
+        return [t.clone() for t in out], grid.last_march_prefetched
+
+    torch.manual_seed(5)
+    ref, used = sample()
+    assert not used and ref[0].shape[0] > 0
+    torch.manual_seed(5)
+    assert grid.prefetch_march(o, d, **kw)
+    got, used = sample()
+    assert used
+    for a, b in zip(ref, got):
+        assert torch.equal(a, b)
+    # a later call without a new prefetch marches on its own
+    torch.manual_seed(5)
+    got, used = sample()
+    assert not used and all(torch.equal(a, b) for a, b in zip(ref, got))
+    # the grid changes between prefetch and use: the prefetched pass is dropped
+    torch.manual_seed(5)
+    assert grid.prefetch_march(o, d, **kw)
+    cells = torch.arange(0, grid.cells_per_lvl, 7, dtype=torch.int32, device="cuda:0")
+    grid.apply_update(cells, torch.zeros(cells.shape[0], device="cuda:0"), occ_thre=0.5, ema_decay=0.0)
+    torch.manual_seed(5)
+    fresh_after, used = sample()
+    assert not used
+    assert fresh_after[0].shape[0] < ref[0].shape[0]                     # cells were emptied: fewer samples
+
+
+def test_trainer_prefetches_the_next_batch(cuda):
+    """``train_iteration(..., next_ray_bundle=)``: every step that is not preceded by a grid update finds its sample count
+    on the host; the run trains like one without the prefetch (same data, different jitter draws)."""
+    from nersemble_amd.workloads import build_workload
+
+    def run(prefetch, steps=36):
+        torch.manual_seed(8)
+        trainer, data, _ = build_workload("p030_h16", device="cuda:0", small=True, n_rays=512)
+        trainer.prefetch_march = prefetch
+        batches = [data.next_train(s) for s in range(steps + 1)]
+        used, losses = [], []
+        for s in range(steps):
+            loss, _, _ = trainer.train_iteration(s, *batches[s], next_ray_bundle=batches[s + 1][0])
+            used.append(bool(trainer.model.occupancy_grid.last_march_prefetched))
+            losses.append(loss)
+        return used, [float(l) for l in losses]
+
+    used, losses = run(True)
+    assert used == [s > 0 and s % 16 != 0 for s in range(36)], used
+    used0, losses0 = run(False)
+    assert not any(used0)
+    assert np.isfinite(losses).all() and losses[-1] < 0.8 * losses[0]
+    assert abs(np.mean(losses[-8:]) - np.mean(losses0[-8:])) < 0.25 * np.mean(losses0[-8:])

@@ -9,6 +9,7 @@ import csv
 import glob
 import json
 import os
+import re
 import sys
 
 ENTRY_OF = {            # kernel-name prefix -> C-ABI entry point it belongs to
@@ -22,6 +23,15 @@ ENTRY_OF = {            # kernel-name prefix -> C-ABI entry point it belongs to
 }
 
 
+def kernel_base_name(raw):
+    """'void nsx::k<32, 4>(args)' / 'nsx::k(args)' / the mangled '_ZN3nsx<len><name>I...' -> 'nsx::k'."""
+    m = re.match(r"_ZN3nsx(\d+)", raw)
+    if m:
+        n = int(m.group(1))
+        return "nsx::" + raw[m.end():m.end() + n]
+    return raw.split("(")[0].replace("void ", "").split("<")[0].strip()
+
+
 def means(directory, counter):
     acc = collections.defaultdict(list)
     for path in glob.glob(os.path.join(directory, "**", "*counter_collection.csv"), recursive=True):
@@ -29,7 +39,7 @@ def means(directory, counter):
             for r in csv.DictReader(f):
                 if r["Counter_Name"] != counter:
                     continue
-                name = r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0].strip()
+                name = kernel_base_name(r["Kernel_Name"])
                 acc[name].append(float(r["Counter_Value"]))
     return {k: {"mean_kb": sum(v) / len(v), "dispatches": len(v)} for k, v in acc.items()}
 

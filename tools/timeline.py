@@ -1,36 +1,86 @@
-"""Development aid: print the device timeline of the last full training step in a rocprofv3 --kernel-trace CSV
-(start offset, duration, queue, kernel), with the idle gaps of the main queue.
+"""rocprofv3 --kernel-trace CSV -> the device timeline of one training step, averaged over the last steps of the run.
 
-    python tools/timeline.py OUT/**/_kernel_trace.csv [step_from_end=1]
+    python tools/timeline.py <dir with *kernel_trace.csv> [n_steps] > timeline.txt
+
+A step is delimited by the table optimizer (nsx::adam_hash_factored_kernel): step k = (end of Adam k-1, end of Adam k].
+Per kernel position inside the step: mean start offset from the step start, mean duration, mean idle time of the device
+in front of it (no kernel of any queue running), whether it overlapped another kernel.  The totals at the end split the
+step period into "some kernel running" and "device idle" -- the idle part is dependent-launch latency, not work.
 """
+import collections
 import csv
+import glob
+import os
+import re
 import sys
 
 
-def short(name: str) -> str:
-    name = name.split("(")[0].replace("void ", "")
-    if "<" in name:
-        head, _, tail = name.partition("<")
-        name = head.split("::")[-1] + "<" + tail[:48]
-    else:
-        name = name.split("::")[-1]
-    return name[:80]
+def short(name):
+    m = re.match(r"_ZN3nsx(\d+)", name)
+    if m:                                                    # some kernels arrive mangled
+        return "nsx::" + name[m.end():m.end() + int(m.group(1))]
+    name = name.replace("void ", "")
+    base = name.split("(")[0]
+    if len(base) > 70:
+        base = base[:67] + "..."
+    return base
 
 
-rows = []
-with open(sys.argv[1]) as f:
-    for r in csv.DictReader(f):
-        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), int(r["Queue_Id"]), r["Kernel_Name"]))
-rows.sort()
-back = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-marks = [i for i, r in enumerate(rows) if "march_count_kernel" in r[3]]
-lo, hi = marks[-1 - back], marks[-back]
-t0 = rows[lo][0]
-main_q = rows[lo][2]
-last_end = {}
-print(f"step = kernels {lo}..{hi}, {(rows[hi][0] - t0) / 1e6:.3f} ms; main queue {main_q}")
-for s, e, q, n in rows[lo:hi]:
-    gap = s - last_end.get(q, s)
-    flag = f"  (+{gap / 1e3:.0f} us idle on q{q})" if gap > 20000 else ""
-    print(f"{(s - t0) / 1e3:9.1f} us  {(e - s) / 1e3:8.1f} us  q{q}  {short(n)}{flag}")
-    last_end[q] = max(last_end.get(q, 0), e)
+def main():
+    directory = sys.argv[1]
+    n_steps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+    rows = []
+    for path in glob.glob(os.path.join(directory, "**", "*kernel_trace.csv"), recursive=True):
+        with open(path) as f:
+            for r in csv.DictReader(f):
+                rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"]),
+                             r.get("Queue_Id", "?")))
+    rows.sort()
+    adam_ends = [e for s, e, n, q in rows if n.startswith("nsx::adam_hash_factored_kernel")]
+    if len(adam_ends) < n_steps + 1:
+        print(f"only {len(adam_ends)} table-optimizer launches in the trace")
+        return
+    bounds = adam_ends[-(n_steps + 1):]
+    per_pos = collections.defaultdict(list)
+    busy_total = idle_total = 0
+    seqs = []
+    for k in range(n_steps):
+        t0, t1 = bounds[k], bounds[k + 1]
+        ks = [r for r in rows if t0 < r[1] <= t1 and r[0] >= t0 - 5_000_000]
+        ks.sort()
+        seqs.append(tuple(n for _, _, n, _ in ks))
+        horizon = t0                                        # the latest end of anything seen so far
+        busy = 0
+        for i, (s, e, n, q) in enumerate(ks):
+            idle_before = max(0, s - horizon)
+            overlapped = s < horizon
+            per_pos[i].append((n, q, max(s, t0) - t0, e - s, idle_before, overlapped))
+            if e > horizon:
+                busy += e - max(s, horizon)
+                horizon = e
+        busy_total += busy
+        idle_total += (t1 - t0) - busy
+    same = len(set(seqs)) == 1
+    print(f"steps analysed: {n_steps}; kernels per step: {sorted(set(len(s) for s in seqs))}; identical sequence: {same}")
+    print(f"mean step period {1e-6 * (bounds[-1] - bounds[0]) / n_steps:.3f} ms = busy "
+          f"{1e-6 * busy_total / n_steps:.3f} ms + device idle {1e-6 * idle_total / n_steps:.3f} ms")
+    print(f"{'#':>3} {'start us':>9} {'dur us':>8} {'idle us':>8} ovl q   kernel")
+    for i in sorted(per_pos):
+        v = per_pos[i]
+        names = collections.Counter(x[0] for x in v).most_common(1)[0][0]
+        mean = lambda j: sum(x[j] for x in v) / len(v)
+        print(f"{i:3d} {1e-3 * mean(2):9.1f} {1e-3 * mean(3):8.1f} {1e-3 * mean(4):8.1f} "
+              f"{'*' if sum(x[5] for x in v) * 2 > len(v) else ' ':>3} {v[0][1]:<3} {names}")
+    by_name = collections.defaultdict(lambda: [0, 0.0, 0.0])
+    for i, v in per_pos.items():
+        for n, q, s, d, idle, o in v:
+            by_name[n][0] += 1
+            by_name[n][1] += d
+            by_name[n][2] += idle
+    print("\nper kernel name and step: launches, total us, idle us in front")
+    for n, (c, d, idle) in sorted(by_name.items(), key=lambda kv: -kv[1][1]):
+        print(f"{c / n_steps:6.1f} {1e-3 * d / n_steps:9.1f} {1e-3 * idle / n_steps:9.1f}  {n}")
+
+
+if __name__ == "__main__":
+    main()
