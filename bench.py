@@ -327,6 +327,7 @@ def main():
         trainer.early_table_step = True
     if os.environ.get("NSX_PREFETCH_MARCH") == "0":
         trainer.prefetch_march = False
+    table_opt = trainer.optimizers.get(trainer.group_of_tables())
 
     for s in range(a.preroll):                                   # optional: start the measurement from a settled state
         trainer.train_iteration(s, *data.next_train(s))
@@ -378,10 +379,13 @@ def main():
     SPLIT_SCATTER = bool(sink is not None and sink.split_scatter)
     _lib.profiler.watch = {"nsx_hash_ensemble_fwd", "nsx_hash_ensemble_bwd_factored", "nsx_hash_ensemble_bwd",
                            "nsx_hash_ensemble_bwd_scatter",
-                           "nsx_adam_hash_factored", "nsx_adam_dense", "nsx_deform_fwd", "nsx_deform_bwd",
+                           "nsx_adam_hash_factored", "nsx_adam_hash_factored_consume", "nsx_adam_dense",
+                           "nsx_deform_fwd", "nsx_deform_bwd",
                            "nsx_mlp_fwd", "nsx_mlp_bwd", "nsx_check_finite", "nsx_march_count", "nsx_march_fill",
                            "nsx_hash_grad_expand", "nsx_hash_grad_expand_f16", "nsx_adam_dense_f16grad",
                            "nsx_check_finite_f16"}
+    # (the variant of the table optimizer that also clears the gradient pieces it reads is priced as the optimizer pass)
+    _lib.profiler.alias = {"nsx_adam_hash_factored_consume": "nsx_adam_hash_factored"}
     if not a.no_kernel_events:
         _lib.profiler.prewarm(2 * 16 * a.steps + 64)
     if world > 1:
@@ -474,7 +478,8 @@ def main():
                                          "schedule, its result is not adopted" if a.grid == "frozen" else "live",
                        "rccl_ranks": world if (world > 1 and a.backend == "nccl") else 0,
                        "early_table_step": bool(trainer.early_table_step),
-                       "march_count_one_step_ahead": bool(trainer.prefetch_march)},
+                       "march_count_one_step_ahead": bool(trainer.prefetch_march),
+                       "table_adam_consumes_gradient": bool(getattr(table_opt, "consume_gradient", False))},
             "rays_per_sec": world * info["rays"] * a.steps / dt_max,
             "psnr_last": float(metrics["psnr"].detach()), "loss_last": float(loss.detach()),
             "roofline": roofline, "rooflines": rooflines, "native_kernel_ms": kernels,

@@ -380,6 +380,13 @@ int nsx_adam_hash_factored(const float* G, int n_slots, const float* code_table,
                            const float* window, int H, const nsx_grid_geom* g, float* master, float* exp_avg,
                            float* exp_avg_sq, nsx_half* tables_f16, float lr, float beta1, float beta2, float eps,
                            int64_t step, const float* inv_scale, const float* found_inf, void* stream);
+/* The same step, CONSUMING G: every 16-byte piece of G that holds a non-zero value is written back as zeros while it is
+ * read (also when the step is skipped because *found_inf != 0), so the buffer can take the next backward's scatter
+ * without a fill of its own.  G must be 16-byte aligned. */
+int nsx_adam_hash_factored_consume(float* G, int n_slots, const float* code_table, int64_t code_stride,
+                           const float* window, int H, const nsx_grid_geom* g, float* master, float* exp_avg,
+                           float* exp_avg_sq, nsx_half* tables_f16, float lr, float beta1, float beta2, float eps,
+                           int64_t step, const float* inv_scale, const float* found_inf, void* stream);
 int nsx_adam_dense(const float* grad, int64_t n, float* master, float* exp_avg, float* exp_avg_sq,
                    nsx_half* params_f16 /* may be NULL */, float lr, float beta1, float beta2, float eps,
                    int64_t step, const float* inv_scale, const float* found_inf, void* stream);

@@ -129,6 +129,9 @@ SIGNATURES = {
     "nsx_adam_hash_factored": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_void_p, c_int, _GEOM_P, c_void_p, c_void_p,
                                        c_void_p, c_void_p, c_float, c_float, c_float, c_float, c_int64, c_void_p,
                                        c_void_p, c_void_p]),
+    "nsx_adam_hash_factored_consume": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_void_p, c_int, _GEOM_P, c_void_p, c_void_p,
+                                       c_void_p, c_void_p, c_float, c_float, c_float, c_float, c_int64, c_void_p,
+                                       c_void_p, c_void_p]),
     "nsx_adam_dense": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_float,
                                c_float, c_int64, c_void_p, c_void_p, c_void_p]),
     "nsx_hash_indices": (c_int, [c_void_p, c_int64, _GEOM_P, c_void_p, c_void_p]),
@@ -153,6 +156,7 @@ class KernelProfiler:
         self.enabled = False
         self.watch = None          # optional set of entry-point names to time (None = all)
         self.records = []          # (name, start_event, end_event, int_args)
+        self.alias = {}            # entry point -> the name it is booked under (variants of one kernel)
         self._pool = []
 
     def reset(self):
@@ -199,7 +203,7 @@ class _LibProxy:
             s.record()
             rc = fn(*args)
             e.record()
-            profiler.records.append((name, s, e, [a for a in args if isinstance(a, int)]))
+            profiler.records.append((profiler.alias.get(name, name), s, e, [a for a in args if isinstance(a, int)]))
             return rc
         return timed
 

@@ -42,13 +42,18 @@ __global__ __launch_bounds__(256) void check_finite_kernel(const float* __restri
 // one contiguous run per slot) is staged through LDS with coalesced loads; every thread then owns 4 consecutive
 // parameters (float4 streams of master / m / v, half4 store of the working copy) and forms their gradient from the
 // LDS-resident G values and code rows.
-template <int HP>
+// CLEAR: the kernel CONSUMES G -- every 16-byte piece it reads that holds a non-zero value is written back as zeros, so
+// the buffer is ready for the next backward's scatter without a 1.6 GB fill in front of it (only the pieces the last
+// scatter touched are written: a few percent of G once the occupancy grid has pruned the scene).  A skipped step
+// (found_inf) still clears.
+template <int HP, bool CLEAR>
 __global__ __launch_bounds__(256) void adam_hash_factored_kernel(
-    const float* __restrict__ G, int n_slots, const float* __restrict__ code, int64_t code_stride,
+    float* __restrict__ G, int n_slots, const float* __restrict__ code, int64_t code_stride,
     const float* __restrict__ window, int Hreal, uint64_t total, float* __restrict__ master, float* __restrict__ m,
     float* __restrict__ v, half_t* __restrict__ f16, AdamHyper hy, const float* __restrict__ inv_scale,
     const float* __restrict__ found_inf) {
-    if (found_inf && found_inf[0] != 0.f) return;
+    const bool skip = found_inf && found_inf[0] != 0.f;
+    if (skip && !CLEAR) return;
     constexpr int HV = HP >= 4 ? 4 : HP;                 // parameters per thread (vector width)
     constexpr int TPE = 2 * HP / HV;                     // threads per entry
     constexpr int EPB = 256 / TPE;                       // entries per block tile
@@ -74,7 +79,7 @@ __global__ __launch_bounds__(256) void adam_hash_factored_kernel(
         const uint64_t at = (e * 2ull + f) * HP + hq * HV;
         // the three parameter streams are requested first: their HBM latency overlaps the staging of G below
         float pp[HV], mm[HV], vv[HV];
-        if (live) {
+        if (live && !skip) {
 #pragma unroll
             for (int k = 0; k < HV; ++k) {          // streamed once per step: keep them out of the way of G in L2
                 pp[k] = __builtin_nontemporal_load(master + at + k);
@@ -90,16 +95,25 @@ __global__ __launch_bounds__(256) void adam_hash_factored_kernel(
             for (int i = threadIdx.x; i < n_slots * Q; i += blockDim.x) {
                 const int sl = i / Q, j = (i % Q) * 4;
                 const uint64_t ge = e0 * 2ull + j;
-                const float* src = G + (uint64_t)sl * total * 2ull + ge;
+                float* src = G + (uint64_t)sl * total * 2ull + ge;
                 float4 g4;
-                if (ge + 3 < total * 2ull) g4 = *reinterpret_cast<const float4*>(src);
-                else g4 = make_float4(ge < total * 2ull ? src[0] : 0.f, ge + 1 < total * 2ull ? src[1] : 0.f,
-                                      ge + 2 < total * 2ull ? src[2] : 0.f, 0.f);
+                if (ge + 3 < total * 2ull) {
+                    g4 = *reinterpret_cast<const float4*>(src);
+                    if (CLEAR && (g4.x != 0.f || g4.y != 0.f || g4.z != 0.f || g4.w != 0.f))
+                        *reinterpret_cast<float4*>(src) = make_float4(0.f, 0.f, 0.f, 0.f);
+                } else {
+                    g4 = make_float4(ge < total * 2ull ? src[0] : 0.f, ge + 1 < total * 2ull ? src[1] : 0.f,
+                                     ge + 2 < total * 2ull ? src[2] : 0.f, 0.f);
+                    if (CLEAR) {
+                        for (int t = 0; t < 3; ++t)
+                            if (ge + t < total * 2ull) src[t] = 0.f;
+                    }
+                }
                 *reinterpret_cast<float4*>(gs + sl * (EPB * 2) + j) = g4;
             }
         }
         __syncthreads();
-        if (!live) continue;
+        if (!live || skip) continue;
         float g[HV];
 #pragma unroll
         for (int k = 0; k < HV; ++k) g[k] = 0.f;
@@ -316,8 +330,8 @@ static AdamHyper make_hyper(float lr, float beta1, float beta2, float eps, int64
     return h;
 }
 
-template <int HP>
-static int launch_adam_factored(const float* G, int n_slots, const float* code, int64_t code_stride, const float* window,
+template <int HP, bool CLEAR>
+static int launch_adam_factored(float* G, int n_slots, const float* code, int64_t code_stride, const float* window,
                                 int H, uint64_t total, float* master, float* m, float* v, nsx_half* f16, AdamHyper hy,
                                 const float* inv_scale, const float* found_inf, hipStream_t st) {
     constexpr int HV = HP >= 4 ? 4 : HP;
@@ -325,11 +339,34 @@ static int launch_adam_factored(const float* G, int n_slots, const float* code, 
     const size_t smem = ((size_t)n_slots * HP + (size_t)n_slots * EPB * 2) * sizeof(float);
     // 4 blocks (16 waves) per CU: measured 2.1-2.2 ms against 2.4-2.55 ms with 8 blocks per CU on the 12 GB pass -- the
     // seven interleaved streams keep more DRAM pages open with fewer concurrent tiles (tools/adam_bench.py)
-    hipLaunchKernelGGL((adam_hash_factored_kernel<HP>), dim3(num_cus() * 4), dim3(256), smem, st, G, n_slots, code,
+    hipLaunchKernelGGL((adam_hash_factored_kernel<HP, CLEAR>), dim3(num_cus() * 4), dim3(256), smem, st, G, n_slots, code,
                        code_stride, window, H, total, master, m, v, reinterpret_cast<half_t*>(f16), hy, inv_scale,
                        found_inf);
     NSX_LAUNCH_CHECK("nsx_adam_hash_factored launch");
     return NSX_OK;
+}
+
+template <bool CLEAR>
+static int adam_hash_factored_entry(float* G, int n_slots, const float* code_table, int64_t code_stride,
+                                    const float* window, int H, const nsx_grid_geom* g, float* master, float* exp_avg,
+                                    float* exp_avg_sq, nsx_half* tables_f16, float lr, float beta1, float beta2, float eps,
+                                    int64_t step, const float* inv_scale, const float* found_inf, void* stream) {
+    NSX_REQUIRE(G && code_table && g && master && exp_avg && exp_avg_sq && tables_f16, "nsx_adam_hash_factored: NULL argument");
+    NSX_REQUIRE(H >= 1 && H <= 32, "nsx_adam_hash_factored: H=%d not in [1,32]", H);
+    NSX_REQUIRE(n_slots >= 1 && n_slots <= NSX_MAX_SLOTS, "nsx_adam_hash_factored: n_slots=%d not in [1,%d]", n_slots, NSX_MAX_SLOTS);
+    NSX_REQUIRE(step >= 1, "nsx_adam_hash_factored: step must be >= 1");
+    NSX_REQUIRE((reinterpret_cast<uintptr_t>(G) & 15) == 0, "nsx_adam_hash_factored: G must be 16-byte aligned");
+    const uint64_t total = g->offset[g->n_levels];
+    const AdamHyper hy = make_hyper(lr, beta1, beta2, eps, step);
+    hipStream_t st = (hipStream_t)stream;
+#define NSX_ADAM_CASE(HP) case HP: return launch_adam_factored<HP, CLEAR>(G, n_slots, code_table, code_stride, window, H, \
+        total, master, exp_avg, exp_avg_sq, tables_f16, hy, inv_scale, found_inf, st);
+    switch (nsx_padded_grids(H)) {
+        NSX_ADAM_CASE(1) NSX_ADAM_CASE(2) NSX_ADAM_CASE(4) NSX_ADAM_CASE(8) NSX_ADAM_CASE(16) NSX_ADAM_CASE(32)
+    }
+#undef NSX_ADAM_CASE
+    set_error("nsx_adam_hash_factored: unsupported H=%d", H);
+    return NSX_ERR_UNSUPPORTED;
 }
 
 }  // namespace nsx
@@ -351,21 +388,17 @@ int nsx_adam_hash_factored(const float* G, int n_slots, const float* code_table,
                            const float* window, int H, const nsx_grid_geom* g, float* master, float* exp_avg,
                            float* exp_avg_sq, nsx_half* tables_f16, float lr, float beta1, float beta2, float eps,
                            int64_t step, const float* inv_scale, const float* found_inf, void* stream) {
-    NSX_REQUIRE(G && code_table && g && master && exp_avg && exp_avg_sq && tables_f16, "nsx_adam_hash_factored: NULL argument");
-    NSX_REQUIRE(H >= 1 && H <= 32, "nsx_adam_hash_factored: H=%d not in [1,32]", H);
-    NSX_REQUIRE(n_slots >= 1 && n_slots <= NSX_MAX_SLOTS, "nsx_adam_hash_factored: n_slots=%d not in [1,%d]", n_slots, NSX_MAX_SLOTS);
-    NSX_REQUIRE(step >= 1, "nsx_adam_hash_factored: step must be >= 1");
-    const uint64_t total = g->offset[g->n_levels];
-    const AdamHyper hy = make_hyper(lr, beta1, beta2, eps, step);
-    hipStream_t st = (hipStream_t)stream;
-#define NSX_ADAM_CASE(HP) case HP: return launch_adam_factored<HP>(G, n_slots, code_table, code_stride, window, H, total, \
-        master, exp_avg, exp_avg_sq, tables_f16, hy, inv_scale, found_inf, st);
-    switch (nsx_padded_grids(H)) {
-        NSX_ADAM_CASE(1) NSX_ADAM_CASE(2) NSX_ADAM_CASE(4) NSX_ADAM_CASE(8) NSX_ADAM_CASE(16) NSX_ADAM_CASE(32)
-    }
-#undef NSX_ADAM_CASE
-    set_error("nsx_adam_hash_factored: unsupported H=%d", H);
-    return NSX_ERR_UNSUPPORTED;
+    return adam_hash_factored_entry<false>(const_cast<float*>(G), n_slots, code_table, code_stride, window, H, g, master,
+                                           exp_avg, exp_avg_sq, tables_f16, lr, beta1, beta2, eps, step, inv_scale,
+                                           found_inf, stream);
+}
+
+int nsx_adam_hash_factored_consume(float* G, int n_slots, const float* code_table, int64_t code_stride,
+                                   const float* window, int H, const nsx_grid_geom* g, float* master, float* exp_avg,
+                                   float* exp_avg_sq, nsx_half* tables_f16, float lr, float beta1, float beta2, float eps,
+                                   int64_t step, const float* inv_scale, const float* found_inf, void* stream) {
+    return adam_hash_factored_entry<true>(G, n_slots, code_table, code_stride, window, H, g, master, exp_avg, exp_avg_sq,
+                                          tables_f16, lr, beta1, beta2, eps, step, inv_scale, found_inf, stream);
 }
 
 int nsx_adam_dense(const float* grad, int64_t n, float* master, float* exp_avg, float* exp_avg_sq,

@@ -191,7 +191,7 @@ class _MainPass(torch.autograd.Function):
         G, dtab = None, None
         if need_tab:
             if sink is not None:
-                G = sink.buffer_for(code_h, inp.window, n_rows, geom.total_entries)
+                G = sink.buffer_for(code_h, inp.window, n_rows, geom.total_entries, n_samples=S)
             else:
                 G = torch.zeros((n_rows, geom.total_entries, 2), dtype=f32, device=dev)
         dcode_s = (torch.zeros if inp.n_dev is not None else torch.empty)((S, H), dtype=f32, device=dev) \

@@ -8,6 +8,7 @@ and the fp32 master and writes the fp16 working copy.  ``NativeGradScaler`` keep
 scale / found_inf on the device so the table gradient never needs its own unscale pass.
 """
 import ctypes as C
+import os
 from typing import List, Optional
 
 import torch
@@ -45,6 +46,11 @@ class HashTableAdam(torch.optim.Optimizer):
         self._early = (found_inf, inv_scale, side_stream)
         self.stepped_early = False
         sink.on_complete = self._early_step
+
+    # the optimizer pass clears the pieces of G it finds non-zero while it reads them (nsx_adam_hash_factored_consume):
+    # no 1.6 GB fill in front of the next backward's scatter.  Off (A/B measurements): the backward clears G itself.
+    consume_gradient = os.environ.get("NSX_ADAM_CONSUMES_G", "1") == "1"
+    consume_density_limit = 0.5      # ... while the scatter is expected to touch less than this share of G's sectors
 
     def disarm_early_step(self) -> None:
         self._early = None
@@ -124,11 +130,17 @@ class HashTableAdam(torch.optim.Optimizer):
         f16 = he.half_tables()            # make sure the working copy exists on the right device
         if len(entries) == 1 and p.grad is None:
             e = entries[0]
-            check(lib().nsx_adam_hash_factored(ptr(e["G"]), e["n_rows"], ptr(e["code"]), e["code"].stride(0),
-                                               ptr(e["window"]), he.n_hash_encodings, C.byref(he.geom), ptr(p.data),
-                                               ptr(st["exp_avg"]), ptr(st["exp_avg_sq"]), ptr(f16), group["lr"], b1, b2,
-                                               group["eps"], st["step"], ptr(inv_scale), ptr(found_inf), stream()),
-                  "nsx_adam_hash_factored")
+            # (worth it while the scatter touches a minority of G's 32-byte sectors -- about 80 per sample; on a densely
+            # written G the clearing stores cost what the fill they replace costs, and the plain pass is the one whose
+            # bytes bench.py prices)
+            sparse = 0 < sink.samples_scattered * 80 < self.consume_density_limit * (e["G"].numel() // 8)
+            consume = self.consume_gradient and sparse and sink.is_persistent(e["G"])
+            fn = lib().nsx_adam_hash_factored_consume if consume else lib().nsx_adam_hash_factored
+            check(fn(ptr(e["G"]), e["n_rows"], ptr(e["code"]), e["code"].stride(0), ptr(e["window"]), he.n_hash_encodings,
+                     C.byref(he.geom), ptr(p.data), ptr(st["exp_avg"]), ptr(st["exp_avg_sq"]), ptr(f16), group["lr"], b1,
+                     b2, group["eps"], st["step"], ptr(inv_scale), ptr(found_inf), stream()), "nsx_adam_hash_factored")
+            if consume:
+                sink.mark_cleared(e["G"])              # (event on the stream the optimizer runs on)
         else:
             grad = p.grad.contiguous() if p.grad is not None else torch.zeros_like(p)
             for e in entries:      # several code tables in one step: expand each into the dense gradient

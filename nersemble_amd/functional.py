@@ -75,6 +75,8 @@ class FactoredGradSink:
         self._cache = {}
         self.nonfinite = None        # device float: set by the backward kernel when it adds an inf/NaN to a G
         self.pending = 0             # forwards recorded for autograd whose backward has not run yet
+        self.pre_cleared = None      # (G, event): the cached buffer was cleared ahead of time on another stream
+        self.samples_scattered = 0   # samples whose gradient the step's backward calls add to G (0: unknown)
         self.on_complete = None      # called inside the backward once the LAST pending one has added its share to G
         # Optional (NSX_SPLIT_SCATTER=1): the scatter into G as its own kernel on its own stream beside the gather half of
         # the HashEnsemble backward and the deformation field's backward (which only needs the gather's dL/dx).
@@ -110,11 +112,14 @@ class FactoredGradSink:
             self.on_complete()
 
     def buffer_for(self, code: torch.Tensor, window: Optional[torch.Tensor], n_rows: int, total_entries: int,
-                   zero: bool = True):
+                   zero: bool = True, n_samples: int = 0):
         """The G this backward adds to.  ``zero=False``: a NEW buffer is returned un-cleared with ``fresh`` set in its
         entry -- the caller clears it right in front of its scatter, on the scatter's stream (freshly written zero lines
         are what the atomics then hit in the Infinity Cache)."""
         key = (code.data_ptr(), n_rows, None if window is None else window.data_ptr())
+        if not self.entries:
+            self.samples_scattered = 0
+        self.samples_scattered += int(n_samples)        # (an upper bound under device-side counts: the capacity)
         for e in self.entries:
             if e["key"] == key:
                 return e["G"]
@@ -128,10 +133,28 @@ class FactoredGradSink:
             self._cache = {n_rows: G}          # keep at most one persistent buffer
         if any(e["G"] is G for e in self.entries):
             G = torch.empty_like(G)
-        if zero:
+        pre = self.pre_cleared
+        cleared = pre is not None and pre[0] is G
+        if cleared:
+            # left all zeros by the optimizer pass that consumed it (mark_cleared)
+            self.pre_cleared = None
+            torch.cuda.current_stream(G.device).wait_event(pre[1])
+        elif zero:
             G.zero_()
-        self.entries.append({"G": G, "code": code, "window": window, "n_rows": n_rows, "key": key, "fresh": not zero})
+        self.entries.append({"G": G, "code": code, "window": window, "n_rows": n_rows, "key": key,
+                             "fresh": not zero and not cleared})
         return G
+
+    def is_persistent(self, G: torch.Tensor) -> bool:
+        """Is ``G`` the buffer the next step's ``buffer_for`` will hand out again?"""
+        return any(G is c for c in self._cache.values())
+
+    def mark_cleared(self, G: torch.Tensor) -> None:
+        """The table optimizer consumed ``G`` and left it all zeros (nsx_adam_hash_factored_consume), on the CURRENT
+        stream: the next ``buffer_for`` waits for that point instead of clearing the buffer."""
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(G.device))
+        self.pre_cleared = (G, ev)
 
     def clear(self):
         self.entries = []
@@ -178,7 +201,7 @@ class _HashEnsembleFn(torch.autograd.Function):
             use_sink = ctx.sink is not None and need_tab
             split = use_sink and ctx.sink.split_scatter and x.is_cuda
             if use_sink:
-                G = ctx.sink.buffer_for(code, window, n_rows, geom.total_entries, zero=not split)
+                G = ctx.sink.buffer_for(code, window, n_rows, geom.total_entries, zero=not split, n_samples=x.shape[0])
             elif need_tab:
                 G = torch.zeros((n_rows, geom.total_entries, 2), dtype=torch.float32, device=x.device)
             if split:

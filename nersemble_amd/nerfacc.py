@@ -284,14 +284,22 @@ class OccGridEstimator(nn.Module):
             done.record(side)
         for t in (near_planes, packed, binary):               # consumed on the caller's stream later
             t.record_stream(main)
-        self._prefetched = {"key": key, "rays": (rays_o, rays_d, t_min), "near_planes": near_planes, "packed": packed,
-                            "total_host": total_host, "done": done, "keep": (counts, total)}
+        # (two are held at most: the pass for the step whose forward has not run yet, and the one for the step after)
+        held = getattr(self, "_prefetched", None) or []
+        held.append({"key": key, "rays": (rays_o, rays_d, t_min), "near_planes": near_planes, "packed": packed,
+                     "total_host": total_host, "done": done, "keep": (counts, total)})
+        self._prefetched = held[-2:]
         return True
 
     def _take_prefetched(self, key):
-        pre = getattr(self, "_prefetched", None)
-        self._prefetched = None
-        return pre if (pre is not None and pre["key"] == key) else None
+        """The prefetched counting pass if it is for exactly this call (it then leaves the estimator); one that is for
+        another call -- the NEXT step's, issued before this step's own sampling -- stays."""
+        held = getattr(self, "_prefetched", None) or []
+        for i, pre in enumerate(held):
+            if pre["key"] == key:
+                del held[i]
+                return pre
+        return None
 
     @torch.no_grad()
     def traverse(self, rays_o: Tensor, rays_d: Tensor, near_planes: Tensor, far_plane: float, step: float,
@@ -348,7 +356,7 @@ class OccGridEstimator(nn.Module):
         if t_max is not None:
             raise NotImplementedError("per-ray t_max is not used by NeRSemble (ray bundles carry no fars)")
         counted = None
-        if getattr(self, "_prefetched", None) is not None:
+        if getattr(self, "_prefetched", None):
             counted = self._take_prefetched(self._march_key(rays_o, rays_d, near_plane, far, render_step_size, stratified,
                                                             t_min))
         if counted is not None:

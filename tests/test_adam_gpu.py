@@ -209,3 +209,50 @@ def test_small_group_adam_equals_torch_adam_with_gradscaler_semantics(cuda):
     fresh = SmallGroupAdam(make()[0], lr=5e-3, eps=eps)
     fresh.load_state_dict(sd)
     assert fresh.step_count == 5
+
+
+def test_optimizer_pass_consumes_the_factored_gradient(cuda):
+    """nsx_adam_hash_factored_consume: same update as nsx_adam_hash_factored, G all zeros afterwards -- also when the
+    step is skipped -- and the next backward adds to that buffer without a fill of its own."""
+    from nersemble_amd.engine.hash_adam import HashTableAdam
+    H, B, T = 32, 3000, 5
+    g = torch.Generator(device=cuda).manual_seed(4)
+    x = torch.rand((B, 3), device=cuda, generator=g)
+    emb = torch.randn((T, H), device=cuda, generator=g)
+    slot = torch.randint(0, T, (B,), device=cuda, generator=g, dtype=torch.int32)
+    dout = torch.randn((B, 12), device=cuda, generator=g).half()
+    inv = torch.tensor([1.0], device=cuda)
+    a, b = _he(H, cuda), _he(H, cuda)
+    opt_a = HashTableAdam(a, lr=5e-3, eps=1e-15, factored=True)
+    opt_b = HashTableAdam(b, lr=5e-3, eps=1e-15, factored=True)
+    opt_a.consume_density_limit = float("inf")          # (the toy table is written densely: take the pass anyway)
+    opt_b.consume_gradient = False
+    for it in range(3):
+        for he, opt in ((a, opt_a), (b, opt_b)):
+            opt.zero_grad()
+            he(x, emb, window_hash_encodings=None, code_index=slot).backward(dout * (1.0 + it))
+            found = torch.zeros(1, device=cuda)
+            opt.check_finite(found)
+            G = he.grad_sink.entries[0]["G"]
+            assert G.abs().sum().item() > 0
+            if he is a and it > 0:
+                assert G.data_ptr() == last_G.data_ptr()                  # the persistent buffer, handed out again
+            opt.step(found_inf=found, inv_scale=inv)
+            if he is a:
+                last_G = G
+                assert not G.any().item()                                  # consumed
+                assert he.grad_sink.pre_cleared is not None and he.grad_sink.pre_cleared[0] is G
+            else:
+                assert G.any().item()
+        # (two runs of the atomic scatter: each is within 5e-5 of the exact sum on the entries whose gradient is pure
+        # cancellation noise -- see test_factored_adam_equals_torch_adam -- so the pair is compared at twice that)
+        d = (a.tables - b.tables).abs()
+        assert d.max().item() <= 1e-4 and d.mean().item() <= 2e-7, (it, d.max().item(), d.mean().item())
+    # a skipped step leaves the parameters alone and still hands back a clean buffer
+    before = a.tables.detach().clone()
+    opt_a.zero_grad()
+    a(x, emb, window_hash_encodings=None, code_index=slot).backward(dout)
+    G = a.grad_sink.entries[0]["G"]
+    opt_a.step(found_inf=torch.ones(1, device=cuda), inv_scale=inv)
+    assert torch.equal(a.tables.detach(), before)
+    assert not G.any().item()

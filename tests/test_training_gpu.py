@@ -577,7 +577,7 @@ def test_trainer_prefetches_the_next_batch(cuda):
         for s in range(steps):
             loss, _, _ = trainer.train_iteration(s, *batches[s], next_ray_bundle=batches[s + 1][0])
             used.append(bool(trainer.model.occupancy_grid.last_march_prefetched))
-            losses.append(loss)
+            losses.append(loss.detach())
         return used, [float(l) for l in losses]
 
     used, losses = run(True)
