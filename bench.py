@@ -42,29 +42,20 @@ DEFORM_FWD_FLOPS = 253952.0     # 2 * 126 976 MAC per sample
 
 
 SPLIT_SCATTER = True            # set in main() from the trainer's gradient sink: the factored backward runs as two kernels
-GRIDS_ON = None                 # hash grids the coarse-to-fine window has switched on (None: all): the kernels fetch only those
-
-
-def _table_row_bytes(H: int) -> float:
-    """Bytes of one trilinear corner's table row that the encoder kernels fetch: 4 B per grid and feature pair, in 16-byte
-    lane pieces of 8 grids per feature (csrc/hash_ensemble.hip); grids the window switches off are not fetched."""
-    if GRIDS_ON is None or H < 8:
-        return 4.0 * H
-    return 2.0 * 16.0 * min(H // 8, (GRIDS_ON + 7) // 8)
 
 
 def kernel_model(name: str, ints, H: int, total_entries: int):
     """(bound, work per launch) for the kernels with a stated algorithmic cost.
     `ints` = the integer arguments of the C-ABI call as recorded by the profiler."""
     if name == "nsx_hash_ensemble_fwd":                       # (B, H, code_stride)
-        return "hbm", ints[0] * (128.0 * _table_row_bytes(H) + 80.0)
+        return "hbm", ints[0] * (512.0 * H + 80.0)
     if name == "nsx_hash_ensemble_bwd_factored":              # (B, H, code_stride, n_slots)
         # table gather for dL/dcode and dL/dx (512 H) + read-modify-write of G (128 corners x 2 floats x 2) + fp16
         # dout (64) + dcode (4 H) + x, dx, slot (28): the factored gradient moves FEWER bytes than SURVEY's dense
         # count 1024 H + 76 -- the kernel is priced against what it has to move
         if SPLIT_SCATTER:                                     # gather half only: table reads + dout + dcode + x, dx, slot
-            return "hbm", ints[0] * (128.0 * _table_row_bytes(H) + 64.0 + 4.0 * H + 28.0)
-        return "hbm", ints[0] * (128.0 * _table_row_bytes(H) + 2048.0 + 64.0 + 4.0 * H + 28.0)
+            return "hbm", ints[0] * (512.0 * H + 64.0 + 4.0 * H + 28.0)
+        return "hbm", ints[0] * (512.0 * H + 2048.0 + 64.0 + 4.0 * H + 28.0)
     if name == "nsx_hash_ensemble_bwd_scatter":               # (B, n_slots, blocks_per_cu): read-modify-write of G + dout
         # + x + slot.  Priced against HBM for uniformity; what bounds it is the rate of memory-side fp32 atomics
         # (measured ~14-20 G 32-B sectors/s; 64 sector requests per sample without duplicate merging)
@@ -78,12 +69,6 @@ def kernel_model(name: str, ints, H: int, total_entries: int):
         params = total_entries * 2.0 * Hp
         # master, m, v read + written (24 B) + fp16 copy written (2 B) per parameter + G read once
         return "hbm", params * 26.0 + ints[0] * total_entries * 8.0
-    if name == "nsx_adam_hash_factored_prefix":               # (consume, h_active, n_slots, code_stride, H, step)
-        Hp = 1
-        while Hp < H:
-            Hp *= 2
-        h_touched = min(Hp, (ints[1] + 3) // 4 * 4)           # grids beyond the window's frontier are left alone
-        return "hbm", total_entries * 2.0 * h_touched * 26.0 + ints[2] * total_entries * 8.0
     if name == "nsx_adam_dense_f16grad":                      # (n, step): the rank's shard in data-parallel runs
         return "hbm", ints[0] * 28.0                          # fp16 gradient + master / m / v read + written + fp16 copy
     if name == "nsx_deform_fwd":                              # (S, code_stride)
@@ -155,35 +140,6 @@ def steady_state(trainer, data, first_step: int, settle_at: int, rays: int, n_ti
     return {"from_step": step, "steps": n_timed, "ms_per_step": dt / n_timed * 1e3, "value": samples / dt,
             "unit": "ray-samples/s", "rays_per_sec": rays * n_timed / dt, "samples_per_step_min_max": [min(counts), max(counts)],
             "psnr": float(metrics["psnr"].detach())}
-
-
-def schedule_start(a, dev: str):
-    """The same workload on ITS OWN coarse-to-fine schedule from step 0 (single GPU): `warmup` + `steps` steps timed like
-    the headline, then the steady state.  One hash grid is switched on for the first 40 000 steps of the default schedule
-    (train_nersemble.py:77-78) and the kernels neither fetch nor update the other 31 (exact: their blend weight, gradient
-    and Adam moments are zero) -- this block is what those steps cost; the headline value prices a step with every grid
-    on."""
-    from nersemble_amd.workloads import build_workload
-    torch.manual_seed(19980801)
-    trainer, data, info = build_workload(a.workload, device=dev)
-    batches = [data.next_train(s) for s in range(a.warmup + a.steps + 1)]
-    for s in range(a.warmup):
-        trainer.train_iteration(s, *batches[s], next_ray_bundle=batches[s + 1][0])
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    samples = 0
-    for s in range(a.warmup, a.warmup + a.steps):
-        _, _, metrics = trainer.train_iteration(s, *batches[s], next_ray_bundle=batches[s + 1][0])
-        samples += metrics["num_samples_per_batch"]
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    trainer.flush_scheduler_step()
-    res = {"grids_switched_on": int(trainer.model.field.hash_ensemble.last_grids_on), "steps": a.steps, "warmup": a.warmup,
-           "ms_per_step": dt / a.steps * 1e3, "value": int(samples) / dt, "unit": "ray-samples/s",
-           "rays_per_sec": info["rays"] * a.steps / dt, "samples_per_step": int(samples) / a.steps}
-    if a.steady_after > 0:
-        res["steady_state"] = steady_state(trainer, data, a.warmup + a.steps, a.steady_after, info["rays"])
-    return res
 
 
 def kernels_alone(trainer, H: int, log2_s: int = 20, iters: int = 10):
@@ -323,13 +279,6 @@ def main():
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="weak: 4096 rays per rank; strong: the 4096-ray batch is sliced 4096/N rays per rank with global "
                          "loss normalisers (SURVEY.md 8e)")
-    ap.add_argument("--grids", choices=("open", "schedule"), default="open",
-                    help="open (default): every hash grid is switched on in the timed region -- the cost of a step once "
-                         "the coarse-to-fine window has opened (after step 80 000 of the default schedule), which is what "
-                         "the headline value prices.  schedule: the workload's own schedule from step 0 (one grid on for "
-                         "the first 40 000 steps: the kernels skip the other 31, see DESIGN.md); the default run reports "
-                         "that phase beside the headline as `schedule_start`")
-    ap.add_argument("--no-schedule-start", action="store_true", help="skip the `schedule_start` block")
     ap.add_argument("--no-kernels-alone", action="store_true", help="skip the stand-alone kernel timings after the run")
     ap.add_argument("--preroll", type=int, default=0,
                     help="untimed training steps BEFORE the warm-up (e.g. 600: the occupancy grid and the visibility "
@@ -369,8 +318,7 @@ def main():
     if a.scaling == "strong" and world > 1:
         n_rays = WORKLOADS[a.workload]["rays"] // world
     trainer, data, info = build_workload(a.workload, device=dev, rank=rank, world_size=world, n_rays=n_rays,
-                                         global_loss_normalisers=(a.scaling == "strong" and world > 1),
-                                         window_hash=(0, 1) if a.grids == "open" else None)
+                                         global_loss_normalisers=(a.scaling == "strong" and world > 1))
     if a.reserve_gb > 0:
         reserve = torch.empty(int(a.reserve_gb * 2 ** 30), dtype=torch.uint8, device=dev)
         del reserve
@@ -426,21 +374,18 @@ def main():
     gc.disable()
     # HIP events only around the calls that are priced against a roofline (+ the other large kernels), allocated
     # before the timed region
-    global SPLIT_SCATTER, GRIDS_ON
-    GRIDS_ON = None if a.grids == "open" else int(trainer.model.field.hash_ensemble.last_grids_on)
+    global SPLIT_SCATTER
     sink = trainer.model.field.hash_ensemble.grad_sink
     SPLIT_SCATTER = bool(sink is not None and sink.split_scatter)
     _lib.profiler.watch = {"nsx_hash_ensemble_fwd", "nsx_hash_ensemble_bwd_factored", "nsx_hash_ensemble_bwd",
                            "nsx_hash_ensemble_bwd_scatter",
-                           "nsx_adam_hash_factored", "nsx_adam_hash_factored_consume", "nsx_adam_hash_factored_prefix",
-                           "nsx_adam_dense",
+                           "nsx_adam_hash_factored", "nsx_adam_hash_factored_consume", "nsx_adam_dense",
                            "nsx_deform_fwd", "nsx_deform_bwd",
                            "nsx_mlp_fwd", "nsx_mlp_bwd", "nsx_check_finite", "nsx_march_count", "nsx_march_fill",
                            "nsx_hash_grad_expand", "nsx_hash_grad_expand_f16", "nsx_adam_dense_f16grad",
                            "nsx_check_finite_f16"}
     # (the variant of the table optimizer that also clears the gradient pieces it reads is priced as the optimizer pass)
     _lib.profiler.alias = {"nsx_adam_hash_factored_consume": "nsx_adam_hash_factored"}
-    ALIAS_AFTER_PRICING = {"nsx_adam_hash_factored_prefix": "nsx_adam_hash_factored"}
     if not a.no_kernel_events:
         _lib.profiler.prewarm(2 * 16 * a.steps + 64)
     if world > 1:
@@ -470,18 +415,12 @@ def main():
 
     if rank == 0:
         prof = _lib.profiler.summary()
-        for variant, booked in ALIAS_AFTER_PRICING.items():      # variants of one kernel: one line in the report
-            if variant in prof:
-                v, t = prof.pop(variant), prof.setdefault(booked, {"calls": 0, "total_ms": 0.0})
-                t["calls"] += v["calls"]
-                t["total_ms"] += v["total_ms"]
-                t["avg_ms"] = t["total_ms"] / t["calls"]
         total_entries = trainer.model.field.hash_ensemble.geom.total_entries
         work = {}
         for name, st, en, ints in _lib.profiler.records:
             bound, w = kernel_model(name, ints, H, total_entries)
             if bound:
-                d = work.setdefault(ALIAS_AFTER_PRICING.get(name, name), {"bound": bound, "work": 0.0})
+                d = work.setdefault(name, {"bound": bound, "work": 0.0})
                 d["work"] += w
         rooflines = {}
         for name, d in work.items():
@@ -540,10 +479,7 @@ def main():
                        "rccl_ranks": world if (world > 1 and a.backend == "nccl") else 0,
                        "early_table_step": bool(trainer.early_table_step),
                        "march_count_one_step_ahead": bool(trainer.prefetch_march),
-                       "table_adam_consumes_gradient": bool(getattr(table_opt, "consume_gradient", False)),
-                       "hash_grids_switched_on": int(trainer.model.field.hash_ensemble.last_grids_on),
-                       "hash_grid_window": "every grid on (the state after step 80 000 of the default schedule)"
-                                           if a.grids == "open" else "the workload's schedule from step 0"},
+                       "table_adam_consumes_gradient": bool(getattr(table_opt, "consume_gradient", False))},
             "rays_per_sec": world * info["rays"] * a.steps / dt_max,
             "psnr_last": float(metrics["psnr"].detach()), "loss_last": float(loss.detach()),
             "roofline": roofline, "rooflines": rooflines, "native_kernel_ms": kernels,
@@ -566,8 +502,6 @@ def main():
             out["kernels_alone"] = kernels_alone(trainer, H)
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(H)
-        if a.grids == "open" and not a.no_schedule_start and world == 1 and a.preroll == 0:
-            out["schedule_start"] = schedule_start(a, dev)          # (a second model: 8 GB of 288)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -387,19 +387,6 @@ int nsx_adam_hash_factored_consume(float* G, int n_slots, const float* code_tabl
                            const float* window, int H, const nsx_grid_geom* g, float* master, float* exp_avg,
                            float* exp_avg_sq, nsx_half* tables_f16, float lr, float beta1, float beta2, float eps,
                            int64_t step, const float* inv_scale, const float* found_inf, void* stream);
-/* The same step (consume != 0: as nsx_adam_hash_factored_consume) restricted to the grids h < h_active, rounded up to a
- * multiple of 4.  NeRSemble switches its hash grids on one after the other (window_hash_encodings_begin / _end,
- * train_nersemble.py:77-78; posenc_window, hash_ensemble.py:133-138): a grid beyond the largest window value seen so far
- * has never had a non-zero blend weight, hence never a non-zero gradient, hence zero Adam moments -- torch.optim.Adam's
- * update of it is lr * 0 / (sqrt(0) + eps) = 0.  Leaving those parameters, their moments and their fp16 copies untouched
- * is therefore the same step, at 1/4 of the parameter traffic while one grid is on (the first 40 000 steps of the
- * default schedule).  The CALLER keeps h_active monotone (engine/hash_adam.py: the maximum of ceil(window) over all
- * steps taken, H after loading optimizer state of unknown history). */
-int nsx_adam_hash_factored_prefix(float* G, int consume, int h_active, int n_slots, const float* code_table,
-                                  int64_t code_stride, const float* window, int H, const nsx_grid_geom* g, float* master,
-                                  float* exp_avg, float* exp_avg_sq, nsx_half* tables_f16, float lr, float beta1,
-                                  float beta2, float eps, int64_t step, const float* inv_scale, const float* found_inf,
-                                  void* stream);
 int nsx_adam_dense(const float* grad, int64_t n, float* master, float* exp_avg, float* exp_avg_sq,
                    nsx_half* params_f16 /* may be NULL */, float lr, float beta1, float beta2, float eps,
                    int64_t step, const float* inv_scale, const float* found_inf, void* stream);

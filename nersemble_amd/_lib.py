@@ -132,9 +132,6 @@ SIGNATURES = {
     "nsx_adam_hash_factored_consume": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_void_p, c_int, _GEOM_P, c_void_p, c_void_p,
                                        c_void_p, c_void_p, c_float, c_float, c_float, c_float, c_int64, c_void_p,
                                        c_void_p, c_void_p]),
-    "nsx_adam_hash_factored_prefix": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int64, c_void_p, c_int, _GEOM_P,
-                                              c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_float, c_float,
-                                              c_int64, c_void_p, c_void_p, c_void_p]),
     "nsx_adam_dense": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_float,
                                c_float, c_int64, c_void_p, c_void_p, c_void_p]),
     "nsx_hash_indices": (c_int, [c_void_p, c_int64, _GEOM_P, c_void_p, c_void_p]),

@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void adam_hash_factored_kernel(
     float* __restrict__ G, int n_slots, const float* __restrict__ code, int64_t code_stride,
     const float* __restrict__ window, int Hreal, uint64_t total, float* __restrict__ master, float* __restrict__ m,
     float* __restrict__ v, half_t* __restrict__ f16, AdamHyper hy, const float* __restrict__ inv_scale,
-    const float* __restrict__ found_inf, int h_active) {
+    const float* __restrict__ found_inf) {
     const bool skip = found_inf && found_inf[0] != 0.f;
     if (skip && !CLEAR) return;
     constexpr int HV = HP >= 4 ? 4 : HP;                 // parameters per thread (vector width)
@@ -75,9 +75,7 @@ __global__ __launch_bounds__(256) void adam_hash_factored_kernel(
     for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const uint64_t e0 = tile * EPB;
         const uint64_t e = e0 + le;
-        // grids h >= h_active never received a gradient and receive none now (see nsx_adam_hash_factored_prefix): their
-        // moments are zero, Adam's update of them is exactly zero, and this thread's 4 of them are not touched at all
-        const bool live = e < total && hq * HV < h_active;
+        const bool live = e < total;
         const uint64_t at = (e * 2ull + f) * HP + hq * HV;
         // the three parameter streams are requested first: their HBM latency overlaps the staging of G below
         float pp[HV], mm[HV], vv[HV];
@@ -335,7 +333,7 @@ static AdamHyper make_hyper(float lr, float beta1, float beta2, float eps, int64
 template <int HP, bool CLEAR>
 static int launch_adam_factored(float* G, int n_slots, const float* code, int64_t code_stride, const float* window,
                                 int H, uint64_t total, float* master, float* m, float* v, nsx_half* f16, AdamHyper hy,
-                                const float* inv_scale, const float* found_inf, hipStream_t st, int h_active) {
+                                const float* inv_scale, const float* found_inf, hipStream_t st) {
     constexpr int HV = HP >= 4 ? 4 : HP;
     constexpr int EPB = 256 / (2 * HP / HV);
     const size_t smem = ((size_t)n_slots * HP + (size_t)n_slots * EPB * 2) * sizeof(float);
@@ -343,7 +341,7 @@ static int launch_adam_factored(float* G, int n_slots, const float* code, int64_
     // seven interleaved streams keep more DRAM pages open with fewer concurrent tiles (tools/adam_bench.py)
     hipLaunchKernelGGL((adam_hash_factored_kernel<HP, CLEAR>), dim3(num_cus() * 4), dim3(256), smem, st, G, n_slots, code,
                        code_stride, window, H, total, master, m, v, reinterpret_cast<half_t*>(f16), hy, inv_scale,
-                       found_inf, h_active);
+                       found_inf);
     NSX_LAUNCH_CHECK("nsx_adam_hash_factored launch");
     return NSX_OK;
 }
@@ -352,9 +350,7 @@ template <bool CLEAR>
 static int adam_hash_factored_entry(float* G, int n_slots, const float* code_table, int64_t code_stride,
                                     const float* window, int H, const nsx_grid_geom* g, float* master, float* exp_avg,
                                     float* exp_avg_sq, nsx_half* tables_f16, float lr, float beta1, float beta2, float eps,
-                                    int64_t step, const float* inv_scale, const float* found_inf, void* stream,
-                                    int h_active) {
-    NSX_REQUIRE(h_active >= 1 && h_active <= H, "nsx_adam_hash_factored: h_active=%d not in [1,%d]", h_active, H);
+                                    int64_t step, const float* inv_scale, const float* found_inf, void* stream) {
     NSX_REQUIRE(G && code_table && g && master && exp_avg && exp_avg_sq && tables_f16, "nsx_adam_hash_factored: NULL argument");
     NSX_REQUIRE(H >= 1 && H <= 32, "nsx_adam_hash_factored: H=%d not in [1,32]", H);
     NSX_REQUIRE(n_slots >= 1 && n_slots <= NSX_MAX_SLOTS, "nsx_adam_hash_factored: n_slots=%d not in [1,%d]", n_slots, NSX_MAX_SLOTS);
@@ -364,7 +360,7 @@ static int adam_hash_factored_entry(float* G, int n_slots, const float* code_tab
     const AdamHyper hy = make_hyper(lr, beta1, beta2, eps, step);
     hipStream_t st = (hipStream_t)stream;
 #define NSX_ADAM_CASE(HP) case HP: return launch_adam_factored<HP, CLEAR>(G, n_slots, code_table, code_stride, window, H, \
-        total, master, exp_avg, exp_avg_sq, tables_f16, hy, inv_scale, found_inf, st, h_active);
+        total, master, exp_avg, exp_avg_sq, tables_f16, hy, inv_scale, found_inf, st);
     switch (nsx_padded_grids(H)) {
         NSX_ADAM_CASE(1) NSX_ADAM_CASE(2) NSX_ADAM_CASE(4) NSX_ADAM_CASE(8) NSX_ADAM_CASE(16) NSX_ADAM_CASE(32)
     }
@@ -394,20 +390,7 @@ int nsx_adam_hash_factored(const float* G, int n_slots, const float* code_table,
                            int64_t step, const float* inv_scale, const float* found_inf, void* stream) {
     return adam_hash_factored_entry<false>(const_cast<float*>(G), n_slots, code_table, code_stride, window, H, g, master,
                                            exp_avg, exp_avg_sq, tables_f16, lr, beta1, beta2, eps, step, inv_scale,
-                                           found_inf, stream, H);
-}
-
-int nsx_adam_hash_factored_prefix(float* G, int consume, int h_active, int n_slots, const float* code_table,
-                                  int64_t code_stride, const float* window, int H, const nsx_grid_geom* g, float* master,
-                                  float* exp_avg, float* exp_avg_sq, nsx_half* tables_f16, float lr, float beta1,
-                                  float beta2, float eps, int64_t step, const float* inv_scale, const float* found_inf,
-                                  void* stream) {
-    if (consume)
-        return adam_hash_factored_entry<true>(G, n_slots, code_table, code_stride, window, H, g, master, exp_avg,
-                                              exp_avg_sq, tables_f16, lr, beta1, beta2, eps, step, inv_scale, found_inf,
-                                              stream, h_active);
-    return adam_hash_factored_entry<false>(G, n_slots, code_table, code_stride, window, H, g, master, exp_avg, exp_avg_sq,
-                                           tables_f16, lr, beta1, beta2, eps, step, inv_scale, found_inf, stream, h_active);
+                                           found_inf, stream);
 }
 
 int nsx_adam_hash_factored_consume(float* G, int n_slots, const float* code_table, int64_t code_stride,
@@ -415,7 +398,7 @@ int nsx_adam_hash_factored_consume(float* G, int n_slots, const float* code_tabl
                                    float* exp_avg_sq, nsx_half* tables_f16, float lr, float beta1, float beta2, float eps,
                                    int64_t step, const float* inv_scale, const float* found_inf, void* stream) {
     return adam_hash_factored_entry<true>(G, n_slots, code_table, code_stride, window, H, g, master, exp_avg, exp_avg_sq,
-                                          tables_f16, lr, beta1, beta2, eps, step, inv_scale, found_inf, stream, H);
+                                          tables_f16, lr, beta1, beta2, eps, step, inv_scale, found_inf, stream);
 }
 
 int nsx_adam_dense(const float* grad, int64_t n, float* master, float* exp_avg, float* exp_avg_sq,

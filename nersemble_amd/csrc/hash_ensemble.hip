@@ -101,40 +101,24 @@ __device__ __forceinline__ void corner_weights(const Cell& c, float w[8]) {
 }
 
 // Packed fp16 code for this lane's dwords (code * window, rounded to fp16 once).
-// Returns whether any of the lane's grids is switched on by the window (always, without one).  The coarse-to-fine
-// schedule (hash_ensemble.py:133-138, train_nersemble.py:77-78) keeps window[h] == 0 for h >= the current window value
-// -- for the first 40 000 steps that is every grid but the first: such a grid's blend weight is exactly zero, so its
-// table values change neither the output nor any gradient that survives the window, and the lane that would fetch them
-// does not (2 of 8 lanes per corner read at window = 1: half the sectors, a quarter of the bytes).
 template <int H>
-__device__ __forceinline__ bool load_code(const float* __restrict__ row, const float* __restrict__ window,
+__device__ __forceinline__ void load_code(const float* __restrict__ row, const float* __restrict__ window,
                                           int Hreal, int q, half2_t cw[EnsCfg<H>::NDW]) {
     using C = EnsCfg<H>;
     if constexpr (H == 1) {
         float c0 = row[0] * (window ? window[0] : 1.0f);
         cw[0] = half2_t{(half_t)c0, (half_t)c0};
-        return !window || window[0] != 0.f;
     } else {
-        bool on = !window;
 #pragma unroll
         for (int j = 0; j < C::NDW; ++j) {
             const int pair = (q * C::NDW + j) % C::DPF;
             const int h0 = 2 * pair, h1 = h0 + 1;
             float c0 = 0.f, c1 = 0.f;
-            if (h0 < Hreal) { const float w0 = window ? window[h0] : 1.0f; c0 = row[h0] * w0; on |= w0 != 0.f; }
-            if (h1 < Hreal) { const float w1 = window ? window[h1] : 1.0f; c1 = row[h1] * w1; on |= w1 != 0.f; }
+            if (h0 < Hreal) c0 = row[h0] * (window ? window[h0] : 1.0f);
+            if (h1 < Hreal) c1 = row[h1] * (window ? window[h1] : 1.0f);
             cw[j] = half2_t{(half_t)c0, (half_t)c1};
         }
-        return on;
     }
-}
-
-template <int NDW>
-__device__ __forceinline__ LaneVec<NDW> zero_lane() {
-    LaneVec<NDW> r;
-#pragma unroll
-    for (int j = 0; j < NDW; ++j) r.d[j] = 0u;
-    return r;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -164,10 +148,9 @@ __global__ __launch_bounds__(WAVES * kWave) void ens_fwd_kernel(
         const int64_t b = b_raw < B ? b_raw : B - 1;
         const float px = x[b * 3 + 0], py = x[b * 3 + 1], pz = x[b * 3 + 2];
         half2_t cw[C::NDW];
-        bool grids_on;
         {
             const int64_t r = code_index ? (int64_t)code_index[b] : b;
-            grids_on = load_code<H>(code + r * code_stride, window, Hreal, q, cw);
+            load_code<H>(code + r * code_stride, window, Hreal, q, cw);
         }
         for (int l = 0; l < L; ++l) {
             const float scale = g.scale[l];
@@ -180,13 +163,9 @@ __global__ __launch_bounds__(WAVES * kWave) void ens_fwd_kernel(
             corner_weights(c, w);
             LaneVec<C::NDW> v[8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] = zero_lane<C::NDW>();
-            if (grids_on) {
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const uint8_t* p = tab + (size_t)(off + idx[k]) * C::ROW_BYTES + q * C::LANE_BYTES;
-                    v[k] = load_lane<C::NDW>(p);
-                }
+            for (int k = 0; k < 8; ++k) {
+                const uint8_t* p = tab + (size_t)(off + idx[k]) * C::ROW_BYTES + q * C::LANE_BYTES;
+                v[k] = load_lane<C::NDW>(p);
             }
             float acc0 = 0.f, acc1 = 0.f;
 #pragma unroll
@@ -294,7 +273,7 @@ __global__ __launch_bounds__(WAVES * kWave) void ens_bwd_kernel(
         const float px = x[b * 3 + 0], py = x[b * 3 + 1], pz = x[b * 3 + 2];
         half2_t cw[C::NDW];
         const int64_t crow = code_index ? (int64_t)code_index[b] : b;
-        const bool grids_on = load_code<H>(code + crow * code_stride, window, Hreal, q, cw);
+        load_code<H>(code + crow * code_stride, window, Hreal, q, cw);
         float dc[NH];
 #pragma unroll
         for (int i = 0; i < NH; ++i) dc[i] = 0.f;
@@ -314,13 +293,9 @@ __global__ __launch_bounds__(WAVES * kWave) void ens_bwd_kernel(
             corner_weights(c, w);
             LaneVec<C::NDW> v[8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] = zero_lane<C::NDW>();
-            if (grids_on) {                  // (grids the window switches off: see load_code)
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const uint8_t* p = tab + (size_t)(off + idx[k]) * C::ROW_BYTES + q * C::LANE_BYTES;
-                    v[k] = load_lane<C::NDW>(p);
-                }
+            for (int k = 0; k < 8; ++k) {
+                const uint8_t* p = tab + (size_t)(off + idx[k]) * C::ROW_BYTES + q * C::LANE_BYTES;
+                v[k] = load_lane<C::NDW>(p);
             }
             // per-lane feature selector for H >= 8 (one feature plane per lane)
             const float gl = (C::LPE >= 2) ? ((q / (C::LPE / 2 > 0 ? C::LPE / 2 : 1)) ? g1 : g0) : 0.f;
@@ -329,7 +304,7 @@ __global__ __launch_bounds__(WAVES * kWave) void ens_bwd_kernel(
             for (int k = 0; k < 8; ++k) {
                 // blended_k = sum_f g_f * sum_h table[f][h] * code[h]  (this lane's share)
                 float blended = 0.f;
-                float* gdst = (MODE == BWD_DENSE && dtab && grids_on)
+                float* gdst = (MODE == BWD_DENSE && dtab)
                                   ? dtab + ((size_t)(off + idx[k]) * C::ROW_BYTES + q * C::LANE_BYTES) / 2 : nullptr;
                 if constexpr (H == 1) {
                     const half2_t t = as_half2(v[k].d[0]);

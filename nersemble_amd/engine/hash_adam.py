@@ -50,7 +50,6 @@ class HashTableAdam(torch.optim.Optimizer):
     # the optimizer pass clears the pieces of G it finds non-zero while it reads them (nsx_adam_hash_factored_consume):
     # no 1.6 GB fill in front of the next backward's scatter.  Off (A/B measurements): the backward clears G itself.
     consume_gradient = os.environ.get("NSX_ADAM_CONSUMES_G", "1") == "1"
-    skip_unopened_grids = os.environ.get("NSX_ADAM_SKIPS_UNOPENED_GRIDS", "1") == "1"
     consume_density_limit = 0.5      # ... while the scatter is expected to touch less than this share of G's sectors
 
     def disarm_early_step(self) -> None:
@@ -136,22 +135,13 @@ class HashTableAdam(torch.optim.Optimizer):
             # bytes bench.py prices)
             sparse = 0 < sink.samples_scattered * 80 < self.consume_density_limit * (e["G"].numel() // 8)
             consume = self.consume_gradient and sparse and sink.is_persistent(e["G"])
-            # grids that the coarse-to-fine window has never switched on have zero moments and get a zero gradient: Adam
-            # does not move them, and the pass leaves them alone (include/nsx.h, nsx_adam_hash_factored_prefix).  The
-            # frontier only ever grows; a window-less forward (or optimizer state of unknown history) opens all grids.
-            H = he.n_hash_encodings
-            on_now = H if e["window"] is None else max(1, min(H, int(he.last_grids_on)))
-            st["grids_seen"] = max(int(st.get("grids_seen", 0)), on_now)
-            h_active = st["grids_seen"] if self.skip_unopened_grids else H
-            check(lib().nsx_adam_hash_factored_prefix(
-                ptr(e["G"]), int(consume), int(h_active), e["n_rows"], ptr(e["code"]), e["code"].stride(0),
-                ptr(e["window"]), H, C.byref(he.geom), ptr(p.data), ptr(st["exp_avg"]), ptr(st["exp_avg_sq"]), ptr(f16),
-                group["lr"], b1, b2, group["eps"], st["step"], ptr(inv_scale), ptr(found_inf), stream()),
-                "nsx_adam_hash_factored_prefix")
+            fn = lib().nsx_adam_hash_factored_consume if consume else lib().nsx_adam_hash_factored
+            check(fn(ptr(e["G"]), e["n_rows"], ptr(e["code"]), e["code"].stride(0), ptr(e["window"]), he.n_hash_encodings,
+                     C.byref(he.geom), ptr(p.data), ptr(st["exp_avg"]), ptr(st["exp_avg_sq"]), ptr(f16), group["lr"], b1,
+                     b2, group["eps"], st["step"], ptr(inv_scale), ptr(found_inf), stream()), "nsx_adam_hash_factored")
             if consume:
                 sink.mark_cleared(e["G"])              # (event on the stream the optimizer runs on)
         else:
-            st["grids_seen"] = he.n_hash_encodings          # (a dense gradient: no statement about unopened grids)
             grad = p.grad.contiguous() if p.grad is not None else torch.zeros_like(p)
             for e in entries:      # several code tables in one step: expand each into the dense gradient
                 check(lib().nsx_hash_grad_expand(ptr(e["G"]), e["n_rows"], ptr(e["code"]), e["code"].stride(0),
@@ -176,7 +166,6 @@ class HashTableAdam(torch.optim.Optimizer):
         self.he.wait_tables()
         st = self._state()
         return {"step": int(st["step"]), "lr": float(self.param_groups[0]["lr"]),
-                "grids_seen": int(st.get("grids_seen", 0)),
                 "exp_avg": self.he.to_tcnn_layout(st["exp_avg"]), "exp_avg_sq": self.he.to_tcnn_layout(st["exp_avg_sq"])}
 
     def load_table_state(self, state: dict) -> None:
@@ -186,8 +175,6 @@ class HashTableAdam(torch.optim.Optimizer):
         self.param_groups[0]["lr"] = float(state.get("lr", self.param_groups[0]["lr"]))
         st["exp_avg"].copy_(self.he.from_tcnn_layout(state["exp_avg"]))
         st["exp_avg_sq"].copy_(self.he.from_tcnn_layout(state["exp_avg_sq"]))
-        # moments written by someone else (e.g. the reference's torch.optim.Adam): every grid may have been touched
-        st["grids_seen"] = int(state.get("grids_seen", self.he.n_hash_encodings))
 
     def zero_grad(self, set_to_none: bool = True):
         super().zero_grad(set_to_none=set_to_none)

@@ -86,10 +86,6 @@ class HashEnsemble(nn.Module):
         # set by engine.hash_adam.HashTableAdam: factored-gradient sink (no dense table gradient is materialised)
         self.grad_sink = None
         self._window_cache = {}
-        self._window_grids_on = self.n_hash_encodings
-        # number of leading grids with a non-zero window weight in the most recent forward (all of them without a window):
-        # the table optimizer leaves grids alone that have never been switched on (engine/hash_adam.py)
-        self.last_grids_on = self.n_hash_encodings
         # torch's fused optimizers update parameters in place WITHOUT bumping Tensor._version: if one of them steps the
         # tables, the fp16 working copy must be rebuilt (the native table optimizers write it themselves)
         import weakref
@@ -196,15 +192,9 @@ class HashEnsemble(nn.Module):
             wkey = (float(window_hash_encodings), str(device))
             window = self._window_cache.get(wkey)
             if window is None:
-                on_host = posenc_window(window_hash_encodings, 0, self.n_hash_encodings - 1, self.n_hash_encodings)
-                # the grids the window switches on are a prefix (the window falls monotonically over h)
-                nz = torch.nonzero(on_host)
-                self._window_grids_on = int(nz.max()) + 1 if nz.numel() else 0
-                window = on_host.to(device=device, dtype=torch.float32)
+                window = posenc_window(window_hash_encodings, 0, self.n_hash_encodings - 1,
+                                       self.n_hash_encodings).to(device=device, dtype=torch.float32)
                 self._window_cache = {wkey: window}
-            self.last_grids_on = self._window_grids_on
-        else:
-            self.last_grids_on = self.n_hash_encodings
         return conditioning_code, window
 
     @torch.no_grad()
