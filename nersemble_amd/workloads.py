@@ -1,6 +1,6 @@
 """BASELINE.json configs -> (trainer, synthetic data) builders.  Hyper-parameters come from the reference's
 scripts/train/train_nersemble.py:59-111,184-256 (the source of truth for the path's constants)."""
-from typing import Tuple
+from typing import Optional, Tuple
 
 import torch
 
@@ -50,8 +50,14 @@ def build_model_config(w: dict, max_n_samples_per_batch: int = 20, small: bool =
 
 def build_workload(name: str, device="cuda:0", small: bool = False, rank: int = 0, world_size: int = 1,
                    n_rays: int = None, factored_table_grad=None, sharded_table_adam=None,
-                   global_loss_normalisers: bool = False) -> Tuple[NeRSembleTrainer, SyntheticNeRSembleData, dict]:
-    w = WORKLOADS[name]
+                   global_loss_normalisers: bool = False, window_hash: Optional[Tuple[int, int]] = None
+                   ) -> Tuple[NeRSembleTrainer, SyntheticNeRSembleData, dict]:
+    """``window_hash``: (begin, end) steps of the coarse-to-fine schedule of the hash grids instead of the workload's
+    (train_nersemble.py:77-78: 40000, 80000); (0, 1) has every grid switched on from step 1 -- the state of a run after
+    ``end``."""
+    w = dict(WORKLOADS[name])
+    if window_hash is not None:
+        w["win"] = (int(window_hash[0]), int(window_hash[1]))
     box = torch.tensor(SCENE_BOXES[w["pid"]], dtype=torch.float32)
     rays = n_rays if n_rays is not None else w["rays"]
     data = SyntheticNeRSembleData(box, n_timesteps=w["T"], n_rays=rays, device=device, rank=rank)

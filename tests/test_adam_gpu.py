@@ -16,7 +16,9 @@ def _he(H, cuda, seed=0):
 
 
 @pytest.mark.parametrize("H", [1, 4, 32])
-def test_factored_adam_equals_torch_adam(H, cuda):
+@pytest.mark.parametrize("first_window", ["half", "one"])
+def test_factored_adam_equals_torch_adam(H, first_window, cuda):
+    """``first_window`` "one": the schedule's start (one grid on, then 1.3, 1.6 -> a second grid opens on the way)."""
     from nersemble_amd.engine.hash_adam import HashTableAdam
     B, T = 4000, 7
     g = torch.Generator(device=cuda).manual_seed(1)
@@ -33,7 +35,7 @@ def test_factored_adam_equals_torch_adam(H, cuda):
     inv = torch.tensor([1.0 / scale], device=cuda)
     found = torch.zeros(1, device=cuda)
     for it in range(3):
-        win = 0.5 * H + it * 0.3
+        win = (0.5 * H if first_window == "half" else 1.0) + it * 0.3
         opt_ref.zero_grad()
         ref(x, emb, window_hash_encodings=win, code_index=slot).backward(dout * scale)
         ref.tables.grad.mul_(1.0 / scale)

@@ -142,16 +142,19 @@ def test_backward_matches_oracle(H, cuda):
 
 
 @pytest.mark.parametrize("H,T", [(32, 5), (16, 24), (4, 64), (1, 3), (8, 200)])
-def test_backward_with_code_index_and_window(H, T, cuda):
+@pytest.mark.parametrize("opened", ["most", "one", "two and a bit"])
+def test_backward_with_code_index_and_window(H, T, opened, cuda):
     """Indexed codes: T <= 64 rows takes the factored table-gradient path (G scatter + expand), T = 200 the
-    generic atomics path; both must equal the oracle (table, code-table, position gradients)."""
+    generic atomics path; both must equal the oracle (table, code-table, position gradients).  ``opened``: how far the
+    coarse-to-fine window has come (train_nersemble.py:77-78: one grid for the first 40 000 steps)."""
     from nersemble_amd import functional as F
     B = 311
+    window_value = {"most": 0.63 * H + 0.2, "one": 1.0, "two and a bit": 2.37}[opened]
     go, gn, tabs, f16, master, x, _ = _setup(H, SMALL_GEOM_KW, 77 + H, B, cuda)
     rng = np.random.default_rng(12)
     emb = (rng.standard_normal((T, H)) * 0.5).astype(np.float32)
     ts = rng.integers(0, T, B).astype(np.int32)
-    win = ohg.posenc_window(0.63 * H + 0.2, 0, H - 1, H)
+    win = ohg.posenc_window(window_value, 0, H - 1, H)
     dout = rng.standard_normal((B, 32)).astype(np.float16).astype(np.float32)
     et = torch.from_numpy(emb).to(cuda).requires_grad_(True)
     mt = master.clone().requires_grad_(True)
