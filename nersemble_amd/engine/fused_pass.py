@@ -32,7 +32,7 @@ class MainPassInputs:
                  "pre_offsets", "pre_features", "pre_base", "image", "alpha_map", "depth_targets",
                  "he", "window", "field_aabb6", "deform_packed", "deform_aabb6", "deform_window7",
                  "base_hidden", "base_out_dim", "base_act", "base_w16", "head_hidden", "head_act", "head_w16", "geo_dim",
-                 "background", "loss_cfg", "aux", "n_dev")
+                 "background", "loss_cfg", "aux", "n_dev", "first_grid")
 
 
 class _MainPass(torch.autograd.Function):
@@ -55,8 +55,16 @@ class _MainPass(torch.autograd.Function):
         # -- parameters in the kernels' formats (fp16 copies made once per optimizer step, tcnn.Network.half_weights)
         base_w, head_w = inp.base_w16, inp.head_w16
         code_h = code_hash.detach().contiguous()
+        # what the HashEnsemble kernels see: the H grids with the batch's code rows and the window -- or, in the compact
+        # first-grid phase (HashEnsemble.first_grid_phase), the contiguous copy of grid 0 with a constant code of one
+        hash_slot, hash_window = inp.slot, inp.window
+        comp = getattr(inp, "first_grid", None)
+        if comp is not None:
+            he.wait_tables()
+            H, code_h, hash_window = 1, comp["code"], None
+            hash_slot = he.zero_slots(S, dev)[:S]
         code_d = code_deform.detach().contiguous()
-        tables_f16 = he.half_tables()
+        tables_f16 = he.half_tables() if comp is None else comp["f16"]
         # -- world positions of the samples, deformation offsets (normalised space)
         pos = torch.empty((S, 3), dtype=f32, device=dev)
         check(L.nsx_sample_positions(ptr(inp.origins), ptr(inp.directions), None, ptr(inp.t0), ptr(inp.t1), None, S, None,
@@ -78,7 +86,7 @@ class _MainPass(torch.autograd.Function):
         else:
             feats = torch.empty((S, 2 * geom.n_levels), dtype=f16, device=dev)
             check(L.nsx_hash_ensemble_fwd(ptr(pn), S, ptr(tables_f16), H, C.byref(geom), ptr(code_h), code_h.stride(0),
-                                          ptr(inp.slot), ptr(inp.window), ptr(feats), st), "nsx_hash_ensemble_fwd")
+                                          ptr(hash_slot), ptr(hash_window), ptr(feats), st), "nsx_hash_ensemble_fwd")
         if inp.pre_base is not None:
             base_out = inp.pre_base
         else:
@@ -122,6 +130,7 @@ class _MainPass(torch.autograd.Function):
                               code_h, code_d, tables_f16)
         ctx.shapes = (tuple(tables_master.shape), [tuple(p.shape) for p in deform_params], code_hash.shape[0])
         ctx.sink = he.grad_sink
+        ctx.hash_args = (H, hash_slot, hash_window, comp is not None)
         # a forward whose backward will add to the sink's G (the sink counts them to know when G is complete)
         ctx.announced = ctx.sink is not None and ctx.needs_input_grad[1]
         if ctx.announced:
@@ -143,7 +152,8 @@ class _MainPass(torch.autograd.Function):
         dev = pos.device
         S, R = pos.shape[0], inp.n_rays
         he = inp.he
-        H, geom = he.n_hash_encodings, he.geom
+        geom = he.geom
+        H, hash_slot, hash_window, first_grid = ctx.hash_args
         f32, f16 = torch.float32, torch.float16
         use_masked, thr, l_alpha, l_depth, l_dist, l_empty, l_near, eps, max_ray = inp.loss_cfg
         g = g_out.to(f32).contiguous()
@@ -187,18 +197,18 @@ class _MainPass(torch.autograd.Function):
         n_rows = code_h.shape[0]
         sink = ctx.sink
         need_tab = ctx.needs_input_grad[1]
-        need_code = ctx.needs_input_grad[4]
+        need_code = ctx.needs_input_grad[4] and not first_grid      # (the code is the constant one in that phase)
         G, dtab = None, None
         if need_tab:
             if sink is not None:
-                G = sink.buffer_for(code_h, inp.window, n_rows, geom.total_entries, n_samples=S)
+                G = sink.buffer_for(code_h, hash_window, n_rows, geom.total_entries, n_samples=S)
             else:
                 G = torch.zeros((n_rows, geom.total_entries, 2), dtype=f32, device=dev)
         dcode_s = (torch.zeros if inp.n_dev is not None else torch.empty)((S, H), dtype=f32, device=dev) \
             if need_code else None
         dx = torch.empty((S, 3), dtype=f32, device=dev)
         check(L.nsx_hash_ensemble_bwd_factored(ptr(pn), S, ptr(tables_f16), H, C.byref(geom), ptr(code_h), code_h.stride(0),
-                                               n_rows, ptr(inp.slot), ptr(inp.window), ptr(dout), ptr(G), ptr(dcode_s),
+                                               n_rows, ptr(hash_slot), ptr(hash_window), ptr(dout), ptr(G), ptr(dcode_s),
                                                ptr(dx), ptr(sink.nonfinite) if (sink is not None and need_tab) else None,
                                                st), "nsx_hash_ensemble_bwd_factored")
         if sink is not None and need_tab and ctx.announced:
@@ -207,14 +217,14 @@ class _MainPass(torch.autograd.Function):
             sink.arrived(group_grads=[d_base, d_head])
         if need_tab and sink is None:
             dtab = torch.empty(ctx.shapes[0], dtype=f32, device=dev)
-            check(L.nsx_hash_grad_expand(ptr(G), n_rows, ptr(code_h), code_h.stride(0), ptr(inp.window), H, C.byref(geom),
+            check(L.nsx_hash_grad_expand(ptr(G), n_rows, ptr(code_h), code_h.stride(0), ptr(hash_window), H, C.byref(geom),
                                          ptr(dtab), 0, st), "nsx_hash_grad_expand")
         g_code_hash = None
         if need_code:
-            if inp.window is not None:
-                dcode_s = dcode_s * inp.window[None, :]
+            if hash_window is not None:
+                dcode_s = dcode_s * hash_window[None, :]
             g_code_hash = torch.zeros((n_rows, H), dtype=f32, device=dev)
-            g_code_hash.index_add_(0, inp.slot.to(torch.int64), dcode_s)
+            g_code_hash.index_add_(0, hash_slot.to(torch.int64), dcode_s)
         # -- normalisation: gradient of the offsets
         goff = torch.empty((S, 3), dtype=f32, device=dev)
         check(L.nsx_normalise_bwd(ptr(dx), ptr(sel), S, inp.field_aabb6, ptr(goff), st), "nsx_normalise_bwd")

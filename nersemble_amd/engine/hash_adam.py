@@ -31,6 +31,27 @@ class HashTableAdam(torch.optim.Optimizer):
         # early step (armed by the trainer for one backward): see arm_early_step
         self._early = None
         self.stepped_early = False
+        # compact first-grid phase of the HashEnsemble (field_components/hash_ensemble.py): the moments of grid 0 as
+        # contiguous [entry][f] arrays while it lasts
+        self._compact_state = None
+        listeners = getattr(hash_ensemble, "_compact_listeners", None)
+        if listeners is None:
+            listeners = hash_ensemble._compact_listeners = []
+        listeners.append(self._on_first_grid_phase)
+
+    @torch.no_grad()
+    def _on_first_grid_phase(self, what: str) -> None:
+        """enter: take column 0 of the moments; sync / leave: write it back (the HashEnsemble has ordered the current
+        stream after the last optimizer pass before it calls)."""
+        st = self._state()
+        if what == "enter":
+            self._compact_state = {"exp_avg": st["exp_avg"][:, :, 0:1].contiguous(),
+                                   "exp_avg_sq": st["exp_avg_sq"][:, :, 0:1].contiguous()}
+        elif self._compact_state is not None:
+            st["exp_avg"][:, :, 0:1].copy_(self._compact_state["exp_avg"])
+            st["exp_avg_sq"][:, :, 0:1].copy_(self._compact_state["exp_avg_sq"])
+            if what == "leave":
+                self._compact_state = None
 
     # ---- the step started from inside the backward -----------------------------------------------------------
     def arm_early_step(self, found_inf: torch.Tensor, inv_scale: torch.Tensor, side_stream) -> None:
@@ -127,6 +148,26 @@ class HashTableAdam(torch.optim.Optimizer):
         st = self._state()
         st["step"] += 1
         b1, b2 = group["betas"]
+        comp = he._compact
+        if comp is not None and len(entries) == 1 and p.grad is None \
+                and entries[0]["code"].data_ptr() == comp["code"].data_ptr():
+            # compact first-grid phase: the step of grid 0 alone, on its contiguous copy (H = 1 pass, 0.7 GB instead of
+            # 11.7 GB at the reference geometry); the other grids have zero gradient and zero moments -- Adam leaves them
+            # where they are
+            e, cs = entries[0], self._compact_state
+            sparse = 0 < sink.samples_scattered * 80 < self.consume_density_limit * (e["G"].numel() // 8)
+            consume = self.consume_gradient and sparse and sink.is_persistent(e["G"])
+            fn = lib().nsx_adam_hash_factored_consume if consume else lib().nsx_adam_hash_factored
+            check(fn(ptr(e["G"]), 1, ptr(comp["code"]), 1, None, 1, C.byref(he.geom), ptr(comp["master"]),
+                     ptr(cs["exp_avg"]), ptr(cs["exp_avg_sq"]), ptr(comp["f16"]), group["lr"], b1, b2, group["eps"],
+                     st["step"], ptr(inv_scale), ptr(found_inf), stream()), "nsx_adam_hash_factored")
+            if consume:
+                sink.mark_cleared(e["G"])
+            sink.clear()
+            return
+        if comp is not None:
+            raise RuntimeError("HashTableAdam: the HashEnsemble is in its compact first-grid phase but the pending gradient "
+                               "is not that phase's (call hash_ensemble.leave_first_grid_phase() before mixing paths)")
         f16 = he.half_tables()            # make sure the working copy exists on the right device
         if len(entries) == 1 and p.grad is None:
             e = entries[0]
@@ -163,12 +204,14 @@ class HashTableAdam(torch.optim.Optimizer):
 
     # ---- checkpointing: moments in the reference's parameter layout (one flat tensor per tcnn encoding) -------------
     def table_state(self) -> dict:
+        self.he.sync_first_grid()
         self.he.wait_tables()
         st = self._state()
         return {"step": int(st["step"]), "lr": float(self.param_groups[0]["lr"]),
                 "exp_avg": self.he.to_tcnn_layout(st["exp_avg"]), "exp_avg_sq": self.he.to_tcnn_layout(st["exp_avg_sq"])}
 
     def load_table_state(self, state: dict) -> None:
+        self.he.leave_first_grid_phase()
         self.he.wait_tables()
         st = self._state()
         st["step"] = int(state["step"])

@@ -64,10 +64,17 @@ class NeRSembleTrainer:
                  mixed_precision: bool = True, world_size: int = 1, factored_table_grad: Optional[bool] = None,
                  rank: Optional[int] = None, sharded_table_adam: Optional[bool] = None,
                  overlap_table_adam: bool = True, calibrate_table_placement: bool = True,
-                 global_loss_normalisers: bool = False, early_table_step: bool = False):
+                 global_loss_normalisers: bool = False, early_table_step: bool = False,
+                 compact_first_grid: bool = False):
         """``global_loss_normalisers``: the ranks hold consecutive slices of ONE ray batch (strong scaling)
         -- loss denominators are made global so that the step equals the single-process step on the union batch."""
         self.model = model
+        # ``compact_first_grid``: while the coarse-to-fine window keeps one hash grid on (the first 40 000 steps of the
+        # reference's schedule), train a contiguous copy of that grid with the H = 1 kernels instead of the 32-grid layout
+        # (HashEnsemble.first_grid_phase: same values, ~2x per step).  Single GPU, factored table gradient.  Off by default:
+        # code that reads ``hash_ensemble.tables`` or the optimizer's moments directly in that phase must call
+        # ``consolidate()`` first (``state_dict()`` / checkpoints do).
+        self.compact_first_grid = compact_first_grid
         # start the table optimizer from inside the backward (HashTableAdam.arm_early_step).  OFF by default: measured
         # slower (8.8 vs 8.3 ms per step early in training, 4.85 vs 4.25 ms in steady state) -- the 12 GB pass next to
         # the deformation backward triples the latter (both are HBM-bound) and crowds the step's tail off the CUs
@@ -126,6 +133,8 @@ class NeRSembleTrainer:
         if calibrate_table_placement and isinstance(table_opt, HashTableAdam):
             from .placement import calibrate_table_placement as _calibrate
             self.placement_report = _calibrate(model.field.hash_ensemble, table_opt)
+        model.field.hash_ensemble.compact_first_grid = bool(
+            compact_first_grid and world_size == 1 and isinstance(table_opt, HashTableAdam) and table_opt.factored)
 
     def group_of_tables(self) -> Optional[str]:
         """Key of the optimizer that owns the hash tables (``"<group>/tables"``), if there is one."""
@@ -264,7 +273,9 @@ class NeRSembleTrainer:
         self._pending = ("pinned", None)
 
     def consolidate(self) -> None:
-        """Data-parallel runs: rebuild the full fp32 master tables on every rank (before ``model.state_dict()``)."""
+        """Data-parallel runs: rebuild the full fp32 master tables on every rank (before ``model.state_dict()``).
+        Compact first-grid phase: write grid 0 and its moments back into the full layout."""
+        self.model.field.hash_ensemble.sync_first_grid()
         for opt in self.optimizers.values():
             if isinstance(opt, ShardedTableAdam):
                 opt.gather_master()

@@ -86,6 +86,11 @@ class HashEnsemble(nn.Module):
         # set by engine.hash_adam.HashTableAdam: factored-gradient sink (no dense table gradient is materialised)
         self.grad_sink = None
         self._window_cache = {}
+        # compact first-grid phase (see first_grid_phase below): None, or the contiguous copies of grid 0
+        self.compact_first_grid = False        # switched on by the trainer (NeRSembleTrainer(compact_first_grid=True))
+        self._compact = None
+        self._ones_code = None
+        self._zero_slots = None
         # torch's fused optimizers update parameters in place WITHOUT bumping Tensor._version: if one of them steps the
         # tables, the fp16 working copy must be rebuilt (the native table optimizers write it themselves)
         import weakref
@@ -126,12 +131,77 @@ class HashEnsemble(nn.Module):
         """Called by the fused Adam step, which writes master and working copy together."""
         self._f16_version = (self.tables._version, self.tables.data_ptr())
 
+    # ---- compact first-grid phase ----------------------------------------------------------------
+    # While the coarse-to-fine window equals 1 -- the first 40 000 steps of the reference's schedule
+    # (train_nersemble.py:77-78) -- and ``disable_initial_hash_ensemble`` pins the blend weights to one
+    # (hash_ensemble.py:121-123), the HashEnsemble IS its first hash grid: every other grid is multiplied by a zero
+    # window weight, receives a zero gradient, keeps zero Adam moments and is not moved by the optimizer.  The native
+    # [entry][f][h] layout puts the 32 grids of an entry into one 128-byte line, so reading / updating "only grid 0"
+    # there still moves every line (measured: no gain, DESIGN.md 7b).  In this phase the module therefore works on a
+    # contiguous copy of grid 0 -- [entry][f], 49 MB instead of 1.6 GB at the reference geometry -- with the H = 1
+    # kernels, its optimizer steps that copy (engine/hash_adam.py), and ``leave_first_grid_phase`` writes it back into
+    # column 0 of the full layout when the window opens (or the module is evaluated / saved).  Same arithmetic on the
+    # same values: the H = 32 kernels at window 1 add exact zeros for the other 31 grids.
+    def first_grid_phase(self, window_hash_encodings: Optional[float]) -> bool:
+        return (self.compact_first_grid and self.training and self.disable_initial_hash_ensemble
+                and window_hash_encodings is not None and window_hash_encodings == 1 and self.n_hash_encodings > 1
+                and self.tables.is_cuda and self.grad_sink is not None)
+
+    def enter_first_grid_phase(self) -> dict:
+        if self._compact is None:
+            self.wait_tables()
+            master = self.tables.detach()[:, :, 0:1].contiguous()
+            dev = master.device
+            self._compact = {"master": master, "f16": master.to(torch.float16), "geom": self.geom,
+                             "code": torch.ones((1, 1), dtype=torch.float32, device=dev)}
+            for cb in list(getattr(self, "_compact_listeners", [])):
+                cb("enter")
+        return self._compact
+
+    def zero_slots(self, n: int, device) -> torch.Tensor:
+        """int32 zeros [>= n] (the code slot of every sample in the compact phase); grown, never shrunk."""
+        z = self._zero_slots
+        if z is None or z.shape[0] < n or z.device != torch.device(device):
+            z = self._zero_slots = torch.zeros((max(n, 1 << 16) * 5 // 4,), dtype=torch.int32, device=device)
+        return z
+
+    def sync_first_grid(self) -> None:
+        """Write the compact copy (and, through the listeners, its optimizer state) into the full layout; stay compact."""
+        c = self._compact
+        if c is None:
+            return
+        self.wait_tables()
+        with torch.no_grad():
+            self.tables.detach()[:, :, 0:1].copy_(c["master"])
+            if self.tables_f16.device != self.tables.device:
+                self.tables_f16 = torch.empty_like(self.tables, dtype=torch.float16)
+                self.tables_f16.copy_(self.tables.detach())
+            else:
+                self.tables_f16[:, :, 0:1].copy_(c["f16"])
+            self._f16_version = (self.tables._version, self.tables.data_ptr())
+        for cb in list(getattr(self, "_compact_listeners", [])):
+            cb("sync")
+
+    def leave_first_grid_phase(self) -> None:
+        if self._compact is None:
+            return
+        self.sync_first_grid()
+        for cb in list(getattr(self, "_compact_listeners", [])):
+            cb("leave")
+        self._compact = None
+
+    def train(self, mode: bool = True):
+        if not mode:
+            self.leave_first_grid_phase()            # evaluation reads the full layout (pre-blended grids, checkpoints)
+        return super().train(mode)
+
     # ---- reference state-dict layout -----------------------------------------------------------
     def _tcnn_keys(self, prefix):
         return [f"{prefix}hash_encodings.{c}.params" for c in range(self.n_tcnn_encodings)]
 
     @staticmethod
     def _export_tcnn_keys(module, state_dict, prefix, local_metadata):
+        module.sync_first_grid()
         module.wait_tables()
         native = state_dict.pop(prefix + "tables")
         if native.is_cuda:
@@ -229,6 +299,17 @@ class HashEnsemble(nn.Module):
         assert conditioning_code.shape[-1] == self.n_hash_encodings, \
             "If blend mixing type is chosen, conditioning code needs to have as many dimensions as there are " \
             "hashtables in the encoding"
+
+        if self.first_grid_phase(window_hash_encodings) and in_tensor.is_cuda:
+            c = self.enter_first_grid_phase()
+            self.wait_tables()                         # (the optimizer pass of the last step, on its own stream)
+            sink = self.grad_sink if torch.is_grad_enabled() else None
+            x = in_tensor.reshape(-1, 3)
+            return F.hash_ensemble(x, self.tables, c["f16"], c["code"], 1, self.geom,
+                                   code_index=self.zero_slots(x.shape[0], x.device)[:x.shape[0]], window=None, sink=sink,
+                                   precomputed=precomputed)
+        if self._compact is not None:
+            self.leave_first_grid_phase()              # the window has opened (or this is not a training forward)
 
         conditioning_code, window = self._conditioned(conditioning_code, window_hash_encodings, in_tensor.device)
 

@@ -456,6 +456,11 @@ class NeRSembleNGPModel(BaseModel):
         inp.alpha_map = alpha_map.reshape(-1).contiguous() if alpha_map is not None else None
         inp.depth_targets = batch["depth_maps"].to(torch.float32).reshape(-1).contiguous()
         inp.he, inp.window = he, window
+        if he.first_grid_phase(window_hash):
+            inp.first_grid = he.enter_first_grid_phase()
+        else:
+            he.leave_first_grid_phase()
+            inp.first_grid = None
         inp.field_aabb6 = self.field._aabb6()
         inp.deform_packed = self.deformation_field.packed_params()
         inp.deform_aabb6 = self.deformation_field._aabb6()

@@ -586,3 +586,75 @@ def test_trainer_prefetches_the_next_batch(cuda):
     assert not any(used0)
     assert np.isfinite(losses).all() and losses[-1] < 0.8 * losses[0]
     assert abs(np.mean(losses[-8:]) - np.mean(losses0[-8:])) < 0.25 * np.mean(losses0[-8:])
+
+
+def _compact_run(compact, steps, window_hash=None, seed=31):
+    from nersemble_amd.workloads import build_workload
+    torch.manual_seed(seed)
+    trainer, data, _ = build_workload("p030_h16", device="cuda:0", small=True, n_rays=512, compact_first_grid=compact,
+                                      window_hash=window_hash)
+    he = trainer.model.field.hash_ensemble
+    init = he.tables.detach().clone()
+    losses, in_phase, first = [], [], None
+    for step in range(steps):
+        torch.manual_seed(500 + step)                                   # same near-plane jitter on both sides
+        loss, loss_dict, metrics = trainer.train_iteration(step, *data.next_train(step))
+        losses.append(loss.item())
+        in_phase.append(he._compact is not None)
+        if step == 0:
+            first = {k: v.item() for k, v in loss_dict.items()}
+            trainer.consolidate()
+            he.wait_tables()
+            first["tables"] = he.tables.detach().clone()
+    trainer.flush_scheduler_step()
+    return trainer, init, losses, in_phase, first
+
+
+def test_compact_first_grid_phase_is_the_same_training(cuda):
+    """``NeRSembleTrainer(compact_first_grid=True)``: while the window keeps one hash grid on, a contiguous copy of that
+    grid is trained with the H = 1 kernels.  Same loss bit for bit in the first forward, the same table after one
+    optimizer step (up to the order of the atomics), the other grids untouched, the same run afterwards."""
+    t_c, init, l_c, phase_c, f_c = _compact_run(True, 12)
+    t_f, _, l_f, phase_f, f_f = _compact_run(False, 12)
+    assert all(phase_c) and not any(phase_f)
+    tab_c, tab_f = f_c.pop("tables"), f_f.pop("tables")
+    assert f_c == f_f, (f_c, f_f)                                            # every loss term of step 0: bit for bit
+    d = (tab_c - tab_f).abs()
+    assert (d <= 1e-5).float().mean().item() >= 0.9995
+    assert torch.equal(tab_c[:, :, 1:], init[:, :, 1:])                      # Adam does not move a grid that is off
+    assert torch.equal(tab_f[:, :, 1:], init[:, :, 1:])
+    assert (tab_c[:, :, 0] != init[:, :, 0]).any()
+    assert np.allclose(l_c[:5], l_f[:5], rtol=2e-3), (l_c, l_f)
+    assert np.allclose(l_c, l_f, rtol=5e-2), (l_c, l_f)
+    # checkpoints see the trained grid: model.state_dict() and the optimizer's moments in the reference layout
+    he = t_c.model.field.hash_ensemble
+    sd_c, sd_f = t_c.model.state_dict(), t_f.model.state_dict()
+    key = "field.hash_ensemble.hash_encodings.0.params"
+    assert (sd_c[key] - sd_f[key]).abs().mean().item() <= 1e-5 and he._compact is not None      # still in the phase
+    st = t_c.state_dict()["optimizers"][t_c.group_of_tables()]["native_table_adam"]
+    st_f = t_f.state_dict()["optimizers"][t_f.group_of_tables()]["native_table_adam"]
+    assert st["step"] == st_f["step"] == 12
+    a, b = st["exp_avg_sq"][0], st_f["exp_avg_sq"][0]
+    assert a.abs().sum().item() > 0
+    assert abs(a.abs().sum().item() - b.abs().sum().item()) <= 0.05 * b.abs().sum().item()
+    # evaluation leaves the phase (pre-blended grids and everything else read the full layout) and agrees with the full run
+    t_c.model.eval()
+    assert he._compact is None
+    t_c.model.train()
+
+
+def test_compact_phase_ends_when_the_window_opens(cuda):
+    """Window schedule (4, 12): one grid until step 4, then the window grows -- the compact copy is written back into
+    column 0 of the full layout and training continues there."""
+    t_c, init, l_c, phase_c, _ = _compact_run(True, 10, window_hash=(4, 12))
+    t_f, _, l_f, phase_f, _ = _compact_run(False, 10, window_hash=(4, 12))
+    assert phase_c == [s <= 4 for s in range(10)], phase_c
+    assert not any(phase_f)
+    assert np.allclose(l_c[:5], l_f[:5], rtol=2e-3), (l_c, l_f)
+    assert np.allclose(l_c, l_f, rtol=5e-2), (l_c, l_f)
+    a = t_c.model.field.hash_ensemble
+    b = t_f.model.field.hash_ensemble
+    a.wait_tables(), b.wait_tables()
+    d = (a.tables.detach() - b.tables.detach()).abs()
+    assert d.mean().item() <= 0.02 * b.tables.detach().abs().mean().item() + 1e-6
+    assert (a.tables.detach()[:, :, 1] != init[:, :, 1]).any()               # the second grid trains once it is on
