@@ -430,8 +430,10 @@ __global__ __launch_bounds__(WAVES * kWave) void ens_bwd_kernel(
 template <int WAVES>
 __global__ __launch_bounds__(WAVES * kWave) void ens_scatter_kernel(
     const float* __restrict__ x, int64_t B, const nsx_grid_geom g, const int32_t* __restrict__ code_index,
-    const float* __restrict__ dout, float* __restrict__ G, int64_t n_tiles, float* __restrict__ nonfinite) {
+    const float* __restrict__ dout, float* __restrict__ G, int64_t n_tiles, float* __restrict__ nonfinite,
+    const int64_t* __restrict__ n_dev) {
     constexpr int SPW = 8, LPE = 8;                   // 8 samples per wave step, 8 lanes (2 items each) per sample
+    NSX_DEVICE_COUNT(B, n_tiles, SPW, n_dev);
     bool bad = false;
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x / kWave;
@@ -841,7 +843,7 @@ int nsx_hash_ensemble_bwd_scatter(const float* x, int64_t B, const nsx_grid_geom
     const int64_t cap = (int64_t)num_cus() * blocks_per_cu;
     if (blocks > cap) blocks = cap;
     hipLaunchKernelGGL((ens_scatter_kernel<WAVES>), dim3((unsigned)blocks), dim3(WAVES * kWave), 0, (hipStream_t)stream, x,
-                       B, *g, code_slot, dout, G, n_tiles, nonfinite);
+                       B, *g, code_slot, dout, G, n_tiles, nonfinite, count_for(B));
     NSX_LAUNCH_CHECK("nsx_hash_ensemble_bwd_scatter launch");
     return NSX_OK;
 }

@@ -61,8 +61,7 @@ class _MainPass(torch.autograd.Function):
         comp = getattr(inp, "first_grid", None)
         if comp is not None:
             he.wait_tables()
-            H, code_h, hash_window = 1, comp["code"], None
-            hash_slot = he.zero_slots(S, dev)[:S]
+            H, code_h, hash_window = 1, he.first_grid_code(code_h.shape[0]), None      # (slots as in the full layout)
         code_d = code_deform.detach().contiguous()
         tables_f16 = he.half_tables() if comp is None else comp["f16"]
         # -- world positions of the samples, deformation offsets (normalised space)
@@ -207,10 +206,20 @@ class _MainPass(torch.autograd.Function):
         dcode_s = (torch.zeros if inp.n_dev is not None else torch.empty)((S, H), dtype=f32, device=dev) \
             if need_code else None
         dx = torch.empty((S, 3), dtype=f32, device=dev)
+        G_fused = G
+        if first_grid and G is not None and sink is not None:
+            # compact first-grid phase: the scatter as its own kernel.  The H = 1 instance of the fused kernel has one lane
+            # per sample, so the 16 (corner, feature) items of a sample and level go out as 16 instructions of 64
+            # unrelated sectors each (5.5 ms at 650 k samples); the stand-alone scatter keeps the 8-lanes-per-sample mapping
+            # whose neighbouring (feature, x) items share a sector.  The gather half (dL/dx of one grid) is cheap.
+            check(L.nsx_hash_ensemble_bwd_scatter(ptr(pn), S, C.byref(geom), n_rows, ptr(hash_slot), ptr(dout), ptr(G),
+                                                  ptr(sink.nonfinite), 8, st), "nsx_hash_ensemble_bwd_scatter")
+            G_fused = None
         check(L.nsx_hash_ensemble_bwd_factored(ptr(pn), S, ptr(tables_f16), H, C.byref(geom), ptr(code_h), code_h.stride(0),
-                                               n_rows, ptr(hash_slot), ptr(hash_window), ptr(dout), ptr(G), ptr(dcode_s),
-                                               ptr(dx), ptr(sink.nonfinite) if (sink is not None and need_tab) else None,
-                                               st), "nsx_hash_ensemble_bwd_factored")
+                                               n_rows, ptr(hash_slot), ptr(hash_window), ptr(dout), ptr(G_fused),
+                                               ptr(dcode_s), ptr(dx),
+                                               ptr(sink.nonfinite) if (sink is not None and need_tab and G_fused is not None)
+                                               else None, st), "nsx_hash_ensemble_bwd_factored")
         if sink is not None and need_tab and ctx.announced:
             # G is complete, and so are the gradients of the two fused MLPs (the rest of the tables' optimizer group):
             # the table optimizer may start its 12 GB pass now, beside the deformation backward below

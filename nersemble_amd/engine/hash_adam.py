@@ -149,8 +149,7 @@ class HashTableAdam(torch.optim.Optimizer):
         st["step"] += 1
         b1, b2 = group["betas"]
         comp = he._compact
-        if comp is not None and len(entries) == 1 and p.grad is None \
-                and entries[0]["code"].data_ptr() == comp["code"].data_ptr():
+        if comp is not None and len(entries) == 1 and p.grad is None and he.is_first_grid_code(entries[0]["code"]):
             # compact first-grid phase: the step of grid 0 alone, on its contiguous copy (H = 1 pass, 0.7 GB instead of
             # 11.7 GB at the reference geometry); the other grids have zero gradient and zero moments -- Adam leaves them
             # where they are
@@ -158,7 +157,8 @@ class HashTableAdam(torch.optim.Optimizer):
             sparse = 0 < sink.samples_scattered * 80 < self.consume_density_limit * (e["G"].numel() // 8)
             consume = self.consume_gradient and sparse and sink.is_persistent(e["G"])
             fn = lib().nsx_adam_hash_factored_consume if consume else lib().nsx_adam_hash_factored
-            check(fn(ptr(e["G"]), 1, ptr(comp["code"]), 1, None, 1, C.byref(he.geom), ptr(comp["master"]),
+            check(fn(ptr(e["G"]), e["n_rows"], ptr(e["code"]), e["code"].stride(0), None, 1, C.byref(he.geom),
+                     ptr(comp["master"]),
                      ptr(cs["exp_avg"]), ptr(cs["exp_avg_sq"]), ptr(comp["f16"]), group["lr"], b1, b2, group["eps"],
                      st["step"], ptr(inv_scale), ptr(found_inf), stream()), "nsx_adam_hash_factored")
             if consume:

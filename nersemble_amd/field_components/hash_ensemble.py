@@ -153,10 +153,25 @@ class HashEnsemble(nn.Module):
             master = self.tables.detach()[:, :, 0:1].contiguous()
             dev = master.device
             self._compact = {"master": master, "f16": master.to(torch.float16), "geom": self.geom,
-                             "code": torch.ones((1, 1), dtype=torch.float32, device=dev)}
+                             "codes": {1: torch.ones((1, 1), dtype=torch.float32, device=dev)}}
+            self._compact["code"] = self._compact["codes"][1]
             for cb in list(getattr(self, "_compact_listeners", [])):
                 cb("enter")
         return self._compact
+
+    def first_grid_code(self, n_rows: int) -> torch.Tensor:
+        """The phase's code table with ``n_rows`` rows of one: the kernels keep one gradient plane per code row, and the
+        samples of a batch stay spread over their time slots' planes -- with a single plane every sample of the batch adds
+        to the same few thousand coarse-level entries, and the memory-side atomics serialise (measured: hash backward
+        5.5 ms instead of 1.9 at 650 k samples)."""
+        codes = self._compact["codes"]
+        if n_rows not in codes:
+            codes[n_rows] = torch.ones((n_rows, 1), dtype=torch.float32, device=self._compact["master"].device)
+        return codes[n_rows]
+
+    def is_first_grid_code(self, code: torch.Tensor) -> bool:
+        c = self._compact
+        return c is not None and any(code.data_ptr() == t.data_ptr() for t in c["codes"].values())
 
     def zero_slots(self, n: int, device) -> torch.Tensor:
         """int32 zeros [>= n] (the code slot of every sample in the compact phase); grown, never shrunk."""
