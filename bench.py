@@ -48,7 +48,7 @@ def kernel_model(name: str, ints, H: int, total_entries: int):
     """(bound, work per launch) for the kernels with a stated algorithmic cost.
     `ints` = the integer arguments of the C-ABI call as recorded by the profiler."""
     if name in ("nsx_hash_ensemble_fwd", "nsx_hash_ensemble_bwd_factored"):
-        H = ints[1]                                           # (the compact first-grid phase calls these with H = 1)
+        H = ints[1] if len(ints) > 1 else H                   # (the compact first-grid phase calls these with H = 1)
     if name == "nsx_hash_ensemble_fwd":                       # (B, H, code_stride)
         return "hbm", ints[0] * (512.0 * H + 80.0)
     if name == "nsx_hash_ensemble_bwd_factored":              # (B, H, code_stride, n_slots)
@@ -65,7 +65,7 @@ def kernel_model(name: str, ints, H: int, total_entries: int):
     if name == "nsx_hash_ensemble_bwd":
         return "hbm", ints[0] * (1024.0 * H + 76.0)
     if name == "nsx_adam_hash_factored":                      # (n_slots, code_stride, H, step)
-        H = ints[2]
+        H = ints[2] if len(ints) > 2 else H
         Hp = 1
         while Hp < H:
             Hp *= 2

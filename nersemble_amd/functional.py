@@ -223,10 +223,18 @@ class _HashEnsembleFn(torch.autograd.Function):
                 for t in (x, dout, code_index, G):                      # allocated on `cur`, read on `side`
                     t.record_stream(side)
                 G = None                                                # the gather half below adds nothing to G
+            elif G is not None and H == 1 and x.is_cuda and use_sink:
+                # one grid: the fused kernel's H = 1 instance has one lane per sample and issues the 16 (corner, feature)
+                # items of a sample and level as 16 instructions of unrelated sectors; the stand-alone scatter keeps the
+                # 8-lanes-per-sample mapping whose neighbouring items share a sector (3x fewer sector atomics)
+                check(lib().nsx_hash_ensemble_bwd_scatter(ptr(x), B, C.byref(geom), n_rows, ptr(code_index), ptr(dout),
+                                                          ptr(G), ptr(ctx.sink.nonfinite), 8, stream()),
+                      "nsx_hash_ensemble_bwd_scatter")
+                G = None
             check(lib().nsx_hash_ensemble_bwd_factored(ptr(x), B, ptr(tables_f16), H, C.byref(geom), ptr(code),
                                                        code.stride(0), n_rows, ptr(code_index), ptr(window),
                                                        ptr(dout), ptr(G), ptr(dcode_s), ptr(dx),
-                                                       ptr(ctx.sink.nonfinite) if (use_sink and not split) else None,
+                                                       ptr(ctx.sink.nonfinite) if (use_sink and G is not None) else None,
                                                        stream()),
                   "nsx_hash_ensemble_bwd_factored")
             if use_sink and ctx.announced:
