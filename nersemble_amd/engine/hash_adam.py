@@ -34,10 +34,7 @@ class HashTableAdam(torch.optim.Optimizer):
         # compact first-grid phase of the HashEnsemble (field_components/hash_ensemble.py): the moments of grid 0 as
         # contiguous [entry][f] arrays while it lasts
         self._compact_state = None
-        listeners = getattr(hash_ensemble, "_compact_listeners", None)
-        if listeners is None:
-            listeners = hash_ensemble._compact_listeners = []
-        listeners.append(self._on_first_grid_phase)
+        hash_ensemble._compact_listeners = [self._on_first_grid_phase]      # (the optimizer that owns the tables now)
 
     @torch.no_grad()
     def _on_first_grid_phase(self, what: str) -> None:

@@ -89,7 +89,7 @@ class HashEnsemble(nn.Module):
         # compact first-grid phase (see first_grid_phase below): None, or the contiguous copies of grid 0
         self.compact_first_grid = False        # switched on by the trainer (NeRSembleTrainer(compact_first_grid=True))
         self._compact = None
-        self._ones_code = None
+        self._compact_listeners = []           # callables(what: "enter" | "sync" | "leave"): the optimizer's moments follow
         self._zero_slots = None
         # torch's fused optimizers update parameters in place WITHOUT bumping Tensor._version: if one of them steps the
         # tables, the fp16 working copy must be rebuilt (the native table optimizers write it themselves)
@@ -155,7 +155,7 @@ class HashEnsemble(nn.Module):
             self._compact = {"master": master, "f16": master.to(torch.float16), "geom": self.geom,
                              "codes": {1: torch.ones((1, 1), dtype=torch.float32, device=dev)}}
             self._compact["code"] = self._compact["codes"][1]
-            for cb in list(getattr(self, "_compact_listeners", [])):
+            for cb in list(self._compact_listeners):
                 cb("enter")
         return self._compact
 
@@ -194,14 +194,14 @@ class HashEnsemble(nn.Module):
             else:
                 self.tables_f16[:, :, 0:1].copy_(c["f16"])
             self._f16_version = (self.tables._version, self.tables.data_ptr())
-        for cb in list(getattr(self, "_compact_listeners", [])):
+        for cb in list(self._compact_listeners):
             cb("sync")
 
     def leave_first_grid_phase(self) -> None:
         if self._compact is None:
             return
         self.sync_first_grid()
-        for cb in list(getattr(self, "_compact_listeners", [])):
+        for cb in list(self._compact_listeners):
             cb("leave")
         self._compact = None
 
