@@ -1,3 +1,5 @@
+# On the GPU box: device timelines (tools/timeline.py) of the steady state (--preroll 600) and of the first steps from
+# rocprofv3 kernel traces, an A/B of the early table step, and the two HBM counter passes.  Results: gpurun_out/tl/, gpurun_out/prof_r02/
 set -u
 export TMPDIR=/tmp
 out=gpurun_out/tl
