@@ -170,15 +170,16 @@ class _MainPass(torch.autograd.Function):
         check(L.nsx_sample_losses_bwd(ptr(w), ptr(inp.t0), ptr(inp.t1), ptr(inp.packed), R, ptr(inp.depth_targets),
                                       float(eps), int(max_ray), R, ptr(sums), ptr(g3), ptr(gw), st), "nsx_sample_losses_bwd")
         # -- compositing
-        ds = torch.zeros((S, 1), dtype=f32, device=dev)
-        dc = torch.zeros((S, 3), dtype=f32, device=dev)
+        # every zero-initialised buffer of the backward out of one fill (functional.zeros_many)
+        n_deform = int(L.nsx_deform_param_count())
+        (ds, dc, d_head, d_base_out, d_base, d_feats, gparams, gtable) = F.zeros_many(
+            [((S, 1), f32), ((S, 3), f32), ((head_w.numel(),), f32), ((S, inp.base_out_dim), f16), ((base_w.numel(),), f32),
+             ((S, feats.shape[1]), f16), ((n_deform,), f32), (tuple(code_d.shape), code_d.dtype)], dev)
         check(L.nsx_composite_bwd(ptr(inp.t0), ptr(inp.t1), ptr(density), ptr(rgb_s), ptr(inp.packed), R,
                                   float(inp.background), ptr(clip), ptr(acc1), ptr(dep1), ptr(gw), ptr(g_rgb), ptr(g_acc),
                                   ptr(g_dep), ptr(ds), ptr(dc), st), "nsx_composite_bwd")
         # -- mlp_head: gradient of its parameters and of the geometry features (columns 1.. of base_out)
         dc16 = dc.to(f16)
-        d_head = torch.zeros(head_w.numel(), dtype=f32, device=dev)
-        d_base_out = torch.zeros((S, inp.base_out_dim), dtype=f16, device=dev)
         check(L.nsx_mlp_bwd(ptr(head_w), inp.head_hidden, S, ptr(inp.directions), inp.directions.stride(0), 3, 0.5, 0.5,
                             ptr(base_out), base_out.stride(0), 1, inp.geo_dim, 3, inp.head_act, ptr(dc16), dc16.stride(0),
                             ptr(d_head), None, ptr(d_base_out), st), "nsx_mlp_bwd")
@@ -186,8 +187,6 @@ class _MainPass(torch.autograd.Function):
         check(L.nsx_density_bwd(ptr(base_out), base_out.stride(0), ptr(sel), ptr(ds), S, ptr(d_base_out), st),
               "nsx_density_bwd")
         # -- mlp_base
-        d_base = torch.zeros(base_w.numel(), dtype=f32, device=dev)
-        d_feats = torch.zeros((S, feats.shape[1]), dtype=f16, device=dev)
         check(L.nsx_mlp_bwd(ptr(base_w), inp.base_hidden, S, None, 0, 0, 1.0, 0.0, ptr(feats), feats.stride(0), 0,
                             feats.shape[1], inp.base_out_dim, inp.base_act, ptr(d_base_out), d_base_out.stride(0), ptr(d_base),
                             None, ptr(d_feats), st), "nsx_mlp_bwd")
@@ -238,9 +237,6 @@ class _MainPass(torch.autograd.Function):
         goff = torch.empty((S, 3), dtype=f32, device=dev)
         check(L.nsx_normalise_bwd(ptr(dx), ptr(sel), S, inp.field_aabb6, ptr(goff), st), "nsx_normalise_bwd")
         # -- deformation field
-        n_params = int(L.nsx_deform_param_count())
-        gparams = torch.zeros(n_params, dtype=f32, device=dev)
-        gtable = torch.zeros_like(code_d)
         scratch = torch.empty(int(L.nsx_deform_scratch_bytes(S)), dtype=torch.uint8, device=dev)
         check(L.nsx_deform_bwd(ptr(inp.deform_packed), ptr(pos), S, inp.deform_aabb6, ptr(code_d), code_d.stride(0),
                                ptr(inp.slot), code_d.shape[0], inp.deform_window7, ptr(goff), ptr(scratch), ptr(gparams),

@@ -592,6 +592,22 @@ class _HashGridFn(torch.autograd.Function):
         return dx, dtab, None, None
 
 
+def zeros_many(specs, device):
+    """Zero tensors of the given (shape, dtype) specs carved out of ONE buffer: one fill launch instead of len(specs)
+    (the steady-state step is a chain of small dependent kernels; every launch on it costs ~5 us of device time).
+    Each tensor starts on a 256-byte boundary."""
+    sizes, total = [], 0
+    for shape, dtype in specs:
+        n = 1
+        for d in shape:
+            n *= int(d)
+        nbytes = n * torch.empty((), dtype=dtype).element_size()
+        sizes.append((total, nbytes))
+        total += (nbytes + 255) // 256 * 256
+    buf = torch.zeros((max(total, 1),), dtype=torch.uint8, device=device)
+    return [buf[off:off + nb].view(dtype).view(tuple(shape)) for (off, nb), (shape, dtype) in zip(sizes, specs)]
+
+
 @torch.no_grad()
 def gather_rows(index: torch.Tensor, *tensors: torch.Tensor, zero_fill: bool = False):
     """[t[index] for t in tensors] (rows along dim 0) in one native launch; no autograd (values only).
@@ -599,8 +615,10 @@ def gather_rows(index: torch.Tensor, *tensors: torch.Tensor, zero_fill: bool = F
     idx = index.to(torch.int64).contiguous()
     n = idx.shape[0]
     srcs = [(t.detach() if t.requires_grad else t).contiguous() for t in tensors]
-    alloc = torch.zeros if zero_fill else torch.empty
-    outs = [alloc((n,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device) for t in srcs]
+    if zero_fill and srcs:
+        outs = zeros_many([((n,) + tuple(t.shape[1:]), t.dtype) for t in srcs], srcs[0].device)
+    else:
+        outs = [torch.empty((n,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device) for t in srcs]
     k = len(srcs)
     if n > 0 and k > 0:
         rb = []
