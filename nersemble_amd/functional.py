@@ -77,6 +77,8 @@ class FactoredGradSink:
         self.pending = 0             # forwards recorded for autograd whose backward has not run yet
         self.pre_cleared = None      # (G, event): the cached buffer was cleared ahead of time on another stream
         self.samples_scattered = 0   # samples whose gradient the step's backward calls add to G (0: unknown)
+        self.clear_ahead_enabled = os.environ.get("NSX_CLEAR_G_AHEAD", "1") == "1"
+        self._fill_stream = None
         self.on_complete = None      # called inside the backward once the LAST pending one has added its share to G
         # Optional (NSX_SPLIT_SCATTER=1): the scatter into G as its own kernel on its own stream beside the gather half of
         # the HashEnsemble backward and the deformation field's backward (which only needs the gather's dL/dx).
@@ -141,9 +143,34 @@ class FactoredGradSink:
             torch.cuda.current_stream(G.device).wait_event(pre[1])
         elif zero:
             G.zero_()
+        if pre is not None and not cleared and not self.entries:
+            self.pre_cleared = None            # a buffer cleared ahead for a step that then asked for another one
         self.entries.append({"G": G, "code": code, "window": window, "n_rows": n_rows, "key": key,
                              "fresh": not zero and not cleared})
         return G
+
+    def clear_ahead(self, n_rows: int, total_entries: int, device) -> None:
+        """Clear the step's gradient buffer on a side stream, starting NOW (everything queued on the current stream so far
+        is waited for): called once the sampler's sigma_fn pass is queued, the 1.6 GB fill then runs beside the small
+        kernels of the main pass's forward and the head of its backward instead of in front of the scatter.  Nothing
+        to do when the optimizer left the buffer clean (mark_cleared) or a backward of this step already holds it."""
+        if not self.clear_ahead_enabled or self.entries or self.pre_cleared is not None:
+            return
+        G = self._cache.get(n_rows)
+        if G is None or G.device != torch.device(device) or G.shape[1] != total_entries:
+            G = torch.empty((n_rows, total_entries, 2), dtype=torch.float32, device=device)
+            self._cache = {n_rows: G}
+        main = torch.cuda.current_stream(G.device)
+        side = self._fill_stream
+        if side is None or side.device != G.device:
+            side = self._fill_stream = torch.cuda.Stream(G.device)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            G.zero_()
+            ev = torch.cuda.Event()
+            ev.record(side)
+        G.record_stream(side)
+        self.pre_cleared = (G, ev)
 
     def is_persistent(self, G: torch.Tensor) -> bool:
         """Is ``G`` the buffer the next step's ``buffer_for`` will hand out again?"""

@@ -440,6 +440,9 @@ class NeRSembleNGPModel(BaseModel):
         elif n_dev is not None:
             raise RuntimeError("device-side sample counts: the sigma_fn pass left no forward values to reuse")
         he = self.field.hash_ensemble
+        if he.grad_sink is not None and not he.first_grid_phase(window_hash):
+            # (the sampler's sigma_fn pass is queued: from here to the HashEnsemble's backward only small kernels run)
+            he.grad_sink.clear_ahead(int(uniq.shape[0]), he.geom.total_entries, ray_indices.device)
         code_hash, window = he._conditioned(self.time_embedding(uniq), window_hash, ray_indices.device)
         emb_d = self.time_embedding_deformation if self.time_embedding_deformation is not None else self.time_embedding
         code_deform = emb_d(uniq)
