@@ -228,6 +228,7 @@ class HashEnsemble(nn.Module):
         return state_dict
 
     def _import_tcnn_keys(self, state_dict, prefix, *args):
+        self.leave_first_grid_phase()          # what is loaded replaces the full layout: no compact copy may outlive it
         keys = self._tcnn_keys(prefix)
         if all(k in state_dict for k in keys):
             tc = torch.stack([state_dict.pop(k).reshape(self.geom.total_entries, -1) for k in keys])

@@ -213,3 +213,39 @@ def test_native_grad_scaler_follows_torch_gradscaler():
 def pytest_approx(v):
     import pytest
     return pytest.approx(v, rel=1e-7)
+
+
+def test_zeros_many_carves_one_buffer():
+    """functional.zeros_many: zero tensors of mixed dtypes / shapes out of one allocation, none overlapping."""
+    import torch
+    from nersemble_amd.functional import zeros_many
+    specs = [((5, 3), torch.float32), ((7,), torch.float16), ((0, 4), torch.int64), ((2, 2, 2), torch.uint8)]
+    outs = zeros_many(specs, "cpu")
+    assert [tuple(t.shape) for t in outs] == [tuple(s) for s, _ in specs]
+    assert [t.dtype for t in outs] == [d for _, d in specs]
+    base = outs[0].untyped_storage().data_ptr()
+    assert all(t.untyped_storage().data_ptr() == base for t in outs)             # one buffer
+    spans = sorted((t.data_ptr(), t.data_ptr() + t.numel() * t.element_size()) for t in outs if t.numel())
+    assert all(a[1] <= b[0] for a, b in zip(spans, spans[1:]))                   # disjoint
+    assert all((t.data_ptr() - base) % 256 == 0 for t in outs)
+    for i, t in enumerate(outs):
+        assert not t.any()
+        t.fill_(i + 1)
+    for i, t in enumerate(outs):
+        assert (t == i + 1).all()
+
+
+def test_prefetched_march_bookkeeping():
+    """OccGridEstimator keeps at most two counting passes ahead and hands one out only for exactly its call."""
+    import torch
+    from nersemble_amd.nerfacc import OccGridEstimator
+    grid = OccGridEstimator(roi_aabb=torch.tensor([-1., -1, -1, 1, 1, 1]), resolution=16, levels=1)
+    grid._prefetched = [{"key": 1}, {"key": 2}]
+    assert grid._take_prefetched(3) is None and len(grid._prefetched) == 2
+    assert grid._take_prefetched(2)["key"] == 2 and [p["key"] for p in grid._prefetched] == [1]
+    assert grid._take_prefetched(2) is None
+    assert grid._take_prefetched(1)["key"] == 1 and not grid._prefetched
+    o = torch.zeros((4, 3))
+    k1 = grid._march_key(o, o, 0.2, 1e3, 0.01, True, None)
+    torch.autograd.graph.increment_version(grid.binaries)                        # what the native grid update does
+    assert grid._march_key(o, o, 0.2, 1e3, 0.01, True, None) != k1
