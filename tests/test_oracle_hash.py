@@ -181,3 +181,31 @@ def test_torch_cpu_encoder_restatement_matches_the_c_oracle():
         base = torch_cpu.mlp_base_forward(got, torch.from_numpy(params)).float().numpy()
         want_b = omlp.mlp_fwd(got.float().numpy(), params, 0, 16, 0).astype(np.float32)
         assert np.abs(base - want_b).max() <= 4 * 2.0 ** -10 * max(1.0, np.abs(want_b).max())
+
+
+@pytest.mark.parametrize("H", [4, 16, 32])
+def test_first_grid_phase_algebra(H):
+    """What the compact first-grid phase of the product rests on (HashEnsemble.first_grid_phase), stated on the oracle:
+    at window 1 with ``disable_initial_hash_ensemble`` the H-grid ensemble IS its first grid -- forward, position
+    gradient and the gradient of grid 0 equal those of a one-grid ensemble holding grid 0, bit for bit, and every other
+    grid receives exactly zero."""
+    g = oracle.grid_geometry(**SMALL_GEOM_KW)
+    f_enc, P, C = ens_layout(H)
+    tabs = make_tcnn_tables(H, g, 11).astype(np.float16)
+    rng = np.random.default_rng(5)
+    B = 57
+    x = rng.random((B, 3), dtype=np.float32)
+    dout = rng.standard_normal((B, 2 * g.n_levels)).astype(np.float16).astype(np.float32)
+    codew = ohg.windowed_code(rng.standard_normal((B, H)), H, 1.0)               # ones * window(1) = e_0
+    assert np.array_equal(codew, np.eye(H, dtype=np.float32)[0][None].repeat(B, 0))
+    first = np.ascontiguousarray(tabs[0:1, :, 0:2])                              # grid 0 = encoding 0, features 0..1
+    out_h = ohg.ensemble_fwd(x, tabs.view(np.uint16), H, g, codew)
+    out_1 = ohg.ensemble_fwd(x, first.view(np.uint16), 1, g, np.ones((B, 1), np.float32))
+    assert np.array_equal(out_h.view(np.uint16), out_1.view(np.uint16))
+    dtab_h, _, dx_h = ohg.ensemble_bwd(x, tabs.view(np.uint16), H, g, codew, dout)
+    dtab_1, _, dx_1 = ohg.ensemble_bwd(x, first.view(np.uint16), 1, g, np.ones((B, 1), np.float32), dout)
+    assert np.array_equal(dx_h, dx_1)
+    assert np.array_equal(dtab_h[0, :, 0:2], dtab_1[0])
+    rest = dtab_h.copy()
+    rest[0, :, 0:2] = 0
+    assert not rest.any()                                                         # Adam never moves the other grids
