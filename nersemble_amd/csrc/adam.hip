@@ -9,6 +9,7 @@
 //           the master weights updated and the fp16 working copy written:  ~ 29 B/param.
 // Semantics are torch.optim.Adam's (no amsgrad / weight decay): m.lerp_(g, 1-b1); v = b2 v + (1-b2) g^2;
 // p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps); skipped entirely when *found_inf != 0 (GradScaler).
+#include <cstdlib>
 #include "nsx_common.h"
 
 namespace nsx {
@@ -337,9 +338,18 @@ static int launch_adam_factored(float* G, int n_slots, const float* code, int64_
     constexpr int HV = HP >= 4 ? 4 : HP;
     constexpr int EPB = 256 / (2 * HP / HV);
     const size_t smem = ((size_t)n_slots * HP + (size_t)n_slots * EPB * 2) * sizeof(float);
-    // 4 blocks (16 waves) per CU: measured 2.1-2.2 ms against 2.4-2.55 ms with 8 blocks per CU on the 12 GB pass -- the
-    // seven interleaved streams keep more DRAM pages open with fewer concurrent tiles (tools/adam_bench.py)
-    hipLaunchKernelGGL((adam_hash_factored_kernel<HP, CLEAR>), dim3(num_cus() * 4), dim3(256), smem, st, G, n_slots, code,
+    // Blocks per CU.  Alone, 4 (16 waves) is the optimum: 2.1-2.2 ms against 2.4-2.55 ms with 8 on the 12 GB pass -- the seven
+    // interleaved streams keep more DRAM pages open with fewer concurrent tiles (tools/adam_bench.py).  Inside the training
+    // step the pass runs beside the next step's marching and deformation forward, and what counts is the pair: 5 gives the
+    // shortest step (7.92-7.97 / 3.61-3.66 ms per step early / steady against 8.02-8.07 / 3.78-3.79 with 4; 6: 7.87-7.93 /
+    // 3.63-3.64; 8 fills every wave slot, the other stream's kernels then simply wait for the pass: 7.93 / 3.73).
+    static int per_cu = 0;
+    if (!per_cu) {
+        const char* e = getenv("NSX_ADAM_BLOCKS_PER_CU");      // (measurement knob)
+        per_cu = e ? atoi(e) : 5;
+        if (per_cu < 1 || per_cu > 8) per_cu = 5;
+    }
+    hipLaunchKernelGGL((adam_hash_factored_kernel<HP, CLEAR>), dim3(num_cus() * per_cu), dim3(256), smem, st, G, n_slots, code,
                        code_stride, window, H, total, master, m, v, reinterpret_cast<half_t*>(f16), hy, inv_scale,
                        found_inf);
     NSX_LAUNCH_CHECK("nsx_adam_hash_factored launch");
