@@ -158,7 +158,7 @@ def first_grid_phase_block(a):
            "--steps", str(a.steps), "--warmup", str(a.warmup), "--workload", a.workload,
            "--steady-after", str(a.steady_after), "--reserve-gb", str(a.reserve_gb)]
     try:
-        res = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+        res = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
         line = [l for l in res.stdout.splitlines() if l.startswith("{")][-1]
         d = json.loads(line)
     except Exception as exc:                                     # the block is a bonus: never lose the headline over it
