@@ -55,6 +55,21 @@ def ensemble_fwd(x: np.ndarray, tables_u16: np.ndarray, H: int, g: GridGeom, cod
     return out.view(np.float16)
 
 
+def ensemble_fwd_fast(x: np.ndarray, tables_u16: np.ndarray, H: int, g: GridGeom, codew: np.ndarray) -> np.ndarray:
+    """The CPU-baseline port of ``ensemble_fwd`` (fp32 accumulation, table-driven fp16 decode; nsx_oracle.c): what
+    bench.py's ``cpu_baseline`` times.  NOT the checker."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    codew = np.ascontiguousarray(codew, dtype=np.float32)
+    f_enc, p, c = ens_layout(H)
+    tables_u16 = np.ascontiguousarray(tables_u16.view(np.uint16))
+    assert tables_u16.shape == (c, g.total_entries, f_enc), tables_u16.shape
+    assert codew.shape == (x.shape[0], H)
+    out = np.empty((x.shape[0], g.n_levels * 2), dtype=np.uint16)
+    lib().nsxo_ensemble_fwd_fast(ptr(x), C.c_int64(x.shape[0]), ptr(tables_u16), C.c_int(H), C.byref(g),
+                                 ptr(codew), ptr(out))
+    return out.view(np.float16)
+
+
 def ensemble_bwd(x, tables_u16, H, g, codew, dout, want_table=True):
     """Returns (dtable fp32 [C,total,F_enc] or None, dcodew [B,H], dx [B,3])."""
     x = np.ascontiguousarray(x, dtype=np.float32)

@@ -196,6 +196,53 @@ void nsxo_ensemble_fwd(const float* x, int64_t B, const uint16_t* tables, int H,
     }
 }
 
+/* ---- CPU BASELINE port of the same forward (bench.py cpu_baseline only; NOT the checker) -------------------------
+ * What a CPU implementation tuned like one would be looks like: fp32 accumulation, fp16 decode through a 64 K-entry
+ * table, one 16-byte row read per (encoding, corner), the whole batch spread over the cores.  Held to the checker above
+ * in tests/test_oracle_hash.py (fp32 vs double accumulation: within one fp16 ulp). */
+static float g_h2f_lut[65536];
+static int g_h2f_lut_ready = 0;
+
+void nsxo_ensemble_fwd_fast(const float* x, int64_t B, const uint16_t* tables, int H,
+                            const nsxo_grid_geom* g, const float* codew, uint16_t* out) {
+    const int L = g->n_levels;
+    int F_enc, P, C; ens_layout(H, &F_enc, &P, &C);
+    const size_t enc_elems = (size_t)g->offset[L] * (size_t)F_enc;
+    if (!g_h2f_lut_ready) {
+        for (uint32_t i = 0; i < 65536u; ++i) g_h2f_lut[i] = nsxo_h2f((uint16_t)i);
+        g_h2f_lut_ready = 1;
+    }
+#pragma omp parallel for schedule(dynamic, 64)
+    for (int64_t b = 0; b < B; ++b) {
+        float code16[64];
+        for (int h = 0; h < H; ++h) code16[h] = g_h2f_lut[nsxo_f2h(codew[b * H + h])];
+        for (int l = 0; l < L; ++l) {
+            uint32_t c0[3]; float wl[3];
+            cell_of(g->scale[l], x + 3 * b, c0, wl);
+            float acc0 = 0.f, acc1 = 0.f;
+            for (int k = 0; k < 8; ++k) {
+                uint32_t c[3] = { c0[0] + (k & 1), c0[1] + ((k >> 1) & 1), c0[2] + ((k >> 2) & 1) };
+                const uint32_t e = entry_index(c, g->res[l], g->size[l]);
+                const float wk = ((k & 1) ? wl[0] : 1.f - wl[0]) * (((k >> 1) & 1) ? wl[1] : 1.f - wl[1])
+                               * (((k >> 2) & 1) ? wl[2] : 1.f - wl[2]);
+                float t0 = 0.f, t1 = 0.f;
+                for (int ce = 0; ce < C; ++ce) {
+                    const uint16_t* row = tables + (size_t)ce * enc_elems + ((size_t)g->offset[l] + e) * (size_t)F_enc;
+                    const float* cd = code16 + ce * P;
+                    for (int p = 0; p < P && ce * P + p < H; ++p) {
+                        t0 += g_h2f_lut[row[2 * p]] * cd[p];
+                        t1 += g_h2f_lut[row[2 * p + 1]] * cd[p];
+                    }
+                }
+                acc0 += wk * t0;
+                acc1 += wk * t1;
+            }
+            out[(size_t)b * (size_t)(L * 2) + (size_t)(l * 2 + 0)] = nsxo_f2h(acc0);
+            out[(size_t)b * (size_t)(L * 2) + (size_t)(l * 2 + 1)] = nsxo_f2h(acc1);
+        }
+    }
+}
+
 void nsxo_ensemble_bwd(const float* x, int64_t B, const uint16_t* tables, int H,
                        const nsxo_grid_geom* g, const float* codew, const float* dout,
                        float* dtable, float* dcodew, float* dx) {

@@ -60,6 +60,9 @@ void nsxo_hashgrid_fwd(const float* x, int64_t B, const uint16_t* table, int F_e
  * out fp16 [B][L*2]. code is rounded to fp16 before use (hash_ensemble.py:155). */
 void nsxo_ensemble_fwd(const float* x, int64_t B, const uint16_t* tables, int H,
                        const nsxo_grid_geom* g, const float* codew, uint16_t* out);
+/* CPU-baseline port of the same forward (fp32 accumulate, table-driven fp16 decode): bench.py cpu_baseline only. */
+void nsxo_ensemble_fwd_fast(const float* x, int64_t B, const uint16_t* tables, int H,
+                       const nsxo_grid_geom* g, const float* codew, uint16_t* out);
 
 /* Backward of the fused ensemble: given dout fp32 [B][L*2], produces
  * dtable fp32 (tcnn layout, same shape as tables; ACCUMULATED into),

@@ -209,3 +209,18 @@ def test_first_grid_phase_algebra(H):
     rest = dtab_h.copy()
     rest[0, :, 0:2] = 0
     assert not rest.any()                                                         # Adam never moves the other grids
+
+
+@pytest.mark.parametrize("H", [1, 4, 32])
+def test_cpu_baseline_port_matches_the_checker(H):
+    """bench.py's cpu_baseline times ``ensemble_fwd_fast`` (fp32 accumulation, table-driven fp16 decode); it computes what
+    the double-precision checker computes, to one fp16 ulp."""
+    g = oracle.grid_geometry(**SMALL_GEOM_KW)
+    tabs = make_tcnn_tables(H, g, 23).astype(np.float16)
+    rng = np.random.default_rng(9)
+    x = rng.random((301, 3), dtype=np.float32)
+    codew = ohg.windowed_code(rng.standard_normal((301, H)), H, 0.6 * H + 0.3)
+    a = ohg.ensemble_fwd(x, tabs.view(np.uint16), H, g, codew).astype(np.float32)
+    b = ohg.ensemble_fwd_fast(x, tabs.view(np.uint16), H, g, codew).astype(np.float32)
+    ulp = np.maximum(np.abs(a), 2.0 ** -14) * 2.0 ** -10
+    assert (np.abs(a - b) <= 1.01 * ulp).all(), np.abs(a - b).max()
