@@ -227,7 +227,8 @@ def test_zeros_many_carves_one_buffer():
     assert all(t.untyped_storage().data_ptr() == base for t in outs)             # one buffer
     spans = sorted((t.data_ptr(), t.data_ptr() + t.numel() * t.element_size()) for t in outs if t.numel())
     assert all(a[1] <= b[0] for a, b in zip(spans, spans[1:]))                   # disjoint
-    assert all((t.data_ptr() - base) % 256 == 0 for t in outs)
+    # offsets inside the buffer (a zero-element view has no defined data pointer: torch may answer nullptr)
+    assert all((t.data_ptr() - base) % 256 == 0 for t in outs if t.numel())
     for i, t in enumerate(outs):
         assert not t.any()
         t.fill_(i + 1)
