@@ -47,6 +47,9 @@ SPLIT_SCATTER = True            # set in main() from the trainer's gradient sink
 def kernel_model(name: str, ints, H: int, total_entries: int):
     """(bound, work per launch) for the kernels with a stated algorithmic cost.
     `ints` = the integer arguments of the C-ABI call as recorded by the profiler."""
+    if name == "nsx_hash_ensemble_bwd_codesum":               # the factored backward + in-kernel code-gradient sums
+        name = "nsx_hash_ensemble_bwd_factored"               # (same byte model; the [B, H] dcode tensor it is priced
+        #                                                        with no longer exists -- the model stays the harder one)
     if name in ("nsx_hash_ensemble_fwd", "nsx_hash_ensemble_bwd_factored"):
         H = ints[1] if len(ints) > 1 else H                   # (the compact first-grid phase calls these with H = 1)
     if name == "nsx_hash_ensemble_fwd":                       # (B, H, code_stride)
@@ -175,6 +178,47 @@ def first_grid_phase_block(a):
     return keep
 
 
+def open_window_block(a):
+    """The same command with the coarse-to-fine window OPEN (`--window-hash 0 1`: every hash grid on from step 1), in a
+    process of its own.  The reference keeps `window_hash_encodings == 1` only for steps 0 ... 40 000 of 300 001
+    (train_nersemble.py:77-78, hash_ensemble.py:121-123); from step 80 000 on all H grids are blended with the trained
+    time codes, the code gradient is needed (ens_bwd<DCODE = true> with the per-row sums in the kernel) and
+    `time_embedding` is stepped.  This block prices that 73-87 % of the schedule; the headline stays the default
+    schedule's first steps (BASELINE's configuration from a fresh model)."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--window-hash", "0", "1", "--no-cpu-baseline", "--no-first-grid-phase",
+           "--no-open-window", "--no-kernels-alone", "--steps", str(a.steps), "--warmup", str(a.warmup), "--workload", a.workload,
+           "--steady-after", str(a.steady_after), "--reserve-gb", str(a.reserve_gb)]
+    try:
+        res = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
+        line = [l for l in res.stdout.splitlines() if l.startswith("{")][-1]
+        d = json.loads(line)
+    except Exception as exc:                                     # the block is a bonus: never lose the headline over it
+        return {"error": repr(exc)[:300]}
+    keep = {k: d.get(k) for k in ("value", "unit", "ms_per_step", "steps", "warmup", "rays_per_sec", "psnr_last",
+                                  "samples_per_step_min_max", "steady_state", "rooflines")}
+    keep["native_kernel_avg_ms"] = {k: v["avg_ms"] for k, v in (d.get("native_kernel_ms") or {}).items()
+                                    if v["avg_ms"] >= 0.05}
+    keep["command"] = " ".join(cmd[1:])
+    return keep
+
+
+def self_launch(a, argv):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script through torch.distributed.run on this
+    node (127.0.0.1, a free port) and hand their output through.  The driver's own launch line sets WORLD_SIZE and never
+    gets here."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *argv]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
 def kernels_alone(trainer, H: int, log2_s: int = 20, iters: int = 10):
     """The priced kernels ONE AT A TIME on S = 2^20 uniformly random samples (seed 0) with the run's own tables and
     weights: no optimizer stream beside them, no ray-coherent sample order that would serve the coarse levels from L2 /
@@ -239,8 +283,26 @@ def kernels_alone(trainer, H: int, log2_s: int = 20, iters: int = 10):
     def scatter():
         check(lib().nsx_hash_ensemble_bwd_scatter(ptr(x), S, C.byref(g), T, ptr(slot), ptr(dout), ptr(G), None, 8,
                                                   stream()), "nsx_hash_ensemble_bwd_scatter")
+    rows = torch.empty((T, H), device=dev)
+    win = torch.ones((H,), device=dev)
+
+    def bwd_codesum():
+        check(lib().nsx_hash_ensemble_bwd_codesum(ptr(x), S, ptr(f16), H, C.byref(g), ptr(code), code.stride(0), T,
+                                                  ptr(slot), ptr(win), ptr(dout), ptr(G), ptr(rows),
+                                                  ptr(F.codesum_scratch(T, H, dev)), ptr(dx), None, stream()),
+              "nsx_hash_ensemble_bwd_codesum")
+
+    def bwd_nocode():
+        check(lib().nsx_hash_ensemble_bwd_factored(ptr(x), S, ptr(f16), H, C.byref(g), ptr(code), code.stride(0), T,
+                                                   ptr(slot), None, ptr(dout), ptr(G), None, ptr(dx), None,
+                                                   stream()), "nsx_hash_ensemble_bwd_factored")
     entry("nsx_hash_ensemble_bwd_factored (fused gather + scatter)", timeit(bwd), "hbm",
           S * (512.0 * H + 2048.0 + 64.0 + 4.0 * H + 28.0))
+    # window open: code gradient summed per code row in the kernel (no [S, H] tensor); window closed: no code gradient
+    entry("nsx_hash_ensemble_bwd_codesum (fused, code-gradient sums in the kernel)", timeit(bwd_codesum), "hbm",
+          S * (512.0 * H + 2048.0 + 64.0 + 28.0))
+    entry("nsx_hash_ensemble_bwd_factored (fused, no code gradient)", timeit(bwd_nocode), "hbm",
+          S * (512.0 * H + 2048.0 + 64.0 + 28.0))
     entry("nsx_hash_ensemble_bwd_factored (gather half)", timeit(gather), "hbm", S * (512.0 * H + 64.0 + 4.0 * H + 28.0))
     entry("nsx_hash_ensemble_bwd_scatter", timeit(scatter), "hbm", S * (2048.0 + 128.0 + 12.0 + 4.0))
     out["nsx_hash_ensemble_bwd_scatter"]["note"] = ("bound by memory-side fp32 atomics, not by bandwidth: uniform samples "
@@ -318,6 +380,11 @@ def main():
                          "contiguous copy of that grid with the H = 1 kernels.  Same results; NOT the headline, which "
                          "prices a step in the full 32-grid layout.  The default run reports it as `first_grid_phase`")
     ap.add_argument("--no-first-grid-phase", action="store_true", help="skip the `first_grid_phase` block")
+    ap.add_argument("--window-hash", type=int, nargs=2, default=None, metavar=("BEGIN", "END"),
+                    help="steps of the coarse-to-fine schedule of the hash grids instead of the workload's (40000 80000, "
+                         "train_nersemble.py:77-78); `0 1` = every grid on from step 1: the state of a run after END")
+    ap.add_argument("--window-open", action="store_true", help="shorthand for --window-hash 0 1")
+    ap.add_argument("--no-open-window", action="store_true", help="skip the `open_window` block")
     ap.add_argument("--no-kernels-alone", action="store_true", help="skip the stand-alone kernel timings after the run")
     ap.add_argument("--preroll", type=int, default=0,
                     help="untimed training steps BEFORE the warm-up (e.g. 600: the occupancy grid and the visibility "
@@ -326,6 +393,10 @@ def main():
                     help="after the timed region, training continues to this step and 100 more steps are timed as the "
                          "`steady_state` block (0: skip)")
     a = ap.parse_args()
+    if a.window_open and a.window_hash is None:
+        a.window_hash = [0, 1]
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(a, sys.argv[1:]))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -358,7 +429,8 @@ def main():
         n_rays = WORKLOADS[a.workload]["rays"] // world
     trainer, data, info = build_workload(a.workload, device=dev, rank=rank, world_size=world, n_rays=n_rays,
                                          global_loss_normalisers=(a.scaling == "strong" and world > 1),
-                                         compact_first_grid=a.compact_first_grid)
+                                         compact_first_grid=a.compact_first_grid,
+                                         window_hash=tuple(a.window_hash) if a.window_hash else None)
     if a.reserve_gb > 0:
         reserve = torch.empty(int(a.reserve_gb * 2 ** 30), dtype=torch.uint8, device=dev)
         del reserve
@@ -385,6 +457,7 @@ def main():
             if mark:
                 ev = torch.cuda.Event(enable_timing=True)
                 ev.record()
+                _lib.profiler.tag = len(step_marks)
             bundle, batch = batches[s]
             loss, loss_dict, metrics = trainer.train_iteration(a.preroll + s, bundle, batch,
                                                                next_ray_bundle=batches[s + 1][0])
@@ -418,6 +491,7 @@ def main():
     sink = trainer.model.field.hash_ensemble.grad_sink
     SPLIT_SCATTER = bool(sink is not None and sink.split_scatter)
     _lib.profiler.watch = {"nsx_hash_ensemble_fwd", "nsx_hash_ensemble_bwd_factored", "nsx_hash_ensemble_bwd",
+                           "nsx_hash_ensemble_bwd_codesum",
                            "nsx_hash_ensemble_bwd_scatter",
                            "nsx_adam_hash_factored", "nsx_adam_hash_factored_consume", "nsx_adam_dense",
                            "nsx_deform_fwd", "nsx_deform_bwd",
@@ -457,7 +531,13 @@ def main():
         prof = _lib.profiler.summary()
         total_entries = trainer.model.field.hash_ensemble.geom.total_entries
         work = {}
-        for name, st, en, ints in _lib.profiler.records:
+        # rows a launch PROCESSED: under a device-side sample count (nsx_device_count_begin) the call is made with the
+        # marched capacity and the kernel reads the kept count when it runs -- that count is the step's
+        # num_samples_per_batch, known to the host after the timed region
+        kept = [int(c) for _, c in step_marks]
+        for (name, st, en, ints), (tag, counted) in zip(_lib.profiler.records, _lib.profiler.tags):
+            if counted and tag is not None and tag < len(kept):
+                ints = [kept[tag]] + list(ints[1:])
             bound, w = kernel_model(name, ints, H, total_entries)
             if bound:
                 d = work.setdefault(name, {"bound": bound, "work": 0.0})
@@ -527,7 +607,9 @@ def main():
                        "early_table_step": bool(trainer.early_table_step),
                        "march_count_one_step_ahead": bool(trainer.prefetch_march),
                        "table_adam_consumes_gradient": bool(getattr(table_opt, "consume_gradient", False)),
-                       "compact_first_grid": bool(trainer.model.field.hash_ensemble.compact_first_grid)},
+                       "compact_first_grid": bool(trainer.model.field.hash_ensemble.compact_first_grid),
+                       "window_hash_schedule": list(a.window_hash) if a.window_hash else
+                       [trainer.model.config.window_hash_encodings_begin, trainer.model.config.window_hash_encodings_end]},
             "rays_per_sec": world * info["rays"] * a.steps / dt_max,
             "psnr_last": float(metrics["psnr"].detach()), "loss_last": float(loss.detach()),
             "roofline": roofline, "rooflines": rooflines, "native_kernel_ms": kernels,
@@ -550,8 +632,11 @@ def main():
             out["kernels_alone"] = kernels_alone(trainer, H)
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(H)
-        if world == 1 and not a.compact_first_grid and not a.no_first_grid_phase and a.preroll == 0:
+        if world == 1 and not a.compact_first_grid and not a.no_first_grid_phase and a.preroll == 0 \
+                and a.window_hash is None:
             out["first_grid_phase"] = first_grid_phase_block(a)
+        if world == 1 and not a.compact_first_grid and not a.no_open_window and a.preroll == 0 and a.window_hash is None:
+            out["open_window"] = open_window_block(a)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -131,6 +131,21 @@ int nsx_hash_ensemble_bwd_factored(const float* x, int64_t B, const nsx_half* ta
                                    int n_slots, const int32_t* code_slot, const float* window,
                                    const float* dout, float* G, float* dcode, float* dx, float* nonfinite,
                                    void* stream);
+/* The factored backward with the CODE gradient reduced inside the kernel.  Once the coarse-to-fine window is open
+ * (window_hash_encodings > 1: steps 40 000 ... 300 000 of the reference's schedule, train_nersemble.py:77-78) the time
+ * codes are trained, and autograd through hash_ensemble.py:125-138,155-156 + the nn.Embedding lookup
+ * (nersemble_instant_ngp.py:300-318) sums the per-sample code gradients into the <= 24 rows a batch uses.  Here the kernel
+ * accumulates those sums per block in LDS (runs of samples with equal rows merged with DPP first), writes one partial
+ * per block, and a one-block-per-row second stage adds the partials and applies the window's chain rule:
+ *   dcode_rows [n_slots][H] fp32 = window[h] * sum_{b: code_slot[b] = row} dL/dcode'_b[h]     (OVERWRITTEN; required)
+ *   scratch    float[nsx_hash_codesum_scratch_floats(n_slots, H)]                             (block partials)
+ * Everything else as nsx_hash_ensemble_bwd_factored (G may be NULL: gather half only).  No [B][H] tensor exists. */
+int64_t nsx_hash_codesum_scratch_floats(int n_slots, int H);
+int nsx_hash_ensemble_bwd_codesum(const float* x, int64_t B, const nsx_half* tables, int H,
+                                  const nsx_grid_geom* g, const float* code_table, int64_t code_stride,
+                                  int n_slots, const int32_t* code_slot, const float* window,
+                                  const float* dout, float* G, float* dcode_rows, float* scratch, float* dx,
+                                  float* nonfinite, void* stream);
 /* The two halves of the factored backward as separate launches, so that they can run on separate streams:
  *   nsx_hash_ensemble_bwd_factored(..., G = NULL, ...)   the GATHER half: dcode and dx only (bandwidth-bound table reads)
  *   nsx_hash_ensemble_bwd_scatter                        the SCATTER half: G only.  It needs neither the tables nor the

@@ -65,6 +65,10 @@ SIGNATURES = {
     "nsx_hash_ensemble_bwd_factored": (c_int, [c_void_p, c_int64, c_void_p, c_int, _GEOM_P, c_void_p, c_int64, c_int,
                                                c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                                c_void_p, c_void_p]),
+    "nsx_hash_codesum_scratch_floats": (c_int64, [c_int, c_int]),
+    "nsx_hash_ensemble_bwd_codesum": (c_int, [c_void_p, c_int64, c_void_p, c_int, _GEOM_P, c_void_p, c_int64, c_int,
+                                              c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                              c_void_p, c_void_p]),
     "nsx_hash_ensemble_bwd_scatter": (c_int, [c_void_p, c_int64, _GEOM_P, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                               c_int, c_void_p]),
     "nsx_tables_preblend": (c_int, [c_void_p, c_int, _GEOM_P, c_void_p, c_void_p, c_void_p, c_void_p]),
@@ -158,9 +162,14 @@ class KernelProfiler:
         self.records = []          # (name, start_event, end_event, int_args)
         self.alias = {}            # entry point -> the name it is booked under (variants of one kernel)
         self._pool = []
+        self.tag = None            # set by the caller (bench.py: index of the timed step); stored with every record
+        self.counted_capacity = None   # capacity of the active ``device_count`` scope, if any
+        self.tags = []             # per record: (tag, counted) -- counted: the call's row count is the scope's capacity,
+        #                            the kernel processed only the device-side count of that step
 
     def reset(self):
         self.records = []
+        self.tags = []
 
     def prewarm(self, n: int):
         """Create (and record once) n events up front: the first record of an event allocates it in the runtime,
@@ -203,7 +212,10 @@ class _LibProxy:
             s.record()
             rc = fn(*args)
             e.record()
-            profiler.records.append((profiler.alias.get(name, name), s, e, [a for a in args if isinstance(a, int)]))
+            ints = [a for a in args if isinstance(a, int)]
+            profiler.records.append((profiler.alias.get(name, name), s, e, ints))
+            profiler.tags.append((profiler.tag, profiler.counted_capacity is not None and bool(ints)
+                                  and ints[0] == profiler.counted_capacity))
             return rc
         return timed
 
@@ -238,11 +250,13 @@ class device_count:
             if self.n_dev.dtype != torch.int64 or self.n_dev.numel() != 1:
                 raise RuntimeError("device_count: n_dev must be one int64 on the device")
             check(lib().nsx_device_count_begin(ptr(self.n_dev), self.capacity), "nsx_device_count_begin")
+            profiler.counted_capacity = self.capacity
         return self
 
     def __exit__(self, *exc):
         if self.n_dev is not None:
             lib().nsx_device_count_end()
+            profiler.counted_capacity = None
         return False
 
 

@@ -251,9 +251,26 @@ __global__ __launch_bounds__(WAVES * kWave) void ens_bwd_kernel(
     const float* __restrict__ code, int64_t code_stride, const int32_t* __restrict__ code_index,
     const float* __restrict__ window, int Hreal, const float* __restrict__ dout,
     float* __restrict__ dtab, float* __restrict__ dcode, float* __restrict__ dx, int64_t n_tiles,
-    int n_slots, float* __restrict__ nonfinite, const int64_t* __restrict__ n_dev) {
+    int n_slots, float* __restrict__ nonfinite, const int64_t* __restrict__ n_dev,
+    float* __restrict__ csum_part) {
     using C = EnsCfg<H>;
-    NSX_DEVICE_COUNT(B, n_tiles, C::SPW, n_dev);
+    // csum_part (DCODE only): the code gradient leaves the kernel summed per code row -- [gridDim.x][n_slots][H] block
+    // partials, accumulated in LDS (code_sums_reduce_kernel adds the blocks and applies the window) -- instead of as a
+    // [B][H] tensor that torch then index_add_s into n_slots rows.  Every block writes its partial, also an idle one.
+    extern __shared__ float csum[];   // [n_slots][H], only when csum_part
+    const bool code_sums = DCODE && csum_part != nullptr;
+    if (n_dev) {
+        const int64_t n__ = *n_dev;
+        if (n__ < B) { B = n__ < 0 ? 0 : n__; n_tiles = (B + C::SPW - 1) / C::SPW; }
+    }
+    if (B <= 0) {
+        if (!code_sums) return;
+        n_tiles = 0;
+    }
+    if (code_sums) {
+        for (int i = threadIdx.x; i < n_slots * H; i += WAVES * kWave) csum[i] = 0.f;
+        __syncthreads();
+    }
     bool bad = false;                 // a non-finite value was added to the factored gradient
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x / kWave;
@@ -387,7 +404,43 @@ __global__ __launch_bounds__(WAVES * kWave) void ens_bwd_kernel(
             if (q == 0 && valid) { dx[b * 3 + 0] = dxa; dx[b * 3 + 1] = dya; dx[b * 3 + 2] = dza; }
         }
         // code gradient: grid h receives contributions of both feature planes
-        if (DCODE && dcode) {
+        if (DCODE && code_sums) {
+            // summed per code row in LDS.  Samples of a tile are adjacent lanes and, being consecutive samples of a
+            // ray, nearly always share their row: runs of equal rows are merged with DPP first, the run head adds.
+            // (Rows of invalid lanes hold zeros: their upstream gradient was forced to zero above.)
+            const uint32_t rk = (uint32_t)crow;
+            const uint32_t pk = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)rk, 0x111, 0xf, 0xf, true);
+            const bool head = ((s & 7) == 0) || (pk != rk);
+            float* crow_sums = csum + (size_t)rk * H;
+            auto emit = [&](int h, float val) {
+                float sum = val;
+                bool alive = true;
+                run_merge<1, 8>(rk, val, s & 7, alive, sum);
+                if (head && h < Hreal && sum != 0.f) atomicAdd(crow_sums + h, sum);
+            };
+            if constexpr (H == 1) {
+                emit(0, dc[0]);
+            } else if constexpr (C::NDW > C::DPF) {   // H = 2, 4
+#pragma unroll
+                for (int j = 0; j < C::DPF; ++j) {
+                    emit(2 * j, dc[2 * j] + dc[2 * (C::DPF + j)]);
+                    emit(2 * j + 1, dc[2 * j + 1] + dc[2 * (C::DPF + j) + 1]);
+                }
+            } else {                                   // H >= 8: both partner lanes hold the sum; each emits half
+#pragma unroll
+                for (int i = 0; i < NH; ++i) dc[i] += __shfl_xor(dc[i], (C::LPE / 2) * C::SPW);
+                const bool upper = q >= C::LPE / 2;
+#pragma unroll
+                for (int jj = 0; jj < C::NDW / 2; ++jj) {
+                    const int j0 = jj, j1 = jj + C::NDW / 2;
+                    const int pair = (q * C::NDW + (upper ? j1 : j0)) % C::DPF;
+                    const float a = upper ? dc[2 * j1] : dc[2 * j0];
+                    const float bq = upper ? dc[2 * j1 + 1] : dc[2 * j0 + 1];
+                    emit(2 * pair, a);
+                    emit(2 * pair + 1, bq);
+                }
+            }
+        } else if (DCODE && dcode) {
             if constexpr (H == 1) {
                 if (valid) dcode[b] = dc[0];
             } else if constexpr (C::NDW > C::DPF) {   // H = 2, 4: features are dwords [0,DPF) and [DPF,2DPF)
@@ -415,6 +468,32 @@ __global__ __launch_bounds__(WAVES * kWave) void ens_bwd_kernel(
         }
     }
     if (nonfinite && __any(bad) && lane == 0) nonfinite[0] = 1.0f;
+    if (code_sums) {
+        __syncthreads();
+        float* part = csum_part + (size_t)blockIdx.x * n_slots * H;
+        for (int i = threadIdx.x; i < n_slots * H; i += WAVES * kWave) part[i] = csum[i];
+    }
+}
+
+// dcode_rows[row][h] = window[h] * sum_blocks part[block][row][h]: the second stage of the in-kernel code-gradient sums
+// (the chain rule through code' = code * window, hash_ensemble.py:133-138, folded in).  One block per code row.
+template <int H>
+__global__ __launch_bounds__(256) void code_sums_reduce_kernel(const float* __restrict__ part, int n_blocks, int n_slots,
+                                                               const float* __restrict__ window, int Hreal,
+                                                               float* __restrict__ dcode_rows) {
+    __shared__ float red[256];
+    const int row = blockIdx.x;
+    constexpr int G = 256 / H;                         // block-partials walked in parallel
+    const int h = threadIdx.x % H, grp = threadIdx.x / H;
+    float acc = 0.f;
+    for (int b = grp; b < n_blocks; b += G) acc += part[((size_t)b * n_slots + row) * H + h];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    if (grp == 0 && h < Hreal) {
+        float t = 0.f;
+        for (int k = 0; k < G; ++k) t += red[k * H + h];
+        dcode_rows[(size_t)row * Hreal + h] = t * (window ? window[h] : 1.0f);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -650,29 +729,37 @@ template <int H>
 static int launch_bwd(const float* x, int64_t B, const nsx_half* tables, int Hreal, const nsx_grid_geom* g,
                       const float* code, int64_t code_stride, const int32_t* code_index, const float* window,
                       const float* dout, float* dtables, float* dcode, float* dx, hipStream_t st,
-                      int n_slots = 0, float* nonfinite = nullptr) {
+                      int n_slots = 0, float* nonfinite = nullptr, float* dcode_rows = nullptr,
+                      float* csum_part = nullptr) {
     using C = EnsCfg<H>;
     constexpr int WAVES = 4;
     const int64_t n_tiles = (B + C::SPW - 1) / C::SPW;
     int64_t blocks = (n_tiles + WAVES - 1) / WAVES;
     const int64_t cap = (int64_t)num_cus() * 8;
     if (blocks > cap) blocks = cap;
-#define NSX_BWD_LAUNCH(MODE, DC, NS, NF)                                                                            \
-    hipLaunchKernelGGL((ens_bwd_kernel<H, WAVES, MODE, DC>), dim3((unsigned)blocks), dim3(WAVES * kWave), 0, st, x, B, \
-                       reinterpret_cast<const uint8_t*>(tables), *g, code, code_stride, code_index, window, Hreal,    \
-                       dout, dtables, dcode, dx, n_tiles, NS, NF, count_for(B))
+    const bool dc = dcode || dcode_rows;
+    const size_t smem = dcode_rows ? (size_t)n_slots * H * sizeof(float) : 0;
+#define NSX_BWD_LAUNCH(MODE, DC, NS, NF)                                                                               \
+    hipLaunchKernelGGL((ens_bwd_kernel<H, WAVES, MODE, DC>), dim3((unsigned)blocks), dim3(WAVES * kWave), smem, st, x, B, \
+                       reinterpret_cast<const uint8_t*>(tables), *g, code, code_stride, code_index, window, Hreal,       \
+                       dout, dtables, dcode, dx, n_tiles, NS, NF, count_for(B), dcode_rows ? csum_part : nullptr)
     if (n_slots > 0 && dtables) {
-        if (dcode) NSX_BWD_LAUNCH(BWD_FACTORED, true, n_slots, nonfinite);
+        if (dc) NSX_BWD_LAUNCH(BWD_FACTORED, true, n_slots, nonfinite);
         else NSX_BWD_LAUNCH(BWD_FACTORED, false, n_slots, nonfinite);
     } else if (n_slots > 0 || !dtables) {              // no table gradient asked of THIS kernel: the gather half alone
-        if (dcode) NSX_BWD_LAUNCH(BWD_GATHER, true, 0, nullptr);
-        else NSX_BWD_LAUNCH(BWD_GATHER, false, 0, nullptr);
+        if (dc) NSX_BWD_LAUNCH(BWD_GATHER, true, n_slots, nullptr);
+        else NSX_BWD_LAUNCH(BWD_GATHER, false, n_slots, nullptr);
     } else {
-        if (dcode) NSX_BWD_LAUNCH(BWD_DENSE, true, 0, nullptr);
+        if (dc) NSX_BWD_LAUNCH(BWD_DENSE, true, 0, nullptr);
         else NSX_BWD_LAUNCH(BWD_DENSE, false, 0, nullptr);
     }
 #undef NSX_BWD_LAUNCH
     NSX_LAUNCH_CHECK("nsx_hash_ensemble_bwd launch");
+    if (dcode_rows) {
+        hipLaunchKernelGGL((code_sums_reduce_kernel<H>), dim3((unsigned)n_slots), dim3(256), 0, st, csum_part, (int)blocks,
+                           n_slots, window, Hreal, dcode_rows);
+        NSX_LAUNCH_CHECK("nsx_hash_ensemble_bwd_codesum reduce launch");
+    }
     return NSX_OK;
 }
 
@@ -821,6 +908,44 @@ int nsx_hash_ensemble_bwd_factored(const float* x, int64_t B, const nsx_half* ta
         case 32: return launch_bwd<32>(x, B, tables, H, g, code_table, code_stride, code_slot, window, dout, G, dcode, dx, st, n_slots, nonfinite);
     }
     set_error("nsx_hash_ensemble_bwd_factored: unsupported H=%d", H);
+    return NSX_ERR_UNSUPPORTED;
+}
+
+int64_t nsx_hash_codesum_scratch_floats(int n_slots, int H) {
+    if (n_slots < 1 || n_slots > NSX_MAX_SLOTS || H < 1 || H > 32) return 0;
+    return (int64_t)num_cus() * 8 * n_slots * nsx_padded_grids(H);
+}
+
+int nsx_hash_ensemble_bwd_codesum(const float* x, int64_t B, const nsx_half* tables, int H,
+                                  const nsx_grid_geom* g, const float* code_table, int64_t code_stride,
+                                  int n_slots, const int32_t* code_slot, const float* window,
+                                  const float* dout, float* G, float* dcode_rows, float* scratch, float* dx,
+                                  float* nonfinite, void* stream) {
+    NSX_REQUIRE(B >= 0, "nsx_hash_ensemble_bwd_codesum: negative batch");
+    NSX_REQUIRE(dcode_rows && scratch, "nsx_hash_ensemble_bwd_codesum: dcode_rows / scratch is NULL");
+    NSX_REQUIRE(H >= 1 && H <= 32, "nsx_hash_ensemble_bwd_codesum: H=%d not in [1,32]", H);
+    NSX_REQUIRE(n_slots >= 1 && n_slots <= NSX_MAX_SLOTS, "nsx_hash_ensemble_bwd_codesum: n_slots=%d not in [1,%d]",
+                n_slots, NSX_MAX_SLOTS);
+    hipStream_t st = (hipStream_t)stream;
+    if (B == 0) {                                       // no sample: the sums are zero
+        if (hipMemsetAsync(dcode_rows, 0, (size_t)n_slots * H * sizeof(float), st) != hipSuccess) {
+            set_error("nsx_hash_ensemble_bwd_codesum: memset failed");
+            return NSX_ERR_INVALID;
+        }
+        return NSX_OK;
+    }
+    NSX_REQUIRE(x && tables && code_table && code_slot && dout, "nsx_hash_ensemble_bwd_codesum: NULL argument");
+    const int Hp = nsx_padded_grids(H);
+    if (int rc = check_geom(g, Hp, "nsx_hash_ensemble_bwd_codesum")) return rc;
+    NSX_REQUIRE(!G || g->offset[g->n_levels] < (1u << 26), "nsx_hash_ensemble_bwd_codesum: %u table entries exceed the "
+                "2^26 the run-merge key can address", g->offset[g->n_levels]);
+    switch (Hp) {
+#define NSX_CS_CASE(HP) case HP: return launch_bwd<HP>(x, B, tables, H, g, code_table, code_stride, code_slot, window, dout, \
+                                                       G, nullptr, dx, st, n_slots, nonfinite, dcode_rows, scratch);
+        NSX_CS_CASE(1) NSX_CS_CASE(2) NSX_CS_CASE(4) NSX_CS_CASE(8) NSX_CS_CASE(16) NSX_CS_CASE(32)
+#undef NSX_CS_CASE
+    }
+    set_error("nsx_hash_ensemble_bwd_codesum: unsupported H=%d", H);
     return NSX_ERR_UNSUPPORTED;
 }
 

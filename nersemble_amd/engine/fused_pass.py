@@ -202,8 +202,8 @@ class _MainPass(torch.autograd.Function):
                 G = sink.buffer_for(code_h, hash_window, n_rows, geom.total_entries, n_samples=S)
             else:
                 G = torch.zeros((n_rows, geom.total_entries, 2), dtype=f32, device=dev)
-        dcode_s = (torch.zeros if inp.n_dev is not None else torch.empty)((S, H), dtype=f32, device=dev) \
-            if need_code else None
+        # the code gradient leaves the kernel summed per code row (nsx_hash_ensemble_bwd_codesum): no [S, H] tensor
+        g_code_hash = torch.empty((n_rows, H), dtype=f32, device=dev) if need_code else None
         dx = torch.empty((S, 3), dtype=f32, device=dev)
         G_fused = G
         if H == 1 and G is not None and sink is not None:
@@ -214,11 +214,17 @@ class _MainPass(torch.autograd.Function):
             check(L.nsx_hash_ensemble_bwd_scatter(ptr(pn), S, C.byref(geom), n_rows, ptr(hash_slot), ptr(dout), ptr(G),
                                                   ptr(sink.nonfinite), 8, st), "nsx_hash_ensemble_bwd_scatter")
             G_fused = None
-        check(L.nsx_hash_ensemble_bwd_factored(ptr(pn), S, ptr(tables_f16), H, C.byref(geom), ptr(code_h), code_h.stride(0),
-                                               n_rows, ptr(hash_slot), ptr(hash_window), ptr(dout), ptr(G_fused),
-                                               ptr(dcode_s), ptr(dx),
-                                               ptr(sink.nonfinite) if (sink is not None and need_tab and G_fused is not None)
-                                               else None, st), "nsx_hash_ensemble_bwd_factored")
+        nonfinite = ptr(sink.nonfinite) if (sink is not None and need_tab and G_fused is not None) else None
+        if need_code:
+            check(L.nsx_hash_ensemble_bwd_codesum(ptr(pn), S, ptr(tables_f16), H, C.byref(geom), ptr(code_h),
+                                                  code_h.stride(0), n_rows, ptr(hash_slot), ptr(hash_window), ptr(dout),
+                                                  ptr(G_fused), ptr(g_code_hash), ptr(F.codesum_scratch(n_rows, H, dev)),
+                                                  ptr(dx), nonfinite, st), "nsx_hash_ensemble_bwd_codesum")
+        else:
+            check(L.nsx_hash_ensemble_bwd_factored(ptr(pn), S, ptr(tables_f16), H, C.byref(geom), ptr(code_h),
+                                                   code_h.stride(0), n_rows, ptr(hash_slot), ptr(hash_window), ptr(dout),
+                                                   ptr(G_fused), None, ptr(dx), nonfinite, st),
+                  "nsx_hash_ensemble_bwd_factored")
         if sink is not None and need_tab and ctx.announced:
             # G is complete, and so are the gradients of the two fused MLPs (the rest of the tables' optimizer group):
             # the table optimizer may start its 12 GB pass now, beside the deformation backward below
@@ -227,12 +233,6 @@ class _MainPass(torch.autograd.Function):
             dtab = torch.empty(ctx.shapes[0], dtype=f32, device=dev)
             check(L.nsx_hash_grad_expand(ptr(G), n_rows, ptr(code_h), code_h.stride(0), ptr(hash_window), H, C.byref(geom),
                                          ptr(dtab), 0, st), "nsx_hash_grad_expand")
-        g_code_hash = None
-        if need_code:
-            if hash_window is not None:
-                dcode_s = dcode_s * hash_window[None, :]
-            g_code_hash = torch.zeros((n_rows, H), dtype=f32, device=dev)
-            g_code_hash.index_add_(0, hash_slot.to(torch.int64), dcode_s)
         # -- normalisation: gradient of the offsets
         goff = torch.empty((S, 3), dtype=f32, device=dev)
         check(L.nsx_normalise_bwd(ptr(dx), ptr(sel), S, inp.field_aabb6, ptr(goff), st), "nsx_normalise_bwd")

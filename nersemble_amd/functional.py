@@ -65,6 +65,20 @@ def _hash_ensemble_fwd_raw(x, tables_f16, H, geom, code, code_index, window):
     return out
 
 
+_CODESUM_SCRATCH = {}
+
+
+def codesum_scratch(n_rows: int, H: int, device) -> torch.Tensor:
+    """Block partials of the in-kernel code-gradient sums (nsx_hash_ensemble_bwd_codesum); one cached buffer per
+    device, grown on demand (stream-ordered reuse: every user launches on torch's current stream)."""
+    n = int(lib().nsx_hash_codesum_scratch_floats(int(n_rows), int(H)))
+    key = str(device)
+    buf = _CODESUM_SCRATCH.get(key)
+    if buf is None or buf.numel() < n:
+        buf = _CODESUM_SCRATCH[key] = torch.empty((n,), dtype=torch.float32, device=device)
+    return buf
+
+
 class FactoredGradSink:
     """Collects the factored table gradient G[e][slot][f] (+ the code rows it factors through) instead of a dense
     1.6 GB table gradient; consumed by ``engine.hash_adam.HashTableAdam`` which forms the gradient on the fly.
@@ -218,10 +232,13 @@ class _HashEnsembleFn(torch.autograd.Function):
         B = x.shape[0]
         need_x, need_tab, _, need_code = ctx.needs_input_grad[0], ctx.needs_input_grad[1], None, ctx.needs_input_grad[3]
         dout = dout.to(torch.float32).contiguous()
-        dcode_s = torch.empty((B, H), dtype=torch.float32, device=x.device) if need_code else None
-        dx = torch.empty((B, 3), dtype=torch.float32, device=x.device) if need_x else None
         n_rows = code.shape[0]
-        if code_index is not None and n_rows <= _lib.NSX_MAX_SLOTS:
+        factored = code_index is not None and n_rows <= _lib.NSX_MAX_SLOTS
+        # code rows shared by many samples: their gradient is summed per row inside the kernel (no [B, H] tensor)
+        dcode_rows = torch.empty((n_rows, H), dtype=torch.float32, device=x.device) if (need_code and factored) else None
+        dcode_s = torch.empty((B, H), dtype=torch.float32, device=x.device) if (need_code and not factored) else None
+        dx = torch.empty((B, 3), dtype=torch.float32, device=x.device) if need_x else None
+        if factored:
             # factored table gradient: scatter 2 scalars per corner into G[e][slot][f], then expand with the codes
             dtab = None
             G = None
@@ -258,12 +275,18 @@ class _HashEnsembleFn(torch.autograd.Function):
                                                           ptr(G), ptr(ctx.sink.nonfinite), 8, stream()),
                       "nsx_hash_ensemble_bwd_scatter")
                 G = None
-            check(lib().nsx_hash_ensemble_bwd_factored(ptr(x), B, ptr(tables_f16), H, C.byref(geom), ptr(code),
-                                                       code.stride(0), n_rows, ptr(code_index), ptr(window),
-                                                       ptr(dout), ptr(G), ptr(dcode_s), ptr(dx),
-                                                       ptr(ctx.sink.nonfinite) if (use_sink and G is not None) else None,
-                                                       stream()),
-                  "nsx_hash_ensemble_bwd_factored")
+            nonfinite = ptr(ctx.sink.nonfinite) if (use_sink and G is not None) else None
+            if dcode_rows is not None:
+                check(lib().nsx_hash_ensemble_bwd_codesum(ptr(x), B, ptr(tables_f16), H, C.byref(geom), ptr(code),
+                                                          code.stride(0), n_rows, ptr(code_index), ptr(window),
+                                                          ptr(dout), ptr(G), ptr(dcode_rows),
+                                                          ptr(codesum_scratch(n_rows, H, x.device)), ptr(dx), nonfinite,
+                                                          stream()), "nsx_hash_ensemble_bwd_codesum")
+            else:
+                check(lib().nsx_hash_ensemble_bwd_factored(ptr(x), B, ptr(tables_f16), H, C.byref(geom), ptr(code),
+                                                           code.stride(0), n_rows, ptr(code_index), ptr(window),
+                                                           ptr(dout), ptr(G), None, ptr(dx), nonfinite, stream()),
+                      "nsx_hash_ensemble_bwd_factored")
             if use_sink and ctx.announced:
                 ctx.sink.arrived()
             if need_tab and not use_sink:
@@ -278,13 +301,16 @@ class _HashEnsembleFn(torch.autograd.Function):
                                               ptr(dcode_s), ptr(dx), stream()), "nsx_hash_ensemble_bwd")
         dcode = None
         if need_code:
-            if window is not None:
-                dcode_s = dcode_s * window[None, :]
-            if code_index is not None:
-                dcode = torch.zeros((ctx.code_rows, H), dtype=torch.float32, device=x.device)
-                dcode.index_add_(0, code_index.to(torch.int64), dcode_s)
+            if dcode_rows is not None:
+                dcode = dcode_rows                       # window chain rule and the per-row sums done by the kernels
             else:
-                dcode = dcode_s
+                if window is not None:
+                    dcode_s = dcode_s * window[None, :]
+                if code_index is not None:               # more rows than NSX_MAX_SLOTS: per-sample gradient + index_add_
+                    dcode = torch.zeros((ctx.code_rows, H), dtype=torch.float32, device=x.device)
+                    dcode.index_add_(0, code_index.to(torch.int64), dcode_s)
+                else:
+                    dcode = dcode_s
         return dx, dtab, None, dcode, None, None, None, None, None, None
 
 

@@ -348,3 +348,69 @@ def test_split_backward_equals_fused(H, coherent, cuda):
     # empty batch: no launch, no error
     check(lib().nsx_hash_ensemble_bwd_scatter(ptr(xt), 0, C.byref(gn), T, ptr(slot), ptr(dout), ptr(G_f), None, 2,
                                               stream()), "nsx_hash_ensemble_bwd_scatter")
+
+
+@pytest.mark.parametrize("H", [1, 2, 4, 8, 16, 32])
+@pytest.mark.parametrize("order", ["sorted", "random"])
+def test_code_gradient_summed_in_the_kernel(H, order, cuda):
+    """nsx_hash_ensemble_bwd_codesum: the code gradient reduced per code row inside the kernel (LDS sums per block +
+    one second-stage block per row, window chain rule folded in) against the per-sample gradient of
+    nsx_hash_ensemble_bwd_factored summed with float64 on the host.  dx and G are the fused kernel's.  ``sorted``:
+    samples of a row are adjacent (a ray's samples: the DPP run-merge path), ``random``: every lane its own row."""
+    import ctypes as C
+    from nersemble_amd import functional as F
+    from nersemble_amd._lib import check, device_count, lib, ptr, stream
+    B, T = 4099, 24
+    go, gn, tabs, f16, master, x, _ = _setup(H, SMALL_GEOM_KW, 500 + H, B, cuda)
+    rng = np.random.default_rng(3 * H)
+    xt = torch.from_numpy(x).to(cuda)
+    table = torch.from_numpy((rng.standard_normal((T, H)) * 0.6).astype(np.float32)).to(cuda)
+    sl = rng.integers(0, T, B)
+    if order == "sorted":
+        sl = np.sort(sl)
+    slot = torch.from_numpy(sl.astype(np.int32)).to(cuda)
+    win_np = ohg.posenc_window(0.6 * H + 0.3, 0, H - 1, H).astype(np.float32)
+    win = torch.from_numpy(win_np).to(cuda)
+    dout = torch.from_numpy(rng.standard_normal((B, 32)).astype(np.float32)).to(cuda)
+    total = gn.total_entries
+
+    G_f = torch.zeros((T, total, 2), device=cuda)
+    dc_f, dx_f = torch.empty((B, H), device=cuda), torch.empty((B, 3), device=cuda)
+    check(lib().nsx_hash_ensemble_bwd_factored(ptr(xt), B, ptr(f16), H, C.byref(gn), ptr(table), table.stride(0), T,
+                                               ptr(slot), ptr(win), ptr(dout), ptr(G_f), ptr(dc_f), ptr(dx_f), None,
+                                               stream()), "nsx_hash_ensemble_bwd_factored")
+    want = np.zeros((T, H), dtype=np.float64)
+    np.add.at(want, sl, dc_f.cpu().numpy().astype(np.float64) * win_np[None].astype(np.float64))
+
+    def run(n, G, rows, dx):
+        check(lib().nsx_hash_ensemble_bwd_codesum(ptr(xt), n, ptr(f16), H, C.byref(gn), ptr(table), table.stride(0), T,
+                                                  ptr(slot), ptr(win), ptr(dout), ptr(G), ptr(rows),
+                                                  ptr(F.codesum_scratch(T, H, cuda)), ptr(dx), None, stream()),
+              "nsx_hash_ensemble_bwd_codesum")
+
+    for with_G in (True, False):
+        G = torch.zeros((T, total, 2), device=cuda) if with_G else None
+        rows = torch.full((T, H), float("nan"), device=cuda)
+        dx = torch.empty((B, 3), device=cuda)
+        run(B, G, rows, dx)
+        got = rows.cpu().numpy().astype(np.float64)
+        assert np.abs(got - want).max() <= 2e-5 * np.abs(want).max() + 1e-7, float(np.abs(got - want).max())
+        assert torch.equal(dx, dx_f)
+        if with_G:
+            assert (G - G_f).abs().max().item() <= 2e-5 * G_f.abs().max().item()
+    # rows no sample uses come out as exact zeros
+    unused = np.setdiff1d(np.arange(T), sl)
+    assert (got[unused] == 0).all()
+    # device-side sample count (nsx_device_count_begin): only the first n rows contribute; n = 0 gives zeros
+    for n in (B // 3, 0):
+        n_dev = torch.tensor([n], dtype=torch.int64, device=cuda)
+        rows = torch.full((T, H), float("nan"), device=cuda)
+        with device_count(n_dev, B):
+            run(B, None, rows, torch.empty((B, 3), device=cuda))
+        w2 = np.zeros((T, H), dtype=np.float64)
+        np.add.at(w2, sl[:n], dc_f.cpu().numpy()[:n].astype(np.float64) * win_np[None].astype(np.float64))
+        assert np.abs(rows.cpu().numpy() - w2).max() <= 2e-5 * np.abs(want).max() + 1e-7
+    # empty batch: zeros, no launch
+    rows = torch.full((T, H), float("nan"), device=cuda)
+    run(0, None, rows, None)
+    assert (rows == 0).all()

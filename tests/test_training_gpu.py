@@ -369,18 +369,24 @@ def test_split_scatter_backward_trains_like_the_fused_one(cuda):
     assert np.allclose(runs[True][0], runs[False][0], rtol=3e-2), runs
 
 
-def test_fused_main_pass_equals_modular_path(cuda):
+@pytest.mark.parametrize("window_open", [False, True])
+def test_fused_main_pass_equals_modular_path(window_open, cuda):
     """engine/fused_pass.py (the kept samples' main pass as ONE autograd node) against the modular path (nine autograd
     Functions): the same kernels in the same order, so the loss vector is equal bit for bit and the gradients agree up
-    to the order of the fp32 atomics; with and without reuse of the sigma_fn pass's forward values."""
+    to the order of the fp32 atomics; with and without reuse of the sigma_fn pass's forward values.  ``window_open``:
+    every hash grid on (the schedule after step 80 000, train_nersemble.py:77-78) -- the time codes are trained and
+    their gradient comes out of the HashEnsemble backward summed per code row."""
     from nersemble_amd.workloads import build_workload
     for reuse in (True, False):
         res = {}
         for fused in (False, True):
             torch.manual_seed(6)
-            trainer, data, _ = build_workload("p030_h16", device="cuda:0", small=True, n_rays=512)
+            trainer, data, _ = build_workload("p030_h16", device="cuda:0", small=True, n_rays=512,
+                                              window_hash=(0, 1) if window_open else None)
             model = trainer.model
             model.fuse_main_pass, model.reuse_sigma_pass = fused, reuse
+            if window_open:                                       # open from step 0 on (the ramp is over before it)
+                model.sched_window_hash_encodings.begin_step, model.sched_window_hash_encodings.end_step = -2, -1
             calls = []
             orig = model.fused_train_forward
 
@@ -407,6 +413,9 @@ def test_fused_main_pass_equals_modular_path(cuda):
         (l_m, t_m, g_m, tab_m), (l_f, t_f, g_f, tab_f) = res[False], res[True]
         assert l_m[0] == l_f[0] and t_m == t_f, (reuse, l_m[0], l_f[0], t_m, t_f)     # forward: bit for bit
         assert set(g_m) == set(g_f)
+        assert ("time_embedding.weight" in g_m) == window_open            # the codes get a gradient once the window is open
+        if window_open:
+            assert g_m["time_embedding.weight"].abs().max().item() > 0
         for name in g_m:
             sc = g_m[name].abs().max().item()
             assert (g_m[name] - g_f[name]).abs().max().item() <= 1e-4 * sc + 1e-12, (reuse, name)
