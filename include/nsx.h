@@ -433,7 +433,9 @@ typedef struct nsx_tensor_ref {
     void*   exp_avg_sq;
     int64_t n;
     int32_t group;
-    int32_t reserved;
+    int32_t step;         /* nsx_multi_adam: 1-based step count of THIS tensor -- torch.optim.Adam keeps `step` per
+                             parameter and starts it when the parameter first receives a gradient (time_embedding: at
+                             step 40 000, when the window opens); 0: use the group's step */
 } nsx_tensor_ref;
 typedef struct nsx_adam_group {
     float   lr, beta1, beta2, eps;

@@ -40,7 +40,7 @@ NSX_MAX_GROUPS = 8
 class TensorRef(C.Structure):
     """Mirror of ``nsx_tensor_ref``."""
     _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
-                ("n", C.c_int64), ("group", C.c_int32), ("reserved", C.c_int32)]
+                ("n", C.c_int64), ("group", C.c_int32), ("step", C.c_int32)]
 
 
 class AdamGroup(C.Structure):

@@ -312,7 +312,11 @@ __global__ __launch_bounds__(256) void multi_adam_kernel(TensorTable T, GroupHyp
     const float* g = reinterpret_cast<const float*>(r.grad);
     if (!g) return;                                          // no gradient this step: torch skips the parameter
     if (found_inf && found_inf[r.group] != 0.f) return;      // GradScaler: the whole group's step is skipped
-    const AdamHyper hy = H.h[r.group];
+    AdamHyper hy = H.h[r.group];
+    if (r.step > 0) {                                        // the tensor's own step count (torch: state[p]["step"])
+        hy.bc1 = (float)(1.0 - pow((double)hy.beta1, (double)r.step));
+        hy.bc2_sqrt = (float)sqrt(1.0 - pow((double)hy.beta2, (double)r.step));
+    }
     float* p = reinterpret_cast<float*>(r.param);
     float* m = reinterpret_cast<float*>(r.exp_avg);
     float* v = reinterpret_cast<float*>(r.exp_avg_sq);

@@ -213,8 +213,12 @@ class HashTableAdam(torch.optim.Optimizer):
         st = self._state()
         st["step"] = int(state["step"])
         self.param_groups[0]["lr"] = float(state.get("lr", self.param_groups[0]["lr"]))
-        st["exp_avg"].copy_(self.he.from_tcnn_layout(state["exp_avg"]))
-        st["exp_avg_sq"].copy_(self.he.from_tcnn_layout(state["exp_avg_sq"]))
+        if state.get("exp_avg") is None:                 # a checkpoint written before the first optimizer step
+            st["exp_avg"].zero_()
+            st["exp_avg_sq"].zero_()
+        else:
+            st["exp_avg"].copy_(self.he.from_tcnn_layout(state["exp_avg"]))
+            st["exp_avg_sq"].copy_(self.he.from_tcnn_layout(state["exp_avg_sq"]))
 
     def zero_grad(self, set_to_none: bool = True):
         super().zero_grad(set_to_none=set_to_none)

@@ -231,8 +231,10 @@ class ShardedTableAdam(torch.optim.Optimizer):
         self._step = int(state["step"])
         self.param_groups[0]["lr"] = float(state.get("lr", self.param_groups[0]["lr"]))
         for key in ("exp_avg", "exp_avg_sq"):
-            full = self.he.from_tcnn_layout(state[key]).reshape(-1)
             b[key].zero_()
+            if state.get(key) is None:                   # a checkpoint written before the first optimizer step
+                continue
+            full = self.he.from_tcnn_layout(state[key]).reshape(-1)
             b[key][:self.n_local].copy_(full[self.lo:self.lo + self.n_local])
         # the working tables / master shard follow the (already loaded) model parameters
         b["f16"][:self.n].copy_(self.he.tables.detach().reshape(-1))

@@ -24,10 +24,20 @@ from .._lib import AdamGroup, NSX_MAX_GROUPS, NSX_MAX_TENSORS, TensorRef, check,
 class SmallGroupAdam(torch.optim.Optimizer):
     def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8):
         super().__init__(list(params), dict(lr=lr, betas=betas, eps=eps))
-        self.step_count = 0                   # host-side (the kernels take bias corrections by value)
+        # torch.optim.Adam keeps ``step`` PER PARAMETER and creates it when the parameter first has a gradient: a tensor
+        # that starts late (time_embedding.weight gets its first gradient when the coarse-to-fine window opens at step
+        # 40 000, train_nersemble.py:77-78) takes its first update with the bias corrections of step 1, not of step
+        # 40 001.  Host-side counts (the kernel takes them by value in nsx_tensor_ref.step).
+        self.steps: Dict[torch.nn.Parameter, int] = {}
+        self._last_stepped: List[torch.nn.Parameter] = []
         for p in self._params():
             if p.dtype != torch.float32:
                 raise TypeError("SmallGroupAdam: fp32 parameters only")
+
+    @property
+    def step_count(self) -> int:
+        """Steps taken by the group = the largest per-parameter count."""
+        return max(self.steps.values(), default=0)
 
     def _params(self) -> List[torch.nn.Parameter]:
         return [p for g in self.param_groups for p in g["params"]]
@@ -39,28 +49,43 @@ class SmallGroupAdam(torch.optim.Optimizer):
             st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
         return st["exp_avg"], st["exp_avg_sq"]
 
+    def advance(self, p) -> int:
+        """Count one step of ``p`` (called for the tensors that have a gradient); returns its 1-based step."""
+        n = self.steps.get(p, 0) + 1
+        self.steps[p] = n
+        self._last_stepped.append(p)
+        return n
+
     def rollback_step(self) -> None:
-        """The last step was skipped on the device (inf / NaN gradient): it does not count."""
-        self.step_count = max(0, self.step_count - 1)
+        """The last step was skipped on the device (inf / NaN gradient): it does not count, for any of its tensors."""
+        for p in self._last_stepped:
+            self.steps[p] = max(0, self.steps.get(p, 0) - 1)
+        self._last_stepped = []
 
     def step(self, closure=None):             # pragma: no cover - the trainer steps all groups together
         raise RuntimeError("SmallGroupAdam steps through step_groups([...]) (all groups in one launch)")
 
-    # torch's Adam state-dict shape: per-parameter {"step", "exp_avg", "exp_avg_sq"}
+    # torch's Adam state-dict shape: per-parameter {"step", "exp_avg", "exp_avg_sq"}; a parameter that never had a
+    # gradient has no state (as in torch)
     def state_dict(self):
         for p in self._params():
-            self._moments(p)
-            self.state[p]["step"] = torch.tensor(float(self.step_count))
+            n = self.steps.get(p, 0)
+            if n > 0:
+                self._moments(p)
+                self.state[p]["step"] = torch.tensor(float(n))
+            elif p in self.state and "step" not in self.state[p]:
+                del self.state[p]              # moments allocated for the tensor table, never used
         return super().state_dict()
 
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)
-        steps = [int(st["step"]) for st in self.state.values() if "step" in st]
-        self.step_count = max(steps) if steps else 0
+        self.steps = {p: int(st["step"]) for p, st in self.state.items() if "step" in st}
+        self._last_stepped = []
 
 
 def _table(optimizers: Sequence[SmallGroupAdam], group_of: Sequence[int]):
     refs = (TensorRef * NSX_MAX_TENSORS)()
+    owners = []
     n = 0
     for opt, grp in zip(optimizers, group_of):
         for p in opt._params():
@@ -76,9 +101,10 @@ def _table(optimizers: Sequence[SmallGroupAdam], group_of: Sequence[int]):
             # raw pointers without a dispatch per tensor (Tensor.data / detach() are torch ops)
             r.param, r.exp_avg, r.exp_avg_sq = p.data_ptr(), m.data_ptr(), v.data_ptr()
             r.grad = g.data_ptr() if g is not None else None
-            r.n, r.group = p.numel(), grp
+            r.n, r.group, r.step = p.numel(), grp, 0
+            owners.append((opt, p))
             n += 1
-    return refs, n
+    return refs, n, owners
 
 
 def unscale_and_check_groups(optimizers: Sequence[SmallGroupAdam], group_of: Sequence[int], n_groups: int,
@@ -86,16 +112,16 @@ def unscale_and_check_groups(optimizers: Sequence[SmallGroupAdam], group_of: Seq
     """found_inf [n_groups] (device, fp32): set to 1 for every group that holds a non-finite gradient; gradients are
     unscaled in place.  Returns the tensor table for ``adam_groups`` (the pointers stay valid for this step)."""
     assert n_groups <= NSX_MAX_GROUPS and found_inf.numel() >= n_groups
-    refs, n = _table(optimizers, group_of)
+    refs, n, owners = _table(optimizers, group_of)
     if n:
         check(lib().nsx_multi_unscale_check(refs, n, n_groups, ptr(inv_scale), ptr(found_inf), stream()),
               "nsx_multi_unscale_check")
-    return refs, n
+    return refs, n, owners
 
 
 def adam_groups(optimizers: Sequence[SmallGroupAdam], group_of: Sequence[int], n_groups: int, table,
                 found_inf: Optional[torch.Tensor]) -> None:
-    refs, n = table
+    refs, n, owners = table
     if not n:
         return
     groups = (AdamGroup * NSX_MAX_GROUPS)()
@@ -104,14 +130,13 @@ def adam_groups(optimizers: Sequence[SmallGroupAdam], group_of: Sequence[int], n
         if grp in seen:
             raise RuntimeError("one SmallGroupAdam per group")
         seen.add(grp)
-        if not any(p.grad is not None for p in opt._params()):
-            opt_step = max(opt.step_count, 1)                     # nothing to do for this group: the kernel skips it
-        else:
-            opt.step_count += 1
-            opt_step = opt.step_count
+        opt._last_stepped = []
         pg = opt.param_groups[0]
         groups[grp].lr, (groups[grp].beta1, groups[grp].beta2), groups[grp].eps = pg["lr"], pg["betas"], pg["eps"]
-        groups[grp].step = opt_step
+        groups[grp].step = 1                                      # (every tensor carries its own count)
+    for i, (opt, p) in enumerate(owners):
+        if refs[i].grad:
+            refs[i].step = opt.advance(p)                         # counted on the host before the device decides to skip
     for k in range(n_groups):
         if k not in seen:
             groups[k].step = 1

@@ -281,33 +281,50 @@ class NeRSembleTrainer:
                 opt.gather_master()
 
     # ---- checkpointing of the training state (nerfstudio's checkpoints carry "optimizers" and "scalers") -------------
+    # Wire format = the reference's: ``optimizers[group] = torch.optim.Adam.state_dict()`` for the three groups of
+    # ``get_param_groups`` (nersemble_instant_ngp.py:502-514; nerfstudio's Optimizers.load_optimizers does
+    # ``self.optimizers[k].load_state_dict(v)`` for every key).  The ``fields`` group holds ``field.parameters()`` in
+    # registration order -- ``hash_ensemble.hash_encodings.{c}.params`` (flat, tcnn layout), ``mlp_base.params``,
+    # ``mlp_head.params`` -- so the natively stepped tables appear there as C per-encoding entries in front of the two
+    # MLPs, each with torch's per-parameter ``step``.
     def state_dict(self) -> Dict:
         """Everything a resumed run needs besides the model: Adam moments + step counts of every group (the table
         moments in the reference's tcnn parameter layout, gathered from all ranks in data-parallel runs -- a
         collective there), StepLR counters, the loss scale and its growth tracker.  Call ``consolidate()`` first in
         data-parallel runs so that ``model.state_dict()`` is complete as well."""
         self.flush_scheduler_step()
-        opts = {}
-        for key, opt in self.optimizers.items():
-            if isinstance(opt, (HashTableAdam, ShardedTableAdam)):
-                opts[key] = {"native_table_adam": opt.table_state()}
-            else:
-                opts[key] = opt.state_dict()
-        return {"optimizers": opts, "schedulers": {k: s.state_dict() for k, s in self.schedulers.items()},
+        opts = {key: opt.state_dict() for key, opt in self.optimizers.items()
+                if not isinstance(opt, (HashTableAdam, ShardedTableAdam))}
+        tkey = self.group_of_tables()
+        if tkey is not None:
+            grp = self.group_of[tkey]
+            opts[grp] = _merge_table_state(self.optimizers[tkey].table_state(), opts[grp])
+        return {"optimizers": opts,
+                "schedulers": {k: s.state_dict() for k, s in self.schedulers.items() if not k.endswith("/tables")},
                 "scalers": self.grad_scaler.state_dict()}
 
     def load_state_dict(self, state: Dict) -> None:
         self.flush_scheduler_step()
+        saved_all = state.get("optimizers", {})
+        tkey = self.group_of_tables()
         for key, opt in self.optimizers.items():
-            saved = state["optimizers"][key]
             if isinstance(opt, (HashTableAdam, ShardedTableAdam)):
-                opt.load_table_state(saved["native_table_adam"])
-            else:
-                opt.load_state_dict(saved)
+                continue
+            if key not in saved_all:
+                raise KeyError(f"checkpoint has no optimizer state for the parameter group '{key}' "
+                               f"(groups in the file: {sorted(saved_all)})")
+            saved = saved_all[key]
+            if tkey is not None and self.group_of[tkey] == key:
+                n_small = sum(len(g["params"]) for g in opt.param_groups)
+                table_state, saved = _split_table_state(saved, self.model.field.hash_ensemble.n_tcnn_encodings, n_small, key)
+                table_state.setdefault("lr", saved["param_groups"][0]["lr"])
+                self.optimizers[tkey].load_table_state(table_state)
+            opt.load_state_dict(saved)
         for key, sch in self.schedulers.items():
-            if key in state.get("schedulers", {}):
-                sch.load_state_dict(state["schedulers"][key])
-        if "scalers" in state:
+            grp = self.group_of[key]
+            if grp in state.get("schedulers", {}):
+                sch.load_state_dict(state["schedulers"][grp])
+        if state.get("scalers"):
             self.grad_scaler.load_state_dict(state["scalers"])
 
     def flush_scheduler_step(self) -> None:
@@ -331,3 +348,54 @@ class NeRSembleTrainer:
         if not any(f != 0.0 for f in flags):
             for sch in self.schedulers.values():
                 sch.step()
+
+
+def _merge_table_state(table: Dict, small: Dict) -> Dict:
+    """One ``torch.optim.Adam.state_dict()`` for the ``fields`` group as the reference holds it: the C tcnn encodings'
+    flat moments (indices 0 .. C-1, one ``step`` each) followed by the small parameters of the group."""
+    C = len(table["exp_avg"])
+    state = {}
+    if int(table["step"]) > 0:
+        for c in range(C):
+            state[c] = {"step": torch.tensor(float(table["step"])), "exp_avg": table["exp_avg"][c],
+                        "exp_avg_sq": table["exp_avg_sq"][c]}
+    for i, st in small["state"].items():
+        state[C + int(i)] = st
+    groups = []
+    for g in small["param_groups"]:
+        g = dict(g)
+        g["params"] = list(range(C)) + [C + int(i) for i in g["params"]]
+        g["lr"] = float(table.get("lr", g["lr"]))
+        groups.append(g)
+    return {"state": state, "param_groups": groups}
+
+
+def _split_table_state(saved: Dict, C: int, n_small: int, key: str):
+    """The inverse: (table state for ``load_table_state``, Adam state dict of the group's small parameters).  Entries
+    without elements (tcnn registers an empty ``params`` for its parameter-free encodings -- Identity / Frequency,
+    nersemble_nerfacto_field.py:99-140 -- which a reference checkpoint then lists) are dropped."""
+    ids = [int(i) for g in saved["param_groups"] for i in g["params"]]
+    state = {int(i): st for i, st in saved["state"].items()}
+    if len(ids) > C + n_small:
+        empty = [i for i in ids if i in state and torch.is_tensor(state[i].get("exp_avg")) and state[i]["exp_avg"].numel() == 0]
+        ids = [i for i in ids if i not in empty]
+    if len(ids) != C + n_small:
+        raise KeyError(f"optimizer state of group '{key}': {len(ids)} parameters in the checkpoint, this model has {C} hash "
+                       f"encodings + {n_small} other tensors in that group")
+    tab_ids, small_ids = ids[:C], ids[C:]
+    have = [i for i in tab_ids if i in state]
+    if have and len(have) != C:
+        raise KeyError(f"optimizer state of group '{key}': moments for {len(have)} of {C} hash encodings")
+    if have:
+        table = {"step": int(state[tab_ids[0]]["step"]),
+                 "exp_avg": [state[i]["exp_avg"] for i in tab_ids], "exp_avg_sq": [state[i]["exp_avg_sq"] for i in tab_ids]}
+    else:
+        table = {"step": 0, "exp_avg": None, "exp_avg_sq": None}
+    groups = []
+    pos = {old: new for new, old in enumerate(small_ids)}
+    for g in saved["param_groups"]:
+        g = dict(g)
+        g["params"] = [pos[int(i)] for i in g["params"] if int(i) in pos]
+        groups.append(g)
+    small_state = {pos[i]: state[i] for i in small_ids if i in state}
+    return table, {"state": small_state, "param_groups": groups}

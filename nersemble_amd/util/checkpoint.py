@@ -46,9 +46,12 @@ def load_nerfstudio_checkpoint(checkpoint: Union[str, Dict], model: torch.nn.Mod
 
 
 def nerfstudio_checkpoint_from_model(model: torch.nn.Module, step: int, trainer=None) -> Dict:
-    """The inverse: a dict in nerfstudio's checkpoint format that the reference's loader accepts.  With ``trainer``
-    (``engine.trainer.NeRSembleTrainer``) the ``optimizers`` / ``scalers`` entries carry the training state (Adam moments,
-    step counts, loss scale) so that a run can resume; data-parallel runs gather the sharded table state first."""
+    """The inverse: a dict in nerfstudio's checkpoint format.  With ``trainer`` (``engine.trainer.NeRSembleTrainer``) the
+    ``optimizers`` / ``scalers`` entries carry the training state in the reference's shape -- ``optimizers[group]`` is a
+    ``torch.optim.Adam.state_dict()`` per parameter group of ``get_param_groups`` (``fields``: the C tcnn hash encodings'
+    moments in tcnn layout, then ``mlp_base`` / ``mlp_head``; ``embeddings``; ``deformation_field``), with torch's
+    per-parameter ``step`` -- so that a run can resume here or there; data-parallel runs gather the sharded table state
+    first.  ``schedulers`` (StepLR counters per group) is an extra entry nerfstudio 0.3.1's loader does not read."""
     training = {"optimizers": {}, "scalers": {}}
     if trainer is not None:
         trainer.consolidate()

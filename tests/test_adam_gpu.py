@@ -176,9 +176,11 @@ def test_small_group_adam_equals_torch_adam_with_gradscaler_semantics(cuda):
     for it in range(5):
         poisoned = 1 if it == 2 else -1
         skip_tensor = (2, 4)                                     # group 2's last tensor gets no gradient at all
+        late_tensor = (1, 1)                                     # its first gradient arrives at iteration 2 (in a step
+        #                                                          that is then skipped): torch starts its `step` there
         for gi, (rp, np_) in enumerate(zip(ref_params, nat_params)):
             for ti, (a, b) in enumerate(zip(rp, np_)):
-                if (gi, ti) == skip_tensor:
+                if (gi, ti) == skip_tensor or ((gi, ti) == late_tensor and it < 2):
                     a.grad = b.grad = None
                     continue
                 grad = torch.randn(a.shape, device=cuda, generator=g)
@@ -198,9 +200,15 @@ def test_small_group_adam_equals_torch_adam_with_gradscaler_semantics(cuda):
         for gi, (rp, np_) in enumerate(zip(ref_params, nat_params)):
             for ti, (a, b) in enumerate(zip(rp, np_)):
                 assert torch.allclose(a, b, rtol=1e-5, atol=1e-7), (it, gi, ti, (a - b).abs().max().item())
-                if (gi, ti) != skip_tensor and gi != poisoned:
+                if (gi, ti) != skip_tensor and gi != poisoned and a.grad is not None:
                     assert torch.allclose(b.grad, a.grad, rtol=1e-6)         # unscaled in place
     assert [o.step_count for o in nat_opts] == [5, 4, 5]
+    # per-parameter step counts, as torch keeps them: the late tensor has taken 2 steps (iterations 3 and 4), with the
+    # bias corrections of steps 1 and 2 -- the parameter comparison above holds it to torch's lazily created state
+    late = nat_params[1][1]
+    assert nat_opts[1].steps[late] == 2 and int(ref_opts[1].state[ref_params[1][1]]["step"]) == 2
+    assert nat_opts[1].steps[nat_params[1][0]] == 4
+    assert nat_params[2][4] not in nat_opts[2].steps
     for ro, no in zip(ref_opts, nat_opts):
         for (pa, sa), (pb, sb) in zip(ro.state.items(), no.state.items()):
             assert torch.allclose(sa["exp_avg"], sb["exp_avg"], rtol=1e-5, atol=1e-6)
@@ -211,6 +219,13 @@ def test_small_group_adam_equals_torch_adam_with_gradscaler_semantics(cuda):
     fresh = SmallGroupAdam(make()[0], lr=5e-3, eps=eps)
     fresh.load_state_dict(sd)
     assert fresh.step_count == 5
+    # per-parameter steps survive the round trip; a parameter that never had a gradient has no state (as in torch)
+    sd1, sd2 = nat_opts[1].state_dict(), nat_opts[2].state_dict()
+    assert [int(sd1["state"][i]["step"]) for i in (0, 1)] == [4, 2]
+    assert 4 not in sd2["state"] and set(sd2["state"]) == {0, 1, 2, 3}
+    again = SmallGroupAdam(make()[1], lr=5e-3, eps=eps)
+    again.load_state_dict(sd1)
+    assert [again.steps[p] for p in again._params()] == [4, 2]
 
 
 def test_optimizer_pass_consumes_the_factored_gradient(cuda):

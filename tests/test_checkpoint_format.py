@@ -109,3 +109,50 @@ def test_run_folder_config_yml_and_checkpoint_lookup(tmp_path, golden_dir):
     import pytest
     with pytest.raises(FileNotFoundError):
         find_checkpoint(run / "checkpoints", 123)
+
+
+def test_fields_optimizer_state_has_the_reference_shape():
+    """``optimizers['fields']`` of a checkpoint is ONE torch.optim.Adam state dict over ``field.parameters()`` in the
+    reference's registration order (nersemble_nerfacto_field.py:99-172: the C tcnn hash encodings, mlp_base, mlp_head;
+    nerfstudio's ``Optimizers.load_optimizers`` hands it to ``Adam.load_state_dict``).  The natively stepped tables are
+    merged in / split off losslessly; entries of parameter-free tcnn encodings (empty ``params``) that a reference
+    checkpoint may list are ignored; a mismatch raises a clear error."""
+    import pytest
+    import torch
+    from nersemble_amd.engine.trainer import _merge_table_state, _split_table_state
+    C, n_small = 3, 2
+    g = torch.Generator().manual_seed(0)
+    table = {"step": 7, "lr": 4e-3, "exp_avg": [torch.randn(40, generator=g) for _ in range(C)],
+             "exp_avg_sq": [torch.rand(40, generator=g) for _ in range(C)]}
+    small_params = [torch.nn.Parameter(torch.randn(5, generator=g)), torch.nn.Parameter(torch.randn(6, generator=g))]
+    opt = torch.optim.Adam(small_params, lr=5e-3, eps=1e-15)
+    for p in small_params:
+        p.grad = torch.randn(p.shape, generator=g)
+    opt.step()
+    merged = _merge_table_state(table, opt.state_dict())
+    assert merged["param_groups"][0]["params"] == list(range(C + n_small)) and merged["param_groups"][0]["lr"] == 4e-3
+    # the reference side accepts it
+    ref = torch.optim.Adam([torch.nn.Parameter(torch.zeros(40)) for _ in range(C)] +
+                           [torch.nn.Parameter(torch.zeros(5)), torch.nn.Parameter(torch.zeros(6))], lr=5e-3, eps=1e-15)
+    ref.load_state_dict(merged)
+    assert [int(st["step"]) for st in ref.state.values()] == [7, 7, 7, 1, 1]
+    # and what the reference writes comes back apart
+    tab, small = _split_table_state(ref.state_dict(), C, n_small, "fields")
+    assert tab["step"] == 7 and all(torch.equal(a, b) for a, b in zip(tab["exp_avg"], table["exp_avg"]))
+    assert small["param_groups"][0]["params"] == [0, 1] and torch.equal(small["state"][1]["exp_avg"],
+                                                                         opt.state_dict()["state"][1]["exp_avg"])
+    # a reference file with the empty `params` of tcnn's Identity / Frequency encodings in the list
+    sd = ref.state_dict()
+    e = {"step": torch.tensor(7.0), "exp_avg": torch.zeros(0), "exp_avg_sq": torch.zeros(0)}
+    shifted = {0: e}
+    for i, st in sd["state"].items():
+        shifted[i + 1 + (i >= C)] = st
+    shifted[C + 1] = dict(e)
+    sd2 = {"state": shifted, "param_groups": [dict(sd["param_groups"][0], params=list(range(C + n_small + 2)))]}
+    tab2, small2 = _split_table_state(sd2, C, n_small, "fields")
+    assert all(torch.equal(a, b) for a, b in zip(tab2["exp_avg_sq"], table["exp_avg_sq"])) and set(small2["state"]) == {0, 1}
+    # before the first step there are no moments
+    tab0, _ = _split_table_state(_merge_table_state(dict(table, step=0), opt.state_dict()), C, n_small, "fields")
+    assert tab0["step"] == 0 and tab0["exp_avg"] is None
+    with pytest.raises(KeyError, match="hash encodings"):
+        _split_table_state(merged, C + 1, n_small, "fields")
