@@ -147,8 +147,12 @@ __global__ __launch_bounds__(256) void occ_scatter_max_kernel(const int32_t* __r
                                                               int64_t n_cells, uint32_t* __restrict__ newmax) {
     for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < M; s += (int64_t)gridDim.x * blockDim.x) {
         const int32_t c = cell_ids[s];
-        const float v = values[s];
-        if (c < 0 || c >= n_cells || !(v >= 0.0f)) continue;           // NaN / negative never win (oracle: same)
+        float v = values[s];
+        if (c < 0 || c >= n_cells) continue;
+        // nerfacc: occs[idx] = maximum(occs[idx] * decay, occ) -- every queried cell is decayed.  A negative value loses
+        // against the decayed one exactly like 0; a NaN is taken as 0 too (the cell decays instead of being poisoned: the
+        // one deviation from torch.maximum, stated in oracle/occgrid.c)
+        if (!(v >= 0.0f)) v = 0.0f;
         // non-negative floats order like their bit patterns; +1 keeps 0 free as the "untouched" mark (+inf + 1 is
         // still below the sign bit)
         atomicMax(&newmax[c], __float_as_uint(v) + 1u);

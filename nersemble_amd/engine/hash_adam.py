@@ -136,6 +136,8 @@ class HashTableAdam(torch.optim.Optimizer):
         for t in keep:                        # allocated on the main stream, still being read on the side stream
             t.record_stream(side_stream)
         he._tables_ready = done
+        if sink is not None:
+            sink.consumed = done                  # G has been read once this event has passed (FactoredGradSink.clear_ahead)
 
     def _step_now(self, found_inf, inv_scale):
         he, p = self.he, self.he.tables

@@ -90,6 +90,8 @@ class FactoredGradSink:
         self.nonfinite = None        # device float: set by the backward kernel when it adds an inf/NaN to a G
         self.pending = 0             # forwards recorded for autograd whose backward has not run yet
         self.pre_cleared = None      # (G, event): the cached buffer was cleared ahead of time on another stream
+        self.consumed = None         # event after the LAST reader of G on another stream (the table optimizer's pass):
+        #                              whoever rewrites the cached buffer off the main stream orders itself behind it
         self.samples_scattered = 0   # samples whose gradient the step's backward calls add to G (0: unknown)
         self.clear_ahead_enabled = os.environ.get("NSX_CLEAR_G_AHEAD", "1") == "1"
         self._fill_stream = None
@@ -179,6 +181,10 @@ class FactoredGradSink:
         if side is None or side.device != G.device:
             side = self._fill_stream = torch.cuda.Stream(G.device)
         side.wait_stream(main)
+        if self.consumed is not None:
+            # the previous step's table optimizer reads this very buffer on ITS stream; the main stream is ordered behind
+            # it only through HashEnsemble.wait_tables() in the sigma_fn forward -- do not rely on that call having run
+            side.wait_event(self.consumed)
         with torch.cuda.stream(side):
             G.zero_()
             ev = torch.cuda.Event()

@@ -39,24 +39,57 @@ class ConfigNode:
         return f"{type(self).__name__}({', '.join(f'{k}={v!r}' for k, v in vars(self).items())})"
 
 
+def _load_storage_from_bytes(b):
+    """What ``torch.storage._load_from_bytes`` does for a tensor dumped into the yaml (the scene box), restricted to
+    tensor data: the original unpickles arbitrary objects."""
+    import io
+    return torch.load(io.BytesIO(b), weights_only=True)
+
+
+# The only python names a run's ``config.yml`` needs CONSTRUCTED: paths, ordered dicts, and the pieces of a dumped
+# torch tensor.  Everything else -- config classes of packages that are not installed, ``_target`` class references,
+# optimizer classes -- becomes an inert ``ConfigNode`` placeholder: no import, no call.
+_ALLOWED_NAMES = {
+    "pathlib.PosixPath": pathlib.PosixPath, "pathlib.WindowsPath": pathlib.WindowsPath, "pathlib.Path": pathlib.Path,
+    "pathlib.PurePosixPath": pathlib.PurePosixPath, "pathlib.PureWindowsPath": pathlib.PureWindowsPath,
+    "collections.OrderedDict": __import__("collections").OrderedDict,
+    "torch._utils._rebuild_tensor_v2": torch._utils._rebuild_tensor_v2,
+    "torch.storage._load_from_bytes": _load_storage_from_bytes,
+    "torch.float32": torch.float32, "torch.float64": torch.float64, "torch.float16": torch.float16,
+    "torch.int64": torch.int64, "torch.int32": torch.int32, "torch.uint8": torch.uint8, "torch.bool": torch.bool,
+}
+
+
 class _LenientLoader(yaml.Loader):
-    """``yaml.Loader`` (what the reference uses, util/setup.py:76) that survives missing packages: a python name / class
-    it cannot import becomes a placeholder class whose instances are ``ConfigNode``s carrying the dumped fields."""
+    """A loader for ``yaml.dump``-ed nerfstudio / nersemble configs (the reference reads them with ``yaml.Loader``,
+    util/setup.py:76) that neither needs the dumped classes' packages nor executes anything a file names: python names
+    on ``_ALLOWED_NAMES`` resolve to what they are, every other name / class becomes a placeholder class whose
+    instances are ``ConfigNode``s carrying the dumped fields.  Opening a run folder of unknown origin therefore cannot
+    import modules or call functions of the file's choosing."""
 
-    def find_python_name(self, name, mark, unsafe=True):
-        try:
-            return yaml.constructor.FullConstructor.find_python_name(self, name, mark, unsafe=True)
-        except yaml.constructor.ConstructorError:
-            # named and "located" like the original, so that yaml.dump of a loaded config writes the original tags again
-            # (the reference's save_config, model_manager/base.py:44-46)
-            module, _, cls_name = name.rpartition(".")
-            return type(cls_name, (ConfigNode,), {"_class": name, "__module__": module})
+    def find_python_name(self, name, mark, unsafe=False):
+        hit = _ALLOWED_NAMES.get(name)
+        if hit is not None:
+            if hit is pathlib.PosixPath or hit is pathlib.WindowsPath:
+                return getattr(pathlib, hit.__name__)      # (try_load_config's PosixPath <-> WindowsPath retry swaps these)
+            return hit
+        # named and "located" like the original, so that yaml.dump of a loaded config writes the original tags again
+        # (the reference's save_config, model_manager/base.py:44-46)
+        module, _, cls_name = name.rpartition(".")
+        return type(cls_name or name, (ConfigNode,), {"_class": name, "__module__": module})
 
-    def find_python_module(self, name, mark, unsafe=True):
-        try:
-            return yaml.constructor.FullConstructor.find_python_module(self, name, mark, unsafe=True)
-        except yaml.constructor.ConstructorError:
-            return types.ModuleType(name)
+    def find_python_module(self, name, mark, unsafe=False):
+        return types.ModuleType(name)
+
+    def make_python_instance(self, suffix, node, args=None, kwds=None, newobj=False, unsafe=False):
+        cls = self.find_python_name(suffix, node.start_mark)
+        if isinstance(cls, type) and issubclass(cls, ConfigNode):
+            # `object:` / `object/apply:` / `object/new:` of a class that is not constructed here: keep what the node says
+            fields = {str(k): v for k, v in (kwds or {}).items()}
+            if args:
+                fields["args"] = list(args)
+            return cls(**fields)
+        return super().make_python_instance(suffix, node, args, kwds, newobj)
 
 
 def try_load_config(config_path) -> ConfigNode:
@@ -149,7 +182,8 @@ def nersemble_eval_setup(config_path, checkpoint_folder, eval_num_rays_per_chunk
     config.unmapped_model_fields = unknown
     device = torch.device(device) if device is not None else torch.device("cuda" if torch.cuda.is_available() else "cpu")
     checkpoint_path, step = find_checkpoint(checkpoint_folder, checkpoint)
-    state = torch.load(checkpoint_path, map_location="cpu")
+    # (tensors and primitives only: a checkpoint of unknown origin cannot run code through the unpickler)
+    state = torch.load(checkpoint_path, map_location="cpu", weights_only=True)
     # the image count only sizes nerfstudio's (unused) appearance embedding: take it from the checkpoint if it is there
     num_train_data = int(getattr(config.pipeline.datamanager, "train_num_images", 0) or 1)
     model = NeRSembleNGPModel(model_cfg, SceneBox(scene_box), num_train_data=num_train_data)

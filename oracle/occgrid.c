@@ -105,10 +105,13 @@ float nsxo_occ_update(float* occs, uint8_t* binaries, int64_t n_cells, const int
         const int32_t c = cell_ids[s];
         if (c < 0) continue;
         const float v = occ_values[s];
-        /* densities are >= 0; a NaN never wins a max (the kernel's unsigned atomic max on the bit pattern would
-           rank it highest, so both sides drop it explicitly) */
-        if (!(v >= 0.0f)) continue;
-        if (v > newmax[c]) newmax[c] = v;
+        /* nerfacc: occs[idx] = maximum(occs[idx] * decay, occ) -- a queried cell is decayed whatever its value.
+           Densities are >= 0 (trunc_exp); a negative value loses against the decayed one exactly like 0 does, so it
+           counts as 0.  A NaN (the kernel's unsigned atomic max on the bit pattern would rank it highest) is taken
+           as 0 as well: the cell decays instead of being poisoned -- the ONE deviation from torch.maximum, which
+           would propagate the NaN into occs, the mean and every later threshold. */
+        const float vv = (v >= 0.0f) ? v : 0.0f;
+        if (vv > newmax[c]) newmax[c] = vv;
     }
     double sum = 0.0;
     int64_t cnt = 0;

@@ -156,3 +156,26 @@ def test_fields_optimizer_state_has_the_reference_shape():
     assert tab0["step"] == 0 and tab0["exp_avg"] is None
     with pytest.raises(KeyError, match="hash encodings"):
         _split_table_state(merged, C + 1, n_small, "fields")
+
+
+def test_config_loader_constructs_nothing_a_file_names(tmp_path):
+    """A ``config.yml`` of unknown origin: names outside the allow-list (paths, OrderedDict, the pieces of a dumped tensor)
+    become inert placeholders -- nothing is imported, nothing is called."""
+    from nersemble_amd.util.setup import ConfigNode, try_load_config
+    marker = tmp_path / "ran"
+    text = (f"a: !!python/object/apply:os.system ['touch {marker}']\n"
+            f"b: !!python/object/apply:subprocess.check_output [['touch', '{marker}']]\n"
+            "c: !!python/name:os.system\n"
+            "d: !!python/module:shutil\n"
+            "e: !!python/object/new:os.system ['true']\n"
+            "p: !!python/object/apply:pathlib.PosixPath [x, y]\n"
+            "t: !!python/tuple [1, 2]\n")
+    path = tmp_path / "config.yml"
+    path.write_text(text)
+    cfg = try_load_config(path)
+    assert not marker.exists()
+    assert isinstance(cfg["a"], ConfigNode) and cfg["a"].args == [f"touch {marker}"]
+    assert isinstance(cfg["b"], ConfigNode) and isinstance(cfg["e"], ConfigNode)
+    assert isinstance(cfg["c"], type) and issubclass(cfg["c"], ConfigNode) and cfg["c"]._class == "os.system"
+    assert type(cfg["d"]).__name__ == "module" and not hasattr(cfg["d"], "rmtree")
+    assert str(cfg["p"]) == "x/y" and cfg["t"] == (1, 2)

@@ -48,16 +48,28 @@ def test_selection_after_warmup_uniform_then_occupied():
 
 
 def test_ema_max_and_threshold_rules():
-    occs = np.array([0.5, 0.0, 0.02, 0.0, 0.3, 0.0], np.float32)
-    cells = np.array([0, 0, 2, 4, 4, 1, 5, 5], np.int32)
-    vals = np.array([0.1, 0.6, 0.001, np.nan, 0.2, 0.004, -1.0, 0.0], np.float32)
-    o, b, thre = og.update(occs, np.zeros(6, bool), cells, vals, ema_decay=0.95, occ_thre=0.01)
+    occs = np.array([0.5, 0.0, 0.02, 0.0, 0.3, 0.0, 0.4, 0.2], np.float32)
+    cells = np.array([0, 0, 2, 4, 4, 1, 5, 5, 6, 7], np.int32)
+    vals = np.array([0.1, 0.6, 0.001, np.nan, 0.2, 0.004, -1.0, 0.0, np.nan, -3.0], np.float32)
+    o, b, thre = og.update(occs, np.zeros(8, bool), cells, vals, ema_decay=0.95, occ_thre=0.01)
+    d = np.float32(0.95)
     want = np.array([0.6,                         # duplicates: the larger of them beats 0.5 * 0.95
-                     0.004, np.float32(0.02) * np.float32(0.95), 0.0,       # cell 3 untouched
-                     np.float32(0.3) * np.float32(0.95),                   # NaN dropped, 0.2 < decayed
-                     0.0], np.float32)                                      # negative dropped, 0.0 kept
+                     0.004, np.float32(0.02) * d, 0.0,                      # cell 3 untouched
+                     np.float32(0.3) * d,                                   # NaN counts as 0, 0.2 < decayed
+                     0.0,                                                   # negative counts as 0
+                     np.float32(0.4) * d,                                   # ONLY a NaN: the cell still decays (nerfacc decays
+                     np.float32(0.2) * d], np.float32)                      # every queried cell); only a negative: same
     assert np.array_equal(o, want)
-    assert thre == np.float32(0.01) and np.array_equal(b, want > 0.01)     # mean 0.15 clamps to occ_thre
+    # torch.maximum(occs * decay, occ) -- nerfacc's rule -- agrees wherever no NaN is involved
+    import torch
+    ref = torch.from_numpy(occs.copy())
+    for c in np.unique(cells):
+        v = torch.from_numpy(vals[cells == c])
+        if not torch.isnan(v).any():
+            ref[c] = torch.maximum(ref[c] * 0.95, v.max())
+    ok = np.array([c not in (4, 6) for c in range(8)])
+    assert np.array_equal(ref.numpy()[ok], o[ok])
+    assert thre == np.float32(0.01) and np.array_equal(b, want > 0.01)     # the mean clamps to occ_thre
     o2, b2, thre2 = og.update(np.zeros(4, np.float32), np.zeros(4, bool), np.array([1], np.int32),
                               np.array([0.004], np.float32))
     assert np.isclose(thre2, 0.001) and b2.tolist() == [False, True, False, False]   # mean below occ_thre
