@@ -229,6 +229,15 @@ int nsx_sample_positions(const float* origins, const float* directions, const in
  * (inside OccGridEstimator.sampling, called at nersemble_volumetric_sampler.py:95-108), the per-field gathers that build
  * the packed RaySamples (nersemble_volumetric_sampler.py:117-134) and the compaction of the sigma-pass values that the
  * main pass reuses. */
+/* Pinhole ray generation (csrc/raygen.hip): what the reference's datamanager obtains from nerfstudio's RayGenerator ->
+ * Cameras.generate_rays for the pixel sampler's (camera, y, x) triples (datamanager/nersemble_datamanager.py:76-81;
+ * perspective cameras without distortion, dataparser/nersemble_dataparser.py:237-244).
+ *   camera_to_worlds [n_cameras][3][4] fp32 (OpenGL convention), fx / fy / cx / cy [n_cameras] fp32
+ *   camera_indices [R] int64, ys / xs [R] fp32 pixel coordinates WITH the pixel-centre offset (+0.5) already added
+ *   origins / directions [R][3] fp32 (unit directions), pixel_area [R] fp32 (may be NULL) */
+int nsx_generate_rays(const float* camera_to_worlds, const float* fx, const float* fy, const float* cx, const float* cy,
+                      int64_t n_cameras, const int64_t* camera_indices, const float* ys, const float* xs, int64_t R,
+                      float* origins, float* directions, float* pixel_area, void* stream);
 #define NSX_MAX_GATHER 8
 int nsx_gather_rows(int n_arrays, const void* const* srcs, const int64_t* row_bytes, void* const* dsts,
                     const int64_t* index, int64_t n, void* stream);

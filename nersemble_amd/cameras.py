@@ -69,6 +69,9 @@ class Cameras:
                          times=None if flat.times is None else flat.times.view(h, w, 1))
 
     def _rays_at(self, cams: Tensor, ys: Tensor, xs: Tensor) -> RayBundle:
+        if self.camera_to_worlds.is_cuda:
+            return self._rays_at_native(cams, ys, xs)
+        # host mirror of csrc/raygen.hip (camera containers that live on the CPU: tests, the evaluation tools' set-up)
         rot = self.camera_to_worlds[cams, :, :3]                       # [N, 3, 3]
         fx, fy, cx, cy = (t[cams, 0] for t in (self.fx, self.fy, self.cx, self.cy))
 
@@ -83,6 +86,25 @@ class Cameras:
         times = None if self.times is None else self.times[cams]
         return RayBundle(origins=self.camera_to_worlds[cams, :, 3].contiguous(), directions=directions.contiguous(),
                          pixel_area=dx * dy, camera_indices=cams[:, None], times=times)
+
+    def _rays_at_native(self, cams: Tensor, ys: Tensor, xs: Tensor) -> RayBundle:
+        """One launch of ``nsx_generate_rays`` (csrc/raygen.hip) instead of ~35 torch kernels."""
+        from ._lib import check, lib, ptr, stream
+        dev = self.device
+        cams = cams.to(device=dev, dtype=torch.int64).contiguous()
+        ys = ys.to(device=dev, dtype=torch.float32).contiguous()
+        xs = xs.to(device=dev, dtype=torch.float32).contiguous()
+        n = cams.shape[0]
+        origins = torch.empty((n, 3), dtype=torch.float32, device=dev)
+        directions = torch.empty((n, 3), dtype=torch.float32, device=dev)
+        area = torch.empty((n, 1), dtype=torch.float32, device=dev)
+        c2w = self.camera_to_worlds.contiguous()
+        fx, fy, cx, cy = (t.reshape(-1).contiguous() for t in (self.fx, self.fy, self.cx, self.cy))
+        check(lib().nsx_generate_rays(ptr(c2w, torch.float32), ptr(fx, torch.float32), ptr(fy, torch.float32),
+                                      ptr(cx, torch.float32), ptr(cy, torch.float32), self.size, ptr(cams), ptr(ys), ptr(xs),
+                                      n, ptr(origins), ptr(directions), ptr(area), stream()), "nsx_generate_rays")
+        times = None if self.times is None else self.times[cams]
+        return RayBundle(origins=origins, directions=directions, pixel_area=area, camera_indices=cams[:, None], times=times)
 
 
 class RayGenerator:

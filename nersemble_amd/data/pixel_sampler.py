@@ -44,6 +44,12 @@ class NeRSemblePixelSampler:
         num_images, image_height, image_width, _ = batch["image"].shape
         indices = self.sample_method(num_rays_per_batch, num_images, image_height, image_width,
                                      mask=batch.get("mask"), device=device)
+        return self.collate_at(batch, indices, keep_full_image)
+
+    def collate_at(self, batch: Dict, indices: Tensor, keep_full_image: bool = False) -> Dict:
+        """The gather half of ``collate_image_dataset_batch`` for given batch-local (image, y, x) triples
+        (nersemble_pixel_sampler.py:44-66)."""
+        num_rays_per_batch = indices.shape[0]
         c, y, x = indices[:, 0], indices[:, 1], indices[:, 2]            # stay on the device (reference: .cpu())
         collated = {key: value[c, y, x] for key, value in batch.items()
                     if key not in self._per_image_attributes and value is not None}

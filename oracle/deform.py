@@ -58,6 +58,20 @@ def _r16(t: torch.Tensor) -> torch.Tensor:
     return t + (r - t.detach())
 
 
+class _Round16Both(torch.autograd.Function):
+    """fp16 rounding of the value in the forward AND of the gradient in the backward: what an fp16 tensor inside an
+    autocast region is -- the gradient of a Linear's fp16 output / input is itself an fp16 tensor (torch computes
+    grad_input = grad_output @ W as an fp16 GEMM), which is where csrc/deform.hip rounds its dZ tiles."""
+
+    @staticmethod
+    def forward(ctx, t):
+        return t.to(torch.float32).to(torch.float16).to(t.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.float32).to(torch.float16).to(g.dtype)
+
+
 def window_weights(windows_param, n=7):
     if windows_param is None:
         return np.ones(n, np.float32)
@@ -91,22 +105,34 @@ def se3_warp(r, v, p, eps=1e-4):
 
 
 def compute_offsets(pos_world, codes, flat_params, aabb, windows_param, half=True, dtype=torch.float64,
-                    width: int = None):
+                    width: int = None, round_grads: bool = False, round_code_grad: bool = None):
     """pos_world [S,3], codes [S,code_dim], flat_params (include/nsx.h order) -> offsets [S,3] (normalised space).
-    ``width`` defaults to 128 unless the parameter count says otherwise (solved from the layout)."""
+    ``width`` defaults to 128 unless the parameter count says otherwise (solved from the layout).
+
+    ``round_grads`` (with ``half``): the BACKWARD follows the autocast numerics too -- the gradient of every Linear
+    output (dZ, heads included) is rounded to fp16 before it meets the weights / the layer input, as torch's fp16
+    GEMMs and csrc/deform.hip do; weight / bias gradients stay wide (the kernel accumulates them in fp32, the
+    reference rounds them once more).  ``round_code_grad`` (default: as ``round_grads``): also the gradient that
+    reaches the warp codes through the first cast -- the kernel's code-TABLE gradient sums fp16 dC tiles, its
+    per-sample code gradient is written from the fp32 accumulators (pass False for that output)."""
     code_dim = codes.shape[1]
     if width is None:
         width = next(w for w in (128, 32, 64, 16, 256) if flat_layout(w, code_dim)[1] == flat_params.numel())
     P = unflatten(flat_params.to(dtype), width, code_dim)
-    rnd = _r16 if half else (lambda t: t)
+    rnd = _r16 if half else (lambda t: t)                   # parameters: straight-through
+    both = half and round_grads
+    rnd_act = _Round16Both.apply if both else rnd           # Linear outputs
+    if round_code_grad is None:
+        round_code_grad = round_grads
+    rnd_in = _Round16Both.apply if (half and round_code_grad) else rnd
     aabb = aabb.to(dtype)
     pn = (pos_world.to(dtype) - aabb[0]) / (aabb[1] - aabb[0])
     if half:   # the kernel normalises in fp32
         pn = ((pos_world.float() - aabb[0].float()) / (aabb[1] - aabb[0]).float()).to(dtype)
-    x0 = rnd(torch.cat([encode(pn, windows_param), codes.to(dtype)], dim=-1))
+    x0 = rnd_in(torch.cat([encode(pn, windows_param), codes.to(dtype)], dim=-1))
 
     def lin(x, Wn, bn, relu=True):
-        y = rnd(x @ rnd(P[Wn]).T + rnd(P[bn]))
+        y = rnd_act(x @ rnd(P[Wn]).T + rnd(P[bn]))
         return torch.relu(y) if relu else y
 
     h = lin(x0, "W0", "b0")

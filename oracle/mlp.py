@@ -56,24 +56,31 @@ def mlp_fwd(x, params, n_hidden_mats, n_out, out_act, return_acts=False):
     return out
 
 
-def mlp_bwd(x, params, n_hidden_mats, n_out, out_act, dout):
-    """Returns (dparams fp64 flat, dx fp64 [B, 32]) for upstream dout [B, n_out] (float)."""
+def mlp_bwd(x, params, n_hidden_mats, n_out, out_act, dout, round_dz=False):
+    """Returns (dparams fp64 flat, dx fp64 [B, 32]) for upstream dout [B, n_out] (float).
+
+    ``round_dz``: the gradient of every layer's pre-activation (dZ) is rounded to fp16 before it is used -- in the
+    weight-gradient product AND in the product that carries it to the layer below -- which is what tcnn's
+    FullyFusedMLP backward does (its dL/doutput and all intermediate gradients are __half matrices) and where
+    csrc/mlp.hip rounds (the MFMA operands are fp16; accumulation is wide).  Without it the chain is exact float64."""
     w0, wh, wo = split_params(params, n_hidden_mats)
     _, acts, y = mlp_fwd(x, params, n_hidden_mats, n_out, out_act, return_acts=True)
+    rz = _r16 if round_dz else (lambda a: a)
     B = acts[0].shape[0]
     dz = np.zeros((B, OUT))
     dz[:, :n_out] = np.asarray(dout, dtype=np.float64)
     if out_act == 1:
         dz = dz * y * (1 - y)
+    dz = rz(dz)
     grads = []
     h = acts[-1]
     grads.append(dz.T @ h)                 # dWo
     dh = dz @ wo
     for li in range(len(wh) - 1, -1, -1):
-        dzh = dh * (acts[2 + li] > 0)
+        dzh = rz(dh * (acts[2 + li] > 0))
         grads.append(dzh.T @ acts[1 + li])
         dh = dzh @ wh[li]
-    dz0 = dh * (acts[1] > 0)
+    dz0 = rz(dh * (acts[1] > 0))
     grads.append(dz0.T @ acts[0])
     dx = dz0 @ w0
     grads = grads[::-1]                    # W0, Wh..., Wo

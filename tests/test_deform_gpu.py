@@ -38,6 +38,12 @@ def test_deform_forward_per_sample_codes(S, window, cuda):
     assert (got - want).abs().max().item() <= tol, ((got - want).abs().max().item(), tol)
 
 
+# gradients vs the oracle whose backward rounds dZ to fp16 where the kernel does: what is left are fp16 rounding-boundary
+# flips of single dZ elements (a value computed in fp32 here, in fp64 there, landing on different sides of a tie) and the
+# order of the fp32 sums
+DEFORM_BWD_TOL = 2e-3
+
+
 def test_deform_forward_code_table_equals_gather(cuda):
     df = _field(1).to(cuda)
     S, T = 2049, 37
@@ -74,11 +80,12 @@ def test_deform_backward(S, T, cuda):
     table = torch.randn(T, 128, generator=g) * 0.3
     slot = torch.randint(0, T, (S,), generator=g)
     goff = torch.randn(S, 3, generator=g)
-    # oracle gradients: float64 autograd through the fp16-rounded forward (straight-through rounding), so the
-    # ReLU masks are those of the autocast forward the kernel reproduces
+    # oracle gradients: autograd through the fp16-rounded forward (the ReLU masks are those of the autocast forward the
+    # kernel reproduces) with dZ rounded to fp16 at every Linear output on the way back, where the kernel rounds
+    # (oracle/deform.py round_grads; the same chain without the roundings is pinned to the reference's autograd)
     flat = df.flat_params().detach().double().requires_grad_(True)
     tab64 = table.double().requires_grad_(True)
-    off = od.compute_offsets(pos, tab64[slot], flat, AABB, 2.75, half=True, dtype=torch.float64)
+    off = od.compute_offsets(pos, tab64[slot], flat, AABB, 2.75, half=True, dtype=torch.float64, round_grads=True)
     off.backward(goff.double())
     dfc = df.to(cuda)
     tabc = table.to(cuda).requires_grad_(True)
@@ -91,9 +98,9 @@ def test_deform_backward(S, T, cuda):
         n = int(np.prod(shp))
         a, b = gflat[o:o + n], flat.grad[o:o + n]
         denom = b.abs().max().item() + 1e-12
-        assert (a - b).abs().max().item() <= 3e-2 * denom, (name, (a - b).abs().max().item() / denom)
+        assert (a - b).abs().max().item() <= DEFORM_BWD_TOL * denom, (name, (a - b).abs().max().item() / denom)
     gt, wt = tabc.grad.cpu().double(), tab64.grad
-    assert (gt - wt).abs().max().item() <= 3e-2 * wt.abs().max().item()
+    assert (gt - wt).abs().max().item() <= DEFORM_BWD_TOL * wt.abs().max().item()
 
 
 def _ordered_params(df):
@@ -113,12 +120,14 @@ def test_deform_backward_per_sample_codes(cuda):
     codes = torch.randn(S, 128, generator=g) * 0.3
     goff = torch.randn(S, 3, generator=g)
     c64 = codes.double().requires_grad_(True)
-    off = od.compute_offsets(pos, c64, df.flat_params().detach().double(), AABB, None, half=True, dtype=torch.float64)
+    # (the per-sample code gradient leaves the kernel from its fp32 accumulators: round_code_grad=False)
+    off = od.compute_offsets(pos, c64, df.flat_params().detach().double(), AABB, None, half=True, dtype=torch.float64,
+                             round_grads=True, round_code_grad=False)
     off.backward(goff.double())
     dfc = df.to(cuda)
     cc = codes.to(cuda).requires_grad_(True)
     dfc.compute_offsets(pos.to(cuda), cc, None).backward(goff.to(cuda))
-    assert (cc.grad.cpu().double() - c64.grad).abs().max().item() <= 3e-2 * c64.grad.abs().max().item()
+    assert (cc.grad.cpu().double() - c64.grad).abs().max().item() <= DEFORM_BWD_TOL * c64.grad.abs().max().item()
 
 
 def test_deform_kernels_are_race_free(cuda):

@@ -57,16 +57,18 @@ def test_mlp_backward(nh, in_dim, n_out, act, B, cuda):
     rng = np.random.default_rng(B + 1)
     x = rng.standard_normal((B, in_dim)).astype(np.float16)
     dout = rng.standard_normal((B, n_out)).astype(np.float16)
-    dW_o, dx_o = omlp.mlp_bwd(x, p, nh, n_out, act, dout.astype(np.float64))
+    dW_o, dx_o = omlp.mlp_bwd(x, p, nh, n_out, act, dout.astype(np.float64), round_dz=True)
     pt = torch.from_numpy(p).to(cuda).requires_grad_(True)
     xt = torch.from_numpy(x).to(cuda).requires_grad_(True)
     out = F.fused_mlp(pt, nh, n_out, act, b=xt)
     out.backward(torch.from_numpy(dout).to(cuda))
     dW = pt.grad.cpu().numpy()
     dx = xt.grad.float().cpu().numpy()
-    # HIP rounds dZ to fp16 between layers (like tcnn); oracle keeps float64 -> ~1e-3 relative to the scale
-    assert np.abs(dW - dW_o).max() <= 3e-3 * np.abs(dW_o).max() + 1e-6, float(np.abs(dW - dW_o).max() / np.abs(dW_o).max())
-    assert np.abs(dx - dx_o[:, :in_dim]).max() <= 3e-3 * np.abs(dx_o).max() + 1e-6
+    # HIP rounds dZ to fp16 between layers (like tcnn) and so does the oracle (round_dz): what is left is the order of
+    # the fp32 sums and single dZ elements landing on the other side of an fp16 tie; the input gradient leaves as fp16
+    assert np.abs(dW - dW_o).max() <= 5e-4 * np.abs(dW_o).max() + 1e-6, float(np.abs(dW - dW_o).max() / np.abs(dW_o).max())
+    d = np.abs(dx - dx_o[:, :in_dim])
+    assert (d <= 2.0 ** -10 * np.abs(dx_o[:, :in_dim]) + 5e-4 * np.abs(dx_o).max() + 1e-6).all(), float(d.max() / np.abs(dx_o).max())
 
 
 def test_mlp_head_backward_segments(cuda):
@@ -78,7 +80,7 @@ def test_mlp_head_backward_segments(cuda):
     base = rng.standard_normal((B, 16)).astype(np.float16)
     dout = rng.standard_normal((B, 3)).astype(np.float16)
     x = np.concatenate([((dirs + 1) / 2).astype(np.float16), base[:, 1:]], axis=1)
-    dW_o, dx_o = omlp.mlp_bwd(x, p, 1, 3, 1, dout.astype(np.float64))
+    dW_o, dx_o = omlp.mlp_bwd(x, p, 1, 3, 1, dout.astype(np.float64), round_dz=True)
     pt = torch.from_numpy(p).to(cuda).requires_grad_(True)
     bt = torch.from_numpy(base).to(cuda).requires_grad_(True)
     dt = torch.from_numpy(dirs).to(cuda).requires_grad_(True)
@@ -87,6 +89,6 @@ def test_mlp_head_backward_segments(cuda):
     sc = np.abs(dx_o).max()
     db = bt.grad.float().cpu().numpy()
     assert np.all(db[:, 0] == 0)
-    assert np.abs(db[:, 1:] - dx_o[:, 3:18]).max() <= 3e-3 * sc
-    assert np.abs(dt.grad.cpu().numpy() - 0.5 * dx_o[:, :3]).max() <= 3e-3 * sc
-    assert np.abs(pt.grad.cpu().numpy() - dW_o).max() <= 3e-3 * np.abs(dW_o).max()
+    assert (np.abs(db[:, 1:] - dx_o[:, 3:18]) <= 2.0 ** -10 * np.abs(dx_o[:, 3:18]) + 5e-4 * sc).all()      # fp16 output
+    assert np.abs(dt.grad.cpu().numpy() - 0.5 * dx_o[:, :3]).max() <= 5e-4 * sc
+    assert np.abs(pt.grad.cpu().numpy() - dW_o).max() <= 5e-4 * np.abs(dW_o).max()

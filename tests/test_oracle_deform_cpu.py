@@ -83,3 +83,45 @@ def test_half_mode_stays_close_to_the_pinned_mode(golden_dir):
     exact = od.compute_offsets(pos, code, flat, AABB, 2.75, half=False).numpy()
     half = od.compute_offsets(pos, code, flat, AABB, 2.75, half=True).numpy()
     assert np.abs(half - exact).max() <= 3e-3 * max(np.abs(exact).max(), 1.0)
+
+
+def test_rounded_backward_mode_is_the_pinned_backward_plus_fp16_roundings(golden_dir):
+    """``round_grads``: the gradient of every Linear output is rounded to fp16 on its way back (autocast's fp16 GEMM
+    outputs; where csrc/deform.hip rounds).  Same code path as the mode that is pinned against the reference's autograd
+    above, so it must stay within fp16 noise of it -- and it must actually differ (the flag does something), with
+    fp16-representable per-sample code gradients when ``round_code_grad`` is on."""
+    z = np.load(f"{golden_dir}/deformation_full.npz")
+    base = od.flat_from_state_dict(make_deform_state_dict(int(z["dff_seed"][0])))
+    pos, gw = torch.from_numpy(z["dff_pos"]), torch.from_numpy(z["dff_gw"]).double()
+
+    def grads(**kw):
+        flat = base.clone().requires_grad_(True)
+        code = torch.from_numpy(z["dff_code"]).double().requires_grad_(True)
+        off = od.compute_offsets(pos, code, flat, AABB, 2.75, half=True, **kw)
+        (off * gw).sum().backward()
+        return code.grad.numpy(), flat.grad.numpy()
+
+    gc0, gp0 = grads()
+    gc1, gp1 = grads(round_grads=True)
+    gc2, _ = grads(round_grads=True, round_code_grad=False)
+    assert 0 < np.abs(gp1 - gp0).max() <= 5e-3 * np.abs(gp0).max()
+    assert 0 < np.abs(gc1 - gc0).max() <= 5e-3 * np.abs(gc0).max()
+    assert np.array_equal(gc1, gc1.astype(np.float16).astype(np.float64))
+    assert not np.array_equal(gc2, gc2.astype(np.float16).astype(np.float64))
+    # and the rounded chain is still the reference's chain: held to the golden autograd within the fp16 noise
+    assert np.abs(gp1 - z["dff_gparams"]).max() <= 3e-2 * np.abs(z["dff_gparams"]).max()
+
+
+def test_mlp_oracle_rounded_backward():
+    """oracle/mlp.py ``round_dz``: dZ rounded to fp16 per layer (tcnn's __half gradient matrices, csrc/mlp.hip's MFMA
+    operands) -- within fp16 noise of the exact chain, not equal to it."""
+    from oracle import mlp as omlp
+    rng = np.random.default_rng(0)
+    nh, B = 1, 200
+    p = (rng.standard_normal(omlp.param_count(nh)) * 0.2).astype(np.float32)
+    x = rng.standard_normal((B, 32)).astype(np.float16)
+    dout = rng.standard_normal((B, 16))
+    dW0, dx0 = omlp.mlp_bwd(x, p, nh, 16, 0, dout)
+    dW1, dx1 = omlp.mlp_bwd(x, p, nh, 16, 0, dout, round_dz=True)
+    assert 0 < np.abs(dW1 - dW0).max() <= 2e-3 * np.abs(dW0).max()
+    assert 0 < np.abs(dx1 - dx0).max() <= 2e-3 * np.abs(dx0).max()
