@@ -65,15 +65,16 @@ class NeRSembleTrainer:
                  rank: Optional[int] = None, sharded_table_adam: Optional[bool] = None,
                  overlap_table_adam: bool = True, calibrate_table_placement: bool = True,
                  global_loss_normalisers: bool = False, early_table_step: bool = False,
-                 compact_first_grid: bool = False):
+                 compact_first_grid: bool = True):
         """``global_loss_normalisers``: the ranks hold consecutive slices of ONE ray batch (strong scaling)
         -- loss denominators are made global so that the step equals the single-process step on the union batch."""
         self.model = model
         # ``compact_first_grid``: while the coarse-to-fine window keeps one hash grid on (the first 40 000 steps of the
         # reference's schedule), train a contiguous copy of that grid with the H = 1 kernels instead of the 32-grid layout
-        # (HashEnsemble.first_grid_phase: same values, ~2x per step).  Single GPU, factored table gradient.  Off by default:
-        # code that reads ``hash_ensemble.tables`` or the optimizer's moments directly in that phase must call
-        # ``consolidate()`` first (``state_dict()`` / checkpoints do).
+        # (HashEnsemble.first_grid_phase: same values, ~1.4-1.7x per step).  Single GPU, factored table gradient.  ON by
+        # default (round 3): the phase ends by itself when the window opens, ``state_dict()`` / checkpoints /
+        # ``model.eval()`` see the full layout; only code that reads the ``hash_ensemble.tables`` PARAMETER or the table
+        # optimizer's moments directly while the phase lasts must call ``consolidate()`` first.
         self.compact_first_grid = compact_first_grid
         # start the table optimizer from inside the backward (HashTableAdam.arm_early_step).  OFF by default: measured
         # slower (8.8 vs 8.3 ms per step early in training, 4.85 vs 4.25 ms in steady state) -- the 12 GB pass next to

@@ -266,6 +266,7 @@ def test_two_ranks_on_half_batches_equal_one_process_on_the_union_batch(cuda, tm
     _no_jitter(single)
     loss, loss_dict, _ = single.train_iteration(0, bundle, batch)
     single.flush_scheduler_step()
+    single.consolidate()                    # (single-GPU default: compact first-grid phase; write grid 0 back)
     tables = single.model.field.hash_ensemble.tables.detach().cpu()
     grads = {n: p.grad.detach().float().cpu() for n, p in single.model.named_parameters()
              if "tables" not in n and p.grad is not None}

@@ -17,6 +17,7 @@ def _run(factored, steps=6, seed=0, workload="p030_h16"):
         bundle, batch = data.next_train(step)
         loss, loss_dict, metrics = trainer.train_iteration(step, bundle, batch)
         losses.append(loss.item())
+    trainer.consolidate()          # (compact first-grid phase, the trainer's default: the callers read `tables` directly)
     return trainer, losses, metrics
 
 
@@ -449,7 +450,7 @@ def test_early_table_step_keeps_gradscaler_skip_semantics(cuda):
     the step count does not advance; the next (finite) step goes through."""
     from nersemble_amd.workloads import build_workload
     torch.manual_seed(9)
-    trainer, data, _ = build_workload("p030_h16", device="cuda:0", small=True, n_rays=512)
+    trainer, data, _ = build_workload("p030_h16", device="cuda:0", small=True, n_rays=512, compact_first_grid=False)
     trainer.early_table_step = True                                      # opt-in (measured slower, see the trainer)
     model = trainer.model
     he = model.field.hash_ensemble
