@@ -198,6 +198,8 @@ int nsx_hashgrid_bwd(const float* x, int64_t B, const nsx_half* table, int F, co
  * nsx_mlp_bwd recomputes the forward (no saved activations) and produces
  *   dweights  fp32 [nsx_mlp_param_count], ACCUMULATED into (caller zeroes)
  *   da        fp32 [B][a_dim] (may be NULL), db fp16 written at b's layout [B][b_stride] cols b_off.. (may be NULL)
+ *   db_f32    fp32 [B][b_dim] contiguous (may be NULL): the values of db (rounded to fp16 first) widened to fp32 -- what
+ *             the HashEnsemble backward reads as `dout`, without a conversion launch in between
  * from dout fp16 [B][dout_stride] (AMP semantics: gradients of fp16 activations are fp16, loss-scaled by the caller). */
 int nsx_mlp_param_count(int n_hidden_mats);
 int nsx_mlp_fwd(const nsx_half* weights, int n_hidden_mats, int64_t B,
@@ -208,7 +210,7 @@ int nsx_mlp_bwd(const nsx_half* weights, int n_hidden_mats, int64_t B,
                 const float* a, int64_t a_stride, int a_dim, float a_mul, float a_add,
                 const nsx_half* b, int64_t b_stride, int b_off, int b_dim,
                 int n_out, int out_act, const nsx_half* dout, int64_t dout_stride,
-                float* dweights, float* da, nsx_half* db, void* stream);
+                float* dweights, float* da, nsx_half* db, float* db_f32, void* stream);
 int nsx_f32_to_f16(const float* src, nsx_half* dst, int64_t n, void* stream);
 
 /* ---- field glue (elementwise, fused) ------------------------------------------------------------------------
@@ -228,7 +230,7 @@ int nsx_sample_positions(const float* origins, const float* directions, const in
  * advanced-indexing launches after the visibility test: nerfacc's ray_indices[keep], t_starts[keep], t_ends[keep]
  * (inside OccGridEstimator.sampling, called at nersemble_volumetric_sampler.py:95-108), the per-field gathers that build
  * the packed RaySamples (nersemble_volumetric_sampler.py:117-134) and the compaction of the sigma-pass values that the
- * main pass reuses. */
+ * main pass reuses.  Under nsx_device_count_begin rows [*n_device, n) of every destination are written as zeros. */
 /* Pinhole ray generation (csrc/raygen.hip): what the reference's datamanager obtains from nerfstudio's RayGenerator ->
  * Cameras.generate_rays for the pixel sampler's (camera, y, x) triples (datamanager/nersemble_datamanager.py:76-81;
  * perspective cameras without distortion, dataparser/nersemble_dataparser.py:237-244).
@@ -331,6 +333,18 @@ int nsx_composite_bwd(const float* t_starts, const float* t_ends, const float* s
                       const float* acc_ray, const float* depth_ray, const float* grad_weights, const float* grad_rgb_ray,
                       const float* grad_acc_ray, const float* grad_depth_ray, float* grad_sigmas, float* grad_rgb,
                       void* stream);
+/* The same two passes with the per-sample colours (and, in the backward, their gradient) in fp16 -- what the fused
+ * mlp_head writes and reads (nersemble_nerfacto_field.py:377 casts to fp32 with `.to(directions)`, autograd casts the
+ * gradient back; both are value-preserving resp. one round-to-nearest, done here instead of in two conversion launches). */
+int nsx_composite_fwd_h(const float* t_starts, const float* t_ends, const float* sigmas, const nsx_half* rgb,
+                        const float* aux /* [S][3] or NULL */, const int64_t* packed_info, int64_t R, float background,
+                        float* clip_workspace, float* weights, float* rgb_ray, float* acc_ray, float* depth_ray,
+                        float* aux_ray, void* stream);
+int nsx_composite_bwd_h(const float* t_starts, const float* t_ends, const float* sigmas, const nsx_half* rgb,
+                        const int64_t* packed_info, int64_t R, float background, const float* clip_workspace,
+                        const float* acc_ray, const float* depth_ray, const float* grad_weights, const float* grad_rgb_ray,
+                        const float* grad_acc_ray, const float* grad_depth_ray, float* grad_sigmas, nsx_half* grad_rgb,
+                        void* stream);
 /* Fused per-sample losses of one step: distortion (models/base.py:224-249, rays < max_ray), empty and near losses
  * (models/base.py:136-202; Normal CDF with sigma = (eps/3)^2, accumulated weights per ray) in one segmented-scan pass.
  *   per_ray   [R][5] = { dist term, sum w^2 over "very near" samples, their count, sum (A - cdf)^2 over "near"
@@ -477,6 +491,13 @@ int64_t nsx_occ_scratch_bytes(int64_t n_cells);
 /* Ascending list of the occupied cells (`occupied`, capacity n_cells, int32) and their number (*n_occ, device). */
 int nsx_occ_compact(const uint8_t* binaries, int64_t n_cells, int32_t* occupied, int32_t* n_occ, void* scratch,
                     void* stream);
+
+/* The same stream compaction for a per-SAMPLE mask: ascending indices of the non-zero bytes of `mask` [n] as int64 in
+ * kept[0 .. *n_kept) (the index type torch and nsx_gather_rows use; rows beyond *n_kept are left unwritten) and their
+ * number as a device int64 -- what the visibility test of OccGridEstimator.sampling needs (nerfacc: masks.nonzero(), a
+ * host synchronisation; here the count stays on the device for nsx_device_count_begin).  Neither output needs clearing.
+ * scratch: nsx_occ_scratch_bytes(n) bytes. */
+int nsx_compact_mask(const uint8_t* mask, int64_t n, int64_t* kept, int64_t* n_kept, void* scratch, void* stream);
 
 /* Slot s of the update -> cell id, jittered world position, random timestep and its normalised time t / (T - 1).
  * warmup != 0: slot s is cell s (M = res^3).  Otherwise M = N/4 + min(N/4, n_occ) with n_occ read back by the caller

@@ -230,9 +230,13 @@ __global__ __launch_bounds__(256) void minmax_mid_kernel(const float* __restrict
     }
 }
 
+// RGBT: type of the per-sample colours (and of their gradient in the backward): float, or half_t -- the fused MLP head
+// writes / reads fp16, and the values are the same either way (fp16 -> fp32 is exact; the gradient is rounded to fp16
+// once, here or by a conversion launch)
+template <typename RGBT>
 __global__ __launch_bounds__(CW * 64) void composite_fwd_kernel(
     const float* __restrict__ t0, const float* __restrict__ t1, const float* __restrict__ sigma,
-    const float* __restrict__ rgb, const float* __restrict__ aux, const int64_t* __restrict__ packed, int64_t R,
+    const RGBT* __restrict__ rgb, const float* __restrict__ aux, const int64_t* __restrict__ packed, int64_t R,
     float bg, const float* __restrict__ clip, float* __restrict__ weights, float* __restrict__ rgb_ray,
     float* __restrict__ acc_ray, float* __restrict__ depth_ray, float* __restrict__ aux_ray) {
     const int lane = threadIdx.x & 63;
@@ -250,7 +254,7 @@ __global__ __launch_bounds__(CW * 64) void composite_fwd_kernel(
         const float w = ok ? T * (1.0f - __expf(-sdt)) : 0.f;
         if (ok) {
             weights[s + i] = w;
-            c0 += w * rgb[(s + i) * 3 + 0]; c1 += w * rgb[(s + i) * 3 + 1]; c2 += w * rgb[(s + i) * 3 + 2];
+            c0 += w * (float)rgb[(s + i) * 3 + 0]; c1 += w * (float)rgb[(s + i) * 3 + 1]; c2 += w * (float)rgb[(s + i) * 3 + 2];
             A += w;
             D += w * ((ta + tb) / 2);
             if (aux) { a0 += w * aux[(s + i) * 3 + 0]; a1 += w * aux[(s + i) * 3 + 1]; a2 += w * aux[(s + i) * 3 + 2]; }
@@ -271,12 +275,13 @@ __global__ __launch_bounds__(CW * 64) void composite_fwd_kernel(
 }
 
 // gradients of (weights, rgb_ray, acc_ray, depth_ray) w.r.t. sigma and per-sample rgb
+template <typename RGBT>
 __global__ __launch_bounds__(CW * 64) void composite_bwd_kernel(
     const float* __restrict__ t0, const float* __restrict__ t1, const float* __restrict__ sigma,
-    const float* __restrict__ rgb, const int64_t* __restrict__ packed, int64_t R, float bg,
+    const RGBT* __restrict__ rgb, const int64_t* __restrict__ packed, int64_t R, float bg,
     const float* __restrict__ clip, const float* __restrict__ acc_ray, const float* __restrict__ depth_ray,
     const float* __restrict__ g_w, const float* __restrict__ g_rgb, const float* __restrict__ g_acc,
-    const float* __restrict__ g_depth, float* __restrict__ dsigma, float* __restrict__ drgb) {
+    const float* __restrict__ g_depth, float* __restrict__ dsigma, RGBT* __restrict__ drgb) {
     const int lane = threadIdx.x & 63;
     const int64_t r = (int64_t)blockIdx.x * CW + (threadIdx.x >> 6);
     if (r >= R) return;
@@ -326,10 +331,10 @@ __global__ __launch_bounds__(CW * 64) void composite_bwd_kernel(
         const float w = T * (1.0f - __expf(-sdt));
         float g = 0.f;
         if (ok) {
-            const float q0 = rgb[(s + i) * 3 + 0], q1 = rgb[(s + i) * 3 + 1], q2 = rgb[(s + i) * 3 + 2];
+            const float q0 = (float)rgb[(s + i) * 3 + 0], q1 = (float)rgb[(s + i) * 3 + 1], q2 = (float)rgb[(s + i) * 3 + 2];
             g = (g_w ? g_w[s + i] : 0.f) + gr0 * (q0 - bg) + gr1 * (q1 - bg) + gr2 * (q2 - bg) + ga
                 + gd_scaled * ((ta + tb) / 2 - dval);
-            if (drgb) { drgb[(s + i) * 3 + 0] = w * gr0; drgb[(s + i) * 3 + 1] = w * gr1; drgb[(s + i) * 3 + 2] = w * gr2; }
+            if (drgb) { drgb[(s + i) * 3 + 0] = (RGBT)(w * gr0); drgb[(s + i) * 3 + 1] = (RGBT)(w * gr1); drgb[(s + i) * 3 + 2] = (RGBT)(w * gr2); }
         }
         const float gwv = g * w;
         const float sincl = wave_incl_scan_rev(gwv, lane);
@@ -448,6 +453,44 @@ __global__ __launch_bounds__(CW * 64) void sample_losses_bwd_kernel(
 
 using namespace nsx;
 
+template <typename RGBT>
+static int composite_fwd_entry(const float* t_starts, const float* t_ends, const float* sigmas, const RGBT* rgb,
+                               const float* aux, const int64_t* packed_info, int64_t R, float background,
+                               float* clip_workspace, float* weights, float* rgb_ray, float* acc_ray, float* depth_ray,
+                               float* aux_ray, void* stream) {
+    NSX_REQUIRE(R >= 0, "nsx_composite_fwd: negative ray count");
+    if (R == 0) return NSX_OK;
+    NSX_REQUIRE(t_starts && t_ends && sigmas && rgb && packed_info && clip_workspace && weights && rgb_ray && acc_ray && depth_ray,
+                "nsx_composite_fwd: NULL argument");
+    NSX_REQUIRE(!aux || aux_ray, "nsx_composite_fwd: aux given without aux_ray");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(minmax_init_kernel, dim3(1), dim3(1), 0, st, clip_workspace);
+    hipLaunchKernelGGL(minmax_mid_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, st, t_starts, t_ends,
+                       packed_info, R, clip_workspace);
+    hipLaunchKernelGGL(composite_fwd_kernel<RGBT>, dim3((unsigned)((R + CW - 1) / CW)), dim3(CW * 64), 0, st, t_starts,
+                       t_ends, sigmas, rgb, aux, packed_info, R, background, clip_workspace, weights, rgb_ray, acc_ray,
+                       depth_ray, aux_ray);
+    NSX_LAUNCH_CHECK("nsx_composite_fwd launch");
+    return NSX_OK;
+}
+
+template <typename RGBT>
+static int composite_bwd_entry(const float* t_starts, const float* t_ends, const float* sigmas, const RGBT* rgb,
+                               const int64_t* packed_info, int64_t R, float background, const float* clip_workspace,
+                               const float* acc_ray, const float* depth_ray, const float* grad_weights,
+                               const float* grad_rgb_ray, const float* grad_acc_ray, const float* grad_depth_ray,
+                               float* grad_sigmas, RGBT* grad_rgb, void* stream) {
+    NSX_REQUIRE(R >= 0, "nsx_composite_bwd: negative ray count");
+    if (R == 0) return NSX_OK;
+    NSX_REQUIRE(t_starts && t_ends && sigmas && rgb && packed_info && clip_workspace && acc_ray && depth_ray && grad_sigmas,
+                "nsx_composite_bwd: NULL argument");
+    hipLaunchKernelGGL(composite_bwd_kernel<RGBT>, dim3((unsigned)((R + CW - 1) / CW)), dim3(CW * 64), 0,
+                       (hipStream_t)stream, t_starts, t_ends, sigmas, rgb, packed_info, R, background, clip_workspace,
+                       acc_ray, depth_ray, grad_weights, grad_rgb_ray, grad_acc_ray, grad_depth_ray, grad_sigmas, grad_rgb);
+    NSX_LAUNCH_CHECK("nsx_composite_bwd launch");
+    return NSX_OK;
+}
+
 extern "C" {
 
 int nsx_render_weights_fwd(const float* t_starts, const float* t_ends, const float* sigmas,
@@ -515,20 +558,15 @@ int nsx_composite_fwd(const float* t_starts, const float* t_ends, const float* s
                       const float* aux /* [S][3] or NULL */, const int64_t* packed_info, int64_t R, float background,
                       float* clip_workspace /* device float[2]: receives min/max sample midpoint */, float* weights,
                       float* rgb_ray, float* acc_ray, float* depth_ray, float* aux_ray, void* stream) {
-    NSX_REQUIRE(R >= 0, "nsx_composite_fwd: negative ray count");
-    if (R == 0) return NSX_OK;
-    NSX_REQUIRE(t_starts && t_ends && sigmas && rgb && packed_info && clip_workspace && weights && rgb_ray && acc_ray && depth_ray,
-                "nsx_composite_fwd: NULL argument");
-    NSX_REQUIRE(!aux || aux_ray, "nsx_composite_fwd: aux given without aux_ray");
-    hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(minmax_init_kernel, dim3(1), dim3(1), 0, st, clip_workspace);
-    hipLaunchKernelGGL(minmax_mid_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, st, t_starts, t_ends,
-                       packed_info, R, clip_workspace);
-    hipLaunchKernelGGL(composite_fwd_kernel, dim3((unsigned)((R + CW - 1) / CW)), dim3(CW * 64), 0, st, t_starts, t_ends,
-                       sigmas, rgb, aux, packed_info, R, background, clip_workspace, weights, rgb_ray, acc_ray, depth_ray,
-                       aux_ray);
-    NSX_LAUNCH_CHECK("nsx_composite_fwd launch");
-    return NSX_OK;
+    return composite_fwd_entry<float>(t_starts, t_ends, sigmas, rgb, aux, packed_info, R, background, clip_workspace, weights,
+                                      rgb_ray, acc_ray, depth_ray, aux_ray, stream);
+}
+
+int nsx_composite_fwd_h(const float* t_starts, const float* t_ends, const float* sigmas, const nsx_half* rgb,
+                        const float* aux, const int64_t* packed_info, int64_t R, float background, float* clip_workspace,
+                        float* weights, float* rgb_ray, float* acc_ray, float* depth_ray, float* aux_ray, void* stream) {
+    return composite_fwd_entry<half_t>(t_starts, t_ends, sigmas, reinterpret_cast<const half_t*>(rgb), aux, packed_info, R,
+                                       background, clip_workspace, weights, rgb_ray, acc_ray, depth_ray, aux_ray, stream);
 }
 
 int nsx_composite_bwd(const float* t_starts, const float* t_ends, const float* sigmas, const float* rgb,
@@ -536,15 +574,19 @@ int nsx_composite_bwd(const float* t_starts, const float* t_ends, const float* s
                       const float* acc_ray, const float* depth_ray, const float* grad_weights, const float* grad_rgb_ray,
                       const float* grad_acc_ray, const float* grad_depth_ray, float* grad_sigmas, float* grad_rgb,
                       void* stream) {
-    NSX_REQUIRE(R >= 0, "nsx_composite_bwd: negative ray count");
-    if (R == 0) return NSX_OK;
-    NSX_REQUIRE(t_starts && t_ends && sigmas && rgb && packed_info && clip_workspace && acc_ray && depth_ray && grad_sigmas,
-                "nsx_composite_bwd: NULL argument");
-    hipLaunchKernelGGL(composite_bwd_kernel, dim3((unsigned)((R + CW - 1) / CW)), dim3(CW * 64), 0, (hipStream_t)stream,
-                       t_starts, t_ends, sigmas, rgb, packed_info, R, background, clip_workspace, acc_ray, depth_ray,
-                       grad_weights, grad_rgb_ray, grad_acc_ray, grad_depth_ray, grad_sigmas, grad_rgb);
-    NSX_LAUNCH_CHECK("nsx_composite_bwd launch");
-    return NSX_OK;
+    return composite_bwd_entry<float>(t_starts, t_ends, sigmas, rgb, packed_info, R, background, clip_workspace, acc_ray,
+                                      depth_ray, grad_weights, grad_rgb_ray, grad_acc_ray, grad_depth_ray, grad_sigmas,
+                                      grad_rgb, stream);
+}
+
+int nsx_composite_bwd_h(const float* t_starts, const float* t_ends, const float* sigmas, const nsx_half* rgb,
+                        const int64_t* packed_info, int64_t R, float background, const float* clip_workspace,
+                        const float* acc_ray, const float* depth_ray, const float* grad_weights, const float* grad_rgb_ray,
+                        const float* grad_acc_ray, const float* grad_depth_ray, float* grad_sigmas, nsx_half* grad_rgb,
+                        void* stream) {
+    return composite_bwd_entry<half_t>(t_starts, t_ends, sigmas, reinterpret_cast<const half_t*>(rgb), packed_info, R,
+                                       background, clip_workspace, acc_ray, depth_ray, grad_weights, grad_rgb_ray,
+                                       grad_acc_ray, grad_depth_ray, grad_sigmas, reinterpret_cast<half_t*>(grad_rgb), stream);
 }
 
 int nsx_sample_losses_fwd(const float* weights, const float* t_starts, const float* t_ends, const int64_t* packed_info,

@@ -95,26 +95,32 @@ struct GatherArgs {
     int n_arrays;
 };
 
+// Under a device-side count (nsx_device_count_begin) rows [*n_dev, n) of every destination are written as ZEROS by the
+// same launch: the caller's arrays keep the capacity, and nothing downstream ever sees uninitialised rows (this used to be
+// a torch fill in front of every call).
 __global__ __launch_bounds__(256) void gather_rows_kernel(GatherArgs A, const int64_t* __restrict__ index, int64_t n,
                                                           const int64_t* __restrict__ n_dev) {
-    int64_t unused_tiles = 0;
-    NSX_DEVICE_COUNT(n, unused_tiles, 1, n_dev);
+    int64_t n_valid = n;
+    if (n_dev) {
+        const int64_t c = *n_dev;
+        if (c < n_valid) n_valid = c < 0 ? 0 : c;
+    }
     const int a = blockIdx.y;
     const int64_t words = A.words[a];
-    const int64_t total = n * words;
+    const int64_t total = n * words, valid = n_valid * words;
     if (A.vec[a]) {
         const uint4* src = reinterpret_cast<const uint4*>(A.src[a]);
         uint4* dst = reinterpret_cast<uint4*>(A.dst[a]);
         for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
             const int64_t row = i / words, w = i - row * words;
-            dst[i] = src[index[row] * words + w];
+            dst[i] = i < valid ? src[index[row] * words + w] : make_uint4(0u, 0u, 0u, 0u);
         }
     } else {
         const uint32_t* src = reinterpret_cast<const uint32_t*>(A.src[a]);
         uint32_t* dst = reinterpret_cast<uint32_t*>(A.dst[a]);
         for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
             const int64_t row = i / words, w = i - row * words;
-            dst[i] = src[index[row] * words + w];
+            dst[i] = i < valid ? src[index[row] * words + w] : 0u;
         }
     }
 }

@@ -250,7 +250,7 @@ template <int NH>
 __global__ __launch_bounds__(MLP_WAVES * kWave) void mlp_bwd_kernel(
     const half_t* __restrict__ W, MlpIO io, int64_t B, int n_out, int out_act, const half_t* __restrict__ dout,
     int64_t dout_stride, float* __restrict__ dW, float* __restrict__ dA, half_t* __restrict__ dBsrc, int64_t n_tiles,
-    const int64_t* __restrict__ n_dev) {
+    const int64_t* __restrict__ n_dev, float* __restrict__ dB32) {
     NSX_DEVICE_COUNT(B, n_tiles, 32, n_dev);
     extern __shared__ __attribute__((aligned(16))) uint8_t smem_raw[];
     const FragPlan p = make_plan(NH, true);
@@ -367,7 +367,7 @@ __global__ __launch_bounds__(MLP_WAVES * kWave) void mlp_bwd_kernel(
         }
         wave_lds_sync();
         // ---- dX = W0^T dZ1 ----
-        if (dA || dBsrc) {
+        if (dA || dBsrc || dB32) {
             f32x16 d = zero16();
 #pragma unroll
             for (int t = 0; t < 4; ++t) d = mfma(frags[(p.w0T + t) * kWave + lane], dz[t], d);
@@ -379,6 +379,8 @@ __global__ __launch_bounds__(MLP_WAVES * kWave) void mlp_bwd_kernel(
                         if (dA) dA[b * io.a_dim + k] = d[r] * io.a_mul;
                     } else if (k - io.a_dim < io.b_dim) {
                         if (dBsrc) dBsrc[b * io.b_stride + io.b_off + (k - io.a_dim)] = (half_t)d[r];
+                        // the same fp16 value widened (the consumer of this gradient reads fp32: no conversion launch)
+                        if (dB32) dB32[b * io.b_dim + (k - io.a_dim)] = (float)(half_t)d[r];
                     }
                 }
             }
@@ -481,7 +483,7 @@ int nsx_mlp_bwd(const nsx_half* weights, int n_hidden_mats, int64_t B,
                 const float* a, int64_t a_stride, int a_dim, float a_mul, float a_add,
                 const nsx_half* b, int64_t b_stride, int b_off, int b_dim,
                 int n_out, int out_act, const nsx_half* dout, int64_t dout_stride,
-                float* dweights, float* da, nsx_half* db, void* stream) {
+                float* dweights, float* da, nsx_half* db, float* db_f32, void* stream) {
     NSX_REQUIRE(B >= 0, "nsx_mlp_bwd: negative batch");
     if (B == 0) return NSX_OK;
     NSX_REQUIRE(weights && dout && dweights, "nsx_mlp_bwd: NULL argument");
@@ -496,11 +498,11 @@ int nsx_mlp_bwd(const nsx_half* weights, int n_hidden_mats, int64_t B,
     if (n_hidden_mats == 0)
         hipLaunchKernelGGL((mlp_bwd_kernel<0>), dim3((unsigned)blocks), dim3(MLP_WAVES * kWave), bwd_smem(0), st, W, io, B,
                            n_out, out_act, reinterpret_cast<const half_t*>(dout), dout_stride, dweights, da,
-                           reinterpret_cast<half_t*>(db), n_tiles, count_for(B));
+                           reinterpret_cast<half_t*>(db), n_tiles, count_for(B), db_f32);
     else
         hipLaunchKernelGGL((mlp_bwd_kernel<1>), dim3((unsigned)blocks), dim3(MLP_WAVES * kWave), bwd_smem(1), st, W, io, B,
                            n_out, out_act, reinterpret_cast<const half_t*>(dout), dout_stride, dweights, da,
-                           reinterpret_cast<half_t*>(db), n_tiles, count_for(B));
+                           reinterpret_cast<half_t*>(db), n_tiles, count_for(B), db_f32);
     NSX_LAUNCH_CHECK("nsx_mlp_bwd launch");
     return NSX_OK;
 }

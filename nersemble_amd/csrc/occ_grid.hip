@@ -60,8 +60,9 @@ __global__ __launch_bounds__(256) void occ_block_count_kernel(const uint8_t* __r
 }
 
 // exclusive scan of the block counts in place (one block; n_blocks is a few thousand), total -> *n_occ
+template <typename CountT>
 __global__ __launch_bounds__(1024) void occ_block_scan_kernel(int32_t* __restrict__ block_counts, int n_blocks,
-                                                              int32_t* __restrict__ n_occ) {
+                                                              CountT* __restrict__ n_occ) {
     __shared__ int32_t wave_sum[16];
     __shared__ int32_t carry;
     if (threadIdx.x == 0) carry = 0;
@@ -84,12 +85,13 @@ __global__ __launch_bounds__(1024) void occ_block_scan_kernel(int32_t* __restric
         if (threadIdx.x == 1023) carry = before + s;
         __syncthreads();
     }
-    if (threadIdx.x == 0) *n_occ = carry;
+    if (threadIdx.x == 0) *n_occ = (CountT)carry;
 }
 
+template <typename IndexT>
 __global__ __launch_bounds__(256) void occ_compact_kernel(const uint8_t* __restrict__ binaries, int64_t n_cells,
                                                           const int32_t* __restrict__ block_offsets,
-                                                          int32_t* __restrict__ occupied) {
+                                                          IndexT* __restrict__ occupied) {
     __shared__ int32_t wave_cnt[4];
     const int64_t base = (int64_t)blockIdx.x * kCellsPerBlock;
     int32_t running = block_offsets[blockIdx.x];
@@ -102,7 +104,7 @@ __global__ __launch_bounds__(256) void occ_compact_kernel(const uint8_t* __restr
         __syncthreads();
         int32_t before = running;
         for (int w = 0; w < wave; ++w) before += wave_cnt[w];
-        if (set) occupied[before + __popcll(mask & ((1ull << lane) - 1ull))] = (int32_t)c;
+        if (set) occupied[before + __popcll(mask & ((1ull << lane) - 1ull))] = (IndexT)c;
         running += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
         __syncthreads();
     }
@@ -249,9 +251,23 @@ int nsx_occ_compact(const uint8_t* binaries, int64_t n_cells, int32_t* occupied,
     int32_t* counts = reinterpret_cast<int32_t*>(reinterpret_cast<uint8_t*>(scratch) + up(n_cells * 4));
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(occ_block_count_kernel, dim3(nb), dim3(256), 0, st, binaries, n_cells, counts);
-    hipLaunchKernelGGL(occ_block_scan_kernel, dim3(1), dim3(1024), 0, st, counts, nb, n_occ);
-    hipLaunchKernelGGL(occ_compact_kernel, dim3(nb), dim3(256), 0, st, binaries, n_cells, counts, occupied);
+    hipLaunchKernelGGL(occ_block_scan_kernel<int32_t>, dim3(1), dim3(1024), 0, st, counts, nb, n_occ);
+    hipLaunchKernelGGL(occ_compact_kernel<int32_t>, dim3(nb), dim3(256), 0, st, binaries, n_cells, counts, occupied);
     NSX_LAUNCH_CHECK("nsx_occ_compact launch");
+    return NSX_OK;
+}
+
+int nsx_compact_mask(const uint8_t* mask, int64_t n, int64_t* kept, int64_t* n_kept, void* scratch, void* stream) {
+    NSX_REQUIRE(mask && kept && n_kept && scratch, "nsx_compact_mask: NULL argument");
+    NSX_REQUIRE(n > 0 && n < (1ll << 31), "nsx_compact_mask: n=%lld out of range", (long long)n);
+    const int nb = n_cell_blocks(n);
+    auto up = [](int64_t v) { return (v + 15) / 16 * 16; };
+    int32_t* counts = reinterpret_cast<int32_t*>(reinterpret_cast<uint8_t*>(scratch) + up(n * 4));
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(occ_block_count_kernel, dim3(nb), dim3(256), 0, st, mask, n, counts);
+    hipLaunchKernelGGL(occ_block_scan_kernel<int64_t>, dim3(1), dim3(1024), 0, st, counts, nb, n_kept);
+    hipLaunchKernelGGL(occ_compact_kernel<int64_t>, dim3(nb), dim3(256), 0, st, mask, n, counts, kept);
+    NSX_LAUNCH_CHECK("nsx_compact_mask launch");
     return NSX_OK;
 }
 

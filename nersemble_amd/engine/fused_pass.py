@@ -100,17 +100,16 @@ class _MainPass(torch.autograd.Function):
         check(L.nsx_mlp_fwd(ptr(head_w), inp.head_hidden, S, ptr(inp.directions), inp.directions.stride(0), 3, 0.5, 0.5,
                             ptr(base_out), base_out.stride(0), 1, inp.geo_dim, 3, inp.head_act, ptr(rgb16), rgb16.stride(0),
                             st), "nsx_mlp_fwd")
-        rgb_s = rgb16.to(f32)
-        # -- compositing (weights, rgb, accumulation, expected depth, rendered deformation)
+        # -- compositing (weights, rgb, accumulation, expected depth, rendered deformation); the colours stay fp16
         w = torch.empty((S,), dtype=f32, device=dev)
         rgb = torch.empty((R, 3), dtype=f32, device=dev)
         acc = torch.empty((R, 1), dtype=f32, device=dev)
         depth = torch.empty((R, 1), dtype=f32, device=dev)
         aux = torch.empty((R, 3), dtype=f32, device=dev)
         clip = torch.empty((2,), dtype=f32, device=dev)
-        check(L.nsx_composite_fwd(ptr(inp.t0), ptr(inp.t1), ptr(density), ptr(rgb_s), ptr(offsets), ptr(inp.packed), R,
-                                  float(inp.background), ptr(clip), ptr(w), ptr(rgb), ptr(acc), ptr(depth), ptr(aux), st),
-              "nsx_composite_fwd")
+        check(L.nsx_composite_fwd_h(ptr(inp.t0), ptr(inp.t1), ptr(density), ptr(rgb16), ptr(offsets), ptr(inp.packed), R,
+                                    float(inp.background), ptr(clip), ptr(w), ptr(rgb), ptr(acc), ptr(depth), ptr(aux), st),
+              "nsx_composite_fwd_h")
         # -- every loss term, their sum and the metrics
         use_masked, thr, l_alpha, l_depth, l_dist, l_empty, l_near, eps, max_ray = inp.loss_cfg
         per_ray = torch.empty((R, 5), dtype=f32, device=dev)
@@ -123,9 +122,9 @@ class _MainPass(torch.autograd.Function):
                                    float(l_alpha), float(l_depth), float(l_dist), float(l_empty), float(l_near), ptr(out),
                                    st), "nsx_ray_losses_fwd")
         inp.aux = {"rgb": rgb, "accumulation": acc, "depth": depth, "weights": w, "deformation": aux,
-                   "offsets": offsets, "density": density, "rgb_samples": rgb_s}
+                   "offsets": offsets, "density": density, "rgb_samples": rgb16}
         ctx.inp = inp
-        ctx.save_for_backward(pos, pn, sel, feats, base_out, density, rgb_s, w, rgb, acc1, dep1, clip, out, base_w, head_w,
+        ctx.save_for_backward(pos, pn, sel, feats, base_out, density, rgb16, w, rgb, acc1, dep1, clip, out, base_w, head_w,
                               code_h, code_d, tables_f16)
         ctx.shapes = (tuple(tables_master.shape), [tuple(p.shape) for p in deform_params], code_hash.shape[0])
         ctx.sink = he.grad_sink
@@ -143,7 +142,7 @@ class _MainPass(torch.autograd.Function):
 
     @staticmethod
     def _backward(ctx, g_out):
-        (pos, pn, sel, feats, base_out, density, rgb_s, w, rgb, acc1, dep1, clip, out, base_w, head_w, code_h, code_d,
+        (pos, pn, sel, feats, base_out, density, rgb16, w, rgb, acc1, dep1, clip, out, base_w, head_w, code_h, code_d,
          tables_f16) = ctx.saved_tensors
         inp: MainPassInputs = ctx.inp
         L = lib()
@@ -172,26 +171,27 @@ class _MainPass(torch.autograd.Function):
         # -- compositing
         # every zero-initialised buffer of the backward out of one fill (functional.zeros_many)
         n_deform = int(L.nsx_deform_param_count())
-        (ds, dc, d_head, d_base_out, d_base, d_feats, gparams, gtable) = F.zeros_many(
-            [((S, 1), f32), ((S, 3), f32), ((head_w.numel(),), f32), ((S, inp.base_out_dim), f16), ((base_w.numel(),), f32),
-             ((S, feats.shape[1]), f16), ((n_deform,), f32), (tuple(code_d.shape), code_d.dtype)], dev)
-        check(L.nsx_composite_bwd(ptr(inp.t0), ptr(inp.t1), ptr(density), ptr(rgb_s), ptr(inp.packed), R,
-                                  float(inp.background), ptr(clip), ptr(acc1), ptr(dep1), ptr(gw), ptr(g_rgb), ptr(g_acc),
-                                  ptr(g_dep), ptr(ds), ptr(dc), st), "nsx_composite_bwd")
+        (ds, dc16, d_head, d_base_out, d_base, gparams, gtable) = F.zeros_many(
+            [((S, 1), f32), ((S, 3), f16), ((head_w.numel(),), f32), ((S, inp.base_out_dim), f16), ((base_w.numel(),), f32),
+             ((n_deform,), f32), (tuple(code_d.shape), code_d.dtype)], dev)
+        # the gradient of the hash features, fp32 as the hash backward reads it: every row the kernels below look at is
+        # written by mlp_base's backward (rows beyond the device-side count are never read)
+        dout = torch.empty((S, feats.shape[1]), dtype=f32, device=dev)
+        check(L.nsx_composite_bwd_h(ptr(inp.t0), ptr(inp.t1), ptr(density), ptr(rgb16), ptr(inp.packed), R,
+                                    float(inp.background), ptr(clip), ptr(acc1), ptr(dep1), ptr(gw), ptr(g_rgb), ptr(g_acc),
+                                    ptr(g_dep), ptr(ds), ptr(dc16), st), "nsx_composite_bwd_h")
         # -- mlp_head: gradient of its parameters and of the geometry features (columns 1.. of base_out)
-        dc16 = dc.to(f16)
         check(L.nsx_mlp_bwd(ptr(head_w), inp.head_hidden, S, ptr(inp.directions), inp.directions.stride(0), 3, 0.5, 0.5,
                             ptr(base_out), base_out.stride(0), 1, inp.geo_dim, 3, inp.head_act, ptr(dc16), dc16.stride(0),
-                            ptr(d_head), None, ptr(d_base_out), st), "nsx_mlp_bwd")
+                            ptr(d_head), None, ptr(d_base_out), None, st), "nsx_mlp_bwd")
         # -- trunc_exp density: column 0 of the same gradient buffer
         check(L.nsx_density_bwd(ptr(base_out), base_out.stride(0), ptr(sel), ptr(ds), S, ptr(d_base_out), st),
               "nsx_density_bwd")
         # -- mlp_base
         check(L.nsx_mlp_bwd(ptr(base_w), inp.base_hidden, S, None, 0, 0, 1.0, 0.0, ptr(feats), feats.stride(0), 0,
                             feats.shape[1], inp.base_out_dim, inp.base_act, ptr(d_base_out), d_base_out.stride(0), ptr(d_base),
-                            None, ptr(d_feats), st), "nsx_mlp_bwd")
-        # -- HashEnsemble: factored table gradient into the sink, per-sample code gradient, position gradient
-        dout = d_feats.to(f32)
+                            None, None, ptr(dout), st), "nsx_mlp_bwd")
+        # -- HashEnsemble: factored table gradient into the sink, code gradient summed per code row, position gradient
         n_rows = code_h.shape[0]
         sink = ctx.sink
         need_tab = ctx.needs_input_grad[1]

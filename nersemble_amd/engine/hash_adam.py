@@ -241,8 +241,30 @@ class NativeGradScaler:
     def scale(self, loss: torch.Tensor) -> torch.Tensor:
         return loss * self._scale if self.enabled else loss
 
+    def _cached(self, key, make):
+        """Device tensors derived from the scale, rebuilt only when ``_scale`` was written (its version counter: the
+        update kernel, ``load_state_dict`` and callers that poke the tensor all bump it)."""
+        cache = self.__dict__.setdefault("_derived", {})
+        stamp = (self._scale._version, self._scale.data_ptr())
+        hit = cache.get(key)
+        if hit is None or hit[0] != stamp:
+            hit = cache[key] = (stamp, make())
+        return hit[1]
+
     def inv_scale(self) -> torch.Tensor:
-        return self._scale.double().reciprocal().float().reshape(1)
+        """1 / scale as a device tensor of shape [1] (three small launches, taken off the step's critical path: the
+        trainer asks for it right after the scale update, beside the table optimizer's pass)."""
+        return self._cached("inv", lambda: self._scale.double().reciprocal().float().reshape(1))
+
+    def loss_grad_vector(self, n: int, index: int) -> torch.Tensor:
+        """The gradient that ``scale(v[index]).backward()`` hands to the producer of the vector ``v`` [n]: zeros with the
+        scale at ``index``.  Starting the backward from it (``torch.autograd.backward([v], [g])``) skips autograd's
+        select / mul / ones nodes -- five tiny launches in front of every backward."""
+        def make():
+            g = torch.zeros((n,), dtype=torch.float32, device=self._scale.device)
+            g[index] = self._scale if self.enabled else 1.0
+            return g
+        return self._cached(("grad", n, index), make)
 
     def unscale_and_check(self, grads: List[torch.Tensor], found_inf: torch.Tensor, inv_scale: torch.Tensor) -> None:
         if grads:
@@ -256,6 +278,8 @@ class NativeGradScaler:
         if self.enabled:
             torch._amp_update_scale_(self._scale, self._growth_tracker, total.reshape(()), self.growth_factor,
                                      self.backoff_factor, self.growth_interval)
+            if self._scale.is_cuda:
+                self.inv_scale()              # the next step's reciprocal now (queued behind the update, off its path)
         return total
 
     def get_scale(self) -> float:

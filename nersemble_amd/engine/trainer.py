@@ -252,7 +252,13 @@ class NeRSembleTrainer:
             if loss is None:
                 loss = functools.reduce(torch.add, loss_dict.values())
         early = self._arm_early_table_step() if fast is not None else None
-        self.grad_scaler.scale(loss).backward()
+        fused_vec = getattr(loss_dict, "fused", None)
+        if fused_vec is not None and loss is getattr(loss_dict, "total", None):
+            # the loss is one entry of the fused pass's output vector: start the backward at that node with the scaled
+            # one-hot gradient `scale(loss).backward()` would have produced there
+            torch.autograd.backward([fused_vec], [self.grad_scaler.loss_grad_vector(fused_vec.numel(), loss_dict.total_index)])
+        else:
+            self.grad_scaler.scale(loss).backward()
         self._all_reduce_grads()
         found_all = self._optimizer_step_all(early)
         # the reference skips the LR step when the scale dropped, i.e. when an inf/NaN was found (:199-203).  Reading

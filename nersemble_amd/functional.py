@@ -397,7 +397,7 @@ class _FusedMLPFn(torch.autograd.Function):
         check(lib().nsx_mlp_bwd(ptr(w16), n_hidden_mats, B,
                                 ptr(a_c), a_c.stride(0) if a_c is not None else 0, a_dim, a_mul, a_add,
                                 ptr(b_c), b_c.stride(0) if b_c is not None else 0, b_off, b_dim if b_c is not None else 0,
-                                n_out, out_act, ptr(dout), dout.stride(0), ptr(dW), ptr(da), ptr(db), stream()),
+                                n_out, out_act, ptr(dout), dout.stride(0), ptr(dW), ptr(da), ptr(db), None, stream()),
               "nsx_mlp_bwd")
         return dW, da, db, None, None, None, None, None, None, None, None, None
 
@@ -651,6 +651,10 @@ class _HashGridFn(torch.autograd.Function):
         return dx, dtab, None, None
 
 
+_ITEMSIZE = {torch.float32: 4, torch.float16: 2, torch.bfloat16: 2, torch.float64: 8, torch.int64: 8, torch.int32: 4,
+             torch.int16: 2, torch.uint8: 1, torch.int8: 1, torch.bool: 1}
+
+
 def zeros_many(specs, device):
     """Zero tensors of the given (shape, dtype) specs carved out of ONE buffer: one fill launch instead of len(specs)
     (the steady-state step is a chain of small dependent kernels; every launch on it costs ~5 us of device time).
@@ -660,7 +664,7 @@ def zeros_many(specs, device):
         n = 1
         for d in shape:
             n *= int(d)
-        nbytes = n * torch.empty((), dtype=dtype).element_size()
+        nbytes = n * _ITEMSIZE[dtype]
         sizes.append((total, nbytes))
         total += (nbytes + 255) // 256 * 256
     buf = torch.zeros((max(total, 1),), dtype=torch.uint8, device=device)
@@ -670,14 +674,12 @@ def zeros_many(specs, device):
 @torch.no_grad()
 def gather_rows(index: torch.Tensor, *tensors: torch.Tensor, zero_fill: bool = False):
     """[t[index] for t in tensors] (rows along dim 0) in one native launch; no autograd (values only).
-    ``zero_fill``: outputs start as zeros (under ``_lib.device_count`` only the first ``n`` rows are written)."""
+    Under ``_lib.device_count`` the kernel writes the first ``n_dev`` rows and zeros the rest itself (``zero_fill`` is
+    kept for callers' readability: no separate fill is launched)."""
     idx = index.to(torch.int64).contiguous()
     n = idx.shape[0]
     srcs = [(t.detach() if t.requires_grad else t).contiguous() for t in tensors]
-    if zero_fill and srcs:
-        outs = zeros_many([((n,) + tuple(t.shape[1:]), t.dtype) for t in srcs], srcs[0].device)
-    else:
-        outs = [torch.empty((n,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device) for t in srcs]
+    outs = [torch.empty((n,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device) for t in srcs]
     k = len(srcs)
     if n > 0 and k > 0:
         rb = []
@@ -687,6 +689,9 @@ def gather_rows(index: torch.Tensor, *tensors: torch.Tensor, zero_fill: bool = F
                 row *= int(d)
             rb.append(row)
         if any(b % 4 for b in rb) or k > _lib.NSX_MAX_GATHER:
+            if _lib.profiler.counted_capacity is not None or zero_fill:
+                raise RuntimeError("gather_rows: rows that are not multiples of 4 bytes (or more than NSX_MAX_GATHER arrays) "
+                                   "cannot be gathered under a device-side count")
             return tuple(t.index_select(0, idx) for t in srcs)
         src_arr = (C.c_void_p * k)(*[t.data_ptr() for t in srcs])
         dst_arr = (C.c_void_p * k)(*[t.data_ptr() for t in outs])

@@ -29,11 +29,28 @@ class NeRSembleVolumetricSampler(nn.Module):
             self.camera_frustum_grid = visibility_grid(camera_frustums, scene_aabb, self.occupancy_grid.resolution,
                                                        view_frustum_culling, device="cpu")
 
-    def get_sigma_fn(self, origins: Tensor, directions: Tensor, times: Optional[Tensor] = None) -> Optional[Callable]:
-        """nerfstudio VolumetricSampler.get_sigma_fn: None in eval mode / without a density_fn."""
+    # set by the model: times [R, 1] -> int32 timesteps [R] (``round(times * (T - 1))``, nersemble_instant_ngp.py:249)
+    timestep_fn: Optional[Callable] = None
+
+    def get_sigma_fn(self, origins: Tensor, directions: Tensor, times: Optional[Tensor] = None,
+                     ray_timesteps: Optional[Tensor] = None) -> Optional[Callable]:
+        """nerfstudio VolumetricSampler.get_sigma_fn: None in eval mode / without a density_fn.
+
+        ``ray_timesteps`` (native extension): the rays' integer timesteps if the bundle carries them
+        (``metadata["timesteps"]``, what ``_add_metadata_to_ray_bundle`` attaches, nersemble_datamanager.py:68-74).  The
+        reference gathers ``times[ray_indices]`` per SAMPLE and the model rounds them to timesteps per sample
+        (nersemble_instant_ngp.py:249) -- four sample-sized launches; rounding commutes with the gather, so here the
+        per-ray timesteps (from the metadata, else rounded once per ray by ``timestep_fn``) are gathered in one launch and
+        handed to the density function as ``timesteps=``."""
         if self.density_fn is None or not self.training:
             return None
         density_fn = self.density_fn
+        ray_ts = None
+        if times is not None and origins.is_cuda and getattr(density_fn, "accepts_timesteps", False):
+            if ray_timesteps is not None and ray_timesteps.numel() == origins.shape[0]:
+                ray_ts = ray_timesteps.reshape(-1).to(torch.int32).contiguous()
+            elif self.timestep_fn is not None:
+                ray_ts = self.timestep_fn(times).reshape(-1).to(torch.int32).contiguous()
 
         def sigma_fn(t_starts, t_ends, ray_indices):
             if origins.is_cuda:
@@ -42,6 +59,8 @@ class NeRSembleVolumetricSampler(nn.Module):
                 positions = origins[ray_indices] + directions[ray_indices] * (t_starts + t_ends)[:, None] / 2.0
             if times is None:
                 return density_fn(positions).squeeze(-1)
+            if ray_ts is not None:
+                return density_fn(positions, None, timesteps=F.gather_rows(ray_indices, ray_ts)[0]).squeeze(-1)
             return density_fn(positions, times[ray_indices]).squeeze(-1)
 
         return sigma_fn
@@ -59,6 +78,14 @@ class NeRSembleVolumetricSampler(nn.Module):
             return                                   # nobody wrote the grid since it was culled: the AND is idempotent
         binaries[0] = binaries[0] & grid
         self._culled_stamp = (binaries.data_ptr(), binaries._version)
+
+    def _zero_column(self, like: Tensor) -> Tensor:
+        """A [1, 1] zero of ``like``'s dtype / device (the packed samples' unused ``pixel_area`` is a broadcast view of it:
+        the reference writes zeros there, :125; one fill launch per step otherwise)."""
+        z = getattr(self, "_zero11", None)
+        if z is None or z.device != like.device or z.dtype != like.dtype:
+            z = self._zero11 = torch.zeros((1, 1), dtype=like.dtype, device=like.device)
+        return z
 
     # per-ray entries of ``ray_bundle.metadata`` that the model wants per sample (gathered in the same launch)
     sample_metadata_keys = ("image_index",)
@@ -87,7 +114,7 @@ class NeRSembleVolumetricSampler(nn.Module):
         samples = RaySamples(
             frustums=Frustums(origins=got["origins"], directions=got["directions"], starts=t0[..., None],
                               ends=t1[..., None],
-                              pixel_area=torch.zeros((ray_indices.shape[0], 1), dtype=o.dtype, device=o.device)),
+                              pixel_area=self._zero_column(o).expand(ray_indices.shape[0], 1)),
             camera_indices=got.get("camera_indices"))
         if "times" in got:
             samples.times = got["times"]
@@ -126,7 +153,8 @@ class NeRSembleVolumetricSampler(nn.Module):
         self._cull_to_camera_frusta()
         ray_indices, t0, t1 = self.occupancy_grid.sampling(
             rays_o=o, rays_d=d, t_min=per_ray_near, t_max=per_ray_far,
-            sigma_fn=self.get_sigma_fn(o, d, ray_bundle.times), render_step_size=render_step_size,
+            sigma_fn=self.get_sigma_fn(o, d, ray_bundle.times, (ray_bundle.metadata or {}).get("timesteps")),
+            render_step_size=render_step_size,
             near_plane=near_plane, far_plane=1e10 if far_plane is None else far_plane, stratified=self.training,
             cone_angle=cone_angle, alpha_thre=alpha_thre, early_stop_eps=early_stop_eps, device_counts=device_counts)
         n_dev = self.occupancy_grid.last_n_kept if device_counts else None

@@ -156,6 +156,7 @@ class NeRSembleNGPModel(BaseModel):
             occupancy_grid=self.occupancy_grid, density_fn=self.field_density_fn, scene_aabb=self.scene_box.aabb,
             camera_frustums=self.kwargs["metadata"].get("camera_frustums"),
             view_frustum_culling=cfg.view_frustum_culling if cfg.use_view_frustum_culling else None)
+        self.sampler.timestep_fn = self._timesteps
 
         self.renderer_rgb = RGBRenderer(background_color=cfg.background_color)
         self.renderer_accumulation = AccumulationRenderer()
@@ -192,7 +193,9 @@ class NeRSembleNGPModel(BaseModel):
         grid.rng_seed, grid.n_timesteps = self._occ_seed, cfg.n_timesteps
         grid.update_every_n_steps(
             step=step,
-            occ_eval_fn=lambda x: self.field_density_fn(x, grid.sample_times).reshape(-1, 1) * cfg.render_step_size,
+            # (the update's kernel hands out the integer timesteps next to the normalised times: no re-rounding)
+            occ_eval_fn=lambda x: self.field_density_fn(x, grid.sample_times, timesteps=grid.sample_timesteps
+                                                        ).reshape(-1, 1) * cfg.render_step_size,
             n=16, occ_thre=cfg.occ_thre, ema_decay=cfg.occupancy_grid_ema_decay,
             warmup_steps=cfg.occupancy_grid_warmup_steps)
 
@@ -225,31 +228,46 @@ class NeRSembleNGPModel(BaseModel):
         return (times * (self.config.n_timesteps - 1)).round().int().reshape(-1)
 
     # ---- density for sigma_fn / occupancy grid (:235-266) ------------------------------------------
-    def field_density_fn(self, positions: Tensor, times: Optional[Tensor]) -> Tensor:
+    def field_density_fn(self, positions: Tensor, times: Optional[Tensor], timesteps: Optional[Tensor] = None) -> Tensor:
+        """``timesteps`` (native extension): the samples' integer timesteps if the caller has them already (the sampler's
+        sigma_fn gathers them per ray); otherwise ``round(times * (T - 1))`` as in the reference (:249)."""
         cfg = self.config
         if cfg.disable_occupancy_grid:
             return torch.ones((positions.shape[0],), dtype=positions.dtype, device=positions.device)
         window_hash = self.sched_window_hash_encodings.value if self.sched_window_hash_encodings is not None else None
         window_deform = self.sched_window_deform.value if self.sched_window_deform is not None else None
-        time_codes = time_codes_deformation = timesteps = None
+        time_codes = time_codes_deformation = None
         if self.time_embedding is not None:
-            assert times is not None, "Times need to be provided to NeRSemble's density_fn"
-            timesteps = self._timesteps(times)
+            if timesteps is None:
+                assert times is not None, "Times need to be provided to NeRSemble's density_fn"
+                timesteps = self._timesteps(times)
+            else:
+                timesteps = timesteps.reshape(-1)
+        else:
+            timesteps = None
+        offsets = None
         if cfg.use_deformation_field:
             emb = self.time_embedding_deformation if self.time_embedding_deformation is not None else self.time_embedding
             # normalised-space offset added to the world-space position, exactly as the reference does (:257-259);
             # the kernel indexes the embedding table per sample instead of gathering [N,128] codes
             offsets = self.deformation_field.compute_offsets(positions, emb.weight, window_deform, code_index=timesteps)
-            positions = positions + offsets
-        density = self.field.density_fn(positions, times, window_hash_encodings=window_hash,
-                                        time_codes=self.time_embedding.weight if self.time_embedding is not None else None,
-                                        time_code_index=timesteps, preblended_table=self._eval_blend)
+        codes = {"time_codes": self.time_embedding.weight if self.time_embedding is not None else None,
+                 "time_code_index": timesteps, "preblended_table": self._eval_blend}
+        if positions.is_cuda:
+            # (the `positions + offsets` of :257-259 happens inside the normalisation kernel: same fp32 add)
+            density, _ = self.field._density_from_positions(positions, offsets, codes, window_hash)
+        else:
+            if offsets is not None:
+                positions = positions + offsets
+            density = self.field.density_fn(positions, times, window_hash_encodings=window_hash, **codes)
         if self.field.keep_density_intermediates:
             # same samples, same parameters, same step as the main pass: its forward values are reused there
             self._sigma_cache = {"n": positions.shape[0],
                                  "offsets": offsets if cfg.use_deformation_field else None,
                                  "features": self.field.last_hash_features, "base_out": self.field.last_base_out}
         return density
+
+    field_density_fn.accepts_timesteps = True        # (read by the sampler's sigma_fn)
 
     def warp_ray_samples(self, ray_samples: RaySamples, time_codes: Optional[Tensor] = None,
                          code_index: Optional[Tensor] = None, precomputed_offsets: Optional[Tensor] = None) -> RaySamples:
@@ -490,6 +508,9 @@ class NeRSembleNGPModel(BaseModel):
         loss_dict.total = fused[dl.LOSS_TOTAL]
         if self.global_loss_normalisers is not None:
             self._apply_global_normalisers(loss_dict, fused, num_rays)
+        else:
+            # (the trainer starts the backward at the vector itself, NativeGradScaler.loss_grad_vector)
+            loss_dict.fused, loss_dict.total_index = fused, dl.LOSS_TOTAL
         m = fused.detach()
         metrics = {"psnr": m[dl.LOSS_PSNR], "num_samples_per_batch": m[dl.LOSS_NUM_SAMPLES]}
         if alpha_map is not None:

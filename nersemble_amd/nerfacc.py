@@ -382,12 +382,12 @@ class OccGridEstimator(nn.Module):
                 # stream compaction on the device: ascending indices of the visible samples + their number
                 from ._lib import device_count
                 from .functional import gather_rows
-                keep32 = torch.zeros((n_marched,), dtype=torch.int32, device=masks.device)
-                n32 = torch.zeros((1,), dtype=torch.int32, device=masks.device)
+                # (neither output needs clearing: rows beyond the count are never read under device_count)
+                keep = torch.empty((n_marched,), dtype=torch.int64, device=masks.device)
+                n_kept = torch.empty((1,), dtype=torch.int64, device=masks.device)
                 scratch = torch.empty((int(lib().nsx_occ_scratch_bytes(n_marched)),), dtype=torch.uint8, device=masks.device)
-                check(lib().nsx_occ_compact(ptr(masks.view(torch.uint8)), n_marched, ptr(keep32), ptr(n32), ptr(scratch),
-                                            stream()), "nsx_occ_compact")
-                keep, n_kept = keep32.to(torch.int64), n32.to(torch.int64)
+                check(lib().nsx_compact_mask(ptr(masks.view(torch.uint8)), n_marched, ptr(keep), ptr(n_kept), ptr(scratch),
+                                             stream()), "nsx_compact_mask")
                 self.last_keep_index, self.last_n_marched, self.last_n_kept = keep, n_marched, n_kept
                 with device_count(n_kept, n_marched):
                     ray_indices, t_starts, t_ends = gather_rows(keep, ray_indices, t_starts, t_ends, zero_fill=True)
