@@ -78,3 +78,29 @@ def test_largest_component_edge_cases():
     d[0, 0, 0] = d[1, 1, 1] = d[1, 1, 2] = True
     got = largest_connected_component(d)
     assert got.sum() == 2 and got[1, 1, 1] and got[1, 1, 2]
+
+
+def test_connectivity_is_the_reference_six_not_twenty_six():
+    """The reference asks cc3d for ``connectivity = 6`` explicitly (util/connected_components.py:75-80; cc3d's own default
+    is 26).  Known-answer volume on which the two differ: a 3x3x3 block and a 2x2x2 block that touch only at a corner, a
+    bar that touches the big block only along an edge, and a far-away 2x2x2 block.  Face connectivity keeps them apart
+    (largest = the 27 voxels of the big block); with 18- or 26-connectivity they would merge.  The mirror, scipy's label()
+    with the face structure (the stub used when the golden was generated) and the known answer agree; the 26-structure
+    gives something else -- so the golden cannot hide a connectivity mix-up."""
+    import scipy.ndimage as ndi
+    v = np.zeros((10, 10, 10), dtype=bool)
+    v[1:4, 1:4, 1:4] = True                      # 27 voxels
+    v[4:6, 4:6, 4:6] = True                      # corner contact with the big block at (3,3,3)-(4,4,4)
+    v[4, 4, 1:3] = False
+    v[4:6, 1:3, 4:6] = True                      # edge contact: shares the edge x=3|4, z=3|4 (no common face)
+    v[7:9, 7:9, 7:9] = True                      # isolated
+    got = largest_connected_component(torch.from_numpy(v)).numpy()
+    assert got.sum() == 27 and got[1:4, 1:4, 1:4].all()
+    lab6, _ = ndi.label(v)                                                       # default structure: faces only
+    big6 = lab6 == np.argmax(np.bincount(lab6.ravel())[1:]) + 1
+    assert np.array_equal(got, big6)
+    lab26, _ = ndi.label(v, structure=np.ones((3, 3, 3)))
+    big26 = lab26 == np.argmax(np.bincount(lab26.ravel())[1:]) + 1
+    assert big26.sum() > 27 and not np.array_equal(got, big26)
+    lab18, _ = ndi.label(v, structure=ndi.generate_binary_structure(3, 2))
+    assert (lab18 == np.argmax(np.bincount(lab18.ravel())[1:]) + 1).sum() > 27
