@@ -80,7 +80,24 @@ __device__ __forceinline__ void corner_indices(const Cell& c, uint32_t res, uint
         idx[2] = (x0 ^ y1 ^ z0) & mask; idx[3] = (x1 ^ y1 ^ z0) & mask;
         idx[4] = (x0 ^ y0 ^ z1) & mask; idx[5] = (x1 ^ y0 ^ z1) & mask;
         idx[6] = (x0 ^ y1 ^ z1) & mask; idx[7] = (x1 ^ y1 ^ z1) & mask;
+    } else if (__builtin_amdgcn_ballot_w64((c.cx >= res) | (c.cy >= res) | (c.cz >= res)) == 0) {
+        // Every lane of the wave is IN CONTRACT (positions in [0, 1): cell coordinates <= res - 1).  Then each corner
+        // index is at most res + res^2 + res^3 < 2 res^3 <= 2 size, so `% size` is one conditional subtraction --
+        // min(i, i - size) on unsigned values -- and the products fit 24 bits (res <= 81 on a dense level of 2^19
+        // entries, <= 645 at the 2^28 cap: nsx_grid_geometry makes a level dense only if res^3 <= size).  The generic
+        // path below costs ~180 VALU instructions per level and lane, this one ~40; the field zeroes samples outside
+        // the scene box before they get here (nersemble_nerfacto_field.py:268-269), so it is the path that runs.
+        const uint32_t r2 = res * res;
+        const uint32_t y0 = __umul24(c.cy, res), y1 = y0 + res;
+        const uint32_t z0 = __umul24(c.cz, r2), z1 = z0 + r2;
+        const uint32_t x0 = c.cx, x1 = c.cx + 1u;
+        auto wrap = [size](uint32_t i) { const uint32_t j = i - size; return j < i ? j : i; };
+        idx[0] = wrap(x0 + y0 + z0); idx[1] = wrap(x1 + y0 + z0);
+        idx[2] = wrap(x0 + y1 + z0); idx[3] = wrap(x1 + y1 + z0);
+        idx[4] = wrap(x0 + y0 + z1); idx[5] = wrap(x1 + y0 + z1);
+        idx[6] = wrap(x0 + y1 + z1); idx[7] = wrap(x1 + y1 + z1);
     } else {
+        // out-of-contract coordinates (negative / beyond the box: uint32 wrap-around): exact idx % size for any idx
         const float inv = 1.0f / (float)size;
         const uint32_t r2 = res * res;
         const uint32_t y0 = c.cy * res, y1 = y0 + res;
@@ -221,16 +238,38 @@ __global__ __launch_bounds__(WAVES * kWave) void ens_fwd_kernel(
 template <int J>
 __device__ __forceinline__ int dpp_row_shl(int x) { return __builtin_amdgcn_update_dpp(0, x, 0x100 + J, 0xf, 0xf, true); }
 
-// sum of `val` over the run of equal keys that starts at this lane (runs live inside aligned 8-lane groups)
-template <int J, int N>
-__device__ __forceinline__ void run_merge(uint32_t key, float val, int s7, bool& alive, float& sum) {
-    if constexpr (J < N) {
-        const uint32_t nk = (uint32_t)dpp_row_shl<J>((int)key);
-        const float nv = __builtin_bit_cast(float, dpp_row_shl<J>(__builtin_bit_cast(int, val)));
-        alive = alive && (s7 + J < 8) && (nk == key);
-        if (alive) sum += nv;
-        run_merge<J + 1, N>(key, val, s7, alive, sum);
-    }
+// Sum of `val` over the run of equal keys that starts at this lane (runs live inside aligned 8-lane groups), in three
+// doubling steps: equal keys are CONTIGUOUS inside a run, so after the step with
+// distance d every lane holds the sum of its run over [lane, lane + 2d) -- a segmented suffix scan (lane i adds lane
+// i + d's partial sum iff that lane is in the same 8-group and carries the same key).  Same terms, tree order.  The
+// three `same` predicates depend on the keys only: a caller that merges several values under one key computes them once.
+struct RunLinks { bool same1, same2, same4; };
+__device__ __forceinline__ RunLinks run_links(uint32_t key, int s7) {
+    // same1: the next lane continues this lane's run; same2 / same4: the run is unbroken over the next 2 / 4 lanes.
+    // Derived from ADJACENT equality only -- keys A B A must not link lanes 0 and 2 -- by the same doubling:
+    // unbroken over [i, i+2] = same1[i] & same1[i+1]; over [i, i+4] = same2[i] & same2[i+2].  same1 is false on the last
+    // lane of an 8-group, which also stops every longer link at the group boundary.
+    // Every DPP read is a statement of its own, executed by ALL lanes: inside the right-hand side of a `&&` it would
+    // run under the narrowed EXEC mask of the left-hand side (a disabled source lane reads as 0) -- or be folded with it.
+    const uint32_t next_key = (uint32_t)dpp_row_shl<1>((int)key);
+    const int s1 = (int)((s7 + 1 < 8) & (next_key == key));
+    const int s1_next = dpp_row_shl<1>(s1);
+    const int s2 = s1 & s1_next;
+    const int s2_next2 = dpp_row_shl<2>(s2);
+    const int s4 = s2 & s2_next2;
+    RunLinks r;
+    r.same1 = s1 != 0; r.same2 = s2 != 0; r.same4 = s4 != 0;
+    return r;
+}
+__device__ __forceinline__ float run_sum(float val, const RunLinks& r) {
+    float sum = val;
+    float nv = __builtin_bit_cast(float, dpp_row_shl<1>(__builtin_bit_cast(int, sum)));
+    sum += r.same1 ? nv : 0.f;
+    nv = __builtin_bit_cast(float, dpp_row_shl<2>(__builtin_bit_cast(int, sum)));
+    sum += r.same2 ? nv : 0.f;
+    nv = __builtin_bit_cast(float, dpp_row_shl<4>(__builtin_bit_cast(int, sum)));
+    sum += r.same4 ? nv : 0.f;
+    return sum;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -371,19 +410,29 @@ __global__ __launch_bounds__(WAVES * kWave) void ens_bwd_kernel(
 #pragma unroll
                     for (int i = 0; i < NI; ++i) {
                         const int item = i * C::LPE + q;
-                        const int f = item & 1, c = (item >> 1) & 7;
-                        uint32_t ik = idx[0];
-                        float wk = w[0];
+                        const int f = item & 1;
+                        uint32_t ik;
+                        float wk;
+                        if constexpr (C::LPE == 8) {
+                            // item = 8 i + q: corner = 4 i + (q >> 1) -- a 4-way select per instruction, not an 8-way one
+                            const int c4 = q >> 1;
+                            ik = idx[4 * i]; wk = w[4 * i];
 #pragma unroll
-                        for (int cc = 1; cc < 8; ++cc) {
-                            if (c == cc) { ik = idx[cc]; wk = w[cc]; }
+                            for (int cc = 1; cc < 4; ++cc) {
+                                if (c4 == cc) { ik = idx[4 * i + cc]; wk = w[4 * i + cc]; }
+                            }
+                        } else {
+                            const int c = (item >> 1) & 7;
+                            ik = idx[0]; wk = w[0];
+#pragma unroll
+                            for (int cc = 1; cc < 8; ++cc) {
+                                if (c == cc) { ik = idx[cc]; wk = w[cc]; }
+                            }
                         }
                         float val = wk * (f ? g1 : g0);
                         const uint32_t key = ((off + ik) << 6) | (uint32_t)crow;      // entry < 2^26 (checked at launch), slot < 64
                         // merge runs of equal keys over the adjacent sample lanes (only the run head issues)
-                        float sum = val;
-                        bool alive = true;
-                        run_merge<1, 8>(key, val, s & 7, alive, sum);
+                        const float sum = run_sum(val, run_links(key, s & 7));
                         const uint32_t pk = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)key, 0x111, 0xf, 0xf, true);
                         const bool head = ((s & 7) == 0) || (pk != key);
                         if (head && sum != 0.f) {
@@ -412,10 +461,9 @@ __global__ __launch_bounds__(WAVES * kWave) void ens_bwd_kernel(
             const uint32_t pk = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)rk, 0x111, 0xf, 0xf, true);
             const bool head = ((s & 7) == 0) || (pk != rk);
             float* crow_sums = csum + (size_t)rk * H;
+            const RunLinks links = run_links(rk, s & 7);
             auto emit = [&](int h, float val) {
-                float sum = val;
-                bool alive = true;
-                run_merge<1, 8>(rk, val, s & 7, alive, sum);
+                const float sum = run_sum(val, links);
                 if (head && h < Hreal && sum != 0.f) atomicAdd(crow_sums + h, sum);
             };
             if constexpr (H == 1) {
@@ -559,9 +607,7 @@ __global__ __launch_bounds__(WAVES * kWave) void ens_scatter_kernel(
             for (int i = 0; i < 2; ++i) {
                 const float val = val2[i];
                 const uint32_t key = ((off + ik[i]) << 6) | crow;                      // entry < 2^26, slot < 64
-                float sum = val;
-                bool alive = true;
-                run_merge<1, 8>(key, val, s, alive, sum);
+                const float sum = run_sum(val, run_links(key, s));
                 const uint32_t pk = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)key, 0x111, 0xf, 0xf, true);
                 const bool head = (s == 0) || (pk != key);
                 if (head && sum != 0.f) {
