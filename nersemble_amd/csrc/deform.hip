@@ -406,16 +406,20 @@ __device__ __forceinline__ void store_tile_T(half_t* __restrict__ dst, int lane,
 // One 32-sample tile through the 6 layers + heads.  On entry stage F0 is resident in L.w[cur]; on exit the stage
 // `next_first` (the first stage of whatever follows: F0 of the next tile, or the first backward stage) is resident in
 // L.w[cur].  BWD: also keeps the ReLU masks and writes the transposed layer-input tiles for the weight gradients.
-template <bool BWD>
+// A0F: how many K-steps of the layer input are written as transposed tiles (BWD): all 11 (192 rows: positional encoding +
+// warp code), or 4 (64 rows: the positional encoding and the first 19 code columns riding along) when the weight
+// gradients of the code columns are formed through the code SLOT (deform_bwd_kernel<true>).
+template <bool BWD, int A0F = DF_TIN>
 __device__ __forceinline__ void forward_tile(const DeformArgs& A, int64_t b, int lane, Fwd& F, half_t* a_tiles,
                                              DeformLds& L, int& cur, int next_first, int next_count) {
+    constexpr int A0_HALFS = ((A0F + 1) / 2) * 32 * 32;         // transposed tiles of the layer input
     const int kb = lane >> 5;
     lds_cfloat* bias = launder_lds(L.bias);
     build_input(A, b, kb, F.pn, F.x);
     TSel tsel;
     if (BWD) {
         tsel = make_tsel(lane);
-        store_tile_T<DF_TIN>(a_tiles, lane, F.x, tsel);
+        store_tile_T<A0F>(a_tiles, lane, F.x, tsel);
     }
     f32x16 acc[4];
     // L0
@@ -423,7 +427,7 @@ __device__ __forceinline__ void forward_tile(const DeformArgs& A, int64_t b, int
     acc_init(acc, bias + 0 * DFW, kb);
     gemm_layer_lds<DF_TIN>(L.w[cur], 0, lane, F.x, acc);
     F.m1 = finish_layer<BWD>(acc, F.h);
-    if (BWD) store_tile_T<DF_TW>(a_tiles + 192 * 32 + 0 * DFW * 32, lane, F.h, tsel);
+    if (BWD) store_tile_T<DF_TW>(a_tiles + A0_HALFS + 0 * DFW * 32, lane, F.h, tsel);
     stage_flip(cur);
     // L1..L3 (the input fragments are dead once the layer's MFMAs are issued: the output overwrites them)
 #pragma unroll 1
@@ -433,7 +437,7 @@ __device__ __forceinline__ void forward_tile(const DeformArgs& A, int64_t b, int
         gemm_layer_lds<DF_TW>(L.w[cur], 0, lane, F.h, acc);
         const u32x2 m = finish_layer<BWD>(acc, F.h);
         if (l == 1) F.m2 = m; else if (l == 2) F.m3 = m; else F.m4 = m;
-        if (BWD) store_tile_T<DF_TW>(a_tiles + 192 * 32 + l * DFW * 32, lane, F.h, tsel);
+        if (BWD) store_tile_T<DF_TW>(a_tiles + A0_HALFS + l * DFW * 32, lane, F.h, tsel);
         stage_flip(cur);
     }
     // L4: cat[input, x] -- two stages, one accumulator
@@ -444,14 +448,14 @@ __device__ __forceinline__ void forward_tile(const DeformArgs& A, int64_t b, int
     stage_issue(A.frags, F5, 40, L.w[cur ^ 1]);
     gemm_layer_lds<DF_TW>(L.w[cur], 0, lane, F.h, acc);
     F.m5 = finish_layer<BWD>(acc, F.h);
-    if (BWD) store_tile_T<DF_TW>(a_tiles + 192 * 32 + 4 * DFW * 32, lane, F.h, tsel);
+    if (BWD) store_tile_T<DF_TW>(a_tiles + A0_HALFS + 4 * DFW * 32, lane, F.h, tsel);
     stage_flip(cur);
     // L5 (+ out_activation ReLU) and the heads share one stage (F5 | FH are contiguous)
     stage_issue(A.frags, next_first, next_count, L.w[cur ^ 1]);
     acc_init(acc, bias + 5 * DFW, kb);
     gemm_layer_lds<DF_TW>(L.w[cur], 0, lane, F.h, acc);
     F.m6 = finish_layer<BWD>(acc, F.h);
-    if (BWD) store_tile_T<DF_TW>(a_tiles + 192 * 32 + 5 * DFW * 32, lane, F.h, tsel);
+    if (BWD) store_tile_T<DF_TW>(a_tiles + A0_HALFS + 5 * DFW * 32, lane, F.h, tsel);
     // heads (one M-tile, rows 0..5)
     f32x16 o = zero16();
 #pragma unroll
@@ -539,13 +543,33 @@ __global__ __launch_bounds__(NW * 64, 1) void deform_fwd_kernel(DeformArgs A, fl
 // ---------------------------------------------------------------------------------------------------------
 // backward chain kernel: writes per-tile a0..a6, dZ0..dZ5, dZheads, dCode tiles
 // ---------------------------------------------------------------------------------------------------------
-// per sample-tile scratch layout (halfs): a0 [192][32] | a1..a6 [6][128][32] | dZ0..dZ5 [6][128][32] | dZh [32][32] | dC [128][32]
-// TILE_A0 = 0: the 192-column input tile comes first
-constexpr int64_t TILE_A = 192 * 32;
-constexpr int64_t TILE_DZ = TILE_A + 6 * DFW * 32;
-constexpr int64_t TILE_DZH = TILE_DZ + 6 * DFW * 32;
-constexpr int64_t TILE_DC = TILE_DZH + 32 * 32;
-constexpr int64_t TILE_HALFS = TILE_DC + DFW * 32;        // 60 416 halfs = 118 KB per 32 samples
+// per sample-tile scratch layout (halfs), the input tile first:
+//   SLOTS = false: a0 [192][32] | a1..a6 [6][128][32] | dZ0..dZ5 [6][128][32] | dZh [32][32] | dC [128][32]     118 KB
+//   SLOTS = true : a0 [ 64][32] | a1..a6               | dZ0..dZ5               | dZh                             102 KB
+// SLOTS: every sample's warp code is a row of a small table (the <= 24 time codes of a batch), so everything that touches
+// the code columns factors through the slot, exactly as the hash tables' gradient does:
+//   dW0[:, code] = sum_s dZ0[:, s] code[slot_s]^T = R0 code,   R0[n][r] = sum_{s: slot_s = r} dZ0[n][s]   (dW4 likewise)
+//   dL/dcode[r]  = W0[:, code]^T R0[:, r] + W4[:, code]^T R4[:, r]
+// The chain kernel then neither forms the per-sample code gradient (two of its 14 weight stages) nor writes it and the
+// code rows of a0 (16 of 118 KB per tile); the weight-gradient kernel accumulates R0 / R4 with a one-hot operand next to
+// the positional-encoding columns, and deform_code_expand_kernel finishes the three small products.
+template <bool SLOTS>
+struct Lay {
+    static constexpr int A0_FRAGS = SLOTS ? 4 : DF_TIN;
+    static constexpr int64_t TILE_A = (SLOTS ? 64 : 192) * 32;
+    static constexpr int64_t TILE_DZ = TILE_A + 6 * DFW * 32;
+    static constexpr int64_t TILE_DZH = TILE_DZ + 6 * DFW * 32;
+    static constexpr int64_t TILE_DC = TILE_DZH + 32 * 32;
+    static constexpr int64_t TILE_HALFS = SLOTS ? TILE_DC : TILE_DC + DFW * 32;    // 52 224 / 60 416 halfs per 32 samples
+    static constexpr int TILE_KB = (int)(TILE_HALFS * 2 / 1024);                   // 102 / 118
+    static constexpr int KB_A0 = 0, KB_A = (int)(TILE_A * 2 / 1024), KB_DZ = (int)(TILE_DZ * 2 / 1024);
+    static constexpr int KB_DZH = (int)(TILE_DZH * 2 / 1024), KB_DC = (int)(TILE_DC * 2 / 1024);
+    static_assert(TILE_HALFS * 2 % 1024 == 0 && TILE_A * 2 % 1024 == 0 && TILE_DZ * 2 % 1024 == 0 &&
+                  TILE_DZH * 2 % 1024 == 0 && TILE_DC * 2 % 1024 == 0, "scratch regions must be KB-aligned");
+};
+// R0 | R4: [2][128 neurons][128 code rows] fp32 at the head of the scratch buffer (SLOTS; zeroed by the chain kernel)
+constexpr int64_t SLOT_SUMS_FLOATS = 2 * DFW * 128;
+constexpr int64_t SLOT_SUMS_BYTES = SLOT_SUMS_FLOATS * 4;
 
 // dZ = dA * relu'(a): accumulators -> packed halfs, AND-ed with 0xFFFF per positive unit (mask layout: finish_layer)
 __device__ __forceinline__ void mask_pack(const f32x16 d[4], u32x2 mask, f16x8 dz[DF_TW]) {
@@ -563,10 +587,18 @@ __device__ __forceinline__ void mask_pack(const f32x16 d[4], u32x2 mask, f16x8 d
     }
 }
 
+template <bool SLOTS>
 __global__ __launch_bounds__(NW * 64, 1) void deform_bwd_kernel(DeformArgs A, const float* __restrict__ goff,
                                                               half_t* __restrict__ scratch, int64_t n_tiles,
                                                               float* __restrict__ gcode_samples,
-                                                              const int64_t* __restrict__ n_dev) {
+                                                              const int64_t* __restrict__ n_dev,
+                                                              float* __restrict__ slot_sums) {
+    using LY = Lay<SLOTS>;
+    constexpr int64_t TILE_HALFS = LY::TILE_HALFS, TILE_DZ = LY::TILE_DZ, TILE_DZH = LY::TILE_DZH, TILE_DC = LY::TILE_DC;
+    if (SLOTS) {      // the per-slot sums the NEXT kernel adds to: cleared here (also when no sample is left to process)
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < SLOT_SUMS_FLOATS;
+             i += (int64_t)gridDim.x * blockDim.x) slot_sums[i] = 0.f;
+    }
     NSX_DEVICE_COUNT(A.S, n_tiles, 32, n_dev);
     __shared__ __attribute__((aligned(16))) DeformLds L;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -584,7 +616,7 @@ __global__ __launch_bounds__(NW * 64, 1) void deform_bwd_kernel(DeformArgs A, co
         // waves past the last tile still walk the layers (barriers) but write into the block-private dummy tile
         half_t* T = scratch + (tile_ok ? tile : n_tiles + (int64_t)blockIdx.x * NW + wave) * TILE_HALFS;
         Fwd F;
-        forward_tile<true>(A, b, lane, F, T, L, cur, BH, 36);
+        forward_tile<true, LY::A0_FRAGS>(A, b, lane, F, T, L, cur, BH, 36);
         // ---- SE(3) backward (fp32): g = dL/dwarped ----
         float g[3] = {0.f, 0.f, 0.f};
         if (valid) { g[0] = goff[b * 3]; g[1] = goff[b * 3 + 1]; g[2] = goff[b * 3 + 2]; }
@@ -638,8 +670,10 @@ __global__ __launch_bounds__(NW * 64, 1) void deform_bwd_kernel(DeformArgs A, co
         store_tile_T<DF_TW>(T + TILE_DZ + 4 * DFW * 32, lane, dz, tsel);
         // keep dZ4 for the code gradient (dC = W4[:, code]^T dZ4 + W0[:, code]^T dZ0), formed at the end
         f16x8 dz4[DF_TW];
+        if constexpr (!SLOTS) {
 #pragma unroll
-        for (int t = 0; t < DF_TW; ++t) dz4[t] = dz[t];
+            for (int t = 0; t < DF_TW; ++t) dz4[t] = dz[t];
+        }
         stage_flip(cur);
         // dA4 = W4[:, x]^T dZ4 ; dZ3
         stage_issue(A.frags, B3, 32, L.w[cur ^ 1]);
@@ -661,12 +695,14 @@ __global__ __launch_bounds__(NW * 64, 1) void deform_bwd_kernel(DeformArgs A, co
         mask_pack(d, F.m2, dz);
         store_tile_T<DF_TW>(T + TILE_DZ + 1 * DFW * 32, lane, dz, tsel);
         stage_flip(cur);
-        stage_issue(A.frags, B0C, 32, L.w[cur ^ 1]);
+        if constexpr (SLOTS) stage_issue(A.frags, F0, 44, L.w[cur ^ 1]);       // first stage of the next tile
+        else stage_issue(A.frags, B0C, 32, L.w[cur ^ 1]);
         for (int i = 0; i < 4; ++i) d[i] = zero16();
         gemm_layer_lds<DF_TW>(L.w[cur], 0, lane, dz, d);
         mask_pack(d, F.m1, dz);
         store_tile_T<DF_TW>(T + TILE_DZ + 0 * DFW * 32, lane, dz, tsel);
         stage_flip(cur);
+        if constexpr (SLOTS) continue;          // the code gradient is formed from the per-slot sums of dZ0 / dZ4
         f32x16 dcode[4];
         for (int i = 0; i < 4; ++i) dcode[i] = zero16();
         stage_issue(A.frags, B4C, 32, L.w[cur ^ 1]);
@@ -709,31 +745,38 @@ __global__ __launch_bounds__(NW * 64, 1) void deform_bwd_kernel(DeformArgs A, co
 //   type 2: dW3 = dZ3 a3^T, db3 | dW4[:, 173:] = dZ4 a4^T            stage = dZ3 a3 dZ4 a4         (32 KB)
 //   type 3: dW5 = dZ5 a5^T, db5 | heads: dZh a6^T, dbr, dbv          stage = dZ5 a5 dZh a6         (26 KB)
 //   type 4: code table: onehot(slot) dC^T                            stage = dC + the 32 slots     ( 9 KB)
+// SLOTS (Lay<true>): type 0 reads dZ0, dZ4, the 64-row a0 tile and the tile's 32 slots (21 KB) and accumulates, next to the
+// positional-encoding columns of dW0 / dW4, the per-slot sums R0 / R4 = dZ onehot(slot)^T; type 4 does not exist.
 // Bias gradients are the row sums of dZ: the same X fragments against an all-ones operand.
 constexpr int WG_K = 4;                         // LDS-DMA copies per wave and stage
 constexpr int WG_PIECES = NW * WG_K;            // 32 one-KB pieces per stage
 constexpr int WG_NS = 4;                        // ring depth
 constexpr int WG_TYPES = 5;
-constexpr int TILE_KB = (int)(TILE_HALFS * 2 / 1024);                    // 118
-constexpr int KB_A0 = 0, KB_A = (int)(TILE_A * 2 / 1024), KB_DZ = (int)(TILE_DZ * 2 / 1024);
-constexpr int KB_DZH = (int)(TILE_DZH * 2 / 1024), KB_DC = (int)(TILE_DC * 2 / 1024);
-static_assert(TILE_HALFS * 2 % 1024 == 0 && TILE_A * 2 % 1024 == 0 && TILE_DZ * 2 % 1024 == 0 &&
-              TILE_DZH * 2 % 1024 == 0 && TILE_DC * 2 % 1024 == 0, "scratch regions must be KB-aligned");
+constexpr int WG_SLOT_KB = 20;                  // SLOTS, type 0: where the tile's slots land inside the stage
 
 // piece q of a stage of block type `type`: source KB offset inside the scratch tile (-1: the slot piece); pieces past
 // the end repeat earlier ones (same bytes to the same place) so that every wave issues exactly WG_K copies per stage
+template <bool SLOTS>
 __device__ __forceinline__ int wg_piece_src(int type, int q, int& dst_kb, bool with_slots) {
+    using LY = Lay<SLOTS>;
+    constexpr int KB_A0 = LY::KB_A0, KB_A = LY::KB_A, KB_DZ = LY::KB_DZ, KB_DZH = LY::KB_DZH, KB_DC = LY::KB_DC;
     auto a_kb = [](int l) { return l == 0 ? KB_A0 : KB_A + 8 * (l - 1); };   // input of layer l (l = 6: input of the heads)
     auto dz_kb = [](int l) { return KB_DZ + 8 * l; };
     int total, src = 0;
     switch (type) {
-        case 0: total = 28; break;
+        case 0: total = SLOTS ? 21 : 28; break;
         case 1: case 2: total = 32; break;
         case 3: total = 26; break;
         default: total = with_slots ? 9 : 8; break;
     }
     q = q % total;
     dst_kb = q;
+    if (SLOTS && type == 0) {
+        if (q < 8) return dz_kb(0) + q;
+        if (q < 16) return dz_kb(4) + q - 8;
+        if (q < 20) return a_kb(0) + q - 16;
+        return -1;                                                          // q == 20 == WG_SLOT_KB: the slots
+    }
     switch (type) {
         case 0: src = q < 8 ? dz_kb(0) + q : (q < 16 ? dz_kb(4) + q - 8 : a_kb(0) + q - 16); break;
         case 1: src = q < 8 ? dz_kb(1) + q : (q < 16 ? a_kb(1) + q - 8 : (q < 24 ? dz_kb(2) + q - 16 : a_kb(2) + q - 24)); break;
@@ -752,11 +795,12 @@ struct WgRole {            // what one wave of a block accumulates
     int job;               // output mapping, see wg_store
 };
 
+template <bool SLOTS>
 __device__ __forceinline__ WgRole wg_role(int type, int wave, int n_code_rows) {
     WgRole r{0, 0, 0, 0, wave & 3, -1};
     const int hi = wave >> 2;
     switch (type) {
-        case 0: r.x_kb = 8 * hi + 2 * (wave & 3); r.y_kb = 16; r.n_y = 6; r.bias = 1; r.job = hi ? 4 : 0; break;
+        case 0: r.x_kb = 8 * hi + 2 * (wave & 3); r.y_kb = 16; r.n_y = SLOTS ? 2 : 6; r.bias = 1; r.job = hi ? 4 : 0; break;
         case 1: r.x_kb = 16 * hi + 2 * (wave & 3); r.y_kb = 8 + 16 * hi; r.n_y = 4; r.bias = 1; r.job = hi ? 2 : 1; break;
         case 2: r.x_kb = 16 * hi + 2 * (wave & 3); r.y_kb = 8 + 16 * hi; r.n_y = 4; r.bias = hi ? 0 : 1; r.job = hi ? 5 : 3; break;
         case 3:
@@ -771,6 +815,7 @@ __device__ __forceinline__ WgRole wg_role(int type, int wave, int n_code_rows) {
 }
 
 // accumulator element r of lane (i, kb) of output tile (x tile mt, y tile nt): X-side row acc_row(r, kb), Y-side column i
+template <bool SLOTS>
 __device__ __forceinline__ void wg_store(const f32x16& acc, int job, int mt, int nt, bool is_bias, int lane,
                                          float* __restrict__ gp, float* __restrict__ gcode, int n_code_rows) {
     const int i = lane & 31, kb = lane >> 5;
@@ -779,7 +824,8 @@ __device__ __forceinline__ void wg_store(const f32x16& acc, int job, int mt, int
     const int64_t b_off[7] = {P_B0, P_B1, P_B2, P_B3, P_B4, -1, P_B5};
     const int ldc[7] = {DF_IN, DFW, DFW, DFW, DF_W4, DF_W4, DFW};
     const bool y_natural = (job == 0 || job == 4);          // a0 tiles are in natural column order
-    const int n_cols = y_natural ? DF_IN : DFW;
+    // (SLOTS: the a0 tile's columns beyond the positional encoding are code columns -- those come from the slot sums)
+    const int n_cols = y_natural ? (SLOTS ? DF_PE : DF_IN) : DFW;
     const int col = y_natural ? 32 * nt + i : tile_neuron_chain(nt, i);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -803,11 +849,29 @@ __device__ __forceinline__ void wg_store(const f32x16& acc, int job, int mt, int
     }
 }
 
+// accumulator of (X tile mt of dZ0 | dZ4) x (one-hot tile nt): R[which][neuron][code row] += sum over the tile's samples
+__device__ __forceinline__ void wg_store_slot_sums(const f32x16& acc, int which, int mt, int nt, int lane,
+                                                   float* __restrict__ slot_sums, int n_code_rows) {
+    const int i = lane & 31, kb = lane >> 5;
+    const int row = 32 * nt + i;                            // code row (Y side, natural order)
+    if (row >= n_code_rows) return;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float v = acc[r];
+        if (v == 0.f) continue;
+        const int neuron = tile_neuron_chain(mt, acc_row(r, kb));
+        atomicAdd(&slot_sums[((int64_t)which * DFW + neuron) * 128 + row], v);
+    }
+}
+
+template <bool SLOTS>
 __global__ __launch_bounds__(NW * 64, 1) void deform_wgrad_kernel(const half_t* __restrict__ scratch, int64_t n_tiles,
                                                                  const int32_t* __restrict__ slot, int64_t S,
                                                                  float* __restrict__ grad_params,
                                                                  float* __restrict__ grad_code, int n_code_rows,
-                                                                 const int64_t* __restrict__ n_dev) {
+                                                                 const int64_t* __restrict__ n_dev,
+                                                                 float* __restrict__ slot_sums) {
+    constexpr int TILE_KB = Lay<SLOTS>::TILE_KB;
     NSX_DEVICE_COUNT(S, n_tiles, 32, n_dev);
     __shared__ __attribute__((aligned(16))) char ring[WG_NS * WG_PIECES * 1024];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -816,12 +880,13 @@ __global__ __launch_bounds__(NW * 64, 1) void deform_wgrad_kernel(const half_t* 
     const int64_t per = (n_tiles + gridDim.y - 1) / gridDim.y;
     const int64_t t_begin = (int64_t)blockIdx.y * per, t_end = (t_begin + per < n_tiles) ? t_begin + per : n_tiles;
     if (t_begin >= t_end) return;                            // whole block
-    const bool with_slots = (type == 4);
-    const WgRole role = wg_role(type, wave, n_code_rows);
+    const bool with_slots = SLOTS ? (type == 0) : (type == 4);
+    const WgRole role = wg_role<SLOTS>(type, wave, n_code_rows);
+    const int n_onehot = (SLOTS && type == 0) ? (n_code_rows + 31) / 32 : 0;      // one-hot Y tiles (<= 4: acc[2..5])
     // this wave's WG_K copies per stage
     int src_kb[WG_K], dst_kb[WG_K];
 #pragma unroll
-    for (int k = 0; k < WG_K; ++k) src_kb[k] = wg_piece_src(type, wave + NW * k, dst_kb[k], with_slots);
+    for (int k = 0; k < WG_K; ++k) src_kb[k] = wg_piece_src<SLOTS>(type, wave + NW * k, dst_kb[k], with_slots);
     const char* sbytes = reinterpret_cast<const char*>(scratch);
     auto issue = [&](int64_t tile, int ring_slot) {
         const int64_t tc = tile < n_tiles ? tile : n_tiles - 1;      // past the end: harmless re-copy (uniform vmcnt)
@@ -883,6 +948,33 @@ __global__ __launch_bounds__(NW * 64, 1) void deform_wgrad_kernel(const half_t* 
                 acc[6] = mfma(x0, ones, acc[6]);
                 acc[6] = mfma(x1, ones, acc[6]);
             }
+            if constexpr (SLOTS) {
+                if (n_onehot > 0) {
+                    // per-slot sums of this wave's dZ rows: Y = onehot(slot) built from the tile's 32 slots in the stage
+                    const int32_t* sl = reinterpret_cast<const int32_t*>(stage + WG_SLOT_KB * 1024);
+                    int32_t s0v[8], s1v[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int s0 = acc_row(j, kb), s1 = acc_row(8 + j, kb);
+                        s0v[j] = (t * 32 + s0 < S) ? sl[s0] : -1;
+                        s1v[j] = (t * 32 + s1 < S) ? sl[s1] : -1;
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        if (q < n_onehot) {
+                            const int row = 32 * q + i;
+                            f16x8 y0, y1;
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) {
+                                y0[j] = (s0v[j] == row) ? (half_t)1.f : (half_t)0.f;
+                                y1[j] = (s1v[j] == row) ? (half_t)1.f : (half_t)0.f;
+                            }
+                            acc[2 + q] = mfma(x0, y0, acc[2 + q]);
+                            acc[2 + q] = mfma(x1, y1, acc[2 + q]);
+                        }
+                    }
+                }
+            }
         }
         cur = (cur + 1) % WG_NS;
     }
@@ -890,8 +982,62 @@ __global__ __launch_bounds__(NW * 64, 1) void deform_wgrad_kernel(const half_t* 
     if (role.n_y == 0) return;
 #pragma unroll
     for (int q = 0; q < 6; ++q)
-        if (q < role.n_y) wg_store(acc[q], role.job, role.x_tile, q, false, lane, grad_params, grad_code, n_code_rows);
-    if (role.bias) wg_store(acc[6], role.job, role.x_tile, 0, true, lane, grad_params, grad_code, n_code_rows);
+        if (q < role.n_y) wg_store<SLOTS>(acc[q], role.job, role.x_tile, q, false, lane, grad_params, grad_code, n_code_rows);
+    if (role.bias) wg_store<SLOTS>(acc[6], role.job, role.x_tile, 0, true, lane, grad_params, grad_code, n_code_rows);
+    if constexpr (SLOTS) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (q < n_onehot) wg_store_slot_sums(acc[2 + q], role.job == 4 ? 1 : 0, role.x_tile, q, lane, slot_sums, n_code_rows);
+    }
+}
+
+// SLOTS, last step: the three small products that finish the code columns and the code-table gradient from the per-slot
+// sums R0 / R4 ([128 neurons][128 code rows] fp32 each):
+//   blocks [0, 128):        neuron n:  dW0[n][45 + c] += sum_r R0[n][r] code16[r][c],  dW4[n][45 + c] += sum_r R4[n][r] code16[r][c]
+//   blocks [128, 128 + R):  code row r: dcode[r][c]   += sum_n W0c[n][c] R0[n][r] + W4c[n][c] R4[n][r]
+// code16 = the fp16-rounded code the forward multiplied with (build_input), W0c / W4c = the fp16 code columns of W0 / W4
+// as packed for the chain kernel (fragment groups B0C / B4C).  ~6 M multiply-adds: microseconds.
+__device__ __forceinline__ float packed_code_weight(const half_t* __restrict__ frags16, int group, int n, int c) {
+    // inverse of pack_source for the groups B0C / B4C: element (o = neuron n, code column c = 32 mt + i)
+    const int mt = c >> 5, i = c & 31;
+    const int n32 = n & 31, kb = (n32 >> 2) & 1, r = (n & 3) + 4 * (n32 >> 3);
+    const int t = 2 * (n >> 5) + (r >> 3), j = r & 7;
+    const int fi = group + mt * DF_TW + t;
+    return (float)frags16[((int64_t)fi * 64 + kb * 32 + i) * 8 + j];
+}
+
+__global__ __launch_bounds__(256) void deform_code_expand_kernel(const float* __restrict__ slot_sums,
+                                                                 const float* __restrict__ code, int64_t code_stride,
+                                                                 int n_code_rows, const f16x8* __restrict__ frags,
+                                                                 float* __restrict__ grad_params,
+                                                                 float* __restrict__ grad_code) {
+    __shared__ float red[256];
+    const float* R0 = slot_sums;
+    const float* R4 = slot_sums + (int64_t)DFW * 128;
+    const int c = threadIdx.x & 127, half = threadIdx.x >> 7;
+    if (blockIdx.x < DFW) {
+        const int n = blockIdx.x;
+        const float* R = half ? R4 : R0;
+        float acc = 0.f;
+        for (int r = 0; r < n_code_rows; ++r) {
+            const float v = R[(int64_t)n * 128 + r];
+            if (v != 0.f) acc = __fmaf_rn(v, (float)(half_t)code[(int64_t)r * code_stride + c], acc);
+        }
+        float* dst = grad_params + (half ? (int64_t)P_W4 + (int64_t)n * DF_W4 : (int64_t)P_W0 + (int64_t)n * DF_IN) + DF_PE + c;
+        *dst += acc;                                        // (the weight-gradient kernel left these columns alone)
+    } else {
+        const int r = blockIdx.x - DFW;
+        if (!grad_code) return;
+        const half_t* f16 = reinterpret_cast<const half_t*>(frags);
+        float acc = 0.f;
+        for (int n = 64 * half; n < 64 * half + 64; ++n) {
+            acc = __fmaf_rn(packed_code_weight(f16, B0C, n, c), R0[(int64_t)n * 128 + r], acc);
+            acc = __fmaf_rn(packed_code_weight(f16, B4C, n, c), R4[(int64_t)n * 128 + r], acc);
+        }
+        red[threadIdx.x] = acc;
+        __syncthreads();
+        if (half == 0) grad_code[(int64_t)r * DF_CODE + c] += red[c] + red[128 + c];
+    }
 }
 
 static void fill_args(DeformArgs& A, const float* pos, int64_t S, const float* aabb, const float* code,
@@ -917,7 +1063,10 @@ extern "C" {
 int nsx_deform_param_count(void) { return P_TOTAL; }
 int64_t nsx_deform_pack_bytes(void) { return (int64_t)N_FRAGS * 64 * 16 + (int64_t)N_BIAS * 4; }
 // + one private dummy tile per possible wave of the launch (tail waves of the lock-stepped blocks write there)
-int64_t nsx_deform_scratch_bytes(int64_t S) { return (((S + 31) / 32) + (int64_t)num_cus() * NW) * TILE_HALFS * 2; }
+// (the larger of the two tile layouts + the per-slot sums at the head of the buffer)
+int64_t nsx_deform_scratch_bytes(int64_t S) {
+    return SLOT_SUMS_BYTES + (((S + 31) / 32) + (int64_t)num_cus() * NW) * Lay<false>::TILE_HALFS * 2;
+}
 
 int nsx_deform_pack(const float* params, void* packed, void* stream) {
     NSX_REQUIRE(params && packed, "nsx_deform_pack: NULL argument");
@@ -981,19 +1130,36 @@ int nsx_deform_bwd(const void* packed, const float* positions, int64_t S, const 
     int64_t blocks = (n_tiles + NW - 1) / NW;
     if (blocks > num_cus()) blocks = num_cus();
     hipStream_t st = (hipStream_t)stream;
-    half_t* sc = reinterpret_cast<half_t*>(scratch);
-    hipLaunchKernelGGL(deform_bwd_kernel, dim3((unsigned)blocks), dim3(NW * 64), 0, st, A, grad_offsets, sc, n_tiles,
-                       grad_code_samples, count_for(S));
+    float* slot_sums = reinterpret_cast<float*>(scratch);
+    half_t* sc = reinterpret_cast<half_t*>(reinterpret_cast<uint8_t*>(scratch) + SLOT_SUMS_BYTES);
+    // the warp codes are rows of a small table and nobody asks for the per-sample code gradient: everything that touches
+    // the code columns is formed through the slot (Lay<true>)
+    const bool slots = code_slot && grad_code_table && !grad_code_samples;
+    if (slots)
+        hipLaunchKernelGGL(deform_bwd_kernel<true>, dim3((unsigned)blocks), dim3(NW * 64), 0, st, A, grad_offsets, sc,
+                           n_tiles, grad_code_samples, count_for(S), slot_sums);
+    else
+        hipLaunchKernelGGL(deform_bwd_kernel<false>, dim3((unsigned)blocks), dim3(NW * 64), 0, st, A, grad_offsets, sc,
+                           n_tiles, grad_code_samples, count_for(S), slot_sums);
     NSX_LAUNCH_CHECK("nsx_deform_bwd chain launch");
     // weight / bias / code-table gradients
-    const int n_types = grad_code_table ? WG_TYPES : WG_TYPES - 1;
+    const int n_types = (grad_code_table && !slots) ? WG_TYPES : WG_TYPES - 1;
     int chunks = num_cus() / n_types;                 // one block per CU
     const int64_t max_chunks = (n_tiles + 3) / 4;     // >= 4 sample tiles per block
     if (chunks > max_chunks) chunks = (int)max_chunks;
     if (chunks < 1) chunks = 1;
-    hipLaunchKernelGGL(deform_wgrad_kernel, dim3(n_types, chunks), dim3(NW * 64), 0, st, sc, n_tiles, code_slot, S,
-                       grad_params, grad_code_table, grad_code_table ? n_code_rows : 0, count_for(S));
-    NSX_LAUNCH_CHECK("nsx_deform_bwd wgrad launch");
+    if (slots) {
+        hipLaunchKernelGGL(deform_wgrad_kernel<true>, dim3(n_types, chunks), dim3(NW * 64), 0, st, sc, n_tiles, code_slot, S,
+                           grad_params, grad_code_table, n_code_rows, count_for(S), slot_sums);
+        NSX_LAUNCH_CHECK("nsx_deform_bwd wgrad launch");
+        hipLaunchKernelGGL(deform_code_expand_kernel, dim3(DFW + n_code_rows), dim3(256), 0, st, slot_sums, code, code_stride,
+                           n_code_rows, A.frags, grad_params, grad_code_table);
+        NSX_LAUNCH_CHECK("nsx_deform_bwd code expand launch");
+    } else {
+        hipLaunchKernelGGL(deform_wgrad_kernel<false>, dim3(n_types, chunks), dim3(NW * 64), 0, st, sc, n_tiles, code_slot, S,
+                           grad_params, grad_code_table, grad_code_table ? n_code_rows : 0, count_for(S), slot_sums);
+        NSX_LAUNCH_CHECK("nsx_deform_bwd wgrad launch");
+    }
     return NSX_OK;
 }
 

@@ -85,7 +85,10 @@ def test_deform_backward(S, T, cuda):
     # (oracle/deform.py round_grads; the same chain without the roundings is pinned to the reference's autograd)
     flat = df.flat_params().detach().double().requires_grad_(True)
     tab64 = table.double().requires_grad_(True)
-    off = od.compute_offsets(pos, tab64[slot], flat, AABB, 2.75, half=True, dtype=torch.float64, round_grads=True)
+    # (code TABLE path: everything that touches the code columns is formed through the slot from fp32 per-slot sums of
+    # dZ0 / dZ4 -- the gradient that reaches the codes is never rounded per sample: round_code_grad=False)
+    off = od.compute_offsets(pos, tab64[slot], flat, AABB, 2.75, half=True, dtype=torch.float64, round_grads=True,
+                             round_code_grad=False)
     off.backward(goff.double())
     dfc = df.to(cuda)
     tabc = table.to(cuda).requires_grad_(True)
