@@ -2,7 +2,7 @@
 # optionally (PROFILES=1) rocprofv3 kernel statistics + the two HBM counter passes and (DP=1) the 2-rank control flow
 # (gloo, both ranks on cuda:0).  Results: gpurun_out/final/ and gpurun_out/prof_<tag>/
 set -u
-tag=${1:-r02}
+tag=${1:-r03}
 out=gpurun_out/final; mkdir -p $out
 python -c "import __graft_entry__ as g; g.smoke()" > $out/smoke.txt 2>&1
 if [ "${DP:-0}" = 1 ]; then
