@@ -305,7 +305,10 @@ int nsx_pack_info(const int64_t* counts, int64_t R, int64_t* packed_info, int64_
     NSX_REQUIRE(R >= 0, "nsx_pack_info: negative ray count");
     NSX_REQUIRE(total, "nsx_pack_info: NULL total");
     NSX_REQUIRE(R == 0 || (counts && packed_info), "nsx_pack_info: NULL argument");
-    hipLaunchKernelGGL(pack_info_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, counts, R, packed_info, total);
+    // ONE wave: the scan of 4096 counts is 64 wave-scans either way, and a single wave finds a free slot on a CU that the
+    // table optimizer's pass has filled (the counting pass of the next step runs beside it) -- a 1024-thread block needs 16
+    // free slots on one CU and waited for them: 0.6 ms on average, up to 1.4 ms, for 10 us of work (profiles/r02, r03)
+    hipLaunchKernelGGL(pack_info_kernel, dim3(1), dim3(kWave), 0, (hipStream_t)stream, counts, R, packed_info, total);
     NSX_LAUNCH_CHECK("nsx_pack_info launch");
     return NSX_OK;
 }
