@@ -397,9 +397,12 @@ class NeRSembleNGPModel(BaseModel):
         if not (self.fuse_main_pass and self.training and torch.is_grad_enabled() and ray_bundle.origins.is_cuda
                 and cfg.use_hash_ensemble and cfg.use_deformation_field and self.time_embedding is not None
                 and self.deformation_field.native_supported() and cfg.background_color in ("white", "black")
-                and not cfg.disable_occupancy_grid and "depth_maps" in batch and cfg.lambda_dist_loss > 0
+                and "depth_maps" in batch and cfg.lambda_dist_loss >= 0
                 and cfg.lambda_near_loss > 0 and cfg.lambda_empty_loss > 0 and len(ray_bundle) <= cfg.dist_loss_max_rays):
             return None
+        # (round 3) also the dense configuration of BASELINE.json configs[3] -- `--disable_occupancy_grid --lambda_dist_loss 0`:
+        # the sampler's sigma_fn answers ones there (nersemble_instant_ngp.py:239-240: nothing to reuse, every marched sample is
+        # kept), the distortion term is absent (models/base.py:224-226: the kernel's lambda is 0, an exact zero in the sum)
         alpha_map = batch.get("alpha_map")
         num_rays = len(ray_bundle)
         if alpha_map is not None and not (alpha_map.dtype == torch.uint8 and alpha_map.numel() == num_rays):
@@ -415,7 +418,8 @@ class NeRSembleNGPModel(BaseModel):
         # the kept-sample count can stay on the device when the per-sample code slot comes with the batch (it is gathered
         # with the other per-ray fields) and the sigma_fn pass's forward values are reused
         on_device = (self.device_sample_counts and self.reuse_sigma_pass and "image_index" in md
-                     and "_image_timesteps" in md and (cfg.alpha_thre > 0 or cfg.early_stop_eps > 0))
+                     and "_image_timesteps" in md and (cfg.alpha_thre > 0 or cfg.early_stop_eps > 0)
+                     and not cfg.disable_occupancy_grid)
         try:
             with torch.no_grad():
                 ray_samples, ray_indices = self.sampler(
@@ -426,10 +430,9 @@ class NeRSembleNGPModel(BaseModel):
             self.field.keep_density_intermediates = False
         n_dev = self.occupancy_grid.last_n_kept if on_device else None
         S = ray_indices.shape[0]
-        max_chunk = cfg.max_n_samples_per_batch
-        if max_chunk != -1 and S > max_chunk:
-            self._sigma_cache = None
-            return None                                  # several chunks: the modular path walks them
+        # `max_n_samples_per_batch` (train_nersemble.py: 2^20) bounds the reference's activation memory by walking the field
+        # in chunks; the result does not depend on it (chunked == un-chunked bit for bit, tests/test_full_size_gpu.py), and
+        # the kernels here take any S (3.3 KB of scratch per sample on a 288 GB device): the fused pass runs un-chunked
         if "image_index" in md and "_image_timesteps" in md:
             uniq = md["_image_timesteps"].reshape(-1).int()
             slot = (ray_samples.metadata or {}).get("image_index")
@@ -500,7 +503,8 @@ class NeRSembleNGPModel(BaseModel):
         loss_dict["rgb_loss"] = fused[dl.LOSS_RGB]
         if alpha_map is not None and cfg.lambda_alpha_loss is not None and cfg.lambda_alpha_loss > 0:
             loss_dict["alpha_loss"] = fused[dl.LOSS_ALPHA]
-        loss_dict["dist_loss"] = fused[dl.LOSS_DIST]
+        if cfg.lambda_dist_loss > 0:
+            loss_dict["dist_loss"] = fused[dl.LOSS_DIST]
         loss_dict["empty_loss"] = fused[dl.LOSS_EMPTY]
         loss_dict["near_loss"] = fused[dl.LOSS_NEAR]
         if cfg.lambda_depth_loss > 0:

@@ -687,3 +687,49 @@ def test_compact_phase_ends_when_the_window_opens(cuda):
     b = t_f.model.field.hash_ensemble
     a.wait_tables(), b.wait_tables()
     assert (a.tables.detach()[:, :, 1] != init[:, :, 1]).any()               # the second grid trains once it is on
+
+
+def test_fused_pass_takes_the_dense_configuration(cuda):
+    """BASELINE.json configs[3] (`--disable_occupancy_grid --lambda_dist_loss 0`, train_nersemble.py) on the fused main pass:
+    the sampler's sigma_fn answers ones (every marched sample is kept, nothing to reuse), the distortion term is absent
+    from the loss dict, and the pass runs UN-CHUNKED although the step has several `max_n_samples_per_batch` chunks --
+    against the modular path, which walks the chunks with the reference's operator structure: same loss terms, same
+    gradients (different summation order only)."""
+    from nersemble_amd.workloads import build_workload
+    res = {}
+    for fused in (False, True):
+        torch.manual_seed(11)
+        trainer, data, _ = build_workload("p097_dense", device="cuda:0", small=True, n_rays=384)
+        model = trainer.model
+        model.fuse_main_pass = fused
+        model.config.max_n_samples_per_batch = 1 << 14                   # several chunks per step on the modular path
+        model.field.max_n_samples_per_batch = 1 << 14
+        if model.deformation_field is not None:
+            model.deformation_field.max_n_samples_per_batch = 1 << 14
+        calls = []
+        orig = model.fused_train_forward
+
+        def counted(*a, _orig=orig, _calls=calls, **k):
+            r = _orig(*a, **k)
+            _calls.append(r is not None)
+            return r
+
+        model.fused_train_forward = counted
+        torch.manual_seed(70)
+        loss, loss_dict, metrics = trainer.train_iteration(0, *data.next_train(0))
+        assert calls == [fused]
+        assert int(metrics["num_samples_per_batch"]) > 3 * (1 << 14)     # really more than one chunk
+        assert "dist_loss" not in loss_dict                              # lambda_dist_loss = 0: the term is absent
+        grads = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+        res[fused] = (loss.item(), {k: v.item() for k, v in loss_dict.items()}, grads,
+                      int(metrics["num_samples_per_batch"]))
+        trainer.flush_scheduler_step()
+    (l_m, t_m, g_m, n_m), (l_f, t_f, g_f, n_f) = res[False], res[True]
+    assert n_m == n_f and set(t_m) == set(t_f)
+    assert np.isclose(l_m, l_f, rtol=1e-5), (l_m, l_f)
+    for k in t_m:
+        assert np.isclose(t_m[k], t_f[k], rtol=1e-4, atol=1e-9), (k, t_m[k], t_f[k])
+    assert set(g_m) == set(g_f)
+    for name in g_m:
+        sc = g_m[name].abs().max().item()
+        assert (g_m[name] - g_f[name]).abs().max().item() <= 2e-3 * sc + 1e-12, name
