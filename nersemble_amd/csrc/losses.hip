@@ -12,7 +12,7 @@
 
 namespace nsx {
 
-constexpr int NL_THREADS = 1024;
+constexpr int NL_THREADS = 256;    // one block; 4 waves find a slot beside co-running kernels (16 waited: 20-33 us for 5 us of work)
 
 struct LossCfg {
     int use_masked_rgb;

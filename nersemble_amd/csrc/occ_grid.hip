@@ -59,7 +59,10 @@ __global__ __launch_bounds__(256) void occ_block_count_kernel(const uint8_t* __r
     if (threadIdx.x == 0) block_counts[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
 }
 
-// exclusive scan of the block counts in place (one block; n_blocks is a few thousand), total -> *n_occ
+// exclusive scan of the block counts in place (one block; n_blocks is a few thousand), total -> *n_occ.
+// 256 threads, not 1024: the scan of the visibility mask sits on the step's critical path, and a 16-wave block has to wait
+// for a CU with 16 free wave slots -- 164 us behind a co-running deformation forward (profiles/r03_timeline_first_steps.txt)
+constexpr int kScanThreads = 256;
 template <typename CountT>
 __global__ __launch_bounds__(1024) void occ_block_scan_kernel(int32_t* __restrict__ block_counts, int n_blocks,
                                                               CountT* __restrict__ n_occ) {
@@ -67,7 +70,7 @@ __global__ __launch_bounds__(1024) void occ_block_scan_kernel(int32_t* __restric
     __shared__ int32_t carry;
     if (threadIdx.x == 0) carry = 0;
     __syncthreads();
-    for (int base = 0; base < n_blocks; base += 1024) {
+    for (int base = 0; base < n_blocks; base += (int)blockDim.x) {
         const int i = base + threadIdx.x;
         const int32_t v = i < n_blocks ? block_counts[i] : 0;
         int32_t s = v;                                    // inclusive scan inside the wave
@@ -82,7 +85,7 @@ __global__ __launch_bounds__(1024) void occ_block_scan_kernel(int32_t* __restric
         for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) before += wave_sum[w];
         if (i < n_blocks) block_counts[i] = before + s - v;
         __syncthreads();
-        if (threadIdx.x == 1023) carry = before + s;
+        if (threadIdx.x == blockDim.x - 1) carry = before + s;
         __syncthreads();
     }
     if (threadIdx.x == 0) *n_occ = (CountT)carry;
@@ -251,7 +254,7 @@ int nsx_occ_compact(const uint8_t* binaries, int64_t n_cells, int32_t* occupied,
     int32_t* counts = reinterpret_cast<int32_t*>(reinterpret_cast<uint8_t*>(scratch) + up(n_cells * 4));
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(occ_block_count_kernel, dim3(nb), dim3(256), 0, st, binaries, n_cells, counts);
-    hipLaunchKernelGGL(occ_block_scan_kernel<int32_t>, dim3(1), dim3(1024), 0, st, counts, nb, n_occ);
+    hipLaunchKernelGGL(occ_block_scan_kernel<int32_t>, dim3(1), dim3(kScanThreads), 0, st, counts, nb, n_occ);
     hipLaunchKernelGGL(occ_compact_kernel<int32_t>, dim3(nb), dim3(256), 0, st, binaries, n_cells, counts, occupied);
     NSX_LAUNCH_CHECK("nsx_occ_compact launch");
     return NSX_OK;
@@ -265,7 +268,7 @@ int nsx_compact_mask(const uint8_t* mask, int64_t n, int64_t* kept, int64_t* n_k
     int32_t* counts = reinterpret_cast<int32_t*>(reinterpret_cast<uint8_t*>(scratch) + up(n * 4));
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(occ_block_count_kernel, dim3(nb), dim3(256), 0, st, mask, n, counts);
-    hipLaunchKernelGGL(occ_block_scan_kernel<int64_t>, dim3(1), dim3(1024), 0, st, counts, nb, n_kept);
+    hipLaunchKernelGGL(occ_block_scan_kernel<int64_t>, dim3(1), dim3(kScanThreads), 0, st, counts, nb, n_kept);
     hipLaunchKernelGGL(occ_compact_kernel<int64_t>, dim3(nb), dim3(256), 0, st, mask, n, counts, kept);
     NSX_LAUNCH_CHECK("nsx_compact_mask launch");
     return NSX_OK;
