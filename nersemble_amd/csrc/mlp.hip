@@ -89,8 +89,19 @@ __device__ __host__ inline FragPlan make_plan(int NH, bool bwd) {
     return p;
 }
 
+// The flat weight vector (14 KB with a hidden matrix) is first copied into LDS with coalesced 16-byte loads; the
+// fragments are then gathered from LDS.  Gathering them from global memory -- 60 dependent 2-byte loads per thread -- was
+// most of the kernels' FIXED cost (57 us for a backward launch on 1024 samples): what a steady-state step pays four times.
 template <int NH>
-__device__ void stage_weights(const half_t* __restrict__ W, int in_pad_unused, f16x8* frags, bool bwd) {
+__device__ void stage_weights(const half_t* __restrict__ Wg, half_t* __restrict__ tmp, f16x8* frags, bool bwd) {
+    constexpr int NPARAM = MLP_W * MLP_IN + (NH ? MLP_W * MLP_W : 0) + MLP_OUT * MLP_W;     // halfs, a multiple of 8
+    const half_t* W = Wg;
+    if ((reinterpret_cast<uintptr_t>(Wg) & 15) == 0) {
+        for (int i = threadIdx.x; i < NPARAM / 8; i += blockDim.x)
+            reinterpret_cast<f16x8*>(tmp)[i] = reinterpret_cast<const f16x8*>(Wg)[i];
+        __syncthreads();
+        W = tmp;
+    }
     // flat parameter layout: W0 [64][32], (Wh [64][64]), Wo [16][64]
     const half_t* W0 = W;
     const half_t* Wh = W + MLP_W * MLP_IN;
@@ -198,9 +209,9 @@ __global__ __launch_bounds__(MLP_WAVES * kWave) void mlp_fwd_kernel(const half_t
     NSX_DEVICE_COUNT(B, n_tiles, 32, n_dev);
     extern __shared__ __attribute__((aligned(16))) uint8_t smem_raw[];
     f16x8* frags = reinterpret_cast<f16x8*>(smem_raw);
-    stage_weights<NH>(W, MLP_IN, frags, false);
-    __syncthreads();
     const FragPlan p = make_plan(NH, false);
+    stage_weights<NH>(W, reinterpret_cast<half_t*>(smem_raw + (size_t)p.total * kWave * sizeof(f16x8)), frags, false);
+    __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n = lane & 31, kb = lane >> 5;
     const bool fast = io.a_dim == 0 && io.b_off == 0 && io.b_dim == MLP_IN && (io.b_stride % 8) == 0;
@@ -260,7 +271,7 @@ __global__ __launch_bounds__(MLP_WAVES * kWave) void mlp_bwd_kernel(
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     half_t* Zt = tbase + (size_t)wave * 2 * MLP_W * TP;     // dZ^T tile  [64][TP]
     half_t* Ht = Zt + MLP_W * TP;                           // H^T  tile  [64][TP]
-    stage_weights<NH>(W, MLP_IN, frags, true);
+    stage_weights<NH>(W, tbase, frags, true);          // (the tile region doubles as the staging buffer: unused until the sync)
     __syncthreads();
     const int n = lane & 31, kb = lane >> 5;
     const bool fast = io.a_dim == 0 && io.b_off == 0 && io.b_dim == MLP_IN && (io.b_stride % 8) == 0;
@@ -387,34 +398,42 @@ __global__ __launch_bounds__(MLP_WAVES * kWave) void mlp_bwd_kernel(
             }
         }
     }
-    // ---- reduce weight gradients over the block's waves, then one atomic per parameter ----
+    // ---- reduce weight gradients over the block's 4 waves, then one atomic per parameter ----
+    // Inside ONE wave every accumulator element has its own address, so a wave can store / add its tiles with plain LDS
+    // accesses; two buffers, two rounds: waves 0 and 1 store, then waves 2 and 3 add to them.  (LDS float atomics from all
+    // four waves at once -- 128 ds_add_f32 per wave -- took 38 us of a 57 us launch on one tile per wave.)
+    static_assert(MLP_WAVES == 4, "two-round reduction over four waves");
     __syncthreads();
-    float* red = reinterpret_cast<float*>(smem_raw);         // reuse LDS: n_params floats
-    const int n_params = MLP_W * MLP_IN + (NH ? MLP_W * MLP_W : 0) + MLP_OUT * MLP_W;
-    for (int i = threadIdx.x; i < n_params; i += blockDim.x) red[i] = 0.f;
-    __syncthreads();
-    float* r0 = red;
-    float* rh = red + MLP_W * MLP_IN;
-    float* ro = rh + (NH ? MLP_W * MLP_W : 0);
+    constexpr int n_params = MLP_W * MLP_IN + (NH ? MLP_W * MLP_W : 0) + MLP_OUT * MLP_W;
+    float* red = reinterpret_cast<float*>(smem_raw) + (size_t)(wave & 1) * n_params;      // reuses the LDS: 2 x n_params floats
+    auto dump = [&](auto combine) {
+        float* r0 = red;
+        float* rh = red + MLP_W * MLP_IN;
+        float* ro = rh + (NH ? MLP_W * MLP_W : 0);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int row = acc_row(r, kb);
+        for (int r = 0; r < 16; ++r) {
+            const int row = acc_row(r, kb);
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) atomicAdd(&r0[(32 * mt + row) * MLP_IN + n], gW0[mt][r]);
-        if constexpr (NH == 1) {
+            for (int mt = 0; mt < 2; ++mt) combine(r0[(32 * mt + row) * MLP_IN + n], gW0[mt][r]);
+            if constexpr (NH == 1) {
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
+                for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt) atomicAdd(&rh[(32 * mt + row) * MLP_W + 32 * nt + n], gWh[mt][nt][r]);
+                    for (int nt = 0; nt < 2; ++nt) combine(rh[(32 * mt + row) * MLP_W + 32 * nt + n], gWh[mt][nt][r]);
+            }
+            if (row < MLP_OUT) {
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) combine(ro[row * MLP_W + 32 * nt + n], gWo[nt][r]);
+            }
         }
-        if (row < MLP_OUT) {
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt) atomicAdd(&ro[row * MLP_W + 32 * nt + n], gWo[nt][r]);
-        }
-    }
+    };
+    if (wave < 2) dump([](float& dst, float v) { dst = v; });         // every parameter has exactly one owner lane per wave
     __syncthreads();
+    if (wave >= 2) dump([](float& dst, float v) { dst += v; });
+    __syncthreads();
+    const float* ra = reinterpret_cast<const float*>(smem_raw);
     for (int i = threadIdx.x; i < n_params; i += blockDim.x) {
-        const float v = red[i];
+        const float v = ra[i] + ra[n_params + i];
         if (v != 0.f) atomicAdd(&dW[i], v);
     }
 }
@@ -424,11 +443,14 @@ __global__ void f32_to_f16_kernel(const float* __restrict__ src, half_t* __restr
         dst[i] = (half_t)src[i];
 }
 
-static size_t fwd_smem(int NH) { return (size_t)make_plan(NH, false).total * kWave * sizeof(f16x8); }
+static size_t fwd_smem(int NH) {      // fragments + the staging copy of the flat weights
+    return (size_t)make_plan(NH, false).total * kWave * sizeof(f16x8) +
+           (size_t)(MLP_W * MLP_IN + (NH ? MLP_W * MLP_W : 0) + MLP_OUT * MLP_W) * sizeof(half_t);
+}
 static size_t bwd_smem(int NH) {
     size_t frag = (size_t)make_plan(NH, true).total * kWave * sizeof(f16x8);
     size_t tiles = (size_t)MLP_WAVES * 2 * MLP_W * TP * sizeof(half_t);
-    size_t red = (size_t)(MLP_W * MLP_IN + (NH ? MLP_W * MLP_W : 0) + MLP_OUT * MLP_W) * sizeof(float);
+    size_t red = 2 * (size_t)(MLP_W * MLP_IN + (NH ? MLP_W * MLP_W : 0) + MLP_OUT * MLP_W) * sizeof(float);
     size_t s = frag + tiles;
     return s > red ? s : red;
 }
@@ -496,9 +518,10 @@ int nsx_mlp_bwd(const nsx_half* weights, int n_hidden_mats, int64_t B,
     // hidden matrix: one wave per SIMD), so a second block per CU only queues behind the first -- and every block ends with
     // n_params atomics onto the same 7 168 addresses.  Measured in-step (645 k samples, 2 calls per step): 2 blocks per CU
     // 0.191 ms per call, 1: 0.166, 1/2: 0.274 (NSX_MLP_BWD_HALF_BLOCKS_PER_CU = blocks per CU x 2, measurement knob).
-    static int per_cu_x2 = 0;
+    static int per_cu_x2 = 0, per_cu0_x2 = 0;
     if (!per_cu_x2) { const char* e = getenv("NSX_MLP_BWD_HALF_BLOCKS_PER_CU"); per_cu_x2 = e ? atoi(e) : 2; if (per_cu_x2 < 1) per_cu_x2 = 2; }
-    const int64_t cap = (int64_t)num_cus() * per_cu_x2 / 2;
+    if (!per_cu0_x2) { const char* e = getenv("NSX_MLP_BWD0_HALF_BLOCKS_PER_CU"); per_cu0_x2 = e ? atoi(e) : 2; if (per_cu0_x2 < 1) per_cu0_x2 = 2; }
+    const int64_t cap = (int64_t)num_cus() * (n_hidden_mats == 0 ? per_cu0_x2 : per_cu_x2) / 2;
     if (blocks > cap) blocks = cap;
     hipStream_t st = (hipStream_t)stream;
     const half_t* W = reinterpret_cast<const half_t*>(weights);
