@@ -296,8 +296,13 @@ __global__ __launch_bounds__(WAVES * kWave) void ens_bwd_kernel(
     // csum_part (DCODE only): the code gradient leaves the kernel summed per code row -- [gridDim.x][n_slots][H] block
     // partials, accumulated in LDS (code_sums_reduce_kernel adds the blocks and applies the window) -- instead of as a
     // [B][H] tensor that torch then index_add_s into n_slots rows.  Every block writes its partial, also an idle one.
-    extern __shared__ float csum[];   // [n_slots][H], only when csum_part
+    // LDS: [n_slots][H], only when csum_part.  H = 32 (SPW = 8): one table PER WAVE -- the head lanes of one wave
+    // instruction then all have distinct (row, grid) addresses (one 8-sample group per grid quarter), so they add with
+    // plain LDS accesses instead of ds_add_f32, which costs ~150 cycles per wave instruction (csrc/mlp.hip's tail).
+    extern __shared__ float csum[];
+    constexpr bool kWaveTables = (C::SPW == 8);
     const bool code_sums = DCODE && csum_part != nullptr;
+    const int n_tables = kWaveTables ? WAVES : 1;
     if (n_dev) {
         const int64_t n__ = *n_dev;
         if (n__ < B) { B = n__ < 0 ? 0 : n__; n_tiles = (B + C::SPW - 1) / C::SPW; }
@@ -307,7 +312,7 @@ __global__ __launch_bounds__(WAVES * kWave) void ens_bwd_kernel(
         n_tiles = 0;
     }
     if (code_sums) {
-        for (int i = threadIdx.x; i < n_slots * H; i += WAVES * kWave) csum[i] = 0.f;
+        for (int i = threadIdx.x; i < n_tables * n_slots * H; i += WAVES * kWave) csum[i] = 0.f;
         __syncthreads();
     }
     bool bad = false;                 // a non-finite value was added to the factored gradient
@@ -460,11 +465,19 @@ __global__ __launch_bounds__(WAVES * kWave) void ens_bwd_kernel(
             const uint32_t rk = (uint32_t)crow;
             const uint32_t pk = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)rk, 0x111, 0xf, 0xf, true);
             const bool head = ((s & 7) == 0) || (pk != rk);
-            float* crow_sums = csum + (size_t)rk * H;
+            float* crow_sums = csum + (kWaveTables ? (size_t)wave * n_slots * H : 0) + (size_t)rk * H;
             const RunLinks links = run_links(rk, s & 7);
+            // plain add only where it is race-free: this lane is the ONLY run head of its 8-sample group (all 8 samples
+            // share the code row -- consecutive samples of a ray); groups of one instruction differ in the grid they own.
+            // Several heads in a group (rows A B A ...) could meet on one address: those lanes use the atomic.
+            const unsigned long long head_bits = __ballot(head);
+            const bool lone_head = __popcll((head_bits >> (lane & ~7)) & 0xFFull) == 1;
             auto emit = [&](int h, float val) {
                 const float sum = run_sum(val, links);
-                if (head && h < Hreal && sum != 0.f) atomicAdd(crow_sums + h, sum);
+                if (head && h < Hreal && sum != 0.f) {
+                    if (kWaveTables && lone_head) crow_sums[h] += sum;    // this wave's table, this lane's own address
+                    else atomicAdd(crow_sums + h, sum);
+                }
             };
             if constexpr (H == 1) {
                 emit(0, dc[0]);
@@ -519,7 +532,14 @@ __global__ __launch_bounds__(WAVES * kWave) void ens_bwd_kernel(
     if (code_sums) {
         __syncthreads();
         float* part = csum_part + (size_t)blockIdx.x * n_slots * H;
-        for (int i = threadIdx.x; i < n_slots * H; i += WAVES * kWave) part[i] = csum[i];
+        for (int i = threadIdx.x; i < n_slots * H; i += WAVES * kWave) {
+            float v = csum[i];
+            if constexpr (kWaveTables) {
+#pragma unroll
+                for (int w = 1; w < WAVES; ++w) v += csum[(size_t)w * n_slots * H + i];
+            }
+            part[i] = v;
+        }
     }
 }
 
@@ -784,7 +804,7 @@ static int launch_bwd(const float* x, int64_t B, const nsx_half* tables, int Hre
     const int64_t cap = (int64_t)num_cus() * 8;
     if (blocks > cap) blocks = cap;
     const bool dc = dcode || dcode_rows;
-    const size_t smem = dcode_rows ? (size_t)n_slots * H * sizeof(float) : 0;
+    const size_t smem = dcode_rows ? (size_t)(C::SPW == 8 ? WAVES : 1) * n_slots * H * sizeof(float) : 0;
 #define NSX_BWD_LAUNCH(MODE, DC, NS, NF)                                                                               \
     hipLaunchKernelGGL((ens_bwd_kernel<H, WAVES, MODE, DC>), dim3((unsigned)blocks), dim3(WAVES * kWave), smem, st, x, B, \
                        reinterpret_cast<const uint8_t*>(tables), *g, code, code_stride, code_index, window, Hreal,       \
