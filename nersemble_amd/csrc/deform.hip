@@ -815,9 +815,18 @@ __device__ __forceinline__ WgRole wg_role(int type, int wave, int n_code_rows) {
 }
 
 // accumulator element r of lane (i, kb) of output tile (x tile mt, y tile nt): X-side row acc_row(r, kb), Y-side column i
+// `part` (SLOTS): this chunk's private copy of the parameter-gradient vector -- every element has exactly one owner
+// (block type, wave, tile, register, lane), so the block leaves its sums with plain stores and deform_finish_kernel adds the
+// chunks; without it the sums go to the gradient buffer with fp32 atomics (one burst of ~1 M sector atomics when all
+// blocks finish together: 60 us of a 100 us launch in steady state).
 template <bool SLOTS>
 __device__ __forceinline__ void wg_store(const f32x16& acc, int job, int mt, int nt, bool is_bias, int lane,
-                                         float* __restrict__ gp, float* __restrict__ gcode, int n_code_rows) {
+                                         float* __restrict__ gp, float* __restrict__ gcode, int n_code_rows,
+                                         float* __restrict__ part = nullptr) {
+    auto put = [&](int64_t idx, float v) {
+        if (part) part[idx] = v;
+        else if (v != 0.f) atomicAdd(&gp[idx], v);
+    };
     const int i = lane & 31, kb = lane >> 5;
     if (is_bias && i != 0) return;                          // every column of X * ones holds the row sum
     const int64_t w_off[7] = {P_W0, P_W1, P_W2, P_W3, P_W4, P_W4 + DF_IN, P_W5};
@@ -830,21 +839,20 @@ __device__ __forceinline__ void wg_store(const f32x16& acc, int job, int mt, int
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const float v = acc[r];
-        if (v == 0.f) continue;
         const int ar = acc_row(r, kb);
         if (job <= 6) {
             const int row = tile_neuron_chain(mt, ar);
-            if (is_bias) atomicAdd(&gp[b_off[job] + row], v);
-            else if (col < n_cols) atomicAdd(&gp[w_off[job] + (int64_t)row * ldc[job] + col], v);
+            if (is_bias) put(b_off[job] + row, v);
+            else if (col < n_cols) put(w_off[job] + (int64_t)row * ldc[job] + col, v);
         } else if (job == 7) {                               // heads: rows 0..2 -> Wr / br, 3..5 -> Wv / bv
             if (ar >= 16) continue;                          // only the first 16 columns of the dZh tile are populated
             const int row = tile_neuron_chain(0, ar);
             if (row >= 6) continue;
-            if (is_bias) atomicAdd(&gp[row < 3 ? P_BR + row : P_BV + row - 3], v);
-            else atomicAdd(&gp[(row < 3 ? (int64_t)P_WR + (int64_t)row * DFW : (int64_t)P_WV + (int64_t)(row - 3) * DFW) + col], v);
+            if (is_bias) put(row < 3 ? P_BR + row : P_BV + row - 3, v);
+            else put((row < 3 ? (int64_t)P_WR + (int64_t)row * DFW : (int64_t)P_WV + (int64_t)(row - 3) * DFW) + col, v);
         } else {                                             // code table rows (natural), code columns (chained)
             const int row = 32 * mt + ar;
-            if (row < n_code_rows) atomicAdd(&gcode[(int64_t)row * DF_CODE + col], v);
+            if (v != 0.f && row < n_code_rows) atomicAdd(&gcode[(int64_t)row * DF_CODE + col], v);
         }
     }
 }
@@ -870,7 +878,8 @@ __global__ __launch_bounds__(NW * 64, 1) void deform_wgrad_kernel(const half_t* 
                                                                  float* __restrict__ grad_params,
                                                                  float* __restrict__ grad_code, int n_code_rows,
                                                                  const int64_t* __restrict__ n_dev,
-                                                                 float* __restrict__ slot_sums) {
+                                                                 float* __restrict__ slot_sums,
+                                                                 float* __restrict__ partials) {
     constexpr int TILE_KB = Lay<SLOTS>::TILE_KB;
     NSX_DEVICE_COUNT(S, n_tiles, 32, n_dev);
     __shared__ __attribute__((aligned(16))) char ring[WG_NS * WG_PIECES * 1024];
@@ -980,10 +989,11 @@ __global__ __launch_bounds__(NW * 64, 1) void deform_wgrad_kernel(const half_t* 
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // no LDS-DMA write may outlive the block
     if (role.n_y == 0) return;
+    float* part = partials ? partials + (int64_t)blockIdx.y * P_TOTAL : nullptr;
 #pragma unroll
     for (int q = 0; q < 6; ++q)
-        if (q < role.n_y) wg_store<SLOTS>(acc[q], role.job, role.x_tile, q, false, lane, grad_params, grad_code, n_code_rows);
-    if (role.bias) wg_store<SLOTS>(acc[6], role.job, role.x_tile, 0, true, lane, grad_params, grad_code, n_code_rows);
+        if (q < role.n_y) wg_store<SLOTS>(acc[q], role.job, role.x_tile, q, false, lane, grad_params, grad_code, n_code_rows, part);
+    if (role.bias) wg_store<SLOTS>(acc[6], role.job, role.x_tile, 0, true, lane, grad_params, grad_code, n_code_rows, part);
     if constexpr (SLOTS) {
 #pragma unroll
         for (int q = 0; q < 4; ++q)
@@ -1006,17 +1016,46 @@ __device__ __forceinline__ float packed_code_weight(const half_t* __restrict__ f
     return (float)frags16[((int64_t)fi * 64 + kb * 32 + i) * 8 + j];
 }
 
+// blocks [0, n_reduce): grad_params[i] += sum over the non-empty chunks of partials[chunk][i], for every parameter the
+// weight-gradient kernel owns (everything but the code columns of W0 / W4, which the blocks behind them produce).
+constexpr int FINISH_REDUCE_BLOCKS = (P_TOTAL + 255) / 256;
+
 __global__ __launch_bounds__(256) void deform_code_expand_kernel(const float* __restrict__ slot_sums,
                                                                  const float* __restrict__ code, int64_t code_stride,
                                                                  int n_code_rows, const f16x8* __restrict__ frags,
                                                                  float* __restrict__ grad_params,
-                                                                 float* __restrict__ grad_code) {
+                                                                 float* __restrict__ grad_code,
+                                                                 const float* __restrict__ partials, int n_chunks,
+                                                                 int64_t n_tiles, int64_t S,
+                                                                 const int64_t* __restrict__ n_dev) {
     __shared__ float red[256];
+    if ((int)blockIdx.x < FINISH_REDUCE_BLOCKS) {
+        if (!partials) return;
+        // the chunks that had tiles: the same split as deform_wgrad_kernel (device-side sample count included)
+        if (n_dev) {
+            const int64_t c = *n_dev;
+            if (c < S) { S = c < 0 ? 0 : c; n_tiles = (S + 31) / 32; }
+        }
+        if (S <= 0) return;
+        const int64_t per = (n_tiles + n_chunks - 1) / n_chunks;
+        const int n_valid = (int)((n_tiles + per - 1) / per);
+        const int idx = blockIdx.x * 256 + threadIdx.x;
+        if (idx >= P_TOTAL) return;
+        int col = -1;                                        // code columns of W0 / W4 are not the reducer's
+        if (idx < P_B0) col = idx % DF_IN;
+        else if (idx >= P_W4 && idx < P_B4) col = (idx - P_W4) % DF_W4;
+        if (col >= DF_PE && col < DF_IN) return;
+        float acc = 0.f;
+        for (int c = 0; c < n_valid; ++c) acc += partials[(int64_t)c * P_TOTAL + idx];
+        grad_params[idx] += acc;
+        return;
+    }
+    const int blk = blockIdx.x - FINISH_REDUCE_BLOCKS;
     const float* R0 = slot_sums;
     const float* R4 = slot_sums + (int64_t)DFW * 128;
     const int c = threadIdx.x & 127, half = threadIdx.x >> 7;
-    if (blockIdx.x < DFW) {
-        const int n = blockIdx.x;
+    if (blk < DFW) {
+        const int n = blk;
         const float* R = half ? R4 : R0;
         float acc = 0.f;
         for (int r = 0; r < n_code_rows; ++r) {
@@ -1026,7 +1065,7 @@ __global__ __launch_bounds__(256) void deform_code_expand_kernel(const float* __
         float* dst = grad_params + (half ? (int64_t)P_W4 + (int64_t)n * DF_W4 : (int64_t)P_W0 + (int64_t)n * DF_IN) + DF_PE + c;
         *dst += acc;                                        // (the weight-gradient kernel left these columns alone)
     } else {
-        const int r = blockIdx.x - DFW;
+        const int r = blk - DFW;
         if (!grad_code) return;
         const half_t* f16 = reinterpret_cast<const half_t*>(frags);
         float acc = 0.f;
@@ -1064,8 +1103,11 @@ int nsx_deform_param_count(void) { return P_TOTAL; }
 int64_t nsx_deform_pack_bytes(void) { return (int64_t)N_FRAGS * 64 * 16 + (int64_t)N_BIAS * 4; }
 // + one private dummy tile per possible wave of the launch (tail waves of the lock-stepped blocks write there)
 // (the larger of the two tile layouts + the per-slot sums at the head of the buffer)
+// + one private parameter-gradient vector per chunk of the weight-gradient kernel (SLOTS: plain stores + one reduction)
+static int64_t tiles_bytes(int64_t S) { return (((S + 31) / 32) + (int64_t)num_cus() * NW) * Lay<false>::TILE_HALFS * 2; }
+static int wgrad_chunks_max() { return num_cus() / (WG_TYPES - 1); }
 int64_t nsx_deform_scratch_bytes(int64_t S) {
-    return SLOT_SUMS_BYTES + (((S + 31) / 32) + (int64_t)num_cus() * NW) * Lay<false>::TILE_HALFS * 2;
+    return SLOT_SUMS_BYTES + tiles_bytes(S) + (int64_t)wgrad_chunks_max() * P_TOTAL * 4;
 }
 
 int nsx_deform_pack(const float* params, void* packed, void* stream) {
@@ -1149,15 +1191,18 @@ int nsx_deform_bwd(const void* packed, const float* positions, int64_t S, const 
     if (chunks > max_chunks) chunks = (int)max_chunks;
     if (chunks < 1) chunks = 1;
     if (slots) {
+        float* partials = reinterpret_cast<float*>(reinterpret_cast<uint8_t*>(scratch) + SLOT_SUMS_BYTES + tiles_bytes(S));
         hipLaunchKernelGGL(deform_wgrad_kernel<true>, dim3(n_types, chunks), dim3(NW * 64), 0, st, sc, n_tiles, code_slot, S,
-                           grad_params, grad_code_table, n_code_rows, count_for(S), slot_sums);
+                           grad_params, grad_code_table, n_code_rows, count_for(S), slot_sums, partials);
         NSX_LAUNCH_CHECK("nsx_deform_bwd wgrad launch");
-        hipLaunchKernelGGL(deform_code_expand_kernel, dim3(DFW + n_code_rows), dim3(256), 0, st, slot_sums, code, code_stride,
-                           n_code_rows, A.frags, grad_params, grad_code_table);
-        NSX_LAUNCH_CHECK("nsx_deform_bwd code expand launch");
+        hipLaunchKernelGGL(deform_code_expand_kernel, dim3(FINISH_REDUCE_BLOCKS + DFW + n_code_rows), dim3(256), 0, st,
+                           slot_sums, code, code_stride, n_code_rows, A.frags, grad_params, grad_code_table, partials, chunks,
+                           n_tiles, S, count_for(S));
+        NSX_LAUNCH_CHECK("nsx_deform_bwd finish launch");
     } else {
         hipLaunchKernelGGL(deform_wgrad_kernel<false>, dim3(n_types, chunks), dim3(NW * 64), 0, st, sc, n_tiles, code_slot, S,
-                           grad_params, grad_code_table, grad_code_table ? n_code_rows : 0, count_for(S), slot_sums);
+                           grad_params, grad_code_table, grad_code_table ? n_code_rows : 0, count_for(S), slot_sums,
+                           (float*)nullptr);
         NSX_LAUNCH_CHECK("nsx_deform_bwd wgrad launch");
     }
     return NSX_OK;
