@@ -228,7 +228,9 @@ class _MainPass(torch.autograd.Function):
         if sink is not None and need_tab and ctx.announced:
             # G is complete, and so are the gradients of the two fused MLPs (the rest of the tables' optimizer group):
             # the table optimizer may start its 12 GB pass now, beside the deformation backward below
-            sink.arrived(group_grads=[d_base, d_head])
+            # (handed over only when somebody waits for them: a held reference makes autograd CLONE the two gradients
+            # instead of adopting them -- two copy launches per step)
+            sink.arrived(group_grads=[d_base, d_head] if sink.on_complete is not None else None)
         if need_tab and sink is None:
             dtab = torch.empty(ctx.shapes[0], dtype=f32, device=dev)
             check(L.nsx_hash_grad_expand(ptr(G), n_rows, ptr(code_h), code_h.stride(0), ptr(hash_window), H, C.byref(geom),

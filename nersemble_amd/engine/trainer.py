@@ -220,6 +220,12 @@ class NeRSembleTrainer:
                     opt.step()
         if native_small:
             adam_groups([o for _, o in native_small], small_groups, len(groups), table, found_all)
+            # the fused MLPs' fp16 weight copies for the NEXT step, now: two small launches that would otherwise sit in
+            # the dependent chain behind the table optimizer (tcnn.Network.half_weights is lazy) run beside it instead
+            field = getattr(self.model, "field", None)
+            for net in (getattr(field, "mlp_base", None), getattr(field, "mlp_head", None)):
+                if net is not None and hasattr(net, "half_weights") and net.params.is_cuda:
+                    net.half_weights()
         scaler.update(list(found.values()))
         self._found_groups = groups
         return found_all
