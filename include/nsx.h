@@ -221,6 +221,7 @@ int nsx_f32_to_f16(const float* src, nsx_half* dst, int64_t n, void* stream);
  * nsx_normalise_bwd: dL/dpos_world = dL/dpos_normalised * selector / extent.
  * nsx_density_fwd/bwd: density = trunc_exp(float(h0)) * selector (nersemble_nerfacto_field.py:286-293); backward
  *   g * selector * exp(clamp(h0, -15, 15)) written as fp16 into column 0 of a caller-zeroed [S][stride] buffer. */
+/* (pos_world receives the position WITHOUT `offsets`; they enter pos_normalised only.) */
 int nsx_sample_positions(const float* origins, const float* directions, const int64_t* ray_indices,
                          const float* t_starts, const float* t_ends, const float* offsets, int64_t S,
                          const float* aabb_host, float* pos_world, float* pos_normalised, uint8_t* selector,

@@ -27,13 +27,18 @@ __global__ __launch_bounds__(256) void sample_positions_kernel(
         const float tt = t0 ? (t0[i] + t1[i]) : 0.f;
         float p[3];
         bool inside = true;
+        // pos_world: the sample position itself; the offsets (a deformation, in normalised units added to the world
+        // position exactly as nersemble_instant_ngp.py:257-259 does) only enter the normalised output -- so one launch
+        // serves a caller that needs both (the deformation field's backward wants the undeformed position)
+        float raw[3];
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
             float v = t0 ? o[r * 3 + a] + (d[r * 3 + a] * tt) / 2.0f : o[r * 3 + a];
+            raw[a] = v;
             if (off) v = v + off[i * 3 + a];
             p[a] = v;
         }
-        if (pos_world) { pos_world[i * 3] = p[0]; pos_world[i * 3 + 1] = p[1]; pos_world[i * 3 + 2] = p[2]; }
+        if (pos_world) { pos_world[i * 3] = raw[0]; pos_world[i * 3 + 1] = raw[1]; pos_world[i * 3 + 2] = raw[2]; }
         if (pos_n) {
             float q[3];
 #pragma unroll

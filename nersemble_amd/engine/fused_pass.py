@@ -66,19 +66,23 @@ class _MainPass(torch.autograd.Function):
         tables_f16 = he.half_tables() if comp is None else comp["f16"]
         # -- world positions of the samples, deformation offsets (normalised space)
         pos = torch.empty((S, 3), dtype=f32, device=dev)
-        check(L.nsx_sample_positions(ptr(inp.origins), ptr(inp.directions), None, ptr(inp.t0), ptr(inp.t1), None, S, None,
-                                     ptr(pos), None, None, st), "nsx_sample_positions")
+        pn = torch.empty((S, 3), dtype=f32, device=dev)
+        sel = torch.empty((S,), dtype=torch.uint8, device=dev)
         if inp.pre_offsets is not None:
+            # offsets known (the sigma_fn pass's): positions, scene-box normalisation of (position + offset) and the
+            # in-box selector in ONE launch
             offsets = inp.pre_offsets
+            check(L.nsx_sample_positions(ptr(inp.origins), ptr(inp.directions), None, ptr(inp.t0), ptr(inp.t1), ptr(offsets),
+                                         S, inp.field_aabb6, ptr(pos), ptr(pn), ptr(sel), st), "nsx_sample_positions")
         else:
+            check(L.nsx_sample_positions(ptr(inp.origins), ptr(inp.directions), None, ptr(inp.t0), ptr(inp.t1), None, S, None,
+                                         ptr(pos), None, None, st), "nsx_sample_positions")
             offsets = torch.empty((S, 3), dtype=f32, device=dev)
             check(L.nsx_deform_fwd(ptr(inp.deform_packed), ptr(pos), S, inp.deform_aabb6, ptr(code_d), code_d.stride(0),
                                    ptr(inp.slot), inp.deform_window7, ptr(offsets), st), "nsx_deform_fwd")
-        # -- scene-box normalisation of (position + offset), in-box selector
-        pn = torch.empty((S, 3), dtype=f32, device=dev)
-        sel = torch.empty((S,), dtype=torch.uint8, device=dev)
-        check(L.nsx_sample_positions(ptr(pos), None, None, None, None, ptr(offsets), S, inp.field_aabb6, None, ptr(pn),
-                                     ptr(sel), st), "nsx_sample_positions")
+            # -- scene-box normalisation of (position + offset), in-box selector
+            check(L.nsx_sample_positions(ptr(pos), None, None, None, None, ptr(offsets), S, inp.field_aabb6, None, ptr(pn),
+                                         ptr(sel), st), "nsx_sample_positions")
         # -- HashEnsemble, mlp_base, density
         if inp.pre_features is not None:
             feats = inp.pre_features

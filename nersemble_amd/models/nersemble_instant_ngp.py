@@ -420,6 +420,17 @@ class NeRSembleNGPModel(BaseModel):
         on_device = (self.device_sample_counts and self.reuse_sigma_pass and "image_index" in md
                      and "_image_timesteps" in md and (cfg.alpha_thre > 0 or cfg.early_stop_eps > 0)
                      and not cfg.disable_occupancy_grid)
+        he = self.field.hash_ensemble
+        early_codes = None
+        if "image_index" in md and "_image_timesteps" in md:
+            # the batch's code rows (two embedding lookups + the window conditioning: ~5 small launches) do not depend on
+            # the sampler: queued BEFORE its sigma_fn pass they run beside the table optimizer instead of behind it
+            uniq0 = md["_image_timesteps"].reshape(-1).int()
+            if uniq0.shape[0] <= 64:
+                emb_d0 = self.time_embedding_deformation if self.time_embedding_deformation is not None \
+                    else self.time_embedding
+                early_codes = (uniq0, he._conditioned(self.time_embedding(uniq0), window_hash, ray_bundle.origins.device),
+                               emb_d0(uniq0))
         try:
             with torch.no_grad():
                 ray_samples, ray_indices = self.sampler(
@@ -434,7 +445,7 @@ class NeRSembleNGPModel(BaseModel):
         # in chunks; the result does not depend on it (chunked == un-chunked bit for bit, tests/test_full_size_gpu.py), and
         # the kernels here take any S (3.3 KB of scratch per sample on a 288 GB device): the fused pass runs un-chunked
         if "image_index" in md and "_image_timesteps" in md:
-            uniq = md["_image_timesteps"].reshape(-1).int()
+            uniq = early_codes[0] if early_codes is not None else md["_image_timesteps"].reshape(-1).int()
             slot = (ray_samples.metadata or {}).get("image_index")
             if slot is None or slot.shape[0] != S:
                 if n_dev is not None:
@@ -460,13 +471,15 @@ class NeRSembleNGPModel(BaseModel):
                                      zero_fill=n_dev is not None)
         elif n_dev is not None:
             raise RuntimeError("device-side sample counts: the sigma_fn pass left no forward values to reuse")
-        he = self.field.hash_ensemble
         if he.grad_sink is not None and not he.first_grid_phase(window_hash):
             # (the sampler's sigma_fn pass is queued: from here to the HashEnsemble's backward only small kernels run)
             he.grad_sink.clear_ahead(int(uniq.shape[0]), he.geom.total_entries, ray_indices.device)
-        code_hash, window = he._conditioned(self.time_embedding(uniq), window_hash, ray_indices.device)
-        emb_d = self.time_embedding_deformation if self.time_embedding_deformation is not None else self.time_embedding
-        code_deform = emb_d(uniq)
+        if early_codes is not None:
+            (code_hash, window), code_deform = early_codes[1], early_codes[2]
+        else:
+            code_hash, window = he._conditioned(self.time_embedding(uniq), window_hash, ray_indices.device)
+            emb_d = self.time_embedding_deformation if self.time_embedding_deformation is not None else self.time_embedding
+            code_deform = emb_d(uniq)
         fr = ray_samples.frustums
         inp = MainPassInputs()
         inp.origins, inp.directions = fr.origins.contiguous(), fr.directions.contiguous()

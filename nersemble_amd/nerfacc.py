@@ -230,6 +230,16 @@ class OccGridEstimator(nn.Module):
             self._occs_mean_key = key
         return self._occs_mean_value
 
+    def _alpha_threshold(self, alpha_thre: float) -> Tensor:
+        """``min(alpha_thre, occs.mean())`` (nerfacc's sampling) as a device tensor of shape [1], cached like the mean: it
+        changes when the grid is written, every 16 steps, not with every sampling call."""
+        mean = self._occs_mean()
+        key = (self._occs_mean_key, alpha_thre)
+        if getattr(self, "_alpha_thre_key", None) != key:
+            self._alpha_thre_value = torch.clamp(mean, max=alpha_thre).reshape(1).float()
+            self._alpha_thre_key = key
+        return self._alpha_thre_value
+
     # ---- traversal -------------------------------------------------------------------------------
     @staticmethod
     def _near_planes(rays_o: Tensor, near_plane: float, t_min: Optional[Tensor], render_step_size: float,
@@ -369,7 +379,7 @@ class OccGridEstimator(nn.Module):
                                                                  counted=counted)
         if (alpha_thre > 0.0 or early_stop_eps > 0.0) and sigma_fn is not None:
             # nerfacc: alpha_thre = min(alpha_thre, occs.mean().item()); kept on the device (no host sync)
-            alpha_thre = torch.clamp(self._occs_mean(), max=alpha_thre).reshape(1).float()
+            alpha_thre = self._alpha_threshold(float(alpha_thre))
             if t_starts.shape[0] != 0:
                 sigmas = sigma_fn(t_starts, t_ends, ray_indices)
             else:

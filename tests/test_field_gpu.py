@@ -62,6 +62,37 @@ def test_sample_positions_kernel_bit_exact(cuda):
     assert np.array_equal(got2, want)
 
 
+def test_positions_and_normalisation_in_one_launch(cuda):
+    """``nsx_sample_positions`` asked for both outputs with offsets: ``pos_world`` is the sample position WITHOUT the
+    offsets (what the deformation field's backward needs), ``pos_normalised`` / ``selector`` are those of position + offset
+    -- bit for bit what the two separate launches give (engine/fused_pass.py takes this form when the offsets are known)."""
+    import ctypes as C
+    from nersemble_amd import functional as F
+    from nersemble_amd._lib import check, lib, ptr, stream
+    rng = np.random.default_rng(4)
+    R, S = 200, 3001
+    box = np.stack([AABB[0], AABB[1]])
+    o = (box[0] + (box[1] - box[0]) * rng.random((R, 3))).astype(np.float32)
+    d = rng.standard_normal((R, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    ri = np.sort(rng.integers(0, R, S)).astype(np.int64)
+    t0 = (rng.random(S) * 2).astype(np.float32)
+    t1 = (t0 + np.float32(0.011)).astype(np.float32)
+    off = (rng.standard_normal((S, 3)) * 0.3).astype(np.float32)           # large enough to move samples across the faces
+    tt = lambda a: torch.from_numpy(a).to(cuda)
+    og, dg = tt(o[ri]), tt(d[ri])
+    pos_want = ofield.sample_positions(o, d, ri, t0, t1)
+    pn_want, sel_want = ofield.normalise(pos_want + off, AABB)
+    pos = torch.empty((S, 3), device=cuda)
+    pn = torch.empty((S, 3), device=cuda)
+    sel = torch.empty((S,), dtype=torch.uint8, device=cuda)
+    check(lib().nsx_sample_positions(ptr(og), ptr(dg), None, ptr(tt(t0)), ptr(tt(t1)), ptr(tt(off)), S, _aabb6(), ptr(pos),
+                                     ptr(pn), ptr(sel), stream()), "nsx_sample_positions")
+    assert np.array_equal(pos.cpu().numpy(), pos_want)                      # no offsets in the world position
+    assert np.array_equal(pn.cpu().numpy(), pn_want) and np.array_equal(sel.cpu().numpy().astype(bool), sel_want)
+    assert 0.1 < sel_want.mean() < 0.95 and np.abs(pos_want + off - pos_want).max() > 0.1
+
+
 @pytest.mark.parametrize("with_offsets", [False, True])
 def test_normalise_selector_kernel_bit_exact_and_backward(with_offsets, cuda):
     from nersemble_amd import functional as F
