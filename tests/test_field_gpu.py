@@ -80,13 +80,13 @@ def test_positions_and_normalisation_in_one_launch(cuda):
     t1 = (t0 + np.float32(0.011)).astype(np.float32)
     off = (rng.standard_normal((S, 3)) * 0.3).astype(np.float32)           # large enough to move samples across the faces
     tt = lambda a: torch.from_numpy(a).to(cuda)
-    og, dg = tt(o[ri]), tt(d[ri])
+    og, dg, t0g, t1g, offg = tt(o[ri]), tt(d[ri]), tt(t0), tt(t1), tt(off)     # (held: the call borrows raw pointers)
     pos_want = ofield.sample_positions(o, d, ri, t0, t1)
     pn_want, sel_want = ofield.normalise(pos_want + off, AABB)
     pos = torch.empty((S, 3), device=cuda)
     pn = torch.empty((S, 3), device=cuda)
     sel = torch.empty((S,), dtype=torch.uint8, device=cuda)
-    check(lib().nsx_sample_positions(ptr(og), ptr(dg), None, ptr(tt(t0)), ptr(tt(t1)), ptr(tt(off)), S, _aabb6(), ptr(pos),
+    check(lib().nsx_sample_positions(ptr(og), ptr(dg), None, ptr(t0g), ptr(t1g), ptr(offg), S, _aabb6(), ptr(pos),
                                      ptr(pn), ptr(sel), stream()), "nsx_sample_positions")
     assert np.array_equal(pos.cpu().numpy(), pos_want)                      # no offsets in the world position
     assert np.array_equal(pn.cpu().numpy(), pn_want) and np.array_equal(sel.cpu().numpy().astype(bool), sel_want)
