@@ -266,7 +266,12 @@ int nsx_density_bwd(const nsx_half* base_out, int64_t stride, const uint8_t* sel
  *   window7_host: 7 per-frequency window weights (host), NULL = no window (windows_param None)
  * Backward (recomputes the forward; scratch of nsx_deform_scratch_bytes(S)): grad_params fp32 [param_count] and
  * grad_code_table fp32 [n_code_rows][128] (needs code_slot, n_code_rows <= 128) are ACCUMULATED into (caller
- * zeroes); grad_code_samples fp32 [S][128] (per-sample code gradient, written) -- either may be NULL. */
+ * zeroes); grad_code_samples fp32 [S][128] (per-sample code gradient, written) -- either may be NULL.
+ * With code_slot and grad_code_table and WITHOUT grad_code_samples (the training step: <= 24 time codes per batch) every
+ * quantity that touches the code columns is formed through the slot -- dW0[:, code] = R0 code, dW4[:, code] = R4 code,
+ * dL/dcode[r] = W0c^T R0[:, r] + W4c^T R4[:, r] with R_l[n][r] = sum over the samples of slot r of dZ_l[n] -- from fp32
+ * per-slot sums (the per-sample code gradient is never formed nor rounded to fp16): three launches (chain, sample-contracted
+ * weight gradients with per-chunk partial vectors, finish), 102 instead of 118 KB of scratch traffic per 32 samples. */
 int     nsx_deform_param_count(void);
 int64_t nsx_deform_pack_bytes(void);
 int64_t nsx_deform_scratch_bytes(int64_t S);
