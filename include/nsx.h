@@ -60,8 +60,11 @@ int nsx_grid_geometry(int n_levels, float per_level_scale, int base_resolution,
  * per-sample entry point of this library that is called with a sample count EQUAL TO `capacity` (buffers are allocated
  * for `capacity` rows) processes only the first *n_device rows -- *n_device is read by the kernels when they run, so the
  * calls can be enqueued without a host synchronisation.  Applies to: nsx_sample_positions, nsx_normalise_bwd,
- * nsx_density_fwd/bwd, nsx_gather_rows, nsx_hash_ensemble_fwd/bwd(_factored), nsx_mlp_fwd/bwd, nsx_deform_fwd/bwd,
- * nsx_ray_histogram (per-ray entry points follow through packed_info).  Thread-local, not nestable; host-only state. */
+ * nsx_density_fwd/bwd, nsx_gather_rows, nsx_hash_ensemble_fwd/bwd(_factored/_codesum/_scatter), nsx_mlp_fwd/bwd,
+ * nsx_deform_fwd/bwd, nsx_ray_histogram (per-ray entry points follow through packed_info).  Thread-local, not nestable;
+ * host-only state.  The match is by row count alone: keep the scope around the per-sample calls of ONE sample set -- a
+ * call of a listed entry point on some other set of rows that happens to have `capacity` rows would be clipped as well
+ * (the generic one is nsx_gather_rows). */
 int nsx_device_count_begin(const int64_t* n_device, int64_t capacity);
 int nsx_device_count_end(void);
 
