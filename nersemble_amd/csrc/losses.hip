@@ -12,6 +12,7 @@
 
 namespace nsx {
 
+constexpr int NL_UNROLL = 8;       // rays per thread and round of ray_losses_fwd_kernel
 constexpr int NL_THREADS = 256;    // one block; 4 waves find a slot beside co-running kernels (16 waited: 20-33 us for 5 us of work)
 
 struct LossCfg {
@@ -43,32 +44,57 @@ __global__ __launch_bounds__(NL_THREADS) void ray_losses_fwd_kernel(
     float p[NP];
 #pragma unroll
     for (int k = 0; k < NP; ++k) p[k] = 0.f;
-    for (int64_t r = threadIdx.x; r < R; r += NL_THREADS) {
-        float sq = 0.f;
+    // NL_UNROLL rays per thread and round: every load of the round is unconditional (clamped row, uniform NULL tests) and
+    // issued before the first use -- one memory latency per round instead of four dependent ones per ray.  The sums are
+    // taken in the same per-thread order as a plain loop over r (bit-identical results).
+    for (int64_t r0 = threadIdx.x; r0 < R; r0 += (int64_t)NL_UNROLL * NL_THREADS) {
+        float im[NL_UNROLL][3], pr[NL_UNROLL][3], pray[NL_UNROLL][5], accv[NL_UNROLL], dt[NL_UNROLL], dp[NL_UNROLL];
+        int am[NL_UNROLL];
+        int64_t ns[NL_UNROLL];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const float d = image[r * 3 + c] - rgb[r * 3 + c];
-            sq += d * d;
-        }
-        p[0] += sq;
-        if (alpha_map) {
-            const float a = (float)alpha_map[r] / 255.0f;
-            if (a > cfg.alpha_thr) { p[1] += sq * (1.0f / 3.0f); p[2] += 1.f; }
-            if (alpha_map[r] > 127) { p[3] += sq * (1.0f / 3.0f); p[4] += 1.f; }
-            if (a < 1.0f) { p[5] += fabsf(acc[r] - a); p[6] += 1.f; }
-        }
-        if (depth_t) {
-            const float t = depth_t[r];
-            if (t > 0.f) { const float d = t - depth[r]; p[7] += d * d; p[8] += 1.f; }
-        }
-        if (per_ray) {
+        for (int u = 0; u < NL_UNROLL; ++u) {
+            const int64_t r = r0 + (int64_t)u * NL_THREADS;
+            const int64_t rr = r < R ? r : R - 1;
 #pragma unroll
-            for (int k = 0; k < 5; ++k) p[9 + k] += per_ray[r * 5 + k];
+            for (int c = 0; c < 3; ++c) { im[u][c] = image[rr * 3 + c]; pr[u][c] = rgb[rr * 3 + c]; }
+            am[u] = alpha_map ? (int)alpha_map[rr] : 0;
+            accv[u] = alpha_map ? acc[rr] : 0.f;
+            dt[u] = depth_t ? depth_t[rr] : 0.f;
+            dp[u] = depth_t ? depth[rr] : 0.f;
+#pragma unroll
+            for (int k = 0; k < 5; ++k) pray[u][k] = per_ray ? per_ray[rr * 5 + k] : 0.f;
+            ns[u] = packed ? packed[2 * rr + 1] : 0;
         }
-        if (packed) {
-            const int64_t n = packed[2 * r + 1];
-            p[14] += (float)n;
-            if (n > 0) p[15] = fmaxf(p[15], (float)(r + 1));
+#pragma unroll
+        for (int u = 0; u < NL_UNROLL; ++u) {
+            const int64_t r = r0 + (int64_t)u * NL_THREADS;
+            if (r >= R) break;
+            float sq = 0.f;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float d = im[u][c] - pr[u][c];
+                sq += d * d;
+            }
+            p[0] += sq;
+            if (alpha_map) {
+                const float a = (float)am[u] / 255.0f;
+                if (a > cfg.alpha_thr) { p[1] += sq * (1.0f / 3.0f); p[2] += 1.f; }
+                if (am[u] > 127) { p[3] += sq * (1.0f / 3.0f); p[4] += 1.f; }
+                if (a < 1.0f) { p[5] += fabsf(accv[u] - a); p[6] += 1.f; }
+            }
+            if (depth_t) {
+                const float t = dt[u];
+                if (t > 0.f) { const float d = t - dp[u]; p[7] += d * d; p[8] += 1.f; }
+            }
+            if (per_ray) {
+#pragma unroll
+                for (int k = 0; k < 5; ++k) p[9 + k] += pray[u][k];
+            }
+            if (packed) {
+                const int64_t n = ns[u];
+                p[14] += (float)n;
+                if (n > 0) p[15] = fmaxf(p[15], (float)(r + 1));
+            }
         }
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

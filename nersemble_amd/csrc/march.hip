@@ -219,18 +219,24 @@ __global__ __launch_bounds__(64) void march_fill_kernel(const float* __restrict_
     }
 }
 
-// packed_info[r] = (exclusive prefix of counts, counts[r]); total written to total[0].  Single block.
-__global__ __launch_bounds__(1024) void pack_info_kernel(const int64_t* __restrict__ counts, int64_t R,
-                                                         int64_t* __restrict__ packed, int64_t* __restrict__ total) {
-    __shared__ int64_t wsum[16];
-    __shared__ int64_t carry_s;
+// packed_info[r] = (exclusive prefix of counts, counts[r]); total written to total[0].  Single block of 4 waves: every
+// thread owns kPackItems CONSECUTIVE rays (its loads are independent and issued together, one memory latency per tile of
+// 4096 rays instead of one per 64), scans them serially, and the thread totals go through one wave scan + 4 LDS words.
+constexpr int kPackThreads = 256, kPackItems = 16;
+__global__ __launch_bounds__(kPackThreads) void pack_info_kernel(const int64_t* __restrict__ counts, int64_t R,
+                                                                 int64_t* __restrict__ packed, int64_t* __restrict__ total) {
+    __shared__ int64_t wsum[kPackThreads / 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) carry_s = 0;
-    __syncthreads();
-    for (int64_t base = 0; base < R; base += blockDim.x) {
-        const int64_t i = base + threadIdx.x;
-        const int64_t c = i < R ? counts[i] : 0;
-        int64_t v = c;
+    int64_t carry = 0;                                         // the same value in every thread
+    for (int64_t base = 0; base < R; base += (int64_t)kPackThreads * kPackItems) {
+        const int64_t first = base + (int64_t)threadIdx.x * kPackItems;
+        int64_t c[kPackItems];
+#pragma unroll
+        for (int k = 0; k < kPackItems; ++k) c[k] = (first + k < R) ? counts[first + k] : 0;
+        int64_t sum = 0;
+#pragma unroll
+        for (int k = 0; k < kPackItems; ++k) sum += c[k];
+        int64_t v = sum;
 #pragma unroll
         for (int dlt = 1; dlt < 64; dlt <<= 1) {
             const int64_t t = __shfl_up(v, dlt);
@@ -238,15 +244,26 @@ __global__ __launch_bounds__(1024) void pack_info_kernel(const int64_t* __restri
         }
         if (lane == 63) wsum[wave] = v;
         __syncthreads();
-        int64_t woff = 0;
-        for (int w = 0; w < wave; ++w) woff += wsum[w];
-        const int64_t carry = carry_s;
-        if (i < R) { packed[2 * i] = carry + woff + v - c; packed[2 * i + 1] = c; }
-        __syncthreads();
-        if (threadIdx.x == blockDim.x - 1) carry_s = carry + woff + v;
-        __syncthreads();
+        int64_t woff = 0, tile_total = 0;
+#pragma unroll
+        for (int w = 0; w < kPackThreads / 64; ++w) {
+            const int64_t s = wsum[w];
+            if (w < wave) woff += s;
+            tile_total += s;
+        }
+        int64_t run = carry + woff + (v - sum);
+#pragma unroll
+        for (int k = 0; k < kPackItems; ++k) {
+            if (first + k < R) {
+                packed[2 * (first + k)] = run;
+                packed[2 * (first + k) + 1] = c[k];
+            }
+            run += c[k];
+        }
+        carry += tile_total;
+        __syncthreads();                                       // wsum is rewritten by the next tile
     }
-    if (threadIdx.x == 0) total[0] = carry_s;
+    if (threadIdx.x == 0) total[0] = carry;
 }
 
 // counts per ray (nerfacc.pack_info).  Ray indices arrive sorted, ~200 samples per ray: each wave merges its runs of
@@ -305,10 +322,9 @@ int nsx_pack_info(const int64_t* counts, int64_t R, int64_t* packed_info, int64_
     NSX_REQUIRE(R >= 0, "nsx_pack_info: negative ray count");
     NSX_REQUIRE(total, "nsx_pack_info: NULL total");
     NSX_REQUIRE(R == 0 || (counts && packed_info), "nsx_pack_info: NULL argument");
-    // ONE wave: the scan of 4096 counts is 64 wave-scans either way, and a single wave finds a free slot on a CU that the
-    // table optimizer's pass has filled (the counting pass of the next step runs beside it) -- a 1024-thread block needs 16
-    // free slots on one CU and waited for them: 0.6 ms on average, up to 1.4 ms, for 10 us of work (profiles/r02, r03)
-    hipLaunchKernelGGL(pack_info_kernel, dim3(1), dim3(kWave), 0, (hipStream_t)stream, counts, R, packed_info, total);
+    // 4 waves, not 16: the counting pass of the next step runs beside the table optimizer's pass, and a 1024-thread block
+    // waited for 16 free wave slots on one CU (0.6 ms on average, up to 1.4 ms, for 10 us of work; profiles/r02, r03)
+    hipLaunchKernelGGL(pack_info_kernel, dim3(1), dim3(kPackThreads), 0, (hipStream_t)stream, counts, R, packed_info, total);
     NSX_LAUNCH_CHECK("nsx_pack_info launch");
     return NSX_OK;
 }

@@ -1,6 +1,15 @@
-"""Host-side profile of the training step (which Python frames / torch ops the CPU spends its time in).
-    python tools/host_profile.py [workload] [steps] [warmup_steps]"""
+"""Where the HOST spends a steady-state step: cProfile over 100 steps from step 600 of the bench workload.
+
+The steady-state step is ~75 kernels in ~3.4 ms; the device timeline (profiles/r03_timeline_steady_state*.txt) shows idle
+gaps in front of the first kernels of the backward, i.e. the host has no lead there.  This prints (a) the step time with the
+device drained at the end, (b) the time the host needs to ISSUE the same steps, (c) the profile of the issuing code.
+
+    python tools/host_profile.py [--window-open] [--steps 100] > gpurun_out/host_profile.txt
+"""
+import argparse
 import cProfile
+import gc
+import io
 import os
 import pstats
 import sys
@@ -9,30 +18,77 @@ import time
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from nersemble_amd.workloads import build_workload  # noqa: E402
 
-name = sys.argv[1] if len(sys.argv) > 1 else "p030_h32"
-steps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
-warm = int(sys.argv[3]) if len(sys.argv) > 3 else 20
-torch.manual_seed(0)
-trainer, data, info = build_workload(name, device="cuda:0")
-batches = [data.next_train(s) for s in range(warm + 2 * steps)]
-for s in range(warm):
-    trainer.train_iteration(s, *batches[s])
-torch.cuda.synchronize()
 
-t0 = time.perf_counter()
-for s in range(warm, warm + steps):
-    trainer.train_iteration(s, *batches[s])
-torch.cuda.synchronize()
-print(f"wall {1e3 * (time.perf_counter() - t0) / steps:.2f} ms/step")
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="p030_h32")
+    ap.add_argument("--window-open", action="store_true")
+    ap.add_argument("--settle-at", type=int, default=600)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--plain", action="store_true", help="only run the timed loop (for use under rocprofv3)")
+    a = ap.parse_args()
+    from nersemble_amd.workloads import build_workload
+    torch.manual_seed(19980801)
+    trainer, data, info = build_workload(a.workload, device="cuda:0", compact_first_grid=False,
+                                         window_hash=(0, 1) if a.window_open else None)
+    reserve = torch.empty(24 * 2 ** 30, dtype=torch.uint8, device="cuda:0")
+    del reserve
+    step = 0
+    while step < a.settle_at:
+        trainer.train_iteration(step, *data.next_train(step))
+        step += 1
+    n = a.steps
+    batches = [data.next_train(step + i) for i in range(3 * n + 1)]
+    gc.collect()
+    gc.freeze()
+    gc.disable()
 
-pr = cProfile.Profile()
-pr.enable()
-for s in range(warm + steps, warm + 2 * steps):
-    trainer.train_iteration(s, *batches[s])
-torch.cuda.synchronize()
-pr.disable()
-st = pstats.Stats(pr)
-st.sort_stats("cumulative").print_stats(60)
-st.sort_stats("tottime").print_stats(45)
+    def loop(first):
+        for i in range(first, first + n):
+            trainer.train_iteration(step + i, *batches[i], next_ray_bundle=batches[i + 1][0])
+
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    loop(0)
+    t_issue = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    t_all = time.perf_counter() - t0
+    print(f"steps {n}: {t_all / n * 1e3:.3f} ms/step with the device drained, {t_issue / n * 1e3:.3f} ms/step until the "
+          f"host had issued them (the difference is the host's lead at the end of the loop)")
+    if a.plain:
+        trainer.flush_scheduler_step()
+        return
+
+    prof = cProfile.Profile()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    prof.enable()
+    loop(n)
+    prof.disable()
+    t_issue = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    t_all = time.perf_counter() - t0
+    print(f"under cProfile: {t_all / n * 1e3:.3f} ms/step drained, {t_issue / n * 1e3:.3f} ms/step issued")
+    for key, rows in (("tottime", 60), ("cumulative", 70)):
+        s = io.StringIO()
+        pstats.Stats(prof, stream=s).strip_dirs().sort_stats(key).print_stats(rows)
+        print(s.getvalue())
+
+    # the same steps with the profiler off again: what the host-side cost of a step is when nothing throttles it is not
+    # observable directly (the queue applies back-pressure), but a step whose device work is short shows it: time the
+    # issue of ONE step after a drain, many times
+    lat = []
+    for i in range(2 * n, 2 * n + min(n, 50)):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        trainer.train_iteration(step + i, *batches[i], next_ray_bundle=batches[i + 1][0])
+        lat.append(time.perf_counter() - t0)
+    lat.sort()
+    print(f"host time of one step issued into an EMPTY queue: median {lat[len(lat) // 2] * 1e3:.3f} ms, "
+          f"min {lat[0] * 1e3:.3f} ms, max {lat[-1] * 1e3:.3f} ms")
+    trainer.flush_scheduler_step()
+
+
+if __name__ == "__main__":
+    main()

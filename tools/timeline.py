@@ -35,6 +35,13 @@ def main():
             for r in csv.DictReader(f):
                 rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"]),
                              r.get("Queue_Id", "?")))
+    # copies made by the DMA engines (host <-> device, sometimes device <-> device) are not kernels but the stream waits for
+    # them all the same: with `--memory-copy-trace` in the same run they appear in the timeline as "memcpy <direction>"
+    for path in glob.glob(os.path.join(directory, "**", "*memory_copy_trace.csv"), recursive=True):
+        with open(path) as f:
+            for r in csv.DictReader(f):
+                rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]),
+                             "memcpy " + r.get("Direction", "?").replace("MEMORY_COPY_", ""), "dma"))
     rows.sort()
     adam_ends = [e for s, e, n, q in rows if n.startswith("nsx::adam_hash_factored_kernel")]
     if len(adam_ends) < n_steps + 1:
