@@ -544,24 +544,37 @@ __global__ __launch_bounds__(WAVES * kWave) void ens_bwd_kernel(
 }
 
 // dcode_rows[row][h] = window[h] * sum_blocks part[block][row][h]: the second stage of the in-kernel code-gradient sums
-// (the chain rule through code' = code * window, hash_ensemble.py:133-138, folded in).  One block per code row.
+// (the chain rule through code' = code * window, hash_ensemble.py:133-138, folded in).  One block per code row; 1024 / H
+// groups of H threads walk the ~2000 block partials with four loads in flight each (the walk is latency-bound: 256
+// dependent rounds of 256 threads took 0.1 ms per step), then a tree over the groups.  Fixed order: deterministic sums.
+constexpr int kCodeSumThreads = 1024;
 template <int H>
-__global__ __launch_bounds__(256) void code_sums_reduce_kernel(const float* __restrict__ part, int n_blocks, int n_slots,
-                                                               const float* __restrict__ window, int Hreal,
-                                                               float* __restrict__ dcode_rows) {
-    __shared__ float red[256];
+__global__ __launch_bounds__(kCodeSumThreads) void code_sums_reduce_kernel(const float* __restrict__ part, int n_blocks,
+                                                                           int n_slots, const float* __restrict__ window,
+                                                                           int Hreal, float* __restrict__ dcode_rows) {
+    __shared__ float red[kCodeSumThreads];
     const int row = blockIdx.x;
-    constexpr int G = 256 / H;                         // block-partials walked in parallel
+    constexpr int G = kCodeSumThreads / H;             // block-partials walked in parallel
     const int h = threadIdx.x % H, grp = threadIdx.x / H;
-    float acc = 0.f;
-    for (int b = grp; b < n_blocks; b += G) acc += part[((size_t)b * n_slots + row) * H + h];
-    red[threadIdx.x] = acc;
-    __syncthreads();
-    if (grp == 0 && h < Hreal) {
-        float t = 0.f;
-        for (int k = 0; k < G; ++k) t += red[k * H + h];
-        dcode_rows[(size_t)row * Hreal + h] = t * (window ? window[h] : 1.0f);
+    const size_t step = (size_t)n_slots * H;
+    const float* p = part + (size_t)row * H + h;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int b = grp;
+    for (; b + 3 * G < n_blocks; b += 4 * G) {
+        a0 += p[(size_t)b * step];
+        a1 += p[(size_t)(b + G) * step];
+        a2 += p[(size_t)(b + 2 * G) * step];
+        a3 += p[(size_t)(b + 3 * G) * step];
     }
+    for (; b < n_blocks; b += G) a0 += p[(size_t)b * step];
+    red[threadIdx.x] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+#pragma unroll
+    for (int half = G / 2; half >= 1; half >>= 1) {
+        if (grp < half) red[threadIdx.x] += red[threadIdx.x + half * H];
+        __syncthreads();
+    }
+    if (grp == 0 && h < Hreal) dcode_rows[(size_t)row * Hreal + h] = red[h] * (window ? window[h] : 1.0f);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -822,8 +835,8 @@ static int launch_bwd(const float* x, int64_t B, const nsx_half* tables, int Hre
 #undef NSX_BWD_LAUNCH
     NSX_LAUNCH_CHECK("nsx_hash_ensemble_bwd launch");
     if (dcode_rows) {
-        hipLaunchKernelGGL((code_sums_reduce_kernel<H>), dim3((unsigned)n_slots), dim3(256), 0, st, csum_part, (int)blocks,
-                           n_slots, window, Hreal, dcode_rows);
+        hipLaunchKernelGGL((code_sums_reduce_kernel<H>), dim3((unsigned)n_slots), dim3(kCodeSumThreads), 0, st,
+                           csum_part, (int)blocks, n_slots, window, Hreal, dcode_rows);
         NSX_LAUNCH_CHECK("nsx_hash_ensemble_bwd_codesum reduce launch");
     }
     return NSX_OK;
