@@ -51,6 +51,7 @@ def main():
     per_pos = collections.defaultdict(list)
     busy_total = idle_total = 0
     seqs = []
+    step_rows = []
     for k in range(n_steps):
         t0, t1 = bounds[k], bounds[k + 1]
         ks = [r for r in rows if t0 < r[1] <= t1 and r[0] >= t0 - 5_000_000]
@@ -58,10 +59,12 @@ def main():
         seqs.append(tuple(n for _, _, n, _ in ks))
         horizon = t0                                        # the latest end of anything seen so far
         busy = 0
+        step_rows.append([])
         for i, (s, e, n, q) in enumerate(ks):
             idle_before = max(0, s - horizon)
             overlapped = s < horizon
             per_pos[i].append((n, q, max(s, t0) - t0, e - s, idle_before, overlapped))
+            step_rows[-1].append(per_pos[i][-1])
             if e > horizon:
                 busy += e - max(s, horizon)
                 horizon = e
@@ -71,9 +74,15 @@ def main():
     print(f"steps analysed: {n_steps}; kernels per step: {sorted(set(len(s) for s in seqs))}; identical sequence: {same}")
     print(f"mean step period {1e-6 * (bounds[-1] - bounds[0]) / n_steps:.3f} ms = busy "
           f"{1e-6 * busy_total / n_steps:.3f} ms + device idle {1e-6 * idle_total / n_steps:.3f} ms")
+    # the per-position table: steps whose kernel sequence is the most common one only (an occupancy-grid update every 16th
+    # step has ~40 kernels more; folding it in position by position would average unrelated kernels).  The totals above and
+    # the per-name table below cover all analysed steps.
+    modal = collections.Counter(seqs).most_common(1)[0][0]
+    members = [k for k, q in enumerate(seqs) if q == modal]
+    print(f"table: mean over the {len(members)} step(s) with the most common sequence ({len(modal)} kernels)")
     print(f"{'#':>3} {'start us':>9} {'dur us':>8} {'idle us':>8} ovl q   kernel")
-    for i in sorted(per_pos):
-        v = per_pos[i]
+    for i in range(len(modal)):
+        v = [step_rows[k][i] for k in members]
         names = collections.Counter(x[0] for x in v).most_common(1)[0][0]
         mean = lambda j: sum(x[j] for x in v) / len(v)
         print(f"{i:3d} {1e-3 * mean(2):9.1f} {1e-3 * mean(3):8.1f} {1e-3 * mean(4):8.1f} "
