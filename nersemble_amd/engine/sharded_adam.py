@@ -196,6 +196,9 @@ class ShardedTableAdam(torch.optim.Optimizer):
         """The last ``step()`` was skipped on the device (inf/NaN): it must not count (torch.optim.Adam semantics)."""
         self._step = max(0, self._step - 1)
 
+    def clear_grads(self) -> None:
+        self.zero_grad(set_to_none=True)
+
     def zero_grad(self, set_to_none: bool = True):
         super().zero_grad(set_to_none=set_to_none)
         early, self._early = self._early, None

@@ -42,6 +42,12 @@ class SmallGroupAdam(torch.optim.Optimizer):
     def _params(self) -> List[torch.nn.Parameter]:
         return [p for g in self.param_groups for p in g["params"]]
 
+    def clear_grads(self) -> None:
+        """``zero_grad(set_to_none=True)`` without torch.optim's profiler scope (see HashTableAdam.clear_grads)."""
+        for g in self.param_groups:
+            for p in g["params"]:
+                p.grad = None
+
     def _moments(self, p):
         st = self.state[p]
         if "exp_avg" not in st:

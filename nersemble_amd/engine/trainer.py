@@ -206,7 +206,7 @@ class NeRSembleTrainer:
             f = found[self.group_of[key]]
             if isinstance(opt, HashTableAdam):
                 if not (stepped_early and opt is table_opt):
-                    opt.step(found_inf=f, inv_scale=inv_scale, side_stream=self._opt_stream)
+                    opt.step_unhooked(found_inf=f, inv_scale=inv_scale, side_stream=self._opt_stream)
             elif isinstance(opt, ShardedTableAdam):
                 opt.step(found_inf=f, inv_scale=inv_scale, side_stream=self._opt_stream)
             elif isinstance(opt, SmallGroupAdam):
@@ -244,7 +244,11 @@ class NeRSembleTrainer:
         if next_ray_bundle is not None and self.prefetch_march:
             self.model.prefetch_sampling(next_ray_bundle, step + 1)
         for opt in self.optimizers.values():
-            opt.zero_grad(set_to_none=True)
+            clear = getattr(opt, "clear_grads", None)          # the native optimizers' zero_grad(set_to_none=True)
+            if clear is not None:
+                clear()
+            else:
+                opt.zero_grad(set_to_none=True)
         dev_type = ray_bundle.origins.device.type
         with torch.autocast(device_type=dev_type, dtype=torch.float16, enabled=self.mixed_precision, cache_enabled=False):
             fast = self.model.fused_train_forward(ray_bundle, batch) if self.mixed_precision else None

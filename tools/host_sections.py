@@ -1,0 +1,89 @@
+"""Host time of ONE steady-state step issued into an empty queue, by section (median over 60 steps).
+
+The compact first-grid phase (steps 0 ... 40 000, the trainer's default) has ~1.9 ms of device work per step in steady state --
+about what the host needs to issue a step -- so there the host's sections are the step's critical path.
+
+    python tools/host_sections.py [--full-layout] [--window-open]
+"""
+import argparse
+import collections
+import gc
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="p030_h32")
+    ap.add_argument("--full-layout", action="store_true")
+    ap.add_argument("--window-open", action="store_true")
+    ap.add_argument("--settle-at", type=int, default=600)
+    ap.add_argument("--steps", type=int, default=60)
+    a = ap.parse_args()
+    from nersemble_amd.workloads import build_workload
+    torch.manual_seed(19980801)
+    trainer, data, info = build_workload(a.workload, device="cuda:0", compact_first_grid=not a.full_layout,
+                                         window_hash=(0, 1) if a.window_open else None)
+    reserve = torch.empty(24 * 2 ** 30, dtype=torch.uint8, device="cuda:0")
+    del reserve
+    step = 0
+    while step < a.settle_at:
+        trainer.train_iteration(step, *data.next_train(step))
+        step += 1
+    acc = collections.defaultdict(list)
+    cur = collections.defaultdict(float)
+
+    def timed(name, fn):
+        def wrapper(*args, **kw):
+            t0 = time.perf_counter()
+            try:
+                return fn(*args, **kw)
+            finally:
+                cur[name] += time.perf_counter() - t0
+        return wrapper
+
+    model = trainer.model
+    model.prefetch_sampling = timed("prefetch_sampling", model.prefetch_sampling)
+    model.fused_train_forward = timed("forward (all)", model.fused_train_forward)
+    model.sampler.forward = timed("  sampler", model.sampler.forward)
+    model.field_density_fn = timed("    sigma_fn density", model.field_density_fn)
+    trainer._optimizer_step_all = timed("optimizer (all)", trainer._optimizer_step_all)
+    trainer.flush_scheduler_step = timed("  flush_scheduler_step", trainer.flush_scheduler_step)
+    trainer._defer_scheduler_step = timed("defer_scheduler_step", trainer._defer_scheduler_step)
+    for cb in trainer.callbacks:
+        cb.run = timed("callbacks", cb.run)
+    for opt in trainer.optimizers.values():
+        opt.zero_grad = timed("zero_grad", opt.zero_grad)
+    real_backward = torch.autograd.backward
+    torch.autograd.backward = timed("backward", real_backward)
+
+    n = a.steps
+    batches = [data.next_train(step + i) for i in range(n + 1)]
+    gc.collect()
+    gc.freeze()
+    gc.disable()
+    for i in range(n):
+        torch.cuda.synchronize()
+        cur.clear()
+        t0 = time.perf_counter()
+        trainer.train_iteration(step + i, *batches[i], next_ray_bundle=batches[i + 1][0])
+        cur["TOTAL"] = time.perf_counter() - t0
+        if (step + i) % 16 != 0:                    # (occupancy-update steps are a different animal)
+            for k, v in cur.items():
+                acc[k].append(v)
+    torch.autograd.backward = real_backward
+    trainer.flush_scheduler_step()
+    print(f"host time per step issued into an empty queue, median of {len(acc['TOTAL'])} steps "
+          f"({'full layout' if a.full_layout else 'compact first-grid phase'}{', window open' if a.window_open else ''})")
+    for k, v in sorted(acc.items(), key=lambda kv: -sorted(kv[1])[len(kv[1]) // 2]):
+        v = sorted(v)
+        print(f"{k:28s} {v[len(v) // 2] * 1e6:8.0f} us   (min {v[0] * 1e6:.0f})")
+
+
+if __name__ == "__main__":
+    main()
