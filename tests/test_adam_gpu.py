@@ -149,7 +149,9 @@ def test_placement_calibration_keeps_values_and_installs_state(cuda):
             o.step()
     assert opt.state[he.tables]["step"] == 3 and opt.state[he.tables]["exp_avg"].any()
     # (fp32 atomics accumulate G in arbitrary order: equal up to that, see test_factored_adam_equals_torch_adam)
-    assert (he.tables - twin.tables).abs().max().item() <= 5e-5
+    # (an entry whose summed gradient is zero up to that order flips the sign of m / sqrt(v): at most a few, each <= lr/step)
+    d = (he.tables - twin.tables).abs()
+    assert int((d > 5e-5).sum().item()) <= 3 and d.max().item() <= 2 * 5e-3 * 3 + 1e-6, d.max().item()
     assert (he.tables.detach() - before).abs().max().item() > 1e-3          # it did train
     assert torch.equal(he.half_tables(), he.tables.detach().half())
 
@@ -264,7 +266,9 @@ def test_optimizer_pass_consumes_the_factored_gradient(cuda):
         # (two runs of the atomic scatter: each is within 5e-5 of the exact sum on the entries whose gradient is pure
         # cancellation noise -- see test_factored_adam_equals_torch_adam -- so the pair is compared at twice that)
         d = (a.tables - b.tables).abs()
-        assert d.max().item() <= 1e-4 and d.mean().item() <= 2e-7, (it, d.max().item(), d.mean().item())
+        outliers = int((d > 1e-4).sum().item())             # (sign flips of m / sqrt(v) on pure-noise entries)
+        assert outliers <= 3 and d.max().item() <= 2 * 5e-3 * (it + 1) + 1e-6 and d.mean().item() <= 2e-7, \
+            (it, d.max().item(), d.mean().item(), outliers)
     # a skipped step leaves the parameters alone and still hands back a clean buffer
     before = a.tables.detach().clone()
     opt_a.zero_grad()
