@@ -46,11 +46,13 @@ def test_factored_adam_equals_torch_adam(H, first_window, cuda):
         opt_nat.check_finite(found)
         opt_nat.step(found_inf=found, inv_scale=inv)
         assert found.item() == 0
-        d = (nat.tables - ref.tables).abs().max().item()
+        d = (nat.tables - ref.tables).abs()
         # Adam with eps = 1e-15 is scale-free: on entries whose gradient is pure cancellation noise the update is
-        # lr * (noise ratio), so the atomics' summation order shows up at ~1e-5 (lr = 5e-3); everything else ~1e-7
-        assert d <= 5e-5, (it, d)
-        assert (nat.tables - ref.tables).abs().mean().item() <= 1e-7
+        # lr * (noise ratio), so the atomics' summation order shows up at ~1e-5 (lr = 5e-3); everything else ~1e-7.
+        # (Counted, not bounded by the maximum: where the noise flips the SIGN of a sum the two differ by up to 2 lr per
+        # step -- seen once, on one of 403 M entries, in tests/test_full_size_gpu.py.)
+        assert int((d > 5e-5).sum().item()) <= 3 and d.max().item() <= 2 * 5e-3 * (it + 1) + 1e-6, (it, d.max().item())
+        assert d.mean().item() <= 1e-7
         # the fp16 working copy is refreshed by the kernel
         assert torch.equal(nat.half_tables(), nat.tables.detach().half())
         ref._f16_version = None
