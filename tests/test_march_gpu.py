@@ -114,6 +114,20 @@ def _packed_case(seed, R=300, maxn=300, cuda=None):
     return ray_idx, t0, t1, sigma, packed
 
 
+@pytest.mark.parametrize("R", [1, 63, 4096, 4097, 2 * 4096 + 37, 40000])
+def test_pack_info_over_tile_boundaries(R, cuda):
+    """The scan walks the rays in tiles of 256 threads x 16 rays: sizes around / beyond one tile, empty rays included."""
+    from nersemble_amd import nerfacc as nf
+    rng = np.random.default_rng(R)
+    counts = rng.integers(0, 5, R)
+    counts[rng.random(R) < 0.3] = 0
+    ray_idx = np.repeat(np.arange(R), counts).astype(np.int64)
+    packed = nf.pack_info(torch.from_numpy(ray_idx).to(cuda), R).cpu().numpy()
+    want = np.stack([np.cumsum(counts) - counts, counts], axis=1)
+    assert np.array_equal(packed, want)
+    assert np.array_equal(packed, om.pack_info(ray_idx, R))
+
+
 def test_pack_info_and_render_weights(cuda):
     from nersemble_amd import nerfacc as nf
     ray_idx, t0, t1, sigma, packed_o = _packed_case(1)
