@@ -108,13 +108,15 @@ def test_sigma_pass_reuse_is_exact(cuda):
         assert d <= 1e-4 * max(b[i].abs().max().item(), 1e-12), (i, d)
 
 
-def test_fused_step_losses_match_composed_losses(cuda):
+@pytest.mark.parametrize("n_rays", [512, 257, 2305])
+def test_fused_step_losses_match_composed_losses(n_rays, cuda):
     """csrc/losses.hip (all loss terms, their sum, metrics, and the gradients w.r.t. rgb / accumulation / depth /
     weights in 2+2 launches) against the operator-by-operator losses of models/base.py on the same outputs.
-    fp32 reductions in a different order: 1e-5 relative."""
+    fp32 reductions in a different order: 1e-5 relative.  (Ray counts on either side of the reduction's rounds of
+    256 threads x 8 rays.)"""
     from nersemble_amd.workloads import build_workload
     torch.manual_seed(5)
-    trainer, data, _ = build_workload("p030_h16", device="cuda:0", small=True, n_rays=512)
+    trainer, data, _ = build_workload("p030_h16", device="cuda:0", small=True, n_rays=n_rays)
     for step in range(3):
         trainer.train_iteration(step, *data.next_train(step))
     model = trainer.model
