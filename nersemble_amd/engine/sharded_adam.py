@@ -124,6 +124,21 @@ class ShardedTableAdam(torch.optim.Optimizer):
         if entries and sink.nonfinite is not None:
             torch.maximum(found_inf, sink.nonfinite.to(found_inf.dtype), out=found_inf)
 
+    @torch.no_grad()
+    def ensure_reduce_started(self) -> None:
+        """Every rank must issue its collectives in the same order: the table reduce-scatter (started from inside the
+        backward, ``_start_reduce``), THEN the all-reduce of the small gradients (``NeRSembleTrainer._all_reduce_grads``).
+        A rank whose backward never completed a G -- its rays produced no samples this step -- joins the reduce-scatter
+        here, with zeros, before the trainer goes on to the small gradients; without this it would meet the other ranks'
+        reduce-scatter with its all-reduce."""
+        if self._early is not None:
+            return
+        sink = self.he.grad_sink
+        if sink is not None and self.he.tables.is_cuda:
+            sink.wait_scatter()
+        self._expand_and_reduce(async_op=False)
+        self._early = "done"
+
     def _expand_and_reduce(self, async_op: bool):
         """Dense fp16 gradient / world from the factored one, then the reduce-scatter (every rank joins, with zeros
         if it has no gradient)."""

@@ -145,7 +145,11 @@ class NeRSembleTrainer:
     def _all_reduce_grads(self) -> None:
         if self.world_size <= 1:
             return
-        # (the sharded table optimizer runs its own reduce-scatter; its parameter has no dense gradient)
+        # (the sharded table optimizer runs its own reduce-scatter; its parameter has no dense gradient -- every rank has
+        # started that collective before the ones below are issued, also a rank without samples)
+        for opt in self.optimizers.values():
+            if isinstance(opt, ShardedTableAdam):
+                opt.ensure_reduce_started()
         params = [p for opt in self.optimizers.values() if not isinstance(opt, ShardedTableAdam)
                   for pg in opt.param_groups for p in pg["params"]]
         all_reduce_gradients(params, self.world_size)

@@ -116,12 +116,28 @@ def _sharded_worker(rank, world, port, out_dir):
     opt = ShardedTableAdam(he, lr=5e-3, eps=1e-15, world_size=world, rank=rank, ops=_TorchTableOps())
     inv = torch.tensor([1.0 / 64.0])
     log = []
-    for it in range(4):
+    small = torch.full((5,), float(rank + 1))            # stands for the small parameters' gradient bucket
+    for it in range(5):
         poison = (it == 2 and rank == 1)                 # only ONE rank produces an inf: everybody must skip
         he.grad_sink.entries = [_fake_entry(he, 100 * it + rank, poison=poison)]
         he.grad_sink.nonfinite = torch.zeros(1)
         found = torch.zeros(1)
-        if it % 2 == 1:
+        if it == 4:
+            # rank 1's rays produced no samples: its backward never completes a G, rank 0's starts the reduce-scatter from
+            # inside the backward.  The trainer's order -- ensure_reduce_started(), then the all-reduce of the small
+            # gradients -- keeps the collectives aligned (rank 1 joins with zeros)
+            if rank == 1:
+                he.grad_sink.entries = []
+            else:
+                he.grad_sink.expect()
+                he.grad_sink.arrived()
+                assert opt._early == "done"
+            opt.ensure_reduce_started()
+            assert opt._early == "done"
+            bucket = small.clone()
+            dist.all_reduce(bucket, op=dist.ReduceOp.SUM)
+            assert torch.equal(bucket, torch.full((5,), 3.0))
+        elif it % 2 == 1:
             # the route a real backward takes: the sink announces completion and the optimizer reduce-scatters at once
             he.grad_sink.expect()
             he.grad_sink.expect()
@@ -149,7 +165,7 @@ def test_sharded_table_adam_world2_matches_single_process(tmp_path):
     mp.spawn(_sharded_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     r0 = torch.load(tmp_path / "s0.pt")
     r1 = torch.load(tmp_path / "s1.pt")
-    assert r0["log"] == r1["log"] == [0.0, 0.0, 1.0, 0.0]              # the poisoned step is skipped on BOTH ranks
+    assert r0["log"] == r1["log"] == [0.0, 0.0, 1.0, 0.0, 0.0]         # the poisoned step is skipped on BOTH ranks
     assert torch.equal(r0["f16"], r1["f16"]) and torch.equal(r0["master"], r1["master"])
     assert torch.equal(r0["f16"], r0["master"].half())
     assert r0["shard"] % 1024 == 0 and 2 * r0["shard"] >= r0["n"]
@@ -160,8 +176,8 @@ def test_sharded_table_adam_world2_matches_single_process(tmp_path):
         he.tables.mul_(1e3)
     opt = torch.optim.Adam([he.tables], lr=5e-3, eps=1e-15)
     ops = _TorchTableOps()
-    for it in (0, 1, 3):
-        g = sum((ops.dense(he, _fake_entry(he, 100 * it + r)) * 0.5).half().float() for r in range(2))
+    for it in (0, 1, 3, 4):
+        g = sum((ops.dense(he, _fake_entry(he, 100 * it + r)) * 0.5).half().float() for r in range(1 if it == 4 else 2))
         he.tables.grad = g.half().float() / 64.0
         opt.step()
     d = (he.tables.detach() - r0["master"]).abs().max().item()
