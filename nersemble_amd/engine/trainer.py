@@ -94,17 +94,34 @@ class NeRSembleTrainer:
         gammas = {"fields": self.cfg.gamma_fields, "deformation_field": self.cfg.gamma_deformation_field,
                   "embeddings": self.cfg.gamma_embeddings}
         self.optimizers, self.schedulers, self.group_of = {}, {}, {}
+        # the reference's numbering of every group (``torch.optim.Adam(list(params))`` numbers its parameters by position;
+        # nerfstudio builds one Adam per group of ``get_param_groups``): per position ("table", c) for the c-th tcnn hash
+        # encoding the native tables stand for, ("param", p) for a tensor an optimizer here steps, ("none", p) for members
+        # that never have a gradient -- tcnn's empty ``params`` of parameter-free encodings, the frozen ``aabb`` of the
+        # deformation field -- which torch's Adam lists in ``param_groups`` and keeps no state for.  Checkpoints are
+        # written and read in THIS numbering (tests/golden/state_manifest.json holds the reference's).
+        self.group_layout = {}
         fused = device.type == "cuda"
         tables = model.field.hash_ensemble.tables
+        n_enc = model.field.hash_ensemble.n_tcnn_encodings
         for name, params in groups.items():
-            small = [p for p in params if p is not tables]
+            layout = []
+            for p in params:
+                if p is tables:
+                    layout.extend(("table", c) for c in range(n_enc))
+                elif p.requires_grad and p.numel() > 0:
+                    layout.append(("param", p))
+                else:
+                    layout.append(("none", p))
+            self.group_layout[name] = layout
+            small = [x for kind, x in layout if kind == "param"]
             if fused:
                 # all small groups step together in two native launches (engine/small_adam.py)
                 self.optimizers[name] = SmallGroupAdam(small, lr=lrs[name], eps=self.cfg.eps)
             else:
                 self.optimizers[name] = torch.optim.Adam(small, lr=lrs[name], eps=self.cfg.eps, weight_decay=0)
             self.group_of[name] = name
-            if len(small) != len(params):
+            if any(p is tables for p in params):
                 # the 403 M-parameter hash tables: native fused step on the factored gradient.  Data-parallel runs
                 # shard the optimizer state and exchange fp16 (reduce-scatter / all-gather, engine/sharded_adam.py);
                 # factored_table_grad=False keeps the dense fp32 gradient + all-reduce path.
@@ -311,15 +328,19 @@ class NeRSembleTrainer:
     def state_dict(self) -> Dict:
         """Everything a resumed run needs besides the model: Adam moments + step counts of every group (the table
         moments in the reference's tcnn parameter layout, gathered from all ranks in data-parallel runs -- a
-        collective there), StepLR counters, the loss scale and its growth tracker.  Call ``consolidate()`` first in
-        data-parallel runs so that ``model.state_dict()`` is complete as well."""
+        collective there), StepLR counters, the loss scale and its growth tracker.  ``consolidate()`` is called first:
+        in the compact first-grid phase (the default for the first 40 000 steps) the moments of grid 0 live in their
+        contiguous copy, and a data-parallel run holds the fp32 master in shards -- ``model.state_dict()`` taken after
+        this call is complete as well."""
         self.flush_scheduler_step()
-        opts = {key: opt.state_dict() for key, opt in self.optimizers.items()
-                if not isinstance(opt, (HashTableAdam, ShardedTableAdam))}
+        self.consolidate()
         tkey = self.group_of_tables()
-        if tkey is not None:
-            grp = self.group_of[tkey]
-            opts[grp] = _merge_table_state(self.optimizers[tkey].table_state(), opts[grp])
+        opts = {}
+        for key, opt in self.optimizers.items():
+            if isinstance(opt, (HashTableAdam, ShardedTableAdam)):
+                continue
+            table = self.optimizers[tkey].table_state() if (tkey is not None and self.group_of[tkey] == key) else None
+            opts[key] = _to_reference_numbering(self.group_layout[key], opt, opt.state_dict(), table)
         return {"optimizers": opts,
                 "schedulers": {k: s.state_dict() for k, s in self.schedulers.items() if not k.endswith("/tables")},
                 "scalers": self.grad_scaler.state_dict()}
@@ -334,10 +355,14 @@ class NeRSembleTrainer:
             if key not in saved_all:
                 raise KeyError(f"checkpoint has no optimizer state for the parameter group '{key}' "
                                f"(groups in the file: {sorted(saved_all)})")
-            saved = saved_all[key]
-            if tkey is not None and self.group_of[tkey] == key:
-                n_small = sum(len(g["params"]) for g in opt.param_groups)
-                table_state, saved = _split_table_state(saved, self.model.field.hash_ensemble.n_tcnn_encodings, n_small, key)
+            has_tables = tkey is not None and self.group_of[tkey] == key
+            table_state, saved = _from_reference_numbering(self.group_layout[key], saved_all[key], key)
+            if has_tables:
+                legacy = saved_all.get(tkey)
+                if table_state is None and isinstance(legacy, dict) and "native_table_adam" in legacy:
+                    table_state = dict(legacy["native_table_adam"])     # files of round 2: tables under their own key
+                if table_state is None:
+                    table_state = {"step": 0, "exp_avg": None, "exp_avg_sq": None}
                 table_state.setdefault("lr", saved["param_groups"][0]["lr"])
                 self.optimizers[tkey].load_table_state(table_state)
             opt.load_state_dict(saved)
@@ -371,52 +396,81 @@ class NeRSembleTrainer:
                 sch.step()
 
 
-def _merge_table_state(table: Dict, small: Dict) -> Dict:
-    """One ``torch.optim.Adam.state_dict()`` for the ``fields`` group as the reference holds it: the C tcnn encodings'
-    flat moments (indices 0 .. C-1, one ``step`` each) followed by the small parameters of the group."""
-    C = len(table["exp_avg"])
+def _to_reference_numbering(layout, opt, small: Dict, table: Optional[Dict]) -> Dict:
+    """``torch.optim.Adam.state_dict()`` of one group in the reference's numbering (``layout``, NeRSembleTrainer.
+    group_layout): ``param_groups[0]["params"]`` lists EVERY position, ``state`` holds the positions that have been
+    stepped -- the C tcnn encodings' flat moments with torch's per-parameter ``step``, the small tensors' -- and nothing for
+    the members without a gradient (what a reference run writes: its Adam never creates state for them)."""
+    small_ids = [int(i) for g in small["param_groups"] for i in g["params"]]
+    small_pos = {id(p): i for i, p in zip(small_ids, (p for g in opt.param_groups for p in g["params"]))}
     state = {}
-    if int(table["step"]) > 0:
-        for c in range(C):
-            state[c] = {"step": torch.tensor(float(table["step"])), "exp_avg": table["exp_avg"][c],
-                        "exp_avg_sq": table["exp_avg_sq"][c]}
-    for i, st in small["state"].items():
-        state[C + int(i)] = st
+    for ref_id, (kind, x) in enumerate(layout):
+        if kind == "table":
+            if table is not None and int(table["step"]) > 0:
+                state[ref_id] = {"step": torch.tensor(float(table["step"])), "exp_avg": table["exp_avg"][x],
+                                 "exp_avg_sq": table["exp_avg_sq"][x]}
+        elif kind == "param":
+            st = small["state"].get(small_pos[id(x)])
+            if st is not None:
+                state[ref_id] = st
     groups = []
     for g in small["param_groups"]:
         g = dict(g)
-        g["params"] = list(range(C)) + [C + int(i) for i in g["params"]]
-        g["lr"] = float(table.get("lr", g["lr"]))
+        g["params"] = list(range(len(layout)))
+        if table is not None:
+            g["lr"] = float(table.get("lr", g["lr"]))
         groups.append(g)
-    return {"state": state, "param_groups": groups}
+    return {"state": state, "param_groups": groups[:1]}
 
 
-def _split_table_state(saved: Dict, C: int, n_small: int, key: str):
-    """The inverse: (table state for ``load_table_state``, Adam state dict of the group's small parameters).  Entries
-    without elements (tcnn registers an empty ``params`` for its parameter-free encodings -- Identity / Frequency,
-    nersemble_nerfacto_field.py:99-140 -- which a reference checkpoint then lists) are dropped."""
+def _from_reference_numbering(layout, saved: Dict, key: str):
+    """The inverse: (table state for ``load_table_state`` or None, Adam state dict of the tensors this trainer's small
+    optimizer steps).  The file's ids are matched BY POSITION in the reference's registration order -- a genuine
+    reference checkpoint lists the parameter-free encodings and the frozen ``aabb`` in ``param_groups`` without a state
+    entry.  Files this package wrote before round 4 numbered only the C encodings + the stepped tensors (and gave the
+    empty encodings moments of zero elements in one synthetic layout): recognised by their count."""
     ids = [int(i) for g in saved["param_groups"] for i in g["params"]]
     state = {int(i): st for i, st in saved["state"].items()}
-    if len(ids) > C + n_small:
-        empty = [i for i in ids if i in state and torch.is_tensor(state[i].get("exp_avg")) and state[i]["exp_avg"].numel() == 0]
-        ids = [i for i in ids if i not in empty]
-    if len(ids) != C + n_small:
-        raise KeyError(f"optimizer state of group '{key}': {len(ids)} parameters in the checkpoint, this model has {C} hash "
-                       f"encodings + {n_small} other tensors in that group")
-    tab_ids, small_ids = ids[:C], ids[C:]
-    have = [i for i in tab_ids if i in state]
-    if have and len(have) != C:
-        raise KeyError(f"optimizer state of group '{key}': moments for {len(have)} of {C} hash encodings")
-    if have:
-        table = {"step": int(state[tab_ids[0]]["step"]),
-                 "exp_avg": [state[i]["exp_avg"] for i in tab_ids], "exp_avg_sq": [state[i]["exp_avg_sq"] for i in tab_ids]}
+    n_table = sum(1 for kind, _ in layout if kind == "table")
+    n_param = sum(1 for kind, _ in layout if kind == "param")
+    if len(ids) == len(layout):
+        kinds = layout
     else:
-        table = {"step": 0, "exp_avg": None, "exp_avg_sq": None}
-    groups = []
+        # legacy numberings: drop ids whose moments have zero elements, then expect tables + stepped tensors only
+        empty = {i for i in ids if i in state and torch.is_tensor(state[i].get("exp_avg")) and state[i]["exp_avg"].numel() == 0}
+        ids = [i for i in ids if i not in empty]
+        if n_table and len(ids) == n_param:
+            kinds = [k for k in layout if k[0] == "param"]         # round 2: the tables under a key of their own
+        elif len(ids) == n_table + n_param:
+            kinds = [k for k in layout if k[0] != "none"]          # round 3: encodings + stepped tensors
+        else:
+            raise KeyError(f"optimizer state of group '{key}': {len(ids)} parameters in the checkpoint; this model's group has "
+                           f"{len(layout)} members in the reference's numbering ({n_table} hash encodings, {n_param} "
+                           f"stepped tensors, {len(layout) - n_table - n_param} without a gradient)")
+    tab_ids, small_ids = [], []
+    for i, (kind, x) in zip(ids, kinds):
+        if kind == "table":
+            tab_ids.append(i)
+        elif kind == "param":
+            small_ids.append(i)
+        elif i in state and torch.is_tensor(state[i].get("exp_avg")) and state[i]["exp_avg"].numel() > 0:
+            raise KeyError(f"optimizer state of group '{key}': position {i} holds moments, but the member there "
+                           f"({tuple(x.shape)}) never has a gradient in this model -- not the same parameter layout")
+    table = None
+    if tab_ids:
+        have = [i for i in tab_ids if i in state]
+        if have and len(have) != len(tab_ids):
+            raise KeyError(f"optimizer state of group '{key}': moments for {len(have)} of {len(tab_ids)} hash encodings")
+        if have:
+            table = {"step": int(state[tab_ids[0]]["step"]), "exp_avg": [state[i]["exp_avg"] for i in tab_ids],
+                     "exp_avg_sq": [state[i]["exp_avg_sq"] for i in tab_ids]}
+        else:
+            table = {"step": 0, "exp_avg": None, "exp_avg_sq": None}
     pos = {old: new for new, old in enumerate(small_ids)}
-    for g in saved["param_groups"]:
+    groups = []
+    for g in saved["param_groups"][:1]:
         g = dict(g)
-        g["params"] = [pos[int(i)] for i in g["params"] if int(i) in pos]
+        g["params"] = list(range(len(small_ids)))
         groups.append(g)
     small_state = {pos[i]: state[i] for i in small_ids if i in state}
     return table, {"state": small_state, "param_groups": groups}

@@ -75,6 +75,8 @@ class NeRSembleNeRFactoField(nn.Module):
 
         self.direction_encoding = tcnn.Encoding(n_input_dims=3, encoding_config={"otype": "Identity"})
         self.hash_ensemble = HashEnsemble(hash_ensemble_config)
+        # (registration order = the reference's, :98-172: it fixes the numbering of the ``fields`` optimizer group)
+        self.position_encoding = tcnn.Encoding(n_input_dims=3, encoding_config={"otype": "Frequency", "n_frequencies": 2})
         self.mlp_base = tcnn.NetworkWithInputEncoding(
             n_input_dims=self.hash_ensemble.get_out_dim(), n_output_dims=1 + self.geo_feat_dim,
             encoding_config={"otype": "Identity", "n_dims_to_encode": self.hash_ensemble.get_out_dim()},

@@ -119,6 +119,9 @@ class NeRSembleNGPModel(BaseModel):
         self._eval_blend = None
         self._eval_blend_cache = (None, None)
         self.populate_modules()
+        # nerfstudio ``Model.__init__`` registers this empty parameter after ``populate_modules()``; it is a key of every
+        # nerfstudio checkpoint (``_model.device_indicator_param``)
+        self.device_indicator_param = Parameter(torch.empty(0))
 
     # ---- construction (nersemble_instant_ngp.py:81-179) ---------------------------------------------
     def populate_modules(self):
@@ -738,11 +741,17 @@ class NeRSembleNGPModel(BaseModel):
         return metrics
 
     def get_param_groups(self) -> Dict[str, List[Parameter]]:
+        """The reference's groups (nersemble_instant_ngp.py:502-514 on nerfstudio's ``NGPModel.get_param_groups``), member
+        for member: ``fields`` = ``list(field.parameters())`` -- the empty ``direction_encoding.params``, the hash tables
+        (ONE native parameter standing for the reference's C tcnn encodings), the empty ``position_encoding.params``,
+        ``mlp_base.params``, ``mlp_head.params``; ``deformation_field`` = ``list(deformation_field.parameters())``, which
+        starts with the frozen ``aabb``.  An optimizer built from a group leaves members without a gradient alone, as
+        ``torch.optim.Adam`` does; their POSITIONS are what numbers an Adam state dict (engine/trainer.py)."""
         groups = {"fields": list(self.field.parameters())}
         if self.time_embedding is not None:
             groups["embeddings"] = list(self.time_embedding.parameters())
             if self.time_embedding_deformation is not None:
                 groups["embeddings"].extend(list(self.time_embedding_deformation.parameters()))
         if self.config.use_deformation_field:
-            groups["deformation_field"] = [p for p in self.deformation_field.parameters() if p.requires_grad]
+            groups["deformation_field"] = list(self.deformation_field.parameters())
         return groups

@@ -79,9 +79,15 @@ class NetworkWithInputEncoding(Network):
 
 class Encoding(nn.Module):
     """``tcnn.Encoding``: ``Identity`` (direction encoding with spherical_harmonics_degree = 0, the default of every
-    shipped NeRSemble config, nersemble_instant_ngp.py:46) and ``HashGrid`` with tcnn's parameter layout and
+    shipped NeRSemble config, nersemble_instant_ngp.py:46), ``Frequency`` (the field's ``position_encoding``,
+    nersemble_nerfacto_field.py:137-140 -- constructed by the reference, evaluated only under ``use_pred_normals``, which
+    no NeRSemble config sets: constructed here too, never evaluated) and ``HashGrid`` with tcnn's parameter layout and
     U(-1e-4, 1e-4) initialisation (the operator the reference's own HashEnsemble instantiates at
-    hash_ensemble.py:42-50; the fused ``nersemble_amd`` HashEnsemble is the fast path)."""
+    hash_ensemble.py:42-50; the fused ``nersemble_amd`` HashEnsemble is the fast path).
+
+    Like every tcnn module, a parameter-free encoding registers an EMPTY flat ``params``: it is an entry of
+    ``field.parameters()`` (hence of the ``fields`` optimizer group's numbering) and a key of the state dict
+    (tests/golden/state_manifest.json, generated from the reference's module tree)."""
 
     def __init__(self, n_input_dims: int, encoding_config: dict, seed: int = 1337):
         super().__init__()
@@ -90,6 +96,10 @@ class Encoding(nn.Module):
         self.n_input_dims = n_input_dims
         if otype == "Identity":
             self.n_output_dims = n_input_dims
+            self.params = nn.Parameter(torch.empty(0, dtype=torch.float32))
+        elif otype == "Frequency":
+            self.n_output_dims = n_input_dims * 2 * int(encoding_config["n_frequencies"])
+            self.params = nn.Parameter(torch.empty(0, dtype=torch.float32))
         elif otype == "HashGrid":
             if n_input_dims != 3 or encoding_config.get("interpolation", "Linear") != "Linear":
                 raise NotImplementedError("native HashGrid: 3-D input, Linear interpolation")
@@ -105,9 +115,12 @@ class Encoding(nn.Module):
             gen = torch.Generator().manual_seed(seed)
             self.params = nn.Parameter((torch.rand(self.geom.total_entries * self.f_enc, generator=gen) * 2 - 1) * 1e-4)
         else:
-            raise NotImplementedError(f"native Encoding: Identity and HashGrid (got {otype})")
+            raise NotImplementedError(f"native Encoding: Identity, Frequency (construction only) and HashGrid (got {otype})")
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if self.otype == "Identity":
             return x.to(torch.float16)
+        if self.otype == "Frequency":
+            raise NotImplementedError("tcnn Frequency encoding: only reached under use_pred_normals "
+                                      "(nersemble_nerfacto_field.py:213-226), which NeRSemble never sets")
         return F.hashgrid_encoding(x, self.params.view(self.geom.total_entries, self.f_enc), self.f_enc, self.geom)

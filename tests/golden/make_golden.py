@@ -185,6 +185,227 @@ sys.modules["nerfstudio.utils.math"].expected_sin = lambda x, v: torch.exp(-0.5 
 
 
 # ------------------------------------------------------------------------------------------------
+# ------------------------------------------------------------------------------------------------
+# nerfstudio 0.3.1 / nerfacc 0.5.2 / torchmetrics MODULE-TREE stubs (what registers which sub-module, parameter and
+# buffer under which name -- restated from the published packages; "upstream-stub" in the manifest)
+# ------------------------------------------------------------------------------------------------
+def _install_model_stubs():
+    """Idempotent.  Everything the reference's models/base.py, models/nersemble_instant_ngp.py, fields/
+    nersemble_nerfacto_field.py and model_components/*.py import from packages that are not installed."""
+    if "nerfstudio.models.base_model" in sys.modules and hasattr(sys.modules["nerfstudio.models.base_model"], "Model"):
+        return
+    import dataclasses
+    from dataclasses import dataclass, field
+    for sub in ["engine", "engine.callbacks", "models", "models.base_model", "models.instant_ngp", "fields",
+                "fields.base_field", "fields.nerfacto_field", "field_components.activations",
+                "field_components.embedding", "field_components.field_heads", "field_components.spatial_distortions",
+                "model_components", "model_components.losses", "model_components.renderers",
+                "model_components.ray_samplers", "utils.colormaps"]:
+        if "nerfstudio." + sub not in sys.modules:
+            _mod("nerfstudio." + sub)
+    cb = sys.modules["nerfstudio.engine.callbacks"]
+
+    class TrainingCallback:
+        def __init__(self, where_to_run=None, func=None, update_every_num_iters=None, iters=None, args=None, kwargs=None):
+            self.where_to_run, self.func, self.update_every_num_iters = where_to_run, func, update_every_num_iters
+            self.args, self.kwargs = args or [], kwargs or {}
+
+    cb.TrainingCallback = TrainingCallback
+    cb.TrainingCallbackAttributes = object
+    cb.TrainingCallbackLocation = types.SimpleNamespace(BEFORE_TRAIN_ITERATION="before", AFTER_TRAIN_ITERATION="after")
+    bm = sys.modules["nerfstudio.models.base_model"]
+
+    @dataclass
+    class ModelConfig:
+        _target: type = None
+        enable_collider: bool = True
+        collider_params: dict = None
+        loss_coefficients: dict = None
+        eval_num_rays_per_chunk: int = 4096
+
+    class Model(nn.Module):
+        """nerfstudio Model.__init__: stores the arguments, calls ``populate_modules()``, then registers the empty
+        ``device_indicator_param`` (which therefore sits LAST in ``parameters()`` / the state dict)."""
+
+        def __init__(self, config, scene_box, num_train_data, **kwargs):
+            super().__init__()
+            self.config, self.scene_box, self.num_train_data, self.kwargs = config, scene_box, num_train_data, kwargs
+            self.render_aabb, self.collider = None, None
+            self.populate_modules()
+            self.callbacks = None
+            self.device_indicator_param = nn.Parameter(torch.empty(0))
+
+        def populate_modules(self):
+            pass
+
+        def get_training_callbacks(self, training_callback_attributes):
+            return []
+
+    bm.Model, bm.ModelConfig = Model, ModelConfig
+    ngp = sys.modules["nerfstudio.models.instant_ngp"]
+
+    @dataclass
+    class InstantNGPModelConfig(ModelConfig):
+        enable_collider: bool = False
+        grid_resolution: int = 128
+        grid_levels: int = 4
+        max_res: int = 2048
+        log2_hashmap_size: int = 19
+        alpha_thre: float = 0.01
+        cone_angle: float = 0.004
+        render_step_size: float = None
+        near_plane: float = 0.05
+        far_plane: float = 1e3
+        use_appearance_embedding: bool = False
+        background_color: str = "random"
+        disable_scene_contraction: bool = False
+
+    class NGPModel(Model):
+        def get_param_groups(self):
+            if self.field is None:
+                raise ValueError("populate_fields() must be called before get_param_groups")
+            return {"fields": list(self.field.parameters())}
+
+    ngp.InstantNGPModelConfig, ngp.NGPModel = InstantNGPModelConfig, NGPModel
+    # fields
+    class Field(nn.Module):
+        def __init__(self):
+            super().__init__()
+
+    class TCNNNerfactoField(Field):
+        pass
+
+    sys.modules["nerfstudio.fields.base_field"].Field = Field
+    sys.modules["nerfstudio.fields.base_field"].shift_directions_for_tcnn = lambda d: (d + 1.0) / 2.0
+    sys.modules["nerfstudio.fields.nerfacto_field"].TCNNNerfactoField = TCNNNerfactoField
+    sys.modules["nerfstudio.field_components.activations"].trunc_exp = torch.exp
+    sys.modules["nerfstudio.field_components.embedding"].Embedding = nn.Embedding
+    fh = sys.modules["nerfstudio.field_components.field_heads"]
+    for name in ("PredNormalsFieldHead", "SemanticFieldHead", "TransientDensityFieldHead", "TransientRGBFieldHead",
+                 "UncertaintyFieldHead"):
+        setattr(fh, name, type(name, (nn.Module,), {}))
+    import enum
+    fh.FieldHeadNames = enum.Enum("FieldHeadNames", {"RGB": "rgb", "DENSITY": "density"})
+    sd = sys.modules["nerfstudio.field_components.spatial_distortions"]
+    sd.SpatialDistortion = type("SpatialDistortion", (nn.Module,), {})
+    sd.SceneContraction = type("SceneContraction", (nn.Module,), {"__init__": lambda self, order=None: nn.Module.__init__(self)})
+    rays = sys.modules["nerfstudio.cameras.rays"]
+    for name in ("RayBundle", "Frustums"):
+        if not hasattr(rays, name):
+            setattr(rays, name, type(name, (), {}))
+    sys.modules["nerfstudio.model_components.losses"].MSELoss = nn.MSELoss
+    rn = sys.modules["nerfstudio.model_components.renderers"]
+    for name in ("AccumulationRenderer", "DepthRenderer", "RGBRenderer"):
+        setattr(rn, name, type(name, (nn.Module,), {"__init__": lambda self, *a, **k: nn.Module.__init__(self)}))
+    rs = sys.modules["nerfstudio.model_components.ray_samplers"]
+
+    class Sampler(nn.Module):
+        def __init__(self, num_samples=None):
+            super().__init__()
+            self.num_samples = num_samples
+
+    class VolumetricSampler(Sampler):
+        """nerfstudio ray_samplers.VolumetricSampler: keeps the estimator as a SUB-MODULE (``sampler.occupancy_grid.*``
+        appears in the state dict a second time)."""
+
+        def __init__(self, occupancy_grid, density_fn=None):
+            super().__init__()
+            assert occupancy_grid is not None
+            self.density_fn = density_fn
+            self.occupancy_grid = occupancy_grid
+
+    rs.Sampler, rs.VolumetricSampler, rs.DensityFn = Sampler, VolumetricSampler, object
+    ut = sys.modules["nerfstudio.utils"]
+    ut.writer = types.SimpleNamespace(put_scalar=lambda **k: None)
+    ut.colormaps = sys.modules["nerfstudio.utils.colormaps"]
+    ut.colormaps.ColormapOptions = object
+    # nerfacc 0.5.2
+    na = sys.modules.get("nerfacc") or _mod("nerfacc")
+
+    class OccGridEstimator(nn.Module):
+        """nerfacc 0.5.2 OccGridEstimator's registered state: persistent buffers ``resolution`` int32 [3], ``aabbs``
+        [levels, 6], ``occs`` [levels * cells], ``binaries`` bool [levels, r, r, r]; non-persistent ``grid_coords``,
+        ``grid_indices`` and AbstractEstimator's ``_dummy``."""
+
+        def __init__(self, roi_aabb, resolution=128, levels=1, **kw):
+            super().__init__()
+            self.register_buffer("_dummy", torch.empty(0), persistent=False)
+            res = torch.tensor([resolution] * 3, dtype=torch.int32)
+            cells = int(resolution) ** 3
+            self.register_buffer("resolution", res)
+            self.register_buffer("aabbs", torch.empty((levels, 6), device="meta"))
+            self.register_buffer("occs", torch.empty((levels * cells,), device="meta"))
+            self.register_buffer("binaries", torch.empty([levels] + [resolution] * 3, dtype=torch.bool, device="meta"))
+            self.register_buffer("grid_coords", torch.empty((cells, 3), dtype=torch.int64, device="meta"), persistent=False)
+            self.register_buffer("grid_indices", torch.empty((cells,), dtype=torch.int64, device="meta"), persistent=False)
+
+    na.OccGridEstimator = OccGridEstimator
+    # torchmetrics / dreifus / distloss: modules without state of their own in this manifest (the real LPIPS carries its
+    # network's weights under ``lpips.net.*`` -- third-party, listed under "upstream_omitted")
+    tm = _mod("torchmetrics")
+    tm.PeakSignalNoiseRatio = type("PeakSignalNoiseRatio", (nn.Module,), {"__init__": lambda self, **k: nn.Module.__init__(self)})
+    _mod("torchmetrics.functional").structural_similarity_index_measure = lambda *a, **k: None
+    _mod("torchmetrics.image")
+    _mod("torchmetrics.image.lpip").LearnedPerceptualImagePatchSimilarity = type(
+        "LearnedPerceptualImagePatchSimilarity", (nn.Module,), {"__init__": lambda self, **k: nn.Module.__init__(self)})
+    _mod("dreifus"), _mod("dreifus.util")
+    _mod("dreifus.util.colormap").apply_scene_flow_colormap = lambda *a, **k: None
+    if "torch_efficient_distloss" not in sys.modules:
+        _mod("torch_efficient_distloss").flatten_eff_distloss = lambda *a, **k: torch.tensor(0.0)
+
+
+class ManifestTCNNModule(nn.Module):
+    """tinycudann ``Module``: ONE flat fp32 ``params`` nn.Parameter -- also when the object has no parameters at all
+    (Identity / Frequency / SphericalHarmonics encodings register an EMPTY one).  Sizes: HashGrid = sum of the level
+    sizes x n_features_per_level; FullyFusedMLP = pad16(in) x W + (hidden - 1) x W x W + W x pad16(out), no biases.
+    Allocated on the ``meta`` device: names, shapes and dtypes are what the manifest records."""
+
+    def _register(self, n_params: int):
+        self.params = nn.Parameter(torch.empty(int(n_params), dtype=torch.float32, device="meta"))
+
+
+def _pad16(n):
+    return (int(n) + 15) // 16 * 16
+
+
+class ManifestEncoding(ManifestTCNNModule):
+    def __init__(self, n_input_dims, encoding_config, **kw):
+        super().__init__()
+        ot = encoding_config["otype"]
+        if ot == "HashGrid":
+            g = oracle.grid_geometry(encoding_config["n_levels"], encoding_config["per_level_scale"],
+                                     encoding_config["base_resolution"], encoding_config["log2_hashmap_size"])
+            self.n_output_dims = encoding_config["n_levels"] * encoding_config["n_features_per_level"]
+            self._register(g.total_entries * encoding_config["n_features_per_level"])
+        elif ot == "Identity":
+            self.n_output_dims = n_input_dims
+            self._register(0)
+        elif ot == "Frequency":
+            self.n_output_dims = n_input_dims * 2 * encoding_config["n_frequencies"]
+            self._register(0)
+        elif ot == "SphericalHarmonics":
+            self.n_output_dims = encoding_config["degree"] ** 2
+            self._register(0)
+        else:
+            raise NotImplementedError(ot)
+
+
+class ManifestNetwork(ManifestTCNNModule):
+    def __init__(self, n_input_dims, n_output_dims, network_config, **kw):
+        super().__init__()
+        assert network_config["otype"] == "FullyFusedMLP"
+        w, nh = network_config["n_neurons"], network_config["n_hidden_layers"]
+        self.n_input_dims, self.n_output_dims = n_input_dims, n_output_dims
+        self._register(_pad16(n_input_dims) * w + (nh - 1) * w * w + w * _pad16(n_output_dims))
+
+
+class ManifestNetworkWithInputEncoding(ManifestNetwork):
+    def __init__(self, n_input_dims, n_output_dims, encoding_config, network_config, **kw):
+        enc = ManifestEncoding(n_input_dims, encoding_config)
+        assert enc.params.numel() == 0, "encoding parameters would be prepended to the network's"
+        super().__init__(enc.n_output_dims, n_output_dims, network_config)
+
+
 def gen_hash_ensemble(out):
     from nersemble.nerfstudio.field_components.hash_ensemble import (HashEnsemble, HashEnsembleConfig,
                                                                      TCNNHashEncodingConfig, posenc_window)
@@ -332,20 +553,7 @@ def gen_misc(out):
 
 
 def gen_distloss_selection(out):
-    # stubs for the model base class imports
-    for sub in ["engine", "engine.callbacks", "models", "models.base_model"]:
-        _mod("nerfstudio." + sub)
-    cb = sys.modules["nerfstudio.engine.callbacks"]
-    cb.TrainingCallbackAttributes = cb.TrainingCallback = cb.TrainingCallbackLocation = object
-    bm = sys.modules["nerfstudio.models.base_model"]
-
-    class Model(nn.Module):
-        pass
-
-    class ModelConfig:
-        pass
-
-    bm.Model, bm.ModelConfig = Model, ModelConfig
+    _install_model_stubs()
     sys.modules["nerfstudio.utils"].writer = types.SimpleNamespace()
     rec = {}
     ted = _mod("torch_efficient_distloss")
@@ -458,7 +666,8 @@ def gen_occupancy_filter(out):
     cc3d.largest_k = largest_k
     if "nerfacc" not in sys.modules:
         _mod("nerfacc")
-    sys.modules["nerfacc"].OccGridEstimator = object
+    if not hasattr(sys.modules["nerfacc"], "OccGridEstimator"):       # (the module-tree stub, if it is installed already)
+        sys.modules["nerfacc"].OccGridEstimator = object
     from nersemble.util.connected_components import extract_top_k_connected_component, filter_occupancy_grid
 
     rng = np.random.default_rng(4242)
@@ -681,10 +890,77 @@ def gen_config_yml(path):
     pathlib.Path(path).write_text(yaml.dump(config))
 
 
+def gen_state_manifest(path):
+    """tests/golden/state_manifest.json: the reference's OWN module tree, instantiated for real --
+    ``NeRSembleNGPModel.populate_modules`` (nersemble_instant_ngp.py:81-179) with ``NeRSembleNeRFactoField``
+    (nersemble_nerfacto_field.py:32-226), ``HashEnsemble`` (hash_ensemble.py:69-91), ``SE3DeformationField``
+    (deformation_field.py:119-131), the two ``nn.Embedding`` tables, ``scene_aabb``, and ``get_param_groups``
+    (:502-514) -- for the configurations of ``train_nersemble.py`` with H = 1, 16 and 32 hash grids.  Recorded per
+    configuration: every ``state_dict()`` key with shape and dtype, in order; every parameter group of
+    ``get_param_groups()`` as the ordered list of parameter NAMES (the order ``torch.optim.Adam.state_dict()`` numbers
+    them in); which entries the reference's own code registers ("reference") and which come from the restated
+    third-party module trees ("upstream-stub": nerfacc's estimator buffers, nerfstudio's ``device_indicator_param``).
+    tcnn objects are the ``Manifest*`` stand-ins above (meta tensors: names / shapes / dtypes only)."""
+    import json
+    _install_model_stubs()
+    tc = sys.modules["tinycudann"]
+    saved = {k: getattr(tc, k, None) for k in ("Encoding", "Network", "NetworkWithInputEncoding")}
+    tc.Encoding, tc.Network, tc.NetworkWithInputEncoding = ManifestEncoding, ManifestNetwork, ManifestNetworkWithInputEncoding
+    try:
+        from nersemble.nerfstudio.field_components.deformation_field import SE3DeformationFieldConfig
+        from nersemble.nerfstudio.field_components.hash_ensemble import HashEnsembleConfig, TCNNHashEncodingConfig
+        from nersemble.nerfstudio.models.nersemble_instant_ngp import NeRSembleNGPModel, NeRSembleNGPModelConfig
+        doc = {"source": "tests/golden/make_golden.py::gen_state_manifest -- the reference's NeRSembleNGPModel instantiated "
+                         "under module-tree stubs of tinycudann / nerfstudio 0.3.1 / nerfacc 0.5.2 / torchmetrics",
+               "upstream_omitted": ["lpips.net.* (torchmetrics LPIPS keeps its pretrained network's weights in the module "
+                                    "tree; a real checkpoint lists them, this manifest cannot)"],
+               "configs": {}}
+        for H, T in ((1, 1), (16, 100), (32, 100)):
+            scene_box = types.SimpleNamespace(aabb=torch.tensor([[-2.5, -1.8, -2.5], [2.2, 1.8, 2.0]]))
+            cfg = NeRSembleNGPModelConfig(
+                # train_nersemble.py:184-241
+                render_step_size=0.011, near_plane=0.2, far_plane=1e3, cone_angle=0, alpha_thre=1e-2, occ_thre=1e-2,
+                early_stop_eps=0, background_color="white", grid_levels=1, disable_scene_contraction=True,
+                max_n_samples_per_batch=2 ** 20, n_timesteps=T, latent_dim_time=H, use_masked_rgb_loss=True,
+                alpha_mask_threshold=0, lambda_alpha_loss=1e-2, lambda_near_loss=1e-4, lambda_empty_loss=1e-2,
+                lambda_depth_loss=1e-4, lambda_dist_loss=1e-4, use_hash_ensemble=True,
+                hash_ensemble_config=HashEnsembleConfig(n_hash_encodings=H, hash_encoding_config=TCNNHashEncodingConfig(),
+                                                        disable_initial_hash_ensemble=True, use_soft_transition=True),
+                use_deformation_field=True, use_separate_deformation_time_embedding=True,
+                deformation_field_config=SE3DeformationFieldConfig(warp_code_dim=128, mlp_num_layers=6,
+                                                                   mlp_layer_width=128),
+                window_hash_encodings_begin=40000, window_hash_encodings_end=80000, window_deform_begin=0,
+                window_deform_end=20000, use_view_frustum_culling=False)
+            model = NeRSembleNGPModel(cfg, scene_box, 12 * T, metadata={"camera_frustums": None})
+            upstream = ("occupancy_grid.", "sampler.occupancy_grid.", "device_indicator_param")
+            state = [{"key": k, "shape": list(v.shape), "dtype": str(v.dtype).replace("torch.", ""),
+                      "origin": "upstream-stub" if k.startswith(upstream) else "reference"}
+                     for k, v in model.state_dict().items()]
+            name_of = {id(p): n for n, p in model.named_parameters()}
+            groups = {g: [name_of[id(p)] for p in ps] for g, ps in model.get_param_groups().items()}
+            trainable = {n: bool(p.requires_grad) for n, p in model.named_parameters()}
+            doc["configs"][f"H{H}"] = {
+                "config": {"n_hash_encodings": H, "latent_dim_time": H, "n_timesteps": T, "log2_hashmap_size": 19,
+                           "warp_code_dim": 128, "num_train_data": 12 * T},
+                "state_dict": state, "param_groups": groups,
+                "requires_grad": trainable}
+        with open(path, "w") as f:
+            json.dump(doc, f, indent=1)
+            f.write("\n")
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                if hasattr(tc, k):
+                    delattr(tc, k)
+            else:
+                setattr(tc, k, v)
+
+
 def main():
     """python tests/golden/make_golden.py [hash_ensemble] [deformation] [deformation_full] [misc] [occupancy_filter] [pixel_sampler] [dataformat]   (default: all)"""
     torch.set_num_threads(4)
-    which = set(sys.argv[1:]) or {"hash_ensemble", "deformation", "deformation_full", "config_yml", "misc", "occupancy_filter", "pixel_sampler", "dataformat"}
+    which = set(sys.argv[1:]) or {"hash_ensemble", "deformation", "deformation_full", "config_yml", "misc", "occupancy_filter", "pixel_sampler", "dataformat",
+                                    "state_manifest"}
     written = []
     if "hash_ensemble" in which:
         a = {}
@@ -726,6 +1002,9 @@ def main():
     if "config_yml" in which:
         gen_config_yml(os.path.join(HERE, "config.yml"))
         written.append("config.yml")
+    if "state_manifest" in which:
+        gen_state_manifest(os.path.join(HERE, "state_manifest.json"))
+        written.append("state_manifest.json")
     for f in written:
         print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")
 

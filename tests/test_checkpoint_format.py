@@ -111,51 +111,207 @@ def test_run_folder_config_yml_and_checkpoint_lookup(tmp_path, golden_dir):
         find_checkpoint(run / "checkpoints", 123)
 
 
-def test_fields_optimizer_state_has_the_reference_shape():
-    """``optimizers['fields']`` of a checkpoint is ONE torch.optim.Adam state dict over ``field.parameters()`` in the
-    reference's registration order (nersemble_nerfacto_field.py:99-172: the C tcnn hash encodings, mlp_base, mlp_head;
-    nerfstudio's ``Optimizers.load_optimizers`` hands it to ``Adam.load_state_dict``).  The natively stepped tables are
-    merged in / split off losslessly; entries of parameter-free tcnn encodings (empty ``params``) that a reference
-    checkpoint may list are ignored; a mismatch raises a clear error."""
-    import pytest
-    import torch
-    from nersemble_amd.engine.trainer import _merge_table_state, _split_table_state
-    C, n_small = 3, 2
-    g = torch.Generator().manual_seed(0)
-    table = {"step": 7, "lr": 4e-3, "exp_avg": [torch.randn(40, generator=g) for _ in range(C)],
-             "exp_avg_sq": [torch.rand(40, generator=g) for _ in range(C)]}
-    small_params = [torch.nn.Parameter(torch.randn(5, generator=g)), torch.nn.Parameter(torch.randn(6, generator=g))]
-    opt = torch.optim.Adam(small_params, lr=5e-3, eps=1e-15)
-    for p in small_params:
-        p.grad = torch.randn(p.shape, generator=g)
-    opt.step()
-    merged = _merge_table_state(table, opt.state_dict())
-    assert merged["param_groups"][0]["params"] == list(range(C + n_small)) and merged["param_groups"][0]["lr"] == 4e-3
-    # the reference side accepts it
-    ref = torch.optim.Adam([torch.nn.Parameter(torch.zeros(40)) for _ in range(C)] +
-                           [torch.nn.Parameter(torch.zeros(5)), torch.nn.Parameter(torch.zeros(6))], lr=5e-3, eps=1e-15)
-    ref.load_state_dict(merged)
-    assert [int(st["step"]) for st in ref.state.values()] == [7, 7, 7, 1, 1]
-    # and what the reference writes comes back apart
-    tab, small = _split_table_state(ref.state_dict(), C, n_small, "fields")
-    assert tab["step"] == 7 and all(torch.equal(a, b) for a, b in zip(tab["exp_avg"], table["exp_avg"]))
-    assert small["param_groups"][0]["params"] == [0, 1] and torch.equal(small["state"][1]["exp_avg"],
-                                                                         opt.state_dict()["state"][1]["exp_avg"])
-    # a reference file with the empty `params` of tcnn's Identity / Frequency encodings in the list
-    sd = ref.state_dict()
-    e = {"step": torch.tensor(7.0), "exp_avg": torch.zeros(0), "exp_avg_sq": torch.zeros(0)}
-    shifted = {0: e}
-    for i, st in sd["state"].items():
-        shifted[i + 1 + (i >= C)] = st
-    shifted[C + 1] = dict(e)
-    sd2 = {"state": shifted, "param_groups": [dict(sd["param_groups"][0], params=list(range(C + n_small + 2)))]}
-    tab2, small2 = _split_table_state(sd2, C, n_small, "fields")
-    assert all(torch.equal(a, b) for a, b in zip(tab2["exp_avg_sq"], table["exp_avg_sq"])) and set(small2["state"]) == {0, 1}
-    # before the first step there are no moments
-    tab0, _ = _split_table_state(_merge_table_state(dict(table, step=0), opt.state_dict()), C, n_small, "fields")
-    assert tab0["step"] == 0 and tab0["exp_avg"] is None
-    with pytest.raises(KeyError, match="hash encodings"):
-        _split_table_state(merged, C + 1, n_small, "fields")
+# ---- the reference's own module tree (tests/golden/state_manifest.json, generated by make_golden.py::gen_state_manifest
+# from NeRSembleNGPModel.populate_modules / get_param_groups of the reference under module-tree stubs) --------------------
+def _manifest(golden_dir, H):
+    import json
+    with open(f"{golden_dir}/state_manifest.json") as f:
+        return json.load(f)["configs"][f"H{H}"]
+
+
+def _full_size_model(entry):
+    from nersemble_amd.models.nersemble_instant_ngp import NeRSembleNGPModel
+    from nersemble_amd.rays import SceneBox
+    from nersemble_amd.workloads import SCENE_BOXES, build_model_config
+    c = entry["config"]
+    cfg = build_model_config(dict(H=c["n_hash_encodings"], T=c["n_timesteps"], disable_occ=False, lambda_dist=1e-4,
+                                  win=(40000, 80000)))
+    cfg.use_view_frustum_culling = False
+    assert cfg.hash_ensemble_config.hash_encoding_config.log2_hashmap_size == c["log2_hashmap_size"]
+    return NeRSembleNGPModel(cfg, SceneBox(torch.tensor(SCENE_BOXES[30], dtype=torch.float32)),
+                             num_train_data=c["num_train_data"])
+
+
+def _expanded_group_names(model, group):
+    """Names of a parameter group's members in order, the native ``tables`` standing for its C tcnn encodings."""
+    name_of = {id(p): n for n, p in model.named_parameters()}
+    out = []
+    for p in group:
+        n = name_of[id(p)]
+        if n.endswith("hash_ensemble.tables"):
+            out += [n[:-len("tables")] + f"hash_encodings.{c}.params" for c in range(model.field.hash_ensemble.n_tcnn_encodings)]
+        else:
+            out.append(n)
+    return out
+
+
+import pytest
+
+
+@pytest.mark.parametrize("H", [1, 16])          # (H = 32 -- 403 M parameters -- runs with the GPU tests)
+def test_state_dict_and_param_groups_equal_the_reference_manifest(H, golden_dir):
+    """f3 pinned to the reference itself: every key / shape / dtype of ``NeRSembleNGPModel.state_dict()`` at the
+    reference's table size, and the membership AND ORDER of every optimizer group, equal what the reference's own
+    ``populate_modules`` / ``get_param_groups`` produce (nersemble_instant_ngp.py:81-179, :502-514;
+    nersemble_nerfacto_field.py:99-172; hash_ensemble.py:84-91; deformation_field.py:50-69,129-131)."""
+    entry = _manifest(golden_dir, H)
+    model = _full_size_model(entry)
+    got = {k: (list(v.shape), str(v.dtype).replace("torch.", "")) for k, v in model.state_dict().items()}
+    want = {e["key"]: (e["shape"], e["dtype"]) for e in entry["state_dict"]}
+    assert set(got) == set(want), (sorted(set(got) - set(want)), sorted(set(want) - set(got)))
+    for k in want:
+        assert got[k] == want[k], (k, got[k], want[k])
+    groups = model.get_param_groups()
+    assert list(groups) == list(entry["param_groups"])
+    for g, names in entry["param_groups"].items():
+        assert _expanded_group_names(model, groups[g]) == names, g
+    for n, p in model.named_parameters():
+        if n in entry["requires_grad"]:
+            assert p.requires_grad == entry["requires_grad"][n], n
+
+
+def _small_trainer(seed=0):
+    from nersemble_amd.workloads import build_workload
+    torch.manual_seed(seed)
+    trainer, _, _ = build_workload("p030_h16", device="cpu", small=True, n_rays=64)
+    return trainer
+
+
+def _fake_training_state(trainer, seed=0):
+    """Moments and step counts as after some steps (the native table step needs the GPU; the wire format does not)."""
+    g = torch.Generator().manual_seed(seed)
+    topt = trainer.optimizers[trainer.group_of_tables()]
+    st = topt._state()
+    st["step"] = 7
+    st["exp_avg"].copy_(torch.randn(st["exp_avg"].shape, generator=g) * 1e-3)
+    st["exp_avg_sq"].copy_(torch.rand(st["exp_avg_sq"].shape, generator=g) * 1e-6)
+    Hn = trainer.model.field.hash_ensemble.n_hash_encodings
+    st["exp_avg"][:, :, Hn:] = 0                # (padding grids hold no state)
+    st["exp_avg_sq"][:, :, Hn:] = 0
+    for key, opt in trainer.optimizers.items():
+        if key.endswith("/tables"):
+            continue
+        for p in (p for pg in opt.param_groups for p in pg["params"]):
+            if key == "embeddings" and p is trainer.model.time_embedding.weight:
+                continue                         # (no gradient before the window opens: no Adam state, as in torch)
+            p.grad = torch.randn(p.shape, generator=g)
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+
+
+def _reference_side_adam(trainer, group):
+    """What nerfstudio builds on the reference side: ``torch.optim.Adam(list(group parameters))`` with one flat tensor per
+    tcnn encoding (shapes of this model's twin in the reference's layout)."""
+    he = trainer.model.field.hash_ensemble
+    per_enc = he.geom.total_entries * (8 if 2 * he.n_hash_encodings >= 8 else 2 * he.n_hash_encodings)
+    params = []
+    for kind, x in trainer.group_layout[group]:
+        params.append(torch.nn.Parameter(torch.zeros(per_enc) if kind == "table" else torch.zeros(tuple(x.shape))))
+    return torch.optim.Adam(params, lr=1.0, eps=1e-15)
+
+
+def test_optimizer_state_travels_both_ways_in_the_reference_numbering(golden_dir):
+    """``optimizers[group]`` of a checkpoint is ONE ``torch.optim.Adam.state_dict()`` per group of ``get_param_groups`` in the
+    reference's numbering (nerfstudio's ``Optimizers.load_optimizers`` hands it to ``Adam.load_state_dict``): ``fields`` has
+    C + 4 members -- ``direction_encoding.params`` (empty), the C hash encodings, ``position_encoding.params`` (empty),
+    ``mlp_base``, ``mlp_head`` -- ``deformation_field`` starts with the frozen ``aabb``; members that never get a
+    gradient are listed in ``param_groups`` and have NO state entry.  (a) what this trainer writes loads into the
+    reference-side Adam objects; (b) what those write -- a genuine reference layout -- loads into a second trainer, and
+    moments / steps / learning rates arrive where they belong."""
+    a = _small_trainer(1)
+    _fake_training_state(a, 3)
+    entry = _manifest(golden_dir, 16)
+    sd = a.state_dict()["optimizers"]
+    assert sorted(sd) == sorted(entry["param_groups"])
+    C = a.model.field.hash_ensemble.n_tcnn_encodings
+    ref_files = {}
+    for group, names in entry["param_groups"].items():
+        assert sd[group]["param_groups"][0]["params"] == list(range(len(names))), group
+        no_grad = [i for i, (kind, _) in enumerate(a.group_layout[group]) if kind == "none"]
+        assert no_grad == [i for i, n in enumerate(names)
+                           if n.endswith(("direction_encoding.params", "position_encoding.params", "deformation_field.aabb"))]
+        assert not (set(no_grad) & set(sd[group]["state"]))
+        ref = _reference_side_adam(a, group)
+        ref.load_state_dict(sd[group])                                  # (a) the reference side accepts it
+        ref_files[group] = ref.state_dict()                            # what a reference run would write back
+        assert set(ref_files[group]["state"]) == set(sd[group]["state"])
+    f = ref_files["fields"]
+    assert len(f["param_groups"][0]["params"]) == C + 4 and 0 not in f["state"] and C + 1 not in f["state"]
+    assert [int(f["state"][i]["step"]) for i in range(1, C + 1)] == [7] * C
+    assert 0 not in ref_files["deformation_field"]["state"] and len(ref_files["deformation_field"]["param_groups"][0]["params"]) == 17
+    assert set(ref_files["embeddings"]["state"]) == {1}                 # time_embedding.weight has not started
+    b = _small_trainer(2)
+    b.load_state_dict({"optimizers": ref_files, "schedulers": {}, "scalers": {}})         # (b)
+    ta, tb = a.optimizers[a.group_of_tables()], b.optimizers[b.group_of_tables()]
+    assert tb._state()["step"] == 7
+    assert torch.equal(ta._state()["exp_avg"], tb._state()["exp_avg"])
+    assert torch.equal(ta._state()["exp_avg_sq"], tb._state()["exp_avg_sq"])
+    for key in ("fields", "embeddings", "deformation_field"):
+        pa = [p for pg in a.optimizers[key].param_groups for p in pg["params"]]
+        pb = [p for pg in b.optimizers[key].param_groups for p in pg["params"]]
+        assert len(pa) == len(pb)
+        for x, y in zip(pa, pb):
+            sa, sb_ = a.optimizers[key].state.get(x, {}), b.optimizers[key].state.get(y, {})
+            assert set(sa) == set(sb_)
+            for k in sa:
+                assert torch.equal(torch.as_tensor(sa[k]), torch.as_tensor(sb_[k])), (key, k)
+    # a file that holds moments where this model has a member without a gradient is another layout: refused
+    bad = {k: {"state": dict(v["state"]), "param_groups": v["param_groups"]} for k, v in ref_files.items()}
+    bad["fields"]["state"][0] = {"step": torch.tensor(1.0), "exp_avg": torch.zeros(5), "exp_avg_sq": torch.zeros(5)}
+    with pytest.raises(KeyError, match="never has a gradient"):
+        _small_trainer(3).load_state_dict({"optimizers": bad})
+
+
+def test_checkpoints_of_earlier_rounds_still_load():
+    """Round 3 numbered the ``fields`` group as the C encodings + the two MLPs (no empty encodings) and the deformation
+    group without its ``aabb``; round 2 kept the tables under ``fields/tables: {native_table_adam: ...}``."""
+    a = _small_trainer(1)
+    _fake_training_state(a, 5)
+    sd = a.state_dict()["optimizers"]
+    C = a.model.field.hash_ensemble.n_tcnn_encodings
+
+    def drop(group_sd, positions):
+        keep = [i for i in group_sd["param_groups"][0]["params"] if i not in positions]
+        renum = {old: new for new, old in enumerate(keep)}
+        return {"state": {renum[i]: st for i, st in group_sd["state"].items() if i in renum},
+                "param_groups": [dict(group_sd["param_groups"][0], params=list(range(len(keep))))]}
+
+    r3 = {"fields": drop(sd["fields"], {0, C + 1}), "embeddings": sd["embeddings"],
+          "deformation_field": drop(sd["deformation_field"], {0})}
+    b = _small_trainer(2)
+    b.load_state_dict({"optimizers": r3})
+    ta, tb = a.optimizers[a.group_of_tables()], b.optimizers[b.group_of_tables()]
+    assert tb._state()["step"] == 7 and torch.equal(ta._state()["exp_avg"], tb._state()["exp_avg"])
+    x = [p for pg in a.optimizers["deformation_field"].param_groups for p in pg["params"]][3]
+    y = [p for pg in b.optimizers["deformation_field"].param_groups for p in pg["params"]][3]
+    assert torch.equal(a.optimizers["deformation_field"].state[x]["exp_avg"], b.optimizers["deformation_field"].state[y]["exp_avg"])
+    # round 2
+    r2 = dict(r3)
+    small_only = drop(sd["fields"], set(range(C + 2)))
+    r2["fields"] = small_only
+    r2["fields/tables"] = {"native_table_adam": ta.table_state()}
+    c = _small_trainer(3)
+    c.load_state_dict({"optimizers": r2})
+    tc = c.optimizers[c.group_of_tables()]
+    assert tc._state()["step"] == 7 and torch.equal(ta._state()["exp_avg_sq"], tc._state()["exp_avg_sq"])
+    with pytest.raises(KeyError, match="reference's numbering"):
+        _small_trainer(4).load_state_dict({"optimizers": dict(r3, fields=drop(sd["fields"], {0, 1, 2}))})
+
+
+def test_checkpoint_keys_are_the_manifests(golden_dir):
+    """``nerfstudio_checkpoint_from_model`` writes ``_model.`` + exactly the reference's key set (small tables here: the
+    names do not depend on the table size) and a resumed trainer continues from it."""
+    from nersemble_amd.util.checkpoint import resume_trainer_from_checkpoint
+    a = _small_trainer(1)
+    _fake_training_state(a, 9)
+    ckpt = nerfstudio_checkpoint_from_model(a.model, 77, trainer=a)
+    want = {"_model." + e["key"] for e in _manifest(golden_dir, 16)["state_dict"]}
+    assert set(ckpt["pipeline"]) == want
+    b = _small_trainer(2)
+    assert resume_trainer_from_checkpoint(ckpt, b) == 77
+    for (k, v), (_, w) in zip(a.model.state_dict().items(), b.model.state_dict().items()):
+        assert torch.equal(v, w), k
+    assert b.optimizers[b.group_of_tables()]._state()["step"] == 7
 
 
 def test_config_loader_constructs_nothing_a_file_names(tmp_path):

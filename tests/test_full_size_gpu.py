@@ -143,7 +143,7 @@ def test_chunk_boundary_of_max_n_samples_per_batch(cuda):
 
 
 @pytest.mark.parametrize("name", ["p030_h32", "p124_dp", "p097_dense"])
-def test_full_size_training_steps(name, cuda):
+def test_full_size_training_steps(name, cuda, golden_dir):
     """Reference-size tables, 4096 rays: a few complete training iterations (march, sigma pass, fields, compositing, all
     losses, backward, GradScaler, Adam on every group) -- finite, learning, sample counts in the expected range."""
     from nersemble_amd.workloads import WORKLOADS, build_workload
@@ -162,5 +162,37 @@ def test_full_size_training_steps(name, cuda):
     else:
         assert 2e5 < max(samples) <= 4096 * 700
     he = trainer.model.field.hash_ensemble
-    assert torch.equal(he.half_tables(), he.tables.detach().half())
     assert trainer.grad_scaler.get_scale() == 65536.0              # no overflow skipped a step
+    if name == "p030_h32":
+        _check_against_reference_manifest(trainer, golden_dir)
+    trainer.consolidate()                                           # (the compact first-grid phase holds grid 0 apart)
+    assert torch.equal(he.half_tables(), he.tables.detach().half())
+
+
+def _check_against_reference_manifest(trainer, golden_dir):
+    """SURVEY 8 f3 at the reference's size (H = 32, 403 M parameters): the trained model's ``state_dict()``, the trainer's
+    parameter groups and the checkpoint it writes equal tests/golden/state_manifest.json -- the reference's own module tree
+    -- key for key, shape for shape, group member for group member; the optimizer state of the natively stepped tables
+    arrives as the 8 tcnn encodings' flat moments with torch's per-parameter step."""
+    import json
+    from nersemble_amd.util.checkpoint import nerfstudio_checkpoint_from_model
+    with open(f"{golden_dir}/state_manifest.json") as f:
+        entry = json.load(f)["configs"]["H32"]
+    model = trainer.model
+    ckpt = nerfstudio_checkpoint_from_model(model, 8, trainer=trainer)
+    got = {k: (list(v.shape), str(v.dtype).replace("torch.", "")) for k, v in ckpt["pipeline"].items()}
+    want = {"_model." + e["key"]: (e["shape"], e["dtype"]) for e in entry["state_dict"]}
+    assert got == want, sorted(set(got) ^ set(want))
+    assert {g: len(v) for g, v in trainer.group_layout.items()} == {g: len(v) for g, v in entry["param_groups"].items()}
+    fields = ckpt["optimizers"]["fields"]
+    names = entry["param_groups"]["fields"]
+    assert fields["param_groups"][0]["params"] == list(range(len(names))) and len(names) == 12
+    for i, n in enumerate(names):
+        if n.endswith(("direction_encoding.params", "position_encoding.params")):
+            assert i not in fields["state"]
+        else:
+            st = fields["state"][i]
+            assert int(st["step"]) == 8 and st["exp_avg"].dtype == torch.float32
+            assert list(st["exp_avg"].shape) == dict((e["key"], e["shape"]) for e in entry["state_dict"])[n]
+    assert 0 not in ckpt["optimizers"]["deformation_field"]["state"]            # the frozen aabb
+    assert len(ckpt["optimizers"]["deformation_field"]["state"]) == 16

@@ -229,15 +229,34 @@ def test_tcnn_shaped_hashgrid_encoding(F_enc, cuda):
     out = enc(xt)
     want = ohg.hashgrid_fwd(x, tab.view(np.uint16), go).astype(np.float32)
     assert (np.abs(out.float().detach().cpu().numpy() - want) <= FP16_EPS * np.abs(want) + 1e-6).all()
-    # gradients through the ensemble oracle with H = F_enc/2 grids, unit codes
+    # gradients, value by value, through the ensemble oracle: an encoding with F_enc features per level IS the
+    # HashEnsemble of H = F_enc / 2 grids (tcnn feature j = p * 2 + f of level l belongs to grid p, hash_ensemble.py:110-112),
+    # so one oracle backward per grid p with the one-hot code e_p and that grid's two columns of dout gives the table
+    # gradient per entry (only grid p's features are touched) and its share of dL/dx; their sums are what the operator
+    # must return.  A wrong corner weight, a swapped feature plane or a swapped level changes single entries.
     H = F_enc // 2
-    dout = rng.standard_normal((B, kw["n_levels"] * F_enc)).astype(np.float16)
+    L = kw["n_levels"]
+    dout = rng.standard_normal((B, L * F_enc)).astype(np.float16)
     out.backward(torch.from_numpy(dout).to(cuda))
-    # reference: finite-sum identity  sum(dtable * T) == sum(dout * out)
-    lhs = float((enc.params.grad.double() * enc.params.detach().double()).sum())
-    rhs = float((torch.from_numpy(dout).double() * torch.from_numpy(want).double()).sum())
-    assert abs(lhs - rhs) <= 2e-3 * max(1.0, abs(rhs))
-    assert torch.isfinite(xt.grad).all() and xt.grad.abs().max().item() > 0
+    d3 = dout.astype(np.float32).reshape(B, L, H, 2)
+    dtab_want = np.zeros((go.total_entries, F_enc), dtype=np.float64)
+    dx_want = np.zeros((B, 3), dtype=np.float64)
+    for p in range(H):
+        code = np.zeros((B, H), dtype=np.float32)
+        code[:, p] = 1.0
+        dtab_p, _, dx_p = ohg.ensemble_bwd(x, tab.view(np.uint16)[None], H, go, code,
+                                           np.ascontiguousarray(d3[:, :, p, :]).reshape(B, L * 2))
+        others = [j for j in range(F_enc) if j // 2 != p]
+        assert not dtab_p[0][:, others].any()                   # (the oracle's own layout: grid p <-> features 2p, 2p+1)
+        dtab_want += dtab_p[0]
+        dx_want += dx_p
+    dtab = enc.params.grad.view(go.total_entries, F_enc).cpu().numpy()
+    sc = np.abs(dtab_want).max()
+    assert np.abs(dtab - dtab_want).max() <= 2e-5 * sc + 1e-7, float(np.abs(dtab - dtab_want).max() / sc)
+    assert (np.abs(dtab_want) > 1e-3 * sc).sum() > 1000          # a gradient that exercises every level
+    dx = xt.grad.cpu().numpy()
+    assert np.abs(dx - dx_want).max() <= 5e-5 * np.abs(dx_want).max() + 1e-6, \
+        float(np.abs(dx - dx_want).max() / np.abs(dx_want).max())
 
 
 def test_reference_layout_ensemble_from_tcnn_encodings_matches_fused(cuda):

@@ -92,3 +92,72 @@ def test_mlp_head_backward_segments(cuda):
     assert (np.abs(db[:, 1:] - dx_o[:, 3:18]) <= 2.0 ** -10 * np.abs(dx_o[:, 3:18]) + 5e-4 * sc).all()      # fp16 output
     assert np.abs(dt.grad.cpu().numpy() - 0.5 * dx_o[:, :3]).max() <= 5e-4 * sc
     assert np.abs(pt.grad.cpu().numpy() - dW_o).max() <= 5e-4 * np.abs(dW_o).max()
+
+
+# ---- through the operator-level drop-in: tcnn.Network / tcnn.NetworkWithInputEncoding (flat [out][in] ``params``) ----
+# Reference call sites: mlp_base = tcnn.NetworkWithInputEncoding(32 -> 16, Identity encoding, 1 hidden layer, no output
+# activation; nersemble_nerfacto_field.py:142-153), mlp_head = tcnn.Network(3 + 15 -> 3, 2 hidden layers, Sigmoid;
+# :162-172).  The module is driven the way the reference drives it: ``module(x)`` on fp16 / fp32 inputs, gradients read from
+# ``module.params.grad`` and ``x.grad``.
+def _module(kind, cuda):
+    from nersemble_amd import tcnn
+    if kind == "base":
+        net = tcnn.NetworkWithInputEncoding(
+            n_input_dims=32, n_output_dims=16, encoding_config={"otype": "Identity", "n_dims_to_encode": 32},
+            network_config={"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": "None", "n_neurons": 64,
+                            "n_hidden_layers": 1})
+        return net.to(cuda), 0, 32, 16, 0
+    net = tcnn.Network(n_input_dims=18, n_output_dims=3,
+                       network_config={"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": "Sigmoid",
+                                       "n_neurons": 64, "n_hidden_layers": 2})
+    return net.to(cuda), 1, 18, 3, 1
+
+
+@pytest.mark.parametrize("kind", ["base", "head"])
+@pytest.mark.parametrize("in_dtype", [torch.float16, torch.float32])
+@pytest.mark.parametrize("B", [1, 96, 1001])
+def test_tcnn_network_module_forward_and_backward(kind, in_dtype, B, cuda):
+    net, nh, in_dim, n_out, act = _module(kind, cuda)
+    assert net.params.dtype == torch.float32 and net.params.dim() == 1 and net.params.numel() == omlp.param_count(nh)
+    assert net.n_output_dims == n_out
+    p = _params(nh, 77 + nh)
+    with torch.no_grad():
+        net.params.copy_(torch.from_numpy(p))
+    rng = np.random.default_rng(1000 * nh + B)
+    x = rng.standard_normal((B, in_dim)).astype(np.float16)           # (fp16-representable either way)
+    dout = rng.standard_normal((B, n_out)).astype(np.float16)
+    xt = torch.from_numpy(x).to(cuda).to(in_dtype).requires_grad_(True)
+    out = net(xt)
+    assert out.dtype == torch.float16 and out.shape == (B, n_out)
+    want = omlp.mlp_fwd(x, p, nh, n_out, act).astype(np.float32)
+    tol = 4 * 2.0 ** -10 * max(1.0, np.abs(want).max())
+    assert np.abs(out.float().detach().cpu().numpy() - want).max() <= tol
+    out.backward(torch.from_numpy(dout).to(cuda))
+    dW_o, dx_o = omlp.mlp_bwd(x, p, nh, n_out, act, dout.astype(np.float64), round_dz=True)
+    dW = net.params.grad.cpu().numpy()
+    assert dW.shape == dW_o.shape
+    assert np.abs(dW - dW_o).max() <= 5e-4 * np.abs(dW_o).max() + 1e-6, float(np.abs(dW - dW_o).max() / np.abs(dW_o).max())
+    assert xt.grad.dtype == in_dtype
+    dx = xt.grad.float().cpu().numpy()
+    d = np.abs(dx - dx_o[:, :in_dim])
+    assert (d <= 2.0 ** -10 * np.abs(dx_o[:, :in_dim]) + 5e-4 * np.abs(dx_o).max() + 1e-6).all(), \
+        float(d.max() / np.abs(dx_o).max())
+
+
+def test_tcnn_network_params_are_row_major_out_in(cuda):
+    """A single non-zero weight W0[n][i] (flat index n * 32 + i) connects input i to hidden unit n, and Wo[o][n] (flat
+    index 64 * 32 + o * 64 + n) connects hidden unit n to output o -- tcnn's flat [out][in] layout of the state dict's
+    ``params``; a transposed reading would route the signal elsewhere."""
+    net, nh, in_dim, n_out, act = _module("base", cuda)
+    n, i, o = 37, 5, 11
+    p = np.zeros(omlp.param_count(0), dtype=np.float32)
+    p[n * 32 + i] = 0.5
+    p[64 * 32 + o * 64 + n] = 2.0
+    with torch.no_grad():
+        net.params.copy_(torch.from_numpy(p))
+    x = np.zeros((4, 32), dtype=np.float16)
+    x[:, i] = [1.0, 2.0, -1.0, 0.25]
+    out = net(torch.from_numpy(x).to(cuda)).float().cpu().numpy()
+    want = np.zeros((4, 16), dtype=np.float32)
+    want[:, o] = [1.0, 2.0, 0.0, 0.25]                               # relu(0.5 x) * 2
+    assert np.array_equal(out, want)

@@ -224,3 +224,37 @@ def test_cpu_baseline_port_matches_the_checker(H):
     b = ohg.ensemble_fwd_fast(x, tabs.view(np.uint16), H, g, codew).astype(np.float32)
     ulp = np.maximum(np.abs(a), 2.0 ** -14) * 2.0 ** -10
     assert (np.abs(a - b) <= 1.01 * ulp).all(), np.abs(a - b).max()
+
+
+@pytest.mark.parametrize("F_enc", [2, 4, 8])
+def test_single_encoding_backward_is_the_sum_of_one_hot_ensemble_backwards(F_enc):
+    """What tests/test_hash_ensemble_gpu.py::test_tcnn_shaped_hashgrid_encoding holds ``nsx_hashgrid_bwd`` to: the table
+    gradient of ONE tcnn HashGrid encoding with F_enc features per level, built from ``ensemble_bwd`` with H = F_enc / 2
+    grids and one-hot codes, equals the direct scatter of (trilinear corner weight x dout) through the oracle's own
+    indices / weights -- entry by entry."""
+    kw = SMALL_GEOM_KW
+    go = oracle.grid_geometry(**kw)
+    rng = np.random.default_rng(F_enc)
+    tab = ((rng.random((go.total_entries, F_enc), dtype=np.float32) - 0.5)).astype(np.float16)
+    B, H, L = 257, F_enc // 2, kw["n_levels"]
+    x = rng.random((B, 3), dtype=np.float32)
+    dout = rng.standard_normal((B, L * F_enc)).astype(np.float16).astype(np.float32)
+    d3 = dout.reshape(B, L, H, 2)
+    got = np.zeros((go.total_entries, F_enc))
+    for p in range(H):
+        code = np.zeros((B, H), dtype=np.float32)
+        code[:, p] = 1.0
+        dtab_p, _, _ = ohg.ensemble_bwd(x, tab.view(np.uint16)[None], H, go, code,
+                                        np.ascontiguousarray(d3[:, :, p, :]).reshape(B, L * 2))
+        got += dtab_p[0]
+    idx, w = ohg.indices(x, go)
+    want = np.zeros((go.total_entries, F_enc))
+    offs = np.array(go.offset[:L + 1])
+    dl = dout.astype(np.float64).reshape(B, L, F_enc)
+    for l in range(L):
+        for c in range(8):
+            wc = np.ones(B)
+            for d in range(3):
+                wc *= w[:, l, d] if (c >> d) & 1 else (1 - w[:, l, d])
+            np.add.at(want, offs[l] + idx[:, l, c], wc[:, None] * dl[:, l, :])
+    assert np.abs(got - want).max() <= 1e-6 * np.abs(want).max()
