@@ -13,34 +13,58 @@ import torch.distributed as dist
 SMALL_BUCKET_ELEMS = 1 << 22
 
 
-def all_reduce_gradients(params: Iterable[torch.nn.Parameter], world_size: int, group=None) -> None:
-    """In-place average of ``p.grad`` over all ranks.  Parameters without a gradient contribute zeros (every rank
-    must join every collective)."""
+def all_reduce_gradients(params: Iterable[torch.nn.Parameter], world_size: int, group=None):
+    """In-place average of ``p.grad`` over all ranks.  A parameter without a gradient on this rank contributes zeros
+    (every rank must join every collective) and is left WITHOUT a gradient afterwards: an optimizer must not count a step
+    for it -- ``torch.optim.Adam`` keeps ``step`` per parameter and creates it with the first real gradient
+    (``time_embedding.weight`` starts when the coarse-to-fine window opens, train_nersemble.py:77-78: its first update
+    then takes the bias corrections of step 1 on one GPU and must do so on eight).  Which parameters take part in a step
+    follows from the configuration and the schedule, the same on every rank; that this holds is CHECKED: the number of
+    ranks that held a gradient travels in the same bucket, and the returned tensor (``[len(params)]``, device) must read 0
+    or ``world_size`` everywhere -- the trainer looks at it one step late, off the critical path
+    (``NeRSembleTrainer.flush_scheduler_step``).  Returns None for a single process."""
     if world_size <= 1:
-        return
+        return None
     params = [p for p in params if p.requires_grad]
-    for p in params:
-        if p.grad is None:
+    if not params:
+        return None
+    absent = [p.grad is None for p in params]
+    for p, a in zip(params, absent):
+        if a:
             p.grad = torch.zeros_like(p)
     big = [p for p in params if p.grad.numel() >= SMALL_BUCKET_ELEMS]
     small = [p for p in params if p.grad.numel() < SMALL_BUCKET_ELEMS]
     handles = [dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, group=group, async_op=True) for p in big]
-    flat = None
-    if small:
-        flat = torch.cat([p.grad.reshape(-1).float() for p in small])
-        handles.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=True))
+    dev = params[0].grad.device
+    presence = torch.tensor([0.0 if a else 1.0 for a in absent], dtype=torch.float32).to(dev, non_blocking=True)
+    flat = torch.cat([p.grad.reshape(-1).float() for p in small] + [presence])
+    handles.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=True))
     for h in handles:
         h.wait()
     inv = 1.0 / world_size
     for p in big:
         p.grad.mul_(inv)
-    if small:
-        flat.mul_(inv)
-        off = 0
-        for p in small:
-            n = p.grad.numel()
-            p.grad.copy_(flat[off:off + n].view_as(p.grad))
-            off += n
+    counts = flat[flat.numel() - len(params):].clone()
+    flat.mul_(inv)
+    off = 0
+    for p in small:
+        n = p.grad.numel()
+        p.grad.copy_(flat[off:off + n].view_as(p.grad))
+        off += n
+    for p, a in zip(params, absent):
+        if a:
+            p.grad = None                   # (zeros went into the sum; the parameter itself did not take part in the step)
+    return counts
+
+
+def check_gradient_presence(counts, world_size: int) -> None:
+    """``counts``: what ``all_reduce_gradients`` returned, on the host.  Every parameter must have had a gradient on all
+    ranks or on none."""
+    bad = [i for i, c in enumerate(counts) if c not in (0.0, float(world_size))]
+    if bad:
+        raise RuntimeError(f"data-parallel step: parameters {bad} (positions in the all-reduced list) received a gradient on "
+                           f"{[counts[i] for i in bad]} of {world_size} ranks -- the ranks ran different graphs; per-parameter "
+                           f"Adam step counts would diverge")
 
 
 def global_normaliser_scales(local_counts: torch.Tensor, n_eff_local: torch.Tensor, n_rays_local: int,

@@ -13,7 +13,7 @@ import torch.distributed as dist
 
 from ..models.nersemble_instant_ngp import NeRSembleNGPModel
 from .hash_adam import HashTableAdam, NativeGradScaler
-from .parallel import all_reduce_gradients
+from .parallel import all_reduce_gradients, check_gradient_presence
 from .sharded_adam import ShardedTableAdam
 from .small_adam import SmallGroupAdam, adam_groups, unscale_and_check_groups
 from ..rays import RayBundle
@@ -142,6 +142,7 @@ class NeRSembleTrainer:
         self.grad_scaler = NativeGradScaler(device, enabled=mixed_precision)
         self.callbacks = model.get_training_callbacks()
         self._pending, self._found_host, self._found_event = None, None, None
+        self._presence, self._presence_host = None, None      # data-parallel: ranks per parameter that held a gradient
         # the table optimizer's 12 GB pass runs beside the rest of the step's tail and the next step's ray marching
         self._opt_stream = torch.cuda.Stream(device) if (overlap_table_adam and device.type == "cuda") else None
         self._found_groups = []
@@ -169,7 +170,7 @@ class NeRSembleTrainer:
                 opt.ensure_reduce_started()
         params = [p for opt in self.optimizers.values() if not isinstance(opt, ShardedTableAdam)
                   for pg in opt.param_groups for p in pg["params"]]
-        all_reduce_gradients(params, self.world_size)
+        self._presence = all_reduce_gradients(params, self.world_size)
 
     def _arm_early_table_step(self):
         """Single GPU, fused main pass: let the table optimizer start from inside the backward (HashTableAdam.
@@ -302,11 +303,17 @@ class NeRSembleTrainer:
         """found_all: one inf/NaN flag per parameter group (device)."""
         if not found_all.is_cuda:
             self._pending = ("host", found_all.clone())
+            self._presence_host, self._presence = (self._presence.clone() if self._presence is not None else None), None
             return
         if self._found_host is None or self._found_host.numel() != found_all.numel():
             self._found_host = torch.empty((found_all.numel(),), dtype=torch.float32).pin_memory()
             self._found_event = torch.cuda.Event()
         self._found_host.copy_(found_all, non_blocking=True)
+        if self._presence is not None:
+            if self._presence_host is None or self._presence_host.numel() != self._presence.numel():
+                self._presence_host = torch.empty((self._presence.numel(),), dtype=torch.float32).pin_memory()
+            self._presence_host.copy_(self._presence, non_blocking=True)
+            self._presence = None
         self._found_event.record()
         self._pending = ("pinned", None)
 
@@ -385,6 +392,8 @@ class NeRSembleTrainer:
             flags = self._found_host.tolist()
         else:
             flags = val.tolist()
+        if self.world_size > 1 and self._presence_host is not None:
+            check_gradient_presence(self._presence_host.tolist(), self.world_size)
         # the native table optimizers count their step on the host before the device decides to skip it: take the
         # count back for the groups that skipped (torch's fused Adam does the same with _foreach_sub_(steps, found_inf))
         for key, opt in self.optimizers.items():

@@ -47,7 +47,16 @@ class NeRSembleVolumetricSampler(nn.Module):
         density_fn = self.density_fn
         ray_ts = None
         if times is not None and origins.is_cuda and getattr(density_fn, "accepts_timesteps", False):
-            if ray_timesteps is not None and ray_timesteps.numel() == origins.shape[0]:
+            # the reference's priority: the rays' ``times`` decide (``round(times * (T - 1))``, nersemble_instant_ngp.py:249;
+            # the main pass does the same, :300-318).  Timesteps that travel as metadata are trusted only after they have
+            # been SEEN to agree with the rounded times (first call, then every 256th: one small comparison with a host
+            # read) -- a dataparser with start_timestep / skip_timesteps carries original frame ids there, not indices
+            have_md = ray_timesteps is not None and ray_timesteps.numel() == origins.shape[0]
+            n = self._md_timestep_checks = getattr(self, "_md_timestep_checks", -1) + 1
+            if have_md and self.timestep_fn is not None and n % 256 == 0:
+                rounded = self.timestep_fn(times).reshape(-1).to(torch.int32)
+                self._md_timesteps_agree = bool(torch.equal(rounded, ray_timesteps.reshape(-1).to(torch.int32)))
+            if have_md and (self.timestep_fn is None or getattr(self, "_md_timesteps_agree", False)):
                 ray_ts = ray_timesteps.reshape(-1).to(torch.int32).contiguous()
             elif self.timestep_fn is not None:
                 ray_ts = self.timestep_fn(times).reshape(-1).to(torch.int32).contiguous()

@@ -109,6 +109,9 @@ class NeRSembleNGPModel(BaseModel):
         self.fuse_main_pass = True
         # ... with the number of kept samples left on the device (no host read-back after the marcher's own count)
         self.device_sample_counts = True
+        # activations + backward scratch of the fused pass per sample (deformation scratch 3.2 KB, features, gradients):
+        # what the un-chunked pass is priced at when a batch is far beyond ``max_n_samples_per_batch``
+        self.fused_pass_bytes_per_sample = 3800
         # evaluation fast path: when every ray of a bundle carries the same timestep the H hash tables
         # are blended once per image into one 2-feature grid (HashEnsemble.preblend)
         self.eval_preblend = True
@@ -446,7 +449,20 @@ class NeRSembleNGPModel(BaseModel):
         S = ray_indices.shape[0]
         # `max_n_samples_per_batch` (train_nersemble.py: 2^20) bounds the reference's activation memory by walking the field
         # in chunks; the result does not depend on it (chunked == un-chunked bit for bit, tests/test_full_size_gpu.py), and
-        # the kernels here take any S (3.3 KB of scratch per sample on a 288 GB device): the fused pass runs un-chunked
+        # the kernels here take any S (3.3 KB of scratch per sample on a 288 GB device): the fused pass runs un-chunked --
+        # unless that would not fit: a batch far beyond the user's bound is checked against the free device memory and
+        # handed to the chunked modular path (which honours the bound) when it needs more than half of it
+        bound = int(cfg.max_n_samples_per_batch or -1)
+        if bound > 0 and S > 4 * bound:
+            free_bytes, _ = torch.cuda.mem_get_info(ray_indices.device)
+            if S * self.fused_pass_bytes_per_sample > 0.5 * free_bytes:
+                if not getattr(self, "_warned_fused_fallback", False):
+                    self._warned_fused_fallback = True
+                    import warnings
+                    warnings.warn(f"fused training pass: {S} samples x {self.fused_pass_bytes_per_sample} B exceed half of the "
+                                  f"free device memory ({free_bytes >> 20} MiB); using the chunked path "
+                                  f"(max_n_samples_per_batch = {bound})")
+                return None
         if "image_index" in md and "_image_timesteps" in md:
             uniq = early_codes[0] if early_codes is not None else md["_image_timesteps"].reshape(-1).int()
             slot = (ray_samples.metadata or {}).get("image_index")

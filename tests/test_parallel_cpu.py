@@ -28,13 +28,24 @@ def _worker(rank, world, port, out_dir):
     big.grad = torch.full_like(big, float(rank + 1))
     small[0].grad = torch.arange(21.).reshape(7, 3) * (rank + 1)
     small[1].grad = torch.ones(11) * (10 * rank)
+    never = torch.nn.Parameter(torch.zeros(3))              # no gradient on ANY rank (a tensor that has not started yet)
     if rank == 0:
         nograd.grad = torch.ones(4) * 8
-    all_reduce_gradients([big] + small + [nograd], world)
+    counts = all_reduce_gradients([big] + small + [nograd, never], world)
     ok = torch.allclose(big.grad, torch.full_like(big, 1.5))
     ok &= torch.allclose(small[0].grad, torch.arange(21.).reshape(7, 3) * 1.5)
     ok &= torch.allclose(small[1].grad, torch.ones(11) * 5)
-    ok &= torch.allclose(nograd.grad, torch.ones(4) * 4)
+    # the rank that had the gradient keeps the average; the other one contributed zeros and is left without a gradient
+    # (its optimizer must not count a step) -- and the disagreement is reported: 1 of 2 ranks
+    ok &= torch.allclose(nograd.grad, torch.ones(4) * 4) if rank == 0 else nograd.grad is None
+    ok &= never.grad is None and counts.tolist() == [2.0, 2.0, 2.0, 1.0, 0.0]
+    from nersemble_amd.engine.parallel import check_gradient_presence
+    check_gradient_presence([2.0, 2.0, 0.0], world)
+    try:
+        check_gradient_presence(counts.tolist(), world)
+        ok = False
+    except RuntimeError as e:
+        ok &= "parameters [3]" in str(e)
     # ray sharding: different rays per rank, same rig
     box = torch.tensor([[-2.5, -1.8, -2.5], [2.2, 1.8, 2.0]])
     data = SyntheticNeRSembleData(box, n_timesteps=10, n_rays=64, device="cpu", rank=rank)
