@@ -275,14 +275,17 @@ def kernels_alone(trainer, H: int, log2_s: int = 20, iters: int = 10):
     def bwd():
         check(lib().nsx_hash_ensemble_bwd_factored(ptr(x), S, ptr(f16), H, C.byref(g), ptr(code), code.stride(0), T,
                                                    ptr(slot), None, ptr(dout), ptr(G), ptr(dcode), ptr(dx), None,
+                                                   None,
                                                    stream()), "nsx_hash_ensemble_bwd_factored")
     def gather():
         check(lib().nsx_hash_ensemble_bwd_factored(ptr(x), S, ptr(f16), H, C.byref(g), ptr(code), code.stride(0), T,
                                                    ptr(slot), None, ptr(dout), None, ptr(dcode), ptr(dx), None,
+                                                   None,
                                                    stream()), "nsx_hash_ensemble_bwd_factored")
 
     def scatter():
         check(lib().nsx_hash_ensemble_bwd_scatter(ptr(x), S, C.byref(g), T, ptr(slot), ptr(dout), ptr(G), None, 8,
+                                                  None,
                                                   stream()), "nsx_hash_ensemble_bwd_scatter")
     rows = torch.empty((T, H), device=dev)
     win = torch.ones((H,), device=dev)
@@ -290,12 +293,13 @@ def kernels_alone(trainer, H: int, log2_s: int = 20, iters: int = 10):
     def bwd_codesum():
         check(lib().nsx_hash_ensemble_bwd_codesum(ptr(x), S, ptr(f16), H, C.byref(g), ptr(code), code.stride(0), T,
                                                   ptr(slot), ptr(win), ptr(dout), ptr(G), ptr(rows),
-                                                  ptr(F.codesum_scratch(T, H, dev)), ptr(dx), None, stream()),
+                                                  ptr(F.codesum_scratch(T, H, dev)), ptr(dx), None, None, stream()),
               "nsx_hash_ensemble_bwd_codesum")
 
     def bwd_nocode():
         check(lib().nsx_hash_ensemble_bwd_factored(ptr(x), S, ptr(f16), H, C.byref(g), ptr(code), code.stride(0), T,
                                                    ptr(slot), None, ptr(dout), ptr(G), None, ptr(dx), None,
+                                                   None,
                                                    stream()), "nsx_hash_ensemble_bwd_factored")
     entry("nsx_hash_ensemble_bwd_factored (fused gather + scatter)", timeit(bwd), "hbm",
           S * (512.0 * H + 2048.0 + 64.0 + 4.0 * H + 28.0))
@@ -338,7 +342,7 @@ def kernels_alone(trainer, H: int, log2_s: int = 20, iters: int = 10):
 
         def dfwd():
             check(lib().nsx_deform_fwd(ptr(packed), ptr(pos), S, aabb6, ptr(dcode_t), dcode_t.stride(0), ptr(slot), w7,
-                                       ptr(off), stream()), "nsx_deform_fwd")
+                                       ptr(off), None, stream()), "nsx_deform_fwd")
         entry("nsx_deform_fwd", timeit(dfwd), "mfma", S * DEFORM_FWD_FLOPS)
         goff = torch.randn((S, 3), device=dev, generator=gen)
         gparams = torch.zeros(int(lib().nsx_deform_param_count()), device=dev)
@@ -347,7 +351,7 @@ def kernels_alone(trainer, H: int, log2_s: int = 20, iters: int = 10):
 
         def dbwd():
             check(lib().nsx_deform_bwd(ptr(packed), ptr(pos), S, aabb6, ptr(dcode_t), dcode_t.stride(0), ptr(slot), T, w7,
-                                       ptr(goff), ptr(scratch), ptr(gparams), ptr(gtable), None, stream()),
+                                       ptr(goff), ptr(scratch), ptr(gparams), ptr(gtable), None, None, stream()),
                   "nsx_deform_bwd")
         entry("nsx_deform_bwd", timeit(dbwd, n=max(3, iters // 2)), "mfma", S * DEFORM_FWD_FLOPS * 3.0)
     return {"samples": S, "sampling": "uniform random positions in the scene box, 24 time-code slots, seed 0",
@@ -533,7 +537,7 @@ def main():
         prof = _lib.profiler.summary()
         total_entries = trainer.model.field.hash_ensemble.geom.total_entries
         work = {}
-        # rows a launch PROCESSED: under a device-side sample count (nsx_device_count_begin) the call is made with the
+        # rows a launch PROCESSED: under a device-side sample count (the n_device argument) the call is made with the
         # marched capacity and the kernel reads the kept count when it runs -- that count is the step's
         # num_samples_per_batch, known to the host after the timed region
         kept = [int(c) for _, c in step_marks]

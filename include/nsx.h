@@ -30,7 +30,7 @@ extern "C" {
 
 #define NSX_MAX_LEVELS 32
 #define NSX_MAX_SLOTS 64
-#define NSX_VERSION 100
+#define NSX_VERSION 110
 
 typedef uint16_t nsx_half;
 
@@ -56,17 +56,15 @@ int nsx_grid_geometry(int n_levels, float per_level_scale, int base_resolution,
                       int log2_hashmap_size, nsx_grid_geom* out);
 
 /* Device-side element counts.  The number of samples a step keeps after visibility pruning is known on the device long
- * before the host could read it back; between nsx_device_count_begin(n_device, capacity) and nsx_device_count_end() every
- * per-sample entry point of this library that is called with a sample count EQUAL TO `capacity` (buffers are allocated
- * for `capacity` rows) processes only the first *n_device rows -- *n_device is read by the kernels when they run, so the
- * calls can be enqueued without a host synchronisation.  Applies to: nsx_sample_positions, nsx_normalise_bwd,
- * nsx_density_fwd/bwd, nsx_gather_rows, nsx_hash_ensemble_fwd/bwd(_factored/_codesum/_scatter), nsx_mlp_fwd/bwd,
- * nsx_deform_fwd/bwd, nsx_ray_histogram (per-ray entry points follow through packed_info).  Thread-local, not nestable;
- * host-only state.  The match is by row count alone: keep the scope around the per-sample calls of ONE sample set -- a
- * call of a listed entry point on some other set of rows that happens to have `capacity` rows would be clipped as well
- * (the generic one is nsx_gather_rows). */
-int nsx_device_count_begin(const int64_t* n_device, int64_t capacity);
-int nsx_device_count_end(void);
+ * before the host could read it back.  Every per-sample entry point of this library therefore takes, right in front of
+ * `stream`, an optional `const int64_t* n_device` (device pointer to ONE int64, or NULL): buffers are allocated for the row
+ * count passed by value (the capacity), the launch is sized for it, and the kernels read *n_device WHEN THEY RUN and
+ * process only the first min(*n_device, capacity) rows -- the call can be enqueued without a host synchronisation.
+ * NULL = every row.  Rows beyond *n_device are neither read nor written (nsx_gather_rows zero-fills them, see there).
+ * Taken by: nsx_sample_positions, nsx_normalise_bwd, nsx_density_fwd/bwd, nsx_gather_rows,
+ * nsx_hash_ensemble_fwd/bwd(_factored/_codesum/_scatter), nsx_mlp_fwd/bwd, nsx_deform_fwd/bwd, nsx_ray_histogram; per-ray
+ * entry points follow through packed_info.  (Rounds 2-3 attached the pointer through a thread-local
+ * nsx_device_count_begin/_end scope matched by row count; removed: the ABI holds no hidden state.) */
 
 /* Padded number of grids used by the interleaved layout (next power of two >= H; the reference's H is any value with
  * 2H <= 8 or 2H a multiple of 8, hash_ensemble.py:80-82). */
@@ -103,7 +101,7 @@ int nsx_tables_to_tcnn(const float* native_master_f32, int H, const nsx_grid_geo
 int nsx_hash_ensemble_fwd(const float* x, int64_t B, const nsx_half* tables, int H,
                           const nsx_grid_geom* g, const float* code, int64_t code_stride,
                           const int32_t* code_index, const float* window, nsx_half* out,
-                          void* stream);
+                          const int64_t* n_device, void* stream);
 
 /* Backward of the above (tcnn kernel_grid_backward + kernel_grid_backward_input + einsum/rearrange
  * backward, reached through autograd from hash_ensemble.py:102-156).
@@ -115,7 +113,7 @@ int nsx_hash_ensemble_fwd(const float* x, int64_t B, const nsx_half* tables, int
 int nsx_hash_ensemble_bwd(const float* x, int64_t B, const nsx_half* tables, int H,
                           const nsx_grid_geom* g, const float* code, int64_t code_stride,
                           const int32_t* code_index, const float* window, const float* dout,
-                          float* dtables, float* dcode, float* dx, void* stream);
+                          float* dtables, float* dcode, float* dx, const int64_t* n_device, void* stream);
 
 /* Factored table gradient -- the MI355X-native backward used when the per-sample code is a row of a SMALL
  * table (the <= 24 distinct time codes of a training batch, nersemble_instant_ngp.py:310-312).  Since
@@ -133,7 +131,7 @@ int nsx_hash_ensemble_bwd_factored(const float* x, int64_t B, const nsx_half* ta
                                    const nsx_grid_geom* g, const float* code_table, int64_t code_stride,
                                    int n_slots, const int32_t* code_slot, const float* window,
                                    const float* dout, float* G, float* dcode, float* dx, float* nonfinite,
-                                   void* stream);
+                                   const int64_t* n_device, void* stream);
 /* The factored backward with the CODE gradient reduced inside the kernel.  Once the coarse-to-fine window is open
  * (window_hash_encodings > 1: steps 40 000 ... 300 000 of the reference's schedule, train_nersemble.py:77-78) the time
  * codes are trained, and autograd through hash_ensemble.py:125-138,155-156 + the nn.Embedding lookup
@@ -148,7 +146,7 @@ int nsx_hash_ensemble_bwd_codesum(const float* x, int64_t B, const nsx_half* tab
                                   const nsx_grid_geom* g, const float* code_table, int64_t code_stride,
                                   int n_slots, const int32_t* code_slot, const float* window,
                                   const float* dout, float* G, float* dcode_rows, float* scratch, float* dx,
-                                  float* nonfinite, void* stream);
+                                  float* nonfinite, const int64_t* n_device, void* stream);
 /* The two halves of the factored backward as separate launches, so that they can run on separate streams:
  *   nsx_hash_ensemble_bwd_factored(..., G = NULL, ...)   the GATHER half: dcode and dx only (bandwidth-bound table reads)
  *   nsx_hash_ensemble_bwd_scatter                        the SCATTER half: G only.  It needs neither the tables nor the
@@ -160,7 +158,7 @@ int nsx_hash_ensemble_bwd_codesum(const float* x, int64_t B, const nsx_half* tab
  * a small value leaves the CU's registers to the kernels it runs beside. */
 int nsx_hash_ensemble_bwd_scatter(const float* x, int64_t B, const nsx_grid_geom* g, int n_slots,
                                   const int32_t* code_slot, const float* dout, float* G, float* nonfinite,
-                                  int blocks_per_cu, void* stream);
+                                  int blocks_per_cu, const int64_t* n_device, void* stream);
 /* dtables (native fp32) = (accumulate ? dtables : 0) + expand(G, code_table*window): the dense table gradient that
  * autograd would have produced through hash_ensemble.py:155-156 (einsum) and the tcnn encodings' backward; only for
  * callers that want a materialised .grad (torch optimizers, the dense all-reduce path). */
@@ -208,12 +206,12 @@ int nsx_mlp_param_count(int n_hidden_mats);
 int nsx_mlp_fwd(const nsx_half* weights, int n_hidden_mats, int64_t B,
                 const float* a, int64_t a_stride, int a_dim, float a_mul, float a_add,
                 const nsx_half* b, int64_t b_stride, int b_off, int b_dim,
-                int n_out, int out_act, nsx_half* out, int64_t out_stride, void* stream);
+                int n_out, int out_act, nsx_half* out, int64_t out_stride, const int64_t* n_device, void* stream);
 int nsx_mlp_bwd(const nsx_half* weights, int n_hidden_mats, int64_t B,
                 const float* a, int64_t a_stride, int a_dim, float a_mul, float a_add,
                 const nsx_half* b, int64_t b_stride, int b_off, int b_dim,
                 int n_out, int out_act, const nsx_half* dout, int64_t dout_stride,
-                float* dweights, float* da, nsx_half* db, float* db_f32, void* stream);
+                float* dweights, float* da, nsx_half* db, float* db_f32, const int64_t* n_device, void* stream);
 int nsx_f32_to_f16(const float* src, nsx_half* dst, int64_t n, void* stream);
 
 /* ---- field glue (elementwise, fused) ------------------------------------------------------------------------
@@ -228,13 +226,13 @@ int nsx_f32_to_f16(const float* src, nsx_half* dst, int64_t n, void* stream);
 int nsx_sample_positions(const float* origins, const float* directions, const int64_t* ray_indices,
                          const float* t_starts, const float* t_ends, const float* offsets, int64_t S,
                          const float* aabb_host, float* pos_world, float* pos_normalised, uint8_t* selector,
-                         void* stream);
+                         const int64_t* n_device, void* stream);
 /* dsts[a][i][:] = srcs[a][index[i]][:] for n_arrays <= NSX_MAX_GATHER device arrays in one launch (row_bytes[a] a
  * multiple of 4; srcs / row_bytes / dsts are HOST arrays of device pointers / sizes).  Replaces the index_select /
  * advanced-indexing launches after the visibility test: nerfacc's ray_indices[keep], t_starts[keep], t_ends[keep]
  * (inside OccGridEstimator.sampling, called at nersemble_volumetric_sampler.py:95-108), the per-field gathers that build
  * the packed RaySamples (nersemble_volumetric_sampler.py:117-134) and the compaction of the sigma-pass values that the
- * main pass reuses.  Under nsx_device_count_begin rows [*n_device, n) of every destination are written as zeros. */
+ * main pass reuses.  With n_device given, rows [*n_device, n) of every destination are written as zeros. */
 /* Pinhole ray generation (csrc/raygen.hip): what the reference's datamanager obtains from nerfstudio's RayGenerator ->
  * Cameras.generate_rays for the pixel sampler's (camera, y, x) triples (datamanager/nersemble_datamanager.py:76-81;
  * perspective cameras without distortion, dataparser/nersemble_dataparser.py:237-244).
@@ -246,13 +244,13 @@ int nsx_generate_rays(const float* camera_to_worlds, const float* fx, const floa
                       float* origins, float* directions, float* pixel_area, void* stream);
 #define NSX_MAX_GATHER 8
 int nsx_gather_rows(int n_arrays, const void* const* srcs, const int64_t* row_bytes, void* const* dsts,
-                    const int64_t* index, int64_t n, void* stream);
+                    const int64_t* index, int64_t n, const int64_t* n_device, void* stream);
 int nsx_normalise_bwd(const float* grad_pos_normalised, const uint8_t* selector, int64_t S, const float* aabb_host,
-                      float* grad_pos_world, void* stream);
+                      float* grad_pos_world, const int64_t* n_device, void* stream);
 int nsx_density_fwd(const nsx_half* base_out, int64_t stride, const uint8_t* selector, int64_t S, float* density,
-                    void* stream);
+                    const int64_t* n_device, void* stream);
 int nsx_density_bwd(const nsx_half* base_out, int64_t stride, const uint8_t* selector, const float* grad_density,
-                    int64_t S, nsx_half* grad_base_out_zeroed, void* stream);
+                    int64_t S, nsx_half* grad_base_out_zeroed, const int64_t* n_device, void* stream);
 
 /* ---- fused SE(3) deformation field -------------------------------------------------------------------------
  * Replaces SE3DeformationField.compute_offsets (deformation_field.py:148-166): WindowedNeRFEncoding
@@ -284,11 +282,11 @@ int nsx_deform_pack(const float* params, void* packed, void* stream);
 int nsx_deform_pack_tensors(const void* const* tensors16_host, void* packed, void* stream);
 int nsx_deform_fwd(const void* packed, const float* positions, int64_t S, const float* aabb_host, const float* code,
                    int64_t code_stride, const int32_t* code_slot, const float* window7_host, float* offsets,
-                   void* stream);
+                   const int64_t* n_device, void* stream);
 int nsx_deform_bwd(const void* packed, const float* positions, int64_t S, const float* aabb_host, const float* code,
                    int64_t code_stride, const int32_t* code_slot, int n_code_rows, const float* window7_host,
                    const float* grad_offsets, void* scratch, float* grad_params, float* grad_code_table,
-                   float* grad_code_samples, void* stream);
+                   float* grad_code_samples, const int64_t* n_device, void* stream);
 
 /* ---- occupancy-grid ray marching (nerfacc 0.5.2 traverse_grids equivalent) -----------------------------
  * Replaces the native part of OccGridEstimator.sampling called at nersemble_volumetric_sampler.py:95-108:
@@ -308,7 +306,7 @@ int nsx_march_fill(const float* rays_o, const float* rays_d, int64_t R, const fl
                    const int64_t* packed_info, float* t_starts, float* t_ends, int64_t* ray_indices,
                    int32_t* cells /* may be NULL */, void* stream);
 /* counts[r] += #samples with ray index r (nerfacc.pack_info, nersemble_instant_ngp.py:325); caller zeroes counts. */
-int nsx_ray_histogram(const int64_t* ray_indices, int64_t S, int64_t R, int64_t* counts_zeroed, void* stream);
+int nsx_ray_histogram(const int64_t* ray_indices, int64_t S, int64_t R, int64_t* counts_zeroed, const int64_t* n_device, void* stream);
 
 /* ---- per-ray scans on packed samples ----------------------------------------------------------------------
  * nerfacc.render_weight_from_density (nersemble_instant_ngp.py:326-331) and render_visibility_from_density
@@ -504,7 +502,7 @@ int nsx_occ_compact(const uint8_t* binaries, int64_t n_cells, int32_t* occupied,
 /* The same stream compaction for a per-SAMPLE mask: ascending indices of the non-zero bytes of `mask` [n] as int64 in
  * kept[0 .. *n_kept) (the index type torch and nsx_gather_rows use; rows beyond *n_kept are left unwritten) and their
  * number as a device int64 -- what the visibility test of OccGridEstimator.sampling needs (nerfacc: masks.nonzero(), a
- * host synchronisation; here the count stays on the device for nsx_device_count_begin).  Neither output needs clearing.
+ * host synchronisation; here the count stays on the device, to be passed on as n_device).  Neither output needs clearing.
  * scratch: nsx_occ_scratch_bytes(n) bytes. */
 int nsx_compact_mask(const uint8_t* mask, int64_t n, int64_t* kept, int64_t* n_kept, void* scratch, void* stream);
 

@@ -54,23 +54,21 @@ SIGNATURES = {
     "nsx_last_error": (C.c_char_p, []),
     "nsx_grid_geometry": (c_int, [c_int, c_float, c_int, c_int, _GEOM_P]),
     "nsx_padded_grids": (c_int, [c_int]),
-    "nsx_device_count_begin": (c_int, [c_void_p, c_int64]),
-    "nsx_device_count_end": (c_int, []),
     "nsx_tables_from_tcnn": (c_int, [c_void_p, c_int, _GEOM_P, c_void_p, c_void_p, c_void_p]),
     "nsx_tables_to_tcnn": (c_int, [c_void_p, c_int, _GEOM_P, c_void_p, c_void_p]),
     "nsx_hash_ensemble_fwd": (c_int, [c_void_p, c_int64, c_void_p, c_int, _GEOM_P, c_void_p, c_int64, c_void_p,
-                                      c_void_p, c_void_p, c_void_p]),
+                                      c_void_p, c_void_p, c_void_p, c_void_p]),
     "nsx_hash_ensemble_bwd": (c_int, [c_void_p, c_int64, c_void_p, c_int, _GEOM_P, c_void_p, c_int64, c_void_p,
-                                      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+                                      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "nsx_hash_ensemble_bwd_factored": (c_int, [c_void_p, c_int64, c_void_p, c_int, _GEOM_P, c_void_p, c_int64, c_int,
                                                c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                               c_void_p, c_void_p]),
+                                               c_void_p, c_void_p, c_void_p]),
     "nsx_hash_codesum_scratch_floats": (c_int64, [c_int, c_int]),
     "nsx_hash_ensemble_bwd_codesum": (c_int, [c_void_p, c_int64, c_void_p, c_int, _GEOM_P, c_void_p, c_int64, c_int,
                                               c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                              c_void_p, c_void_p]),
+                                              c_void_p, c_void_p, c_void_p]),
     "nsx_hash_ensemble_bwd_scatter": (c_int, [c_void_p, c_int64, _GEOM_P, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
-                                              c_int, c_void_p]),
+                                              c_int, c_void_p, c_void_p]),
     "nsx_tables_preblend": (c_int, [c_void_p, c_int, _GEOM_P, c_void_p, c_void_p, c_void_p, c_void_p]),
     "nsx_hash_grad_expand": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_void_p, c_int, _GEOM_P, c_void_p, c_int,
                                      c_void_p]),
@@ -78,34 +76,34 @@ SIGNATURES = {
     "nsx_hashgrid_bwd": (c_int, [c_void_p, c_int64, c_void_p, c_int, _GEOM_P, c_void_p, c_void_p, c_void_p, c_void_p]),
     "nsx_mlp_param_count": (c_int, [c_int]),
     "nsx_mlp_fwd": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_int64, c_int, c_float, c_float, c_void_p, c_int64,
-                            c_int, c_int, c_int, c_int, c_void_p, c_int64, c_void_p]),
+                            c_int, c_int, c_int, c_int, c_void_p, c_int64, c_void_p, c_void_p]),
     "nsx_mlp_bwd": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_int64, c_int, c_float, c_float, c_void_p, c_int64,
                             c_int, c_int, c_int, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
-                            c_void_p]),
+                            c_void_p, c_void_p]),
     "nsx_f32_to_f16": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "nsx_sample_positions": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p,
-                                     c_void_p, c_void_p, c_void_p, c_void_p]),
+                                     c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "nsx_generate_rays": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p,
                                   c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
-    "nsx_gather_rows": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
-    "nsx_normalise_bwd": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
-    "nsx_density_fwd": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p]),
-    "nsx_density_bwd": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
+    "nsx_gather_rows": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
+    "nsx_normalise_bwd": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "nsx_density_fwd": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
+    "nsx_density_bwd": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "nsx_deform_param_count": (c_int, []),
     "nsx_deform_pack_bytes": (c_int64, []),
     "nsx_deform_scratch_bytes": (c_int64, [c_int64]),
     "nsx_deform_pack": (c_int, [c_void_p, c_void_p, c_void_p]),
     "nsx_deform_pack_tensors": (c_int, [C.POINTER(c_void_p), c_void_p, c_void_p]),
     "nsx_deform_fwd": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p,
-                               c_void_p]),
+                               c_void_p, c_void_p]),
     "nsx_deform_bwd": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int, c_void_p,
-                               c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+                               c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "nsx_march_count": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_void_p, c_float, c_float,
                                 c_void_p, c_void_p]),
     "nsx_pack_info": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "nsx_march_fill": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_void_p, c_float, c_float,
                                c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
-    "nsx_ray_histogram": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p]),
+    "nsx_ray_histogram": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
     "nsx_render_weights_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p,
                                        c_void_p, c_float, c_float, c_void_p, c_void_p]),
     "nsx_render_weights_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
@@ -245,27 +243,47 @@ def lib():
     return _lib
 
 
+_COUNT_SCOPE = None          # (n_dev tensor, capacity) of the active ``device_count`` block, host-side Python state only
+
+
 class device_count:
-    """``with device_count(n_dev, capacity): ...`` -- native per-sample calls made with a sample count equal to
-    ``capacity`` process only the first ``n_dev[0]`` rows (include/nsx.h, nsx_device_count_begin).  ``n_dev``: int64 device
-    tensor with one element, or None (then the block runs unchanged)."""
+    """``with device_count(n_dev, capacity): ...`` -- Python-side convenience over the C ABI's explicit ``n_device``
+    argument (include/nsx.h, "Device-side element counts"): the wrappers of this package ask ``ndev(n)`` for the pointer to
+    hand to a per-sample entry point, and get ``n_dev`` when the call's row count equals ``capacity`` of the enclosing
+    block (the arrays of ONE sample set: marched capacity, valid rows counted on the device).  The native library itself
+    holds no such state any more; callers that prefer to be explicit pass the pointer themselves (engine/fused_pass.py).
+    ``n_dev``: int64 device tensor with one element, or None (then the block runs unchanged)."""
 
     def __init__(self, n_dev, capacity: int):
         self.n_dev, self.capacity = n_dev, int(capacity)
+        self._outer = None
 
     def __enter__(self):
+        global _COUNT_SCOPE
         if self.n_dev is not None:
             if self.n_dev.dtype != torch.int64 or self.n_dev.numel() != 1:
                 raise RuntimeError("device_count: n_dev must be one int64 on the device")
-            check(lib().nsx_device_count_begin(ptr(self.n_dev), self.capacity), "nsx_device_count_begin")
+            if _COUNT_SCOPE is not None:
+                raise RuntimeError("device_count: a device count is already attached (blocks do not nest)")
+            _COUNT_SCOPE = (self.n_dev, self.capacity)
             profiler.counted_capacity = self.capacity
         return self
 
     def __exit__(self, *exc):
+        global _COUNT_SCOPE
         if self.n_dev is not None:
-            lib().nsx_device_count_end()
+            _COUNT_SCOPE = None
             profiler.counted_capacity = None
         return False
+
+
+def ndev(n: int) -> c_void_p:
+    """The ``n_device`` argument for a per-sample native call on ``n`` rows: the active ``device_count`` block's pointer
+    if ``n`` is its capacity, else NULL."""
+    sc = _COUNT_SCOPE
+    if sc is not None and int(n) == sc[1]:
+        return c_void_p(sc[0].data_ptr())
+    return c_void_p(0)
 
 
 def check(rc: int, what: str = "") -> None:

@@ -1139,7 +1139,7 @@ int nsx_deform_pack_tensors(const void* const* tensors16_host, void* packed, voi
 
 int nsx_deform_fwd(const void* packed, const float* positions, int64_t S, const float* aabb_host, const float* code,
                    int64_t code_stride, const int32_t* code_slot, const float* window7_host, float* offsets,
-                   void* stream) {
+                   const int64_t* n_device, void* stream) {
     NSX_REQUIRE(S >= 0, "nsx_deform_fwd: negative sample count");
     if (S == 0) return NSX_OK;
     NSX_REQUIRE(packed && positions && aabb_host && code && offsets, "nsx_deform_fwd: NULL argument");
@@ -1150,7 +1150,7 @@ int nsx_deform_fwd(const void* packed, const float* positions, int64_t S, const 
     int64_t blocks = (n_tiles + NW - 1) / NW;
     if (blocks > num_cus()) blocks = num_cus();
     hipLaunchKernelGGL(deform_fwd_kernel, dim3((unsigned)blocks), dim3(NW * 64), 0, (hipStream_t)stream, A, offsets, n_tiles,
-                       count_for(S));
+                       n_device);
     NSX_LAUNCH_CHECK("nsx_deform_fwd launch");
     return NSX_OK;
 }
@@ -1158,7 +1158,7 @@ int nsx_deform_fwd(const void* packed, const float* positions, int64_t S, const 
 int nsx_deform_bwd(const void* packed, const float* positions, int64_t S, const float* aabb_host, const float* code,
                    int64_t code_stride, const int32_t* code_slot, int n_code_rows, const float* window7_host,
                    const float* grad_offsets, void* scratch, float* grad_params, float* grad_code_table,
-                   float* grad_code_samples, void* stream) {
+                   float* grad_code_samples, const int64_t* n_device, void* stream) {
     NSX_REQUIRE(S >= 0, "nsx_deform_bwd: negative sample count");
     if (S == 0) return NSX_OK;
     NSX_REQUIRE(packed && positions && aabb_host && code && grad_offsets && scratch && grad_params,
@@ -1179,10 +1179,10 @@ int nsx_deform_bwd(const void* packed, const float* positions, int64_t S, const 
     const bool slots = code_slot && grad_code_table && !grad_code_samples;
     if (slots)
         hipLaunchKernelGGL(deform_bwd_kernel<true>, dim3((unsigned)blocks), dim3(NW * 64), 0, st, A, grad_offsets, sc,
-                           n_tiles, grad_code_samples, count_for(S), slot_sums);
+                           n_tiles, grad_code_samples, n_device, slot_sums);
     else
         hipLaunchKernelGGL(deform_bwd_kernel<false>, dim3((unsigned)blocks), dim3(NW * 64), 0, st, A, grad_offsets, sc,
-                           n_tiles, grad_code_samples, count_for(S), slot_sums);
+                           n_tiles, grad_code_samples, n_device, slot_sums);
     NSX_LAUNCH_CHECK("nsx_deform_bwd chain launch");
     // weight / bias / code-table gradients
     const int n_types = (grad_code_table && !slots) ? WG_TYPES : WG_TYPES - 1;
@@ -1193,15 +1193,15 @@ int nsx_deform_bwd(const void* packed, const float* positions, int64_t S, const 
     if (slots) {
         float* partials = reinterpret_cast<float*>(reinterpret_cast<uint8_t*>(scratch) + SLOT_SUMS_BYTES + tiles_bytes(S));
         hipLaunchKernelGGL(deform_wgrad_kernel<true>, dim3(n_types, chunks), dim3(NW * 64), 0, st, sc, n_tiles, code_slot, S,
-                           grad_params, grad_code_table, n_code_rows, count_for(S), slot_sums, partials);
+                           grad_params, grad_code_table, n_code_rows, n_device, slot_sums, partials);
         NSX_LAUNCH_CHECK("nsx_deform_bwd wgrad launch");
         hipLaunchKernelGGL(deform_code_expand_kernel, dim3(FINISH_REDUCE_BLOCKS + DFW + n_code_rows), dim3(256), 0, st,
                            slot_sums, code, code_stride, n_code_rows, A.frags, grad_params, grad_code_table, partials, chunks,
-                           n_tiles, S, count_for(S));
+                           n_tiles, S, n_device);
         NSX_LAUNCH_CHECK("nsx_deform_bwd finish launch");
     } else {
         hipLaunchKernelGGL(deform_wgrad_kernel<false>, dim3(n_types, chunks), dim3(NW * 64), 0, st, sc, n_tiles, code_slot, S,
-                           grad_params, grad_code_table, grad_code_table ? n_code_rows : 0, count_for(S), slot_sums,
+                           grad_params, grad_code_table, grad_code_table ? n_code_rows : 0, n_device, slot_sums,
                            (float*)nullptr);
         NSX_LAUNCH_CHECK("nsx_deform_bwd wgrad launch");
     }

@@ -100,7 +100,7 @@ struct GatherArgs {
     int n_arrays;
 };
 
-// Under a device-side count (nsx_device_count_begin) rows [*n_dev, n) of every destination are written as ZEROS by the
+// Under a device-side count (n_device) rows [*n_dev, n) of every destination are written as ZEROS by the
 // same launch: the caller's arrays keep the capacity, and nothing downstream ever sees uninitialised rows (this used to be
 // a torch fill in front of every call).
 __global__ __launch_bounds__(256) void gather_rows_kernel(GatherArgs A, const int64_t* __restrict__ index, int64_t n,
@@ -150,7 +150,7 @@ extern "C" {
 int nsx_sample_positions(const float* origins, const float* directions, const int64_t* ray_indices,
                          const float* t_starts, const float* t_ends, const float* offsets, int64_t S,
                          const float* aabb_host, float* pos_world, float* pos_normalised, uint8_t* selector,
-                         void* stream) {
+                         const int64_t* n_device, void* stream) {
     NSX_REQUIRE(S >= 0, "nsx_sample_positions: negative sample count");
     if (S == 0) return NSX_OK;
     NSX_REQUIRE(origins, "nsx_sample_positions: NULL origins");
@@ -160,13 +160,13 @@ int nsx_sample_positions(const float* origins, const float* directions, const in
     NSX_REQUIRE(!pos_normalised || aabb_host, "nsx_sample_positions: aabb required for normalised positions");
     hipLaunchKernelGGL(sample_positions_kernel, dim3(grid_for(S)), dim3(256), 0, (hipStream_t)stream, origins, directions,
                        ray_indices, t_starts, t_ends, offsets, S, make_box(aabb_host), pos_world, pos_normalised, selector,
-                       count_for(S));
+                       n_device);
     NSX_LAUNCH_CHECK("nsx_sample_positions launch");
     return NSX_OK;
 }
 
 int nsx_gather_rows(int n_arrays, const void* const* srcs, const int64_t* row_bytes, void* const* dsts,
-                    const int64_t* index, int64_t n, void* stream) {
+                    const int64_t* index, int64_t n, const int64_t* n_device, void* stream) {
     NSX_REQUIRE(n >= 0, "nsx_gather_rows: negative row count");
     NSX_REQUIRE(n_arrays >= 1 && n_arrays <= NSX_MAX_GATHER, "nsx_gather_rows: n_arrays=%d not in [1,%d]", n_arrays,
                 NSX_MAX_GATHER);
@@ -188,41 +188,41 @@ int nsx_gather_rows(int n_arrays, const void* const* srcs, const int64_t* row_by
         if (n * A.words[a] > max_pieces) max_pieces = n * A.words[a];
     }
     hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for(max_pieces), n_arrays), dim3(256), 0, (hipStream_t)stream, A, index, n,
-                       count_for(n));
+                       n_device);
     NSX_LAUNCH_CHECK("nsx_gather_rows launch");
     return NSX_OK;
 }
 
 int nsx_normalise_bwd(const float* grad_pos_normalised, const uint8_t* selector, int64_t S, const float* aabb_host,
-                      float* grad_pos_world, void* stream) {
+                      float* grad_pos_world, const int64_t* n_device, void* stream) {
     NSX_REQUIRE(S >= 0, "nsx_normalise_bwd: negative sample count");
     if (S == 0) return NSX_OK;
     NSX_REQUIRE(grad_pos_normalised && selector && aabb_host && grad_pos_world, "nsx_normalise_bwd: NULL argument");
     hipLaunchKernelGGL(normalise_bwd_kernel, dim3(grid_for(S)), dim3(256), 0, (hipStream_t)stream, grad_pos_normalised,
-                       selector, S, make_box(aabb_host), grad_pos_world, count_for(S));
+                       selector, S, make_box(aabb_host), grad_pos_world, n_device);
     NSX_LAUNCH_CHECK("nsx_normalise_bwd launch");
     return NSX_OK;
 }
 
 int nsx_density_fwd(const nsx_half* base_out, int64_t stride, const uint8_t* selector, int64_t S, float* density,
-                    void* stream) {
+                    const int64_t* n_device, void* stream) {
     NSX_REQUIRE(S >= 0, "nsx_density_fwd: negative sample count");
     if (S == 0) return NSX_OK;
     NSX_REQUIRE(base_out && selector && density, "nsx_density_fwd: NULL argument");
     hipLaunchKernelGGL(density_fwd_kernel, dim3(grid_for(S)), dim3(256), 0, (hipStream_t)stream,
-                       reinterpret_cast<const half_t*>(base_out), stride, selector, S, density, count_for(S));
+                       reinterpret_cast<const half_t*>(base_out), stride, selector, S, density, n_device);
     NSX_LAUNCH_CHECK("nsx_density_fwd launch");
     return NSX_OK;
 }
 
 int nsx_density_bwd(const nsx_half* base_out, int64_t stride, const uint8_t* selector, const float* grad_density,
-                    int64_t S, nsx_half* grad_base_out_zeroed, void* stream) {
+                    int64_t S, nsx_half* grad_base_out_zeroed, const int64_t* n_device, void* stream) {
     NSX_REQUIRE(S >= 0, "nsx_density_bwd: negative sample count");
     if (S == 0) return NSX_OK;
     NSX_REQUIRE(base_out && selector && grad_density && grad_base_out_zeroed, "nsx_density_bwd: NULL argument");
     hipLaunchKernelGGL(density_bwd_kernel, dim3(grid_for(S)), dim3(256), 0, (hipStream_t)stream,
                        reinterpret_cast<const half_t*>(base_out), stride, selector, grad_density, S,
-                       reinterpret_cast<half_t*>(grad_base_out_zeroed), count_for(S));
+                       reinterpret_cast<half_t*>(grad_base_out_zeroed), n_device);
     NSX_LAUNCH_CHECK("nsx_density_bwd launch");
     return NSX_OK;
 }

@@ -789,7 +789,7 @@ static int ens_layout(int H, int* F_enc, int* P) {
 template <int H>
 static int launch_fwd(const float* x, int64_t B, const nsx_half* tables, int Hreal, const nsx_grid_geom* g,
                       const float* code, int64_t code_stride, const int32_t* code_index, const float* window,
-                      nsx_half* out, hipStream_t st) {
+                      nsx_half* out, const int64_t* n_dev, hipStream_t st) {
     using C = EnsCfg<H>;
     constexpr int WAVES = 4;
     const int64_t n_tiles = (B + C::SPW - 1) / C::SPW;
@@ -799,7 +799,7 @@ static int launch_fwd(const float* x, int64_t B, const nsx_half* tables, int Hre
     const size_t smem = (size_t)WAVES * C::SPW * (g->n_levels + 4) * sizeof(uint32_t);
     hipLaunchKernelGGL((ens_fwd_kernel<H, WAVES>), dim3((unsigned)blocks), dim3(WAVES * kWave), smem, st, x, B,
                        reinterpret_cast<const uint8_t*>(tables), *g, code, code_stride, code_index, window, Hreal,
-                       reinterpret_cast<uint32_t*>(out), n_tiles, count_for(B));
+                       reinterpret_cast<uint32_t*>(out), n_tiles, n_dev);
     NSX_LAUNCH_CHECK("nsx_hash_ensemble_fwd launch");
     return NSX_OK;
 }
@@ -807,7 +807,7 @@ static int launch_fwd(const float* x, int64_t B, const nsx_half* tables, int Hre
 template <int H>
 static int launch_bwd(const float* x, int64_t B, const nsx_half* tables, int Hreal, const nsx_grid_geom* g,
                       const float* code, int64_t code_stride, const int32_t* code_index, const float* window,
-                      const float* dout, float* dtables, float* dcode, float* dx, hipStream_t st,
+                      const float* dout, float* dtables, float* dcode, float* dx, const int64_t* n_dev, hipStream_t st,
                       int n_slots = 0, float* nonfinite = nullptr, float* dcode_rows = nullptr,
                       float* csum_part = nullptr) {
     using C = EnsCfg<H>;
@@ -821,7 +821,7 @@ static int launch_bwd(const float* x, int64_t B, const nsx_half* tables, int Hre
 #define NSX_BWD_LAUNCH(MODE, DC, NS, NF)                                                                               \
     hipLaunchKernelGGL((ens_bwd_kernel<H, WAVES, MODE, DC>), dim3((unsigned)blocks), dim3(WAVES * kWave), smem, st, x, B, \
                        reinterpret_cast<const uint8_t*>(tables), *g, code, code_stride, code_index, window, Hreal,       \
-                       dout, dtables, dcode, dx, n_tiles, NS, NF, count_for(B), dcode_rows ? csum_part : nullptr)
+                       dout, dtables, dcode, dx, n_tiles, NS, NF, n_dev, dcode_rows ? csum_part : nullptr)
     if (n_slots > 0 && dtables) {
         if (dc) NSX_BWD_LAUNCH(BWD_FACTORED, true, n_slots, nonfinite);
         else NSX_BWD_LAUNCH(BWD_FACTORED, false, n_slots, nonfinite);
@@ -918,7 +918,7 @@ int nsx_tables_preblend(const nsx_half* tables, int H, const nsx_grid_geom* g, c
 
 int nsx_hash_ensemble_fwd(const float* x, int64_t B, const nsx_half* tables, int H, const nsx_grid_geom* g,
                           const float* code, int64_t code_stride, const int32_t* code_index,
-                          const float* window, nsx_half* out, void* stream) {
+                          const float* window, nsx_half* out, const int64_t* n_device, void* stream) {
     NSX_REQUIRE(B >= 0, "nsx_hash_ensemble_fwd: negative batch");
     if (B == 0) return NSX_OK;
     NSX_REQUIRE(x && tables && code && out, "nsx_hash_ensemble_fwd: NULL argument");
@@ -927,12 +927,12 @@ int nsx_hash_ensemble_fwd(const float* x, int64_t B, const nsx_half* tables, int
     if (int rc = check_geom(g, Hp, "nsx_hash_ensemble_fwd")) return rc;
     hipStream_t st = (hipStream_t)stream;
     switch (Hp) {
-        case 1: return launch_fwd<1>(x, B, tables, H, g, code, code_stride, code_index, window, out, st);
-        case 2: return launch_fwd<2>(x, B, tables, H, g, code, code_stride, code_index, window, out, st);
-        case 4: return launch_fwd<4>(x, B, tables, H, g, code, code_stride, code_index, window, out, st);
-        case 8: return launch_fwd<8>(x, B, tables, H, g, code, code_stride, code_index, window, out, st);
-        case 16: return launch_fwd<16>(x, B, tables, H, g, code, code_stride, code_index, window, out, st);
-        case 32: return launch_fwd<32>(x, B, tables, H, g, code, code_stride, code_index, window, out, st);
+        case 1: return launch_fwd<1>(x, B, tables, H, g, code, code_stride, code_index, window, out, n_device, st);
+        case 2: return launch_fwd<2>(x, B, tables, H, g, code, code_stride, code_index, window, out, n_device, st);
+        case 4: return launch_fwd<4>(x, B, tables, H, g, code, code_stride, code_index, window, out, n_device, st);
+        case 8: return launch_fwd<8>(x, B, tables, H, g, code, code_stride, code_index, window, out, n_device, st);
+        case 16: return launch_fwd<16>(x, B, tables, H, g, code, code_stride, code_index, window, out, n_device, st);
+        case 32: return launch_fwd<32>(x, B, tables, H, g, code, code_stride, code_index, window, out, n_device, st);
     }
     set_error("nsx_hash_ensemble_fwd: unsupported H=%d", H);
     return NSX_ERR_UNSUPPORTED;
@@ -941,7 +941,7 @@ int nsx_hash_ensemble_fwd(const float* x, int64_t B, const nsx_half* tables, int
 int nsx_hash_ensemble_bwd(const float* x, int64_t B, const nsx_half* tables, int H, const nsx_grid_geom* g,
                           const float* code, int64_t code_stride, const int32_t* code_index,
                           const float* window, const float* dout, float* dtables, float* dcode, float* dx,
-                          void* stream) {
+                          const int64_t* n_device, void* stream) {
     NSX_REQUIRE(B >= 0, "nsx_hash_ensemble_bwd: negative batch");
     if (B == 0) return NSX_OK;
     NSX_REQUIRE(x && tables && code && dout, "nsx_hash_ensemble_bwd: NULL argument");
@@ -950,12 +950,12 @@ int nsx_hash_ensemble_bwd(const float* x, int64_t B, const nsx_half* tables, int
     if (int rc = check_geom(g, Hp, "nsx_hash_ensemble_bwd")) return rc;
     hipStream_t st = (hipStream_t)stream;
     switch (Hp) {
-        case 1: return launch_bwd<1>(x, B, tables, H, g, code, code_stride, code_index, window, dout, dtables, dcode, dx, st);
-        case 2: return launch_bwd<2>(x, B, tables, H, g, code, code_stride, code_index, window, dout, dtables, dcode, dx, st);
-        case 4: return launch_bwd<4>(x, B, tables, H, g, code, code_stride, code_index, window, dout, dtables, dcode, dx, st);
-        case 8: return launch_bwd<8>(x, B, tables, H, g, code, code_stride, code_index, window, dout, dtables, dcode, dx, st);
-        case 16: return launch_bwd<16>(x, B, tables, H, g, code, code_stride, code_index, window, dout, dtables, dcode, dx, st);
-        case 32: return launch_bwd<32>(x, B, tables, H, g, code, code_stride, code_index, window, dout, dtables, dcode, dx, st);
+        case 1: return launch_bwd<1>(x, B, tables, H, g, code, code_stride, code_index, window, dout, dtables, dcode, dx, n_device, st);
+        case 2: return launch_bwd<2>(x, B, tables, H, g, code, code_stride, code_index, window, dout, dtables, dcode, dx, n_device, st);
+        case 4: return launch_bwd<4>(x, B, tables, H, g, code, code_stride, code_index, window, dout, dtables, dcode, dx, n_device, st);
+        case 8: return launch_bwd<8>(x, B, tables, H, g, code, code_stride, code_index, window, dout, dtables, dcode, dx, n_device, st);
+        case 16: return launch_bwd<16>(x, B, tables, H, g, code, code_stride, code_index, window, dout, dtables, dcode, dx, n_device, st);
+        case 32: return launch_bwd<32>(x, B, tables, H, g, code, code_stride, code_index, window, dout, dtables, dcode, dx, n_device, st);
     }
     set_error("nsx_hash_ensemble_bwd: unsupported H=%d", H);
     return NSX_ERR_UNSUPPORTED;
@@ -965,7 +965,7 @@ int nsx_hash_ensemble_bwd_factored(const float* x, int64_t B, const nsx_half* ta
                                    const nsx_grid_geom* g, const float* code_table, int64_t code_stride,
                                    int n_slots, const int32_t* code_slot, const float* window,
                                    const float* dout, float* G, float* dcode, float* dx, float* nonfinite,
-                                   void* stream) {
+                                   const int64_t* n_device, void* stream) {
     NSX_REQUIRE(B >= 0, "nsx_hash_ensemble_bwd_factored: negative batch");
     if (B == 0) return NSX_OK;
     NSX_REQUIRE(x && tables && code_table && code_slot && dout, "nsx_hash_ensemble_bwd_factored: NULL argument");
@@ -979,12 +979,12 @@ int nsx_hash_ensemble_bwd_factored(const float* x, int64_t B, const nsx_half* ta
                 "2^26 the run-merge key can address", g->offset[g->n_levels]);
     hipStream_t st = (hipStream_t)stream;
     switch (Hp) {
-        case 1: return launch_bwd<1>(x, B, tables, H, g, code_table, code_stride, code_slot, window, dout, G, dcode, dx, st, n_slots, nonfinite);
-        case 2: return launch_bwd<2>(x, B, tables, H, g, code_table, code_stride, code_slot, window, dout, G, dcode, dx, st, n_slots, nonfinite);
-        case 4: return launch_bwd<4>(x, B, tables, H, g, code_table, code_stride, code_slot, window, dout, G, dcode, dx, st, n_slots, nonfinite);
-        case 8: return launch_bwd<8>(x, B, tables, H, g, code_table, code_stride, code_slot, window, dout, G, dcode, dx, st, n_slots, nonfinite);
-        case 16: return launch_bwd<16>(x, B, tables, H, g, code_table, code_stride, code_slot, window, dout, G, dcode, dx, st, n_slots, nonfinite);
-        case 32: return launch_bwd<32>(x, B, tables, H, g, code_table, code_stride, code_slot, window, dout, G, dcode, dx, st, n_slots, nonfinite);
+        case 1: return launch_bwd<1>(x, B, tables, H, g, code_table, code_stride, code_slot, window, dout, G, dcode, dx, n_device, st, n_slots, nonfinite);
+        case 2: return launch_bwd<2>(x, B, tables, H, g, code_table, code_stride, code_slot, window, dout, G, dcode, dx, n_device, st, n_slots, nonfinite);
+        case 4: return launch_bwd<4>(x, B, tables, H, g, code_table, code_stride, code_slot, window, dout, G, dcode, dx, n_device, st, n_slots, nonfinite);
+        case 8: return launch_bwd<8>(x, B, tables, H, g, code_table, code_stride, code_slot, window, dout, G, dcode, dx, n_device, st, n_slots, nonfinite);
+        case 16: return launch_bwd<16>(x, B, tables, H, g, code_table, code_stride, code_slot, window, dout, G, dcode, dx, n_device, st, n_slots, nonfinite);
+        case 32: return launch_bwd<32>(x, B, tables, H, g, code_table, code_stride, code_slot, window, dout, G, dcode, dx, n_device, st, n_slots, nonfinite);
     }
     set_error("nsx_hash_ensemble_bwd_factored: unsupported H=%d", H);
     return NSX_ERR_UNSUPPORTED;
@@ -999,7 +999,7 @@ int nsx_hash_ensemble_bwd_codesum(const float* x, int64_t B, const nsx_half* tab
                                   const nsx_grid_geom* g, const float* code_table, int64_t code_stride,
                                   int n_slots, const int32_t* code_slot, const float* window,
                                   const float* dout, float* G, float* dcode_rows, float* scratch, float* dx,
-                                  float* nonfinite, void* stream) {
+                                  float* nonfinite, const int64_t* n_device, void* stream) {
     NSX_REQUIRE(B >= 0, "nsx_hash_ensemble_bwd_codesum: negative batch");
     NSX_REQUIRE(dcode_rows && scratch, "nsx_hash_ensemble_bwd_codesum: dcode_rows / scratch is NULL");
     NSX_REQUIRE(H >= 1 && H <= 32, "nsx_hash_ensemble_bwd_codesum: H=%d not in [1,32]", H);
@@ -1020,7 +1020,7 @@ int nsx_hash_ensemble_bwd_codesum(const float* x, int64_t B, const nsx_half* tab
                 "2^26 the run-merge key can address", g->offset[g->n_levels]);
     switch (Hp) {
 #define NSX_CS_CASE(HP) case HP: return launch_bwd<HP>(x, B, tables, H, g, code_table, code_stride, code_slot, window, dout, \
-                                                       G, nullptr, dx, st, n_slots, nonfinite, dcode_rows, scratch);
+                                                       G, nullptr, dx, n_device, st, n_slots, nonfinite, dcode_rows, scratch);
         NSX_CS_CASE(1) NSX_CS_CASE(2) NSX_CS_CASE(4) NSX_CS_CASE(8) NSX_CS_CASE(16) NSX_CS_CASE(32)
 #undef NSX_CS_CASE
     }
@@ -1030,7 +1030,7 @@ int nsx_hash_ensemble_bwd_codesum(const float* x, int64_t B, const nsx_half* tab
 
 int nsx_hash_ensemble_bwd_scatter(const float* x, int64_t B, const nsx_grid_geom* g, int n_slots,
                                   const int32_t* code_slot, const float* dout, float* G, float* nonfinite,
-                                  int blocks_per_cu, void* stream) {
+                                  int blocks_per_cu, const int64_t* n_device, void* stream) {
     NSX_REQUIRE(B >= 0, "nsx_hash_ensemble_bwd_scatter: negative batch");
     if (B == 0) return NSX_OK;
     NSX_REQUIRE(x && code_slot && dout && G, "nsx_hash_ensemble_bwd_scatter: NULL argument");
@@ -1047,7 +1047,7 @@ int nsx_hash_ensemble_bwd_scatter(const float* x, int64_t B, const nsx_grid_geom
     const int64_t cap = (int64_t)num_cus() * blocks_per_cu;
     if (blocks > cap) blocks = cap;
     hipLaunchKernelGGL((ens_scatter_kernel<WAVES>), dim3((unsigned)blocks), dim3(WAVES * kWave), 0, (hipStream_t)stream, x,
-                       B, *g, code_slot, dout, G, n_tiles, nonfinite, count_for(B));
+                       B, *g, code_slot, dout, G, n_tiles, nonfinite, n_device);
     NSX_LAUNCH_CHECK("nsx_hash_ensemble_bwd_scatter launch");
     return NSX_OK;
 }

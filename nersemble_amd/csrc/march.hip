@@ -346,14 +346,14 @@ int nsx_march_fill(const float* rays_o, const float* rays_d, int64_t R, const fl
     return NSX_OK;
 }
 
-int nsx_ray_histogram(const int64_t* ray_indices, int64_t S, int64_t R, int64_t* counts_zeroed, void* stream) {
+int nsx_ray_histogram(const int64_t* ray_indices, int64_t S, int64_t R, int64_t* counts_zeroed, const int64_t* n_device, void* stream) {
     NSX_REQUIRE(S >= 0 && R >= 0, "nsx_ray_histogram: negative size");
     if (S == 0) return NSX_OK;
     NSX_REQUIRE(ray_indices && counts_zeroed, "nsx_ray_histogram: NULL argument");
     int64_t blocks = (S + 255) / 256;
     if (blocks > num_cus() * 8) blocks = num_cus() * 8;
     hipLaunchKernelGGL(ray_hist_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, ray_indices, S, R,
-                       reinterpret_cast<unsigned long long*>(counts_zeroed), count_for(S));
+                       reinterpret_cast<unsigned long long*>(counts_zeroed), n_device);
     NSX_LAUNCH_CHECK("nsx_ray_histogram launch");
     return NSX_OK;
 }

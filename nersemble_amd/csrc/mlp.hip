@@ -479,7 +479,7 @@ static int check_io(const char* who, int n_hidden_mats, int a_dim, int b_dim, in
 int nsx_mlp_fwd(const nsx_half* weights, int n_hidden_mats, int64_t B,
                 const float* a, int64_t a_stride, int a_dim, float a_mul, float a_add,
                 const nsx_half* b, int64_t b_stride, int b_off, int b_dim,
-                int n_out, int out_act, nsx_half* out, int64_t out_stride, void* stream) {
+                int n_out, int out_act, nsx_half* out, int64_t out_stride, const int64_t* n_device, void* stream) {
     NSX_REQUIRE(B >= 0, "nsx_mlp_fwd: negative batch");
     if (B == 0) return NSX_OK;
     NSX_REQUIRE(weights && out, "nsx_mlp_fwd: NULL argument");
@@ -494,10 +494,10 @@ int nsx_mlp_fwd(const nsx_half* weights, int n_hidden_mats, int64_t B,
     half_t* o = reinterpret_cast<half_t*>(out);
     if (n_hidden_mats == 0)
         hipLaunchKernelGGL((mlp_fwd_kernel<0>), dim3((unsigned)blocks), dim3(MLP_WAVES * kWave), fwd_smem(0), st, W, io, B,
-                           n_out, out_act, o, out_stride, n_tiles, count_for(B));
+                           n_out, out_act, o, out_stride, n_tiles, n_device);
     else
         hipLaunchKernelGGL((mlp_fwd_kernel<1>), dim3((unsigned)blocks), dim3(MLP_WAVES * kWave), fwd_smem(1), st, W, io, B,
-                           n_out, out_act, o, out_stride, n_tiles, count_for(B));
+                           n_out, out_act, o, out_stride, n_tiles, n_device);
     NSX_LAUNCH_CHECK("nsx_mlp_fwd launch");
     return NSX_OK;
 }
@@ -506,7 +506,7 @@ int nsx_mlp_bwd(const nsx_half* weights, int n_hidden_mats, int64_t B,
                 const float* a, int64_t a_stride, int a_dim, float a_mul, float a_add,
                 const nsx_half* b, int64_t b_stride, int b_off, int b_dim,
                 int n_out, int out_act, const nsx_half* dout, int64_t dout_stride,
-                float* dweights, float* da, nsx_half* db, float* db_f32, void* stream) {
+                float* dweights, float* da, nsx_half* db, float* db_f32, const int64_t* n_device, void* stream) {
     NSX_REQUIRE(B >= 0, "nsx_mlp_bwd: negative batch");
     if (B == 0) return NSX_OK;
     NSX_REQUIRE(weights && dout && dweights, "nsx_mlp_bwd: NULL argument");
@@ -528,11 +528,11 @@ int nsx_mlp_bwd(const nsx_half* weights, int n_hidden_mats, int64_t B,
     if (n_hidden_mats == 0)
         hipLaunchKernelGGL((mlp_bwd_kernel<0>), dim3((unsigned)blocks), dim3(MLP_WAVES * kWave), bwd_smem(0), st, W, io, B,
                            n_out, out_act, reinterpret_cast<const half_t*>(dout), dout_stride, dweights, da,
-                           reinterpret_cast<half_t*>(db), n_tiles, count_for(B), db_f32);
+                           reinterpret_cast<half_t*>(db), n_tiles, n_device, db_f32);
     else
         hipLaunchKernelGGL((mlp_bwd_kernel<1>), dim3((unsigned)blocks), dim3(MLP_WAVES * kWave), bwd_smem(1), st, W, io, B,
                            n_out, out_act, reinterpret_cast<const half_t*>(dout), dout_stride, dweights, da,
-                           reinterpret_cast<half_t*>(db), n_tiles, count_for(B), db_f32);
+                           reinterpret_cast<half_t*>(db), n_tiles, n_device, db_f32);
     NSX_LAUNCH_CHECK("nsx_mlp_bwd launch");
     return NSX_OK;
 }

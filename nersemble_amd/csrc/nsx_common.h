@@ -25,10 +25,7 @@ int hip_fail(hipError_t e, const char* what);
 
 constexpr int kWave = 64;   // CDNA wavefront
 
-// Device-side element counts (nsx_device_count_begin / _end, include/nsx.h): the registered device pointer when a
-// per-sample entry point is called with exactly the registered capacity, else NULL.
-const int64_t* count_for(int64_t n);
-
+// Device-side element counts (the `n_device` argument of the per-sample entry points, include/nsx.h).
 // First statement of a per-sample kernel: shrink the element count (and the tile count derived from it) to the value in
 // device memory, if one is attached; nothing to do -> the whole grid returns.
 #define NSX_DEVICE_COUNT(B, n_tiles, per_tile, n_dev)                                              \

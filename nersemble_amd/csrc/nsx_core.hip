@@ -16,11 +16,6 @@ void set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
-static thread_local const int64_t* g_count_ptr = nullptr;
-static thread_local int64_t g_count_capacity = -1;
-
-const int64_t* count_for(int64_t n) { return (g_count_ptr && n == g_count_capacity) ? g_count_ptr : nullptr; }
-
 int hip_fail(hipError_t e, const char* what) {
     set_error("%s: %s", what, hipGetErrorString(e));
     return NSX_ERR_HIP;
@@ -33,21 +28,6 @@ extern "C" {
 int nsx_version(void) { return NSX_VERSION; }
 
 const char* nsx_last_error(void) { return nsx::g_err; }
-
-int nsx_device_count_begin(const int64_t* n_device, int64_t capacity) {
-    NSX_REQUIRE(n_device != nullptr && capacity >= 1, "nsx_device_count_begin: NULL count or capacity %lld < 1",
-                (long long)capacity);
-    NSX_REQUIRE(nsx::g_count_ptr == nullptr, "nsx_device_count_begin: a device count is already attached");
-    nsx::g_count_ptr = n_device;
-    nsx::g_count_capacity = capacity;
-    return NSX_OK;
-}
-
-int nsx_device_count_end(void) {
-    nsx::g_count_ptr = nullptr;
-    nsx::g_count_capacity = -1;
-    return NSX_OK;
-}
 
 int nsx_padded_grids(int H) {
     int p = 1;

@@ -23,7 +23,7 @@ import torch
 from .. import _lib
 from .. import distloss as dl
 from .. import functional as F
-from .._lib import check, device_count, lib, ptr, stream
+from .._lib import check, device_count, lib, ndev, ptr, stream
 
 
 class MainPassInputs:
@@ -73,36 +73,37 @@ class _MainPass(torch.autograd.Function):
             # in-box selector in ONE launch
             offsets = inp.pre_offsets
             check(L.nsx_sample_positions(ptr(inp.origins), ptr(inp.directions), None, ptr(inp.t0), ptr(inp.t1), ptr(offsets),
-                                         S, inp.field_aabb6, ptr(pos), ptr(pn), ptr(sel), st), "nsx_sample_positions")
+                                         S, inp.field_aabb6, ptr(pos), ptr(pn), ptr(sel), ndev(S), st), "nsx_sample_positions")
         else:
             check(L.nsx_sample_positions(ptr(inp.origins), ptr(inp.directions), None, ptr(inp.t0), ptr(inp.t1), None, S, None,
-                                         ptr(pos), None, None, st), "nsx_sample_positions")
+                                         ptr(pos), None, None, ndev(S), st), "nsx_sample_positions")
             offsets = torch.empty((S, 3), dtype=f32, device=dev)
             check(L.nsx_deform_fwd(ptr(inp.deform_packed), ptr(pos), S, inp.deform_aabb6, ptr(code_d), code_d.stride(0),
-                                   ptr(inp.slot), inp.deform_window7, ptr(offsets), st), "nsx_deform_fwd")
+                                   ptr(inp.slot), inp.deform_window7, ptr(offsets), ndev(S), st), "nsx_deform_fwd")
             # -- scene-box normalisation of (position + offset), in-box selector
             check(L.nsx_sample_positions(ptr(pos), None, None, None, None, ptr(offsets), S, inp.field_aabb6, None, ptr(pn),
-                                         ptr(sel), st), "nsx_sample_positions")
+                                         ptr(sel), ndev(S), st), "nsx_sample_positions")
         # -- HashEnsemble, mlp_base, density
         if inp.pre_features is not None:
             feats = inp.pre_features
         else:
             feats = torch.empty((S, 2 * geom.n_levels), dtype=f16, device=dev)
             check(L.nsx_hash_ensemble_fwd(ptr(pn), S, ptr(tables_f16), H, C.byref(geom), ptr(code_h), code_h.stride(0),
-                                          ptr(hash_slot), ptr(hash_window), ptr(feats), st), "nsx_hash_ensemble_fwd")
+                                          ptr(hash_slot), ptr(hash_window), ptr(feats), ndev(S), st), "nsx_hash_ensemble_fwd")
         if inp.pre_base is not None:
             base_out = inp.pre_base
         else:
             base_out = torch.empty((S, inp.base_out_dim), dtype=f16, device=dev)
             check(L.nsx_mlp_fwd(ptr(base_w), inp.base_hidden, S, None, 0, 0, 1.0, 0.0, ptr(feats), feats.stride(0), 0,
-                                feats.shape[1], inp.base_out_dim, inp.base_act, ptr(base_out), base_out.stride(0), st),
+                                feats.shape[1], inp.base_out_dim, inp.base_act, ptr(base_out), base_out.stride(0), ndev(S), st),
                   "nsx_mlp_fwd")
         density = torch.empty((S, 1), dtype=f32, device=dev)
-        check(L.nsx_density_fwd(ptr(base_out), base_out.stride(0), ptr(sel), S, ptr(density), st), "nsx_density_fwd")
+        check(L.nsx_density_fwd(ptr(base_out), base_out.stride(0), ptr(sel), S, ptr(density), ndev(S), st), "nsx_density_fwd")
         # -- colour: mlp_head([(d + 1) / 2, geometry features]) with sigmoid, read in place
         rgb16 = torch.empty((S, 3), dtype=f16, device=dev)
         check(L.nsx_mlp_fwd(ptr(head_w), inp.head_hidden, S, ptr(inp.directions), inp.directions.stride(0), 3, 0.5, 0.5,
                             ptr(base_out), base_out.stride(0), 1, inp.geo_dim, 3, inp.head_act, ptr(rgb16), rgb16.stride(0),
+                            ndev(S),
                             st), "nsx_mlp_fwd")
         # -- compositing (weights, rgb, accumulation, expected depth, rendered deformation); the colours stay fp16
         w = torch.empty((S,), dtype=f32, device=dev)
@@ -187,14 +188,14 @@ class _MainPass(torch.autograd.Function):
         # -- mlp_head: gradient of its parameters and of the geometry features (columns 1.. of base_out)
         check(L.nsx_mlp_bwd(ptr(head_w), inp.head_hidden, S, ptr(inp.directions), inp.directions.stride(0), 3, 0.5, 0.5,
                             ptr(base_out), base_out.stride(0), 1, inp.geo_dim, 3, inp.head_act, ptr(dc16), dc16.stride(0),
-                            ptr(d_head), None, ptr(d_base_out), None, st), "nsx_mlp_bwd")
+                            ptr(d_head), None, ptr(d_base_out), None, ndev(S), st), "nsx_mlp_bwd")
         # -- trunc_exp density: column 0 of the same gradient buffer
-        check(L.nsx_density_bwd(ptr(base_out), base_out.stride(0), ptr(sel), ptr(ds), S, ptr(d_base_out), st),
+        check(L.nsx_density_bwd(ptr(base_out), base_out.stride(0), ptr(sel), ptr(ds), S, ptr(d_base_out), ndev(S), st),
               "nsx_density_bwd")
         # -- mlp_base
         check(L.nsx_mlp_bwd(ptr(base_w), inp.base_hidden, S, None, 0, 0, 1.0, 0.0, ptr(feats), feats.stride(0), 0,
                             feats.shape[1], inp.base_out_dim, inp.base_act, ptr(d_base_out), d_base_out.stride(0), ptr(d_base),
-                            None, None, ptr(dout), st), "nsx_mlp_bwd")
+                            None, None, ptr(dout), ndev(S), st), "nsx_mlp_bwd")
         # -- HashEnsemble: factored table gradient into the sink, code gradient summed per code row, position gradient
         n_rows = code_h.shape[0]
         sink = ctx.sink
@@ -216,18 +217,18 @@ class _MainPass(torch.autograd.Function):
             # unrelated sectors each (5.5 ms at 650 k samples); the stand-alone scatter keeps the 8-lanes-per-sample mapping
             # whose neighbouring (feature, x) items share a sector.  The gather half (dL/dx of one grid) is cheap.
             check(L.nsx_hash_ensemble_bwd_scatter(ptr(pn), S, C.byref(geom), n_rows, ptr(hash_slot), ptr(dout), ptr(G),
-                                                  ptr(sink.nonfinite), 8, st), "nsx_hash_ensemble_bwd_scatter")
+                                                  ptr(sink.nonfinite), 8, ndev(S), st), "nsx_hash_ensemble_bwd_scatter")
             G_fused = None
         nonfinite = ptr(sink.nonfinite) if (sink is not None and need_tab and G_fused is not None) else None
         if need_code:
             check(L.nsx_hash_ensemble_bwd_codesum(ptr(pn), S, ptr(tables_f16), H, C.byref(geom), ptr(code_h),
                                                   code_h.stride(0), n_rows, ptr(hash_slot), ptr(hash_window), ptr(dout),
                                                   ptr(G_fused), ptr(g_code_hash), ptr(F.codesum_scratch(n_rows, H, dev)),
-                                                  ptr(dx), nonfinite, st), "nsx_hash_ensemble_bwd_codesum")
+                                                  ptr(dx), nonfinite, ndev(S), st), "nsx_hash_ensemble_bwd_codesum")
         else:
             check(L.nsx_hash_ensemble_bwd_factored(ptr(pn), S, ptr(tables_f16), H, C.byref(geom), ptr(code_h),
                                                    code_h.stride(0), n_rows, ptr(hash_slot), ptr(hash_window), ptr(dout),
-                                                   ptr(G_fused), None, ptr(dx), nonfinite, st),
+                                                   ptr(G_fused), None, ptr(dx), nonfinite, ndev(S), st),
                   "nsx_hash_ensemble_bwd_factored")
         if sink is not None and need_tab and ctx.announced:
             # G is complete, and so are the gradients of the two fused MLPs (the rest of the tables' optimizer group):
@@ -241,12 +242,12 @@ class _MainPass(torch.autograd.Function):
                                          ptr(dtab), 0, st), "nsx_hash_grad_expand")
         # -- normalisation: gradient of the offsets
         goff = torch.empty((S, 3), dtype=f32, device=dev)
-        check(L.nsx_normalise_bwd(ptr(dx), ptr(sel), S, inp.field_aabb6, ptr(goff), st), "nsx_normalise_bwd")
+        check(L.nsx_normalise_bwd(ptr(dx), ptr(sel), S, inp.field_aabb6, ptr(goff), ndev(S), st), "nsx_normalise_bwd")
         # -- deformation field
         scratch = torch.empty(int(L.nsx_deform_scratch_bytes(S)), dtype=torch.uint8, device=dev)
         check(L.nsx_deform_bwd(ptr(inp.deform_packed), ptr(pos), S, inp.deform_aabb6, ptr(code_d), code_d.stride(0),
                                ptr(inp.slot), code_d.shape[0], inp.deform_window7, ptr(goff), ptr(scratch), ptr(gparams),
-                               ptr(gtable), None, st), "nsx_deform_bwd")
+                               ptr(gtable), None, ndev(S), st), "nsx_deform_bwd")
         sizes = []
         for shp in ctx.shapes[1]:
             n = 1

@@ -11,7 +11,7 @@ from typing import Optional
 import torch
 
 from . import _lib
-from ._lib import GridGeom, check, lib, ptr, stream
+from ._lib import GridGeom, check, lib, ndev, ptr, stream
 
 
 # ------------------------------------------------------------------------------------------------
@@ -61,7 +61,7 @@ def _hash_ensemble_fwd_raw(x, tables_f16, H, geom, code, code_index, window):
     out = torch.empty((B, 2 * geom.n_levels), dtype=torch.float16, device=x.device)
     check(lib().nsx_hash_ensemble_fwd(ptr(x, torch.float32), B, ptr(tables_f16, torch.float16), H, C.byref(geom),
                                       ptr(code, torch.float32), code.stride(0), ptr(code_index, torch.int32),
-                                      ptr(window, torch.float32), ptr(out), stream()), "nsx_hash_ensemble_fwd")
+                                      ptr(window, torch.float32), ptr(out), ndev(B), stream()), "nsx_hash_ensemble_fwd")
     return out
 
 
@@ -267,6 +267,7 @@ class _HashEnsembleFn(torch.autograd.Function):
                         entry["fresh"] = False
                     check(lib().nsx_hash_ensemble_bwd_scatter(ptr(x), B, C.byref(geom), n_rows, ptr(code_index), ptr(dout),
                                                               ptr(G), ptr(sink.nonfinite), sink.scatter_blocks_per_cu,
+                                                              ndev(B),
                                                               stream()), "nsx_hash_ensemble_bwd_scatter")
                     sink.scatter_done = torch.cuda.Event()
                     sink.scatter_done.record(side)
@@ -278,7 +279,7 @@ class _HashEnsembleFn(torch.autograd.Function):
                 # items of a sample and level as 16 instructions of unrelated sectors; the stand-alone scatter keeps the
                 # 8-lanes-per-sample mapping whose neighbouring items share a sector (3x fewer sector atomics)
                 check(lib().nsx_hash_ensemble_bwd_scatter(ptr(x), B, C.byref(geom), n_rows, ptr(code_index), ptr(dout),
-                                                          ptr(G), ptr(ctx.sink.nonfinite), 8, stream()),
+                                                          ptr(G), ptr(ctx.sink.nonfinite), 8, ndev(B), stream()),
                       "nsx_hash_ensemble_bwd_scatter")
                 G = None
             nonfinite = ptr(ctx.sink.nonfinite) if (use_sink and G is not None) else None
@@ -287,11 +288,12 @@ class _HashEnsembleFn(torch.autograd.Function):
                                                           code.stride(0), n_rows, ptr(code_index), ptr(window),
                                                           ptr(dout), ptr(G), ptr(dcode_rows),
                                                           ptr(codesum_scratch(n_rows, H, x.device)), ptr(dx), nonfinite,
+                                                          ndev(B),
                                                           stream()), "nsx_hash_ensemble_bwd_codesum")
             else:
                 check(lib().nsx_hash_ensemble_bwd_factored(ptr(x), B, ptr(tables_f16), H, C.byref(geom), ptr(code),
                                                            code.stride(0), n_rows, ptr(code_index), ptr(window),
-                                                           ptr(dout), ptr(G), None, ptr(dx), nonfinite, stream()),
+                                                           ptr(dout), ptr(G), None, ptr(dx), nonfinite, ndev(B), stream()),
                       "nsx_hash_ensemble_bwd_factored")
             if use_sink and ctx.announced:
                 ctx.sink.arrived()
@@ -304,7 +306,7 @@ class _HashEnsembleFn(torch.autograd.Function):
             dtab = torch.zeros(ctx.master_shape, dtype=torch.float32, device=x.device) if need_tab else None
             check(lib().nsx_hash_ensemble_bwd(ptr(x), B, ptr(tables_f16), H, C.byref(geom), ptr(code),
                                               code.stride(0), ptr(code_index), ptr(window), ptr(dout), ptr(dtab),
-                                              ptr(dcode_s), ptr(dx), stream()), "nsx_hash_ensemble_bwd")
+                                              ptr(dcode_s), ptr(dx), ndev(B), stream()), "nsx_hash_ensemble_bwd")
         dcode = None
         if need_code:
             if dcode_rows is not None:
@@ -375,7 +377,7 @@ class _FusedMLPFn(torch.autograd.Function):
             check(lib().nsx_mlp_fwd(ptr(w16), n_hidden_mats, B,
                                     ptr(a_c), a_c.stride(0) if a_c is not None else 0, a_dim, a_mul, a_add,
                                     ptr(b_c), b_c.stride(0) if b_c is not None else 0, b_off,
-                                    b_dim if b_c is not None else 0, n_out, out_act, ptr(out), out.stride(0), stream()),
+                                    b_dim if b_c is not None else 0, n_out, out_act, ptr(out), out.stride(0), ndev(B), stream()),
                   "nsx_mlp_fwd")
         ctx.save_for_backward(w16, a_c, b_c)
         ctx.cfg = (n_hidden_mats, a_mul, a_add, b_off, b_dim, n_out, out_act, a_dim)
@@ -397,7 +399,7 @@ class _FusedMLPFn(torch.autograd.Function):
         check(lib().nsx_mlp_bwd(ptr(w16), n_hidden_mats, B,
                                 ptr(a_c), a_c.stride(0) if a_c is not None else 0, a_dim, a_mul, a_add,
                                 ptr(b_c), b_c.stride(0) if b_c is not None else 0, b_off, b_dim if b_c is not None else 0,
-                                n_out, out_act, ptr(dout), dout.stride(0), ptr(dW), ptr(da), ptr(db), None, stream()),
+                                n_out, out_act, ptr(dout), dout.stride(0), ptr(dW), ptr(da), ptr(db), None, ndev(B), stream()),
               "nsx_mlp_bwd")
         return dW, da, db, None, None, None, None, None, None, None, None, None
 
@@ -457,7 +459,7 @@ class _DeformFn(torch.autograd.Function):
         else:
             off = torch.empty((S, 3), dtype=torch.float32, device=dev)
             check(lib().nsx_deform_fwd(ptr(packed), ptr(pos), S, aabb6, ptr(code_c), code_c.stride(0), ptr(code_slot),
-                                       window7, ptr(off), stream()), "nsx_deform_fwd")
+                                       window7, ptr(off), ndev(S), stream()), "nsx_deform_fwd")
         ctx.save_for_backward(packed, pos, code_c, code_slot)
         ctx.aabb6, ctx.window7 = aabb6, window7
         ctx.param_shapes = [tuple(p.shape) for p in params]
@@ -481,7 +483,7 @@ class _DeformFn(torch.autograd.Function):
         scratch = torch.empty(int(lib().nsx_deform_scratch_bytes(S)), dtype=torch.uint8, device=dev)
         check(lib().nsx_deform_bwd(ptr(packed), ptr(pos), S, ctx.aabb6, ptr(code_c), code_c.stride(0), ptr(code_slot),
                                    code_c.shape[0] if gtable is not None else 0, ctx.window7, ptr(goff), ptr(scratch),
-                                   ptr(gparams), ptr(gtable), ptr(gsamples), stream()), "nsx_deform_bwd")
+                                   ptr(gparams), ptr(gtable), ptr(gsamples), ndev(S), stream()), "nsx_deform_bwd")
         gcode = None
         if need_code:
             if gtable is not None:
@@ -559,6 +561,7 @@ def sample_positions(origins: torch.Tensor, directions: Optional[torch.Tensor], 
     ri = ray_indices.to(torch.int64).contiguous() if ray_indices is not None else None
     out = torch.empty((S, 3), dtype=torch.float32, device=o.device)
     check(lib().nsx_sample_positions(ptr(o), ptr(d), ptr(ri), ptr(t0), ptr(t1), None, S, None, ptr(out), None, None,
+                                     ndev(S),
                                      stream()), "nsx_sample_positions")
     return out
 
@@ -574,6 +577,7 @@ class _NormalisedPositionsFn(torch.autograd.Function):
         pn = torch.empty((S, 3), dtype=torch.float32, device=p.device)
         sel = torch.empty((S,), dtype=torch.uint8, device=p.device)
         check(lib().nsx_sample_positions(ptr(p), None, None, None, None, ptr(off), S, aabb6, None, ptr(pn), ptr(sel),
+                                         ndev(S),
                                          stream()), "nsx_sample_positions")
         ctx.save_for_backward(sel)
         ctx.aabb6 = aabb6
@@ -589,7 +593,8 @@ class _NormalisedPositionsFn(torch.autograd.Function):
             return None, None, None
         g = g.to(torch.float32).contiguous()
         dpos = torch.empty_like(g)
-        check(lib().nsx_normalise_bwd(ptr(g), ptr(sel), g.shape[0], ctx.aabb6, ptr(dpos), stream()), "nsx_normalise_bwd")
+        check(lib().nsx_normalise_bwd(ptr(g), ptr(sel), g.shape[0], ctx.aabb6, ptr(dpos), ndev(g.shape[0]), stream()),
+              "nsx_normalise_bwd")
         return (dpos if need_p else None), (dpos if need_o else None), None
 
 
@@ -607,7 +612,7 @@ class _DensityFn(torch.autograd.Function):
         S = b.shape[0]
         dens = torch.empty((S, 1), dtype=torch.float32, device=b.device)
         check(lib().nsx_density_fwd(ptr(b) if b.is_contiguous() else C.c_void_p(b.data_ptr()), b.stride(0), ptr(sel), S,
-                                    ptr(dens), stream()), "nsx_density_fwd")
+                                    ptr(dens), ndev(S), stream()), "nsx_density_fwd")
         ctx.save_for_backward(b, sel)
         return dens
 
@@ -617,6 +622,7 @@ class _DensityFn(torch.autograd.Function):
         g = g.reshape(-1).to(torch.float32).contiguous()
         db = torch.zeros(b.shape, dtype=torch.float16, device=b.device)
         check(lib().nsx_density_bwd(C.c_void_p(b.data_ptr()), b.stride(0), ptr(sel), ptr(g), b.shape[0], ptr(db),
+                                    ndev(b.shape[0]),
                                     stream()), "nsx_density_bwd")
         return db, None
 
@@ -696,7 +702,7 @@ def gather_rows(index: torch.Tensor, *tensors: torch.Tensor, zero_fill: bool = F
         src_arr = (C.c_void_p * k)(*[t.data_ptr() for t in srcs])
         dst_arr = (C.c_void_p * k)(*[t.data_ptr() for t in outs])
         rb_arr = (C.c_int64 * k)(*rb)
-        check(lib().nsx_gather_rows(k, src_arr, rb_arr, dst_arr, ptr(idx), n, stream()), "nsx_gather_rows")
+        check(lib().nsx_gather_rows(k, src_arr, rb_arr, dst_arr, ptr(idx), n, ndev(n), stream()), "nsx_gather_rows")
     return tuple(outs)
 
 

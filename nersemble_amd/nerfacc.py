@@ -13,7 +13,7 @@ from typing import Callable, Optional, Tuple
 import torch
 from torch import nn, Tensor
 
-from ._lib import check, lib, ptr, stream
+from ._lib import check, lib, ndev, ptr, stream
 
 
 # ------------------------------------------------------------------------------------------------
@@ -27,7 +27,8 @@ def pack_info(ray_indices: Tensor, n_rays: Optional[int] = None) -> Tensor:
         n_rays = int(ray_indices.max().item()) + 1 if ray_indices.numel() else 0
     dev = ray_indices.device
     counts = torch.zeros((n_rays,), dtype=torch.int64, device=dev)
-    check(lib().nsx_ray_histogram(ptr(ray_indices), ray_indices.numel(), n_rays, ptr(counts), stream()),
+    check(lib().nsx_ray_histogram(ptr(ray_indices), ray_indices.numel(), n_rays, ptr(counts), ndev(ray_indices.numel()),
+                                  stream()),
           "nsx_ray_histogram")
     packed = torch.empty((n_rays, 2), dtype=torch.int64, device=dev)
     total = torch.empty((1,), dtype=torch.int64, device=dev)

@@ -87,7 +87,7 @@ def test_positions_and_normalisation_in_one_launch(cuda):
     pn = torch.empty((S, 3), device=cuda)
     sel = torch.empty((S,), dtype=torch.uint8, device=cuda)
     check(lib().nsx_sample_positions(ptr(og), ptr(dg), None, ptr(t0g), ptr(t1g), ptr(offg), S, _aabb6(), ptr(pos),
-                                     ptr(pn), ptr(sel), stream()), "nsx_sample_positions")
+                                     ptr(pn), ptr(sel), None, stream()), "nsx_sample_positions")
     assert np.array_equal(pos.cpu().numpy(), pos_want)                      # no offsets in the world position
     assert np.array_equal(pn.cpu().numpy(), pn_want) and np.array_equal(sel.cpu().numpy().astype(bool), sel_want)
     assert 0.1 < sel_want.mean() < 0.95 and np.abs(pos_want + off - pos_want).max() > 0.1

@@ -39,9 +39,10 @@ def test_full_size_backward_h32_vs_oracle(cuda):
         dcode = torch.empty((n, H), device=cuda)
         dx = torch.empty((n, 3), device=cuda)
         check(lib().nsx_hash_ensemble_bwd_scatter(ptr(x), n, C.byref(gn), T, ptr(slot), ptr(dout), ptr(G), None, 8,
+                                                  None,
                                                   stream()), "scatter")
         check(lib().nsx_hash_ensemble_bwd_factored(ptr(x), n, ptr(f16), H, C.byref(gn), ptr(table), table.stride(0), T,
-                                                   ptr(slot), None, ptr(dout), None, ptr(dcode), ptr(dx), None, stream()),
+                                                   ptr(slot), None, ptr(dout), None, ptr(dcode), ptr(dx), None, None, stream()),
               "gather")
         return G, dcode, dx
 

@@ -340,7 +340,7 @@ def test_split_backward_equals_fused(H, coherent, cuda):
 
     def run(G, dc, dx, nf):
         check(lib().nsx_hash_ensemble_bwd_factored(ptr(xt), B, ptr(f16), H, C.byref(gn), ptr(table), table.stride(0), T,
-                                                   ptr(slot), None, ptr(dout), ptr(G), ptr(dc), ptr(dx), ptr(nf), stream()),
+                                                   ptr(slot), None, ptr(dout), ptr(G), ptr(dc), ptr(dx), ptr(nf), None, stream()),
               "nsx_hash_ensemble_bwd_factored")
 
     G_f = torch.zeros((T, total, 2), device=cuda)
@@ -354,7 +354,7 @@ def test_split_backward_equals_fused(H, coherent, cuda):
         G_s = torch.zeros((T, total, 2), device=cuda)
         nf_s = torch.zeros((1,), device=cuda)
         check(lib().nsx_hash_ensemble_bwd_scatter(ptr(xt), B, C.byref(gn), T, ptr(slot), ptr(dout), ptr(G_s), ptr(nf_s),
-                                                  blocks, stream()), "nsx_hash_ensemble_bwd_scatter")
+                                                  blocks, None, stream()), "nsx_hash_ensemble_bwd_scatter")
         sc = G_f.abs().max().item()
         assert sc > 0 and (G_s - G_f).abs().max().item() <= 2e-5 * sc
         assert torch.equal((G_s != 0), (G_f != 0)) and nf_s.item() == 0
@@ -362,10 +362,11 @@ def test_split_backward_equals_fused(H, coherent, cuda):
     dout[B // 2, 7] = float("inf")
     nf_s = torch.zeros((1,), device=cuda)
     check(lib().nsx_hash_ensemble_bwd_scatter(ptr(xt), B, C.byref(gn), T, ptr(slot), ptr(dout), ptr(torch.zeros_like(G_f)),
-                                              ptr(nf_s), 2, stream()), "nsx_hash_ensemble_bwd_scatter")
+                                              ptr(nf_s), 2, None, stream()), "nsx_hash_ensemble_bwd_scatter")
     assert nf_s.item() == 1
     # empty batch: no launch, no error
     check(lib().nsx_hash_ensemble_bwd_scatter(ptr(xt), 0, C.byref(gn), T, ptr(slot), ptr(dout), ptr(G_f), None, 2,
+                                              None,
                                               stream()), "nsx_hash_ensemble_bwd_scatter")
 
 
@@ -397,6 +398,7 @@ def test_code_gradient_summed_in_the_kernel(H, order, cuda):
     dc_f, dx_f = torch.empty((B, H), device=cuda), torch.empty((B, 3), device=cuda)
     check(lib().nsx_hash_ensemble_bwd_factored(ptr(xt), B, ptr(f16), H, C.byref(gn), ptr(table), table.stride(0), T,
                                                ptr(slot), ptr(win), ptr(dout), ptr(G_f), ptr(dc_f), ptr(dx_f), None,
+                                               None,
                                                stream()), "nsx_hash_ensemble_bwd_factored")
     want = np.zeros((T, H), dtype=np.float64)
     np.add.at(want, sl, dc_f.cpu().numpy().astype(np.float64) * win_np[None].astype(np.float64))
@@ -404,7 +406,7 @@ def test_code_gradient_summed_in_the_kernel(H, order, cuda):
     def run(n, G, rows, dx):
         check(lib().nsx_hash_ensemble_bwd_codesum(ptr(xt), n, ptr(f16), H, C.byref(gn), ptr(table), table.stride(0), T,
                                                   ptr(slot), ptr(win), ptr(dout), ptr(G), ptr(rows),
-                                                  ptr(F.codesum_scratch(T, H, cuda)), ptr(dx), None, stream()),
+                                                  ptr(F.codesum_scratch(T, H, cuda)), ptr(dx), None, None, stream()),
               "nsx_hash_ensemble_bwd_codesum")
 
     for with_G in (True, False):
@@ -420,7 +422,7 @@ def test_code_gradient_summed_in_the_kernel(H, order, cuda):
     # rows no sample uses come out as exact zeros
     unused = np.setdiff1d(np.arange(T), sl)
     assert (got[unused] == 0).all()
-    # device-side sample count (nsx_device_count_begin): only the first n rows contribute; n = 0 gives zeros
+    # device-side sample count (the entry points' n_device argument): only the first n rows contribute; n = 0 gives zeros
     for n in (B // 3, 0):
         n_dev = torch.tensor([n], dtype=torch.int64, device=cuda)
         rows = torch.full((T, H), float("nan"), device=cuda)

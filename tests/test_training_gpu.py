@@ -522,31 +522,48 @@ def test_device_side_sample_counts_equal_host_side_counts(cuda):
     assert np.allclose(l_h, l_d, rtol=5e-2)
 
 
-def test_device_count_scope_of_the_c_abi(cuda):
-    """nsx_device_count_begin / _end: a per-sample entry point called with the registered capacity touches only the first
-    *n rows; other sizes and calls outside the scope are unaffected; the scope does not nest."""
-    from nersemble_amd import _lib, functional as F
-    from nersemble_amd._lib import device_count
+def test_device_count_argument_of_the_c_abi(cuda):
+    """``n_device`` (include/nsx.h, "Device-side element counts"): a per-sample entry point handed a device-side count
+    touches only the first ``min(*n_device, rows)`` rows -- straight through the C ABI, no state between calls: the same
+    call with NULL right after it processes every row.  Then the Python convenience over it (``_lib.device_count`` +
+    ``ndev``): the pointer goes to calls of exactly the block's capacity, blocks do not nest."""
+    import ctypes as C
+    from nersemble_amd import functional as F
+    from nersemble_amd._lib import check, device_count, lib, ndev, ptr, stream
     src = torch.arange(40, device=cuda, dtype=torch.float32).reshape(10, 4)
     idx = torch.tensor([9, 8, 7, 6, 5, 4, 3, 2, 1, 0], device=cuda)
     n = torch.tensor([3], device=cuda, dtype=torch.int64)
+
+    def gather_c(count_ptr):
+        dst = torch.full((10, 4), -1.0, device=cuda)
+        srcs, dsts, rb = (C.c_void_p * 1)(src.data_ptr()), (C.c_void_p * 1)(dst.data_ptr()), (C.c_int64 * 1)(16)
+        check(lib().nsx_gather_rows(1, srcs, rb, dsts, ptr(idx), 10, count_ptr, stream()), "nsx_gather_rows")
+        return dst
+
+    part, full = gather_c(ptr(n)), gather_c(None)
+    assert torch.equal(part[:3], src[idx[:3]]) and bool((part[3:] == 0).all())          # (gather zero-fills its tail)
+    assert torch.equal(full, src[idx])
+    # a kernel that leaves rows beyond the count alone: the density epilogue
+    base = torch.randn(10, 16, device=cuda).half()
+    sel = torch.ones(10, dtype=torch.uint8, device=cuda)
+    dens = torch.full((10, 1), -7.0, device=cuda)
+    check(lib().nsx_density_fwd(ptr(base), 16, ptr(sel), 10, ptr(dens), ptr(n), stream()), "nsx_density_fwd")
+    assert torch.equal(dens[:3, 0], torch.exp(base[:3, 0].float())) and bool((dens[3:] == -7.0).all())
+    # the Python scope
     with device_count(n, 10):
-        (part,) = F.gather_rows(idx, src, zero_fill=True)
+        assert ndev(10).value == n.data_ptr() and not ndev(5).value
+        (part2,) = F.gather_rows(idx, src, zero_fill=True)
         (other,) = F.gather_rows(idx[:5], src, zero_fill=True)              # size != capacity: every row
         with pytest.raises(RuntimeError):
             with device_count(n, 10):
                 pass
-    (full,) = F.gather_rows(idx, src)
-    assert torch.equal(part[:3], src[idx[:3]]) and bool((part[3:] == 0).all())
-    assert torch.equal(other, src[idx[:5]]) and torch.equal(full, src[idx])
+    assert not ndev(10).value
+    (full2,) = F.gather_rows(idx, src)
+    assert torch.equal(part2, part) and torch.equal(other, src[idx[:5]]) and torch.equal(full2, src[idx])
     n.fill_(0)
-    with device_count(n, 10):
-        (none,) = F.gather_rows(idx, src, zero_fill=True)
-    assert bool((none == 0).all())
+    assert bool((gather_c(ptr(n)) == 0).all())
     n.fill_(25)                                                               # more than the capacity: capped
-    with device_count(n, 10):
-        (capped,) = F.gather_rows(idx, src, zero_fill=True)
-    assert torch.equal(capped, src[idx])
+    assert torch.equal(gather_c(ptr(n)), src[idx])
 
 
 def test_march_counted_one_step_ahead_is_the_same_march(cuda):

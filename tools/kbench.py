@@ -64,7 +64,7 @@ def main():
     def bwd(dt=dtab):
         _lib.check(_lib.lib().nsx_hash_ensemble_bwd(_lib.ptr(x), B, _lib.ptr(f16), H, C.byref(g), _lib.ptr(emb),
                                                     emb.stride(0), _lib.ptr(ts), None, _lib.ptr(dout), _lib.ptr(dt),
-                                                    _lib.ptr(dcode), _lib.ptr(dx), _lib.stream()))
+                                                    _lib.ptr(dcode), _lib.ptr(dx), None, _lib.stream()))
     if a.generic:
         ms = timeit(bwd, 2, 1)
         res["bwd_generic_ms"] = ms
@@ -76,7 +76,7 @@ def main():
         _lib.check(_lib.lib().nsx_hash_ensemble_bwd_factored(_lib.ptr(x), B, _lib.ptr(f16), H, C.byref(g),
                                                              _lib.ptr(emb), emb.stride(0), T, _lib.ptr(ts), None,
                                                              _lib.ptr(dout), _lib.ptr(Gp), _lib.ptr(dcode),
-                                                             _lib.ptr(dx), None, _lib.stream()))
+                                                             _lib.ptr(dx), None, None, _lib.stream()))
     res["bwd_factored_ms"] = timeit(bwdf, a.iters)
     res["bwd_factored_GBps"] = B * (1024 * H + 76) / res["bwd_factored_ms"] / 1e6
     res["expand_ms"] = timeit(lambda: _lib.check(_lib.lib().nsx_hash_grad_expand(

@@ -76,19 +76,19 @@ def main():
             dout = torch.randn(S, 16, device=dev).half()
             db32 = torch.empty(S, 32, device=dev)
             fns["mlp_fwd_base"] = lambda w=w, out=out: check(lib().nsx_mlp_fwd(
-                ptr(w), 0, S, None, 0, 0, 1.0, 0.0, ptr(feats), 32, 0, 32, 16, 0, ptr(out), 16, stream()), "f")
+                ptr(w), 0, S, None, 0, 0, 1.0, 0.0, ptr(feats), 32, 0, 32, 16, 0, ptr(out), 16, None, stream()), "f")
             fns["mlp_bwd_base"] = lambda w=w, dout=dout, dW=dW, db32=db32: check(lib().nsx_mlp_bwd(
                 ptr(w), 0, S, None, 0, 0, 1.0, 0.0, ptr(feats), 32, 0, 32, 16, 0, ptr(dout), 16, ptr(dW), None, None,
-                ptr(db32), stream()), "b")
+                ptr(db32), None, stream()), "b")
         else:
             out3 = torch.empty(S, 3, device=dev).half()
             dout3 = torch.randn(S, 3, device=dev).half()
             dbo = torch.zeros(S, 16, device=dev).half()
             fns["mlp_fwd_head"] = lambda w=w, out3=out3: check(lib().nsx_mlp_fwd(
-                ptr(w), 1, S, ptr(dirs), 3, 3, 0.5, 0.5, ptr(base_out), 16, 1, 15, 3, 1, ptr(out3), 3, stream()), "f")
+                ptr(w), 1, S, ptr(dirs), 3, 3, 0.5, 0.5, ptr(base_out), 16, 1, 15, 3, 1, ptr(out3), 3, None, stream()), "f")
             fns["mlp_bwd_head"] = lambda w=w, dout3=dout3, dW=dW, dbo=dbo: check(lib().nsx_mlp_bwd(
                 ptr(w), 1, S, ptr(dirs), 3, 3, 0.5, 0.5, ptr(base_out), 16, 1, 15, 3, 1, ptr(dout3), 3, ptr(dW), None,
-                ptr(dbo), None, stream()), "h")
+                ptr(dbo), None, None, stream()), "h")
     res = {"S": S, "peak_tflops": PEAK_TFLOPS}
     for name, fn in fns.items():
         if only and name not in only:

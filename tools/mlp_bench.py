@@ -23,8 +23,8 @@ for nh, name in ((0, "base"), (1, "head")):
     dW = torch.zeros(w.numel(), device=dev)
     if nh == 0:
         dout = torch.randn(S, 16, device=dev).half(); db32 = torch.empty(S, 32, device=dev)
-        fn = lambda: check(lib().nsx_mlp_bwd(ptr(w), 0, S, None, 0, 0, 1.0, 0.0, ptr(feats), 32, 0, 32, 16, 0, ptr(dout), 16, ptr(dW), None, None, ptr(db32), stream()), "b")
+        fn = lambda: check(lib().nsx_mlp_bwd(ptr(w), 0, S, None, 0, 0, 1.0, 0.0, ptr(feats), 32, 0, 32, 16, 0, ptr(dout), 16, ptr(dW), None, None, ptr(db32), None, stream()), "b")
     else:
         dout = torch.randn(S, 3, device=dev).half(); dbo = torch.zeros(S, 16, device=dev).half()
-        fn = lambda: check(lib().nsx_mlp_bwd(ptr(w), 1, S, ptr(dirs), 3, 3, 0.5, 0.5, ptr(base_out), 16, 1, 15, 3, 1, ptr(dout), 3, ptr(dW), None, ptr(dbo), None, stream()), "h")
+        fn = lambda: check(lib().nsx_mlp_bwd(ptr(w), 1, S, ptr(dirs), 3, 3, 0.5, 0.5, ptr(base_out), 16, 1, 15, 3, 1, ptr(dout), 3, ptr(dW), None, ptr(dbo), None, None, stream()), "h")
     print(name, S, round(timeit(fn), 4), "ms", os.environ.get("NSX_MLP_BWD_HALF_BLOCKS_PER_CU"), os.environ.get("NSX_MLP_BWD0_HALF_BLOCKS_PER_CU"))

@@ -23,7 +23,7 @@ for mode in ("uniform", "rays"):
     dout = torch.randn(S, 32, device=dev)
     G = torch.zeros(T, total, 2, device=dev)
     def run():
-        check(lib().nsx_hash_ensemble_bwd_scatter(ptr(x), S, C.byref(g), T, ptr(slot), ptr(dout), ptr(G), None, 8, stream()), "s")
+        check(lib().nsx_hash_ensemble_bwd_scatter(ptr(x), S, C.byref(g), T, ptr(slot), ptr(dout), ptr(G), None, 8, None, stream()), "s")
     for _ in range(2): run()
     torch.cuda.synchronize()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
