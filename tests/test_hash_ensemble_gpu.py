@@ -379,7 +379,7 @@ def test_code_gradient_summed_in_the_kernel(H, order, cuda):
     samples of a row are adjacent (a ray's samples: the DPP run-merge path), ``random``: every lane its own row."""
     import ctypes as C
     from nersemble_amd import functional as F
-    from nersemble_amd._lib import check, device_count, lib, ptr, stream
+    from nersemble_amd._lib import check, lib, ptr, stream
     B, T = 4099, 24
     go, gn, tabs, f16, master, x, _ = _setup(H, SMALL_GEOM_KW, 500 + H, B, cuda)
     rng = np.random.default_rng(3 * H)
@@ -403,10 +403,11 @@ def test_code_gradient_summed_in_the_kernel(H, order, cuda):
     want = np.zeros((T, H), dtype=np.float64)
     np.add.at(want, sl, dc_f.cpu().numpy().astype(np.float64) * win_np[None].astype(np.float64))
 
-    def run(n, G, rows, dx):
+    def run(n, G, rows, dx, n_device=None):
         check(lib().nsx_hash_ensemble_bwd_codesum(ptr(xt), n, ptr(f16), H, C.byref(gn), ptr(table), table.stride(0), T,
                                                   ptr(slot), ptr(win), ptr(dout), ptr(G), ptr(rows),
-                                                  ptr(F.codesum_scratch(T, H, cuda)), ptr(dx), None, None, stream()),
+                                                  ptr(F.codesum_scratch(T, H, cuda)), ptr(dx), None, ptr(n_device),
+                                                  stream()),
               "nsx_hash_ensemble_bwd_codesum")
 
     for with_G in (True, False):
@@ -426,8 +427,7 @@ def test_code_gradient_summed_in_the_kernel(H, order, cuda):
     for n in (B // 3, 0):
         n_dev = torch.tensor([n], dtype=torch.int64, device=cuda)
         rows = torch.full((T, H), float("nan"), device=cuda)
-        with device_count(n_dev, B):
-            run(B, None, rows, torch.empty((B, 3), device=cuda))
+        run(B, None, rows, torch.empty((B, 3), device=cuda), n_device=n_dev)
         w2 = np.zeros((T, H), dtype=np.float64)
         np.add.at(w2, sl[:n], dc_f.cpu().numpy()[:n].astype(np.float64) * win_np[None].astype(np.float64))
         assert np.abs(rows.cpu().numpy() - w2).max() <= 2e-5 * np.abs(want).max() + 1e-7
