@@ -519,6 +519,193 @@ int nsx_occ_sample_cells(int res, const float* aabb_host, int warmup, const int3
 int nsx_occ_update(float* occs, uint8_t* binaries, int64_t n_cells, const int32_t* cell_ids, const float* occ_values,
                    int64_t M, float ema_decay, float occ_thre, void* scratch, float* threshold_out, void* stream);
 
+/* ---- training-step drivers (csrc/step.hip) ------------------------------------------------------------------
+ * One optimisation step of the reference (engine/nersemble_trainer.py:169-206 -> nersemble_instant_ngp.py:280-422)
+ * is ~45 launches of the entry points above.  Issued one by one from the host language they cost ~10 us each of
+ * marshalling -- more than the kernels themselves once the occupancy grid has pruned the scene (the step is then paced
+ * by the HOST).  The drivers below enqueue whole phases of the step from C: same kernels, same arguments, same order
+ * as the per-kernel path (engine/fused_pass.py, nerfacc.py, the sampler), held to it bit for bit by
+ * tests/test_native_step_gpu.py.  The caller owns every byte: it asks nsx_step_plan for the sizes and the offsets of
+ * the sub-buffers, allocates the workspaces and passes their base pointers.
+ *
+ *   nsx_step_sample     the sampler behind NeRSembleVolumetricSampler.forward (nersemble_volumetric_sampler.py:95-134)
+ *                       after the traversal's counting pass: nsx_march_fill, the sigma_fn density pass
+ *                       (nersemble_instant_ngp.py:235-266: midpoints, per-ray timestep gather, deformation, scene-box
+ *                       normalisation, HashEnsemble, mlp_base, trunc_exp), the visibility test, its stream compaction, the
+ *                       gathers of the kept samples (intervals, rays, code slots, and the sigma pass's forward values the
+ *                       main pass reuses) and pack_info of the kept samples.  The kept count stays on the device.
+ *   nsx_step_main_fwd   NeRSembleNGPModel.get_outputs + get_loss_dict + get_metrics_dict on the kept samples (:300-422)
+ *   nsx_step_main_bwd   its backward in three stages (0: losses ... mlp_base, 1: HashEnsemble, 2: normalisation +
+ *                       deformation field) so that the caller can resolve the factored-gradient buffer and start
+ *                       collectives in between.
+ * Struct fields are grouped pointers / int64 / int32 / float so that no padding depends on the compiler; the Python
+ * binding (nersemble_amd/_lib.py) builds its mirrors by parsing this header, tests check sizeof and a field echo. */
+typedef struct nsx_step_plan {
+    int64_t S;                  /* marched samples = capacity of every per-sample array */
+    int64_t R;
+    int64_t sample_bytes;       /* workspace of nsx_step_sample */
+    int64_t m_ri;               /* marched: ray index int64 [S] */
+    int64_t m_t0;
+    int64_t m_t1;
+    int64_t m_pos;              /* world midpoints [S][3] */
+    int64_t m_ts;               /* timestep of the sample's ray int32 [S] */
+    int64_t m_off;              /* deformation offsets [S][3] */
+    int64_t m_pn;               /* normalised positions [S][3] */
+    int64_t m_sel;              /* in-box selector u8 [S] */
+    int64_t m_feat;             /* hash features fp16 [S][32] */
+    int64_t m_base;             /* mlp_base output fp16 [S][16] */
+    int64_t m_dens;             /* density [S] */
+    int64_t m_vis;              /* visibility mask u8 [S] */
+    int64_t m_keep;             /* ascending indices of the visible samples int64 [S] */
+    int64_t m_scratch;          /* scan scratch of nsx_compact_mask */
+    int64_t n_kept;             /* device int64: number of kept samples (the n_device of everything downstream) */
+    int64_t k_ri;               /* kept (first *n_kept rows valid, capacity S): ray index int64 */
+    int64_t k_t0;
+    int64_t k_t1;
+    int64_t k_org;              /* ray origin per sample [S][3] */
+    int64_t k_dir;
+    int64_t k_slot;             /* code slot int32 [S] */
+    int64_t k_off;              /* sigma-pass forward values of the kept samples: offsets, hash features, mlp_base output */
+    int64_t k_feat;
+    int64_t k_base;
+    int64_t k_counts;           /* samples per ray int64 [R] */
+    int64_t k_packed;           /* packed_info int64 [R][2] */
+    int64_t k_total;            /* device int64 (unused by the drivers) */
+    int64_t fwd_bytes;          /* workspace of nsx_step_main_fwd (kept until the backward has run) */
+    int64_t f_pos;
+    int64_t f_pn;
+    int64_t f_sel;
+    int64_t f_dens;
+    int64_t f_rgb16;            /* per-sample colours fp16 [S][3] */
+    int64_t f_w;                /* rendering weights [S] */
+    int64_t f_rgb;              /* per ray [R][3] */
+    int64_t f_acc;
+    int64_t f_depth;
+    int64_t f_aux;              /* rendered deformation [R][3] */
+    int64_t f_clip;
+    int64_t f_per_ray;          /* [R][5] of nsx_sample_losses_fwd */
+    int64_t grad_bytes;         /* parameter gradients (handed to the caller's autograd) */
+    int64_t g_head;             /* mlp_head fp32 [nsx_mlp_param_count(head_hidden)] */
+    int64_t g_base;
+    int64_t g_deform;           /* fp32 [nsx_deform_param_count()] */
+    int64_t g_code_deform;      /* fp32 [n_code_rows][128] */
+    int64_t g_zero_end;         /* [g_head, g_zero_end) is cleared by stage 0 */
+    int64_t g_code_hash;        /* fp32 [n_code_rows][H] (written whole by the code-sum kernel) */
+    int64_t bwd_bytes;          /* scratch of the backward (free again when stage 2 has been enqueued) */
+    int64_t b_grgb;
+    int64_t b_gacc;
+    int64_t b_gdep;
+    int64_t b_g3;
+    int64_t b_gw;
+    int64_t b_ds;               /* [b_ds, b_zero_end) is cleared by stage 0: dL/dsigma, dL/drgb fp16, dL/dbase_out fp16 */
+    int64_t b_dc16;
+    int64_t b_dbase;
+    int64_t b_zero_end;
+    int64_t b_dout;             /* dL/dfeatures fp32 [S][32] */
+    int64_t b_dx;
+    int64_t b_goff;
+    int64_t b_csum;             /* block partials of the code sums */
+    int64_t b_deform;           /* nsx_deform_scratch_bytes(S) */
+} nsx_step_plan;
+int nsx_step_plan_make(int64_t S, int64_t R, int n_code_rows, int H, int base_hidden, int head_hidden,
+                       nsx_step_plan* out);
+
+typedef struct nsx_step_sample {
+    const float* origins;            /* [R][3] */
+    const float* directions;
+    const float* near_planes;        /* [R] (jittered), the ones the counting pass ran with */
+    const int64_t* packed_march;     /* [R][2] of the counting pass */
+    const uint8_t* binaries;         /* occupancy grid [res]^3 */
+    const int32_t* ray_timesteps;    /* [R]: row of the ray's samples in deform_codes / hash_codes */
+    const int32_t* ray_slots;        /* [R]: code slot of the ray in the main pass's compacted code tables */
+    const void* deform_packed;
+    const float* deform_codes;       /* [T][128] */
+    const nsx_half* tables;
+    const nsx_grid_geom* geom;
+    const float* hash_codes;         /* [T][H] (conditioned time codes; ones [T][1] in the compact first-grid phase) */
+    const float* hash_window;        /* [H] or NULL */
+    const nsx_half* base_w16;
+    const float* alpha_thre_dev;     /* device scalar: min(alpha_thre, occs.mean()) */
+    const float* window7_host;       /* 7 floats or NULL */
+    uint8_t* ws;                     /* plan->sample_bytes */
+    const nsx_step_plan* plan;
+    int64_t R;
+    int64_t S;
+    int64_t deform_code_stride;
+    int64_t hash_code_stride;
+    int32_t grid_res;
+    int32_t H;
+    int32_t base_hidden;
+    int32_t base_out_dim;
+    int32_t base_act;
+    int32_t reserved;
+    float far_plane;
+    float step;
+    float early_stop_eps;
+    float reserved_f;
+    float occ_aabb[6];
+    float deform_aabb[6];
+    float field_aabb[6];
+} nsx_step_sample;
+int nsx_step_sample_run(const nsx_step_sample* a, void* stream);
+
+typedef struct nsx_step_main {
+    uint8_t* ws_sample;              /* the workspace nsx_step_sample_run filled (kept arrays, n_kept) */
+    uint8_t* ws_fwd;                 /* plan->fwd_bytes */
+    float* out;                      /* float[NSX_LOSS_OUT] */
+    const float* image;              /* [R][3] */
+    const uint8_t* alpha_map;        /* [R] or NULL */
+    const float* depth_targets;      /* [R] */
+    const nsx_half* tables;
+    const nsx_grid_geom* geom;
+    const float* code_hash;          /* [n_code_rows][H] conditioned code rows of the batch */
+    const float* hash_window;
+    const void* deform_packed;
+    const float* code_deform;        /* [n_code_rows][128] */
+    const nsx_half* base_w16;
+    const nsx_half* head_w16;
+    const float* window7_host;
+    const float* grad_out;           /* backward: dL/d out, float[NSX_LOSS_OUT] */
+    uint8_t* ws_bwd;                 /* plan->bwd_bytes */
+    uint8_t* grads;                  /* plan->grad_bytes */
+    float* G;                        /* factored table gradient [n_code_rows][entries][2] or NULL */
+    float* nonfinite;                /* device flag or NULL */
+    const nsx_step_plan* plan;
+    int64_t R;
+    int64_t S;
+    int64_t code_hash_stride;
+    int64_t code_deform_stride;
+    int64_t max_ray;
+    int32_t H;                       /* grids the hash kernels run with (1 in the compact first-grid phase) */
+    int32_t n_code_rows;
+    int32_t base_hidden;
+    int32_t base_out_dim;
+    int32_t base_act;
+    int32_t head_hidden;
+    int32_t head_act;
+    int32_t geo_dim;
+    int32_t use_masked;
+    int32_t need_code_grad;          /* the code gradient (window open); 0: nsx_hash_ensemble_bwd_factored without it */
+    int32_t scatter_separately;      /* H == 1: the scatter as its own kernel (nsx_hash_ensemble_bwd_scatter) */
+    int32_t reserved;
+    float background;
+    float thr;
+    float l_alpha;
+    float l_depth;
+    float l_dist;
+    float l_empty;
+    float l_near;
+    float eps;
+    float field_aabb[6];
+    float deform_aabb[6];
+} nsx_step_main;
+int nsx_step_main_fwd(const nsx_step_main* a, void* stream);
+int nsx_step_main_bwd(const nsx_step_main* a, int stage, void* stream);
+/* sizeof / field echo for the binding's layout checks: nsx_step_echo writes the fields of the struct `kind`
+ * (0 sample, 1 main) as doubles in declaration order (pointers as addresses, arrays element by element). */
+int64_t nsx_step_sizeof(int kind /* 0 sample, 1 main, 2 plan */);
+int nsx_step_echo(int kind, const void* s, double* out, int capacity);
+
 #ifdef __cplusplus
 }
 #endif

@@ -153,7 +153,53 @@ SIGNATURES = {
                                      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "nsx_occ_update": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_float, c_float, c_void_p,
                                c_void_p, c_void_p]),
+    # training-step drivers (structs: see step_struct below)
+    "nsx_step_plan_make": (c_int, [c_int64, c_int64, c_int, c_int, c_int, c_int, c_void_p]),
+    "nsx_step_sample_run": (c_int, [c_void_p, c_void_p]),
+    "nsx_step_main_fwd": (c_int, [c_void_p, c_void_p]),
+    "nsx_step_main_bwd": (c_int, [c_void_p, c_int, c_void_p]),
+    "nsx_step_sizeof": (c_int64, [c_int]),
+    "nsx_step_echo": (c_int, [c_int, c_void_p, c_void_p, c_int]),
 }
+
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "nsx.h")
+_STEP_STRUCTS = {}
+
+
+def step_struct(name: str):
+    """ctypes mirror of one of the training-step driver structs (``nsx_step_plan`` / ``nsx_step_sample`` /
+    ``nsx_step_main``), built from its declaration in include/nsx.h -- one field per line there -- so that the two cannot
+    drift apart: pointers -> c_void_p, int64_t -> c_int64, int32_t -> c_int32, float -> c_float, ``float x[n]`` -> array.
+    tests/test_boundary.py holds ``ctypes.sizeof`` and a field-by-field echo against the compiled library."""
+    cls = _STEP_STRUCTS.get(name)
+    if cls is not None:
+        return cls
+    import re
+    with open(HEADER_PATH) as f:
+        text = f.read()
+    m = re.search(r"typedef struct " + name + r" \{(.*?)\} " + name + ";", text, re.S)
+    if m is None:
+        raise RuntimeError(f"{name} not found in {HEADER_PATH}")
+    fields = []
+    for line in m.group(1).splitlines():
+        line = line.split("/*")[0].strip()
+        if not line:
+            continue
+        if line.endswith("*/") or line.startswith("*"):
+            continue                                          # continuation of a comment
+        d = re.match(r"^(const\s+)?([A-Za-z_0-9]+)\s*(\*?)\s*([A-Za-z_0-9]+)(\[(\d+)\])?;$", line)
+        if d is None:
+            raise RuntimeError(f"{name}: cannot parse field line {line!r}")
+        ctype, star, fname, n = d.group(2), d.group(3), d.group(4), d.group(6)
+        if star:
+            t = c_void_p
+        else:
+            t = {"int64_t": c_int64, "int32_t": C.c_int32, "int": C.c_int32, "float": c_float}[ctype]
+        fields.append((fname, t * int(n) if n else t))
+    cls = type(name, (C.Structure,), {"_fields_": fields, "__doc__": f"Mirror of ``{name}`` (include/nsx.h)."})
+    _STEP_STRUCTS[name] = cls
+    return cls
+
 
 _lib = None
 

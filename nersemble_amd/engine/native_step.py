@@ -1,0 +1,355 @@
+"""A training step's sampler and main pass enqueued by the native step drivers (csrc/step.hip, include/nsx.h
+"training-step drivers") instead of one ctypes call per kernel.
+
+What runs on the device is what ``NeRSembleNGPModel.fused_train_forward`` runs -- ``NeRSembleVolumetricSampler.forward``
+(nersemble_volumetric_sampler.py:95-134) with its sigma_fn density pass (nersemble_instant_ngp.py:235-266), then
+``get_outputs`` + ``get_loss_dict`` + ``get_metrics_dict`` (:280-422) on the kept samples and their backward -- the same
+kernels with the same arguments in the same order (tests/test_native_step_gpu.py holds the two paths together bit for bit
+in the forward).  What changes is the host side: ~45 marshalled native calls, ~60 ``torch.empty`` and the RaySamples /
+Frustums objects of a step become 6 native calls (plan, sampler, forward, three backward stages) on 5 workspaces whose
+sub-buffers the C side carves.  Python keeps what is policy, not launching: the traversal's counting pass (possibly issued
+a step ahead), the code-row lookups that autograd differentiates, the factored-gradient sink, streams and events.
+
+Covers the configuration the reference trains (occupancy grid on, deformation field on, time codes per image, fp16
+mixed precision, the sigma pass's forward values reused); anything else -> ``None`` and the caller takes the per-kernel path.
+"""
+import ctypes as C
+from typing import Dict, Optional
+
+import torch
+
+from .. import _lib
+from .. import distloss as dl
+from .. import functional as F
+from .._lib import check, lib, ptr, stream
+
+
+def _view(buf: torch.Tensor, off: int, shape, dtype) -> torch.Tensor:
+    n = 1
+    for d in shape:
+        n *= int(d)
+    nbytes = n * F._ITEMSIZE[dtype]
+    return buf[off:off + nbytes].view(dtype).view(tuple(shape))
+
+
+class _StepState:
+    """Everything one step's drivers share: the plan, the argument structs, the workspaces (kept alive until the backward
+    has been enqueued), the tensors the factored-gradient sink and the optimizer look at afterwards."""
+    __slots__ = ("plan", "sample", "main", "ws_sample", "ws_fwd", "out", "S", "R", "n_rows", "H", "he", "first_grid",
+                 "main_code", "main_window", "code_deform_shape", "deform_shapes", "keep", "n_kept")
+
+
+class _NativeMain(torch.autograd.Function):
+    """The kept samples' main pass (forward: nsx_step_main_fwd, backward: nsx_step_main_bwd stages 0-2) as one autograd
+    node with the inputs of ``engine.fused_pass._MainPass``: hash tables, the two fused MLPs, the batch's conditioned
+    hash-code rows, its deformation-code rows, the 16 deformation tensors."""
+
+    @staticmethod
+    def forward(ctx, st: _StepState, tables_master, base_params, head_params, code_hash, code_deform, *deform_params):
+        dev = code_deform.device
+        st.ws_fwd = torch.empty((st.plan.fwd_bytes,), dtype=torch.uint8, device=dev)
+        st.out = torch.empty((dl.LOSS_OUT,), dtype=torch.float32, device=dev)
+        m = st.main
+        m.ws_fwd, m.out = st.ws_fwd.data_ptr(), st.out.data_ptr()
+        check(lib().nsx_step_main_fwd(C.byref(m), stream()), "nsx_step_main_fwd")
+        ctx.st = st
+        ctx.sink = st.he.grad_sink
+        ctx.announced = ctx.needs_input_grad[1]
+        if ctx.announced:
+            ctx.sink.expect()
+        return st.out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        st: _StepState = ctx.st
+        plan, m, sink = st.plan, st.main, ctx.sink
+        dev = g_out.device
+        g = g_out.to(torch.float32).contiguous()
+        grads = torch.empty((plan.grad_bytes,), dtype=torch.uint8, device=dev)
+        ws_bwd = torch.empty((plan.bwd_bytes,), dtype=torch.uint8, device=dev)
+        need_tab = ctx.needs_input_grad[1]
+        need_code = bool(ctx.needs_input_grad[4]) and not st.first_grid    # (the code is the constant one in that phase)
+        m.grad_out, m.ws_bwd, m.grads = g.data_ptr(), ws_bwd.data_ptr(), grads.data_ptr()
+        m.need_code_grad = 1 if need_code else 0
+        L, s = lib(), stream()
+        check(L.nsx_step_main_bwd(C.byref(m), 0, s), "nsx_step_main_bwd stage 0")
+        # the factored table gradient of the step (cleared ahead / left clean by the optimizer / cleared here)
+        G = None
+        if need_tab:
+            G = sink.buffer_for(st.main_code, st.main_window, st.n_rows, st.he.geom.total_entries, n_samples=st.S)
+        m.G = G.data_ptr() if G is not None else None
+        m.nonfinite = sink.nonfinite.data_ptr() if G is not None else None
+        m.scatter_separately = 1 if (st.H == 1 and G is not None) else 0
+        check(L.nsx_step_main_bwd(C.byref(m), 1, s), "nsx_step_main_bwd stage 1")
+        f32 = torch.float32
+        d_head = _view(grads, plan.g_head, (F.mlp_param_count(m.head_hidden),), f32)
+        d_base = _view(grads, plan.g_base, (F.mlp_param_count(m.base_hidden),), f32)
+        if need_tab and ctx.announced:
+            # G is complete, and so are the gradients of the two fused MLPs (the rest of the tables' optimizer group)
+            sink.arrived(group_grads=[d_base, d_head] if sink.on_complete is not None else None)
+        check(L.nsx_step_main_bwd(C.byref(m), 2, s), "nsx_step_main_bwd stage 2")
+        gparams = _view(grads, plan.g_deform, (F.deform_param_count(),), f32)
+        gtable = _view(grads, plan.g_code_deform, st.code_deform_shape, f32)
+        g_code_hash = _view(grads, plan.g_code_hash, (st.n_rows, st.H), f32) if need_code else None
+        sizes = []
+        for shp in st.deform_shapes:
+            n = 1
+            for d in shp:
+                n *= d
+            sizes.append(n)
+        deform_grads = [gp if len(shp) == 1 else gp.view(shp) for gp, shp in zip(torch.split(gparams, sizes), st.deform_shapes)]
+        ctx.st = None                    # the workspaces go back to the allocator with this node
+        return (None, None, d_base, d_head, g_code_hash, gtable, *deform_grads)
+
+
+class LazyOutputs(dict):
+    """``get_outputs``' dict for a natively driven step: the per-ray / per-sample tensors are views of the step's
+    workspaces, made when somebody asks (the trainer does not)."""
+
+    def __init__(self, make):
+        super().__init__()
+        self._make = make
+
+    def _fill(self):
+        if self._make is not None:
+            make, self._make = self._make, None
+            super().update(make())
+
+    def __getitem__(self, k):
+        self._fill()
+        return super().__getitem__(k)
+
+    def __contains__(self, k):
+        self._fill()
+        return super().__contains__(k)
+
+    def get(self, k, default=None):
+        self._fill()
+        return super().get(k, default)
+
+    def keys(self):
+        self._fill()
+        return super().keys()
+
+    def items(self):
+        self._fill()
+        return super().items()
+
+    def values(self):
+        self._fill()
+        return super().values()
+
+    def __iter__(self):
+        self._fill()
+        return super().__iter__()
+
+    def __len__(self):
+        self._fill()
+        return super().__len__()
+
+
+class NativeStep:
+    def __init__(self, model):
+        self.model = model
+        self._plan_cls = _lib.step_struct("nsx_step_plan")
+        self._sample_cls = _lib.step_struct("nsx_step_sample")
+        self._main_cls = _lib.step_struct("nsx_step_main")
+        self._ones_codes = {}
+
+    def _ray_timesteps(self, ray_bundle, R: int) -> torch.Tensor:
+        """int32 [R]: the reference rounds the rays' ``times`` (nersemble_instant_ngp.py:249); metadata timesteps are
+        used once the sampler has seen them agree (NeRSembleVolumetricSampler.get_sigma_fn)."""
+        model, sampler = self.model, self.model.sampler
+        md_ts = (ray_bundle.metadata or {}).get("timesteps")
+        have_md = md_ts is not None and md_ts.numel() == R
+        n = sampler._md_timestep_checks = getattr(sampler, "_md_timestep_checks", -1) + 1
+        if have_md and ray_bundle.times is not None and n % 256 == 0:
+            rounded = model._timesteps(ray_bundle.times).to(torch.int32)
+            sampler._md_timesteps_agree = bool(torch.equal(rounded, md_ts.reshape(-1).to(torch.int32)))
+        if have_md and (ray_bundle.times is None or getattr(sampler, "_md_timesteps_agree", False)):
+            return md_ts.reshape(-1).to(torch.int32).contiguous()
+        return model._timesteps(ray_bundle.times).to(torch.int32).contiguous()
+
+    def forward(self, ray_bundle, batch: Dict[str, torch.Tensor]):
+        """(loss_dict, metrics_dict, outputs) of ``fused_train_forward`` -- or None when this step is outside what the
+        drivers cover (the caller then takes the per-kernel path)."""
+        model = self.model
+        cfg = model.config
+        md = ray_bundle.metadata or {}
+        he = model.field.hash_ensemble
+        if not (model.reuse_sigma_pass and model.device_sample_counts and "image_index" in md and "_image_timesteps" in md
+                and (cfg.alpha_thre > 0 or cfg.early_stop_eps > 0) and not cfg.disable_occupancy_grid
+                and he.grad_sink is not None and ray_bundle.nears is None and ray_bundle.fars is None
+                and (ray_bundle.times is not None or "timesteps" in md)):
+            return None
+        uniq = md["_image_timesteps"].reshape(-1).int()
+        n_rows = int(uniq.shape[0])
+        if n_rows > _lib.NSX_MAX_SLOTS or he.geom.n_levels != 16 or model.field.mlp_base.n_output_dims != 16:
+            return None
+        alpha_map = batch.get("alpha_map")
+        R = len(ray_bundle)
+        if alpha_map is not None and not (alpha_map.dtype == torch.uint8 and alpha_map.numel() == R):
+            return None
+        from ..models.nersemble_instant_ngp import LossDict
+        dev = ray_bundle.origins.device
+        window_hash = model.sched_window_hash_encodings.value if model.sched_window_hash_encodings is not None else None
+        window_deform = model.sched_window_deform.value if model.sched_window_deform is not None else None
+        df = model.deformation_field
+        emb_d = model.time_embedding_deformation if model.time_embedding_deformation is not None else model.time_embedding
+        # the batch's code rows (two embedding lookups + the window conditioning; autograd differentiates them): queued
+        # before the sampler so that they run beside the table optimizer instead of behind it
+        code_hash, window = he._conditioned(model.time_embedding(uniq), window_hash, dev)
+        code_deform = emb_d(uniq)
+        # -- traversal, pass 1 (possibly prefetched)
+        o = ray_bundle.origins.to(torch.float32).contiguous()
+        d = ray_bundle.directions.to(torch.float32).contiguous()
+        model.sampler._cull_to_camera_frusta()
+        grid = model.occupancy_grid
+        far = 1e10 if cfg.far_plane is None else float(cfg.far_plane)
+        near_planes, packed_march, S = grid.counted_march(o, d, cfg.near_plane, far, cfg.render_step_size, stratified=True)
+        if S <= 0:
+            return None                     # (nothing marched: the per-kernel path owns the one-fake-sample fallback)
+        grid.last_keep_index, grid.last_n_marched, grid.last_n_kept = None, S, None
+        ray_ts = self._ray_timesteps(ray_bundle, R)
+        ray_slots = md["image_index"].reshape(-1).to(torch.int32).contiguous()
+        alpha_thre_dev = grid._alpha_threshold(float(cfg.alpha_thre))
+        # -- what the HashEnsemble kernels see: the H grids with conditioned codes and the window -- or, in the compact
+        # first-grid phase (HashEnsemble.first_grid_phase), the contiguous copy of grid 0 with a constant code of one
+        first = he.first_grid_phase(window_hash)
+        T = model.time_embedding.weight.shape[0]
+        if first:
+            comp = he.enter_first_grid_phase()
+            he.wait_tables()
+            tables, Hk = comp["f16"], 1
+            sig_codes, sig_window = he.first_grid_code(T), None
+            main_code, main_window = he.first_grid_code(n_rows), None
+        else:
+            he.leave_first_grid_phase()
+            tables, Hk = he.half_tables(), he.n_hash_encodings
+            with torch.no_grad():
+                if window_hash is not None and window_hash == 1 and he.disable_initial_hash_ensemble:
+                    key = (T, Hk, str(dev))
+                    sig_codes = self._ones_codes.get(key)
+                    if sig_codes is None:
+                        sig_codes = self._ones_codes[key] = torch.ones((T, Hk), dtype=torch.float32, device=dev)
+                    sig_window = window
+                else:
+                    sig_codes, sig_window = he._conditioned(model.time_embedding.weight.detach(), window_hash, dev)
+                    sig_codes = sig_codes.contiguous()
+            main_code, main_window = code_hash.detach().contiguous(), window
+        mb, mh = model.field.mlp_base, model.field.mlp_head
+        packed_w = df.packed_params()
+        w7 = F.deform_window7(window_deform)
+        L = lib()
+        plan = self._plan_cls()
+        check(L.nsx_step_plan_make(S, R, n_rows, Hk, mb.n_hidden_mats, mh.n_hidden_mats, C.byref(plan)), "nsx_step_plan_make")
+        ws_sample = torch.empty((plan.sample_bytes,), dtype=torch.uint8, device=dev)
+        binary = grid.binaries[0].contiguous().view(torch.uint8)
+        base_w16, head_w16 = mb.half_weights(), mh.half_weights()
+        field_aabb, deform_aabb, occ_aabb = model.field._aabb6(), df._aabb6(), grid._aabb6()
+        a = self._sample_cls()
+        a.origins, a.directions, a.near_planes = o.data_ptr(), d.data_ptr(), near_planes.data_ptr()
+        a.packed_march, a.binaries = packed_march.data_ptr(), binary.data_ptr()
+        a.ray_timesteps, a.ray_slots = ray_ts.data_ptr(), ray_slots.data_ptr()
+        a.deform_packed, a.deform_codes = packed_w.data_ptr(), emb_d.weight.data_ptr()
+        a.tables, a.geom = tables.data_ptr(), C.addressof(he.geom)
+        a.hash_codes = sig_codes.data_ptr()
+        a.hash_window = sig_window.data_ptr() if sig_window is not None else None
+        a.base_w16, a.alpha_thre_dev = base_w16.data_ptr(), alpha_thre_dev.data_ptr()
+        a.window7_host = C.addressof(w7) if w7 is not None else None
+        a.ws, a.plan = ws_sample.data_ptr(), C.addressof(plan)
+        a.R, a.S = R, S
+        a.deform_code_stride, a.hash_code_stride = emb_d.weight.stride(0), sig_codes.stride(0)
+        a.grid_res, a.H = grid._res, Hk
+        a.base_hidden, a.base_out_dim, a.base_act = mb.n_hidden_mats, mb.n_output_dims, mb.out_act
+        a.far_plane, a.step, a.early_stop_eps = far, float(cfg.render_step_size), float(cfg.early_stop_eps)
+        for i in range(6):
+            a.occ_aabb[i], a.deform_aabb[i], a.field_aabb[i] = occ_aabb[i], deform_aabb[i], field_aabb[i]
+        check(L.nsx_step_sample_run(C.byref(a), stream()), "nsx_step_sample_run")
+        if not first:
+            # (the sampler's sigma_fn pass is queued: from here to the HashEnsemble's backward only small kernels run)
+            he.grad_sink.clear_ahead(n_rows, he.geom.total_entries, dev)
+        # -- the kept samples' main pass: one autograd node
+        m = self._main_cls()
+        m.ws_sample = ws_sample.data_ptr()
+        image_t = batch["image"].to(torch.float32).contiguous()
+        m.image = image_t.data_ptr()
+        amap = alpha_map.reshape(-1).contiguous() if alpha_map is not None else None
+        m.alpha_map = amap.data_ptr() if amap is not None else None
+        depth_t = batch["depth_maps"].to(torch.float32).reshape(-1).contiguous()
+        m.depth_targets = depth_t.data_ptr()
+        m.tables, m.geom = tables.data_ptr(), C.addressof(he.geom)
+        m.code_hash = main_code.data_ptr()
+        m.hash_window = main_window.data_ptr() if main_window is not None else None
+        code_d = code_deform.detach().contiguous()
+        m.deform_packed, m.code_deform = packed_w.data_ptr(), code_d.data_ptr()
+        m.base_w16, m.head_w16 = base_w16.data_ptr(), head_w16.data_ptr()
+        m.window7_host = C.addressof(w7) if w7 is not None else None
+        m.plan = C.addressof(plan)
+        m.R, m.S = R, S
+        m.code_hash_stride, m.code_deform_stride = main_code.stride(0), code_d.stride(0)
+        m.max_ray = int(cfg.dist_loss_max_rays)
+        m.H, m.n_code_rows = Hk, n_rows
+        m.base_hidden, m.base_out_dim, m.base_act = mb.n_hidden_mats, mb.n_output_dims, mb.out_act
+        m.head_hidden, m.head_act, m.geo_dim = mh.n_hidden_mats, mh.out_act, model.field.geo_feat_dim
+        m.use_masked = 1 if cfg.use_masked_rgb_loss else 0
+        m.background = 1.0 if cfg.background_color == "white" else 0.0
+        m.thr, m.l_alpha = float(cfg.alpha_mask_threshold), float(cfg.lambda_alpha_loss or 0.0)
+        m.l_depth, m.l_dist = float(cfg.lambda_depth_loss or 0.0), float(cfg.lambda_dist_loss)
+        m.l_empty, m.l_near = float(cfg.lambda_empty_loss), float(cfg.lambda_near_loss)
+        m.eps = float(model.sched_eps_depth.value)
+        for i in range(6):
+            m.field_aabb[i], m.deform_aabb[i] = field_aabb[i], deform_aabb[i]
+        st = _StepState()
+        st.plan, st.sample, st.main, st.ws_sample = plan, a, m, ws_sample
+        st.S, st.R, st.n_rows, st.H, st.he, st.first_grid = S, R, n_rows, Hk, he, first
+        st.main_code, st.main_window = main_code, main_window
+        st.code_deform_shape = tuple(code_d.shape)
+        deform_params = df.ordered_params()
+        st.deform_shapes = [tuple(p.shape) for p in deform_params]
+        # every tensor a raw pointer above borrows lives at least as long as the step's state
+        st.keep = (o, d, near_planes, packed_march, binary, ray_ts, ray_slots, packed_w, tables, sig_codes, sig_window,
+                   base_w16, head_w16, alpha_thre_dev, w7, image_t, amap, depth_t, code_d, he.geom)
+        fused = _NativeMain.apply(st, he.tables, mb.params, mh.params, code_hash, code_deform, *deform_params)
+        st.n_kept = _view(ws_sample, plan.n_kept, (1,), torch.int64)
+        grid.last_n_kept = st.n_kept
+        loss_dict = LossDict()
+        loss_dict["rgb_loss"] = fused[dl.LOSS_RGB]
+        if alpha_map is not None and cfg.lambda_alpha_loss is not None and cfg.lambda_alpha_loss > 0:
+            loss_dict["alpha_loss"] = fused[dl.LOSS_ALPHA]
+        if cfg.lambda_dist_loss > 0:
+            loss_dict["dist_loss"] = fused[dl.LOSS_DIST]
+        loss_dict["empty_loss"] = fused[dl.LOSS_EMPTY]
+        loss_dict["near_loss"] = fused[dl.LOSS_NEAR]
+        if cfg.lambda_depth_loss > 0:
+            loss_dict["depth_loss"] = fused[dl.LOSS_DEPTH]
+        loss_dict.total = fused[dl.LOSS_TOTAL]
+        if model.global_loss_normalisers is not None:
+            model._apply_global_normalisers(loss_dict, fused, R)
+        else:
+            # (the trainer starts the backward at the vector itself, NativeGradScaler.loss_grad_vector)
+            loss_dict.fused, loss_dict.total_index = fused, dl.LOSS_TOTAL
+        mt = fused.detach()
+        metrics = {"psnr": mt[dl.LOSS_PSNR], "num_samples_per_batch": mt[dl.LOSS_NUM_SAMPLES]}
+        if alpha_map is not None:
+            metrics["psnr_masked"] = mt[dl.LOSS_PSNR_MASKED]
+        return loss_dict, metrics, LazyOutputs(lambda: self._outputs(st))
+
+    @staticmethod
+    def _outputs(st: _StepState) -> dict:
+        """The ``get_outputs`` dict (nersemble_instant_ngp.py:345-362) as views of the step's workspaces; per-sample
+        arrays keep the marched capacity, their first ``n_kept`` rows are valid."""
+        from ..rays import Frustums, RaySamples
+        p, ws, wf, S, R = st.plan, st.ws_sample, st.ws_fwd, st.S, st.R
+        f32 = torch.float32
+        offsets = _view(ws, p.k_off, (S, 3), f32)
+        fr = Frustums(origins=_view(ws, p.k_org, (S, 3), f32), directions=_view(ws, p.k_dir, (S, 3), f32),
+                      starts=_view(ws, p.k_t0, (S, 1), f32), ends=_view(ws, p.k_t1, (S, 1), f32),
+                      pixel_area=torch.zeros((1, 1), device=ws.device).expand(S, 1), offsets=offsets)
+        samples = RaySamples(frustums=fr, metadata={"image_index": _view(ws, p.k_slot, (S, 1), torch.int32)})
+        packed = _view(ws, p.k_packed, (R, 2), torch.int64)
+        return {"rgb": _view(wf, p.f_rgb, (R, 3), f32), "accumulation": _view(wf, p.f_acc, (R, 1), f32),
+                "depth": _view(wf, p.f_depth, (R, 1), f32), "num_samples_per_ray": packed[:, 1],
+                "ray_samples": (samples,), "ray_indices": (_view(ws, p.k_ri, (S,), torch.int64),),
+                "weights": (_view(wf, p.f_w, (S, 1), f32),), "packed_info": (packed,),
+                "deformation": _view(wf, p.f_aux, (R, 3), f32), "n_kept": st.n_kept}

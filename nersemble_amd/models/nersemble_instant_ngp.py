@@ -109,6 +109,10 @@ class NeRSembleNGPModel(BaseModel):
         self.fuse_main_pass = True
         # ... with the number of kept samples left on the device (no host read-back after the marcher's own count)
         self.device_sample_counts = True
+        # ... and the sampler + main pass of such a step enqueued by the native step drivers (engine/native_step.py: six
+        # native calls instead of ~45); False keeps the per-kernel path (same kernels, same results)
+        self.native_step = True
+        self._native = None
         # activations + backward scratch of the fused pass per sample (deformation scratch 3.2 KB, features, gradients):
         # what the un-chunked pass is priced at when a batch is far beyond ``max_n_samples_per_batch``
         self.fused_pass_bytes_per_sample = 3800
@@ -413,6 +417,13 @@ class NeRSembleNGPModel(BaseModel):
         num_rays = len(ray_bundle)
         if alpha_map is not None and not (alpha_map.dtype == torch.uint8 and alpha_map.numel() == num_rays):
             return None
+        if self.native_step:
+            if self._native is None:
+                from ..engine.native_step import NativeStep
+                self._native = NativeStep(self)
+            res = self._native.forward(ray_bundle, batch)
+            if res is not None:
+                return res
         from ..engine.fused_pass import MainPassInputs, main_pass
         from .. import distloss as dl
         from .. import functional as Fn

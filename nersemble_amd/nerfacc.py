@@ -313,6 +313,33 @@ class OccGridEstimator(nn.Module):
         return None
 
     @torch.no_grad()
+    def counted_march(self, rays_o: Tensor, rays_d: Tensor, near_plane: float, far_plane: float, render_step_size: float,
+                      stratified: bool, t_min: Optional[Tensor] = None) -> Tuple[Tensor, Tensor, int]:
+        """Pass 1 of the two-pass traversal as the training-step driver needs it (engine/native_step.py): the (jittered)
+        near planes [R], ``packed_info`` [R, 2] of the marched samples and their number on the host -- taken from the pass
+        ``prefetch_march`` issued a step ahead when there is one for exactly these rays / arguments / grid, else run here
+        (one host read-back, as in nerfacc's two-pass design).  ``rays_o`` / ``rays_d``: contiguous fp32."""
+        R, dev = rays_o.shape[0], rays_o.device
+        counted = None
+        if getattr(self, "_prefetched", None):
+            counted = self._take_prefetched(self._march_key(rays_o, rays_d, near_plane, far_plane, render_step_size,
+                                                            stratified, t_min))
+        self.last_march_prefetched = counted is not None
+        if counted is not None:
+            torch.cuda.current_stream(dev).wait_event(counted["done"])
+            counted["done"].synchronize()                     # long complete when issued a step ahead
+            return counted["near_planes"], counted["packed"], int(counted["total_host"][0])
+        near_planes = self._near_planes(rays_o, near_plane, t_min, render_step_size, stratified)
+        binary = self.binaries[0].contiguous().view(torch.uint8)
+        counts = torch.empty((R,), dtype=torch.int64, device=dev)
+        packed = torch.empty((R, 2), dtype=torch.int64, device=dev)
+        total = torch.zeros((1,), dtype=torch.int64, device=dev)
+        check(lib().nsx_march_count(ptr(rays_o), ptr(rays_d), R, self._aabb6(), ptr(binary), self._res, ptr(near_planes),
+                                    float(far_plane), float(render_step_size), ptr(counts), stream()), "nsx_march_count")
+        check(lib().nsx_pack_info(ptr(counts), R, ptr(packed), ptr(total), stream()), "nsx_pack_info")
+        return near_planes, packed, int(total.item())
+
+    @torch.no_grad()
     def traverse(self, rays_o: Tensor, rays_d: Tensor, near_planes: Tensor, far_plane: float, step: float,
                  want_cells: bool = False, counted: Optional[dict] = None):
         """Two-pass marching; returns (ray_indices int64 [S], t_starts, t_ends, packed_info [R,2], cells|None).

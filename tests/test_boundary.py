@@ -94,3 +94,54 @@ def test_hash_ensemble_state_dict_uses_reference_keys():
     he2 = HashEnsemble(cfg, seed=99)
     he2.load_state_dict(sd)
     assert torch.equal(he2.tables, he.tables)
+
+
+@pytest.mark.parametrize("kind,name", [(0, "nsx_step_sample"), (1, "nsx_step_main")])
+def test_step_driver_structs_have_the_compilers_layout(kind, name):
+    """The training-step drivers take their arguments as structs (include/nsx.h).  The binding's ctypes mirrors are built
+    from the header text; here they are held to the COMPILED layout: same size, and every field written through ctypes
+    arrives in the library where the header says (``nsx_step_echo`` reads each field by name on the C side)."""
+    from nersemble_amd import _lib
+    cls = _lib.step_struct(name)
+    L = _lib.lib()
+    assert ctypes.sizeof(cls) == L.nsx_step_sizeof(kind)
+    assert ctypes.sizeof(_lib.step_struct("nsx_step_plan")) == L.nsx_step_sizeof(2)
+    s = cls()
+    want = []
+    v = 1000
+    for fname, ftype in cls._fields_:
+        if hasattr(ftype, "_length_"):
+            arr = getattr(s, fname)
+            for i in range(ftype._length_):
+                arr[i] = float(v)
+                want.append(float(v))
+                v += 1
+        elif ftype is ctypes.c_float:
+            setattr(s, fname, float(v) + 0.5)
+            want.append(float(v) + 0.5)
+            v += 1
+        else:                                   # pointers and integers
+            setattr(s, fname, v)
+            want.append(float(v))
+            v += 1
+    out = (ctypes.c_double * 256)()
+    n = L.nsx_step_echo(kind, ctypes.byref(s), out, 256)
+    assert n == len(want), (n, len(want))
+    assert list(out[:n]) == want
+
+
+def test_step_plan_offsets_are_disjoint_and_aligned():
+    from nersemble_amd import _lib
+    plan = _lib.step_struct("nsx_step_plan")()
+    _lib.check(_lib.lib().nsx_step_plan_make(100_003, 4096, 24, 32, 0, 1, ctypes.byref(plan)), "nsx_step_plan_make")
+    groups = {"sample": ("m_ri", "k_total", "sample_bytes"), "fwd": ("f_pos", "f_per_ray", "fwd_bytes"),
+              "grad": ("g_head", "g_code_hash", "grad_bytes"), "bwd": ("b_grgb", "b_deform", "bwd_bytes")}
+    names = [f for f, _ in plan._fields_]
+    for first, last, total in groups.values():
+        offs = [getattr(plan, n) for n in names[names.index(first):names.index(last) + 1]]
+        offs = [o for o in offs]
+        assert offs[0] == 0 and all(o % 256 == 0 for o in offs)
+        assert all(b >= a for a, b in zip(offs, offs[1:])) and getattr(plan, total) >= offs[-1]
+    assert plan.S == 100_003 and plan.R == 4096 and plan.g_zero_end == plan.g_code_hash
+    assert plan.b_zero_end - plan.b_ds >= 100_003 * (4 + 6 + 32)
+    assert _lib.lib().nsx_step_plan_make(0, 4096, 24, 32, 0, 1, ctypes.byref(plan)) != 0

@@ -1,0 +1,144 @@
+"""GPU: the native step drivers (csrc/step.hip behind engine/native_step.py) against the per-kernel path
+(``fused_train_forward`` issuing every native call from Python): the SAME kernels with the same arguments in the same
+order, so everything the forward produces is equal bit for bit and the gradients agree up to the order of the fp32
+atomics.  Phases of the reference's schedule (train_nersemble.py:77-78): one grid on (compact first-grid copy / full
+layout), every grid on (time codes trained)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _build(phase, native, seed=6, n_rays=512, workload="p030_h16"):
+    from nersemble_amd.workloads import build_workload
+    torch.manual_seed(seed)
+    trainer, data, _ = build_workload(workload, device="cuda:0", small=True, n_rays=n_rays,
+                                      window_hash=(0, 1) if phase == "open" else None,
+                                      compact_first_grid=(phase == "compact"))
+    model = trainer.model
+    model.native_step = native
+    if phase == "open":                                           # open from step 0 on (the ramp is over before it)
+        model.sched_window_hash_encodings.begin_step, model.sched_window_hash_encodings.end_step = -2, -1
+    return trainer, data, model
+
+
+@pytest.mark.parametrize("phase", ["compact", "closed", "open"])
+def test_native_forward_equals_the_per_kernel_forward(phase, cuda):
+    """One forward of a training step: loss vector, metrics and every entry of the ``get_outputs`` dict."""
+    res = {}
+    for native in (False, True):
+        trainer, data, model = _build(phase, native)
+        for cb in trainer.callbacks:
+            cb.run(0)
+        model.train()
+        bundle, batch = data.next_train(0)
+        torch.manual_seed(70)
+        with torch.autocast(device_type="cuda", dtype=torch.float16, cache_enabled=False):
+            out = model.fused_train_forward(bundle, batch)
+        assert out is not None
+        loss_dict, metrics, outputs = out
+        assert (model._native is not None) == native
+        n = int(metrics["num_samples_per_batch"])
+        o = {k: outputs[k] for k in ("rgb", "accumulation", "depth", "deformation", "num_samples_per_ray")}
+        o["weights"] = outputs["weights"][0].reshape(-1)[:n]
+        o["ray_indices"] = outputs["ray_indices"][0][:n]
+        fr = outputs["ray_samples"][0].frustums
+        o.update(starts=fr.starts.reshape(-1)[:n], ends=fr.ends.reshape(-1)[:n], offsets=fr.offsets[:n],
+                 origins=fr.origins[:n], directions=fr.directions[:n])
+        res[native] = (loss_dict.fused.detach().clone(), n, {k: v.detach().clone() for k, v in o.items()},
+                       {k: float(v) for k, v in loss_dict.items()})
+    (f_p, n_p, o_p, t_p), (f_n, n_n, o_n, t_n) = res[False], res[True]
+    assert n_p == n_n and n_p > 1000
+    assert torch.equal(f_p, f_n), (f_p, f_n)
+    assert t_p == t_n
+    for k in o_p:
+        assert torch.equal(o_p[k], o_n[k]), k
+
+
+@pytest.mark.parametrize("phase", ["compact", "closed", "open"])
+def test_native_training_steps_equal_the_per_kernel_steps(phase, cuda):
+    res = {}
+    for native in (False, True):
+        trainer, data, model = _build(phase, native)
+        calls = []
+        orig = model.fused_train_forward
+
+        def counted(*a, _orig=orig, _calls=calls, **k):
+            r = _orig(*a, **k)
+            _calls.append(r is not None)
+            return r
+
+        model.fused_train_forward = counted
+        losses, terms, grads = [], None, None
+        for step in range(5):
+            torch.manual_seed(70 + step)                          # same near-plane jitter on both sides
+            b_next = None
+            loss, loss_dict, metrics = trainer.train_iteration(step, *data.next_train(step))
+            losses.append(loss.item())
+            if step == 0:
+                terms = {k: v.item() for k, v in loss_dict.items()}
+                terms.update({"m:" + k: float(v) for k, v in metrics.items()})
+                grads = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+        trainer.flush_scheduler_step()
+        trainer.consolidate()
+        model.field.hash_ensemble.wait_tables()
+        assert all(calls) and len(calls) == 5
+        assert (model._native is not None) == native
+        res[native] = (losses, terms, grads, model.field.hash_ensemble.tables.detach().clone(),
+                       trainer.grad_scaler.get_scale())
+    (l_p, t_p, g_p, tab_p, sc_p), (l_n, t_n, g_n, tab_n, sc_n) = res[False], res[True]
+    assert l_p[0] == l_n[0] and t_p == t_n, (l_p[0], l_n[0], t_p, t_n)                 # forward: bit for bit
+    assert set(g_p) == set(g_n) and sc_p == sc_n == 65536.0
+    assert ("time_embedding.weight" in g_n) == (phase == "open")
+    for name in g_p:
+        sc = g_p[name].abs().max().item()
+        assert (g_p[name] - g_n[name]).abs().max().item() <= 1e-4 * sc + 1e-12, name
+    assert np.allclose(l_p, l_n, rtol=2e-3), (l_p, l_n)
+    assert l_n[-1] < l_n[0]
+    # five Adam steps (+-lr per touched entry and step): equal unless a cancelling gradient changed sign with the
+    # atomics' order; compared through their distribution
+    d = (tab_p - tab_n).abs()
+    assert (d <= 1e-4).float().mean().item() >= 0.995
+
+
+def test_native_step_with_the_march_counted_a_step_ahead(cuda):
+    """The trainer's ``next_ray_bundle`` hand-over (the traversal's counting pass on a side stream, one step ahead) feeds
+    the native sampler as it feeds the per-kernel one: same losses as marching in place."""
+    runs = {}
+    for ahead in (False, True):
+        trainer, data, model = _build("compact", True, seed=11)
+        batches = [data.next_train(s) for s in range(7)]
+        losses, used = [], []
+        for step in range(6):
+            torch.manual_seed(500 + step)
+            nxt = batches[step + 1][0] if ahead else None
+            if ahead and step + 1 < 6:
+                pass
+            loss, _, metrics = trainer.train_iteration(step, *batches[step], next_ray_bundle=nxt)
+            losses.append((loss.item(), int(metrics["num_samples_per_batch"])))
+            used.append(model.occupancy_grid.last_march_prefetched)
+        trainer.flush_scheduler_step()
+        runs[ahead] = (losses, used)
+    assert not any(runs[False][1])
+    assert sum(runs[True][1]) >= 3                    # (a step that follows a grid update marches on its own)
+    # the jitter of a prefetched pass is drawn one step earlier: the runs see different random near planes, so they
+    # agree statistically, not bit for bit
+    a, b = np.array(runs[False][0]), np.array(runs[True][0])
+    assert np.allclose(a[:, 0], b[:, 0], rtol=0.1) and np.allclose(a[:, 1], b[:, 1], rtol=0.1)
+
+
+def test_native_step_falls_back_outside_its_configuration(cuda):
+    """Dense configuration (occupancy grid off: nothing to reuse from a sigma pass) and per-sample-count read-backs stay on
+    the per-kernel path; the step still runs."""
+    from nersemble_amd.workloads import build_workload
+    torch.manual_seed(3)
+    trainer, data, _ = build_workload("p097_dense", device="cuda:0", small=True, n_rays=128)
+    model = trainer.model
+    assert model.native_step
+    loss, _, metrics = trainer.train_iteration(0, *data.next_train(0))
+    assert torch.isfinite(loss) and model._native is not None       # asked, declined
+    trainer2, data2, model2 = _build("compact", True)
+    model2.device_sample_counts = False
+    loss2, _, _ = trainer2.train_iteration(0, *data2.next_train(0))
+    assert torch.isfinite(loss2)
