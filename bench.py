@@ -44,6 +44,10 @@ DEFORM_FWD_FLOPS = 253952.0     # 2 * 126 976 MAC per sample
 SPLIT_SCATTER = True            # set in main() from the trainer's gradient sink: the factored backward runs as two kernels
 
 
+MLP_BASE_FLOPS = 6_144.0
+MLP_HEAD_FLOPS = 14_336.0
+
+
 def kernel_model(name: str, ints, H: int, total_entries: int):
     """(bound, work per launch) for the kernels with a stated algorithmic cost.
     `ints` = the integer arguments of the C-ABI call as recorded by the profiler."""
@@ -81,6 +85,11 @@ def kernel_model(name: str, ints, H: int, total_entries: int):
         return "mfma", ints[0] * DEFORM_FWD_FLOPS
     if name == "nsx_deform_bwd":                              # recompute fwd + dX chain + weight gradients = 3x fwd
         return "mfma", ints[0] * DEFORM_FWD_FLOPS * 3.0
+    if name in ("nsx_mlp_fwd", "nsx_mlp_bwd") and len(ints) > 1:     # (n_hidden_mats, B, ...): SURVEY 8(d): mlp_base
+        # 2 (32 64 + 64 16) = 6 144 FLOP per sample, mlp_head (padded) 2 (32 64 + 64 64 + 64 16) = 14 336; backward =
+        # recompute + dX + dW = 3x.  Memory / latency bound (<= 16 MFMAs per 32 samples): priced so that nobody has to guess
+        flops = MLP_HEAD_FLOPS if ints[0] == 1 else MLP_BASE_FLOPS
+        return "mfma", ints[1] * flops * (3.0 if name == "nsx_mlp_bwd" else 1.0)
     return None, 0.0
 
 
@@ -126,21 +135,29 @@ def cpu_baseline(H: int, seconds_budget: float = 30.0):
             "torch_cpu_sweep": sweep, "c_port_samples_per_s": c_rate}
 
 
-def steady_state(trainer, data, first_step: int, settle_at: int, rays: int, n_timed: int = 100):
+def steady_state(trainer, data, first_step: int, settle_at: int, rays: int, n_timed: int = 100, datamanager=None):
     """Continues the run to step `settle_at` (untimed), then times `n_timed` steps: by then the occupancy grid and the
-    visibility pruning have settled and every step sees about the same number of samples."""
+    visibility pruning have settled and every step sees about the same number of samples.  `datamanager`: draw every
+    batch inside the timed loop through its `next_train` instead of pre-generating them."""
     import gc
+    src = datamanager if datamanager is not None else data
     step = first_step
     while step < settle_at:
-        trainer.train_iteration(step, *data.next_train(step))
+        trainer.train_iteration(step, *src.next_train(step))
         step += 1
-    batches = [data.next_train(step + i) for i in range(n_timed + 1)]      # (+1: the loader is one batch ahead)
+    batches = [data.next_train(step + i) for i in range(n_timed + 1)] if datamanager is None else None
+    nxt = datamanager.next_train(step) if datamanager is not None else None
     gc.collect()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     samples, counts = 0, []
     for i in range(n_timed):
-        _, _, metrics = trainer.train_iteration(step + i, *batches[i], next_ray_bundle=batches[i + 1][0])
+        if datamanager is None:
+            cur, ahead = batches[i], batches[i + 1]
+        else:
+            cur = nxt
+            ahead = nxt = datamanager.next_train(step + i + 1)
+        _, _, metrics = trainer.train_iteration(step + i, *cur, next_ray_bundle=ahead[0])
         counts.append(metrics["num_samples_per_batch"])
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
@@ -200,6 +217,44 @@ def open_window_block(a):
                                   "samples_per_step_min_max", "steady_state", "rooflines")}
     keep["native_kernel_avg_ms"] = {k: v["avg_ms"] for k, v in (d.get("native_kernel_ms") or {}).items()
                                     if v["avg_ms"] >= 0.05}
+    keep["command"] = " ".join(cmd[1:])
+    return keep
+
+
+def build_datamanager(data, dev, n_timesteps_cached: int = 20):
+    """``NeRSembleVanillaDataManager`` (datamanager/nersemble_datamanager.py:15-118 with the values of
+    train_nersemble.py:172-179: 4096 rays from a cache of 24 images, redrawn every 20 iterations) over an in-memory
+    dataset of the synthetic rig's 12 training cameras x `n_timesteps_cached` timesteps at full resolution (1100 x 1604;
+    7 GB of fp32 images resident on the device -- the dataset's file decoding is out of scope, the cache refresh is a
+    24-image stack of resident tensors).  Every image is rendered before anything is timed."""
+    from nersemble_amd.data.datamanager import NeRSembleVanillaDataManager, NeRSembleVanillaDataManagerConfig
+    T = data.n_timesteps
+    stride = max(T // n_timesteps_cached, 1)
+    images = [(int(c), t) for t in range(0, T, stride) for c in data.train_cams.tolist()]
+    ds = data.image_dataset(images, downscale=1)
+    for i in range(len(ds)):
+        ds[i]                                                     # (rendered and cached now, not in the timed region)
+    gen = torch.Generator().manual_seed(19980801)
+    return NeRSembleVanillaDataManager(NeRSembleVanillaDataManagerConfig(train_num_rays_per_batch=data.n_rays), ds,
+                                       device=dev, generator=gen), len(images)
+
+
+def with_datamanager_block(a):
+    """The same command with `--with-datamanager` in a process of its own: what the step costs when
+    `datamanager.next_train(step)` runs inside it, as in the reference's clocked `train_iteration`
+    (nersemble_trainer.py:41-68,169-206 -> nersemble_datamanager.py:76-81)."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--with-datamanager", "--no-cpu-baseline", "--no-first-grid-phase",
+           "--no-open-window", "--no-kernels-alone", "--no-with-datamanager", "--steps", str(a.steps), "--warmup",
+           str(a.warmup), "--workload", a.workload, "--steady-after", str(a.steady_after), "--reserve-gb", str(a.reserve_gb)]
+    try:
+        res = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+        line = [l for l in res.stdout.splitlines() if l.startswith("{")][-1]
+        d = json.loads(line)
+    except Exception as exc:                                     # the block is a bonus: never lose the headline over it
+        return {"error": repr(exc)[:300]}
+    keep = {k: d.get(k) for k in ("value", "unit", "ms_per_step", "steps", "warmup", "rays_per_sec", "psnr_last",
+                                  "samples_per_step_min_max", "steady_state", "datamanager")}
     keep["command"] = " ".join(cmd[1:])
     return keep
 
@@ -354,6 +409,42 @@ def kernels_alone(trainer, H: int, log2_s: int = 20, iters: int = 10):
                                        ptr(goff), ptr(scratch), ptr(gparams), ptr(gtable), None, None, stream()),
                   "nsx_deform_bwd")
         entry("nsx_deform_bwd", timeit(dbwd, n=max(3, iters // 2)), "mfma", S * DEFORM_FWD_FLOPS * 3.0)
+    # the two fused MLPs (tcnn FullyFusedMLP equivalents): <= 16 MFMAs per 32 samples -- bound by their 100-170 B of
+    # activations per sample and by launch ramps, priced against the matrix cores all the same
+    field = model.field
+    feats = torch.randn((S, 32), device=dev, generator=gen).half()
+    base_out = torch.randn((S, 16), device=dev, generator=gen).half()
+    dirs = torch.nn.functional.normalize(torch.randn((S, 3), device=dev, generator=gen), dim=-1)
+    for net, tag, flops in ((field.mlp_base, "mlp_base", MLP_BASE_FLOPS), (field.mlp_head, "mlp_head", MLP_HEAD_FLOPS)):
+        w16 = net.half_weights()
+        nh = net.n_hidden_mats
+        dW = torch.zeros((w16.numel(),), device=dev)
+        if tag == "mlp_base":
+            o16 = torch.empty((S, 16), device=dev, dtype=torch.float16)
+            d16 = torch.randn((S, 16), device=dev, generator=gen).half()
+            d32 = torch.empty((S, 32), device=dev)
+
+            def mfwd(w16=w16, nh=nh, o16=o16):
+                check(lib().nsx_mlp_fwd(ptr(w16), nh, S, None, 0, 0, 1.0, 0.0, ptr(feats), 32, 0, 32, 16, net.out_act,
+                                        ptr(o16), 16, None, stream()), "nsx_mlp_fwd")
+
+            def mbwd(w16=w16, nh=nh, d16=d16, dW=dW, d32=d32):
+                check(lib().nsx_mlp_bwd(ptr(w16), nh, S, None, 0, 0, 1.0, 0.0, ptr(feats), 32, 0, 32, 16, net.out_act,
+                                        ptr(d16), 16, ptr(dW), None, None, ptr(d32), None, stream()), "nsx_mlp_bwd")
+        else:
+            o3 = torch.empty((S, 3), device=dev, dtype=torch.float16)
+            d3 = torch.randn((S, 3), device=dev, generator=gen).half()
+            dbo = torch.zeros((S, 16), device=dev, dtype=torch.float16)
+
+            def mfwd(w16=w16, nh=nh, o3=o3, act=net.out_act):
+                check(lib().nsx_mlp_fwd(ptr(w16), nh, S, ptr(dirs), 3, 3, 0.5, 0.5, ptr(base_out), 16, 1, 15, 3, act,
+                                        ptr(o3), 3, None, stream()), "nsx_mlp_fwd")
+
+            def mbwd(w16=w16, nh=nh, d3=d3, dW=dW, dbo=dbo, act=net.out_act):
+                check(lib().nsx_mlp_bwd(ptr(w16), nh, S, ptr(dirs), 3, 3, 0.5, 0.5, ptr(base_out), 16, 1, 15, 3, act,
+                                        ptr(d3), 3, ptr(dW), None, ptr(dbo), None, None, stream()), "nsx_mlp_bwd")
+        entry(f"nsx_mlp_fwd ({tag})", timeit(mfwd), "mfma", S * flops)
+        entry(f"nsx_mlp_bwd ({tag})", timeit(mbwd), "mfma", S * flops * 3.0)
     return {"samples": S, "sampling": "uniform random positions in the scene box, 24 time-code slots, seed 0",
             "kernels": out}
 
@@ -392,6 +483,11 @@ def main():
     ap.add_argument("--window-open", action="store_true", help="shorthand for --window-hash 0 1")
     ap.add_argument("--no-open-window", action="store_true", help="skip the `open_window` block")
     ap.add_argument("--no-kernels-alone", action="store_true", help="skip the stand-alone kernel timings after the run")
+    ap.add_argument("--with-datamanager", action="store_true",
+                    help="draw every batch INSIDE the timed loop through NeRSembleVanillaDataManager.next_train (24-image "
+                         "cache refreshed every 20 iterations, device pixel sampler, nsx_generate_rays), as the reference's "
+                         "TRAIN_RAYS_PER_SEC clocks it (nersemble_trainer.py:41-68); default: batches pre-generated")
+    ap.add_argument("--no-with-datamanager", action="store_true", help="skip the `with_datamanager` block")
     ap.add_argument("--preroll", type=int, default=0,
                     help="untimed training steps BEFORE the warm-up (e.g. 600: the occupancy grid and the visibility "
                          "pruning have settled, the timed window is stationary)")
@@ -452,10 +548,26 @@ def main():
     # synthetic inputs are generated up front: they are resident in HBM when the timed region starts
     # (one more than is trained on: like a loader, the loop knows the next batch, and the trainer starts the counting pass
     # of its ray marching one step ahead -- every timed step issues exactly one such pass)
-    batches = [data.next_train(a.preroll + s) for s in range(a.warmup + a.steps + 1)]
+    dm, dm_stats = None, {"calls": 0, "host_s": 0.0}
+    if a.with_datamanager:
+        dm, n_dm_images = build_datamanager(data, dev)
+        batches = None
+    else:
+        batches = [data.next_train(a.preroll + s) for s in range(a.warmup + a.steps + 1)]
     torch.cuda.synchronize()
 
+    def fetch(s):
+        """The batch of step `s`: pre-generated, or drawn NOW through the datamanager (host time booked)."""
+        if dm is None:
+            return batches[s]
+        t_ = time.perf_counter()
+        out_ = dm.next_train(a.preroll + s)
+        dm_stats["host_s"] += time.perf_counter() - t_
+        dm_stats["calls"] += 1
+        return out_
+
     step_marks = []                          # (event at step start, device-side sample count) per timed step
+    held = {"next": fetch(0)}
 
     def run(n_steps, first_step, mark=False):
         samples = 0
@@ -464,9 +576,10 @@ def main():
                 ev = torch.cuda.Event(enable_timing=True)
                 ev.record()
                 _lib.profiler.tag = len(step_marks)
-            bundle, batch = batches[s]
+            bundle, batch = held["next"]
+            held["next"] = fetch(s + 1)      # (like a loader, the loop knows its next batch: one next_train per step)
             loss, loss_dict, metrics = trainer.train_iteration(a.preroll + s, bundle, batch,
-                                                               next_ray_bundle=batches[s + 1][0])
+                                                               next_ray_bundle=held["next"][0])
             samples += metrics["num_samples_per_batch"]
             if mark:
                 step_marks.append((ev, metrics["num_samples_per_batch"]))
@@ -513,6 +626,7 @@ def main():
     torch.cuda.synchronize()
     _lib.profiler.reset()
     _lib.profiler.enabled = not a.no_kernel_events
+    dm_stats["calls"], dm_stats["host_s"] = 0, 0.0
     t0 = time.perf_counter()
     samples, loss, metrics = run(a.steps, a.warmup, mark=True)
     end_mark = torch.cuda.Event(enable_timing=True)
@@ -525,6 +639,7 @@ def main():
     trainer.flush_scheduler_step()
     _lib.profiler.enabled = False
     samples = int(samples)
+    dm_timed = dict(dm_stats)
 
     t = torch.tensor([dt], device=dev, dtype=torch.float64)
     n = torch.tensor([samples], device=dev, dtype=torch.int64)
@@ -534,6 +649,7 @@ def main():
     dt_max, total_samples = float(t.item()), int(n.item())
 
     if rank == 0:
+        _lib.profiler.collect_native()          # the kernel calls the native step drivers made (their own HIP events)
         prof = _lib.profiler.summary()
         total_entries = trainer.model.field.hash_ensemble.geom.total_entries
         work = {}
@@ -543,7 +659,8 @@ def main():
         kept = [int(c) for _, c in step_marks]
         for (name, st, en, ints), (tag, counted) in zip(_lib.profiler.records, _lib.profiler.tags):
             if counted and tag is not None and tag < len(kept):
-                ints = [kept[tag]] + list(ints[1:])
+                ints = list(ints)
+                ints[1 if name.startswith("nsx_mlp_") else 0] = kept[tag]      # (the MLP calls lead with n_hidden_mats)
             bound, w = kernel_model(name, ints, H, total_entries)
             if bound:
                 d = work.setdefault(name, {"bound": bound, "work": 0.0})
@@ -628,8 +745,16 @@ def main():
         }
         if trainer.placement_report is not None:
             out["table_placement"] = trainer.placement_report       # one-off, before the warm-up (engine/placement.py)
+        if dm is not None:
+            out["datamanager"] = {
+                "next_train_host_us_per_step": dm_timed["host_s"] / max(dm_timed["calls"], 1) * 1e6,
+                "next_train_calls_in_timed_region": dm_timed["calls"], "dataset_images": n_dm_images,
+                "image_cache": "24 images, redrawn every 20 iterations (train_nersemble.py:174-175)",
+                "note": "next_train(step) is called inside the timed loop, one call per step, for the NEXT step's batch "
+                        "(its ray bundle is handed to train_iteration as next_ray_bundle)"}
         if a.steady_after > 0 and world == 1:
-            out["steady_state"] = steady_state(trainer, data, a.preroll + a.warmup + a.steps, a.steady_after, info["rays"])
+            out["steady_state"] = steady_state(trainer, data, a.preroll + a.warmup + a.steps, a.steady_after, info["rays"],
+                                               datamanager=dm)
         spp = [p["samples"] for p in out["per_step"]]
         out["samples_per_step_min_max"] = [min(spp), max(spp)] if spp else None
         if len(out["per_step"]) > 40:                            # long runs: every k-th step is enough to see the trend
@@ -643,6 +768,9 @@ def main():
             out["first_grid_phase"] = first_grid_phase_block(a)
         if world == 1 and not a.compact_first_grid and not a.no_open_window and a.preroll == 0 and a.window_hash is None:
             out["open_window"] = open_window_block(a)
+        if world == 1 and not a.compact_first_grid and not a.no_with_datamanager and not a.with_datamanager \
+                and a.preroll == 0 and a.window_hash is None:
+            out["with_datamanager"] = with_datamanager_block(a)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -701,6 +701,16 @@ typedef struct nsx_step_main {
 } nsx_step_main;
 int nsx_step_main_fwd(const nsx_step_main* a, void* stream);
 int nsx_step_main_bwd(const nsx_step_main* a, int stage, void* stream);
+/* Optional HIP-event timing of the kernel calls the drivers make (the per-call events a host-language binding records
+ * around its own calls do not see them): nsx_step_profile(1, tag) switches it on for the calls that follow (`tag` is
+ * stored with every record, e.g. the index of the step), (0, .) off.  After the stream has drained: _count records, _get
+ * reads one (name of the entry point, milliseconds between the two events, rows the call was sized for, info4 = {H or
+ * n_hidden_mats, n_code_rows, 1 if the call ran under the kept-sample count, tag}); _reset recycles the events.
+ * Host-side state of the process; not thread-safe; off by default. */
+int nsx_step_profile(int enable, int tag);
+int nsx_step_profile_count(void);
+int nsx_step_profile_get(int i, char* name_out, int name_capacity, float* ms, int64_t* rows, int32_t* info4);
+int nsx_step_profile_reset(void);
 /* sizeof / field echo for the binding's layout checks: nsx_step_echo writes the fields of the struct `kind`
  * (0 sample, 1 main) as doubles in declaration order (pointers as addresses, arrays element by element). */
 int64_t nsx_step_sizeof(int kind /* 0 sample, 1 main, 2 plan */);

@@ -158,6 +158,10 @@ SIGNATURES = {
     "nsx_step_sample_run": (c_int, [c_void_p, c_void_p]),
     "nsx_step_main_fwd": (c_int, [c_void_p, c_void_p]),
     "nsx_step_main_bwd": (c_int, [c_void_p, c_int, c_void_p]),
+    "nsx_step_profile": (c_int, [c_int, c_int]),
+    "nsx_step_profile_count": (c_int, []),
+    "nsx_step_profile_get": (c_int, [c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "nsx_step_profile_reset": (c_int, []),
     "nsx_step_sizeof": (c_int64, [c_int]),
     "nsx_step_echo": (c_int, [c_int, c_void_p, c_void_p, c_int]),
 }
@@ -234,6 +238,24 @@ class KernelProfiler:
     def event(self):
         return self._pool.pop() if self._pool else torch.cuda.Event(enable_timing=True)
 
+    def collect_native(self):
+        """Append the records the native step drivers took of their own kernel calls (csrc/step.hip,
+        nsx_step_profile*): same shape as the per-call records -- (entry-point name, span, integer arguments in the
+        positions bench.py's kernel_model reads) + (tag, counted).  Call after torch.cuda.synchronize()."""
+        L = lib()
+        n = int(L._h.nsx_step_profile_count())
+        name = C.create_string_buffer(64)
+        ms, rows, info = C.c_float(), C.c_int64(), (C.c_int32 * 4)()
+        for i in range(n):
+            check(L._h.nsx_step_profile_get(i, name, 64, C.byref(ms), C.byref(rows), info), "nsx_step_profile_get")
+            nm = name.value.decode()
+            H, n_slots, counted, tag = int(info[0]), int(info[1]), bool(info[2]), int(info[3])
+            ints = [H, int(rows.value)] if nm.startswith("nsx_mlp_") else [int(rows.value), H, 0, n_slots]
+            self.records.append((self.alias.get(nm, nm), _Span(0.0), _Span(float(ms.value)), ints))
+            self.tags.append((tag if tag >= 0 else None, counted))
+        L._h.nsx_step_profile_reset()
+        return n
+
     def summary(self):
         """name -> dict(calls, total_ms, avg_ms, samples); call after torch.cuda.synchronize()."""
         out = {}
@@ -244,6 +266,16 @@ class KernelProfiler:
         for d in out.values():
             d["avg_ms"] = d["total_ms"] / max(d["calls"], 1)
         return out
+
+
+class _Span:
+    """A duration measured elsewhere, shaped like a pair of events (``start.elapsed_time(end)``)."""
+
+    def __init__(self, ms: float):
+        self.ms = ms
+
+    def elapsed_time(self, other) -> float:
+        return other.ms - self.ms
 
 
 profiler = KernelProfiler()

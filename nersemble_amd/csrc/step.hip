@@ -5,6 +5,7 @@
 // (field_density_fn), :280-364 (get_outputs), :366-422 (losses / metrics), nersemble_volumetric_sampler.py:95-134.
 #include "nsx_common.h"
 #include <cstring>
+#include <vector>
 
 namespace nsx {
 
@@ -28,6 +29,55 @@ static inline const T* cat(const uint8_t* base, int64_t off) { return reinterpre
     do {                                 \
         const int rc__ = (call);         \
         if (rc__ != NSX_OK) return rc__; \
+    } while (0)
+
+// Optional HIP-event timing of the drivers' kernel calls (nsx_step_profile*, include/nsx.h): what bench.py's per-call
+// events were when every kernel was launched from Python.  Events are recorded on the stream the call launches on.
+struct ProfRec {
+    const char* name;
+    hipEvent_t a, b;
+    int64_t rows;
+    int32_t H, n_slots, counted, tag;
+};
+static bool g_prof_on = false;
+static int g_prof_tag = -1;
+static std::vector<ProfRec> g_prof;
+static std::vector<hipEvent_t> g_prof_pool;
+
+static hipEvent_t prof_event() {
+    if (!g_prof_pool.empty()) {
+        hipEvent_t e = g_prof_pool.back();
+        g_prof_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+struct ProfScope {
+    hipStream_t st;
+    bool on;
+    ProfRec r;
+    ProfScope(const char* name, void* stream, int64_t rows, int H, int n_slots, int counted)
+        : st((hipStream_t)stream), on(g_prof_on) {
+        if (!on) return;
+        r = ProfRec{name, prof_event(), prof_event(), rows, H, n_slots, counted, g_prof_tag};
+        (void)hipEventRecord(r.a, st);
+    }
+    ~ProfScope() {
+        if (!on) return;
+        (void)hipEventRecord(r.b, st);
+        g_prof.push_back(r);
+    }
+};
+
+// a kernel call of a driver: timed when profiling is on
+#define NSX_CALL(name, rows, H, n_slots, counted, call)                \
+    do {                                                               \
+        ::nsx::ProfScope ps__(name, stream, rows, H, n_slots, counted); \
+        const int rc__ = (call);                                       \
+        if (rc__ != NSX_OK) return rc__;                               \
     } while (0)
 
 }  // namespace nsx
@@ -151,8 +201,9 @@ int nsx_step_sample_run(const nsx_step_sample* a, void* stream) {
     int64_t* m_keep = at<int64_t>(w, p.m_keep);
     int64_t* n_kept = at<int64_t>(w, p.n_kept);
     // -- pass 2 of the traversal (OccGridEstimator.sampling -> traverse)
-    NSX_TRY(nsx_march_fill(a->origins, a->directions, R, a->occ_aabb, a->binaries, a->grid_res, a->near_planes, a->far_plane,
-                           a->step, a->packed_march, m_t0, m_t1, m_ri, nullptr, stream));
+    NSX_CALL("nsx_march_fill", R, 0, 0, 0,
+             nsx_march_fill(a->origins, a->directions, R, a->occ_aabb, a->binaries, a->grid_res, a->near_planes, a->far_plane,
+                            a->step, a->packed_march, m_t0, m_t1, m_ri, nullptr, stream));
     // -- sigma_fn: density at the marched midpoints (get_sigma_fn -> field_density_fn)
     NSX_TRY(nsx_sample_positions(a->origins, a->directions, m_ri, m_t0, m_t1, nullptr, S, nullptr, m_pos, nullptr, nullptr,
                                  nullptr, stream));
@@ -162,14 +213,17 @@ int nsx_step_sample_run(const nsx_step_sample* a, void* stream) {
         const int64_t rb[1] = {4};
         NSX_TRY(nsx_gather_rows(1, srcs, rb, dsts, m_ri, S, nullptr, stream));
     }
-    NSX_TRY(nsx_deform_fwd(a->deform_packed, m_pos, S, a->deform_aabb, a->deform_codes, a->deform_code_stride, m_ts,
-                           a->window7_host, m_off, nullptr, stream));
+    NSX_CALL("nsx_deform_fwd", S, 0, 0, 0,
+             nsx_deform_fwd(a->deform_packed, m_pos, S, a->deform_aabb, a->deform_codes, a->deform_code_stride, m_ts,
+                            a->window7_host, m_off, nullptr, stream));
     NSX_TRY(nsx_sample_positions(m_pos, nullptr, nullptr, nullptr, nullptr, m_off, S, a->field_aabb, nullptr, m_pn, m_sel,
                                  nullptr, stream));
-    NSX_TRY(nsx_hash_ensemble_fwd(m_pn, S, a->tables, a->H, a->geom, a->hash_codes, a->hash_code_stride, m_ts,
-                                  a->hash_window, m_feat, nullptr, stream));
-    NSX_TRY(nsx_mlp_fwd(a->base_w16, a->base_hidden, S, nullptr, 0, 0, 1.0f, 0.0f, m_feat, 32, 0, 32, a->base_out_dim,
-                        a->base_act, m_base, a->base_out_dim, nullptr, stream));
+    NSX_CALL("nsx_hash_ensemble_fwd", S, a->H, 0, 0,
+             nsx_hash_ensemble_fwd(m_pn, S, a->tables, a->H, a->geom, a->hash_codes, a->hash_code_stride, m_ts,
+                                   a->hash_window, m_feat, nullptr, stream));
+    NSX_CALL("nsx_mlp_fwd", S, a->base_hidden, 0, 0,
+             nsx_mlp_fwd(a->base_w16, a->base_hidden, S, nullptr, 0, 0, 1.0f, 0.0f, m_feat, 32, 0, 32, a->base_out_dim,
+                         a->base_act, m_base, a->base_out_dim, nullptr, stream));
     NSX_TRY(nsx_density_fwd(m_base, a->base_out_dim, m_sel, S, m_dens, nullptr, stream));
     // -- visibility test (nerfacc: T >= early_stop_eps && alpha >= min(alpha_thre, occs.mean())), stream compaction
     NSX_TRY(nsx_render_weights_fwd(m_t0, m_t1, m_dens, a->packed_march, R, nullptr, nullptr, nullptr, m_vis,
@@ -243,8 +297,9 @@ int nsx_step_main_fwd(const nsx_step_main* a, void* stream) {
     NSX_TRY(nsx_sample_positions(org, dir, nullptr, t0, t1, off, S, a->field_aabb, pos, pn, sel, n_dev, stream));
     // hash features and mlp_base output are the sigma pass's (same samples, same parameters): density, colour
     NSX_TRY(nsx_density_fwd(base_out, a->base_out_dim, sel, S, dens, n_dev, stream));
-    NSX_TRY(nsx_mlp_fwd(a->head_w16, a->head_hidden, S, dir, 3, 3, 0.5f, 0.5f, base_out, a->base_out_dim, 1, a->geo_dim, 3,
-                        a->head_act, rgb16, 3, n_dev, stream));
+    NSX_CALL("nsx_mlp_fwd", S, a->head_hidden, 0, 1,
+             nsx_mlp_fwd(a->head_w16, a->head_hidden, S, dir, 3, 3, 0.5f, 0.5f, base_out, a->base_out_dim, 1, a->geo_dim, 3,
+                         a->head_act, rgb16, 3, n_dev, stream));
     NSX_TRY(nsx_composite_fwd_h(t0, t1, dens, rgb16, off, packed, R, a->background, clip, wgt, rgb, acc, depth, aux, stream));
     NSX_TRY(nsx_sample_losses_fwd(wgt, t0, t1, packed, R, a->depth_targets, a->eps, a->max_ray, per_ray, stream));
     NSX_TRY(nsx_ray_losses_fwd(rgb, acc, depth, a->image, a->alpha_map, a->depth_targets, per_ray, packed, R, a->use_masked,
@@ -304,41 +359,77 @@ int nsx_step_main_bwd(const nsx_step_main* a, int stage, void* stream) {
         // -- compositing, mlp_head, trunc_exp density, mlp_base
         NSX_TRY(nsx_composite_bwd_h(t0, t1, dens, rgb16, packed, R, a->background, clip, acc, depth, gw, g_rgb, g_acc, g_dep,
                                     ds, dc16, stream));
-        NSX_TRY(nsx_mlp_bwd(a->head_w16, a->head_hidden, S, dir, 3, 3, 0.5f, 0.5f, base_out, a->base_out_dim, 1, a->geo_dim,
-                            3, a->head_act, dc16, 3, at<float>(wg, p.g_head), nullptr, dbase, nullptr, n_dev, stream));
+        NSX_CALL("nsx_mlp_bwd", S, a->head_hidden, 0, 1,
+                 nsx_mlp_bwd(a->head_w16, a->head_hidden, S, dir, 3, 3, 0.5f, 0.5f, base_out, a->base_out_dim, 1, a->geo_dim,
+                             3, a->head_act, dc16, 3, at<float>(wg, p.g_head), nullptr, dbase, nullptr, n_dev, stream));
         NSX_TRY(nsx_density_bwd(base_out, a->base_out_dim, sel, ds, S, dbase, n_dev, stream));
-        NSX_TRY(nsx_mlp_bwd(a->base_w16, a->base_hidden, S, nullptr, 0, 0, 1.0f, 0.0f, feats, 32, 0, 32, a->base_out_dim,
-                            a->base_act, dbase, a->base_out_dim, at<float>(wg, p.g_base), nullptr, nullptr, dout, n_dev,
-                            stream));
+        NSX_CALL("nsx_mlp_bwd", S, a->base_hidden, 0, 1,
+                 nsx_mlp_bwd(a->base_w16, a->base_hidden, S, nullptr, 0, 0, 1.0f, 0.0f, feats, 32, 0, 32, a->base_out_dim,
+                             a->base_act, dbase, a->base_out_dim, at<float>(wg, p.g_base), nullptr, nullptr, dout, n_dev,
+                             stream));
         return NSX_OK;
     }
     if (stage == 1) {
         // -- HashEnsemble: factored table gradient into G, code gradient summed per code row, position gradient
         float* G_fused = a->G;
         if (a->scatter_separately && a->G) {
-            NSX_TRY(nsx_hash_ensemble_bwd_scatter(pn, S, a->geom, a->n_code_rows, slot, dout, a->G, a->nonfinite, 8, n_dev,
-                                                  stream));
+            NSX_CALL("nsx_hash_ensemble_bwd_scatter", S, a->H, a->n_code_rows, 1,
+                     nsx_hash_ensemble_bwd_scatter(pn, S, a->geom, a->n_code_rows, slot, dout, a->G, a->nonfinite, 8, n_dev,
+                                                   stream));
             G_fused = nullptr;
         }
         float* nonfinite = G_fused ? a->nonfinite : nullptr;
         if (a->need_code_grad) {
-            NSX_TRY(nsx_hash_ensemble_bwd_codesum(pn, S, a->tables, a->H, a->geom, a->code_hash, a->code_hash_stride,
-                                                  a->n_code_rows, slot, a->hash_window, dout, G_fused,
-                                                  at<float>(wg, p.g_code_hash), at<float>(wb, p.b_csum), dx, nonfinite,
-                                                  n_dev, stream));
+            NSX_CALL("nsx_hash_ensemble_bwd_codesum", S, a->H, a->n_code_rows, 1,
+                     nsx_hash_ensemble_bwd_codesum(pn, S, a->tables, a->H, a->geom, a->code_hash, a->code_hash_stride,
+                                                   a->n_code_rows, slot, a->hash_window, dout, G_fused,
+                                                   at<float>(wg, p.g_code_hash), at<float>(wb, p.b_csum), dx, nonfinite,
+                                                   n_dev, stream));
         } else {
-            NSX_TRY(nsx_hash_ensemble_bwd_factored(pn, S, a->tables, a->H, a->geom, a->code_hash, a->code_hash_stride,
-                                                   a->n_code_rows, slot, a->hash_window, dout, G_fused, nullptr, dx,
-                                                   nonfinite, n_dev, stream));
+            NSX_CALL("nsx_hash_ensemble_bwd_factored", S, a->H, a->n_code_rows, 1,
+                     nsx_hash_ensemble_bwd_factored(pn, S, a->tables, a->H, a->geom, a->code_hash, a->code_hash_stride,
+                                                    a->n_code_rows, slot, a->hash_window, dout, G_fused, nullptr, dx,
+                                                    nonfinite, n_dev, stream));
         }
         return NSX_OK;
     }
     // -- stage 2: normalisation (gradient of the offsets), deformation field
     float* goff = at<float>(wb, p.b_goff);
     NSX_TRY(nsx_normalise_bwd(dx, sel, S, a->field_aabb, goff, n_dev, stream));
-    NSX_TRY(nsx_deform_bwd(a->deform_packed, pos, S, a->deform_aabb, a->code_deform, a->code_deform_stride, slot,
-                           a->n_code_rows, a->window7_host, goff, wb + p.b_deform, at<float>(wg, p.g_deform),
-                           at<float>(wg, p.g_code_deform), nullptr, n_dev, stream));
+    NSX_CALL("nsx_deform_bwd", S, 0, a->n_code_rows, 1,
+             nsx_deform_bwd(a->deform_packed, pos, S, a->deform_aabb, a->code_deform, a->code_deform_stride, slot,
+                            a->n_code_rows, a->window7_host, goff, wb + p.b_deform, at<float>(wg, p.g_deform),
+                            at<float>(wg, p.g_code_deform), nullptr, n_dev, stream));
+    return NSX_OK;
+}
+
+int nsx_step_profile(int enable, int tag) {
+    g_prof_on = enable != 0;
+    g_prof_tag = tag;
+    return NSX_OK;
+}
+
+int nsx_step_profile_count(void) { return (int)g_prof.size(); }
+
+int nsx_step_profile_get(int i, char* name_out, int name_capacity, float* ms, int64_t* rows, int32_t* info4) {
+    NSX_REQUIRE(i >= 0 && i < (int)g_prof.size(), "nsx_step_profile_get: record %d of %d", i, (int)g_prof.size());
+    NSX_REQUIRE(name_out && name_capacity > 1 && ms && rows && info4, "nsx_step_profile_get: NULL argument");
+    const ProfRec& r = g_prof[i];
+    strncpy(name_out, r.name, (size_t)name_capacity - 1);
+    name_out[name_capacity - 1] = 0;
+    if (hipEventSynchronize(r.b) != hipSuccess || hipEventElapsedTime(ms, r.a, r.b) != hipSuccess)
+        return hip_fail(hipGetLastError(), "nsx_step_profile_get");
+    *rows = r.rows;
+    info4[0] = r.H; info4[1] = r.n_slots; info4[2] = r.counted; info4[3] = r.tag;
+    return NSX_OK;
+}
+
+int nsx_step_profile_reset(void) {
+    for (const ProfRec& r : g_prof) {
+        g_prof_pool.push_back(r.a);
+        g_prof_pool.push_back(r.b);
+    }
+    g_prof.clear();
     return NSX_OK;
 }
 

@@ -153,12 +153,21 @@ class NeRSembleVanillaDataManager:
         ray_bundle = generator(batch["indices"])
         self._add_metadata_to_ray_bundle(ray_bundle, batch)
         # ray -> position of its image in the cached batch, and the batch's per-image timesteps (code slots)
+        local = getattr(sampler, "last_local_image_index", None)
+        if local is not None and local.shape[0] != batch["indices"].shape[0]:
+            local = None
         if "timesteps" in image_batch:
-            image_idx = image_batch["image_idx"].reshape(-1)
-            lookup = torch.full((int(image_idx.max()) + 1,), -1, dtype=torch.int32, device=image_idx.device)
-            lookup[image_idx] = torch.arange(image_idx.numel(), dtype=torch.int32, device=image_idx.device)
-            ray_bundle.metadata["image_index"] = lookup[batch["indices"][:, 0]][:, None]
-            ray_bundle.metadata["_image_timesteps"] = image_batch["timesteps"].reshape(-1).int()
+            if local is not None:
+                ray_bundle.metadata["image_index"] = local.to(torch.int32)[:, None]
+            else:
+                image_idx = image_batch["image_idx"].reshape(-1)
+                lookup = torch.full((int(image_idx.max()) + 1,), -1, dtype=torch.int32, device=image_idx.device)
+                lookup[image_idx] = torch.arange(image_idx.numel(), dtype=torch.int32, device=image_idx.device)
+                ray_bundle.metadata["image_index"] = lookup[batch["indices"][:, 0]][:, None]
+            cached = getattr(self, "_timesteps_i32", None)     # (one conversion per image batch: 20 steps share it)
+            if cached is None or cached[0] is not image_batch["timesteps"]:
+                cached = self._timesteps_i32 = (image_batch["timesteps"], image_batch["timesteps"].reshape(-1).int())
+            ray_bundle.metadata["_image_timesteps"] = cached[1]
         return ray_bundle, batch
 
     def next_train(self, step: int) -> Tuple[RayBundle, Dict]:

@@ -60,6 +60,10 @@ class NeRSemblePixelSampler:
         absolute = indices.clone()
         absolute[:, 0] = batch["image_idx"][c]          # batch-local image number -> dataset image index
         collated["indices"] = absolute
+        # (native extension, outside the returned dict -- its keys are the reference's) the batch-local image number
+        # itself: the model's code slot of the ray; the datamanager puts it into the ray bundle's metadata instead of
+        # inverting ``image_idx`` through a lookup table every step
+        self.last_local_image_index = c
         if keep_full_image:
             collated["full_image"] = batch["image"]
         return collated

@@ -155,6 +155,7 @@ class NativeStep:
         self._sample_cls = _lib.step_struct("nsx_step_sample")
         self._main_cls = _lib.step_struct("nsx_step_main")
         self._ones_codes = {}
+        self._prof_state = (0, -1)
 
     def _ray_timesteps(self, ray_bundle, R: int) -> torch.Tensor:
         """int32 [R]: the reference rounds the rays' ``times`` (nersemble_instant_ngp.py:249); metadata timesteps are
@@ -206,7 +207,8 @@ class NativeStep:
         model.sampler._cull_to_camera_frusta()
         grid = model.occupancy_grid
         far = 1e10 if cfg.far_plane is None else float(cfg.far_plane)
-        near_planes, packed_march, S = grid.counted_march(o, d, cfg.near_plane, far, cfg.render_step_size, stratified=True)
+        near_planes, packed_march, S = grid.counted_march(o, d, cfg.near_plane, far, cfg.render_step_size,
+                                                          stratified=model.sampler.training)
         if S <= 0:
             return None                     # (nothing marched: the per-kernel path owns the one-fake-sample fallback)
         grid.last_keep_index, grid.last_n_marched, grid.last_n_kept = None, S, None
@@ -241,6 +243,11 @@ class NativeStep:
         packed_w = df.packed_params()
         w7 = F.deform_window7(window_deform)
         L = lib()
+        prof = _lib.profiler
+        want_prof = (1, prof.tag if prof.tag is not None else -1) if prof.enabled else (0, -1)
+        if want_prof != self._prof_state:                # HIP events around the drivers' kernel calls (bench.py)
+            L.nsx_step_profile(*want_prof)
+            self._prof_state = want_prof
         plan = self._plan_cls()
         check(L.nsx_step_plan_make(S, R, n_rows, Hk, mb.n_hidden_mats, mh.n_hidden_mats, C.byref(plan)), "nsx_step_plan_make")
         ws_sample = torch.empty((plan.sample_bytes,), dtype=torch.uint8, device=dev)

@@ -157,7 +157,7 @@ def test_tcnn_network_params_are_row_major_out_in(cuda):
         net.params.copy_(torch.from_numpy(p))
     x = np.zeros((4, 32), dtype=np.float16)
     x[:, i] = [1.0, 2.0, -1.0, 0.25]
-    out = net(torch.from_numpy(x).to(cuda)).float().cpu().numpy()
+    out = net(torch.from_numpy(x).to(cuda)).detach().float().cpu().numpy()
     want = np.zeros((4, 16), dtype=np.float32)
     want[:, o] = [1.0, 2.0, 0.0, 0.25]                               # relu(0.5 x) * 2
     assert np.array_equal(out, want)

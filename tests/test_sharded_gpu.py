@@ -202,6 +202,13 @@ def _no_jitter(trainer):
         return orig(*args, **kw)
 
     grid.sampling = sampling
+    orig_count = grid.counted_march                  # (the native step drivers run the counting pass through this one)
+
+    def counted_march(*args, **kw):
+        kw["stratified"] = False
+        return orig_count(*args, **kw)
+
+    grid.counted_march = counted_march
 
 
 def _union_data(n_rays_total):

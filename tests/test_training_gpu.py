@@ -307,19 +307,25 @@ def test_resume_from_checkpoint_continues_the_run(cuda):
     he = a.model.field.hash_ensemble
     C = he.n_tcnn_encodings
     fields = ckpt["optimizers"]["fields"]
-    assert fields["param_groups"][0]["params"] == list(range(C + 2)) and set(fields["state"]) == set(range(C + 2))
-    assert all(int(fields["state"][i]["step"]) == 4 for i in range(C + 2))
+    # the reference's numbering (tests/golden/state_manifest.json): direction_encoding.params (empty, no state), the C hash
+    # encodings, position_encoding.params (empty, no state), mlp_base, mlp_head
+    tab_ids, mlp_ids = list(range(1, C + 1)), [C + 2, C + 3]
+    assert fields["param_groups"][0]["params"] == list(range(C + 4)) and set(fields["state"]) == set(tab_ids + mlp_ids)
+    assert all(int(fields["state"][i]["step"]) == 4 for i in tab_ids + mlp_ids)
     for c in range(C):
-        assert fields["state"][c]["exp_avg"].shape == ckpt["pipeline"][f"_model.field.hash_ensemble.hash_encodings.{c}.params"].shape
-    assert fields["state"][C]["exp_avg"].shape == ckpt["pipeline"]["_model.field.mlp_base.params"].shape
-    assert float(sum(fields["state"][c]["exp_avg_sq"].abs().sum() for c in range(C))) > 0
+        assert fields["state"][1 + c]["exp_avg"].shape == ckpt["pipeline"][f"_model.field.hash_ensemble.hash_encodings.{c}.params"].shape
+    assert fields["state"][C + 2]["exp_avg"].shape == ckpt["pipeline"]["_model.field.mlp_base.params"].shape
+    assert float(sum(fields["state"][i]["exp_avg_sq"].abs().sum() for i in tab_ids)) > 0
     # torch.optim.Adam over the reference's parameter list accepts it (what nerfstudio's Optimizers.load_optimizers does)
-    ref_params = [torch.nn.Parameter(ckpt["pipeline"][f"_model.field.hash_ensemble.hash_encodings.{c}.params"].clone())
-                  for c in range(C)] + [torch.nn.Parameter(ckpt["pipeline"]["_model.field.mlp_base.params"].clone()),
-                                        torch.nn.Parameter(ckpt["pipeline"]["_model.field.mlp_head.params"].clone())]
+    sd = ckpt["pipeline"]
+    ref_params = [torch.nn.Parameter(sd["_model.field.direction_encoding.params"].clone())] + \
+        [torch.nn.Parameter(sd[f"_model.field.hash_ensemble.hash_encodings.{c}.params"].clone()) for c in range(C)] + \
+        [torch.nn.Parameter(sd["_model.field.position_encoding.params"].clone()),
+         torch.nn.Parameter(sd["_model.field.mlp_base.params"].clone()),
+         torch.nn.Parameter(sd["_model.field.mlp_head.params"].clone())]
     ref_adam = torch.optim.Adam(ref_params, lr=5e-3, eps=1e-15)
     ref_adam.load_state_dict(fields)
-    assert int(ref_adam.state[ref_params[0]]["step"]) == 4
+    assert int(ref_adam.state[ref_params[1]]["step"]) == 4 and ref_params[0] not in ref_adam.state
     # the time codes are not trained while the window is closed: no state for time_embedding.weight, as in torch
     emb = ckpt["optimizers"]["embeddings"]
     assert set(emb["state"]) == {1} and emb["param_groups"][0]["params"] == [0, 1]
@@ -681,8 +687,8 @@ def test_compact_first_grid_phase_is_the_same_training(cuda):
     from nersemble_amd import functional as Fn
     tc = Fn.tables_to_tcnn(he.tables.detach(), he.n_hash_encodings, he.geom)
     assert torch.equal(sd_c["field.hash_ensemble.hash_encodings.0.params"], tc[0].reshape(-1))
-    st = t_c.state_dict()["optimizers"]["fields"]["state"][0]
-    st_f = t_f.state_dict()["optimizers"]["fields"]["state"][0]
+    st = t_c.state_dict()["optimizers"]["fields"]["state"][1]        # (position 0 is the empty direction_encoding.params)
+    st_f = t_f.state_dict()["optimizers"]["fields"]["state"][1]
     assert int(st["step"]) == int(st_f["step"]) == 12
     a, b = st["exp_avg_sq"], st_f["exp_avg_sq"]
     assert a.abs().sum().item() > 0
