@@ -614,7 +614,7 @@ def main():
                            "nsx_hash_ensemble_bwd_scatter",
                            "nsx_adam_hash_factored", "nsx_adam_hash_factored_consume", "nsx_adam_dense",
                            "nsx_deform_fwd", "nsx_deform_bwd",
-                           "nsx_mlp_fwd", "nsx_mlp_bwd", "nsx_check_finite", "nsx_march_count", "nsx_march_fill",
+                           "nsx_mlp_fwd", "nsx_mlp_bwd", "nsx_check_finite", "nsx_march_fill",
                            "nsx_hash_grad_expand", "nsx_hash_grad_expand_f16", "nsx_adam_dense_f16grad",
                            "nsx_check_finite_f16"}
     # (the variant of the table optimizer that also clears the gradient pieces it reads is priced as the optimizer pass)

@@ -301,6 +301,10 @@ int nsx_march_count(const float* rays_o, const float* rays_d, int64_t R, const f
                     int64_t* counts, void* stream);
 int nsx_pack_info(const int64_t* counts, int64_t R, int64_t* packed_info /* [R][2] start,count */,
                   int64_t* total /* device scalar */, void* stream);
+/* The read-back of the marched total (nerfacc's one host synchronisation per sampling call) as an asynchronous copy into
+ * PINNED host memory on `stream`: a counting pass issued a step ahead on its own stream (OccGridEstimator.prefetch_march)
+ * leaves the number on the host before the step that needs it starts. */
+int nsx_copy_to_host_async(void* dst_pinned_host, const void* src_device, int64_t bytes, void* stream);
 int nsx_march_fill(const float* rays_o, const float* rays_d, int64_t R, const float* aabb_host,
                    const uint8_t* binary, int res, const float* near, float far_plane, float step,
                    const int64_t* packed_info, float* t_starts, float* t_ends, int64_t* ray_indices,

@@ -318,6 +318,14 @@ int nsx_march_count(const float* rays_o, const float* rays_d, int64_t R, const f
     return NSX_OK;
 }
 
+int nsx_copy_to_host_async(void* dst_pinned_host, const void* src_device, int64_t bytes, void* stream) {
+    NSX_REQUIRE(dst_pinned_host && src_device && bytes >= 0, "nsx_copy_to_host_async: NULL argument / negative size");
+    if (bytes == 0) return NSX_OK;
+    hipError_t e = hipMemcpyAsync(dst_pinned_host, src_device, (size_t)bytes, hipMemcpyDeviceToHost, (hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail(e, "nsx_copy_to_host_async");
+    return NSX_OK;
+}
+
 int nsx_pack_info(const int64_t* counts, int64_t R, int64_t* packed_info, int64_t* total, void* stream) {
     NSX_REQUIRE(R >= 0, "nsx_pack_info: negative ray count");
     NSX_REQUIRE(total, "nsx_pack_info: NULL total");

@@ -36,7 +36,35 @@ class _StepState:
     """Everything one step's drivers share: the plan, the argument structs, the workspaces (kept alive until the backward
     has been enqueued), the tensors the factored-gradient sink and the optimizer look at afterwards."""
     __slots__ = ("plan", "sample", "main", "ws_sample", "ws_fwd", "out", "S", "R", "n_rows", "H", "he", "first_grid",
-                 "main_code", "main_window", "code_deform_shape", "deform_shapes", "keep", "n_kept")
+                 "main_code", "main_window", "keep", "grads")
+
+
+class _GradBuffers:
+    """The parameter gradients a step's backward produces (mlp_head, mlp_base, the 16 deformation tensors, the batch's
+    deformation-code rows, its hash-code rows) in ONE persistent fp32 buffer with ready-made views -- laid out by the plan
+    (``g_*`` offsets; they depend on the number of code rows and grids only).  Stage 0 of the backward clears it, autograd
+    adopts the views as ``.grad``, the optimizers have read them (same stream) before the next backward writes again."""
+
+    def __init__(self, plan, n_rows: int, H: int, code_deform_shape, deform_shapes, head_hidden: int, base_hidden: int,
+                 device):
+        f32 = torch.float32
+        self.flat = torch.empty((plan.grad_bytes // 4,), dtype=f32, device=device)
+
+        def cut(off, n):
+            return self.flat[off // 4:off // 4 + n]
+
+        self.d_head = cut(plan.g_head, F.mlp_param_count(head_hidden))
+        self.d_base = cut(plan.g_base, F.mlp_param_count(base_hidden))
+        gparams = cut(plan.g_deform, F.deform_param_count())
+        sizes = []
+        for shp in deform_shapes:
+            n = 1
+            for d in shp:
+                n *= d
+            sizes.append(n)
+        self.deform = [gp if len(shp) == 1 else gp.view(shp) for gp, shp in zip(torch.split(gparams, sizes), deform_shapes)]
+        self.gtable = cut(plan.g_code_deform, code_deform_shape[0] * code_deform_shape[1]).view(code_deform_shape)
+        self.g_code_hash = cut(plan.g_code_hash, n_rows * H).view(n_rows, H)
 
 
 class _NativeMain(torch.autograd.Function):
@@ -65,11 +93,11 @@ class _NativeMain(torch.autograd.Function):
         plan, m, sink = st.plan, st.main, ctx.sink
         dev = g_out.device
         g = g_out.to(torch.float32).contiguous()
-        grads = torch.empty((plan.grad_bytes,), dtype=torch.uint8, device=dev)
+        gb: _GradBuffers = st.grads
         ws_bwd = torch.empty((plan.bwd_bytes,), dtype=torch.uint8, device=dev)
         need_tab = ctx.needs_input_grad[1]
         need_code = bool(ctx.needs_input_grad[4]) and not st.first_grid    # (the code is the constant one in that phase)
-        m.grad_out, m.ws_bwd, m.grads = g.data_ptr(), ws_bwd.data_ptr(), grads.data_ptr()
+        m.grad_out, m.ws_bwd, m.grads = g.data_ptr(), ws_bwd.data_ptr(), gb.flat.data_ptr()
         m.need_code_grad = 1 if need_code else 0
         L, s = lib(), stream()
         check(L.nsx_step_main_bwd(C.byref(m), 0, s), "nsx_step_main_bwd stage 0")
@@ -81,25 +109,56 @@ class _NativeMain(torch.autograd.Function):
         m.nonfinite = sink.nonfinite.data_ptr() if G is not None else None
         m.scatter_separately = 1 if (st.H == 1 and G is not None) else 0
         check(L.nsx_step_main_bwd(C.byref(m), 1, s), "nsx_step_main_bwd stage 1")
-        f32 = torch.float32
-        d_head = _view(grads, plan.g_head, (F.mlp_param_count(m.head_hidden),), f32)
-        d_base = _view(grads, plan.g_base, (F.mlp_param_count(m.base_hidden),), f32)
         if need_tab and ctx.announced:
             # G is complete, and so are the gradients of the two fused MLPs (the rest of the tables' optimizer group)
-            sink.arrived(group_grads=[d_base, d_head] if sink.on_complete is not None else None)
+            sink.arrived(group_grads=[gb.d_base, gb.d_head] if sink.on_complete is not None else None)
         check(L.nsx_step_main_bwd(C.byref(m), 2, s), "nsx_step_main_bwd stage 2")
-        gparams = _view(grads, plan.g_deform, (F.deform_param_count(),), f32)
-        gtable = _view(grads, plan.g_code_deform, st.code_deform_shape, f32)
-        g_code_hash = _view(grads, plan.g_code_hash, (st.n_rows, st.H), f32) if need_code else None
-        sizes = []
-        for shp in st.deform_shapes:
-            n = 1
-            for d in shp:
-                n *= d
-            sizes.append(n)
-        deform_grads = [gp if len(shp) == 1 else gp.view(shp) for gp, shp in zip(torch.split(gparams, sizes), st.deform_shapes)]
         ctx.st = None                    # the workspaces go back to the allocator with this node
-        return (None, None, d_base, d_head, g_code_hash, gtable, *deform_grads)
+        return (None, None, gb.d_base, gb.d_head, gb.g_code_hash if need_code else None, gb.gtable, *gb.deform)
+
+
+class LazyVectorDict(dict):
+    """name -> element of one device vector, selected on first access (a ``select`` dispatch per entry otherwise, every
+    step, for entries nobody may read)."""
+
+    def __init__(self, vector, terms):
+        super().__init__()
+        self._vector, self._index = vector, dict(terms)
+        for name, _ in terms:
+            super().__setitem__(name, None)
+
+    def __getitem__(self, k):
+        v = super().__getitem__(k)
+        if v is None and k in self._index:
+            v = self._vector[self._index[k]]
+            super().__setitem__(k, v)
+        return v
+
+    def get(self, k, default=None):
+        return self[k] if k in self else default
+
+    def values(self):
+        return [self[k] for k in self.keys()]
+
+    def items(self):
+        return [(k, self[k]) for k in self.keys()]
+
+
+class LazyLossDict(LazyVectorDict):
+    """``loss_dict`` of a natively driven step: the terms of ``get_loss_dict`` (nersemble_instant_ngp.py:366-407) as
+    elements of the fused loss vector; ``total`` = their sum as the kernel formed it (``reduce(add, values)`` order),
+    ``fused`` / ``total_index`` for the trainer's direct backward start."""
+
+    def __init__(self, fused, terms, total_index):
+        super().__init__(fused, terms)
+        self.fused, self.total_index = fused, total_index
+        self._total = None
+
+    @property
+    def total(self):
+        if self._total is None:
+            self._total = self.fused[self.total_index]
+        return self._total
 
 
 class LazyOutputs(dict):
@@ -156,6 +215,7 @@ class NativeStep:
         self._main_cls = _lib.step_struct("nsx_step_main")
         self._ones_codes = {}
         self._prof_state = (0, -1)
+        self._grad_buffers = {}
 
     def _ray_timesteps(self, ray_bundle, R: int) -> torch.Tensor:
         """int32 [R]: the reference rounds the rays' ``times`` (nersemble_instant_ngp.py:249); metadata timesteps are
@@ -199,7 +259,16 @@ class NativeStep:
         emb_d = model.time_embedding_deformation if model.time_embedding_deformation is not None else model.time_embedding
         # the batch's code rows (two embedding lookups + the window conditioning; autograd differentiates them): queued
         # before the sampler so that they run beside the table optimizer instead of behind it
-        code_hash, window = he._conditioned(model.time_embedding(uniq), window_hash, dev)
+        if window_hash is not None and window_hash == 1 and he.disable_initial_hash_ensemble:
+            # hash_ensemble.py:121-123: the code is replaced by ones while the window is 1 -- the lookup's result would not
+            # be read, and no gradient reaches the time codes
+            key = ("rows", n_rows, he.n_hash_encodings, str(dev))
+            ones = self._ones_codes.get(key)
+            if ones is None:
+                ones = self._ones_codes[key] = torch.ones((n_rows, he.n_hash_encodings), dtype=torch.float32, device=dev)
+            code_hash, window = ones, he.window_tensor(window_hash, dev)
+        else:
+            code_hash, window = he._conditioned(model.time_embedding(uniq), window_hash, dev)
         code_deform = emb_d(uniq)
         # -- traversal, pass 1 (possibly prefetched)
         o = ray_bundle.origins.to(torch.float32).contiguous()
@@ -311,35 +380,40 @@ class NativeStep:
         st.plan, st.sample, st.main, st.ws_sample = plan, a, m, ws_sample
         st.S, st.R, st.n_rows, st.H, st.he, st.first_grid = S, R, n_rows, Hk, he, first
         st.main_code, st.main_window = main_code, main_window
-        st.code_deform_shape = tuple(code_d.shape)
         deform_params = df.ordered_params()
-        st.deform_shapes = [tuple(p.shape) for p in deform_params]
+        gkey = (n_rows, Hk, str(dev), plan.grad_bytes)
+        st.grads = self._grad_buffers.get(gkey)
+        if st.grads is None:
+            self._grad_buffers = {gkey: _GradBuffers(plan, n_rows, Hk, tuple(code_d.shape),
+                                                     [tuple(p.shape) for p in deform_params], mh.n_hidden_mats,
+                                                     mb.n_hidden_mats, dev)}
+            st.grads = self._grad_buffers[gkey]
         # every tensor a raw pointer above borrows lives at least as long as the step's state
         st.keep = (o, d, near_planes, packed_march, binary, ray_ts, ray_slots, packed_w, tables, sig_codes, sig_window,
                    base_w16, head_w16, alpha_thre_dev, w7, image_t, amap, depth_t, code_d, he.geom)
         fused = _NativeMain.apply(st, he.tables, mb.params, mh.params, code_hash, code_deform, *deform_params)
-        st.n_kept = _view(ws_sample, plan.n_kept, (1,), torch.int64)
-        grid.last_n_kept = st.n_kept
-        loss_dict = LossDict()
-        loss_dict["rgb_loss"] = fused[dl.LOSS_RGB]
+        terms = [("rgb_loss", dl.LOSS_RGB)]
         if alpha_map is not None and cfg.lambda_alpha_loss is not None and cfg.lambda_alpha_loss > 0:
-            loss_dict["alpha_loss"] = fused[dl.LOSS_ALPHA]
+            terms.append(("alpha_loss", dl.LOSS_ALPHA))
         if cfg.lambda_dist_loss > 0:
-            loss_dict["dist_loss"] = fused[dl.LOSS_DIST]
-        loss_dict["empty_loss"] = fused[dl.LOSS_EMPTY]
-        loss_dict["near_loss"] = fused[dl.LOSS_NEAR]
+            terms.append(("dist_loss", dl.LOSS_DIST))
+        terms += [("empty_loss", dl.LOSS_EMPTY), ("near_loss", dl.LOSS_NEAR)]
         if cfg.lambda_depth_loss > 0:
-            loss_dict["depth_loss"] = fused[dl.LOSS_DEPTH]
-        loss_dict.total = fused[dl.LOSS_TOTAL]
+            terms.append(("depth_loss", dl.LOSS_DEPTH))
         if model.global_loss_normalisers is not None:
+            loss_dict = LossDict()
+            for name, idx in terms:
+                loss_dict[name] = fused[idx]
+            loss_dict.total = fused[dl.LOSS_TOTAL]
             model._apply_global_normalisers(loss_dict, fused, R)
         else:
-            # (the trainer starts the backward at the vector itself, NativeGradScaler.loss_grad_vector)
-            loss_dict.fused, loss_dict.total_index = fused, dl.LOSS_TOTAL
-        mt = fused.detach()
-        metrics = {"psnr": mt[dl.LOSS_PSNR], "num_samples_per_batch": mt[dl.LOSS_NUM_SAMPLES]}
+            # the entries are elements of ONE vector: selected when somebody reads them (the trainer starts the backward at
+            # the vector itself, NativeGradScaler.loss_grad_vector, and hands the dict on)
+            loss_dict = LazyLossDict(fused, terms, dl.LOSS_TOTAL)
+        mterms = [("psnr", dl.LOSS_PSNR), ("num_samples_per_batch", dl.LOSS_NUM_SAMPLES)]
         if alpha_map is not None:
-            metrics["psnr_masked"] = mt[dl.LOSS_PSNR_MASKED]
+            mterms.append(("psnr_masked", dl.LOSS_PSNR_MASKED))
+        metrics = LazyVectorDict(fused.detach(), mterms)
         return loss_dict, metrics, LazyOutputs(lambda: self._outputs(st))
 
     @staticmethod
@@ -359,4 +433,4 @@ class NativeStep:
                 "depth": _view(wf, p.f_depth, (R, 1), f32), "num_samples_per_ray": packed[:, 1],
                 "ray_samples": (samples,), "ray_indices": (_view(ws, p.k_ri, (S,), torch.int64),),
                 "weights": (_view(wf, p.f_w, (S, 1), f32),), "packed_info": (packed,),
-                "deformation": _view(wf, p.f_aux, (R, 3), f32), "n_kept": st.n_kept}
+                "deformation": _view(wf, p.f_aux, (R, 3), f32), "n_kept": _view(ws, p.n_kept, (1,), torch.int64)}

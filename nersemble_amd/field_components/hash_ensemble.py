@@ -274,14 +274,19 @@ class HashEnsemble(nn.Module):
                 first = torch.zeros_like(conditioning_code)
                 first[:, 0] = (1 - alpha) * 1
                 conditioning_code = alpha * conditioning_code + first
-            # one device tensor per window value (chunks / passes of a step share it)
-            wkey = (float(window_hash_encodings), str(device))
-            window = self._window_cache.get(wkey)
-            if window is None:
-                window = posenc_window(window_hash_encodings, 0, self.n_hash_encodings - 1,
-                                       self.n_hash_encodings).to(device=device, dtype=torch.float32)
-                self._window_cache = {wkey: window}
+            window = self.window_tensor(window_hash_encodings, device)
         return conditioning_code, window
+
+    def window_tensor(self, window_hash_encodings: float, device) -> torch.Tensor:
+        """The cosine grid window of hash_ensemble.py:133-138 as ONE device tensor per window value (chunks / passes of a
+        step share it; the factored-gradient sink keys its buffer on it)."""
+        wkey = (float(window_hash_encodings), str(device))
+        window = self._window_cache.get(wkey)
+        if window is None:
+            window = posenc_window(window_hash_encodings, 0, self.n_hash_encodings - 1,
+                                   self.n_hash_encodings).to(device=device, dtype=torch.float32)
+            self._window_cache = {wkey: window}
+        return window
 
     @torch.no_grad()
     def preblend(self, conditioning_code: torch.Tensor, window_hash_encodings: Optional[float] = None) -> torch.Tensor:

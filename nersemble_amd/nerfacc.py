@@ -277,28 +277,32 @@ class OccGridEstimator(nn.Module):
         side = getattr(self, "_prefetch_stream", None)
         if side is None or side.device != dev:
             side = self._prefetch_stream = torch.cuda.Stream(dev, priority=-1)
+            # pinned read-back words + completion events, recycled (three in flight at most: two held + the one being made)
+            self._prefetch_ring = [(torch.empty((1,), dtype=torch.int64, pin_memory=True), torch.cuda.Event())
+                                   for _ in range(4)]
+            self._prefetch_turn = 0
         key = self._march_key(rays_o, rays_d, near_plane, far_plane, render_step_size, stratified, t_min)
         binary = self.binaries[0].contiguous().view(torch.uint8)
-        total_host = torch.empty((1,), dtype=torch.int64, pin_memory=True)
-        side.wait_stream(main)                               # rays and grid were written on the caller's stream
-        with torch.cuda.stream(side):
-            near_planes = self._near_planes(rays_o, near_plane, t_min, render_step_size, stratified)
-            counts = torch.empty((R,), dtype=torch.int64, device=dev)
-            packed = torch.empty((R, 2), dtype=torch.int64, device=dev)
-            total = torch.zeros((1,), dtype=torch.int64, device=dev)
-            check(lib().nsx_march_count(ptr(rays_o), ptr(rays_d), R, self._aabb6(), ptr(binary), self._res,
-                                        ptr(near_planes), float(far_plane), float(render_step_size), ptr(counts),
-                                        stream()), "nsx_march_count")
-            check(lib().nsx_pack_info(ptr(counts), R, ptr(packed), ptr(total), stream()), "nsx_pack_info")
-            total_host.copy_(total, non_blocking=True)
-            done = torch.cuda.Event()
-            done.record(side)
-        for t in (near_planes, packed, binary):               # consumed on the caller's stream later
-            t.record_stream(main)
+        total_host, done = self._prefetch_ring[self._prefetch_turn % 4]
+        self._prefetch_turn += 1
+        # the jitter is drawn on the caller's stream (same generator, same order of draws as marching in place); the two
+        # traversal kernels and the read-back are enqueued on the side stream through its raw handle
+        near_planes = self._near_planes(rays_o, near_plane, t_min, render_step_size, stratified)
+        work = torch.empty((3 * R + 1,), dtype=torch.int64, device=dev)      # counts [R] | packed_info [R, 2] | total
+        counts, packed, total = work[:R], work[R:3 * R].view(R, 2), work[3 * R:]
+        side.wait_stream(main)                               # rays, grid and near planes were written on the caller's stream
+        raw = C.c_void_p(side.cuda_stream)
+        check(lib().nsx_march_count(ptr(rays_o), ptr(rays_d), R, self._aabb6(), ptr(binary), self._res,
+                                    ptr(near_planes), float(far_plane), float(render_step_size), ptr(counts), raw),
+              "nsx_march_count")
+        check(lib().nsx_pack_info(ptr(counts), R, ptr(packed), ptr(total), raw), "nsx_pack_info")
+        check(lib().nsx_copy_to_host_async(C.c_void_p(total_host.data_ptr()), ptr(total), 8, raw), "nsx_copy_to_host_async")
+        done.record(side)
+        work.record_stream(side)                             # allocated on the caller's stream, written on the side stream
         # (two are held at most: the pass for the step whose forward has not run yet, and the one for the step after)
         held = getattr(self, "_prefetched", None) or []
         held.append({"key": key, "rays": (rays_o, rays_d, t_min), "near_planes": near_planes, "packed": packed,
-                     "total_host": total_host, "done": done, "keep": (counts, total)})
+                     "total_host": total_host, "done": done, "keep": (work, binary)})
         self._prefetched = held[-2:]
         return True
 
