@@ -541,6 +541,8 @@ def main():
         trainer.early_table_step = True
     if os.environ.get("NSX_PREFETCH_MARCH") == "0":
         trainer.prefetch_march = False
+    if os.environ.get("NSX_NATIVE_STEP") == "0":                  # A/B: every native call issued from Python (round 3's path)
+        trainer.model.native_step = False
     table_opt = trainer.optimizers.get(trainer.group_of_tables())
 
     for s in range(a.preroll):                                   # optional: start the measurement from a settled state
@@ -548,7 +550,7 @@ def main():
     # synthetic inputs are generated up front: they are resident in HBM when the timed region starts
     # (one more than is trained on: like a loader, the loop knows the next batch, and the trainer starts the counting pass
     # of its ray marching one step ahead -- every timed step issues exactly one such pass)
-    dm, dm_stats = None, {"calls": 0, "host_s": 0.0}
+    dm, dm_stats = None, {"calls": 0, "host_s": 0.0, "each": []}
     if a.with_datamanager:
         dm, n_dm_images = build_datamanager(data, dev)
         batches = None
@@ -563,6 +565,7 @@ def main():
         t_ = time.perf_counter()
         out_ = dm.next_train(a.preroll + s)
         dm_stats["host_s"] += time.perf_counter() - t_
+        dm_stats["each"].append(time.perf_counter() - t_)
         dm_stats["calls"] += 1
         return out_
 
@@ -621,12 +624,16 @@ def main():
     _lib.profiler.alias = {"nsx_adam_hash_factored_consume": "nsx_adam_hash_factored"}
     if not a.no_kernel_events:
         _lib.profiler.prewarm(2 * 16 * a.steps + 64)
+    from nersemble_amd.engine.sharded_adam import ShardedTableAdam
+    if isinstance(table_opt, ShardedTableAdam):
+        table_opt.timing = True                # HIP events around expand / reduce-scatter / shard Adam / all-gather
+        table_opt._events = []
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     _lib.profiler.reset()
     _lib.profiler.enabled = not a.no_kernel_events
-    dm_stats["calls"], dm_stats["host_s"] = 0, 0.0
+    dm_stats["calls"], dm_stats["host_s"], dm_stats["each"] = 0, 0.0, []
     t0 = time.perf_counter()
     samples, loss, metrics = run(a.steps, a.warmup, mark=True)
     end_mark = torch.cuda.Event(enable_timing=True)
@@ -643,9 +650,25 @@ def main():
 
     t = torch.tensor([dt], device=dev, dtype=torch.float64)
     n = torch.tensor([samples], device=dev, dtype=torch.int64)
+    dt_all = [dt]
+    comm = None
     if world > 1:
+        every = torch.zeros((world,), device=dev, dtype=torch.float64)
+        dist.all_gather_into_tensor(every, t)
+        dt_all = every.tolist()
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(n, op=dist.ReduceOp.SUM)
+        if isinstance(table_opt, ShardedTableAdam):
+            table_opt.timing = False
+            comm = table_opt.comm_report()                      # this rank's (rank 0 prints)
+            comm["backend"] = a.backend
+            comm["rccl_ranks"] = world if a.backend == "nccl" else 0
+            comm["ms_per_step_per_rank_min_max"] = [min(dt_all) / a.steps * 1e3, max(dt_all) / a.steps * 1e3]
+            comm["note"] = ("HIP events on the streams the phases run on, rank 0, mean over the timed steps; "
+                            "reduce_scatter_ms spans the first piece's issue to the last piece's completion (the "
+                            "expansion of the later pieces runs inside it), reduce_scatter_exposed_ms is what the main "
+                            "stream waited for it before the inf check; shard Adam + all-gather run on the optimizer "
+                            "stream beside the step's tail and the next step's marching")
     dt_max, total_samples = float(t.item()), int(n.item())
 
     if rank == 0:
@@ -731,6 +754,7 @@ def main():
                        "march_count_one_step_ahead": bool(trainer.prefetch_march),
                        "table_adam_consumes_gradient": bool(getattr(table_opt, "consume_gradient", False)),
                        "compact_first_grid": bool(trainer.model.field.hash_ensemble.compact_first_grid),
+                       "native_step_drivers": bool(trainer.model.native_step and trainer.model._native is not None),
                        "window_hash_schedule": list(a.window_hash) if a.window_hash else
                        [trainer.model.config.window_hash_encodings_begin, trainer.model.config.window_hash_encodings_end]},
             "rays_per_sec": world * info["rays"] * a.steps / dt_max,
@@ -745,9 +769,15 @@ def main():
         }
         if trainer.placement_report is not None:
             out["table_placement"] = trainer.placement_report       # one-off, before the warm-up (engine/placement.py)
+        if comm is not None:
+            out["comm"] = comm
         if dm is not None:
             out["datamanager"] = {
                 "next_train_host_us_per_step": dm_timed["host_s"] / max(dm_timed["calls"], 1) * 1e6,
+                "next_train_host_us_median": sorted(dm_timed["each"])[len(dm_timed["each"]) // 2] * 1e6
+                if dm_timed["each"] else None,
+                "next_train_host_us_max": max(dm_timed["each"]) * 1e6 if dm_timed["each"] else None,
+                "max_is": "the call that redraws the 24-image cache (one in 20: a 0.7 GB stack of resident tensors)",
                 "next_train_calls_in_timed_region": dm_timed["calls"], "dataset_images": n_dm_images,
                 "image_cache": "24 images, redrawn every 20 iterations (train_nersemble.py:174-175)",
                 "note": "next_train(step) is called inside the timed loop, one call per step, for the NEXT step's batch "

@@ -448,6 +448,15 @@ int nsx_adam_dense(const float* grad, int64_t n, float* master, float* exp_avg, 
 int nsx_hash_grad_expand_f16(const float* G, int n_slots, const float* code_table, int64_t code_stride,
                              const float* window, int H, const nsx_grid_geom* g, nsx_half* dtables_f16, float scale,
                              int accumulate, void* stream);
+/* One BUCKET of the same dense gradient for a bucketed reduce-scatter: the ranks' shards are shard_elements long (rank r
+ * owns table elements [r * shard, (r + 1) * shard)), cut into shard / bucket pieces; bucket k gathers piece k of every
+ * rank -- bucket_f16 [world][bucket_elements], rank r's part = table elements r * shard + k * bucket ... (zeros beyond the
+ * table's end) -- so that reduce_scatter(bucket k) hands rank r piece k of ITS shard, and the expansion of bucket k + 1
+ * runs while bucket k is on the links.  bucket_elements: a multiple of 1024. */
+int nsx_hash_grad_expand_f16_bucket(const float* G, int n_slots, const float* code_table, int64_t code_stride,
+                                    const float* window, int H, const nsx_grid_geom* g, nsx_half* bucket_f16, float scale,
+                                    int accumulate, int64_t shard_elements, int64_t bucket_elements, int64_t bucket_index,
+                                    int world_size, void* stream);
 int nsx_check_finite_f16(const nsx_half* x, int64_t n, float* found_inf /* set to 1 if any inf/NaN */, void* stream);
 int nsx_adam_dense_f16grad(const nsx_half* grad, int64_t n, float* master, float* exp_avg, float* exp_avg_sq,
                            nsx_half* params_f16 /* may be NULL */, float lr, float beta1, float beta2, float eps,
@@ -538,6 +547,9 @@ int nsx_occ_update(float* occs, uint8_t* binaries, int64_t n_cells, const int32_
  *                       normalisation, HashEnsemble, mlp_base, trunc_exp), the visibility test, its stream compaction, the
  *                       gathers of the kept samples (intervals, rays, code slots, and the sigma pass's forward values the
  *                       main pass reuses) and pack_info of the kept samples.  The kept count stays on the device.
+ *                       `tables_ready_event` (optional): an event behind the writer of `tables` on ANOTHER stream (the
+ *                       table optimizer's pass of the previous step); the wait is enqueued in front of the HashEnsemble
+ *                       kernel only, so the traversal and the deformation field run beside that writer.
  *   nsx_step_main_fwd   NeRSembleNGPModel.get_outputs + get_loss_dict + get_metrics_dict on the kept samples (:300-422)
  *   nsx_step_main_bwd   its backward in three stages (0: losses ... mlp_base, 1: HashEnsemble, 2: normalisation +
  *                       deformation field) so that the caller can resolve the factored-gradient buffer and start
@@ -633,6 +645,7 @@ typedef struct nsx_step_sample {
     const float* window7_host;       /* 7 floats or NULL */
     uint8_t* ws;                     /* plan->sample_bytes */
     const nsx_step_plan* plan;
+    const void* tables_ready_event;  /* hipEvent_t or NULL: `stream` waits for it right in front of the HashEnsemble */
     int64_t R;
     int64_t S;
     int64_t deform_code_stride;

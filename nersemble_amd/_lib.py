@@ -136,6 +136,8 @@ SIGNATURES = {
                                        c_float, c_int64, c_void_p, c_void_p, c_void_p]),
     "nsx_hash_grad_expand_f16": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_void_p, c_int, _GEOM_P, c_void_p, c_float,
                                          c_int, c_void_p]),
+    "nsx_hash_grad_expand_f16_bucket": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_void_p, c_int, _GEOM_P, c_void_p,
+                                                c_float, c_int, c_int64, c_int64, c_int64, c_int, c_void_p]),
     "nsx_adam_hash_factored": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_void_p, c_int, _GEOM_P, c_void_p, c_void_p,
                                        c_void_p, c_void_p, c_float, c_float, c_float, c_float, c_int64, c_void_p,
                                        c_void_p, c_void_p]),

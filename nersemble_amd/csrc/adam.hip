@@ -210,11 +210,16 @@ __global__ __launch_bounds__(256) void adam_dense_f16grad_kernel(const half_t* _
 }
 
 // out[e][f][h] (+)= scale * sum_slot G[slot][e][f] * code'[slot][h], written as fp16 (same tile staging as the fused
-// Adam kernel: G crosses HBM once)
+// Adam kernel: G crosses HBM once).
+// Bucket mode (bucket_entries > 0; nsx_hash_grad_expand_f16_bucket): `out` is ONE bucket of a bucketed reduce-scatter --
+// [rank][bucket_entries] entries, rank r's piece holding the table entries r * rank_entries + entry_base ... -- so the
+// kernel walks VIRTUAL entries v = r * bucket_entries + w and reads the table entry they stand for; entries beyond the
+// table (the padding of the last shard) are written as zeros.  bucket_entries is a multiple of the tile (EPB).
 template <int HP>
 __global__ __launch_bounds__(256) void expand_f16_kernel(
     const float* __restrict__ G, int n_slots, const float* __restrict__ code, int64_t code_stride,
-    const float* __restrict__ window, int Hreal, uint64_t total, half_t* __restrict__ out, float scale, int accumulate) {
+    const float* __restrict__ window, int Hreal, uint64_t total, half_t* __restrict__ out, float scale, int accumulate,
+    uint64_t bucket_entries, uint64_t rank_entries, uint64_t entry_base, uint64_t virtual_total) {
     constexpr int HV = HP >= 4 ? 4 : HP;
     constexpr int TPE = 2 * HP / HV;
     constexpr int EPB = 256 / TPE;
@@ -227,10 +232,12 @@ __global__ __launch_bounds__(256) void expand_f16_kernel(
         if (h < Hreal) c = code[sl * code_stride + h] * (window ? window[h] : 1.0f);
         cs[i] = (float)(half_t)c;
     }
-    const uint64_t n_tiles = (total + EPB - 1) / EPB;
+    const uint64_t n_walk = bucket_entries ? virtual_total : total;
+    const uint64_t n_tiles = (n_walk + EPB - 1) / EPB;
     const int le = threadIdx.x / TPE, part = threadIdx.x % TPE, f = part / (TPE / 2), hq = part % (TPE / 2);
     for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const uint64_t e0 = tile * EPB;
+        const uint64_t v0 = tile * EPB;                       // first (virtual) entry of the tile = its place in `out`
+        const uint64_t e0 = bucket_entries ? (v0 / bucket_entries) * rank_entries + entry_base + (v0 % bucket_entries) : v0;
         __syncthreads();
         constexpr int Q = EPB * 2 / 4;
         for (int i = threadIdx.x; i < n_slots * Q; i += blockDim.x) {
@@ -245,18 +252,21 @@ __global__ __launch_bounds__(256) void expand_f16_kernel(
         }
         __syncthreads();
         const uint64_t e = e0 + le;
-        if (e >= total) continue;
+        if (v0 + le >= n_walk) continue;
+        if (e >= total && !bucket_entries) continue;
         float g[HV];
 #pragma unroll
         for (int k = 0; k < HV; ++k) g[k] = 0.f;
-        for (int sl = 0; sl < n_slots; ++sl) {
-            const float gv = gs[sl * (EPB * 2) + le * 2 + f];
-            if (gv != 0.f) {
+        if (e < total) {
+            for (int sl = 0; sl < n_slots; ++sl) {
+                const float gv = gs[sl * (EPB * 2) + le * 2 + f];
+                if (gv != 0.f) {
 #pragma unroll
-                for (int k = 0; k < HV; ++k) g[k] = __fmaf_rn(gv, cs[sl * HP + hq * HV + k], g[k]);
+                    for (int k = 0; k < HV; ++k) g[k] = __fmaf_rn(gv, cs[sl * HP + hq * HV + k], g[k]);
+                }
             }
         }
-        const uint64_t at = (e * 2ull + f) * HP + hq * HV;
+        const uint64_t at = ((v0 + le) * 2ull + f) * HP + hq * HV;
 #pragma unroll
         for (int k = 0; k < HV; ++k) {
             const float prev = accumulate ? (float)out[at + k] : 0.f;
@@ -267,12 +277,17 @@ __global__ __launch_bounds__(256) void expand_f16_kernel(
 
 template <int HP>
 static int launch_expand_f16(const float* G, int n_slots, const float* code, int64_t code_stride, const float* window,
-                             int H, uint64_t total, nsx_half* out, float scale, int accumulate, hipStream_t st) {
+                             int H, uint64_t total, nsx_half* out, float scale, int accumulate, hipStream_t st,
+                             uint64_t bucket_entries = 0, uint64_t rank_entries = 0, uint64_t entry_base = 0,
+                             uint64_t virtual_total = 0) {
     constexpr int HV = HP >= 4 ? 4 : HP;
     constexpr int EPB = 256 / (2 * HP / HV);
+    NSX_REQUIRE(bucket_entries % EPB == 0, "nsx_hash_grad_expand_f16_bucket: bucket of %llu entries is not a multiple of "
+                "the kernel's tile (%d entries)", (unsigned long long)bucket_entries, EPB);
     const size_t smem = ((size_t)n_slots * HP + (size_t)n_slots * EPB * 2) * sizeof(float);
     hipLaunchKernelGGL((expand_f16_kernel<HP>), dim3(num_cus() * 8), dim3(256), smem, st, G, n_slots, code, code_stride,
-                       window, H, total, reinterpret_cast<half_t*>(out), scale, accumulate);
+                       window, H, total, reinterpret_cast<half_t*>(out), scale, accumulate, bucket_entries, rank_entries,
+                       entry_base, virtual_total);
     NSX_LAUNCH_CHECK("nsx_hash_grad_expand_f16 launch");
     return NSX_OK;
 }
@@ -475,6 +490,34 @@ int nsx_hash_grad_expand_f16(const float* G, int n_slots, const float* code_tabl
     }
 #undef NSX_EXP_CASE
     set_error("nsx_hash_grad_expand_f16: unsupported H=%d", H);
+    return NSX_ERR_UNSUPPORTED;
+}
+
+int nsx_hash_grad_expand_f16_bucket(const float* G, int n_slots, const float* code_table, int64_t code_stride,
+                                    const float* window, int H, const nsx_grid_geom* g, nsx_half* bucket_f16, float scale,
+                                    int accumulate, int64_t shard_elements, int64_t bucket_elements, int64_t bucket_index,
+                                    int world_size, void* stream) {
+    NSX_REQUIRE(G && code_table && bucket_f16 && g, "nsx_hash_grad_expand_f16_bucket: NULL argument");
+    NSX_REQUIRE(H >= 1 && H <= 32, "nsx_hash_grad_expand_f16_bucket: H=%d not in [1,32]", H);
+    NSX_REQUIRE(n_slots >= 1 && n_slots <= NSX_MAX_SLOTS, "nsx_hash_grad_expand_f16_bucket: n_slots=%d not in [1,%d]",
+                n_slots, NSX_MAX_SLOTS);
+    const int Hp = nsx_padded_grids(H);
+    const int64_t per_entry = 2ll * Hp;
+    NSX_REQUIRE(world_size >= 1 && bucket_elements >= per_entry && shard_elements >= bucket_elements &&
+                shard_elements % bucket_elements == 0 && bucket_elements % per_entry == 0 && bucket_index >= 0 &&
+                (bucket_index + 1) * bucket_elements <= shard_elements,
+                "nsx_hash_grad_expand_f16_bucket: shard %lld / bucket %lld / index %lld / world %d",
+                (long long)shard_elements, (long long)bucket_elements, (long long)bucket_index, world_size);
+    const uint64_t total = g->offset[g->n_levels];
+    const uint64_t be = (uint64_t)(bucket_elements / per_entry), re = (uint64_t)(shard_elements / per_entry);
+    hipStream_t st = (hipStream_t)stream;
+#define NSX_EXPB_CASE(HP) case HP: return launch_expand_f16<HP>(G, n_slots, code_table, code_stride, window, H, total, \
+        bucket_f16, scale, accumulate, st, be, re, (uint64_t)bucket_index * be, (uint64_t)world_size * be);
+    switch (Hp) {
+        NSX_EXPB_CASE(1) NSX_EXPB_CASE(2) NSX_EXPB_CASE(4) NSX_EXPB_CASE(8) NSX_EXPB_CASE(16) NSX_EXPB_CASE(32)
+    }
+#undef NSX_EXPB_CASE
+    set_error("nsx_hash_grad_expand_f16_bucket: unsupported H=%d", H);
     return NSX_ERR_UNSUPPORTED;
 }
 

@@ -218,6 +218,9 @@ int nsx_step_sample_run(const nsx_step_sample* a, void* stream) {
                             a->window7_host, m_off, nullptr, stream));
     NSX_TRY(nsx_sample_positions(m_pos, nullptr, nullptr, nullptr, nullptr, m_off, S, a->field_aabb, nullptr, m_pn, m_sel,
                                  nullptr, stream));
+    if (a->tables_ready_event &&
+        hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)const_cast<void*>(a->tables_ready_event), 0) != hipSuccess)
+        return hip_fail(hipGetLastError(), "nsx_step_sample_run: waiting for the tables");
     NSX_CALL("nsx_hash_ensemble_fwd", S, a->H, 0, 0,
              nsx_hash_ensemble_fwd(m_pn, S, a->tables, a->H, a->geom, a->hash_codes, a->hash_code_stride, m_ts,
                                    a->hash_window, m_feat, nullptr, stream));
@@ -456,7 +459,7 @@ int nsx_step_echo(int kind, const void* s, double* out, int capacity) {
         PUTP(a->origins); PUTP(a->directions); PUTP(a->near_planes); PUTP(a->packed_march); PUTP(a->binaries);
         PUTP(a->ray_timesteps); PUTP(a->ray_slots); PUTP(a->deform_packed); PUTP(a->deform_codes); PUTP(a->tables);
         PUTP(a->geom); PUTP(a->hash_codes); PUTP(a->hash_window); PUTP(a->base_w16); PUTP(a->alpha_thre_dev);
-        PUTP(a->window7_host); PUTP(a->ws); PUTP(a->plan);
+        PUTP(a->window7_host); PUTP(a->ws); PUTP(a->plan); PUTP(a->tables_ready_event);
         PUT(a->R); PUT(a->S); PUT(a->deform_code_stride); PUT(a->hash_code_stride);
         PUT(a->grid_res); PUT(a->H); PUT(a->base_hidden); PUT(a->base_out_dim); PUT(a->base_act); PUT(a->reserved);
         PUT(a->far_plane); PUT(a->step); PUT(a->early_stop_eps); PUT(a->reserved_f);

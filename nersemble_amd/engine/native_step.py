@@ -32,6 +32,25 @@ def _view(buf: torch.Tensor, off: int, shape, dtype) -> torch.Tensor:
     return buf[off:off + nbytes].view(dtype).view(tuple(shape))
 
 
+class _LazyView:
+    """A tensor view of a workspace region, made when somebody needs the tensor (``OccGridEstimator.last_n_kept``)."""
+    __slots__ = ("buf", "off", "shape", "dtype", "_t")
+
+    def __init__(self, buf, off, shape, dtype):
+        self.buf, self.off, self.shape, self.dtype, self._t = buf, off, shape, dtype, None
+
+    def tensor(self) -> torch.Tensor:
+        if self._t is None:
+            self._t = _view(self.buf, self.off, self.shape, self.dtype)
+        return self._t
+
+    def __getattr__(self, name):                    # (behaves like the tensor for the occasional reader)
+        return getattr(self.tensor(), name)
+
+    def __getitem__(self, i):
+        return self.tensor()[i]
+
+
 class _StepState:
     """Everything one step's drivers share: the plan, the argument structs, the workspaces (kept alive until the backward
     has been enqueued), the tensors the factored-gradient sink and the optimizer look at afterwards."""
@@ -288,15 +307,16 @@ class NativeStep:
         # first-grid phase (HashEnsemble.first_grid_phase), the contiguous copy of grid 0 with a constant code of one
         first = he.first_grid_phase(window_hash)
         T = model.time_embedding.weight.shape[0]
+        # (the previous step's table optimizer may still be running on its stream: only the HashEnsemble kernel waits for it --
+        # the traversal and the deformation field of this step run beside it, as on the per-kernel path)
         if first:
             comp = he.enter_first_grid_phase()
-            he.wait_tables()
             tables, Hk = comp["f16"], 1
             sig_codes, sig_window = he.first_grid_code(T), None
             main_code, main_window = he.first_grid_code(n_rows), None
         else:
             he.leave_first_grid_phase()
-            tables, Hk = he.half_tables(), he.n_hash_encodings
+            tables, Hk = he.half_tables(wait=False), he.n_hash_encodings
             with torch.no_grad():
                 if window_hash is not None and window_hash == 1 and he.disable_initial_hash_ensemble:
                     key = (T, Hk, str(dev))
@@ -334,6 +354,8 @@ class NativeStep:
         a.base_w16, a.alpha_thre_dev = base_w16.data_ptr(), alpha_thre_dev.data_ptr()
         a.window7_host = C.addressof(w7) if w7 is not None else None
         a.ws, a.plan = ws_sample.data_ptr(), C.addressof(plan)
+        tables_event = he.take_tables_event()
+        a.tables_ready_event = tables_event.cuda_event if tables_event is not None else None
         a.R, a.S = R, S
         a.deform_code_stride, a.hash_code_stride = emb_d.weight.stride(0), sig_codes.stride(0)
         a.grid_res, a.H = grid._res, Hk
@@ -390,8 +412,9 @@ class NativeStep:
             st.grads = self._grad_buffers[gkey]
         # every tensor a raw pointer above borrows lives at least as long as the step's state
         st.keep = (o, d, near_planes, packed_march, binary, ray_ts, ray_slots, packed_w, tables, sig_codes, sig_window,
-                   base_w16, head_w16, alpha_thre_dev, w7, image_t, amap, depth_t, code_d, he.geom)
+                   base_w16, head_w16, alpha_thre_dev, w7, image_t, amap, depth_t, code_d, he.geom, tables_event)
         fused = _NativeMain.apply(st, he.tables, mb.params, mh.params, code_hash, code_deform, *deform_params)
+        grid.last_n_kept = _LazyView(ws_sample, plan.n_kept, (1,), torch.int64)
         terms = [("rgb_loss", dl.LOSS_RGB)]
         if alpha_map is not None and cfg.lambda_alpha_loss is not None and cfg.lambda_alpha_loss > 0:
             terms.append(("alpha_loss", dl.LOSS_ALPHA))

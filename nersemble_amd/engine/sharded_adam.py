@@ -17,6 +17,14 @@ sized for xGMI's point-to-point links):
 Per GPU and step that is 1.4 GB over the links instead of 2.8 GB, and 1.5 GB instead of 12 GB of optimizer traffic.
 The fp32 master copy in ``HashEnsemble.tables`` is authoritative only inside the rank's shard;
 ``gather_master()`` rebuilds the full tensor (checkpointing).
+
+Round 4: steps 1-2 run in ``n_buckets`` pieces.  Bucket k is piece k of EVERY rank's shard (``[world][shard / K]``
+elements, expanded straight into that order by ``nsx_hash_grad_expand_f16_bucket``), so ``reduce_scatter(bucket k)`` hands
+a rank piece k of its own shard -- the shard, the Adam pass and the all-gather are what they were -- and the expansion of
+bucket k + 1 runs while bucket k is on the links; two bucket buffers alternate, the 0.8 GB dense gradient is gone
+(2 / K of it).  The result is bit-identical to the one-piece exchange (same values, same reduction per element;
+tests/test_parallel_cpu.py).  ``timing = True`` records HIP events around every phase (``comm_report``; bench.py's
+``comm`` block).
 """
 import ctypes as C
 from typing import Optional
@@ -42,6 +50,15 @@ class NativeTableOps:
                                              float(scale), int(accumulate), stream()), "nsx_hash_grad_expand_f16")
 
     @staticmethod
+    def expand_f16_bucket(he: HashEnsemble, entry, out: torch.Tensor, scale: float, accumulate: bool, shard: int,
+                          bucket: int, k: int, world: int) -> None:
+        check(lib().nsx_hash_grad_expand_f16_bucket(ptr(entry["G"]), entry["n_rows"], ptr(entry["code"]),
+                                                    entry["code"].stride(0), ptr(entry["window"]), he.n_hash_encodings,
+                                                    C.byref(he.geom), ptr(out), float(scale), int(accumulate), int(shard),
+                                                    int(bucket), int(k), int(world), stream()),
+              "nsx_hash_grad_expand_f16_bucket")
+
+    @staticmethod
     def check_finite_f16(x: torch.Tensor, found_inf: torch.Tensor) -> None:
         check(lib().nsx_check_finite_f16(ptr(x), x.numel(), ptr(found_inf), stream()), "nsx_check_finite_f16")
 
@@ -52,13 +69,25 @@ class NativeTableOps:
               "nsx_adam_dense_f16grad")
 
 
+class _Handles:
+    """The work handles of a bucketed collective as one."""
+
+    def __init__(self, handles):
+        self.handles = [h for h in handles if h is not None]
+
+    def wait(self):
+        for h in self.handles:
+            h.wait()
+
+
 class ShardedTableAdam(torch.optim.Optimizer):
     """torch.optim.Adam (no amsgrad / weight decay) for ``HashEnsemble.tables`` with the state sharded over the ranks."""
     writes_half_tables = True      # HashEnsemble keeps its fp16 working copy; this optimizer refreshes it itself
 
 
     def __init__(self, hash_ensemble: HashEnsemble, lr: float = 5e-3, betas=(0.9, 0.999), eps: float = 1e-15,
-                 world_size: int = 1, rank: int = 0, group=None, ops=None, overlap_reduce: bool = True):
+                 world_size: int = 1, rank: int = 0, group=None, ops=None, overlap_reduce: bool = True,
+                 n_buckets: int = 8):
         self.he = hash_ensemble
         super().__init__([hash_ensemble.tables], dict(lr=lr, betas=betas, eps=eps))
         self.world_size, self.rank, self.group = int(world_size), int(rank), group
@@ -66,7 +95,15 @@ class ShardedTableAdam(torch.optim.Optimizer):
         hash_ensemble.grad_sink = F.FactoredGradSink()
         self.n = hash_ensemble.tables.numel()
         per = (self.n + self.world_size - 1) // self.world_size
-        self.shard = (per + SHARD_ALIGN - 1) // SHARD_ALIGN * SHARD_ALIGN
+        # pieces of the exchange (1: the one-piece exchange of rounds 1-3); every piece a multiple of SHARD_ALIGN elements
+        self.n_buckets = max(1, int(n_buckets))
+        while self.n_buckets > 1 and per < self.n_buckets * SHARD_ALIGN:
+            self.n_buckets //= 2                                   # (small test tables: fewer, larger pieces)
+        unit = SHARD_ALIGN * self.n_buckets
+        self.shard = (per + unit - 1) // unit * unit
+        self.bucket = self.shard // self.n_buckets
+        self.timing = False           # HIP events around expand / reduce-scatter / shard Adam / all-gather (comm_report)
+        self._events = []
         self.lo = self.rank * self.shard
         self.n_local = max(0, min(self.shard, self.n - self.lo))          # the last shards may be short or empty
         self._buf = None
@@ -92,7 +129,10 @@ class ShardedTableAdam(torch.optim.Optimizer):
             self._buf = {
                 "dev": dev,
                 "f16": f16_padded,
-                "grad_dense": torch.zeros((padded,), dtype=torch.float16, device=dev),     # tail stays zero
+                # one-piece exchange: the dense gradient (tail stays zero); bucketed: two alternating bucket buffers
+                "grad_dense": torch.zeros((padded,), dtype=torch.float16, device=dev) if self.n_buckets == 1 else None,
+                "buckets": [torch.zeros((self.world_size * self.bucket,), dtype=torch.float16, device=dev)
+                            for _ in range(2)] if self.n_buckets > 1 else None,
                 "grad_shard": torch.empty((self.shard,), dtype=torch.float16, device=dev),
                 "exp_avg": torch.zeros((self.shard,), dtype=torch.float32, device=dev),
                 "exp_avg_sq": torch.zeros((self.shard,), dtype=torch.float32, device=dev),
@@ -118,8 +158,11 @@ class ShardedTableAdam(torch.optim.Optimizer):
             if sink is not None and he.tables.is_cuda:
                 sink.wait_scatter()
             self._expand_and_reduce(async_op=False)              # not started from the backward: do it here
+            self._mark("rs_end")
         elif early != "done":
+            self._mark("rs_wait_begin")
             early.wait()                                         # the current stream waits for the collective
+            self._mark("rs_wait_end")
         self.ops.check_finite_f16(b["grad_shard"], found_inf)
         if entries and sink.nonfinite is not None:
             torch.maximum(found_inf, sink.nonfinite.to(found_inf.dtype), out=found_inf)
@@ -137,19 +180,50 @@ class ShardedTableAdam(torch.optim.Optimizer):
         if sink is not None and self.he.tables.is_cuda:
             sink.wait_scatter()
         self._expand_and_reduce(async_op=False)
+        self._mark("rs_end")
         self._early = "done"
+
+    def _mark(self, what: str):
+        """A timing event on the current stream (``timing`` only)."""
+        if not self.timing or not self.he.tables.is_cuda:
+            return None
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        self._events.append((what, ev))
+        return ev
 
     def _expand_and_reduce(self, async_op: bool):
         """Dense fp16 gradient / world from the factored one, then the reduce-scatter (every rank joins, with zeros
-        if it has no gradient)."""
+        if it has no gradient) -- in ``n_buckets`` pieces: piece k + 1 is expanded while piece k is on the links."""
         he, b = self.he, self._buffers()
         entries = he.grad_sink.entries if he.grad_sink is not None else []
-        if not entries:
-            b["grad_dense"][:self.n].zero_()
-        for i, e in enumerate(entries):
-            self.ops.expand_f16(he, e, b["grad_dense"], 1.0 / self.world_size, i > 0)
-        return dist.reduce_scatter_tensor(b["grad_shard"], b["grad_dense"], op=dist.ReduceOp.SUM, group=self.group,
-                                          async_op=async_op)
+        scale = 1.0 / self.world_size
+        if self.n_buckets == 1:
+            self._mark("expand_begin")
+            if not entries:
+                b["grad_dense"][:self.n].zero_()
+            for i, e in enumerate(entries):
+                self.ops.expand_f16(he, e, b["grad_dense"], scale, i > 0)
+            self._mark("expand_end")
+            self._mark("rs_begin")
+            return dist.reduce_scatter_tensor(b["grad_shard"], b["grad_dense"], op=dist.ReduceOp.SUM, group=self.group,
+                                              async_op=async_op)
+        handles = []
+        for k in range(self.n_buckets):
+            buf = b["buckets"][k % 2]
+            if k >= 2 and handles[k - 2] is not None:
+                handles[k - 2].wait()                          # (stream-side: the buffer's previous piece has left)
+            self._mark("expand_begin")
+            if not entries:
+                buf.zero_()
+            for i, e in enumerate(entries):
+                self.ops.expand_f16_bucket(he, e, buf, scale, i > 0, self.shard, self.bucket, k, self.world_size)
+            self._mark("expand_end")
+            if k == 0:
+                self._mark("rs_begin")
+            out = b["grad_shard"][k * self.bucket:(k + 1) * self.bucket]
+            handles.append(dist.reduce_scatter_tensor(out, buf, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op))
+        return _Handles(handles) if async_op else None
 
     @torch.no_grad()
     def _start_reduce(self) -> None:
@@ -168,6 +242,9 @@ class ShardedTableAdam(torch.optim.Optimizer):
         he.grad_sink.wait_scatter(comm)                          # G is complete on the scatter's stream
         with torch.cuda.stream(comm):
             self._early = self._expand_and_reduce(async_op=True)
+            if self.timing:
+                self._early.wait()                               # (stream-side wait: the event behind it marks completion)
+                self._mark("rs_end")
         for e in he.grad_sink.entries:                           # allocated on the main stream, read on this one
             for t in (e["G"], e["code"], e["window"]):
                 if t is not None:
@@ -198,11 +275,14 @@ class ShardedTableAdam(torch.optim.Optimizer):
         group = self.param_groups[0]
         self._step += 1
         b1, b2 = group["betas"]
+        self._mark("adam_begin")
         if self.n_local > 0:
             self.ops.adam_f16grad(b["grad_shard"], self.n_local, self._master_shard(), b["exp_avg"], b["exp_avg_sq"],
                                   b["f16"][self.lo:self.lo + self.shard], group["lr"], b1, b2, group["eps"], self._step,
                                   inv_scale, found_inf)
+        self._mark("adam_end")
         dist.all_gather_into_tensor(b["f16"], b["f16"][self.lo:self.lo + self.shard], group=self.group)
+        self._mark("ag_end")
         if he.grad_sink is not None:
             he.grad_sink.clear()
         he.mark_half_synced()
@@ -210,6 +290,38 @@ class ShardedTableAdam(torch.optim.Optimizer):
     def rollback_step(self) -> None:
         """The last ``step()`` was skipped on the device (inf/NaN): it must not count (torch.optim.Adam semantics)."""
         self._step = max(0, self._step - 1)
+
+    def comm_report(self, reset: bool = True) -> dict:
+        """Mean per-step durations (ms) of the exchange's phases from the events recorded while ``timing`` was on; call
+        after a device synchronisation.  ``reduce_scatter_ms`` spans the first piece's issue to the last piece's
+        completion on the communication stream (the expansions of the later pieces run inside it),
+        ``reduce_scatter_exposed_ms`` is what the main stream waited for it, ``bus_GBps`` prices (W - 1) / W of the
+        exchanged bytes per rank against the span."""
+        ev, acc, n_steps = self._events, {}, 0
+        spans = {"expand_f16_ms": ("expand_begin", "expand_end"), "reduce_scatter_ms": ("rs_begin", "rs_end"),
+                 "reduce_scatter_exposed_ms": ("rs_wait_begin", "rs_wait_end"), "shard_adam_ms": ("adam_begin", "adam_end"),
+                 "all_gather_ms": ("adam_end", "ag_end")}
+        for name, (a, b) in spans.items():
+            total, open_ev = 0.0, None
+            for what, e in ev:
+                if what == a:
+                    open_ev = e
+                elif what == b and open_ev is not None:
+                    total += open_ev.elapsed_time(e)
+                    open_ev = None
+            acc[name] = total
+        n_steps = max(1, sum(1 for what, _ in ev if what == "adam_begin"))
+        out = {k: v / n_steps for k, v in acc.items()}
+        W = self.world_size
+        bytes_rs = (W - 1) / W * self.shard * W * 2          # fp16 gradient pieces leaving / arriving per rank
+        out.update(steps=n_steps, buckets=self.n_buckets, world_size=W,
+                   reduce_scatter_bytes_per_rank=bytes_rs, all_gather_bytes_per_rank=bytes_rs,
+                   reduce_scatter_bus_GBps=(bytes_rs / (out["reduce_scatter_ms"] * 1e-3) / 1e9)
+                   if out["reduce_scatter_ms"] > 0 else None,
+                   all_gather_bus_GBps=(bytes_rs / (out["all_gather_ms"] * 1e-3) / 1e9) if out["all_gather_ms"] > 0 else None)
+        if reset:
+            self._events = []
+        return out
 
     def clear_grads(self) -> None:
         self.zero_grad(set_to_none=True)

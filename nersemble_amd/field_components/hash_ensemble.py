@@ -109,10 +109,12 @@ class HashEnsemble(nn.Module):
         self._register_load_state_dict_pre_hook(self._import_tcnn_keys)
 
     # ---- working copy management --------------------------------------------------------------
-    def half_tables(self) -> torch.Tensor:
-        """fp16 working copy; refreshed lazily whenever the fp32 master changed (any optimizer works)."""
-        self.wait_tables()
+    def half_tables(self, wait: bool = True) -> torch.Tensor:
+        """fp16 working copy; refreshed lazily whenever the fp32 master changed (any optimizer works).  ``wait=False``:
+        the caller orders its reader behind the optimizer pass itself (``take_tables_event``)."""
         v = (self.tables._version, self.tables.data_ptr())
+        if wait or self._f16_version != v:
+            self.wait_tables()
         if self._f16_version != v:
             if self.tables_f16.device != self.tables.device:
                 self.tables_f16 = torch.empty_like(self.tables, dtype=torch.float16)
@@ -126,6 +128,12 @@ class HashEnsemble(nn.Module):
         if ev is not None:
             torch.cuda.current_stream(self.tables.device).wait_event(ev)
             self._tables_ready = None
+
+    def take_tables_event(self):
+        """The event behind an optimizer pass that is still running on its own stream (or None), handed over: the caller
+        makes the first reader of the tables wait for it -- and nothing in front of that reader."""
+        ev, self._tables_ready = self._tables_ready, None
+        return ev
 
     def mark_half_synced(self):
         """Called by the fused Adam step, which writes master and working copy together."""

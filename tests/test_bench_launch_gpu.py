@@ -26,3 +26,10 @@ def test_bench_gpus_2_launches_its_own_ranks(cuda):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["config"]["parallelism"] == "dp2" and d["value"] > 0
     assert d["config"]["rays_per_gpu"] == 4096 and d["scaling"] == "weak"
+    # the line diagnoses its own exchange: durations of the phases of the sharded table step on the streams they run on
+    comm = d["comm"]
+    assert comm["world_size"] == 2 and comm["buckets"] >= 2 and comm["steps"] == 3 and comm["backend"] == "gloo"
+    for key in ("expand_f16_ms", "reduce_scatter_ms", "shard_adam_ms", "all_gather_ms"):
+        assert comm[key] > 0, (key, comm)
+    assert comm["reduce_scatter_exposed_ms"] >= 0 and comm["reduce_scatter_bytes_per_rank"] > 0
+    assert comm["reduce_scatter_bus_GBps"] > 0 and len(comm["ms_per_step_per_rank_min_max"]) == 2

@@ -71,23 +71,22 @@ def test_native_training_steps_equal_the_per_kernel_steps(phase, cuda):
             return r
 
         model.fused_train_forward = counted
-        losses, terms, grads = [], None, None
+        losses, terms, grads, tables = [], None, None, None
         for step in range(5):
             torch.manual_seed(70 + step)                          # same near-plane jitter on both sides
-            b_next = None
             loss, loss_dict, metrics = trainer.train_iteration(step, *data.next_train(step))
             losses.append(loss.item())
             if step == 0:
                 terms = {k: v.item() for k, v in loss_dict.items()}
                 terms.update({"m:" + k: float(v) for k, v in metrics.items()})
                 grads = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+                trainer.consolidate()                             # (the compact phase holds grid 0 apart)
+                model.field.hash_ensemble.wait_tables()
+                tables = model.field.hash_ensemble.tables.detach().clone()           # after ONE optimizer step
         trainer.flush_scheduler_step()
-        trainer.consolidate()
-        model.field.hash_ensemble.wait_tables()
         assert all(calls) and len(calls) == 5
         assert (model._native is not None) == native
-        res[native] = (losses, terms, grads, model.field.hash_ensemble.tables.detach().clone(),
-                       trainer.grad_scaler.get_scale())
+        res[native] = (losses, terms, grads, tables, trainer.grad_scaler.get_scale())
     (l_p, t_p, g_p, tab_p, sc_p), (l_n, t_n, g_n, tab_n, sc_n) = res[False], res[True]
     assert l_p[0] == l_n[0] and t_p == t_n, (l_p[0], l_n[0], t_p, t_n)                 # forward: bit for bit
     assert set(g_p) == set(g_n) and sc_p == sc_n == 65536.0
@@ -97,10 +96,10 @@ def test_native_training_steps_equal_the_per_kernel_steps(phase, cuda):
         assert (g_p[name] - g_n[name]).abs().max().item() <= 1e-4 * sc + 1e-12, name
     assert np.allclose(l_p, l_n, rtol=2e-3), (l_p, l_n)
     assert l_n[-1] < l_n[0]
-    # five Adam steps (+-lr per touched entry and step): equal unless a cancelling gradient changed sign with the
-    # atomics' order; compared through their distribution
+    # one Adam step (+-lr per touched entry): equal unless a cancelling gradient changed sign with the atomics' order;
+    # later steps diverge chaotically from there, which is why the run is compared through the loss
     d = (tab_p - tab_n).abs()
-    assert (d <= 1e-4).float().mean().item() >= 0.995
+    assert (d <= 1e-5).float().mean().item() >= 0.9995
 
 
 def test_native_step_with_the_march_counted_a_step_ahead(cuda):

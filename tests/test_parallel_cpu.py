@@ -87,6 +87,14 @@ class _TorchTableOps:
         n = d.numel()
         out[:n] = (out[:n].float() + d).half() if accumulate else d.half()
 
+    def expand_f16_bucket(self, he, entry, out, scale, accumulate, shard, bucket, k, world):
+        """Piece k of every rank's shard, rank-major: what nsx_hash_grad_expand_f16_bucket writes."""
+        d = (self.dense(he, entry) * scale).reshape(-1)
+        padded = torch.zeros((world * shard,), dtype=torch.float32)
+        padded[:d.numel()] = d
+        piece = padded.view(world, shard)[:, k * bucket:(k + 1) * bucket].reshape(-1)
+        out.copy_((out.float() + piece).half() if accumulate else piece.half())
+
     @staticmethod
     def check_finite_f16(x, found_inf):
         if not torch.isfinite(x.float()).all():
@@ -115,16 +123,17 @@ def _fake_entry(he, seed, n_rows=3, poison=False):
     return {"G": G, "code": code, "window": None, "n_rows": n_rows, "key": seed}
 
 
-def _sharded_worker(rank, world, port, out_dir):
+def _sharded_worker(rank, world, port, out_dir, n_buckets=8, log2_hashmap_size=8):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from nersemble_amd.engine.sharded_adam import ShardedTableAdam
     from nersemble_amd.field_components.hash_ensemble import HashEnsemble, HashEnsembleConfig, TCNNHashEncodingConfig
-    he = HashEnsemble(HashEnsembleConfig(3, TCNNHashEncodingConfig(n_levels=3, log2_hashmap_size=8), True, True), seed=5)
+    he = HashEnsemble(HashEnsembleConfig(3, TCNNHashEncodingConfig(n_levels=3, log2_hashmap_size=log2_hashmap_size), True,
+                                         True), seed=5)
     with torch.no_grad():
         he.tables.mul_(1e3)
-    opt = ShardedTableAdam(he, lr=5e-3, eps=1e-15, world_size=world, rank=rank, ops=_TorchTableOps())
+    opt = ShardedTableAdam(he, lr=5e-3, eps=1e-15, world_size=world, rank=rank, ops=_TorchTableOps(), n_buckets=n_buckets)
     inv = torch.tensor([1.0 / 64.0])
     log = []
     small = torch.full((5,), float(rank + 1))            # stands for the small parameters' gradient bucket
@@ -165,7 +174,8 @@ def _sharded_worker(rank, world, port, out_dir):
         log.append(float(found))
     f16 = he.tables_f16.detach().clone()
     opt.gather_master()
-    torch.save({"log": log, "f16": f16, "master": he.tables.detach().clone(), "shard": opt.shard, "n": opt.n},
+    torch.save({"log": log, "f16": f16, "master": he.tables.detach().clone(), "shard": opt.shard, "n": opt.n,
+                "buckets": opt.n_buckets},
                os.path.join(out_dir, f"s{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
@@ -193,6 +203,26 @@ def test_sharded_table_adam_world2_matches_single_process(tmp_path):
         opt.step()
     d = (he.tables.detach() - r0["master"]).abs().max().item()
     assert d <= 2e-5, d                                   # fp16 summation order inside the reduce-scatter
+
+
+def test_bucketed_exchange_equals_the_one_piece_exchange_bit_for_bit(tmp_path):
+    """The reduce-scatter in pieces (piece k of every rank's shard per collective, the expansion of piece k + 1 beside it,
+    two alternating buffers) against the one-piece exchange of rounds 1-3: the same values reduced per element -- tables,
+    master weights and skip decisions identical bit for bit, also through the poisoned step and the zero-sample rank."""
+    res = {}
+    for k in (1, 4):
+        out = tmp_path / f"k{k}"
+        out.mkdir()
+        mp.spawn(_sharded_worker, args=(2, _free_port(), str(out), k, 10), nprocs=2, join=True)
+        res[k] = [torch.load(out / f"s{r}.pt") for r in range(2)]
+    assert res[1][0]["buckets"] == 1 and res[4][0]["buckets"] == 4
+    assert res[4][0]["shard"] % (4 * 1024) == 0
+    for r in range(2):
+        assert res[1][r]["log"] == res[4][r]["log"] == [0.0, 0.0, 1.0, 0.0, 0.0]
+        # (the shard sizes differ by the alignment unit: compare the table, not the padding)
+        assert torch.equal(res[1][r]["f16"], res[4][r]["f16"])
+        assert torch.equal(res[1][r]["master"], res[4][r]["master"])
+    assert torch.equal(res[4][0]["f16"], res[4][1]["f16"])
 
 
 # ---- strong scaling: one ray batch sliced over the ranks, loss denominators made global -------------------------------
