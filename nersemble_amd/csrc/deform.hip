@@ -23,6 +23,7 @@
 //     through a 4-deep LDS ring by LDS-DMA, each scratch byte read once) -- the only form in which K = #samples fits
 //     MFMA.
 #include "nsx_common.h"
+#include <cstdlib>
 
 namespace nsx {
 
@@ -535,6 +536,125 @@ __global__ __launch_bounds__(NW * 64, 1) void deform_fwd_kernel(DeformArgs A, fl
             for (int d = 0; d < 3; ++d) {
                 const float wd = (w[d] != w[d]) ? F.pn[d] : w[d];          // NaN deformation -> keep the point
                 offsets[b * 3 + d] = wd - F.pn[d];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// forward kernel, round 4: TWO independent 4-wave blocks per CU instead of one 8-wave block.
+// Counters of the 8-wave kernel at 2^20 samples (profiles/pmc/r04_sq_mfma_kernels.json): matrix cores busy 40 % of the
+// cycles, waves parked on s_waitcnt / s_barrier 47 %.  Its 8 waves walk the layers in lock-step -- one barrier per stage
+// -- so the two waves of a SIMD are always in the SAME phase: both in the MFMA stream, then both in the epilogue (cvt / ReLU
+// / bias reload, ~1200 VALU instructions per 256 MFMAs); the matrix cores idle through every epilogue and every barrier.
+// Two blocks that share a CU are not synchronised with each other: a SIMD holds one wave of each, and one block's epilogues
+// and barriers fall into the other's MFMA streams.  LDS: 2 x (2 x 32 KB stage buffers + biases) = 137 KB of 160 KB, which
+// needs stages of <= 32 fragments: the two 44-fragment stages (W0, W4 over the input: 4 M-tiles x 11 K-steps) are copied
+// as K-steps 0-5 (24 fragments) and 6-10 (20), four accumulators live across both; the 8 head fragments share a buffer
+// with the next tile's first stage.  Same MFMAs on the same operands in the same order as deform_fwd_kernel: results are
+// bit-identical.  Weights cross L2 -> CU once per 128 samples instead of 256 (2 KB / sample from L2).
+// ---------------------------------------------------------------------------------------------------------
+constexpr int NWF = 4;
+constexpr int STAGE_F = 32;
+constexpr int S0A_LOCAL = 8;          // the first stage of a tile sits behind the previous tile's head fragments
+
+struct DeformLdsF {
+    f16x8 w[2][STAGE_F * 64];
+    float bias[N_BIAS];
+};
+
+// runs of `run_len` consecutive fragments, `n_runs` of them `run_stride` fragments apart, copied back to back to `buf`
+__device__ __forceinline__ void stage_issue_runs(const f16x8* __restrict__ frags, int first, int run_len, int run_stride,
+                                                 int n_runs, f16x8* buf) {
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t voff = (threadIdx.x & 63u) * 16u;
+    const char* base = reinterpret_cast<const char*>(frags);
+    const int count = run_len * n_runs;
+    for (int f = wave; f < count; f += NWF) {
+        const int src = first + (f / run_len) * run_stride + (f % run_len);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + (size_t)src * 1024 + voff),
+                                         (__attribute__((address_space(3))) void*)(buf + f * 64), 16, 0, 0);
+    }
+}
+
+__global__ __launch_bounds__(NWF * 64, 2) void deform_fwd2_kernel(DeformArgs A, float* __restrict__ offsets, int64_t n_tiles,
+                                                                const int64_t* __restrict__ n_dev) {
+    NSX_DEVICE_COUNT(A.S, n_tiles, 32, n_dev);
+    __shared__ __attribute__((aligned(16))) DeformLdsF L;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int kb = lane >> 5;
+    const int64_t n_groups = (n_tiles + NWF - 1) / NWF;
+    for (int i = threadIdx.x; i < N_BIAS; i += blockDim.x) L.bias[i] = A.bias[i];
+    stage_issue_runs(A.frags, F0, 6, DF_TIN, 4, L.w[0] + S0A_LOCAL * 64);           // W0, K-steps 0..5
+    __syncthreads();
+    int cur = 0;
+    for (int64_t grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {        // all waves iterate together
+        const int64_t tile = grp * NWF + wave;
+        const int64_t b_raw = tile * 32 + (lane & 31);
+        const int64_t b = b_raw < A.S ? b_raw : A.S - 1;
+        lds_cfloat* bias = launder_lds(L.bias);
+        f16x8 x[DF_TIN], h[DF_TW];
+        float pn[3];
+        build_input(A, b, kb, pn, x);
+        f32x16 acc[4];
+        // L0: K-steps 0..5 | 6..10
+        stage_issue_runs(A.frags, F0 + 6, 5, DF_TIN, 4, L.w[cur ^ 1]);
+        acc_init(acc, bias + 0 * DFW, kb);
+        gemm_layer_lds<6>(L.w[cur], S0A_LOCAL, lane, x, acc);
+        stage_flip(cur);
+        stage_issue_runs(A.frags, F1, 32, 32, 1, L.w[cur ^ 1]);
+        gemm_layer_lds<5>(L.w[cur], 0, lane, x + 6, acc);
+        finish_layer<false>(acc, h);
+        stage_flip(cur);
+        // L1..L3
+#pragma unroll 1
+        for (int l = 1; l <= 3; ++l) {
+            if (l < 3) stage_issue_runs(A.frags, l == 1 ? F2 : F3, 32, 32, 1, L.w[cur ^ 1]);
+            else stage_issue_runs(A.frags, F4, 6, DF_TIN, 4, L.w[cur ^ 1]);           // W4 over the input, K-steps 0..5
+            acc_init(acc, bias + l * DFW, kb);
+            gemm_layer_lds<DF_TW>(L.w[cur], 0, lane, h, acc);
+            finish_layer<false>(acc, h);
+            stage_flip(cur);
+        }
+        // L4: cat[input, x] -- three stages, one accumulator
+        stage_issue_runs(A.frags, F4 + 6, 5, DF_TIN, 4, L.w[cur ^ 1]);
+        acc_init(acc, bias + 4 * DFW, kb);
+        gemm_layer_lds<6>(L.w[cur], 0, lane, x, acc);
+        stage_flip(cur);
+        stage_issue_runs(A.frags, F4X, 32, 32, 1, L.w[cur ^ 1]);
+        gemm_layer_lds<5>(L.w[cur], 0, lane, x + 6, acc);
+        stage_flip(cur);
+        stage_issue_runs(A.frags, F5, 32, 32, 1, L.w[cur ^ 1]);
+        gemm_layer_lds<DF_TW>(L.w[cur], 0, lane, h, acc);
+        finish_layer<false>(acc, h);
+        stage_flip(cur);
+        // L5 (+ out_activation ReLU); meanwhile the heads' 8 fragments and the next tile's first stage arrive together
+        stage_issue_runs(A.frags, FH, 8, 8, 1, L.w[cur ^ 1]);
+        stage_issue_runs(A.frags, F0, 6, DF_TIN, 4, L.w[cur ^ 1] + S0A_LOCAL * 64);
+        acc_init(acc, bias + 5 * DFW, kb);
+        gemm_layer_lds<DF_TW>(L.w[cur], 0, lane, h, acc);
+        finish_layer<false>(acc, h);
+        stage_flip(cur);
+        // heads (one M-tile, rows 0..5)
+        f32x16 o = zero16();
+#pragma unroll
+        for (int t = 0; t < DF_TW; ++t) o = mfma(L.w[cur][t * 64 + lane], h[t], o);
+        float own[4], oth[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) own[r] = (float)(half_t)(o[r] + bias[6 * DFW + acc_row(r, kb)]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) oth[r] = __shfl_xor(own[r], 32);
+        // rows 0..3 live on kb = 0, rows 4..7 on kb = 1
+        float rr[3], vv[3];
+        rr[0] = kb ? oth[0] : own[0]; rr[1] = kb ? oth[1] : own[1]; rr[2] = kb ? oth[2] : own[2];
+        vv[0] = kb ? oth[3] : own[3]; vv[1] = kb ? own[0] : oth[0]; vv[2] = kb ? own[1] : oth[1];
+        float w[3];
+        se3_apply(rr, vv, pn, w);
+        if (b_raw < A.S && kb == 0) {
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                const float wd = (w[d] != w[d]) ? pn[d] : w[d];            // NaN deformation -> keep the point
+                offsets[b * 3 + d] = wd - pn[d];
             }
         }
     }
@@ -1147,10 +1267,21 @@ int nsx_deform_fwd(const void* packed, const float* positions, int64_t S, const 
     const float* bias = reinterpret_cast<const float*>(reinterpret_cast<const uint8_t*>(packed) + (size_t)N_FRAGS * 64 * 16);
     fill_args(A, positions, S, aabb_host, code, code_stride, code_slot, window7_host, packed, bias);
     const int64_t n_tiles = (S + 31) / 32;
-    int64_t blocks = (n_tiles + NW - 1) / NW;
-    if (blocks > num_cus()) blocks = num_cus();
-    hipLaunchKernelGGL(deform_fwd_kernel, dim3((unsigned)blocks), dim3(NW * 64), 0, (hipStream_t)stream, A, offsets, n_tiles,
-                       n_device);
+    static const int variant = [] {                      // NSX_DEFORM_FWD=1: the one-block-per-CU kernel of rounds 1-3 (A/B)
+        const char* e = getenv("NSX_DEFORM_FWD");
+        return e ? atoi(e) : 2;
+    }();
+    if (variant == 1) {
+        int64_t blocks = (n_tiles + NW - 1) / NW;
+        if (blocks > num_cus()) blocks = num_cus();
+        hipLaunchKernelGGL(deform_fwd_kernel, dim3((unsigned)blocks), dim3(NW * 64), 0, (hipStream_t)stream, A, offsets,
+                           n_tiles, n_device);
+    } else {
+        int64_t blocks = (n_tiles + NWF - 1) / NWF;
+        if (blocks > 2 * num_cus()) blocks = 2 * num_cus();
+        hipLaunchKernelGGL(deform_fwd2_kernel, dim3((unsigned)blocks), dim3(NWF * 64), 0, (hipStream_t)stream, A, offsets,
+                           n_tiles, n_device);
+    }
     NSX_LAUNCH_CHECK("nsx_deform_fwd launch");
     return NSX_OK;
 }
