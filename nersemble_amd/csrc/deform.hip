@@ -286,6 +286,7 @@ __device__ __forceinline__ u32x2 finish_layer(const f32x16 acc[4], f16x8 h[DF_TW
 // no VGPR round trip) into the buffer that is NOT being read, while the MFMAs of the current stage run; one barrier
 // per stage.  A stage is consumed by 8 x 32 samples, so the weights cross L2 -> CU once per 256 samples. ----
 constexpr int NW = 8;                                       // waves per block (one block per CU, 2 waves per SIMD)
+
 constexpr int STAGE_FRAGS = 44;                             // largest stage: W0 / W4-input (4 M-tiles x 11 K-steps)
 
 struct DeformLds {
@@ -333,23 +334,30 @@ __device__ __forceinline__ void acc_init(f32x16 acc[4], lds_cfloat* bias_lds, in
         }
 }
 
-// acc[mt] += sum_t W_frag(stage-local index local + mt * KT + t) * in[t], fragments read from LDS one K-step ahead
-template <int KT>
+// acc[mt] += sum_t W_frag(stage-local index local + mt * KT + t) * in[t], fragments read from LDS PF K-steps ahead
+// (PF = 1: 8 fragment registers; PF = 2: 12 -- the forward kernel has the registers to spare, the backward chain does not)
+template <int KT, int PF = 1>
 __device__ __forceinline__ void gemm_layer_lds(const f16x8* lds, int local, int lane, const f16x8* in, f32x16 acc[4]) {
     const f16x8* base = lds + (size_t)local * 64 + lane;
-    f16x8 a[4], nx[4];
+    f16x8 a[PF + 1][4];
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) a[mt] = base[(mt * KT) * 64];
+    for (int p = 0; p < PF; ++p)
+        if (p < KT) {
 #pragma unroll
-    for (int t = 0; t < KT; ++t) {
-        if (t + 1 < KT) {
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) nx[mt] = base[(mt * KT + t + 1) * 64];
+            for (int mt = 0; mt < 4; ++mt) a[p][mt] = base[(mt * KT + p) * 64];
         }
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) acc[mt] = mfma(a[mt], in[t], acc[mt]);
+    for (int t = 0; t < KT; ++t) {
+        if (t + PF < KT) {
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) a[mt] = nx[mt];
+            for (int mt = 0; mt < 4; ++mt) a[(t + PF) % (PF + 1)][mt] = base[(mt * KT + t + PF) * 64];
+        }
+        // PF >= 2: pin the software pipeline (the machine scheduler otherwise sinks the reads to 1-2 MFMAs ahead of their
+        // use, and the wave parks on lgkmcnt in front of every other MFMA)
+        if (PF >= 2) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) acc[mt] = mfma(a[t % (PF + 1)][mt], in[t], acc[mt]);
+        if (PF >= 2) __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -410,10 +418,11 @@ __device__ __forceinline__ void store_tile_T(half_t* __restrict__ dst, int lane,
 // A0F: how many K-steps of the layer input are written as transposed tiles (BWD): all 11 (192 rows: positional encoding +
 // warp code), or 4 (64 rows: the positional encoding and the first 19 code columns riding along) when the weight
 // gradients of the code columns are formed through the code SLOT (deform_bwd_kernel<true>).
-template <bool BWD, int A0F = DF_TIN>
+template <bool BWD, int A0F = DF_TIN, int PFW = 1>
 __device__ __forceinline__ void forward_tile(const DeformArgs& A, int64_t b, int lane, Fwd& F, half_t* a_tiles,
                                              DeformLds& L, int& cur, int next_first, int next_count) {
     constexpr int A0_HALFS = ((A0F + 1) / 2) * 32 * 32;         // transposed tiles of the layer input
+    constexpr int PF = BWD ? 1 : PFW;                           // LDS fragment look-ahead of the layer GEMMs
     const int kb = lane >> 5;
     lds_cfloat* bias = launder_lds(L.bias);
     build_input(A, b, kb, F.pn, F.x);
@@ -426,7 +435,7 @@ __device__ __forceinline__ void forward_tile(const DeformArgs& A, int64_t b, int
     // L0
     stage_issue(A.frags, F1, 32, L.w[cur ^ 1]);
     acc_init(acc, bias + 0 * DFW, kb);
-    gemm_layer_lds<DF_TIN>(L.w[cur], 0, lane, F.x, acc);
+    gemm_layer_lds<DF_TIN, PF>(L.w[cur], 0, lane, F.x, acc);
     F.m1 = finish_layer<BWD>(acc, F.h);
     if (BWD) store_tile_T<DF_TW>(a_tiles + A0_HALFS + 0 * DFW * 32, lane, F.h, tsel);
     stage_flip(cur);
@@ -435,7 +444,7 @@ __device__ __forceinline__ void forward_tile(const DeformArgs& A, int64_t b, int
     for (int l = 1; l <= 3; ++l) {
         stage_issue(A.frags, l == 1 ? F2 : (l == 2 ? F3 : F4), l == 3 ? 44 : 32, L.w[cur ^ 1]);
         acc_init(acc, bias + l * DFW, kb);
-        gemm_layer_lds<DF_TW>(L.w[cur], 0, lane, F.h, acc);
+        gemm_layer_lds<DF_TW, PF>(L.w[cur], 0, lane, F.h, acc);
         const u32x2 m = finish_layer<BWD>(acc, F.h);
         if (l == 1) F.m2 = m; else if (l == 2) F.m3 = m; else F.m4 = m;
         if (BWD) store_tile_T<DF_TW>(a_tiles + A0_HALFS + l * DFW * 32, lane, F.h, tsel);
@@ -444,17 +453,17 @@ __device__ __forceinline__ void forward_tile(const DeformArgs& A, int64_t b, int
     // L4: cat[input, x] -- two stages, one accumulator
     stage_issue(A.frags, F4X, 32, L.w[cur ^ 1]);
     acc_init(acc, bias + 4 * DFW, kb);
-    gemm_layer_lds<DF_TIN>(L.w[cur], 0, lane, F.x, acc);
+    gemm_layer_lds<DF_TIN, PF>(L.w[cur], 0, lane, F.x, acc);
     stage_flip(cur);
     stage_issue(A.frags, F5, 40, L.w[cur ^ 1]);
-    gemm_layer_lds<DF_TW>(L.w[cur], 0, lane, F.h, acc);
+    gemm_layer_lds<DF_TW, PF>(L.w[cur], 0, lane, F.h, acc);
     F.m5 = finish_layer<BWD>(acc, F.h);
     if (BWD) store_tile_T<DF_TW>(a_tiles + A0_HALFS + 4 * DFW * 32, lane, F.h, tsel);
     stage_flip(cur);
     // L5 (+ out_activation ReLU) and the heads share one stage (F5 | FH are contiguous)
     stage_issue(A.frags, next_first, next_count, L.w[cur ^ 1]);
     acc_init(acc, bias + 5 * DFW, kb);
-    gemm_layer_lds<DF_TW>(L.w[cur], 0, lane, F.h, acc);
+    gemm_layer_lds<DF_TW, PF>(L.w[cur], 0, lane, F.h, acc);
     F.m6 = finish_layer<BWD>(acc, F.h);
     if (BWD) store_tile_T<DF_TW>(a_tiles + A0_HALFS + 5 * DFW * 32, lane, F.h, tsel);
     // heads (one M-tile, rows 0..5)
@@ -515,6 +524,7 @@ __device__ __forceinline__ void lds_prologue(const DeformArgs& A, DeformLds& L, 
     __syncthreads();
 }
 
+template <int PFW>
 __global__ __launch_bounds__(NW * 64, 1) void deform_fwd_kernel(DeformArgs A, float* __restrict__ offsets, int64_t n_tiles,
                                                               const int64_t* __restrict__ n_dev) {
     NSX_DEVICE_COUNT(A.S, n_tiles, 32, n_dev);
@@ -528,7 +538,7 @@ __global__ __launch_bounds__(NW * 64, 1) void deform_fwd_kernel(DeformArgs A, fl
         const int64_t b_raw = tile * 32 + (lane & 31);
         const int64_t b = b_raw < A.S ? b_raw : A.S - 1;
         Fwd F;
-        forward_tile<false>(A, b, lane, F, nullptr, L, cur, F0, 44);
+        forward_tile<false, DF_TIN, PFW>(A, b, lane, F, nullptr, L, cur, F0, 44);
         float w[3];
         se3_apply(F.r, F.v, F.pn, w);
         if (b_raw < A.S && (lane >> 5) == 0) {
@@ -1267,15 +1277,21 @@ int nsx_deform_fwd(const void* packed, const float* positions, int64_t S, const 
     const float* bias = reinterpret_cast<const float*>(reinterpret_cast<const uint8_t*>(packed) + (size_t)N_FRAGS * 64 * 16);
     fill_args(A, positions, S, aabb_host, code, code_stride, code_slot, window7_host, packed, bias);
     const int64_t n_tiles = (S + 31) / 32;
-    static const int variant = [] {                      // NSX_DEFORM_FWD=1: the one-block-per-CU kernel of rounds 1-3 (A/B)
+    // NSX_DEFORM_FWD (A/B): 1 = one 8-wave block per CU, LDS reads scheduled by the compiler (rounds 1-3); 3 = the same with
+    // the weight fragments read two K-steps ahead, pinned; 2 = two independent 4-wave blocks per CU
+    static const int variant = [] {
         const char* e = getenv("NSX_DEFORM_FWD");
-        return e ? atoi(e) : 2;
+        return e ? atoi(e) : 1;
     }();
-    if (variant == 1) {
+    if (variant != 2) {
         int64_t blocks = (n_tiles + NW - 1) / NW;
         if (blocks > num_cus()) blocks = num_cus();
-        hipLaunchKernelGGL(deform_fwd_kernel, dim3((unsigned)blocks), dim3(NW * 64), 0, (hipStream_t)stream, A, offsets,
-                           n_tiles, n_device);
+        if (variant == 3)
+            hipLaunchKernelGGL(deform_fwd_kernel<2>, dim3((unsigned)blocks), dim3(NW * 64), 0, (hipStream_t)stream, A, offsets,
+                               n_tiles, n_device);
+        else
+            hipLaunchKernelGGL(deform_fwd_kernel<1>, dim3((unsigned)blocks), dim3(NW * 64), 0, (hipStream_t)stream, A, offsets,
+                               n_tiles, n_device);
     } else {
         int64_t blocks = (n_tiles + NWF - 1) / NWF;
         if (blocks > 2 * num_cus()) blocks = 2 * num_cus();

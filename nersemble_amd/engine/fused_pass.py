@@ -59,7 +59,10 @@ class _MainPass(torch.autograd.Function):
         # first-grid phase (HashEnsemble.first_grid_phase), the contiguous copy of grid 0 with a constant code of one
         hash_slot, hash_window = inp.slot, inp.window
         comp = getattr(inp, "first_grid", None)
-        if comp is not None:
+        if comp is not None and comp["width"] >= 2:
+            he.wait_tables()
+            H = comp["width"]                        # window ramp: the first H grids; codes and window as in the full layout
+        elif comp is not None:
             he.wait_tables()
             H, code_h, hash_window = 1, he.first_grid_code(code_h.shape[0]), None      # (slots as in the full layout)
         code_d = code_deform.detach().contiguous()
@@ -133,7 +136,8 @@ class _MainPass(torch.autograd.Function):
                               code_h, code_d, tables_f16)
         ctx.shapes = (tuple(tables_master.shape), [tuple(p.shape) for p in deform_params], code_hash.shape[0])
         ctx.sink = he.grad_sink
-        ctx.hash_args = (H, hash_slot, hash_window, comp is not None)
+        ctx.hash_args = (H, hash_slot, hash_window, comp is not None and comp["width"] == 1)
+        ctx.code_width = code_hash.shape[1]
         # a forward whose backward will add to the sink's G (the sink counts them to know when G is complete)
         ctx.announced = ctx.sink is not None and ctx.needs_input_grad[1]
         if ctx.announced:
@@ -255,6 +259,10 @@ class _MainPass(torch.autograd.Function):
                 n *= d
             sizes.append(n)
         grads = [gp if len(shp) == 1 else gp.view(shp) for gp, shp in zip(torch.split(gparams, sizes), ctx.shapes[1])]
+        if g_code_hash is not None and g_code_hash.shape[1] != ctx.code_width:
+            full = torch.zeros((n_rows, ctx.code_width), dtype=f32, device=dev)        # (compact window-ramp layout)
+            full[:, :H] = g_code_hash
+            g_code_hash = full
         return (None, dtab, d_base, d_head, g_code_hash, gtable, *grads)
 
 

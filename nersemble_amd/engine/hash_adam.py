@@ -42,11 +42,13 @@ class HashTableAdam(torch.optim.Optimizer):
         stream after the last optimizer pass before it calls)."""
         st = self._state()
         if what == "enter":
-            self._compact_state = {"exp_avg": st["exp_avg"][:, :, 0:1].contiguous(),
-                                   "exp_avg_sq": st["exp_avg_sq"][:, :, 0:1].contiguous()}
+            w = self.he._compact["width"]            # grids of the compact copy (1: first-grid phase; 2 ... 16: window ramp)
+            self._compact_state = {"width": w, "exp_avg": st["exp_avg"][:, :, 0:w].contiguous(),
+                                   "exp_avg_sq": st["exp_avg_sq"][:, :, 0:w].contiguous()}
         elif self._compact_state is not None:
-            st["exp_avg"][:, :, 0:1].copy_(self._compact_state["exp_avg"])
-            st["exp_avg_sq"][:, :, 0:1].copy_(self._compact_state["exp_avg_sq"])
+            w = self._compact_state["width"]
+            st["exp_avg"][:, :, 0:w].copy_(self._compact_state["exp_avg"])
+            st["exp_avg_sq"][:, :, 0:w].copy_(self._compact_state["exp_avg_sq"])
             if what == "leave":
                 self._compact_state = None
 
@@ -156,6 +158,20 @@ class HashTableAdam(torch.optim.Optimizer):
         st["step"] += 1
         b1, b2 = group["betas"]
         comp = he._compact
+        if comp is not None and comp["width"] >= 2 and len(entries) == 1 and p.grad is None:
+            # compact window-ramp layout: the first `width` grids alone (HashEnsemble.compact_width); the gradient's codes
+            # and window are the full layout's, the kernel reads their first `width` entries
+            e, cs, w = entries[0], self._compact_state, comp["width"]
+            sparse = 0 < sink.samples_scattered * 80 < self.consume_density_limit * (e["G"].numel() // 8)
+            consume = self.consume_gradient and sparse and sink.is_persistent(e["G"])
+            fn = lib().nsx_adam_hash_factored_consume if consume else lib().nsx_adam_hash_factored
+            check(fn(ptr(e["G"]), e["n_rows"], ptr(e["code"]), e["code"].stride(0), ptr(e["window"]), w, C.byref(he.geom),
+                     ptr(comp["master"]), ptr(cs["exp_avg"]), ptr(cs["exp_avg_sq"]), ptr(comp["f16"]), group["lr"], b1, b2,
+                     group["eps"], st["step"], ptr(inv_scale), ptr(found_inf), stream()), "nsx_adam_hash_factored")
+            if consume:
+                sink.mark_cleared(e["G"])
+            sink.clear()
+            return
         if comp is not None and len(entries) == 1 and p.grad is None and he.is_first_grid_code(entries[0]["code"]):
             # compact first-grid phase: the step of grid 0 alone, on its contiguous copy (H = 1 pass, 0.7 GB instead of
             # 11.7 GB at the reference geometry); the other grids have zero gradient and zero moments -- Adam leaves them

@@ -55,7 +55,7 @@ class _StepState:
     """Everything one step's drivers share: the plan, the argument structs, the workspaces (kept alive until the backward
     has been enqueued), the tensors the factored-gradient sink and the optimizer look at afterwards."""
     __slots__ = ("plan", "sample", "main", "ws_sample", "ws_fwd", "out", "S", "R", "n_rows", "H", "he", "first_grid",
-                 "main_code", "main_window", "keep", "grads")
+                 "main_code", "main_window", "keep", "grads", "code_width")
 
 
 class _GradBuffers:
@@ -133,7 +133,12 @@ class _NativeMain(torch.autograd.Function):
             sink.arrived(group_grads=[gb.d_base, gb.d_head] if sink.on_complete is not None else None)
         check(L.nsx_step_main_bwd(C.byref(m), 2, s), "nsx_step_main_bwd stage 2")
         ctx.st = None                    # the workspaces go back to the allocator with this node
-        return (None, None, gb.d_base, gb.d_head, gb.g_code_hash if need_code else None, gb.gtable, *gb.deform)
+        g_code = gb.g_code_hash if need_code else None
+        if g_code is not None and st.H != st.code_width:
+            full = torch.zeros((st.n_rows, st.code_width), dtype=torch.float32, device=dev)   # (compact window-ramp layout)
+            full[:, :st.H] = g_code
+            g_code = full
+        return (None, None, gb.d_base, gb.d_head, g_code, gb.gtable, *gb.deform)
 
 
 class LazyVectorDict(dict):
@@ -305,7 +310,8 @@ class NativeStep:
         alpha_thre_dev = grid._alpha_threshold(float(cfg.alpha_thre))
         # -- what the HashEnsemble kernels see: the H grids with conditioned codes and the window -- or, in the compact
         # first-grid phase (HashEnsemble.first_grid_phase), the contiguous copy of grid 0 with a constant code of one
-        first = he.first_grid_phase(window_hash)
+        width = he.compact_width(window_hash)
+        first = width == 1
         T = model.time_embedding.weight.shape[0]
         # (the previous step's table optimizer may still be running on its stream: only the HashEnsemble kernel waits for it --
         # the traversal and the deformation field of this step run beside it, as on the per-kernel path)
@@ -315,14 +321,19 @@ class NativeStep:
             sig_codes, sig_window = he.first_grid_code(T), None
             main_code, main_window = he.first_grid_code(n_rows), None
         else:
-            he.leave_first_grid_phase()
-            tables, Hk = he.half_tables(wait=False), he.n_hash_encodings
+            if width >= 2:
+                # window ramp: the first `width` grids as a contiguous copy, codes and window as in the full layout
+                tables, Hk = he.enter_compact(width)["f16"], width
+            else:
+                he.leave_first_grid_phase()
+                tables, Hk = he.half_tables(wait=False), he.n_hash_encodings
             with torch.no_grad():
                 if window_hash is not None and window_hash == 1 and he.disable_initial_hash_ensemble:
-                    key = (T, Hk, str(dev))
+                    key = (T, he.n_hash_encodings, str(dev))
                     sig_codes = self._ones_codes.get(key)
                     if sig_codes is None:
-                        sig_codes = self._ones_codes[key] = torch.ones((T, Hk), dtype=torch.float32, device=dev)
+                        sig_codes = self._ones_codes[key] = torch.ones((T, he.n_hash_encodings), dtype=torch.float32,
+                                                                       device=dev)
                     sig_window = window
                 else:
                     sig_codes, sig_window = he._conditioned(model.time_embedding.weight.detach(), window_hash, dev)
@@ -402,6 +413,7 @@ class NativeStep:
         st.plan, st.sample, st.main, st.ws_sample = plan, a, m, ws_sample
         st.S, st.R, st.n_rows, st.H, st.he, st.first_grid = S, R, n_rows, Hk, he, first
         st.main_code, st.main_window = main_code, main_window
+        st.code_width = int(code_hash.shape[1])
         deform_params = df.ordered_params()
         gkey = (n_rows, Hk, str(dev), plan.grad_bytes)
         st.grads = self._grad_buffers.get(gkey)

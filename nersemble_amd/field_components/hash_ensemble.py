@@ -9,6 +9,7 @@ reference's tcnn layout (``hash_encodings.{c}.params``) through a lossless permu
 """
 from collections import defaultdict
 from dataclasses import dataclass, field
+import math
 from math import ceil
 from typing import Dict, List, Literal, Optional
 
@@ -151,21 +152,51 @@ class HashEnsemble(nn.Module):
     # column 0 of the full layout when the window opens (or the module is evaluated / saved).  Same arithmetic on the
     # same values: the H = 32 kernels at window 1 add exact zeros for the other 31 grids.
     def first_grid_phase(self, window_hash_encodings: Optional[float]) -> bool:
-        return (self.compact_first_grid and self.training and self.disable_initial_hash_ensemble
-                and window_hash_encodings is not None and window_hash_encodings == 1 and self.n_hash_encodings > 1
-                and self.tables.is_cuda and self.grad_sink is not None)
+        return self.compact_width(window_hash_encodings) == 1
 
-    def enter_first_grid_phase(self) -> dict:
+    # ---- compact layouts for the window RAMP (round 4) -------------------------------------------------------------
+    # The schedule switches the grids on one after the other (train_nersemble.py:77-78: window 1 -> H over steps 40 000 ...
+    # 80 000; hash_ensemble.py:133-138: grid h has weight 0 while window <= h).  While ceil(window) <= Hc < H, grids
+    # Hc ... H - 1 have a zero window weight: zero contribution, zero gradient, zero Adam moments -- exactly the argument of
+    # the first-grid phase, for the first Hc grids instead of the first one.  The module then works on a contiguous
+    # [entry][f][Hc] copy (Hc = the next power of two >= ceil(window): 2, 4, 8, 16 -- 1 is the first-grid phase above)
+    # with the H = Hc kernels: 1/16 ... 1/2 of the table bytes in forward, backward and optimizer.  Codes and window are
+    # the full layout's (the kernels read their first Hc entries).  At every doubling -- and when the window passes H / 2
+    # -- the copy and its moments are written back and the next width is cut from the full layout.
+    compact_window_ramp = True
+
+    def compact_width(self, window_hash_encodings: Optional[float]) -> int:
+        """Number of grids of the compact copy this window is trained with; 0 = the full layout."""
+        if not (self.compact_first_grid and self.training and window_hash_encodings is not None
+                and self.n_hash_encodings > 1 and self.tables.is_cuda and self.grad_sink is not None):
+            return 0
+        w = float(window_hash_encodings)
+        if w == 1:
+            return 1 if self.disable_initial_hash_ensemble else 0
+        if not self.compact_window_ramp or w < 1:
+            return 0
+        n = int(math.ceil(w))
+        width = 1 << (n - 1).bit_length()
+        return width if 2 <= width < self.Hp else 0
+
+    def enter_compact(self, width: int) -> dict:
+        """The compact copy of the first ``width`` grids (made from the full layout on first use; a copy of another width
+        is written back first)."""
+        if self._compact is not None and self._compact["width"] != width:
+            self.leave_first_grid_phase()
         if self._compact is None:
             self.wait_tables()
-            master = self.tables.detach()[:, :, 0:1].contiguous()
+            master = self.tables.detach()[:, :, 0:width].contiguous()
             dev = master.device
-            self._compact = {"master": master, "f16": master.to(torch.float16), "geom": self.geom,
+            self._compact = {"width": width, "master": master, "f16": master.to(torch.float16), "geom": self.geom,
                              "codes": {1: torch.ones((1, 1), dtype=torch.float32, device=dev)}}
             self._compact["code"] = self._compact["codes"][1]
             for cb in list(self._compact_listeners):
                 cb("enter")
         return self._compact
+
+    def enter_first_grid_phase(self) -> dict:
+        return self.enter_compact(1)
 
     def first_grid_code(self, n_rows: int) -> torch.Tensor:
         """The phase's code table with ``n_rows`` rows of one: the kernels keep one gradient plane per code row, and the
@@ -179,7 +210,7 @@ class HashEnsemble(nn.Module):
 
     def is_first_grid_code(self, code: torch.Tensor) -> bool:
         c = self._compact
-        return c is not None and any(code.data_ptr() == t.data_ptr() for t in c["codes"].values())
+        return c is not None and c["width"] == 1 and any(code.data_ptr() == t.data_ptr() for t in c["codes"].values())
 
     def zero_slots(self, n: int, device) -> torch.Tensor:
         """int32 zeros [>= n] (the code slot of every sample in the compact phase); grown, never shrunk."""
@@ -194,13 +225,14 @@ class HashEnsemble(nn.Module):
         if c is None:
             return
         self.wait_tables()
+        w = c["width"]
         with torch.no_grad():
-            self.tables.detach()[:, :, 0:1].copy_(c["master"])
+            self.tables.detach()[:, :, 0:w].copy_(c["master"])
             if self.tables_f16.device != self.tables.device:
                 self.tables_f16 = torch.empty_like(self.tables, dtype=torch.float16)
                 self.tables_f16.copy_(self.tables.detach())
             else:
-                self.tables_f16[:, :, 0:1].copy_(c["f16"])
+                self.tables_f16[:, :, 0:w].copy_(c["f16"])
             self._f16_version = (self.tables._version, self.tables.data_ptr())
         for cb in list(self._compact_listeners):
             cb("sync")
@@ -329,7 +361,16 @@ class HashEnsemble(nn.Module):
             "If blend mixing type is chosen, conditioning code needs to have as many dimensions as there are " \
             "hashtables in the encoding"
 
-        if self.first_grid_phase(window_hash_encodings) and in_tensor.is_cuda:
+        width = self.compact_width(window_hash_encodings) if in_tensor.is_cuda else 0
+        if width >= 2:
+            # window ramp: the first `width` grids as a contiguous copy; codes / window are the full layout's
+            c = self.enter_compact(width)
+            self.wait_tables()
+            conditioning_code, window = self._conditioned(conditioning_code, window_hash_encodings, in_tensor.device)
+            sink = self.grad_sink if torch.is_grad_enabled() else None
+            return F.hash_ensemble(in_tensor, self.tables, c["f16"], conditioning_code, width, self.geom,
+                                   code_index=code_index, window=window, sink=sink, precomputed=precomputed)
+        if width == 1:
             c = self.enter_first_grid_phase()
             self.wait_tables()                         # (the optimizer pass of the last step, on its own stream)
             sink = self.grad_sink if torch.is_grad_enabled() else None

@@ -311,9 +311,15 @@ class _HashEnsembleFn(torch.autograd.Function):
         if need_code:
             if dcode_rows is not None:
                 dcode = dcode_rows                       # window chain rule and the per-row sums done by the kernels
+                if dcode.shape[1] != code.shape[1]:      # compact window-ramp layout: the kernel ran with H < code width
+                    full = torch.zeros((n_rows, code.shape[1]), dtype=torch.float32, device=x.device)
+                    full[:, :H] = dcode
+                    dcode = full
             else:
                 if window is not None:
-                    dcode_s = dcode_s * window[None, :]
+                    dcode_s = dcode_s * window[None, :H]
+                if dcode_s.shape[1] != code.shape[1]:
+                    dcode_s = torch.nn.functional.pad(dcode_s, (0, code.shape[1] - dcode_s.shape[1]))
                 if code_index is not None:               # more rows than NSX_MAX_SLOTS: per-sample gradient + index_add_
                     dcode = torch.zeros((ctx.code_rows, H), dtype=torch.float32, device=x.device)
                     dcode.index_add_(0, code_index.to(torch.int64), dcode_s)

@@ -523,8 +523,9 @@ class NeRSembleNGPModel(BaseModel):
         inp.alpha_map = alpha_map.reshape(-1).contiguous() if alpha_map is not None else None
         inp.depth_targets = batch["depth_maps"].to(torch.float32).reshape(-1).contiguous()
         inp.he, inp.window = he, window
-        if he.first_grid_phase(window_hash):
-            inp.first_grid = he.enter_first_grid_phase()
+        width = he.compact_width(window_hash)
+        if width:
+            inp.first_grid = he.enter_compact(width)          # first-grid phase (1) or a window-ramp width (2 ... 16)
         else:
             he.leave_first_grid_phase()
             inp.first_grid = None

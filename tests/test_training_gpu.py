@@ -640,19 +640,26 @@ def test_trainer_prefetches_the_next_batch(cuda):
     assert abs(np.mean(losses[-8:]) - np.mean(losses0[-8:])) < 0.25 * np.mean(losses0[-8:])
 
 
-def _compact_run(compact, steps, window_hash=None, seed=31):
+def _compact_run(compact, steps, window_hash=None, seed=31, ramp=True, window_at_step0=None):
     from nersemble_amd.workloads import build_workload
     torch.manual_seed(seed)
     trainer, data, _ = build_workload("p030_h16", device="cuda:0", small=True, n_rays=512, compact_first_grid=compact,
                                       window_hash=window_hash)
     he = trainer.model.field.hash_ensemble
+    he.compact_window_ramp = ramp
+    if window_at_step0 is not None:
+        # a schedule whose value at step 0 is `window_at_step0` and that barely moves over a few steps
+        sch = trainer.model.sched_window_hash_encodings
+        span = 100000.0
+        sch.begin_step = -(window_at_step0 - 1.0) / (he.n_hash_encodings - 1.0) * span
+        sch.end_step = sch.begin_step + span
     init = he.tables.detach().clone()
     losses, in_phase, first = [], [], None
     for step in range(steps):
         torch.manual_seed(500 + step)                                   # same near-plane jitter on both sides
         loss, loss_dict, metrics = trainer.train_iteration(step, *data.next_train(step))
         losses.append(loss.item())
-        in_phase.append(he._compact is not None)
+        in_phase.append(he._compact["width"] if he._compact is not None else 0)
         if step == 0:
             first = {k: v.item() for k, v in loss_dict.items()}
             trainer.consolidate()
@@ -702,9 +709,9 @@ def test_compact_first_grid_phase_is_the_same_training(cuda):
 def test_compact_phase_ends_when_the_window_opens(cuda):
     """Window schedule (4, 12): one grid until step 4, then the window grows -- the compact copy is written back into
     column 0 of the full layout and training continues there."""
-    t_c, init, l_c, phase_c, _ = _compact_run(True, 10, window_hash=(4, 12))
+    t_c, init, l_c, phase_c, _ = _compact_run(True, 10, window_hash=(4, 12), ramp=False)
     t_f, _, l_f, phase_f, _ = _compact_run(False, 10, window_hash=(4, 12))
-    assert phase_c == [s <= 4 for s in range(10)], phase_c
+    assert phase_c == [int(s <= 4) for s in range(10)], phase_c
     assert not any(phase_f)
     assert np.allclose(l_c[:5], l_f[:5], rtol=2e-3), (l_c, l_f)
     assert np.allclose(l_c, l_f, rtol=5e-2), (l_c, l_f)
@@ -712,6 +719,55 @@ def test_compact_phase_ends_when_the_window_opens(cuda):
     b = t_f.model.field.hash_ensemble
     a.wait_tables(), b.wait_tables()
     assert (a.tables.detach()[:, :, 1] != init[:, :, 1]).any()               # the second grid trains once it is on
+
+
+@pytest.mark.parametrize("window,width", [(1.5, 2), (3.5, 4), (6.0, 8)])
+def test_compact_window_ramp_widths_are_the_same_training(window, width, cuda):
+    """Window ramp (train_nersemble.py:77-78; hash_ensemble.py:133-138): while ceil(window) <= width < H the grids
+    width ... H - 1 have zero window weight, zero gradient and zero Adam moments; the module trains a contiguous copy of the
+    first `width` grids with the H = width kernels.  Against the full layout at the same window: every loss term of the
+    first step bit for bit, the tables after one optimizer step up to the order of the atomics -- the grids beyond the
+    width untouched --, the time codes' gradient in place (their first `width` columns), the same run afterwards."""
+    t_c, init, l_c, phase_c, f_c = _compact_run(True, 6, window_at_step0=window)
+    t_f, _, l_f, phase_f, f_f = _compact_run(False, 6, window_at_step0=window)
+    assert phase_c == [width] * 6 and not any(phase_f), (phase_c, phase_f)
+    tab_c, tab_f = f_c.pop("tables"), f_f.pop("tables")
+    assert f_c == f_f, (f_c, f_f)                                            # every loss term of step 0: bit for bit
+    d = (tab_c - tab_f).abs()
+    assert (d <= 1e-5).float().mean().item() >= 0.9995
+    assert torch.equal(tab_c[:, :, width:], init[:, :, width:])              # Adam does not move a grid that is off
+    assert (tab_c[:, :, width - 1] != init[:, :, width - 1]).any()           # the last grid of the width trains
+    assert np.allclose(l_c[:4], l_f[:4], rtol=2e-3), (l_c, l_f)
+    ga = t_c.model.time_embedding.weight.grad
+    gb = t_f.model.time_embedding.weight.grad
+    assert ga is not None and gb is not None and ga.shape == gb.shape
+    assert bool((ga[:, width:] == 0).all()) and ga[:, :width].abs().max().item() > 0
+    # checkpoints see the trained grids and their moments
+    he = t_c.model.field.hash_ensemble
+    st = t_c.state_dict()["optimizers"]["fields"]["state"][1]
+    st_f = t_f.state_dict()["optimizers"]["fields"]["state"][1]
+    assert int(st["step"]) == int(st_f["step"]) == 6
+    a, b = st["exp_avg_sq"], st_f["exp_avg_sq"]
+    assert abs(a.abs().sum().item() - b.abs().sum().item()) <= 0.05 * b.abs().sum().item()
+    assert torch.equal(he.tables.detach()[:, :, :width], he._compact["master"])
+
+
+def test_compact_layout_is_handed_over_at_every_doubling(cuda):
+    """A schedule that walks the window from 1 to 8.5 in 17 steps: the compact copy goes 1 -> 2 -> 4 -> 8 grids and ends
+    when the window passes H / 2 (H = 16); every hand-over writes the trained grids and their moments back and cuts the
+    next width from the full layout.  The run follows the full-layout run."""
+    t_c, init, l_c, phase_c, _ = _compact_run(True, 19, window_hash=(2, 32))
+    t_f, _, l_f, phase_f, _ = _compact_run(False, 19, window_hash=(2, 32))
+    want = [1, 1, 1] + [2, 2] + [4] * 4 + [8] * 8 + [0, 0]        # window(step) = 1 + (step - 2) / 2
+    assert phase_c == want, phase_c
+    assert not any(phase_f)
+    assert np.allclose(l_c[:4], l_f[:4], rtol=2e-3), (l_c, l_f)
+    assert np.allclose(l_c, l_f, rtol=5e-2), (l_c, l_f)
+    a, b = t_c.model.field.hash_ensemble, t_f.model.field.hash_ensemble
+    a.wait_tables(), b.wait_tables()
+    for h in (0, 1, 3, 7, 8):                                       # every grid that was on has moved, in both runs
+        assert (a.tables.detach()[:, :, h] != init[:, :, h]).any() and (b.tables.detach()[:, :, h] != init[:, :, h]).any()
+    assert torch.equal(a.tables.detach()[:, :, 10:], init[:, :, 10:])
 
 
 def test_fused_pass_takes_the_dense_configuration(cuda):
