@@ -735,13 +735,15 @@ def test_compact_window_ramp_widths_are_the_same_training(window, width, cuda):
     assert f_c == f_f, (f_c, f_f)                                            # every loss term of step 0: bit for bit
     d = (tab_c - tab_f).abs()
     assert (d <= 1e-5).float().mean().item() >= 0.9995
-    assert torch.equal(tab_c[:, :, width:], init[:, :, width:])              # Adam does not move a grid that is off
-    assert (tab_c[:, :, width - 1] != init[:, :, width - 1]).any()           # the last grid of the width trains
+    n_on = int(np.ceil(window))                                              # grids with a non-zero window weight
+    assert torch.equal(tab_c[:, :, n_on:], init[:, :, n_on:])                # Adam does not move a grid that is off
+    assert torch.equal(tab_f[:, :, n_on:], init[:, :, n_on:])
+    assert (tab_c[:, :, n_on - 1] != init[:, :, n_on - 1]).any()             # the last grid that is on trains
     assert np.allclose(l_c[:4], l_f[:4], rtol=2e-3), (l_c, l_f)
     ga = t_c.model.time_embedding.weight.grad
     gb = t_f.model.time_embedding.weight.grad
     assert ga is not None and gb is not None and ga.shape == gb.shape
-    assert bool((ga[:, width:] == 0).all()) and ga[:, :width].abs().max().item() > 0
+    assert bool((ga[:, n_on:] == 0).all()) and ga[:, :n_on].abs().max().item() > 0
     # checkpoints see the trained grids and their moments
     he = t_c.model.field.hash_ensemble
     st = t_c.state_dict()["optimizers"]["fields"]["state"][1]

@@ -27,11 +27,19 @@ def main():
     ap.add_argument("--settle-at", type=int, default=600)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--plain", action="store_true", help="only run the timed loop (for use under rocprofv3)")
+    ap.add_argument("--compact", action="store_true", help="the trainer's default: compact first-grid phase")
+    ap.add_argument("--datamanager", action="store_true",
+                    help="draw the batches inside the loop through NeRSembleVanillaDataManager.next_train (bench.py --with-datamanager)")
     a = ap.parse_args()
     from nersemble_amd.workloads import build_workload
     torch.manual_seed(19980801)
-    trainer, data, info = build_workload(a.workload, device="cuda:0", compact_first_grid=False,
+    trainer, data, info = build_workload(a.workload, device="cuda:0", compact_first_grid=a.compact,
                                          window_hash=(0, 1) if a.window_open else None)
+    dm = None
+    if a.datamanager:
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from bench import build_datamanager
+        dm, _ = build_datamanager(data, "cuda:0")
     reserve = torch.empty(24 * 2 ** 30, dtype=torch.uint8, device="cuda:0")
     del reserve
     step = 0
@@ -39,14 +47,20 @@ def main():
         trainer.train_iteration(step, *data.next_train(step))
         step += 1
     n = a.steps
-    batches = [data.next_train(step + i) for i in range(3 * n + 1)]
+    batches = [data.next_train(step + i) for i in range(3 * n + 1)] if dm is None else None
     gc.collect()
     gc.freeze()
     gc.disable()
+    held = {"next": dm.next_train(step) if dm is not None else None}
 
     def loop(first):
         for i in range(first, first + n):
-            trainer.train_iteration(step + i, *batches[i], next_ray_bundle=batches[i + 1][0])
+            if dm is None:
+                cur, ahead = batches[i], batches[i + 1]
+            else:
+                cur = held["next"]
+                ahead = held["next"] = dm.next_train(step + i + 1)
+            trainer.train_iteration(step + i, *cur, next_ray_bundle=ahead[0])
 
     torch.cuda.synchronize()
     t0 = time.perf_counter()
