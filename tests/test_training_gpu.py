@@ -721,7 +721,7 @@ def test_compact_phase_ends_when_the_window_opens(cuda):
     assert (a.tables.detach()[:, :, 1] != init[:, :, 1]).any()               # the second grid trains once it is on
 
 
-@pytest.mark.parametrize("window,width", [(1.5, 2), (3.5, 4), (6.0, 8)])
+@pytest.mark.parametrize("window,width", [(1.5, 2), (3.5, 4), (5.5, 8)])
 def test_compact_window_ramp_widths_are_the_same_training(window, width, cuda):
     """Window ramp (train_nersemble.py:77-78; hash_ensemble.py:133-138): while ceil(window) <= width < H the grids
     width ... H - 1 have zero window weight, zero gradient and zero Adam moments; the module trains a contiguous copy of the

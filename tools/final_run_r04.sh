@@ -21,6 +21,10 @@ for k in ("first_grid_phase","open_window","with_datamanager"):
     v=d.get(k,{}); print(k, v.get("ms_per_step"), (v.get("steady_state") or {}).get("ms_per_step"), v.get("datamanager"), v.get("error"))
 P
 else
+python -m pytest tests/test_training_gpu.py -q -k "ramp or handed" 2>&1 | tail -2 > $out/ramp_tests.txt
+DM="python bench.py --with-datamanager --steps 20 --warmup 5 --no-cpu-baseline --no-kernels-alone --no-first-grid-phase --no-open-window --no-with-datamanager"
+$DM > $out/bench_with_datamanager.json 2>/dev/null
+$DM --compact-first-grid > $out/bench_with_datamanager_compact.json 2>/dev/null
 tl=$out/tl; mkdir -p $tl
 for mode in full compact datamanager; do
   flags=""; [ $mode = compact ] && flags="--compact"; [ $mode = datamanager ] && flags="--compact --datamanager"
@@ -42,11 +46,12 @@ for w in "-7000 80000" "-44000 80000"; do
   $B --window-hash $w --compact-first-grid > $out/ramp_compact_$n.json 2>/dev/null
   $B --window-hash $w > $out/ramp_full_$n.json 2>/dev/null
 done
+cat $out/ramp_tests.txt
 python - <<'P'
 import json, glob
-for f in sorted(glob.glob("gpurun_out/final_r04/ramp_*.json")) + ["gpurun_out/final_r04/dp2_weak.json"]:
+for f in sorted(glob.glob("gpurun_out/final_r04/ramp_*.json")) + sorted(glob.glob("gpurun_out/final_r04/bench_with_datamanager*.json")) + ["gpurun_out/final_r04/dp2_weak.json"]:
     try:
-        d=json.loads([l for l in open(f) if l.startswith("{")][-1]); print(f, round(d["ms_per_step"],3), (d.get("steady_state") or {}).get("ms_per_step"), d.get("comm"))
+        d=json.loads([l for l in open(f) if l.startswith("{")][-1]); print(f, round(d["ms_per_step"],3), (d.get("steady_state") or {}).get("ms_per_step"), d.get("comm"), {k: v for k, v in (d.get("datamanager") or {}).items() if k.startswith("next_train_host")})
     except Exception as e: print(f, "ERR", e)
 P
 cat $out/config_lines.txt | tail -5; cat $out/host_sections_compact.txt | head -8; tail -3 $out/eval_bench.txt
