@@ -395,15 +395,20 @@ __device__ __forceinline__ TSel make_tsel(int lane) {
     return s;
 }
 
+// one transposed tile in registers: o0 | o1 = the two K-steps (8 samples each) of lane = column
+__device__ __forceinline__ void transpose_pair(const f16x8& f_lo, const f16x8* f_hi, const TSel& sel, u32x4& o0, u32x4& o1) {
+    f32x16 d = mfma(f_lo, sel.lo, zero16());
+    if (f_hi) d = mfma(*f_hi, sel.hi, d);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { o0[r] = cvt_pk(d[2 * r], d[2 * r + 1]); o1[r] = cvt_pk(d[8 + 2 * r], d[9 + 2 * r]); }
+}
+
 template <int NF>
 __device__ __forceinline__ void store_tile_T(half_t* __restrict__ dst, int lane, const f16x8* frags, const TSel& sel) {
 #pragma unroll
     for (int p = 0; p < (NF + 1) / 2; ++p) {
-        f32x16 d = mfma(frags[2 * p], sel.lo, zero16());
-        if (2 * p + 1 < NF) d = mfma(frags[2 * p + 1], sel.hi, d);
         u32x4 o0, o1;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { o0[r] = cvt_pk(d[2 * r], d[2 * r + 1]); o1[r] = cvt_pk(d[8 + 2 * r], d[9 + 2 * r]); }
+        transpose_pair(frags[2 * p], (2 * p + 1 < NF) ? &frags[2 * p + 1] : nullptr, sel, o0, o1);
         // tile p = [2 K-steps][64 lanes][8 halfs]: each store instruction writes one contiguous KB, and the weight-gradient
         // kernel can copy the tile into LDS linearly and read it back conflict-free as MFMA operand fragments
         u32x4* out = reinterpret_cast<u32x4*>(dst + (size_t)p * 1024 + (size_t)lane * 8);
@@ -418,7 +423,8 @@ __device__ __forceinline__ void store_tile_T(half_t* __restrict__ dst, int lane,
 // A0F: how many K-steps of the layer input are written as transposed tiles (BWD): all 11 (192 rows: positional encoding +
 // warp code), or 4 (64 rows: the positional encoding and the first 19 code columns riding along) when the weight
 // gradients of the code columns are formed through the code SLOT (deform_bwd_kernel<true>).
-template <bool BWD, int A0F = DF_TIN, int PFW = 1>
+// A6T: write the transposed tile of the heads' input (a6); the SLOTS chain kernel forms the head gradients itself
+template <bool BWD, int A0F = DF_TIN, int PFW = 1, bool A6T = true>
 __device__ __forceinline__ void forward_tile(const DeformArgs& A, int64_t b, int lane, Fwd& F, half_t* a_tiles,
                                              DeformLds& L, int& cur, int next_first, int next_count) {
     constexpr int A0_HALFS = ((A0F + 1) / 2) * 32 * 32;         // transposed tiles of the layer input
@@ -465,7 +471,7 @@ __device__ __forceinline__ void forward_tile(const DeformArgs& A, int64_t b, int
     acc_init(acc, bias + 5 * DFW, kb);
     gemm_layer_lds<DF_TW, PF>(L.w[cur], 0, lane, F.h, acc);
     F.m6 = finish_layer<BWD>(acc, F.h);
-    if (BWD) store_tile_T<DF_TW>(a_tiles + A0_HALFS + 5 * DFW * 32, lane, F.h, tsel);
+    if (BWD && A6T) store_tile_T<DF_TW>(a_tiles + A0_HALFS + 5 * DFW * 32, lane, F.h, tsel);
     // heads (one M-tile, rows 0..5)
     f32x16 o = zero16();
 #pragma unroll
@@ -675,7 +681,7 @@ __global__ __launch_bounds__(NWF * 64, 2) void deform_fwd2_kernel(DeformArgs A, 
 // ---------------------------------------------------------------------------------------------------------
 // per sample-tile scratch layout (halfs), the input tile first:
 //   SLOTS = false: a0 [192][32] | a1..a6 [6][128][32] | dZ0..dZ5 [6][128][32] | dZh [32][32] | dC [128][32]     118 KB
-//   SLOTS = true : a0 [ 64][32] | a1..a6               | dZ0..dZ5               | dZh                             102 KB
+//   SLOTS = true : a0 [ 64][32] | a1..a5 [5][128][32] | dZ0..dZ5                                                  92 KB
 // SLOTS: every sample's warp code is a row of a small table (the <= 24 time codes of a batch), so everything that touches
 // the code columns factors through the slot, exactly as the hash tables' gradient does:
 //   dW0[:, code] = sum_s dZ0[:, s] code[slot_s]^T = R0 code,   R0[n][r] = sum_{s: slot_s = r} dZ0[n][s]   (dW4 likewise)
@@ -683,15 +689,21 @@ __global__ __launch_bounds__(NWF * 64, 2) void deform_fwd2_kernel(DeformArgs A, 
 // The chain kernel then neither forms the per-sample code gradient (two of its 14 weight stages) nor writes it and the
 // code rows of a0 (16 of 118 KB per tile); the weight-gradient kernel accumulates R0 / R4 with a one-hot operand next to
 // the positional-encoding columns, and deform_code_expand_kernel finishes the three small products.
+// SLOTS (round 4) also forms the HEAD gradients (dWr, dWv, dbr, dbv = dZh a6^T and the row sums of dZh: 774 numbers) inside
+// the chain kernel, where a6 and dZh of the tile are in registers: 18 matrix instructions per tile (the transposes of the
+// two operands + the product; the chain has ~750) into transient accumulators whose 6 useful rows are added to a 3-KB LDS
+// array of the block, written out once per block and summed by deform_code_expand_kernel.  Neither the a6 tile (8 KB) nor
+// dZh (2 KB) crosses HBM any more: 102 -> 92 KB written per tile, 111 -> 101 KB read by the weight-gradient kernel.
 template <bool SLOTS>
 struct Lay {
     static constexpr int A0_FRAGS = SLOTS ? 4 : DF_TIN;
+    static constexpr int N_A = SLOTS ? 5 : 6;                                      // transposed activation tiles a1..
     static constexpr int64_t TILE_A = (SLOTS ? 64 : 192) * 32;
-    static constexpr int64_t TILE_DZ = TILE_A + 6 * DFW * 32;
+    static constexpr int64_t TILE_DZ = TILE_A + N_A * DFW * 32;
     static constexpr int64_t TILE_DZH = TILE_DZ + 6 * DFW * 32;
-    static constexpr int64_t TILE_DC = TILE_DZH + 32 * 32;
-    static constexpr int64_t TILE_HALFS = SLOTS ? TILE_DC : TILE_DC + DFW * 32;    // 52 224 / 60 416 halfs per 32 samples
-    static constexpr int TILE_KB = (int)(TILE_HALFS * 2 / 1024);                   // 102 / 118
+    static constexpr int64_t TILE_DC = TILE_DZH + (SLOTS ? 0 : 32 * 32);
+    static constexpr int64_t TILE_HALFS = SLOTS ? TILE_DC : TILE_DC + DFW * 32;    // 47 104 / 60 416 halfs per 32 samples
+    static constexpr int TILE_KB = (int)(TILE_HALFS * 2 / 1024);                   // 92 / 118
     static constexpr int KB_A0 = 0, KB_A = (int)(TILE_A * 2 / 1024), KB_DZ = (int)(TILE_DZ * 2 / 1024);
     static constexpr int KB_DZH = (int)(TILE_DZH * 2 / 1024), KB_DC = (int)(TILE_DC * 2 / 1024);
     static_assert(TILE_HALFS * 2 % 1024 == 0 && TILE_A * 2 % 1024 == 0 && TILE_DZ * 2 % 1024 == 0 &&
@@ -700,6 +712,11 @@ struct Lay {
 // R0 | R4: [2][128 neurons][128 code rows] fp32 at the head of the scratch buffer (SLOTS; zeroed by the chain kernel)
 constexpr int64_t SLOT_SUMS_FLOATS = 2 * DFW * 128;
 constexpr int64_t SLOT_SUMS_BYTES = SLOT_SUMS_FLOATS * 4;
+// head gradients of one chain block, in parameter order: Wr [3][128] | br [3] | Wv [3][128] | bv [3] (= P_WR .. P_TOTAL)
+constexpr int HEAD_PARAMS = P_TOTAL - P_WR;
+constexpr int HEAD_STRIDE = (HEAD_PARAMS + 63) / 64 * 64;
+static_assert(HEAD_PARAMS == 2 * (3 * DFW + 3) && P_BR == P_WR + 3 * DFW && P_WV == P_BR + 3 && P_BV == P_WV + 3 * DFW,
+              "the head parameters are one contiguous run");
 
 // dZ = dA * relu'(a): accumulators -> packed halfs, AND-ed with 0xFFFF per positive unit (mask layout: finish_layer)
 __device__ __forceinline__ void mask_pack(const f32x16 d[4], u32x2 mask, f16x8 dz[DF_TW]) {
@@ -722,7 +739,8 @@ __global__ __launch_bounds__(NW * 64, 1) void deform_bwd_kernel(DeformArgs A, co
                                                               half_t* __restrict__ scratch, int64_t n_tiles,
                                                               float* __restrict__ gcode_samples,
                                                               const int64_t* __restrict__ n_dev,
-                                                              float* __restrict__ slot_sums) {
+                                                              float* __restrict__ slot_sums,
+                                                              float* __restrict__ head_partials) {
     using LY = Lay<SLOTS>;
     constexpr int64_t TILE_HALFS = LY::TILE_HALFS, TILE_DZ = LY::TILE_DZ, TILE_DZH = LY::TILE_DZH, TILE_DC = LY::TILE_DC;
     if (SLOTS) {      // the per-slot sums the NEXT kernel adds to: cleared here (also when no sample is left to process)
@@ -731,6 +749,10 @@ __global__ __launch_bounds__(NW * 64, 1) void deform_bwd_kernel(DeformArgs A, co
     }
     NSX_DEVICE_COUNT(A.S, n_tiles, 32, n_dev);
     __shared__ __attribute__((aligned(16))) DeformLds L;
+    __shared__ float head_sums[SLOTS ? HEAD_STRIDE : 1];
+    if (SLOTS) {
+        for (int i = threadIdx.x; i < HEAD_STRIDE; i += blockDim.x) head_sums[i] = 0.f;
+    }
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int n = lane & 31, kb = lane >> 5;
     const int64_t n_groups = (n_tiles + NW - 1) / NW;
@@ -746,7 +768,7 @@ __global__ __launch_bounds__(NW * 64, 1) void deform_bwd_kernel(DeformArgs A, co
         // waves past the last tile still walk the layers (barriers) but write into the block-private dummy tile
         half_t* T = scratch + (tile_ok ? tile : n_tiles + (int64_t)blockIdx.x * NW + wave) * TILE_HALFS;
         Fwd F;
-        forward_tile<true, LY::A0_FRAGS>(A, b, lane, F, T, L, cur, BH, 36);
+        forward_tile<true, LY::A0_FRAGS, 1, !SLOTS>(A, b, lane, F, T, L, cur, BH, 36);
         // ---- SE(3) backward (fp32): g = dL/dwarped ----
         float g[3] = {0.f, 0.f, 0.f};
         if (valid) { g[0] = goff[b * 3]; g[1] = goff[b * 3 + 1]; g[2] = goff[b * 3 + 2]; }
@@ -783,7 +805,43 @@ __global__ __launch_bounds__(NW * 64, 1) void deform_bwd_kernel(DeformArgs A, co
         if (kb == 0) { dzh[0] = (half_t)dr[0]; dzh[1] = (half_t)dr[1]; dzh[2] = (half_t)dr[2]; dzh[3] = (half_t)dv[0]; }
         else         { dzh[0] = (half_t)dv[1]; dzh[1] = (half_t)dv[2]; }
         const TSel tsel = make_tsel(lane);
-        store_tile_T<1>(T + TILE_DZH, lane, &dzh, tsel);       // head rows (only columns < 16 are populated)
+        if constexpr (!SLOTS) store_tile_T<1>(T + TILE_DZH, lane, &dzh, tsel);   // head rows (only columns < 16 are populated)
+        else {
+            // head gradients of this tile: dWh[rho][k] += sum_s dZh[rho][s] a6[k][s], dbh[rho] += sum_s dZh[rho][s].
+            // X = transposed dZh (lane = head column, 8 samples per K-step), Y = transposed a6 tiles (lane = neuron column):
+            // accumulator element r of lane (i, half) is head column acc_row(r, half) x neuron tile_neuron_chain(p, i);
+            // head column c holds head row tile_neuron_chain(0, c), so rows 0..5 are elements r = 0..5 of the half-0 lanes.
+            f16x8 dzv = dzh;
+            if (!valid) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) dzv[j] = (half_t)0.f;
+            }
+            u32x4 x0, x1;
+            transpose_pair(dzv, nullptr, tsel, x0, x1);
+            const f16x8 X0 = __builtin_bit_cast(f16x8, x0), X1 = __builtin_bit_cast(f16x8, x1);
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                u32x4 y0, y1;
+                transpose_pair(F.h[2 * p], &F.h[2 * p + 1], tsel, y0, y1);
+                f32x16 hw = mfma(X0, __builtin_bit_cast(f16x8, y0), zero16());
+                hw = mfma(X1, __builtin_bit_cast(f16x8, y1), hw);
+                if (kb == 0) {
+                    const int col = tile_neuron_chain(p, n);
+#pragma unroll
+                    for (int r = 0; r < 6; ++r)
+                        atomicAdd(&head_sums[(r < 3 ? r * DFW : 3 * DFW + 3 + (r - 3) * DFW) + col], hw[r]);
+                }
+            }
+            f16x8 ones;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ones[j] = (half_t)1.f;
+            f32x16 hb = mfma(X0, ones, zero16());
+            hb = mfma(X1, ones, hb);
+            if (lane == 0) {
+#pragma unroll
+                for (int r = 0; r < 6; ++r) atomicAdd(&head_sums[r < 3 ? 3 * DFW + r : 2 * (3 * DFW) + 3 + (r - 3)], hb[r]);
+            }
+        }
         // ---- chain (stage BH | B5 is resident in L.w[cur]) ----
         f32x16 d[4];
         f16x8 dz[DF_TW];
@@ -859,6 +917,11 @@ __global__ __launch_bounds__(NW * 64, 1) void deform_bwd_kernel(DeformArgs A, co
         }
         stage_flip(cur);
     }
+    if constexpr (SLOTS) {          // every launched block leaves its sums (zeros if it had no tile): the reducer adds gridDim.x rows
+        __syncthreads();
+        for (int i = threadIdx.x; i < HEAD_STRIDE; i += blockDim.x)
+            head_partials[(int64_t)blockIdx.x * HEAD_STRIDE + i] = head_sums[i];
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -873,7 +936,8 @@ __global__ __launch_bounds__(NW * 64, 1) void deform_bwd_kernel(DeformArgs A, co
 //   type 0: dW0 = dZ0 a0^T, db0 | dW4[:, :173] = dZ4 a0^T, db4       stage = dZ0 dZ4 a0            (28 KB)
 //   type 1: dW1 = dZ1 a1^T, db1 | dW2 = dZ2 a2^T, db2                stage = dZ1 a1 dZ2 a2         (32 KB)
 //   type 2: dW3 = dZ3 a3^T, db3 | dW4[:, 173:] = dZ4 a4^T            stage = dZ3 a3 dZ4 a4         (32 KB)
-//   type 3: dW5 = dZ5 a5^T, db5 | heads: dZh a6^T, dbr, dbv          stage = dZ5 a5 dZh a6         (26 KB)
+//   type 3: dW5 = dZ5 a5^T, db5 | heads: dZh a6^T, dbr, dbv          stage = dZ5 a5 dZh a6         (26 KB; SLOTS: dZ5 a5,
+//           16 KB -- the chain kernel forms the head gradients)
 //   type 4: code table: onehot(slot) dC^T                            stage = dC + the 32 slots     ( 9 KB)
 // SLOTS (Lay<true>): type 0 reads dZ0, dZ4, the 64-row a0 tile and the tile's 32 slots (21 KB) and accumulates, next to the
 // positional-encoding columns of dW0 / dW4, the per-slot sums R0 / R4 = dZ onehot(slot)^T; type 4 does not exist.
@@ -896,7 +960,7 @@ __device__ __forceinline__ int wg_piece_src(int type, int q, int& dst_kb, bool w
     switch (type) {
         case 0: total = SLOTS ? 21 : 28; break;
         case 1: case 2: total = 32; break;
-        case 3: total = 26; break;
+        case 3: total = SLOTS ? 16 : 26; break;
         default: total = with_slots ? 9 : 8; break;
     }
     q = q % total;
@@ -935,7 +999,7 @@ __device__ __forceinline__ WgRole wg_role(int type, int wave, int n_code_rows) {
         case 2: r.x_kb = 16 * hi + 2 * (wave & 3); r.y_kb = 8 + 16 * hi; r.n_y = 4; r.bias = hi ? 0 : 1; r.job = hi ? 5 : 3; break;
         case 3:
             if (!hi) { r.x_kb = 2 * wave; r.y_kb = 8; r.n_y = 4; r.bias = 1; r.job = 6; }
-            else if (wave == 4) { r.x_kb = 16; r.y_kb = 18; r.n_y = 4; r.bias = 1; r.x_tile = 0; r.job = 7; }
+            else if (wave == 4 && !SLOTS) { r.x_kb = 16; r.y_kb = 18; r.n_y = 4; r.bias = 1; r.x_tile = 0; r.job = 7; }
             break;
         default:
             if (!hi && 32 * wave < n_code_rows) { r.x_kb = -1; r.y_kb = 0; r.n_y = 4; r.job = 8; }
@@ -1156,6 +1220,7 @@ __global__ __launch_bounds__(256) void deform_code_expand_kernel(const float* __
                                                                  float* __restrict__ grad_params,
                                                                  float* __restrict__ grad_code,
                                                                  const float* __restrict__ partials, int n_chunks,
+                                                                 const float* __restrict__ head_partials, int n_chain_blocks,
                                                                  int64_t n_tiles, int64_t S,
                                                                  const int64_t* __restrict__ n_dev) {
     __shared__ float red[256];
@@ -1176,7 +1241,11 @@ __global__ __launch_bounds__(256) void deform_code_expand_kernel(const float* __
         else if (idx >= P_W4 && idx < P_B4) col = (idx - P_W4) % DF_W4;
         if (col >= DF_PE && col < DF_IN) return;
         float acc = 0.f;
-        for (int c = 0; c < n_valid; ++c) acc += partials[(int64_t)c * P_TOTAL + idx];
+        if (idx >= P_WR) {                                   // the heads: one row per block of the chain kernel
+            for (int c = 0; c < n_chain_blocks; ++c) acc += head_partials[(int64_t)c * HEAD_STRIDE + (idx - P_WR)];
+        } else {
+            for (int c = 0; c < n_valid; ++c) acc += partials[(int64_t)c * P_TOTAL + idx];
+        }
         grad_params[idx] += acc;
         return;
     }
@@ -1237,7 +1306,8 @@ int64_t nsx_deform_pack_bytes(void) { return (int64_t)N_FRAGS * 64 * 16 + (int64
 static int64_t tiles_bytes(int64_t S) { return (((S + 31) / 32) + (int64_t)num_cus() * NW) * Lay<false>::TILE_HALFS * 2; }
 static int wgrad_chunks_max() { return num_cus() / (WG_TYPES - 1); }
 int64_t nsx_deform_scratch_bytes(int64_t S) {
-    return SLOT_SUMS_BYTES + tiles_bytes(S) + (int64_t)wgrad_chunks_max() * P_TOTAL * 4;
+    return SLOT_SUMS_BYTES + tiles_bytes(S) + (int64_t)wgrad_chunks_max() * P_TOTAL * 4
+           + (int64_t)num_cus() * HEAD_STRIDE * 4;
 }
 
 int nsx_deform_pack(const float* params, void* packed, void* stream) {
@@ -1324,12 +1394,14 @@ int nsx_deform_bwd(const void* packed, const float* positions, int64_t S, const 
     // the warp codes are rows of a small table and nobody asks for the per-sample code gradient: everything that touches
     // the code columns is formed through the slot (Lay<true>)
     const bool slots = code_slot && grad_code_table && !grad_code_samples;
+    float* chunk_partials = reinterpret_cast<float*>(reinterpret_cast<uint8_t*>(scratch) + SLOT_SUMS_BYTES + tiles_bytes(S));
+    float* head_partials = chunk_partials + (int64_t)wgrad_chunks_max() * P_TOTAL;
     if (slots)
         hipLaunchKernelGGL(deform_bwd_kernel<true>, dim3((unsigned)blocks), dim3(NW * 64), 0, st, A, grad_offsets, sc,
-                           n_tiles, grad_code_samples, n_device, slot_sums);
+                           n_tiles, grad_code_samples, n_device, slot_sums, head_partials);
     else
         hipLaunchKernelGGL(deform_bwd_kernel<false>, dim3((unsigned)blocks), dim3(NW * 64), 0, st, A, grad_offsets, sc,
-                           n_tiles, grad_code_samples, n_device, slot_sums);
+                           n_tiles, grad_code_samples, n_device, slot_sums, (float*)nullptr);
     NSX_LAUNCH_CHECK("nsx_deform_bwd chain launch");
     // weight / bias / code-table gradients
     const int n_types = (grad_code_table && !slots) ? WG_TYPES : WG_TYPES - 1;
@@ -1338,13 +1410,13 @@ int nsx_deform_bwd(const void* packed, const float* positions, int64_t S, const 
     if (chunks > max_chunks) chunks = (int)max_chunks;
     if (chunks < 1) chunks = 1;
     if (slots) {
-        float* partials = reinterpret_cast<float*>(reinterpret_cast<uint8_t*>(scratch) + SLOT_SUMS_BYTES + tiles_bytes(S));
+        float* partials = chunk_partials;
         hipLaunchKernelGGL(deform_wgrad_kernel<true>, dim3(n_types, chunks), dim3(NW * 64), 0, st, sc, n_tiles, code_slot, S,
                            grad_params, grad_code_table, n_code_rows, n_device, slot_sums, partials);
         NSX_LAUNCH_CHECK("nsx_deform_bwd wgrad launch");
         hipLaunchKernelGGL(deform_code_expand_kernel, dim3(FINISH_REDUCE_BLOCKS + DFW + n_code_rows), dim3(256), 0, st,
                            slot_sums, code, code_stride, n_code_rows, A.frags, grad_params, grad_code_table, partials, chunks,
-                           n_tiles, S, n_device);
+                           head_partials, (int)blocks, n_tiles, S, n_device);
         NSX_LAUNCH_CHECK("nsx_deform_bwd finish launch");
     } else {
         hipLaunchKernelGGL(deform_wgrad_kernel<false>, dim3(n_types, chunks), dim3(NW * 64), 0, st, sc, n_tiles, code_slot, S,

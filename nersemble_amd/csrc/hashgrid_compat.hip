@@ -21,8 +21,9 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_kernel(const float* __restri
                                                            const half_t* __restrict__ table, const nsx_grid_geom g,
                                                            half_t* __restrict__ out) {
     const int L = g.n_levels;
+    const int shift = (L & (L - 1)) == 0 ? __builtin_ctz((unsigned)L) : -1;     // (a 64-bit division per item otherwise)
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < B * L; i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t b = i / L;
+        const int64_t b = shift >= 0 ? (i >> shift) : i / L;
         const int l = (int)(i - b * L);
         const float scale = g.scale[l];
         uint32_t c0[3]; float w[3];
@@ -39,12 +40,26 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_kernel(const float* __restri
             const uint32_t c[3] = {c0[0] + (k & 1), c0[1] + ((k >> 1) & 1), c0[2] + ((k >> 2) & 1)};
             const uint32_t e = entry_of(c, g.res[l], g.size[l], g.hashed[l] != 0);
             const float wk = ((k & 1) ? w[0] : 1.f - w[0]) * ((k & 2) ? w[1] : 1.f - w[1]) * ((k & 4) ? w[2] : 1.f - w[2]);
-            const half_t* row = table + ((size_t)g.offset[l] + e) * F;
+            // one entry = F halfs = F / 2 dwords, naturally aligned (the table is): ONE load per corner, not F
+            typedef uint32_t row_t __attribute__((ext_vector_type(F / 2)));
+            const row_t rv = *reinterpret_cast<const row_t*>(table + ((size_t)g.offset[l] + e) * F);
 #pragma unroll
-            for (int j = 0; j < F; ++j) acc[j] = __fmaf_rn(wk, (float)row[j], acc[j]);
+            for (int j = 0; j < F / 2; ++j) {
+                const half2_t t = as_half2(rv[j]);
+                acc[2 * j] = __fmaf_rn(wk, (float)t.x, acc[2 * j]);
+                acc[2 * j + 1] = __fmaf_rn(wk, (float)t.y, acc[2 * j + 1]);
+            }
         }
+        {
+            typedef uint32_t row_t __attribute__((ext_vector_type(F / 2)));
+            row_t ov;
 #pragma unroll
-        for (int j = 0; j < F; ++j) out[b * (int64_t)(L * F) + l * F + j] = (half_t)acc[j];
+            for (int j = 0; j < F / 2; ++j) {
+                half2_t t; t.x = (half_t)acc[2 * j]; t.y = (half_t)acc[2 * j + 1];
+                ov[j] = as_u32(t);
+            }
+            *reinterpret_cast<row_t*>(out + b * (int64_t)(L * F) + l * F) = ov;
+        }
     }
 }
 

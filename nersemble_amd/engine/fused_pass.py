@@ -215,8 +215,8 @@ class _MainPass(torch.autograd.Function):
         g_code_hash = torch.empty((n_rows, H), dtype=f32, device=dev) if need_code else None
         dx = torch.empty((S, 3), dtype=f32, device=dev)
         G_fused = G
-        if H == 1 and G is not None and sink is not None:
-            # one grid (compact first-grid phase, static models): the scatter as its own kernel.  The H = 1 instance of the fused kernel has one lane
+        if F.scatter_alone(H) and G is not None and sink is not None:
+            # <= 4 grids (compact first-grid phase, static models, the first widths of the window ramp): the scatter as its own kernel.  The H = 1 instance of the fused kernel has one lane
             # per sample, so the 16 (corner, feature) items of a sample and level go out as 16 instructions of 64
             # unrelated sectors each (5.5 ms at 650 k samples); the stand-alone scatter keeps the 8-lanes-per-sample mapping
             # whose neighbouring (feature, x) items share a sector.  The gather half (dL/dx of one grid) is cheap.

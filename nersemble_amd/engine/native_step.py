@@ -126,7 +126,7 @@ class _NativeMain(torch.autograd.Function):
             G = sink.buffer_for(st.main_code, st.main_window, st.n_rows, st.he.geom.total_entries, n_samples=st.S)
         m.G = G.data_ptr() if G is not None else None
         m.nonfinite = sink.nonfinite.data_ptr() if G is not None else None
-        m.scatter_separately = 1 if (st.H == 1 and G is not None) else 0
+        m.scatter_separately = 1 if (F.scatter_alone(st.H) and G is not None) else 0
         check(L.nsx_step_main_bwd(C.byref(m), 1, s), "nsx_step_main_bwd stage 1")
         if need_tab and ctx.announced:
             # G is complete, and so are the gradients of the two fused MLPs (the rest of the tables' optimizer group)

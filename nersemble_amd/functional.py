@@ -14,6 +14,14 @@ from . import _lib
 from ._lib import GridGeom, check, lib, ndev, ptr, stream
 
 
+def scatter_alone(H: int) -> bool:
+    """Padded grid counts whose fused backward has ONE lane per sample (table rows of <= 16 bytes: H <= 4): its 16
+    (corner, feature) gradient items per sample and level leave as 16 instructions of 64 unrelated sectors each, while
+    ``nsx_hash_ensemble_bwd_scatter`` keeps the 8-lanes-per-sample mapping whose (feature, x) neighbours share a sector.
+    Measured at 0.95 M samples: H = 1 5.5 -> 1.8 ms, H = 4 (window ramp, compact width 4) 7.9 ms fused."""
+    return H <= 4
+
+
 # ------------------------------------------------------------------------------------------------
 # table layout conversion (checkpoint compatibility with the reference's tcnn state dict)
 # ------------------------------------------------------------------------------------------------
@@ -274,8 +282,8 @@ class _HashEnsembleFn(torch.autograd.Function):
                 for t in (x, dout, code_index, G):                      # allocated on `cur`, read on `side`
                     t.record_stream(side)
                 G = None                                                # the gather half below adds nothing to G
-            elif G is not None and H == 1 and x.is_cuda and use_sink:
-                # one grid: the fused kernel's H = 1 instance has one lane per sample and issues the 16 (corner, feature)
+            elif G is not None and scatter_alone(H) and x.is_cuda and use_sink:
+                # <= 4 grids: the fused kernel's instance has one lane per sample and issues the 16 (corner, feature)
                 # items of a sample and level as 16 instructions of unrelated sectors; the stand-alone scatter keeps the
                 # 8-lanes-per-sample mapping whose neighbouring items share a sector (3x fewer sector atomics)
                 check(lib().nsx_hash_ensemble_bwd_scatter(ptr(x), B, C.byref(geom), n_rows, ptr(code_index), ptr(dout),
