@@ -749,9 +749,11 @@ __global__ __launch_bounds__(NW * 64, 1) void deform_bwd_kernel(DeformArgs A, co
     }
     NSX_DEVICE_COUNT(A.S, n_tiles, 32, n_dev);
     __shared__ __attribute__((aligned(16))) DeformLds L;
-    __shared__ float head_sums[SLOTS ? HEAD_STRIDE : 1];
+    // one table PER WAVE: within one instruction every lane then owns its address, so the sums are plain LDS
+    // read-modify-writes (ds_add_f32 costs ~150 cycles per wave instruction; 30 per tile were + 17 % on this kernel)
+    __shared__ float head_sums[SLOTS ? NW * HEAD_STRIDE : 1];
     if (SLOTS) {
-        for (int i = threadIdx.x; i < HEAD_STRIDE; i += blockDim.x) head_sums[i] = 0.f;
+        for (int i = threadIdx.x; i < NW * HEAD_STRIDE; i += blockDim.x) head_sums[i] = 0.f;
     }
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int n = lane & 31, kb = lane >> 5;
@@ -819,6 +821,7 @@ __global__ __launch_bounds__(NW * 64, 1) void deform_bwd_kernel(DeformArgs A, co
             u32x4 x0, x1;
             transpose_pair(dzv, nullptr, tsel, x0, x1);
             const f16x8 X0 = __builtin_bit_cast(f16x8, x0), X1 = __builtin_bit_cast(f16x8, x1);
+            float* hs = head_sums + wave * HEAD_STRIDE;
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
                 u32x4 y0, y1;
@@ -826,10 +829,12 @@ __global__ __launch_bounds__(NW * 64, 1) void deform_bwd_kernel(DeformArgs A, co
                 f32x16 hw = mfma(X0, __builtin_bit_cast(f16x8, y0), zero16());
                 hw = mfma(X1, __builtin_bit_cast(f16x8, y1), hw);
                 if (kb == 0) {
-                    const int col = tile_neuron_chain(p, n);
+                    float* dst = hs + tile_neuron_chain(p, n);      // (distinct per lane)
+                    float old[6];
 #pragma unroll
-                    for (int r = 0; r < 6; ++r)
-                        atomicAdd(&head_sums[(r < 3 ? r * DFW : 3 * DFW + 3 + (r - 3) * DFW) + col], hw[r]);
+                    for (int r = 0; r < 6; ++r) old[r] = dst[r < 3 ? r * DFW : 3 * DFW + 3 + (r - 3) * DFW];
+#pragma unroll
+                    for (int r = 0; r < 6; ++r) dst[r < 3 ? r * DFW : 3 * DFW + 3 + (r - 3) * DFW] = old[r] + hw[r];
                 }
             }
             f16x8 ones;
@@ -839,7 +844,7 @@ __global__ __launch_bounds__(NW * 64, 1) void deform_bwd_kernel(DeformArgs A, co
             hb = mfma(X1, ones, hb);
             if (lane == 0) {
 #pragma unroll
-                for (int r = 0; r < 6; ++r) atomicAdd(&head_sums[r < 3 ? 3 * DFW + r : 2 * (3 * DFW) + 3 + (r - 3)], hb[r]);
+                for (int r = 0; r < 6; ++r) hs[r < 3 ? 3 * DFW + r : 2 * (3 * DFW) + 3 + (r - 3)] += hb[r];
             }
         }
         // ---- chain (stage BH | B5 is resident in L.w[cur]) ----
@@ -919,8 +924,12 @@ __global__ __launch_bounds__(NW * 64, 1) void deform_bwd_kernel(DeformArgs A, co
     }
     if constexpr (SLOTS) {          // every launched block leaves its sums (zeros if it had no tile): the reducer adds gridDim.x rows
         __syncthreads();
-        for (int i = threadIdx.x; i < HEAD_STRIDE; i += blockDim.x)
-            head_partials[(int64_t)blockIdx.x * HEAD_STRIDE + i] = head_sums[i];
+        for (int i = threadIdx.x; i < HEAD_STRIDE; i += blockDim.x) {
+            float v = head_sums[i];
+#pragma unroll
+            for (int w = 1; w < NW; ++w) v += head_sums[w * HEAD_STRIDE + i];
+            head_partials[(int64_t)blockIdx.x * HEAD_STRIDE + i] = v;
+        }
     }
 }
 
@@ -1213,6 +1222,9 @@ __device__ __forceinline__ float packed_code_weight(const half_t* __restrict__ f
 // blocks [0, n_reduce): grad_params[i] += sum over the non-empty chunks of partials[chunk][i], for every parameter the
 // weight-gradient kernel owns (everything but the code columns of W0 / W4, which the blocks behind them produce).
 constexpr int FINISH_REDUCE_BLOCKS = (P_TOTAL + 255) / 256;
+// blocks [n_reduce, n_reduce + n_head): the head gradients = the sum of the chain kernel's per-block rows, 16 threads per
+// entry (a serial walk over 256 rows per thread took 75 us)
+constexpr int FINISH_HEAD_BLOCKS = (HEAD_PARAMS * 16 + 255) / 256;
 
 __global__ __launch_bounds__(256) void deform_code_expand_kernel(const float* __restrict__ slot_sums,
                                                                  const float* __restrict__ code, int64_t code_stride,
@@ -1240,16 +1252,30 @@ __global__ __launch_bounds__(256) void deform_code_expand_kernel(const float* __
         if (idx < P_B0) col = idx % DF_IN;
         else if (idx >= P_W4 && idx < P_B4) col = (idx - P_W4) % DF_W4;
         if (col >= DF_PE && col < DF_IN) return;
+        if (idx >= P_WR) return;                             // the heads: the blocks behind these
         float acc = 0.f;
-        if (idx >= P_WR) {                                   // the heads: one row per block of the chain kernel
-            for (int c = 0; c < n_chain_blocks; ++c) acc += head_partials[(int64_t)c * HEAD_STRIDE + (idx - P_WR)];
-        } else {
-            for (int c = 0; c < n_valid; ++c) acc += partials[(int64_t)c * P_TOTAL + idx];
-        }
+        for (int c = 0; c < n_valid; ++c) acc += partials[(int64_t)c * P_TOTAL + idx];
         grad_params[idx] += acc;
         return;
     }
-    const int blk = blockIdx.x - FINISH_REDUCE_BLOCKS;
+    if ((int)blockIdx.x < FINISH_REDUCE_BLOCKS + FINISH_HEAD_BLOCKS) {
+        if (!head_partials) return;
+        if (n_dev) {
+            const int64_t c = *n_dev;
+            if (c < S) S = c;
+        }
+        if (S <= 0) return;                                  // (the chain kernel wrote nothing)
+        const int t = (blockIdx.x - FINISH_REDUCE_BLOCKS) * 256 + threadIdx.x;
+        const int e = t >> 4, part = t & 15;
+        float acc = 0.f;
+        if (e < HEAD_PARAMS)
+            for (int c = part; c < n_chain_blocks; c += 16) acc += head_partials[(int64_t)c * HEAD_STRIDE + e];
+#pragma unroll
+        for (int m = 1; m < 16; m <<= 1) acc += __shfl_xor(acc, m);
+        if (e < HEAD_PARAMS && part == 0) grad_params[P_WR + e] += acc;
+        return;
+    }
+    const int blk = blockIdx.x - FINISH_REDUCE_BLOCKS - FINISH_HEAD_BLOCKS;
     const float* R0 = slot_sums;
     const float* R4 = slot_sums + (int64_t)DFW * 128;
     const int c = threadIdx.x & 127, half = threadIdx.x >> 7;
@@ -1414,7 +1440,8 @@ int nsx_deform_bwd(const void* packed, const float* positions, int64_t S, const 
         hipLaunchKernelGGL(deform_wgrad_kernel<true>, dim3(n_types, chunks), dim3(NW * 64), 0, st, sc, n_tiles, code_slot, S,
                            grad_params, grad_code_table, n_code_rows, n_device, slot_sums, partials);
         NSX_LAUNCH_CHECK("nsx_deform_bwd wgrad launch");
-        hipLaunchKernelGGL(deform_code_expand_kernel, dim3(FINISH_REDUCE_BLOCKS + DFW + n_code_rows), dim3(256), 0, st,
+        hipLaunchKernelGGL(deform_code_expand_kernel, dim3(FINISH_REDUCE_BLOCKS + FINISH_HEAD_BLOCKS + DFW + n_code_rows),
+                           dim3(256), 0, st,
                            slot_sums, code, code_stride, n_code_rows, A.frags, grad_params, grad_code_table, partials, chunks,
                            head_partials, (int)blocks, n_tiles, S, n_device);
         NSX_LAUNCH_CHECK("nsx_deform_bwd finish launch");

@@ -61,8 +61,12 @@ class _StepState:
 class _GradBuffers:
     """The parameter gradients a step's backward produces (mlp_head, mlp_base, the 16 deformation tensors, the batch's
     deformation-code rows, its hash-code rows) in ONE persistent fp32 buffer with ready-made views -- laid out by the plan
-    (``g_*`` offsets; they depend on the number of code rows and grids only).  Stage 0 of the backward clears it, autograd
-    adopts the views as ``.grad``, the optimizers have read them (same stream) before the next backward writes again."""
+    (``g_*`` offsets; they depend on the number of code rows and grids only).  Stage 0 of the backward clears it, the
+    views of the LEAF parameters (the two fused MLPs, the 16 deformation tensors) become their ``.grad`` directly
+    (``_deposit``; what DDP does with ``gradient_as_bucket_view``), the optimizers have read them (same stream) before the
+    next backward writes again.  Handing them to autograd instead costs a clone each: the views are referenced from here,
+    so ``AccumulateGrad`` copies instead of stealing -- 18 device copies of ~5 us in a row at the end of every backward,
+    with their allocations and launches on the host (``profiles/r04_timeline_steady_state_compact.txt``)."""
 
     def __init__(self, plan, n_rows: int, H: int, code_deform_shape, deform_shapes, head_hidden: int, base_hidden: int,
                  device):
@@ -86,6 +90,21 @@ class _GradBuffers:
         self.g_code_hash = cut(plan.g_code_hash, n_rows * H).view(n_rows, H)
 
 
+def _aliases(t: Optional[torch.Tensor], flat: torch.Tensor) -> bool:
+    if t is None or t.device != flat.device:
+        return False
+    lo = flat.data_ptr()
+    return lo <= t.data_ptr() < lo + flat.numel() * 4
+
+
+def _deposit(p: torch.Tensor, view: torch.Tensor) -> None:
+    """``AccumulateGrad`` for a leaf whose gradient already sits in its final place."""
+    if p.grad is None:
+        p.grad = view
+    else:
+        p.grad.add_(view)
+
+
 class _NativeMain(torch.autograd.Function):
     """The kept samples' main pass (forward: nsx_step_main_fwd, backward: nsx_step_main_bwd stages 0-2) as one autograd
     node with the inputs of ``engine.fused_pass._MainPass``: hash tables, the two fused MLPs, the batch's conditioned
@@ -100,6 +119,7 @@ class _NativeMain(torch.autograd.Function):
         m.ws_fwd, m.out = st.ws_fwd.data_ptr(), st.out.data_ptr()
         check(lib().nsx_step_main_fwd(C.byref(m), stream()), "nsx_step_main_fwd")
         ctx.st = st
+        ctx.leaves = (base_params, head_params) + tuple(deform_params)
         ctx.sink = st.he.grad_sink
         ctx.announced = ctx.needs_input_grad[1]
         if ctx.announced:
@@ -113,6 +133,10 @@ class _NativeMain(torch.autograd.Function):
         dev = g_out.device
         g = g_out.to(torch.float32).contiguous()
         gb: _GradBuffers = st.grads
+        leaves = ctx.leaves
+        for p in leaves:                 # a gradient accumulated by an earlier backward lives in the buffer stage 0 clears
+            if _aliases(p.grad, gb.flat):
+                p.grad = p.grad.clone()
         ws_bwd = torch.empty((plan.bwd_bytes,), dtype=torch.uint8, device=dev)
         need_tab = ctx.needs_input_grad[1]
         need_code = bool(ctx.needs_input_grad[4]) and not st.first_grid    # (the code is the constant one in that phase)
@@ -138,7 +162,12 @@ class _NativeMain(torch.autograd.Function):
             full = torch.zeros((st.n_rows, st.code_width), dtype=torch.float32, device=dev)   # (compact window-ramp layout)
             full[:, :st.H] = g_code
             g_code = full
-        return (None, None, gb.d_base, gb.d_head, g_code, gb.gtable, *gb.deform)
+        # leaf parameters: the views ARE the gradients (see _GradBuffers); the two code lookups are differentiated by autograd
+        for k, (p, view) in enumerate(zip(leaves, (gb.d_base, gb.d_head, *gb.deform))):
+            if ctx.needs_input_grad[2 + k if k < 2 else 4 + k]:
+                _deposit(p, view.view(p.shape) if view.shape != p.shape else view)
+        ctx.leaves = None
+        return (None, None, None, None, g_code, gb.gtable) + (None,) * len(gb.deform)
 
 
 class LazyVectorDict(dict):

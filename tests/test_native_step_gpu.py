@@ -142,3 +142,35 @@ def test_native_step_falls_back_outside_its_configuration(cuda):
     model2.device_sample_counts = False
     loss2, _, _ = trainer2.train_iteration(0, *data2.next_train(0))
     assert torch.isfinite(loss2)
+
+
+def test_leaf_gradients_are_the_steps_buffer_and_still_accumulate(cuda):
+    """The native backward leaves the gradients of the leaf parameters (fused MLPs, deformation tensors) in its persistent
+    buffer and makes the views their ``.grad`` (no clone per tensor).  A second backward without clearing must still ADD,
+    as ``AccumulateGrad`` would: the earlier sum is moved out of the buffer before stage 0 clears it."""
+    trainer, data, model = _build("compact", True, seed=3)
+    for cb in trainer.callbacks:
+        cb.run(0)
+    model.train()
+    bundle, batch = data.next_train(0)
+
+    def one_backward():
+        torch.manual_seed(70)
+        with torch.autocast(device_type="cuda", dtype=torch.float16, cache_enabled=False):
+            loss_dict, _, _ = model.fused_train_forward(bundle, batch)
+        loss_dict.total.backward()
+
+    one_backward()
+    flat = model._native._grad_buffers[next(iter(model._native._grad_buffers))].flat
+    lo, hi = flat.data_ptr(), flat.data_ptr() + flat.numel() * 4
+    leaves = {n: p for n, p in model.named_parameters()
+              if p.grad is not None and ("mlp_base" in n or "mlp_head" in n or "deformation" in n.lower())}
+    assert len(leaves) >= 10
+    inside = [n for n, p in leaves.items() if lo <= p.grad.data_ptr() < hi]
+    assert len(inside) == len(leaves), set(leaves) - set(inside)
+    first = {n: p.grad.detach().clone() for n, p in leaves.items()}
+    model.field.hash_ensemble.grad_sink.clear()                     # (the table gradient is not this test's subject)
+    one_backward()                                                  # same batch, same jitter: the gradient doubles
+    for n, p in leaves.items():
+        sc = first[n].abs().max().item()
+        assert (p.grad - 2 * first[n]).abs().max().item() <= 2e-4 * sc + 1e-12, n
