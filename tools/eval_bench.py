@@ -1,4 +1,7 @@
-"""Development aid: render one evaluation image (one timestep) with and without the pre-blended eval grid."""
+"""Development aid: render one evaluation image (one timestep) with and without the pre-blended eval grid.
+``--price``: per C-ABI entry point, the milliseconds one pre-blended image spends in it (HIP events around every native call
+of the render, ``_lib.KernelProfiler``) beside the image's wall time -- the table DESIGN.md §5 prices the eval image with."""
+import json
 import os
 import sys
 import time
@@ -6,6 +9,7 @@ import time
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from nersemble_amd import _lib  # noqa: E402
 from nersemble_amd.workloads import build_workload  # noqa: E402
 
 torch.manual_seed(0)
@@ -43,3 +47,23 @@ for fast in (False, True, False, True):
     dt = time.perf_counter() - t0
     print(f"preblend={fast}: {h}x{w} = {n} rays, {samples} samples, {dt * 1e3:.1f} ms, {samples / dt / 1e6:.1f} M samples/s, "
           f"psnr {float(10 * torch.log10(1 / ((img - batch['image']) ** 2).mean())):.2f}")
+
+if "--price" in sys.argv:
+    model.eval_preblend = True
+    prof = _lib.profiler
+    prof.watch, prof.alias = None, {}
+    prof.prewarm(4096)
+    prof.reset()
+    prof.enabled = True
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    img, samples = render()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    prof.enabled = False
+    rows = sorted(prof.summary().items(), key=lambda kv: -kv[1]["total_ms"])
+    native = sum(v["total_ms"] for _, v in rows)
+    print(json.dumps({"image": f"{h}x{w}", "rays": n, "samples": samples, "wall_ms_with_events": round(dt * 1e3, 2),
+                      "native_calls_ms": round(native, 2),
+                      "per_entry_point": {k: {"calls": v["calls"], "total_ms": round(v["total_ms"], 3),
+                                              "avg_ms": round(v["avg_ms"], 4)} for k, v in rows}}))
