@@ -5,6 +5,8 @@
 // HashEnsemble kernels (hash_ensemble.hip) are the performance path; this one is the straightforward per-(sample,
 // level) formulation of the same algorithm: fp16 table [total][F] in, fp16 features [B][L*F] out, fp32 atomics for
 // the parameter gradient, analytic dL/dx.
+#include <cstdlib>
+
 #include "nsx_common.h"
 
 namespace nsx {
@@ -57,6 +59,70 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_kernel(const float* __restri
             for (int j = 0; j < F / 2; ++j) {
                 half2_t t; t.x = (half_t)acc[2 * j]; t.y = (half_t)acc[2 * j + 1];
                 ov[j] = as_u32(t);
+            }
+            *reinterpret_cast<row_t*>(out + b * (int64_t)(L * F) + l * F) = ov;
+        }
+    }
+}
+
+// The same lookup with TWO lanes per (sample, level): lane pair = the two x-corners of the cell, each lane gathers the 4
+// (y, z) corners of its x.  Entries of x and x + 1 are neighbours in the table (dense levels: consecutive indices; hashed
+// levels: x enters the hash un-multiplied, so x ^ h and (x + 1) ^ h differ in their low bits only and share a 128-byte line
+// unless x is the last of its 32-block), and lanes of ONE instruction that hit one line cost one request: 32 lines per
+// wave instruction instead of 64.  The 4-byte gathers of the one-lane kernel run at 254 G/s = 32.5 TB/s of 128-byte lines,
+// the L2's limit (MI355X_MICROARCH: ~34.5 TB/s).
+template <int F>
+__global__ __launch_bounds__(256) void hashgrid_fwd_pair_kernel(const float* __restrict__ x, int64_t B,
+                                                                const half_t* __restrict__ table, const nsx_grid_geom g,
+                                                                half_t* __restrict__ out) {
+    const int L = g.n_levels;
+    const int shift = (L & (L - 1)) == 0 ? __builtin_ctz((unsigned)L) : -1;
+    const int64_t n_items = B * L;
+    const int64_t n_iter = (n_items * 2 + (int64_t)gridDim.x * blockDim.x - 1) / ((int64_t)gridDim.x * blockDim.x);
+    for (int64_t it = 0; it < n_iter; ++it) {           // (all lanes iterate together: the pair exchange below is a shuffle)
+        const int64_t t = it * (int64_t)gridDim.x * blockDim.x + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+        const int64_t i_raw = t >> 1;
+        const bool live = i_raw < n_items;
+        const int64_t i = live ? i_raw : n_items - 1;
+        const int xc = (int)(t & 1);
+        const int64_t b = shift >= 0 ? (i >> shift) : i / L;
+        const int l = (int)(i - b * L);
+        const float scale = g.scale[l];
+        uint32_t c0[3]; float w[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const float p = __fmaf_rn(scale, x[b * 3 + d], 0.5f), f = floorf(p);
+            c0[d] = (uint32_t)(int32_t)f; w[d] = p - f;
+        }
+        const float wx = xc ? w[0] : 1.f - w[0];
+        const uint32_t res = g.res[l], size = g.size[l];
+        const bool hashed = g.hashed[l] != 0;
+        float acc[F];
+#pragma unroll
+        for (int j = 0; j < F; ++j) acc[j] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t c[3] = {c0[0] + (uint32_t)xc, c0[1] + (k & 1), c0[2] + ((k >> 1) & 1)};
+            const uint32_t e = entry_of(c, res, size, hashed);
+            const float wk = wx * ((k & 1) ? w[1] : 1.f - w[1]) * ((k & 2) ? w[2] : 1.f - w[2]);
+            typedef uint32_t row_t __attribute__((ext_vector_type(F / 2)));
+            const row_t rv = *reinterpret_cast<const row_t*>(table + ((size_t)g.offset[l] + e) * F);
+#pragma unroll
+            for (int j = 0; j < F / 2; ++j) {
+                const half2_t h = as_half2(rv[j]);
+                acc[2 * j] = __fmaf_rn(wk, (float)h.x, acc[2 * j]);
+                acc[2 * j + 1] = __fmaf_rn(wk, (float)h.y, acc[2 * j + 1]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < F; ++j) acc[j] += __shfl_xor(acc[j], 1);
+        if (live && xc == 0) {
+            typedef uint32_t row_t __attribute__((ext_vector_type(F / 2)));
+            row_t ov;
+#pragma unroll
+            for (int j = 0; j < F / 2; ++j) {
+                half2_t h; h.x = (half_t)acc[2 * j]; h.y = (half_t)acc[2 * j + 1];
+                ov[j] = as_u32(h);
             }
             *reinterpret_cast<row_t*>(out + b * (int64_t)(L * F) + l * F) = ov;
         }
@@ -125,7 +191,16 @@ int nsx_hashgrid_fwd(const float* x, int64_t B, const nsx_half* table, int F, co
     hipStream_t st = (hipStream_t)stream;
     const half_t* t = reinterpret_cast<const half_t*>(table);
     half_t* o = reinterpret_cast<half_t*>(out);
-    if (F == 2) hipLaunchKernelGGL((hashgrid_fwd_kernel<2>), grid, block, 0, st, x, B, t, *g, o);
+    // NSX_HASHGRID_FWD (A/B): 1 = one lane per (sample, level), 2 = a lane pair per (sample, level) (see the kernels)
+    static const int variant = [] {
+        const char* e = getenv("NSX_HASHGRID_FWD");
+        return e ? atoi(e) : 2;
+    }();
+    if (variant == 2) {
+        if (F == 2) hipLaunchKernelGGL((hashgrid_fwd_pair_kernel<2>), grid, block, 0, st, x, B, t, *g, o);
+        else if (F == 4) hipLaunchKernelGGL((hashgrid_fwd_pair_kernel<4>), grid, block, 0, st, x, B, t, *g, o);
+        else hipLaunchKernelGGL((hashgrid_fwd_pair_kernel<8>), grid, block, 0, st, x, B, t, *g, o);
+    } else if (F == 2) hipLaunchKernelGGL((hashgrid_fwd_kernel<2>), grid, block, 0, st, x, B, t, *g, o);
     else if (F == 4) hipLaunchKernelGGL((hashgrid_fwd_kernel<4>), grid, block, 0, st, x, B, t, *g, o);
     else hipLaunchKernelGGL((hashgrid_fwd_kernel<8>), grid, block, 0, st, x, B, t, *g, o);
     NSX_LAUNCH_CHECK("nsx_hashgrid_fwd launch");

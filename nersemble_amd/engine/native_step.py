@@ -14,6 +14,7 @@ Covers the configuration the reference trains (occupancy grid on, deformation fi
 mixed precision, the sigma pass's forward values reused); anything else -> ``None`` and the caller takes the per-kernel path.
 """
 import ctypes as C
+import os
 from typing import Dict, Optional
 
 import torch
@@ -90,6 +91,9 @@ class _GradBuffers:
         self.g_code_hash = cut(plan.g_code_hash, n_rows * H).view(n_rows, H)
 
 
+_DEPOSIT = os.environ.get("NSX_GRAD_DEPOSIT", "1") != "0"
+
+
 def _aliases(t: Optional[torch.Tensor], flat: torch.Tensor) -> bool:
     if t is None or t.device != flat.device:
         return False
@@ -162,6 +166,9 @@ class _NativeMain(torch.autograd.Function):
             full = torch.zeros((st.n_rows, st.code_width), dtype=torch.float32, device=dev)   # (compact window-ramp layout)
             full[:, :st.H] = g_code
             g_code = full
+        if not _DEPOSIT:                 # (A/B knob: hand every gradient to autograd, which clones the referenced views)
+            ctx.leaves = None
+            return (None, None, gb.d_base, gb.d_head, g_code, gb.gtable, *gb.deform)
         # leaf parameters: the views ARE the gradients (see _GradBuffers); the two code lookups are differentiated by autograd
         for k, (p, view) in enumerate(zip(leaves, (gb.d_base, gb.d_head, *gb.deform))):
             if ctx.needs_input_grad[2 + k if k < 2 else 4 + k]:
