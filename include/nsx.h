@@ -30,7 +30,7 @@ extern "C" {
 
 #define NSX_MAX_LEVELS 32
 #define NSX_MAX_SLOTS 64
-#define NSX_VERSION 110
+#define NSX_VERSION 111
 
 typedef uint16_t nsx_half;
 
@@ -457,6 +457,28 @@ int nsx_hash_grad_expand_f16_bucket(const float* G, int n_slots, const float* co
                                     const float* window, int H, const nsx_grid_geom* g, nsx_half* bucket_f16, float scale,
                                     int accumulate, int64_t shard_elements, int64_t bucket_elements, int64_t bucket_index,
                                     int world_size, void* stream);
+/* The exchange restricted to the grids the coarse-to-fine window has reached (round 4).  While ceil(window) <= width the
+ * grids [width, H) have zero gradient and zero Adam moments (hash_ensemble.py:133-138: their window weight is 0), so a
+ * data-parallel step needs to exchange only [entry][f][width] of every entry: 1 / 32 of the bytes while one grid is on
+ * (steps 0 ... 40 000 of the reference's schedule), 1/16 ... 1/2 along the ramp.  State keeps the full layout.
+ *   _bucket_width : bucket k of the packed gradient, [world][bucket_entries][2][width] fp16; bucket_elements /
+ *                   shard_elements still count FULL-layout elements (entries * 2 * padded H).  *beyond_width (may be
+ *                   NULL) is set to 1 if a conditioned code is non-zero at a grid >= width -- the caller's premise fails.
+ *   _adam ..width : torch.optim.Adam on the grids [0, width) of n_entries entries: grad_packed [n_entries][2][width];
+ *                   master / moments / params_f16 in the full layout (pointers to the shard's first entry); the new fp16
+ *                   values also go to packed_out [n_entries][2][width] (a skipped step copies the current ones there).
+ *   _unpack_width : params_f16 [n_entries][2][padded H] <- packed [n_entries][2][width] (after the all-gather). */
+int nsx_hash_grad_expand_f16_bucket_width(const float* G, int n_slots, const float* code_table, int64_t code_stride,
+                                          const float* window, int H, const nsx_grid_geom* g, nsx_half* bucket_f16,
+                                          float scale, int accumulate, int64_t shard_elements, int64_t bucket_elements,
+                                          int64_t bucket_index, int world_size, int width, float* beyond_width,
+                                          void* stream);
+int nsx_adam_dense_f16grad_width(const nsx_half* grad_packed, int64_t n_entries, int width, int H_padded, float* master,
+                                 float* exp_avg, float* exp_avg_sq, nsx_half* params_f16, nsx_half* packed_out, float lr,
+                                 float beta1, float beta2, float eps, int64_t step, const float* inv_scale,
+                                 const float* found_inf, void* stream);
+int nsx_tables_unpack_width(const nsx_half* packed, int64_t n_entries, int width, int H_padded, nsx_half* tables_f16,
+                            void* stream);
 int nsx_check_finite_f16(const nsx_half* x, int64_t n, float* found_inf /* set to 1 if any inf/NaN */, void* stream);
 int nsx_adam_dense_f16grad(const nsx_half* grad, int64_t n, float* master, float* exp_avg, float* exp_avg_sq,
                            nsx_half* params_f16 /* may be NULL */, float lr, float beta1, float beta2, float eps,

@@ -18,7 +18,11 @@ struct AdamHyper {
     float lr, beta1, beta2, eps, bc1, bc2_sqrt;     // bc1 = 1 - b1^t ; bc2_sqrt = sqrt(1 - b2^t)
 };
 
+// (no contraction inside, and none with the caller's unscale multiply: every kernel that updates a parameter -- fused,
+// dense, packed -- then computes the same bits from the same inputs, which is what lets the data-parallel exchange change
+// its format with the window without changing a run)
 __device__ __forceinline__ void adam_update(float g, float& p, float& m, float& v, const AdamHyper& h) {
+#pragma clang fp contract(off)
     m = m + (g - m) * (1.0f - h.beta1);
     v = v * h.beta2 + (1.0f - h.beta2) * g * g;
     const float denom = sqrtf(v) / h.bc2_sqrt + h.eps;
@@ -219,7 +223,11 @@ template <int HP>
 __global__ __launch_bounds__(256) void expand_f16_kernel(
     const float* __restrict__ G, int n_slots, const float* __restrict__ code, int64_t code_stride,
     const float* __restrict__ window, int Hreal, uint64_t total, half_t* __restrict__ out, float scale, int accumulate,
-    uint64_t bucket_entries, uint64_t rank_entries, uint64_t entry_base, uint64_t virtual_total) {
+    uint64_t bucket_entries, uint64_t rank_entries, uint64_t entry_base, uint64_t virtual_total, int out_width,
+    float* __restrict__ beyond_width) {
+    // out_width < HP (nsx_hash_grad_expand_f16_bucket_width): only the grids [0, out_width) are written, packed as
+    // [entry][f][out_width] -- the caller knows the others' gradient to be zero (the coarse-to-fine window has not reached
+    // them); a conditioned code that is NOT zero there raises *beyond_width instead of being dropped silently.
     constexpr int HV = HP >= 4 ? 4 : HP;
     constexpr int TPE = 2 * HP / HV;
     constexpr int EPB = 256 / TPE;
@@ -231,6 +239,7 @@ __global__ __launch_bounds__(256) void expand_f16_kernel(
         float c = 0.f;
         if (h < Hreal) c = code[sl * code_stride + h] * (window ? window[h] : 1.0f);
         cs[i] = (float)(half_t)c;
+        if (h >= out_width && cs[i] != 0.f && beyond_width) beyond_width[0] = 1.0f;
     }
     const uint64_t n_walk = bucket_entries ? virtual_total : total;
     const uint64_t n_tiles = (n_walk + EPB - 1) / EPB;
@@ -254,6 +263,7 @@ __global__ __launch_bounds__(256) void expand_f16_kernel(
         const uint64_t e = e0 + le;
         if (v0 + le >= n_walk) continue;
         if (e >= total && !bucket_entries) continue;
+        if (hq * HV >= out_width) continue;                   // grids the packed output does not carry
         float g[HV];
 #pragma unroll
         for (int k = 0; k < HV; ++k) g[k] = 0.f;
@@ -266,12 +276,47 @@ __global__ __launch_bounds__(256) void expand_f16_kernel(
                 }
             }
         }
-        const uint64_t at = ((v0 + le) * 2ull + f) * HP + hq * HV;
+        const uint64_t at = ((v0 + le) * 2ull + f) * (uint64_t)out_width + hq * HV;
 #pragma unroll
         for (int k = 0; k < HV; ++k) {
+            if (hq * HV + k >= out_width) continue;
             const float prev = accumulate ? (float)out[at + k] : 0.f;
             out[at + k] = (half_t)(prev + scale * g[k]);
         }
+    }
+}
+
+// Adam on the grids [0, width) of a shard's entries: grad is PACKED [entry][f][width] (what the narrow reduce-scatter
+// delivered), master / moments / working tables keep the full [entry][f][HP] layout; the new fp16 values are also written
+// packed, for the narrow all-gather.  The arithmetic per element is adam_dense_f16grad_kernel's.
+__global__ __launch_bounds__(256) void adam_f16grad_width_kernel(const half_t* __restrict__ grad, int64_t n_packed,
+                                                                 int width, int HP, float* __restrict__ master,
+                                                                 float* __restrict__ m, float* __restrict__ v,
+                                                                 half_t* __restrict__ f16, half_t* __restrict__ packed_out,
+                                                                 AdamHyper hy, const float* __restrict__ inv_scale,
+                                                                 const float* __restrict__ found_inf) {
+    const bool skip = found_inf && found_inf[0] != 0.f;      // GradScaler: nothing moves -- but the all-gather still needs
+    const float is = inv_scale ? inv_scale[0] : 1.0f;        // this rank's CURRENT values in the packed buffer
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_packed; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = i / width;                       // (entry, f)
+        const int h = (int)(i - row * width);
+        const int64_t at = row * HP + h;
+        if (skip) { packed_out[i] = f16[at]; continue; }
+        float p = master[at], mm = m[at], vv = v[at];
+        adam_update((float)grad[i] * is, p, mm, vv, hy);
+        master[at] = p; m[at] = mm; v[at] = vv;
+        const half_t ph = (half_t)p;
+        f16[at] = ph;
+        packed_out[i] = ph;
+    }
+}
+
+// working tables [entry][f][HP] <- the gathered packed values [entry][f][width] of ALL ranks (rank-major = entry order)
+__global__ __launch_bounds__(256) void tables_unpack_width_kernel(const half_t* __restrict__ packed, int64_t n_packed,
+                                                                  int width, int HP, half_t* __restrict__ f16) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_packed; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = i / width;
+        f16[row * HP + (i - row * width)] = packed[i];
     }
 }
 
@@ -279,7 +324,7 @@ template <int HP>
 static int launch_expand_f16(const float* G, int n_slots, const float* code, int64_t code_stride, const float* window,
                              int H, uint64_t total, nsx_half* out, float scale, int accumulate, hipStream_t st,
                              uint64_t bucket_entries = 0, uint64_t rank_entries = 0, uint64_t entry_base = 0,
-                             uint64_t virtual_total = 0) {
+                             uint64_t virtual_total = 0, int out_width = HP, float* beyond_width = nullptr) {
     constexpr int HV = HP >= 4 ? 4 : HP;
     constexpr int EPB = 256 / (2 * HP / HV);
     NSX_REQUIRE(bucket_entries % EPB == 0, "nsx_hash_grad_expand_f16_bucket: bucket of %llu entries is not a multiple of "
@@ -287,7 +332,7 @@ static int launch_expand_f16(const float* G, int n_slots, const float* code, int
     const size_t smem = ((size_t)n_slots * HP + (size_t)n_slots * EPB * 2) * sizeof(float);
     hipLaunchKernelGGL((expand_f16_kernel<HP>), dim3(num_cus() * 8), dim3(256), smem, st, G, n_slots, code, code_stride,
                        window, H, total, reinterpret_cast<half_t*>(out), scale, accumulate, bucket_entries, rank_entries,
-                       entry_base, virtual_total);
+                       entry_base, virtual_total, out_width, beyond_width);
     NSX_LAUNCH_CHECK("nsx_hash_grad_expand_f16 launch");
     return NSX_OK;
 }
@@ -493,10 +538,69 @@ int nsx_hash_grad_expand_f16(const float* G, int n_slots, const float* code_tabl
     return NSX_ERR_UNSUPPORTED;
 }
 
+static int expand_bucket(const float* G, int n_slots, const float* code_table, int64_t code_stride, const float* window,
+                         int H, const nsx_grid_geom* g, nsx_half* bucket_f16, float scale, int accumulate,
+                         int64_t shard_elements, int64_t bucket_elements, int64_t bucket_index, int world_size, int width,
+                         float* beyond_width, void* stream);
+
 int nsx_hash_grad_expand_f16_bucket(const float* G, int n_slots, const float* code_table, int64_t code_stride,
                                     const float* window, int H, const nsx_grid_geom* g, nsx_half* bucket_f16, float scale,
                                     int accumulate, int64_t shard_elements, int64_t bucket_elements, int64_t bucket_index,
                                     int world_size, void* stream) {
+    return expand_bucket(G, n_slots, code_table, code_stride, window, H, g, bucket_f16, scale, accumulate, shard_elements,
+                         bucket_elements, bucket_index, world_size, nsx_padded_grids(H), nullptr, stream);
+}
+
+int nsx_hash_grad_expand_f16_bucket_width(const float* G, int n_slots, const float* code_table, int64_t code_stride,
+                                          const float* window, int H, const nsx_grid_geom* g, nsx_half* bucket_f16,
+                                          float scale, int accumulate, int64_t shard_elements, int64_t bucket_elements,
+                                          int64_t bucket_index, int world_size, int width, float* beyond_width,
+                                          void* stream) {
+    const int Hp = nsx_padded_grids(H);
+    NSX_REQUIRE(width >= 1 && width <= Hp && (width & (width - 1)) == 0,
+                "nsx_hash_grad_expand_f16_bucket_width: width %d is not a power of two in [1, %d]", width, Hp);
+    return expand_bucket(G, n_slots, code_table, code_stride, window, H, g, bucket_f16, scale, accumulate, shard_elements,
+                         bucket_elements, bucket_index, world_size, width, beyond_width, stream);
+}
+
+int nsx_adam_dense_f16grad_width(const nsx_half* grad_packed, int64_t n_entries, int width, int H_padded, float* master,
+                                 float* exp_avg, float* exp_avg_sq, nsx_half* params_f16, nsx_half* packed_out, float lr,
+                                 float beta1, float beta2, float eps, int64_t step, const float* inv_scale,
+                                 const float* found_inf, void* stream) {
+    NSX_REQUIRE(n_entries >= 0, "nsx_adam_dense_f16grad_width: negative size");
+    if (n_entries == 0) return NSX_OK;
+    NSX_REQUIRE(grad_packed && master && exp_avg && exp_avg_sq && params_f16 && packed_out,
+                "nsx_adam_dense_f16grad_width: NULL argument");
+    NSX_REQUIRE(width >= 1 && width <= H_padded && H_padded <= 32, "nsx_adam_dense_f16grad_width: width %d of %d grids",
+                width, H_padded);
+    NSX_REQUIRE(step >= 1, "nsx_adam_dense_f16grad_width: step must be >= 1");
+    const AdamHyper hy = make_hyper(lr, beta1, beta2, eps, step);
+    hipLaunchKernelGGL(adam_f16grad_width_kernel, dim3(num_cus() * 4), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const half_t*>(grad_packed), n_entries * 2 * width, width, H_padded, master, exp_avg,
+                       exp_avg_sq, reinterpret_cast<half_t*>(params_f16), reinterpret_cast<half_t*>(packed_out), hy,
+                       inv_scale, found_inf);
+    NSX_LAUNCH_CHECK("nsx_adam_dense_f16grad_width launch");
+    return NSX_OK;
+}
+
+int nsx_tables_unpack_width(const nsx_half* packed, int64_t n_entries, int width, int H_padded, nsx_half* tables_f16,
+                            void* stream) {
+    NSX_REQUIRE(n_entries >= 0, "nsx_tables_unpack_width: negative size");
+    if (n_entries == 0) return NSX_OK;
+    NSX_REQUIRE(packed && tables_f16, "nsx_tables_unpack_width: NULL argument");
+    NSX_REQUIRE(width >= 1 && width <= H_padded && H_padded <= 32, "nsx_tables_unpack_width: width %d of %d grids", width,
+                H_padded);
+    hipLaunchKernelGGL(tables_unpack_width_kernel, dim3(num_cus() * 4), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const half_t*>(packed), n_entries * 2 * width, width, H_padded,
+                       reinterpret_cast<half_t*>(tables_f16));
+    NSX_LAUNCH_CHECK("nsx_tables_unpack_width launch");
+    return NSX_OK;
+}
+
+static int expand_bucket(const float* G, int n_slots, const float* code_table, int64_t code_stride, const float* window,
+                         int H, const nsx_grid_geom* g, nsx_half* bucket_f16, float scale, int accumulate,
+                         int64_t shard_elements, int64_t bucket_elements, int64_t bucket_index, int world_size, int width,
+                         float* beyond_width, void* stream) {
     NSX_REQUIRE(G && code_table && bucket_f16 && g, "nsx_hash_grad_expand_f16_bucket: NULL argument");
     NSX_REQUIRE(H >= 1 && H <= 32, "nsx_hash_grad_expand_f16_bucket: H=%d not in [1,32]", H);
     NSX_REQUIRE(n_slots >= 1 && n_slots <= NSX_MAX_SLOTS, "nsx_hash_grad_expand_f16_bucket: n_slots=%d not in [1,%d]",
@@ -512,7 +616,7 @@ int nsx_hash_grad_expand_f16_bucket(const float* G, int n_slots, const float* co
     const uint64_t be = (uint64_t)(bucket_elements / per_entry), re = (uint64_t)(shard_elements / per_entry);
     hipStream_t st = (hipStream_t)stream;
 #define NSX_EXPB_CASE(HP) case HP: return launch_expand_f16<HP>(G, n_slots, code_table, code_stride, window, H, total, \
-        bucket_f16, scale, accumulate, st, be, re, (uint64_t)bucket_index * be, (uint64_t)world_size * be);
+        bucket_f16, scale, accumulate, st, be, re, (uint64_t)bucket_index * be, (uint64_t)world_size * be, width, beyond_width);
     switch (Hp) {
         NSX_EXPB_CASE(1) NSX_EXPB_CASE(2) NSX_EXPB_CASE(4) NSX_EXPB_CASE(8) NSX_EXPB_CASE(16) NSX_EXPB_CASE(32)
     }

@@ -25,9 +25,19 @@ bucket k + 1 runs while bucket k is on the links; two bucket buffers alternate, 
 (2 / K of it).  The result is bit-identical to the one-piece exchange (same values, same reduction per element;
 tests/test_parallel_cpu.py).  ``timing = True`` records HIP events around every phase (``comm_report``; bench.py's
 ``comm`` block).
+
+Round 4, the exchange follows the coarse-to-fine window (``width_source``): while ``ceil(window) <= W < H`` the grids
+``W ... H - 1`` have zero window weight, hence zero gradient and zero Adam moments (hash_ensemble.py:133-138), and neither
+their gradient nor their (unchanged) working values need to travel.  Steps 1, 2 and 5 then move ``[entry][f][W]`` instead
+of ``[entry][f][H]`` -- 1/32 of the bytes while one grid is on (steps 0 ... 40 000 of the reference's schedule, and the
+configuration ``bench.py`` prices), 1/16 ... 1/2 along the ramp -- and step 4 touches W / H of the shard.  Master weights,
+moments and working tables keep the full layout (nothing is handed over when W doubles); W never shrinks below the widest
+exchange so far (moments, once non-zero, decay for ever).  Bit-identical to the full-width exchange, which remains the
+path once the window has passed H / 2 (87 % of the schedule).
 """
 import ctypes as C
-from typing import Optional
+import math
+from typing import Callable, Optional
 
 import torch
 import torch.distributed as dist
@@ -59,6 +69,29 @@ class NativeTableOps:
               "nsx_hash_grad_expand_f16_bucket")
 
     @staticmethod
+    def expand_f16_bucket_width(he: HashEnsemble, entry, out: torch.Tensor, scale: float, accumulate: bool, shard: int,
+                                bucket: int, k: int, world: int, width: int, beyond: Optional[torch.Tensor]) -> None:
+        check(lib().nsx_hash_grad_expand_f16_bucket_width(ptr(entry["G"]), entry["n_rows"], ptr(entry["code"]),
+                                                          entry["code"].stride(0), ptr(entry["window"]),
+                                                          he.n_hash_encodings, C.byref(he.geom), ptr(out), float(scale),
+                                                          int(accumulate), int(shard), int(bucket), int(k), int(world),
+                                                          int(width), ptr(beyond), stream()),
+              "nsx_hash_grad_expand_f16_bucket_width")
+
+    @staticmethod
+    def adam_f16grad_width(grad, n_entries, width, Hp, master, exp_avg, exp_avg_sq, f16, packed_out, lr, b1, b2, eps, step,
+                           inv_scale, found_inf) -> None:
+        check(lib().nsx_adam_dense_f16grad_width(ptr(grad), int(n_entries), int(width), int(Hp), ptr(master), ptr(exp_avg),
+                                                 ptr(exp_avg_sq), ptr(f16), ptr(packed_out), lr, b1, b2, eps, int(step),
+                                                 ptr(inv_scale), ptr(found_inf), stream()),
+              "nsx_adam_dense_f16grad_width")
+
+    @staticmethod
+    def unpack_width(packed, n_entries, width, Hp, f16) -> None:
+        check(lib().nsx_tables_unpack_width(ptr(packed), int(n_entries), int(width), int(Hp), ptr(f16), stream()),
+              "nsx_tables_unpack_width")
+
+    @staticmethod
     def check_finite_f16(x: torch.Tensor, found_inf: torch.Tensor) -> None:
         check(lib().nsx_check_finite_f16(ptr(x), x.numel(), ptr(found_inf), stream()), "nsx_check_finite_f16")
 
@@ -87,8 +120,18 @@ class ShardedTableAdam(torch.optim.Optimizer):
 
     def __init__(self, hash_ensemble: HashEnsemble, lr: float = 5e-3, betas=(0.9, 0.999), eps: float = 1e-15,
                  world_size: int = 1, rank: int = 0, group=None, ops=None, overlap_reduce: bool = True,
-                 n_buckets: int = 8):
+                 n_buckets: int = 8, width_source: Optional[Callable[[], Optional[float]]] = None):
         self.he = hash_ensemble
+        # the coarse-to-fine window of the CURRENT step as every rank's schedule gives it (None: every grid is on); the
+        # exchange is restricted to the grids it has reached (module docstring).  Must be the same on all ranks.
+        self.width_source = width_source
+        self.Hp = int(hash_ensemble.tables.shape[-1])            # padded grid count of the [entry][f][Hp] layout
+        self._max_width = 0           # widest exchange so far: grids below it may hold non-zero moments
+        self._width = None            # width of the step in flight (decided with its first collective)
+        self._last_width = self.Hp
+        self._beyond = None           # device flag: a code was non-zero at a grid the narrow exchange left out
+        self._beyond_pending = None
+        self._beyond_host = None
         super().__init__([hash_ensemble.tables], dict(lr=lr, betas=betas, eps=eps))
         self.world_size, self.rank, self.group = int(world_size), int(rank), group
         self.ops = ops or NativeTableOps()
@@ -136,8 +179,50 @@ class ShardedTableAdam(torch.optim.Optimizer):
                 "grad_shard": torch.empty((self.shard,), dtype=torch.float16, device=dev),
                 "exp_avg": torch.zeros((self.shard,), dtype=torch.float32, device=dev),
                 "exp_avg_sq": torch.zeros((self.shard,), dtype=torch.float32, device=dev),
+                "packed": None,       # narrow exchange: [world][shard entries][2][W] fp16 for the all-gather
             }
         return self._buf
+
+    # ---- the width of this step's exchange --------------------------------------------------------------------------
+    def _exchange_width(self) -> int:
+        """Grids this step exchanges: the smallest power of two >= ceil(window), never below an earlier step's, H when
+        no schedule is known or the exchange runs in one piece."""
+        if self._width is not None:
+            return self._width
+        Hp = self.Hp
+        need = Hp
+        if self.width_source is not None and self.n_buckets > 1:
+            w = self.width_source()
+            if w is not None:
+                need = 1
+                while need < min(Hp, max(1, int(math.ceil(float(w))))):
+                    need *= 2
+        need = min(Hp, max(need, self._max_width))
+        if 2 * need > Hp:
+            need = Hp                 # (half of the bytes does not pay the pack / unpack passes)
+        self._width = need
+        return need
+
+    def _packed(self, W: int) -> torch.Tensor:
+        b = self._buffers()
+        n = self.world_size * (self.shard // (2 * self.Hp)) * 2 * W
+        if b["packed"] is None or b["packed"].numel() != n:
+            b["packed"] = torch.zeros((n,), dtype=torch.float16, device=b["dev"])
+        return b["packed"]
+
+    def _raise_if_beyond(self) -> None:
+        """The narrow exchange's premise, checked one step late (no host sync in the step): no conditioned code may be
+        non-zero at a grid the exchange left out."""
+        pend = self._beyond_pending
+        if pend is None:
+            return
+        host, ev = pend
+        if ev is not None and not ev.query():
+            return                    # (not there yet: the flag is sticky, a later look finds it)
+        self._beyond_pending = None
+        if float(host[0]) != 0.0:
+            raise RuntimeError("ShardedTableAdam: a hash grid beyond the exchanged width received a gradient -- the window "
+                               "handed to the optimizer (width_source) is not the one the HashEnsemble was evaluated with")
 
     def _master_shard(self) -> torch.Tensor:
         return self.he.tables.data.reshape(-1)[self.lo:self.lo + self.n_local]
@@ -163,7 +248,9 @@ class ShardedTableAdam(torch.optim.Optimizer):
             self._mark("rs_wait_begin")
             early.wait()                                         # the current stream waits for the collective
             self._mark("rs_wait_end")
-        self.ops.check_finite_f16(b["grad_shard"], found_inf)
+        W = self._exchange_width()
+        shard_grad = b["grad_shard"] if W == self.Hp else b["grad_shard"][:self.shard // self.Hp * W]
+        self.ops.check_finite_f16(shard_grad, found_inf)
         if entries and sink.nonfinite is not None:
             torch.maximum(found_inf, sink.nonfinite.to(found_inf.dtype), out=found_inf)
 
@@ -198,6 +285,10 @@ class ShardedTableAdam(torch.optim.Optimizer):
         he, b = self.he, self._buffers()
         entries = he.grad_sink.entries if he.grad_sink is not None else []
         scale = 1.0 / self.world_size
+        self._raise_if_beyond()
+        W = self._exchange_width()
+        if W < self.Hp:
+            return self._expand_and_reduce_narrow(W, entries, scale, async_op)
         if self.n_buckets == 1:
             self._mark("expand_begin")
             if not entries:
@@ -222,6 +313,32 @@ class ShardedTableAdam(torch.optim.Optimizer):
             if k == 0:
                 self._mark("rs_begin")
             out = b["grad_shard"][k * self.bucket:(k + 1) * self.bucket]
+            handles.append(dist.reduce_scatter_tensor(out, buf, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op))
+        return _Handles(handles) if async_op else None
+
+    def _expand_and_reduce_narrow(self, W: int, entries, scale: float, async_op: bool):
+        """The bucketed exchange on the grids [0, W): the same pieces, each W / H as long."""
+        he, b = self.he, self._buffers()
+        per_entry = 2 * self.Hp
+        be = self.bucket // per_entry                            # entries per piece and rank
+        n_piece = be * 2 * W
+        if self._beyond is None or self._beyond.device != b["dev"]:
+            self._beyond = torch.zeros((1,), dtype=torch.float32, device=b["dev"])
+        handles = []
+        for k in range(self.n_buckets):
+            buf = b["buckets"][k % 2][:self.world_size * n_piece]
+            if k >= 2 and handles[k - 2] is not None:
+                handles[k - 2].wait()
+            self._mark("expand_begin")
+            if not entries:
+                buf.zero_()
+            for i, e in enumerate(entries):
+                self.ops.expand_f16_bucket_width(he, e, buf, scale, i > 0, self.shard, self.bucket, k, self.world_size, W,
+                                                 self._beyond)
+            self._mark("expand_end")
+            if k == 0:
+                self._mark("rs_begin")
+            out = b["grad_shard"][k * n_piece:(k + 1) * n_piece]
             handles.append(dist.reduce_scatter_tensor(out, buf, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op))
         return _Handles(handles) if async_op else None
 
@@ -275,14 +392,40 @@ class ShardedTableAdam(torch.optim.Optimizer):
         group = self.param_groups[0]
         self._step += 1
         b1, b2 = group["betas"]
+        W = self._exchange_width()
         self._mark("adam_begin")
-        if self.n_local > 0:
-            self.ops.adam_f16grad(b["grad_shard"], self.n_local, self._master_shard(), b["exp_avg"], b["exp_avg_sq"],
-                                  b["f16"][self.lo:self.lo + self.shard], group["lr"], b1, b2, group["eps"], self._step,
-                                  inv_scale, found_inf)
-        self._mark("adam_end")
-        dist.all_gather_into_tensor(b["f16"], b["f16"][self.lo:self.lo + self.shard], group=self.group)
+        if W == self.Hp:
+            if self.n_local > 0:
+                self.ops.adam_f16grad(b["grad_shard"], self.n_local, self._master_shard(), b["exp_avg"], b["exp_avg_sq"],
+                                      b["f16"][self.lo:self.lo + self.shard], group["lr"], b1, b2, group["eps"], self._step,
+                                      inv_scale, found_inf)
+            self._mark("adam_end")
+            dist.all_gather_into_tensor(b["f16"], b["f16"][self.lo:self.lo + self.shard], group=self.group)
+        else:
+            per_entry = 2 * self.Hp
+            se = self.shard // per_entry                          # entries per shard
+            packed = self._packed(W)
+            mine = packed[self.rank * se * 2 * W:(self.rank + 1) * se * 2 * W]
+            if self.n_local > 0:
+                self.ops.adam_f16grad_width(b["grad_shard"], self.n_local // per_entry, W, self.Hp, self._master_shard(),
+                                            b["exp_avg"], b["exp_avg_sq"], b["f16"][self.lo:self.lo + self.shard], mine,
+                                            group["lr"], b1, b2, group["eps"], self._step, inv_scale, found_inf)
+            self._mark("adam_end")
+            dist.all_gather_into_tensor(packed, mine, group=self.group)
+            self.ops.unpack_width(packed, self.n // per_entry, W, self.Hp, b["f16"])
+            if self._beyond is not None and self._beyond_pending is None:
+                if self._beyond.is_cuda:
+                    if self._beyond_host is None:
+                        self._beyond_host = torch.zeros((1,), dtype=torch.float32).pin_memory()
+                    self._beyond_host.copy_(self._beyond, non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record()
+                    self._beyond_pending = (self._beyond_host, ev)
+                else:
+                    self._beyond_pending = (self._beyond.clone(), None)
         self._mark("ag_end")
+        self._max_width = max(self._max_width, W)
+        self._last_width, self._width = W, None
         if he.grad_sink is not None:
             he.grad_sink.clear()
         he.mark_half_synced()
@@ -313,8 +456,9 @@ class ShardedTableAdam(torch.optim.Optimizer):
         n_steps = max(1, sum(1 for what, _ in ev if what == "adam_begin"))
         out = {k: v / n_steps for k, v in acc.items()}
         W = self.world_size
-        bytes_rs = (W - 1) / W * self.shard * W * 2          # fp16 gradient pieces leaving / arriving per rank
-        out.update(steps=n_steps, buckets=self.n_buckets, world_size=W,
+        # fp16 pieces leaving / arriving per rank, at the width of the LAST step's exchange
+        bytes_rs = (W - 1) / W * self.shard * W * 2 * self._last_width / self.Hp
+        out.update(steps=n_steps, buckets=self.n_buckets, world_size=W, exchange_width=self._last_width, grids=self.Hp,
                    reduce_scatter_bytes_per_rank=bytes_rs, all_gather_bytes_per_rank=bytes_rs,
                    reduce_scatter_bus_GBps=(bytes_rs / (out["reduce_scatter_ms"] * 1e-3) / 1e9)
                    if out["reduce_scatter_ms"] > 0 else None,
@@ -331,6 +475,7 @@ class ShardedTableAdam(torch.optim.Optimizer):
         early, self._early = self._early, None
         if early is not None and early != "done":
             early.wait()                          # a reduce-scatter nobody consumed: let it finish before G is reused
+        self._width = None
         if self.he.grad_sink is not None:
             self.he.grad_sink.clear()
 
@@ -359,6 +504,7 @@ class ShardedTableAdam(torch.optim.Optimizer):
         self.he.wait_tables()
         b = self._buffers()
         self._step = int(state["step"])
+        self._max_width = self.Hp if self._step > 0 else 0           # (which grids hold moments is not recorded)
         self.param_groups[0]["lr"] = float(state.get("lr", self.param_groups[0]["lr"]))
         for key in ("exp_avg", "exp_avg_sq"):
             b[key].zero_()

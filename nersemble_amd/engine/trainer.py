@@ -128,9 +128,11 @@ class NeRSembleTrainer:
                 sharded = (world_size > 1 and factored_table_grad is not False) if sharded_table_adam is None \
                     else sharded_table_adam
                 if sharded:
-                    self.optimizers[name + "/tables"] = ShardedTableAdam(model.field.hash_ensemble, lr=lrs[name],
-                                                                         eps=self.cfg.eps, world_size=world_size,
-                                                                         rank=self.rank)
+                    # (the exchange follows the coarse-to-fine window: every rank's schedule holds the same value)
+                    sched = getattr(model, "sched_window_hash_encodings", None)
+                    self.optimizers[name + "/tables"] = ShardedTableAdam(
+                        model.field.hash_ensemble, lr=lrs[name], eps=self.cfg.eps, world_size=world_size, rank=self.rank,
+                        width_source=(lambda s=sched: s.value) if sched is not None else None)
                 else:
                     self.optimizers[name + "/tables"] = HashTableAdam(model.field.hash_ensemble, lr=lrs[name],
                                                                       eps=self.cfg.eps,

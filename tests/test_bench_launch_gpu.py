@@ -33,3 +33,6 @@ def test_bench_gpus_2_launches_its_own_ranks(cuda):
         assert comm[key] > 0, (key, comm)
     assert comm["reduce_scatter_exposed_ms"] >= 0 and comm["reduce_scatter_bytes_per_rank"] > 0
     assert comm["reduce_scatter_bus_GBps"] > 0 and len(comm["ms_per_step_per_rank_min_max"]) == 2
+    # the window keeps one of the 16 grids on in this configuration: the exchange carries that grid only
+    assert comm["exchange_width"] == 1 and comm["grids"] == 16
+    assert comm["reduce_scatter_bytes_per_rank"] < 0.07 * 2 * 16 * 2 * 6.3e6

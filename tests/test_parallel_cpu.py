@@ -95,6 +95,47 @@ class _TorchTableOps:
         piece = padded.view(world, shard)[:, k * bucket:(k + 1) * bucket].reshape(-1)
         out.copy_((out.float() + piece).half() if accumulate else piece.half())
 
+    def expand_f16_bucket_width(self, he, entry, out, scale, accumulate, shard, bucket, k, world, width, beyond):
+        """Piece k of every rank's shard restricted to the grids [0, width), packed [rank][entry][f][width]: what
+        nsx_hash_grad_expand_f16_bucket_width writes (+ its flag for a code that is non-zero beyond the width)."""
+        d = self.dense(he, entry) * scale                                  # [total, 2, Hp]
+        Hp = d.shape[-1]
+        H = he.n_hash_encodings
+        code = entry["code"][:entry["n_rows"], :H].float()
+        if entry["window"] is not None:
+            code = code * entry["window"][:H]
+        if beyond is not None and bool((code.half()[:, width:] != 0).any()):
+            beyond.fill_(1.0)
+        se, be = shard // (2 * Hp), bucket // (2 * Hp)
+        padded = torch.zeros((world * se, 2, Hp), dtype=torch.float32)
+        padded[:d.shape[0]] = d
+        piece = padded.view(world, se, 2, Hp)[:, k * be:(k + 1) * be, :, :width].reshape(-1)
+        out.copy_((out.float() + piece).half() if accumulate else piece.half())
+
+    @staticmethod
+    def adam_f16grad_width(grad, n_entries, width, Hp, master, exp_avg, exp_avg_sq, f16, packed_out, lr, b1, b2, eps, step,
+                           inv_scale, found_inf):
+        n, npk = n_entries * 2 * Hp, n_entries * 2 * width
+
+        def cut(t):
+            return t[:n].view(n_entries, 2, Hp)[..., :width]
+
+        if found_inf is not None and float(found_inf) != 0:
+            packed_out[:npk] = cut(f16).reshape(-1)
+            return
+        g = grad[:npk].float().view(n_entries, 2, width) * (float(inv_scale) if inv_scale is not None else 1.0)
+        m, v, p = cut(exp_avg), cut(exp_avg_sq), cut(master)
+        m.lerp_(g, 1 - b1)
+        v.mul_(b2).addcmul_(g, g, value=1 - b2)
+        bc1, bc2 = 1 - b1 ** step, 1 - b2 ** step
+        p.sub_((lr / bc1) * m / (v.sqrt() / bc2 ** 0.5 + eps))
+        cut(f16).copy_(p.half())
+        packed_out[:npk] = p.half().reshape(-1)
+
+    @staticmethod
+    def unpack_width(packed, n_entries, width, Hp, f16):
+        f16[:n_entries * 2 * Hp].view(n_entries, 2, Hp)[..., :width] = packed[:n_entries * 2 * width].view(n_entries, 2, width)
+
     @staticmethod
     def check_finite_f16(x, found_inf):
         if not torch.isfinite(x.float()).all():
@@ -113,14 +154,18 @@ class _TorchTableOps:
         f16_out[:n] = master.half()
 
 
-def _fake_entry(he, seed, n_rows=3, poison=False):
+def _fake_entry(he, seed, n_rows=3, poison=False, window=None):
     g = torch.Generator().manual_seed(seed)
     G = torch.randn((n_rows, he.geom.total_entries, 2), generator=g) * 1e-2
     G[torch.rand(G.shape, generator=g) < 0.5] = 0.0
     if poison:
         G[1, 7, 0] = float("inf")
     code = torch.randn((n_rows, he.n_hash_encodings), generator=g)
-    return {"G": G, "code": code, "window": None, "n_rows": n_rows, "key": seed}
+    win = None
+    if window is not None:
+        from nersemble_amd.field_components.hash_ensemble import posenc_window
+        win = posenc_window(window, 0, he.n_hash_encodings - 1, he.n_hash_encodings).to(torch.float32)
+    return {"G": G, "code": code, "window": win, "n_rows": n_rows, "key": seed}
 
 
 def _sharded_worker(rank, world, port, out_dir, n_buckets=8, log2_hashmap_size=8):
@@ -179,6 +224,107 @@ def _sharded_worker(rank, world, port, out_dir, n_buckets=8, log2_hashmap_size=8
                os.path.join(out_dir, f"s{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
+
+
+_WINDOWS = [1.0, 1.0, 1.4, 2.0, 2.0, 2.6, 1.0]          # per step (the last: a window that shrank -- the width must not)
+
+
+def _window_worker(rank, world, port, out_dir, narrow):
+    """ShardedTableAdam over a schedule of coarse-to-fine windows, with the exchange following the window (``narrow``) or
+    always at full width: 4 grids (padded), widths 1, 1, 2, 2, 2, full, full."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from nersemble_amd.engine.sharded_adam import ShardedTableAdam
+    from nersemble_amd.field_components.hash_ensemble import HashEnsemble, HashEnsembleConfig, TCNNHashEncodingConfig
+    he = HashEnsemble(HashEnsembleConfig(4, TCNNHashEncodingConfig(n_levels=3, log2_hashmap_size=10), True, True), seed=5)
+    with torch.no_grad():
+        he.tables.mul_(1e3)
+    now = {"w": None}
+    opt = ShardedTableAdam(he, lr=5e-3, eps=1e-15, world_size=world, rank=rank, ops=_TorchTableOps(), n_buckets=4,
+                           width_source=(lambda: now["w"]) if narrow else None)
+    inv = torch.tensor([1.0 / 64.0])
+    log, widths = [], []
+    for it, w in enumerate(_WINDOWS):
+        now["w"] = w
+        poison = (it == 3 and rank == 0)
+        he.grad_sink.entries = [] if (it == 4 and rank == 1) else [_fake_entry(he, 100 * it + rank, poison=poison, window=w)]
+        he.grad_sink.nonfinite = torch.zeros(1)
+        found = torch.zeros(1)
+        if it == 4:
+            opt.ensure_reduce_started()                  # (rank 1 has no samples this step: it joins with zeros)
+        elif it % 2 == 1:
+            he.grad_sink.expect()
+            he.grad_sink.arrived()
+            assert opt._early == "done"
+        opt.check_finite(found)
+        dist.all_reduce(found, op=dist.ReduceOp.MAX)
+        opt.step(found_inf=found, inv_scale=inv)
+        if float(found) != 0:
+            opt.rollback_step()
+        log.append(float(found))
+        widths.append(opt._last_width)
+    f16 = he.tables_f16.detach().clone()
+    b = opt._buffers()
+    moments = (b["exp_avg"].clone(), b["exp_avg_sq"].clone())
+    opt.gather_master()
+    torch.save({"log": log, "widths": widths, "f16": f16, "master": he.tables.detach().clone(), "moments": moments,
+                "report": opt.comm_report()}, os.path.join(out_dir, f"w{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_exchange_that_follows_the_window_equals_the_full_exchange_bit_for_bit(tmp_path):
+    """While ceil(window) <= W < H only the grids [0, W) are exchanged (reduce-scatter, shard Adam, all-gather on
+    [entry][f][W]): working tables, master weights, both moments and the skip decisions are those of the full-width
+    exchange bit for bit -- through a poisoned step, a rank without samples, and a window that shrinks again."""
+    res = {}
+    for narrow in (False, True):
+        out = tmp_path / f"n{int(narrow)}"
+        out.mkdir()
+        mp.spawn(_window_worker, args=(2, _free_port(), str(out), narrow), nprocs=2, join=True)
+        res[narrow] = [torch.load(out / f"w{r}.pt") for r in range(2)]
+    assert res[False][0]["widths"] == [4] * len(_WINDOWS)
+    assert res[True][0]["widths"] == res[True][1]["widths"] == [1, 1, 2, 2, 2, 4, 4]
+    assert res[True][0]["report"]["exchange_width"] == 4 and res[True][0]["report"]["grids"] == 4
+    for r in range(2):
+        assert res[False][r]["log"] == res[True][r]["log"] == [0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0]
+        assert torch.equal(res[False][r]["f16"], res[True][r]["f16"])
+        assert torch.equal(res[False][r]["master"], res[True][r]["master"])
+        for a, b in zip(res[False][r]["moments"], res[True][r]["moments"]):
+            assert torch.equal(a, b)
+    assert torch.equal(res[True][0]["f16"], res[True][1]["f16"])
+    # the grids the window never reached: untouched
+    assert bool((res[True][0]["moments"][0].view(-1, 4)[:, 3] == 0).all())
+
+
+def _beyond_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from nersemble_amd.engine.sharded_adam import ShardedTableAdam
+    from nersemble_amd.field_components.hash_ensemble import HashEnsemble, HashEnsembleConfig, TCNNHashEncodingConfig
+    he = HashEnsemble(HashEnsembleConfig(4, TCNNHashEncodingConfig(n_levels=3, log2_hashmap_size=10), True, True), seed=5)
+    opt = ShardedTableAdam(he, world_size=world, rank=rank, ops=_TorchTableOps(), n_buckets=4, width_source=lambda: 1.0)
+    raised = False
+    for it in range(2):
+        he.grad_sink.entries = [_fake_entry(he, it + rank, window=3.0)]          # evaluated with another window
+        he.grad_sink.nonfinite = torch.zeros(1)
+        found = torch.zeros(1)
+        try:
+            opt.check_finite(found)
+        except RuntimeError as e:
+            raised = "beyond the exchanged width" in str(e)
+            break
+        opt.step(found_inf=found, inv_scale=torch.ones(1))
+    torch.save({"raised": raised}, os.path.join(out_dir, f"b{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_a_gradient_beyond_the_exchanged_width_is_an_error(tmp_path):
+    mp.spawn(_beyond_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    assert all(torch.load(tmp_path / f"b{r}.pt")["raised"] for r in range(2))
 
 
 def test_sharded_table_adam_world2_matches_single_process(tmp_path):

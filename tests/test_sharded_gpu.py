@@ -305,3 +305,120 @@ def test_two_ranks_on_half_batches_equal_one_process_on_the_union_batch(cuda, tm
             sc = g_ref.abs().max().item()
             err = (a["grads"][name] - g_ref).abs().max().item()
             assert err <= 2e-3 * sc + 1e-9, (mode, name, err, sc)
+
+
+# ---- the exchange that follows the coarse-to-fine window (grids [0, W) only) -------------------------------------------
+@pytest.mark.parametrize("H,W", [(3, 2), (8, 1), (8, 2), (32, 1), (32, 4), (32, 16)])
+def test_narrow_exchange_kernels(H, W, cuda):
+    """nsx_hash_grad_expand_f16_bucket_width / nsx_adam_dense_f16grad_width / nsx_tables_unpack_width: the packed piece is
+    the full-width piece's first W grids, the packed Adam is the dense Adam where the other grids have neither gradient
+    nor moments (bit for bit), unpack scatters back; a code that is non-zero beyond W raises the flag."""
+    from nersemble_amd.engine.sharded_adam import NativeTableOps
+    ops = NativeTableOps()
+    he = _he(H, cuda)
+    Hp = int(he.tables.shape[-1])
+    g = torch.Generator(device=cuda).manual_seed(7 * H + W)
+    T = 5
+    G = torch.randn((T, he.geom.total_entries, 2), device=cuda, generator=g) * 1e-2
+    G[torch.rand(G.shape, device=cuda, generator=g) < 0.5] = 0
+    code = torch.randn((T, H), device=cuda, generator=g)
+    win = torch.rand((H,), device=cuda, generator=g) + 0.1
+    win[W:] = 0
+    entry = {"G": G, "code": code, "window": win, "n_rows": T}
+    world, nb, per_entry = 2, 2, 2 * Hp
+    unit = 1024 * nb
+    shard = ((he.tables.numel() + world - 1) // world + unit - 1) // unit * unit
+    bucket = shard // nb
+    be = bucket // per_entry
+    beyond = torch.zeros(1, device=cuda)
+    for k in range(nb):
+        full = torch.zeros(world * bucket, dtype=torch.float16, device=cuda)
+        ops.expand_f16_bucket(he, entry, full, 0.5, False, shard, bucket, k, world)
+        packed = torch.full((world * be * 2 * W,), 7.0, dtype=torch.float16, device=cuda)
+        ops.expand_f16_bucket_width(he, entry, packed, 0.5, False, shard, bucket, k, world, W, beyond)
+        want = full.view(world * be, 2, Hp)
+        assert torch.equal(packed.view(world * be, 2, W), want[..., :W])
+        assert want[..., W:].abs().max().item() == 0 or W == Hp
+        ops.expand_f16_bucket(he, entry, full, 0.5, True, shard, bucket, k, world)
+        ops.expand_f16_bucket_width(he, entry, packed, 0.5, True, shard, bucket, k, world, W, beyond)
+        assert torch.equal(packed.view(world * be, 2, W), full.view(world * be, 2, Hp)[..., :W])
+    assert beyond.item() == 0
+    if W < H:
+        win2 = win.clone()
+        win2[W] = 0.25
+        ops.expand_f16_bucket_width(he, dict(entry, window=win2), packed, 0.5, False, shard, bucket, 0, world, W, beyond)
+        assert beyond.item() == 1
+    # Adam on the packed gradient == the dense kernel on the same gradient with zeros (and zero moments) beyond W
+    ne = 3000
+    n = ne * per_entry
+    gp = (torch.randn((ne, 2, W), device=cuda, generator=g) * 30).half()
+    gd = torch.zeros((ne, 2, Hp), dtype=torch.float16, device=cuda)
+    gd[..., :W] = gp
+    state = {}
+    for name in ("narrow", "dense"):
+        gg = torch.Generator(device=cuda).manual_seed(99)
+        master = torch.randn((n,), device=cuda, generator=gg)
+        m = torch.randn((ne, 2, Hp), device=cuda, generator=gg) * 1e-2
+        v = torch.rand((ne, 2, Hp), device=cuda, generator=gg) * 1e-3
+        m[..., W:] = 0
+        v[..., W:] = 0
+        state[name] = [master, m.reshape(-1).contiguous(), v.reshape(-1).contiguous(), master.half()]
+    inv, found = torch.tensor([1.0 / 64], device=cuda), torch.zeros(1, device=cuda)
+    out = torch.zeros(ne * 2 * W, dtype=torch.float16, device=cuda)
+    for step in (1, 2):
+        a, d = state["narrow"], state["dense"]
+        ops.adam_f16grad_width(gp.reshape(-1), ne, W, Hp, a[0], a[1], a[2], a[3], out, 5e-3, 0.9, 0.999, 1e-15, step, inv,
+                               found)
+        ops.adam_f16grad(gd.reshape(-1), n, d[0], d[1], d[2], d[3], 5e-3, 0.9, 0.999, 1e-15, step, inv, found)
+        for x, y in zip(a, d):
+            assert torch.equal(x, y)
+        assert torch.equal(out.view(ne, 2, W), a[3].view(ne, 2, Hp)[..., :W])
+    # a skipped step moves nothing and still fills the packed buffer with the current values
+    found.fill_(1)
+    before = [t.clone() for t in state["narrow"]]
+    out.zero_()
+    a = state["narrow"]
+    ops.adam_f16grad_width(gp.reshape(-1), ne, W, Hp, a[0], a[1], a[2], a[3], out, 5e-3, 0.9, 0.999, 1e-15, 3, inv, found)
+    assert all(torch.equal(x, y) for x, y in zip(a, before))
+    assert torch.equal(out.view(ne, 2, W), a[3].view(ne, 2, Hp)[..., :W])
+    # unpack: the first W grids of every (entry, f) row are replaced, the others stay
+    tab = torch.randn((ne, 2, Hp), device=cuda, generator=g).half()
+    keep = tab.clone()
+    ops.unpack_width(gp.reshape(-1), ne, W, Hp, tab)
+    assert torch.equal(tab[..., :W], gp) and torch.equal(tab[..., W:], keep[..., W:])
+
+
+def test_sharded_step_follows_the_window(cuda, single_rank_group):
+    """ShardedTableAdam with a window schedule (1, 1, 1.5, 2.5, 6): the exchange widens 1, 1, 2, 4, full and the tables are
+    those of the optimizer that always exchanges every grid, bit for bit."""
+    from nersemble_amd.engine.sharded_adam import ShardedTableAdam
+    B, T, H = 4000, 7, 8
+    g = torch.Generator(device=cuda).manual_seed(2)
+    x = torch.rand((B, 3), device=cuda, generator=g)
+    emb = torch.randn((T, H), device=cuda, generator=g)
+    slot = torch.randint(0, T, (B,), device=cuda, generator=g, dtype=torch.int32)
+    dout = torch.randn((B, 12), device=cuda, generator=g).half()
+    scale = 1024.0
+    now = {"w": None}
+    a, b = _he(H, cuda), _he(H, cuda)
+    opt_a = ShardedTableAdam(a, lr=5e-3, eps=1e-15, world_size=1, rank=0)
+    opt_b = ShardedTableAdam(b, lr=5e-3, eps=1e-15, world_size=1, rank=0, width_source=lambda: now["w"])
+    inv = torch.tensor([1.0 / scale], device=cuda)
+    widths = []
+    for w in (1.0, 1.0, 1.5, 2.5, 6.0):
+        now["w"] = w
+        for he, opt in ((a, opt_a), (b, opt_b)):
+            found = torch.zeros(1, device=cuda)
+            opt.zero_grad()
+            he(x, emb, window_hash_encodings=w, code_index=slot).backward(dout * scale)
+            opt.check_finite(found)
+            opt.step(found_inf=found, inv_scale=inv)
+            assert found.item() == 0
+        widths.append(opt_b._last_width)
+        # (the scatter's fp32 atomics run in another order in the two runs: equal up to that, as two runs of ONE optimizer are)
+        d = (a.half_tables().float() - b.half_tables().float()).abs()
+        assert (d == 0).float().mean().item() >= 0.999, (w, d.max().item())
+    assert widths == [1, 1, 2, 4, 8]
+    ba, bb = opt_a._buffers(), opt_b._buffers()
+    assert (bb["exp_avg"].view(-1, 8)[:, 6:] == 0).all()              # grids the window never reached
+    assert torch.allclose(ba["exp_avg"], bb["exp_avg"], rtol=1e-3, atol=1e-7)
