@@ -30,7 +30,7 @@ extern "C" {
 
 #define NSX_MAX_LEVELS 32
 #define NSX_MAX_SLOTS 64
-#define NSX_VERSION 111
+#define NSX_VERSION 112
 
 typedef uint16_t nsx_half;
 
@@ -510,6 +510,20 @@ int nsx_multi_unscale_check(const nsx_tensor_ref* tensors_host, int n_tensors, i
                             float* found_inf /* [n_groups] */, void* stream);
 int nsx_multi_adam(const nsx_tensor_ref* tensors_host, int n_tensors, const nsx_adam_group* groups_host, int n_groups,
                    const float* found_inf /* [n_groups], may be NULL */, void* stream);
+
+/* torch.amp.GradScaler.update() for the step's found_inf flags (nersemble_trainer.py:186-203: one scale update from all
+ * optimizer groups) in ONE launch: total = sum(found_inf[0..n_groups)); the scale backs off when total != 0, grows after
+ * growth_interval clean steps (torch._amp_update_scale_'s rules, the growth only if the result is finite); found_inf is
+ * copied to found_copy (may be NULL; what the host reads one step late); clear_flags [n_groups] (may be NULL, may be
+ * found_inf itself) is zeroed -- the NEXT step's flag buffer; *inv_scale (may be NULL) = 1 / new scale in double precision,
+ * rounded -- the next step's; the new scale is also written to the n_mirrors device addresses of scale_mirrors_host (places
+ * that cache it, e.g. the one-hot loss gradient a backward starts from).  A table optimizer that runs on another stream
+ * still reads THIS step's flags and 1 / scale while the update executes: give the next step its own buffers (two slots in
+ * turn).  enabled = 0: the scale stays (a disabled scaler), flags and derived values are still handled. */
+#define NSX_MAX_SCALE_MIRRORS 8
+int nsx_grad_scaler_update(const float* found_inf, int n_groups, float* scale, int32_t* growth_tracker, float* inv_scale,
+                           float* found_copy, float* clear_flags, float* const* scale_mirrors_host, int n_mirrors,
+                           float growth_factor, float backoff_factor, int growth_interval, int enabled, void* stream);
 
 /* Debug/parity helper: the 8 level-local entry indices per (sample, level), uint32 [B][L][8] -- what tcnn's HashGrid
  * (instantiated at hash_ensemble.py:42-50; algorithm: SURVEY.md A.1) computes internally.  Integer outputs are held

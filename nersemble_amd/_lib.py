@@ -35,6 +35,7 @@ class GridGeom(C.Structure):
 _GEOM_P = C.POINTER(GridGeom)
 NSX_MAX_TENSORS = 64
 NSX_MAX_GROUPS = 8
+NSX_MAX_SCALE_MIRRORS = 8
 
 
 class TensorRef(C.Structure):
@@ -144,6 +145,8 @@ SIGNATURES = {
     "nsx_adam_dense_f16grad_width": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                              c_float, c_float, c_float, c_float, c_int64, c_void_p, c_void_p, c_void_p]),
     "nsx_tables_unpack_width": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p]),
+    "nsx_grad_scaler_update": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                       c_float, c_float, c_int, c_int, c_void_p]),
     "nsx_adam_hash_factored": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_void_p, c_int, _GEOM_P, c_void_p, c_void_p,
                                        c_void_p, c_void_p, c_float, c_float, c_float, c_float, c_int64, c_void_p,
                                        c_void_p, c_void_p]),

@@ -367,6 +367,49 @@ __global__ __launch_bounds__(256) void multi_unscale_check_kernel(TensorTable T,
     if (__any(bad) && (threadIdx.x & 63) == 0) found_inf[r.group] = 1.0f;
 }
 
+// torch.amp.GradScaler.update (torch._amp_update_scale_ on the sum of the groups' flags) + everything the next step
+// derives from the scale, in one single-thread launch: the flags are copied out for the host's deferred read and cleared
+// for the next step, 1 / scale is refreshed, and the new scale is written to every place that caches it (the one-hot
+// loss gradient the backward starts from).
+struct ScaleMirrors {
+    float* p[NSX_MAX_SCALE_MIRRORS];
+    int n;
+};
+__global__ void grad_scaler_update_kernel(const float* found_inf, int n_groups, float* __restrict__ scale,
+                                          int32_t* __restrict__ growth_tracker, float* inv_scale, float* found_copy,
+                                          float* clear_flags, ScaleMirrors M, float growth_factor, float backoff_factor,
+                                          int growth_interval, int enabled) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float total = 0.f;
+    for (int i = 0; i < n_groups; ++i) {
+        const float f = found_inf[i];
+        total += f;
+        if (found_copy) found_copy[i] = f;
+    }
+    if (clear_flags) {
+        for (int i = 0; i < n_groups; ++i) clear_flags[i] = 0.f;
+    }
+    float s = scale[0];
+    if (enabled) {
+        if (total != 0.f) {
+            s = s * backoff_factor;
+            growth_tracker[0] = 0;
+        } else {
+            const int successful = growth_tracker[0] + 1;
+            if (successful == growth_interval) {
+                const float grown = s * growth_factor;
+                if (isfinite(grown)) s = grown;
+                growth_tracker[0] = 0;
+            } else {
+                growth_tracker[0] = successful;
+            }
+        }
+        scale[0] = s;
+    }
+    if (inv_scale) inv_scale[0] = (float)(1.0 / (double)s);
+    for (int k = 0; k < M.n; ++k) M.p[k][0] = s;
+}
+
 __global__ __launch_bounds__(256) void multi_adam_kernel(TensorTable T, GroupHyper H, const float* __restrict__ found_inf) {
     const nsx_tensor_ref r = T.t[blockIdx.y];
     const float* g = reinterpret_cast<const float*>(r.grad);
@@ -678,6 +721,26 @@ int nsx_multi_adam(const nsx_tensor_ref* tensors_host, int n_tensors, const nsx_
     hipLaunchKernelGGL(multi_adam_kernel, dim3((unsigned)bx, (unsigned)n_tensors), dim3(256), 0, (hipStream_t)stream, T, H,
                        found_inf);
     NSX_LAUNCH_CHECK("nsx_multi_adam launch");
+    return NSX_OK;
+}
+
+int nsx_grad_scaler_update(const float* found_inf, int n_groups, float* scale, int32_t* growth_tracker, float* inv_scale,
+                           float* found_copy, float* clear_flags, float* const* scale_mirrors_host, int n_mirrors,
+                           float growth_factor, float backoff_factor, int growth_interval, int enabled, void* stream) {
+    NSX_REQUIRE(found_inf && scale && growth_tracker, "nsx_grad_scaler_update: NULL argument");
+    NSX_REQUIRE(n_groups >= 1 && n_groups <= NSX_MAX_GROUPS, "nsx_grad_scaler_update: n_groups=%d not in [1,%d]", n_groups,
+                NSX_MAX_GROUPS);
+    NSX_REQUIRE(n_mirrors >= 0 && n_mirrors <= NSX_MAX_SCALE_MIRRORS && (n_mirrors == 0 || scale_mirrors_host),
+                "nsx_grad_scaler_update: n_mirrors=%d not in [0,%d]", n_mirrors, NSX_MAX_SCALE_MIRRORS);
+    NSX_REQUIRE(growth_interval >= 1, "nsx_grad_scaler_update: growth_interval must be >= 1");
+    ScaleMirrors M;
+    M.n = n_mirrors;
+    for (int k = 0; k < NSX_MAX_SCALE_MIRRORS; ++k) M.p[k] = k < n_mirrors ? scale_mirrors_host[k] : nullptr;
+    for (int k = 0; k < n_mirrors; ++k) NSX_REQUIRE(M.p[k], "nsx_grad_scaler_update: mirror %d is NULL", k);
+    hipLaunchKernelGGL(grad_scaler_update_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, found_inf, n_groups, scale,
+                       growth_tracker, inv_scale, found_copy, clear_flags, M, growth_factor, backoff_factor, growth_interval,
+                       enabled);
+    NSX_LAUNCH_CHECK("nsx_grad_scaler_update launch");
     return NSX_OK;
 }
 

@@ -13,6 +13,7 @@ from typing import List, Optional
 
 import torch
 
+from .. import _lib
 from .. import functional as F
 from .._lib import check, lib, ptr, stream
 from ..field_components.hash_ensemble import HashEnsemble
@@ -312,6 +313,34 @@ class NativeGradScaler:
             if self._scale.is_cuda:
                 self.inv_scale()              # the next step's reciprocal now (queued behind the update, off its path)
         return total
+
+    def update_native(self, found_all: torch.Tensor, found_copy: Optional[torch.Tensor], next_flags: torch.Tensor,
+                      next_inv: torch.Tensor) -> None:
+        """``update`` as ONE launch (``nsx_grad_scaler_update``): sum of the flags, scale / growth-tracker update, the
+        flags copied to ``found_copy``, the NEXT step's flag buffer cleared and its 1 / scale written, and the one-hot loss
+        gradients (``loss_grad_vector``) rewritten IN PLACE.  The torch route (a clone, two adds, ``_amp_update_scale_``,
+        three ops for the reciprocal, a fill for the next step's flags) costs ~0.09 ms of host time per step, which is
+        what paces a step once the occupancy grid has pruned the scene.  ``found_all`` / this step's 1 / scale are left
+        alone: the table optimizer reads them on its own stream while this kernel runs (the caller alternates two slots).
+        The kernel does not bump ``_scale``'s version counter, so the cached loss gradients stay the current ones; a
+        torch-side write to ``_scale`` (``load_state_dict``) bumps it and they are rebuilt."""
+        cache = self.__dict__.setdefault("_derived", {})
+        cache.pop("inv", None)                               # (the cached reciprocal is not kept current on this route)
+        stamp = (self._scale._version, self._scale.data_ptr())
+        ptrs = tuple(t.data_ptr() + 4 * key[2] for key, (st, t) in cache.items()
+                     if isinstance(key, tuple) and key[0] == "grad" and st == stamp)
+        if len(ptrs) > _lib.NSX_MAX_SCALE_MIRRORS:
+            for key in [k for k in cache if isinstance(k, tuple) and k[0] == "grad"]:
+                del cache[key]                               # (rebuilt on their next use)
+            ptrs = ()
+        arr = self.__dict__.get("_mirror_arr")
+        if arr is None or arr[0] != ptrs:
+            arr = self._mirror_arr = (ptrs, (C.c_void_p * max(1, len(ptrs)))(*ptrs))
+        check(lib().nsx_grad_scaler_update(ptr(found_all), found_all.numel(), ptr(self._scale), ptr(self._growth_tracker),
+                                           ptr(next_inv), ptr(found_copy), ptr(next_flags), arr[1], len(ptrs),
+                                           float(self.growth_factor), float(self.backoff_factor),
+                                           int(self.growth_interval), int(self.enabled), stream()),
+              "nsx_grad_scaler_update")
 
     def get_scale(self) -> float:
         return float(self._scale.item())

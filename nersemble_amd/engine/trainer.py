@@ -144,6 +144,7 @@ class NeRSembleTrainer:
         self.grad_scaler = NativeGradScaler(device, enabled=mixed_precision)
         self.callbacks = model.get_training_callbacks()
         self._pending, self._found_host, self._found_event = None, None, None
+        self._flag_state = None       # persistent found_inf flags of the native scale update
         self._presence, self._presence_host = None, None      # data-parallel: ranks per parameter that held a gradient
         # the table optimizer's 12 GB pass runs beside the rest of the step's tail and the next step's ray marching
         self._opt_stream = torch.cuda.Stream(device) if (overlap_table_adam and device.type == "cuda") else None
@@ -197,14 +198,39 @@ class NeRSembleTrainer:
         self.flush_scheduler_step()        # the learning rates of this step depend on the previous step's outcome
         scaler = self.grad_scaler
         groups = sorted(set(self.group_of.values()))
+        native_update = False
         if early is not None:
             found_all, inv_scale = early
             dev = inv_scale.device
+            found = {g: found_all[i:i + 1] for i, g in enumerate(groups)}
         else:
-            inv_scale = scaler.inv_scale()
-            dev = inv_scale.device
-            found_all = torch.zeros((len(groups),), dtype=torch.float32, device=dev)
-        found = {g: found_all[i:i + 1] for i, g in enumerate(groups)}
+            native_update = isinstance(scaler, NativeGradScaler) and scaler._scale.is_cuda
+            dev = scaler._scale.device
+            if native_update:
+                # the flags and 1 / scale live in TWO persistent slots used in turn: the scale update of step n
+                # (nsx_grad_scaler_update) copies step n's flags out, clears slot n + 1 and writes ITS 1 / scale, while the
+                # table optimizer of step n may still be reading slot n on its own stream (it has finished before the
+                # HashEnsemble forward of step n + 1, i.e. long before slot n is written again at the end of that step)
+                st = self._flag_state
+                stamp = (scaler._scale._version, scaler._scale.data_ptr())
+                if st is None or st["groups"] != groups or st["copy"].device != dev:
+                    slots = []
+                    for _ in range(2):
+                        all_ = torch.zeros((len(groups),), dtype=torch.float32, device=dev)
+                        slots.append({"all": all_, "views": {g: all_[i:i + 1] for i, g in enumerate(groups)},
+                                      "inv": scaler.inv_scale().clone()})
+                    st = self._flag_state = {"groups": groups, "slots": slots, "turn": 0, "stamp": stamp,
+                                             "copy": torch.zeros((len(groups),), dtype=torch.float32, device=dev)}
+                elif st["stamp"] != stamp:                       # the scale was written from torch (load_state_dict)
+                    st["slots"][st["turn"]]["inv"].copy_(scaler.inv_scale())
+                    st["stamp"] = stamp
+                slot = st["slots"][st["turn"]]
+                found_all, found, inv_scale = slot["all"], slot["views"], slot["inv"]
+            else:
+                inv_scale = scaler.inv_scale()
+                dev = inv_scale.device
+                found_all = torch.zeros((len(groups),), dtype=torch.float32, device=dev)
+                found = {g: found_all[i:i + 1] for i, g in enumerate(groups)}
         table_opt = self.optimizers.get(self.group_of_tables() or "")
         stepped_early = isinstance(table_opt, HashTableAdam) and table_opt.stepped_early
         if isinstance(table_opt, HashTableAdam):
@@ -250,8 +276,14 @@ class NeRSembleTrainer:
             for net in (getattr(field, "mlp_base", None), getattr(field, "mlp_head", None)):
                 if net is not None and hasattr(net, "half_weights") and net.params.is_cuda:
                     net.half_weights()
-        scaler.update(list(found.values()))
         self._found_groups = groups
+        if native_update:
+            st = self._flag_state
+            nxt = st["slots"][1 - st["turn"]]
+            scaler.update_native(found_all, st["copy"], nxt["all"], nxt["inv"])
+            st["turn"] = 1 - st["turn"]
+            return st["copy"]
+        scaler.update(list(found.values()))
         return found_all
 
     def train_iteration(self, step: int, ray_bundle: RayBundle, batch: Dict[str, torch.Tensor],

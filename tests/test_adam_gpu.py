@@ -279,3 +279,40 @@ def test_optimizer_pass_consumes_the_factored_gradient(cuda):
     opt_a.step(found_inf=torch.ones(1, device=cuda), inv_scale=inv)
     assert torch.equal(a.tables.detach(), before)
     assert not G.any().item()
+
+
+def test_native_scale_update_is_torchs_amp_update(cuda):
+    """nsx_grad_scaler_update against torch._amp_update_scale_ over a sequence of clean and poisoned steps (growth every 3
+    clean steps, back-off on a flag of ANY group): scale and growth tracker bit for bit; the flags are copied out, the next
+    step's buffer is cleared, 1 / scale and the mirrors of the scale follow."""
+    from nersemble_amd.engine.hash_adam import NativeGradScaler
+    a = NativeGradScaler(cuda, init_scale=1024.0, growth_interval=3)
+    b_scale = torch.full((), 1024.0, device=cuda)
+    b_track = torch.zeros((), dtype=torch.int32, device=cuda)
+    g = a.loss_grad_vector(8, 5)                              # a cached one-hot loss gradient: must follow the scale
+    assert g[5].item() == 1024.0 and g.sum().item() == 1024.0
+    slots = [torch.zeros(3, device=cuda), torch.zeros(3, device=cuda)]
+    invs = [torch.ones(1, device=cuda), torch.ones(1, device=cuda)]
+    copy = torch.full((3,), -1.0, device=cuda)
+    pattern = [0, 0, 0, 0, 1, 0, 0, 2, 0, 0, 0, 0, 0, 0]       # group that raises a flag (0: none)
+    turn = 0
+    for step, bad in enumerate(pattern):
+        cur, nxt = slots[turn], slots[1 - turn]
+        assert cur.abs().sum().item() == 0                     # cleared by the previous update
+        if bad:
+            cur[bad] = 1.0
+        nxt.fill_(7.0)                                         # (stale content the update must clear)
+        want_flags = cur.clone()
+        a.update_native(cur, copy, nxt, invs[1 - turn])
+        torch._amp_update_scale_(b_scale, b_track, want_flags.sum().reshape(()), 2.0, 0.5, 3)
+        assert a._scale.item() == b_scale.item() and a._growth_tracker.item() == b_track.item(), step
+        assert torch.equal(copy, want_flags) and torch.equal(cur, want_flags)      # this step's flags stay readable
+        assert nxt.abs().sum().item() == 0
+        assert invs[1 - turn].item() == 1.0 / b_scale.item()
+        assert a.loss_grad_vector(8, 5) is g and g[5].item() == b_scale.item() and g.sum().item() == b_scale.item()
+        turn = 1 - turn
+    assert a.get_scale() == b_scale.item() != 1024.0
+    # a torch-side write to the scale is noticed: the cached gradient is rebuilt
+    a.load_state_dict({"scale": 64.0, "_growth_tracker": 1})
+    g2 = a.loss_grad_vector(8, 5)
+    assert g2 is not g and g2[5].item() == 64.0
