@@ -5,6 +5,7 @@ from scripts/train/train_nersemble.py:243-256.  Adds what the reference lacks: d
 process per GPU, gradients averaged with RCCL all-reduce over xGMI.
 """
 import functools
+import os
 from dataclasses import dataclass
 from typing import Dict, Optional, Tuple
 
@@ -29,6 +30,9 @@ class OptimizerConfig:
     gamma_fields: float = 0.8
     gamma_deformation_field: float = 0.5
     gamma_embeddings: float = 0.8
+
+
+_NATIVE_SCALE_UPDATE = os.environ.get("NSX_NATIVE_SCALER", "1") != "0"      # (A/B knob: the torch route of GradScaler.update)
 
 
 class StepLR:
@@ -204,7 +208,7 @@ class NeRSembleTrainer:
             dev = inv_scale.device
             found = {g: found_all[i:i + 1] for i, g in enumerate(groups)}
         else:
-            native_update = isinstance(scaler, NativeGradScaler) and scaler._scale.is_cuda
+            native_update = isinstance(scaler, NativeGradScaler) and scaler._scale.is_cuda and _NATIVE_SCALE_UPDATE
             dev = scaler._scale.device
             if native_update:
                 # the flags and 1 / scale live in TWO persistent slots used in turn: the scale update of step n
