@@ -677,6 +677,115 @@ __global__ __launch_bounds__(NWF * 64, 2) void deform_fwd2_kernel(DeformArgs A, 
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// forward kernel, round 4 (third attempt at the 40 % matrix-core duty of deform_fwd_kernel): the two waves of a SIMD in
+// ANTI-PHASE inside the lock-stepped block.  One barrier per weight stage keeps the 8 waves on the same stage, which is
+// what lets the weights cross L2 -> LDS once per 256 samples -- but it also keeps the two waves of a SIMD in the same
+// PHASE: both in the layer's MFMA stream, then both in its epilogue (cvt / ReLU / bias reload; the positional encoding; the
+// SE(3) tail), and the matrix cores idle through every epilogue.  Here half of the waves ("late": one of the two on every
+// SIMD) run the epilogue of a layer at the BEGINNING of the next stage's interval, in front of that stage's MFMAs -- their
+// accumulators live across the barrier -- and the SE(3) tail + store of a tile at the beginning of the next tile.  In every
+// interval one wave of a SIMD then streams MFMAs while the other runs VALU work, and vice versa; stages, barriers, LDS
+// footprint and the order of the MFMAs of a tile are deform_fwd_kernel's: outputs are bit-identical.
+// GMODE: which waves are late -- 0: waves 4..7 (a workgroup's waves go to the SIMDs round-robin: w and w + 4 share one),
+// 1: the odd waves (if they are placed in pairs).
+// ---------------------------------------------------------------------------------------------------------
+template <int GMODE>
+__global__ __launch_bounds__(NW * 64, 1) void deform_fwd_skew_kernel(DeformArgs A, float* __restrict__ offsets,
+                                                                   int64_t n_tiles, const int64_t* __restrict__ n_dev) {
+    NSX_DEVICE_COUNT(A.S, n_tiles, 32, n_dev);
+    __shared__ __attribute__((aligned(16))) DeformLds L;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int kb = lane >> 5;
+    const bool late = GMODE == 0 ? (wave >= NW / 2) : ((wave & 1) != 0);      // wave-uniform
+    const int64_t n_groups = (n_tiles + NW - 1) / NW;
+    lds_prologue(A, L, F0, 44);
+    int cur = 0;
+    // the late waves' finished tile whose SE(3) tail is still to run
+    float p_r[3] = {0.f, 0.f, 0.f}, p_v[3] = {0.f, 0.f, 0.f}, p_pn[3] = {0.f, 0.f, 0.f};
+    int64_t p_b = -1;
+    auto emit = [&](const float r[3], const float v[3], const float pn[3], int64_t b) {
+        float w[3];
+        se3_apply(r, v, pn, w);
+        if (b >= 0 && kb == 0) {
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                const float wd = (w[d] != w[d]) ? pn[d] : w[d];            // NaN deformation -> keep the point
+                offsets[b * 3 + d] = wd - pn[d];
+            }
+        }
+    };
+    for (int64_t grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {        // all waves iterate together
+        const int64_t tile = grp * NW + wave;
+        const int64_t b_raw = tile * 32 + (lane & 31);
+        const int64_t b = b_raw < A.S ? b_raw : A.S - 1;
+        lds_cfloat* bias = launder_lds(L.bias);
+        f16x8 x[DF_TIN], h[DF_TW];
+        f32x16 acc[4];
+        float pn[3];
+        // ---- interval 0: W0 over the input
+        stage_issue(A.frags, F1, 32, L.w[cur ^ 1]);
+        if (late) {
+            emit(p_r, p_v, p_pn, p_b);
+            p_b = -1;
+        }
+        build_input(A, b, kb, pn, x);
+        acc_init(acc, bias + 0 * DFW, kb);
+        gemm_layer_lds<DF_TIN, 1>(L.w[cur], 0, lane, x, acc);
+        if (!late) finish_layer<false>(acc, h);
+        stage_flip(cur);
+        // ---- intervals 1..3: W1..W3
+#pragma unroll 1
+        for (int l = 1; l <= 3; ++l) {
+            stage_issue(A.frags, l == 1 ? F2 : (l == 2 ? F3 : F4), l == 3 ? 44 : 32, L.w[cur ^ 1]);
+            if (late) finish_layer<false>(acc, h);                             // the previous layer's epilogue
+            acc_init(acc, bias + l * DFW, kb);
+            gemm_layer_lds<DF_TW, 1>(L.w[cur], 0, lane, h, acc);
+            if (!late) finish_layer<false>(acc, h);
+            stage_flip(cur);
+        }
+        // ---- interval 4: W4 over the input
+        stage_issue(A.frags, F4X, 32, L.w[cur ^ 1]);
+        if (late) finish_layer<false>(acc, h);                                 // L3's epilogue
+        acc_init(acc, bias + 4 * DFW, kb);
+        gemm_layer_lds<DF_TIN, 1>(L.w[cur], 0, lane, x, acc);
+        stage_flip(cur);
+        // ---- interval 5: W4 over x
+        stage_issue(A.frags, F5, 40, L.w[cur ^ 1]);
+        gemm_layer_lds<DF_TW, 1>(L.w[cur], 0, lane, h, acc);
+        if (!late) finish_layer<false>(acc, h);
+        stage_flip(cur);
+        // ---- interval 6: W5 (+ out_activation ReLU) and the heads
+        stage_issue(A.frags, F0, 44, L.w[cur ^ 1]);                            // the next tile's first stage
+        if (late) finish_layer<false>(acc, h);                                 // L4's epilogue
+        acc_init(acc, bias + 5 * DFW, kb);
+        gemm_layer_lds<DF_TW, 1>(L.w[cur], 0, lane, h, acc);
+        finish_layer<false>(acc, h);
+        f32x16 o = zero16();
+#pragma unroll
+        for (int t = 0; t < DF_TW; ++t) o = mfma(L.w[cur][(32 + t) * 64 + lane], h[t], o);
+        float own[4], oth[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) own[r] = (float)(half_t)(o[r] + bias[6 * DFW + acc_row(r, kb)]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) oth[r] = __shfl_xor(own[r], 32);
+        // rows 0..3 live on kb = 0, rows 4..7 on kb = 1
+        float rr[3], vv[3];
+        rr[0] = kb ? oth[0] : own[0]; rr[1] = kb ? oth[1] : own[1]; rr[2] = kb ? oth[2] : own[2];
+        vv[0] = kb ? oth[3] : own[3]; vv[1] = kb ? own[0] : oth[0]; vv[2] = kb ? own[1] : oth[1];
+        const int64_t b_out = b_raw < A.S ? b : -1;
+        if (!late) {
+            emit(rr, vv, pn, b_out);
+        } else {
+#pragma unroll
+            for (int d = 0; d < 3; ++d) { p_r[d] = rr[d]; p_v[d] = vv[d]; p_pn[d] = pn[d]; }
+            p_b = b_out;
+        }
+        stage_flip(cur);
+    }
+    if (late) emit(p_r, p_v, p_pn, p_b);
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // backward chain kernel: writes per-tile a0..a6, dZ0..dZ5, dZheads, dCode tiles
 // ---------------------------------------------------------------------------------------------------------
 // per sample-tile scratch layout (halfs), the input tile first:
@@ -1374,7 +1483,8 @@ int nsx_deform_fwd(const void* packed, const float* positions, int64_t S, const 
     fill_args(A, positions, S, aabb_host, code, code_stride, code_slot, window7_host, packed, bias);
     const int64_t n_tiles = (S + 31) / 32;
     // NSX_DEFORM_FWD (A/B): 1 = one 8-wave block per CU, LDS reads scheduled by the compiler (rounds 1-3); 3 = the same with
-    // the weight fragments read two K-steps ahead, pinned; 2 = two independent 4-wave blocks per CU
+    // the weight fragments read two K-steps ahead, pinned; 2 = two independent 4-wave blocks per CU; 4 / 5 = the two waves of
+    // a SIMD in anti-phase (late waves = 4..7 / the odd ones)
     static const int variant = [] {
         const char* e = getenv("NSX_DEFORM_FWD");
         return e ? atoi(e) : 1;
@@ -1382,7 +1492,13 @@ int nsx_deform_fwd(const void* packed, const float* positions, int64_t S, const 
     if (variant != 2) {
         int64_t blocks = (n_tiles + NW - 1) / NW;
         if (blocks > num_cus()) blocks = num_cus();
-        if (variant == 3)
+        if (variant == 4)
+            hipLaunchKernelGGL(deform_fwd_skew_kernel<0>, dim3((unsigned)blocks), dim3(NW * 64), 0, (hipStream_t)stream, A,
+                               offsets, n_tiles, n_device);
+        else if (variant == 5)
+            hipLaunchKernelGGL(deform_fwd_skew_kernel<1>, dim3((unsigned)blocks), dim3(NW * 64), 0, (hipStream_t)stream, A,
+                               offsets, n_tiles, n_device);
+        else if (variant == 3)
             hipLaunchKernelGGL(deform_fwd_kernel<2>, dim3((unsigned)blocks), dim3(NW * 64), 0, (hipStream_t)stream, A, offsets,
                                n_tiles, n_device);
         else
