@@ -689,17 +689,56 @@ __global__ __launch_bounds__(NWF * 64, 2) void deform_fwd2_kernel(DeformArgs A, 
 // GMODE: which waves are late -- 0: waves 4..7 (a workgroup's waves go to the SIMDs round-robin: w and w + 4 share one),
 // 1: the odd waves (if they are placed in pairs).
 // ---------------------------------------------------------------------------------------------------------
-template <int GMODE>
+// PROBE != 0: TIMING PROBES, results are wrong on purpose (tools/deform_fwd_ab.py --variants 1,6,7,8,9): which resource
+// the layer GEMMs wait for.  1: one weight-fragment read per K-step instead of four (LDS reads / 4); 2: none (the MFMAs
+// take the activation fragment as both operands); 3: half of the MFMAs (all fragments still read); 4: no block barrier
+// between the stages.
+template <int KT, int PROBE>
+__device__ __forceinline__ void gemm_layer_probe(const f16x8* lds, int lane, const f16x8* in, f32x16 acc[4]) {
+    if constexpr (PROBE == 0 || PROBE == 4) {
+        gemm_layer_lds<KT, 1>(lds, 0, lane, in, acc);
+    } else {
+        const f16x8* base = lds + lane;
+#pragma unroll
+        for (int t = 0; t < KT; ++t) {
+            f16x8 a[4];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                if (PROBE == 1) a[mt] = base[(0 * KT + t) * 64];
+                else if (PROBE == 2) a[mt] = in[t];
+                else a[mt] = base[(mt * KT + t) * 64];
+            }
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                if (PROBE == 3 && mt >= 2) {
+                    asm volatile("" ::"v"(a[mt]));                 // (the read stays)
+                    continue;
+                }
+                acc[mt] = mfma(a[mt], in[t], acc[mt]);
+            }
+        }
+    }
+}
+
+template <int GMODE, int PROBE = 0>
 __global__ __launch_bounds__(NW * 64, 1) void deform_fwd_skew_kernel(DeformArgs A, float* __restrict__ offsets,
                                                                    int64_t n_tiles, const int64_t* __restrict__ n_dev) {
     NSX_DEVICE_COUNT(A.S, n_tiles, 32, n_dev);
     __shared__ __attribute__((aligned(16))) DeformLds L;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int kb = lane >> 5;
-    const bool late = GMODE == 0 ? (wave >= NW / 2) : ((wave & 1) != 0);      // wave-uniform
+    const bool late = GMODE == 2 ? false : (GMODE == 0 ? (wave >= NW / 2) : ((wave & 1) != 0));      // wave-uniform
     const int64_t n_groups = (n_tiles + NW - 1) / NW;
     lds_prologue(A, L, F0, 44);
     int cur = 0;
+    auto flip = [&](int& c) {
+        if constexpr (PROBE == 4) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            c ^= 1;
+        } else {
+            stage_flip(c);
+        }
+    };
     // the late waves' finished tile whose SE(3) tail is still to run
     float p_r[3] = {0.f, 0.f, 0.f}, p_v[3] = {0.f, 0.f, 0.f}, p_pn[3] = {0.f, 0.f, 0.f};
     int64_t p_b = -1;
@@ -730,35 +769,35 @@ __global__ __launch_bounds__(NW * 64, 1) void deform_fwd_skew_kernel(DeformArgs 
         }
         build_input(A, b, kb, pn, x);
         acc_init(acc, bias + 0 * DFW, kb);
-        gemm_layer_lds<DF_TIN, 1>(L.w[cur], 0, lane, x, acc);
+        gemm_layer_probe<DF_TIN, PROBE>(L.w[cur], lane, x, acc);
         if (!late) finish_layer<false>(acc, h);
-        stage_flip(cur);
+        flip(cur);
         // ---- intervals 1..3: W1..W3
 #pragma unroll 1
         for (int l = 1; l <= 3; ++l) {
             stage_issue(A.frags, l == 1 ? F2 : (l == 2 ? F3 : F4), l == 3 ? 44 : 32, L.w[cur ^ 1]);
             if (late) finish_layer<false>(acc, h);                             // the previous layer's epilogue
             acc_init(acc, bias + l * DFW, kb);
-            gemm_layer_lds<DF_TW, 1>(L.w[cur], 0, lane, h, acc);
+            gemm_layer_probe<DF_TW, PROBE>(L.w[cur], lane, h, acc);
             if (!late) finish_layer<false>(acc, h);
-            stage_flip(cur);
+            flip(cur);
         }
         // ---- interval 4: W4 over the input
         stage_issue(A.frags, F4X, 32, L.w[cur ^ 1]);
         if (late) finish_layer<false>(acc, h);                                 // L3's epilogue
         acc_init(acc, bias + 4 * DFW, kb);
-        gemm_layer_lds<DF_TIN, 1>(L.w[cur], 0, lane, x, acc);
-        stage_flip(cur);
+        gemm_layer_probe<DF_TIN, PROBE>(L.w[cur], lane, x, acc);
+        flip(cur);
         // ---- interval 5: W4 over x
         stage_issue(A.frags, F5, 40, L.w[cur ^ 1]);
-        gemm_layer_lds<DF_TW, 1>(L.w[cur], 0, lane, h, acc);
+        gemm_layer_probe<DF_TW, PROBE>(L.w[cur], lane, h, acc);
         if (!late) finish_layer<false>(acc, h);
-        stage_flip(cur);
+        flip(cur);
         // ---- interval 6: W5 (+ out_activation ReLU) and the heads
         stage_issue(A.frags, F0, 44, L.w[cur ^ 1]);                            // the next tile's first stage
         if (late) finish_layer<false>(acc, h);                                 // L4's epilogue
         acc_init(acc, bias + 5 * DFW, kb);
-        gemm_layer_lds<DF_TW, 1>(L.w[cur], 0, lane, h, acc);
+        gemm_layer_probe<DF_TW, PROBE>(L.w[cur], lane, h, acc);
         finish_layer<false>(acc, h);
         f32x16 o = zero16();
 #pragma unroll
@@ -780,7 +819,7 @@ __global__ __launch_bounds__(NW * 64, 1) void deform_fwd_skew_kernel(DeformArgs 
             for (int d = 0; d < 3; ++d) { p_r[d] = rr[d]; p_v[d] = vv[d]; p_pn[d] = pn[d]; }
             p_b = b_out;
         }
-        stage_flip(cur);
+        flip(cur);
     }
     if (late) emit(p_r, p_v, p_pn, p_b);
 }
@@ -1498,6 +1537,11 @@ int nsx_deform_fwd(const void* packed, const float* positions, int64_t S, const 
         else if (variant == 5)
             hipLaunchKernelGGL(deform_fwd_skew_kernel<1>, dim3((unsigned)blocks), dim3(NW * 64), 0, (hipStream_t)stream, A,
                                offsets, n_tiles, n_device);
+        else if (variant >= 6 && variant <= 9) {               // timing probes (wrong results on purpose)
+            auto k = variant == 6 ? deform_fwd_skew_kernel<2, 1> : variant == 7 ? deform_fwd_skew_kernel<2, 2>
+                     : variant == 8 ? deform_fwd_skew_kernel<2, 3> : deform_fwd_skew_kernel<2, 4>;
+            hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(NW * 64), 0, (hipStream_t)stream, A, offsets, n_tiles, n_device);
+        }
         else if (variant == 3)
             hipLaunchKernelGGL(deform_fwd_kernel<2>, dim3((unsigned)blocks), dim3(NW * 64), 0, (hipStream_t)stream, A, offsets,
                                n_tiles, n_device);
