@@ -692,7 +692,8 @@ __global__ __launch_bounds__(NWF * 64, 2) void deform_fwd2_kernel(DeformArgs A, 
 // PROBE != 0: TIMING PROBES, results are wrong on purpose (tools/deform_fwd_ab.py --variants 1,6,7,8,9): which resource
 // the layer GEMMs wait for.  1: one weight-fragment read per K-step instead of four (LDS reads / 4); 2: none (the MFMAs
 // take the activation fragment as both operands); 3: half of the MFMAs (all fragments still read); 4: no block barrier
-// between the stages.
+// between the stages; 5: no input construction (positional encoding, code rows) and no SE(3) tail; 6: epilogues without
+// conversion / ReLU.
 template <int KT, int PROBE>
 __device__ __forceinline__ void gemm_layer_probe(const f16x8* lds, int lane, const f16x8* in, f32x16 acc[4]) {
     if constexpr (PROBE == 0 || PROBE == 4) {
@@ -731,6 +732,19 @@ __global__ __launch_bounds__(NW * 64, 1) void deform_fwd_skew_kernel(DeformArgs 
     const int64_t n_groups = (n_tiles + NW - 1) / NW;
     lds_prologue(A, L, F0, 44);
     int cur = 0;
+    auto fin = [&](const f32x16 a4[4], f16x8 hh[DF_TW]) {
+        if constexpr (PROBE == 6) {
+#pragma unroll
+            for (int t = 0; t < DF_TW; ++t) {
+                u32x4 hv;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) hv[q] = __builtin_bit_cast(uint32_t, a4[t >> 1][8 * (t & 1) + 2 * q]) & 0x3BFF3BFFu;
+                hh[t] = __builtin_bit_cast(f16x8, hv);
+            }
+        } else {
+            finish_layer<false>(a4, hh);
+        }
+    };
     auto flip = [&](int& c) {
         if constexpr (PROBE == 4) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -744,7 +758,8 @@ __global__ __launch_bounds__(NW * 64, 1) void deform_fwd_skew_kernel(DeformArgs 
     int64_t p_b = -1;
     auto emit = [&](const float r[3], const float v[3], const float pn[3], int64_t b) {
         float w[3];
-        se3_apply(r, v, pn, w);
+        if constexpr (PROBE == 5) { w[0] = r[0] + v[0]; w[1] = r[1] + v[1]; w[2] = r[2] + v[2]; }
+        else se3_apply(r, v, pn, w);
         if (b >= 0 && kb == 0) {
 #pragma unroll
             for (int d = 0; d < 3; ++d) {
@@ -767,38 +782,46 @@ __global__ __launch_bounds__(NW * 64, 1) void deform_fwd_skew_kernel(DeformArgs 
             emit(p_r, p_v, p_pn, p_b);
             p_b = -1;
         }
-        build_input(A, b, kb, pn, x);
+        if constexpr (PROBE == 5) {
+            pn[0] = pn[1] = pn[2] = 0.25f;
+#pragma unroll
+            for (int t = 0; t < DF_TIN; ++t)
+#pragma unroll
+                for (int q = 0; q < 8; ++q) x[t][q] = (half_t)(float)((lane + t + q) & 7);
+        } else {
+            build_input(A, b, kb, pn, x);
+        }
         acc_init(acc, bias + 0 * DFW, kb);
         gemm_layer_probe<DF_TIN, PROBE>(L.w[cur], lane, x, acc);
-        if (!late) finish_layer<false>(acc, h);
+        if (!late) fin(acc, h);
         flip(cur);
         // ---- intervals 1..3: W1..W3
 #pragma unroll 1
         for (int l = 1; l <= 3; ++l) {
             stage_issue(A.frags, l == 1 ? F2 : (l == 2 ? F3 : F4), l == 3 ? 44 : 32, L.w[cur ^ 1]);
-            if (late) finish_layer<false>(acc, h);                             // the previous layer's epilogue
+            if (late) fin(acc, h);                             // the previous layer's epilogue
             acc_init(acc, bias + l * DFW, kb);
             gemm_layer_probe<DF_TW, PROBE>(L.w[cur], lane, h, acc);
-            if (!late) finish_layer<false>(acc, h);
+            if (!late) fin(acc, h);
             flip(cur);
         }
         // ---- interval 4: W4 over the input
         stage_issue(A.frags, F4X, 32, L.w[cur ^ 1]);
-        if (late) finish_layer<false>(acc, h);                                 // L3's epilogue
+        if (late) fin(acc, h);                                 // L3's epilogue
         acc_init(acc, bias + 4 * DFW, kb);
         gemm_layer_probe<DF_TIN, PROBE>(L.w[cur], lane, x, acc);
         flip(cur);
         // ---- interval 5: W4 over x
         stage_issue(A.frags, F5, 40, L.w[cur ^ 1]);
         gemm_layer_probe<DF_TW, PROBE>(L.w[cur], lane, h, acc);
-        if (!late) finish_layer<false>(acc, h);
+        if (!late) fin(acc, h);
         flip(cur);
         // ---- interval 6: W5 (+ out_activation ReLU) and the heads
         stage_issue(A.frags, F0, 44, L.w[cur ^ 1]);                            // the next tile's first stage
-        if (late) finish_layer<false>(acc, h);                                 // L4's epilogue
+        if (late) fin(acc, h);                                 // L4's epilogue
         acc_init(acc, bias + 5 * DFW, kb);
         gemm_layer_probe<DF_TW, PROBE>(L.w[cur], lane, h, acc);
-        finish_layer<false>(acc, h);
+        fin(acc, h);
         f32x16 o = zero16();
 #pragma unroll
         for (int t = 0; t < DF_TW; ++t) o = mfma(L.w[cur][(32 + t) * 64 + lane], h[t], o);
@@ -1537,9 +1560,10 @@ int nsx_deform_fwd(const void* packed, const float* positions, int64_t S, const 
         else if (variant == 5)
             hipLaunchKernelGGL(deform_fwd_skew_kernel<1>, dim3((unsigned)blocks), dim3(NW * 64), 0, (hipStream_t)stream, A,
                                offsets, n_tiles, n_device);
-        else if (variant >= 6 && variant <= 9) {               // timing probes (wrong results on purpose)
+        else if (variant >= 6 && variant <= 11) {              // timing probes (wrong results on purpose)
             auto k = variant == 6 ? deform_fwd_skew_kernel<2, 1> : variant == 7 ? deform_fwd_skew_kernel<2, 2>
-                     : variant == 8 ? deform_fwd_skew_kernel<2, 3> : deform_fwd_skew_kernel<2, 4>;
+                     : variant == 8 ? deform_fwd_skew_kernel<2, 3> : variant == 9 ? deform_fwd_skew_kernel<2, 4>
+                     : variant == 10 ? deform_fwd_skew_kernel<2, 5> : deform_fwd_skew_kernel<2, 6>;
             hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(NW * 64), 0, (hipStream_t)stream, A, offsets, n_tiles, n_device);
         }
         else if (variant == 3)
