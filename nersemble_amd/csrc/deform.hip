@@ -692,8 +692,8 @@ __global__ __launch_bounds__(NWF * 64, 2) void deform_fwd2_kernel(DeformArgs A, 
 // PROBE != 0: TIMING PROBES, results are wrong on purpose (tools/deform_fwd_ab.py --variants 1,6,7,8,9): which resource
 // the layer GEMMs wait for.  1: one weight-fragment read per K-step instead of four (LDS reads / 4); 2: none (the MFMAs
 // take the activation fragment as both operands); 3: half of the MFMAs (all fragments still read); 4: no block barrier
-// between the stages; 5: no input construction (positional encoding, code rows) and no SE(3) tail; 6: epilogues without
-// conversion / ReLU.
+// between the stages; 5: no input construction (positional encoding, code rows) and no SE(3) tail (7: the first only, 8: the
+// second only); 6: epilogues without conversion / ReLU.
 template <int KT, int PROBE>
 __device__ __forceinline__ void gemm_layer_probe(const f16x8* lds, int lane, const f16x8* in, f32x16 acc[4]) {
     if constexpr (PROBE == 0 || PROBE == 4) {
@@ -758,7 +758,7 @@ __global__ __launch_bounds__(NW * 64, 1) void deform_fwd_skew_kernel(DeformArgs 
     int64_t p_b = -1;
     auto emit = [&](const float r[3], const float v[3], const float pn[3], int64_t b) {
         float w[3];
-        if constexpr (PROBE == 5) { w[0] = r[0] + v[0]; w[1] = r[1] + v[1]; w[2] = r[2] + v[2]; }
+        if constexpr (PROBE == 5 || PROBE == 8) { w[0] = r[0] + v[0]; w[1] = r[1] + v[1]; w[2] = r[2] + v[2]; }
         else se3_apply(r, v, pn, w);
         if (b >= 0 && kb == 0) {
 #pragma unroll
@@ -782,7 +782,7 @@ __global__ __launch_bounds__(NW * 64, 1) void deform_fwd_skew_kernel(DeformArgs 
             emit(p_r, p_v, p_pn, p_b);
             p_b = -1;
         }
-        if constexpr (PROBE == 5) {
+        if constexpr (PROBE == 5 || PROBE == 7) {
             pn[0] = pn[1] = pn[2] = 0.25f;
 #pragma unroll
             for (int t = 0; t < DF_TIN; ++t)
@@ -1560,10 +1560,11 @@ int nsx_deform_fwd(const void* packed, const float* positions, int64_t S, const 
         else if (variant == 5)
             hipLaunchKernelGGL(deform_fwd_skew_kernel<1>, dim3((unsigned)blocks), dim3(NW * 64), 0, (hipStream_t)stream, A,
                                offsets, n_tiles, n_device);
-        else if (variant >= 6 && variant <= 11) {              // timing probes (wrong results on purpose)
+        else if (variant >= 6 && variant <= 13) {              // timing probes (wrong results on purpose)
             auto k = variant == 6 ? deform_fwd_skew_kernel<2, 1> : variant == 7 ? deform_fwd_skew_kernel<2, 2>
                      : variant == 8 ? deform_fwd_skew_kernel<2, 3> : variant == 9 ? deform_fwd_skew_kernel<2, 4>
-                     : variant == 10 ? deform_fwd_skew_kernel<2, 5> : deform_fwd_skew_kernel<2, 6>;
+                     : variant == 10 ? deform_fwd_skew_kernel<2, 5> : variant == 11 ? deform_fwd_skew_kernel<2, 6>
+                     : variant == 12 ? deform_fwd_skew_kernel<2, 7> : deform_fwd_skew_kernel<2, 8>;
             hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(NW * 64), 0, (hipStream_t)stream, A, offsets, n_tiles, n_device);
         }
         else if (variant == 3)
