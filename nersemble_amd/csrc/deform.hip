@@ -194,6 +194,7 @@ struct DeformArgs {
 //   k <  45 : 2 pi pn_d                           (the 2 pi-SCALED input is appended, :72-73)
 //   k < 173 : warp code
 // sin(2 pi x) is the native v_sin_f32 (input in revolutions, range-reduced in hardware).
+template <int BPROBE = 0>
 __device__ __forceinline__ void build_input(const DeformArgs& A, int64_t b, int kb, float pn[3], f16x8 x[DF_TIN]) {
 #pragma unroll
     for (int d = 0; d < 3; ++d) pn[d] = (A.pos[b * 3 + d] - A.aabb_min[d]) / A.aabb_ext[d];
@@ -205,7 +206,7 @@ __device__ __forceinline__ void build_input(const DeformArgs& A, int64_t b, int 
             const int kk = k < 21 ? k : k - 21;
             const int d = kk / 7, f = kk - 7 * d;
             const float rev = pn[d] * (float)(1 << f) + (k >= 21 ? 0.25f : 0.f);
-            return A.window[f] * __builtin_amdgcn_sinf(rev);
+            return A.window[f] * (BPROBE == 1 ? rev : __builtin_amdgcn_sinf(rev));
         }
         if (k < DF_PE) return 6.283185307179586f * pn[k - 42];
         return 0.f;                                   // code part handled by the caller
@@ -221,7 +222,7 @@ __device__ __forceinline__ void build_input(const DeformArgs& A, int64_t b, int 
             const int k = k0 + 8 * kb;
             if (k1 >= DF_PE) {                         // at least the kb = 1 variant is a code element
                 const int kc = k - DF_PE;
-                const float cv = crow[kc < 0 ? 0 : kc];
+                const float cv = BPROBE == 2 ? 0.125f * (float)(kc & 7) : crow[kc < 0 ? 0 : kc];
                 if (k >= DF_PE) v = cv;
             }
             x[t][j] = (half_t)v;
@@ -232,7 +233,7 @@ __device__ __forceinline__ void build_input(const DeformArgs& A, int64_t b, int 
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int k = 16 * t + 8 * kb + j;
-            x[t][j] = (k < DF_IN) ? (half_t)crow[k - DF_PE] : (half_t)0.f;
+            x[t][j] = (k < DF_IN) ? (BPROBE == 2 ? (half_t)(0.125f * (float)(k & 7)) : (half_t)crow[k - DF_PE]) : (half_t)0.f;
         }
     }
 }
@@ -693,7 +694,7 @@ __global__ __launch_bounds__(NWF * 64, 2) void deform_fwd2_kernel(DeformArgs A, 
 // the layer GEMMs wait for.  1: one weight-fragment read per K-step instead of four (LDS reads / 4); 2: none (the MFMAs
 // take the activation fragment as both operands); 3: half of the MFMAs (all fragments still read); 4: no block barrier
 // between the stages; 5: no input construction (positional encoding, code rows) and no SE(3) tail (7: the first only, 8: the
-// second only); 6: epilogues without conversion / ReLU.
+// second only; 9: the positional encoding without its 42 v_sin, 10: no code-row loads); 6: epilogues without conversion / ReLU.
 template <int KT, int PROBE>
 __device__ __forceinline__ void gemm_layer_probe(const f16x8* lds, int lane, const f16x8* in, f32x16 acc[4]) {
     if constexpr (PROBE == 0 || PROBE == 4) {
@@ -788,6 +789,10 @@ __global__ __launch_bounds__(NW * 64, 1) void deform_fwd_skew_kernel(DeformArgs 
             for (int t = 0; t < DF_TIN; ++t)
 #pragma unroll
                 for (int q = 0; q < 8; ++q) x[t][q] = (half_t)(float)((lane + t + q) & 7);
+        } else if constexpr (PROBE == 9) {
+            build_input<1>(A, b, kb, pn, x);
+        } else if constexpr (PROBE == 10) {
+            build_input<2>(A, b, kb, pn, x);
         } else {
             build_input(A, b, kb, pn, x);
         }
@@ -1560,11 +1565,12 @@ int nsx_deform_fwd(const void* packed, const float* positions, int64_t S, const 
         else if (variant == 5)
             hipLaunchKernelGGL(deform_fwd_skew_kernel<1>, dim3((unsigned)blocks), dim3(NW * 64), 0, (hipStream_t)stream, A,
                                offsets, n_tiles, n_device);
-        else if (variant >= 6 && variant <= 13) {              // timing probes (wrong results on purpose)
+        else if (variant >= 6 && variant <= 15) {              // timing probes (wrong results on purpose)
             auto k = variant == 6 ? deform_fwd_skew_kernel<2, 1> : variant == 7 ? deform_fwd_skew_kernel<2, 2>
                      : variant == 8 ? deform_fwd_skew_kernel<2, 3> : variant == 9 ? deform_fwd_skew_kernel<2, 4>
                      : variant == 10 ? deform_fwd_skew_kernel<2, 5> : variant == 11 ? deform_fwd_skew_kernel<2, 6>
-                     : variant == 12 ? deform_fwd_skew_kernel<2, 7> : deform_fwd_skew_kernel<2, 8>;
+                     : variant == 12 ? deform_fwd_skew_kernel<2, 7> : variant == 13 ? deform_fwd_skew_kernel<2, 8>
+                     : variant == 14 ? deform_fwd_skew_kernel<2, 9> : deform_fwd_skew_kernel<2, 10>;
             hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(NW * 64), 0, (hipStream_t)stream, A, offsets, n_tiles, n_device);
         }
         else if (variant == 3)
