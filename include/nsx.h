@@ -30,7 +30,7 @@ extern "C" {
 
 #define NSX_MAX_LEVELS 32
 #define NSX_MAX_SLOTS 64
-#define NSX_VERSION 112
+#define NSX_VERSION 113
 
 typedef uint16_t nsx_half;
 
@@ -283,6 +283,16 @@ int nsx_deform_pack_tensors(const void* const* tensors16_host, void* packed, voi
 int nsx_deform_fwd(const void* packed, const float* positions, int64_t S, const float* aabb_host, const float* code,
                    int64_t code_stride, const int32_t* code_slot, const float* window7_host, float* offsets,
                    const int64_t* n_device, void* stream);
+/* nsx_deform_fwd when every sample's code is row code_slot[s] of a table of n_code_rows rows (always, in this path: the
+ * time codes of the batch): the 125 code columns k >= 48 of the two input layers are factored through the slot --
+ * T_l[row][n] = sum_k W_l[n][k] code16[row][k - 45] once per launch (terms_scratch: nsx_deform_terms_floats(n_code_rows)
+ * floats of device memory), added to the bias; the input GEMMs keep 3 of their 11 K-steps.  Same products in another
+ * summation order (fp32): equal to nsx_deform_fwd up to the rounding of the pre-activations.  n_code_rows > 48 or
+ * terms_scratch == NULL: forwards to nsx_deform_fwd. */
+int64_t nsx_deform_terms_floats(int n_code_rows);
+int nsx_deform_fwd_rows(const void* packed, const float* positions, int64_t S, const float* aabb_host, const float* code_table,
+                        int64_t code_stride, const int32_t* code_slot, int n_code_rows, const float* window7_host,
+                        float* offsets, float* terms_scratch, const int64_t* n_device, void* stream);
 int nsx_deform_bwd(const void* packed, const float* positions, int64_t S, const float* aabb_host, const float* code,
                    int64_t code_stride, const int32_t* code_slot, int n_code_rows, const float* window7_host,
                    const float* grad_offsets, void* scratch, float* grad_params, float* grad_code_table,

@@ -145,6 +145,9 @@ SIGNATURES = {
     "nsx_adam_dense_f16grad_width": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                              c_float, c_float, c_float, c_float, c_int64, c_void_p, c_void_p, c_void_p]),
     "nsx_tables_unpack_width": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p]),
+    "nsx_deform_terms_floats": (c_int64, [c_int]),
+    "nsx_deform_fwd_rows": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int, c_void_p,
+                                    c_void_p, c_void_p, c_void_p, c_void_p]),
     "nsx_grad_scaler_update": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                        c_float, c_float, c_int, c_int, c_void_p]),
     "nsx_adam_hash_factored": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_void_p, c_int, _GEOM_P, c_void_p, c_void_p,

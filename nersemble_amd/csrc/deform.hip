@@ -853,6 +853,185 @@ __global__ __launch_bounds__(NW * 64, 1) void deform_fwd_skew_kernel(DeformArgs 
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// forward kernel with the warp-code columns of the two input layers factored through the code SLOT (round 4; not the default
+// until tests/test_deform_gpu.py has run on it).  What the timing probes of deform_fwd_skew_kernel say: building the layer
+// input costs 27 % of deform_fwd_kernel, 16 % of it the per-lane loads of the sample's 128-float code row (33 uncoalesced
+// 16-byte loads per lane and tile), and the two input GEMMs (W0, W4 over the 176-wide input: 2 x 44 MFMAs) are a third of the
+// tile's 256 MFMAs although 128 of their 173 columns multiply a vector that only depends on the sample's slot.  So, as
+// the backward does for the gradients: T_l[row][n] = sum_{k >= 48} W_l[n][k] * code16[row][k - 45] (l = 0, 4; fp16 operands,
+// fp32 sums; deform_code_terms_kernel, n_rows x 2 x 128 numbers) is added to the bias the accumulators start from, and the
+// GEMMs keep the first 3 K-steps (k < 48: the 45 positional-encoding columns + the first 3 code columns, so that the packed
+// fragments stay as they are).  Per tile 192 instead of 256 MFMAs, 3 instead of 11 input fragments, 2 code-row loads per lane
+// instead of 33; the terms live in LDS (<= 48 rows).  Same products, another summation order: equal to deform_fwd_kernel up
+// to fp32 rounding of the pre-activations, not bit for bit.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int TERM_KSTEPS = 3;                  // K-steps of the input stages that stay in the GEMM (k < 48)
+constexpr int TERM_K0 = 16 * TERM_KSTEPS;       // first input column the terms cover
+constexpr int TERM_ROW = 2 * DFW;               // floats per code row: T0 | T4
+constexpr int TERM_STRIDE = TERM_ROW + 4;       // LDS row stride (lanes of one instruction read different rows at one offset)
+constexpr int TERM_MAX_ROWS = 48;
+
+__global__ __launch_bounds__(DFW) void deform_code_terms_kernel(const f16x8* __restrict__ frags, const float* __restrict__ code,
+                                                               int64_t code_stride, int n_rows, float* __restrict__ terms) {
+    const int row = blockIdx.x >> 1, which = blockIdx.x & 1, n = threadIdx.x;
+    if (row >= n_rows) return;
+    const half_t* f16 = reinterpret_cast<const half_t*>(frags);
+    const int group = which ? F4 : F0;                       // both groups: [4 M-tiles][11 K-steps], natural k order
+    float acc = 0.f;
+    for (int k = TERM_K0; k < DF_IN; ++k) {
+        const int fi = group + (n >> 5) * DF_TIN + (k >> 4);
+        const float w = (float)f16[((int64_t)fi * 64 + ((k >> 3) & 1) * 32 + (n & 31)) * 8 + (k & 7)];
+        const float c = (float)(half_t)code[(int64_t)row * code_stride + (k - DF_PE)];
+        acc = __fmaf_rn(w, c, acc);
+    }
+    terms[(int64_t)row * TERM_ROW + which * DFW + n] = acc;
+}
+
+struct DeformLdsT {
+    f16x8 w[2][STAGE_FRAGS * 64];
+    float bias[N_BIAS];
+    float terms[TERM_MAX_ROWS * TERM_STRIDE];
+};
+
+// the first TERM_KSTEPS input fragments of sample b (build_input's first loop)
+__device__ __forceinline__ void build_input_head(const DeformArgs& A, int64_t b, int kb, float pn[3], f16x8 x[TERM_KSTEPS]) {
+#pragma unroll
+    for (int d = 0; d < 3; ++d) pn[d] = (A.pos[b * 3 + d] - A.aabb_min[d]) / A.aabb_ext[d];
+    const float* crow = A.code + (A.slot ? (int64_t)A.slot[b] : b) * A.code_stride;
+    auto pe_value = [&](int k) -> float {
+        if (k < 42) {
+            const int kk = k < 21 ? k : k - 21;
+            const int d = kk / 7, f = kk - 7 * d;
+            const float rev = pn[d] * (float)(1 << f) + (k >= 21 ? 0.25f : 0.f);
+            return A.window[f] * __builtin_amdgcn_sinf(rev);
+        }
+        if (k < DF_PE) return 6.283185307179586f * pn[k - 42];
+        return 0.f;
+    };
+#pragma unroll
+    for (int t = 0; t < TERM_KSTEPS; ++t) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k0 = 16 * t + j, k1 = k0 + 8;
+            float v0 = k0 < DF_PE ? pe_value(k0) : 0.f;
+            float v1 = k1 < DF_PE ? pe_value(k1) : 0.f;
+            float v = kb ? v1 : v0;
+            const int k = k0 + 8 * kb;
+            if (k1 >= DF_PE) {
+                const int kc = k - DF_PE;
+                const float cv = crow[kc < 0 ? 0 : kc];
+                if (k >= DF_PE) v = cv;
+            }
+            x[t][j] = (half_t)v;
+        }
+    }
+}
+
+// accumulators start at bias + the slot's code term
+__device__ __forceinline__ void acc_init_terms(f32x16 acc[4], lds_cfloat* bias_lds, const float* term_lds, int kb) {
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 v = *reinterpret_cast<lds_cfloat4*>(bias_lds + 32 * mt + 8 * q + 4 * kb);
+            const f32x4 tv = *reinterpret_cast<const f32x4*>(term_lds + 32 * mt + 8 * q + 4 * kb);
+            acc[mt][4 * q + 0] = v.x + tv.x; acc[mt][4 * q + 1] = v.y + tv.y;
+            acc[mt][4 * q + 2] = v.z + tv.z; acc[mt][4 * q + 3] = v.w + tv.w;
+        }
+}
+
+// the first TERM_KSTEPS K-steps of an input stage ([4][DF_TIN] fragments)
+__device__ __forceinline__ void gemm_input_head(const f16x8* lds, int lane, const f16x8* in, f32x16 acc[4]) {
+    const f16x8* base = lds + lane;
+#pragma unroll
+    for (int t = 0; t < TERM_KSTEPS; ++t) {
+        f16x8 a[4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) a[mt] = base[(mt * DF_TIN + t) * 64];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) acc[mt] = mfma(a[mt], in[t], acc[mt]);
+    }
+}
+
+__global__ __launch_bounds__(NW * 64, 1) void deform_fwd_terms_kernel(DeformArgs A, const float* __restrict__ terms, int n_rows,
+                                                                    float* __restrict__ offsets, int64_t n_tiles,
+                                                                    const int64_t* __restrict__ n_dev) {
+    NSX_DEVICE_COUNT(A.S, n_tiles, 32, n_dev);
+    __shared__ __attribute__((aligned(16))) DeformLdsT L;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int kb = lane >> 5;
+    const int64_t n_groups = (n_tiles + NW - 1) / NW;
+    for (int i = threadIdx.x; i < n_rows * TERM_ROW; i += blockDim.x)
+        L.terms[(i / TERM_ROW) * TERM_STRIDE + (i % TERM_ROW)] = terms[i];
+    for (int i = threadIdx.x; i < N_BIAS; i += blockDim.x) L.bias[i] = A.bias[i];
+    stage_issue(A.frags, F0, 44, L.w[0]);
+    __syncthreads();
+    int cur = 0;
+    for (int64_t grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {        // all waves iterate together
+        const int64_t tile = grp * NW + wave;
+        const int64_t b_raw = tile * 32 + (lane & 31);
+        const int64_t b = b_raw < A.S ? b_raw : A.S - 1;
+        lds_cfloat* bias = launder_lds(L.bias);
+        int row = A.slot[b];
+        row = row < 0 ? 0 : (row >= n_rows ? n_rows - 1 : row);
+        const float* term = L.terms + row * TERM_STRIDE;
+        f16x8 x[TERM_KSTEPS], h[DF_TW];
+        f32x16 acc[4];
+        float pn[3];
+        // L0
+        stage_issue(A.frags, F1, 32, L.w[cur ^ 1]);
+        build_input_head(A, b, kb, pn, x);
+        acc_init_terms(acc, bias + 0 * DFW, term, kb);
+        gemm_input_head(L.w[cur], lane, x, acc);
+        finish_layer<false>(acc, h);
+        stage_flip(cur);
+#pragma unroll 1
+        for (int l = 1; l <= 3; ++l) {
+            stage_issue(A.frags, l == 1 ? F2 : (l == 2 ? F3 : F4), l == 3 ? 44 : 32, L.w[cur ^ 1]);
+            acc_init(acc, bias + l * DFW, kb);
+            gemm_layer_lds<DF_TW, 1>(L.w[cur], 0, lane, h, acc);
+            finish_layer<false>(acc, h);
+            stage_flip(cur);
+        }
+        // L4: cat[input, x]
+        stage_issue(A.frags, F4X, 32, L.w[cur ^ 1]);
+        acc_init_terms(acc, bias + 4 * DFW, term + DFW, kb);
+        gemm_input_head(L.w[cur], lane, x, acc);
+        stage_flip(cur);
+        stage_issue(A.frags, F5, 40, L.w[cur ^ 1]);
+        gemm_layer_lds<DF_TW, 1>(L.w[cur], 0, lane, h, acc);
+        finish_layer<false>(acc, h);
+        stage_flip(cur);
+        // L5 + heads
+        stage_issue(A.frags, F0, 44, L.w[cur ^ 1]);
+        acc_init(acc, bias + 5 * DFW, kb);
+        gemm_layer_lds<DF_TW, 1>(L.w[cur], 0, lane, h, acc);
+        finish_layer<false>(acc, h);
+        f32x16 o = zero16();
+#pragma unroll
+        for (int t = 0; t < DF_TW; ++t) o = mfma(L.w[cur][(32 + t) * 64 + lane], h[t], o);
+        float own[4], oth[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) own[r] = (float)(half_t)(o[r] + bias[6 * DFW + acc_row(r, kb)]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) oth[r] = __shfl_xor(own[r], 32);
+        float rr[3], vv[3];
+        rr[0] = kb ? oth[0] : own[0]; rr[1] = kb ? oth[1] : own[1]; rr[2] = kb ? oth[2] : own[2];
+        vv[0] = kb ? oth[3] : own[3]; vv[1] = kb ? own[0] : oth[0]; vv[2] = kb ? own[1] : oth[1];
+        float w[3];
+        se3_apply(rr, vv, pn, w);
+        if (b_raw < A.S && kb == 0) {
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                const float wd = (w[d] != w[d]) ? pn[d] : w[d];            // NaN deformation -> keep the point
+                offsets[b * 3 + d] = wd - pn[d];
+            }
+        }
+        stage_flip(cur);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // backward chain kernel: writes per-tile a0..a6, dZ0..dZ5, dZheads, dCode tiles
 // ---------------------------------------------------------------------------------------------------------
 // per sample-tile scratch layout (halfs), the input tile first:
@@ -1586,6 +1765,34 @@ int nsx_deform_fwd(const void* packed, const float* positions, int64_t S, const 
                            n_tiles, n_device);
     }
     NSX_LAUNCH_CHECK("nsx_deform_fwd launch");
+    return NSX_OK;
+}
+
+int64_t nsx_deform_terms_floats(int n_code_rows) { return (int64_t)(n_code_rows > 0 ? n_code_rows : 0) * TERM_ROW; }
+
+int nsx_deform_fwd_rows(const void* packed, const float* positions, int64_t S, const float* aabb_host, const float* code_table,
+                        int64_t code_stride, const int32_t* code_slot, int n_code_rows, const float* window7_host,
+                        float* offsets, float* terms_scratch, const int64_t* n_device, void* stream) {
+    NSX_REQUIRE(S >= 0, "nsx_deform_fwd_rows: negative sample count");
+    if (S == 0) return NSX_OK;
+    NSX_REQUIRE(packed && positions && aabb_host && code_table && code_slot && offsets,
+                "nsx_deform_fwd_rows: NULL argument");
+    NSX_REQUIRE(n_code_rows >= 1, "nsx_deform_fwd_rows: n_code_rows=%d", n_code_rows);
+    if (n_code_rows > TERM_MAX_ROWS || !terms_scratch)           // the terms do not fit LDS: the general kernel
+        return nsx_deform_fwd(packed, positions, S, aabb_host, code_table, code_stride, code_slot, window7_host, offsets,
+                              n_device, stream);
+    DeformArgs A;
+    const float* bias = reinterpret_cast<const float*>(reinterpret_cast<const uint8_t*>(packed) + (size_t)N_FRAGS * 64 * 16);
+    fill_args(A, positions, S, aabb_host, code_table, code_stride, code_slot, window7_host, packed, bias);
+    hipLaunchKernelGGL(deform_code_terms_kernel, dim3(2 * n_code_rows), dim3(DFW), 0, (hipStream_t)stream, A.frags, code_table,
+                       code_stride, n_code_rows, terms_scratch);
+    NSX_LAUNCH_CHECK("nsx_deform_fwd_rows terms launch");
+    const int64_t n_tiles = (S + 31) / 32;
+    int64_t blocks = (n_tiles + NW - 1) / NW;
+    if (blocks > num_cus()) blocks = num_cus();
+    hipLaunchKernelGGL(deform_fwd_terms_kernel, dim3((unsigned)blocks), dim3(NW * 64), 0, (hipStream_t)stream, A,
+                       (const float*)terms_scratch, n_code_rows, offsets, n_tiles, n_device);
+    NSX_LAUNCH_CHECK("nsx_deform_fwd_rows launch");
     return NSX_OK;
 }
 

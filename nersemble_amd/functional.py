@@ -14,6 +14,9 @@ from . import _lib
 from ._lib import GridGeom, check, lib, ndev, ptr, stream
 
 
+_DEFORM_FWD_TERMS = os.environ.get("NSX_DEFORM_FWD_TERMS", "0") == "1"
+
+
 def scatter_alone(H: int) -> bool:
     """Padded grid counts whose fused backward has ONE lane per sample (table rows of <= 16 bytes: H <= 4): its 16
     (corner, feature) gradient items per sample and level leave as 16 instructions of 64 unrelated sectors each, while
@@ -472,8 +475,17 @@ class _DeformFn(torch.autograd.Function):
             off = precomputed.detach()
         else:
             off = torch.empty((S, 3), dtype=torch.float32, device=dev)
-            check(lib().nsx_deform_fwd(ptr(packed), ptr(pos), S, aabb6, ptr(code_c), code_c.stride(0), ptr(code_slot),
-                                       window7, ptr(off), ndev(S), stream()), "nsx_deform_fwd")
+            if _DEFORM_FWD_TERMS and code_slot is not None and code_c.shape[0] <= 48:
+                # the code columns of the two input layers factored through the slot (nsx_deform_fwd_rows; opt-in until
+                # tests/test_deform_gpu.py has been run on it: NSX_DEFORM_FWD_TERMS=1)
+                n_rows = int(code_c.shape[0])
+                terms = torch.empty((int(lib().nsx_deform_terms_floats(n_rows)),), dtype=torch.float32, device=dev)
+                check(lib().nsx_deform_fwd_rows(ptr(packed), ptr(pos), S, aabb6, ptr(code_c), code_c.stride(0),
+                                                ptr(code_slot), n_rows, window7, ptr(off), ptr(terms), ndev(S), stream()),
+                      "nsx_deform_fwd_rows")
+            else:
+                check(lib().nsx_deform_fwd(ptr(packed), ptr(pos), S, aabb6, ptr(code_c), code_c.stride(0), ptr(code_slot),
+                                           window7, ptr(off), ndev(S), stream()), "nsx_deform_fwd")
         ctx.save_for_backward(packed, pos, code_c, code_slot)
         ctx.aabb6, ctx.window7 = aabb6, window7
         ctx.param_shapes = [tuple(p.shape) for p in params]

@@ -64,7 +64,7 @@ def main():
     got = {}
     for v in a.variants.split(","):
         path = os.path.join(tmp, f"v{v}.pt")
-        env = dict(os.environ, NSX_DEFORM_FWD=v)
+        env = dict(os.environ, NSX_DEFORM_FWD="1", NSX_DEFORM_FWD_TERMS="1") if v == "T" else dict(os.environ, NSX_DEFORM_FWD=v)
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "--worker", path, "--S", str(a.S), "--iters",
                             str(a.iters)], env=env, capture_output=True, text=True, timeout=600)
         if r.returncode != 0 or not os.path.exists(path):
@@ -81,9 +81,12 @@ def main():
         if ref is not None and "out" in ref:
             same = all(torch.equal(d["out"][n], ref["out"][n]) for n in ref["out"])
         finite = all(bool(torch.isfinite(t).all()) for t in d["out"].values())
+        dmax = None
+        if ref is not None and "out" in ref:
+            dmax = float(max((d["out"][n] - ref["out"][n]).abs().max() for n in ref["out"]))
         line[v] = {"ms": round(d["ms"], 4), "frac_of_mfma_peak": round(a.S * FLOP_PER_SAMPLE / (d["ms"] * 1e-3) / 1e12
                                                                       / PEAK_TFLOPS, 4),
-                   "bit_identical_to_variant_1": same, "finite": finite,
+                   "bit_identical_to_variant_1": same, "max_abs_diff_to_variant_1": dmax, "finite": finite,
                    "abs_max": float(max(t.abs().max() for t in d["out"].values()))}
     print(json.dumps(line))
 
