@@ -54,7 +54,46 @@ def test_deform_forward_code_table_equals_gather(cuda):
     with torch.no_grad():
         a = df.compute_offsets(pos, table, 3.5, code_index=slot)
         b = df.compute_offsets(pos, table[slot], 3.5)
-    assert torch.equal(a, b)
+    from nersemble_amd import functional as F
+    if F._DEFORM_FWD_TERMS:
+        # (opt-in: the table route sums the code columns per slot first -- same products, another order)
+        assert (a - b).abs().max().item() <= 3e-3 * b.abs().max().item() + 2e-5
+    else:
+        assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("S,T", [(1, 1), (33, 1), (2049, 24), (5000, 48), (700, 49)])
+@pytest.mark.parametrize("window", [None, 2.75])
+def test_deform_forward_through_the_slot_terms(S, T, window, cuda):
+    """nsx_deform_fwd_rows (the code columns k >= 48 of the two input layers summed per code row first, 3 of 11 K-steps left
+    in the input GEMMs) against nsx_deform_fwd on the same table: the same products in another fp32 order -- equal up to
+    the fp16 rounding of a hidden unit; more than 48 rows forward to the general kernel (bit-equal)."""
+    import ctypes as C
+    from nersemble_amd import functional as F
+    from nersemble_amd._lib import check, lib, ptr, stream
+    df = _field(2).to(cuda)
+    g = torch.Generator().manual_seed(S + T)
+    pos = (torch.rand(S, 3, generator=g) * (AABB[1] - AABB[0]) + AABB[0]).to(cuda)
+    table = (torch.randn(T, 128, generator=g) * 0.3).to(cuda)
+    slot = torch.randint(0, T, (S,), generator=g, dtype=torch.int32).to(cuda)
+    packed, aabb6, w7 = df.packed_params(), df._aabb6(), F.deform_window7(window)
+    want = torch.empty((S, 3), device=cuda)
+    check(lib().nsx_deform_fwd(ptr(packed), ptr(pos), S, aabb6, ptr(table), table.stride(0), ptr(slot), w7, ptr(want), None,
+                               stream()), "nsx_deform_fwd")
+    got = torch.full((S, 3), 7.0, device=cuda)
+    terms = torch.empty((int(lib().nsx_deform_terms_floats(T)),), device=cuda)
+    assert terms.numel() == T * 256
+    check(lib().nsx_deform_fwd_rows(ptr(packed), ptr(pos), S, aabb6, ptr(table), table.stride(0), ptr(slot), T, w7, ptr(got),
+                                    ptr(terms), None, stream()), "nsx_deform_fwd_rows")
+    if T > 48:
+        assert torch.equal(got, want)
+    else:
+        tol = 3e-3 * want.abs().max().item() + 2e-5
+        assert (got - want).abs().max().item() <= tol, ((got - want).abs().max().item(), tol)
+        # and against the oracle, as the general kernel is held
+        ref = od.compute_offsets(pos.cpu(), table.cpu()[slot.cpu().long()], df.flat_params().detach().cpu(), AABB, window,
+                                 half=True).float()
+        assert (got.cpu() - ref).abs().max().item() <= 3e-3 * ref.abs().max().item() + 2e-5
 
 
 def test_deform_nan_fallback_and_identity_init(cuda):
