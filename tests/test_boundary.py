@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(handle, s), f"libnsx.so does not export {s}"
     # the ctypes signature table covers exactly the header
     assert set(_lib.SIGNATURES) == declared
-    assert handle.nsx_version() >= 110
+    assert handle.nsx_version() >= 113
 
 
 def test_error_reporting_across_abi():
