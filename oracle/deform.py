@@ -144,3 +144,48 @@ def compute_offsets(pos_world, codes, flat_params, aabb, windows_param, half=Tru
     warped = se3_warp(r, v, pn)
     warped = torch.where(torch.isnan(warped), pn, warped)
     return warped - pn
+
+
+TERM_K0 = 48            # first input column the slot terms cover (csrc/deform.hip: TERM_K0)
+
+
+def compute_offsets_slot_terms(pos_world, table, slot, flat_params, aabb, windows_param, half=True, dtype=torch.float64):
+    """Restatement of ``nsx_deform_fwd_rows`` (csrc/deform.hip: deform_code_terms_kernel + deform_fwd_terms_kernel): every
+    sample's code is row ``slot[s]`` of ``table`` [T, code_dim], and the code columns k >= 48 of the two layers that read
+    the 173-wide input (W0, and W4 over ``cat[input, x]``, deformation_field.py:77-131) are summed per table row first,
+
+        T_l[row] = W_l[:, 48:173] @ code16[row][3:]        (l = 0, 4; fp16 operands)
+
+    then added to the bias while the GEMM keeps the columns k < 48 (45 positional-encoding columns + the first 3 code
+    columns).  The same products as ``compute_offsets`` in another order: equal to it up to the summation order of the
+    pre-activations (in float64: to ~1e-12 before the fp16 roundings that both apply at the same places)."""
+    code_dim = table.shape[1]
+    width = next(w for w in (128, 32, 64, 16, 256) if flat_layout(w, code_dim)[1] == flat_params.numel())
+    P = unflatten(flat_params.to(dtype), width, code_dim)
+    rnd = _r16 if half else (lambda t: t)
+    aabb = aabb.to(dtype)
+    pn = (pos_world.to(dtype) - aabb[0]) / (aabb[1] - aabb[0])
+    if half:
+        pn = ((pos_world.float() - aabb[0].float()) / (aabb[1] - aabb[0]).float()).to(dtype)
+    slot = slot.long()
+    code16 = rnd(table.to(dtype))
+    x_head = rnd(torch.cat([encode(pn, windows_param), table.to(dtype)[slot][:, :TERM_K0 - 45]], dim=-1))      # [S, 48]
+    n_in = 45 + code_dim
+    T0 = code16[:, TERM_K0 - 45:] @ rnd(P["W0"])[:, TERM_K0:n_in].T                                            # [T, width]
+    T4 = code16[:, TERM_K0 - 45:] @ rnd(P["W4"])[:, TERM_K0:n_in].T
+
+    def act(y, relu=True):
+        y = rnd(y)
+        return torch.relu(y) if relu else y
+
+    h = act(x_head @ rnd(P["W0"])[:, :TERM_K0].T + rnd(P["b0"]) + T0[slot])
+    for W, b in (("W1", "b1"), ("W2", "b2"), ("W3", "b3")):
+        h = act(h @ rnd(P[W]).T + rnd(P[b]))
+    W4 = rnd(P["W4"])
+    h = act(x_head @ W4[:, :TERM_K0].T + h @ W4[:, n_in:].T + rnd(P["b4"]) + T4[slot])
+    h = act(h @ rnd(P["W5"]).T + rnd(P["b5"]))
+    r = act(h @ rnd(P["Wr"]).T + rnd(P["br"]), relu=False)
+    v = act(h @ rnd(P["Wv"]).T + rnd(P["bv"]), relu=False)
+    warped = se3_warp(r, v, pn)
+    warped = torch.where(torch.isnan(warped), pn, warped)
+    return warped - pn

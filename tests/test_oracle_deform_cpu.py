@@ -8,6 +8,7 @@ This closes the chain  HIP kernel <-> oracle/deform.py (tests/test_deform_gpu.py
     codes and all 127 750 parameters.
 The oracle runs in its un-rounded mode (half=False; the fp16 mode adds roundings to the same code path)."""
 import numpy as np
+import pytest
 import torch
 
 from oracle import deform as od
@@ -125,3 +126,27 @@ def test_mlp_oracle_rounded_backward():
     dW1, dx1 = omlp.mlp_bwd(x, p, nh, 16, 0, dout, round_dz=True)
     assert 0 < np.abs(dW1 - dW0).max() <= 2e-3 * np.abs(dW0).max()
     assert 0 < np.abs(dx1 - dx0).max() <= 2e-3 * np.abs(dx0).max()
+
+
+@pytest.mark.parametrize("window", [None, 2.75])
+def test_slot_terms_restatement_equals_the_direct_forward(window):
+    """The forward with the code columns k >= 48 of the two input layers summed per code row first (what
+    nsx_deform_fwd_rows computes) is the direct forward: in float64 without roundings to 1e-12; with the fp16 roundings of
+    both routes at the same places, equal up to the rare hidden unit whose pre-activation sits on a rounding boundary."""
+    torch.manual_seed(5)
+    S, T = 700, 9
+    aabb = torch.tensor([[-2.5, -1.8, -2.5], [2.2, 1.8, 2.0]])
+    n = od.flat_layout(128, 128)[1]
+    flat = torch.randn(n, dtype=torch.float64) * 0.08
+    pos = torch.rand(S, 3, dtype=torch.float64) * (aabb[1] - aabb[0]).double() + aabb[0].double()
+    table = torch.randn(T, 128, dtype=torch.float64) * 0.3
+    slot = torch.randint(0, T, (S,))
+    for half in (False, True):
+        a = od.compute_offsets(pos, table[slot], flat, aabb, window, half=half)
+        b = od.compute_offsets_slot_terms(pos, table, slot, flat, aabb, window, half=half)
+        d = (a - b).abs()
+        if not half:
+            assert d.max().item() <= 1e-11, d.max().item()
+        else:
+            assert d.max().item() <= 3e-3 * a.abs().max().item() + 2e-5
+            assert (d <= 1e-9).float().mean().item() >= 0.9
