@@ -30,7 +30,7 @@ extern "C" {
 
 #define NSX_MAX_LEVELS 32
 #define NSX_MAX_SLOTS 64
-#define NSX_VERSION 113
+#define NSX_VERSION 120
 
 typedef uint16_t nsx_half;
 
@@ -50,6 +50,18 @@ typedef struct nsx_grid_geom {
 
 int         nsx_version(void);
 const char* nsx_last_error(void);
+
+/* Launch-shape options: how many workgroups a few bandwidth- or register-bound kernels launch per CU.  They never change a
+ * result, only how a kernel shares the device with its neighbours (the table optimizer beside the next step's
+ * marching).  Process-wide atomics with the defaults the measurements chose; a value outside the option's range is an
+ * error.  These replace the NSX_* environment variables of rounds 2-4: no entry point of this library reads the environment
+ * (tests/test_boundary.py checks the binary for getenv). */
+#define NSX_OPT_ADAM_BLOCKS_PER_CU 0           /* nsx_adam_hash_factored(_consume): 1..8, default 5 */
+#define NSX_OPT_MLP_BWD_HALF_BLOCKS_PER_CU 1   /* nsx_mlp_bwd with a hidden matrix: blocks per CU x 2, 1..8, default 2 */
+#define NSX_OPT_MLP_BWD0_HALF_BLOCKS_PER_CU 2  /* nsx_mlp_bwd without one: blocks per CU x 2, 1..8, default 2 */
+#define NSX_OPT_COUNT 3
+int nsx_set_option(int option, int value);
+int nsx_get_option(int option);                /* the current value, or NSX_ERR_INVALID */
 
 /* Host-only.  hash_ensemble.py:31-50. */
 int nsx_grid_geometry(int n_levels, float per_level_scale, int base_resolution,
@@ -242,6 +254,13 @@ int nsx_sample_positions(const float* origins, const float* directions, const in
 int nsx_generate_rays(const float* camera_to_worlds, const float* fx, const float* fy, const float* cx, const float* cy,
                       int64_t n_cameras, const int64_t* camera_indices, const float* ys, const float* xs, int64_t R,
                       float* origins, float* directions, float* pixel_area, void* stream);
+/* The reference derives a sample's time-code rows from its ray's normalised time -- round(times * (T - 1)),
+ * nersemble_instant_ngp.py:249 (sigma_fn) and :300-318 (main pass) --; this path indexes the batch's compacted code tables
+ * with a per-ray slot that the datamanager attaches (image of the cached batch -> row).  The two agree iff
+ * row_timesteps[ray_slots[r]] == rint(ray_times[r] * (n_timesteps - 1)) for every ray; a ray that disagrees (or whose slot is
+ * outside [0, n_code_rows)) ORs 1 into *flag (device int32, sticky: never cleared here).  One launch, no host read. */
+int nsx_check_code_rows(const float* ray_times, const int32_t* ray_slots, int64_t R, const int32_t* row_timesteps,
+                        int n_code_rows, int n_timesteps, int32_t* flag, void* stream);
 #define NSX_MAX_GATHER 8
 int nsx_gather_rows(int n_arrays, const void* const* srcs, const int64_t* row_bytes, void* const* dsts,
                     const int64_t* index, int64_t n, const int64_t* n_device, void* stream);
@@ -283,12 +302,16 @@ int nsx_deform_pack_tensors(const void* const* tensors16_host, void* packed, voi
 int nsx_deform_fwd(const void* packed, const float* positions, int64_t S, const float* aabb_host, const float* code,
                    int64_t code_stride, const int32_t* code_slot, const float* window7_host, float* offsets,
                    const int64_t* n_device, void* stream);
-/* nsx_deform_fwd when every sample's code is row code_slot[s] of a table of n_code_rows rows (always, in this path: the
- * time codes of the batch): the 125 code columns k >= 48 of the two input layers are factored through the slot --
- * T_l[row][n] = sum_k W_l[n][k] code16[row][k - 45] once per launch (terms_scratch: nsx_deform_terms_floats(n_code_rows)
- * floats of device memory), added to the bias; the input GEMMs keep 3 of their 11 K-steps.  Same products in another
- * summation order (fp32): equal to nsx_deform_fwd up to the rounding of the pre-activations.  n_code_rows > 48 or
- * terms_scratch == NULL: forwards to nsx_deform_fwd. */
+/* nsx_deform_fwd when every sample's code is row code_slot[s] of a table of n_code_rows rows (always, on this path: the
+ * time codes of the batch, of the image, of the dataset): the 125 code columns k >= 48 of the two input layers are factored
+ * through the row -- T_l[row][n] = sum_k W_l[n][k] code16[row][k - 45] once per launch (terms_scratch:
+ * nsx_deform_terms_floats(n_code_rows) floats of device memory, required), added to the bias; the input GEMMs keep 3 of their
+ * 11 K-steps.  Same products in another summation order (fp32): equal to nsx_deform_fwd up to the rounding of the
+ * pre-activations; a sample's result depends on its row's VALUES only (not on the table the row sits in, nor on the table's
+ * size: <= 64 rows keep the terms in LDS, larger tables read them from L2 -- the same numbers in the same order).
+ * code_slot == NULL is allowed for a one-row table: every sample takes row 0 (an evaluation image's single timestep).
+ * Round 5: the route of every table-indexed forward of the model (sampler sigma_fn, occupancy update, evaluation, the
+ * fused pass); nsx_deform_fwd stays the per-sample-code operator of SE3DeformationField.compute_offsets(positions, codes). */
 int64_t nsx_deform_terms_floats(int n_code_rows);
 int nsx_deform_fwd_rows(const void* packed, const float* positions, int64_t S, const float* aabb_host, const float* code_table,
                         int64_t code_stride, const int32_t* code_slot, int n_code_rows, const float* window7_host,
@@ -589,7 +612,8 @@ int nsx_occ_update(float* occs, uint8_t* binaries, int64_t n_cells, const int32_
  *
  *   nsx_step_sample     the sampler behind NeRSembleVolumetricSampler.forward (nersemble_volumetric_sampler.py:95-134)
  *                       after the traversal's counting pass: nsx_march_fill, the sigma_fn density pass
- *                       (nersemble_instant_ngp.py:235-266: midpoints, per-ray timestep gather, deformation, scene-box
+ *                       (nersemble_instant_ngp.py:235-266: midpoints, per-ray code-row gather, deformation
+ *                       [nsx_deform_fwd_rows: the batch's <= 64 code rows, terms in LDS], scene-box
  *                       normalisation, HashEnsemble, mlp_base, trunc_exp), the visibility test, its stream compaction, the
  *                       gathers of the kept samples (intervals, rays, code slots, and the sigma pass's forward values the
  *                       main pass reuses) and pack_info of the kept samples.  The kept count stays on the device.
@@ -610,7 +634,7 @@ typedef struct nsx_step_plan {
     int64_t m_t0;
     int64_t m_t1;
     int64_t m_pos;              /* world midpoints [S][3] */
-    int64_t m_ts;               /* timestep of the sample's ray int32 [S] */
+    int64_t m_slot;             /* code row of the sample's ray int32 [S] */
     int64_t m_off;              /* deformation offsets [S][3] */
     int64_t m_pn;               /* normalised positions [S][3] */
     int64_t m_sel;              /* in-box selector u8 [S] */
@@ -620,6 +644,7 @@ typedef struct nsx_step_plan {
     int64_t m_vis;              /* visibility mask u8 [S] */
     int64_t m_keep;             /* ascending indices of the visible samples int64 [S] */
     int64_t m_scratch;          /* scan scratch of nsx_compact_mask */
+    int64_t m_terms;            /* nsx_deform_terms_floats(n_code_rows) floats of nsx_deform_fwd_rows */
     int64_t n_kept;             /* device int64: number of kept samples (the n_device of everything downstream) */
     int64_t k_ri;               /* kept (first *n_kept rows valid, capacity S): ray index int64 */
     int64_t k_t0;
@@ -678,13 +703,21 @@ typedef struct nsx_step_sample {
     const float* near_planes;        /* [R] (jittered), the ones the counting pass ran with */
     const int64_t* packed_march;     /* [R][2] of the counting pass */
     const uint8_t* binaries;         /* occupancy grid [res]^3 */
-    const int32_t* ray_timesteps;    /* [R]: row of the ray's samples in deform_codes / hash_codes */
-    const int32_t* ray_slots;        /* [R]: code slot of the ray in the main pass's compacted code tables */
+    const int32_t* ray_slots;        /* [R]: row of the ray's samples in deform_codes / hash_codes = its code slot in the main
+                                        pass's compacted code tables (the batch's images: the sigma_fn pass and the main pass
+                                        read the SAME rows, round 5; rounds 3-4 indexed the dataset's [T] tables here) */
+    const float* ray_times;          /* [R] or NULL: the rays' normalised times.  With row_timesteps the driver checks on the
+                                        device that rint(times * (n_timesteps - 1)) == row_timesteps[ray_slots] for every ray
+                                        (the reference derives its code rows from the times, nersemble_instant_ngp.py:249,
+                                        300-318) and raises *rows_flag (sticky, never cleared here) when a ray disagrees */
+    const int32_t* row_timesteps;    /* [n_code_rows] timestep of every code row, or NULL */
+    int32_t* rows_flag;              /* device int32 or NULL */
     const void* deform_packed;
-    const float* deform_codes;       /* [T][128] */
+    const float* deform_codes;       /* [n_code_rows][128] */
     const nsx_half* tables;
     const nsx_grid_geom* geom;
-    const float* hash_codes;         /* [T][H] (conditioned time codes; ones [T][1] in the compact first-grid phase) */
+    const float* hash_codes;         /* [n_code_rows][H] (conditioned time codes; ones [n_code_rows][1] in the compact
+                                        first-grid phase) */
     const float* hash_window;        /* [H] or NULL */
     const nsx_half* base_w16;
     const float* alpha_thre_dev;     /* device scalar: min(alpha_thre, occs.mean()) */
@@ -701,6 +734,8 @@ typedef struct nsx_step_sample {
     int32_t base_hidden;
     int32_t base_out_dim;
     int32_t base_act;
+    int32_t n_code_rows;             /* rows of deform_codes / hash_codes (= the plan's) */
+    int32_t n_timesteps;             /* T of the model (the check above) */
     int32_t reserved;
     float far_plane;
     float step;
@@ -769,7 +804,8 @@ int nsx_step_main_bwd(const nsx_step_main* a, int stage, void* stream);
  * stored with every record, e.g. the index of the step), (0, .) off.  After the stream has drained: _count records, _get
  * reads one (name of the entry point, milliseconds between the two events, rows the call was sized for, info4 = {H or
  * n_hidden_mats, n_code_rows, 1 if the call ran under the kept-sample count, tag}); _reset recycles the events.
- * Host-side state of the process; not thread-safe; off by default. */
+ * Process-wide host-side state behind one mutex (records of concurrent callers interleave; every call is safe);
+ * off by default. */
 int nsx_step_profile(int enable, int tag);
 int nsx_step_profile_count(void);
 int nsx_step_profile_get(int i, char* name_out, int name_capacity, float* ms, int64_t* rows, int32_t* info4);

@@ -9,6 +9,7 @@ SO_PATH = os.path.join(_HERE, "csrc", "libnsx.so")
 NSX_MAX_LEVELS = 32
 NSX_MAX_SLOTS = 64
 NSX_MAX_GATHER = 8
+NSX_OPT_ADAM_BLOCKS_PER_CU, NSX_OPT_MLP_BWD_HALF_BLOCKS_PER_CU, NSX_OPT_MLP_BWD0_HALF_BLOCKS_PER_CU = 0, 1, 2
 
 c_void_p, c_int, c_int64, c_float = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
@@ -55,6 +56,9 @@ SIGNATURES = {
     "nsx_last_error": (C.c_char_p, []),
     "nsx_grid_geometry": (c_int, [c_int, c_float, c_int, c_int, _GEOM_P]),
     "nsx_padded_grids": (c_int, [c_int]),
+    "nsx_set_option": (c_int, [c_int, c_int]),
+    "nsx_get_option": (c_int, [c_int]),
+    "nsx_check_code_rows": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "nsx_tables_from_tcnn": (c_int, [c_void_p, c_int, _GEOM_P, c_void_p, c_void_p, c_void_p]),
     "nsx_tables_to_tcnn": (c_int, [c_void_p, c_int, _GEOM_P, c_void_p, c_void_p]),
     "nsx_hash_ensemble_fwd": (c_int, [c_void_p, c_int64, c_void_p, c_int, _GEOM_P, c_void_p, c_int64, c_void_p,
@@ -200,12 +204,11 @@ def step_struct(name: str):
     if m is None:
         raise RuntimeError(f"{name} not found in {HEADER_PATH}")
     fields = []
-    for line in m.group(1).splitlines():
-        line = line.split("/*")[0].strip()
+    body = re.sub(r"/\*.*?\*/", "", m.group(1), flags=re.S)      # comments may span lines
+    for line in body.splitlines():
+        line = line.strip()
         if not line:
             continue
-        if line.endswith("*/") or line.startswith("*"):
-            continue                                          # continuation of a comment
         d = re.match(r"^(const\s+)?([A-Za-z_0-9]+)\s*(\*?)\s*([A-Za-z_0-9]+)(\[(\d+)\])?;$", line)
         if d is None:
             raise RuntimeError(f"{name}: cannot parse field line {line!r}")

@@ -450,12 +450,7 @@ static int launch_adam_factored(float* G, int n_slots, const float* code, int64_
     // step the pass runs beside the next step's marching and deformation forward, and what counts is the pair: 5 gives the
     // shortest step (7.92-7.97 / 3.61-3.66 ms per step early / steady against 8.02-8.07 / 3.78-3.79 with 4; 6: 7.87-7.93 /
     // 3.63-3.64; 8 fills every wave slot, the other stream's kernels then simply wait for the pass: 7.93 / 3.73).
-    static int per_cu = 0;
-    if (!per_cu) {
-        const char* e = getenv("NSX_ADAM_BLOCKS_PER_CU");      // (measurement knob)
-        per_cu = e ? atoi(e) : 5;
-        if (per_cu < 1 || per_cu > 8) per_cu = 5;
-    }
+    const int per_cu = option(NSX_OPT_ADAM_BLOCKS_PER_CU);
     hipLaunchKernelGGL((adam_hash_factored_kernel<HP, CLEAR>), dim3(num_cus() * per_cu), dim3(256), smem, st, G, n_slots, code,
                        code_stride, window, H, total, master, m, v, reinterpret_cast<half_t*>(f16), hy, inv_scale,
                        found_inf);

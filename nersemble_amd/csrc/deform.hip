@@ -23,7 +23,6 @@
 //     through a 4-deep LDS ring by LDS-DMA, each scratch byte read once) -- the only form in which K = #samples fits
 //     MFMA.
 #include "nsx_common.h"
-#include <cstdlib>
 
 namespace nsx {
 
@@ -194,7 +193,6 @@ struct DeformArgs {
 //   k <  45 : 2 pi pn_d                           (the 2 pi-SCALED input is appended, :72-73)
 //   k < 173 : warp code
 // sin(2 pi x) is the native v_sin_f32 (input in revolutions, range-reduced in hardware).
-template <int BPROBE = 0>
 __device__ __forceinline__ void build_input(const DeformArgs& A, int64_t b, int kb, float pn[3], f16x8 x[DF_TIN]) {
 #pragma unroll
     for (int d = 0; d < 3; ++d) pn[d] = (A.pos[b * 3 + d] - A.aabb_min[d]) / A.aabb_ext[d];
@@ -206,7 +204,7 @@ __device__ __forceinline__ void build_input(const DeformArgs& A, int64_t b, int 
             const int kk = k < 21 ? k : k - 21;
             const int d = kk / 7, f = kk - 7 * d;
             const float rev = pn[d] * (float)(1 << f) + (k >= 21 ? 0.25f : 0.f);
-            return A.window[f] * (BPROBE == 1 ? rev : __builtin_amdgcn_sinf(rev));
+            return A.window[f] * __builtin_amdgcn_sinf(rev);
         }
         if (k < DF_PE) return 6.283185307179586f * pn[k - 42];
         return 0.f;                                   // code part handled by the caller
@@ -222,7 +220,7 @@ __device__ __forceinline__ void build_input(const DeformArgs& A, int64_t b, int 
             const int k = k0 + 8 * kb;
             if (k1 >= DF_PE) {                         // at least the kb = 1 variant is a code element
                 const int kc = k - DF_PE;
-                const float cv = BPROBE == 2 ? 0.125f * (float)(kc & 7) : crow[kc < 0 ? 0 : kc];
+                const float cv = crow[kc < 0 ? 0 : kc];
                 if (k >= DF_PE) v = cv;
             }
             x[t][j] = (half_t)v;
@@ -233,7 +231,7 @@ __device__ __forceinline__ void build_input(const DeformArgs& A, int64_t b, int 
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int k = 16 * t + 8 * kb + j;
-            x[t][j] = (k < DF_IN) ? (BPROBE == 2 ? (half_t)(0.125f * (float)(k & 7)) : (half_t)crow[k - DF_PE]) : (half_t)0.f;
+            x[t][j] = (k < DF_IN) ? (half_t)crow[k - DF_PE] : (half_t)0.f;
         }
     }
 }
@@ -335,10 +333,11 @@ __device__ __forceinline__ void acc_init(f32x16 acc[4], lds_cfloat* bias_lds, in
         }
 }
 
-// acc[mt] += sum_t W_frag(stage-local index local + mt * KT + t) * in[t], fragments read from LDS PF K-steps ahead
-// (PF = 1: 8 fragment registers; PF = 2: 12 -- the forward kernel has the registers to spare, the backward chain does not)
-template <int KT, int PF = 1>
+// acc[mt] += sum_t W_frag(stage-local index local + mt * KT + t) * in[t], fragments read from LDS one K-step ahead
+// (8 fragment registers; two K-steps ahead, pinned with sched_barrier, measured equal in round 4 and was removed)
+template <int KT>
 __device__ __forceinline__ void gemm_layer_lds(const f16x8* lds, int local, int lane, const f16x8* in, f32x16 acc[4]) {
+    constexpr int PF = 1;
     const f16x8* base = lds + (size_t)local * 64 + lane;
     f16x8 a[PF + 1][4];
 #pragma unroll
@@ -353,12 +352,8 @@ __device__ __forceinline__ void gemm_layer_lds(const f16x8* lds, int local, int 
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) a[(t + PF) % (PF + 1)][mt] = base[(mt * KT + t + PF) * 64];
         }
-        // PF >= 2: pin the software pipeline (the machine scheduler otherwise sinks the reads to 1-2 MFMAs ahead of their
-        // use, and the wave parks on lgkmcnt in front of every other MFMA)
-        if (PF >= 2) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) acc[mt] = mfma(a[t % (PF + 1)][mt], in[t], acc[mt]);
-        if (PF >= 2) __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -425,11 +420,10 @@ __device__ __forceinline__ void store_tile_T(half_t* __restrict__ dst, int lane,
 // warp code), or 4 (64 rows: the positional encoding and the first 19 code columns riding along) when the weight
 // gradients of the code columns are formed through the code SLOT (deform_bwd_kernel<true>).
 // A6T: write the transposed tile of the heads' input (a6); the SLOTS chain kernel forms the head gradients itself
-template <bool BWD, int A0F = DF_TIN, int PFW = 1, bool A6T = true>
+template <bool BWD, int A0F = DF_TIN, bool A6T = true>
 __device__ __forceinline__ void forward_tile(const DeformArgs& A, int64_t b, int lane, Fwd& F, half_t* a_tiles,
                                              DeformLds& L, int& cur, int next_first, int next_count) {
     constexpr int A0_HALFS = ((A0F + 1) / 2) * 32 * 32;         // transposed tiles of the layer input
-    constexpr int PF = BWD ? 1 : PFW;                           // LDS fragment look-ahead of the layer GEMMs
     const int kb = lane >> 5;
     lds_cfloat* bias = launder_lds(L.bias);
     build_input(A, b, kb, F.pn, F.x);
@@ -442,7 +436,7 @@ __device__ __forceinline__ void forward_tile(const DeformArgs& A, int64_t b, int
     // L0
     stage_issue(A.frags, F1, 32, L.w[cur ^ 1]);
     acc_init(acc, bias + 0 * DFW, kb);
-    gemm_layer_lds<DF_TIN, PF>(L.w[cur], 0, lane, F.x, acc);
+    gemm_layer_lds<DF_TIN>(L.w[cur], 0, lane, F.x, acc);
     F.m1 = finish_layer<BWD>(acc, F.h);
     if (BWD) store_tile_T<DF_TW>(a_tiles + A0_HALFS + 0 * DFW * 32, lane, F.h, tsel);
     stage_flip(cur);
@@ -451,7 +445,7 @@ __device__ __forceinline__ void forward_tile(const DeformArgs& A, int64_t b, int
     for (int l = 1; l <= 3; ++l) {
         stage_issue(A.frags, l == 1 ? F2 : (l == 2 ? F3 : F4), l == 3 ? 44 : 32, L.w[cur ^ 1]);
         acc_init(acc, bias + l * DFW, kb);
-        gemm_layer_lds<DF_TW, PF>(L.w[cur], 0, lane, F.h, acc);
+        gemm_layer_lds<DF_TW>(L.w[cur], 0, lane, F.h, acc);
         const u32x2 m = finish_layer<BWD>(acc, F.h);
         if (l == 1) F.m2 = m; else if (l == 2) F.m3 = m; else F.m4 = m;
         if (BWD) store_tile_T<DF_TW>(a_tiles + A0_HALFS + l * DFW * 32, lane, F.h, tsel);
@@ -460,17 +454,17 @@ __device__ __forceinline__ void forward_tile(const DeformArgs& A, int64_t b, int
     // L4: cat[input, x] -- two stages, one accumulator
     stage_issue(A.frags, F4X, 32, L.w[cur ^ 1]);
     acc_init(acc, bias + 4 * DFW, kb);
-    gemm_layer_lds<DF_TIN, PF>(L.w[cur], 0, lane, F.x, acc);
+    gemm_layer_lds<DF_TIN>(L.w[cur], 0, lane, F.x, acc);
     stage_flip(cur);
     stage_issue(A.frags, F5, 40, L.w[cur ^ 1]);
-    gemm_layer_lds<DF_TW, PF>(L.w[cur], 0, lane, F.h, acc);
+    gemm_layer_lds<DF_TW>(L.w[cur], 0, lane, F.h, acc);
     F.m5 = finish_layer<BWD>(acc, F.h);
     if (BWD) store_tile_T<DF_TW>(a_tiles + A0_HALFS + 4 * DFW * 32, lane, F.h, tsel);
     stage_flip(cur);
     // L5 (+ out_activation ReLU) and the heads share one stage (F5 | FH are contiguous)
     stage_issue(A.frags, next_first, next_count, L.w[cur ^ 1]);
     acc_init(acc, bias + 5 * DFW, kb);
-    gemm_layer_lds<DF_TW, PF>(L.w[cur], 0, lane, F.h, acc);
+    gemm_layer_lds<DF_TW>(L.w[cur], 0, lane, F.h, acc);
     F.m6 = finish_layer<BWD>(acc, F.h);
     if (BWD && A6T) store_tile_T<DF_TW>(a_tiles + A0_HALFS + 5 * DFW * 32, lane, F.h, tsel);
     // heads (one M-tile, rows 0..5)
@@ -531,7 +525,6 @@ __device__ __forceinline__ void lds_prologue(const DeformArgs& A, DeformLds& L, 
     __syncthreads();
 }
 
-template <int PFW>
 __global__ __launch_bounds__(NW * 64, 1) void deform_fwd_kernel(DeformArgs A, float* __restrict__ offsets, int64_t n_tiles,
                                                               const int64_t* __restrict__ n_dev) {
     NSX_DEVICE_COUNT(A.S, n_tiles, 32, n_dev);
@@ -545,7 +538,7 @@ __global__ __launch_bounds__(NW * 64, 1) void deform_fwd_kernel(DeformArgs A, fl
         const int64_t b_raw = tile * 32 + (lane & 31);
         const int64_t b = b_raw < A.S ? b_raw : A.S - 1;
         Fwd F;
-        forward_tile<false, DF_TIN, PFW>(A, b, lane, F, nullptr, L, cur, F0, 44);
+        forward_tile<false>(A, b, lane, F, nullptr, L, cur, F0, 44);
         float w[3];
         se3_apply(F.r, F.v, F.pn, w);
         if (b_raw < A.S && (lane >> 5) == 0) {
@@ -559,317 +552,27 @@ __global__ __launch_bounds__(NW * 64, 1) void deform_fwd_kernel(DeformArgs A, fl
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// forward kernel, round 4: TWO independent 4-wave blocks per CU instead of one 8-wave block.
-// Counters of the 8-wave kernel at 2^20 samples (profiles/pmc/r04_sq_mfma_kernels.json): matrix cores busy 40 % of the
-// cycles, waves parked on s_waitcnt / s_barrier 47 %.  Its 8 waves walk the layers in lock-step -- one barrier per stage
-// -- so the two waves of a SIMD are always in the SAME phase: both in the MFMA stream, then both in the epilogue (cvt / ReLU
-// / bias reload, ~1200 VALU instructions per 256 MFMAs); the matrix cores idle through every epilogue and every barrier.
-// Two blocks that share a CU are not synchronised with each other: a SIMD holds one wave of each, and one block's epilogues
-// and barriers fall into the other's MFMA streams.  LDS: 2 x (2 x 32 KB stage buffers + biases) = 137 KB of 160 KB, which
-// needs stages of <= 32 fragments: the two 44-fragment stages (W0, W4 over the input: 4 M-tiles x 11 K-steps) are copied
-// as K-steps 0-5 (24 fragments) and 6-10 (20), four accumulators live across both; the 8 head fragments share a buffer
-// with the next tile's first stage.  Same MFMAs on the same operands in the same order as deform_fwd_kernel: results are
-// bit-identical.  Weights cross L2 -> CU once per 128 samples instead of 256 (2 KB / sample from L2).
-// ---------------------------------------------------------------------------------------------------------
-constexpr int NWF = 4;
-constexpr int STAGE_F = 32;
-constexpr int S0A_LOCAL = 8;          // the first stage of a tile sits behind the previous tile's head fragments
-
-struct DeformLdsF {
-    f16x8 w[2][STAGE_F * 64];
-    float bias[N_BIAS];
-};
-
-// runs of `run_len` consecutive fragments, `n_runs` of them `run_stride` fragments apart, copied back to back to `buf`
-__device__ __forceinline__ void stage_issue_runs(const f16x8* __restrict__ frags, int first, int run_len, int run_stride,
-                                                 int n_runs, f16x8* buf) {
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const uint32_t voff = (threadIdx.x & 63u) * 16u;
-    const char* base = reinterpret_cast<const char*>(frags);
-    const int count = run_len * n_runs;
-    for (int f = wave; f < count; f += NWF) {
-        const int src = first + (f / run_len) * run_stride + (f % run_len);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + (size_t)src * 1024 + voff),
-                                         (__attribute__((address_space(3))) void*)(buf + f * 64), 16, 0, 0);
-    }
-}
-
-__global__ __launch_bounds__(NWF * 64, 2) void deform_fwd2_kernel(DeformArgs A, float* __restrict__ offsets, int64_t n_tiles,
-                                                                const int64_t* __restrict__ n_dev) {
-    NSX_DEVICE_COUNT(A.S, n_tiles, 32, n_dev);
-    __shared__ __attribute__((aligned(16))) DeformLdsF L;
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int kb = lane >> 5;
-    const int64_t n_groups = (n_tiles + NWF - 1) / NWF;
-    for (int i = threadIdx.x; i < N_BIAS; i += blockDim.x) L.bias[i] = A.bias[i];
-    stage_issue_runs(A.frags, F0, 6, DF_TIN, 4, L.w[0] + S0A_LOCAL * 64);           // W0, K-steps 0..5
-    __syncthreads();
-    int cur = 0;
-    for (int64_t grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {        // all waves iterate together
-        const int64_t tile = grp * NWF + wave;
-        const int64_t b_raw = tile * 32 + (lane & 31);
-        const int64_t b = b_raw < A.S ? b_raw : A.S - 1;
-        lds_cfloat* bias = launder_lds(L.bias);
-        f16x8 x[DF_TIN], h[DF_TW];
-        float pn[3];
-        build_input(A, b, kb, pn, x);
-        f32x16 acc[4];
-        // L0: K-steps 0..5 | 6..10
-        stage_issue_runs(A.frags, F0 + 6, 5, DF_TIN, 4, L.w[cur ^ 1]);
-        acc_init(acc, bias + 0 * DFW, kb);
-        gemm_layer_lds<6>(L.w[cur], S0A_LOCAL, lane, x, acc);
-        stage_flip(cur);
-        stage_issue_runs(A.frags, F1, 32, 32, 1, L.w[cur ^ 1]);
-        gemm_layer_lds<5>(L.w[cur], 0, lane, x + 6, acc);
-        finish_layer<false>(acc, h);
-        stage_flip(cur);
-        // L1..L3
-#pragma unroll 1
-        for (int l = 1; l <= 3; ++l) {
-            if (l < 3) stage_issue_runs(A.frags, l == 1 ? F2 : F3, 32, 32, 1, L.w[cur ^ 1]);
-            else stage_issue_runs(A.frags, F4, 6, DF_TIN, 4, L.w[cur ^ 1]);           // W4 over the input, K-steps 0..5
-            acc_init(acc, bias + l * DFW, kb);
-            gemm_layer_lds<DF_TW>(L.w[cur], 0, lane, h, acc);
-            finish_layer<false>(acc, h);
-            stage_flip(cur);
-        }
-        // L4: cat[input, x] -- three stages, one accumulator
-        stage_issue_runs(A.frags, F4 + 6, 5, DF_TIN, 4, L.w[cur ^ 1]);
-        acc_init(acc, bias + 4 * DFW, kb);
-        gemm_layer_lds<6>(L.w[cur], 0, lane, x, acc);
-        stage_flip(cur);
-        stage_issue_runs(A.frags, F4X, 32, 32, 1, L.w[cur ^ 1]);
-        gemm_layer_lds<5>(L.w[cur], 0, lane, x + 6, acc);
-        stage_flip(cur);
-        stage_issue_runs(A.frags, F5, 32, 32, 1, L.w[cur ^ 1]);
-        gemm_layer_lds<DF_TW>(L.w[cur], 0, lane, h, acc);
-        finish_layer<false>(acc, h);
-        stage_flip(cur);
-        // L5 (+ out_activation ReLU); meanwhile the heads' 8 fragments and the next tile's first stage arrive together
-        stage_issue_runs(A.frags, FH, 8, 8, 1, L.w[cur ^ 1]);
-        stage_issue_runs(A.frags, F0, 6, DF_TIN, 4, L.w[cur ^ 1] + S0A_LOCAL * 64);
-        acc_init(acc, bias + 5 * DFW, kb);
-        gemm_layer_lds<DF_TW>(L.w[cur], 0, lane, h, acc);
-        finish_layer<false>(acc, h);
-        stage_flip(cur);
-        // heads (one M-tile, rows 0..5)
-        f32x16 o = zero16();
-#pragma unroll
-        for (int t = 0; t < DF_TW; ++t) o = mfma(L.w[cur][t * 64 + lane], h[t], o);
-        float own[4], oth[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) own[r] = (float)(half_t)(o[r] + bias[6 * DFW + acc_row(r, kb)]);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) oth[r] = __shfl_xor(own[r], 32);
-        // rows 0..3 live on kb = 0, rows 4..7 on kb = 1
-        float rr[3], vv[3];
-        rr[0] = kb ? oth[0] : own[0]; rr[1] = kb ? oth[1] : own[1]; rr[2] = kb ? oth[2] : own[2];
-        vv[0] = kb ? oth[3] : own[3]; vv[1] = kb ? own[0] : oth[0]; vv[2] = kb ? own[1] : oth[1];
-        float w[3];
-        se3_apply(rr, vv, pn, w);
-        if (b_raw < A.S && kb == 0) {
-#pragma unroll
-            for (int d = 0; d < 3; ++d) {
-                const float wd = (w[d] != w[d]) ? pn[d] : w[d];            // NaN deformation -> keep the point
-                offsets[b * 3 + d] = wd - pn[d];
-            }
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// forward kernel, round 4 (third attempt at the 40 % matrix-core duty of deform_fwd_kernel): the two waves of a SIMD in
-// ANTI-PHASE inside the lock-stepped block.  One barrier per weight stage keeps the 8 waves on the same stage, which is
-// what lets the weights cross L2 -> LDS once per 256 samples -- but it also keeps the two waves of a SIMD in the same
-// PHASE: both in the layer's MFMA stream, then both in its epilogue (cvt / ReLU / bias reload; the positional encoding; the
-// SE(3) tail), and the matrix cores idle through every epilogue.  Here half of the waves ("late": one of the two on every
-// SIMD) run the epilogue of a layer at the BEGINNING of the next stage's interval, in front of that stage's MFMAs -- their
-// accumulators live across the barrier -- and the SE(3) tail + store of a tile at the beginning of the next tile.  In every
-// interval one wave of a SIMD then streams MFMAs while the other runs VALU work, and vice versa; stages, barriers, LDS
-// footprint and the order of the MFMAs of a tile are deform_fwd_kernel's: outputs are bit-identical.
-// GMODE: which waves are late -- 0: waves 4..7 (a workgroup's waves go to the SIMDs round-robin: w and w + 4 share one),
-// 1: the odd waves (if they are placed in pairs).
-// ---------------------------------------------------------------------------------------------------------
-// PROBE != 0: TIMING PROBES, results are wrong on purpose (tools/deform_fwd_ab.py --variants 1,6,7,8,9): which resource
-// the layer GEMMs wait for.  1: one weight-fragment read per K-step instead of four (LDS reads / 4); 2: none (the MFMAs
-// take the activation fragment as both operands); 3: half of the MFMAs (all fragments still read); 4: no block barrier
-// between the stages; 5: no input construction (positional encoding, code rows) and no SE(3) tail (7: the first only, 8: the
-// second only; 9: the positional encoding without its 42 v_sin, 10: no code-row loads); 6: epilogues without conversion / ReLU.
-template <int KT, int PROBE>
-__device__ __forceinline__ void gemm_layer_probe(const f16x8* lds, int lane, const f16x8* in, f32x16 acc[4]) {
-    if constexpr (PROBE == 0 || PROBE == 4) {
-        gemm_layer_lds<KT, 1>(lds, 0, lane, in, acc);
-    } else {
-        const f16x8* base = lds + lane;
-#pragma unroll
-        for (int t = 0; t < KT; ++t) {
-            f16x8 a[4];
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-                if (PROBE == 1) a[mt] = base[(0 * KT + t) * 64];
-                else if (PROBE == 2) a[mt] = in[t];
-                else a[mt] = base[(mt * KT + t) * 64];
-            }
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-                if (PROBE == 3 && mt >= 2) {
-                    asm volatile("" ::"v"(a[mt]));                 // (the read stays)
-                    continue;
-                }
-                acc[mt] = mfma(a[mt], in[t], acc[mt]);
-            }
-        }
-    }
-}
-
-template <int GMODE, int PROBE = 0>
-__global__ __launch_bounds__(NW * 64, 1) void deform_fwd_skew_kernel(DeformArgs A, float* __restrict__ offsets,
-                                                                   int64_t n_tiles, const int64_t* __restrict__ n_dev) {
-    NSX_DEVICE_COUNT(A.S, n_tiles, 32, n_dev);
-    __shared__ __attribute__((aligned(16))) DeformLds L;
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int kb = lane >> 5;
-    const bool late = GMODE == 2 ? false : (GMODE == 0 ? (wave >= NW / 2) : ((wave & 1) != 0));      // wave-uniform
-    const int64_t n_groups = (n_tiles + NW - 1) / NW;
-    lds_prologue(A, L, F0, 44);
-    int cur = 0;
-    auto fin = [&](const f32x16 a4[4], f16x8 hh[DF_TW]) {
-        if constexpr (PROBE == 6) {
-#pragma unroll
-            for (int t = 0; t < DF_TW; ++t) {
-                u32x4 hv;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) hv[q] = __builtin_bit_cast(uint32_t, a4[t >> 1][8 * (t & 1) + 2 * q]) & 0x3BFF3BFFu;
-                hh[t] = __builtin_bit_cast(f16x8, hv);
-            }
-        } else {
-            finish_layer<false>(a4, hh);
-        }
-    };
-    auto flip = [&](int& c) {
-        if constexpr (PROBE == 4) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            c ^= 1;
-        } else {
-            stage_flip(c);
-        }
-    };
-    // the late waves' finished tile whose SE(3) tail is still to run
-    float p_r[3] = {0.f, 0.f, 0.f}, p_v[3] = {0.f, 0.f, 0.f}, p_pn[3] = {0.f, 0.f, 0.f};
-    int64_t p_b = -1;
-    auto emit = [&](const float r[3], const float v[3], const float pn[3], int64_t b) {
-        float w[3];
-        if constexpr (PROBE == 5 || PROBE == 8) { w[0] = r[0] + v[0]; w[1] = r[1] + v[1]; w[2] = r[2] + v[2]; }
-        else se3_apply(r, v, pn, w);
-        if (b >= 0 && kb == 0) {
-#pragma unroll
-            for (int d = 0; d < 3; ++d) {
-                const float wd = (w[d] != w[d]) ? pn[d] : w[d];            // NaN deformation -> keep the point
-                offsets[b * 3 + d] = wd - pn[d];
-            }
-        }
-    };
-    for (int64_t grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {        // all waves iterate together
-        const int64_t tile = grp * NW + wave;
-        const int64_t b_raw = tile * 32 + (lane & 31);
-        const int64_t b = b_raw < A.S ? b_raw : A.S - 1;
-        lds_cfloat* bias = launder_lds(L.bias);
-        f16x8 x[DF_TIN], h[DF_TW];
-        f32x16 acc[4];
-        float pn[3];
-        // ---- interval 0: W0 over the input
-        stage_issue(A.frags, F1, 32, L.w[cur ^ 1]);
-        if (late) {
-            emit(p_r, p_v, p_pn, p_b);
-            p_b = -1;
-        }
-        if constexpr (PROBE == 5 || PROBE == 7) {
-            pn[0] = pn[1] = pn[2] = 0.25f;
-#pragma unroll
-            for (int t = 0; t < DF_TIN; ++t)
-#pragma unroll
-                for (int q = 0; q < 8; ++q) x[t][q] = (half_t)(float)((lane + t + q) & 7);
-        } else if constexpr (PROBE == 9) {
-            build_input<1>(A, b, kb, pn, x);
-        } else if constexpr (PROBE == 10) {
-            build_input<2>(A, b, kb, pn, x);
-        } else {
-            build_input(A, b, kb, pn, x);
-        }
-        acc_init(acc, bias + 0 * DFW, kb);
-        gemm_layer_probe<DF_TIN, PROBE>(L.w[cur], lane, x, acc);
-        if (!late) fin(acc, h);
-        flip(cur);
-        // ---- intervals 1..3: W1..W3
-#pragma unroll 1
-        for (int l = 1; l <= 3; ++l) {
-            stage_issue(A.frags, l == 1 ? F2 : (l == 2 ? F3 : F4), l == 3 ? 44 : 32, L.w[cur ^ 1]);
-            if (late) fin(acc, h);                             // the previous layer's epilogue
-            acc_init(acc, bias + l * DFW, kb);
-            gemm_layer_probe<DF_TW, PROBE>(L.w[cur], lane, h, acc);
-            if (!late) fin(acc, h);
-            flip(cur);
-        }
-        // ---- interval 4: W4 over the input
-        stage_issue(A.frags, F4X, 32, L.w[cur ^ 1]);
-        if (late) fin(acc, h);                                 // L3's epilogue
-        acc_init(acc, bias + 4 * DFW, kb);
-        gemm_layer_probe<DF_TIN, PROBE>(L.w[cur], lane, x, acc);
-        flip(cur);
-        // ---- interval 5: W4 over x
-        stage_issue(A.frags, F5, 40, L.w[cur ^ 1]);
-        gemm_layer_probe<DF_TW, PROBE>(L.w[cur], lane, h, acc);
-        if (!late) fin(acc, h);
-        flip(cur);
-        // ---- interval 6: W5 (+ out_activation ReLU) and the heads
-        stage_issue(A.frags, F0, 44, L.w[cur ^ 1]);                            // the next tile's first stage
-        if (late) fin(acc, h);                                 // L4's epilogue
-        acc_init(acc, bias + 5 * DFW, kb);
-        gemm_layer_probe<DF_TW, PROBE>(L.w[cur], lane, h, acc);
-        fin(acc, h);
-        f32x16 o = zero16();
-#pragma unroll
-        for (int t = 0; t < DF_TW; ++t) o = mfma(L.w[cur][(32 + t) * 64 + lane], h[t], o);
-        float own[4], oth[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) own[r] = (float)(half_t)(o[r] + bias[6 * DFW + acc_row(r, kb)]);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) oth[r] = __shfl_xor(own[r], 32);
-        // rows 0..3 live on kb = 0, rows 4..7 on kb = 1
-        float rr[3], vv[3];
-        rr[0] = kb ? oth[0] : own[0]; rr[1] = kb ? oth[1] : own[1]; rr[2] = kb ? oth[2] : own[2];
-        vv[0] = kb ? oth[3] : own[3]; vv[1] = kb ? own[0] : oth[0]; vv[2] = kb ? own[1] : oth[1];
-        const int64_t b_out = b_raw < A.S ? b : -1;
-        if (!late) {
-            emit(rr, vv, pn, b_out);
-        } else {
-#pragma unroll
-            for (int d = 0; d < 3; ++d) { p_r[d] = rr[d]; p_v[d] = vv[d]; p_pn[d] = pn[d]; }
-            p_b = b_out;
-        }
-        flip(cur);
-    }
-    if (late) emit(p_r, p_v, p_pn, p_b);
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// forward kernel with the warp-code columns of the two input layers factored through the code SLOT (round 4; not the default
-// until tests/test_deform_gpu.py has run on it).  What the timing probes of deform_fwd_skew_kernel say: building the layer
-// input costs 27 % of deform_fwd_kernel, 16 % of it the per-lane loads of the sample's 128-float code row (33 uncoalesced
-// 16-byte loads per lane and tile), and the two input GEMMs (W0, W4 over the 176-wide input: 2 x 44 MFMAs) are a third of the
-// tile's 256 MFMAs although 128 of their 173 columns multiply a vector that only depends on the sample's slot.  So, as
-// the backward does for the gradients: T_l[row][n] = sum_{k >= 48} W_l[n][k] * code16[row][k - 45] (l = 0, 4; fp16 operands,
-// fp32 sums; deform_code_terms_kernel, n_rows x 2 x 128 numbers) is added to the bias the accumulators start from, and the
-// GEMMs keep the first 3 K-steps (k < 48: the 45 positional-encoding columns + the first 3 code columns, so that the packed
-// fragments stay as they are).  Per tile 192 instead of 256 MFMAs, 3 instead of 11 input fragments, 2 code-row loads per lane
-// instead of 33; the terms live in LDS (<= 48 rows).  Same products, another summation order: equal to deform_fwd_kernel up
-// to fp32 rounding of the pre-activations, not bit for bit.
+// forward kernel with the warp-code columns of the two input layers factored through the code ROW (round 4; the route of every
+// forward whose codes are rows of a table -- training, sigma_fn, occupancy update, evaluation -- since round 5).
+// Timing probes of round 4 (the probe kernels live in the history, commit 010eae6): building the layer input costs
+// 27 % of deform_fwd_kernel, 16 % of it the per-lane loads of the sample's 128-float code row (33 uncoalesced 16-byte loads per
+// lane and tile), and the two input GEMMs (W0, W4 over the 176-wide input: 2 x 44 MFMAs) are a third of the tile's 256 MFMAs
+// although 128 of their 173 columns multiply a vector that only depends on the sample's code row.  So, as the backward does for
+// the gradients: T_l[row][n] = sum_{k >= 48} W_l[n][k] * code16[row][k - 45] (l = 0, 4; fp16 operands, fp32 sums;
+// deform_code_terms_kernel, n_rows x 2 x 128 numbers) is added to the bias the accumulators start from, and the GEMMs keep the
+// first 3 K-steps (k < 48: the 45 positional-encoding columns + the first 3 code columns, so that the packed fragments stay as
+// they are).  Per tile 192 instead of 256 MFMAs, 3 instead of 11 input fragments, 2 code-row loads per lane instead of 33.
+// The terms live in LDS when the table has <= TERM_LDS_ROWS rows (a training batch: <= 24 images; an evaluation image: 1), and
+// are read from global memory (L2-resident: 1 KB per row) otherwise (the occupancy update draws from all T timesteps) -- the same
+// fp32 numbers added in the same order, so the two placements agree bit for bit, and a row's result does not depend on which
+// table it sits in.  Same products as deform_fwd_kernel in another summation order: equal up to fp32 rounding of the
+// pre-activations, not bit for bit.
 // ---------------------------------------------------------------------------------------------------------
 constexpr int TERM_KSTEPS = 3;                  // K-steps of the input stages that stay in the GEMM (k < 48)
 constexpr int TERM_K0 = 16 * TERM_KSTEPS;       // first input column the terms cover
 constexpr int TERM_ROW = 2 * DFW;               // floats per code row: T0 | T4
 constexpr int TERM_STRIDE = TERM_ROW + 4;       // LDS row stride (lanes of one instruction read different rows at one offset)
-constexpr int TERM_MAX_ROWS = 48;
+constexpr int TERM_LDS_ROWS = 64;               // = NSX_MAX_SLOTS: every batch table fits
 
 __global__ __launch_bounds__(DFW) void deform_code_terms_kernel(const f16x8* __restrict__ frags, const float* __restrict__ code,
                                                                int64_t code_stride, int n_rows, float* __restrict__ terms) {
@@ -887,17 +590,19 @@ __global__ __launch_bounds__(DFW) void deform_code_terms_kernel(const f16x8* __r
     terms[(int64_t)row * TERM_ROW + which * DFW + n] = acc;
 }
 
+template <bool LDS_TERMS>
 struct DeformLdsT {
     f16x8 w[2][STAGE_FRAGS * 64];
     float bias[N_BIAS];
-    float terms[TERM_MAX_ROWS * TERM_STRIDE];
+    float terms[LDS_TERMS ? TERM_LDS_ROWS * TERM_STRIDE : 4];
 };
+static_assert(sizeof(DeformLdsT<true>) <= 160 * 1024, "the forward's LDS block must fit the CU's 160 KB");
 
-// the first TERM_KSTEPS input fragments of sample b (build_input's first loop)
-__device__ __forceinline__ void build_input_head(const DeformArgs& A, int64_t b, int kb, float pn[3], f16x8 x[TERM_KSTEPS]) {
+// the first TERM_KSTEPS input fragments of sample b (build_input's first loop); `crow`: the sample's code row
+__device__ __forceinline__ void build_input_head(const DeformArgs& A, int64_t b, int kb, const float* crow, float pn[3],
+                                                 f16x8 x[TERM_KSTEPS]) {
 #pragma unroll
     for (int d = 0; d < 3; ++d) pn[d] = (A.pos[b * 3 + d] - A.aabb_min[d]) / A.aabb_ext[d];
-    const float* crow = A.code + (A.slot ? (int64_t)A.slot[b] : b) * A.code_stride;
     auto pe_value = [&](int k) -> float {
         if (k < 42) {
             const int kk = k < 21 ? k : k - 21;
@@ -927,14 +632,15 @@ __device__ __forceinline__ void build_input_head(const DeformArgs& A, int64_t b,
     }
 }
 
-// accumulators start at bias + the slot's code term
-__device__ __forceinline__ void acc_init_terms(f32x16 acc[4], lds_cfloat* bias_lds, const float* term_lds, int kb) {
+// accumulators start at bias + the row's code term (TP: an LDS or a global pointer)
+template <typename TP>
+__device__ __forceinline__ void acc_init_terms(f32x16 acc[4], lds_cfloat* bias_lds, TP term, int kb) {
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const f32x4 v = *reinterpret_cast<lds_cfloat4*>(bias_lds + 32 * mt + 8 * q + 4 * kb);
-            const f32x4 tv = *reinterpret_cast<const f32x4*>(term_lds + 32 * mt + 8 * q + 4 * kb);
+            const f32x4 tv = *reinterpret_cast<const f32x4*>(term + 32 * mt + 8 * q + 4 * kb);
             acc[mt][4 * q + 0] = v.x + tv.x; acc[mt][4 * q + 1] = v.y + tv.y;
             acc[mt][4 * q + 2] = v.z + tv.z; acc[mt][4 * q + 3] = v.w + tv.w;
         }
@@ -953,16 +659,20 @@ __device__ __forceinline__ void gemm_input_head(const f16x8* lds, int lane, cons
     }
 }
 
+// A.slot == nullptr: every sample takes row 0 (one code for the whole launch: an evaluation image's timestep)
+template <bool LDS_TERMS>
 __global__ __launch_bounds__(NW * 64, 1) void deform_fwd_terms_kernel(DeformArgs A, const float* __restrict__ terms, int n_rows,
                                                                     float* __restrict__ offsets, int64_t n_tiles,
                                                                     const int64_t* __restrict__ n_dev) {
     NSX_DEVICE_COUNT(A.S, n_tiles, 32, n_dev);
-    __shared__ __attribute__((aligned(16))) DeformLdsT L;
+    __shared__ __attribute__((aligned(16))) DeformLdsT<LDS_TERMS> L;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int kb = lane >> 5;
     const int64_t n_groups = (n_tiles + NW - 1) / NW;
-    for (int i = threadIdx.x; i < n_rows * TERM_ROW; i += blockDim.x)
-        L.terms[(i / TERM_ROW) * TERM_STRIDE + (i % TERM_ROW)] = terms[i];
+    if constexpr (LDS_TERMS) {
+        for (int i = threadIdx.x; i < n_rows * TERM_ROW; i += blockDim.x)
+            L.terms[(i / TERM_ROW) * TERM_STRIDE + (i % TERM_ROW)] = terms[i];
+    }
     for (int i = threadIdx.x; i < N_BIAS; i += blockDim.x) L.bias[i] = A.bias[i];
     stage_issue(A.frags, F0, 44, L.w[0]);
     __syncthreads();
@@ -972,15 +682,18 @@ __global__ __launch_bounds__(NW * 64, 1) void deform_fwd_terms_kernel(DeformArgs
         const int64_t b_raw = tile * 32 + (lane & 31);
         const int64_t b = b_raw < A.S ? b_raw : A.S - 1;
         lds_cfloat* bias = launder_lds(L.bias);
-        int row = A.slot[b];
+        int row = A.slot ? A.slot[b] : 0;
         row = row < 0 ? 0 : (row >= n_rows ? n_rows - 1 : row);
-        const float* term = L.terms + row * TERM_STRIDE;
+        const float* crow = A.code + (int64_t)row * A.code_stride;
+        const float* term;
+        if constexpr (LDS_TERMS) term = L.terms + row * TERM_STRIDE;
+        else term = terms + (int64_t)row * TERM_ROW;
         f16x8 x[TERM_KSTEPS], h[DF_TW];
         f32x16 acc[4];
         float pn[3];
         // L0
         stage_issue(A.frags, F1, 32, L.w[cur ^ 1]);
-        build_input_head(A, b, kb, pn, x);
+        build_input_head(A, b, kb, crow, pn, x);
         acc_init_terms(acc, bias + 0 * DFW, term, kb);
         gemm_input_head(L.w[cur], lane, x, acc);
         finish_layer<false>(acc, h);
@@ -989,7 +702,7 @@ __global__ __launch_bounds__(NW * 64, 1) void deform_fwd_terms_kernel(DeformArgs
         for (int l = 1; l <= 3; ++l) {
             stage_issue(A.frags, l == 1 ? F2 : (l == 2 ? F3 : F4), l == 3 ? 44 : 32, L.w[cur ^ 1]);
             acc_init(acc, bias + l * DFW, kb);
-            gemm_layer_lds<DF_TW, 1>(L.w[cur], 0, lane, h, acc);
+            gemm_layer_lds<DF_TW>(L.w[cur], 0, lane, h, acc);
             finish_layer<false>(acc, h);
             stage_flip(cur);
         }
@@ -999,13 +712,13 @@ __global__ __launch_bounds__(NW * 64, 1) void deform_fwd_terms_kernel(DeformArgs
         gemm_input_head(L.w[cur], lane, x, acc);
         stage_flip(cur);
         stage_issue(A.frags, F5, 40, L.w[cur ^ 1]);
-        gemm_layer_lds<DF_TW, 1>(L.w[cur], 0, lane, h, acc);
+        gemm_layer_lds<DF_TW>(L.w[cur], 0, lane, h, acc);
         finish_layer<false>(acc, h);
         stage_flip(cur);
         // L5 + heads
         stage_issue(A.frags, F0, 44, L.w[cur ^ 1]);
         acc_init(acc, bias + 5 * DFW, kb);
-        gemm_layer_lds<DF_TW, 1>(L.w[cur], 0, lane, h, acc);
+        gemm_layer_lds<DF_TW>(L.w[cur], 0, lane, h, acc);
         finish_layer<false>(acc, h);
         f32x16 o = zero16();
 #pragma unroll
@@ -1125,7 +838,7 @@ __global__ __launch_bounds__(NW * 64, 1) void deform_bwd_kernel(DeformArgs A, co
         // waves past the last tile still walk the layers (barriers) but write into the block-private dummy tile
         half_t* T = scratch + (tile_ok ? tile : n_tiles + (int64_t)blockIdx.x * NW + wave) * TILE_HALFS;
         Fwd F;
-        forward_tile<true, LY::A0_FRAGS, 1, !SLOTS>(A, b, lane, F, T, L, cur, BH, 36);
+        forward_tile<true, LY::A0_FRAGS, !SLOTS>(A, b, lane, F, T, L, cur, BH, 36);
         // ---- SE(3) backward (fp32): g = dL/dwarped ----
         float g[3] = {0.f, 0.f, 0.f};
         if (valid) { g[0] = goff[b * 3]; g[1] = goff[b * 3 + 1]; g[2] = goff[b * 3 + 2]; }
@@ -1728,42 +1441,10 @@ int nsx_deform_fwd(const void* packed, const float* positions, int64_t S, const 
     const float* bias = reinterpret_cast<const float*>(reinterpret_cast<const uint8_t*>(packed) + (size_t)N_FRAGS * 64 * 16);
     fill_args(A, positions, S, aabb_host, code, code_stride, code_slot, window7_host, packed, bias);
     const int64_t n_tiles = (S + 31) / 32;
-    // NSX_DEFORM_FWD (A/B): 1 = one 8-wave block per CU, LDS reads scheduled by the compiler (rounds 1-3); 3 = the same with
-    // the weight fragments read two K-steps ahead, pinned; 2 = two independent 4-wave blocks per CU; 4 / 5 = the two waves of
-    // a SIMD in anti-phase (late waves = 4..7 / the odd ones)
-    static const int variant = [] {
-        const char* e = getenv("NSX_DEFORM_FWD");
-        return e ? atoi(e) : 1;
-    }();
-    if (variant != 2) {
-        int64_t blocks = (n_tiles + NW - 1) / NW;
-        if (blocks > num_cus()) blocks = num_cus();
-        if (variant == 4)
-            hipLaunchKernelGGL(deform_fwd_skew_kernel<0>, dim3((unsigned)blocks), dim3(NW * 64), 0, (hipStream_t)stream, A,
-                               offsets, n_tiles, n_device);
-        else if (variant == 5)
-            hipLaunchKernelGGL(deform_fwd_skew_kernel<1>, dim3((unsigned)blocks), dim3(NW * 64), 0, (hipStream_t)stream, A,
-                               offsets, n_tiles, n_device);
-        else if (variant >= 6 && variant <= 15) {              // timing probes (wrong results on purpose)
-            auto k = variant == 6 ? deform_fwd_skew_kernel<2, 1> : variant == 7 ? deform_fwd_skew_kernel<2, 2>
-                     : variant == 8 ? deform_fwd_skew_kernel<2, 3> : variant == 9 ? deform_fwd_skew_kernel<2, 4>
-                     : variant == 10 ? deform_fwd_skew_kernel<2, 5> : variant == 11 ? deform_fwd_skew_kernel<2, 6>
-                     : variant == 12 ? deform_fwd_skew_kernel<2, 7> : variant == 13 ? deform_fwd_skew_kernel<2, 8>
-                     : variant == 14 ? deform_fwd_skew_kernel<2, 9> : deform_fwd_skew_kernel<2, 10>;
-            hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(NW * 64), 0, (hipStream_t)stream, A, offsets, n_tiles, n_device);
-        }
-        else if (variant == 3)
-            hipLaunchKernelGGL(deform_fwd_kernel<2>, dim3((unsigned)blocks), dim3(NW * 64), 0, (hipStream_t)stream, A, offsets,
-                               n_tiles, n_device);
-        else
-            hipLaunchKernelGGL(deform_fwd_kernel<1>, dim3((unsigned)blocks), dim3(NW * 64), 0, (hipStream_t)stream, A, offsets,
-                               n_tiles, n_device);
-    } else {
-        int64_t blocks = (n_tiles + NWF - 1) / NWF;
-        if (blocks > 2 * num_cus()) blocks = 2 * num_cus();
-        hipLaunchKernelGGL(deform_fwd2_kernel, dim3((unsigned)blocks), dim3(NWF * 64), 0, (hipStream_t)stream, A, offsets,
-                           n_tiles, n_device);
-    }
+    int64_t blocks = (n_tiles + NW - 1) / NW;
+    if (blocks > num_cus()) blocks = num_cus();
+    hipLaunchKernelGGL(deform_fwd_kernel, dim3((unsigned)blocks), dim3(NW * 64), 0, (hipStream_t)stream, A, offsets, n_tiles,
+                       n_device);
     NSX_LAUNCH_CHECK("nsx_deform_fwd launch");
     return NSX_OK;
 }
@@ -1775,12 +1456,11 @@ int nsx_deform_fwd_rows(const void* packed, const float* positions, int64_t S, c
                         float* offsets, float* terms_scratch, const int64_t* n_device, void* stream) {
     NSX_REQUIRE(S >= 0, "nsx_deform_fwd_rows: negative sample count");
     if (S == 0) return NSX_OK;
-    NSX_REQUIRE(packed && positions && aabb_host && code_table && code_slot && offsets,
+    NSX_REQUIRE(packed && positions && aabb_host && code_table && offsets && terms_scratch,
                 "nsx_deform_fwd_rows: NULL argument");
     NSX_REQUIRE(n_code_rows >= 1, "nsx_deform_fwd_rows: n_code_rows=%d", n_code_rows);
-    if (n_code_rows > TERM_MAX_ROWS || !terms_scratch)           // the terms do not fit LDS: the general kernel
-        return nsx_deform_fwd(packed, positions, S, aabb_host, code_table, code_stride, code_slot, window7_host, offsets,
-                              n_device, stream);
+    NSX_REQUIRE(code_slot || n_code_rows == 1, "nsx_deform_fwd_rows: code_slot may only be NULL for a one-row table (got %d rows)",
+                n_code_rows);
     DeformArgs A;
     const float* bias = reinterpret_cast<const float*>(reinterpret_cast<const uint8_t*>(packed) + (size_t)N_FRAGS * 64 * 16);
     fill_args(A, positions, S, aabb_host, code_table, code_stride, code_slot, window7_host, packed, bias);
@@ -1790,8 +1470,12 @@ int nsx_deform_fwd_rows(const void* packed, const float* positions, int64_t S, c
     const int64_t n_tiles = (S + 31) / 32;
     int64_t blocks = (n_tiles + NW - 1) / NW;
     if (blocks > num_cus()) blocks = num_cus();
-    hipLaunchKernelGGL(deform_fwd_terms_kernel, dim3((unsigned)blocks), dim3(NW * 64), 0, (hipStream_t)stream, A,
-                       (const float*)terms_scratch, n_code_rows, offsets, n_tiles, n_device);
+    if (n_code_rows <= TERM_LDS_ROWS)
+        hipLaunchKernelGGL(deform_fwd_terms_kernel<true>, dim3((unsigned)blocks), dim3(NW * 64), 0, (hipStream_t)stream, A,
+                           (const float*)terms_scratch, n_code_rows, offsets, n_tiles, n_device);
+    else                                                         // the terms stay in global memory (L2): same numbers, same order
+        hipLaunchKernelGGL(deform_fwd_terms_kernel<false>, dim3((unsigned)blocks), dim3(NW * 64), 0, (hipStream_t)stream, A,
+                           (const float*)terms_scratch, n_code_rows, offsets, n_tiles, n_device);
     NSX_LAUNCH_CHECK("nsx_deform_fwd_rows launch");
     return NSX_OK;
 }

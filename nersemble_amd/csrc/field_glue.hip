@@ -141,6 +141,18 @@ static unsigned grid_for(int64_t n) {
     return (unsigned)(b > cap ? cap : (b < 1 ? 1 : b));
 }
 
+// ray r: rint(times[r] * (T - 1)) must be the timestep of the code row the ray was given (nsx_check_code_rows)
+__global__ __launch_bounds__(256) void check_code_rows_kernel(const float* __restrict__ times, const int32_t* __restrict__ slots,
+                                                             int64_t R, const int32_t* __restrict__ row_timesteps, int n_rows,
+                                                             int n_timesteps, int32_t* __restrict__ flag) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    const int32_t s = slots[r];
+    bool bad = s < 0 || s >= n_rows;
+    if (!bad) bad = row_timesteps[s] != (int32_t)rintf(times[r] * (float)(n_timesteps - 1));   // torch: (t * (T - 1)).round().int()
+    if (bad) atomicOr(flag, 1);
+}
+
 }  // namespace nsx
 
 using namespace nsx;
@@ -190,6 +202,19 @@ int nsx_gather_rows(int n_arrays, const void* const* srcs, const int64_t* row_by
     hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for(max_pieces), n_arrays), dim3(256), 0, (hipStream_t)stream, A, index, n,
                        n_device);
     NSX_LAUNCH_CHECK("nsx_gather_rows launch");
+    return NSX_OK;
+}
+
+int nsx_check_code_rows(const float* ray_times, const int32_t* ray_slots, int64_t R, const int32_t* row_timesteps,
+                        int n_code_rows, int n_timesteps, int32_t* flag, void* stream) {
+    NSX_REQUIRE(R >= 0, "nsx_check_code_rows: negative ray count");
+    if (R == 0) return NSX_OK;
+    NSX_REQUIRE(ray_times && ray_slots && row_timesteps && flag, "nsx_check_code_rows: NULL argument");
+    NSX_REQUIRE(n_code_rows >= 1 && n_timesteps >= 1, "nsx_check_code_rows: n_code_rows=%d n_timesteps=%d", n_code_rows,
+                n_timesteps);
+    hipLaunchKernelGGL(check_code_rows_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ray_times,
+                       ray_slots, R, row_timesteps, n_code_rows, n_timesteps, flag);
+    NSX_LAUNCH_CHECK("nsx_check_code_rows launch");
     return NSX_OK;
 }
 

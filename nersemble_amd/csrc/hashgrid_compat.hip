@@ -5,8 +5,6 @@
 // HashEnsemble kernels (hash_ensemble.hip) are the performance path; this one is the straightforward per-(sample,
 // level) formulation of the same algorithm: fp16 table [total][F] in, fp16 features [B][L*F] out, fp32 atomics for
 // the parameter gradient, analytic dL/dx.
-#include <cstdlib>
-
 #include "nsx_common.h"
 
 namespace nsx {
@@ -18,54 +16,8 @@ __device__ __forceinline__ uint32_t entry_of(const uint32_t c[3], uint32_t res, 
     return umod(c[0] + c[1] * res + c[2] * res * res, size, 1.0f / (float)size);
 }
 
-template <int F>
-__global__ __launch_bounds__(256) void hashgrid_fwd_kernel(const float* __restrict__ x, int64_t B,
-                                                           const half_t* __restrict__ table, const nsx_grid_geom g,
-                                                           half_t* __restrict__ out) {
-    const int L = g.n_levels;
-    const int shift = (L & (L - 1)) == 0 ? __builtin_ctz((unsigned)L) : -1;     // (a 64-bit division per item otherwise)
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < B * L; i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t b = shift >= 0 ? (i >> shift) : i / L;
-        const int l = (int)(i - b * L);
-        const float scale = g.scale[l];
-        uint32_t c0[3]; float w[3];
-#pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            const float p = __fmaf_rn(scale, x[b * 3 + d], 0.5f), f = floorf(p);
-            c0[d] = (uint32_t)(int32_t)f; w[d] = p - f;
-        }
-        float acc[F];
-#pragma unroll
-        for (int j = 0; j < F; ++j) acc[j] = 0.f;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const uint32_t c[3] = {c0[0] + (k & 1), c0[1] + ((k >> 1) & 1), c0[2] + ((k >> 2) & 1)};
-            const uint32_t e = entry_of(c, g.res[l], g.size[l], g.hashed[l] != 0);
-            const float wk = ((k & 1) ? w[0] : 1.f - w[0]) * ((k & 2) ? w[1] : 1.f - w[1]) * ((k & 4) ? w[2] : 1.f - w[2]);
-            // one entry = F halfs = F / 2 dwords, naturally aligned (the table is): ONE load per corner, not F
-            typedef uint32_t row_t __attribute__((ext_vector_type(F / 2)));
-            const row_t rv = *reinterpret_cast<const row_t*>(table + ((size_t)g.offset[l] + e) * F);
-#pragma unroll
-            for (int j = 0; j < F / 2; ++j) {
-                const half2_t t = as_half2(rv[j]);
-                acc[2 * j] = __fmaf_rn(wk, (float)t.x, acc[2 * j]);
-                acc[2 * j + 1] = __fmaf_rn(wk, (float)t.y, acc[2 * j + 1]);
-            }
-        }
-        {
-            typedef uint32_t row_t __attribute__((ext_vector_type(F / 2)));
-            row_t ov;
-#pragma unroll
-            for (int j = 0; j < F / 2; ++j) {
-                half2_t t; t.x = (half_t)acc[2 * j]; t.y = (half_t)acc[2 * j + 1];
-                ov[j] = as_u32(t);
-            }
-            *reinterpret_cast<row_t*>(out + b * (int64_t)(L * F) + l * F) = ov;
-        }
-    }
-}
-
-// The same lookup with TWO lanes per (sample, level): lane pair = the two x-corners of the cell, each lane gathers the 4
+// Forward lookup with TWO lanes per (sample, level) (round 4; the one-lane-per-item form it replaced -- one lane gathers all 8
+// corners -- was 10 % slower on the evaluation image and is gone since round 5): lane pair = the two x-corners of the cell, each lane gathers the 4
 // (y, z) corners of its x.  Entries of x and x + 1 are neighbours in the table (dense levels: consecutive indices; hashed
 // levels: x enters the hash un-multiplied, so x ^ h and (x + 1) ^ h differ in their low bits only and share a 128-byte line
 // unless x is the last of its 32-block), and lanes of ONE instruction that hit one line cost one request: 32 lines per
@@ -191,18 +143,9 @@ int nsx_hashgrid_fwd(const float* x, int64_t B, const nsx_half* table, int F, co
     hipStream_t st = (hipStream_t)stream;
     const half_t* t = reinterpret_cast<const half_t*>(table);
     half_t* o = reinterpret_cast<half_t*>(out);
-    // NSX_HASHGRID_FWD (A/B): 1 = one lane per (sample, level), 2 = a lane pair per (sample, level) (see the kernels)
-    static const int variant = [] {
-        const char* e = getenv("NSX_HASHGRID_FWD");
-        return e ? atoi(e) : 2;
-    }();
-    if (variant == 2) {
-        if (F == 2) hipLaunchKernelGGL((hashgrid_fwd_pair_kernel<2>), grid, block, 0, st, x, B, t, *g, o);
-        else if (F == 4) hipLaunchKernelGGL((hashgrid_fwd_pair_kernel<4>), grid, block, 0, st, x, B, t, *g, o);
-        else hipLaunchKernelGGL((hashgrid_fwd_pair_kernel<8>), grid, block, 0, st, x, B, t, *g, o);
-    } else if (F == 2) hipLaunchKernelGGL((hashgrid_fwd_kernel<2>), grid, block, 0, st, x, B, t, *g, o);
-    else if (F == 4) hipLaunchKernelGGL((hashgrid_fwd_kernel<4>), grid, block, 0, st, x, B, t, *g, o);
-    else hipLaunchKernelGGL((hashgrid_fwd_kernel<8>), grid, block, 0, st, x, B, t, *g, o);
+    if (F == 2) hipLaunchKernelGGL((hashgrid_fwd_pair_kernel<2>), grid, block, 0, st, x, B, t, *g, o);
+    else if (F == 4) hipLaunchKernelGGL((hashgrid_fwd_pair_kernel<4>), grid, block, 0, st, x, B, t, *g, o);
+    else hipLaunchKernelGGL((hashgrid_fwd_pair_kernel<8>), grid, block, 0, st, x, B, t, *g, o);
     NSX_LAUNCH_CHECK("nsx_hashgrid_fwd launch");
     return NSX_OK;
 }

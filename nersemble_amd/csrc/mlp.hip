@@ -517,10 +517,8 @@ int nsx_mlp_bwd(const nsx_half* weights, int n_hidden_mats, int64_t B,
     // One block (4 waves) per CU: the backward holds its weight gradients in registers (218 VGPRs + 144 AGPRs with a
     // hidden matrix: one wave per SIMD), so a second block per CU only queues behind the first -- and every block ends with
     // n_params atomics onto the same 7 168 addresses.  Measured in-step (645 k samples, 2 calls per step): 2 blocks per CU
-    // 0.191 ms per call, 1: 0.166, 1/2: 0.274 (NSX_MLP_BWD_HALF_BLOCKS_PER_CU = blocks per CU x 2, measurement knob).
-    static int per_cu_x2 = 0, per_cu0_x2 = 0;
-    if (!per_cu_x2) { const char* e = getenv("NSX_MLP_BWD_HALF_BLOCKS_PER_CU"); per_cu_x2 = e ? atoi(e) : 2; if (per_cu_x2 < 1) per_cu_x2 = 2; }
-    if (!per_cu0_x2) { const char* e = getenv("NSX_MLP_BWD0_HALF_BLOCKS_PER_CU"); per_cu0_x2 = e ? atoi(e) : 2; if (per_cu0_x2 < 1) per_cu0_x2 = 2; }
+    // 0.191 ms per call, 1: 0.166, 1/2: 0.274 (NSX_OPT_MLP_BWD(0)_HALF_BLOCKS_PER_CU = blocks per CU x 2).
+    const int per_cu_x2 = option(NSX_OPT_MLP_BWD_HALF_BLOCKS_PER_CU), per_cu0_x2 = option(NSX_OPT_MLP_BWD0_HALF_BLOCKS_PER_CU);
     const int64_t cap = (int64_t)num_cus() * (n_hidden_mats == 0 ? per_cu0_x2 : per_cu_x2) / 2;
     if (blocks > cap) blocks = cap;
     hipStream_t st = (hipStream_t)stream;

@@ -8,6 +8,7 @@ namespace nsx {
 
 void set_error(const char* fmt, ...);
 int hip_fail(hipError_t e, const char* what);
+int option(int which);      // nsx_get_option without the range check (nsx_core.hip)
 
 #define NSX_REQUIRE(cond, ...)                         \
     do {                                               \

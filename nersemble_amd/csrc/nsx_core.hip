@@ -3,9 +3,16 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <atomic>
 #include <cstring>
 
 namespace nsx {
+
+// launch-shape options (include/nsx.h): value, lowest and highest admissible value
+static std::atomic<int> g_opt[NSX_OPT_COUNT] = {{5}, {2}, {2}};
+static const int g_opt_lo[NSX_OPT_COUNT] = {1, 1, 1}, g_opt_hi[NSX_OPT_COUNT] = {8, 8, 8};
+
+int option(int which) { return g_opt[which].load(std::memory_order_relaxed); }
 
 static thread_local char g_err[512] = "";
 
@@ -28,6 +35,19 @@ extern "C" {
 int nsx_version(void) { return NSX_VERSION; }
 
 const char* nsx_last_error(void) { return nsx::g_err; }
+
+int nsx_set_option(int option, int value) {
+    NSX_REQUIRE(option >= 0 && option < NSX_OPT_COUNT, "nsx_set_option: unknown option %d", option);
+    NSX_REQUIRE(value >= nsx::g_opt_lo[option] && value <= nsx::g_opt_hi[option], "nsx_set_option: option %d takes %d..%d (got %d)",
+                option, nsx::g_opt_lo[option], nsx::g_opt_hi[option], value);
+    nsx::g_opt[option].store(value, std::memory_order_relaxed);
+    return NSX_OK;
+}
+
+int nsx_get_option(int option) {
+    NSX_REQUIRE(option >= 0 && option < NSX_OPT_COUNT, "nsx_get_option: unknown option %d", option);
+    return nsx::option(option);
+}
 
 int nsx_padded_grids(int H) {
     int p = 1;

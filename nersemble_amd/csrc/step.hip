@@ -5,6 +5,7 @@
 // (field_density_fn), :280-364 (get_outputs), :366-422 (losses / metrics), nersemble_volumetric_sampler.py:95-134.
 #include "nsx_common.h"
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 namespace nsx {
@@ -39,12 +40,14 @@ struct ProfRec {
     int64_t rows;
     int32_t H, n_slots, counted, tag;
 };
+// process-wide, behind ONE mutex (include/nsx.h): the records of concurrent callers interleave, no call races
+static std::mutex g_prof_mu;
 static bool g_prof_on = false;
 static int g_prof_tag = -1;
 static std::vector<ProfRec> g_prof;
 static std::vector<hipEvent_t> g_prof_pool;
 
-static hipEvent_t prof_event() {
+static hipEvent_t prof_event() {          // (g_prof_mu held)
     if (!g_prof_pool.empty()) {
         hipEvent_t e = g_prof_pool.back();
         g_prof_pool.pop_back();
@@ -60,14 +63,19 @@ struct ProfScope {
     bool on;
     ProfRec r;
     ProfScope(const char* name, void* stream, int64_t rows, int H, int n_slots, int counted)
-        : st((hipStream_t)stream), on(g_prof_on) {
-        if (!on) return;
-        r = ProfRec{name, prof_event(), prof_event(), rows, H, n_slots, counted, g_prof_tag};
+        : st((hipStream_t)stream), on(false) {
+        {
+            std::lock_guard<std::mutex> lk(g_prof_mu);
+            on = g_prof_on;
+            if (!on) return;
+            r = ProfRec{name, prof_event(), prof_event(), rows, H, n_slots, counted, g_prof_tag};
+        }
         (void)hipEventRecord(r.a, st);
     }
     ~ProfScope() {
         if (!on) return;
         (void)hipEventRecord(r.b, st);
+        std::lock_guard<std::mutex> lk(g_prof_mu);
         g_prof.push_back(r);
     }
 };
@@ -102,7 +110,7 @@ int nsx_step_plan_make(int64_t S, int64_t R, int n_code_rows, int H, int base_hi
         p->m_t0 = c.take(S * 4);
         p->m_t1 = c.take(S * 4);
         p->m_pos = c.take(S * 12);
-        p->m_ts = c.take(S * 4);
+        p->m_slot = c.take(S * 4);
         p->m_off = c.take(S * 12);
         p->m_pn = c.take(S * 12);
         p->m_sel = c.take(S);
@@ -112,6 +120,7 @@ int nsx_step_plan_make(int64_t S, int64_t R, int n_code_rows, int H, int base_hi
         p->m_vis = c.take(S);
         p->m_keep = c.take(S * 8);
         p->m_scratch = c.take(nsx_occ_scratch_bytes(S));
+        p->m_terms = c.take(nsx_deform_terms_floats(n_code_rows) * 4);
         p->n_kept = c.take(8);
         p->k_ri = c.take(S * 8);
         p->k_t0 = c.take(S * 4);
@@ -180,17 +189,20 @@ int nsx_step_sample_run(const nsx_step_sample* a, void* stream) {
     const int64_t S = a->S, R = a->R;
     NSX_REQUIRE(S >= 1 && S == p.S && R == p.R, "nsx_step_sample_run: S=%lld R=%lld do not match the plan (%lld, %lld)",
                 (long long)S, (long long)R, (long long)p.S, (long long)p.R);
-    NSX_REQUIRE(a->origins && a->directions && a->near_planes && a->packed_march && a->binaries && a->ray_timesteps &&
+    NSX_REQUIRE(a->origins && a->directions && a->near_planes && a->packed_march && a->binaries &&
                 a->ray_slots && a->deform_packed && a->deform_codes && a->tables && a->geom && a->hash_codes &&
                 a->base_w16 && a->alpha_thre_dev, "nsx_step_sample_run: NULL argument");
     NSX_REQUIRE(a->base_out_dim == 16 && a->geom->n_levels * 2 == 32, "nsx_step_sample_run: the drivers are built for 16 "
                 "levels x 2 features and a 16-wide mlp_base output (got %d levels, %d)", a->geom->n_levels, a->base_out_dim);
+    NSX_REQUIRE(a->n_code_rows >= 1 && a->n_code_rows <= NSX_MAX_SLOTS &&
+                p.m_terms + nsx_deform_terms_floats(a->n_code_rows) * 4 <= p.sample_bytes,
+                "nsx_step_sample_run: n_code_rows=%d does not match the plan", a->n_code_rows);
     uint8_t* w = a->ws;
     int64_t* m_ri = at<int64_t>(w, p.m_ri);
     float* m_t0 = at<float>(w, p.m_t0);
     float* m_t1 = at<float>(w, p.m_t1);
     float* m_pos = at<float>(w, p.m_pos);
-    int32_t* m_ts = at<int32_t>(w, p.m_ts);
+    int32_t* m_slot = at<int32_t>(w, p.m_slot);
     float* m_off = at<float>(w, p.m_off);
     float* m_pn = at<float>(w, p.m_pn);
     uint8_t* m_sel = at<uint8_t>(w, p.m_sel);
@@ -207,22 +219,25 @@ int nsx_step_sample_run(const nsx_step_sample* a, void* stream) {
     // -- sigma_fn: density at the marched midpoints (get_sigma_fn -> field_density_fn)
     NSX_TRY(nsx_sample_positions(a->origins, a->directions, m_ri, m_t0, m_t1, nullptr, S, nullptr, m_pos, nullptr, nullptr,
                                  nullptr, stream));
+    if (a->ray_times && a->row_timesteps && a->rows_flag)
+        NSX_TRY(nsx_check_code_rows(a->ray_times, a->ray_slots, R, a->row_timesteps, a->n_code_rows, a->n_timesteps,
+                                    a->rows_flag, stream));
     {
-        const void* srcs[1] = {a->ray_timesteps};
-        void* dsts[1] = {m_ts};
+        const void* srcs[1] = {a->ray_slots};
+        void* dsts[1] = {m_slot};
         const int64_t rb[1] = {4};
         NSX_TRY(nsx_gather_rows(1, srcs, rb, dsts, m_ri, S, nullptr, stream));
     }
-    NSX_CALL("nsx_deform_fwd", S, 0, 0, 0,
-             nsx_deform_fwd(a->deform_packed, m_pos, S, a->deform_aabb, a->deform_codes, a->deform_code_stride, m_ts,
-                            a->window7_host, m_off, nullptr, stream));
+    NSX_CALL("nsx_deform_fwd_rows", S, 0, a->n_code_rows, 0,
+             nsx_deform_fwd_rows(a->deform_packed, m_pos, S, a->deform_aabb, a->deform_codes, a->deform_code_stride, m_slot,
+                                 a->n_code_rows, a->window7_host, m_off, at<float>(w, p.m_terms), nullptr, stream));
     NSX_TRY(nsx_sample_positions(m_pos, nullptr, nullptr, nullptr, nullptr, m_off, S, a->field_aabb, nullptr, m_pn, m_sel,
                                  nullptr, stream));
     if (a->tables_ready_event &&
         hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)const_cast<void*>(a->tables_ready_event), 0) != hipSuccess)
         return hip_fail(hipGetLastError(), "nsx_step_sample_run: waiting for the tables");
     NSX_CALL("nsx_hash_ensemble_fwd", S, a->H, 0, 0,
-             nsx_hash_ensemble_fwd(m_pn, S, a->tables, a->H, a->geom, a->hash_codes, a->hash_code_stride, m_ts,
+             nsx_hash_ensemble_fwd(m_pn, S, a->tables, a->H, a->geom, a->hash_codes, a->hash_code_stride, m_slot,
                                    a->hash_window, m_feat, nullptr, stream));
     NSX_CALL("nsx_mlp_fwd", S, a->base_hidden, 0, 0,
              nsx_mlp_fwd(a->base_w16, a->base_hidden, S, nullptr, 0, 0, 1.0f, 0.0f, m_feat, 32, 0, 32, a->base_out_dim,
@@ -241,16 +256,16 @@ int nsx_step_sample_run(const nsx_step_sample* a, void* stream) {
         NSX_TRY(nsx_gather_rows(3, srcs, rb, dsts, m_keep, S, n_kept, stream));
     }
     {
-        const void* srcs[3] = {a->origins, a->directions, a->ray_slots};
-        void* dsts[3] = {w + p.k_org, w + p.k_dir, w + p.k_slot};
-        const int64_t rb[3] = {12, 12, 4};
-        NSX_TRY(nsx_gather_rows(3, srcs, rb, dsts, k_ri, S, n_kept, stream));
+        const void* srcs[2] = {a->origins, a->directions};
+        void* dsts[2] = {w + p.k_org, w + p.k_dir};
+        const int64_t rb[2] = {12, 12};
+        NSX_TRY(nsx_gather_rows(2, srcs, rb, dsts, k_ri, S, n_kept, stream));
     }
     {
-        const void* srcs[3] = {m_off, m_feat, m_base};
-        void* dsts[3] = {w + p.k_off, w + p.k_feat, w + p.k_base};
-        const int64_t rb[3] = {12, 64, 32};
-        NSX_TRY(nsx_gather_rows(3, srcs, rb, dsts, m_keep, S, n_kept, stream));
+        const void* srcs[4] = {m_off, m_feat, m_base, m_slot};
+        void* dsts[4] = {w + p.k_off, w + p.k_feat, w + p.k_base, w + p.k_slot};
+        const int64_t rb[4] = {12, 64, 32, 4};
+        NSX_TRY(nsx_gather_rows(4, srcs, rb, dsts, m_keep, S, n_kept, stream));
     }
     // -- nerfacc.pack_info of the kept samples (nersemble_instant_ngp.py:325)
     if (hipMemsetAsync(w + p.k_counts, 0, (size_t)R * 8, (hipStream_t)stream) != hipSuccess)
@@ -407,17 +422,25 @@ int nsx_step_main_bwd(const nsx_step_main* a, int stage, void* stream) {
 }
 
 int nsx_step_profile(int enable, int tag) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
     g_prof_on = enable != 0;
     g_prof_tag = tag;
     return NSX_OK;
 }
 
-int nsx_step_profile_count(void) { return (int)g_prof.size(); }
+int nsx_step_profile_count(void) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    return (int)g_prof.size();
+}
 
 int nsx_step_profile_get(int i, char* name_out, int name_capacity, float* ms, int64_t* rows, int32_t* info4) {
-    NSX_REQUIRE(i >= 0 && i < (int)g_prof.size(), "nsx_step_profile_get: record %d of %d", i, (int)g_prof.size());
     NSX_REQUIRE(name_out && name_capacity > 1 && ms && rows && info4, "nsx_step_profile_get: NULL argument");
-    const ProfRec& r = g_prof[i];
+    ProfRec r;
+    {
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        NSX_REQUIRE(i >= 0 && i < (int)g_prof.size(), "nsx_step_profile_get: record %d of %d", i, (int)g_prof.size());
+        r = g_prof[i];
+    }
     strncpy(name_out, r.name, (size_t)name_capacity - 1);
     name_out[name_capacity - 1] = 0;
     if (hipEventSynchronize(r.b) != hipSuccess || hipEventElapsedTime(ms, r.a, r.b) != hipSuccess)
@@ -428,6 +451,7 @@ int nsx_step_profile_get(int i, char* name_out, int name_capacity, float* ms, in
 }
 
 int nsx_step_profile_reset(void) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
     for (const ProfRec& r : g_prof) {
         g_prof_pool.push_back(r.a);
         g_prof_pool.push_back(r.b);
@@ -457,11 +481,12 @@ int nsx_step_echo(int kind, const void* s, double* out, int capacity) {
     if (kind == 0) {
         const nsx_step_sample* a = static_cast<const nsx_step_sample*>(s);
         PUTP(a->origins); PUTP(a->directions); PUTP(a->near_planes); PUTP(a->packed_march); PUTP(a->binaries);
-        PUTP(a->ray_timesteps); PUTP(a->ray_slots); PUTP(a->deform_packed); PUTP(a->deform_codes); PUTP(a->tables);
+        PUTP(a->ray_slots); PUTP(a->ray_times); PUTP(a->row_timesteps); PUTP(a->rows_flag); PUTP(a->deform_packed); PUTP(a->deform_codes); PUTP(a->tables);
         PUTP(a->geom); PUTP(a->hash_codes); PUTP(a->hash_window); PUTP(a->base_w16); PUTP(a->alpha_thre_dev);
         PUTP(a->window7_host); PUTP(a->ws); PUTP(a->plan); PUTP(a->tables_ready_event);
         PUT(a->R); PUT(a->S); PUT(a->deform_code_stride); PUT(a->hash_code_stride);
-        PUT(a->grid_res); PUT(a->H); PUT(a->base_hidden); PUT(a->base_out_dim); PUT(a->base_act); PUT(a->reserved);
+        PUT(a->grid_res); PUT(a->H); PUT(a->base_hidden); PUT(a->base_out_dim); PUT(a->base_act); PUT(a->n_code_rows);
+        PUT(a->n_timesteps); PUT(a->reserved);
         PUT(a->far_plane); PUT(a->step); PUT(a->early_stop_eps); PUT(a->reserved_f);
         for (int i = 0; i < 6; ++i) PUT(a->occ_aabb[i]);
         for (int i = 0; i < 6; ++i) PUT(a->deform_aabb[i]);

@@ -80,9 +80,7 @@ class _MainPass(torch.autograd.Function):
         else:
             check(L.nsx_sample_positions(ptr(inp.origins), ptr(inp.directions), None, ptr(inp.t0), ptr(inp.t1), None, S, None,
                                          ptr(pos), None, None, ndev(S), st), "nsx_sample_positions")
-            offsets = torch.empty((S, 3), dtype=f32, device=dev)
-            check(L.nsx_deform_fwd(ptr(inp.deform_packed), ptr(pos), S, inp.deform_aabb6, ptr(code_d), code_d.stride(0),
-                                   ptr(inp.slot), inp.deform_window7, ptr(offsets), ndev(S), st), "nsx_deform_fwd")
+            offsets = F.deform_fwd_rows(inp.deform_packed, pos, inp.deform_aabb6, code_d, inp.slot, inp.deform_window7)
             # -- scene-box normalisation of (position + offset), in-box selector
             check(L.nsx_sample_positions(ptr(pos), None, None, None, None, ptr(offsets), S, inp.field_aabb6, None, ptr(pn),
                                          ptr(sel), ndev(S), st), "nsx_sample_positions")

@@ -277,23 +277,12 @@ class NativeStep:
         self._prof_state = (0, -1)
         self._grad_buffers = {}
 
-    def _ray_timesteps(self, ray_bundle, R: int) -> torch.Tensor:
-        """int32 [R]: the reference rounds the rays' ``times`` (nersemble_instant_ngp.py:249); metadata timesteps are
-        used once the sampler has seen them agree (NeRSembleVolumetricSampler.get_sigma_fn)."""
-        model, sampler = self.model, self.model.sampler
-        md_ts = (ray_bundle.metadata or {}).get("timesteps")
-        have_md = md_ts is not None and md_ts.numel() == R
-        n = sampler._md_timestep_checks = getattr(sampler, "_md_timestep_checks", -1) + 1
-        if have_md and ray_bundle.times is not None and n % 256 == 0:
-            rounded = model._timesteps(ray_bundle.times).to(torch.int32)
-            sampler._md_timesteps_agree = bool(torch.equal(rounded, md_ts.reshape(-1).to(torch.int32)))
-        if have_md and (ray_bundle.times is None or getattr(sampler, "_md_timesteps_agree", False)):
-            return md_ts.reshape(-1).to(torch.int32).contiguous()
-        return model._timesteps(ray_bundle.times).to(torch.int32).contiguous()
-
     def forward(self, ray_bundle, batch: Dict[str, torch.Tensor]):
         """(loss_dict, metrics_dict, outputs) of ``fused_train_forward`` -- or None when this step is outside what the
-        drivers cover (the caller then takes the per-kernel path)."""
+        drivers cover (the caller then takes the per-kernel path).  The caller has established that the bundle's metadata
+        code rows stand for its times (``NeRSembleNGPModel._metadata_rows_trusted``): the sigma_fn pass and the main pass
+        both index the batch's compacted code tables with the per-ray slot, and the sampler driver re-checks every ray
+        against ``times`` on the device (``nsx_check_code_rows``, a sticky flag read at the model's periodic check)."""
         model = self.model
         cfg = model.config
         md = ray_bundle.metadata or {}
@@ -341,20 +330,21 @@ class NativeStep:
         if S <= 0:
             return None                     # (nothing marched: the per-kernel path owns the one-fake-sample fallback)
         grid.last_keep_index, grid.last_n_marched, grid.last_n_kept = None, S, None
-        ray_ts = self._ray_timesteps(ray_bundle, R)
         ray_slots = md["image_index"].reshape(-1).to(torch.int32).contiguous()
+        ray_times = None
+        if ray_bundle.times is not None and ray_bundle.times.numel() == R:
+            ray_times = ray_bundle.times.reshape(-1).to(torch.float32).contiguous()
+        rows_flag = model._rows_flag_tensor(dev)
         alpha_thre_dev = grid._alpha_threshold(float(cfg.alpha_thre))
         # -- what the HashEnsemble kernels see: the H grids with conditioned codes and the window -- or, in the compact
         # first-grid phase (HashEnsemble.first_grid_phase), the contiguous copy of grid 0 with a constant code of one
         width = he.compact_width(window_hash)
         first = width == 1
-        T = model.time_embedding.weight.shape[0]
         # (the previous step's table optimizer may still be running on its stream: only the HashEnsemble kernel waits for it --
         # the traversal and the deformation field of this step run beside it, as on the per-kernel path)
         if first:
             comp = he.enter_first_grid_phase()
             tables, Hk = comp["f16"], 1
-            sig_codes, sig_window = he.first_grid_code(T), None
             main_code, main_window = he.first_grid_code(n_rows), None
         else:
             if width >= 2:
@@ -363,18 +353,10 @@ class NativeStep:
             else:
                 he.leave_first_grid_phase()
                 tables, Hk = he.half_tables(wait=False), he.n_hash_encodings
-            with torch.no_grad():
-                if window_hash is not None and window_hash == 1 and he.disable_initial_hash_ensemble:
-                    key = (T, he.n_hash_encodings, str(dev))
-                    sig_codes = self._ones_codes.get(key)
-                    if sig_codes is None:
-                        sig_codes = self._ones_codes[key] = torch.ones((T, he.n_hash_encodings), dtype=torch.float32,
-                                                                       device=dev)
-                    sig_window = window
-                else:
-                    sig_codes, sig_window = he._conditioned(model.time_embedding.weight.detach(), window_hash, dev)
-                    sig_codes = sig_codes.contiguous()
             main_code, main_window = code_hash.detach().contiguous(), window
+        # (the sigma_fn pass reads the SAME rows as the main pass: the batch's conditioned code rows through the per-ray slot;
+        # rounds 3-4 conditioned the dataset's whole [T, H] table for it every step)
+        code_d = code_deform.detach().contiguous()
         mb, mh = model.field.mlp_base, model.field.mlp_head
         packed_w = df.packed_params()
         w7 = F.deform_window7(window_deform)
@@ -393,19 +375,22 @@ class NativeStep:
         a = self._sample_cls()
         a.origins, a.directions, a.near_planes = o.data_ptr(), d.data_ptr(), near_planes.data_ptr()
         a.packed_march, a.binaries = packed_march.data_ptr(), binary.data_ptr()
-        a.ray_timesteps, a.ray_slots = ray_ts.data_ptr(), ray_slots.data_ptr()
-        a.deform_packed, a.deform_codes = packed_w.data_ptr(), emb_d.weight.data_ptr()
+        a.ray_slots = ray_slots.data_ptr()
+        if ray_times is not None:
+            a.ray_times, a.row_timesteps, a.rows_flag = ray_times.data_ptr(), uniq.data_ptr(), rows_flag.data_ptr()
+        a.deform_packed, a.deform_codes = packed_w.data_ptr(), code_d.data_ptr()
         a.tables, a.geom = tables.data_ptr(), C.addressof(he.geom)
-        a.hash_codes = sig_codes.data_ptr()
-        a.hash_window = sig_window.data_ptr() if sig_window is not None else None
+        a.hash_codes = main_code.data_ptr()
+        a.hash_window = main_window.data_ptr() if main_window is not None else None
         a.base_w16, a.alpha_thre_dev = base_w16.data_ptr(), alpha_thre_dev.data_ptr()
         a.window7_host = C.addressof(w7) if w7 is not None else None
         a.ws, a.plan = ws_sample.data_ptr(), C.addressof(plan)
         tables_event = he.take_tables_event()
         a.tables_ready_event = tables_event.cuda_event if tables_event is not None else None
         a.R, a.S = R, S
-        a.deform_code_stride, a.hash_code_stride = emb_d.weight.stride(0), sig_codes.stride(0)
+        a.deform_code_stride, a.hash_code_stride = code_d.stride(0), main_code.stride(0)
         a.grid_res, a.H = grid._res, Hk
+        a.n_code_rows, a.n_timesteps = n_rows, int(cfg.n_timesteps)
         a.base_hidden, a.base_out_dim, a.base_act = mb.n_hidden_mats, mb.n_output_dims, mb.out_act
         a.far_plane, a.step, a.early_stop_eps = far, float(cfg.render_step_size), float(cfg.early_stop_eps)
         for i in range(6):
@@ -426,7 +411,6 @@ class NativeStep:
         m.tables, m.geom = tables.data_ptr(), C.addressof(he.geom)
         m.code_hash = main_code.data_ptr()
         m.hash_window = main_window.data_ptr() if main_window is not None else None
-        code_d = code_deform.detach().contiguous()
         m.deform_packed, m.code_deform = packed_w.data_ptr(), code_d.data_ptr()
         m.base_w16, m.head_w16 = base_w16.data_ptr(), head_w16.data_ptr()
         m.window7_host = C.addressof(w7) if w7 is not None else None
@@ -459,8 +443,9 @@ class NativeStep:
                                                      mb.n_hidden_mats, dev)}
             st.grads = self._grad_buffers[gkey]
         # every tensor a raw pointer above borrows lives at least as long as the step's state
-        st.keep = (o, d, near_planes, packed_march, binary, ray_ts, ray_slots, packed_w, tables, sig_codes, sig_window,
-                   base_w16, head_w16, alpha_thre_dev, w7, image_t, amap, depth_t, code_d, he.geom, tables_event)
+        st.keep = (o, d, near_planes, packed_march, binary, ray_slots, ray_times, uniq, rows_flag, packed_w, tables,
+                   main_code, main_window, base_w16, head_w16, alpha_thre_dev, w7, image_t, amap, depth_t, code_d, he.geom,
+                   tables_event)
         fused = _NativeMain.apply(st, he.tables, mb.params, mh.params, code_hash, code_deform, *deform_params)
         grid.last_n_kept = _LazyView(ws_sample, plan.n_kept, (1,), torch.int64)
         terms = [("rgb_loss", dl.LOSS_RGB)]

@@ -5,7 +5,7 @@ independent until the loss mean, so each rank draws its own rays and holds a ful
 the sum of gradients.  Large buffers (the 1.6 GB hash-table gradient) go out as their own
 collective; small tensors are flattened into one bucket so a step issues O(1) collectives.
 """
-from typing import Iterable
+from typing import Iterable, Optional, Sequence
 
 import torch
 import torch.distributed as dist
@@ -13,22 +13,37 @@ import torch.distributed as dist
 SMALL_BUCKET_ELEMS = 1 << 22
 
 
-def all_reduce_gradients(params: Iterable[torch.nn.Parameter], world_size: int, group=None):
+def all_reduce_gradients(params: Iterable[torch.nn.Parameter], world_size: int, group=None,
+                         takes_part: Optional[Sequence[bool]] = None):
     """In-place average of ``p.grad`` over all ranks.  A parameter without a gradient on this rank contributes zeros
-    (every rank must join every collective) and is left WITHOUT a gradient afterwards: an optimizer must not count a step
-    for it -- ``torch.optim.Adam`` keeps ``step`` per parameter and creates it with the first real gradient
-    (``time_embedding.weight`` starts when the coarse-to-fine window opens, train_nersemble.py:77-78: its first update
-    then takes the bias corrections of step 1 on one GPU and must do so on eight).  Which parameters take part in a step
-    follows from the configuration and the schedule, the same on every rank; that this holds is CHECKED: the number of
-    ranks that held a gradient travels in the same bucket, and the returned tensor (``[len(params)]``, device) must read 0
-    or ``world_size`` everywhere -- the trainer looks at it one step late, off the critical path
-    (``NeRSembleTrainer.flush_scheduler_step``).  Returns None for a single process."""
+    (every rank must join every collective).  What it is left with afterwards follows from whether the parameter took
+    part in the step on ANY rank:
+
+    * no rank had a gradient: it stays WITHOUT one -- an optimizer must not count a step for it (``torch.optim.Adam`` keeps
+      ``step`` per parameter and creates it with the first real gradient: ``time_embedding.weight`` starts when the
+      coarse-to-fine window opens, train_nersemble.py:77-78; its first update then takes the bias corrections of step 1 on
+      one GPU and must do so on eight);
+    * some rank had one (this rank's rays produced no samples, say): it keeps the AVERAGED gradient and every rank steps
+      identically.  (Round 4 dropped the gradient here: the rank skipped an update the others applied -- the replicas
+      diverged and the step after raised.)
+
+    The global count is on the device when the decision is made.  ``takes_part`` -- the previous step's global counts > 0, per
+    parameter, identical on every rank (the trainer reads the counts one step late, off the critical path) -- stands in for
+    it: membership changes only where the schedule says so, on all ranks at once.  ``None`` (the first step; callers without
+    a history) reads this step's counts on the host -- one blocking read.  The remaining hole -- a parameter that starts to
+    take part in exactly the step in which this rank has no gradient at all -- is DETECTED: the number of ranks that dropped a
+    gradient travels in the same bucket, and ``check_gradient_presence`` raises on every rank when a parameter was stepped
+    by some ranks and dropped by others.
+
+    Returns ``[2, len(params)]`` (device): ranks that held a gradient, ranks that dropped theirs.  None for one process."""
     if world_size <= 1:
         return None
     params = [p for p in params if p.requires_grad]
     if not params:
         return None
     absent = [p.grad is None for p in params]
+    if takes_part is not None and len(takes_part) != len(params):
+        takes_part = None
     for p, a in zip(params, absent):
         if a:
             p.grad = torch.zeros_like(p)
@@ -36,35 +51,43 @@ def all_reduce_gradients(params: Iterable[torch.nn.Parameter], world_size: int, 
     small = [p for p in params if p.grad.numel() < SMALL_BUCKET_ELEMS]
     handles = [dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, group=group, async_op=True) for p in big]
     dev = params[0].grad.device
-    presence = torch.tensor([0.0 if a else 1.0 for a in absent], dtype=torch.float32).to(dev, non_blocking=True)
-    flat = torch.cat([p.grad.reshape(-1).float() for p in small] + [presence])
+    n = len(params)
+    # what this rank will do with an absent gradient, decided BEFORE the exchange when a history exists
+    drops = [a and takes_part is not None and not takes_part[i] for i, a in enumerate(absent)]
+    tail = torch.tensor([0.0 if a else 1.0 for a in absent] + [1.0 if d else 0.0 for d in drops], dtype=torch.float32)
+    flat = torch.cat([p.grad.reshape(-1).float() for p in small] + [tail.to(dev, non_blocking=True)])
     handles.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=True))
     for h in handles:
         h.wait()
     inv = 1.0 / world_size
     for p in big:
         p.grad.mul_(inv)
-    counts = flat[flat.numel() - len(params):].clone()
+    counts = flat[flat.numel() - 2 * n:].clone().view(2, n)
     flat.mul_(inv)
     off = 0
     for p in small:
-        n = p.grad.numel()
-        p.grad.copy_(flat[off:off + n].view_as(p.grad))
-        off += n
-    for p, a in zip(params, absent):
-        if a:
-            p.grad = None                   # (zeros went into the sum; the parameter itself did not take part in the step)
+        k = p.grad.numel()
+        p.grad.copy_(flat[off:off + k].view_as(p.grad))
+        off += k
+    if takes_part is None and any(absent):
+        present_any = (counts[0] > 0).tolist()               # one blocking read (first step / no history)
+        drops = [a and not present_any[i] for i, a in enumerate(absent)]
+    for p, d in zip(params, drops):
+        if d:
+            p.grad = None                   # (zeros went into the sum; no rank stepped the parameter)
     return counts
 
 
 def check_gradient_presence(counts, world_size: int) -> None:
-    """``counts``: what ``all_reduce_gradients`` returned, on the host.  Every parameter must have had a gradient on all
-    ranks or on none."""
-    bad = [i for i, c in enumerate(counts) if c not in (0.0, float(world_size))]
+    """``counts``: what ``all_reduce_gradients`` returned, on the host (``[2][n]``: ranks with a gradient, ranks that
+    dropped theirs).  A parameter some rank had a gradient for must not have been dropped by another: the first would have
+    stepped it, the second not."""
+    held, dropped = counts[0], counts[1]
+    bad = [i for i, (h, d) in enumerate(zip(held, dropped)) if h > 0 and d > 0]
     if bad:
         raise RuntimeError(f"data-parallel step: parameters {bad} (positions in the all-reduced list) received a gradient on "
-                           f"{[counts[i] for i in bad]} of {world_size} ranks -- the ranks ran different graphs; per-parameter "
-                           f"Adam step counts would diverge")
+                           f"{[held[i] for i in bad]} of {world_size} ranks while {[dropped[i] for i in bad]} ranks left them "
+                           f"without one -- the replicas have diverged (per-parameter Adam step counts differ)")
 
 
 def global_normaliser_scales(local_counts: torch.Tensor, n_eff_local: torch.Tensor, n_rays_local: int,

@@ -150,6 +150,7 @@ class NeRSembleTrainer:
         self._pending, self._found_host, self._found_event = None, None, None
         self._flag_state = None       # persistent found_inf flags of the native scale update
         self._presence, self._presence_host = None, None      # data-parallel: ranks per parameter that held a gradient
+        self._took_part = None                                # ... > 0 in the previous step (engine/parallel.py)
         # the table optimizer's 12 GB pass runs beside the rest of the step's tail and the next step's ray marching
         self._opt_stream = torch.cuda.Stream(device) if (overlap_table_adam and device.type == "cuda") else None
         self._found_groups = []
@@ -177,7 +178,9 @@ class NeRSembleTrainer:
                 opt.ensure_reduce_started()
         params = [p for opt in self.optimizers.values() if not isinstance(opt, ShardedTableAdam)
                   for pg in opt.param_groups for p in pg["params"]]
-        self._presence = all_reduce_gradients(params, self.world_size)
+        # which parameters took part in the PREVIOUS step (on any rank): its counts have reached the host by now
+        self.flush_scheduler_step()
+        self._presence = all_reduce_gradients(params, self.world_size, takes_part=self._took_part)
 
     def _arm_early_table_step(self):
         """Single GPU, fused main pass: let the table optimizer start from inside the backward (HashTableAdam.
@@ -348,8 +351,8 @@ class NeRSembleTrainer:
             self._found_event = torch.cuda.Event()
         self._found_host.copy_(found_all, non_blocking=True)
         if self._presence is not None:
-            if self._presence_host is None or self._presence_host.numel() != self._presence.numel():
-                self._presence_host = torch.empty((self._presence.numel(),), dtype=torch.float32).pin_memory()
+            if self._presence_host is None or self._presence_host.shape != self._presence.shape:
+                self._presence_host = torch.empty(tuple(self._presence.shape), dtype=torch.float32).pin_memory()
             self._presence_host.copy_(self._presence, non_blocking=True)
             self._presence = None
         self._found_event.record()
@@ -431,7 +434,9 @@ class NeRSembleTrainer:
         else:
             flags = val.tolist()
         if self.world_size > 1 and self._presence_host is not None:
-            check_gradient_presence(self._presence_host.tolist(), self.world_size)
+            counts = self._presence_host.tolist()
+            check_gradient_presence(counts, self.world_size)
+            self._took_part = [c > 0 for c in counts[0]]
         # the native table optimizers count their step on the host before the device decides to skip it: take the
         # count back for the groups that skipped (torch's fused Adam does the same with _foreach_sub_(steps, found_inf))
         for key, opt in self.optimizers.items():

@@ -191,7 +191,11 @@ class SE3DeformationField(nn.Module):
             max_chunk = len(positions) if self.max_n_samples_per_batch == -1 else self.max_n_samples_per_batch
             params, packed = self.ordered_params(), self.packed_params()
             outs = []
-            if code_index is None:
+            if code_index is None and warp_code.shape[0] == 1 and len(positions) != 1:
+                # ONE code for every sample (native extension: an evaluation image's timestep) -- a one-row table
+                for pos_c, pre_c in chunked(max(max_chunk, 1), positions, precomputed):
+                    outs.append(F.deform_offsets(params, packed, pos_c, warp_code, self._aabb6(), windows_param, None, pre_c))
+            elif code_index is None:
                 for pos_c, code_c, pre_c in chunked(max(max_chunk, 1), positions, warp_code, precomputed):
                     outs.append(F.deform_offsets(params, packed, pos_c, code_c, self._aabb6(), windows_param, None, pre_c))
             else:
@@ -204,6 +208,8 @@ class SE3DeformationField(nn.Module):
         # CPU tensors: plain torch restatement (used to pin the glue against the reference's goldens)
         if code_index is not None:
             warp_code = warp_code[code_index.long()]
+        elif warp_code is not None and warp_code.shape[0] == 1 and len(positions) != 1:
+            warp_code = warp_code.expand(len(positions), -1)
         max_chunk = len(positions) if self.max_n_samples_per_batch == -1 else self.max_n_samples_per_batch
         offsets = []
         for pos_c, code_c in chunked(max(max_chunk, 1), positions, warp_code):

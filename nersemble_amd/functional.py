@@ -14,9 +14,6 @@ from . import _lib
 from ._lib import GridGeom, check, lib, ndev, ptr, stream
 
 
-_DEFORM_FWD_TERMS = os.environ.get("NSX_DEFORM_FWD_TERMS", "0") == "1"
-
-
 def scatter_alone(H: int) -> bool:
     """Padded grid counts whose fused backward has ONE lane per sample (table rows of <= 16 bytes: H <= 4): its 16
     (corner, feature) gradient items per sample and level leave as 16 instructions of 64 unrelated sectors each, while
@@ -471,18 +468,17 @@ class _DeformFn(torch.autograd.Function):
         pos = positions.detach().to(torch.float32).contiguous()
         code_c = code.detach().to(torch.float32).contiguous()
         S = pos.shape[0]
+        if code_slot is None and code_c.shape[0] == 1 and S != 1 and any(ctx.needs_input_grad):
+            code_slot = torch.zeros((S,), dtype=torch.int32, device=dev)     # (the backward indexes the table per sample)
         if precomputed is not None:
             off = precomputed.detach()
         else:
             off = torch.empty((S, 3), dtype=torch.float32, device=dev)
-            if _DEFORM_FWD_TERMS and code_slot is not None and code_c.shape[0] <= 48:
-                # the code columns of the two input layers factored through the slot (nsx_deform_fwd_rows; opt-in until
-                # tests/test_deform_gpu.py has been run on it: NSX_DEFORM_FWD_TERMS=1)
-                n_rows = int(code_c.shape[0])
-                terms = torch.empty((int(lib().nsx_deform_terms_floats(n_rows)),), dtype=torch.float32, device=dev)
-                check(lib().nsx_deform_fwd_rows(ptr(packed), ptr(pos), S, aabb6, ptr(code_c), code_c.stride(0),
-                                                ptr(code_slot), n_rows, window7, ptr(off), ptr(terms), ndev(S), stream()),
-                      "nsx_deform_fwd_rows")
+            if code_slot is not None or (code_c.shape[0] == 1 and S != 1):
+                # codes are rows of a table (always, in the model): the code columns of the two input layers are factored
+                # through the row (nsx_deform_fwd_rows, the default since round 5); a one-row table without slots is ONE code
+                # for every sample (an evaluation image's timestep)
+                off = deform_fwd_rows(packed, pos, aabb6, code_c, code_slot, window7, out=off)
             else:
                 check(lib().nsx_deform_fwd(ptr(packed), ptr(pos), S, aabb6, ptr(code_c), code_c.stride(0), ptr(code_slot),
                                            window7, ptr(off), ndev(S), stream()), "nsx_deform_fwd")
@@ -528,6 +524,20 @@ class _DeformFn(torch.autograd.Function):
         # views of the flat gradient, nsx.h order (one split dispatch; biases are already 1-D)
         grads = [g if len(shp) == 1 else g.view(shp) for g, shp in zip(torch.split(gparams, sizes), ctx.param_shapes)]
         return (None, gcode, None, None, None, None, None, *grads)
+
+
+@torch.no_grad()
+def deform_fwd_rows(packed: torch.Tensor, positions: torch.Tensor, aabb6, code_table: torch.Tensor,
+                    code_slot: Optional[torch.Tensor], window7, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``nsx_deform_fwd_rows`` (values only): offsets [S,3] of ``positions`` whose warp code is row ``code_slot[s]`` of
+    ``code_table`` (``code_slot`` None: a one-row table, every sample takes it)."""
+    S, n_rows = int(positions.shape[0]), int(code_table.shape[0])
+    off = out if out is not None else torch.empty((S, 3), dtype=torch.float32, device=positions.device)
+    terms = torch.empty((int(lib().nsx_deform_terms_floats(n_rows)),), dtype=torch.float32, device=positions.device)
+    check(lib().nsx_deform_fwd_rows(ptr(packed), ptr(positions, torch.float32), S, aabb6, ptr(code_table, torch.float32),
+                                    code_table.stride(0), ptr(code_slot), n_rows, window7, ptr(off), ptr(terms), ndev(S),
+                                    stream()), "nsx_deform_fwd_rows")
+    return off
 
 
 def deform_pack(flat_params: torch.Tensor) -> torch.Tensor:

@@ -124,6 +124,7 @@ class NeRSembleNGPModel(BaseModel):
         # its own (weak scaling, single GPU)
         self.global_loss_normalisers = None
         self._eval_blend = None
+        self._eval_single_timestep = None        # set next to _eval_blend: the bundle's one timestep (host int)
         self._eval_blend_cache = (None, None)
         self.populate_modules()
         # nerfstudio ``Model.__init__`` registers this empty parameter after ``populate_modules()``; it is a key of every
@@ -237,6 +238,44 @@ class NeRSembleNGPModel(BaseModel):
     def _timesteps(self, times: Tensor) -> Tensor:
         return (times * (self.config.n_timesteps - 1)).round().int().reshape(-1)
 
+    def _rows_flag_tensor(self, device) -> Tensor:
+        """Sticky device int32 the native sampler driver raises when a ray's metadata code row disagrees with its time
+        (``nsx_check_code_rows``); read at the periodic check of ``_metadata_rows_trusted``."""
+        f = self.__dict__.get("_rows_flag")
+        if f is None or f.device != torch.device(device):
+            f = self.__dict__["_rows_flag"] = torch.zeros((1,), dtype=torch.int32, device=device)
+        return f
+
+    def _metadata_rows_trusted(self, ray_bundle: RayBundle) -> bool:
+        """May ``metadata["image_index"]`` / ``["_image_timesteps"]`` (ray -> image of the cached batch, the images' timesteps:
+        what this package's datamanager attaches) stand for the reference's per-ray ``round(times * (T - 1))``
+        (nersemble_instant_ngp.py:249, 300-318)?  They are compared with the rounded times -- and with
+        ``metadata["timesteps"]`` -- on the first call and on every 256th (one small comparison with a host read; in
+        between, the native sampler driver checks EVERY step on the device and raises a sticky flag that is read here).
+        A disagreement (a dataparser whose metadata carries original frame ids, a stale image index) makes every path
+        derive its code rows from the times (``torch.unique``) from then on."""
+        md = ray_bundle.metadata or {}
+        if "image_index" not in md or "_image_timesteps" not in md:
+            return False
+        n = self.__dict__["_md_row_checks"] = self.__dict__.get("_md_row_checks", -1) + 1
+        if n % 256 == 0 and self.__dict__.get("_md_rows_agree", True):
+            uniq = md["_image_timesteps"].reshape(-1).to(torch.int32)
+            slots = md["image_index"].reshape(-1).to(torch.int64)
+            ok = bool(((slots >= 0) & (slots < uniq.shape[0])).all()) if slots.numel() else True
+            if ok and slots.numel():
+                rows = uniq[slots]
+                if ray_bundle.times is not None:
+                    ok = bool(torch.equal(rows, self._timesteps(ray_bundle.times).to(torch.int32)))
+                if ok and "timesteps" in md and md["timesteps"].numel() == rows.numel():
+                    ok = bool(torch.equal(rows, md["timesteps"].reshape(-1).to(torch.int32)))
+            flag = self.__dict__.get("_rows_flag")
+            if flag is not None and int(flag) != 0:
+                raise RuntimeError("the batch metadata's code rows (image_index / _image_timesteps) disagreed with the rays' "
+                                   "times on an earlier step (device-side check of the native sampler driver): the sigma_fn "
+                                   "pass and the main pass would read different time codes")
+            self.__dict__["_md_rows_agree"] = ok
+        return bool(self.__dict__.get("_md_rows_agree", False))
+
     # ---- density for sigma_fn / occupancy grid (:235-266) ------------------------------------------
     def field_density_fn(self, positions: Tensor, times: Optional[Tensor], timesteps: Optional[Tensor] = None) -> Tensor:
         """``timesteps`` (native extension): the samples' integer timesteps if the caller has them already (the sampler's
@@ -260,7 +299,12 @@ class NeRSembleNGPModel(BaseModel):
             emb = self.time_embedding_deformation if self.time_embedding_deformation is not None else self.time_embedding
             # normalised-space offset added to the world-space position, exactly as the reference does (:257-259);
             # the kernel indexes the embedding table per sample instead of gathering [N,128] codes
-            offsets = self.deformation_field.compute_offsets(positions, emb.weight, window_deform, code_index=timesteps)
+            t0 = self._eval_single_timestep
+            if t0 is not None and positions.is_cuda:
+                # every ray of the bundle carries timestep t0 (evaluation image): ONE code row, its terms in LDS
+                offsets = self.deformation_field.compute_offsets(positions, emb.weight[t0:t0 + 1], window_deform)
+            else:
+                offsets = self.deformation_field.compute_offsets(positions, emb.weight, window_deform, code_index=timesteps)
         codes = {"time_codes": self.time_embedding.weight if self.time_embedding is not None else None,
                  "time_code_index": timesteps, "preblended_table": self._eval_blend}
         if positions.is_cuda:
@@ -296,6 +340,7 @@ class NeRSembleNGPModel(BaseModel):
         t0 = int(ray_timesteps[0])                              # evaluation only: a host read per bundle is fine
         if not bool((ray_timesteps == t0).all()):
             return None
+        self._eval_single_timestep = t0
         he = self.field.hash_ensemble
         window = self.sched_window_hash_encodings.value if self.sched_window_hash_encodings is not None else None
         # the native table optimizers write through raw pointers and torch's fused Adam does not bump Tensor._version:
@@ -312,6 +357,7 @@ class NeRSembleNGPModel(BaseModel):
             return self._get_outputs(ray_bundle)
         finally:
             self._eval_blend = None
+            self._eval_single_timestep = None
 
     def _get_outputs(self, ray_bundle: RayBundle):
         cfg = self.config
@@ -354,7 +400,7 @@ class NeRSembleNGPModel(BaseModel):
         if self.time_embedding is not None:
             # small code tables + per-sample slot instead of [S,H] / [S,128] gathers.  The datamanager knows the <= 24
             # images of the batch (image index per ray + per-image timestep); otherwise compact the distinct timesteps.
-            if "image_index" in ray_bundle.metadata and "_image_timesteps" in ray_bundle.metadata:
+            if self._metadata_rows_trusted(ray_bundle):
                 uniq = ray_bundle.metadata["_image_timesteps"].reshape(-1).int()
                 inv = ray_bundle.metadata["image_index"].reshape(-1)
             else:
@@ -417,7 +463,10 @@ class NeRSembleNGPModel(BaseModel):
         num_rays = len(ray_bundle)
         if alpha_map is not None and not (alpha_map.dtype == torch.uint8 and alpha_map.numel() == num_rays):
             return None
-        if self.native_step:
+        # the batch's code rows come with its metadata (ray -> image of the cached batch -> timestep) when that metadata
+        # has been seen to agree with the rays' times; otherwise they are derived from the times (torch.unique)
+        md_rows = self._metadata_rows_trusted(ray_bundle)
+        if self.native_step and md_rows:
             if self._native is None:
                 from ..engine.native_step import NativeStep
                 self._native = NativeStep(self)
@@ -434,12 +483,11 @@ class NeRSembleNGPModel(BaseModel):
         md = ray_bundle.metadata
         # the kept-sample count can stay on the device when the per-sample code slot comes with the batch (it is gathered
         # with the other per-ray fields) and the sigma_fn pass's forward values are reused
-        on_device = (self.device_sample_counts and self.reuse_sigma_pass and "image_index" in md
-                     and "_image_timesteps" in md and (cfg.alpha_thre > 0 or cfg.early_stop_eps > 0)
-                     and not cfg.disable_occupancy_grid)
+        on_device = (self.device_sample_counts and self.reuse_sigma_pass and md_rows
+                     and (cfg.alpha_thre > 0 or cfg.early_stop_eps > 0) and not cfg.disable_occupancy_grid)
         he = self.field.hash_ensemble
         early_codes = None
-        if "image_index" in md and "_image_timesteps" in md:
+        if md_rows:
             # the batch's code rows (two embedding lookups + the window conditioning: ~5 small launches) do not depend on
             # the sampler: queued BEFORE its sigma_fn pass they run beside the table optimizer instead of behind it
             uniq0 = md["_image_timesteps"].reshape(-1).int()
@@ -474,7 +522,7 @@ class NeRSembleNGPModel(BaseModel):
                                   f"free device memory ({free_bytes >> 20} MiB); using the chunked path "
                                   f"(max_n_samples_per_batch = {bound})")
                 return None
-        if "image_index" in md and "_image_timesteps" in md:
+        if md_rows:
             uniq = early_codes[0] if early_codes is not None else md["_image_timesteps"].reshape(-1).int()
             slot = (ray_samples.metadata or {}).get("image_index")
             if slot is None or slot.shape[0] != S:

@@ -29,7 +29,37 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(handle, s), f"libnsx.so does not export {s}"
     # the ctypes signature table covers exactly the header
     assert set(_lib.SIGNATURES) == declared
-    assert handle.nsx_version() >= 113
+    assert handle.nsx_version() >= 120
+
+
+def test_no_exported_path_reads_the_environment():
+    """Rounds 2-4 selected kernel variants -- some of them timing probes with wrong results on purpose -- through NSX_*
+    environment variables read inside entry points of the C ABI.  Round 5: launch shapes are explicit options
+    (nsx_set_option), the variants are gone; neither the sources nor the built library reference getenv."""
+    src_dir = os.path.join(ROOT, "nersemble_amd", "csrc")
+    for f in sorted(os.listdir(src_dir)):
+        if f.endswith((".hip", ".h", ".cpp")):
+            txt = open(os.path.join(src_dir, f)).read()
+            assert not re.search(r"\b(secure_)?getenv\b|\benviron\b", txt), f"{f} reads the environment"
+    from nersemble_amd import _lib
+    blob = open(_lib.SO_PATH, "rb").read()
+    assert b"getenv" not in blob, "libnsx.so imports getenv"
+    for name in (b"NSX_DEFORM_FWD", b"NSX_HASHGRID_FWD", b"NSX_ADAM_BLOCKS_PER_CU", b"NSX_MLP_BWD"):
+        assert name not in blob
+
+
+def test_launch_shape_options_are_explicit_and_checked():
+    from nersemble_amd import _lib
+    L = _lib.lib()
+    defaults = {_lib.NSX_OPT_ADAM_BLOCKS_PER_CU: 5, _lib.NSX_OPT_MLP_BWD_HALF_BLOCKS_PER_CU: 2,
+                _lib.NSX_OPT_MLP_BWD0_HALF_BLOCKS_PER_CU: 2}
+    for opt, dflt in defaults.items():
+        assert L.nsx_get_option(opt) == dflt
+        assert L.nsx_set_option(opt, 4) == 0 and L.nsx_get_option(opt) == 4
+        assert L.nsx_set_option(opt, 0) != 0 and b"takes" in L.nsx_last_error()       # out of range: refused, value kept
+        assert L.nsx_set_option(opt, 9) != 0 and L.nsx_get_option(opt) == 4
+        assert L.nsx_set_option(opt, dflt) == 0
+    assert L.nsx_set_option(99, 1) != 0 and L.nsx_get_option(99) < 0
 
 
 def test_error_reporting_across_abi():

@@ -54,20 +54,19 @@ def test_deform_forward_code_table_equals_gather(cuda):
     with torch.no_grad():
         a = df.compute_offsets(pos, table, 3.5, code_index=slot)
         b = df.compute_offsets(pos, table[slot], 3.5)
-    from nersemble_amd import functional as F
-    if F._DEFORM_FWD_TERMS:
-        # (opt-in: the table route sums the code columns per slot first -- same products, another order)
-        assert (a - b).abs().max().item() <= 3e-3 * b.abs().max().item() + 2e-5
-    else:
-        assert torch.equal(a, b)
+    # (round 5: the table route sums the code columns per row first -- nsx_deform_fwd_rows, same products in another fp32
+    # order; the per-sample-code operator keeps the general kernel)
+    assert (a - b).abs().max().item() <= 3e-3 * b.abs().max().item() + 2e-5
 
 
-@pytest.mark.parametrize("S,T", [(1, 1), (33, 1), (2049, 24), (5000, 48), (700, 49)])
+@pytest.mark.parametrize("S,T", [(1, 1), (33, 1), (2049, 24), (5000, 48), (700, 64), (700, 65), (3000, 475)])
 @pytest.mark.parametrize("window", [None, 2.75])
 def test_deform_forward_through_the_slot_terms(S, T, window, cuda):
     """nsx_deform_fwd_rows (the code columns k >= 48 of the two input layers summed per code row first, 3 of 11 K-steps left
     in the input GEMMs) against nsx_deform_fwd on the same table: the same products in another fp32 order -- equal up to
-    the fp16 rounding of a hidden unit; more than 48 rows forward to the general kernel (bit-equal)."""
+    the fp16 rounding of a hidden unit.  Tables of <= 64 rows keep the terms in LDS, larger ones (the occupancy update draws
+    from every timestep of the dataset) read them from global memory: the same numbers in the same order, so a sample's
+    offsets depend on its row's VALUES only -- checked by running the same samples against a compacted table."""
     import ctypes as C
     from nersemble_amd import functional as F
     from nersemble_amd._lib import check, lib, ptr, stream
@@ -85,15 +84,49 @@ def test_deform_forward_through_the_slot_terms(S, T, window, cuda):
     assert terms.numel() == T * 256
     check(lib().nsx_deform_fwd_rows(ptr(packed), ptr(pos), S, aabb6, ptr(table), table.stride(0), ptr(slot), T, w7, ptr(got),
                                     ptr(terms), None, stream()), "nsx_deform_fwd_rows")
-    if T > 48:
-        assert torch.equal(got, want)
-    else:
-        tol = 3e-3 * want.abs().max().item() + 2e-5
-        assert (got - want).abs().max().item() <= tol, ((got - want).abs().max().item(), tol)
-        # and against the oracle, as the general kernel is held
-        ref = od.compute_offsets(pos.cpu(), table.cpu()[slot.cpu().long()], df.flat_params().detach().cpu(), AABB, window,
-                                 half=True).float()
-        assert (got.cpu() - ref).abs().max().item() <= 3e-3 * ref.abs().max().item() + 2e-5
+    tol = 3e-3 * want.abs().max().item() + 2e-5
+    assert (got - want).abs().max().item() <= tol, ((got - want).abs().max().item(), tol)
+    # and against the oracle, as the general kernel is held
+    ref = od.compute_offsets(pos.cpu(), table.cpu()[slot.cpu().long()], df.flat_params().detach().cpu(), AABB, window,
+                             half=True).float()
+    assert (got.cpu() - ref).abs().max().item() <= 3e-3 * ref.abs().max().item() + 2e-5
+    # the same samples against the table compacted to the rows they use (<= 24 of them -> terms in LDS): bit for bit
+    few = min(T, 24)
+    slot_few = (slot % few).contiguous()
+    sub = torch.randperm(T, generator=g)[:few].to(cuda)             # where the `few` rows sit in the big table
+    got_big = torch.empty((S, 3), device=cuda)
+    check(lib().nsx_deform_fwd_rows(ptr(packed), ptr(pos), S, aabb6, ptr(table), table.stride(0),
+                                    ptr(sub[slot_few.long()].to(torch.int32).contiguous()), T, w7, ptr(got_big), ptr(terms),
+                                    None, stream()), "nsx_deform_fwd_rows")
+    small = table[sub].contiguous()
+    terms_small = torch.empty((int(lib().nsx_deform_terms_floats(few)),), device=cuda)
+    got_small = torch.empty((S, 3), device=cuda)
+    check(lib().nsx_deform_fwd_rows(ptr(packed), ptr(pos), S, aabb6, ptr(small), small.stride(0), ptr(slot_few), few, w7,
+                                    ptr(got_small), ptr(terms_small), None, stream()), "nsx_deform_fwd_rows")
+    assert torch.equal(got_big, got_small)
+    if T == 1:
+        # a one-row table without slots: every sample takes row 0
+        got_one = torch.empty((S, 3), device=cuda)
+        check(lib().nsx_deform_fwd_rows(ptr(packed), ptr(pos), S, aabb6, ptr(table), table.stride(0), None, 1, w7,
+                                        ptr(got_one), ptr(terms), None, stream()), "nsx_deform_fwd_rows")
+        assert torch.equal(got_one, got)
+        with torch.no_grad():
+            assert torch.equal(df.compute_offsets(pos, table, window), got)
+
+
+def test_deform_rows_entry_rejects_a_missing_slot_array(cuda):
+    from nersemble_amd import functional as F
+    from nersemble_amd._lib import lib, ptr, stream
+    df = _field(2).to(cuda)
+    pos = torch.rand(8, 3, device=cuda)
+    table = torch.zeros(3, 128, device=cuda)
+    out, terms = torch.empty(8, 3, device=cuda), torch.empty(3 * 256, device=cuda)
+    rc = lib().nsx_deform_fwd_rows(ptr(df.packed_params()), ptr(pos), 8, df._aabb6(), ptr(table), 128, None, 3, None,
+                                   ptr(out), ptr(terms), None, stream())
+    assert rc != 0 and b"code_slot" in lib().nsx_last_error()
+    rc = lib().nsx_deform_fwd_rows(ptr(df.packed_params()), ptr(pos), 8, df._aabb6(), ptr(table), 128, None, 1, None,
+                                   ptr(out), None, None, stream())
+    assert rc != 0                                                   # (the terms scratch is required)
 
 
 def test_deform_nan_fallback_and_identity_init(cuda):

@@ -31,21 +31,44 @@ def _worker(rank, world, port, out_dir):
     never = torch.nn.Parameter(torch.zeros(3))              # no gradient on ANY rank (a tensor that has not started yet)
     if rank == 0:
         nograd.grad = torch.ones(4) * 8
-    counts = all_reduce_gradients([big] + small + [nograd, never], world)
+    plist = [big] + small + [nograd, never]
+    counts = all_reduce_gradients(plist, world)               # no history: this step's counts decide (one host read)
     ok = torch.allclose(big.grad, torch.full_like(big, 1.5))
     ok &= torch.allclose(small[0].grad, torch.arange(21.).reshape(7, 3) * 1.5)
     ok &= torch.allclose(small[1].grad, torch.ones(11) * 5)
-    # the rank that had the gradient keeps the average; the other one contributed zeros and is left without a gradient
-    # (its optimizer must not count a step) -- and the disagreement is reported: 1 of 2 ranks
-    ok &= torch.allclose(nograd.grad, torch.ones(4) * 4) if rank == 0 else nograd.grad is None
-    ok &= never.grad is None and counts.tolist() == [2.0, 2.0, 2.0, 1.0, 0.0]
+    # a parameter SOME rank had a gradient for keeps the averaged gradient on EVERY rank (round 4 dropped it on the rank
+    # that had none: that rank skipped an update the other one applied); one that no rank had a gradient for stays
+    # without one (its optimizer must not count a step)
+    ok &= torch.allclose(nograd.grad, torch.ones(4) * 4)
+    ok &= never.grad is None and counts.tolist() == [[2.0, 2.0, 2.0, 1.0, 0.0], [0.0] * 5]
     from nersemble_amd.engine.parallel import check_gradient_presence
-    check_gradient_presence([2.0, 2.0, 0.0], world)
+    check_gradient_presence(counts.tolist(), world)           # nobody dropped what somebody stepped: fine
+    # with a history (the previous step's global counts): the same decisions without a host read
+    for p in plist:
+        p.grad = None
+    big.grad = torch.full_like(big, float(rank + 1))
+    small[0].grad, small[1].grad = torch.ones(7, 3), torch.ones(11)
+    if rank == 1:
+        nograd.grad = torch.ones(4) * 6
+    counts2 = all_reduce_gradients(plist, world, takes_part=[c > 0 for c in counts[0].tolist()])
+    ok &= torch.allclose(nograd.grad, torch.ones(4) * 3) and never.grad is None
+    ok &= counts2.tolist() == [[2.0, 2.0, 2.0, 1.0, 0.0], [0.0, 0.0, 0.0, 0.0, 2.0]]
+    check_gradient_presence(counts2.tolist(), world)
+    # the hole that is only DETECTED: `never` starts on rank 0 in a step in which rank 1 has no gradient for it and the
+    # history says it does not take part -> rank 1 drops, rank 0 steps: reported on both ranks
+    for p in plist:
+        p.grad = None
+    big.grad, small[0].grad, small[1].grad, nograd.grad = (torch.ones_like(big), torch.ones(7, 3), torch.ones(11),
+                                                           torch.ones(4))
+    if rank == 0:
+        never.grad = torch.ones(3)
+    counts3 = all_reduce_gradients(plist, world, takes_part=[True, True, True, True, False])
+    ok &= (never.grad is not None) == (rank == 0) and counts3[:, 4].tolist() == [1.0, 1.0]
     try:
-        check_gradient_presence(counts.tolist(), world)
+        check_gradient_presence(counts3.tolist(), world)
         ok = False
     except RuntimeError as e:
-        ok &= "parameters [3]" in str(e)
+        ok &= "parameters [4]" in str(e)
     # ray sharding: different rays per rank, same rig
     box = torch.tensor([[-2.5, -1.8, -2.5], [2.2, 1.8, 2.0]])
     data = SyntheticNeRSembleData(box, n_timesteps=10, n_rays=64, device="cpu", rank=rank)

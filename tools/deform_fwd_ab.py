@@ -1,25 +1,47 @@
-"""Development aid: the variants of nsx_deform_fwd (NSX_DEFORM_FWD, read once per process) against each other -- each in its
-own process on the same inputs: outputs must be bit-identical to variant 1, the kernel is timed alone at S samples.
+"""Development aid: the two forwards of the deformation field against each other on the same inputs -- nsx_deform_fwd (general:
+per-sample code rows, 11 K-steps in the input GEMMs) and nsx_deform_fwd_rows (codes are rows of a table: the code columns
+summed per row first; terms in LDS for <= 64 rows, in L2 otherwise) -- each timed alone at S samples, outputs compared.
 
-    python tools/deform_fwd_ab.py [--variants 1,4,5] [--S 1048576] [--iters 20]          (driver)
-    NSX_DEFORM_FWD=4 python tools/deform_fwd_ab.py --worker out.pt                          (one variant)
+    python tools/deform_fwd_ab.py [--S 1048576] [--iters 20] [--rows 24,1,100,475]
+
+(Rounds 3-4 A/B-ed kernel VARIANTS of nsx_deform_fwd through an environment variable read inside the entry point -- two-block,
+pinned LDS reads, anti-phase waves, timing probes with wrong results on purpose.  All measured equal or slower, DESIGN.md 7b;
+their source is in the history at commit 010eae6 and no longer in libnsx.so.)
 """
 import argparse
 import json
 import os
-import subprocess
 import sys
-import tempfile
 
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-FLOP_PER_SAMPLE = 253_952
+FLOP_PER_SAMPLE = 253_952          # the general kernel's (what the reference's eight Linear layers spend)
 PEAK_TFLOPS = 2500.0
 
 
-def worker(path, S, iters):
+def timeit(fn, iters):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--S", type=int, default=1 << 20)
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--rows", default="24,1,64,100,475")
+    a = ap.parse_args()
+    from nersemble_amd import functional as F
+    from nersemble_amd._lib import check, lib, ptr, stream
     from nersemble_amd.field_components.deformation_field import SE3DeformationField, SE3DeformationFieldConfig
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
@@ -29,65 +51,32 @@ def worker(path, S, iters):
         for p in df.parameters():
             if p.requires_grad and p.dim() == 2:
                 p.mul_(3.0)                               # (non-trivial offsets)
-    res = {}
-    for n in (100_003, 257, S):                           # ragged tails, fewer tiles than waves, the timed size
-        g = torch.Generator().manual_seed(n)
-        pos = (torch.rand(n, 3, generator=g) * (aabb[1] - aabb[0]) + aabb[0]).to(dev)
-        table = (torch.randn(24, 128, generator=g) * 0.3).to(dev)
-        slot = torch.randint(0, 24, (n,), generator=g, dtype=torch.int32).to(dev)
-        with torch.no_grad():
-            res[n] = df.compute_offsets(pos, table, 3.5, code_index=slot).cpu()
-    with torch.no_grad():
-        for _ in range(3):
-            df.compute_offsets(pos, table, 3.5, code_index=slot)
-        torch.cuda.synchronize()
-        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        s.record()
-        for _ in range(iters):
-            df.compute_offsets(pos, table, 3.5, code_index=slot)
-        e.record()
-        torch.cuda.synchronize()
-    torch.save({"out": res, "ms": s.elapsed_time(e) / iters}, path)
-
-
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--variants", default="1,4,5")
-    ap.add_argument("--S", type=int, default=1 << 20)
-    ap.add_argument("--iters", type=int, default=20)
-    ap.add_argument("--worker", default="")
-    a = ap.parse_args()
-    if a.worker:
-        worker(a.worker, a.S, a.iters)
-        return
-    tmp = tempfile.mkdtemp()
-    got = {}
-    for v in a.variants.split(","):
-        path = os.path.join(tmp, f"v{v}.pt")
-        env = dict(os.environ, NSX_DEFORM_FWD="1", NSX_DEFORM_FWD_TERMS="1") if v == "T" else dict(os.environ, NSX_DEFORM_FWD=v)
-        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--worker", path, "--S", str(a.S), "--iters",
-                            str(a.iters)], env=env, capture_output=True, text=True, timeout=600)
-        if r.returncode != 0 or not os.path.exists(path):
-            got[v] = {"error": r.stderr[-1500:]}
-            continue
-        got[v] = torch.load(path)
-    ref = got.get("1")
+    packed, aabb6, w7 = df.packed_params(), df._aabb6(), F.deform_window7(3.5)
+    S = a.S
+    g = torch.Generator().manual_seed(S)
+    pos = (torch.rand(S, 3, generator=g) * (aabb[1] - aabb[0]) + aabb[0]).to(dev)
     line = {}
-    for v, d in got.items():
-        if "error" in d:
-            line[v] = d
-            continue
-        same = None
-        if ref is not None and "out" in ref:
-            same = all(torch.equal(d["out"][n], ref["out"][n]) for n in ref["out"])
-        finite = all(bool(torch.isfinite(t).all()) for t in d["out"].values())
-        dmax = None
-        if ref is not None and "out" in ref:
-            dmax = float(max((d["out"][n] - ref["out"][n]).abs().max() for n in ref["out"]))
-        line[v] = {"ms": round(d["ms"], 4), "frac_of_mfma_peak": round(a.S * FLOP_PER_SAMPLE / (d["ms"] * 1e-3) / 1e12
-                                                                      / PEAK_TFLOPS, 4),
-                   "bit_identical_to_variant_1": same, "max_abs_diff_to_variant_1": dmax, "finite": finite,
-                   "abs_max": float(max(t.abs().max() for t in d["out"].values()))}
+    for T in [int(t) for t in a.rows.split(",")]:
+        table = (torch.randn(T, 128, generator=g) * 0.3).to(dev)
+        slot = torch.randint(0, T, (S,), generator=g, dtype=torch.int32).to(dev)
+        want, got = torch.empty((S, 3), device=dev), torch.empty((S, 3), device=dev)
+        terms = torch.empty((int(lib().nsx_deform_terms_floats(T)),), device=dev)
+
+        def general():
+            check(lib().nsx_deform_fwd(ptr(packed), ptr(pos), S, aabb6, ptr(table), table.stride(0), ptr(slot), w7, ptr(want),
+                                       None, stream()), "nsx_deform_fwd")
+
+        def rows():
+            check(lib().nsx_deform_fwd_rows(ptr(packed), ptr(pos), S, aabb6, ptr(table), table.stride(0), ptr(slot), T, w7,
+                                            ptr(got), ptr(terms), None, stream()), "nsx_deform_fwd_rows")
+
+        ms_g, ms_r = timeit(general, a.iters), timeit(rows, a.iters)
+        frac = lambda ms: round(S * FLOP_PER_SAMPLE / (ms * 1e-3) / 1e12 / PEAK_TFLOPS, 4)
+        line[f"rows_{T}"] = {"general_ms": round(ms_g, 4), "rows_ms": round(ms_r, 4), "general_frac_of_mfma_peak": frac(ms_g),
+                             "rows_frac_of_mfma_peak_in_general_flops": frac(ms_r),
+                             "terms_in": "LDS" if T <= 64 else "L2",
+                             "max_abs_diff": float((got - want).abs().max()), "abs_max": float(want.abs().max()),
+                             "finite": bool(torch.isfinite(got).all())}
     print(json.dumps(line))
 
 
