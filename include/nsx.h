@@ -321,6 +321,21 @@ int nsx_deform_bwd(const void* packed, const float* positions, int64_t S, const 
                    const float* grad_offsets, void* scratch, float* grad_params, float* grad_code_table,
                    float* grad_code_samples, const int64_t* n_device, void* stream);
 
+/* ---- fused no-grad density pass on a pre-blended grid (csrc/density_fused.hip) --------------------------------------
+ * Replaces NeRSembleNeRFactoField.density_fn / get_density (nersemble_nerfacto_field.py:228-301) for bundles whose rays share
+ * ONE timestep -- an evaluation image (evaluate_nersemble.py:141 -> get_outputs_for_camera_ray_bundle), whose sampler marches
+ * 25.9 M samples through sigma_fn (nersemble_instant_ngp.py:235-266) -- with the H tables blended once per image into one
+ * 2-feature grid (nsx_tables_preblend: the blend of hash_ensemble.py:155-156 is linear in the tables).  One launch instead
+ * of nsx_sample_positions (normalise) + nsx_hashgrid_fwd (F = 2) + nsx_mlp_fwd (mlp_base) + nsx_density_fwd; the [S][32]
+ * features, the normalised positions and the selector stay in registers.  Outputs are bit-identical to the four launches.
+ *   positions_world [S][3] fp32, offsets [S][3] fp32 or NULL (deformation, added to the world position as :257-259 does)
+ *   field_aabb_host: 6 floats (host); table fp16 [total_entries][2]; g: 16 levels
+ *   base_weights: mlp_base's flat fp16 vector (nsx_mlp_fwd's layout), base_hidden_mats 0 or 1
+ *   base_out fp16 [S][base_out_stride >= 16] or NULL (the whole 16-wide row: h0 + 15 geometry features), density fp32 [S] */
+int nsx_density_fused_fwd(const float* positions_world, const float* offsets, int64_t S, const float* field_aabb_host,
+                          const nsx_half* table, const nsx_grid_geom* g, const nsx_half* base_weights, int base_hidden_mats,
+                          nsx_half* base_out, int64_t base_out_stride, float* density, const int64_t* n_device, void* stream);
+
 /* ---- occupancy-grid ray marching (nerfacc 0.5.2 traverse_grids equivalent) -----------------------------
  * Replaces the native part of OccGridEstimator.sampling called at nersemble_volumetric_sampler.py:95-108:
  * ray/AABB slab test + DDA through ONE res^3 boolean grid level (grid_levels=1, train_nersemble.py:100) +

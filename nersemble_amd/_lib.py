@@ -79,6 +79,8 @@ SIGNATURES = {
                                      c_void_p]),
     "nsx_hashgrid_fwd": (c_int, [c_void_p, c_int64, c_void_p, c_int, _GEOM_P, c_void_p, c_void_p]),
     "nsx_hashgrid_bwd": (c_int, [c_void_p, c_int64, c_void_p, c_int, _GEOM_P, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "nsx_density_fused_fwd": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, _GEOM_P, c_void_p, c_int, c_void_p,
+                                      c_int64, c_void_p, c_void_p, c_void_p]),
     "nsx_mlp_param_count": (c_int, [c_int]),
     "nsx_mlp_fwd": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_int64, c_int, c_float, c_float, c_void_p, c_int64,
                             c_int, c_int, c_int, c_int, c_void_p, c_int64, c_void_p, c_void_p]),

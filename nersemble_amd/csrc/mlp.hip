@@ -23,182 +23,9 @@
 //     the wave and reduced block-wide before one fp32 atomic per parameter per block.
 //   * these kernels are memory/latency bound (<= 16 MFMAs per 32 samples): MFMA time is noise next to the
 //     hash gather, so the design optimises bytes and launches, not matrix-core utilisation.
-#include "nsx_common.h"
-#include <stdlib.h>
+#include "mlp_device.h"
 
 namespace nsx {
-
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-constexpr int MLP_W = 64;        // hidden width
-constexpr int MLP_IN = 32;       // padded input width
-constexpr int MLP_OUT = 16;      // padded output width
-constexpr int MLP_WAVES = 4;
-
-struct MlpIO {
-    // input vector of sample b = [ a[b][0..a_dim) * a_mul + a_add  (fp32 source),  bsrc[b][b_off .. b_off+b_dim) (fp16 source), 0... ]
-    const float* a; int64_t a_stride; int a_dim; float a_mul, a_add;
-    const half_t* b; int64_t b_stride; int b_off; int b_dim;
-};
-
-__device__ __forceinline__ f32x16 mfma(f16x8 a, f16x8 b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
-}
-__device__ __forceinline__ f32x16 zero16() {
-    f32x16 z;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) z[i] = 0.f;
-    return z;
-}
-// accumulator register r of lane-half `half` holds row:
-__device__ __host__ __forceinline__ int acc_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
-// k-permutation when the accumulator tile mt of the previous layer is used as B operand:
-// K-step t = 2*mt + tt uses registers 8*tt .. 8*tt+7 -> actual neuron index
-__device__ __host__ __forceinline__ int kmap_chain(int t, int kb, int j) {
-    return 32 * (t >> 1) + acc_row(8 * (t & 1) + j, kb);
-}
-__device__ __host__ __forceinline__ int kmap_natural(int t, int kb, int j) { return 16 * t + 8 * kb + j; }
-
-// ---- LDS weight fragments ----------------------------------------------------------------------
-// Fragment (mt, t) of a matrix product D = Wm * Xm with Wm[M][K]: lane (i = lane&31, kb = lane>>5) element j
-// holds Wm[32*mt + i][kmap(t, kb, j)] (zero outside the matrix).
-struct FragPlan {
-    // forward
-    int w0;          // [2 mt][2 t]    W0 [64][32], natural k
-    int wh;          // [2 mt][4 t]    Wh [64][64], chained k        (only if NH == 1)
-    int wo;          // [1 mt][4 t]    Wo [16->32][64], chained k
-    // backward (transposed matrices, K = output neurons in chained order)
-    int woT;         // [2 mt][1 t]    Wo^T [64][16->(K-step 0 only)]
-    int whT;         // [2 mt][4 t]    Wh^T [64][64]
-    int w0T;         // [1 mt][4 t]    W0^T [32][64]
-    int total;
-};
-__device__ __host__ inline FragPlan make_plan(int NH, bool bwd) {
-    FragPlan p{};
-    int n = 0;
-    p.w0 = n; n += 4;
-    p.wh = n; if (NH) n += 8;
-    p.wo = n; n += 4;
-    if (bwd) {
-        p.woT = n; n += 2;
-        p.whT = n; if (NH) n += 8;
-        p.w0T = n; n += 4;
-    }
-    p.total = n;
-    return p;
-}
-
-// The flat weight vector (14 KB with a hidden matrix) is first copied into LDS with coalesced 16-byte loads; the
-// fragments are then gathered from LDS.  Gathering them from global memory -- 60 dependent 2-byte loads per thread -- was
-// most of the kernels' FIXED cost (57 us for a backward launch on 1024 samples): what a steady-state step pays four times.
-template <int NH>
-__device__ void stage_weights(const half_t* __restrict__ Wg, half_t* __restrict__ tmp, f16x8* frags, bool bwd) {
-    constexpr int NPARAM = MLP_W * MLP_IN + (NH ? MLP_W * MLP_W : 0) + MLP_OUT * MLP_W;     // halfs, a multiple of 8
-    const half_t* W = Wg;
-    if ((reinterpret_cast<uintptr_t>(Wg) & 15) == 0) {
-        for (int i = threadIdx.x; i < NPARAM / 8; i += blockDim.x)
-            reinterpret_cast<f16x8*>(tmp)[i] = reinterpret_cast<const f16x8*>(Wg)[i];
-        __syncthreads();
-        W = tmp;
-    }
-    // flat parameter layout: W0 [64][32], (Wh [64][64]), Wo [16][64]
-    const half_t* W0 = W;
-    const half_t* Wh = W + MLP_W * MLP_IN;
-    const half_t* Wo = Wh + (NH ? MLP_W * MLP_W : 0);
-    const FragPlan p = make_plan(NH, bwd);
-    for (int e = threadIdx.x; e < p.total * kWave; e += blockDim.x) {
-        const int fi = e / kWave, ll = e % kWave;
-        const int i = ll & 31, kb = ll >> 5;
-        f16x8 v;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            half_t x = (half_t)0.f;
-            if (fi < p.wh) {                       // W0: mt = (fi-p.w0)/2, t = %2, natural k
-                const int mt = (fi - p.w0) >> 1, t = (fi - p.w0) & 1;
-                x = W0[(32 * mt + i) * MLP_IN + kmap_natural(t, kb, j)];
-            } else if (fi < p.wo) {                // Wh
-                const int mt = (fi - p.wh) >> 2, t = (fi - p.wh) & 3;
-                x = Wh[(32 * mt + i) * MLP_W + kmap_chain(t, kb, j)];
-            } else if (!bwd || fi < p.woT) {       // Wo (rows >= 16 are zero padding)
-                const int t = fi - p.wo;
-                if (i < MLP_OUT) x = Wo[i * MLP_W + kmap_chain(t, kb, j)];
-            } else if (fi < p.whT) {               // Wo^T: M = hidden neuron (2 tiles), K-step 0 of chained out neurons
-                const int mt = fi - p.woT;
-                const int o = kmap_chain(0, kb, j);          // rows 0..3,8..11 / 4..7,12..15
-                if (o < MLP_OUT) x = Wo[o * MLP_W + 32 * mt + i];
-            } else if (fi < p.w0T) {               // Wh^T
-                const int mt = (fi - p.whT) >> 2, t = (fi - p.whT) & 3;
-                x = Wh[kmap_chain(t, kb, j) * MLP_W + 32 * mt + i];
-            } else {                               // W0^T: M = input feature (1 tile), K = 64 hidden chained
-                const int t = fi - p.w0T;
-                x = W0[kmap_chain(t, kb, j) * MLP_IN + i];
-            }
-            v[j] = x;
-        }
-        frags[e] = v;
-    }
-}
-
-// ---- input fragments (orientation: lane = sample) ------------------------------------------------
-__device__ __forceinline__ half_t input_elem(const MlpIO& io, int64_t b, int k) {
-    if (k < io.a_dim) return (half_t)__fmaf_rn(io.a[b * io.a_stride + k], io.a_mul, io.a_add);
-    k -= io.a_dim;
-    if (k < io.b_dim) return io.b[b * io.b_stride + io.b_off + k];
-    return (half_t)0.f;
-}
-
-__device__ __forceinline__ void load_input(const MlpIO& io, int64_t b, int kb, bool fast, f16x8 x[2]) {
-    if (fast) {
-        const f16x8* row = reinterpret_cast<const f16x8*>(io.b + b * io.b_stride);
-        x[0] = row[kb];
-        x[1] = row[2 + kb];
-    } else {
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) x[t][j] = input_elem(io, b, kmap_natural(t, kb, j));
-    }
-}
-
-__device__ __forceinline__ void relu_pack(const f32x16& d, f16x8& lo, f16x8& hi) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        lo[j] = (half_t)fmaxf(d[j], 0.f);
-        hi[j] = (half_t)fmaxf(d[8 + j], 0.f);
-    }
-}
-
-// forward chain for one tile; keeps hidden activations (fp16 fragments, chained-k order)
-template <int NH>
-__device__ __forceinline__ f32x16 forward_tile(const f16x8* frags, const FragPlan& p, int lane, const f16x8 x[2],
-                                               f16x8 h1[4], f16x8 h2[4]) {
-    f32x16 z[2];
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-        z[mt] = zero16();
-#pragma unroll
-        for (int t = 0; t < 2; ++t) z[mt] = mfma(frags[(p.w0 + mt * 2 + t) * kWave + lane], x[t], z[mt]);
-        relu_pack(z[mt], h1[2 * mt], h1[2 * mt + 1]);
-    }
-    const f16x8* hl = h1;
-    if constexpr (NH == 1) {
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-            z[mt] = zero16();
-#pragma unroll
-            for (int t = 0; t < 4; ++t) z[mt] = mfma(frags[(p.wh + mt * 4 + t) * kWave + lane], h1[t], z[mt]);
-            relu_pack(z[mt], h2[2 * mt], h2[2 * mt + 1]);
-        }
-        hl = h2;
-    }
-    f32x16 o = zero16();
-#pragma unroll
-    for (int t = 0; t < 4; ++t) o = mfma(frags[(p.wo + t) * kWave + lane], hl[t], o);
-    return o;
-}
-
-__device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + __expf(-v)); }
 
 // ------------------------------------------------------------------------------------------------
 template <int NH>
@@ -210,26 +37,50 @@ __global__ __launch_bounds__(MLP_WAVES * kWave) void mlp_fwd_kernel(const half_t
     extern __shared__ __attribute__((aligned(16))) uint8_t smem_raw[];
     f16x8* frags = reinterpret_cast<f16x8*>(smem_raw);
     const FragPlan p = make_plan(NH, false);
+    // (the staging copy behind the fragments is only touched for a weight vector that is not 16-byte aligned)
     stage_weights<NH>(W, reinterpret_cast<half_t*>(smem_raw + (size_t)p.total * kWave * sizeof(f16x8)), frags, false);
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n = lane & 31, kb = lane >> 5;
     const bool fast = io.a_dim == 0 && io.b_off == 0 && io.b_dim == MLP_IN && (io.b_stride % 8) == 0;
-    for (int64_t tile = (int64_t)blockIdx.x * MLP_WAVES + wave; tile < n_tiles; tile += (int64_t)gridDim.x * MLP_WAVES) {
+    // the two 4-neuron runs a lane holds leave as two 8-byte stores when the whole 16-wide row is wanted (mlp_base)
+    const bool wide_out = n_out == MLP_OUT && out_act == 0 && (out_stride % 4) == 0 &&
+                          (reinterpret_cast<uintptr_t>(out) & 7) == 0;
+    const int64_t tile_step = (int64_t)gridDim.x * MLP_WAVES;
+    int64_t tile = (int64_t)blockIdx.x * MLP_WAVES + wave;
+    f16x8 xn[2];
+    if (tile < n_tiles) {
+        const int64_t b0 = tile * 32 + n;
+        load_input(io, b0 < B ? b0 : B - 1, kb, fast, xn);
+    }
+    for (; tile < n_tiles; tile += tile_step) {
         const int64_t b_raw = tile * 32 + n;
         const int64_t b = b_raw < B ? b_raw : B - 1;
         f16x8 x[2], h1[4], h2[4];
-        load_input(io, b, kb, fast, x);
+        x[0] = xn[0]; x[1] = xn[1];
+        if (tile + tile_step < n_tiles) {          // the next tile's input is in flight while this tile's MFMAs chain
+            const int64_t bn = (tile + tile_step) * 32 + n;
+            load_input(io, bn < B ? bn : B - 1, kb, fast, xn);
+        }
         f32x16 o = forward_tile<NH>(frags, p, lane, x, h1, h2);
         if (b_raw < B) {
             // rows held by this lane: r = 0..7 -> neurons (r&3) + 8*(r>>2) + 4*kb  (two runs of 4 consecutive)
+            if (wide_out) {
+                f16x4 lo, hi;
 #pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                const int m = acc_row(r, kb);
-                if (m < n_out) {
-                    float v = o[r];
-                    if (out_act == 1) v = sigmoidf_(v);
-                    out[b * out_stride + m] = (half_t)v;
+                for (int r = 0; r < 4; ++r) { lo[r] = (half_t)o[r]; hi[r] = (half_t)o[4 + r]; }
+                half_t* row = out + b * out_stride + 4 * kb;
+                *reinterpret_cast<f16x4*>(row) = lo;
+                *reinterpret_cast<f16x4*>(row + 8) = hi;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const int m = acc_row(r, kb);
+                    if (m < n_out) {
+                        float v = o[r];
+                        if (out_act == 1) v = sigmoidf_(v);
+                        out[b * out_stride + m] = (half_t)v;
+                    }
                 }
             }
         }

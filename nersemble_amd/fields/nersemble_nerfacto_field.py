@@ -72,6 +72,9 @@ class NeRSembleNeRFactoField(nn.Module):
         # set by the model around the sampler's sigma_fn pass: keep hash features / base-MLP outputs for reuse
         self.keep_density_intermediates = False
         self.last_hash_features = self.last_base_out = None
+        # evaluation fast path: lookup in the pre-blended grid -> mlp_base -> trunc_exp as ONE launch (csrc/density_fused.hip;
+        # bit-identical to the four launches it replaces)
+        self.fused_eval_density = True
 
         self.direction_encoding = tcnn.Encoding(n_input_dims=3, encoding_config={"otype": "Identity"})
         self.hash_ensemble = HashEnsemble(hash_ensemble_config)
@@ -124,6 +127,11 @@ class NeRSembleNeRFactoField(nn.Module):
                                 window_hash_encodings: Optional[float]) -> Tuple[Tensor, Tensor]:
         """positions (+ offsets) -> scene-box normalisation, selector (:257, :268-269) -> HashEnsemble -> mlp_base ->
         trunc_exp density (:286-293)."""
+        blended = md.get("preblended_table")           # eval fast path: one time code for every sample of the image
+        if (blended is not None and positions_world.is_cuda and self.fused_eval_density and not torch.is_grad_enabled()
+                and md.get("precomputed_base_out") is None and self.hash_ensemble.geom.n_levels == 16
+                and self.mlp_base.n_output_dims == 16):
+            return self._density_fused(positions_world, offsets, blended)
         if positions_world.is_cuda:
             positions, selector_all = F.normalised_positions(positions_world, offsets, self._aabb6())
         else:
@@ -134,7 +142,6 @@ class NeRSembleNeRFactoField(nn.Module):
         max_chunk = len(positions) if self.max_n_samples_per_batch == -1 else self.max_n_samples_per_batch
         time_codes = md.get("time_codes")
         code_index = md.get("time_code_index")        # native extension: time_codes is a [T,H] table
-        blended = md.get("preblended_table")           # eval fast path: one time code for every sample of the image
         pre_feats = md.get("precomputed_hash_features")       # from the step's sigma_fn pass (same samples, same params)
         pre_base = md.get("precomputed_base_out")
         densities, base_outs, feats_all = [], [], []
@@ -149,16 +156,21 @@ class NeRSembleNeRFactoField(nn.Module):
                 # tcnn needs inputs in [0,1): zero the samples outside the scene box (:268-269)
                 selector = ((pos_c > 0.0) & (pos_c < 1.0)).all(dim=-1)
                 pos_c = pos_c * selector[..., None]
-            if blended is not None:
+            if blended is not None and pre_b is not None and not torch.is_grad_enabled():
+                feats = None                 # (the sigma_fn pass's mlp_base rows are reused: nobody reads the features)
+            elif blended is not None:
                 feats = self.hash_ensemble.forward_preblended(pos_c.view(-1, 3), blended)
             else:
                 feats = self.hash_ensemble(pos_c.view(-1, 3), conditioning_code=codes_c,
                                            window_hash_encodings=window_hash_encodings, code_index=idx_c,
                                            precomputed=pre_f)
-            h = F.fused_mlp(self.mlp_base.params, self.mlp_base.n_hidden_mats, self.mlp_base.n_output_dims,
-                            self.mlp_base.out_act, b=feats, precomputed=pre_b,
-                            w16=self.mlp_base.half_weights()).view(*pos_c.shape[:-1], -1)   # [S,16] fp16
-            if self.keep_density_intermediates:
+            if feats is None:
+                h = pre_b.detach().view(*pos_c.shape[:-1], -1)
+            else:
+                h = F.fused_mlp(self.mlp_base.params, self.mlp_base.n_hidden_mats, self.mlp_base.n_output_dims,
+                                self.mlp_base.out_act, b=feats, precomputed=pre_b,
+                                w16=self.mlp_base.half_weights()).view(*pos_c.shape[:-1], -1)   # [S,16] fp16
+            if self.keep_density_intermediates and feats is not None:
                 feats_all.append(feats)
             if sel_c is not None:
                 density = F.density_from_base(h, sel_c)
@@ -171,8 +183,26 @@ class NeRSembleNeRFactoField(nn.Module):
         base_out = base_outs[0] if len(base_outs) == 1 else torch.cat(base_outs, dim=0)
         self._base_out = base_out                      # full [S,16] tensor for the fused head read
         if self.keep_density_intermediates:
-            self.last_hash_features = feats_all[0] if len(feats_all) == 1 else torch.cat(feats_all, dim=0)
+            self.last_hash_features = None if not feats_all else (feats_all[0] if len(feats_all) == 1
+                                                                  else torch.cat(feats_all, dim=0))
             self.last_base_out = base_out
+        return density, base_out[..., 1:]
+
+    def _density_fused(self, positions_world: Tensor, offsets: Optional[Tensor], blended: Tensor) -> Tuple[Tensor, Tensor]:
+        """``_density_from_positions`` on the pre-blended grid without gradients: one launch per chunk
+        (``nsx_density_fused_fwd``); the hash features are never materialised."""
+        max_chunk = len(positions_world) if self.max_n_samples_per_batch == -1 else self.max_n_samples_per_batch
+        w16, nh, geom, aabb6 = self.mlp_base.half_weights(), self.mlp_base.n_hidden_mats, self.hash_ensemble.geom, self._aabb6()
+        densities, base_outs = [], []
+        for pos_c, off_c in chunked(max(max_chunk, 1), positions_world, offsets):
+            d, b = F.density_fused(pos_c, off_c, aabb6, blended, geom, w16, nh)
+            densities.append(d)
+            base_outs.append(b)
+        density = densities[0] if len(densities) == 1 else torch.cat(densities, dim=0)
+        base_out = base_outs[0] if len(base_outs) == 1 else torch.cat(base_outs, dim=0)
+        self._base_out = base_out
+        if self.keep_density_intermediates:
+            self.last_hash_features, self.last_base_out = None, base_out
         return density, base_out[..., 1:]
 
     # ---- colour ------------------------------------------------------------------------------------

@@ -765,6 +765,23 @@ def hashgrid_fwd_f16(x: torch.Tensor, table_f16: torch.Tensor, F_enc: int, geom:
     return out
 
 
+@torch.no_grad()
+def density_fused(positions_world: torch.Tensor, offsets: Optional[torch.Tensor], aabb6, table_f16: torch.Tensor,
+                  geom: GridGeom, base_w16: torch.Tensor, base_hidden_mats: int, want_base_out: bool = True):
+    """``nsx_density_fused_fwd``: (world positions + offsets) -> scene-box normalisation + selector -> lookup in the
+    pre-blended 2-feature grid -> mlp_base -> (density [S,1] fp32, base_out [S,16] fp16 or None) in one launch; values only."""
+    pos = positions_world.detach().to(torch.float32).contiguous()
+    off = offsets.detach().to(torch.float32).contiguous() if offsets is not None else None
+    S = pos.shape[0]
+    density = torch.empty((S, 1), dtype=torch.float32, device=pos.device)
+    base_out = torch.empty((S, 16), dtype=torch.float16, device=pos.device) if want_base_out else None
+    if S > 0:
+        check(lib().nsx_density_fused_fwd(ptr(pos), ptr(off), S, aabb6, ptr(table_f16, torch.float16), C.byref(geom),
+                                          ptr(base_w16, torch.float16), int(base_hidden_mats), ptr(base_out), 16, ptr(density),
+                                          ndev(S), stream()), "nsx_density_fused_fwd")
+    return density, base_out
+
+
 def hashgrid_encoding(x: torch.Tensor, params: torch.Tensor, F_enc: int, geom: GridGeom) -> torch.Tensor:
     """x [B,3] in [0,1), params flat fp32 (tcnn layout [total][F_enc]) -> [B, n_levels*F_enc] fp16."""
     return _HashGridFn.apply(x, params, F_enc, geom)

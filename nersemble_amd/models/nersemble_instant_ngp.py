@@ -386,14 +386,16 @@ class NeRSembleNGPModel(BaseModel):
         cache, keep = self._sigma_cache, self.occupancy_grid.last_keep_index
         pre_offsets = None
         if cache is not None and keep is not None and cache["n"] == self.occupancy_grid.last_n_marched \
-                and keep.shape[0] == ray_indices.shape[0] and cache["features"] is not None:
+                and keep.shape[0] == ray_indices.shape[0] and cache["base_out"] is not None \
+                and (cache["features"] is not None or not torch.is_grad_enabled()):
             from ..functional import gather_rows
-            vals = [cache["features"], cache["base_out"]] + ([cache["offsets"]] if cache["offsets"] is not None else [])
-            got = gather_rows(keep, *vals)                                                # one launch
-            ray_samples.metadata["precomputed_hash_features"] = got[0]
-            ray_samples.metadata["precomputed_base_out"] = got[1]
-            if cache["offsets"] is not None:
-                pre_offsets = got[2]
+            # (the fused evaluation density pass leaves no hash features: only a backward would read them)
+            names = [k for k in ("base_out", "features", "offsets") if cache[k] is not None]
+            got = dict(zip(names, gather_rows(keep, *[cache[k] for k in names])))         # one launch
+            if "features" in got:
+                ray_samples.metadata["precomputed_hash_features"] = got["features"]
+            ray_samples.metadata["precomputed_base_out"] = got["base_out"]
+            pre_offsets = got.get("offsets")
         self._sigma_cache = None
 
         time_codes_deformation = deform_slot = None

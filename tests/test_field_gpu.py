@@ -279,6 +279,49 @@ def test_get_outputs_rgb_vs_oracle(cuda):
 # ---------------------------------------------------------------------------------------------------------
 # a7: NeRSembleNGPModel.field_density_fn
 # ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("H,with_offsets,S", [(16, True, 5000), (32, False, 1), (4, True, 33), (16, True, 70001)])
+def test_fused_density_equals_the_four_launches(H, with_offsets, S, cuda):
+    """nsx_density_fused_fwd (normalise + selector -> pre-blended lookup -> mlp_base -> trunc_exp in one launch, features in
+    registers) against the route it replaces -- nsx_sample_positions + nsx_hashgrid_fwd(F = 2) + nsx_mlp_fwd + nsx_density_fwd,
+    themselves held to the oracle above: the same arithmetic operation by operation, so density AND the 16-wide mlp_base row
+    are equal bit for bit (incl. samples outside the box, on its faces, ragged tiles, a device-side count)."""
+    from nersemble_amd import functional as F
+    from nersemble_amd._lib import check, lib, ptr, stream
+    fld, go, _, _, _ = _field(H, cuda, seed=H + S)
+    fld.max_n_samples_per_batch = -1
+    he = fld.hash_ensemble
+    rng = np.random.default_rng(S)
+    code = torch.from_numpy(rng.standard_normal(H).astype(np.float32) * 0.7).to(cuda)
+    p = torch.from_numpy(_positions(S, seed=S)).to(cuda)
+    off = (torch.from_numpy(rng.standard_normal((S, 3)).astype(np.float32) * 0.02).to(cuda)) if with_offsets else None
+    with torch.no_grad():
+        table = he.preblend(code, window_hash_encodings=None)
+        md = {"preblended_table": table}
+        fld.fused_eval_density = False
+        d_ref, _ = fld._density_from_positions(p, off, md, None)
+        base_ref = fld._base_out.clone()
+        fld.fused_eval_density = True
+        d_got, _ = fld._density_from_positions(p, off, md, None)
+        base_got = fld._base_out.clone()
+    assert d_ref.shape == d_got.shape == (S, 1) and base_got.shape == (S, 16)
+    assert torch.equal(base_got.view(torch.int16), base_ref.view(torch.int16))
+    assert torch.equal(d_got.view(torch.int32), d_ref.view(torch.int32))
+    if S >= 64:
+        assert (d_got == 0).any() and (d_got > 0).any()                  # both sides of the box are in the batch
+        # a device-side count: only the first rows are written
+        n_dev = torch.tensor([S // 2 + 3], dtype=torch.int64, device=cuda)
+        dens = torch.full((S, 1), -1.0, device=cuda)
+        bo = torch.full((S, 16), -1.0, device=cuda, dtype=torch.float16)
+        check(lib().nsx_density_fused_fwd(ptr(p), ptr(off), S, fld._aabb6(), ptr(table), he.geom, ptr(fld.mlp_base.half_weights()),
+                                          fld.mlp_base.n_hidden_mats, ptr(bo), 16, ptr(dens), ptr(n_dev), stream()), "fused")
+        k = S // 2 + 3
+        assert torch.equal(dens[:k], d_ref[:k]) and bool((dens[k:] == -1).all()) and bool((bo[k:] == -1).all())
+    # wrong geometry / layout is refused
+    rc = lib().nsx_density_fused_fwd(ptr(p), None, S, fld._aabb6(), ptr(table), he.geom, ptr(fld.mlp_base.half_weights()), 0,
+                                     None, 0, None, None, stream())
+    assert rc != 0
+
+
 def _model(name, cuda, seed, log2=15):
     from nersemble_amd.models.nersemble_instant_ngp import NeRSembleNGPModel
     from nersemble_amd.rays import SceneBox

@@ -214,6 +214,32 @@ def test_eval_preblend_fast_path_matches_per_sample_blend(cuda):
     model.train()
 
 
+def test_eval_image_through_the_fused_density_pass_is_the_same_image(cuda):
+    """An evaluation bundle (one timestep) with the fused density pass (one launch: pre-blended lookup -> mlp_base -> trunc_exp;
+    the sampler's sigma_fn reads ONE deformation code row) against the same bundle with the four-launch route: the same
+    samples per ray and the same image, bit for bit."""
+    from nersemble_amd.workloads import build_workload
+    torch.manual_seed(3)
+    trainer, data, _ = build_workload("p030_h16", device="cuda:0", small=True, n_rays=512)
+    for step in range(6):
+        trainer.train_iteration(step, *data.next_train(step))
+    model = trainer.model
+    model.eval()
+    bundle, _, _ = data.eval_image_rays(cam=2, timestep=5, downscale=64)
+    outs = {}
+    with torch.no_grad():
+        for fused in (False, True):
+            model.field.fused_eval_density = fused
+            torch.manual_seed(7)
+            outs[fused] = model(bundle)
+    a, b = outs[False], outs[True]
+    assert int(a["num_samples_per_ray"].sum()) > 0
+    assert torch.equal(a["num_samples_per_ray"], b["num_samples_per_ray"])
+    for k in ("rgb", "accumulation", "depth"):
+        assert torch.equal(a[k], b[k]), k
+    model.train()
+
+
 def test_dense_march_config_runs(cuda):
     """BASELINE configs[3]-like: --disable_occupancy_grid --lambda_dist_loss 0 (every cell occupied, density_fn == 1 for
     the visibility pass, no distortion loss -> the operator-by-operator loss path)."""

@@ -37,15 +37,16 @@ def render():
     return torch.cat(outs), int(samples)
 
 
-for fast in (False, True, False, True):
+for fast, fused in ((False, True), (True, False), (True, True), (True, False), (True, True)):
     model.eval_preblend = fast
+    model.field.fused_eval_density = fused         # (only read on the pre-blended route)
     render()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     img, samples = render()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    print(f"preblend={fast}: {h}x{w} = {n} rays, {samples} samples, {dt * 1e3:.1f} ms, {samples / dt / 1e6:.1f} M samples/s, "
+    print(f"preblend={fast} fused_density={fused}: {h}x{w} = {n} rays, {samples} samples, {dt * 1e3:.1f} ms, {samples / dt / 1e6:.1f} M samples/s, "
           f"psnr {float(10 * torch.log10(1 / ((img - batch['image']) ** 2).mean())):.2f}")
 
 if "--price" in sys.argv:
