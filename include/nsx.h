@@ -30,6 +30,8 @@ extern "C" {
 
 #define NSX_MAX_LEVELS 32
 #define NSX_MAX_SLOTS 64
+#define NSX_MAX_ADAM_SLOTS 192   /* gradient planes nsx_adam_hash_factored(_consume) reads (level-parallel runs: one per
+                                   (source rank, code row), engine/level_parallel.py) */
 #define NSX_VERSION 120
 
 typedef uint16_t nsx_half;

@@ -384,6 +384,12 @@ def ndev(n: int) -> c_void_p:
     return c_void_p(0)
 
 
+def ndev_tensor(n: int):
+    """The int64 device tensor of the active ``device_count`` block if ``n`` is its capacity, else None."""
+    sc = _COUNT_SCOPE
+    return sc[0] if (sc is not None and int(n) == sc[1]) else None
+
+
 def check(rc: int, what: str = "") -> None:
     if rc != 0:
         msg = lib().nsx_last_error().decode("utf-8", "replace")

@@ -465,7 +465,8 @@ static int adam_hash_factored_entry(float* G, int n_slots, const float* code_tab
                                     int64_t step, const float* inv_scale, const float* found_inf, void* stream) {
     NSX_REQUIRE(G && code_table && g && master && exp_avg && exp_avg_sq && tables_f16, "nsx_adam_hash_factored: NULL argument");
     NSX_REQUIRE(H >= 1 && H <= 32, "nsx_adam_hash_factored: H=%d not in [1,32]", H);
-    NSX_REQUIRE(n_slots >= 1 && n_slots <= NSX_MAX_SLOTS, "nsx_adam_hash_factored: n_slots=%d not in [1,%d]", n_slots, NSX_MAX_SLOTS);
+    NSX_REQUIRE(n_slots >= 1 && n_slots <= NSX_MAX_ADAM_SLOTS, "nsx_adam_hash_factored: n_slots=%d not in [1,%d]", n_slots,
+                NSX_MAX_ADAM_SLOTS);
     NSX_REQUIRE(step >= 1, "nsx_adam_hash_factored: step must be >= 1");
     NSX_REQUIRE((reinterpret_cast<uintptr_t>(G) & 15) == 0, "nsx_adam_hash_factored: G must be 16-byte aligned");
     const uint64_t total = g->offset[g->n_levels];

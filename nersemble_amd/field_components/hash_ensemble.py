@@ -86,6 +86,10 @@ class HashEnsemble(nn.Module):
         self._tables_ready = None
         # set by engine.hash_adam.HashTableAdam: factored-gradient sink (no dense table gradient is materialised)
         self.grad_sink = None
+        # set by engine.level_parallel.LevelParallelTableAdam (data-parallel runs with the window open): this rank holds the
+        # CURRENT values of its levels' entries only, forward / backward go through the sample exchange
+        self.level_parallel = None
+        self._level_parallel_owner = None
         self._window_cache = {}
         # compact first-grid phase (see first_grid_phase below): None, or the contiguous copies of grid 0
         self.compact_first_grid = False        # switched on by the trainer (NeRSembleTrainer(compact_first_grid=True))
@@ -248,6 +252,10 @@ class HashEnsemble(nn.Module):
     def train(self, mode: bool = True):
         if not mode:
             self.leave_first_grid_phase()            # evaluation reads the full layout (pre-blended grids, checkpoints)
+            if self.level_parallel is not None and self._level_parallel_owner is not None and self.training:
+                # level-parallel run: every rank's entry range becomes current everywhere (a collective: the ranks leave
+                # training mode together)
+                self._level_parallel_owner.gather_master()
         return super().train(mode)
 
     # ---- reference state-dict layout -----------------------------------------------------------
@@ -378,6 +386,19 @@ class HashEnsemble(nn.Module):
             "If blend mixing type is chosen, conditioning code needs to have as many dimensions as there are " \
             "hashtables in the encoding"
 
+        lp = self.level_parallel
+        if lp is not None and in_tensor.is_cuda and self.training:
+            # data-parallel, window open: this rank evaluates ITS levels for every rank's samples (engine/level_parallel.py)
+            if code_index is None:
+                raise NotImplementedError("level-parallel HashEnsemble: codes are rows of a table (code_index)")
+            conditioning_code, window = self._conditioned(conditioning_code, window_hash_encodings, in_tensor.device)
+            x = in_tensor.reshape(-1, 3)
+            if torch.is_grad_enabled() and (self.tables.requires_grad or x.requires_grad or conditioning_code.requires_grad):
+                from ..engine.level_parallel import lp_hash_ensemble
+                return lp_hash_ensemble(lp, x, self.tables, conditioning_code, code_index, window, precomputed)
+            if precomputed is not None:
+                return precomputed.detach()
+            return lp.features(x, conditioning_code, code_index, window, n_dev=_lib.ndev_tensor(x.shape[0]))
         width = self.compact_width(window_hash_encodings) if in_tensor.is_cuda else 0
         if width >= 2:
             # window ramp: the first `width` grids as a contiguous copy; codes / window are the full layout's

@@ -140,6 +140,8 @@ class NeRSembleNeRFactoField(nn.Module):
             positions = SceneBox.get_normalized_positions(positions_world, self.aabb)
             selector_all = None
         max_chunk = len(positions) if self.max_n_samples_per_batch == -1 else self.max_n_samples_per_batch
+        if self.hash_ensemble.level_parallel is not None and self.hash_ensemble.training:
+            max_chunk = len(positions)         # (every rank issues ONE exchange per pass, whatever its sample count)
         time_codes = md.get("time_codes")
         code_index = md.get("time_code_index")        # native extension: time_codes is a [T,H] table
         pre_feats = md.get("precomputed_hash_features")       # from the step's sigma_fn pass (same samples, same params)
