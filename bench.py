@@ -169,6 +169,53 @@ def steady_state(trainer, data, first_step: int, settle_at: int, rays: int, n_ti
             "psnr": float(metrics["psnr"].detach())}
 
 
+def steady_state_ranks(trainer, data, first_step: int, settle_at: int, rays: int, world: int, dev, backend: str,
+                       n_timed: int = 100):
+    """``steady_state`` for N > 1 ranks (every rank calls it: the steps are collective): continues to step `settle_at`, then
+    times `n_timed` steps between barriers, max over ranks; with the level-parallel exchange the `comm` block of exactly
+    these steps (bytes arriving per rank and step, the job's samples per step) -- the regime a run lives in."""
+    import gc
+    import torch.distributed as dist
+    from nersemble_amd.engine.level_parallel import LevelParallelTableAdam
+    step = first_step
+    while step < settle_at:
+        trainer.train_iteration(step, *data.next_train(step))
+        step += 1
+    batches = [data.next_train(step + i) for i in range(n_timed + 1)]
+    table_opt = trainer.optimizers.get(trainer.group_of_tables())
+    lp = isinstance(table_opt, LevelParallelTableAdam)
+    if lp:
+        table_opt.comm_report()
+        table_opt.timing = True
+    gc.collect()
+    torch.cuda.synchronize()
+    dist.barrier()
+    t0 = time.perf_counter()
+    counts = []
+    for i in range(n_timed):
+        _, _, metrics = trainer.train_iteration(step + i, *batches[i], next_ray_bundle=batches[i + 1][0])
+        counts.append(metrics["num_samples_per_batch"])
+    torch.cuda.synchronize()
+    dist.barrier()
+    dt = time.perf_counter() - t0
+    trainer.flush_scheduler_step()
+    counts = [int(c) for c in counts]
+    t = torch.tensor([dt], device=dev, dtype=torch.float64)
+    n = torch.tensor([sum(counts)], device=dev, dtype=torch.int64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dist.all_reduce(n, op=dist.ReduceOp.SUM)
+    out = {"from_step": step, "steps": n_timed, "ms_per_step": float(t.item()) / n_timed * 1e3,
+           "value": int(n.item()) / float(t.item()), "unit": "ray-samples/s", "rays_per_sec": world * rays * n_timed / float(t.item()),
+           "samples_per_step_min_max_rank0": [min(counts), max(counts)], "psnr_rank0": float(metrics["psnr"].detach())}
+    if lp:
+        table_opt.timing = False
+        comm = table_opt.comm_report()
+        comm["backend"] = backend
+        comm["bar_bytes_per_rank"] = 2 * 64 * (comm["samples_fwd_per_step"] + comm["samples_bwd_per_step"]) / 2 * 1.05
+        out["comm"] = comm
+    return out
+
+
 def first_grid_phase_block(a):
     """The same command with `--compact-first-grid` in a process of its own (fresh allocator, own placement calibration):
     what the steps of this benchmark cost in the compact first-grid phase -- the DEFAULT of `NeRSembleTrainer` since round 3
@@ -481,6 +528,11 @@ def main():
                     help="steps of the coarse-to-fine schedule of the hash grids instead of the workload's (40000 80000, "
                          "train_nersemble.py:77-78); `0 1` = every grid on from step 1: the state of a run after END")
     ap.add_argument("--window-open", action="store_true", help="shorthand for --window-hash 0 1")
+    ap.add_argument("--table-parallel", choices=("auto", "level", "shard"), default="auto",
+                    help="N > 1: how the hash tables' step is shared -- shard: fp16 reduce-scatter / shard Adam / all-gather "
+                         "(engine/sharded_adam.py); level: rank r owns levels [r L / N, (r + 1) L / N), samples travel instead "
+                         "of parameters (engine/level_parallel.py); auto: shard while the coarse-to-fine window is below "
+                         "H / 2, level from then on")
     ap.add_argument("--no-open-window", action="store_true", help="skip the `open_window` block")
     ap.add_argument("--no-kernels-alone", action="store_true", help="skip the stand-alone kernel timings after the run")
     ap.add_argument("--with-datamanager", action="store_true",
@@ -532,7 +584,8 @@ def main():
     trainer, data, info = build_workload(a.workload, device=dev, rank=rank, world_size=world, n_rays=n_rays,
                                          global_loss_normalisers=(a.scaling == "strong" and world > 1),
                                          compact_first_grid=a.compact_first_grid,
-                                         window_hash=tuple(a.window_hash) if a.window_hash else None)
+                                         window_hash=tuple(a.window_hash) if a.window_hash else None,
+                                         table_parallel=a.table_parallel)
     if a.reserve_gb > 0:
         reserve = torch.empty(int(a.reserve_gb * 2 ** 30), dtype=torch.uint8, device=dev)
         del reserve
@@ -624,10 +677,15 @@ def main():
     _lib.profiler.alias = {"nsx_adam_hash_factored_consume": "nsx_adam_hash_factored"}
     if not a.no_kernel_events:
         _lib.profiler.prewarm(2 * 16 * a.steps + 64)
+    from nersemble_amd.engine.level_parallel import LevelParallelTableAdam
     from nersemble_amd.engine.sharded_adam import ShardedTableAdam
-    if isinstance(table_opt, ShardedTableAdam):
+    table_opt = trainer.optimizers.get(trainer.group_of_tables())     # (the warm-up may have switched the exchange)
+    if isinstance(table_opt, (ShardedTableAdam, LevelParallelTableAdam)):
         table_opt.timing = True                # HIP events around expand / reduce-scatter / shard Adam / all-gather
         table_opt._events = []
+        if isinstance(table_opt, LevelParallelTableAdam):
+            table_opt.comm_report()            # (zeroes the byte / sample counters of the warm-up)
+            table_opt.timing = True
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -658,7 +716,24 @@ def main():
         dt_all = every.tolist()
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(n, op=dist.ReduceOp.SUM)
-        if isinstance(table_opt, ShardedTableAdam):
+        table_opt = trainer.optimizers.get(trainer.group_of_tables())
+        if isinstance(table_opt, LevelParallelTableAdam):
+            table_opt.timing = False
+            comm = table_opt.comm_report()
+            comm["backend"] = a.backend
+            comm["rccl_ranks"] = world if a.backend == "nccl" else 0
+            comm["ms_per_step_per_rank_min_max"] = [min(dt_all) / a.steps * 1e3, max(dt_all) / a.steps * 1e3]
+            # the bar of the round-4 review: the exchange must scale with the samples (2 x 64 B per sample of the JOB and
+            # pass for features out / gradients back), not with the 806 MB of parameters
+            job_samples = max(comm["samples_bwd_per_step"], 1.0)
+            comm["bytes_per_job_sample"] = comm["bytes_per_rank"] / job_samples
+            comm["bar_bytes_per_rank"] = 2 * 64 * (comm["samples_fwd_per_step"] + comm["samples_bwd_per_step"]) / 2 * 1.05
+            comm["note"] = ("level-parallel exchange (engine/level_parallel.py): bytes ARRIVING at this rank per step over all "
+                            "its collectives -- positions + code slots all-gathered, feature columns / dL/dfeatures / "
+                            "dL/dx by all-to-all (counted as all-to-all also on the gloo stand-in, which gathers) -- and "
+                            "the job's samples that went through this rank's kernels; no table gradient and no table "
+                            "values travel")
+        elif isinstance(table_opt, ShardedTableAdam):
             table_opt.timing = False
             comm = table_opt.comm_report()                      # this rank's (rank 0 prints)
             comm["backend"] = a.backend
@@ -670,6 +745,10 @@ def main():
                             "stream waited for it before the inf check; shard Adam + all-gather run on the optimizer "
                             "stream beside the step's tail and the next step's marching")
     dt_max, total_samples = float(t.item()), int(n.item())
+    steady_ranks = None
+    if world > 1 and a.steady_after > 0:
+        steady_ranks = steady_state_ranks(trainer, data, a.preroll + a.warmup + a.steps, a.steady_after, info["rays"], world,
+                                          dev, a.backend)
 
     if rank == 0:
         _lib.profiler.collect_native()          # the kernel calls the native step drivers made (their own HIP events)
@@ -785,6 +864,8 @@ def main():
         if a.steady_after > 0 and world == 1:
             out["steady_state"] = steady_state(trainer, data, a.preroll + a.warmup + a.steps, a.steady_after, info["rays"],
                                                datamanager=dm)
+        if steady_ranks is not None:
+            out["steady_state"] = steady_ranks
         spp = [p["samples"] for p in out["per_step"]]
         out["samples_per_step_min_max"] = [min(spp), max(spp)] if spp else None
         if len(out["per_step"]) > 40:                            # long runs: every k-th step is enough to see the trend

@@ -85,8 +85,12 @@ class _MainPass(torch.autograd.Function):
             check(L.nsx_sample_positions(ptr(pos), None, None, None, None, ptr(offsets), S, inp.field_aabb6, None, ptr(pn),
                                          ptr(sel), ndev(S), st), "nsx_sample_positions")
         # -- HashEnsemble, mlp_base, density
+        lp = getattr(he, "level_parallel", None)
         if inp.pre_features is not None:
             feats = inp.pre_features
+        elif lp is not None:
+            # data-parallel run with the window open: this rank's levels for every rank's samples (engine/level_parallel.py)
+            feats = lp.features(pn, code_h, hash_slot, hash_window, n_dev=inp.n_dev)
         else:
             feats = torch.empty((S, 2 * geom.n_levels), dtype=f16, device=dev)
             check(L.nsx_hash_ensemble_fwd(ptr(pn), S, ptr(tables_f16), H, C.byref(geom), ptr(code_h), code_h.stride(0),
@@ -204,6 +208,15 @@ class _MainPass(torch.autograd.Function):
         need_tab = ctx.needs_input_grad[1]
         need_code = ctx.needs_input_grad[4] and not first_grid      # (the code is the constant one in that phase)
         G, dtab = None, None
+        lp = getattr(he, "level_parallel", None)
+        if lp is not None:
+            # level-parallel exchange: dL/dfeatures travels to the levels' owners, the table gradient of the owned levels
+            # stays in their gradient planes (no G here, no dense gradient), dL/dx and the code gradient come back summed
+            lp._last_need_code = bool(need_code)
+            dx, g_code_hash = lp.backward(pn, hash_slot, dout, code_h, hash_window, inp.n_dev, need_code=bool(need_code),
+                                          need_table=bool(need_tab))
+            return _MainPass._finish_backward(ctx, L, st, dev, S, inp, dx, sel, pos, code_d, gparams, gtable, g_code_hash,
+                                              n_rows, H, None, d_base, d_head)
         if need_tab:
             if sink is not None:
                 G = sink.buffer_for(code_h, hash_window, n_rows, geom.total_entries, n_samples=S)
@@ -242,6 +255,13 @@ class _MainPass(torch.autograd.Function):
             dtab = torch.empty(ctx.shapes[0], dtype=f32, device=dev)
             check(L.nsx_hash_grad_expand(ptr(G), n_rows, ptr(code_h), code_h.stride(0), ptr(hash_window), H, C.byref(geom),
                                          ptr(dtab), 0, st), "nsx_hash_grad_expand")
+        return _MainPass._finish_backward(ctx, L, st, dev, S, inp, dx, sel, pos, code_d, gparams, gtable, g_code_hash, n_rows,
+                                          H, dtab, d_base, d_head)
+
+    @staticmethod
+    def _finish_backward(ctx, L, st, dev, S, inp, dx, sel, pos, code_d, gparams, gtable, g_code_hash, n_rows, H, dtab,
+                         d_base, d_head):
+        f32 = torch.float32
         # -- normalisation: gradient of the offsets
         goff = torch.empty((S, 3), dtype=f32, device=dev)
         check(L.nsx_normalise_bwd(ptr(dx), ptr(sel), S, inp.field_aabb6, ptr(goff), ndev(S), st), "nsx_normalise_bwd")

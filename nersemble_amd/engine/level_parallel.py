@@ -163,9 +163,10 @@ class LevelParallel:
     # ---- forward ------------------------------------------------------------------------------------------------------
     @torch.no_grad()
     def features(self, x: torch.Tensor, code: torch.Tensor, code_index: torch.Tensor,
-                 window: Optional[torch.Tensor]) -> torch.Tensor:
+                 window: Optional[torch.Tensor], n_dev: Optional[torch.Tensor] = None) -> torch.Tensor:
         """``HashEnsemble.forward`` (values): x [S,3] in [0,1), ``code`` the CONDITIONED code table [rows,H], ``code_index``
-        [S] -> [S, 2 L] fp16.  Collective: every rank calls it the same number of times per step (S may be 0)."""
+        [S] -> [S, 2 L] fp16.  ``n_dev``: device count of valid rows.  Collective: every rank calls it the same number of
+        times per step (S may be 0)."""
         he, W = self.he, self.world_size
         he.wait_tables()
         dev = x.device
@@ -187,12 +188,17 @@ class LevelParallel:
             self.stats["samples_fwd"] += S
             return allc.permute(1, 0, 2).reshape(S, W * n2).contiguous()
         sizes, S_cap, xs, slots, codes = self._gather_samples(x, slot, code)
+        counts = None
+        if n_dev is not None:
+            counts = torch.empty((W,), dtype=torch.int64, device=dev)
+            self._all_gather(counts, n_dev.reshape(1))
         send = torch.empty((W, S_cap, n2), dtype=torch.float16, device=dev)
         for j in range(W):
             Sj = sizes[j][0]
             if Sj:
                 check(L_.nsx_hash_ensemble_fwd(ptr(xs[j]), Sj, ptr(tables), H, C.byref(self.geom), ptr(codes[j]),
-                                               codes[j].stride(0), ptr(slots[j]), ptr(window), ptr(send[j]), None, stream()),
+                                               codes[j].stride(0), ptr(slots[j]), ptr(window), ptr(send[j]),
+                                               ptr(counts[j:j + 1]) if counts is not None else None, stream()),
                       "nsx_hash_ensemble_fwd")
         recv = torch.empty_like(send)
         if S_cap:
@@ -498,6 +504,7 @@ class LevelParallelTableAdam(torch.optim.Optimizer):
         he.wait_tables()
         self.lp.gather_entry_ranges(he.tables.data)
         self.lp.gather_entry_ranges(he.half_tables())
+        he.mark_half_synced()
 
     def _gather_moment(self, mine: torch.Tensor) -> torch.Tensor:
         full = torch.zeros_like(self.he.tables.data)

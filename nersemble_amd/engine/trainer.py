@@ -15,6 +15,7 @@ import torch.distributed as dist
 from ..models.nersemble_instant_ngp import NeRSembleNGPModel
 from .hash_adam import HashTableAdam, NativeGradScaler
 from .parallel import all_reduce_gradients, check_gradient_presence
+from .level_parallel import LevelParallelTableAdam
 from .sharded_adam import ShardedTableAdam
 from .small_adam import SmallGroupAdam, adam_groups, unscale_and_check_groups
 from ..rays import RayBundle
@@ -69,10 +70,16 @@ class NeRSembleTrainer:
                  rank: Optional[int] = None, sharded_table_adam: Optional[bool] = None,
                  overlap_table_adam: bool = True, calibrate_table_placement: bool = True,
                  global_loss_normalisers: bool = False, early_table_step: bool = False,
-                 compact_first_grid: bool = True):
+                 compact_first_grid: bool = True, table_parallel: Optional[str] = "auto"):
         """``global_loss_normalisers``: the ranks hold consecutive slices of ONE ray batch (strong scaling)
         -- loss denominators are made global so that the step equals the single-process step on the union batch."""
         self.model = model
+        # ``table_parallel`` (data-parallel runs with the sharded table optimizer): "auto" = the exchange follows the
+        # coarse-to-fine window -- narrow fp16 reduce-scatter / all-gather while few grids are on (engine/sharded_adam.py),
+        # and from the step at which the window passes H / 2 the LEVEL-parallel exchange that moves samples instead of
+        # parameters (engine/level_parallel.py); "level" = level-parallel from the first step; "shard" / None = the
+        # reduce-scatter exchange throughout (rounds 1-4)
+        self.table_parallel = table_parallel
         # ``compact_first_grid``: while the coarse-to-fine window keeps one hash grid on (the first 40 000 steps of the
         # reference's schedule), train a contiguous copy of that grid with the H = 1 kernels instead of the 32-grid layout
         # (HashEnsemble.first_grid_phase: same values, ~1.4-1.7x per step).  Single GPU, factored table gradient.  ON by
@@ -163,6 +170,36 @@ class NeRSembleTrainer:
         model.field.hash_ensemble.compact_first_grid = bool(
             compact_first_grid and world_size == 1 and isinstance(table_opt, HashTableAdam) and table_opt.factored)
 
+    def _maybe_level_parallel(self) -> None:
+        """Data-parallel runs: hand the tables from the reduce-scatter exchange (``ShardedTableAdam``) to the level-parallel
+        one once the coarse-to-fine window has passed H / 2 -- a collective every rank reaches at the same step (the schedule
+        is the same everywhere).  The fp32 master and both moments are gathered once; each rank keeps its levels' range."""
+        key = self.group_of_tables()
+        opt = self.optimizers.get(key) if key else None
+        if not isinstance(opt, ShardedTableAdam) or self.table_parallel not in ("auto", "level"):
+            return
+        he = self.model.field.hash_ensemble
+        if he.geom.n_levels % self.world_size != 0 or not he.tables.is_cuda:
+            return
+        if self.table_parallel == "auto":
+            sched = getattr(self.model, "sched_window_hash_encodings", None)
+            if sched is not None and float(sched.value) < opt.Hp / 2:
+                return
+        self.flush_scheduler_step()
+        he.wait_tables()
+        opt.gather_master()
+        b = opt._buffers()
+        exp_avg, exp_avg_sq = opt._gather_shards(b["exp_avg"]), opt._gather_shards(b["exp_avg_sq"])
+        pg = opt.param_groups[0]
+        new = LevelParallelTableAdam(he, lr=pg["lr"], betas=pg["betas"], eps=pg["eps"], world_size=self.world_size,
+                                     rank=self.rank, group=opt.group, step=opt._step, exp_avg=exp_avg, exp_avg_sq=exp_avg_sq)
+        he._level_parallel_owner = new
+        new.timing = opt.timing
+        self.optimizers[key] = new
+        self.schedulers[key].optimizer = new
+        del exp_avg, exp_avg_sq
+        opt._buf = None                                       # (the working tables stay: HashEnsemble.tables_f16 views them)
+
     def group_of_tables(self) -> Optional[str]:
         """Key of the optimizer that owns the hash tables (``"<group>/tables"``), if there is one."""
         return next((k for k in self.optimizers if k.endswith("/tables")), None)
@@ -174,9 +211,9 @@ class NeRSembleTrainer:
         # (the sharded table optimizer runs its own reduce-scatter; its parameter has no dense gradient -- every rank has
         # started that collective before the ones below are issued, also a rank without samples)
         for opt in self.optimizers.values():
-            if isinstance(opt, ShardedTableAdam):
+            if isinstance(opt, (ShardedTableAdam, LevelParallelTableAdam)):
                 opt.ensure_reduce_started()
-        params = [p for opt in self.optimizers.values() if not isinstance(opt, ShardedTableAdam)
+        params = [p for opt in self.optimizers.values() if not isinstance(opt, (ShardedTableAdam, LevelParallelTableAdam))
                   for pg in opt.param_groups for p in pg["params"]]
         # which parameters took part in the PREVIOUS step (on any rank): its counts have reached the host by now
         self.flush_scheduler_step()
@@ -250,7 +287,7 @@ class NeRSembleTrainer:
             table = unscale_and_check_groups([o for _, o in native_small], small_groups, len(groups), found_all, inv_scale)
         for key, opt in self.optimizers.items():
             f = found[self.group_of[key]]
-            if isinstance(opt, (HashTableAdam, ShardedTableAdam)):
+            if isinstance(opt, (HashTableAdam, ShardedTableAdam, LevelParallelTableAdam)):
                 if not (stepped_early and opt is table_opt):
                     opt.check_finite(f)
             elif not isinstance(opt, SmallGroupAdam):
@@ -264,7 +301,7 @@ class NeRSembleTrainer:
             if isinstance(opt, HashTableAdam):
                 if not (stepped_early and opt is table_opt):
                     opt.step_unhooked(found_inf=f, inv_scale=inv_scale, side_stream=self._opt_stream)
-            elif isinstance(opt, ShardedTableAdam):
+            elif isinstance(opt, (ShardedTableAdam, LevelParallelTableAdam)):
                 opt.step(found_inf=f, inv_scale=inv_scale, side_stream=self._opt_stream)
             elif isinstance(opt, SmallGroupAdam):
                 continue
@@ -304,6 +341,8 @@ class NeRSembleTrainer:
             self.model.train()
         for cb in self.callbacks:
             cb.run(step)
+        if self.world_size > 1:
+            self._maybe_level_parallel()
         if next_ray_bundle is not None and self.prefetch_march:
             self.model.prefetch_sampling(next_ray_bundle, step + 1)
         for opt in self.optimizers.values():
@@ -363,7 +402,7 @@ class NeRSembleTrainer:
         Compact first-grid phase: write grid 0 and its moments back into the full layout."""
         self.model.field.hash_ensemble.sync_first_grid()
         for opt in self.optimizers.values():
-            if isinstance(opt, ShardedTableAdam):
+            if isinstance(opt, (ShardedTableAdam, LevelParallelTableAdam)):
                 opt.gather_master()
 
     # ---- checkpointing of the training state (nerfstudio's checkpoints carry "optimizers" and "scalers") -------------
@@ -385,7 +424,7 @@ class NeRSembleTrainer:
         tkey = self.group_of_tables()
         opts = {}
         for key, opt in self.optimizers.items():
-            if isinstance(opt, (HashTableAdam, ShardedTableAdam)):
+            if isinstance(opt, (HashTableAdam, ShardedTableAdam, LevelParallelTableAdam)):
                 continue
             table = self.optimizers[tkey].table_state() if (tkey is not None and self.group_of[tkey] == key) else None
             opts[key] = _to_reference_numbering(self.group_layout[key], opt, opt.state_dict(), table)
@@ -398,7 +437,7 @@ class NeRSembleTrainer:
         saved_all = state.get("optimizers", {})
         tkey = self.group_of_tables()
         for key, opt in self.optimizers.items():
-            if isinstance(opt, (HashTableAdam, ShardedTableAdam)):
+            if isinstance(opt, (HashTableAdam, ShardedTableAdam, LevelParallelTableAdam)):
                 continue
             if key not in saved_all:
                 raise KeyError(f"checkpoint has no optimizer state for the parameter group '{key}' "
@@ -440,7 +479,7 @@ class NeRSembleTrainer:
         # the native table optimizers count their step on the host before the device decides to skip it: take the
         # count back for the groups that skipped (torch's fused Adam does the same with _foreach_sub_(steps, found_inf))
         for key, opt in self.optimizers.items():
-            if isinstance(opt, (HashTableAdam, ShardedTableAdam, SmallGroupAdam)) and \
+            if isinstance(opt, (HashTableAdam, ShardedTableAdam, LevelParallelTableAdam, SmallGroupAdam)) and \
                     flags[self._found_groups.index(self.group_of[key])] != 0.0:
                 opt.rollback_step()
         if not any(f != 0.0 for f in flags):

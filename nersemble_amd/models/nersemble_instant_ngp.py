@@ -202,6 +202,15 @@ class NeRSembleNGPModel(BaseModel):
         cfg = self.config
         grid = self.occupancy_grid
         grid.rng_seed, grid.n_timesteps = self._occ_seed, cfg.n_timesteps
+        lp = getattr(self.field.hash_ensemble, "level_parallel", None)
+        if lp is not None and self.training:
+            # level-parallel run: the update's cells are the same on every rank (shared generator) -- only the feature
+            # columns of the ranks' levels travel
+            with lp.shared():
+                return self._update_occupancy_grid(step, grid, cfg)
+        return self._update_occupancy_grid(step, grid, cfg)
+
+    def _update_occupancy_grid(self, step: int, grid, cfg):
         grid.update_every_n_steps(
             step=step,
             # (the update's kernel hands out the integer timesteps next to the normalised times: no re-rounding)

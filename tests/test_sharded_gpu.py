@@ -307,6 +307,161 @@ def test_two_ranks_on_half_batches_equal_one_process_on_the_union_batch(cuda, tm
             assert err <= 2e-3 * sc + 1e-9, (mode, name, err, sc)
 
 
+# ---- level-parallel exchange (engine/level_parallel.py): samples travel, parameters do not --------------------------------
+OPEN_WINDOW = (-10, 1)          # the coarse-to-fine window at step 0: 1 + 15 * 10 / 11 = 14.6 of 16 grids (> H / 2)
+
+
+def _level_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from nersemble_amd.engine.level_parallel import LevelParallelTableAdam
+    from nersemble_amd.workloads import build_workload
+    per = 256
+    bundle, batch = _union_data(per * world).next_train(0)
+    torch.manual_seed(19980801)
+    trainer, data, _ = build_workload("p030_h16", device="cuda:0", small=True, n_rays=per, rank=rank, world_size=world,
+                                      global_loss_normalisers=True, window_hash=OPEN_WINDOW, table_parallel="auto")
+    _no_jitter(trainer)
+    loss, loss_dict, _ = trainer.train_iteration(0, *_slice_batch(bundle, batch, rank * per, (rank + 1) * per))
+    trainer.flush_scheduler_step()
+    opt = trainer.optimizers[trainer.group_of_tables()]
+    assert isinstance(opt, LevelParallelTableAdam)             # the window is beyond H / 2: the exchange switched at step 0
+    comm = opt.comm_report(reset=False)
+    model = trainer.model
+    grads = {n: p.grad.detach().float().cpu() for n, p in model.named_parameters() if "tables" not in n and p.grad is not None}
+    lp = opt.lp
+    own = (lp.e0, lp.e1)
+    stale_before = model.field.hash_ensemble.half_tables().detach().cpu().clone()
+    trainer.consolidate()
+    res = {"loss": loss.item(), "terms": {k: v.item() for k, v in loss_dict.items()}, "grads": grads,
+           "tables": model.field.hash_ensemble.tables.detach().cpu(), "f16": model.field.hash_ensemble.half_tables().detach().cpu(),
+           "small": torch.cat([p.detach().reshape(-1).cpu() for n, p in model.named_parameters() if "tables" not in n]),
+           "comm": comm, "own": own, "stale_before": stale_before}
+    # two more steps on rank-local rays (weak scaling): the replicas of everything that IS replicated stay identical
+    model.global_loss_normalisers = None
+    losses = []
+    for step in (1, 2):
+        l, _, _ = trainer.train_iteration(step, *data.next_train(step))
+        losses.append(l.item())
+    trainer.flush_scheduler_step()
+    trainer.consolidate()
+    res["losses_after"] = losses
+    res["tables_after"] = model.field.hash_ensemble.tables.detach().cpu()
+    res["small_after"] = torch.cat([p.detach().reshape(-1).cpu() for n, p in model.named_parameters() if "tables" not in n])
+    state = trainer.state_dict()                                # (collective: the moments of all level ranges)
+    res["table_step"] = int(opt._step)
+    res["n_opt_groups"] = len(state["optimizers"])
+    torch.save(res, os.path.join(out_dir, f"l{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_level_parallel_ranks_equal_one_process_on_the_union_batch(cuda, tmp_path):
+    """The level-parallel exchange with the real kernels, world_size 2 (two processes share the GPU, gloo carries the
+    collectives), coarse-to-fine window open: rank r evaluates and differentiates levels [8 r, 8 r + 8) of the hash grids
+    for BOTH ranks' samples, no table gradient and no table values travel.  One optimizer step on a 512-ray batch sliced
+    256 + 256 (global loss normalisers) equals the single-process step on the whole batch at the bars of the reduce-scatter
+    exchange: loss and every term 2e-4 / 2e-3, the small groups' averaged gradients 2e-3 of their maximum, the hash tables
+    on >= 99.5 % of the touched entries; and what arrives at a rank is bounded by the samples, not by the table."""
+    import torch.multiprocessing as mp
+    from nersemble_amd.workloads import build_workload
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_level_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    a, b = torch.load(tmp_path / "l0.pt"), torch.load(tmp_path / "l1.pt")
+    bundle, batch = _union_data(512).next_train(0)
+    torch.manual_seed(19980801)
+    single, _, _ = build_workload("p030_h16", device="cuda:0", small=True, n_rays=512, window_hash=OPEN_WINDOW)
+    init_tables = single.model.field.hash_ensemble.tables.detach().cpu().clone()
+    _no_jitter(single)
+    loss, loss_dict, _ = single.train_iteration(0, bundle, batch)
+    single.flush_scheduler_step()
+    single.consolidate()
+    tables = single.model.field.hash_ensemble.tables.detach().cpu()
+    grads = {n: p.grad.detach().float().cpu() for n, p in single.model.named_parameters()
+             if "tables" not in n and p.grad is not None}
+    moved = (tables - init_tables).abs() > 1e-4
+    assert moved.float().mean().item() > 1e-3 and moved[:, :, 8:].any()            # grids beyond the first are stepped
+    # after consolidation both ranks hold the whole table again, identical; before it a rank held only ITS levels current
+    assert torch.equal(a["tables"], b["tables"]) and torch.equal(a["small"], b["small"]) and torch.equal(a["f16"], b["f16"])
+    assert torch.equal(a["tables"].half(), a["f16"])
+    (a0, a1), (b0, b1) = a["own"], b["own"]
+    assert a0 == 0 and a1 == b0 and b1 == tables.shape[0]
+    assert torch.equal(a["stale_before"][a0:a1], a["f16"][a0:a1]) and not torch.equal(a["stale_before"][b0:b1], a["f16"][b0:b1])
+    assert np.isclose((a["loss"] + b["loss"]) / 2, loss.item(), rtol=2e-4), (a["loss"], b["loss"], loss.item())
+    for k, v in loss_dict.items():
+        assert np.isclose((a["terms"][k] + b["terms"][k]) / 2, v.item(), rtol=2e-3, atol=1e-9), k
+    d = (a["tables"] - tables).abs()
+    frac = (d[moved] <= 1e-5).float().mean().item()
+    assert frac >= 0.995, frac
+    assert "time_embedding.weight" in grads                                        # the window is open: the time codes train
+    for name, g_ref in grads.items():
+        sc = g_ref.abs().max().item()
+        for r in (a, b):
+            err = (r["grads"][name] - g_ref).abs().max().item()
+            assert err <= 2e-3 * sc + 1e-9, (name, err, sc)
+    # the exchange: bytes arriving at a rank per step are bounded by the job's samples (2 x 64 B per sample and pass + the
+    # 16-byte positions + 12-byte dL/dx), far below the 2 x (W - 1) / W x table bytes of the reduce-scatter exchange
+    for r in (a, b):
+        c = r["comm"]
+        assert c["exchange"] == "level_parallel" and c["levels_per_rank"] == 8 and c["gradient_planes"] > 0
+        n_job = c["samples_bwd_per_step"]
+        assert n_job > 0 and c["bytes_per_rank"] <= (2 * 64 + 16 + 16 + 12) * max(c["samples_fwd_per_step"], n_job) + 65536
+        table_bytes = tables.numel() * 2
+        assert c["bytes_per_rank"] < 0.5 * table_bytes
+    # the run goes on: replicated parameters identical, tables identical after consolidation, the optimizer counted 3 steps
+    assert all(np.isfinite(a["losses_after"])) and all(np.isfinite(b["losses_after"]))
+    assert torch.equal(a["tables_after"], b["tables_after"]) and torch.equal(a["small_after"], b["small_after"])
+    assert not torch.equal(a["tables_after"], a["tables"]) and a["table_step"] == b["table_step"] == 3
+
+
+def _switch_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from nersemble_amd.engine.level_parallel import LevelParallelTableAdam
+    from nersemble_amd.engine.sharded_adam import ShardedTableAdam
+    from nersemble_amd.workloads import build_workload
+    torch.manual_seed(19980801)
+    # window: 1 at step 0, 6 at step 1, 11 at step 2 (> H / 2 = 8: the hand-over), 16 from step 3
+    trainer, data, _ = build_workload("p030_h16", device="cuda:0", small=True, n_rays=256, rank=rank, world_size=world,
+                                      window_hash=(0, 3))
+    kinds, losses = [], []
+    for step in range(5):
+        loss, _, _ = trainer.train_iteration(step, *data.next_train(step))
+        kinds.append(type(trainer.optimizers[trainer.group_of_tables()]).__name__)
+        losses.append(loss.item())
+    trainer.flush_scheduler_step()
+    state = trainer.state_dict()
+    key = [k for k in state["optimizers"] if k == "fields"][0]
+    st = state["optimizers"][key]["state"]
+    first = min(st)
+    torch.save({"kinds": kinds, "losses": losses, "tables": trainer.model.field.hash_ensemble.tables.detach().cpu(),
+                "exp_avg": st[first]["exp_avg"].cpu(), "step": float(st[first]["step"])}, os.path.join(out_dir, f"w{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_exchange_is_handed_from_reduce_scatter_to_level_parallel_when_the_window_opens(cuda, tmp_path):
+    """``table_parallel="auto"`` (the trainer's default): the narrow fp16 reduce-scatter exchange while the window is below
+    H / 2, the level-parallel exchange from the step at which it passes H / 2 -- master, both moments and the step count are
+    handed over (a checkpoint written afterwards holds 5 steps of moments for every entry)."""
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_switch_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    a, b = torch.load(tmp_path / "w0.pt"), torch.load(tmp_path / "w1.pt")
+    assert a["kinds"] == b["kinds"] == ["ShardedTableAdam"] * 2 + ["LevelParallelTableAdam"] * 3
+    assert all(np.isfinite(a["losses"])) and all(np.isfinite(b["losses"]))
+    assert torch.equal(a["tables"], b["tables"]) and torch.equal(a["exp_avg"], b["exp_avg"])
+    assert a["step"] == b["step"] == 5.0 and a["exp_avg"].abs().max().item() > 0
+
+
 # ---- the exchange that follows the coarse-to-fine window (grids [0, W) only) -------------------------------------------
 @pytest.mark.parametrize("H,W", [(3, 2), (8, 1), (8, 2), (32, 1), (32, 4), (32, 16)])
 def test_narrow_exchange_kernels(H, W, cuda):
