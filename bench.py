@@ -81,7 +81,9 @@ def kernel_model(name: str, ints, H: int, total_entries: int):
         return "hbm", params * 26.0 + ints[0] * total_entries * 8.0
     if name == "nsx_adam_dense_f16grad":                      # (n, step): the rank's shard in data-parallel runs
         return "hbm", ints[0] * 28.0                          # fp16 gradient + master / m / v read + written + fp16 copy
-    if name == "nsx_deform_fwd":                              # (S, code_stride)
+    if name in ("nsx_deform_fwd", "nsx_deform_fwd_rows"):     # (S, code_stride[, n_rows])
+        # (the table-indexed forward spends 192 of the 256 MFMAs: priced in the FLOPs of the reference's eight Linear
+        # layers, the work it replaces)
         return "mfma", ints[0] * DEFORM_FWD_FLOPS
     if name == "nsx_deform_bwd":                              # recompute fwd + dX chain + weight gradients = 3x fwd
         return "mfma", ints[0] * DEFORM_FWD_FLOPS * 3.0
@@ -135,10 +137,90 @@ def cpu_baseline(H: int, seconds_budget: float = 30.0):
             "torch_cpu_sweep": sweep, "c_port_samples_per_s": c_rate}
 
 
-def steady_state(trainer, data, first_step: int, settle_at: int, rays: int, n_timed: int = 100, datamanager=None):
+def compute_rooflines(prof, records, tags, kept, H: int, total_entries: int, side_stream: bool, pmc_state=None):
+    """(roofline of the dominant priced kernel, all rooflines) from the profiler's records of a timed region.
+    ``kept``: per step (the records' tags) the rows a launch under a device-side sample count PROCESSED -- such a call is
+    made with the marched capacity and the kernel reads the kept count when it runs: the step's num_samples_per_batch,
+    known to the host after the region.  ``pmc_state``: which committed counter pass belongs to this state of the run
+    ("headline": profiles/pmc/latest.json; "steady_full" / "steady_open_window" / "steady_compact":
+    profiles/pmc/r05_<state>.json) -- counters need passes of their own, `traffic` is theirs, never this run's."""
+    work = {}
+    for (name, st, en, ints), (tag, counted) in zip(records, tags):
+        if counted and tag is not None and 0 <= tag < len(kept):
+            ints = list(ints)
+            ints[1 if name.startswith("nsx_mlp_") else 0] = kept[tag]      # (the MLP calls lead with n_hidden_mats)
+        bound, w = kernel_model(name, ints, H, total_entries)
+        if bound:
+            d = work.setdefault(name, {"bound": bound, "work": 0.0})
+            d["work"] += w
+    rooflines = {}
+    for name, d in work.items():
+        p = prof[name]
+        per_launch = d["work"] / p["calls"]
+        if d["bound"] == "hbm":
+            ach = per_launch / (p["avg_ms"] * 1e-3) / 1e9
+            rooflines[name] = {"bound": "hbm", "kernel": name, "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS,
+                               "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": None,
+                               "avg_launch_ms": round(p["avg_ms"], 4), "launches": p["calls"],
+                               "algorithmic_bytes_per_launch": per_launch}
+            if ach > HBM_PEAK_GBPS:
+                # ray-ordered samples: the coarse levels are served from L2 / Infinity Cache, so the algorithmic
+                # byte count is not HBM traffic here -- not a roofline fraction (see kernels_alone for one)
+                rooflines[name]["frac"] = None
+                rooflines[name]["note"] = ("algorithmic bytes per second exceed the HBM peak: cache hits on "
+                                           "ray-coherent samples; the HBM-roofline fraction of this kernel is "
+                                           "kernels_alone's (uniform samples)")
+        else:
+            ach = per_launch / (p["avg_ms"] * 1e-3) / 1e12
+            rooflines[name] = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS,
+                               "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                               "avg_launch_ms": round(p["avg_ms"], 4), "launches": p["calls"],
+                               "algorithmic_flops_per_launch": per_launch}
+            if name in ("nsx_deform_fwd", "nsx_deform_fwd_rows") and side_stream:
+                # most of its launches (the sigma_fn pass of the NEXT step) run beside the table optimizer's 12 GB
+                # pass on the other stream, 3-5x slower than alone and off the critical path: a duration measured
+                # while co-running says nothing about the kernel
+                rooflines[name]["note"] = ("launched beside the table optimizer's stream (off the critical path): "
+                                           "this duration is a co-scheduling figure; the kernel's own fraction is "
+                                           "kernels_alone's")
+    # the dominant kernel = the modelled kernel with the largest total time in the timed region; kernels whose totals
+    # are within 5 % of it are named beside it (in the benchmark window the hash backward is as large as the optimizer)
+    priced = [k for k in rooflines if rooflines[k]["frac"] is not None]
+    dom_name = max(priced, key=lambda k: prof[k]["total_ms"]) if priced else None
+    roofline = dict(rooflines[dom_name]) if dom_name else None
+    if roofline:
+        top = prof[dom_name]["total_ms"]
+        roofline["total_ms_in_region"] = round(top, 3)
+        roofline["co_dominant"] = [
+            {"kernel": k, "total_ms_in_region": round(prof[k]["total_ms"], 3), "frac": rooflines[k]["frac"],
+             "avg_launch_ms": rooflines[k]["avg_launch_ms"], "bound": rooflines[k]["bound"]}
+            for k in sorted(rooflines, key=lambda k: -prof[k]["total_ms"])
+            if k != dom_name and prof[k]["total_ms"] >= 0.95 * top]
+    pmc_path = {"headline": os.path.join(ROOT, "profiles", "pmc", "latest.json")}.get(
+        pmc_state, os.path.join(ROOT, "profiles", "pmc", f"r05_{pmc_state}.json") if pmc_state else None)
+    if roofline and pmc_path and os.path.exists(pmc_path):
+        try:
+            pmc_doc = json.load(open(pmc_path))
+            pmc = pmc_doc.get("per_launch_hbm_bytes", {})
+            for r in [roofline] + roofline["co_dominant"]:
+                if r["kernel"] in pmc:
+                    # NOT a counter of this run: the committed rocprofv3 --pmc passes of this command in this state
+                    # (counters need their own passes; gpurun refuses --pmc together with tracing)
+                    r["traffic"] = pmc[r["kernel"]]
+                    r["traffic_source"] = os.path.relpath(pmc_path, ROOT) + " <- " + str(pmc_doc.get("source", "?"))
+        except Exception:
+            pass
+    return roofline, rooflines
+
+
+def steady_state(trainer, data, first_step: int, settle_at: int, rays: int, n_timed: int = 100, datamanager=None,
+                 H: int = 0, pmc_state=None, n_profiled: int = 20):
     """Continues the run to step `settle_at` (untimed), then times `n_timed` steps: by then the occupancy grid and the
     visibility pruning have settled and every step sees about the same number of samples.  `datamanager`: draw every
-    batch inside the timed loop through its `next_train` instead of pre-generating them."""
+    batch inside the timed loop through its `next_train` instead of pre-generating them.
+    `H` > 0: `n_profiled` MORE steps follow with HIP events around every priced native call (not inside the timed steps:
+    the events cost ~0.08 ms per step) -- the regime's own `roofline` / `rooflines`, with `traffic` from the committed
+    counter pass of this state (`pmc_state`)."""
     import gc
     src = datamanager if datamanager is not None else data
     step = first_step
@@ -164,9 +246,37 @@ def steady_state(trainer, data, first_step: int, settle_at: int, rays: int, n_ti
     trainer.flush_scheduler_step()
     counts = [int(c) for c in counts]
     samples = sum(counts)
-    return {"from_step": step, "steps": n_timed, "ms_per_step": dt / n_timed * 1e3, "value": samples / dt,
-            "unit": "ray-samples/s", "rays_per_sec": rays * n_timed / dt, "samples_per_step_min_max": [min(counts), max(counts)],
-            "psnr": float(metrics["psnr"].detach())}
+    out = {"from_step": step, "steps": n_timed, "ms_per_step": dt / n_timed * 1e3, "value": samples / dt,
+           "unit": "ray-samples/s", "rays_per_sec": rays * n_timed / dt, "samples_per_step_min_max": [min(counts), max(counts)],
+           "psnr": float(metrics["psnr"].detach())}
+    if H > 0 and datamanager is None and n_profiled > 0:
+        from nersemble_amd import _lib
+        prof = _lib.profiler
+        more = [data.next_train(step + n_timed + i) for i in range(n_profiled + 1)]
+        prof.prewarm(2 * 16 * n_profiled + 64)
+        torch.cuda.synchronize()
+        prof.reset()
+        prof.enabled = True
+        kept = []
+        for i in range(n_profiled):
+            prof.tag = i
+            _, _, m = trainer.train_iteration(step + n_timed + i, *more[i], next_ray_bundle=more[i + 1][0])
+            kept.append(m["num_samples_per_batch"])
+        torch.cuda.synchronize()
+        prof.enabled, prof.tag = False, None
+        trainer.flush_scheduler_step()
+        prof.collect_native()
+        kept = [int(c) for c in kept]
+        total_entries = trainer.model.field.hash_ensemble.geom.total_entries
+        summary = prof.summary()
+        roofline, rooflines = compute_rooflines(summary, prof.records, prof.tags, kept, H, total_entries,
+                                                trainer._opt_stream is not None, pmc_state)
+        out["roofline"] = roofline
+        out["rooflines"] = {k: {"frac": v["frac"], "avg_launch_ms": v["avg_launch_ms"], "bound": v["bound"],
+                                "total_ms": round(summary[k]["total_ms"], 3)} for k, v in rooflines.items()}
+        out["profiled_steps"] = n_profiled
+        prof.reset()
+    return out
 
 
 def steady_state_ranks(trainer, data, first_step: int, settle_at: int, rays: int, world: int, dev, backend: str,
@@ -446,6 +556,16 @@ def kernels_alone(trainer, H: int, log2_s: int = 20, iters: int = 10):
             check(lib().nsx_deform_fwd(ptr(packed), ptr(pos), S, aabb6, ptr(dcode_t), dcode_t.stride(0), ptr(slot), w7,
                                        ptr(off), None, stream()), "nsx_deform_fwd")
         entry("nsx_deform_fwd", timeit(dfwd), "mfma", S * DEFORM_FWD_FLOPS)
+        out["nsx_deform_fwd"]["note"] = "the per-sample-code operator (11 K-steps in the input GEMMs); the model's forwards take nsx_deform_fwd_rows"
+        terms = torch.empty((int(lib().nsx_deform_terms_floats(T)),), device=dev)
+
+        def dfwd_rows():
+            check(lib().nsx_deform_fwd_rows(ptr(packed), ptr(pos), S, aabb6, ptr(dcode_t), dcode_t.stride(0), ptr(slot), T, w7,
+                                            ptr(off), ptr(terms), None, stream()), "nsx_deform_fwd_rows")
+        entry("nsx_deform_fwd_rows", timeit(dfwd_rows), "mfma", S * DEFORM_FWD_FLOPS)
+        out["nsx_deform_fwd_rows"]["note"] = ("codes are rows of a table (every forward of the model): code columns summed per "
+                                              "row first, 192 of 256 MFMAs per tile; priced in the FLOPs of the reference's "
+                                              "eight Linear layers")
         goff = torch.randn((S, 3), device=dev, generator=gen)
         gparams = torch.zeros(int(lib().nsx_deform_param_count()), device=dev)
         gtable = torch.zeros_like(dcode_t)
@@ -669,7 +789,7 @@ def main():
                            "nsx_hash_ensemble_bwd_codesum",
                            "nsx_hash_ensemble_bwd_scatter",
                            "nsx_adam_hash_factored", "nsx_adam_hash_factored_consume", "nsx_adam_dense",
-                           "nsx_deform_fwd", "nsx_deform_bwd",
+                           "nsx_deform_fwd", "nsx_deform_fwd_rows", "nsx_deform_bwd",
                            "nsx_mlp_fwd", "nsx_mlp_bwd", "nsx_check_finite", "nsx_march_fill",
                            "nsx_hash_grad_expand", "nsx_hash_grad_expand_f16", "nsx_adam_dense_f16grad",
                            "nsx_check_finite_f16"}
@@ -754,67 +874,11 @@ def main():
         _lib.profiler.collect_native()          # the kernel calls the native step drivers made (their own HIP events)
         prof = _lib.profiler.summary()
         total_entries = trainer.model.field.hash_ensemble.geom.total_entries
-        work = {}
-        # rows a launch PROCESSED: under a device-side sample count (the n_device argument) the call is made with the
-        # marched capacity and the kernel reads the kept count when it runs -- that count is the step's
-        # num_samples_per_batch, known to the host after the timed region
         kept = [int(c) for _, c in step_marks]
-        for (name, st, en, ints), (tag, counted) in zip(_lib.profiler.records, _lib.profiler.tags):
-            if counted and tag is not None and tag < len(kept):
-                ints = list(ints)
-                ints[1 if name.startswith("nsx_mlp_") else 0] = kept[tag]      # (the MLP calls lead with n_hidden_mats)
-            bound, w = kernel_model(name, ints, H, total_entries)
-            if bound:
-                d = work.setdefault(name, {"bound": bound, "work": 0.0})
-                d["work"] += w
-        rooflines = {}
-        for name, d in work.items():
-            p = prof[name]
-            per_launch = d["work"] / p["calls"]
-            if d["bound"] == "hbm":
-                ach = per_launch / (p["avg_ms"] * 1e-3) / 1e9
-                rooflines[name] = {"bound": "hbm", "kernel": name, "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS,
-                                   "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": None,
-                                   "avg_launch_ms": round(p["avg_ms"], 4), "launches": p["calls"],
-                                   "algorithmic_bytes_per_launch": per_launch}
-                if ach > HBM_PEAK_GBPS:
-                    # ray-ordered samples: the coarse levels are served from L2 / Infinity Cache, so the algorithmic
-                    # byte count is not HBM traffic here -- not a roofline fraction (see kernels_alone for one)
-                    rooflines[name]["frac"] = None
-                    rooflines[name]["note"] = ("algorithmic bytes per second exceed the HBM peak: cache hits on "
-                                               "ray-coherent samples; the HBM-roofline fraction of this kernel is "
-                                               "kernels_alone's (uniform samples)")
-            else:
-                ach = per_launch / (p["avg_ms"] * 1e-3) / 1e12
-                rooflines[name] = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS,
-                                   "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": None,
-                                   "avg_launch_ms": round(p["avg_ms"], 4), "launches": p["calls"],
-                                   "algorithmic_flops_per_launch": per_launch}
-                if name == "nsx_deform_fwd" and trainer._opt_stream is not None:
-                    # most of its launches (the sigma_fn pass of the NEXT step) run beside the table optimizer's 12 GB
-                    # pass on the other stream, 3-5x slower than alone and off the critical path: a duration measured
-                    # while co-running says nothing about the kernel
-                    rooflines[name]["note"] = ("launched beside the table optimizer's stream (off the critical path): "
-                                               "this duration is a co-scheduling figure; the kernel's own fraction is "
-                                               "kernels_alone's")
-        # the dominant kernel = the modelled kernel with the largest total time in the timed region
-        priced = [k for k in rooflines if rooflines[k]["frac"] is not None]
-        dom_name = max(priced, key=lambda k: prof[k]["total_ms"]) if priced else None
-        roofline = dict(rooflines[dom_name]) if dom_name else None
-        pmc_path = os.path.join(ROOT, "profiles", "pmc", "latest.json")
-        # the committed counter passes were taken on the default workload at one rank: their per-launch bytes say
-        # nothing about another table size / sample count, so any other run reports traffic = null
-        if roofline and os.path.exists(pmc_path) and a.workload == "p030_h32" and world == 1:
-            try:
-                pmc_doc = json.load(open(pmc_path))
-                pmc = pmc_doc.get("per_launch_hbm_bytes", {})
-                if dom_name in pmc:
-                    # NOT a counter of this run: the committed rocprofv3 --pmc passes of this command (counters need
-                    # their own passes; gpurun refuses --pmc together with tracing)
-                    roofline["traffic"] = pmc[dom_name]
-                    roofline["traffic_source"] = "profiles/pmc/latest.json <- " + str(pmc_doc.get("source", "?"))
-            except Exception:
-                pass
+        pmc_state = "headline" if (a.workload == "p030_h32" and world == 1 and a.preroll == 0 and a.window_hash is None
+                                   and not a.compact_first_grid) else None
+        roofline, rooflines = compute_rooflines(prof, _lib.profiler.records, _lib.profiler.tags, kept, H, total_entries,
+                                                trainer._opt_stream is not None, pmc_state)
         kernels = {k: {"calls": v["calls"], "total_ms": round(v["total_ms"], 3), "avg_ms": round(v["avg_ms"], 4)}
                    for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])}
         out = {
@@ -862,8 +926,13 @@ def main():
                 "note": "next_train(step) is called inside the timed loop, one call per step, for the NEXT step's batch "
                         "(its ray bundle is handed to train_iteration as next_ray_bundle)"}
         if a.steady_after > 0 and world == 1:
+            state = None
+            if a.workload == "p030_h32" and a.preroll == 0:
+                state = ("steady_compact" if a.compact_first_grid else
+                         "steady_open_window" if (a.window_hash and tuple(a.window_hash) == (0, 1)) else
+                         "steady_full" if a.window_hash is None else None)
             out["steady_state"] = steady_state(trainer, data, a.preroll + a.warmup + a.steps, a.steady_after, info["rays"],
-                                               datamanager=dm)
+                                               datamanager=dm, H=0 if a.no_kernel_events else H, pmc_state=state)
         if steady_ranks is not None:
             out["steady_state"] = steady_ranks
         spp = [p["samples"] for p in out["per_step"]]

@@ -42,7 +42,7 @@ __global__ __launch_bounds__(MLP_WAVES * kWave) void mlp_fwd_kernel(const half_t
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n = lane & 31, kb = lane >> 5;
-    const bool fast = io.a_dim == 0 && io.b_off == 0 && io.b_dim == MLP_IN && (io.b_stride % 8) == 0;
+    const int fast = input_mode(io);
     // the two 4-neuron runs a lane holds leave as two 8-byte stores when the whole 16-wide row is wanted (mlp_base)
     const bool wide_out = n_out == MLP_OUT && out_act == 0 && (out_stride % 4) == 0 &&
                           (reinterpret_cast<uintptr_t>(out) & 7) == 0;
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(MLP_WAVES * kWave) void mlp_bwd_kernel(
     stage_weights<NH>(W, tbase, frags, true);          // (the tile region doubles as the staging buffer: unused until the sync)
     __syncthreads();
     const int n = lane & 31, kb = lane >> 5;
-    const bool fast = io.a_dim == 0 && io.b_off == 0 && io.b_dim == MLP_IN && (io.b_stride % 8) == 0;
+    const int fast = input_mode(io);
 
     // weight-gradient accumulators (D[o][i] tiles): Wo: 1x2, Wh: 2x2, W0: 2x1
     f32x16 gWo[2], gWh[2][2], gW0[2];

@@ -170,11 +170,48 @@ __device__ __forceinline__ half_t input_elem(const MlpIO& io, int64_t b, int k) 
     return (half_t)0.f;
 }
 
-__device__ __forceinline__ void load_input(const MlpIO& io, int64_t b, int kb, bool fast, f16x8 x[2]) {
-    if (fast) {
+// how the input fragments are read: 1 = the whole 32-wide fp16 row (mlp_base: hash features), 2 = mlp_head's
+// [(d + 1) / 2 (3 fp32), mlp_base's row without its first column (15 fp16)] from two 16-byte loads of the 16-wide row
+// + three floats, 0 = element by element (any other layout)
+__device__ __forceinline__ int input_mode(const MlpIO& io) {
+    if (io.a_dim == 0 && io.b_off == 0 && io.b_dim == MLP_IN && (io.b_stride % 8) == 0 &&
+        (reinterpret_cast<uintptr_t>(io.b) & 15) == 0) return 1;
+    if (io.a_dim == 3 && io.b_off == 1 && io.b_dim == 15 && io.b_stride == 16 && (reinterpret_cast<uintptr_t>(io.b) & 15) == 0)
+        return 2;
+    return 0;
+}
+
+__device__ __forceinline__ void load_input(const MlpIO& io, int64_t b, int kb, int mode, f16x8 x[2]) {
+    if (mode == 1) {
         const f16x8* row = reinterpret_cast<const f16x8*>(io.b + b * io.b_stride);
         x[0] = row[kb];
         x[1] = row[2 + kb];
+    } else if (mode == 2) {
+        // input k: 0..2 = a * a_mul + a_add, 3..17 = row[1..15], 18..31 = 0;  lane kb holds k = 16 t + 8 kb + j
+        const f16x8* row = reinterpret_cast<const f16x8*>(io.b + b * 16);
+        const f16x8 r0 = row[0], r1 = row[1];
+        f16x8 z;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) z[j] = (half_t)0.f;
+        if (kb == 0) {
+            const float* a = io.a + b * io.a_stride;
+            f16x8 v = z;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) v[j] = (half_t)__fmaf_rn(a[j], io.a_mul, io.a_add);
+#pragma unroll
+            for (int j = 3; j < 8; ++j) v[j] = r0[j - 2];
+            x[0] = v;
+            f16x8 w = z;
+            w[0] = r1[6]; w[1] = r1[7];
+            x[1] = w;
+        } else {
+            f16x8 v;
+            v[0] = r0[6]; v[1] = r0[7];
+#pragma unroll
+            for (int j = 2; j < 8; ++j) v[j] = r1[j - 2];
+            x[0] = v;
+            x[1] = z;
+        }
     } else {
 #pragma unroll
         for (int t = 0; t < 2; ++t)

@@ -104,7 +104,8 @@ class LevelParallel:
         return out.view(self.world_size, len(values)).tolist()
 
     def _all_gather(self, out: torch.Tensor, mine: torch.Tensor) -> None:
-        dist.all_gather_into_tensor(out, mine.contiguous(), group=self.group)
+        # (flat views: gloo's all-gather compares the shard of the output with the input shape by shape)
+        dist.all_gather_into_tensor(out.view(-1), mine.contiguous().view(-1), group=self.group)
         self.stats["bytes_in"] += (self.world_size - 1) * mine.numel() * mine.element_size()
 
     def _all_to_all(self, out: torch.Tensor, inp: torch.Tensor) -> None:
@@ -117,7 +118,7 @@ class LevelParallel:
             dist.all_to_all_single(out.view(-1), inp.view(-1), group=self.group)
         else:
             full = torch.empty((W,) + tuple(inp.shape), dtype=inp.dtype, device=inp.device)
-            dist.all_gather_into_tensor(full, inp, group=self.group)
+            dist.all_gather_into_tensor(full.view(-1), inp.view(-1), group=self.group)
             out.copy_(full[:, self.rank])
         self.stats["bytes_in"] += (W - 1) * (inp.numel() // W) * inp.element_size()
 

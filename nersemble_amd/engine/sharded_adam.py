@@ -155,6 +155,12 @@ class ShardedTableAdam(torch.optim.Optimizer):
         # then runs beside the deformation field's backward (which comes later in the graph) instead of after it
         self._early = None            # handle of a reduce-scatter already started for this step ("done" = finished)
         self._comm_stream = None
+        # narrow phases (exchange width W < H): fp32 master and both moments of the W active grids of this rank's entries
+        # as CONTIGUOUS [entries][2][W] arrays -- the shard's Adam is then a dense pass over W / H of the bytes instead of
+        # one 4 W-byte run per 128-byte line of the full layout (1.65 ms at W = 1 on a half-table shard: as long as the
+        # full-width pass).  Written back into the full-layout shard when the width changes and before anybody reads it
+        # (gather_master / table_state); the same adam_update on the same values: bit-identical.
+        self._compact = None
         if overlap_reduce:
             hash_ensemble.grad_sink.on_complete = self._start_reduce
 
@@ -226,6 +232,39 @@ class ShardedTableAdam(torch.optim.Optimizer):
 
     def _master_shard(self) -> torch.Tensor:
         return self.he.tables.data.reshape(-1)[self.lo:self.lo + self.n_local]
+
+    # ---- compact state of the narrow phases ---------------------------------------------------------------------------
+    def _full_views(self):
+        """This rank's master / exp_avg / exp_avg_sq in the full layout as [local entries][2][Hp] views."""
+        b = self._buffers()
+        e = self.n_local // (2 * self.Hp)
+        return [t[:e * 2 * self.Hp].view(e, 2, self.Hp) for t in (self._master_shard(), b["exp_avg"], b["exp_avg_sq"])]
+
+    def _sync_compact(self) -> None:
+        """Write the compact arrays back into the full-layout shard (they stay the working state)."""
+        c = self._compact
+        if c is None:
+            return
+        W = c["W"]
+        for full, key in zip(self._full_views(), ("master", "exp_avg", "exp_avg_sq")):
+            full[:, :, :W].copy_(c[key].view(full.shape[0], 2, W))
+
+    def _compact_state(self, W: int) -> dict:
+        """The contiguous fp32 state of grids [0, W) of this rank's entries; cut from the full layout on first use and
+        handed over (written back, cut again) whenever the width changes."""
+        c = self._compact
+        if c is not None and c["W"] == W:
+            return c
+        self._sync_compact()
+        views = self._full_views()
+        self._compact = c = {"W": W}
+        for full, key in zip(views, ("master", "exp_avg", "exp_avg_sq")):
+            c[key] = full[:, :, :W].contiguous().view(-1)
+        return c
+
+    def _leave_compact(self) -> None:
+        self._sync_compact()
+        self._compact = None
 
     # ---- step, in the two phases the trainer runs for every optimizer ----------------------------------------------
     @torch.no_grad()
@@ -395,6 +434,7 @@ class ShardedTableAdam(torch.optim.Optimizer):
         W = self._exchange_width()
         self._mark("adam_begin")
         if W == self.Hp:
+            self._leave_compact()
             if self.n_local > 0:
                 self.ops.adam_f16grad(b["grad_shard"], self.n_local, self._master_shard(), b["exp_avg"], b["exp_avg_sq"],
                                       b["f16"][self.lo:self.lo + self.shard], group["lr"], b1, b2, group["eps"], self._step,
@@ -407,9 +447,12 @@ class ShardedTableAdam(torch.optim.Optimizer):
             packed = self._packed(W)
             mine = packed[self.rank * se * 2 * W:(self.rank + 1) * se * 2 * W]
             if self.n_local > 0:
-                self.ops.adam_f16grad_width(b["grad_shard"], self.n_local // per_entry, W, self.Hp, self._master_shard(),
-                                            b["exp_avg"], b["exp_avg_sq"], b["f16"][self.lo:self.lo + self.shard], mine,
-                                            group["lr"], b1, b2, group["eps"], self._step, inv_scale, found_inf)
+                # dense Adam over the compact [entries][2][W] state; its fp16 output IS this rank's packed piece of the
+                # all-gather (the full-layout working tables take every rank's values from unpack_width below)
+                c = self._compact_state(W)
+                n_c = (self.n_local // per_entry) * 2 * W
+                self.ops.adam_f16grad(b["grad_shard"][:n_c], n_c, c["master"], c["exp_avg"], c["exp_avg_sq"], mine[:n_c],
+                                      group["lr"], b1, b2, group["eps"], self._step, inv_scale, found_inf)
             self._mark("adam_end")
             dist.all_gather_into_tensor(packed, mine, group=self.group)
             self.ops.unpack_width(packed, self.n // per_entry, W, self.Hp, b["f16"])
@@ -482,6 +525,7 @@ class ShardedTableAdam(torch.optim.Optimizer):
     # ---- checkpointing ------------------------------------------------------------------------------------------
     def _gather_shards(self, mine_local: torch.Tensor) -> torch.Tensor:
         """All ranks' shards of one fp32 per-parameter array -> the full array, shaped like ``tables``."""
+        self._sync_compact()
         p = self.he.tables
         full = torch.zeros((self.shard * self.world_size,), dtype=torch.float32, device=p.device)
         mine = full[self.lo:self.lo + self.shard]
@@ -503,6 +547,7 @@ class ShardedTableAdam(torch.optim.Optimizer):
     def load_table_state(self, state: dict) -> None:
         self.he.wait_tables()
         b = self._buffers()
+        self._compact = None                         # (what is loaded replaces the full-layout state)
         self._step = int(state["step"])
         self._max_width = self.Hp if self._step > 0 else 0           # (which grids hold moments is not recorded)
         self.param_groups[0]["lr"] = float(state.get("lr", self.param_groups[0]["lr"]))
@@ -520,6 +565,7 @@ class ShardedTableAdam(torch.optim.Optimizer):
     def gather_master(self) -> None:
         """Rebuild the full fp32 master tables on every rank from the shards (call before ``state_dict()``)."""
         self.he.wait_tables()                    # a step may still be running on the optimizer stream
+        self._sync_compact()
         p = self.he.tables
         full = torch.zeros((self.shard * self.world_size,), dtype=torch.float32, device=p.device)
         mine = full[self.lo:self.lo + self.shard]

@@ -476,3 +476,63 @@ def test_global_loss_normalisers_world2_equal_the_union_batch(tmp_path):
     h0, c0, _ = _loss_terms(d, torch.arange(R // 2), torch.nonzero(d["ray_of"] < R // 2)[:, 0])
     h1, c1, _ = _loss_terms(d, torch.arange(R // 2, R), torch.nonzero(d["ray_of"] >= R // 2)[:, 0])
     assert not torch.allclose((h0.sum() + h1.sum()) / 2, loss.detach(), rtol=1e-3)
+
+
+# ---- level-parallel exchange (engine/level_parallel.py): the collectives' plumbing on CPU tensors --------------------------
+def _lp_plumbing_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from types import SimpleNamespace
+    from nersemble_amd import _lib
+    from nersemble_amd.engine.level_parallel import LevelParallel, sub_geometry
+    geom = _lib.grid_geometry(n_levels=8, per_level_scale=1.5, base_resolution=4, log2_hashmap_size=9)
+    he = SimpleNamespace(geom=geom, n_hash_encodings=4)
+    lp = LevelParallel(he, world, rank)
+    ok = lp.n_own == 4 and lp.first_level == 4 * rank and lp.e0 == int(geom.offset[4 * rank])
+    ok &= lp.entry_ranges[0][1] == lp.entry_ranges[1][0] and lp.entry_ranges[1][1] == geom.total_entries
+    # sub-geometry: the owned levels, offsets re-based to the range's first entry
+    sg = sub_geometry(geom, 4 * rank, 4)
+    for i in range(4):
+        l = 4 * rank + i
+        ok &= sg.scale[i] == geom.scale[l] and sg.res[i] == geom.res[l] and sg.size[i] == geom.size[l]
+        ok &= sg.hashed[i] == geom.hashed[l] and sg.offset[i] == geom.offset[l] - geom.offset[4 * rank]
+    ok &= sg.total_entries == lp.n_entries
+    # ragged sample sets: rank 0 has 5 samples and 2 code rows, rank 1 has 3 samples and 3 code rows
+    S, rows = (5, 2) if rank == 0 else (3, 3)
+    x = torch.arange(S * 3, dtype=torch.float32).reshape(S, 3) + 100 * rank
+    slot = (torch.arange(S, dtype=torch.int32) % rows) + 7 * rank
+    code = torch.arange(rows * 4, dtype=torch.float32).reshape(rows, 4) + 1000 * rank
+    sizes, S_cap, xs, slots, codes = lp._gather_samples(x, slot, code)
+    ok &= sizes == [[5, 2], [3, 3]] and S_cap == 5
+    for j, (Sj, rj) in enumerate(sizes):
+        ok &= torch.equal(xs[j], torch.arange(Sj * 3, dtype=torch.float32).reshape(Sj, 3) + 100 * j)
+        ok &= torch.equal(slots[j], (torch.arange(Sj, dtype=torch.int32) % rj) + 7 * j)
+        ok &= torch.equal(codes[j], torch.arange(rj * 4, dtype=torch.float32).reshape(rj, 4) + 1000 * j)
+    # all-to-all of equal blocks: out[j] = rank j's inp[this rank]
+    inp = torch.stack([torch.full((S_cap, 2), float(10 * rank + k)) for k in range(world)])
+    out = torch.empty_like(inp)
+    lp._all_to_all(out, inp)
+    for j in range(world):
+        ok &= bool((out[j] == 10 * j + rank).all())
+    # an empty rank takes part
+    sizes2, cap2, xs2, _, _ = lp._gather_samples(x[:0] if rank == 1 else x, slot[:0] if rank == 1 else slot, code)
+    ok &= sizes2[1][0] == 0 and cap2 == 5 and xs2[1].shape == (0, 3) and torch.equal(xs2[0][:, 0], x[:, 0] if rank == 0 else xs2[0][:, 0])
+    # every rank's entry range becomes current everywhere
+    full = torch.full((geom.total_entries, 2, 4), float(rank + 1))
+    lp.gather_entry_ranges(full)
+    a, b = lp.entry_ranges
+    ok &= bool((full[a[0]:a[1]] == 1).all()) and bool((full[b[0]:b[1]] == 2).all())
+    ok &= lp.stats["bytes_in"] > 0
+    torch.save({"ok": bool(ok)}, os.path.join(out_dir, f"lp{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_level_parallel_exchange_plumbing_world2(tmp_path):
+    """The collectives of the level-parallel HashEnsemble on CPU tensors over gloo: level ownership and sub-geometries,
+    the ragged all-gather of (positions, code slots, code rows), the block all-to-all (gloo stand-in), an empty rank, the
+    broadcast of the ranks' entry ranges.  The kernels between them run on the GPU (tests/test_sharded_gpu.py)."""
+    port = _free_port()
+    mp.spawn(_lp_plumbing_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert torch.load(tmp_path / "lp0.pt")["ok"] and torch.load(tmp_path / "lp1.pt")["ok"]

@@ -19,7 +19,7 @@ from nersemble_amd.field_components.deformation_field import SE3DeformationField
 
 PEAK_TFLOPS = 2500.0          # dense fp16 MFMA peak of one MI355X (MI355X_MICROARCH.md)
 # backward kernels recompute the forward: forward + dX chain + weight gradients = 3 x the forward's FLOPs (bench.py's model)
-FLOP = {"deform_fwd": 253_952, "deform_bwd": 3 * 253_952, "mlp_fwd_base": 6_144, "mlp_bwd_base": 3 * 6_144,
+FLOP = {"deform_fwd": 253_952, "deform_fwd_general": 253_952, "deform_bwd": 3 * 253_952, "mlp_fwd_base": 6_144, "mlp_bwd_base": 3 * 6_144,
         "mlp_fwd_head": 14_336, "mlp_bwd_head": 3 * 14_336}
 
 
@@ -67,7 +67,14 @@ def main():
     def deform_bwd():
         off.backward(g, retain_graph=True)
 
-    fns["deform_fwd"], fns["deform_bwd"] = deform_fwd, deform_bwd
+    codes_per_sample = table.detach()[slot.long()].contiguous()
+
+    def deform_fwd_general():             # the per-sample-code operator: nsx_deform_fwd (11 K-steps in the input GEMMs)
+        with torch.no_grad():
+            df.compute_offsets(pos, codes_per_sample, 3.5)
+
+    # deform_fwd: codes are rows of a table -> nsx_deform_fwd_rows (the model's route; priced in the general kernel's FLOPs)
+    fns["deform_fwd"], fns["deform_fwd_general"], fns["deform_bwd"] = deform_fwd, deform_fwd_general, deform_bwd
     for nh, name in ((0, "base"), (1, "head")):
         w = (torch.randn(F.mlp_param_count(nh), device=dev) * 0.1).half()
         dW = torch.zeros(w.numel(), device=dev)

@@ -20,6 +20,8 @@ ENTRY_OF = {            # kernel-name prefix -> C-ABI entry point it belongs to
     "nsx::deform_bwd_kernel": "nsx_deform_bwd",
     "nsx::deform_wgrad_kernel": "nsx_deform_bwd",
     "nsx::deform_fwd_kernel": "nsx_deform_fwd",
+    "nsx::deform_fwd_terms_kernel": "nsx_deform_fwd_rows",
+    "nsx::density_fused_kernel": "nsx_density_fused_fwd",
 }
 
 
@@ -32,6 +34,10 @@ def kernel_base_name(raw):
     return raw.split("(")[0].replace("void ", "").split("<")[0].strip()
 
 
+LAST = int(os.environ.get("PMC_LAST_DISPATCHES", "0"))      # > 0: only the last N dispatches of every kernel (a run that
+#                                                              settles first: the pre-roll's dispatches are another state)
+
+
 def means(directory, counter):
     acc = collections.defaultdict(list)
     for path in glob.glob(os.path.join(directory, "**", "*counter_collection.csv"), recursive=True):
@@ -40,8 +46,15 @@ def means(directory, counter):
                 if r["Counter_Name"] != counter:
                     continue
                 name = kernel_base_name(r["Kernel_Name"])
-                acc[name].append(float(r["Counter_Value"]))
-    return {k: {"mean_kb": sum(v) / len(v), "dispatches": len(v)} for k, v in acc.items()}
+                acc[name].append((int(r.get("Dispatch_Id", 0) or 0), float(r["Counter_Value"])))
+    out = {}
+    for k, rows in acc.items():
+        if LAST > 0:
+            keep = set(sorted({d for d, _ in rows})[-LAST:])
+            rows = [r for r in rows if r[0] in keep]
+        v = [x for _, x in rows]
+        out[k] = {"mean_kb": sum(v) / len(v), "dispatches": len({d for d, _ in rows})}
+    return out
 
 
 def main():
