@@ -574,8 +574,11 @@ constexpr int TERM_ROW = 2 * DFW;               // floats per code row: T0 | T4
 constexpr int TERM_STRIDE = TERM_ROW + 4;       // LDS row stride (lanes of one instruction read different rows at one offset)
 constexpr int TERM_LDS_ROWS = 64;               // = NSX_MAX_SLOTS: every batch table fits
 
-__global__ __launch_bounds__(DFW) void deform_code_terms_kernel(const f16x8* __restrict__ frags, const float* __restrict__ code,
-                                                               int64_t code_stride, int n_rows, float* __restrict__ terms) {
+// terms[row] = T0 + b0 | T4 + b4: the value the accumulators of the two input layers start from (the same fp32 add the forward
+// kernel made per tile in round 4, made once per row here)
+__global__ __launch_bounds__(DFW) void deform_code_terms_kernel(const f16x8* __restrict__ frags, const float* __restrict__ bias,
+                                                               const float* __restrict__ code, int64_t code_stride, int n_rows,
+                                                               float* __restrict__ terms) {
     const int row = blockIdx.x >> 1, which = blockIdx.x & 1, n = threadIdx.x;
     if (row >= n_rows) return;
     const half_t* f16 = reinterpret_cast<const half_t*>(frags);
@@ -587,7 +590,7 @@ __global__ __launch_bounds__(DFW) void deform_code_terms_kernel(const f16x8* __r
         const float c = (float)(half_t)code[(int64_t)row * code_stride + (k - DF_PE)];
         acc = __fmaf_rn(w, c, acc);
     }
-    terms[(int64_t)row * TERM_ROW + which * DFW + n] = acc;
+    terms[(int64_t)row * TERM_ROW + which * DFW + n] = bias[(which ? 4 : 0) * DFW + n] + acc;
 }
 
 template <bool LDS_TERMS>
@@ -598,65 +601,103 @@ struct DeformLdsT {
 };
 static_assert(sizeof(DeformLdsT<true>) <= 160 * 1024, "the forward's LDS block must fit the CU's 160 KB");
 
-// the first TERM_KSTEPS input fragments of sample b (build_input's first loop); `crow`: the sample's code row
+// the first TERM_KSTEPS input fragments of sample b (build_input's first loop); `crow`: the sample's code row.
+// Element (t, j) of lane half kb is input column k = 16 t + 8 kb + j: the two candidates k0 = 16 t + j (kb = 0) and k0 + 8 are
+// compile-time, so the lane selects the ARGUMENT (axis, frequency, phase, window weight) and evaluates ONE v_sin per element --
+// build_input evaluates both candidates and selects the value: twice the quarter-rate transcendentals for the same numbers.
 __device__ __forceinline__ void build_input_head(const DeformArgs& A, int64_t b, int kb, const float* crow, float pn[3],
                                                  f16x8 x[TERM_KSTEPS]) {
 #pragma unroll
     for (int d = 0; d < 3; ++d) pn[d] = (A.pos[b * 3 + d] - A.aabb_min[d]) / A.aabb_ext[d];
-    auto pe_value = [&](int k) -> float {
-        if (k < 42) {
-            const int kk = k < 21 ? k : k - 21;
-            const int d = kk / 7, f = kk - 7 * d;
-            const float rev = pn[d] * (float)(1 << f) + (k >= 21 ? 0.25f : 0.f);
-            return A.window[f] * __builtin_amdgcn_sinf(rev);
-        }
-        if (k < DF_PE) return 6.283185307179586f * pn[k - 42];
-        return 0.f;
-    };
+    // the window weights as opaque scalars: a select between two loads of the by-value argument struct would be folded into ONE
+    // load with a selected (per-lane) index, and a dynamically indexed kernel argument is copied to scratch memory
+    float win[7];
+#pragma unroll
+    for (int f = 0; f < 7; ++f) {
+        float wf = A.window[f];
+        asm volatile("" : "+s"(wf));
+        win[f] = wf;
+    }
 #pragma unroll
     for (int t = 0; t < TERM_KSTEPS; ++t) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int k0 = 16 * t + j, k1 = k0 + 8;
-            float v0 = k0 < DF_PE ? pe_value(k0) : 0.f;
-            float v1 = k1 < DF_PE ? pe_value(k1) : 0.f;
-            float v = kb ? v1 : v0;
-            const int k = k0 + 8 * kb;
-            if (k1 >= DF_PE) {
-                const int kc = k - DF_PE;
-                const float cv = crow[kc < 0 ? 0 : kc];
-                if (k >= DF_PE) v = cv;
+            float v;
+            if (k1 < 42) {                                   // both candidates are windowed sines
+                const int q0 = k0 < 21 ? k0 : k0 - 21, q1 = k1 < 21 ? k1 : k1 - 21;
+                const int d0 = q0 / 7, f0 = q0 - 7 * d0, d1 = q1 / 7, f1 = q1 - 7 * d1;
+                const float p = kb ? pn[d1] : pn[d0];
+                const float sc = kb ? (float)(1 << f1) : (float)(1 << f0);
+                const float ph = kb ? (k1 >= 21 ? 0.25f : 0.f) : (k0 >= 21 ? 0.25f : 0.f);
+                const float w = kb ? win[f1] : win[f0];
+                v = w * __builtin_amdgcn_sinf(p * sc + ph);
+            } else {                                         // k0 in [32, 40): sines, the scaled inputs, the first code columns
+                auto value = [&](int k) -> float {
+                    if (k < 42) {
+                        const int q = k - 21, d = q / 7, f = q - 7 * d;
+                        return win[f] * __builtin_amdgcn_sinf(pn[d] * (float)(1 << f) + 0.25f);
+                    }
+                    if (k < DF_PE) return 6.283185307179586f * pn[k - 42];
+                    return crow[k - DF_PE];
+                };
+                const float v0 = value(k0), v1 = value(k1);
+                v = kb ? v1 : v0;
             }
             x[t][j] = (half_t)v;
         }
     }
 }
 
-// accumulators start at bias + the row's code term (TP: an LDS or a global pointer)
+// accumulators start at the row's term (bias included; TP: an LDS or a global pointer)
 template <typename TP>
-__device__ __forceinline__ void acc_init_terms(f32x16 acc[4], lds_cfloat* bias_lds, TP term, int kb) {
+__device__ __forceinline__ void acc_init_terms(f32x16 acc[4], TP term, int kb) {
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const f32x4 v = *reinterpret_cast<lds_cfloat4*>(bias_lds + 32 * mt + 8 * q + 4 * kb);
             const f32x4 tv = *reinterpret_cast<const f32x4*>(term + 32 * mt + 8 * q + 4 * kb);
-            acc[mt][4 * q + 0] = v.x + tv.x; acc[mt][4 * q + 1] = v.y + tv.y;
-            acc[mt][4 * q + 2] = v.z + tv.z; acc[mt][4 * q + 3] = v.w + tv.w;
+            acc[mt][4 * q + 0] = tv.x; acc[mt][4 * q + 1] = tv.y; acc[mt][4 * q + 2] = tv.z; acc[mt][4 * q + 3] = tv.w;
         }
 }
 
-// the first TERM_KSTEPS K-steps of an input stage ([4][DF_TIN] fragments)
-__device__ __forceinline__ void gemm_input_head(const f16x8* lds, int lane, const f16x8* in, f32x16 acc[4]) {
-    const f16x8* base = lds + lane;
+// the TERM_KSTEPS K-steps of an input stage that stay in the GEMM, copied as [4 M-tiles][TERM_KSTEPS] fragments at `local`
+__device__ __forceinline__ void gemm_input_head(const f16x8* lds, int local, int lane, const f16x8* in, f32x16 acc[4]) {
+    const f16x8* base = lds + (size_t)local * 64 + lane;
 #pragma unroll
     for (int t = 0; t < TERM_KSTEPS; ++t) {
         f16x8 a[4];
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) a[mt] = base[(mt * DF_TIN + t) * 64];
+        for (int mt = 0; mt < 4; ++mt) a[mt] = base[(mt * TERM_KSTEPS + t) * 64];
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) acc[mt] = mfma(a[mt], in[t], acc[mt]);
     }
+}
+
+// `n_runs` runs of `run_len` consecutive fragments, `run_stride` fragments apart in the packed buffer, copied back to back
+// to buf[dst ...] by LDS-DMA (one 1-KB fragment per wave instruction)
+__device__ __forceinline__ void stage_issue_runs(const f16x8* __restrict__ frags, int first, int run_len, int run_stride,
+                                                 int n_runs, f16x8* buf, int dst) {
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t voff = (threadIdx.x & 63u) * 16u;
+    const char* base = reinterpret_cast<const char*>(frags);
+    const int count = run_len * n_runs;
+    for (int f = wave; f < count; f += NW) {
+        const int src = first + (f / run_len) * run_stride + (f % run_len);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + (size_t)src * 1024 + voff),
+                                         (__attribute__((address_space(3))) void*)(buf + (size_t)(dst + f) * 64), 16, 0, 0);
+    }
+}
+
+// Weight stages of the terms kernel (fragments per stage, barriers per tile: 5 instead of the general kernel's 8; 192 instead
+// of 256 KB copied L2 -> LDS per 256 samples -- only the 12 fragments of W0 / W4-over-the-input that the GEMM still uses):
+//   S0 = W0[:, k < 48] (12) | W1 (32)     S1 = W2 (32)     S2 = W3 (32)     S3 = W4[:, k < 48] (12) | W4 over x (32)
+//   S4 = W5 (32) | heads (8)
+constexpr int TS_HEAD = 4 * TERM_KSTEPS;        // 12
+
+__device__ __forceinline__ void terms_issue_s0(const f16x8* frags, f16x8* buf) {
+    stage_issue_runs(frags, F0, TERM_KSTEPS, DF_TIN, 4, buf, 0);
+    stage_issue_runs(frags, F1, 32, 32, 1, buf, TS_HEAD);
 }
 
 // A.slot == nullptr: every sample takes row 0 (one code for the whole launch: an evaluation image's timestep)
@@ -674,7 +715,7 @@ __global__ __launch_bounds__(NW * 64, 1) void deform_fwd_terms_kernel(DeformArgs
             L.terms[(i / TERM_ROW) * TERM_STRIDE + (i % TERM_ROW)] = terms[i];
     }
     for (int i = threadIdx.x; i < N_BIAS; i += blockDim.x) L.bias[i] = A.bias[i];
-    stage_issue(A.frags, F0, 44, L.w[0]);
+    terms_issue_s0(A.frags, L.w[0]);
     __syncthreads();
     int cur = 0;
     for (int64_t grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {        // all waves iterate together
@@ -691,32 +732,38 @@ __global__ __launch_bounds__(NW * 64, 1) void deform_fwd_terms_kernel(DeformArgs
         f16x8 x[TERM_KSTEPS], h[DF_TW];
         f32x16 acc[4];
         float pn[3];
-        // L0
-        stage_issue(A.frags, F1, 32, L.w[cur ^ 1]);
+        // S0: L0 (input head, accumulators start at T0 + b0) and L1
+        stage_issue(A.frags, F2, 32, L.w[cur ^ 1]);
         build_input_head(A, b, kb, crow, pn, x);
-        acc_init_terms(acc, bias + 0 * DFW, term, kb);
-        gemm_input_head(L.w[cur], lane, x, acc);
+        acc_init_terms(acc, term, kb);
+        gemm_input_head(L.w[cur], 0, lane, x, acc);
+        finish_layer<false>(acc, h);
+        acc_init(acc, bias + 1 * DFW, kb);
+        gemm_layer_lds<DF_TW>(L.w[cur], TS_HEAD, lane, h, acc);
         finish_layer<false>(acc, h);
         stage_flip(cur);
-#pragma unroll 1
-        for (int l = 1; l <= 3; ++l) {
-            stage_issue(A.frags, l == 1 ? F2 : (l == 2 ? F3 : F4), l == 3 ? 44 : 32, L.w[cur ^ 1]);
-            acc_init(acc, bias + l * DFW, kb);
-            gemm_layer_lds<DF_TW>(L.w[cur], 0, lane, h, acc);
-            finish_layer<false>(acc, h);
-            stage_flip(cur);
-        }
-        // L4: cat[input, x]
-        stage_issue(A.frags, F4X, 32, L.w[cur ^ 1]);
-        acc_init_terms(acc, bias + 4 * DFW, term + DFW, kb);
-        gemm_input_head(L.w[cur], lane, x, acc);
-        stage_flip(cur);
-        stage_issue(A.frags, F5, 40, L.w[cur ^ 1]);
+        // S1: L2
+        stage_issue(A.frags, F3, 32, L.w[cur ^ 1]);
+        acc_init(acc, bias + 2 * DFW, kb);
         gemm_layer_lds<DF_TW>(L.w[cur], 0, lane, h, acc);
         finish_layer<false>(acc, h);
         stage_flip(cur);
-        // L5 + heads
-        stage_issue(A.frags, F0, 44, L.w[cur ^ 1]);
+        // S2: L3
+        stage_issue_runs(A.frags, F4, TERM_KSTEPS, DF_TIN, 4, L.w[cur ^ 1], 0);
+        stage_issue_runs(A.frags, F4X, 32, 32, 1, L.w[cur ^ 1], TS_HEAD);
+        acc_init(acc, bias + 3 * DFW, kb);
+        gemm_layer_lds<DF_TW>(L.w[cur], 0, lane, h, acc);
+        finish_layer<false>(acc, h);
+        stage_flip(cur);
+        // S3: L4 = cat[input, x]: the input head from T4 + b4, then the 8 K-steps over x
+        stage_issue(A.frags, F5, 40, L.w[cur ^ 1]);
+        acc_init_terms(acc, term + DFW, kb);
+        gemm_input_head(L.w[cur], 0, lane, x, acc);
+        gemm_layer_lds<DF_TW>(L.w[cur], TS_HEAD, lane, h, acc);
+        finish_layer<false>(acc, h);
+        stage_flip(cur);
+        // S4: L5 + heads
+        terms_issue_s0(A.frags, L.w[cur ^ 1]);                              // the next tile's first stage
         acc_init(acc, bias + 5 * DFW, kb);
         gemm_layer_lds<DF_TW>(L.w[cur], 0, lane, h, acc);
         finish_layer<false>(acc, h);
@@ -1464,8 +1511,8 @@ int nsx_deform_fwd_rows(const void* packed, const float* positions, int64_t S, c
     DeformArgs A;
     const float* bias = reinterpret_cast<const float*>(reinterpret_cast<const uint8_t*>(packed) + (size_t)N_FRAGS * 64 * 16);
     fill_args(A, positions, S, aabb_host, code_table, code_stride, code_slot, window7_host, packed, bias);
-    hipLaunchKernelGGL(deform_code_terms_kernel, dim3(2 * n_code_rows), dim3(DFW), 0, (hipStream_t)stream, A.frags, code_table,
-                       code_stride, n_code_rows, terms_scratch);
+    hipLaunchKernelGGL(deform_code_terms_kernel, dim3(2 * n_code_rows), dim3(DFW), 0, (hipStream_t)stream, A.frags, A.bias,
+                       code_table, code_stride, n_code_rows, terms_scratch);
     NSX_LAUNCH_CHECK("nsx_deform_fwd_rows terms launch");
     const int64_t n_tiles = (S + 31) / 32;
     int64_t blocks = (n_tiles + NW - 1) / NW;

@@ -101,8 +101,17 @@ def _aliases(t: Optional[torch.Tensor], flat: torch.Tensor) -> bool:
     return lo <= t.data_ptr() < lo + flat.numel() * 4
 
 
+def _has_grad_hooks(p: torch.Tensor) -> bool:
+    return bool(getattr(p, "_backward_hooks", None)) or bool(getattr(p, "_post_accumulate_grad_hooks", None))
+
+
 def _deposit(p: torch.Tensor, view: torch.Tensor) -> None:
-    """``AccumulateGrad`` for a leaf whose gradient already sits in its final place."""
+    """``AccumulateGrad`` for a leaf whose gradient already sits in its final place.
+
+    Contract (what DDP's ``gradient_as_bucket_view`` also asks of its users): ``p.grad`` is a VIEW of the step's persistent
+    gradient buffer -- stage 0 of the next backward clears it, so a reference kept across steps (gradient logging) must be
+    cloned by its holder; tensor hooks and post-accumulate hooks do not see a deposited gradient, therefore a leaf that has
+    any takes the autograd route (``_NativeMain.backward``), as does every leaf when ``NSX_GRAD_DEPOSIT=0``."""
     if p.grad is None:
         p.grad = view
     else:
@@ -166,7 +175,9 @@ class _NativeMain(torch.autograd.Function):
             full = torch.zeros((st.n_rows, st.code_width), dtype=torch.float32, device=dev)   # (compact window-ramp layout)
             full[:, :st.H] = g_code
             g_code = full
-        if not _DEPOSIT:                 # (A/B knob: hand every gradient to autograd, which clones the referenced views)
+        if not _DEPOSIT or any(_has_grad_hooks(p) for p in leaves):
+            # autograd's own accumulation (it clones the referenced views): asked for (A/B knob), or a leaf carries hooks
+            # that a deposited gradient would bypass
             ctx.leaves = None
             return (None, None, gb.d_base, gb.d_head, g_code, gb.gtable, *gb.deform)
         # leaf parameters: the views ARE the gradients (see _GradBuffers); the two code lookups are differentiated by autograd

@@ -127,6 +127,11 @@ def _table(optimizers: Sequence[SmallGroupAdam], group_of: Sequence[int]):
         _TABLE_CACHE["t"] = hit
     _, refs, n, owners = hit
     for i, (opt, p) in enumerate(owners):
+        if refs[i].param != p.data_ptr():
+            # the parameter's storage was replaced (``model.to()``, a master-weight swap): the cached raw pointers are stale
+            # -- rebuild the table (advisor, round 4: the kernels would otherwise read and write freed memory)
+            _TABLE_CACHE.pop("t", None)
+            return _table(optimizers, group_of)
         g = p.grad
         if g is None:
             refs[i].grad = None
