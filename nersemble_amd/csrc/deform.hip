@@ -607,8 +607,13 @@ static_assert(sizeof(DeformLdsT<true>) <= 160 * 1024, "the forward's LDS block m
 // build_input evaluates both candidates and selects the value: twice the quarter-rate transcendentals for the same numbers.
 __device__ __forceinline__ void build_input_head(const DeformArgs& A, int64_t b, int kb, const float* crow, float pn[3],
                                                  f16x8 x[TERM_KSTEPS]) {
-#pragma unroll
-    for (int d = 0; d < 3; ++d) pn[d] = (A.pos[b * 3 + d] - A.aabb_min[d]) / A.aabb_ext[d];
+    // (scalars, not the caller's array: a select between two elements of an array in memory is folded into ONE load with a
+    // per-lane index -- scratch memory)
+    const float q0 = (A.pos[b * 3 + 0] - A.aabb_min[0]) / A.aabb_ext[0];
+    const float q1 = (A.pos[b * 3 + 1] - A.aabb_min[1]) / A.aabb_ext[1];
+    const float q2 = (A.pos[b * 3 + 2] - A.aabb_min[2]) / A.aabb_ext[2];
+    pn[0] = q0; pn[1] = q1; pn[2] = q2;
+    auto P = [&](int d) -> float { return d == 0 ? q0 : (d == 1 ? q1 : q2); };
     // the window weights as opaque scalars: a select between two loads of the by-value argument struct would be folded into ONE
     // load with a selected (per-lane) index, and a dynamically indexed kernel argument is copied to scratch memory
     float win[7];
@@ -627,7 +632,7 @@ __device__ __forceinline__ void build_input_head(const DeformArgs& A, int64_t b,
             if (k1 < 42) {                                   // both candidates are windowed sines
                 const int q0 = k0 < 21 ? k0 : k0 - 21, q1 = k1 < 21 ? k1 : k1 - 21;
                 const int d0 = q0 / 7, f0 = q0 - 7 * d0, d1 = q1 / 7, f1 = q1 - 7 * d1;
-                const float p = kb ? pn[d1] : pn[d0];
+                const float p = kb ? P(d1) : P(d0);
                 const float sc = kb ? (float)(1 << f1) : (float)(1 << f0);
                 const float ph = kb ? (k1 >= 21 ? 0.25f : 0.f) : (k0 >= 21 ? 0.25f : 0.f);
                 const float w = kb ? win[f1] : win[f0];
@@ -636,9 +641,9 @@ __device__ __forceinline__ void build_input_head(const DeformArgs& A, int64_t b,
                 auto value = [&](int k) -> float {
                     if (k < 42) {
                         const int q = k - 21, d = q / 7, f = q - 7 * d;
-                        return win[f] * __builtin_amdgcn_sinf(pn[d] * (float)(1 << f) + 0.25f);
+                        return win[f] * __builtin_amdgcn_sinf(P(d) * (float)(1 << f) + 0.25f);
                     }
-                    if (k < DF_PE) return 6.283185307179586f * pn[k - 42];
+                    if (k < DF_PE) return 6.283185307179586f * P(k - 42);
                     return crow[k - DF_PE];
                 };
                 const float v0 = value(k0), v1 = value(k1);
@@ -791,6 +796,78 @@ __global__ __launch_bounds__(NW * 64, 1) void deform_fwd_terms_kernel(DeformArgs
     }
 }
 
+// The terms forward of ONE tile inside the backward chain kernel (SLOTS: codes are rows of the batch's table): the same
+// stages, accumulator starts and MFMA order as deform_fwd_terms_kernel -- the recomputed pre-activations are the forward
+// kernel's bit for bit, so the ReLU masks are those of the activations the step actually used -- plus what the backward keeps:
+// the masks and the transposed layer-input tiles (a0: the 3 input fragments, 48 rows; rows 48..63 of its 64-row tile are
+// zeros -- the weight-gradient kernel reads the positional-encoding columns k < 45 of it only).  On entry stage S0 is resident
+// in L.w[cur]; on exit the chain's first stage (heads^T | W5^T, 36 fragments).
+__device__ __forceinline__ void forward_tile_terms_bwd(const DeformArgs& A, int64_t b, int lane, Fwd& F, half_t* a_tiles,
+                                                       DeformLds& L, int& cur, const float* term, const float* crow) {
+    constexpr int A0_HALFS = 2 * 32 * 32;                       // the 64-row a0 tile of Lay<true>
+    const int kb = lane >> 5;
+    lds_cfloat* bias = launder_lds(L.bias);
+    const TSel tsel = make_tsel(lane);
+    f32x16 acc[4];
+    // stage "W0 head" (12 fragments): L0, accumulators start at T0 + b0
+    stage_issue(A.frags, F1, 32, L.w[cur ^ 1]);
+    build_input_head(A, b, kb, crow, F.pn, F.x);
+    store_tile_T<TERM_KSTEPS>(a_tiles, lane, F.x, tsel);
+    acc_init_terms(acc, term, kb);
+    gemm_input_head(L.w[cur], 0, lane, F.x, acc);
+    F.m1 = finish_layer<true>(acc, F.h);
+    store_tile_T<DF_TW>(a_tiles + A0_HALFS + 0 * DFW * 32, lane, F.h, tsel);
+    stage_flip(cur);
+    // L1 .. L3 (one loop body, as in forward_tile: the chain kernel sits at the register limit, and three unrolled layers
+    // spilled 95 VGPRs instead of 20)
+#pragma unroll 1
+    for (int l = 1; l <= 3; ++l) {
+        if (l < 3) {
+            stage_issue(A.frags, l == 1 ? F2 : F3, 32, L.w[cur ^ 1]);
+        } else {
+            stage_issue_runs(A.frags, F4, TERM_KSTEPS, DF_TIN, 4, L.w[cur ^ 1], 0);
+            stage_issue_runs(A.frags, F4X, 32, 32, 1, L.w[cur ^ 1], TS_HEAD);
+        }
+        acc_init(acc, bias + l * DFW, kb);
+        gemm_layer_lds<DF_TW>(L.w[cur], 0, lane, F.h, acc);
+        const u32x2 m = finish_layer<true>(acc, F.h);
+        if (l == 1) F.m2 = m; else if (l == 2) F.m3 = m; else F.m4 = m;
+        store_tile_T<DF_TW>(a_tiles + A0_HALFS + l * DFW * 32, lane, F.h, tsel);
+        stage_flip(cur);
+    }
+    // stage "W4 head | W4 over x" (44): L4 = cat[input, x], accumulators start at T4 + b4
+    stage_issue(A.frags, F5, 40, L.w[cur ^ 1]);
+    acc_init_terms(acc, term + DFW, kb);
+    gemm_input_head(L.w[cur], 0, lane, F.x, acc);
+    gemm_layer_lds<DF_TW>(L.w[cur], TS_HEAD, lane, F.h, acc);
+    F.m5 = finish_layer<true>(acc, F.h);
+    store_tile_T<DF_TW>(a_tiles + A0_HALFS + 4 * DFW * 32, lane, F.h, tsel);
+    stage_flip(cur);
+    // L5 (+ out_activation ReLU) and the heads; the chain's first stage arrives meanwhile
+    stage_issue(A.frags, BH, 36, L.w[cur ^ 1]);
+    acc_init(acc, bias + 5 * DFW, kb);
+    gemm_layer_lds<DF_TW>(L.w[cur], 0, lane, F.h, acc);
+    F.m6 = finish_layer<true>(acc, F.h);
+    f32x16 o = zero16();
+#pragma unroll
+    for (int t = 0; t < DF_TW; ++t) o = mfma(L.w[cur][(32 + t) * 64 + lane], F.h[t], o);
+    float own[4], oth[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) own[r] = (float)(half_t)(o[r] + bias[6 * DFW + acc_row(r, kb)]);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) oth[r] = __shfl_xor(own[r], 32);
+    F.r[0] = kb ? oth[0] : own[0]; F.r[1] = kb ? oth[1] : own[1]; F.r[2] = kb ? oth[2] : own[2];
+    F.v[0] = kb ? oth[3] : own[3]; F.v[1] = kb ? own[0] : oth[0]; F.v[2] = kb ? own[1] : oth[1];
+    stage_flip(cur);
+}
+
+// first stage of a tile of the chain kernel's terms forward: the 12 fragments of W0 over the input head
+__device__ __forceinline__ void terms_bwd_issue_first(const f16x8* frags, f16x8* buf) {
+    stage_issue_runs(frags, F0, TERM_KSTEPS, DF_TIN, 4, buf, 0);
+}
+
+constexpr int BWD_TERM_LDS_ROWS = 24;           // code rows whose terms fit beside the chain kernel's 120 KB of LDS
+
 // ---------------------------------------------------------------------------------------------------------
 // backward chain kernel: writes per-tile a0..a6, dZ0..dZ5, dZheads, dCode tiles
 // ---------------------------------------------------------------------------------------------------------
@@ -849,13 +926,17 @@ __device__ __forceinline__ void mask_pack(const f32x16 d[4], u32x2 mask, f16x8 d
     }
 }
 
-template <bool SLOTS>
+// TERMS (SLOTS only; round 5): the forward recompute is the terms forward (forward_tile_terms_bwd) -- 1: the rows' terms in LDS
+// (<= BWD_TERM_LDS_ROWS rows: a training batch's images), 2: read from global memory (L2).
+template <bool SLOTS, int TERMS = 0>
 __global__ __launch_bounds__(NW * 64, 1) void deform_bwd_kernel(DeformArgs A, const float* __restrict__ goff,
                                                               half_t* __restrict__ scratch, int64_t n_tiles,
                                                               float* __restrict__ gcode_samples,
                                                               const int64_t* __restrict__ n_dev,
                                                               float* __restrict__ slot_sums,
-                                                              float* __restrict__ head_partials) {
+                                                              float* __restrict__ head_partials,
+                                                              const float* __restrict__ terms = nullptr, int n_rows = 0) {
+    static_assert(TERMS == 0 || SLOTS, "the terms forward needs codes that are rows of a table");
     using LY = Lay<SLOTS>;
     constexpr int64_t TILE_HALFS = LY::TILE_HALFS, TILE_DZ = LY::TILE_DZ, TILE_DZH = LY::TILE_DZH, TILE_DC = LY::TILE_DC;
     if (SLOTS) {      // the per-slot sums the NEXT kernel adds to: cleared here (also when no sample is left to process)
@@ -873,7 +954,18 @@ __global__ __launch_bounds__(NW * 64, 1) void deform_bwd_kernel(DeformArgs A, co
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int n = lane & 31, kb = lane >> 5;
     const int64_t n_groups = (n_tiles + NW - 1) / NW;
-    lds_prologue(A, L, F0, 44);
+    __shared__ float terms_lds[TERMS == 1 ? BWD_TERM_LDS_ROWS * TERM_STRIDE : 4];
+    if constexpr (TERMS == 0) {
+        lds_prologue(A, L, F0, 44);
+    } else {
+        if constexpr (TERMS == 1) {
+            for (int i = threadIdx.x; i < n_rows * TERM_ROW; i += blockDim.x)
+                terms_lds[(i / TERM_ROW) * TERM_STRIDE + (i % TERM_ROW)] = terms[i];
+        }
+        for (int i = threadIdx.x; i < N_BIAS; i += blockDim.x) L.bias[i] = A.bias[i];
+        terms_bwd_issue_first(A.frags, L.w[0]);
+        __syncthreads();
+    }
     int cur = 0;
     for (int64_t grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {        // all waves iterate together
         const int64_t tile_raw = grp * NW + wave;
@@ -885,7 +977,16 @@ __global__ __launch_bounds__(NW * 64, 1) void deform_bwd_kernel(DeformArgs A, co
         // waves past the last tile still walk the layers (barriers) but write into the block-private dummy tile
         half_t* T = scratch + (tile_ok ? tile : n_tiles + (int64_t)blockIdx.x * NW + wave) * TILE_HALFS;
         Fwd F;
-        forward_tile<true, LY::A0_FRAGS, !SLOTS>(A, b, lane, F, T, L, cur, BH, 36);
+        if constexpr (TERMS == 0) {
+            forward_tile<true, LY::A0_FRAGS, !SLOTS>(A, b, lane, F, T, L, cur, BH, 36);
+        } else {
+            int row = A.slot[b];
+            row = row < 0 ? 0 : (row >= n_rows ? n_rows - 1 : row);
+            const float* term;
+            if constexpr (TERMS == 1) term = terms_lds + row * TERM_STRIDE;
+            else term = terms + (int64_t)row * TERM_ROW;
+            forward_tile_terms_bwd(A, b, lane, F, T, L, cur, term, A.code + (int64_t)row * A.code_stride);
+        }
         // ---- SE(3) backward (fp32): g = dL/dwarped ----
         float g[3] = {0.f, 0.f, 0.f};
         if (valid) { g[0] = goff[b * 3]; g[1] = goff[b * 3 + 1]; g[2] = goff[b * 3 + 2]; }
@@ -1003,7 +1104,8 @@ __global__ __launch_bounds__(NW * 64, 1) void deform_bwd_kernel(DeformArgs A, co
         mask_pack(d, F.m2, dz);
         store_tile_T<DF_TW>(T + TILE_DZ + 1 * DFW * 32, lane, dz, tsel);
         stage_flip(cur);
-        if constexpr (SLOTS) stage_issue(A.frags, F0, 44, L.w[cur ^ 1]);       // first stage of the next tile
+        if constexpr (TERMS != 0) terms_bwd_issue_first(A.frags, L.w[cur ^ 1]);       // first stage of the next tile
+        else if constexpr (SLOTS) stage_issue(A.frags, F0, 44, L.w[cur ^ 1]);
         else stage_issue(A.frags, B0C, 32, L.w[cur ^ 1]);
         for (int i = 0; i < 4; ++i) d[i] = zero16();
         gemm_layer_lds<DF_TW>(L.w[cur], 0, lane, dz, d);
@@ -1446,9 +1548,11 @@ int64_t nsx_deform_pack_bytes(void) { return (int64_t)N_FRAGS * 64 * 16 + (int64
 // + one private parameter-gradient vector per chunk of the weight-gradient kernel (SLOTS: plain stores + one reduction)
 static int64_t tiles_bytes(int64_t S) { return (((S + 31) / 32) + (int64_t)num_cus() * NW) * Lay<false>::TILE_HALFS * 2; }
 static int wgrad_chunks_max() { return num_cus() / (WG_TYPES - 1); }
+// + the row terms of the backward's forward recompute (<= 128 code rows)
+constexpr int64_t BWD_TERMS_BYTES = 128 * TERM_ROW * 4;
 int64_t nsx_deform_scratch_bytes(int64_t S) {
     return SLOT_SUMS_BYTES + tiles_bytes(S) + (int64_t)wgrad_chunks_max() * P_TOTAL * 4
-           + (int64_t)num_cus() * HEAD_STRIDE * 4;
+           + (int64_t)num_cus() * HEAD_STRIDE * 4 + BWD_TERMS_BYTES;
 }
 
 int nsx_deform_pack(const float* params, void* packed, void* stream) {
@@ -1551,10 +1655,19 @@ int nsx_deform_bwd(const void* packed, const float* positions, int64_t S, const 
     const bool slots = code_slot && grad_code_table && !grad_code_samples;
     float* chunk_partials = reinterpret_cast<float*>(reinterpret_cast<uint8_t*>(scratch) + SLOT_SUMS_BYTES + tiles_bytes(S));
     float* head_partials = chunk_partials + (int64_t)wgrad_chunks_max() * P_TOTAL;
-    if (slots)
-        hipLaunchKernelGGL(deform_bwd_kernel<true>, dim3((unsigned)blocks), dim3(NW * 64), 0, st, A, grad_offsets, sc,
-                           n_tiles, grad_code_samples, n_device, slot_sums, head_partials);
-    else
+    if (slots) {
+        // the forward recompute is the terms forward of nsx_deform_fwd_rows (the same pre-activations bit for bit)
+        float* terms = head_partials + (int64_t)num_cus() * HEAD_STRIDE;
+        hipLaunchKernelGGL(deform_code_terms_kernel, dim3(2 * n_code_rows), dim3(DFW), 0, st, A.frags, A.bias, code, code_stride,
+                           n_code_rows, terms);
+        NSX_LAUNCH_CHECK("nsx_deform_bwd terms launch");
+        if (n_code_rows <= BWD_TERM_LDS_ROWS)
+            hipLaunchKernelGGL((deform_bwd_kernel<true, 1>), dim3((unsigned)blocks), dim3(NW * 64), 0, st, A, grad_offsets, sc,
+                               n_tiles, grad_code_samples, n_device, slot_sums, head_partials, (const float*)terms, n_code_rows);
+        else
+            hipLaunchKernelGGL((deform_bwd_kernel<true, 2>), dim3((unsigned)blocks), dim3(NW * 64), 0, st, A, grad_offsets, sc,
+                               n_tiles, grad_code_samples, n_device, slot_sums, head_partials, (const float*)terms, n_code_rows);
+    } else
         hipLaunchKernelGGL(deform_bwd_kernel<false>, dim3((unsigned)blocks), dim3(NW * 64), 0, st, A, grad_offsets, sc,
                            n_tiles, grad_code_samples, n_device, slot_sums, (float*)nullptr);
     NSX_LAUNCH_CHECK("nsx_deform_bwd chain launch");

@@ -3,7 +3,7 @@
 # (separate runs: gpurun refuses --pmc together with tracing).  Results land in gpurun_out/prof_<tag>/ ; copy the
 # summaries into profiles/ afterwards.   usage: tools/collect_profiles.sh r02
 set -u
-tag=${1:-r04}
+tag=${1:-r05}
 out=gpurun_out/prof_$tag
 mkdir -p $out
 export TMPDIR=/tmp

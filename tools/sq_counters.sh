@@ -3,7 +3,7 @@
 # S = 2^20 (tools/mfma_bench.py, one warm-up + one measured launch each).  Results: gpurun_out/sq_<tag>/ ; the JSON summary
 # is what gets copied to profiles/pmc/.      usage: tools/sq_counters.sh r04
 set -u
-tag=${1:-r04}
+tag=${1:-r05}
 out=gpurun_out/sq_$tag
 mkdir -p $out
 export TMPDIR=/tmp

@@ -73,11 +73,13 @@ def main():
             d["kernel_cycles_per_xcd"] = c["GRBM_GUI_ACTIVE"] / 8.0
         if c.get("SQ_LDS_IDX_ACTIVE") and "SQ_LDS_BANK_CONFLICT" in c:
             d["lds_conflict_frac"] = round(c["SQ_LDS_BANK_CONFLICT"] / c["SQ_LDS_IDX_ACTIVE"], 4)
+        if c.get("SQ_INSTS_MFMA") and "SQ_INSTS_VALU" in c:
+            d["valu_per_mfma"] = round(c["SQ_INSTS_VALU"] / c["SQ_INSTS_MFMA"], 3)
         doc["kernels"][name] = d
     with open(out, "w") as f:
         json.dump(doc, f, indent=1)
     for name, d in doc["kernels"].items():
-        print(name, {k: v for k, v in d.items() if k.endswith("_frac") or k in ("SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE",
+        print(name, {k: v for k, v in d.items() if k.endswith("_frac") or k.endswith("_per_mfma") or k in ("SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE",
                                                                                 "SQ_INSTS_VALU", "SQ_BUSY_CYCLES")})
 
 
