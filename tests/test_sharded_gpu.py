@@ -576,4 +576,10 @@ def test_sharded_step_follows_the_window(cuda, single_rank_group):
     assert widths == [1, 1, 2, 4, 8]
     ba, bb = opt_a._buffers(), opt_b._buffers()
     assert (bb["exp_avg"].view(-1, 8)[:, 6:] == 0).all()              # grids the window never reached
-    assert torch.allclose(ba["exp_avg"], bb["exp_avg"], rtol=1e-3, atol=1e-7)
+    # (the two runs' scatters add their fp32 atomics in different orders, so single elements of the fp16 gradient the Adam
+    # kernels read differ by one fp16 ulp: the moments agree to that -- relative to their scale, not element by element, where
+    # five steps' contributions may cancel.  Bit-identity of the two exchanges on identical gradients is the CPU test's,
+    # tests/test_parallel_cpu.py::test_exchange_that_follows_the_window_equals_the_full_exchange_bit_for_bit.)
+    diff = (ba["exp_avg"] - bb["exp_avg"]).abs()
+    assert diff.max().item() <= 2e-3 * ba["exp_avg"].abs().max().item(), diff.max().item()
+    assert (diff <= 1e-3 * ba["exp_avg"].abs() + 1e-7).float().mean().item() >= 0.999

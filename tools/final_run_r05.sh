@@ -33,6 +33,9 @@ for k in ("first_grid_phase","open_window","with_datamanager"):
 P
 for s in steady_full steady_open_window steady_compact; do echo $s; head -12 gpurun_out/prof_r05/${s}_summary.txt; done
 else
+# (part A's suite: 335 passed, 1 failed on a tolerance that sat at one fp16 ulp of the gradient -- tests/test_sharded_gpu.py::
+# test_sharded_step_follows_the_window; the file again with the bound restated)
+timeout 600 python -m pytest tests/test_sharded_gpu.py -q -m gpu 2>&1 | tail -3 > $out/sharded_again.txt; cat $out/sharded_again.txt
 bash tools/sq_counters.sh r05 > $out/sq.log 2>&1; tail -30 $out/sq.log | cut -c1-400
 timeout 400 python tools/eval_bench.py --price > $out/eval_bench.txt 2> $out/eval.err; grep -a "preblend=" $out/eval_bench.txt; tail -1 $out/eval_bench.txt | cut -c1-1200
 bash tools/config_lines.sh > $out/config_lines.txt 2>&1; cat $out/config_lines.txt | tail -5
