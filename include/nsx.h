@@ -473,7 +473,11 @@ int nsx_distloss(const float* weights, const float* midpoints, const float* inte
  * torch.optim.Adam semantics (no amsgrad, no weight decay); `step` is the 1-based step count; inv_scale /
  * found_inf are DEVICE scalars (may be NULL): gradients are multiplied by *inv_scale and the whole update is
  * skipped when *found_inf != 0.  nsx_adam_hash_factored forms the gradient on the fly from the factored
- * gradient G (see nsx_hash_ensemble_bwd_factored) -- the dense table gradient is never materialised. */
+ * gradient G (see nsx_hash_ensemble_bwd_factored) -- the dense table gradient is never materialised.
+ * n_slots <= NSX_MAX_SLOTS: the planes are walked in slot order by fp32 FMAs (the bits every single-process run and the
+ * golden vectors have).  NSX_MAX_SLOTS < n_slots <= NSX_MAX_ADAM_SLOTS with 17..32 grids (level-parallel runs only): the
+ * product G x code runs on the matrix cores on a three-way bf16 split of G -- fp32 accuracy (<= 1e-6 of sum |G c|), other
+ * rounding than the FMA chain. */
 int nsx_check_finite(const float* x, int64_t n, float* found_inf /* set to 1 if any non-finite */, void* stream);
 int nsx_adam_hash_factored(const float* G, int n_slots, const float* code_table, int64_t code_stride,
                            const float* window, int H, const nsx_grid_geom* g, float* master, float* exp_avg,

@@ -143,6 +143,188 @@ __global__ __launch_bounds__(256) void adam_hash_factored_kernel(
     }
 }
 
+// ---- the same pass with the gradient formed on the matrix cores: many gradient planes --------------------------------------
+// The level-parallel exchange (engine/level_parallel.py) hands this pass one gradient plane per (source rank, code row): up to
+// 8 x 24 = 192 planes over 1 / N of the entries.  The gradient of an entry is then a [64 (entry, feature)] x [planes] x [32 grids]
+// product per 32 entries -- 6 144 multiply-adds per parameter pair against 3.2 KB of HBM traffic: the kernel above, which walks
+// the planes on the VALU out of 74 KB of LDS per block, takes 1.56 ms for the 2^20 entries of the finest two levels where their
+// bytes take 0.42 ms.  Here a wave owns 32 consecutive (entry, feature) rows at a time and forms their gradient with
+// v_mfma_f32_32x32x16_bf16: rows = (entry, feature), columns = grids -- the D layout of the instruction (lane = column, 16 rows per
+// lane) is then exactly the table layout [(entry, feature)][grid]: every load / store of master / moments / working copy is a
+// pair of full 128-byte lines per wave instruction.  G is fp32 and must stay so (loss-scaled sums: outside the fp16 range), the
+// codes are fp16 values: G is split into three truncated bf16 pieces (8 + 8 + 8 bits: exact up to 2^-24 of the value), a code
+// into two (exact), and five of the six products are accumulated (the sixth is below 2^-24) -- the sum carries fp32 accuracy;
+// its rounding differs from the VALU chain's in the last bits, which is why only plane counts the VALU kernel was never given
+// (> 64: no single-process run has them) come here.  A operand straight from global memory (lane = row, 8 planes per lane: eight
+// dword loads whose half-waves read one 128-byte line each), B operand (codes) from LDS in fragment order.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float acc16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+template <class P>
+__device__ __forceinline__ P* at_bytes(P* base, unsigned int bytes) {
+    return reinterpret_cast<P*>(reinterpret_cast<char*>(base) + bytes);
+}
+
+__device__ __forceinline__ unsigned int hi_halves(unsigned int a, unsigned int b) {      // (a >> 16) | (b & 0xffff0000)
+    return __builtin_amdgcn_perm(b, a, 0x07060302u);
+}
+
+#define MFMA_ADAM_WAVES(T) ((T) >= 8 ? 2 : 3)              /* waves per SIMD the register budget is set for */
+// T: K steps of 16 planes, a template parameter -- the column of G a row block needs is then a fixed set of registers requested
+// in one go (with T a run-time bound the loads end up behind per-step branches, each with its own wait).
+template <int T, bool CLEAR>
+__global__ __launch_bounds__(256, MFMA_ADAM_WAVES(T)) void adam_hash_factored_mfma_kernel(
+    float* __restrict__ G, int n_slots, const float* __restrict__ code, int64_t code_stride,
+    const float* __restrict__ window, int Hreal, uint64_t total, float* __restrict__ master, float* __restrict__ m,
+    float* __restrict__ v, half_t* __restrict__ f16, AdamHyper hy, const float* __restrict__ inv_scale,
+    const float* __restrict__ found_inf) {
+    constexpr int HP = 32;
+    const bool skip = found_inf && found_inf[0] != 0.f;
+    if (skip && !CLEAR) return;
+    extern __shared__ float smem[];
+    // fragment order: [K step][half-wave][grid][8 planes] bf16, the high pieces then the low pieces
+    unsigned short* ch = reinterpret_cast<unsigned short*>(smem);
+    unsigned short* cl = ch + T * 16 * HP;
+    for (int i = threadIdx.x; i < T * 16 * HP; i += blockDim.x) {
+        const int sl = i / HP, h = i % HP;
+        float c = 0.f;
+        if (sl < n_slots && h < Hreal) c = code[sl * code_stride + h] * (window ? window[h] : 1.0f);
+        c = (float)(half_t)c;
+        const unsigned int u = __float_as_uint(c) & 0xffff0000u;
+        const float lo = c - __uint_as_float(u);             // <= 3 significant bits: exact in bf16
+        const int at = ((sl >> 3) * HP + h) * 8 + (sl & 7);
+        ch[at] = (unsigned short)(u >> 16);
+        cl[at] = (unsigned short)(__float_as_uint(lo) >> 16);
+    }
+    __syncthreads();
+    const float is = inv_scale ? inv_scale[0] : 1.0f;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 31, kg = lane >> 5;
+    const uint64_t n_rows = total * 2ull;                    // (entry, feature) rows
+    const uint64_t n_blocks = (n_rows + 31) / 32;
+    const u32x4* bh = reinterpret_cast<const u32x4*>(ch);
+    const u32x4* bl = reinterpret_cast<const u32x4*>(cl);
+    const bool col_live = j < Hreal;
+    // Addresses: a wave-uniform 64-bit base (SGPRs, scalar arithmetic) + one 32-bit lane offset that does not change over the
+    // loop -- with per-lane 64-bit addresses the 96 loads of a column cost 192 registers before the first one is issued.
+    // (BYTE offsets, so that base + zero-extended offset is the instruction's own addressing mode; the launcher checks that
+    // 9 planes of the range stay below 4 GB)
+    const unsigned int lane_g = (unsigned int)(kg * 8) * (unsigned int)n_rows * 4u;  // + the lane's row within the block
+    const unsigned int lane_t = (unsigned int)(4 * kg * HP + j) * 4u;
+    const uint64_t wave0 = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + wave));
+    for (uint64_t rb = wave0; rb < n_blocks; rb += (uint64_t)gridDim.x * 4) {
+        const uint64_t row0 = rb * 32;
+        const bool full = row0 + 32 <= n_rows;               // (all but the last row block of the range)
+        // Every load of G is unconditional: a load under a per-lane condition is compiled into a branch with its own wait -- one
+        // HBM round trip per element.  Rows past the end read the last row (their results are never stored), planes past
+        // n_slots read a valid plane against code rows that are zero.
+        const bool a_live = row0 + j < n_rows;
+        const unsigned int jc = (a_live ? (unsigned int)j : (unsigned int)(n_rows - 1 - row0)) * 4u;
+        const unsigned int off_g = lane_g + jc;
+        float* gbase = G + row0;
+        // the row block's whole column of G is requested at once (<= 96 registers): one HBM round trip per row block instead
+        // of one per K step
+        float gq[T][8];
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int sa = t * 16 + i;                   // the plane of the lower half-wave; the upper one reads sa + 8
+                if (t < T - 1) {
+                    gq[t][i] = *at_bytes(gbase + (uint64_t)sa * n_rows, off_g);
+                } else {
+                    float* src = gbase + (uint64_t)(sa < n_slots ? sa : 0) * n_rows;
+                    gq[t][i] = *at_bytes(src, (sa + 8 < n_slots) ? off_g : jc);
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);                   // (or the scheduler sinks each K step's loads to its products)
+        acc16 acc;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            if (CLEAR) {
+                // (the plane stride through an opaque scalar: the stores' bases are then formed again here, 8 scalar adds,
+                // instead of 96 address pairs kept from the loads)
+                uint64_t stride = n_rows;
+                asm volatile("" : "+s"(stride));
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    if (gq[t][i] != 0.f && a_live && t * 16 + kg * 8 + i < n_slots)
+                        *at_bytes(gbase + (uint64_t)(t * 16 + i) * stride, off_g) = 0.f;
+            }
+            if (skip) continue;
+            unsigned int u1[8], u2[8], u3[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                u1[i] = __float_as_uint(gq[t][i]);
+                const float r = gq[t][i] - __uint_as_float(u1[i] & 0xffff0000u);    // exact
+                u2[i] = __float_as_uint(r);
+                const float r2 = r - __uint_as_float(u2[i] & 0xffff0000u);          // exact
+                u3[i] = __float_as_uint(r2);
+            }
+            u32x4 a1, a2, a3;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                a1[i] = hi_halves(u1[2 * i], u1[2 * i + 1]);
+                a2[i] = hi_halves(u2[2 * i], u2[2 * i + 1]);
+                a3[i] = hi_halves(u3[2 * i], u3[2 * i + 1]);
+            }
+            const u32x4 h8 = bh[(t * 2 + kg) * HP + j];
+            const u32x4 l8 = bl[(t * 2 + kg) * HP + j];
+            const bf16x8 A1 = __builtin_bit_cast(bf16x8, a1), A2 = __builtin_bit_cast(bf16x8, a2),
+                         A3 = __builtin_bit_cast(bf16x8, a3);
+            const bf16x8 BH = __builtin_bit_cast(bf16x8, h8), BL = __builtin_bit_cast(bf16x8, l8);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A3, BH, acc, 0, 0, 0);      // the small terms first
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A2, BL, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, BL, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A2, BH, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, BH, acc, 0, 0, 0);
+        }
+        if (skip) continue;
+        // the three parameter streams after the products (their registers are the column's until here; the other waves of
+        // the CU cover the round trip)
+        float pp[16], mm[16], vv[16];
+        if (full) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const uint64_t at = (row0 + 8 * (q >> 2) + (q & 3)) * HP;
+                pp[q] = __builtin_nontemporal_load(at_bytes(master + at, lane_t));
+                mm[q] = __builtin_nontemporal_load(at_bytes(m + at, lane_t));
+                vv[q] = __builtin_nontemporal_load(at_bytes(v + at, lane_t));
+            }
+            if (!col_live) continue;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const uint64_t at = (row0 + 8 * (q >> 2) + (q & 3)) * HP;
+                adam_update(acc[q] * is, pp[q], mm[q], vv[q], hy);
+                __builtin_nontemporal_store(pp[q], at_bytes(master + at, lane_t));
+                __builtin_nontemporal_store(mm[q], at_bytes(m + at, lane_t));
+                __builtin_nontemporal_store(vv[q], at_bytes(v + at, lane_t));
+                *at_bytes(f16 + at, lane_t / 2) = (half_t)pp[q];
+            }
+        } else {
+            if (!col_live) continue;
+#pragma unroll 1
+            for (int q = 0; q < 16; ++q) {
+                const uint64_t row = row0 + 8 * (q >> 2) + 4 * kg + (q & 3);
+                if (row >= n_rows) continue;
+                float p1 = master[row * HP + j], m1 = m[row * HP + j], v1 = v[row * HP + j];
+                float gsel = 0.f;
+#pragma unroll
+                for (int qq = 0; qq < 16; ++qq) gsel = qq == q ? acc[qq] : gsel;
+                adam_update(gsel * is, p1, m1, v1, hy);
+                master[row * HP + j] = p1;
+                m[row * HP + j] = m1;
+                v[row * HP + j] = v1;
+                f16[row * HP + j] = (half_t)p1;
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void adam_dense_kernel(const float* __restrict__ grad, int64_t n,
                                                          float* __restrict__ master, float* __restrict__ m,
                                                          float* __restrict__ v, half_t* __restrict__ f16, AdamHyper hy,
@@ -472,6 +654,22 @@ static int adam_hash_factored_entry(float* G, int n_slots, const float* code_tab
     const uint64_t total = g->offset[g->n_levels];
     const AdamHyper hy = make_hyper(lr, beta1, beta2, eps, step);
     hipStream_t st = (hipStream_t)stream;
+    if (n_slots > NSX_MAX_SLOTS && nsx_padded_grids(H) == 32 && total * 2ull * 9ull * 4ull < (1ull << 32)) {
+        const int T = (n_slots + 15) / 16;
+        const size_t smem = (size_t)T * 16 * 32 * 2 * sizeof(unsigned short);
+#define NSX_ADAM_MFMA_CASE(TT) case TT: hipLaunchKernelGGL((adam_hash_factored_mfma_kernel<TT, CLEAR>), \
+        dim3(num_cus() * MFMA_ADAM_WAVES(TT)), \
+        dim3(256), smem, st, G, n_slots, code_table, code_stride, window, H, total, master, exp_avg, exp_avg_sq, \
+        reinterpret_cast<half_t*>(tables_f16), hy, inv_scale, found_inf); break;
+        switch (T) {
+            NSX_ADAM_MFMA_CASE(5) NSX_ADAM_MFMA_CASE(6) NSX_ADAM_MFMA_CASE(7) NSX_ADAM_MFMA_CASE(8) NSX_ADAM_MFMA_CASE(9)
+            NSX_ADAM_MFMA_CASE(10) NSX_ADAM_MFMA_CASE(11) NSX_ADAM_MFMA_CASE(12)
+        }
+#undef NSX_ADAM_MFMA_CASE
+        static_assert(NSX_MAX_ADAM_SLOTS == 12 * 16 && NSX_MAX_SLOTS == 4 * 16, "the K steps instantiated above");
+        NSX_LAUNCH_CHECK("nsx_adam_hash_factored (matrix-core expansion) launch");
+        return NSX_OK;
+    }
 #define NSX_ADAM_CASE(HP) case HP: return launch_adam_factored<HP, CLEAR>(G, n_slots, code_table, code_stride, window, H, \
         total, master, exp_avg, exp_avg_sq, tables_f16, hy, inv_scale, found_inf, st);
     switch (nsx_padded_grids(H)) {

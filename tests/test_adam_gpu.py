@@ -316,3 +316,86 @@ def test_native_scale_update_is_torchs_amp_update(cuda):
     a.load_state_dict({"scale": 64.0, "_growth_tracker": 1})
     g2 = a.loss_grad_vector(8, 5)
     assert g2 is not g and g2[5].item() == 64.0
+
+
+@pytest.mark.parametrize("planes,H,entries", [(192, 32, 4099), (150, 30, 1000), (65, 32, 37)])
+def test_many_plane_pass_forms_the_gradient_on_the_matrix_cores(planes, H, entries, cuda):
+    """More than NSX_MAX_SLOTS gradient planes (level-parallel runs: one per (source rank, code row)): the pass expands
+    G x code with bf16 MFMAs on a three-way split of G -- fp32 accuracy.  Held to an fp64 expansion + the Adam formula, to
+    the VALU pass on <= 64 planes (the other planes zero), and the consuming variant to its contract."""
+    import ctypes as C
+    from nersemble_amd._lib import lib, ptr, stream, check, GridGeom
+    g = torch.Generator(device=cuda).manual_seed(planes)
+    geom = GridGeom()
+    geom.n_levels = 1
+    geom.offset[0], geom.offset[1] = 0, entries
+    G = torch.randn((planes, entries, 2), device=cuda, generator=g)
+    G = G * torch.exp2(torch.randint(-20, 22, G.shape, device=cuda, generator=g).float())     # loss-scaled sums: any magnitude
+    G = torch.where(torch.rand(G.shape, device=cuda, generator=g) < 0.6, torch.zeros_like(G), G)
+    # (fp16 codes and a window in sixteenths: their product is exact in fp32, so its rounding to fp16 is the same single rounding
+    # wherever it is formed -- a product that is itself rounded first can land one fp16 ulp away, once in ~ 2^13 values)
+    code = torch.randn((planes, 32), device=cuda, generator=g)[:, :H].half().float().contiguous()
+    window = torch.randint(1, 17, (H,), device=cuda, generator=g).float() / 16.0
+    window[0] = 1.0
+    inv = torch.tensor([1.0 / 512], device=cuda)
+    zero = torch.zeros(1, device=cuda)
+
+    def state():
+        gs = torch.Generator(device=cuda).manual_seed(7)
+        p = torch.randn((entries, 2, 32), device=cuda, generator=gs)
+        m = torch.randn((entries, 2, 32), device=cuda, generator=gs) * 1e-2
+        v = torch.rand((entries, 2, 32), device=cuda, generator=gs) * 1e-3
+        return p, m, v, torch.zeros((entries, 2, 32), device=cuda, dtype=torch.float16)
+
+    def run(fn, Gt, n, found=zero):
+        p, m, v, h = state()
+        check(fn(ptr(Gt), n, ptr(code), code.stride(0), ptr(window), H, C.byref(geom), ptr(p), ptr(m), ptr(v), ptr(h),
+                 5e-3, 0.9, 0.999, 1e-15, 3, ptr(inv), ptr(found), stream()), "adam")
+        torch.cuda.synchronize()
+        return p, m, v, h
+
+    p, m, v, h = run(lib().nsx_adam_hash_factored, G, planes)
+    cw = (code * window).half().double()                                      # the kernels' fp16-rounded windowed codes
+    grad = torch.einsum("sef,sh->efh", G.double(), cw) * float(inv.item())
+    mag = torch.einsum("sef,sh->efh", G.double().abs(), cw.abs()) * float(inv.item())
+    p0, m0, v0, _ = state()
+    # (the kernels form 1 - beta in fp32 from the fp32 betas of the C-ABI: 1.3e-5 away from the double's 0.001)
+    import numpy as np
+    omb1, b2 = float(np.float32(1) - np.float32(0.9)), float(np.float32(0.999))
+    omb2 = float(np.float32(1) - np.float32(0.999))
+    m_ref = m0[..., :H].double() + (grad - m0[..., :H].double()) * omb1
+    v_ref = v0[..., :H].double() * b2 + omb2 * grad * grad
+    # the first moment is linear in the gradient: its error IS the expansion's error -- fp32 accumulation of <= 192 terms
+    err = (m[..., :H].double() - m_ref).abs()
+    bound = 0.1 * 4e-6 * mag + 3e-7 * (m0[..., :H].abs().double() + 0.1 * grad.abs()) + 1e-30
+    assert bool((err <= bound).all()), (err / bound).max().item()
+    err_g = (4e-6 * mag + 3e-7 * grad.abs())
+    assert bool(((v[..., :H].double() - v_ref).abs() <= 0.001 * (2 * grad.abs() + err_g) * err_g + 3e-7 * v_ref).all())
+    bc1, bc2 = 1 - 0.9 ** 3, (1 - 0.999 ** 3) ** 0.5
+    p_ref = p0[..., :H].double() - (5e-3 / bc1) * (m_ref / (v_ref.sqrt() / bc2 + 1e-15))
+    upd = (p_ref - p0[..., :H].double()).abs()
+    # (the first moment's bound carried through m / denom, + the fp32 rounding of the parameter and of the quotient)
+    carried = (5e-3 / bc1) * 2.0 * bound / (v_ref.sqrt() / bc2 + 1e-15)
+    assert bool(((p[..., :H].double() - p_ref).abs() <= 2e-6 * (1.0 + upd) + carried).all())
+    assert torch.equal(h[..., :H], p[..., :H].half())
+    if H < 32:                                                                # padded grids: never touched
+        assert torch.equal(p[..., H:], p0[..., H:]) and torch.equal(m[..., H:], m0[..., H:])
+    # the VALU pass on the first 64 planes == this pass on all planes with the others zero (up to the sums' rounding)
+    G64 = G.clone()
+    G64[64:] = 0
+    pa, ma, va, _ = run(lib().nsx_adam_hash_factored, G64, planes)
+    pb, mb, vb, _ = run(lib().nsx_adam_hash_factored, G64[:64].contiguous(), 64)
+    mag64 = torch.einsum("sef,sh->efh", G64.double().abs(), cw.abs()) * float(inv.item())
+    assert bool(((ma - mb)[..., :H].abs().double() <= 0.1 * 8e-6 * mag64 + 3e-7 * ma[..., :H].abs().double() + 1e-30).all())
+    assert bool(((pa - pb).abs().double()[..., :H] <= 2e-6 + 2e-5 * (pa - p0).abs().double()[..., :H]).all())
+    # consuming variant: the same bits as the plain pass, G all zeros afterwards; a skipped step leaves the state alone and clears
+    Gc = G.clone()
+    pc, mc, vc, hc = run(lib().nsx_adam_hash_factored_consume, Gc, planes)
+    assert torch.equal(pc, p) and torch.equal(mc, m) and torch.equal(vc, v) and torch.equal(hc, h)
+    assert not Gc.any().item()
+    Gc = G.clone()
+    ps, ms, vs, _ = run(lib().nsx_adam_hash_factored_consume, Gc, planes, found=torch.ones(1, device=cuda))
+    assert torch.equal(ps, p0) and torch.equal(ms, m0) and torch.equal(vs, v0) and not Gc.any().item()
+    Gk = G.clone()
+    ps, ms, vs, _ = run(lib().nsx_adam_hash_factored, Gk, planes, found=torch.ones(1, device=cuda))
+    assert torch.equal(ps, p0) and torch.equal(Gk, G)

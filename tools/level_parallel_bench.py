@@ -36,6 +36,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--samples", default="100000,350000,900000")
     ap.add_argument("--world", default="2,4,8")
+    ap.add_argument("--adam-only", action="store_true", help="only the optimizer passes")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     H, T = 32, 24
@@ -80,7 +81,7 @@ def main():
         return round(timeit(step), 4)
 
     out["replica"] = {"adam_full_table_24_planes_ms": adam(g, 0, g.total_entries, T, False)}
-    for S in [int(s) for s in a.samples.split(",")]:
+    for S in ([] if a.adam_only else [int(s) for s in a.samples.split(",")]):
         out["replica"][f"S={S}"] = kernels(g, f16, S, T, "replica")
     for W in [int(w) for w in a.world.split(",")]:
         n_own = g.n_levels // W
@@ -91,7 +92,7 @@ def main():
             rr = {"levels": [r * n_own, (r + 1) * n_own], "entries": e1 - e0,
                   "adam_slice_ms": adam(sg, e0, e1, min(W * T, 192), False),
                   "adam_slice_consume_ms": adam(sg, e0, e1, min(W * T, 192), True)}
-            for S in [int(s) for s in a.samples.split(",")]:
+            for S in ([] if a.adam_only else [int(s) for s in a.samples.split(",")]):
                 rr[f"S={S}/rank"] = kernels(sg, f16[e0:e1], W * S, min(W * T, 192), "level_parallel")
             res[f"rank{r}"] = rr
         out[f"world_{W}"] = res
