@@ -515,6 +515,14 @@ def _lp_plumbing_worker(rank, world, port, out_dir):
     lp._all_to_all(out, inp)
     for j in range(world):
         ok &= bool((out[j] == 10 * j + rank).all())
+    # ... and the branch RCCL takes (dist.all_to_all_single, which gloo has for CPU tensors) gives the same blocks
+    inp3 = torch.arange(world * S_cap * 3, dtype=torch.float16).reshape(world, S_cap, 3) + 1000 * rank
+    out_a, out_b = torch.empty_like(inp3), torch.empty_like(inp3)
+    lp._all_to_all(out_a, inp3)
+    lp._a2a_native = True
+    lp._all_to_all(out_b, inp3)
+    lp._a2a_native = False
+    ok &= torch.equal(out_a, out_b) and bool((out_b[1 - rank] == inp3[rank] - 1000 * rank + 1000 * (1 - rank)).all())
     # an empty rank takes part
     sizes2, cap2, xs2, _, _ = lp._gather_samples(x[:0] if rank == 1 else x, slot[:0] if rank == 1 else slot, code)
     ok &= sizes2[1][0] == 0 and cap2 == 5 and xs2[1].shape == (0, 3) and torch.equal(xs2[0][:, 0], x[:, 0] if rank == 0 else xs2[0][:, 0])
@@ -531,7 +539,7 @@ def _lp_plumbing_worker(rank, world, port, out_dir):
 
 def test_level_parallel_exchange_plumbing_world2(tmp_path):
     """The collectives of the level-parallel HashEnsemble on CPU tensors over gloo: level ownership and sub-geometries,
-    the ragged all-gather of (positions, code slots, code rows), the block all-to-all (gloo stand-in), an empty rank, the
+    the ragged all-gather of (positions, code slots, code rows), the block all-to-all (gloo stand-in and the all_to_all_single branch RCCL takes), an empty rank, the
     broadcast of the ranks' entry ranges.  The kernels between them run on the GPU (tests/test_sharded_gpu.py)."""
     port = _free_port()
     mp.spawn(_lp_plumbing_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
