@@ -311,16 +311,15 @@ def test_two_ranks_on_half_batches_equal_one_process_on_the_union_batch(cuda, tm
 OPEN_WINDOW = (-10, 1)          # the coarse-to-fine window at step 0: 1 + 15 * 10 / 11 = 14.6 of 16 grids (> H / 2)
 
 
-def _level_worker(rank, world, port, out_dir):
+def _level_worker(rank, world, port, out_dir, workload="p030_h16", per=256):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from nersemble_amd.engine.level_parallel import LevelParallelTableAdam
     from nersemble_amd.workloads import build_workload
-    per = 256
     bundle, batch = _union_data(per * world).next_train(0)
     torch.manual_seed(19980801)
-    trainer, data, _ = build_workload("p030_h16", device="cuda:0", small=True, n_rays=per, rank=rank, world_size=world,
+    trainer, data, _ = build_workload(workload, device="cuda:0", small=True, n_rays=per, rank=rank, world_size=world,
                                       global_loss_normalisers=True, window_hash=OPEN_WINDOW, table_parallel="auto")
     _no_jitter(trainer)
     loss, loss_dict, _ = trainer.train_iteration(0, *_slice_batch(bundle, batch, rank * per, (rank + 1) * per))
@@ -416,6 +415,63 @@ def test_level_parallel_ranks_equal_one_process_on_the_union_batch(cuda, tmp_pat
     assert all(np.isfinite(a["losses_after"])) and all(np.isfinite(b["losses_after"]))
     assert torch.equal(a["tables_after"], b["tables_after"]) and torch.equal(a["small_after"], b["small_after"])
     assert not torch.equal(a["tables_after"], a["tables"]) and a["table_step"] == b["table_step"] == 3
+
+
+def test_four_level_parallel_ranks_with_32_grids_step_through_the_matrix_core_pass(cuda, tmp_path):
+    """world_size 4 on one GPU (gloo), 32 hash grids, 4 levels per rank: every rank brings the 24 code rows of its batch, the
+    owned range's optimizer pass reads 96 gradient planes -- more than NSX_MAX_SLOTS, so ``nsx_adam_hash_factored`` forms the
+    gradient on the matrix cores (csrc/adam.hip) -- in plane order (source rank, code row).  One step on a 512-ray batch sliced
+    4 x 128 equals the single-process step on the whole batch at the bars of the world-2 test."""
+    import torch.multiprocessing as mp
+    from nersemble_amd.workloads import build_workload
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    world = 4
+    mp.spawn(_level_worker, args=(world, port, str(tmp_path), "p030_h32", 128), nprocs=world, join=True)
+    rs = [torch.load(tmp_path / f"l{r}.pt") for r in range(world)]
+    bundle, batch = _union_data(512).next_train(0)
+    torch.manual_seed(19980801)
+    single, _, _ = build_workload("p030_h32", device="cuda:0", small=True, n_rays=512, window_hash=OPEN_WINDOW)
+    init_tables = single.model.field.hash_ensemble.tables.detach().cpu().clone()
+    _no_jitter(single)
+    loss, loss_dict, _ = single.train_iteration(0, bundle, batch)
+    single.flush_scheduler_step()
+    single.consolidate()
+    tables = single.model.field.hash_ensemble.tables.detach().cpu()
+    grads = {n: p.grad.detach().float().cpu() for n, p in single.model.named_parameters()
+             if "tables" not in n and p.grad is not None}
+    moved = (tables - init_tables).abs() > 1e-4
+    assert moved.float().mean().item() > 1e-3 and moved[:, :, 16:].any()
+    bounds = [r["own"] for r in rs]
+    assert bounds[0][0] == 0 and bounds[-1][1] == tables.shape[0] and all(bounds[i][1] == bounds[i + 1][0] for i in range(3))
+    for r in rs:
+        c = r["comm"]
+        assert c["exchange"] == "level_parallel" and c["levels_per_rank"] == 4
+        assert 64 < c["gradient_planes"] <= 96, c["gradient_planes"]             # the matrix-core pass is the one that ran
+        assert torch.equal(r["tables"], rs[0]["tables"]) and torch.equal(r["small"], rs[0]["small"])
+        assert torch.equal(r["tables"].half(), r["f16"])
+        assert torch.equal(r["tables_after"], rs[0]["tables_after"]) and torch.equal(r["small_after"], rs[0]["small_after"])
+        assert all(np.isfinite(r["losses_after"])) and r["table_step"] == 3
+    assert np.isclose(sum(r["loss"] for r in rs) / world, loss.item(), rtol=2e-4)
+    for k, v in loss_dict.items():
+        assert np.isclose(sum(r["terms"][k] for r in rs) / world, v.item(), rtol=2e-3, atol=1e-9), k
+    d = (rs[0]["tables"] - tables).abs()
+    frac = (d[moved] <= 1e-5).float().mean().item()
+    assert frac >= 0.995, frac
+    # ... level range by level range (a plane order that is wrong for ONE owner would hide in the average)
+    for lo, hi in bounds:
+        mv = moved[lo:hi]
+        if mv.any():
+            f = (d[lo:hi][mv] <= 1e-5).float().mean().item()
+            assert f >= 0.99, (lo, hi, f)
+    for name, g_ref in grads.items():
+        sc = g_ref.abs().max().item()
+        for r in rs:
+            err = (r["grads"][name] - g_ref).abs().max().item()
+            assert err <= 2e-3 * sc + 1e-9, (name, err, sc)
+    assert not torch.equal(rs[0]["tables_after"], rs[0]["tables"])
 
 
 def _switch_worker(rank, world, port, out_dir):
