@@ -355,16 +355,25 @@ class ShardedTableAdam(torch.optim.Optimizer):
             handles.append(dist.reduce_scatter_tensor(out, buf, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op))
         return _Handles(handles) if async_op else None
 
+    def _narrow_pieces(self, W: int) -> int:
+        """Reduce-scatter calls of a step whose exchange is W of H grids wide (1 ... n_buckets)."""
+        return max(1, (self.n_buckets * W) // self.Hp)
+
     def _expand_and_reduce_narrow(self, W: int, entries, scale: float, async_op: bool):
         """The bucketed exchange on the grids [0, W): the same pieces, each W / H as long."""
         he, b = self.he, self._buffers()
         per_entry = 2 * self.Hp
-        be = self.bucket // per_entry                            # entries per piece and rank
+        # pieces stay about as long as the full-width ones: K W / H of them, each H / (K W) x as many entries -- at W = 1 the
+        # whole exchange is ONE 12.6 MB reduce-scatter instead of eight of 1.6 MB, whose launch latencies (not their bytes)
+        # were what the links saw.  The entries keep their order in ``grad_shard`` (piece-major = ascending either way).
+        n_pieces = self._narrow_pieces(W)
+        bucket = self.bucket * (self.n_buckets // n_pieces)
+        be = bucket // per_entry                                 # entries per piece and rank
         n_piece = be * 2 * W
         if self._beyond is None or self._beyond.device != b["dev"]:
             self._beyond = torch.zeros((1,), dtype=torch.float32, device=b["dev"])
         handles = []
-        for k in range(self.n_buckets):
+        for k in range(n_pieces):
             buf = b["buckets"][k % 2][:self.world_size * n_piece]
             if k >= 2 and handles[k - 2] is not None:
                 handles[k - 2].wait()
@@ -372,7 +381,7 @@ class ShardedTableAdam(torch.optim.Optimizer):
             if not entries:
                 buf.zero_()
             for i, e in enumerate(entries):
-                self.ops.expand_f16_bucket_width(he, e, buf, scale, i > 0, self.shard, self.bucket, k, self.world_size, W,
+                self.ops.expand_f16_bucket_width(he, e, buf, scale, i > 0, self.shard, bucket, k, self.world_size, W,
                                                  self._beyond)
             self._mark("expand_end")
             if k == 0:
@@ -501,7 +510,10 @@ class ShardedTableAdam(torch.optim.Optimizer):
         W = self.world_size
         # fp16 pieces leaving / arriving per rank, at the width of the LAST step's exchange
         bytes_rs = (W - 1) / W * self.shard * W * 2 * self._last_width / self.Hp
-        out.update(steps=n_steps, buckets=self.n_buckets, world_size=W, exchange_width=self._last_width, grids=self.Hp,
+        lw = self._last_width
+        out.update(steps=n_steps, buckets=self.n_buckets, world_size=W,
+                   reduce_scatter_calls=self.n_buckets if (lw is None or lw >= self.Hp) else self._narrow_pieces(int(lw)),
+                   exchange_width=self._last_width, grids=self.Hp,
                    reduce_scatter_bytes_per_rank=bytes_rs, all_gather_bytes_per_rank=bytes_rs,
                    reduce_scatter_bus_GBps=(bytes_rs / (out["reduce_scatter_ms"] * 1e-3) / 1e9)
                    if out["reduce_scatter_ms"] > 0 else None,

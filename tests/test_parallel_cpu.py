@@ -292,7 +292,8 @@ def _window_worker(rank, world, port, out_dir, narrow):
     moments = (b["exp_avg"].clone(), b["exp_avg_sq"].clone())
     opt.gather_master()
     torch.save({"log": log, "widths": widths, "f16": f16, "master": he.tables.detach().clone(), "moments": moments,
-                "report": opt.comm_report()}, os.path.join(out_dir, f"w{rank}.pt"))
+                "report": opt.comm_report(), "buckets": opt.n_buckets,
+                "pieces": [opt._narrow_pieces(w) for w in (1, 2)]}, os.path.join(out_dir, f"w{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -310,6 +311,8 @@ def test_exchange_that_follows_the_window_equals_the_full_exchange_bit_for_bit(t
     assert res[False][0]["widths"] == [4] * len(_WINDOWS)
     assert res[True][0]["widths"] == res[True][1]["widths"] == [1, 1, 2, 2, 2, 4, 4]
     assert res[True][0]["report"]["exchange_width"] == 4 and res[True][0]["report"]["grids"] == 4
+    # narrow steps travel in FEWER, longer pieces (one reduce-scatter at width 1, two at width 2, four at full width)
+    assert res[True][0]["buckets"] == 4 and res[True][0]["pieces"] == [1, 2] and res[True][0]["report"]["reduce_scatter_calls"] == 4
     for r in range(2):
         assert res[False][r]["log"] == res[True][r]["log"] == [0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0]
         assert torch.equal(res[False][r]["f16"], res[True][r]["f16"])
