@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--samples", default="100000,350000,900000")
     ap.add_argument("--world", default="2,4,8")
     ap.add_argument("--adam-only", action="store_true", help="only the optimizer passes")
+    ap.add_argument("--last-rank-only", action="store_true", help="only the owner of the finest levels (profiling runs)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     H, T = 32, 24
@@ -80,13 +81,13 @@ def main():
                      ptr(v[e0:e1]), ptr(f16[e0:e1]), 0.0, 0.9, 0.999, 1e-15, 3, ptr(one), ptr(zero), stream()), "adam")
         return round(timeit(step), 4)
 
-    out["replica"] = {"adam_full_table_24_planes_ms": adam(g, 0, g.total_entries, T, False)}
+    out["replica"] = {} if a.last_rank_only else {"adam_full_table_24_planes_ms": adam(g, 0, g.total_entries, T, False)}
     for S in ([] if a.adam_only else [int(s) for s in a.samples.split(",")]):
         out["replica"][f"S={S}"] = kernels(g, f16, S, T, "replica")
     for W in [int(w) for w in a.world.split(",")]:
         n_own = g.n_levels // W
         res = {}
-        for r in (0, W - 1):                                  # the coarsest and the finest levels' owner
+        for r in ((W - 1,) if a.last_rank_only else (0, W - 1)):   # the coarsest and the finest levels' owner
             sg = sub_geometry(g, r * n_own, n_own)
             e0, e1 = int(g.offset[r * n_own]), int(g.offset[(r + 1) * n_own])
             rr = {"levels": [r * n_own, (r + 1) * n_own], "entries": e1 - e0,

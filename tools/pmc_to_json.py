@@ -17,6 +17,7 @@ ENTRY_OF = {            # kernel-name prefix -> C-ABI entry point it belongs to
     "nsx::ens_bwd_kernel": "nsx_hash_ensemble_bwd_factored",
     "nsx::ens_scatter_kernel": "nsx_hash_ensemble_bwd_scatter",
     "nsx::adam_hash_factored_kernel": "nsx_adam_hash_factored",
+    "nsx::adam_hash_factored_mfma_kernel": "nsx_adam_hash_factored (> 64 planes: matrix-core expansion)",
     "nsx::deform_bwd_kernel": "nsx_deform_bwd",
     "nsx::deform_wgrad_kernel": "nsx_deform_bwd",
     "nsx::deform_fwd_kernel": "nsx_deform_fwd",
