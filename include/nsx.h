@@ -32,7 +32,7 @@ extern "C" {
 #define NSX_MAX_SLOTS 64
 #define NSX_MAX_ADAM_SLOTS 192   /* gradient planes nsx_adam_hash_factored(_consume) reads (level-parallel runs: one per
                                    (source rank, code row), engine/level_parallel.py) */
-#define NSX_VERSION 120
+#define NSX_VERSION 121
 
 typedef uint16_t nsx_half;
 
@@ -263,9 +263,16 @@ int nsx_generate_rays(const float* camera_to_worlds, const float* fx, const floa
  * outside [0, n_code_rows)) ORs 1 into *flag (device int32, sticky: never cleared here).  One launch, no host read. */
 int nsx_check_code_rows(const float* ray_times, const int32_t* ray_slots, int64_t R, const int32_t* row_timesteps,
                         int n_code_rows, int n_timesteps, int32_t* flag, void* stream);
-#define NSX_MAX_GATHER 8
+#define NSX_MAX_GATHER 12
 int nsx_gather_rows(int n_arrays, const void* const* srcs, const int64_t* row_bytes, void* const* dsts,
                     const int64_t* index, int64_t n, const int64_t* n_device, void* stream);
+/* The same launch with arrays that are indexed by what the index points at: array a with use_via_host[a] != 0 takes
+ * dsts[a][i] = srcs[a][via[index[i]]] (via: device int64) -- the rays' origins / directions of the kept samples
+ * (index = kept sample ids, via = the marched samples' ray indices) beside the per-sample arrays, one launch instead of
+ * two dependent ones. */
+int nsx_gather_rows_via(int n_arrays, const void* const* srcs, const int64_t* row_bytes, void* const* dsts,
+                        const int64_t* index, const int64_t* via, const uint8_t* use_via_host, int64_t n,
+                        const int64_t* n_device, void* stream);
 int nsx_normalise_bwd(const float* grad_pos_normalised, const uint8_t* selector, int64_t S, const float* aabb_host,
                       float* grad_pos_world, const int64_t* n_device, void* stream);
 int nsx_density_fwd(const nsx_half* base_out, int64_t stride, const uint8_t* selector, int64_t S, float* density,
@@ -371,6 +378,12 @@ int nsx_render_weights_fwd(const float* t_starts, const float* t_ends, const flo
                            uint8_t* visibility, float early_stop_eps, float alpha_thre,
                            const float* alpha_thre_dev /* device scalar overriding alpha_thre; may be NULL */,
                            void* stream);
+/* The visibility test alone, with the number of visible samples of every ray (visible_per_ray [R] int64, every entry
+ * written): what OccGridEstimator.sampling does with render_visibility_from_density before it compacts -- the counts
+ * are the kept samples' nerfacc.pack_info input. */
+int nsx_render_visibility(const float* t_starts, const float* t_ends, const float* sigmas, const int64_t* packed_info,
+                          int64_t R, uint8_t* visibility, int64_t* visible_per_ray, float early_stop_eps, float alpha_thre,
+                          const float* alpha_thre_dev /* may be NULL */, void* stream);
 int nsx_render_weights_bwd(const float* t_starts, const float* t_ends, const float* sigmas,
                            const int64_t* packed_info, int64_t R, const float* grad_weights, float* grad_sigmas,
                            void* stream);
@@ -608,6 +621,12 @@ int nsx_occ_compact(const uint8_t* binaries, int64_t n_cells, int32_t* occupied,
  * host synchronisation; here the count stays on the device, to be passed on as n_device).  Neither output needs clearing.
  * scratch: nsx_occ_scratch_bytes(n) bytes. */
 int nsx_compact_mask(const uint8_t* mask, int64_t n, int64_t* kept, int64_t* n_kept, void* scratch, void* stream);
+/* The same compaction when the mask's samples are packed per ray (packed_info_all [R][2]) and the packed_info of the
+ * KEPT samples is already known (packed_info_kept [R][2]: nsx_render_visibility counted per ray, nsx_pack_info scanned):
+ * one wave per ray writes kept[offset_r ...] -- the same ascending list as nsx_compact_mask's, in one launch, and the
+ * kept samples' per-ray counts need no histogram afterwards.  n_kept (may be NULL) receives *total_kept. */
+int nsx_compact_rays(const uint8_t* mask, const int64_t* packed_info_all, const int64_t* packed_info_kept, int64_t R,
+                     int64_t* kept, const int64_t* total_kept, int64_t* n_kept, void* stream);
 
 /* Slot s of the update -> cell id, jittered world position, random timestep and its normalised time t / (T - 1).
  * warmup != 0: slot s is cell s (M = res^3).  Otherwise M = N/4 + min(N/4, n_occ) with n_occ read back by the caller

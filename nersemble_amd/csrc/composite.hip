@@ -43,13 +43,14 @@ __global__ __launch_bounds__(CW * 64) void render_weights_kernel(
     const float* __restrict__ t0, const float* __restrict__ t1, const float* __restrict__ sigma,
     const int64_t* __restrict__ packed, int64_t R, float* __restrict__ weights, float* __restrict__ trans,
     float* __restrict__ alphas, uint8_t* __restrict__ vis, float early_stop_eps, float alpha_thre,
-    const float* __restrict__ alpha_thre_dev) {
+    const float* __restrict__ alpha_thre_dev, int64_t* __restrict__ vis_counts) {
     if (alpha_thre_dev) alpha_thre = alpha_thre_dev[0];
     const int lane = threadIdx.x & 63;
     const int64_t r = (int64_t)blockIdx.x * CW + (threadIdx.x >> 6);
     if (r >= R) return;
     const int64_t s = packed[2 * r], n = packed[2 * r + 1];
     float carry = 0.f;
+    int64_t n_vis = 0;
     for (int64_t base = 0; base < n; base += 64) {
         const int64_t i = base + lane;
         const bool ok = i < n;
@@ -62,10 +63,15 @@ __global__ __launch_bounds__(CW * 64) void render_weights_kernel(
             if (weights) weights[s + i] = T * a;
             if (trans) trans[s + i] = T;
             if (alphas) alphas[s + i] = a;
-            if (vis) vis[s + i] = (T >= early_stop_eps) && (alpha_thre <= 0.f || a >= alpha_thre);
+        }
+        if (vis) {
+            const bool v = ok && (T >= early_stop_eps) && (alpha_thre <= 0.f || a >= alpha_thre);
+            if (ok) vis[s + i] = v;
+            if (vis_counts) n_vis += __popcll(__ballot(v));
         }
         carry += __shfl(incl, 63);
     }
+    if (vis_counts && lane == 0) vis_counts[r] = n_vis;
 }
 
 // dL/dsigma_i = dt_i * ( gw_i * T_{i+1} - sum_{j>i} gw_j w_j )
@@ -502,8 +508,22 @@ int nsx_render_weights_fwd(const float* t_starts, const float* t_ends, const flo
     NSX_REQUIRE(t_starts && t_ends && sigmas && packed_info, "nsx_render_weights_fwd: NULL argument");
     hipLaunchKernelGGL(render_weights_kernel, dim3((unsigned)((R + CW - 1) / CW)), dim3(CW * 64), 0, (hipStream_t)stream,
                        t_starts, t_ends, sigmas, packed_info, R, weights, trans, alphas, visibility, early_stop_eps,
-                       alpha_thre, alpha_thre_dev);
+                       alpha_thre, alpha_thre_dev, nullptr);
     NSX_LAUNCH_CHECK("nsx_render_weights_fwd launch");
+    return NSX_OK;
+}
+
+int nsx_render_visibility(const float* t_starts, const float* t_ends, const float* sigmas, const int64_t* packed_info,
+                          int64_t R, uint8_t* visibility, int64_t* visible_per_ray, float early_stop_eps, float alpha_thre,
+                          const float* alpha_thre_dev, void* stream) {
+    NSX_REQUIRE(R >= 0, "nsx_render_visibility: negative ray count");
+    if (R == 0) return NSX_OK;
+    NSX_REQUIRE(t_starts && t_ends && sigmas && packed_info && visibility && visible_per_ray,
+                "nsx_render_visibility: NULL argument");
+    hipLaunchKernelGGL(render_weights_kernel, dim3((unsigned)((R + CW - 1) / CW)), dim3(CW * 64), 0, (hipStream_t)stream,
+                       t_starts, t_ends, sigmas, packed_info, R, nullptr, nullptr, nullptr, visibility, early_stop_eps,
+                       alpha_thre, alpha_thre_dev, visible_per_ray);
+    NSX_LAUNCH_CHECK("nsx_render_visibility launch");
     return NSX_OK;
 }
 

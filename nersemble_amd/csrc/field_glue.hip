@@ -97,6 +97,7 @@ struct GatherArgs {
     uint8_t* dst[NSX_MAX_GATHER];
     int words[NSX_MAX_GATHER];       // row length in pieces (uint32 or uint4)
     int vec[NSX_MAX_GATHER];         // 1: uint4 pieces, 0: uint32 pieces
+    int via[NSX_MAX_GATHER];         // 1: the row is via[index[i]] (an array indexed by what the index points at)
     int n_arrays;
 };
 
@@ -104,7 +105,8 @@ struct GatherArgs {
 // same launch: the caller's arrays keep the capacity, and nothing downstream ever sees uninitialised rows (this used to be
 // a torch fill in front of every call).
 __global__ __launch_bounds__(256) void gather_rows_kernel(GatherArgs A, const int64_t* __restrict__ index, int64_t n,
-                                                          const int64_t* __restrict__ n_dev) {
+                                                          const int64_t* __restrict__ n_dev,
+                                                          const int64_t* __restrict__ via) {
     int64_t n_valid = n;
     if (n_dev) {
         const int64_t c = *n_dev;
@@ -113,19 +115,32 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(GatherArgs A, const in
     const int a = blockIdx.y;
     const int64_t words = A.words[a];
     const int64_t total = n * words, valid = n_valid * words;
+    const bool hop = A.via[a] != 0;
     if (A.vec[a]) {
         const uint4* src = reinterpret_cast<const uint4*>(A.src[a]);
         uint4* dst = reinterpret_cast<uint4*>(A.dst[a]);
         for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
             const int64_t row = i / words, w = i - row * words;
-            dst[i] = i < valid ? src[index[row] * words + w] : make_uint4(0u, 0u, 0u, 0u);
+            uint4 val = make_uint4(0u, 0u, 0u, 0u);
+            if (i < valid) {
+                int64_t at = index[row];
+                if (hop) at = via[at];
+                val = src[at * words + w];
+            }
+            dst[i] = val;
         }
     } else {
         const uint32_t* src = reinterpret_cast<const uint32_t*>(A.src[a]);
         uint32_t* dst = reinterpret_cast<uint32_t*>(A.dst[a]);
         for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
             const int64_t row = i / words, w = i - row * words;
-            dst[i] = i < valid ? src[index[row] * words + w] : 0u;
+            uint32_t val = 0u;
+            if (i < valid) {
+                int64_t at = index[row];
+                if (hop) at = via[at];
+                val = src[at * words + w];
+            }
+            dst[i] = val;
         }
     }
 }
@@ -177,8 +192,25 @@ int nsx_sample_positions(const float* origins, const float* directions, const in
     return NSX_OK;
 }
 
+static int gather_rows(int n_arrays, const void* const* srcs, const int64_t* row_bytes, void* const* dsts,
+                       const int64_t* index, const int64_t* via, const uint8_t* use_via, int64_t n, const int64_t* n_device,
+                       void* stream);
+
 int nsx_gather_rows(int n_arrays, const void* const* srcs, const int64_t* row_bytes, void* const* dsts,
                     const int64_t* index, int64_t n, const int64_t* n_device, void* stream) {
+    return gather_rows(n_arrays, srcs, row_bytes, dsts, index, nullptr, nullptr, n, n_device, stream);
+}
+
+int nsx_gather_rows_via(int n_arrays, const void* const* srcs, const int64_t* row_bytes, void* const* dsts,
+                        const int64_t* index, const int64_t* via, const uint8_t* use_via_host, int64_t n,
+                        const int64_t* n_device, void* stream) {
+    NSX_REQUIRE(via && use_via_host, "nsx_gather_rows_via: NULL argument");
+    return gather_rows(n_arrays, srcs, row_bytes, dsts, index, via, use_via_host, n, n_device, stream);
+}
+
+static int gather_rows(int n_arrays, const void* const* srcs, const int64_t* row_bytes, void* const* dsts,
+                       const int64_t* index, const int64_t* via, const uint8_t* use_via, int64_t n, const int64_t* n_device,
+                       void* stream) {
     NSX_REQUIRE(n >= 0, "nsx_gather_rows: negative row count");
     NSX_REQUIRE(n_arrays >= 1 && n_arrays <= NSX_MAX_GATHER, "nsx_gather_rows: n_arrays=%d not in [1,%d]", n_arrays,
                 NSX_MAX_GATHER);
@@ -196,11 +228,12 @@ int nsx_gather_rows(int n_arrays, const void* const* srcs, const int64_t* row_by
         const bool vec = row_bytes[a] % 16 == 0 && (reinterpret_cast<uintptr_t>(srcs[a]) & 15) == 0 &&
                          (reinterpret_cast<uintptr_t>(dsts[a]) & 15) == 0;
         A.vec[a] = vec ? 1 : 0;
+        A.via[a] = (use_via && use_via[a]) ? 1 : 0;
         A.words[a] = (int)(row_bytes[a] / (vec ? 16 : 4));
         if (n * A.words[a] > max_pieces) max_pieces = n * A.words[a];
     }
     hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for(max_pieces), n_arrays), dim3(256), 0, (hipStream_t)stream, A, index, n,
-                       n_device);
+                       n_device, via);
     NSX_LAUNCH_CHECK("nsx_gather_rows launch");
     return NSX_OK;
 }

@@ -289,11 +289,47 @@ __global__ __launch_bounds__(256) void ray_hist_kernel(const int64_t* __restrict
     }
 }
 
+// Stream compaction of a per-sample mask whose samples are packed per ray, with the kept samples' packed_info already
+// known (the visibility kernel counted per ray, nsx_pack_info scanned the counts): one wave per ray writes the ascending
+// indices of its visible samples at the ray's offset -- the output of the three-kernel scan compaction (nsx_compact_mask)
+// without its passes over the mask, and no histogram of the kept ray indices afterwards.
+constexpr int kCompactWaves = 4;
+__global__ __launch_bounds__(kCompactWaves * 64) void compact_rays_kernel(
+    const uint8_t* __restrict__ mask, const int64_t* __restrict__ packed_all, const int64_t* __restrict__ packed_kept,
+    int64_t R, int64_t* __restrict__ kept, const int64_t* __restrict__ total, int64_t* __restrict__ n_kept) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * kCompactWaves + (threadIdx.x >> 6);
+    if (r == 0 && lane == 0 && n_kept) n_kept[0] = total[0];
+    if (r >= R) return;
+    const int64_t s = packed_all[2 * r], n = packed_all[2 * r + 1];
+    int64_t out = packed_kept[2 * r];
+    for (int64_t base = 0; base < n; base += 64) {
+        const int64_t i = base + lane;
+        const bool v = i < n && mask[s + i] != 0;
+        const unsigned long long m = __ballot(v);
+        if (v) kept[out + __popcll(m & ((1ull << lane) - 1ull))] = s + i;
+        out += __popcll(m);
+    }
+}
+
 }  // namespace nsx
 
 using namespace nsx;
 
 extern "C" {
+
+int nsx_compact_rays(const uint8_t* mask, const int64_t* packed_info_all, const int64_t* packed_info_kept, int64_t R,
+                     int64_t* kept, const int64_t* total_kept, int64_t* n_kept, void* stream) {
+    NSX_REQUIRE(R >= 0, "nsx_compact_rays: negative ray count");
+    if (R == 0) return NSX_OK;
+    NSX_REQUIRE(mask && packed_info_all && packed_info_kept && kept, "nsx_compact_rays: NULL argument");
+    NSX_REQUIRE(!n_kept || total_kept, "nsx_compact_rays: n_kept requires total_kept");
+    hipLaunchKernelGGL(compact_rays_kernel, dim3((unsigned)((R + kCompactWaves - 1) / kCompactWaves)),
+                       dim3(kCompactWaves * 64), 0, (hipStream_t)stream, mask, packed_info_all, packed_info_kept, R, kept,
+                       total_kept, n_kept);
+    NSX_LAUNCH_CHECK("nsx_compact_rays launch");
+    return NSX_OK;
+}
 
 static int check_march(const char* who, const float* rays_o, const float* rays_d, const float* aabb,
                        const uint8_t* binary, int res, const float* near, float step) {

@@ -243,35 +243,27 @@ int nsx_step_sample_run(const nsx_step_sample* a, void* stream) {
              nsx_mlp_fwd(a->base_w16, a->base_hidden, S, nullptr, 0, 0, 1.0f, 0.0f, m_feat, 32, 0, 32, a->base_out_dim,
                          a->base_act, m_base, a->base_out_dim, nullptr, stream));
     NSX_TRY(nsx_density_fwd(m_base, a->base_out_dim, m_sel, S, m_dens, nullptr, stream));
-    // -- visibility test (nerfacc: T >= early_stop_eps && alpha >= min(alpha_thre, occs.mean())), stream compaction
-    NSX_TRY(nsx_render_weights_fwd(m_t0, m_t1, m_dens, a->packed_march, R, nullptr, nullptr, nullptr, m_vis,
-                                   a->early_stop_eps, 0.0f, a->alpha_thre_dev, stream));
-    NSX_TRY(nsx_compact_mask(m_vis, S, m_keep, n_kept, w + p.m_scratch, stream));
-    // -- the kept samples: intervals, then the rays' fields, then the sigma pass's forward values (all under n_kept)
-    int64_t* k_ri = at<int64_t>(w, p.k_ri);
+    // -- visibility test (nerfacc: T >= early_stop_eps && alpha >= min(alpha_thre, occs.mean())) with the visible samples
+    //    of every ray counted in the same launch; nerfacc.pack_info of the KEPT samples (nersemble_instant_ngp.py:325) is the
+    //    scan of those counts, and with it the compaction is one wave per ray (round 4: mask -> three-kernel scan
+    //    compaction -> gathers -> memset -> histogram of the kept ray indices -> scan: 10 launches, now 4)
+    int64_t* k_counts = at<int64_t>(w, p.k_counts);
+    int64_t* k_packed = at<int64_t>(w, p.k_packed);
+    int64_t* k_total = at<int64_t>(w, p.k_total);
+    NSX_TRY(nsx_render_visibility(m_t0, m_t1, m_dens, a->packed_march, R, m_vis, k_counts, a->early_stop_eps, 0.0f,
+                                  a->alpha_thre_dev, stream));
+    NSX_TRY(nsx_pack_info(k_counts, R, k_packed, k_total, stream));
+    NSX_TRY(nsx_compact_rays(m_vis, a->packed_march, k_packed, R, m_keep, k_total, n_kept, stream));
+    // -- the kept samples: ray index and interval, the rays' fields (through the marched samples' ray indices), the sigma
+    //    pass's forward values -- one launch, rows [*n_kept, S) of every destination zeroed
     {
-        const void* srcs[3] = {m_ri, m_t0, m_t1};
-        void* dsts[3] = {k_ri, w + p.k_t0, w + p.k_t1};
-        const int64_t rb[3] = {8, 4, 4};
-        NSX_TRY(nsx_gather_rows(3, srcs, rb, dsts, m_keep, S, n_kept, stream));
+        const void* srcs[9] = {m_ri, m_t0, m_t1, a->origins, a->directions, m_off, m_feat, m_base, m_slot};
+        void* dsts[9] = {w + p.k_ri, w + p.k_t0, w + p.k_t1, w + p.k_org, w + p.k_dir, w + p.k_off, w + p.k_feat,
+                         w + p.k_base, w + p.k_slot};
+        const int64_t rb[9] = {8, 4, 4, 12, 12, 12, 64, 32, 4};
+        const uint8_t hop[9] = {0, 0, 0, 1, 1, 0, 0, 0, 0};
+        NSX_TRY(nsx_gather_rows_via(9, srcs, rb, dsts, m_keep, m_ri, hop, S, n_kept, stream));
     }
-    {
-        const void* srcs[2] = {a->origins, a->directions};
-        void* dsts[2] = {w + p.k_org, w + p.k_dir};
-        const int64_t rb[2] = {12, 12};
-        NSX_TRY(nsx_gather_rows(2, srcs, rb, dsts, k_ri, S, n_kept, stream));
-    }
-    {
-        const void* srcs[4] = {m_off, m_feat, m_base, m_slot};
-        void* dsts[4] = {w + p.k_off, w + p.k_feat, w + p.k_base, w + p.k_slot};
-        const int64_t rb[4] = {12, 64, 32, 4};
-        NSX_TRY(nsx_gather_rows(4, srcs, rb, dsts, m_keep, S, n_kept, stream));
-    }
-    // -- nerfacc.pack_info of the kept samples (nersemble_instant_ngp.py:325)
-    if (hipMemsetAsync(w + p.k_counts, 0, (size_t)R * 8, (hipStream_t)stream) != hipSuccess)
-        return hip_fail(hipGetLastError(), "nsx_step_sample_run: clearing the ray counts");
-    NSX_TRY(nsx_ray_histogram(k_ri, S, R, at<int64_t>(w, p.k_counts), n_kept, stream));
-    NSX_TRY(nsx_pack_info(at<int64_t>(w, p.k_counts), R, at<int64_t>(w, p.k_packed), at<int64_t>(w, p.k_total), stream));
     return NSX_OK;
 }
 

@@ -302,3 +302,88 @@ def test_gather_rows_matches_indexing(cuda):
         got = gather_rows(idx, a, b, c, d, e)
         for t, o in zip((a, b, c, d, e), got):
             assert o.dtype == t.dtype and torch.equal(o, t[idx])
+
+
+@pytest.mark.parametrize("R,mean_n", [(1, 300), (517, 90), (4096, 200)])
+def test_ray_wise_compaction_equals_the_scan_compaction(R, mean_n, cuda):
+    """The sampler tail of the native step (csrc/step.hip): visibility with per-ray counts (nsx_render_visibility) ->
+    nsx_pack_info -> one wave per ray writes the kept indices (nsx_compact_rays) -> ONE gather for the per-sample rows and
+    the rays' rows (nsx_gather_rows_via) -- against the round-4 sequence it replaces: nsx_render_weights_fwd ->
+    nsx_compact_mask -> nsx_gather_rows x 3 -> nsx_ray_histogram -> nsx_pack_info.  Bit for bit, zero tails included; rays
+    without samples, rays longer than a wave, all / none visible."""
+    import ctypes as C
+    from nersemble_amd._lib import lib, ptr, stream, check
+    g = torch.Generator(device=cuda).manual_seed(R)
+    counts = torch.randint(0, 2 * mean_n, (R,), device=cuda, generator=g)
+    counts[torch.rand((R,), device=cuda, generator=g) < 0.15] = 0
+    if R > 3:
+        counts[1], counts[2] = 64, 65
+    S = int(counts.sum().item())
+    if S == 0:
+        counts[0] = 5
+        S = 5
+    packed = torch.stack([torch.cumsum(counts, 0) - counts, counts], 1).contiguous()
+    m_ri = torch.repeat_interleave(torch.arange(R, device=cuda), counts)
+    t0 = torch.rand((S,), device=cuda, generator=g)
+    t1 = t0 + 0.01 + 0.02 * torch.rand((S,), device=cuda, generator=g)
+    org, dirs = torch.randn((R, 3), device=cuda, generator=g), torch.randn((R, 3), device=cuda, generator=g)
+    off = torch.randn((S, 3), device=cuda, generator=g)
+    feat = torch.randn((S, 32), device=cuda, generator=g).half()
+    base = torch.randn((S, 16), device=cuda, generator=g).half()
+    slot = torch.randint(0, 24, (S,), device=cuda, generator=g, dtype=torch.int32)
+    thre = torch.tensor([0.01], device=cuda)
+
+    def arrays(n):
+        return [torch.full((S,) + sh, -7, dtype=dt, device=cuda) for sh, dt in
+                (((), torch.int64), ((), torch.float32), ((), torch.float32), ((3,), torch.float32), ((3,), torch.float32),
+                 ((3,), torch.float32), ((32,), torch.float16), ((16,), torch.float16), ((), torch.int32))][:n]
+
+    def pointers(ts):
+        return (C.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+
+    for sig_scale, thre_v in ((3.0, 0.01), (0.0, 0.01), (1e-4, 0.0), (1e4, 0.01)):   # a mix / nothing / everything / the rays' heads
+        thre.fill_(thre_v)
+        dens = torch.rand((S,), device=cuda, generator=g) * sig_scale * 20
+        # -- the sequence of round 4
+        vis_a = torch.zeros((S,), dtype=torch.uint8, device=cuda)
+        check(lib().nsx_render_weights_fwd(ptr(t0), ptr(t1), ptr(dens), ptr(packed), R, None, None, None, ptr(vis_a), 1e-4, 0.0,
+                                           ptr(thre), stream()), "vis")
+        keep_a = torch.full((S,), -1, dtype=torch.int64, device=cuda)
+        n_a = torch.zeros((1,), dtype=torch.int64, device=cuda)
+        scratch = torch.empty((int(lib().nsx_occ_scratch_bytes(S)),), dtype=torch.uint8, device=cuda)
+        check(lib().nsx_compact_mask(ptr(vis_a), S, ptr(keep_a), ptr(n_a), ptr(scratch), stream()), "compact")
+        out_a = arrays(9)
+        rb = (C.c_int64 * 3)(8, 4, 4)
+        check(lib().nsx_gather_rows(3, pointers([m_ri, t0, t1]), rb, pointers(out_a[:3]), ptr(keep_a), S, ptr(n_a), stream()), "g1")
+        rb = (C.c_int64 * 2)(12, 12)
+        check(lib().nsx_gather_rows(2, pointers([org, dirs]), rb, pointers(out_a[3:5]), ptr(out_a[0]), S, ptr(n_a), stream()), "g2")
+        rb = (C.c_int64 * 4)(12, 64, 32, 4)
+        check(lib().nsx_gather_rows(4, pointers([off, feat, base, slot]), rb, pointers(out_a[5:]), ptr(keep_a), S, ptr(n_a),
+                                    stream()), "g3")
+        cnt_a = torch.zeros((R,), dtype=torch.int64, device=cuda)
+        check(lib().nsx_ray_histogram(ptr(out_a[0]), S, R, ptr(cnt_a), ptr(n_a), stream()), "hist")
+        pk_a, tot_a = torch.zeros((R, 2), dtype=torch.int64, device=cuda), torch.zeros((1,), dtype=torch.int64, device=cuda)
+        check(lib().nsx_pack_info(ptr(cnt_a), R, ptr(pk_a), ptr(tot_a), stream()), "pack")
+        # -- the sequence of round 5
+        vis_b = torch.zeros((S,), dtype=torch.uint8, device=cuda)
+        cnt_b = torch.full((R,), -3, dtype=torch.int64, device=cuda)
+        check(lib().nsx_render_visibility(ptr(t0), ptr(t1), ptr(dens), ptr(packed), R, ptr(vis_b), ptr(cnt_b), 1e-4, 0.0,
+                                          ptr(thre), stream()), "vis2")
+        pk_b, tot_b = torch.zeros((R, 2), dtype=torch.int64, device=cuda), torch.zeros((1,), dtype=torch.int64, device=cuda)
+        check(lib().nsx_pack_info(ptr(cnt_b), R, ptr(pk_b), ptr(tot_b), stream()), "pack2")
+        keep_b = torch.full((S,), -1, dtype=torch.int64, device=cuda)
+        n_b = torch.zeros((1,), dtype=torch.int64, device=cuda)
+        check(lib().nsx_compact_rays(ptr(vis_b), ptr(packed), ptr(pk_b), R, ptr(keep_b), ptr(tot_b), ptr(n_b), stream()), "rays")
+        out_b = arrays(9)
+        rb = (C.c_int64 * 9)(8, 4, 4, 12, 12, 12, 64, 32, 4)
+        hop = (C.c_uint8 * 9)(0, 0, 0, 1, 1, 0, 0, 0, 0)
+        check(lib().nsx_gather_rows_via(9, pointers([m_ri, t0, t1, org, dirs, off, feat, base, slot]), rb, pointers(out_b),
+                                        ptr(keep_b), ptr(m_ri), hop, S, ptr(n_b), stream()), "via")
+        torch.cuda.synchronize()
+        n = int(n_a.item())
+        assert int(n_b.item()) == n == int(tot_b.item()) == int(tot_a.item()) == int(vis_a.sum().item())
+        assert n == (0 if sig_scale == 0.0 else S if thre_v == 0.0 else n) and (0 < n < S or sig_scale in (0.0, 1e-4))
+        assert torch.equal(vis_a, vis_b) and torch.equal(keep_a[:n], keep_b[:n])
+        assert torch.equal(cnt_a, cnt_b) and torch.equal(pk_a, pk_b)
+        for x, y in zip(out_a, out_b):
+            assert torch.equal(x.view(torch.uint8), y.view(torch.uint8))           # (bytes: the zero tails included)
