@@ -16,11 +16,8 @@ for them; the table gradient goes to the HashEnsemble's factored sink as in the 
 for bit, same gradients up to the order of atomics).
 """
 import ctypes as C
-from typing import Dict, Optional
-
 import torch
 
-from .. import _lib
 from .. import distloss as dl
 from .. import functional as F
 from .._lib import check, device_count, lib, ndev, ptr, stream

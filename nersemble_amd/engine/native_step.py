@@ -22,7 +22,7 @@ import torch
 from .. import _lib
 from .. import distloss as dl
 from .. import functional as F
-from .._lib import check, lib, ptr, stream
+from .._lib import check, lib, stream
 
 
 def _view(buf: torch.Tensor, off: int, shape, dtype) -> torch.Tensor:

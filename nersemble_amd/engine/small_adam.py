@@ -13,7 +13,6 @@ LR schedulers, ``state`` / ``state_dict`` with ``exp_avg`` / ``exp_avg_sq`` / ``
 
 Semantics are torch.optim.Adam's (no amsgrad, no weight decay); parameters without a gradient are left alone.
 """
-import ctypes as C
 from typing import Dict, List, Optional, Sequence
 
 import torch
