@@ -654,6 +654,10 @@ def main():
                          "of parameters (engine/level_parallel.py); auto: shard while the coarse-to-fine window is below "
                          "H / 2, level from then on")
     ap.add_argument("--no-open-window", action="store_true", help="skip the `open_window` block")
+    ap.add_argument("--sharded-one-rank", action="store_true",
+                    help="N = 1 only: the table step of a data-parallel rank (ShardedTableAdam: fp16 expansion, reduce-scatter "
+                         "and all-gather through RCCL on a ONE-rank group, Adam on the shard) instead of the fused "
+                         "single-GPU pass -- what a rank of an N-GPU job computes per step, without the links")
     ap.add_argument("--no-kernels-alone", action="store_true", help="skip the stand-alone kernel timings after the run")
     ap.add_argument("--with-datamanager", action="store_true",
                     help="draw every batch INSIDE the timed loop through NeRSembleVanillaDataManager.next_train (24-image "
@@ -685,6 +689,17 @@ def main():
         else:
             dist.init_process_group(backend=a.backend)
     assert a.gpus == world, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    if a.sharded_one_rank:
+        assert world == 1, "--sharded-one-rank is a single-process measurement"
+        import socket
+        s_ = socket.socket()
+        s_.bind(("127.0.0.1", 0))
+        os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(s_.getsockname()[1])
+        s_.close()
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend=a.backend, rank=0, world_size=1,
+                                **({"device_id": torch.device(f"cuda:{local_rank}")} if a.backend == "nccl" else {}))
     dev = f"cuda:{local_rank}"
     torch.cuda.set_device(local_rank)
 
@@ -705,7 +720,8 @@ def main():
                                          global_loss_normalisers=(a.scaling == "strong" and world > 1),
                                          compact_first_grid=a.compact_first_grid,
                                          window_hash=tuple(a.window_hash) if a.window_hash else None,
-                                         table_parallel=a.table_parallel)
+                                         table_parallel=a.table_parallel,
+                                         **({"sharded_table_adam": True} if a.sharded_one_rank else {}))
     if a.reserve_gb > 0:
         reserve = torch.empty(int(a.reserve_gb * 2 ** 30), dtype=torch.uint8, device=dev)
         del reserve
@@ -830,7 +846,7 @@ def main():
     n = torch.tensor([samples], device=dev, dtype=torch.int64)
     dt_all = [dt]
     comm = None
-    if world > 1:
+    if world > 1 or a.sharded_one_rank:
         every = torch.zeros((world,), device=dev, dtype=torch.float64)
         dist.all_gather_into_tensor(every, t)
         dt_all = every.tolist()
@@ -893,6 +909,8 @@ def main():
                        "occupancy_grid": "state at the end of the warm-up kept for the timed region; the update runs on "
                                          "schedule, its result is not adopted" if a.grid == "frozen" else "live",
                        "rccl_ranks": world if (world > 1 and a.backend == "nccl") else 0,
+                       "table_step": ("one rank of a data-parallel job: ShardedTableAdam on a one-rank group (NOT the headline)"
+                                      if a.sharded_one_rank else type(table_opt).__name__),
                        "early_table_step": bool(trainer.early_table_step),
                        "march_count_one_step_ahead": bool(trainer.prefetch_march),
                        "table_adam_consumes_gradient": bool(getattr(table_opt, "consume_gradient", False)),
@@ -952,7 +970,7 @@ def main():
                 and a.preroll == 0 and a.window_hash is None:
             out["with_datamanager"] = with_datamanager_block(a)
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or a.sharded_one_rank:
         dist.destroy_process_group()
 
 

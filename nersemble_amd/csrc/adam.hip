@@ -502,6 +502,84 @@ __global__ __launch_bounds__(256) void tables_unpack_width_kernel(const half_t* 
     }
 }
 
+// The same expansion for the first W <= 4 grids of a padded width HP >= 8 (the narrow exchange of the schedule's first grid
+// and of the first steps of its ramp).  In the kernel above only the threads of the first grid quad work then -- 1 / 8 of a
+// block at HP = 32 -- behind an LDS staging of 32-entry tiles with two barriers each: 0.70 ms for the 1.2 GB of G where the
+// bytes take 0.15 ms.  Here a thread owns one entry (both features): its values of every plane are one 8-byte load each,
+// coalesced across the wave, nothing is staged, and the 2 W results leave as one vector store.  The arithmetic per element
+// is the kernel's above (the planes in ascending order, fmaf, zeros skipped): the same bits.
+template <int W>
+__global__ __launch_bounds__(256) void expand_f16_narrow_kernel(
+    const float* __restrict__ G, int n_slots, const float* __restrict__ code, int64_t code_stride,
+    const float* __restrict__ window, int Hreal, int HP, uint64_t total, half_t* __restrict__ out, float scale,
+    int accumulate, uint64_t bucket_entries, uint64_t rank_entries, uint64_t entry_base, uint64_t virtual_total,
+    float* __restrict__ beyond_width) {
+    extern __shared__ float smem[];
+    float* cs = smem;                                         // [n_slots][W]
+    for (int i = threadIdx.x; i < n_slots * HP; i += blockDim.x) {
+        const int sl = i / HP, h = i % HP;
+        float c = 0.f;
+        if (h < Hreal) c = code[sl * code_stride + h] * (window ? window[h] : 1.0f);
+        c = (float)(half_t)c;
+        if (h < W) cs[sl * W + h] = c;
+        else if (c != 0.f && beyond_width) beyond_width[0] = 1.0f;
+    }
+    __syncthreads();
+    const uint64_t n_walk = bucket_entries ? virtual_total : total;
+    const float2* G2 = reinterpret_cast<const float2*>(G);
+    for (uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; v < n_walk; v += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t e = bucket_entries ? (v / bucket_entries) * rank_entries + entry_base + (v % bucket_entries) : v;
+        float g0[W], g1[W];
+#pragma unroll
+        for (int k = 0; k < W; ++k) { g0[k] = 0.f; g1[k] = 0.f; }
+        if (e < total) {
+            int sl = 0;
+            for (; sl + 4 <= n_slots; sl += 4) {              // four planes in flight
+                float2 q[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) q[u] = G2[(uint64_t)(sl + u) * total + e];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (q[u].x != 0.f) {
+#pragma unroll
+                        for (int k = 0; k < W; ++k) g0[k] = __fmaf_rn(q[u].x, cs[(sl + u) * W + k], g0[k]);
+                    }
+                    if (q[u].y != 0.f) {
+#pragma unroll
+                        for (int k = 0; k < W; ++k) g1[k] = __fmaf_rn(q[u].y, cs[(sl + u) * W + k], g1[k]);
+                    }
+                }
+            }
+            for (; sl < n_slots; ++sl) {
+                const float2 q = G2[(uint64_t)sl * total + e];
+                if (q.x != 0.f) {
+#pragma unroll
+                    for (int k = 0; k < W; ++k) g0[k] = __fmaf_rn(q.x, cs[sl * W + k], g0[k]);
+                }
+                if (q.y != 0.f) {
+#pragma unroll
+                    for (int k = 0; k < W; ++k) g1[k] = __fmaf_rn(q.y, cs[sl * W + k], g1[k]);
+                }
+            }
+        }
+        half_t* dst = out + v * 2ull * W;                     // [entry][f][W]
+        half_t res[2 * W];
+#pragma unroll
+        for (int k = 0; k < W; ++k) {
+            const float p0 = accumulate ? (float)dst[k] : 0.f, p1 = accumulate ? (float)dst[W + k] : 0.f;
+            res[k] = (half_t)(p0 + scale * g0[k]);
+            res[W + k] = (half_t)(p1 + scale * g1[k]);
+        }
+        if (W == 1) {
+            *reinterpret_cast<uint32_t*>(dst) = *reinterpret_cast<const uint32_t*>(res);
+        } else if (W == 2) {
+            *reinterpret_cast<uint2*>(dst) = *reinterpret_cast<const uint2*>(res);
+        } else {
+            *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(res);
+        }
+    }
+}
+
 template <int HP>
 static int launch_expand_f16(const float* G, int n_slots, const float* code, int64_t code_stride, const float* window,
                              int H, uint64_t total, nsx_half* out, float scale, int accumulate, hipStream_t st,
@@ -511,6 +589,18 @@ static int launch_expand_f16(const float* G, int n_slots, const float* code, int
     constexpr int EPB = 256 / (2 * HP / HV);
     NSX_REQUIRE(bucket_entries % EPB == 0, "nsx_hash_grad_expand_f16_bucket: bucket of %llu entries is not a multiple of "
                 "the kernel's tile (%d entries)", (unsigned long long)bucket_entries, EPB);
+    if (HP >= 8 && out_width <= 4 && (reinterpret_cast<uintptr_t>(G) & 7) == 0 &&
+        (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
+        const size_t smem_n = (size_t)n_slots * out_width * sizeof(float);
+        const dim3 grid(num_cus() * 8), block(256);
+#define NSX_EXPN_CASE(WW) case WW: hipLaunchKernelGGL((expand_f16_narrow_kernel<WW>), grid, block, smem_n, st, G, n_slots, code, \
+        code_stride, window, H, HP, total, reinterpret_cast<half_t*>(out), scale, accumulate, bucket_entries, rank_entries, \
+        entry_base, virtual_total, beyond_width); break;
+        switch (out_width) { NSX_EXPN_CASE(1) NSX_EXPN_CASE(2) NSX_EXPN_CASE(4) }
+#undef NSX_EXPN_CASE
+        NSX_LAUNCH_CHECK("nsx_hash_grad_expand_f16 (narrow) launch");
+        return NSX_OK;
+    }
     const size_t smem = ((size_t)n_slots * HP + (size_t)n_slots * EPB * 2) * sizeof(float);
     hipLaunchKernelGGL((expand_f16_kernel<HP>), dim3(num_cus() * 8), dim3(256), smem, st, G, n_slots, code, code_stride,
                        window, H, total, reinterpret_cast<half_t*>(out), scale, accumulate, bucket_entries, rank_entries,
