@@ -502,10 +502,10 @@ __global__ __launch_bounds__(256) void tables_unpack_width_kernel(const half_t* 
     }
 }
 
-// The same expansion for the first W <= 4 grids of a padded width HP >= 8 (the narrow exchange of the schedule's first grid
-// and of the first steps of its ramp).  In the kernel above only the threads of the first grid quad work then -- 1 / 8 of a
-// block at HP = 32 -- behind an LDS staging of 32-entry tiles with two barriers each: 0.70 ms for the 1.2 GB of G where the
-// bytes take 0.15 ms.  Here a thread owns one entry (both features): its values of every plane are one 8-byte load each,
+// expand_f16_kernel's expansion for the first W <= 4 grids of a padded width HP >= 8 (the narrow exchange of the schedule's
+// first grid and of the first steps of its ramp).  In expand_f16_kernel only the threads of the first grid quad work then --
+// 1 / 8 of a block at HP = 32 -- behind an LDS staging of 32-entry tiles with two barriers each: 0.70 ms for the 1.2 GB of G
+// where the bytes take 0.15 ms.  Here a thread owns one entry (both features): its values of every plane are one 8-byte load each,
 // coalesced across the wave, nothing is staged, and the 2 W results leave as one vector store.  The arithmetic per element
 // is the kernel's above (the planes in ascending order, fmaf, zeros skipped): the same bits.
 template <int W>
