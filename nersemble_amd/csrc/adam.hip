@@ -502,8 +502,8 @@ __global__ __launch_bounds__(256) void tables_unpack_width_kernel(const half_t* 
     }
 }
 
-// expand_f16_kernel's expansion for the first W <= 4 grids of a padded width HP >= 8 (the narrow exchange of the schedule's
-// first grid and of the first steps of its ramp).  In expand_f16_kernel only the threads of the first grid quad work then --
+// expand_f16_kernel's expansion for the first W < HP grids of a padded width HP >= 8 (the narrow exchange of the schedule's
+// first grid and of its ramp).  In expand_f16_kernel only the threads of the first grid quad work then --
 // 1 / 8 of a block at HP = 32 -- behind an LDS staging of 32-entry tiles with two barriers each: 0.70 ms for the 1.2 GB of G
 // where the bytes take 0.15 ms.  Here a thread owns one entry (both features): its values of every plane are one 8-byte load each,
 // coalesced across the wave, nothing is staged, and the 2 W results leave as one vector store.  The arithmetic per element
@@ -563,7 +563,7 @@ __global__ __launch_bounds__(256) void expand_f16_narrow_kernel(
             }
         }
         half_t* dst = out + v * 2ull * W;                     // [entry][f][W]
-        half_t res[2 * W];
+        __attribute__((aligned(16))) half_t res[2 * W];
 #pragma unroll
         for (int k = 0; k < W; ++k) {
             const float p0 = accumulate ? (float)dst[k] : 0.f, p1 = accumulate ? (float)dst[W + k] : 0.f;
@@ -575,7 +575,9 @@ __global__ __launch_bounds__(256) void expand_f16_narrow_kernel(
         } else if (W == 2) {
             *reinterpret_cast<uint2*>(dst) = *reinterpret_cast<const uint2*>(res);
         } else {
-            *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(res);
+#pragma unroll
+            for (int q = 0; q < W / 4; ++q)
+                reinterpret_cast<uint4*>(dst)[q] = reinterpret_cast<const uint4*>(res)[q];
         }
     }
 }
@@ -589,14 +591,14 @@ static int launch_expand_f16(const float* G, int n_slots, const float* code, int
     constexpr int EPB = 256 / (2 * HP / HV);
     NSX_REQUIRE(bucket_entries % EPB == 0, "nsx_hash_grad_expand_f16_bucket: bucket of %llu entries is not a multiple of "
                 "the kernel's tile (%d entries)", (unsigned long long)bucket_entries, EPB);
-    if (HP >= 8 && out_width <= 4 && (reinterpret_cast<uintptr_t>(G) & 7) == 0 &&
+    if (HP >= 8 && out_width < HP && out_width <= 16 && (reinterpret_cast<uintptr_t>(G) & 7) == 0 &&
         (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
         const size_t smem_n = (size_t)n_slots * out_width * sizeof(float);
         const dim3 grid(num_cus() * 8), block(256);
 #define NSX_EXPN_CASE(WW) case WW: hipLaunchKernelGGL((expand_f16_narrow_kernel<WW>), grid, block, smem_n, st, G, n_slots, code, \
         code_stride, window, H, HP, total, reinterpret_cast<half_t*>(out), scale, accumulate, bucket_entries, rank_entries, \
         entry_base, virtual_total, beyond_width); break;
-        switch (out_width) { NSX_EXPN_CASE(1) NSX_EXPN_CASE(2) NSX_EXPN_CASE(4) }
+        switch (out_width) { NSX_EXPN_CASE(1) NSX_EXPN_CASE(2) NSX_EXPN_CASE(4) NSX_EXPN_CASE(8) NSX_EXPN_CASE(16) }
 #undef NSX_EXPN_CASE
         NSX_LAUNCH_CHECK("nsx_hash_grad_expand_f16 (narrow) launch");
         return NSX_OK;

@@ -519,7 +519,7 @@ def test_exchange_is_handed_from_reduce_scatter_to_level_parallel_when_the_windo
 
 
 # ---- the exchange that follows the coarse-to-fine window (grids [0, W) only) -------------------------------------------
-@pytest.mark.parametrize("H,W", [(3, 2), (8, 1), (8, 2), (32, 1), (32, 4), (32, 16)])
+@pytest.mark.parametrize("H,W", [(3, 2), (8, 1), (8, 2), (16, 8), (32, 1), (32, 4), (32, 8), (32, 16)])
 def test_narrow_exchange_kernels(H, W, cuda):
     """nsx_hash_grad_expand_f16_bucket_width / nsx_adam_dense_f16grad_width / nsx_tables_unpack_width: the packed piece is
     the full-width piece's first W grids, the packed Adam is the dense Adam where the other grids have neither gradient
