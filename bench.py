@@ -229,6 +229,12 @@ def steady_state(trainer, data, first_step: int, settle_at: int, rays: int, n_ti
         step += 1
     batches = [data.next_train(step + i) for i in range(n_timed + 1)] if datamanager is None else None
     nxt = datamanager.next_train(step) if datamanager is not None else None
+    from nersemble_amd.engine.level_parallel import LevelParallelTableAdam
+    lp_opt = trainer.optimizers.get(trainer.group_of_tables())
+    lp_opt = lp_opt if isinstance(lp_opt, LevelParallelTableAdam) else None
+    if lp_opt is not None:
+        lp_opt.comm_report()
+        lp_opt.timing = True
     gc.collect()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -249,6 +255,24 @@ def steady_state(trainer, data, first_step: int, settle_at: int, rays: int, n_ti
     out = {"from_step": step, "steps": n_timed, "ms_per_step": dt / n_timed * 1e3, "value": samples / dt,
            "unit": "ray-samples/s", "rays_per_sec": rays * n_timed / dt, "samples_per_step_min_max": [min(counts), max(counts)],
            "psnr": float(metrics["psnr"].detach())}
+    if lp_opt is not None:
+        lp_opt.timing = False
+        out["_comm"] = lp_opt.comm_report()
+        # host issue time: the same steps issued into an EMPTY queue (a device synchronisation in front of every step), the
+        # median of the host's time inside train_iteration -- what the host needs per step when it never waits for the device
+        host = []
+        more = [data.next_train(step + n_timed + i) for i in range(33)]
+        for i in range(32):
+            torch.cuda.synchronize()
+            th = time.perf_counter()
+            trainer.train_iteration(step + n_timed + i, *more[i], next_ray_bundle=more[i + 1][0])
+            if (step + n_timed + i) % 16 != 0:
+                host.append(time.perf_counter() - th)
+        torch.cuda.synchronize()
+        trainer.flush_scheduler_step()
+        host.sort()
+        out["host_issue_ms_per_step"] = host[len(host) // 2] * 1e3
+        step += 32
     if H > 0 and datamanager is None and n_profiled > 0:
         from nersemble_amd import _lib
         prof = _lib.profiler
@@ -658,6 +682,15 @@ def main():
                     help="N = 1 only: the table step of a data-parallel rank (ShardedTableAdam: fp16 expansion, reduce-scatter "
                          "and all-gather through RCCL on a ONE-rank group, Adam on the shard) instead of the fused "
                          "single-GPU pass -- what a rank of an N-GPU job computes per step, without the links")
+    ap.add_argument("--level-parallel-one-rank", type=int, default=0, metavar="N",
+                    help="N = 1 process only: train as rank --rank of an N-rank LEVEL-PARALLEL job whose other ranks are "
+                         "replicas of this one (engine/level_parallel.py, emulate): the level partition, the sample "
+                         "exchange's payloads and per-source-rank launches, N x 24 gradient planes, and every collective of "
+                         "such a rank through RCCL on a ONE-rank group (+ the gloo side group).  What a rank of an N-GPU "
+                         "job computes and issues per step with the window open, without the links (NOT the headline; the "
+                         "numbers it trains on are not the model's).  Implies --window-hash 0 1")
+    ap.add_argument("--rank", type=int, default=-1, help="the emulated rank of --level-parallel-one-rank (default N - 1: the "
+                                                         "finest levels' owner, the slowest rank)")
     ap.add_argument("--no-kernels-alone", action="store_true", help="skip the stand-alone kernel timings after the run")
     ap.add_argument("--with-datamanager", action="store_true",
                     help="draw every batch INSIDE the timed loop through NeRSembleVanillaDataManager.next_train (24-image "
@@ -671,8 +704,12 @@ def main():
                     help="after the timed region, training continues to this step and 100 more steps are timed as the "
                          "`steady_state` block (0: skip)")
     a = ap.parse_args()
-    if a.window_open and a.window_hash is None:
+    if (a.window_open or a.level_parallel_one_rank) and a.window_hash is None:
         a.window_hash = [0, 1]
+    lp_emulation = None
+    if a.level_parallel_one_rank:
+        lp_emulation = (a.level_parallel_one_rank, a.rank if a.rank >= 0 else a.level_parallel_one_rank - 1)
+        a.no_first_grid_phase = a.no_open_window = a.no_with_datamanager = True
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(a, sys.argv[1:]))
 
@@ -689,8 +726,8 @@ def main():
         else:
             dist.init_process_group(backend=a.backend)
     assert a.gpus == world, f"--gpus {a.gpus} but WORLD_SIZE={world}"
-    if a.sharded_one_rank:
-        assert world == 1, "--sharded-one-rank is a single-process measurement"
+    if a.sharded_one_rank or lp_emulation:
+        assert world == 1, "--sharded-one-rank / --level-parallel-one-rank are single-process measurements"
         import socket
         s_ = socket.socket()
         s_.bind(("127.0.0.1", 0))
@@ -720,7 +757,7 @@ def main():
                                          global_loss_normalisers=(a.scaling == "strong" and world > 1),
                                          compact_first_grid=a.compact_first_grid,
                                          window_hash=tuple(a.window_hash) if a.window_hash else None,
-                                         table_parallel=a.table_parallel,
+                                         table_parallel=a.table_parallel, level_parallel_emulation=lp_emulation,
                                          **({"sharded_table_adam": True} if a.sharded_one_rank else {}))
     if a.reserve_gb > 0:
         reserve = torch.empty(int(a.reserve_gb * 2 ** 30), dtype=torch.uint8, device=dev)
@@ -808,7 +845,7 @@ def main():
                            "nsx_deform_fwd", "nsx_deform_fwd_rows", "nsx_deform_bwd",
                            "nsx_mlp_fwd", "nsx_mlp_bwd", "nsx_check_finite", "nsx_march_fill",
                            "nsx_hash_grad_expand", "nsx_hash_grad_expand_f16", "nsx_adam_dense_f16grad",
-                           "nsx_check_finite_f16"}
+                           "nsx_check_finite_f16", "nsx_lp_fwd_run", "nsx_lp_bwd_run"}
     # (the variant of the table optimizer that also clears the gradient pieces it reads is priced as the optimizer pass)
     _lib.profiler.alias = {"nsx_adam_hash_factored_consume": "nsx_adam_hash_factored"}
     if not a.no_kernel_events:
@@ -846,7 +883,7 @@ def main():
     n = torch.tensor([samples], device=dev, dtype=torch.int64)
     dt_all = [dt]
     comm = None
-    if world > 1 or a.sharded_one_rank:
+    if world > 1 or a.sharded_one_rank or lp_emulation:
         every = torch.zeros((world,), device=dev, dtype=torch.float64)
         dist.all_gather_into_tensor(every, t)
         dt_all = every.tolist()
@@ -858,6 +895,8 @@ def main():
             comm = table_opt.comm_report()
             comm["backend"] = a.backend
             comm["rccl_ranks"] = world if a.backend == "nccl" else 0
+            if lp_emulation:
+                comm["emulated_world_size"] = lp_emulation[0]
             comm["ms_per_step_per_rank_min_max"] = [min(dt_all) / a.steps * 1e3, max(dt_all) / a.steps * 1e3]
             # the bar of the round-4 review: the exchange must scale with the samples (2 x 64 B per sample of the JOB and
             # pass for features out / gradients back), not with the 806 MB of parameters
@@ -910,7 +949,10 @@ def main():
                                          "schedule, its result is not adopted" if a.grid == "frozen" else "live",
                        "rccl_ranks": world if (world > 1 and a.backend == "nccl") else 0,
                        "table_step": ("one rank of a data-parallel job: ShardedTableAdam on a one-rank group (NOT the headline)"
-                                      if a.sharded_one_rank else type(table_opt).__name__),
+                                      if a.sharded_one_rank else
+                                      f"rank {lp_emulation[1]} of {lp_emulation[0]} of a level-parallel job, the other ranks "
+                                      f"emulated as replicas, collectives on a one-rank group (NOT the headline)"
+                                      if lp_emulation else type(table_opt).__name__),
                        "early_table_step": bool(trainer.early_table_step),
                        "march_count_one_step_ahead": bool(trainer.prefetch_march),
                        "table_adam_consumes_gradient": bool(getattr(table_opt, "consume_gradient", False)),
@@ -951,6 +993,8 @@ def main():
                          "steady_full" if a.window_hash is None else None)
             out["steady_state"] = steady_state(trainer, data, a.preroll + a.warmup + a.steps, a.steady_after, info["rays"],
                                                datamanager=dm, H=0 if a.no_kernel_events else H, pmc_state=state)
+            if lp_emulation:
+                out["steady_state"]["comm"] = out["steady_state"].pop("_comm", None)
         if steady_ranks is not None:
             out["steady_state"] = steady_ranks
         spp = [p["samples"] for p in out["per_step"]]
@@ -970,7 +1014,7 @@ def main():
                 and a.preroll == 0 and a.window_hash is None:
             out["with_datamanager"] = with_datamanager_block(a)
         print(json.dumps(out))
-    if world > 1 or a.sharded_one_rank:
+    if world > 1 or a.sharded_one_rank or lp_emulation:
         dist.destroy_process_group()
 
 

@@ -32,7 +32,7 @@ extern "C" {
 #define NSX_MAX_SLOTS 64
 #define NSX_MAX_ADAM_SLOTS 192   /* gradient planes nsx_adam_hash_factored(_consume) reads (level-parallel runs: one per
                                    (source rank, code row), engine/level_parallel.py) */
-#define NSX_VERSION 121
+#define NSX_VERSION 122
 
 typedef uint16_t nsx_half;
 
@@ -776,7 +776,10 @@ typedef struct nsx_step_sample {
     int32_t base_act;
     int32_t n_code_rows;             /* rows of deform_codes / hash_codes (= the plan's) */
     int32_t n_timesteps;             /* T of the model (the check above) */
-    int32_t reserved;
+    int32_t phase;                   /* 0: the whole sampler; level-parallel runs split it at the HashEnsemble, whose features
+                                        then arrive through the sample exchange (nsx_lp_*): 1 = everything in front of it
+                                        (traversal ... normalised positions m_pn, code slots m_slot), 2 = everything behind
+                                        it (mlp_base on m_feat ... the kept samples) */
     float far_plane;
     float step;
     float early_stop_eps;
@@ -854,6 +857,72 @@ int nsx_step_profile_reset(void);
  * (0 sample, 1 main) as doubles in declaration order (pointers as addresses, arrays element by element). */
 int64_t nsx_step_sizeof(int kind /* 0 sample, 1 main, 2 plan */);
 int nsx_step_echo(int kind, const void* s, double* out, int capacity);
+
+/* ---- level-parallel exchange (csrc/level_parallel.hip; host side: nersemble_amd/engine/level_parallel.py) ---------------
+ * The reference trains on ONE GPU (scripts/train/train_nersemble.py:272-274 hard-codes world_size = 1); this is the
+ * package's data-parallel contract for the HashEnsemble once the coarse-to-fine window is open (train_nersemble.py:77-78):
+ * rank r of W owns levels [r L / W, (r + 1) L / W) of all H grids -- a contiguous entry range of the [entry][f][h] tables --
+ * and evaluates / differentiates them for EVERY rank's samples.  The columns out[:, 2 l + f] of HashEnsemble.forward
+ * (hash_ensemble.py:93-158) depend on level l's entries only, so samples travel and parameters do not.  The binding issues
+ * four collectives per step on byte buffers whose layout nsx_lp_layout_make fixes; everything in between is enqueued by the
+ * entry points below (the per-source-rank kernels are the UNCHANGED nsx_hash_ensemble_fwd / _bwd_codesum on a sub-geometry).
+ *
+ *   1. nsx_lp_fwd_pack    this rank's [count | positions | code slots | conditioned code rows]   -> ALL-GATHER (fwd_bytes)
+ *   2. nsx_lp_fwd_run     W launches: the owned levels for the samples of source rank j -> block j of `send`
+ *                                                                                               -> ALL-TO-ALL (feat_bytes)
+ *   3. nsx_lp_fwd_unpack  column blocks -> features [S][2 L] fp16
+ *   4. nsx_lp_bwd_pack    [count | dL/dfeatures column block fp16 | positions | slots] for every owner
+ *                                                                                               -> ALL-TO-ALL (bwd_bytes)
+ *   5. nsx_lp_bwd_run     W launches: factored table gradient of the owned entries into the planes of source rank j
+ *                         (plane = sum of the code rows of ranks < j, + code row), partial dL/dx and partial code-row
+ *                         gradient into block j of `ret`                                        -> ALL-TO-ALL (ret_bytes)
+ *   6. nsx_lp_bwd_unpack  partials summed over the owners (fixed order) -> dL/dx [S][3], dL/dcode [rows][H]
+ *
+ * Capacities (S_cap = max over the ranks of the marched samples, R_cap = max code rows) are host-known; the number of VALID
+ * rows of every rank travels inside the payloads and is read by the kernels when they run (n_device semantics). */
+typedef struct nsx_lp_layout {
+    int64_t S_cap;
+    int64_t fwd_bytes;          /* the all-gather payload of ONE rank */
+    int64_t f_count;            /* int64: valid rows */
+    int64_t f_pn;               /* float [S_cap][3] normalised positions */
+    int64_t f_slot;             /* int32 [S_cap] code row of the sample within ITS rank's code rows */
+    int64_t f_codes;            /* float [R_cap][H] conditioned code rows */
+    int64_t feat_bytes;         /* one (owner -> source) block of the feature all-to-all: fp16 [S_cap][n2] */
+    int64_t bwd_bytes;          /* one (source -> owner) block of the gradient all-to-all */
+    int64_t b_count;
+    int64_t b_dz;               /* fp16 [S_cap][n2] */
+    int64_t b_pn;
+    int64_t b_slot;
+    int64_t ret_bytes;          /* one (owner -> source) block of the return all-to-all */
+    int64_t r_dx;               /* float [S_cap][3] */
+    int64_t r_dcode;            /* float [R_cap][H] */
+    int32_t W;
+    int32_t R_cap;
+    int32_t H;
+    int32_t n2;                 /* feature columns per rank = 2 x owned levels */
+} nsx_lp_layout;
+int nsx_lp_layout_make(int W, int64_t S_cap, int R_cap, int H, int n2, nsx_lp_layout* out);
+int64_t nsx_lp_sizeof(void);
+int nsx_lp_fwd_pack(const nsx_lp_layout* lay, const float* pn, const int32_t* slot, int64_t S, const int64_t* n_device,
+                    const float* codes, int64_t code_stride, int rows, uint8_t* payload, void* stream);
+/* gathered: [W][fwd_bytes]; sizes_host / rows_host: HOST arrays [W] (row capacity and code rows of every rank);
+ * tables / sub_geom: this rank's entry range and its geometry (entry offsets re-based to 0); send: [W][feat_bytes];
+ * codes_packed (optional): float [sum rows][H], the job's code rows in gradient-plane order (what the optimizer pass reads) */
+int nsx_lp_fwd_run(const nsx_lp_layout* lay, const uint8_t* gathered, const int64_t* sizes_host, const int32_t* rows_host,
+                   const nsx_half* tables, const nsx_grid_geom* sub_geom, const float* window, uint8_t* send,
+                   float* codes_packed, void* stream);
+int nsx_lp_fwd_unpack(const nsx_lp_layout* lay, const uint8_t* recv, int64_t S, const int64_t* n_device, nsx_half* feats,
+                      void* stream);
+/* dout: fp32 [S][W * n2] (fp16-representable values: nsx_mlp_bwd emits them); send: [W][bwd_bytes] */
+int nsx_lp_bwd_pack(const nsx_lp_layout* lay, const float* dout, const float* pn, const int32_t* slot, int64_t S,
+                    const int64_t* n_device, uint8_t* send, void* stream);
+/* recv: [W][bwd_bytes]; gathered: the forward's all-gather (its code rows); G: [sum rows][owned entries][2] fp32 or NULL;
+ * dz_scratch: float [W][S_cap][n2]; csum_scratch: nsx_hash_codesum_scratch_floats(R_cap, H) floats; ret: [W][ret_bytes] */
+int nsx_lp_bwd_run(const nsx_lp_layout* lay, const uint8_t* recv, const uint8_t* gathered, const int64_t* sizes_host,
+                   const int32_t* rows_host, const nsx_half* tables, const nsx_grid_geom* sub_geom, const float* window,
+                   float* G, float* dz_scratch, float* csum_scratch, uint8_t* ret, float* nonfinite, void* stream);
+int nsx_lp_bwd_unpack(const nsx_lp_layout* lay, const uint8_t* ret_recv, int64_t S, const int64_t* n_device, int rows,
+                      float* dx, float* dcode, void* stream);
 
 #ifdef __cplusplus
 }

@@ -9,6 +9,7 @@ SO_PATH = os.path.join(_HERE, "csrc", "libnsx.so")
 NSX_MAX_LEVELS = 32
 NSX_MAX_SLOTS = 64
 NSX_MAX_GATHER = 8
+NSX_MAX_ADAM_SLOTS = 192
 NSX_OPT_ADAM_BLOCKS_PER_CU, NSX_OPT_MLP_BWD_HALF_BLOCKS_PER_CU, NSX_OPT_MLP_BWD0_HALF_BLOCKS_PER_CU = 0, 1, 2
 
 c_void_p, c_int, c_int64, c_float = C.c_void_p, C.c_int, C.c_int64, C.c_float
@@ -190,6 +191,18 @@ SIGNATURES = {
     "nsx_step_profile_reset": (c_int, []),
     "nsx_step_sizeof": (c_int64, [c_int]),
     "nsx_step_echo": (c_int, [c_int, c_void_p, c_void_p, c_int]),
+    # level-parallel exchange (csrc/level_parallel.hip; struct nsx_lp_layout through step_struct)
+    "nsx_lp_layout_make": (c_int, [c_int, c_int64, c_int, c_int, c_int, c_void_p]),
+    "nsx_lp_sizeof": (c_int64, []),
+    "nsx_lp_fwd_pack": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_void_p,
+                                c_void_p]),
+    "nsx_lp_fwd_run": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, _GEOM_P, c_void_p, c_void_p, c_void_p,
+                               c_void_p]),
+    "nsx_lp_fwd_unpack": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
+    "nsx_lp_bwd_pack": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
+    "nsx_lp_bwd_run": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, _GEOM_P, c_void_p, c_void_p,
+                               c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "nsx_lp_bwd_unpack": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
 }
 
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "nsx.h")

@@ -212,6 +212,9 @@ int nsx_step_sample_run(const nsx_step_sample* a, void* stream) {
     uint8_t* m_vis = at<uint8_t>(w, p.m_vis);
     int64_t* m_keep = at<int64_t>(w, p.m_keep);
     int64_t* n_kept = at<int64_t>(w, p.n_kept);
+    NSX_REQUIRE(a->phase >= 0 && a->phase <= 2, "nsx_step_sample_run: phase %d not in [0,2]", a->phase);
+    const bool front = a->phase != 2, back = a->phase != 1;      // level-parallel runs split at the HashEnsemble
+    if (front) {
     // -- pass 2 of the traversal (OccGridEstimator.sampling -> traverse)
     NSX_CALL("nsx_march_fill", R, 0, 0, 0,
              nsx_march_fill(a->origins, a->directions, R, a->occ_aabb, a->binaries, a->grid_res, a->near_planes, a->far_plane,
@@ -233,12 +236,16 @@ int nsx_step_sample_run(const nsx_step_sample* a, void* stream) {
                                  a->n_code_rows, a->window7_host, m_off, at<float>(w, p.m_terms), nullptr, stream));
     NSX_TRY(nsx_sample_positions(m_pos, nullptr, nullptr, nullptr, nullptr, m_off, S, a->field_aabb, nullptr, m_pn, m_sel,
                                  nullptr, stream));
+    }
+    if (a->phase == 0) {
     if (a->tables_ready_event &&
         hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)const_cast<void*>(a->tables_ready_event), 0) != hipSuccess)
         return hip_fail(hipGetLastError(), "nsx_step_sample_run: waiting for the tables");
     NSX_CALL("nsx_hash_ensemble_fwd", S, a->H, 0, 0,
              nsx_hash_ensemble_fwd(m_pn, S, a->tables, a->H, a->geom, a->hash_codes, a->hash_code_stride, m_slot,
                                    a->hash_window, m_feat, nullptr, stream));
+    }
+    if (!back) return NSX_OK;
     NSX_CALL("nsx_mlp_fwd", S, a->base_hidden, 0, 0,
              nsx_mlp_fwd(a->base_w16, a->base_hidden, S, nullptr, 0, 0, 1.0f, 0.0f, m_feat, 32, 0, 32, a->base_out_dim,
                          a->base_act, m_base, a->base_out_dim, nullptr, stream));
@@ -478,7 +485,7 @@ int nsx_step_echo(int kind, const void* s, double* out, int capacity) {
         PUTP(a->window7_host); PUTP(a->ws); PUTP(a->plan); PUTP(a->tables_ready_event);
         PUT(a->R); PUT(a->S); PUT(a->deform_code_stride); PUT(a->hash_code_stride);
         PUT(a->grid_res); PUT(a->H); PUT(a->base_hidden); PUT(a->base_out_dim); PUT(a->base_act); PUT(a->n_code_rows);
-        PUT(a->n_timesteps); PUT(a->reserved);
+        PUT(a->n_timesteps); PUT(a->phase);
         PUT(a->far_plane); PUT(a->step); PUT(a->early_stop_eps); PUT(a->reserved_f);
         for (int i = 0; i < 6; ++i) PUT(a->occ_aabb[i]);
         for (int i = 0; i < 6; ++i) PUT(a->deform_aabb[i]);

@@ -88,6 +88,8 @@ class _MainPass(torch.autograd.Function):
         elif lp is not None:
             # data-parallel run with the window open: this rank's levels for every rank's samples (engine/level_parallel.py)
             feats = lp.features(pn, code_h, hash_slot, hash_window, n_dev=inp.n_dev)
+        # (level-parallel: the forward exchange whose backward this node's is -- its own, or the sigma_fn pass's)
+        ctx.lp_ex = lp.last_exchange if lp is not None else None
         else:
             feats = torch.empty((S, 2 * geom.n_levels), dtype=f16, device=dev)
             check(L.nsx_hash_ensemble_fwd(ptr(pn), S, ptr(tables_f16), H, C.byref(geom), ptr(code_h), code_h.stride(0),
@@ -209,9 +211,9 @@ class _MainPass(torch.autograd.Function):
         if lp is not None:
             # level-parallel exchange: dL/dfeatures travels to the levels' owners, the table gradient of the owned levels
             # stays in their gradient planes (no G here, no dense gradient), dL/dx and the code gradient come back summed
-            lp._last_need_code = bool(need_code)
-            dx, g_code_hash = lp.backward(pn, hash_slot, dout, code_h, hash_window, inp.n_dev, need_code=bool(need_code),
-                                          need_table=bool(need_tab))
+            dx, g_code_hash = lp.backward(pn, hash_slot, dout, n_dev=inp.n_dev, need_table=bool(need_tab), ex=ctx.lp_ex)
+            if not need_code:
+                g_code_hash = None
             return _MainPass._finish_backward(ctx, L, st, dev, S, inp, dx, sel, pos, code_d, gparams, gtable, g_code_hash,
                                               n_rows, H, None, d_base, d_head)
         if need_tab:

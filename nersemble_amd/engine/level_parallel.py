@@ -65,14 +65,95 @@ def sub_geometry(g: GridGeom, first_level: int, n_levels: int) -> GridGeom:
     return s
 
 
-class LevelParallel:
-    """The exchange around the HashEnsemble kernels (attached as ``HashEnsemble.level_parallel``)."""
+class NativeLPOps:
+    """The device side of the exchange: csrc/level_parallel.hip through the C ABI (include/nsx.h, "level-parallel exchange").
+    Tests substitute a torch restatement to run the collectives' plumbing on CPU over gloo (tests/test_parallel_cpu.py)."""
 
-    def __init__(self, he: HashEnsemble, world_size: int, rank: int, group=None):
+    @staticmethod
+    def layout(W: int, S_cap: int, R_cap: int, H: int, n2: int):
+        lay = _lib.step_struct("nsx_lp_layout")()
+        check(lib().nsx_lp_layout_make(int(W), int(S_cap), int(R_cap), int(H), int(n2), C.byref(lay)), "nsx_lp_layout_make")
+        return lay
+
+    @staticmethod
+    def fwd_pack(lay, pn, slot, S, n_dev, codes, rows, payload) -> None:
+        check(lib().nsx_lp_fwd_pack(C.byref(lay), ptr(pn), ptr(slot), int(S), ptr(n_dev), ptr(codes), codes.stride(0),
+                                    int(rows), ptr(payload), stream()), "nsx_lp_fwd_pack")
+
+    @staticmethod
+    def fwd_run(lay, gathered, ex, tables, geom, window, send, codes_packed) -> None:
+        check(lib().nsx_lp_fwd_run(C.byref(lay), ptr(gathered), ex.sizes_host, ex.rows_host, ptr(tables), C.byref(geom),
+                                   ptr(window), ptr(send), ptr(codes_packed), stream()), "nsx_lp_fwd_run")
+
+    @staticmethod
+    def fwd_unpack(lay, recv, S, n_dev, feats) -> None:
+        check(lib().nsx_lp_fwd_unpack(C.byref(lay), ptr(recv), int(S), ptr(n_dev), ptr(feats), stream()), "nsx_lp_fwd_unpack")
+
+    @staticmethod
+    def bwd_pack(lay, dout, pn, slot, S, n_dev, send) -> None:
+        check(lib().nsx_lp_bwd_pack(C.byref(lay), ptr(dout), ptr(pn), ptr(slot), int(S), ptr(n_dev), ptr(send), stream()),
+              "nsx_lp_bwd_pack")
+
+    @staticmethod
+    def bwd_run(lay, recv, gathered, ex, tables, geom, window, G, ret, nonfinite) -> None:
+        dev = recv.device
+        dz = torch.empty((lay.W * lay.S_cap * lay.n2,), dtype=torch.float32, device=dev)
+        check(lib().nsx_lp_bwd_run(C.byref(lay), ptr(recv), ptr(gathered), ex.sizes_host, ex.rows_host, ptr(tables),
+                                   C.byref(geom), ptr(window), ptr(G), ptr(dz), ptr(F.codesum_scratch(lay.R_cap, lay.H, dev)),
+                                   ptr(ret), ptr(nonfinite), stream()), "nsx_lp_bwd_run")
+
+    @staticmethod
+    def bwd_unpack(lay, ret_recv, S, n_dev, rows, dx, dcode) -> None:
+        check(lib().nsx_lp_bwd_unpack(C.byref(lay), ptr(ret_recv), int(S), ptr(n_dev), int(rows), ptr(dx), ptr(dcode),
+                                      stream()), "nsx_lp_bwd_unpack")
+
+    @staticmethod
+    def shared_columns(x, S, tables, H, geom, code, slot, window, cols) -> None:
+        check(lib().nsx_hash_ensemble_fwd(ptr(x), int(S), ptr(tables), int(H), C.byref(geom), ptr(code), code.stride(0),
+                                          ptr(slot), ptr(window), ptr(cols), None, stream()), "nsx_hash_ensemble_fwd")
+
+
+class Exchange:
+    """One forward exchange and what its backward needs again: the job's sizes (host), the layout of the payloads, the
+    gathered forward payloads (the owners read every rank's code rows from them in the backward)."""
+    __slots__ = ("lay", "sizes", "rows", "S", "n_rows", "S_cap", "R_cap", "sizes_host", "rows_host", "n_planes", "gathered",
+                 "codes_packed", "window", "backward_done")
+
+    def __init__(self, lay, sizes, rows, rank):
+        W = len(sizes)
+        self.lay, self.sizes, self.rows = lay, list(sizes), list(rows)
+        self.S, self.n_rows = int(sizes[rank]), int(rows[rank])
+        self.S_cap, self.R_cap = int(lay.S_cap), int(lay.R_cap)
+        self.sizes_host = (C.c_int64 * W)(*[int(s) for s in sizes])
+        self.rows_host = (C.c_int32 * W)(*[int(r) for r in rows])
+        self.n_planes = int(sum(rows))
+        self.gathered = self.codes_packed = self.window = None
+        self.backward_done = False
+
+
+class LevelParallel:
+    """The exchange around the HashEnsemble kernels (attached as ``HashEnsemble.level_parallel``).
+
+    One training step = ONE host-side size exchange (``exchange_sizes``: the marched sample count and the code rows of every
+    rank, 16 bytes per rank through a gloo group) and FOUR device collectives: all-gather + all-to-all in the forward
+    (``features``), two all-to-alls in the backward (``backward``).  The counts of valid rows, the positions, the code slots
+    and the conditioned code rows travel inside those payloads (csrc/level_parallel.hip), and the partial code gradients
+    return with the partial dL/dx -- every rank issues the same collectives in the same order whatever its rays produced.
+
+    ``emulate=True``: this process is rank ``rank`` of a ``world_size``-rank job whose other ranks are REPLICAS of itself --
+    the partition, the payload layouts, the per-source-rank launches and the gradient planes are those of the real job, the
+    collectives run on the (one-rank) group and what they would have delivered from rank j is this rank's own block.  What a
+    rank of an 8-GPU job computes and issues per step, measurable on one GPU (``bench.py --level-parallel-one-rank``); the
+    feature columns of the levels this rank does not own are then copies of its own, so the numbers it trains on are not the
+    model's."""
+
+    def __init__(self, he: HashEnsemble, world_size: int, rank: int, group=None, emulate: bool = False, ops=None):
         L = int(he.geom.n_levels)
         if world_size < 2 or L % world_size != 0:
             raise ValueError(f"level-parallel tables need a world size that divides the {L} levels (got {world_size})")
         self.he, self.world_size, self.rank, self.group = he, int(world_size), int(rank), group
+        self.emulate = bool(emulate)
+        self.ops = ops or NativeLPOps()
         self.n_own = L // self.world_size
         self.first_level = self.rank * self.n_own
         self.geom = sub_geometry(he.geom, self.first_level, self.n_own)
@@ -85,6 +166,8 @@ class LevelParallel:
         backend = dist.get_backend(group)
         self._a2a_native = backend == "nccl"
         self.cpu_group = group if backend == "gloo" else dist.new_group(backend="gloo")
+        if self.emulate and dist.get_world_size(group) != 1:
+            raise ValueError("an emulated rank runs on a one-rank process group")
         self.shared_inputs = False       # every rank holds the SAME positions (occupancy update): no position exchange
         self.nonfinite = None            # device float: a backward added an inf / NaN to G
         self.G = None                    # [planes][own entries][2] fp32, planes = sum of the ranks' code rows
@@ -93,34 +176,56 @@ class LevelParallel:
         self.window = None
         self.backward_calls = 0
         self.samples_scattered = 0
+        self.last_exchange = None        # the most recent forward exchange (its backward follows)
         self._g_clean = None             # event: the optimizer pass left G all zeros (nsx_adam_hash_factored_consume)
-        self.stats = {"bytes_in": 0, "samples_fwd": 0, "samples_bwd": 0, "fwd_calls": 0, "bwd_calls": 0}
+        self.stats = {"bytes_in": 0, "samples_fwd": 0, "samples_bwd": 0, "fwd_calls": 0, "bwd_calls": 0, "collectives": 0,
+                      "host_exchanges": 0}
 
     # ---- collectives -------------------------------------------------------------------------------------------------
-    def _host_sizes(self, values: List[int]) -> List[List[int]]:
-        mine = torch.tensor([int(v) for v in values], dtype=torch.int64)
-        out = torch.empty((self.world_size * len(values),), dtype=torch.int64)
+    def exchange_sizes(self, S: int, rows: int) -> Exchange:
+        """The one host-side collective of a pass: every rank's (sample capacity, code rows).  Blocking, 16 bytes per rank."""
+        W = self.world_size
+        mine = torch.tensor([int(S), int(rows)], dtype=torch.int64)
+        n = dist.get_world_size(self.cpu_group)
+        out = torch.empty((n * 2,), dtype=torch.int64)
         dist.all_gather_into_tensor(out, mine, group=self.cpu_group)
-        return out.view(self.world_size, len(values)).tolist()
+        self.stats["host_exchanges"] += 1
+        got = out.view(n, 2).tolist()
+        if self.emulate:
+            got = [got[0]] * W
+        sizes, rws = [g[0] for g in got], [max(1, g[1]) for g in got]
+        if sum(rws) > MAX_ADAM_SLOTS:
+            raise RuntimeError(f"level-parallel HashEnsemble: {sum(rws)} code rows in the job's batch (limit {MAX_ADAM_SLOTS}: "
+                               f"NSX_MAX_ADAM_SLOTS gradient planes per optimizer pass)")
+        lay = self.ops.layout(W, max(1, max(sizes)), max(rws), self.he.n_hash_encodings, 2 * self.n_own)
+        return Exchange(lay, sizes, rws, self.rank)
 
     def _all_gather(self, out: torch.Tensor, mine: torch.Tensor) -> None:
-        # (flat views: gloo's all-gather compares the shard of the output with the input shape by shape)
-        dist.all_gather_into_tensor(out.view(-1), mine.contiguous().view(-1), group=self.group)
-        self.stats["bytes_in"] += (self.world_size - 1) * mine.numel() * mine.element_size()
+        """``out`` = every rank's ``mine`` in rank order (flat byte buffers)."""
+        W, n = self.world_size, mine.numel()
+        if self.emulate:
+            dist.all_gather_into_tensor(out[self.rank * n:(self.rank + 1) * n], mine, group=self.group)
+            out.view(W, n).copy_(mine.view(1, n).expand(W, n))             # the replicas' payloads
+        else:
+            dist.all_gather_into_tensor(out, mine, group=self.group)
+        self.stats["bytes_in"] += (W - 1) * n * mine.element_size()
+        self.stats["collectives"] += 1
 
     def _all_to_all(self, out: torch.Tensor, inp: torch.Tensor) -> None:
-        """``out[j] = rank j's inp[self.rank]`` for equal blocks ``[W, ...]``.  RCCL: ``all_to_all_single``; gloo (the
-        CPU / one-GPU test backends) has no device all-to-all: every rank's whole block matrix is gathered and the column
-        picked -- the same result, W x the bytes (``stats`` counts the all-to-all's)."""
+        """``out`` block j = rank j's ``inp`` block [this rank], W equal blocks.  RCCL: ``all_to_all_single``; gloo (the CPU /
+        one-GPU test backends) has no device all-to-all: every rank's whole block matrix is gathered and the column picked
+        -- the same result, W x the bytes (``stats`` counts the all-to-all's).  Emulated rank: the one-rank collective hands
+        the blocks back as they are -- block j stands for what replica j would have sent."""
         W = self.world_size
-        inp = inp.contiguous()
-        if self._a2a_native:
-            dist.all_to_all_single(out.view(-1), inp.view(-1), group=self.group)
+        blk = inp.numel() // W
+        if self.emulate or self._a2a_native:
+            dist.all_to_all_single(out, inp, group=self.group)
         else:
-            full = torch.empty((W,) + tuple(inp.shape), dtype=inp.dtype, device=inp.device)
-            dist.all_gather_into_tensor(full.view(-1), inp.view(-1), group=self.group)
-            out.copy_(full[:, self.rank])
-        self.stats["bytes_in"] += (W - 1) * (inp.numel() // W) * inp.element_size()
+            full = torch.empty((W, W, blk), dtype=inp.dtype, device=inp.device)
+            dist.all_gather_into_tensor(full.view(-1), inp, group=self.group)
+            out.view(W, blk).copy_(full[:, self.rank])
+        self.stats["bytes_in"] += (W - 1) * blk * inp.element_size()
+        self.stats["collectives"] += 1
 
     @contextmanager
     def shared(self):
@@ -139,35 +244,19 @@ class LevelParallel:
     def slice_master(self) -> torch.Tensor:
         return self.he.tables.data[self.e0:self.e1]
 
-    def _gather_samples(self, x: torch.Tensor, slot: torch.Tensor, code: torch.Tensor):
-        """All ranks' (positions, code slots, conditioned code rows): lists per source rank + the capacities."""
-        W, dev = self.world_size, x.device
-        S, rows, H = int(x.shape[0]), int(code.shape[0]), int(code.shape[1])
-        sizes = self._host_sizes([S, rows])
-        S_cap, R_cap = max(s for s, _ in sizes), max(r for _, r in sizes)
-        pack = torch.zeros((S_cap * 4,), dtype=torch.float32, device=dev)
-        if S:
-            pack[:S * 3].copy_(x.reshape(-1))
-            pack[S_cap * 3:S_cap * 3 + S].copy_(slot.view(torch.float32))
-        allp = torch.empty((W, S_cap * 4), dtype=torch.float32, device=dev)
-        if S_cap:
-            self._all_gather(allp, pack)
-        cpack = torch.zeros((R_cap, H), dtype=torch.float32, device=dev)
-        cpack[:rows].copy_(code)
-        allc = torch.empty((W, R_cap, H), dtype=torch.float32, device=dev)
-        self._all_gather(allc, cpack)
-        xs = [allp[j, :S_cap * 3].view(S_cap, 3)[:sizes[j][0]] for j in range(W)]
-        slots = [allp[j, S_cap * 3:].view(torch.int32)[:sizes[j][0]] for j in range(W)]
-        codes = [allc[j, :sizes[j][1]] for j in range(W)]
-        return sizes, S_cap, xs, slots, codes
+    @staticmethod
+    def _bytes(n: int, dev) -> torch.Tensor:
+        return torch.empty((int(n),), dtype=torch.uint8, device=dev)
 
     # ---- forward ------------------------------------------------------------------------------------------------------
     @torch.no_grad()
     def features(self, x: torch.Tensor, code: torch.Tensor, code_index: torch.Tensor,
-                 window: Optional[torch.Tensor], n_dev: Optional[torch.Tensor] = None) -> torch.Tensor:
+                 window: Optional[torch.Tensor], n_dev: Optional[torch.Tensor] = None, ex: Optional[Exchange] = None,
+                 out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """``HashEnsemble.forward`` (values): x [S,3] in [0,1), ``code`` the CONDITIONED code table [rows,H], ``code_index``
-        [S] -> [S, 2 L] fp16.  ``n_dev``: device count of valid rows.  Collective: every rank calls it the same number of
-        times per step (S may be 0)."""
+        [S] -> [S, 2 L] fp16 (``out``: written there).  ``n_dev``: device count of valid rows (rows beyond it are not
+        written).  ``ex``: the sizes of this pass if the caller exchanged them already.  Collective: every rank calls it the
+        same number of times per step (S may be 0)."""
         he, W = self.he, self.world_size
         he.wait_tables()
         dev = x.device
@@ -176,36 +265,40 @@ class LevelParallel:
         slot = code_index.detach().to(torch.int32).contiguous()
         S, H, n2 = int(x.shape[0]), he.n_hash_encodings, 2 * self.n_own
         tables = self.slice_f16()
-        L_ = lib()
+        ops = self.ops
         self.stats["fwd_calls"] += 1
         if self.shared_inputs:
-            cols = torch.empty((S, n2), dtype=torch.float16, device=dev)
+            lay = ops.layout(W, max(1, S), 1, H, n2)
+            cols = self._bytes(lay.feat_bytes, dev)
             if S:
-                check(L_.nsx_hash_ensemble_fwd(ptr(x), S, ptr(tables), H, C.byref(self.geom), ptr(code), code.stride(0),
-                                               ptr(slot), ptr(window), ptr(cols), None, stream()), "nsx_hash_ensemble_fwd")
-            allc = torch.empty((W, S, n2), dtype=torch.float16, device=dev)
-            if S:
-                self._all_gather(allc, cols)
+                ops.shared_columns(x, S, tables, H, self.geom, code, slot, window, cols)
+            allc = self._bytes(W * lay.feat_bytes, dev)
+            self._all_gather(allc, cols)
+            feats = out if out is not None else torch.empty((S, W * n2), dtype=torch.float16, device=dev)
+            ops.fwd_unpack(lay, allc, S, None, feats)
             self.stats["samples_fwd"] += S
-            return allc.permute(1, 0, 2).reshape(S, W * n2).contiguous()
-        sizes, S_cap, xs, slots, codes = self._gather_samples(x, slot, code)
-        counts = None
-        if n_dev is not None:
-            counts = torch.empty((W,), dtype=torch.int64, device=dev)
-            self._all_gather(counts, n_dev.reshape(1))
-        send = torch.empty((W, S_cap, n2), dtype=torch.float16, device=dev)
-        for j in range(W):
-            Sj = sizes[j][0]
-            if Sj:
-                check(L_.nsx_hash_ensemble_fwd(ptr(xs[j]), Sj, ptr(tables), H, C.byref(self.geom), ptr(codes[j]),
-                                               codes[j].stride(0), ptr(slots[j]), ptr(window), ptr(send[j]),
-                                               ptr(counts[j:j + 1]) if counts is not None else None, stream()),
-                      "nsx_hash_ensemble_fwd")
-        recv = torch.empty_like(send)
-        if S_cap:
-            self._all_to_all(recv, send)
-        self.stats["samples_fwd"] += sum(s for s, _ in sizes)
-        return recv[:, :S].permute(1, 0, 2).reshape(S, W * n2).contiguous()
+            return feats
+        if ex is None:
+            ex = self.exchange_sizes(S, int(code.shape[0]))
+        if S != ex.S or int(code.shape[0]) > ex.R_cap:
+            raise RuntimeError(f"level-parallel HashEnsemble: this pass has {S} samples / {code.shape[0]} code rows, the sizes "
+                               f"exchanged for it say {ex.S} / <= {ex.R_cap}")
+        lay = ex.lay
+        payload = self._bytes(lay.fwd_bytes, dev)
+        ops.fwd_pack(lay, x, slot, S, n_dev, code, int(code.shape[0]), payload)
+        ex.gathered = self._bytes(W * lay.fwd_bytes, dev)
+        self._all_gather(ex.gathered, payload)
+        send = self._bytes(W * lay.feat_bytes, dev)
+        ex.codes_packed = torch.empty((ex.n_planes, H), dtype=torch.float32, device=dev)
+        ex.window = window
+        ops.fwd_run(lay, ex.gathered, ex, tables, self.geom, window, send, ex.codes_packed)
+        recv = self._bytes(W * lay.feat_bytes, dev)
+        self._all_to_all(recv, send)
+        feats = out if out is not None else torch.empty((S, W * n2), dtype=torch.float16, device=dev)
+        ops.fwd_unpack(lay, recv, S, n_dev, feats)
+        self.stats["samples_fwd"] += sum(ex.sizes)
+        self.last_exchange = ex
+        return feats
 
     # ---- backward -----------------------------------------------------------------------------------------------------
     def begin_step(self) -> None:
@@ -236,103 +329,79 @@ class LevelParallel:
         return self.G[:need].view(n_planes, self.n_entries, 2)
 
     @torch.no_grad()
-    def backward(self, x: torch.Tensor, code_index: torch.Tensor, dout: torch.Tensor, code: torch.Tensor,
-                 window: Optional[torch.Tensor], n_dev: Optional[torch.Tensor], need_code: bool, need_table: bool = True):
-        """The backward of ``features`` for this rank's samples: returns (dL/dx [S,3] fp32, dL/dcode [rows,H] fp32 or None);
-        the table gradient of the OWNED levels over ALL ranks' samples is left in the factored planes for
-        ``LevelParallelTableAdam``.  ``n_dev``: device count of valid rows (the arrays have marched capacity).  Collective."""
-        he, W, r = self.he, self.world_size, self.rank
+    def backward(self, x: torch.Tensor, code_index: torch.Tensor, dout: torch.Tensor, code: Optional[torch.Tensor] = None,
+                 window: Optional[torch.Tensor] = None, n_dev: Optional[torch.Tensor] = None, need_code: bool = True,
+                 need_table: bool = True, ex: Optional[Exchange] = None, dx_out: Optional[torch.Tensor] = None,
+                 dcode_out: Optional[torch.Tensor] = None):
+        """The backward of ``features`` for this rank's samples: returns (dL/dx [S,3] fp32, dL/dcode [rows,H] fp32); the
+        table gradient of the OWNED levels over ALL ranks' samples is left in the factored planes for
+        ``LevelParallelTableAdam``.  ``ex``: the forward exchange this is the backward of (default: the most recent one) --
+        its sizes, its code rows and its window are used again; ``x`` may hold fewer rows than that forward (the kept
+        samples), ``n_dev`` counts the valid ones on the device.  The code gradient is always formed (the exchange does not
+        depend on a rank-local flag).  Collective."""
+        he, W = self.he, self.world_size
         he.wait_tables()
+        ex = ex if ex is not None else self.last_exchange
+        if ex is None or ex.gathered is None:
+            raise RuntimeError("level-parallel HashEnsemble: a backward without a forward exchange")
         dev = x.device
         x = x.detach().to(torch.float32).contiguous()
-        code = code.detach().to(torch.float32).contiguous()
         slot = code_index.detach().to(torch.int32).contiguous()
-        S, rows, H, n2 = int(x.shape[0]), int(code.shape[0]), he.n_hash_encodings, 2 * self.n_own
-        sizes, S_cap, xs, slots, codes = self._gather_samples(x, slot, code)
-        counts = None
-        if n_dev is not None:
-            counts = torch.empty((W,), dtype=torch.int64, device=dev)
-            self._all_gather(counts, n_dev.reshape(1))
-        # dL/dfeatures by column block of the owning rank, fp16 on the links
-        send = torch.zeros((W, S_cap, n2), dtype=torch.float16, device=dev)
-        if S:
-            send[:, :S].copy_(dout.detach().reshape(S, W, n2).permute(1, 0, 2))
-        recv = torch.empty_like(send)
-        if S_cap:
-            self._all_to_all(recv, send)
-        dz = recv.to(torch.float32)
-        row_base, n_planes = [], 0
-        for _, rj in sizes:
-            row_base.append(n_planes)
-            n_planes += rj
-        if n_planes > MAX_ADAM_SLOTS:
-            raise RuntimeError(f"level-parallel HashEnsemble: {n_planes} code rows in the job's batch (limit {MAX_ADAM_SLOTS})")
-        G = self._planes(n_planes, dev) if need_table else None
+        dout = dout.detach().to(torch.float32).contiguous()
+        S, H = int(x.shape[0]), he.n_hash_encodings
+        if S > ex.S_cap:
+            raise RuntimeError(f"level-parallel HashEnsemble: {S} samples in the backward of a forward exchange of capacity {ex.S_cap}")
+        lay, ops = ex.lay, self.ops
+        send = self._bytes(W * lay.bwd_bytes, dev)
+        ops.bwd_pack(lay, dout, x, slot, S, n_dev, send)
+        recv = self._bytes(W * lay.bwd_bytes, dev)
+        self._all_to_all(recv, send)
+        G = self._planes(ex.n_planes, dev) if need_table else None
+        if self.nonfinite is None or self.nonfinite.device != dev:
+            self.nonfinite = torch.zeros((1,), dtype=torch.float32, device=dev)
+        ret = self._bytes(W * lay.ret_bytes, dev)
+        ops.bwd_run(lay, recv, ex.gathered, ex, self.slice_f16(), self.geom, ex.window, G, ret, self.nonfinite)
         if self.backward_calls == 0 or self.codes_packed is None:
-            self.codes_packed = torch.cat(codes, dim=0).contiguous() if n_planes else None
-            self.window = window
-        dx_all = torch.zeros((W, S_cap, 3), dtype=torch.float32, device=dev)
-        R_cap = max(rj for _, rj in sizes)
-        dcode_all = torch.zeros((W, R_cap, H), dtype=torch.float32, device=dev) if need_code else None
-        tables = self.slice_f16()
-        L_ = lib()
-        for j in range(W):
-            Sj, rj = sizes[j]
-            if not Sj:
-                continue
-            Gj = G[row_base[j]:row_base[j] + rj] if G is not None else None
-            cnt = counts[j:j + 1] if counts is not None else None
-            nonf = ptr(self.nonfinite) if Gj is not None else None
-            if need_code:
-                dcj = dcode_all[j, :rj]
-                check(L_.nsx_hash_ensemble_bwd_codesum(ptr(xs[j]), Sj, ptr(tables), H, C.byref(self.geom), ptr(codes[j]),
-                                                       codes[j].stride(0), rj, ptr(slots[j]), ptr(window), ptr(dz[j]),
-                                                       ptr(Gj), ptr(dcj), ptr(F.codesum_scratch(rj, H, dev)), ptr(dx_all[j]),
-                                                       nonf, ptr(cnt), stream()), "nsx_hash_ensemble_bwd_codesum")
-            else:
-                check(L_.nsx_hash_ensemble_bwd_factored(ptr(xs[j]), Sj, ptr(tables), H, C.byref(self.geom), ptr(codes[j]),
-                                                        codes[j].stride(0), rj, ptr(slots[j]), ptr(window), ptr(dz[j]),
-                                                        ptr(Gj), None, ptr(dx_all[j]), nonf, ptr(cnt), stream()),
-                      "nsx_hash_ensemble_bwd_factored")
+            self.codes_packed, self.window = ex.codes_packed, ex.window
         self.backward_calls += 1
-        self.samples_scattered += sum(s for s, _ in sizes)
+        n_job = sum(min(s, ex.S_cap) for s in ex.sizes)
+        self.samples_scattered += n_job
         self.stats["bwd_calls"] += 1
-        self.stats["samples_bwd"] += sum(s for s, _ in sizes)
-        # partial dL/dx back to the samples' owners, partial code gradients summed over the level owners
-        dx_recv = torch.empty_like(dx_all)
-        if S_cap:
-            self._all_to_all(dx_recv, dx_all)
-        dx = dx_recv[:, :S].sum(dim=0)
-        dcode = None
-        if need_code:
-            dist.all_reduce(dcode_all, op=dist.ReduceOp.SUM, group=self.group)
-            self.stats["bytes_in"] += 2 * (W - 1) * dcode_all.numel() * 4 // W
-            dcode = dcode_all[r, :rows].contiguous()
+        self.stats["samples_bwd"] += n_job
+        # partial dL/dx and partial code-row gradients back to the samples' owners, summed over the level owners
+        ret_recv = self._bytes(W * lay.ret_bytes, dev)
+        self._all_to_all(ret_recv, ret)
+        dx = dx_out if dx_out is not None else torch.empty((S, 3), dtype=torch.float32, device=dev)
+        dcode = dcode_out if dcode_out is not None else torch.empty((ex.n_rows, H), dtype=torch.float32, device=dev)
+        ops.bwd_unpack(lay, ret_recv, S, n_dev, ex.n_rows, dx, dcode)
+        ex.backward_done = True
         return dx, dcode
 
     @torch.no_grad()
     def join_backward(self) -> None:
-        """A rank whose step produced no backward (its rays marched no sample) joins the other ranks' exchange with zero
-        samples -- every rank issues the same collectives in the same order."""
-        he = self.he
-        dev = he.tables.device
-        H = he.n_hash_encodings
-        self.backward(torch.zeros((0, 3), device=dev), torch.zeros((0,), dtype=torch.int32, device=dev),
-                      torch.zeros((0, 2 * he.geom.n_levels), device=dev), torch.zeros((1, H), device=dev), self.window, None,
-                      need_code=self._last_need_code, need_table=True)
-
-    _last_need_code = False
+        """A rank whose step ran a forward exchange but no backward (nothing of its loss reached the hash features) joins
+        the other ranks' backward exchange with zero valid rows -- every rank issues the same collectives in the same
+        order."""
+        ex = self.last_exchange
+        if ex is None or ex.backward_done or ex.gathered is None:
+            return
+        dev = ex.gathered.device
+        L2 = 2 * self.he.geom.n_levels
+        self.backward(torch.zeros((1, 3), device=dev), torch.zeros((1,), dtype=torch.int32, device=dev),
+                      torch.zeros((1, L2), device=dev), n_dev=torch.zeros((1,), dtype=torch.int64, device=dev), ex=ex)
 
     # ---- the whole table on every rank again (evaluation, checkpoints, leaving the mode) -----------------------------------
     @torch.no_grad()
     def gather_entry_ranges(self, full: torch.Tensor, mine: Optional[torch.Tensor] = None) -> torch.Tensor:
         """``full`` [entries, 2, Hp]: every rank's owned entry range is made current everywhere (``mine``: this rank's
         range if it does not live in ``full`` already).  Collective; the ranges differ in size, so each one is broadcast by
-        its owner."""
+        its owner.  (An emulated rank has nobody to hear from: its own range is all it can make current.)"""
         for r, (a, b) in enumerate(self.entry_ranges):
             piece = full[a:b]
             if r == self.rank and mine is not None:
                 piece.copy_(mine)
+            if self.emulate:
+                continue
             dist.broadcast(piece, src=dist.get_global_rank(self.group, r) if self.group is not None else r, group=self.group)
         return full
 
@@ -345,21 +414,20 @@ class _LPHashFn(torch.autograd.Function):
     def forward(ctx, lp: LevelParallel, x, tables_master, code, code_index, window, precomputed):
         xx = x.detach().to(torch.float32).contiguous()
         cc = code.detach().to(torch.float32).contiguous()
-        out = precomputed.detach() if precomputed is not None else lp.features(xx, cc, code_index, window)
-        ctx.lp = lp
-        ctx.save_for_backward(xx, cc, code_index, window)
         ctx.n_dev = _lib.ndev_tensor(xx.shape[0])
+        out = precomputed.detach() if precomputed is not None else lp.features(xx, cc, code_index, window, n_dev=ctx.n_dev)
+        ctx.lp = lp
+        ctx.ex = lp.last_exchange         # (precomputed: the exchange of the pass that produced the values -- the sigma pass)
+        ctx.save_for_backward(xx, code_index)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        xx, cc, code_index, window = ctx.saved_tensors
+        xx, code_index = ctx.saved_tensors
         lp = ctx.lp
-        need_code = bool(ctx.needs_input_grad[3])
-        lp._last_need_code = need_code
-        dx, dcode = lp.backward(xx, code_index, dout, cc, window, ctx.n_dev, need_code=need_code,
-                                need_table=bool(ctx.needs_input_grad[2]))
-        return None, (dx if ctx.needs_input_grad[1] else None), None, dcode, None, None, None
+        dx, dcode = lp.backward(xx, code_index, dout, n_dev=ctx.n_dev, need_table=bool(ctx.needs_input_grad[2]), ex=ctx.ex)
+        return (None, (dx if ctx.needs_input_grad[1] else None), None, (dcode if ctx.needs_input_grad[3] else None), None,
+                None, None)
 
 
 def lp_hash_ensemble(lp: LevelParallel, x, tables_master, code, code_index, window, precomputed=None):
@@ -374,11 +442,11 @@ class LevelParallelTableAdam(torch.optim.Optimizer):
 
     def __init__(self, hash_ensemble: HashEnsemble, lr: float = 5e-3, betas=(0.9, 0.999), eps: float = 1e-15,
                  world_size: int = 1, rank: int = 0, group=None, step: int = 0, exp_avg: Optional[torch.Tensor] = None,
-                 exp_avg_sq: Optional[torch.Tensor] = None):
+                 exp_avg_sq: Optional[torch.Tensor] = None, emulate: bool = False):
         super().__init__([hash_ensemble.tables], dict(lr=lr, betas=betas, eps=eps))
         self.he = hash_ensemble
         self.world_size, self.rank, self.group = int(world_size), int(rank), group
-        self.lp = LevelParallel(hash_ensemble, world_size, rank, group)
+        self.lp = LevelParallel(hash_ensemble, world_size, rank, group, emulate=emulate)
         hash_ensemble.level_parallel = self.lp
         hash_ensemble.grad_sink = None                       # (the planes of LevelParallel take the table gradient)
         p = hash_ensemble.tables
@@ -491,7 +559,11 @@ class LevelParallelTableAdam(torch.optim.Optimizer):
         out = {"exchange": "level_parallel", "world_size": self.world_size, "levels_per_rank": lp.n_own,
                "owned_entries": lp.n_entries, "steps": n, "bytes_per_rank": st["bytes_in"] / n,
                "samples_fwd_per_step": st["samples_fwd"] / n, "samples_bwd_per_step": st["samples_bwd"] / n,
-               "fwd_exchanges_per_step": st["fwd_calls"] / n, "shard_adam_ms": total / n_adam, "gradient_planes": lp.planes}
+               "fwd_exchanges_per_step": st["fwd_calls"] / n, "shard_adam_ms": total / n_adam, "gradient_planes": lp.planes,
+               # device collectives (all-gather / all-to-all of this exchange; the occupancy update's column all-gather every
+               # 16th step is among them) and host-side size exchanges per step
+               "collectives_per_step": st["collectives"] / n, "host_exchanges_per_step": st["host_exchanges"] / n,
+               "emulated_rank": (lp.rank if lp.emulate else None)}
         if reset:
             lp.stats = {k: 0 for k in st}
             self._events = []

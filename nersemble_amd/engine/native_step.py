@@ -56,7 +56,7 @@ class _StepState:
     """Everything one step's drivers share: the plan, the argument structs, the workspaces (kept alive until the backward
     has been enqueued), the tensors the factored-gradient sink and the optimizer look at afterwards."""
     __slots__ = ("plan", "sample", "main", "ws_sample", "ws_fwd", "out", "S", "R", "n_rows", "H", "he", "first_grid",
-                 "main_code", "main_window", "keep", "grads", "code_width")
+                 "main_code", "main_window", "keep", "grads", "code_width", "lp", "lp_ex")
 
 
 class _GradBuffers:
@@ -134,7 +134,7 @@ class _NativeMain(torch.autograd.Function):
         ctx.st = st
         ctx.leaves = (base_params, head_params) + tuple(deform_params)
         ctx.sink = st.he.grad_sink
-        ctx.announced = ctx.needs_input_grad[1]
+        ctx.announced = ctx.needs_input_grad[1] and ctx.sink is not None
         if ctx.announced:
             ctx.sink.expect()
         return st.out
@@ -157,6 +157,16 @@ class _NativeMain(torch.autograd.Function):
         m.need_code_grad = 1 if need_code else 0
         L, s = lib(), stream()
         check(L.nsx_step_main_bwd(C.byref(m), 0, s), "nsx_step_main_bwd stage 0")
+        if st.lp is not None:
+            # level-parallel exchange instead of stage 1: dL/dfeatures travels to the levels' owners, whose gradient planes
+            # take the table gradient; dL/dx and the code-row gradient come back summed (engine/level_parallel.py)
+            S = st.S
+            st.lp.backward(_view(st.ws_fwd, plan.f_pn, (S, 3), torch.float32), _view(st.ws_sample, plan.k_slot, (S,), torch.int32),
+                           _view(ws_bwd, plan.b_dout, (S, 32), torch.float32),
+                           n_dev=_view(st.ws_sample, plan.n_kept, (1,), torch.int64), need_table=bool(need_tab), ex=st.lp_ex,
+                           dx_out=_view(ws_bwd, plan.b_dx, (S, 3), torch.float32), dcode_out=gb.g_code_hash)
+            check(L.nsx_step_main_bwd(C.byref(m), 2, s), "nsx_step_main_bwd stage 2")
+            return _NativeMain._hand_over(ctx, st, gb, leaves, need_code, dev)
         # the factored table gradient of the step (cleared ahead / left clean by the optimizer / cleared here)
         G = None
         if need_tab:
@@ -169,6 +179,10 @@ class _NativeMain(torch.autograd.Function):
             # G is complete, and so are the gradients of the two fused MLPs (the rest of the tables' optimizer group)
             sink.arrived(group_grads=[gb.d_base, gb.d_head] if sink.on_complete is not None else None)
         check(L.nsx_step_main_bwd(C.byref(m), 2, s), "nsx_step_main_bwd stage 2")
+        return _NativeMain._hand_over(ctx, st, gb, leaves, need_code, dev)
+
+    @staticmethod
+    def _hand_over(ctx, st, gb, leaves, need_code, dev):
         ctx.st = None                    # the workspaces go back to the allocator with this node
         g_code = gb.g_code_hash if need_code else None
         if g_code is not None and st.H != st.code_width:
@@ -300,7 +314,8 @@ class NativeStep:
         he = model.field.hash_ensemble
         if not (model.reuse_sigma_pass and model.device_sample_counts and "image_index" in md and "_image_timesteps" in md
                 and (cfg.alpha_thre > 0 or cfg.early_stop_eps > 0) and not cfg.disable_occupancy_grid
-                and he.grad_sink is not None and ray_bundle.nears is None and ray_bundle.fars is None
+                and (he.grad_sink is not None or he.level_parallel is not None)
+                and ray_bundle.nears is None and ray_bundle.fars is None
                 and (ray_bundle.times is not None or "timesteps" in md)):
             return None
         uniq = md["_image_timesteps"].reshape(-1).int()
@@ -349,7 +364,8 @@ class NativeStep:
         alpha_thre_dev = grid._alpha_threshold(float(cfg.alpha_thre))
         # -- what the HashEnsemble kernels see: the H grids with conditioned codes and the window -- or, in the compact
         # first-grid phase (HashEnsemble.first_grid_phase), the contiguous copy of grid 0 with a constant code of one
-        width = he.compact_width(window_hash)
+        lp = he.level_parallel
+        width = he.compact_width(window_hash) if lp is None else 0
         first = width == 1
         # (the previous step's table optimizer may still be running on its stream: only the HashEnsemble kernel waits for it --
         # the traversal and the deformation field of this step run beside it, as on the per-kernel path)
@@ -365,6 +381,8 @@ class NativeStep:
                 he.leave_first_grid_phase()
                 tables, Hk = he.half_tables(wait=False), he.n_hash_encodings
             main_code, main_window = code_hash.detach().contiguous(), window
+            if lp is not None and main_window is None:
+                raise RuntimeError("level-parallel HashEnsemble needs the window schedule (window_hash_encodings)")
         # (the sigma_fn pass reads the SAME rows as the main pass: the batch's conditioned code rows through the per-ray slot;
         # rounds 3-4 conditioned the dataset's whole [T, H] table for it every step)
         code_d = code_deform.detach().contiguous()
@@ -406,8 +424,23 @@ class NativeStep:
         a.far_plane, a.step, a.early_stop_eps = far, float(cfg.render_step_size), float(cfg.early_stop_eps)
         for i in range(6):
             a.occ_aabb[i], a.deform_aabb[i], a.field_aabb[i] = occ_aabb[i], deform_aabb[i], field_aabb[i]
-        check(L.nsx_step_sample_run(C.byref(a), stream()), "nsx_step_sample_run")
-        if not first:
+        lp_ex = None
+        if lp is None:
+            check(L.nsx_step_sample_run(C.byref(a), stream()), "nsx_step_sample_run")
+        else:
+            # level-parallel: the sampler up to the normalised positions, the sample exchange (this rank's levels for every
+            # rank's samples; the features of ALL levels come back into the workspace), the rest of the sampler
+            a.phase = 1
+            check(L.nsx_step_sample_run(C.byref(a), stream()), "nsx_step_sample_run (front)")
+            lp_ex = lp.exchange_sizes(S, n_rows)                 # (host-side, while the device runs the front)
+            if tables_event is not None:
+                torch.cuda.current_stream(dev).wait_event(tables_event)
+            lp.features(_view(ws_sample, plan.m_pn, (S, 3), torch.float32), main_code,
+                        _view(ws_sample, plan.m_slot, (S,), torch.int32), main_window, ex=lp_ex,
+                        out=_view(ws_sample, plan.m_feat, (S, 32), torch.float16))
+            a.phase = 2
+            check(L.nsx_step_sample_run(C.byref(a), stream()), "nsx_step_sample_run (back)")
+        if not first and he.grad_sink is not None:
             # (the sampler's sigma_fn pass is queued: from here to the HashEnsemble's backward only small kernels run)
             he.grad_sink.clear_ahead(n_rows, he.geom.total_entries, dev)
         # -- the kept samples' main pass: one autograd node
@@ -445,6 +478,7 @@ class NativeStep:
         st.S, st.R, st.n_rows, st.H, st.he, st.first_grid = S, R, n_rows, Hk, he, first
         st.main_code, st.main_window = main_code, main_window
         st.code_width = int(code_hash.shape[1])
+        st.lp, st.lp_ex = lp, lp_ex
         deform_params = df.ordered_params()
         gkey = (n_rows, Hk, str(dev), plan.grad_bytes)
         st.grads = self._grad_buffers.get(gkey)

@@ -14,7 +14,7 @@ SMALL_BUCKET_ELEMS = 1 << 22
 
 
 def all_reduce_gradients(params: Iterable[torch.nn.Parameter], world_size: int, group=None,
-                         takes_part: Optional[Sequence[bool]] = None):
+                         takes_part: Optional[Sequence[bool]] = None, force: bool = False):
     """In-place average of ``p.grad`` over all ranks.  A parameter without a gradient on this rank contributes zeros
     (every rank must join every collective).  What it is left with afterwards follows from whether the parameter took
     part in the step on ANY rank:
@@ -36,7 +36,7 @@ def all_reduce_gradients(params: Iterable[torch.nn.Parameter], world_size: int, 
     by some ranks and dropped by others.
 
     Returns ``[2, len(params)]`` (device): ranks that held a gradient, ranks that dropped theirs.  None for one process."""
-    if world_size <= 1:
+    if world_size <= 1 and not force:             # (force: a one-rank group still issues its collectives -- emulated ranks)
         return None
     params = [p for p in params if p.requires_grad]
     if not params:

@@ -70,7 +70,8 @@ class NeRSembleTrainer:
                  rank: Optional[int] = None, sharded_table_adam: Optional[bool] = None,
                  overlap_table_adam: bool = True, calibrate_table_placement: bool = True,
                  global_loss_normalisers: bool = False, early_table_step: bool = False,
-                 compact_first_grid: bool = True, table_parallel: Optional[str] = "auto"):
+                 compact_first_grid: bool = True, table_parallel: Optional[str] = "auto",
+                 level_parallel_emulation: Optional[Tuple[int, int]] = None):
         """``global_loss_normalisers``: the ranks hold consecutive slices of ONE ray batch (strong scaling)
         -- loss denominators are made global so that the step equals the single-process step on the union batch."""
         self.model = model
@@ -80,6 +81,12 @@ class NeRSembleTrainer:
         # parameters (engine/level_parallel.py); "level" = level-parallel from the first step; "shard" / None = the
         # reduce-scatter exchange throughout (rounds 1-4)
         self.table_parallel = table_parallel
+        # ``level_parallel_emulation = (N, r)`` (single process, a one-rank process group): train as rank r of an N-rank
+        # level-parallel job whose other ranks are replicas of this one -- the partition, the exchange and every collective
+        # of such a rank (on the one-rank group), measurable on one GPU (engine/level_parallel.py, ``emulate``)
+        self.level_parallel_emulation = tuple(level_parallel_emulation) if level_parallel_emulation else None
+        if self.level_parallel_emulation is not None and world_size != 1:
+            raise ValueError("level_parallel_emulation runs in a single process (world_size = 1)")
         # ``compact_first_grid``: while the coarse-to-fine window keeps one hash grid on (the first 40 000 steps of the
         # reference's schedule), train a contiguous copy of that grid with the H = 1 kernels instead of the 32-grid layout
         # (HashEnsemble.first_grid_phase: same values, ~1.4-1.7x per step).  Single GPU, factored table gradient.  ON by
@@ -138,7 +145,13 @@ class NeRSembleTrainer:
                 # factored_table_grad=False keeps the dense fp32 gradient + all-reduce path.
                 sharded = (world_size > 1 and factored_table_grad is not False) if sharded_table_adam is None \
                     else sharded_table_adam
-                if sharded:
+                if self.level_parallel_emulation is not None:
+                    n_emu, r_emu = self.level_parallel_emulation
+                    opt_emu = LevelParallelTableAdam(model.field.hash_ensemble, lr=lrs[name], eps=self.cfg.eps,
+                                                     world_size=n_emu, rank=r_emu, emulate=True)
+                    model.field.hash_ensemble._level_parallel_owner = opt_emu
+                    self.optimizers[name + "/tables"] = opt_emu
+                elif sharded:
                     # (the exchange follows the coarse-to-fine window: every rank's schedule holds the same value)
                     sched = getattr(model, "sched_window_hash_encodings", None)
                     self.optimizers[name + "/tables"] = ShardedTableAdam(
@@ -206,7 +219,7 @@ class NeRSembleTrainer:
 
     # ---- data-parallel gradient averaging ------------------------------------------------------------
     def _all_reduce_grads(self) -> None:
-        if self.world_size <= 1:
+        if self.world_size <= 1 and self.level_parallel_emulation is None:
             return
         # (the sharded table optimizer runs its own reduce-scatter; its parameter has no dense gradient -- every rank has
         # started that collective before the ones below are issued, also a rank without samples)
@@ -217,7 +230,8 @@ class NeRSembleTrainer:
                   for pg in opt.param_groups for p in pg["params"]]
         # which parameters took part in the PREVIOUS step (on any rank): its counts have reached the host by now
         self.flush_scheduler_step()
-        self._presence = all_reduce_gradients(params, self.world_size, takes_part=self._took_part)
+        self._presence = all_reduce_gradients(params, self.world_size, takes_part=self._took_part,
+                                              force=self.level_parallel_emulation is not None)
 
     def _arm_early_table_step(self):
         """Single GPU, fused main pass: let the table optimizer start from inside the backward (HashTableAdam.
@@ -293,7 +307,7 @@ class NeRSembleTrainer:
             elif not isinstance(opt, SmallGroupAdam):
                 grads = [p.grad for pg in opt.param_groups for p in pg["params"] if p.grad is not None]
                 scaler.unscale_and_check(grads, f, inv_scale)
-        if self.world_size > 1:
+        if self.world_size > 1 or self.level_parallel_emulation is not None:
             # a step is skipped on every rank or on none: the shard-level checks of the table gradient differ per rank
             dist.all_reduce(found_all, op=dist.ReduceOp.MAX)
         for key, opt in self.optimizers.items():
@@ -472,7 +486,7 @@ class NeRSembleTrainer:
             flags = self._found_host.tolist()
         else:
             flags = val.tolist()
-        if self.world_size > 1 and self._presence_host is not None:
+        if (self.world_size > 1 or self.level_parallel_emulation is not None) and self._presence_host is not None:
             counts = self._presence_host.tolist()
             check_gradient_presence(counts, self.world_size)
             self._took_part = [c > 0 for c in counts[0]]

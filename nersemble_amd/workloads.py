@@ -51,7 +51,8 @@ def build_model_config(w: dict, max_n_samples_per_batch: int = 20, small: bool =
 def build_workload(name: str, device="cuda:0", small: bool = False, rank: int = 0, world_size: int = 1,
                    n_rays: int = None, factored_table_grad=None, sharded_table_adam=None,
                    global_loss_normalisers: bool = False, window_hash: Optional[Tuple[int, int]] = None,
-                   compact_first_grid: Optional[bool] = None, table_parallel: Optional[str] = "auto"
+                   compact_first_grid: Optional[bool] = None, table_parallel: Optional[str] = "auto",
+                   level_parallel_emulation: Optional[Tuple[int, int]] = None
                    ) -> Tuple[NeRSembleTrainer, SyntheticNeRSembleData, dict]:
     """``window_hash``: (begin, end) steps of the coarse-to-fine schedule of the hash grids instead of the workload's
     (train_nersemble.py:77-78: 40000, 80000); (0, 1) has every grid switched on from step 1 -- the state of a run after
@@ -71,7 +72,7 @@ def build_workload(name: str, device="cuda:0", small: bool = False, rank: int = 
     trainer = NeRSembleTrainer(model, OptimizerConfig(), mixed_precision=True, world_size=world_size,
                                factored_table_grad=factored_table_grad, rank=rank,
                                sharded_table_adam=sharded_table_adam, global_loss_normalisers=global_loss_normalisers,
-                               table_parallel=table_parallel,
+                               table_parallel=table_parallel, level_parallel_emulation=level_parallel_emulation,
                                **({} if compact_first_grid is None else {"compact_first_grid": compact_first_grid}))
     info = dict(workload=name, participant=w["pid"], n_hash_encodings=w["H"], n_timesteps=w["T"], rays=rays,
                 params=sum(p.numel() for p in model.parameters()))

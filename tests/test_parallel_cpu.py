@@ -2,6 +2,8 @@
 import os
 import socket
 
+import pytest
+
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -482,6 +484,136 @@ def test_global_loss_normalisers_world2_equal_the_union_batch(tmp_path):
 
 
 # ---- level-parallel exchange (engine/level_parallel.py): the collectives' plumbing on CPU tensors --------------------------
+class _TorchLPOps:
+    """Torch restatement of csrc/level_parallel.hip's pack / run / unpack entry points on CPU byte buffers with the layout of
+    ``nsx_lp_layout_make`` (host-only: the library's own), so that the whole exchange -- sizes, payloads, counts, blocks,
+    gradient planes -- runs over gloo.  The two per-source-rank KERNELS are stand-ins with a closed form the test can
+    recompute from the ranks' inputs:
+
+        feature[s][2 i + f]  = fp16( x[s][0] * (l + 1) + code[slot[s]][0] / 2 + f ),  l = first owned level + i
+        dx partial[s][d]     = (d + 1) * (owner + 1) * sum_c dz[s][c]
+        dcode partial[r][h]  = (h + 1) * sum_{s in row r} sum_c dz[s][c]
+        G[plane of (j, r)][0][0] += sum_{s in row r} sum_c dz[s][c]
+    """
+
+    def __init__(self, owner_rank, first_level):
+        self.owner, self.first_level = owner_rank, first_level
+
+    @staticmethod
+    def layout(W, S_cap, R_cap, H, n2):
+        from nersemble_amd.engine.level_parallel import NativeLPOps
+        return NativeLPOps.layout(W, S_cap, R_cap, H, n2)
+
+    @staticmethod
+    def _count(S, n_dev):
+        return int(S) if n_dev is None else max(0, min(int(n_dev.item()), int(S)))
+
+    @staticmethod
+    def _f32(buf, off, n):
+        return buf[off:off + 4 * n].view(torch.float32)
+
+    @staticmethod
+    def _i32(buf, off, n):
+        return buf[off:off + 4 * n].view(torch.int32)
+
+    @staticmethod
+    def _f16(buf, off, n):
+        return buf[off:off + 2 * n].view(torch.float16)
+
+    def fwd_pack(self, lay, pn, slot, S, n_dev, codes, rows, payload):
+        n = self._count(S, n_dev)
+        payload[lay.f_count:lay.f_count + 8].view(torch.int64)[0] = n
+        self._f32(payload, lay.f_pn, n * 3).copy_(pn[:n].reshape(-1))
+        self._i32(payload, lay.f_slot, n).copy_(slot[:n])
+        self._f32(payload, lay.f_codes, rows * lay.H).copy_(codes[:rows].reshape(-1))
+
+    def fwd_run(self, lay, gathered, ex, tables, geom, window, send, codes_packed):
+        W, n_own = lay.W, lay.n2 // 2
+        base = 0
+        for j in range(W):
+            blk = gathered[j * lay.fwd_bytes:(j + 1) * lay.fwd_bytes]
+            rows = int(ex.rows_host[j])
+            codes = self._f32(blk, lay.f_codes, rows * lay.H).view(rows, lay.H)
+            codes_packed[base:base + rows].copy_(codes)
+            base += rows
+            Sj = int(ex.sizes_host[j])
+            n = min(Sj, int(blk[lay.f_count:lay.f_count + 8].view(torch.int64)[0]))
+            if n == 0:
+                continue
+            x = self._f32(blk, lay.f_pn, n * 3).view(n, 3)
+            sl = self._i32(blk, lay.f_slot, n).long()
+            out = self._f16(send[j * lay.feat_bytes:(j + 1) * lay.feat_bytes], 0, n * lay.n2).view(n, n_own, 2)
+            for i in range(n_own):
+                for f in range(2):
+                    out[:, i, f] = (x[:, 0] * (self.first_level + i + 1) + codes[sl, 0] / 2 + f).half()
+
+    def fwd_unpack(self, lay, recv, S, n_dev, feats):
+        n = self._count(S, n_dev)
+        for j in range(lay.W):
+            blk = recv[j * lay.feat_bytes:(j + 1) * lay.feat_bytes]
+            feats[:n, j * lay.n2:(j + 1) * lay.n2] = self._f16(blk, 0, n * lay.n2).view(n, lay.n2)
+
+    def bwd_pack(self, lay, dout, pn, slot, S, n_dev, send):
+        n = self._count(S, n_dev)
+        for j in range(lay.W):
+            blk = send[j * lay.bwd_bytes:(j + 1) * lay.bwd_bytes]
+            blk[lay.b_count:lay.b_count + 8].view(torch.int64)[0] = n
+            self._f16(blk, lay.b_dz, n * lay.n2).view(n, lay.n2).copy_(dout[:n, j * lay.n2:(j + 1) * lay.n2].half())
+            self._f32(blk, lay.b_pn, n * 3).copy_(pn[:n].reshape(-1))
+            self._i32(blk, lay.b_slot, n).copy_(slot[:n])
+
+    def bwd_run(self, lay, recv, gathered, ex, tables, geom, window, G, ret, nonfinite):
+        plane = 0
+        for j in range(lay.W):
+            rows, Sj = int(ex.rows_host[j]), int(ex.sizes_host[j])
+            blk = recv[j * lay.bwd_bytes:(j + 1) * lay.bwd_bytes]
+            rj = ret[j * lay.ret_bytes:(j + 1) * lay.ret_bytes]
+            dcode = self._f32(rj, lay.r_dcode, lay.R_cap * lay.H).view(lay.R_cap, lay.H)
+            dcode.zero_()
+            n = min(Sj, max(0, int(blk[lay.b_count:lay.b_count + 8].view(torch.int64)[0])))
+            if Sj > 0 and n > 0:
+                dz = self._f16(blk, lay.b_dz, n * lay.n2).view(n, lay.n2).float().sum(dim=1)
+                sl = self._i32(blk, lay.b_slot, n).long()
+                dx = self._f32(rj, lay.r_dx, n * 3).view(n, 3)
+                for d in range(3):
+                    dx[:, d] = (d + 1) * (self.owner + 1) * dz
+                per_row = torch.zeros((rows,)).index_add_(0, sl, dz)
+                dcode[:rows] = per_row[:, None] * torch.arange(1, lay.H + 1, dtype=torch.float32)[None, :]
+                if G is not None:
+                    G[plane:plane + rows, 0, 0] += per_row
+            plane += rows
+
+    def bwd_unpack(self, lay, ret_recv, S, n_dev, rows, dx, dcode):
+        n = self._count(S, n_dev)
+        dx[:n] = 0
+        dcode[:rows] = 0
+        for j in range(lay.W):
+            rj = ret_recv[j * lay.ret_bytes:(j + 1) * lay.ret_bytes]
+            dx[:n] += self._f32(rj, lay.r_dx, n * 3).view(n, 3)
+            dcode[:rows] += self._f32(rj, lay.r_dcode, lay.R_cap * lay.H).view(lay.R_cap, lay.H)[:rows]
+
+    def shared_columns(self, x, S, tables, H, geom, code, slot, window, cols):
+        n_own = geom.n_levels
+        out = self._f16(cols, 0, S * 2 * n_own).view(S, n_own, 2)
+        for i in range(n_own):
+            for f in range(2):
+                out[:, i, f] = (x[:, 0] * (self.first_level + i + 1) + code[slot.long(), 0] / 2 + f).half()
+
+
+def _lp_rank_inputs(rank, world, H, L):
+    """What rank ``rank`` brings to a step (every rank can rebuild everyone's): ragged sample sets, ranks 1 and world - 2
+    without samples (world > 2; rank 1 of 2 in the second pass), 1 ... 3 code rows, fewer kept samples than marched ones."""
+    g = torch.Generator().manual_seed(1000 + rank)
+    S = 0 if (world > 2 and rank in (1, world - 2)) else 3 + 2 * rank
+    rows = 1 + rank % 3
+    x = torch.rand((S, 3), generator=g)
+    slot = torch.randint(0, rows, (S,), generator=g, dtype=torch.int32)
+    code = torch.randn((rows, H), generator=g)
+    kept = S if rank % 2 == 0 else max(S - 2, 0)                   # the backward's device-side count
+    dout = (torch.randn((S, 2 * L), generator=g) * 4).half().float()    # fp16-representable, as nsx_mlp_bwd emits
+    return S, rows, x, slot, code, kept, dout
+
+
 def _lp_plumbing_worker(rank, world, port, out_dir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -489,61 +621,104 @@ def _lp_plumbing_worker(rank, world, port, out_dir):
     from types import SimpleNamespace
     from nersemble_amd import _lib
     from nersemble_amd.engine.level_parallel import LevelParallel, sub_geometry
-    geom = _lib.grid_geometry(n_levels=8, per_level_scale=1.5, base_resolution=4, log2_hashmap_size=9)
-    he = SimpleNamespace(geom=geom, n_hash_encodings=4)
-    lp = LevelParallel(he, world, rank)
-    ok = lp.n_own == 4 and lp.first_level == 4 * rank and lp.e0 == int(geom.offset[4 * rank])
-    ok &= lp.entry_ranges[0][1] == lp.entry_ranges[1][0] and lp.entry_ranges[1][1] == geom.total_entries
+    L, H = (8 if world == 2 else 2 * world), 4
+    n_own = L // world
+    geom = _lib.grid_geometry(n_levels=L, per_level_scale=1.3, base_resolution=4, log2_hashmap_size=9)
+    f16 = torch.zeros((geom.total_entries, 2, H), dtype=torch.float16)
+    he = SimpleNamespace(geom=geom, n_hash_encodings=H, wait_tables=lambda: None, half_tables=lambda: f16,
+                         tables=SimpleNamespace(data=f16.float()))
+    lp = LevelParallel(he, world, rank, ops=_TorchLPOps(rank, rank * n_own))
+    ok = lp.n_own == n_own and lp.first_level == n_own * rank and lp.e0 == int(geom.offset[n_own * rank])
+    ok &= all(lp.entry_ranges[r][1] == lp.entry_ranges[r + 1][0] for r in range(world - 1))
+    ok &= lp.entry_ranges[-1][1] == geom.total_entries
     # sub-geometry: the owned levels, offsets re-based to the range's first entry
-    sg = sub_geometry(geom, 4 * rank, 4)
-    for i in range(4):
-        l = 4 * rank + i
+    sg = sub_geometry(geom, n_own * rank, n_own)
+    for i in range(n_own):
+        l = n_own * rank + i
         ok &= sg.scale[i] == geom.scale[l] and sg.res[i] == geom.res[l] and sg.size[i] == geom.size[l]
-        ok &= sg.hashed[i] == geom.hashed[l] and sg.offset[i] == geom.offset[l] - geom.offset[4 * rank]
+        ok &= sg.hashed[i] == geom.hashed[l] and sg.offset[i] == geom.offset[l] - geom.offset[n_own * rank]
     ok &= sg.total_entries == lp.n_entries
-    # ragged sample sets: rank 0 has 5 samples and 2 code rows, rank 1 has 3 samples and 3 code rows
-    S, rows = (5, 2) if rank == 0 else (3, 3)
-    x = torch.arange(S * 3, dtype=torch.float32).reshape(S, 3) + 100 * rank
-    slot = (torch.arange(S, dtype=torch.int32) % rows) + 7 * rank
-    code = torch.arange(rows * 4, dtype=torch.float32).reshape(rows, 4) + 1000 * rank
-    sizes, S_cap, xs, slots, codes = lp._gather_samples(x, slot, code)
-    ok &= sizes == [[5, 2], [3, 3]] and S_cap == 5
-    for j, (Sj, rj) in enumerate(sizes):
-        ok &= torch.equal(xs[j], torch.arange(Sj * 3, dtype=torch.float32).reshape(Sj, 3) + 100 * j)
-        ok &= torch.equal(slots[j], (torch.arange(Sj, dtype=torch.int32) % rj) + 7 * j)
-        ok &= torch.equal(codes[j], torch.arange(rj * 4, dtype=torch.float32).reshape(rj, 4) + 1000 * j)
-    # all-to-all of equal blocks: out[j] = rank j's inp[this rank]
-    inp = torch.stack([torch.full((S_cap, 2), float(10 * rank + k)) for k in range(world)])
-    out = torch.empty_like(inp)
-    lp._all_to_all(out, inp)
-    for j in range(world):
-        ok &= bool((out[j] == 10 * j + rank).all())
-    # ... and the branch RCCL takes (dist.all_to_all_single, which gloo has for CPU tensors) gives the same blocks
-    inp3 = torch.arange(world * S_cap * 3, dtype=torch.float16).reshape(world, S_cap, 3) + 1000 * rank
-    out_a, out_b = torch.empty_like(inp3), torch.empty_like(inp3)
-    lp._all_to_all(out_a, inp3)
-    lp._a2a_native = True
-    lp._all_to_all(out_b, inp3)
-    lp._a2a_native = False
-    ok &= torch.equal(out_a, out_b) and bool((out_b[1 - rank] == inp3[rank] - 1000 * rank + 1000 * (1 - rank)).all())
-    # an empty rank takes part
-    sizes2, cap2, xs2, _, _ = lp._gather_samples(x[:0] if rank == 1 else x, slot[:0] if rank == 1 else slot, code)
-    ok &= sizes2[1][0] == 0 and cap2 == 5 and xs2[1].shape == (0, 3) and torch.equal(xs2[0][:, 0], x[:, 0] if rank == 0 else xs2[0][:, 0])
+    everyone = [_lp_rank_inputs(r, world, H, L) for r in range(world)]
+    S, rows, x, slot, code, kept, dout = everyone[rank]
+    window = torch.ones((H,))
+    for a2a_native in (False, True):             # the gloo stand-in, then the all_to_all_single branch RCCL takes
+        lp._a2a_native = a2a_native
+        lp.begin_step()
+        before = dict(lp.stats)
+        # ---- forward: every level's columns of MY samples, whoever owns the level
+        feats = lp.features(x, code, slot, window)
+        ex = lp.last_exchange
+        ok &= ex.sizes == [e[0] for e in everyone] and ex.rows == [e[1] for e in everyone]
+        ok &= ex.S_cap == max(1, max(e[0] for e in everyone)) and ex.n_planes == sum(e[1] for e in everyone)
+        want = torch.empty((S, 2 * L), dtype=torch.float16)
+        for l in range(L):
+            for f in range(2):
+                want[:, 2 * l + f] = (x[:, 0] * (l + 1) + code[slot.long(), 0] / 2 + f).half()
+        ok &= feats.shape == (S, 2 * L) and torch.equal(feats, want)
+        ok &= torch.equal(ex.codes_packed, torch.cat([e[4] for e in everyone]))
+        # ---- backward under a device-side count: partials summed over the owners, planes in (source rank, row) order
+        n_dev = torch.tensor([kept], dtype=torch.int64)
+        dx, dcode = lp.backward(x, slot, dout, n_dev=n_dev)
+        colsum = dout[:kept].view(kept, world, 2 * n_own).sum(dim=2)                  # per owner
+        want_dx = torch.stack([(d + 1) * (colsum * torch.arange(1, world + 1)[None, :]).sum(dim=1) for d in range(3)], dim=1)
+        ok &= torch.allclose(dx[:kept], want_dx, rtol=1e-5, atol=1e-4)
+        per_row = torch.zeros((rows,)).index_add_(0, slot[:kept].long(), dout[:kept].sum(dim=1))
+        ok &= torch.allclose(dcode, per_row[:, None] * torch.arange(1, H + 1)[None, :], rtol=1e-5, atol=1e-4)
+        G = lp.G[:lp.planes * lp.n_entries * 2].view(lp.planes, lp.n_entries, 2)
+        plane = 0
+        for r, (Sr, rr, _, slr, _, kr, dr) in enumerate(everyone):
+            mine = dr[:kr, rank * 2 * n_own:(rank + 1) * 2 * n_own].sum(dim=1)
+            wantG = torch.zeros((rr,)).index_add_(0, slr[:kr].long(), mine)
+            ok &= torch.allclose(G[plane:plane + rr, 0, 0], wantG, rtol=1e-5, atol=1e-4)
+            plane += rr
+        ok &= lp.planes == plane and G.abs().sum().item() == G[:, 0, 0].abs().sum().item()
+        # ONE host exchange and FOUR collectives per step, whatever this rank brought
+        ok &= lp.stats["host_exchanges"] - before["host_exchanges"] == 1
+        ok &= lp.stats["collectives"] - before["collectives"] == 4
+    # the occupancy update: identical positions everywhere, only the column blocks travel
+    xs = torch.rand((7, 3), generator=torch.Generator().manual_seed(5))
+    cs = torch.randn((2, H), generator=torch.Generator().manual_seed(6))
+    ss = torch.tensor([0, 1, 1, 0, 1, 0, 0], dtype=torch.int32)
+    before = dict(lp.stats)
+    with lp.shared():
+        fs = lp.features(xs, cs, ss, window)
+    want = torch.empty((7, 2 * L), dtype=torch.float16)
+    for l in range(L):
+        for f in range(2):
+            want[:, 2 * l + f] = (xs[:, 0] * (l + 1) + cs[ss.long(), 0] / 2 + f).half()
+    ok &= torch.equal(fs, want) and lp.stats["collectives"] - before["collectives"] == 1
+    ok &= lp.stats["host_exchanges"] == before["host_exchanges"]
+    # a rank whose loss never reached the hash features joins the backward exchange with zero rows
+    lp.begin_step()
+    lp.features(x, code, slot, window)
+    if rank == 0:
+        lp.join_backward()
+    else:
+        lp.backward(x, slot, dout, n_dev=torch.tensor([kept], dtype=torch.int64))
+    G = lp.G[:lp.planes * lp.n_entries * 2].view(lp.planes, lp.n_entries, 2)
+    ok &= float(G[:everyone[0][1], 0, 0].abs().sum()) == 0.0                        # rank 0's planes: nothing arrived
     # every rank's entry range becomes current everywhere
     full = torch.full((geom.total_entries, 2, 4), float(rank + 1))
     lp.gather_entry_ranges(full)
-    a, b = lp.entry_ranges
-    ok &= bool((full[a[0]:a[1]] == 1).all()) and bool((full[b[0]:b[1]] == 2).all())
+    for r, (a, b) in enumerate(lp.entry_ranges):
+        ok &= bool((full[a:b] == r + 1).all())
     ok &= lp.stats["bytes_in"] > 0
     torch.save({"ok": bool(ok)}, os.path.join(out_dir, f"lp{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_level_parallel_exchange_plumbing_world2(tmp_path):
-    """The collectives of the level-parallel HashEnsemble on CPU tensors over gloo: level ownership and sub-geometries,
-    the ragged all-gather of (positions, code slots, code rows), the block all-to-all (gloo stand-in and the all_to_all_single branch RCCL takes), an empty rank, the
-    broadcast of the ranks' entry ranges.  The kernels between them run on the GPU (tests/test_sharded_gpu.py)."""
+@pytest.mark.parametrize("world", [2, 8])
+def test_level_parallel_exchange_plumbing(world, tmp_path):
+    """The whole level-parallel exchange on CPU tensors over gloo with the library's own payload layout
+    (``nsx_lp_layout_make``) and torch stand-ins for the device side: level ownership and sub-geometries, the one host-side
+    size exchange, ragged sample sets and code rows, ranks without samples, device-side counts below the capacity, the
+    all-gather of the forward payloads, the three block all-to-alls (gloo stand-in AND the all_to_all_single branch RCCL
+    takes), the gradient planes in (source rank, code row) order, partial dL/dx / code gradients summed over the owners, the
+    shared-input exchange of the occupancy update, a rank that joins the backward without one, the broadcast of the ranks'
+    entry ranges.  world 8 = 2 levels per rank, the shape of BASELINE.json configs[4].  The kernels between the collectives
+    run on the GPU (tests/test_sharded_gpu.py)."""
     port = _free_port()
-    mp.spawn(_lp_plumbing_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
-    assert torch.load(tmp_path / "lp0.pt")["ok"] and torch.load(tmp_path / "lp1.pt")["ok"]
+    mp.spawn(_lp_plumbing_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        assert torch.load(tmp_path / f"lp{r}.pt")["ok"], r

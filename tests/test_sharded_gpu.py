@@ -211,11 +211,12 @@ def _no_jitter(trainer):
     grid.counted_march = counted_march
 
 
-def _union_data(n_rays_total):
+def _union_data(n_rays_total, workload="p030_h16"):
     from nersemble_amd.data.synthetic import SyntheticNeRSembleData
-    from nersemble_amd.workloads import SCENE_BOXES
-    box = torch.tensor(SCENE_BOXES[30], dtype=torch.float32)
-    return SyntheticNeRSembleData(box, n_timesteps=100, n_rays=n_rays_total, device="cuda:0", rank=0)
+    from nersemble_amd.workloads import SCENE_BOXES, WORKLOADS
+    w = WORKLOADS[workload]
+    box = torch.tensor(SCENE_BOXES[w["pid"]], dtype=torch.float32)
+    return SyntheticNeRSembleData(box, n_timesteps=w["T"], n_rays=n_rays_total, device="cuda:0", rank=0)
 
 
 def _slice_batch(bundle, batch, lo, hi):
@@ -317,7 +318,7 @@ def _level_worker(rank, world, port, out_dir, workload="p030_h16", per=256):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from nersemble_amd.engine.level_parallel import LevelParallelTableAdam
     from nersemble_amd.workloads import build_workload
-    bundle, batch = _union_data(per * world).next_train(0)
+    bundle, batch = _union_data(per * world, workload).next_train(0)
     torch.manual_seed(19980801)
     trainer, data, _ = build_workload(workload, device="cuda:0", small=True, n_rays=per, rank=rank, world_size=world,
                                       global_loss_normalisers=True, window_hash=OPEN_WINDOW, table_parallel="auto")
@@ -328,6 +329,7 @@ def _level_worker(rank, world, port, out_dir, workload="p030_h16", per=256):
     assert isinstance(opt, LevelParallelTableAdam)             # the window is beyond H / 2: the exchange switched at step 0
     comm = opt.comm_report(reset=False)
     model = trainer.model
+    assert model._native is not None                            # the step ran through the native drivers, split at the exchange
     grads = {n: p.grad.detach().float().cpu() for n, p in model.named_parameters() if "tables" not in n and p.grad is not None}
     lp = opt.lp
     own = (lp.e0, lp.e1)
@@ -396,6 +398,7 @@ def test_level_parallel_ranks_equal_one_process_on_the_union_batch(cuda, tmp_pat
     d = (a["tables"] - tables).abs()
     frac = (d[moved] <= 1e-5).float().mean().item()
     assert frac >= 0.995, frac
+    _differences_are_sign_flips(a["tables"], tables, init_tables, lr=5e-3)
     assert "time_embedding.weight" in grads                                        # the window is open: the time codes train
     for name, g_ref in grads.items():
         sc = g_ref.abs().max().item()
@@ -409,6 +412,8 @@ def test_level_parallel_ranks_equal_one_process_on_the_union_batch(cuda, tmp_pat
         assert c["exchange"] == "level_parallel" and c["levels_per_rank"] == 8 and c["gradient_planes"] > 0
         n_job = c["samples_bwd_per_step"]
         assert n_job > 0 and c["bytes_per_rank"] <= (2 * 64 + 16 + 16 + 12) * max(c["samples_fwd_per_step"], n_job) + 65536
+        # ONE host-side size exchange and FOUR device collectives per step (+ the occupancy update's column all-gather)
+        assert c["host_exchanges_per_step"] == 1 and c["collectives_per_step"] <= 5
         # (this test's tables are 4 MB; at the reference geometry the reduce-scatter exchange moves 2 x 403 MB per rank and
         # step at W = 2 whatever the batch kept -- profiles/r05_two_ranks_one_gpu_gloo_level_parallel.json)
     # the run goes on: replicated parameters identical, tables identical after consolidation, the optimizer counted 3 steps
@@ -460,6 +465,7 @@ def test_four_level_parallel_ranks_with_32_grids_step_through_the_matrix_core_pa
     d = (rs[0]["tables"] - tables).abs()
     frac = (d[moved] <= 1e-5).float().mean().item()
     assert frac >= 0.995, frac
+    _differences_are_sign_flips(rs[0]["tables"], tables, init_tables, lr=5e-3)
     # ... level range by level range (a plane order that is wrong for ONE owner would hide in the average)
     for lo, hi in bounds:
         mv = moved[lo:hi]
@@ -472,6 +478,204 @@ def test_four_level_parallel_ranks_with_32_grids_step_through_the_matrix_core_pa
             err = (r["grads"][name] - g_ref).abs().max().item()
             assert err <= 2e-3 * sc + 1e-9, (name, err, sc)
     assert not torch.equal(rs[0]["tables_after"], rs[0]["tables"])
+
+
+def test_eight_level_parallel_ranks_on_the_p124_model_equal_one_process(cuda, tmp_path):
+    """The shape of BASELINE.json configs[4] (participant 124, 475 timesteps, 32 hash grids, ray batch sharded over 8 ranks):
+    world_size 8 on one GPU (gloo), 2 levels per rank, 8 x 24 = 192 gradient planes -- the limit of the optimizer pass.  One
+    step on a 512-ray batch sliced 8 x 64 equals the single-process step on the whole batch at the bars of the world-2 test."""
+    import torch.multiprocessing as mp
+    from nersemble_amd.workloads import build_workload
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    world = 8
+    mp.spawn(_level_worker, args=(world, port, str(tmp_path), "p124_dp", 64), nprocs=world, join=True)
+    rs = [torch.load(tmp_path / f"l{r}.pt") for r in range(world)]
+    bundle, batch = _union_data(512, "p124_dp").next_train(0)
+    torch.manual_seed(19980801)
+    single, _, _ = build_workload("p124_dp", device="cuda:0", small=True, n_rays=512, window_hash=OPEN_WINDOW)
+    init_tables = single.model.field.hash_ensemble.tables.detach().cpu().clone()
+    _no_jitter(single)
+    loss, loss_dict, _ = single.train_iteration(0, bundle, batch)
+    single.flush_scheduler_step()
+    single.consolidate()
+    tables = single.model.field.hash_ensemble.tables.detach().cpu()
+    grads = {n: p.grad.detach().float().cpu() for n, p in single.model.named_parameters()
+             if "tables" not in n and p.grad is not None}
+    moved = (tables - init_tables).abs() > 1e-4
+    assert moved.float().mean().item() > 1e-3
+    bounds = [r["own"] for r in rs]
+    assert bounds[0][0] == 0 and bounds[-1][1] == tables.shape[0] and all(bounds[i][1] == bounds[i + 1][0] for i in range(7))
+    for r in rs:
+        c = r["comm"]
+        assert c["exchange"] == "level_parallel" and c["levels_per_rank"] == 2 and c["gradient_planes"] == 192
+        assert torch.equal(r["tables"], rs[0]["tables"]) and torch.equal(r["small"], rs[0]["small"])
+        assert torch.equal(r["tables_after"], rs[0]["tables_after"]) and torch.equal(r["small_after"], rs[0]["small_after"])
+        assert all(np.isfinite(r["losses_after"])) and r["table_step"] == 3
+    assert np.isclose(sum(r["loss"] for r in rs) / world, loss.item(), rtol=2e-4)
+    for k, v in loss_dict.items():
+        assert np.isclose(sum(r["terms"][k] for r in rs) / world, v.item(), rtol=2e-3, atol=1e-9), k
+    d = (rs[0]["tables"] - tables).abs()
+    assert (d[moved] <= 1e-5).float().mean().item() >= 0.995
+    _differences_are_sign_flips(rs[0]["tables"], tables, init_tables, lr=5e-3)
+    for lo, hi in bounds:
+        mv = moved[lo:hi]
+        if mv.any():
+            assert (d[lo:hi][mv] <= 1e-5).float().mean().item() >= 0.99, (lo, hi)
+    for name, g_ref in grads.items():
+        sc = g_ref.abs().max().item()
+        for r in rs:
+            err = (r["grads"][name] - g_ref).abs().max().item()
+            assert err <= 2e-3 * sc + 1e-9, (name, err, sc)
+
+
+def _differences_are_sign_flips(tables, ref, init, lr):
+    """Adam's FIRST step moves an entry with gradient g by -lr * g / (|g| + eps): +-lr unless g is within a few orders of
+    eps = 1e-15, never more.  Two runs whose gradients agree up to summation order can therefore differ at an entry only
+    because the (cancelling) gradient changed sign -- the entries are 2 lr apart -- or vanished in one of them -- lr apart.
+    Said entry by entry instead of as a percentage: EVERY entry that differs holds two first-step moves (both within
+    [-lr, lr], at most 2 lr apart), and nearly all of them sit exactly on {-lr, 0, +lr}."""
+    a, b = tables - init, ref - init
+    differs = (tables - ref).abs() > 1e-5
+    if not differs.any():
+        return
+    da, db = a[differs], b[differs]
+    assert float(da.abs().max()) <= lr + 1e-5 and float(db.abs().max()) <= lr + 1e-5, "a move larger than a first Adam step"
+    on_lattice = lambda v: ((v.abs() - lr).abs() <= 1e-5) | (v.abs() <= 1e-7)
+    exact = (on_lattice(da) & on_lattice(db)).float().mean().item()
+    assert exact >= 0.99, f"only {exact:.4f} of the differing entries are sign flips / vanishings of a +-lr move"
+
+
+def test_emulated_level_parallel_rank_through_rccl(cuda, single_rank_group):
+    """Rank r of a W-rank level-parallel job whose other ranks are replicas of itself (``LevelParallel(emulate=True)``) on a
+    real one-rank RCCL group: ``all_gather_into_tensor`` / ``all_to_all_single`` run on NCCL, the size exchange on the gloo
+    side group.  The own levels' columns are bit-identical to the single kernel's columns of those levels, every replica's
+    gradient planes equal the direct backward on the sub-geometry, the partial dL/dx / code gradients come back summed
+    over the W (identical) owners, and the valid-row count never leaves the device."""
+    import ctypes as C
+    from nersemble_amd import functional as F
+    from nersemble_amd._lib import check, lib, ptr, stream
+    from nersemble_amd.engine.level_parallel import LevelParallel
+    H, W, r, B, T, kept = 8, 3, 1, 3001, 5, 2500
+    he = _he(H, cuda)
+    he.train()
+    lp = LevelParallel(he, W, r, emulate=True)
+    assert lp._a2a_native and dist.get_backend(lp.cpu_group) == "gloo" and dist.get_backend() == "nccl"
+    g = torch.Generator(device=cuda).manual_seed(3)
+    x = torch.rand((B, 3), device=cuda, generator=g)
+    code = torch.randn((T, H), device=cuda, generator=g)
+    slot = torch.randint(0, T, (B,), device=cuda, generator=g, dtype=torch.int32)
+    window = torch.rand((H,), device=cuda, generator=g)
+    full = F._hash_ensemble_fwd_raw(x, he.half_tables(), H, he.geom, code, slot, window)
+    feats = lp.features(x, code, slot, window)
+    n2 = 2 * lp.n_own
+    assert feats.shape == (B, W * n2)
+    for j in range(W):
+        assert torch.equal(feats[:, j * n2:(j + 1) * n2], full[:, r * n2:(r + 1) * n2])
+    assert lp.stats["collectives"] == 2 and lp.stats["host_exchanges"] == 1
+    ex = lp.last_exchange
+    assert ex.sizes == [B] * W and ex.rows == [T] * W and ex.n_planes == W * T
+    assert torch.equal(ex.codes_packed, code.repeat(W, 1))
+    block = (torch.randn((B, n2), device=cuda, generator=g) * 3).half().float()
+    n_dev = torch.tensor([kept], dtype=torch.int64, device=cuda)
+    lp.begin_step()
+    dx, dcode = lp.backward(x, slot, block.repeat(1, W), n_dev=n_dev)
+    assert lp.stats["collectives"] == 4
+    n_e = lp.n_entries
+    G_d = torch.zeros((T, n_e, 2), device=cuda)
+    dcode_d = torch.empty((T, H), device=cuda)
+    dx_d = torch.zeros((B, 3), device=cuda)
+    check(lib().nsx_hash_ensemble_bwd_codesum(ptr(x), B, ptr(lp.slice_f16()), H, C.byref(lp.geom), ptr(code), code.stride(0), T,
+                                              ptr(slot), ptr(window), ptr(block), ptr(G_d), ptr(dcode_d),
+                                              ptr(F.codesum_scratch(T, H, cuda)), ptr(dx_d), None, ptr(n_dev), stream()),
+          "direct backward")
+    G = lp.G[:W * T * n_e * 2].view(W, T, n_e, 2)
+    tol = 2e-5 * G_d.abs().max().item()
+    assert G_d.abs().max().item() > 0
+    for j in range(W):
+        assert (G[j] - G_d).abs().max().item() <= tol
+    assert torch.allclose(dx[:kept], W * dx_d[:kept], rtol=1e-5, atol=1e-6 * dx_d.abs().max().item())
+    assert torch.allclose(dcode, W * dcode_d, rtol=1e-5, atol=1e-6 * dcode_d.abs().max().item())
+    # rows beyond the device-side count were neither packed nor unpacked
+    dx2 = torch.full((B, 3), 7.0, device=cuda)
+    lp.begin_step()
+    lp.backward(x, slot, block.repeat(1, W), n_dev=n_dev, dx_out=dx2)
+    assert bool((dx2[kept:] == 7.0).all()) and torch.allclose(dx2[:kept], dx[:kept])
+
+
+def test_emulated_rank_7_of_8_trains_through_the_native_step(cuda, single_rank_group):
+    """``NeRSembleTrainer(level_parallel_emulation=(8, 7))``: the training step of the finest levels' owner of an 8-rank job on
+    one GPU -- native step drivers split at the exchange, four device collectives + one host-side size exchange per step on
+    the one-rank RCCL / gloo groups, 8 x 24 gradient planes through the matrix-core optimizer pass."""
+    from nersemble_amd.engine.level_parallel import LevelParallelTableAdam
+    from nersemble_amd.workloads import build_workload
+    torch.manual_seed(0)
+    trainer, data, _ = build_workload("p030_h32", device="cuda:0", small=True, n_rays=512, window_hash=OPEN_WINDOW,
+                                      level_parallel_emulation=(8, 7))
+    opt = trainer.optimizers[trainer.group_of_tables()]
+    assert isinstance(opt, LevelParallelTableAdam) and opt.lp.emulate and opt.lp.n_own == 2 and opt.lp.first_level == 14
+    losses = []
+    for step in range(1, 4):                                    # (no occupancy update in these steps: step % 16 != 0)
+        loss, _, _ = trainer.train_iteration(step, *data.next_train(step))
+        losses.append(loss.item())
+    trainer.flush_scheduler_step()
+    assert all(np.isfinite(losses))
+    assert trainer.model._native is not None
+    st = opt.lp.stats
+    assert st["bwd_calls"] == 3 and st["fwd_calls"] == 3 and st["collectives"] == 12 and st["host_exchanges"] == 3
+    assert opt.lp.planes == 8 * 24 and opt._step == 3
+    c = opt.comm_report()
+    assert c["collectives_per_step"] == 4 and c["host_exchanges_per_step"] == 1 and c["gradient_planes"] == 192
+
+
+def _empty_rank_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from nersemble_amd.workloads import build_workload
+    torch.manual_seed(19980801)
+    trainer, data, _ = build_workload("p030_h16", device="cuda:0", small=True, n_rays=256, rank=rank, world_size=world,
+                                      window_hash=OPEN_WINDOW, table_parallel="level")
+    losses, marched = [], []
+    for step in range(1, 4):
+        bundle, batch = data.next_train(step)
+        if rank == 1 and step == 2:
+            bundle.directions = -bundle.directions              # every ray leaves the scene: nothing is marched on this rank
+        loss, _, metrics = trainer.train_iteration(step, bundle, batch)
+        losses.append(loss.item())
+        marched.append(int(trainer.model.occupancy_grid.last_n_marched))
+    trainer.flush_scheduler_step()
+    opt = trainer.optimizers[trainer.group_of_tables()]
+    stats = dict(opt.lp.stats)
+    trainer.consolidate()
+    model = trainer.model
+    torch.save({"losses": losses, "marched": marched, "stats": stats,
+                "tables": model.field.hash_ensemble.tables.detach().cpu(),
+                "small": torch.cat([p.detach().reshape(-1).cpu() for n, p in model.named_parameters() if "tables" not in n])},
+               os.path.join(out_dir, f"e{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_a_rank_that_marches_nothing_issues_the_same_collectives(cuda, tmp_path):
+    """Two level-parallel ranks on one GPU (gloo); in the second step every ray of rank 1 points away from the scene, so
+    its marcher counts zero samples, the native drivers decline and the per-kernel path runs the reference's one-fake-sample
+    step (nersemble_volumetric_sampler.py:109-115).  The collective sequence does not depend on it: one size exchange, an
+    all-gather and three all-to-alls per step on BOTH ranks, no hang, replicas identical afterwards."""
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_empty_rank_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    a, b = torch.load(tmp_path / "e0.pt"), torch.load(tmp_path / "e1.pt")
+    assert all(np.isfinite(a["losses"])) and all(np.isfinite(b["losses"]))
+    assert b["marched"][1] <= 0 < a["marched"][1]
+    for r in (a, b):
+        assert r["stats"]["host_exchanges"] == 3 and r["stats"]["collectives"] == 12
+    assert torch.equal(a["tables"], b["tables"]) and torch.equal(a["small"], b["small"])
 
 
 def _switch_worker(rank, world, port, out_dir):
