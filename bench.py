@@ -234,7 +234,7 @@ def steady_state(trainer, data, first_step: int, settle_at: int, rays: int, n_ti
     lp_opt = lp_opt if isinstance(lp_opt, LevelParallelTableAdam) else None
     if lp_opt is not None:
         lp_opt.comm_report()
-        lp_opt.timing = True
+        lp_opt.timing = lp_opt.lp.timing = True
     gc.collect()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -256,7 +256,7 @@ def steady_state(trainer, data, first_step: int, settle_at: int, rays: int, n_ti
            "unit": "ray-samples/s", "rays_per_sec": rays * n_timed / dt, "samples_per_step_min_max": [min(counts), max(counts)],
            "psnr": float(metrics["psnr"].detach())}
     if lp_opt is not None:
-        lp_opt.timing = False
+        lp_opt.timing = lp_opt.lp.timing = False
         out["_comm"] = lp_opt.comm_report()
         # host issue time: the same steps issued into an EMPTY queue (a device synchronisation in front of every step), the
         # median of the host's time inside train_iteration -- what the host needs per step when it never waits for the device
@@ -991,10 +991,32 @@ def main():
                 state = ("steady_compact" if a.compact_first_grid else
                          "steady_open_window" if (a.window_hash and tuple(a.window_hash) == (0, 1)) else
                          "steady_full" if a.window_hash is None else None)
-            out["steady_state"] = steady_state(trainer, data, a.preroll + a.warmup + a.steps, a.steady_after, info["rays"],
-                                               datamanager=dm, H=0 if a.no_kernel_events else H, pmc_state=state)
             if lp_emulation:
+                # the emulated rank of a TRAINED model: a single-GPU run to the steady state (the real model: its occupancy
+                # grid and visibility pruning decide how many samples a step marches and keeps), which then goes on as the
+                # emulated rank with frozen parameters and the true feature columns (engine/trainer.py,
+                # become_emulated_level_parallel_rank) -- every kernel and collective of such a rank at a trained model's
+                # sample counts.  (The timed region above is the same rank from a FRESH model: dense steps need no model.)
+                del trainer
+                torch.cuda.empty_cache()
+                torch.manual_seed(19980801)
+                trainer, data, info = build_workload(a.workload, device=dev, window_hash=tuple(a.window_hash),
+                                                     compact_first_grid=False)
+                for s_ in range(a.steady_after):
+                    trainer.train_iteration(s_, *data.next_train(s_))
+                trainer.flush_scheduler_step()
+                trainer.become_emulated_level_parallel_rank(*lp_emulation)
+                out["steady_state"] = steady_state(trainer, data, a.steady_after, a.steady_after, info["rays"],
+                                                   H=0 if a.no_kernel_events else H)
                 out["steady_state"]["comm"] = out["steady_state"].pop("_comm", None)
+                out["steady_state"]["protocol"] = (
+                    f"{a.steady_after} single-GPU steps (window open), then rank {lp_emulation[1]} of {lp_emulation[0]} "
+                    f"emulated with frozen parameters; the replicas' feature columns replaced by one full-geometry forward "
+                    f"per pass (comm.shadow_fwd_ms: extra work of the emulation, inside ms_per_step)")
+            else:
+                out["steady_state"] = steady_state(trainer, data, a.preroll + a.warmup + a.steps, a.steady_after,
+                                                   info["rays"], datamanager=dm, H=0 if a.no_kernel_events else H,
+                                                   pmc_state=state)
         if steady_ranks is not None:
             out["steady_state"] = steady_ranks
         spp = [p["samples"] for p in out["per_step"]]

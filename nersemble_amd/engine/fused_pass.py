@@ -88,12 +88,12 @@ class _MainPass(torch.autograd.Function):
         elif lp is not None:
             # data-parallel run with the window open: this rank's levels for every rank's samples (engine/level_parallel.py)
             feats = lp.features(pn, code_h, hash_slot, hash_window, n_dev=inp.n_dev)
-        # (level-parallel: the forward exchange whose backward this node's is -- its own, or the sigma_fn pass's)
-        ctx.lp_ex = lp.last_exchange if lp is not None else None
         else:
             feats = torch.empty((S, 2 * geom.n_levels), dtype=f16, device=dev)
             check(L.nsx_hash_ensemble_fwd(ptr(pn), S, ptr(tables_f16), H, C.byref(geom), ptr(code_h), code_h.stride(0),
                                           ptr(hash_slot), ptr(hash_window), ptr(feats), ndev(S), st), "nsx_hash_ensemble_fwd")
+        # (level-parallel: the forward exchange whose backward this node's is -- its own, or the sigma_fn pass's)
+        ctx.lp_ex = lp.last_exchange if lp is not None else None
         if inp.pre_base is not None:
             base_out = inp.pre_base
         else:

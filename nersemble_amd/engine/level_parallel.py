@@ -168,6 +168,14 @@ class LevelParallel:
         self.cpu_group = group if backend == "gloo" else dist.new_group(backend="gloo")
         if self.emulate and dist.get_world_size(group) != 1:
             raise ValueError("an emulated rank runs on a one-rank process group")
+        # emulated rank only: after the exchange, ONE launch of the full-geometry forward on this rank's own samples writes
+        # the TRUE feature columns of all levels over the replicas' copies (this process holds the whole table): the model
+        # then sees what the real job's ranks would have delivered, and -- with its parameters frozen -- the sample counts
+        # of the steps stay those of the trained model while every kernel and collective of the emulated rank runs.  The
+        # launch is extra work the real rank does not have; ``comm_report`` prices it (``shadow_fwd_ms``).
+        self.shadow_forward = False
+        self.timing = False
+        self._shadow_events = []
         self.shared_inputs = False       # every rank holds the SAME positions (occupancy update): no position exchange
         self.nonfinite = None            # device float: a backward added an inf / NaN to G
         self.G = None                    # [planes][own entries][2] fp32, planes = sum of the ranks' code rows
@@ -277,6 +285,7 @@ class LevelParallel:
             feats = out if out is not None else torch.empty((S, W * n2), dtype=torch.float16, device=dev)
             ops.fwd_unpack(lay, allc, S, None, feats)
             self.stats["samples_fwd"] += S
+            self._shadow(x, code, slot, window, None, feats)
             return feats
         if ex is None:
             ex = self.exchange_sizes(S, int(code.shape[0]))
@@ -298,7 +307,23 @@ class LevelParallel:
         ops.fwd_unpack(lay, recv, S, n_dev, feats)
         self.stats["samples_fwd"] += sum(ex.sizes)
         self.last_exchange = ex
+        self._shadow(x, code, slot, window, n_dev, feats)
         return feats
+
+    def _shadow(self, x, code, slot, window, n_dev, feats) -> None:
+        if not (self.emulate and self.shadow_forward) or x.shape[0] == 0:
+            return
+        he = self.he
+        ev = None
+        if self.timing:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+        check(lib().nsx_hash_ensemble_fwd(ptr(x), int(x.shape[0]), ptr(he.half_tables()), he.n_hash_encodings,
+                                          C.byref(he.geom), ptr(code), code.stride(0), ptr(slot), ptr(window), ptr(feats),
+                                          ptr(n_dev), stream()), "nsx_hash_ensemble_fwd (shadow)")
+        if ev is not None:
+            ev[1].record()
+            self._shadow_events.append(ev)
 
     # ---- backward -----------------------------------------------------------------------------------------------------
     def begin_step(self) -> None:
@@ -464,8 +489,25 @@ class LevelParallelTableAdam(torch.optim.Optimizer):
         hash_ensemble.half_tables()                          # the working copy exists and is current when the mode starts
 
     # ---- the trainer's two phases ---------------------------------------------------------------------------------------
+    reduced_nonfinite = None        # set by the trainer: the ranks' flags summed in the small gradients' bucket
+
+    def local_nonfinite(self) -> torch.Tensor:
+        """This rank's flag: one of its backward calls added an inf / NaN to its gradient planes (device, fp32 [1])."""
+        lp = self.lp
+        if lp.nonfinite is None or not lp.backward_calls:
+            dev = self.he.tables.device
+            if lp.nonfinite is None or lp.nonfinite.device != dev:
+                lp.nonfinite = torch.zeros((1,), dtype=torch.float32, device=dev)
+            else:
+                lp.nonfinite.zero_()
+        return lp.nonfinite
+
     @torch.no_grad()
     def check_finite(self, found_inf: torch.Tensor) -> None:
+        if self.reduced_nonfinite is not None:
+            # the job's flags (summed over the ranks): every rank skips the step or none does
+            torch.maximum(found_inf, (self.reduced_nonfinite > 0).to(found_inf.dtype), out=found_inf)
+            return
         nf = self.lp.nonfinite
         if self.lp.backward_calls and nf is not None:
             torch.maximum(found_inf, nf.to(found_inf.dtype), out=found_inf)
@@ -477,6 +519,7 @@ class LevelParallelTableAdam(torch.optim.Optimizer):
             self.lp.join_backward()
 
     def _mark(self, what: str):
+        self.lp.timing = self.timing
         if not self.timing or not self.he.tables.is_cuda:
             return
         ev = torch.cuda.Event(enable_timing=True)
@@ -564,9 +607,13 @@ class LevelParallelTableAdam(torch.optim.Optimizer):
                # 16th step is among them) and host-side size exchanges per step
                "collectives_per_step": st["collectives"] / n, "host_exchanges_per_step": st["host_exchanges"] / n,
                "emulated_rank": (lp.rank if lp.emulate else None)}
+        if lp.emulate and lp.shadow_forward:
+            # what the emulation ADDS to a step: the full-geometry forward that replaces the replicas' feature columns
+            out["shadow_fwd_ms"] = sum(a.elapsed_time(b) for a, b in lp._shadow_events) / n
         if reset:
             lp.stats = {k: 0 for k in st}
             self._events = []
+            lp._shadow_events = []
         return out
 
     # ---- checkpointing / leaving the mode ------------------------------------------------------------------------------------

@@ -69,10 +69,15 @@ class _GradBuffers:
     so ``AccumulateGrad`` copies instead of stealing -- 18 device copies of ~5 us in a row at the end of every backward,
     with their allocations and launches on the host (``profiles/r04_timeline_steady_state_compact.txt``)."""
 
+    SLACK = 1 << 18
+
     def __init__(self, plan, n_rows: int, H: int, code_deform_shape, deform_shapes, head_hidden: int, base_hidden: int,
                  device):
         f32 = torch.float32
-        self.flat = torch.empty((plan.grad_bytes // 4,), dtype=f32, device=device)
+        # (+ slack behind the plan's bytes: a data-parallel step all-reduces the gradients HERE and lets the few gradients
+        # that live elsewhere, the presence counts and the flags ride behind them -- engine/parallel.py)
+        self.used = plan.grad_bytes // 4
+        self.flat = torch.empty((self.used + self.SLACK,), dtype=f32, device=device)
 
         def cut(off, n):
             return self.flat[off // 4:off // 4 + n]
@@ -301,6 +306,7 @@ class NativeStep:
         self._ones_codes = {}
         self._prof_state = (0, -1)
         self._grad_buffers = {}
+        self.last_grads = None             # the step's parameter-gradient buffer (the data-parallel all-reduce works in it)
 
     def forward(self, ray_bundle, batch: Dict[str, torch.Tensor]):
         """(loss_dict, metrics_dict, outputs) of ``fused_train_forward`` -- or None when this step is outside what the
@@ -487,6 +493,7 @@ class NativeStep:
                                                      [tuple(p.shape) for p in deform_params], mh.n_hidden_mats,
                                                      mb.n_hidden_mats, dev)}
             st.grads = self._grad_buffers[gkey]
+        self.last_grads = st.grads
         # every tensor a raw pointer above borrows lives at least as long as the step's state
         st.keep = (o, d, near_planes, packed_march, binary, ray_slots, ray_times, uniq, rows_flag, packed_w, tables,
                    main_code, main_window, base_w16, head_w16, alpha_thre_dev, w7, image_t, amap, depth_t, code_d, he.geom,

@@ -213,6 +213,39 @@ class NeRSembleTrainer:
         del exp_avg, exp_avg_sq
         opt._buf = None                                       # (the working tables stay: HashEnsemble.tables_f16 views them)
 
+    def become_emulated_level_parallel_rank(self, n_ranks: int, rank: int, frozen: bool = True, shadow: bool = True) -> None:
+        """A single-GPU run (``HashTableAdam``) goes on as rank ``rank`` of an ``n_ranks``-rank level-parallel job whose other
+        ranks are replicas of this process (``LevelParallel(emulate=True)``; a one-rank process group must exist).  Made for
+        measuring what such a rank computes and issues per step once the model is TRAINED: ``shadow`` keeps the feature
+        columns the model sees the true ones (one extra launch per forward, priced by ``comm_report``), ``frozen`` sets
+        every learning rate to zero -- the emulated backward's table gradient is a stand-in (the replicas' planes receive
+        this rank's own column blocks), so the parameters must not move; every kernel still runs with its full traffic."""
+        key = self.group_of_tables()
+        opt = self.optimizers.get(key) if key else None
+        if not isinstance(opt, HashTableAdam) or self.world_size != 1:
+            raise RuntimeError("become_emulated_level_parallel_rank: a single-process run with the fused table optimizer")
+        he = self.model.field.hash_ensemble
+        self.flush_scheduler_step()
+        he.leave_first_grid_phase()
+        he.wait_tables()
+        st = opt._state()
+        pg = opt.param_groups[0]
+        new = LevelParallelTableAdam(he, lr=pg["lr"], betas=pg["betas"], eps=pg["eps"], world_size=n_ranks, rank=rank,
+                                     step=int(st["step"]), exp_avg=st["exp_avg"], exp_avg_sq=st["exp_avg_sq"], emulate=True)
+        new.lp.shadow_forward = bool(shadow)
+        he._level_parallel_owner = new
+        he._compact_listeners = []
+        he.compact_first_grid = False
+        opt.state.clear()
+        self.optimizers[key] = new
+        self.schedulers[key].optimizer = new
+        self.level_parallel_emulation = (int(n_ranks), int(rank))
+        self._took_part = None
+        if frozen:
+            for o in self.optimizers.values():
+                for g in o.param_groups:
+                    g["lr"] = 0.0
+
     def group_of_tables(self) -> Optional[str]:
         """Key of the optimizer that owns the hash tables (``"<group>/tables"``), if there is one."""
         return next((k for k in self.optimizers if k.endswith("/tables")), None)
@@ -230,8 +263,20 @@ class NeRSembleTrainer:
                   for pg in opt.param_groups for p in pg["params"]]
         # which parameters took part in the PREVIOUS step (on any rank): its counts have reached the host by now
         self.flush_scheduler_step()
-        self._presence = all_reduce_gradients(params, self.world_size, takes_part=self._took_part,
-                                              force=self.level_parallel_emulation is not None)
+        # the native step deposited most of these gradients as views of ONE persistent buffer: reduced where they are
+        native = getattr(self.model, "_native", None)
+        arena = getattr(native, "last_grads", None) if native is not None else None
+        # level-parallel tables: the owners' non-finite flags ride in the same bucket (a step is skipped on every rank or on
+        # none); every other flag is computed from the REDUCED gradients, identical on all ranks -- no collective of its own
+        table_opt = self.optimizers.get(self.group_of_tables() or "")
+        lp_flag = None
+        if isinstance(table_opt, LevelParallelTableAdam):
+            lp_flag = table_opt.local_nonfinite()
+        self._presence, flags = all_reduce_gradients(params, self.world_size, takes_part=self._took_part,
+                                                     force=self.level_parallel_emulation is not None, arena=arena,
+                                                     extra_flags=lp_flag)
+        if isinstance(table_opt, LevelParallelTableAdam):
+            table_opt.reduced_nonfinite = flags
 
     def _arm_early_table_step(self):
         """Single GPU, fused main pass: let the table optimizer start from inside the backward (HashTableAdam.
@@ -307,9 +352,13 @@ class NeRSembleTrainer:
             elif not isinstance(opt, SmallGroupAdam):
                 grads = [p.grad for pg in opt.param_groups for p in pg["params"] if p.grad is not None]
                 scaler.unscale_and_check(grads, f, inv_scale)
-        if self.world_size > 1 or self.level_parallel_emulation is not None:
+        flags_agree = isinstance(table_opt, LevelParallelTableAdam) and table_opt.reduced_nonfinite is not None
+        if (self.world_size > 1 or self.level_parallel_emulation is not None) and not flags_agree:
             # a step is skipped on every rank or on none: the shard-level checks of the table gradient differ per rank
+            # (level-parallel tables: the flags already agree -- see _all_reduce_grads)
             dist.all_reduce(found_all, op=dist.ReduceOp.MAX)
+        if flags_agree:
+            table_opt.reduced_nonfinite = None
         for key, opt in self.optimizers.items():
             f = found[self.group_of[key]]
             if isinstance(opt, HashTableAdam):

@@ -34,7 +34,7 @@ def _worker(rank, world, port, out_dir):
     if rank == 0:
         nograd.grad = torch.ones(4) * 8
     plist = [big] + small + [nograd, never]
-    counts = all_reduce_gradients(plist, world)               # no history: this step's counts decide (one host read)
+    counts, _ = all_reduce_gradients(plist, world)             # no history: this step's counts decide (one host read)
     ok = torch.allclose(big.grad, torch.full_like(big, 1.5))
     ok &= torch.allclose(small[0].grad, torch.arange(21.).reshape(7, 3) * 1.5)
     ok &= torch.allclose(small[1].grad, torch.ones(11) * 5)
@@ -52,7 +52,7 @@ def _worker(rank, world, port, out_dir):
     small[0].grad, small[1].grad = torch.ones(7, 3), torch.ones(11)
     if rank == 1:
         nograd.grad = torch.ones(4) * 6
-    counts2 = all_reduce_gradients(plist, world, takes_part=[c > 0 for c in counts[0].tolist()])
+    counts2, _ = all_reduce_gradients(plist, world, takes_part=[c > 0 for c in counts[0].tolist()])
     ok &= torch.allclose(nograd.grad, torch.ones(4) * 3) and never.grad is None
     ok &= counts2.tolist() == [[2.0, 2.0, 2.0, 1.0, 0.0], [0.0, 0.0, 0.0, 0.0, 2.0]]
     check_gradient_presence(counts2.tolist(), world)
@@ -64,13 +64,36 @@ def _worker(rank, world, port, out_dir):
                                                            torch.ones(4))
     if rank == 0:
         never.grad = torch.ones(3)
-    counts3 = all_reduce_gradients(plist, world, takes_part=[True, True, True, True, False])
+    counts3, _ = all_reduce_gradients(plist, world, takes_part=[True, True, True, True, False])
     ok &= (never.grad is not None) == (rank == 0) and counts3[:, 4].tolist() == [1.0, 1.0]
     try:
         check_gradient_presence(counts3.tolist(), world)
         ok = False
     except RuntimeError as e:
         ok &= "parameters [4]" in str(e)
+    # round 6: gradients deposited as views of ONE persistent buffer (the native step's) are reduced where they are; the
+    # gradients that live elsewhere, the presence counts and the extra flags ride in the buffer's slack -- one collective, the
+    # same values as the flattened bucket, the views stay views
+    from types import SimpleNamespace
+    flat = torch.zeros(64 + 256)
+    a1, a2 = torch.nn.Parameter(torch.zeros(4, 5)), torch.nn.Parameter(torch.zeros(9))
+    out1 = torch.nn.Parameter(torch.zeros(6))
+    flat[3:23] = torch.arange(20.) * (rank + 1)
+    flat[23:30] = 99.0                                       # (a region between two gradients that belongs to nobody)
+    flat[30:39] = float(rank + 2)
+    a1.grad, a2.grad = flat[3:23].view(4, 5), flat[30:39]
+    out1.grad = torch.ones(6) * 3 if rank == 0 else None
+    cnt, fl = all_reduce_gradients([a1, a2, out1], world, arena=SimpleNamespace(flat=flat, used=64),
+                                   extra_flags=torch.tensor([float(rank)]))
+    ok &= a1.grad.data_ptr() == flat[3:23].data_ptr() and torch.allclose(a1.grad, torch.arange(20.).view(4, 5) * 1.5)
+    ok &= a2.grad.data_ptr() == flat[30:39].data_ptr() and torch.allclose(a2.grad, torch.full((9,), 2.5))
+    ok &= torch.allclose(out1.grad, torch.ones(6) * 1.5)
+    ok &= cnt.tolist() == [[2.0, 2.0, 1.0], [0.0, 0.0, 0.0]] and fl.tolist() == [1.0]
+    # ... and without room in the slack the call falls back to the flattened bucket
+    a1.grad.copy_(torch.ones(4, 5) * (rank + 1))
+    cnt, fl = all_reduce_gradients([a1, a2, out1], world, arena=SimpleNamespace(flat=flat[:66], used=64),
+                                   extra_flags=torch.tensor([1.0]))
+    ok &= torch.allclose(a1.grad, torch.full((4, 5), 1.5)) and fl.tolist() == [2.0] and cnt[0].tolist() == [2.0, 2.0, 2.0]
     # ray sharding: different rays per rank, same rig
     box = torch.tensor([[-2.5, -1.8, -2.5], [2.2, 1.8, 2.0]])
     data = SyntheticNeRSembleData(box, n_timesteps=10, n_rays=64, device="cpu", rank=rank)

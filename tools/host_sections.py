@@ -24,9 +24,22 @@ def main():
     ap.add_argument("--window-open", action="store_true")
     ap.add_argument("--settle-at", type=int, default=600)
     ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--level-parallel-one-rank", type=int, default=0, metavar="N",
+                    help="after settling: go on as the finest levels' owner of an N-rank level-parallel job (emulated, frozen)")
     a = ap.parse_args()
     from nersemble_amd.workloads import build_workload
     torch.manual_seed(19980801)
+    if a.level_parallel_one_rank:
+        import socket
+        import torch.distributed as dist
+        s_ = socket.socket()
+        s_.bind(("127.0.0.1", 0))
+        os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(s_.getsockname()[1])
+        s_.close()
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(0)
+        dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+        a.window_open, a.full_layout = True, True
     trainer, data, info = build_workload(a.workload, device="cuda:0", compact_first_grid=not a.full_layout,
                                          window_hash=(0, 1) if a.window_open else None)
     reserve = torch.empty(24 * 2 ** 30, dtype=torch.uint8, device="cuda:0")
@@ -35,6 +48,12 @@ def main():
     while step < a.settle_at:
         trainer.train_iteration(step, *data.next_train(step))
         step += 1
+    if a.level_parallel_one_rank:
+        trainer.flush_scheduler_step()
+        trainer.become_emulated_level_parallel_rank(a.level_parallel_one_rank, a.level_parallel_one_rank - 1)
+        for _ in range(8):
+            trainer.train_iteration(step, *data.next_train(step))
+            step += 1
     acc = collections.defaultdict(list)
     cur = collections.defaultdict(float)
 
@@ -53,6 +72,14 @@ def main():
     model.sampler.forward = timed("  sampler", model.sampler.forward)
     model.field_density_fn = timed("    sigma_fn density", model.field_density_fn)
     trainer._optimizer_step_all = timed("optimizer (all)", trainer._optimizer_step_all)
+    trainer._all_reduce_grads = timed("all-reduce of the small gradients", trainer._all_reduce_grads)
+    lp = getattr(model.field.hash_ensemble, "level_parallel", None)
+    if lp is not None:
+        lp.exchange_sizes = timed("  lp: size exchange (host, gloo)", lp.exchange_sizes)
+        lp.features = timed("  lp: forward exchange", lp.features)
+        lp.backward = timed("  lp: backward exchange", lp.backward)
+        lp._all_gather = timed("    lp: all_gather call", lp._all_gather)
+        lp._all_to_all = timed("    lp: all_to_all calls", lp._all_to_all)
     trainer.flush_scheduler_step = timed("  flush_scheduler_step", trainer.flush_scheduler_step)
     trainer._defer_scheduler_step = timed("defer_scheduler_step", trainer._defer_scheduler_step)
     for cb in trainer.callbacks:
