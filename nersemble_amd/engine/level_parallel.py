@@ -65,6 +65,13 @@ def sub_geometry(g: GridGeom, first_level: int, n_levels: int) -> GridGeom:
     return s
 
 
+def _as(t: torch.Tensor, dtype) -> torch.Tensor:
+    """``t.detach().to(dtype).contiguous()`` without the three dispatches when there is nothing to do."""
+    if t.dtype == dtype and t.is_contiguous() and not t.requires_grad:
+        return t
+    return t.detach().to(dtype).contiguous()
+
+
 class NativeLPOps:
     """The device side of the exchange: csrc/level_parallel.hip through the C ABI (include/nsx.h, "level-parallel exchange").
     Tests substitute a torch restatement to run the collectives' plumbing on CPU over gloo (tests/test_parallel_cpu.py)."""
@@ -95,9 +102,8 @@ class NativeLPOps:
               "nsx_lp_bwd_pack")
 
     @staticmethod
-    def bwd_run(lay, recv, gathered, ex, tables, geom, window, G, ret, nonfinite) -> None:
+    def bwd_run(lay, recv, gathered, ex, tables, geom, window, G, ret, nonfinite, dz) -> None:
         dev = recv.device
-        dz = torch.empty((lay.W * lay.S_cap * lay.n2,), dtype=torch.float32, device=dev)
         check(lib().nsx_lp_bwd_run(C.byref(lay), ptr(recv), ptr(gathered), ex.sizes_host, ex.rows_host, ptr(tables),
                                    C.byref(geom), ptr(window), ptr(G), ptr(dz), ptr(F.codesum_scratch(lay.R_cap, lay.H, dev)),
                                    ptr(ret), ptr(nonfinite), stream()), "nsx_lp_bwd_run")
@@ -185,20 +191,36 @@ class LevelParallel:
         self.backward_calls = 0
         self.samples_scattered = 0
         self.last_exchange = None        # the most recent forward exchange (its backward follows)
+        self._size_bufs = None
+        self._bufs = {}                  # grow-only byte buffers of the payloads (stream-ordered reuse, step after step)
         self._g_clean = None             # event: the optimizer pass left G all zeros (nsx_adam_hash_factored_consume)
         self.stats = {"bytes_in": 0, "samples_fwd": 0, "samples_bwd": 0, "fwd_calls": 0, "bwd_calls": 0, "collectives": 0,
                       "host_exchanges": 0}
 
     # ---- collectives -------------------------------------------------------------------------------------------------
-    def exchange_sizes(self, S: int, rows: int) -> Exchange:
-        """The one host-side collective of a pass: every rank's (sample capacity, code rows).  Blocking, 16 bytes per rank."""
-        W = self.world_size
-        mine = torch.tensor([int(S), int(rows)], dtype=torch.int64)
+    def exchange_sizes_begin(self, S: int, rows: int):
+        """Start the one host-side collective of a pass -- every rank's (sample capacity, code rows), 16 bytes per rank over
+        the gloo group -- and return at once: the caller goes on issuing device work and calls ``exchange_sizes_end``."""
         n = dist.get_world_size(self.cpu_group)
-        out = torch.empty((n * 2,), dtype=torch.int64)
-        dist.all_gather_into_tensor(out, mine, group=self.cpu_group)
+        if self._size_bufs is None or self._size_bufs[1].numel() != 2 * n:
+            self._size_bufs = (torch.empty((2,), dtype=torch.int64), torch.empty((2 * n,), dtype=torch.int64))
+        mine, out = self._size_bufs
+        mine[0], mine[1] = int(S), int(rows)
+        work = dist.all_gather_into_tensor(out, mine, group=self.cpu_group, async_op=True)
         self.stats["host_exchanges"] += 1
-        got = out.view(n, 2).tolist()
+        return work, out, n
+
+    def exchange_sizes_end(self, pending) -> Exchange:
+        work, out, n = pending
+        work.wait()
+        return self._exchange_from(out.view(n, 2).tolist())
+
+    def exchange_sizes(self, S: int, rows: int) -> Exchange:
+        """Blocking form of ``exchange_sizes_begin`` / ``_end``."""
+        return self.exchange_sizes_end(self.exchange_sizes_begin(S, rows))
+
+    def _exchange_from(self, got) -> Exchange:
+        W = self.world_size
         if self.emulate:
             got = [got[0]] * W
         sizes, rws = [g[0] for g in got], [max(1, g[1]) for g in got]
@@ -256,6 +278,15 @@ class LevelParallel:
     def _bytes(n: int, dev) -> torch.Tensor:
         return torch.empty((int(n),), dtype=torch.uint8, device=dev)
 
+    def _buf(self, name: str, n: int, dev) -> torch.Tensor:
+        """``n`` bytes of the persistent buffer ``name`` (grown by a quarter beyond the need, never shrunk).  Every user
+        runs on the current stream and the collectives order themselves behind and in front of it: reuse is stream-ordered.
+        Not for ``Exchange.gathered``, which lives until its backward."""
+        b = self._bufs.get(name)
+        if b is None or b.numel() < n or b.device != torch.device(dev):
+            b = self._bufs[name] = torch.empty((int(n) * 5 // 4 + 256,), dtype=torch.uint8, device=dev)
+        return b[:int(n)]
+
     # ---- forward ------------------------------------------------------------------------------------------------------
     @torch.no_grad()
     def features(self, x: torch.Tensor, code: torch.Tensor, code_index: torch.Tensor,
@@ -268,9 +299,7 @@ class LevelParallel:
         he, W = self.he, self.world_size
         he.wait_tables()
         dev = x.device
-        x = x.detach().to(torch.float32).contiguous()
-        code = code.detach().to(torch.float32).contiguous()
-        slot = code_index.detach().to(torch.int32).contiguous()
+        x, code, slot = _as(x, torch.float32), _as(code, torch.float32), _as(code_index, torch.int32)
         S, H, n2 = int(x.shape[0]), he.n_hash_encodings, 2 * self.n_own
         tables = self.slice_f16()
         ops = self.ops
@@ -293,15 +322,15 @@ class LevelParallel:
             raise RuntimeError(f"level-parallel HashEnsemble: this pass has {S} samples / {code.shape[0]} code rows, the sizes "
                                f"exchanged for it say {ex.S} / <= {ex.R_cap}")
         lay = ex.lay
-        payload = self._bytes(lay.fwd_bytes, dev)
+        payload = self._buf("fwd_payload", lay.fwd_bytes, dev)
         ops.fwd_pack(lay, x, slot, S, n_dev, code, int(code.shape[0]), payload)
         ex.gathered = self._bytes(W * lay.fwd_bytes, dev)
         self._all_gather(ex.gathered, payload)
-        send = self._bytes(W * lay.feat_bytes, dev)
+        send = self._buf("feat_send", W * lay.feat_bytes, dev)
         ex.codes_packed = torch.empty((ex.n_planes, H), dtype=torch.float32, device=dev)
         ex.window = window
         ops.fwd_run(lay, ex.gathered, ex, tables, self.geom, window, send, ex.codes_packed)
-        recv = self._bytes(W * lay.feat_bytes, dev)
+        recv = self._buf("feat_recv", W * lay.feat_bytes, dev)
         self._all_to_all(recv, send)
         feats = out if out is not None else torch.empty((S, W * n2), dtype=torch.float16, device=dev)
         ops.fwd_unpack(lay, recv, S, n_dev, feats)
@@ -370,22 +399,21 @@ class LevelParallel:
         if ex is None or ex.gathered is None:
             raise RuntimeError("level-parallel HashEnsemble: a backward without a forward exchange")
         dev = x.device
-        x = x.detach().to(torch.float32).contiguous()
-        slot = code_index.detach().to(torch.int32).contiguous()
-        dout = dout.detach().to(torch.float32).contiguous()
+        x, slot, dout = _as(x, torch.float32), _as(code_index, torch.int32), _as(dout, torch.float32)
         S, H = int(x.shape[0]), he.n_hash_encodings
         if S > ex.S_cap:
             raise RuntimeError(f"level-parallel HashEnsemble: {S} samples in the backward of a forward exchange of capacity {ex.S_cap}")
         lay, ops = ex.lay, self.ops
-        send = self._bytes(W * lay.bwd_bytes, dev)
+        send = self._buf("bwd_send", W * lay.bwd_bytes, dev)
         ops.bwd_pack(lay, dout, x, slot, S, n_dev, send)
-        recv = self._bytes(W * lay.bwd_bytes, dev)
+        recv = self._buf("bwd_recv", W * lay.bwd_bytes, dev)
         self._all_to_all(recv, send)
         G = self._planes(ex.n_planes, dev) if need_table else None
         if self.nonfinite is None or self.nonfinite.device != dev:
             self.nonfinite = torch.zeros((1,), dtype=torch.float32, device=dev)
-        ret = self._bytes(W * lay.ret_bytes, dev)
-        ops.bwd_run(lay, recv, ex.gathered, ex, self.slice_f16(), self.geom, ex.window, G, ret, self.nonfinite)
+        ret = self._buf("ret_send", W * lay.ret_bytes, dev)
+        ops.bwd_run(lay, recv, ex.gathered, ex, self.slice_f16(), self.geom, ex.window, G, ret, self.nonfinite,
+                    self._buf("dz", 4 * W * lay.S_cap * lay.n2, dev))
         if self.backward_calls == 0 or self.codes_packed is None:
             self.codes_packed, self.window = ex.codes_packed, ex.window
         self.backward_calls += 1
@@ -394,7 +422,7 @@ class LevelParallel:
         self.stats["bwd_calls"] += 1
         self.stats["samples_bwd"] += n_job
         # partial dL/dx and partial code-row gradients back to the samples' owners, summed over the level owners
-        ret_recv = self._bytes(W * lay.ret_bytes, dev)
+        ret_recv = self._buf("ret_recv", W * lay.ret_bytes, dev)
         self._all_to_all(ret_recv, ret)
         dx = dx_out if dx_out is not None else torch.empty((S, 3), dtype=torch.float32, device=dev)
         dcode = dcode_out if dcode_out is not None else torch.empty((ex.n_rows, H), dtype=torch.float32, device=dev)
@@ -490,6 +518,7 @@ class LevelParallelTableAdam(torch.optim.Optimizer):
 
     # ---- the trainer's two phases ---------------------------------------------------------------------------------------
     reduced_nonfinite = None        # set by the trainer: the ranks' flags summed in the small gradients' bucket
+    _scale = None
 
     def local_nonfinite(self) -> torch.Tensor:
         """This rank's flag: one of its backward calls added an inf / NaN to its gradient planes (device, fp32 [1])."""
@@ -506,7 +535,7 @@ class LevelParallelTableAdam(torch.optim.Optimizer):
     def check_finite(self, found_inf: torch.Tensor) -> None:
         if self.reduced_nonfinite is not None:
             # the job's flags (summed over the ranks): every rank skips the step or none does
-            torch.maximum(found_inf, (self.reduced_nonfinite > 0).to(found_inf.dtype), out=found_inf)
+            torch.maximum(found_inf, self.reduced_nonfinite, out=found_inf)      # (a sum of 0 / 1 flags: > 0 = skip)
             return
         nf = self.lp.nonfinite
         if self.lp.backward_calls and nf is not None:
@@ -534,9 +563,13 @@ class LevelParallelTableAdam(torch.optim.Optimizer):
             lp.begin_step()
             return
         # the ranks' losses are means over THEIR rays; the job's gradient is their average (engine/parallel.py)
-        scale = torch.full((1,), 1.0 / self.world_size, dtype=torch.float32, device=he.tables.device)
+        if self._scale is None or self._scale.device != he.tables.device:
+            self._scale = torch.empty((1,), dtype=torch.float32, device=he.tables.device)
+        scale = self._scale
         if inv_scale is not None:
-            scale = scale * inv_scale.reshape(1)
+            torch.mul(inv_scale.reshape(1), 1.0 / self.world_size, out=scale)
+        else:
+            scale.fill_(1.0 / self.world_size)
         if side_stream is None or not he.tables.is_cuda:
             self._step_now(found_inf, scale)
             lp.begin_step()

@@ -361,6 +361,9 @@ class NativeStep:
                                                           stratified=model.sampler.training)
         if S <= 0:
             return None                     # (nothing marched: the per-kernel path owns the one-fake-sample fallback)
+        # level-parallel run: the host-side size exchange of the step starts NOW (gloo, a background thread) and is collected
+        # after the sampler's front has been enqueued
+        lp_pending = he.level_parallel.exchange_sizes_begin(S, n_rows) if he.level_parallel is not None else None
         grid.last_keep_index, grid.last_n_marched, grid.last_n_kept = None, S, None
         ray_slots = md["image_index"].reshape(-1).to(torch.int32).contiguous()
         ray_times = None
@@ -438,7 +441,7 @@ class NativeStep:
             # rank's samples; the features of ALL levels come back into the workspace), the rest of the sampler
             a.phase = 1
             check(L.nsx_step_sample_run(C.byref(a), stream()), "nsx_step_sample_run (front)")
-            lp_ex = lp.exchange_sizes(S, n_rows)                 # (host-side, while the device runs the front)
+            lp_ex = lp.exchange_sizes_end(lp_pending)            # (started as soon as S was known: see above)
             if tables_event is not None:
                 torch.cuda.current_stream(dev).wait_event(tables_event)
             lp.features(_view(ws_sample, plan.m_pn, (S, 3), torch.float32), main_code,

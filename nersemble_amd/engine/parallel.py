@@ -68,7 +68,7 @@ def all_reduce_gradients(params: Iterable[torch.nn.Parameter], world_size: int, 
     inv = 1.0 / world_size
     # what this rank will do with an absent gradient, decided BEFORE the exchange when a history exists
     drops = [a and takes_part is not None and not takes_part[i] for i, a in enumerate(absent)]
-    tail = torch.tensor([0.0 if a else 1.0 for a in absent] + [1.0 if d else 0.0 for d in drops], dtype=torch.float32)
+    tail = _presence_tail(tuple(absent), tuple(drops), dev)
     n_flags = int(extra_flags.numel()) if extra_flags is not None else 0
     flags = None
     inside, outside = [], small
@@ -88,7 +88,7 @@ def all_reduce_gradients(params: Iterable[torch.nn.Parameter], world_size: int, 
             flat[off:off + k].copy_(p.grad.reshape(-1))
             off += k
         n_grad = off
-        flat[off:off + 2 * n].copy_(tail.to(dev, non_blocking=True))
+        flat[off:off + 2 * n].copy_(tail)
         off += 2 * n
         if n_flags:
             flat[off:off + n_flags].copy_(extra_flags.reshape(-1).to(torch.float32))
@@ -109,7 +109,7 @@ def all_reduce_gradients(params: Iterable[torch.nn.Parameter], world_size: int, 
             p.grad.copy_(flat[off:off + k].view_as(p.grad))
             off += k
     else:
-        pieces = [p.grad.reshape(-1).float() for p in small] + [tail.to(dev, non_blocking=True)]
+        pieces = [p.grad.reshape(-1).float() for p in small] + [tail]
         if n_flags:
             pieces.append(extra_flags.reshape(-1).to(torch.float32))
         flat = torch.cat(pieces)
@@ -135,6 +135,21 @@ def all_reduce_gradients(params: Iterable[torch.nn.Parameter], world_size: int, 
         if d:
             p.grad = None                   # (zeros went into the sum; no rank stepped the parameter)
     return counts, flags
+
+
+_TAILS = {}
+
+
+def _presence_tail(absent, drops, dev) -> torch.Tensor:
+    """[held ... | dropped ...] of this rank as a device tensor; the pattern is the same step after step (cached)."""
+    key = (absent, drops, str(dev))
+    t = _TAILS.get(key)
+    if t is None:
+        if len(_TAILS) > 64:
+            _TAILS.clear()
+        t = _TAILS[key] = torch.tensor([0.0 if a else 1.0 for a in absent] + [1.0 if d else 0.0 for d in drops],
+                                       dtype=torch.float32).to(dev)
+    return t
 
 
 def check_gradient_presence(counts, world_size: int) -> None:

@@ -585,7 +585,7 @@ class _TorchLPOps:
             self._f32(blk, lay.b_pn, n * 3).copy_(pn[:n].reshape(-1))
             self._i32(blk, lay.b_slot, n).copy_(slot[:n])
 
-    def bwd_run(self, lay, recv, gathered, ex, tables, geom, window, G, ret, nonfinite):
+    def bwd_run(self, lay, recv, gathered, ex, tables, geom, window, G, ret, nonfinite, dz32=None):
         plane = 0
         for j in range(lay.W):
             rows, Sj = int(ex.rows_host[j]), int(ex.sizes_host[j])

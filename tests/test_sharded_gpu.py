@@ -532,11 +532,13 @@ def test_eight_level_parallel_ranks_on_the_p124_model_equal_one_process(cuda, tm
 
 
 def _differences_are_sign_flips(tables, ref, init, lr):
-    """Adam's FIRST step moves an entry with gradient g by -lr * g / (|g| + eps): +-lr unless g is within a few orders of
-    eps = 1e-15, never more.  Two runs whose gradients agree up to summation order can therefore differ at an entry only
-    because the (cancelling) gradient changed sign -- the entries are 2 lr apart -- or vanished in one of them -- lr apart.
-    Said entry by entry instead of as a percentage: EVERY entry that differs holds two first-step moves (both within
-    [-lr, lr], at most 2 lr apart), and nearly all of them sit exactly on {-lr, 0, +lr}."""
+    """What the ">= 99.5 % of the touched entries agree" bars leave out, said entry by entry.  Adam's FIRST step moves an
+    entry with gradient g by -lr * g / (|g| + eps), eps = 1e-15: by +-lr when |g| >> eps, by less when the gradient is a
+    cancellation residue within a few orders of eps, never by more.  Two runs whose gradients agree up to summation order
+    can therefore differ at an entry only if (i) its gradient is such a residue in at least one of them -- a move strictly
+    inside (-lr, lr), i.e. |g| < 1e-12 against typical gradients of 1e-7 ... 1e-4 -- or (ii) a residue's sign flipped or it
+    vanished (moves on {-lr, 0, +lr}, 2 lr / lr apart).  EVERY differing entry must be one of the two; an entry whose
+    gradient is robust in both runs never differs."""
     a, b = tables - init, ref - init
     differs = (tables - ref).abs() > 1e-5
     if not differs.any():
@@ -544,8 +546,9 @@ def _differences_are_sign_flips(tables, ref, init, lr):
     da, db = a[differs], b[differs]
     assert float(da.abs().max()) <= lr + 1e-5 and float(db.abs().max()) <= lr + 1e-5, "a move larger than a first Adam step"
     on_lattice = lambda v: ((v.abs() - lr).abs() <= 1e-5) | (v.abs() <= 1e-7)
-    exact = (on_lattice(da) & on_lattice(db)).float().mean().item()
-    assert exact >= 0.99, f"only {exact:.4f} of the differing entries are sign flips / vanishings of a +-lr move"
+    residue = (da.abs() < lr * (1 - 1e-3)) | (db.abs() < lr * (1 - 1e-3))
+    flip = on_lattice(da) & on_lattice(db)
+    assert bool((residue | flip).all()), "an entry with a robust gradient in both runs differs"
 
 
 def test_emulated_level_parallel_rank_through_rccl(cuda, single_rank_group):
@@ -616,16 +619,20 @@ def test_emulated_rank_7_of_8_trains_through_the_native_step(cuda, single_rank_g
                                       level_parallel_emulation=(8, 7))
     opt = trainer.optimizers[trainer.group_of_tables()]
     assert isinstance(opt, LevelParallelTableAdam) and opt.lp.emulate and opt.lp.n_own == 2 and opt.lp.first_level == 14
+    trainer.train_iteration(0, *data.next_train(0))              # (step 0 refreshes the occupancy grid: one more exchange)
+    assert opt.lp.stats["collectives"] == 5
+    opt.comm_report()
     losses = []
     for step in range(1, 4):                                    # (no occupancy update in these steps: step % 16 != 0)
         loss, _, _ = trainer.train_iteration(step, *data.next_train(step))
         losses.append(loss.item())
+        assert int(trainer.model.occupancy_grid.last_n_marched) > 0
     trainer.flush_scheduler_step()
     assert all(np.isfinite(losses))
     assert trainer.model._native is not None
     st = opt.lp.stats
     assert st["bwd_calls"] == 3 and st["fwd_calls"] == 3 and st["collectives"] == 12 and st["host_exchanges"] == 3
-    assert opt.lp.planes == 8 * 24 and opt._step == 3
+    assert opt.lp.planes == 8 * 24 and opt._step == 4
     c = opt.comm_report()
     assert c["collectives_per_step"] == 4 and c["host_exchanges_per_step"] == 1 and c["gradient_planes"] == 192
 
@@ -639,9 +646,9 @@ def _empty_rank_worker(rank, world, port, out_dir):
     trainer, data, _ = build_workload("p030_h16", device="cuda:0", small=True, n_rays=256, rank=rank, world_size=world,
                                       window_hash=OPEN_WINDOW, table_parallel="level")
     losses, marched = [], []
-    for step in range(1, 4):
+    for step in range(0, 3):                                    # (step 0 refreshes the occupancy grid on both ranks)
         bundle, batch = data.next_train(step)
-        if rank == 1 and step == 2:
+        if rank == 1 and step == 1:
             bundle.directions = -bundle.directions              # every ray leaves the scene: nothing is marched on this rank
         loss, _, metrics = trainer.train_iteration(step, bundle, batch)
         losses.append(loss.item())
@@ -674,7 +681,8 @@ def test_a_rank_that_marches_nothing_issues_the_same_collectives(cuda, tmp_path)
     assert all(np.isfinite(a["losses"])) and all(np.isfinite(b["losses"]))
     assert b["marched"][1] <= 0 < a["marched"][1]
     for r in (a, b):
-        assert r["stats"]["host_exchanges"] == 3 and r["stats"]["collectives"] == 12
+        # (3 steps x (one size exchange, all-gather + three all-to-alls) + the occupancy update's column all-gather)
+        assert r["stats"]["host_exchanges"] == 3 and r["stats"]["collectives"] == 13
     assert torch.equal(a["tables"], b["tables"]) and torch.equal(a["small"], b["small"])
 
 
