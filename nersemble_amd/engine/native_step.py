@@ -78,6 +78,10 @@ class _GradBuffers:
         # that live elsewhere, the presence counts and the flags ride behind them -- engine/parallel.py)
         self.used = plan.grad_bytes // 4
         self.flat = torch.empty((self.used + self.SLACK,), dtype=f32, device=device)
+        # [0, fixed): the leaf parameters' gradients (mlp_head, mlp_base, the deformation tensors) -- offsets that depend on
+        # the model only, not on the batch; behind it the two code-row gradients autograd consumes inside the backward
+        self.fixed = plan.g_code_deform // 4
+        self.slots = {}                # id(parameter) -> its view (filled by NativeStep: it knows the leaves)
 
         def cut(off, n):
             return self.flat[off // 4:off // 4 + n]
@@ -94,6 +98,9 @@ class _GradBuffers:
         self.deform = [gp if len(shp) == 1 else gp.view(shp) for gp, shp in zip(torch.split(gparams, sizes), deform_shapes)]
         self.gtable = cut(plan.g_code_deform, code_deform_shape[0] * code_deform_shape[1]).view(code_deform_shape)
         self.g_code_hash = cut(plan.g_code_hash, n_rows * H).view(n_rows, H)
+
+    def slot_of(self, p):
+        return self.slots.get(id(p))
 
 
 _DEPOSIT = os.environ.get("NSX_GRAD_DEPOSIT", "1") != "0"
@@ -496,6 +503,7 @@ class NativeStep:
                                                      [tuple(p.shape) for p in deform_params], mh.n_hidden_mats,
                                                      mb.n_hidden_mats, dev)}
             st.grads = self._grad_buffers[gkey]
+            st.grads.slots = self._slots(st.grads, mb, mh, deform_params)
         self.last_grads = st.grads
         # every tensor a raw pointer above borrows lives at least as long as the step's state
         st.keep = (o, d, near_planes, packed_march, binary, ray_slots, ray_times, uniq, rows_flag, packed_w, tables,
@@ -526,6 +534,29 @@ class NativeStep:
             mterms.append(("psnr_masked", dl.LOSS_PSNR_MASKED))
         metrics = LazyVectorDict(fused.detach(), mterms)
         return loss_dict, metrics, LazyOutputs(lambda: self._outputs(st))
+
+    @staticmethod
+    def _slots(gb, mb, mh, deform_params) -> dict:
+        return {id(mb.params): gb.d_base, id(mh.params): gb.d_head, **{id(p): v for p, v in zip(deform_params, gb.deform)}}
+
+    def grad_arena(self):
+        """The persistent parameter-gradient buffer (``_GradBuffers``) for the data-parallel all-reduce -- the last step's, or
+        (a rank that has not run the drivers yet) one laid out for a single code row: the leaf gradients' offsets depend on
+        the model only."""
+        if self.last_grads is not None:
+            return self.last_grads
+        model = self.model
+        he, df = model.field.hash_ensemble, model.deformation_field
+        mb, mh = model.field.mlp_base, model.field.mlp_head
+        plan = self._plan_cls()
+        check(lib().nsx_step_plan_make(1, 1, 1, he.n_hash_encodings, mb.n_hidden_mats, mh.n_hidden_mats, C.byref(plan)),
+              "nsx_step_plan_make")
+        deform_params = df.ordered_params()
+        gb = _GradBuffers(plan, 1, he.n_hash_encodings, (1, 128), [tuple(p.shape) for p in deform_params], mh.n_hidden_mats,
+                          mb.n_hidden_mats, mb.params.device)
+        gb.slots = self._slots(gb, mb, mh, deform_params)
+        self.last_grads = gb
+        return gb
 
     @staticmethod
     def _outputs(st: _StepState) -> dict:

@@ -36,13 +36,16 @@ def all_reduce_gradients(params: Iterable[torch.nn.Parameter], world_size: int, 
     gradient travels in the same bucket, and ``check_gradient_presence`` raises on every rank when a parameter was stepped
     by some ranks and dropped by others.
 
-    ``arena`` (round 6): an object with ``flat`` (1-D fp32 device tensor) and ``used`` (elements in use) -- the persistent
-    buffer in which the native training step deposits its parameter gradients as views (``engine.native_step._GradBuffers``).
-    Gradients that live there are reduced WHERE THEY ARE: the used span is all-reduced in place, and the few gradients that
-    live elsewhere (the embeddings'), the presence counts and ``extra_flags`` ride in the buffer's slack behind it -- one
-    collective and ~10 small launches per step instead of a ``cat`` of ~40 gradients and as many copies back (VERDICT r05
-    item 9: ~80 launches on a path the host paces).  Without an arena (or without room in its slack) the small gradients are
-    flattened into one bucket as before.
+    ``arena`` (round 6): the persistent buffer in which the native training step deposits its parameter gradients as views
+    (``engine.native_step._GradBuffers``): ``flat`` (1-D fp32 device tensor), ``fixed`` (its leading elements that hold the
+    leaf parameters' gradients -- the two fused MLPs and the deformation tensors; a constant of the model) and
+    ``slot_of(p)`` (the view a parameter's gradient lives in, or None).  The wire format of the bucket is then
+    ``flat[:fixed] | gradients without a slot (the embeddings') | presence counts | extra_flags`` -- the same length on every
+    rank whatever path its step took -- and the slotted gradients are reduced WHERE THEY ARE: one collective and ~10 small
+    launches per step instead of a ``cat`` of ~40 gradients and as many copies back (~80 launches on a
+    path the host paces).  A rank whose step did not run the native drivers (nothing marched: the per-kernel path) copies its
+    gradients into their slots first.  Every rank must pass an arena of the same model, or none (the trainer decides from
+    the configuration): without one the small gradients are flattened into one bucket as before.
 
     ``extra_flags``: a small fp32 device tensor summed over the ranks in the same bucket (the level-parallel optimizer's
     non-finite flag: a step is skipped on every rank or on none) -- returned as the third value.
@@ -72,17 +75,22 @@ def all_reduce_gradients(params: Iterable[torch.nn.Parameter], world_size: int, 
     n_flags = int(extra_flags.numel()) if extra_flags is not None else 0
     flags = None
     inside, outside = [], small
-    if arena is not None and arena.flat.device == dev:
-        lo = arena.flat.data_ptr()
-        hi = lo + int(arena.used) * 4
-        inside = [p for p in small if lo <= p.grad.data_ptr() < hi and p.grad.is_contiguous()]
-        outside = [p for p in small if not (lo <= p.grad.data_ptr() < hi and p.grad.is_contiguous())]
+    if arena is not None:
+        if arena.flat.device != dev:
+            raise RuntimeError("all_reduce_gradients: the gradient arena lives on another device than the gradients")
+        slots = [arena.slot_of(p) for p in small]
+        inside = [p for p, sl in zip(small, slots) if sl is not None]
+        outside = [p for p, sl in zip(small, slots) if sl is None]
         need = sum(p.grad.numel() for p in outside) + 2 * n + n_flags
-        if not inside or int(arena.used) + need > arena.flat.numel():
-            inside, outside = [], small
-    if inside:
+        if int(arena.fixed) + need > arena.flat.numel():
+            raise RuntimeError(f"all_reduce_gradients: {need} elements do not fit behind the arena's {arena.fixed}")
+        for p, sl in zip(small, slots):
+            if sl is not None and p.grad.data_ptr() != sl.data_ptr():
+                sl.copy_(p.grad.reshape(sl.shape))                 # (a step that did not deposit its gradients)
+                p.grad = sl.view(p.shape)
+    if arena is not None:
         flat = arena.flat
-        off = int(arena.used)
+        off = int(arena.fixed)
         for p in outside:                                        # (two embeddings' gradients, typically)
             k = p.grad.numel()
             flat[off:off + k].copy_(p.grad.reshape(-1))
@@ -97,13 +105,14 @@ def all_reduce_gradients(params: Iterable[torch.nn.Parameter], world_size: int, 
         handles.append(dist.all_reduce(span, op=dist.ReduceOp.SUM, group=group, async_op=True))
         for h in handles:
             h.wait()
-        aux = flat[n_grad:off].clone()                           # counts (+ flags): not averaged
+        aux = flat[n_grad:off]                                   # counts (+ flags): not averaged; views of the arena -- their
+        #                                                          readers (the inf check, the copy to the host) run this step
         counts = aux[:2 * n].view(2, n)
         if n_flags:
             flags = aux[2 * n:]
         if inv != 1.0:
             flat[:n_grad].mul_(inv)
-        off = int(arena.used)
+        off = int(arena.fixed)
         for p in outside:
             k = p.grad.numel()
             p.grad.copy_(flat[off:off + k].view_as(p.grad))

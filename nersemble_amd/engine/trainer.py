@@ -264,8 +264,16 @@ class NeRSembleTrainer:
         # which parameters took part in the PREVIOUS step (on any rank): its counts have reached the host by now
         self.flush_scheduler_step()
         # the native step deposited most of these gradients as views of ONE persistent buffer: reduced where they are
-        native = getattr(self.model, "_native", None)
-        arena = getattr(native, "last_grads", None) if native is not None else None
+        # (whether there is one follows from the configuration, the same on every rank: the bucket's wire format)
+        arena = None
+        model = self.model
+        if (getattr(model, "native_step", False) and getattr(model, "fuse_main_pass", False) and self.mixed_precision
+                and model.deformation_field is not None and next(model.parameters()).is_cuda
+                and model.field.hash_ensemble.geom.n_levels == 16 and model.field.mlp_base.n_output_dims == 16):
+            if model._native is None:
+                from .native_step import NativeStep
+                model._native = NativeStep(model)
+            arena = model._native.grad_arena()
         # level-parallel tables: the owners' non-finite flags ride in the same bucket (a step is skipped on every rank or on
         # none); every other flag is computed from the REDUCED gradients, identical on all ranks -- no collective of its own
         table_opt = self.optimizers.get(self.group_of_tables() or "")

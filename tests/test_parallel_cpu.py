@@ -72,28 +72,36 @@ def _worker(rank, world, port, out_dir):
     except RuntimeError as e:
         ok &= "parameters [4]" in str(e)
     # round 6: gradients deposited as views of ONE persistent buffer (the native step's) are reduced where they are; the
-    # gradients that live elsewhere, the presence counts and the extra flags ride in the buffer's slack -- one collective, the
-    # same values as the flattened bucket, the views stay views
-    from types import SimpleNamespace
+    # gradients without a slot there, the presence counts and the extra flags ride behind the buffer's fixed part -- one
+    # collective with the same wire format on every rank, the views stay views.  Rank 1 plays a step that did NOT deposit
+    # (its gradients live elsewhere): they are copied into their slots first.
     flat = torch.zeros(64 + 256)
     a1, a2 = torch.nn.Parameter(torch.zeros(4, 5)), torch.nn.Parameter(torch.zeros(9))
     out1 = torch.nn.Parameter(torch.zeros(6))
-    flat[3:23] = torch.arange(20.) * (rank + 1)
+    slots = {id(a1): flat[3:23].view(4, 5), id(a2): flat[30:39]}
+
+    class _Arena:
+        fixed = 40
+
+        def __init__(self, flat):
+            self.flat = flat
+
+        def slot_of(self, p):
+            return slots.get(id(p))
+
     flat[23:30] = 99.0                                       # (a region between two gradients that belongs to nobody)
-    flat[30:39] = float(rank + 2)
-    a1.grad, a2.grad = flat[3:23].view(4, 5), flat[30:39]
+    if rank == 0:
+        flat[3:23] = torch.arange(20.)
+        flat[30:39] = 2.0
+        a1.grad, a2.grad = slots[id(a1)], slots[id(a2)]
+    else:
+        a1.grad, a2.grad = torch.arange(20.).view(4, 5) * 2, torch.full((9,), 3.0)
     out1.grad = torch.ones(6) * 3 if rank == 0 else None
-    cnt, fl = all_reduce_gradients([a1, a2, out1], world, arena=SimpleNamespace(flat=flat, used=64),
-                                   extra_flags=torch.tensor([float(rank)]))
+    cnt, fl = all_reduce_gradients([a1, a2, out1], world, arena=_Arena(flat), extra_flags=torch.tensor([float(rank)]))
     ok &= a1.grad.data_ptr() == flat[3:23].data_ptr() and torch.allclose(a1.grad, torch.arange(20.).view(4, 5) * 1.5)
     ok &= a2.grad.data_ptr() == flat[30:39].data_ptr() and torch.allclose(a2.grad, torch.full((9,), 2.5))
     ok &= torch.allclose(out1.grad, torch.ones(6) * 1.5)
     ok &= cnt.tolist() == [[2.0, 2.0, 1.0], [0.0, 0.0, 0.0]] and fl.tolist() == [1.0]
-    # ... and without room in the slack the call falls back to the flattened bucket
-    a1.grad.copy_(torch.ones(4, 5) * (rank + 1))
-    cnt, fl = all_reduce_gradients([a1, a2, out1], world, arena=SimpleNamespace(flat=flat[:66], used=64),
-                                   extra_flags=torch.tensor([1.0]))
-    ok &= torch.allclose(a1.grad, torch.full((4, 5), 1.5)) and fl.tolist() == [2.0] and cnt[0].tolist() == [2.0, 2.0, 2.0]
     # ray sharding: different rays per rank, same rig
     box = torch.tensor([[-2.5, -1.8, -2.5], [2.2, 1.8, 2.0]])
     data = SyntheticNeRSembleData(box, n_timesteps=10, n_rays=64, device="cpu", rank=rank)

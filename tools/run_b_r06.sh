@@ -2,7 +2,7 @@
 set -u
 out=gpurun_out/r06_b; mkdir -p $out
 export TMPDIR=/tmp
-timeout 1500 python -m pytest tests/test_sharded_gpu.py -q -m gpu -k "level_parallel or emulated or marches_nothing or handed" 2>&1 | grep -v "amdgpu.ids\|socket.cpp\|Gloo" > $out/tests_full.txt
+timeout 1500 python -m pytest tests/test_sharded_gpu.py -q -m gpu -k "marches_nothing or two_rank_training or two_ranks_on_half or emulated_rank_7" 2>&1 | grep -v "amdgpu.ids\|socket.cpp\|Gloo" > $out/tests_full.txt
 grep -n "^E \|Error\|FAILED\|passed\|failed" $out/tests_full.txt | head -60
 timeout 600 python bench.py --level-parallel-one-rank 8 --steps 20 --warmup 5 --no-cpu-baseline --no-kernels-alone > $out/lp8_rank7.json 2> $out/lp8_rank7.err
 python - <<'P'
