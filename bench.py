@@ -261,8 +261,8 @@ def steady_state(trainer, data, first_step: int, settle_at: int, rays: int, n_ti
         # host issue time: the same steps issued into an EMPTY queue (a device synchronisation in front of every step), the
         # median of the host's time inside train_iteration -- what the host needs per step when it never waits for the device
         host = []
-        more = [data.next_train(step + n_timed + i) for i in range(33)]
-        for i in range(32):
+        more = [data.next_train(step + n_timed + i) for i in range(65)]
+        for i in range(64):
             torch.cuda.synchronize()
             th = time.perf_counter()
             trainer.train_iteration(step + n_timed + i, *more[i], next_ray_bundle=more[i + 1][0])
@@ -272,7 +272,8 @@ def steady_state(trainer, data, first_step: int, settle_at: int, rays: int, n_ti
         trainer.flush_scheduler_step()
         host.sort()
         out["host_issue_ms_per_step"] = host[len(host) // 2] * 1e3
-        step += 32
+        out["host_issue_ms_per_step_min"] = host[0] * 1e3
+        step += 64
     if H > 0 and datamanager is None and n_profiled > 0:
         from nersemble_amd import _lib
         prof = _lib.profiler

@@ -81,6 +81,7 @@ class _GradBuffers:
         # [0, fixed): the leaf parameters' gradients (mlp_head, mlp_base, the deformation tensors) -- offsets that depend on
         # the model only, not on the batch; behind it the two code-row gradients autograd consumes inside the backward
         self.fixed = plan.g_code_deform // 4
+        self.slack = self.SLACK        # elements behind ``fixed`` every rank's buffer has, whatever its batch
         self.slots = {}                # id(parameter) -> its view (filled by NativeStep: it knows the leaves)
 
         def cut(off, n):

@@ -81,7 +81,7 @@ def _worker(rank, world, port, out_dir):
     slots = {id(a1): flat[3:23].view(4, 5), id(a2): flat[30:39]}
 
     class _Arena:
-        fixed = 40
+        fixed, slack = 40, 256
 
         def __init__(self, flat):
             self.flat = flat

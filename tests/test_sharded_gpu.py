@@ -681,8 +681,9 @@ def test_a_rank_that_marches_nothing_issues_the_same_collectives(cuda, tmp_path)
     assert all(np.isfinite(a["losses"])) and all(np.isfinite(b["losses"]))
     assert b["marched"][1] <= 0 < a["marched"][1]
     for r in (a, b):
-        # (3 steps x (one size exchange, all-gather + three all-to-alls) + the occupancy update's column all-gather)
-        assert r["stats"]["host_exchanges"] == 3 and r["stats"]["collectives"] == 13
+        # 3 steps x (one size exchange, all-gather + three all-to-alls); (the occupancy update of step 0 runs in front of
+        # the hand-over to the level-parallel exchange)
+        assert r["stats"]["host_exchanges"] == 3 and r["stats"]["collectives"] == 12
     assert torch.equal(a["tables"], b["tables"]) and torch.equal(a["small"], b["small"])
 
 
