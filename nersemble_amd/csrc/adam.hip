@@ -365,7 +365,15 @@ __global__ __launch_bounds__(256) void adam_dense_f16grad_kernel(const half_t* _
                                                                  float* __restrict__ v, half_t* __restrict__ f16,
                                                                  AdamHyper hy, const float* __restrict__ inv_scale,
                                                                  const float* __restrict__ found_inf) {
-    if (found_inf && found_inf[0] != 0.f) return;
+    if (found_inf && found_inf[0] != 0.f) {
+        // GradScaler: nothing moves -- but the fp16 output still has to hold this rank's CURRENT values: in the narrow
+        // exchange it is this rank's piece of the all-gather, a buffer that is re-allocated (as zeros) whenever the width
+        // changes; a skip on such a step used to gather zeros into every rank's working tables (advisor, round 5)
+        if (f16)
+            for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+                f16[i] = (half_t)master[i];
+        return;
+    }
     const float is = inv_scale ? inv_scale[0] : 1.0f;
     const int64_t n4 = n / 4;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {

@@ -161,6 +161,12 @@ class ShardedTableAdam(torch.optim.Optimizer):
         # full-width pass).  Written back into the full-layout shard when the width changes and before anybody reads it
         # (gather_master / table_state); the same adam_update on the same values: bit-identical.
         self._compact = None
+        # round 6: while the HashEnsemble trains a compact copy of its first W grids (field_components/hash_ensemble.py:
+        # the first-grid phase and the window ramp), the PACKED buffer of the narrow all-gather -- [entry][f][W] fp16 of all
+        # ranks -- IS that copy's working table: the kernels read it with the H = W instances, the shard's Adam writes this
+        # rank's piece, the all-gather the others', and nothing is unpacked into the 32-grid layout until the width changes
+        hash_ensemble._compact_listeners = [self._on_compact]
+        hash_ensemble.compact_from_f16 = True
         if overlap_reduce:
             hash_ensemble.grad_sink.on_complete = self._start_reduce
 
@@ -265,6 +271,39 @@ class ShardedTableAdam(torch.optim.Optimizer):
     def _leave_compact(self) -> None:
         self._sync_compact()
         self._compact = None
+
+    # ---- the HashEnsemble's compact copy (its listener) -----------------------------------------------------------------
+    def compact_layouts_supported(self) -> bool:
+        """Can the HashEnsemble train compact copies under this optimizer?  The exchange must be able to follow the window."""
+        return self.width_source is not None and self.n_buckets > 1
+
+    @torch.no_grad()
+    def _on_compact(self, what: str) -> None:
+        he = self.he
+        comp = he._compact
+        if comp is None:
+            return
+        W, per_entry = comp["width"], 2 * self.Hp
+        n_entries = self.n // per_entry
+        if what == "enter":
+            if not self.compact_layouts_supported():
+                raise RuntimeError("ShardedTableAdam: the HashEnsemble entered a compact layout, but this exchange cannot "
+                                   "follow the window (no width_source, or a one-piece exchange)")
+            packed = self._packed(W)
+            n = n_entries * 2 * W
+            packed[:n].copy_(comp["f16"].reshape(-1))          # every rank's current values (the tail stays zero)
+            comp["f16"] = packed[:n].view(n_entries, 2, W)
+            comp["sharded"] = True
+            return
+        # "sync" / "leave": the compact state goes back into the full layout -- this rank's master / moment shard, and the
+        # fp16 working tables of ALL entries (every rank holds the gathered packed values)
+        self._sync_compact()
+        if comp.get("sharded"):
+            b = self._buffers()
+            self.ops.unpack_width(self._packed(W), n_entries, W, self.Hp, b["f16"])
+            he.mark_half_synced()
+        if what == "leave":
+            self._compact = None
 
     # ---- step, in the two phases the trainer runs for every optimizer ----------------------------------------------
     @torch.no_grad()
@@ -381,6 +420,10 @@ class ShardedTableAdam(torch.optim.Optimizer):
             if not entries:
                 buf.zero_()
             for i, e in enumerate(entries):
+                if he._compact is not None and he.is_first_grid_code(e["code"]):
+                    # (the compact first-grid phase runs its kernels with a [rows, 1] code of ones: the expansion reads a
+                    # table over all grids)
+                    e = dict(e, code=he.first_grid_code_full(e["n_rows"]))
                 self.ops.expand_f16_bucket_width(he, e, buf, scale, i > 0, self.shard, bucket, k, self.world_size, W,
                                                  self._beyond)
             self._mark("expand_end")
@@ -443,6 +486,8 @@ class ShardedTableAdam(torch.optim.Optimizer):
         W = self._exchange_width()
         self._mark("adam_begin")
         if W == self.Hp:
+            if he._compact is not None:
+                he.leave_first_grid_phase()              # (the window has passed H / 2: back to the 32-grid layout)
             self._leave_compact()
             if self.n_local > 0:
                 self.ops.adam_f16grad(b["grad_shard"], self.n_local, self._master_shard(), b["exp_avg"], b["exp_avg_sq"],
@@ -464,7 +509,14 @@ class ShardedTableAdam(torch.optim.Optimizer):
                                       group["lr"], b1, b2, group["eps"], self._step, inv_scale, found_inf)
             self._mark("adam_end")
             dist.all_gather_into_tensor(packed, mine, group=self.group)
-            self.ops.unpack_width(packed, self.n // per_entry, W, self.Hp, b["f16"])
+            comp = he._compact
+            if comp is not None and comp.get("sharded"):
+                if comp["width"] != W:
+                    raise RuntimeError(f"ShardedTableAdam: the HashEnsemble trains a compact copy of {comp['width']} grids, "
+                                       f"the exchange is {W} wide")
+                # (the gathered buffer IS the compact copy's working table: nothing to unpack)
+            else:
+                self.ops.unpack_width(packed, self.n // per_entry, W, self.Hp, b["f16"])
             if self._beyond is not None and self._beyond_pending is None:
                 if self._beyond.is_cuda:
                     if self._beyond_host is None:
@@ -477,6 +529,7 @@ class ShardedTableAdam(torch.optim.Optimizer):
                     self._beyond_pending = (self._beyond.clone(), None)
         self._mark("ag_end")
         self._max_width = max(self._max_width, W)
+        he.min_compact_width = self._max_width
         self._last_width, self._width = W, None
         if he.grad_sink is not None:
             he.grad_sink.clear()

@@ -180,8 +180,12 @@ class NeRSembleTrainer:
         if calibrate_table_placement and isinstance(table_opt, HashTableAdam):
             from .placement import calibrate_table_placement as _calibrate
             self.placement_report = _calibrate(model.field.hash_ensemble, table_opt)
-        model.field.hash_ensemble.compact_first_grid = bool(
-            compact_first_grid and world_size == 1 and isinstance(table_opt, HashTableAdam) and table_opt.factored)
+        # (round 6: also data-parallel ranks -- the packed buffer of the narrow exchange is the compact copy's working table,
+        # engine/sharded_adam.py)
+        model.field.hash_ensemble.compact_first_grid = bool(compact_first_grid and (
+            (world_size == 1 and isinstance(table_opt, HashTableAdam) and table_opt.factored)
+            or (isinstance(table_opt, ShardedTableAdam) and table_opt.compact_layouts_supported()
+                and self.table_parallel != "level")))
 
     def _maybe_level_parallel(self) -> None:
         """Data-parallel runs: hand the tables from the reduce-scatter exchange (``ShardedTableAdam``) to the level-parallel
@@ -199,6 +203,7 @@ class NeRSembleTrainer:
             if sched is not None and float(sched.value) < opt.Hp / 2:
                 return
         self.flush_scheduler_step()
+        he.leave_first_grid_phase()                           # (a compact copy of the window ramp goes back into the full layout)
         he.wait_tables()
         opt.gather_master()
         b = opt._buffers()

@@ -95,6 +95,11 @@ class HashEnsemble(nn.Module):
         self.compact_first_grid = False        # switched on by the trainer (NeRSembleTrainer(compact_first_grid=True))
         self._compact = None
         self._compact_listeners = []           # callables(what: "enter" | "sync" | "leave"): the optimizer's moments follow
+        # data-parallel runs (engine/sharded_adam.py): the fp32 master is authoritative in a rank's shard only, so the compact
+        # copy is cut from the fp16 WORKING tables (current everywhere), carries no master of its own, and is written back by
+        # the optimizer (its listener); the optimizer also keeps the copy from narrowing below its widest exchange so far
+        self.compact_from_f16 = False
+        self.min_compact_width = 0
         self._zero_slots = None
         # torch's fused optimizers update parameters in place WITHOUT bumping Tensor._version: if one of them steps the
         # tables, the fp16 working copy must be rebuilt (the native table optimizers write it themselves)
@@ -176,12 +181,16 @@ class HashEnsemble(nn.Module):
             return 0
         w = float(window_hash_encodings)
         if w == 1:
-            return 1 if self.disable_initial_hash_ensemble else 0
-        if not self.compact_window_ramp or w < 1:
-            return 0
-        n = int(math.ceil(w))
-        width = 1 << (n - 1).bit_length()
-        return width if 2 <= width < self.Hp else 0
+            width = 1 if self.disable_initial_hash_ensemble else 0
+        elif not self.compact_window_ramp or w < 1:
+            width = 0
+        else:
+            n = int(math.ceil(w))
+            width = 1 << (n - 1).bit_length()
+            width = width if 2 <= width < self.Hp else 0
+        if width and self.min_compact_width > width:
+            width = self.min_compact_width if self.min_compact_width < self.Hp else 0
+        return width
 
     def enter_compact(self, width: int) -> dict:
         """The compact copy of the first ``width`` grids (made from the full layout on first use; a copy of another width
@@ -190,9 +199,13 @@ class HashEnsemble(nn.Module):
             self.leave_first_grid_phase()
         if self._compact is None:
             self.wait_tables()
-            master = self.tables.detach()[:, :, 0:width].contiguous()
-            dev = master.device
-            self._compact = {"width": width, "master": master, "f16": master.to(torch.float16), "geom": self.geom,
+            if self.compact_from_f16:
+                master, f16 = None, self.half_tables()[:, :, 0:width].contiguous()
+            else:
+                master = self.tables.detach()[:, :, 0:width].contiguous()
+                f16 = master.to(torch.float16)
+            dev = f16.device
+            self._compact = {"width": width, "master": master, "f16": f16, "geom": self.geom,
                              "codes": {1: torch.ones((1, 1), dtype=torch.float32, device=dev)}}
             self._compact["code"] = self._compact["codes"][1]
             for cb in list(self._compact_listeners):
@@ -209,12 +222,24 @@ class HashEnsemble(nn.Module):
         5.5 ms instead of 1.9 at 650 k samples)."""
         codes = self._compact["codes"]
         if n_rows not in codes:
-            codes[n_rows] = torch.ones((n_rows, 1), dtype=torch.float32, device=self._compact["master"].device)
+            codes[n_rows] = torch.ones((n_rows, 1), dtype=torch.float32, device=self._compact["f16"].device)
         return codes[n_rows]
+
+    def first_grid_code_full(self, n_rows: int) -> torch.Tensor:
+        """The same code as a table over ALL grids -- [n_rows, Hp], one in column 0, zeros elsewhere -- for a consumer that
+        expands the factored gradient at the full layout's width (the data-parallel exchange, engine/sharded_adam.py)."""
+        key = ("full", n_rows)
+        codes = self._compact["codes"]
+        if key not in codes:
+            t = torch.zeros((n_rows, self.Hp), dtype=torch.float32, device=self._compact["f16"].device)
+            t[:, 0] = 1.0
+            codes[key] = t
+        return codes[key]
 
     def is_first_grid_code(self, code: torch.Tensor) -> bool:
         c = self._compact
-        return c is not None and c["width"] == 1 and any(code.data_ptr() == t.data_ptr() for t in c["codes"].values())
+        return c is not None and c["width"] == 1 and any(code.data_ptr() == t.data_ptr() for k, t in c["codes"].items()
+                                                         if not isinstance(k, tuple))
 
     def zero_slots(self, n: int, device) -> torch.Tensor:
         """int32 zeros [>= n] (the code slot of every sample in the compact phase); grown, never shrunk."""
@@ -230,14 +255,17 @@ class HashEnsemble(nn.Module):
             return
         self.wait_tables()
         w = c["width"]
-        with torch.no_grad():
-            self.tables.detach()[:, :, 0:w].copy_(c["master"])
-            if self.tables_f16.device != self.tables.device:
-                self.tables_f16 = torch.empty_like(self.tables, dtype=torch.float16)
-                self.tables_f16.copy_(self.tables.detach())
-            else:
-                self.tables_f16[:, :, 0:w].copy_(c["f16"])
-            self._f16_version = (self.tables._version, self.tables.data_ptr())
+        if c["master"] is not None:
+            with torch.no_grad():
+                self.tables.detach()[:, :, 0:w].copy_(c["master"])
+                if self.tables_f16.device != self.tables.device:
+                    self.tables_f16 = torch.empty_like(self.tables, dtype=torch.float16)
+                    self.tables_f16.copy_(self.tables.detach())
+                else:
+                    self.tables_f16[:, :, 0:w].copy_(c["f16"])
+                self._f16_version = (self.tables._version, self.tables.data_ptr())
+        # (a copy without a master -- data-parallel runs -- is written back by its optimizer: master shard, moments and
+        # the working tables of every rank)
         for cb in list(self._compact_listeners):
             cb("sync")
 

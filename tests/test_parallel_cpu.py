@@ -200,6 +200,7 @@ class _TorchTableOps:
     @staticmethod
     def adam_f16grad(grad, n, master, exp_avg, exp_avg_sq, f16_out, lr, b1, b2, eps, step, inv_scale, found_inf):
         if found_inf is not None and float(found_inf) != 0:
+            f16_out[:n] = master[:n].half()              # (skipped: the output still holds the current values)
             return
         g = grad[:n].float() * (float(inv_scale) if inv_scale is not None else 1.0)
         m, v = exp_avg[:n], exp_avg_sq[:n]
@@ -210,13 +211,15 @@ class _TorchTableOps:
         f16_out[:n] = master.half()
 
 
-def _fake_entry(he, seed, n_rows=3, poison=False, window=None):
+def _fake_entry(he, seed, n_rows=3, poison=False, window=None, ones=False):
     g = torch.Generator().manual_seed(seed)
     G = torch.randn((n_rows, he.geom.total_entries, 2), generator=g) * 1e-2
     G[torch.rand(G.shape, generator=g) < 0.5] = 0.0
     if poison:
         G[1, 7, 0] = float("inf")
     code = torch.randn((n_rows, he.n_hash_encodings), generator=g)
+    if ones:
+        code = torch.ones_like(code)              # (hash_ensemble.py:121-123: the code is replaced by ones while the window is 1)
     win = None
     if window is not None:
         from nersemble_amd.field_components.hash_ensemble import posenc_window
@@ -283,11 +286,29 @@ def _sharded_worker(rank, world, port, out_dir, n_buckets=8, log2_hashmap_size=8
 
 
 _WINDOWS = [1.0, 1.0, 1.4, 2.0, 2.0, 2.6, 1.0]          # per step (the last: a window that shrank -- the width must not)
+_POISON = {0: 0, 2: 1, 3: 0}                             # step -> the rank whose gradient holds an inf: the very first step,
+#                                                          the FIRST step at a new width (advisor, round 5), a later one
 
 
-def _window_worker(rank, world, port, out_dir, narrow):
-    """ShardedTableAdam over a schedule of coarse-to-fine windows, with the exchange following the window (``narrow``) or
-    always at full width: 4 grids (padded), widths 1, 1, 2, 2, 2, full, full."""
+def _model_compact_width(w, floor, Hp):
+    """HashEnsemble.compact_width without its device test (the CPU stand-in for what the model's forward decides)."""
+    import math
+    if w == 1:
+        width = 1
+    else:
+        n = int(math.ceil(w))
+        width = 1 << (n - 1).bit_length()
+        width = width if 2 <= width < Hp else 0
+    if width and floor > width:
+        width = floor if floor < Hp else 0
+    return width
+
+
+def _window_worker(rank, world, port, out_dir, mode):
+    """ShardedTableAdam over a schedule of coarse-to-fine windows: the exchange always at full width (``full``), following
+    the window in the 32-grid layout (``narrow``), or following it while the HashEnsemble trains COMPACT copies of its first
+    W grids, handed over 1 -> 2 -> full (``compact``: the gathered packed buffer is the copy's working table).  4 grids
+    (padded), widths 1, 1, 2, 2, 2, full, full."""
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -298,13 +319,26 @@ def _window_worker(rank, world, port, out_dir, narrow):
         he.tables.mul_(1e3)
     now = {"w": None}
     opt = ShardedTableAdam(he, lr=5e-3, eps=1e-15, world_size=world, rank=rank, ops=_TorchTableOps(), n_buckets=4,
-                           width_source=(lambda: now["w"]) if narrow else None)
+                           width_source=(lambda: now["w"]) if mode != "full" else None)
+    opt._buffers()
     inv = torch.tensor([1.0 / 64.0])
-    log, widths = [], []
+    log, widths, reads, layouts = [], [], [], []
     for it, w in enumerate(_WINDOWS):
         now["w"] = w
-        poison = (it == 3 and rank == 0)
-        he.grad_sink.entries = [] if (it == 4 and rank == 1) else [_fake_entry(he, 100 * it + rank, poison=poison, window=w)]
+        cw = _model_compact_width(w, he.min_compact_width, 4) if mode == "compact" else 0
+        # what the step's forward would READ: the compact copy's working table, or the 4-grid working tables
+        if cw:
+            comp = he.enter_compact(cw)
+            reads.append(comp["f16"].clone())
+        else:
+            he.leave_first_grid_phase()
+            reads.append(he.tables_f16.clone())
+        layouts.append(cw)
+        poison = _POISON.get(it) == rank
+        entry = _fake_entry(he, 100 * it + rank, poison=poison, window=w, ones=(w == 1.0))
+        if mode == "compact" and cw == 1:
+            entry["code"] = he.first_grid_code(entry["n_rows"])          # (the phase's [rows, 1] code of ones)
+        he.grad_sink.entries = [] if (it == 4 and rank == 1) else [entry]
         he.grad_sink.nonfinite = torch.zeros(1)
         found = torch.zeros(1)
         if it == 4:
@@ -320,12 +354,14 @@ def _window_worker(rank, world, port, out_dir, narrow):
             opt.rollback_step()
         log.append(float(found))
         widths.append(opt._last_width)
+    he.leave_first_grid_phase()
     f16 = he.tables_f16.detach().clone()
+    opt._sync_compact()
     b = opt._buffers()
     moments = (b["exp_avg"].clone(), b["exp_avg_sq"].clone())
     opt.gather_master()
     torch.save({"log": log, "widths": widths, "f16": f16, "master": he.tables.detach().clone(), "moments": moments,
-                "report": opt.comm_report(), "buckets": opt.n_buckets,
+                "report": opt.comm_report(), "buckets": opt.n_buckets, "reads": reads, "layouts": layouts,
                 "pieces": [opt._narrow_pieces(w) for w in (1, 2)]}, os.path.join(out_dir, f"w{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
@@ -334,27 +370,39 @@ def _window_worker(rank, world, port, out_dir, narrow):
 def test_exchange_that_follows_the_window_equals_the_full_exchange_bit_for_bit(tmp_path):
     """While ceil(window) <= W < H only the grids [0, W) are exchanged (reduce-scatter, shard Adam, all-gather on
     [entry][f][W]): working tables, master weights, both moments and the skip decisions are those of the full-width
-    exchange bit for bit -- through a poisoned step, a rank without samples, and a window that shrinks again."""
+    exchange bit for bit -- through poisoned steps (the very first one, the first one at a new width, a later one), a rank
+    without samples, and a window that shrinks again.  Round 6: the same with the HashEnsemble training COMPACT copies of
+    its first W grids (hand-overs 1 -> 2 -> full): what every step's forward reads is what it reads in the 32-grid layout."""
     res = {}
-    for narrow in (False, True):
-        out = tmp_path / f"n{int(narrow)}"
+    for mode in ("full", "narrow", "compact"):
+        out = tmp_path / mode
         out.mkdir()
-        mp.spawn(_window_worker, args=(2, _free_port(), str(out), narrow), nprocs=2, join=True)
-        res[narrow] = [torch.load(out / f"w{r}.pt") for r in range(2)]
-    assert res[False][0]["widths"] == [4] * len(_WINDOWS)
-    assert res[True][0]["widths"] == res[True][1]["widths"] == [1, 1, 2, 2, 2, 4, 4]
-    assert res[True][0]["report"]["exchange_width"] == 4 and res[True][0]["report"]["grids"] == 4
-    # narrow steps travel in FEWER, longer pieces (one reduce-scatter at width 1, two at width 2, four at full width)
-    assert res[True][0]["buckets"] == 4 and res[True][0]["pieces"] == [1, 2] and res[True][0]["report"]["reduce_scatter_calls"] == 4
+        mp.spawn(_window_worker, args=(2, _free_port(), str(out), mode), nprocs=2, join=True)
+        res[mode] = [torch.load(out / f"w{r}.pt") for r in range(2)]
+    assert res["full"][0]["widths"] == [4] * len(_WINDOWS)
+    for mode in ("narrow", "compact"):
+        assert res[mode][0]["widths"] == res[mode][1]["widths"] == [1, 1, 2, 2, 2, 4, 4]
+        assert res[mode][0]["report"]["exchange_width"] == 4 and res[mode][0]["report"]["grids"] == 4
+        # narrow steps travel in FEWER, longer pieces (one reduce-scatter at width 1, two at width 2, four at full width)
+        assert res[mode][0]["buckets"] == 4 and res[mode][0]["pieces"] == [1, 2]
+        assert res[mode][0]["report"]["reduce_scatter_calls"] == 4
+        for r in range(2):
+            assert res["full"][r]["log"] == res[mode][r]["log"] == [1.0, 0.0, 1.0, 1.0, 0.0, 0.0, 0.0]
+            assert torch.equal(res["full"][r]["f16"], res[mode][r]["f16"])
+            assert torch.equal(res["full"][r]["master"], res[mode][r]["master"])
+            for a, b in zip(res["full"][r]["moments"], res[mode][r]["moments"]):
+                assert torch.equal(a, b)
+        assert torch.equal(res[mode][0]["f16"], res[mode][1]["f16"])
+        # the grids the window never reached: untouched
+        assert bool((res[mode][0]["moments"][0].view(-1, 4)[:, 3] == 0).all())
+    # the compact copies: 1, 1, 2, 2, 2 grids wide, then the full layout; every step's forward reads the bits the 32-grid
+    # layout holds for those grids at that step -- on both ranks, through the skipped steps
+    assert res["compact"][0]["layouts"] == [1, 1, 2, 2, 2, 0, 0]
     for r in range(2):
-        assert res[False][r]["log"] == res[True][r]["log"] == [0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0]
-        assert torch.equal(res[False][r]["f16"], res[True][r]["f16"])
-        assert torch.equal(res[False][r]["master"], res[True][r]["master"])
-        for a, b in zip(res[False][r]["moments"], res[True][r]["moments"]):
-            assert torch.equal(a, b)
-    assert torch.equal(res[True][0]["f16"], res[True][1]["f16"])
-    # the grids the window never reached: untouched
-    assert bool((res[True][0]["moments"][0].view(-1, 4)[:, 3] == 0).all())
+        for it, (got, cw) in enumerate(zip(res["compact"][r]["reads"], res["compact"][r]["layouts"])):
+            want = res["full"][r]["reads"][it]
+            want = want[:, :, :cw] if cw else want
+            assert torch.equal(got.reshape(want.shape), want), (r, it, cw)
 
 
 def _beyond_worker(rank, world, port, out_dir):

@@ -814,7 +814,9 @@ def test_narrow_exchange_kernels(H, W, cuda):
 
 def test_sharded_step_follows_the_window(cuda, single_rank_group):
     """ShardedTableAdam with a window schedule (1, 1, 1.5, 2.5, 6): the exchange widens 1, 1, 2, 4, full and the tables are
-    those of the optimizer that always exchanges every grid, bit for bit."""
+    those of the optimizer that always exchanges every grid, bit for bit.  Round 6: a third run trains COMPACT copies of the
+    first 1 / 2 / 4 grids with the H = 1 / 2 / 4 kernels (``compact_first_grid``: the gathered packed buffer of the narrow
+    exchange is the copy's working table, handed over at every doubling) -- the same tables again."""
     from nersemble_amd.engine.sharded_adam import ShardedTableAdam
     B, T, H = 4000, 7, 8
     g = torch.Generator(device=cuda).manual_seed(2)
@@ -824,26 +826,40 @@ def test_sharded_step_follows_the_window(cuda, single_rank_group):
     dout = torch.randn((B, 12), device=cuda, generator=g).half()
     scale = 1024.0
     now = {"w": None}
-    a, b = _he(H, cuda), _he(H, cuda)
+    a, b, c = _he(H, cuda), _he(H, cuda), _he(H, cuda)
     opt_a = ShardedTableAdam(a, lr=5e-3, eps=1e-15, world_size=1, rank=0)
     opt_b = ShardedTableAdam(b, lr=5e-3, eps=1e-15, world_size=1, rank=0, width_source=lambda: now["w"])
+    opt_c = ShardedTableAdam(c, lr=5e-3, eps=1e-15, world_size=1, rank=0, width_source=lambda: now["w"])
+    c.compact_first_grid = True
     inv = torch.tensor([1.0 / scale], device=cuda)
-    widths = []
+    widths, layouts = [], []
     for w in (1.0, 1.0, 1.5, 2.5, 6.0):
         now["w"] = w
-        for he, opt in ((a, opt_a), (b, opt_b)):
+        for he, opt in ((a, opt_a), (b, opt_b), (c, opt_c)):
             found = torch.zeros(1, device=cuda)
             opt.zero_grad()
             he(x, emb, window_hash_encodings=w, code_index=slot).backward(dout * scale)
+            if he is c:
+                layouts.append(c._compact["width"] if c._compact is not None else 0)
             opt.check_finite(found)
             opt.step(found_inf=found, inv_scale=inv)
             assert found.item() == 0
         widths.append(opt_b._last_width)
+        assert opt_c._last_width == opt_b._last_width
         # (the scatter's fp32 atomics run in another order in the two runs: equal up to that, as two runs of ONE optimizer are)
         d = (a.half_tables().float() - b.half_tables().float()).abs()
         assert (d == 0).float().mean().item() >= 0.999, (w, d.max().item())
-    assert widths == [1, 1, 2, 4, 8]
+        c.sync_first_grid()                                   # (the compact copy written back; it stays the working state)
+        d = (a.half_tables().float() - c.half_tables().float()).abs()
+        assert (d == 0).float().mean().item() >= 0.999, ("compact", w, d.max().item())
+    assert widths == [1, 1, 2, 4, 8] and layouts == [1, 1, 2, 4, 0]
     ba, bb = opt_a._buffers(), opt_b._buffers()
+    opt_c.gather_master()
+    dm = (a.tables.detach() - c.tables.detach()).abs()
+    assert (dm <= 1e-6).float().mean().item() >= 0.999
+    bc = opt_c._buffers()
+    diff_c = (ba["exp_avg"] - bc["exp_avg"]).abs()
+    assert diff_c.max().item() <= 2e-3 * ba["exp_avg"].abs().max().item() and (bc["exp_avg"].view(-1, 8)[:, 6:] == 0).all()
     assert (bb["exp_avg"].view(-1, 8)[:, 6:] == 0).all()              # grids the window never reached
     # (the two runs' scatters add their fp32 atomics in different orders, so single elements of the fp16 gradient the Adam
     # kernels read differ by one fp16 ulp: the moments agree to that -- relative to their scale, not element by element, where
