@@ -534,12 +534,21 @@ int nsx_hash_grad_expand_f16_bucket(const float* G, int n_slots, const float* co
  *   _adam ..width : torch.optim.Adam on the grids [0, width) of n_entries entries: grad_packed [n_entries][2][width];
  *                   master / moments / params_f16 in the full layout (pointers to the shard's first entry); the new fp16
  *                   values also go to packed_out [n_entries][2][width] (a skipped step copies the current ones there).
- *   _unpack_width : params_f16 [n_entries][2][padded H] <- packed [n_entries][2][width] (after the all-gather). */
+ *   _unpack_width : params_f16 [n_entries][2][padded H] <- packed [n_entries][2][width] (after the all-gather).
+ *   _bucket_width_consume (round 6): _bucket_width that CLEARS the pairs of G it finds non-zero while it reads them (padded
+ *                   H >= 8, width <= 16): once every bucket of the step has been expanded G is all zeros again, and the next
+ *                   backward needs no fill in front of its scatter (nsx_adam_hash_factored_consume's device for the
+ *                   data-parallel exchange).  One code table per step only (a second expansion would read zeros). */
 int nsx_hash_grad_expand_f16_bucket_width(const float* G, int n_slots, const float* code_table, int64_t code_stride,
                                           const float* window, int H, const nsx_grid_geom* g, nsx_half* bucket_f16,
                                           float scale, int accumulate, int64_t shard_elements, int64_t bucket_elements,
                                           int64_t bucket_index, int world_size, int width, float* beyond_width,
                                           void* stream);
+int nsx_hash_grad_expand_f16_bucket_width_consume(float* G, int n_slots, const float* code_table, int64_t code_stride,
+                                                  const float* window, int H, const nsx_grid_geom* g, nsx_half* bucket_f16,
+                                                  float scale, int accumulate, int64_t shard_elements,
+                                                  int64_t bucket_elements, int64_t bucket_index, int world_size, int width,
+                                                  float* beyond_width, void* stream);
 int nsx_adam_dense_f16grad_width(const nsx_half* grad_packed, int64_t n_entries, int width, int H_padded, float* master,
                                  float* exp_avg, float* exp_avg_sq, nsx_half* params_f16, nsx_half* packed_out, float lr,
                                  float beta1, float beta2, float eps, int64_t step, const float* inv_scale,

@@ -154,6 +154,9 @@ SIGNATURES = {
     "nsx_hash_grad_expand_f16_bucket_width": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_void_p, c_int, _GEOM_P, c_void_p,
                                                       c_float, c_int, c_int64, c_int64, c_int64, c_int, c_int, c_void_p,
                                                       c_void_p]),
+    "nsx_hash_grad_expand_f16_bucket_width_consume": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_void_p, c_int, _GEOM_P,
+                                                              c_void_p, c_float, c_int, c_int64, c_int64, c_int64, c_int,
+                                                              c_int, c_void_p, c_void_p]),
     "nsx_adam_dense_f16grad_width": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                              c_float, c_float, c_float, c_float, c_int64, c_void_p, c_void_p, c_void_p]),
     "nsx_tables_unpack_width": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p]),

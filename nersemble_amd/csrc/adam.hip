@@ -516,9 +516,9 @@ __global__ __launch_bounds__(256) void tables_unpack_width_kernel(const half_t* 
 // where the bytes take 0.15 ms.  Here a thread owns one entry (both features): its values of every plane are one 8-byte load each,
 // coalesced across the wave, nothing is staged, and the 2 W results leave as one vector store.  The arithmetic per element
 // is the kernel's above (the planes in ascending order, fmaf, zeros skipped): the same bits.
-template <int W>
+template <int W, bool CONSUME>
 __global__ __launch_bounds__(256) void expand_f16_narrow_kernel(
-    const float* __restrict__ G, int n_slots, const float* __restrict__ code, int64_t code_stride,
+    float* __restrict__ G, int n_slots, const float* __restrict__ code, int64_t code_stride,
     const float* __restrict__ window, int Hreal, int HP, uint64_t total, half_t* __restrict__ out, float scale,
     int accumulate, uint64_t bucket_entries, uint64_t rank_entries, uint64_t entry_base, uint64_t virtual_total,
     float* __restrict__ beyond_width) {
@@ -534,7 +534,10 @@ __global__ __launch_bounds__(256) void expand_f16_narrow_kernel(
     }
     __syncthreads();
     const uint64_t n_walk = bucket_entries ? virtual_total : total;
-    const float2* G2 = reinterpret_cast<const float2*>(G);
+    float2* G2 = reinterpret_cast<float2*>(G);
+    // CONSUME (nsx_hash_grad_expand_f16_bucket_width_consume): the pairs found non-zero are cleared as they are read -- G is
+    // all zeros again once every piece of the exchange has been expanded, and the next backward's scatter needs no 1.2 GB
+    // fill in front of it (what nsx_adam_hash_factored_consume does for the single-GPU optimizer pass)
     for (uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; v < n_walk; v += (uint64_t)gridDim.x * blockDim.x) {
         const uint64_t e = bucket_entries ? (v / bucket_entries) * rank_entries + entry_base + (v % bucket_entries) : v;
         float g0[W], g1[W];
@@ -548,6 +551,7 @@ __global__ __launch_bounds__(256) void expand_f16_narrow_kernel(
                 for (int u = 0; u < 4; ++u) q[u] = G2[(uint64_t)(sl + u) * total + e];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
+                    if (CONSUME && (q[u].x != 0.f || q[u].y != 0.f)) G2[(uint64_t)(sl + u) * total + e] = float2{0.f, 0.f};
                     if (q[u].x != 0.f) {
 #pragma unroll
                         for (int k = 0; k < W; ++k) g0[k] = __fmaf_rn(q[u].x, cs[(sl + u) * W + k], g0[k]);
@@ -560,6 +564,7 @@ __global__ __launch_bounds__(256) void expand_f16_narrow_kernel(
             }
             for (; sl < n_slots; ++sl) {
                 const float2 q = G2[(uint64_t)sl * total + e];
+                if (CONSUME && (q.x != 0.f || q.y != 0.f)) G2[(uint64_t)sl * total + e] = float2{0.f, 0.f};
                 if (q.x != 0.f) {
 #pragma unroll
                     for (int k = 0; k < W; ++k) g0[k] = __fmaf_rn(q.x, cs[sl * W + k], g0[k]);
@@ -594,7 +599,8 @@ template <int HP>
 static int launch_expand_f16(const float* G, int n_slots, const float* code, int64_t code_stride, const float* window,
                              int H, uint64_t total, nsx_half* out, float scale, int accumulate, hipStream_t st,
                              uint64_t bucket_entries = 0, uint64_t rank_entries = 0, uint64_t entry_base = 0,
-                             uint64_t virtual_total = 0, int out_width = HP, float* beyond_width = nullptr) {
+                             uint64_t virtual_total = 0, int out_width = HP, float* beyond_width = nullptr,
+                             bool consume = false) {
     constexpr int HV = HP >= 4 ? 4 : HP;
     constexpr int EPB = 256 / (2 * HP / HV);
     NSX_REQUIRE(bucket_entries % EPB == 0, "nsx_hash_grad_expand_f16_bucket: bucket of %llu entries is not a multiple of "
@@ -603,14 +609,22 @@ static int launch_expand_f16(const float* G, int n_slots, const float* code, int
         (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
         const size_t smem_n = (size_t)n_slots * out_width * sizeof(float);
         const dim3 grid(num_cus() * 8), block(256);
-#define NSX_EXPN_CASE(WW) case WW: hipLaunchKernelGGL((expand_f16_narrow_kernel<WW>), grid, block, smem_n, st, G, n_slots, code, \
-        code_stride, window, H, HP, total, reinterpret_cast<half_t*>(out), scale, accumulate, bucket_entries, rank_entries, \
-        entry_base, virtual_total, beyond_width); break;
+        float* Gw = const_cast<float*>(G);
+#define NSX_EXPN_CASE(WW) case WW: \
+        if (consume) hipLaunchKernelGGL((expand_f16_narrow_kernel<WW, true>), grid, block, smem_n, st, Gw, n_slots, code, \
+            code_stride, window, H, HP, total, reinterpret_cast<half_t*>(out), scale, accumulate, bucket_entries, rank_entries, \
+            entry_base, virtual_total, beyond_width); \
+        else hipLaunchKernelGGL((expand_f16_narrow_kernel<WW, false>), grid, block, smem_n, st, Gw, n_slots, code, \
+            code_stride, window, H, HP, total, reinterpret_cast<half_t*>(out), scale, accumulate, bucket_entries, rank_entries, \
+            entry_base, virtual_total, beyond_width); \
+        break;
         switch (out_width) { NSX_EXPN_CASE(1) NSX_EXPN_CASE(2) NSX_EXPN_CASE(4) NSX_EXPN_CASE(8) NSX_EXPN_CASE(16) }
 #undef NSX_EXPN_CASE
         NSX_LAUNCH_CHECK("nsx_hash_grad_expand_f16 (narrow) launch");
         return NSX_OK;
     }
+    NSX_REQUIRE(!consume, "nsx_hash_grad_expand_f16_bucket_width_consume: only the narrow expansion (padded H >= 8, width <= "
+                "16, aligned buffers) clears the planes it reads");
     const size_t smem = ((size_t)n_slots * HP + (size_t)n_slots * EPB * 2) * sizeof(float);
     hipLaunchKernelGGL((expand_f16_kernel<HP>), dim3(num_cus() * 8), dim3(256), smem, st, G, n_slots, code, code_stride,
                        window, H, total, reinterpret_cast<half_t*>(out), scale, accumulate, bucket_entries, rank_entries,
@@ -878,7 +892,7 @@ int nsx_hash_grad_expand_f16(const float* G, int n_slots, const float* code_tabl
 static int expand_bucket(const float* G, int n_slots, const float* code_table, int64_t code_stride, const float* window,
                          int H, const nsx_grid_geom* g, nsx_half* bucket_f16, float scale, int accumulate,
                          int64_t shard_elements, int64_t bucket_elements, int64_t bucket_index, int world_size, int width,
-                         float* beyond_width, void* stream);
+                         float* beyond_width, void* stream, bool consume = false);
 
 int nsx_hash_grad_expand_f16_bucket(const float* G, int n_slots, const float* code_table, int64_t code_stride,
                                     const float* window, int H, const nsx_grid_geom* g, nsx_half* bucket_f16, float scale,
@@ -898,6 +912,18 @@ int nsx_hash_grad_expand_f16_bucket_width(const float* G, int n_slots, const flo
                 "nsx_hash_grad_expand_f16_bucket_width: width %d is not a power of two in [1, %d]", width, Hp);
     return expand_bucket(G, n_slots, code_table, code_stride, window, H, g, bucket_f16, scale, accumulate, shard_elements,
                          bucket_elements, bucket_index, world_size, width, beyond_width, stream);
+}
+
+int nsx_hash_grad_expand_f16_bucket_width_consume(float* G, int n_slots, const float* code_table, int64_t code_stride,
+                                                  const float* window, int H, const nsx_grid_geom* g, nsx_half* bucket_f16,
+                                                  float scale, int accumulate, int64_t shard_elements,
+                                                  int64_t bucket_elements, int64_t bucket_index, int world_size, int width,
+                                                  float* beyond_width, void* stream) {
+    const int Hp = nsx_padded_grids(H);
+    NSX_REQUIRE(width >= 1 && width <= Hp && (width & (width - 1)) == 0,
+                "nsx_hash_grad_expand_f16_bucket_width_consume: width %d is not a power of two in [1, %d]", width, Hp);
+    return expand_bucket(G, n_slots, code_table, code_stride, window, H, g, bucket_f16, scale, accumulate, shard_elements,
+                         bucket_elements, bucket_index, world_size, width, beyond_width, stream, true);
 }
 
 int nsx_adam_dense_f16grad_width(const nsx_half* grad_packed, int64_t n_entries, int width, int H_padded, float* master,
@@ -937,7 +963,7 @@ int nsx_tables_unpack_width(const nsx_half* packed, int64_t n_entries, int width
 static int expand_bucket(const float* G, int n_slots, const float* code_table, int64_t code_stride, const float* window,
                          int H, const nsx_grid_geom* g, nsx_half* bucket_f16, float scale, int accumulate,
                          int64_t shard_elements, int64_t bucket_elements, int64_t bucket_index, int world_size, int width,
-                         float* beyond_width, void* stream) {
+                         float* beyond_width, void* stream, bool consume) {
     NSX_REQUIRE(G && code_table && bucket_f16 && g, "nsx_hash_grad_expand_f16_bucket: NULL argument");
     NSX_REQUIRE(H >= 1 && H <= 32, "nsx_hash_grad_expand_f16_bucket: H=%d not in [1,32]", H);
     NSX_REQUIRE(n_slots >= 1 && n_slots <= NSX_MAX_SLOTS, "nsx_hash_grad_expand_f16_bucket: n_slots=%d not in [1,%d]",
@@ -953,7 +979,8 @@ static int expand_bucket(const float* G, int n_slots, const float* code_table, i
     const uint64_t be = (uint64_t)(bucket_elements / per_entry), re = (uint64_t)(shard_elements / per_entry);
     hipStream_t st = (hipStream_t)stream;
 #define NSX_EXPB_CASE(HP) case HP: return launch_expand_f16<HP>(G, n_slots, code_table, code_stride, window, H, total, \
-        bucket_f16, scale, accumulate, st, be, re, (uint64_t)bucket_index * be, (uint64_t)world_size * be, width, beyond_width);
+        bucket_f16, scale, accumulate, st, be, re, (uint64_t)bucket_index * be, (uint64_t)world_size * be, width, beyond_width, \
+        consume);
     switch (Hp) {
         NSX_EXPB_CASE(1) NSX_EXPB_CASE(2) NSX_EXPB_CASE(4) NSX_EXPB_CASE(8) NSX_EXPB_CASE(16) NSX_EXPB_CASE(32)
     }

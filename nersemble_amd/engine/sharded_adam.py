@@ -70,12 +70,12 @@ class NativeTableOps:
 
     @staticmethod
     def expand_f16_bucket_width(he: HashEnsemble, entry, out: torch.Tensor, scale: float, accumulate: bool, shard: int,
-                                bucket: int, k: int, world: int, width: int, beyond: Optional[torch.Tensor]) -> None:
-        check(lib().nsx_hash_grad_expand_f16_bucket_width(ptr(entry["G"]), entry["n_rows"], ptr(entry["code"]),
-                                                          entry["code"].stride(0), ptr(entry["window"]),
-                                                          he.n_hash_encodings, C.byref(he.geom), ptr(out), float(scale),
-                                                          int(accumulate), int(shard), int(bucket), int(k), int(world),
-                                                          int(width), ptr(beyond), stream()),
+                                bucket: int, k: int, world: int, width: int, beyond: Optional[torch.Tensor],
+                                consume: bool = False) -> None:
+        fn = lib().nsx_hash_grad_expand_f16_bucket_width_consume if consume else lib().nsx_hash_grad_expand_f16_bucket_width
+        check(fn(ptr(entry["G"]), entry["n_rows"], ptr(entry["code"]),
+                 entry["code"].stride(0), ptr(entry["window"]), he.n_hash_encodings, C.byref(he.geom), ptr(out), float(scale),
+                 int(accumulate), int(shard), int(bucket), int(k), int(world), int(width), ptr(beyond), stream()),
               "nsx_hash_grad_expand_f16_bucket_width")
 
     @staticmethod
@@ -411,6 +411,12 @@ class ShardedTableAdam(torch.optim.Optimizer):
         n_piece = be * 2 * W
         if self._beyond is None or self._beyond.device != b["dev"]:
             self._beyond = torch.zeros((1,), dtype=torch.float32, device=b["dev"])
+        # the expansion clears the planes it reads (every entry is in exactly one piece): no 1.2 GB fill in front of the next
+        # backward's scatter -- while the scatter touches a minority of G's sectors (as HashTableAdam decides for its pass)
+        sink = he.grad_sink
+        consume = (self.consume_gradient and len(entries) == 1 and self.Hp >= 8 and W <= 16 and entries[0]["G"].is_cuda
+                   and sink.is_persistent(entries[0]["G"])
+                   and 0 < sink.samples_scattered * 80 < self.consume_density_limit * (entries[0]["G"].numel() // 8))
         handles = []
         for k in range(n_pieces):
             buf = b["buckets"][k % 2][:self.world_size * n_piece]
@@ -425,13 +431,18 @@ class ShardedTableAdam(torch.optim.Optimizer):
                     # table over all grids)
                     e = dict(e, code=he.first_grid_code_full(e["n_rows"]))
                 self.ops.expand_f16_bucket_width(he, e, buf, scale, i > 0, self.shard, bucket, k, self.world_size, W,
-                                                 self._beyond)
+                                                 self._beyond, **({"consume": True} if consume else {}))
             self._mark("expand_end")
             if k == 0:
                 self._mark("rs_begin")
             out = b["grad_shard"][k * n_piece:(k + 1) * n_piece]
             handles.append(dist.reduce_scatter_tensor(out, buf, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op))
+        if consume:
+            sink.mark_cleared(entries[0]["G"])           # (an event on the stream the expansions ran on)
         return _Handles(handles) if async_op else None
+
+    consume_gradient = True
+    consume_density_limit = 0.5
 
     @torch.no_grad()
     def _start_reduce(self) -> None:

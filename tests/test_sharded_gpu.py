@@ -161,9 +161,15 @@ def _two_rank_worker(rank, world, port, out_dir):
         losses.append(loss.item())
     trainer.flush_scheduler_step()
     model = trainer.model
-    f16 = model.field.hash_ensemble.half_tables().detach().cpu()
     small = torch.cat([p.detach().reshape(-1).cpu() for n, p in model.named_parameters() if "tables" not in n])
+    # (round 6: the ranks train the compact copy of the first grid -- its working table is the gathered packed buffer of the
+    # narrow exchange; the 32-grid layout is current again after consolidate())
+    compact = model.field.hash_ensemble._compact
+    assert compact is not None and compact["width"] == 1 and compact.get("sharded")
+    first = compact["f16"].detach().cpu().clone()
     trainer.consolidate()
+    f16 = model.field.hash_ensemble.half_tables().detach().cpu()
+    assert torch.equal(f16[:, :, 0:1], first)
     master = model.field.hash_ensemble.tables.detach().cpu()
     torch.save({"losses": losses, "f16": f16, "small": small, "master": master,
                 "rays": data.next_train(99)[0].directions.cpu()}, os.path.join(out_dir, f"r{rank}.pt"))
@@ -766,6 +772,17 @@ def test_narrow_exchange_kernels(H, W, cuda):
         ops.expand_f16_bucket(he, entry, full, 0.5, True, shard, bucket, k, world)
         ops.expand_f16_bucket_width(he, entry, packed, 0.5, True, shard, bucket, k, world, W, beyond)
         assert torch.equal(packed.view(world * be, 2, W), full.view(world * be, 2, Hp)[..., :W])
+    if Hp >= 8 and W <= 16 and W < Hp:
+        # round 6: the variant that clears the planes it reads -- the same bits, and once every piece has been expanded G is
+        # all zeros (no fill in front of the next backward's scatter)
+        consumed = dict(entry, G=G.clone())
+        for k in range(nb):
+            plain = torch.full((world * be * 2 * W,), 7.0, dtype=torch.float16, device=cuda)
+            eaten = torch.full((world * be * 2 * W,), 7.0, dtype=torch.float16, device=cuda)
+            ops.expand_f16_bucket_width(he, entry, plain, 0.5, False, shard, bucket, k, world, W, beyond)
+            ops.expand_f16_bucket_width(he, consumed, eaten, 0.5, False, shard, bucket, k, world, W, beyond, consume=True)
+            assert torch.equal(plain, eaten)
+        assert float(consumed["G"].abs().max()) == 0.0 and float(G.abs().max()) > 0
     assert beyond.item() == 0
     if W < H:
         win2 = win.clone()
