@@ -230,6 +230,21 @@ class LevelParallel:
         lay = self.ops.layout(W, max(1, max(sizes)), max(rws), self.he.n_hash_encodings, 2 * self.n_own)
         return Exchange(lay, sizes, rws, self.rank)
 
+    collective_timeout_s = 120.0
+
+    def collective_entry(self, what: str) -> None:
+        """Called in front of a collective that user code can reach from ONE rank by accident (leaving training mode, a
+        checkpoint): all ranks must arrive within ``collective_timeout_s`` -- otherwise a RuntimeError that says which ranks
+        did not, instead of a hang in the first broadcast."""
+        if self.emulate:
+            return
+        from datetime import timedelta
+        try:
+            dist.monitored_barrier(group=self.cpu_group, timeout=timedelta(seconds=self.collective_timeout_s))
+        except RuntimeError as exc:
+            raise RuntimeError(f"level-parallel HashEnsemble: {what} is a collective -- every rank has to call it (the ranks "
+                               f"hold different levels of the tables); not all of them did: {exc}") from exc
+
     def _all_gather(self, out: torch.Tensor, mine: torch.Tensor) -> None:
         """``out`` = every rank's ``mine`` in rank order (flat byte buffers)."""
         W, n = self.world_size, mine.numel()

@@ -187,7 +187,7 @@ class NeRSembleTrainer:
             or (isinstance(table_opt, ShardedTableAdam) and table_opt.compact_layouts_supported()
                 and self.table_parallel != "level")))
 
-    def _maybe_level_parallel(self) -> None:
+    def _maybe_level_parallel(self, ray_bundle: Optional[RayBundle] = None) -> None:
         """Data-parallel runs: hand the tables from the reduce-scatter exchange (``ShardedTableAdam``) to the level-parallel
         one once the coarse-to-fine window has passed H / 2 -- a collective every rank reaches at the same step (the schedule
         is the same everywhere).  The fp32 master and both moments are gathered once; each rank keeps its levels' range."""
@@ -202,6 +202,20 @@ class NeRSembleTrainer:
             sched = getattr(self.model, "sched_window_hash_encodings", None)
             if sched is not None and float(sched.value) < opt.Hp / 2:
                 return
+        # the optimizer pass of a level owner reads one gradient plane per (rank, code row of that rank's batch): the job's
+        # rows must fit NSX_MAX_ADAM_SLOTS.  Decided ONCE, together (advisor, round 5: 8 ranks with more than 24 images per
+        # batch used to abort at the hand-over step): a job that does not fit stays on the reduce-scatter exchange.
+        md = (ray_bundle.metadata or {}) if ray_bundle is not None else {}
+        rows = int(md["_image_timesteps"].numel()) if "_image_timesteps" in md else 0
+        most = torch.tensor([float(rows)], device=he.tables.device)
+        dist.all_reduce(most, op=dist.ReduceOp.MAX, group=opt.group)
+        from .level_parallel import MAX_ADAM_SLOTS
+        if int(most.item()) * self.world_size > MAX_ADAM_SLOTS or int(most.item()) > 64:
+            import warnings
+            warnings.warn(f"level-parallel tables need <= {MAX_ADAM_SLOTS} code rows in the job's batch; this job has "
+                          f"{self.world_size} ranks x up to {int(most.item())} rows: staying on the reduce-scatter exchange")
+            self.table_parallel = "shard"
+            return
         self.flush_scheduler_step()
         he.leave_first_grid_phase()                           # (a compact copy of the window ramp goes back into the full layout)
         he.wait_tables()
@@ -418,7 +432,7 @@ class NeRSembleTrainer:
         for cb in self.callbacks:
             cb.run(step)
         if self.world_size > 1:
-            self._maybe_level_parallel()
+            self._maybe_level_parallel(ray_bundle)
         if next_ray_bundle is not None and self.prefetch_march:
             self.model.prefetch_sampling(next_ray_bundle, step + 1)
         for opt in self.optimizers.values():

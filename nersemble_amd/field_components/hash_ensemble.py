@@ -281,8 +281,11 @@ class HashEnsemble(nn.Module):
         if not mode:
             self.leave_first_grid_phase()            # evaluation reads the full layout (pre-blended grids, checkpoints)
             if self.level_parallel is not None and self._level_parallel_owner is not None and self.training:
-                # level-parallel run: every rank's entry range becomes current everywhere (a collective: the ranks leave
-                # training mode together)
+                # level-parallel run: every rank's entry range becomes current everywhere -- a COLLECTIVE: the ranks leave
+                # training mode together.  A rank that calls model.eval() alone (a rank-0-only evaluation callback or
+                # checkpoint) would wait for ever inside the first broadcast: the side group's monitored barrier turns that
+                # into an error that names the missing ranks (advisor, round 5)
+                self.level_parallel.collective_entry("HashEnsemble.train(False) / model.eval()")
                 self._level_parallel_owner.gather_master()
         return super().train(mode)
 

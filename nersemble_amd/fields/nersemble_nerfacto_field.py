@@ -130,7 +130,9 @@ class NeRSembleNeRFactoField(nn.Module):
         blended = md.get("preblended_table")           # eval fast path: one time code for every sample of the image
         if (blended is not None and positions_world.is_cuda and self.fused_eval_density and not torch.is_grad_enabled()
                 and md.get("precomputed_base_out") is None and self.hash_ensemble.geom.n_levels == 16
-                and self.mlp_base.n_output_dims == 16):
+                and self.mlp_base.n_output_dims == 16 and self.mlp_base.n_hidden_mats in (0, 1)):
+            # (what nsx_density_fused_fwd is built for -- 16 levels, a 64-wide mlp_base [tcnn.Network admits no other width]
+            # with 0 or 1 hidden matrices, 16 outputs; any other model takes the four launches below)
             return self._density_fused(positions_world, offsets, blended)
         if positions_world.is_cuda:
             positions, selector_all = F.normalised_positions(positions_world, offsets, self._aabb6())

@@ -490,6 +490,9 @@ class NeRSembleNGPModel(BaseModel):
         window_hash = self.sched_window_hash_encodings.value if self.sched_window_hash_encodings is not None else None
         window_deform = self.sched_window_deform.value if self.sched_window_deform is not None else None
         self._sigma_cache = None
+        if self.field.hash_ensemble.level_parallel is not None and not self.reuse_sigma_pass:
+            raise RuntimeError("level-parallel run: the main pass reuses the sigma_fn pass's forward values (reuse_sigma_pass) -- "
+                               "one forward and one backward exchange per step on every rank, whatever it marched")
         self.field.keep_density_intermediates = self.reuse_sigma_pass
         md = ray_bundle.metadata
         # the kept-sample count can stay on the device when the per-sample code slot comes with the batch (it is gathered
@@ -526,6 +529,11 @@ class NeRSembleNGPModel(BaseModel):
         if bound > 0 and S > 4 * bound:
             free_bytes, _ = torch.cuda.mem_get_info(ray_indices.device)
             if S * self.fused_pass_bytes_per_sample > 0.5 * free_bytes:
+                if he.level_parallel is not None:
+                    # (a rank that re-ran its sampler on the chunked path would issue collectives the others do not: the
+                    # level-parallel exchange has no rank-local fallbacks -- advisor, round 5)
+                    raise RuntimeError(f"fused training pass: {S} samples do not fit in half of the free device memory, and a "
+                                       f"level-parallel run cannot fall back to the chunked path on one rank alone")
                 if not getattr(self, "_warned_fused_fallback", False):
                     self._warned_fused_fallback = True
                     import warnings
@@ -547,6 +555,8 @@ class NeRSembleNGPModel(BaseModel):
             slot = inv.to(torch.int32)[ray_indices]
         slot = slot.reshape(-1).to(torch.int32).contiguous()
         if uniq.shape[0] > 64:
+            if he.level_parallel is not None:
+                raise RuntimeError(f"level-parallel run: {uniq.shape[0]} code rows in this rank's batch (limit 64)")
             return None
         # forward values of the sampler's sigma_fn pass for the kept samples (exact reuse)
         cache, keep = self._sigma_cache, self.occupancy_grid.last_keep_index
