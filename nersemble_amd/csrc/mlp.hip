@@ -132,12 +132,24 @@ __global__ __launch_bounds__(MLP_WAVES * kWave) void mlp_bwd_kernel(
 #pragma unroll
     for (int i = 0; i < 2; ++i) { gWo[i] = zero16(); gW0[i] = zero16(); gWh[i][0] = zero16(); gWh[i][1] = zero16(); }
 
-    for (int64_t tile = (int64_t)blockIdx.x * MLP_WAVES + wave; tile < n_tiles; tile += (int64_t)gridDim.x * MLP_WAVES) {
+    // (round 6: the next tile's input is requested while this tile's chain runs -- what the forward got in round 5)
+    const int64_t tile_step = (int64_t)gridDim.x * MLP_WAVES;
+    int64_t tile = (int64_t)blockIdx.x * MLP_WAVES + wave;
+    f16x8 xn[2];
+    if (tile < n_tiles) {
+        const int64_t b0 = tile * 32 + n;
+        load_input(io, b0 < B ? b0 : B - 1, kb, fast, xn);
+    }
+    for (; tile < n_tiles; tile += tile_step) {
         const int64_t b_raw = tile * 32 + n;
         const bool valid = b_raw < B;
         const int64_t b = valid ? b_raw : B - 1;
         f16x8 x[2], h1[4], h2[4];
-        load_input(io, b, kb, fast, x);
+        x[0] = xn[0]; x[1] = xn[1];
+        if (tile + tile_step < n_tiles) {
+            const int64_t bn = (tile + tile_step) * 32 + n;
+            load_input(io, bn < B ? bn : B - 1, kb, fast, xn);
+        }
         if (!valid) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) { x[0][j] = (half_t)0.f; x[1][j] = (half_t)0.f; }
