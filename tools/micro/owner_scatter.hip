@@ -24,7 +24,11 @@
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
 
-constexpr int TILE_LOG2 = 14, TILE = 1 << TILE_LOG2;      // entries per tile: 128 KB of float2 in LDS
+#ifndef TILE_LOG2_
+#define TILE_LOG2_ 14
+#endif
+constexpr int TILE_LOG2 = TILE_LOG2_, TILE = 1 << TILE_LOG2;   // entries per tile: 128 KB of float2 in LDS at 14, 64 KB at 13
+constexpr int SB = 19 - TILE_LOG2;                        // bits of a tile number on a hashed level (2^19 entries)
 constexpr int THREADS = 1024;
 
 struct Tiles { int level[512]; int first[512]; int n; };
@@ -38,11 +42,19 @@ __device__ __forceinline__ void cell1(float scale, float p, uint32_t& c, float& 
 
 // signature of a (level, sample): hashed level -- the tile of the 4 (y, z) corner pairs, 5 bits each (bit 31 clear);
 // dense level -- lowest and highest tile any corner can fall in (8 bits each, bit 31 set)
-__global__ __launch_bounds__(256) void signature_kernel(const float* __restrict__ x, int64_t S, const nsx_grid_geom g,
-                                                        uint32_t* __restrict__ sig) {
-    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= S) return;
+// (second version: everything the tile blocks read is written in SLOT-SORTED order -- position i = sample perm[i] -- so that a
+// block's walk over its slot is a contiguous stream: the first version gathered sig[perm[i]], one 64-byte line per dword)
+__global__ __launch_bounds__(256) void signature_kernel(const float* __restrict__ x, const int32_t* __restrict__ perm,
+                                                        const float* __restrict__ dout, int64_t S, const nsx_grid_geom g,
+                                                        uint32_t* __restrict__ sig, float* __restrict__ xs,
+                                                        float2* __restrict__ ds) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= S) return;
+    const int64_t b = perm[i];
     const float py = x[b * 3 + 1], pz = x[b * 3 + 2], px = x[b * 3];
+    xs[i * 3] = px; xs[i * 3 + 1] = py; xs[i * 3 + 2] = pz;
+    for (int l = 0; l < g.n_levels; ++l)
+        ds[(int64_t)l * S + i] = float2{dout[b * 2 * g.n_levels + 2 * l], dout[b * 2 * g.n_levels + 2 * l + 1]};
     for (int l = 0; l < g.n_levels; ++l) {
         uint32_t cy, cz, cx; float wy, wz, wx;
         cell1(g.scale[l], py, cy, wy); cell1(g.scale[l], pz, cz, wz);
@@ -51,8 +63,8 @@ __global__ __launch_bounds__(256) void signature_kernel(const float* __restrict_
             const uint32_t mask = g.size[l] - 1u;
             const uint32_t y0 = cy * 2654435761u, y1 = (cy + 1u) * 2654435761u;
             const uint32_t z0 = cz * 805459861u, z1 = (cz + 1u) * 805459861u;
-            s = (((y0 ^ z0) & mask) >> TILE_LOG2) | ((((y1 ^ z0) & mask) >> TILE_LOG2) << 5) |
-                ((((y0 ^ z1) & mask) >> TILE_LOG2) << 10) | ((((y1 ^ z1) & mask) >> TILE_LOG2) << 15);
+            s = (((y0 ^ z0) & mask) >> TILE_LOG2) | ((((y1 ^ z0) & mask) >> TILE_LOG2) << SB) |
+                ((((y0 ^ z1) & mask) >> TILE_LOG2) << (2 * SB)) | ((((y1 ^ z1) & mask) >> TILE_LOG2) << (3 * SB));
         } else {
             cell1(g.scale[l], px, cx, wx);
             const uint32_t res = g.res[l], size = g.size[l];
@@ -60,13 +72,13 @@ __global__ __launch_bounds__(256) void signature_kernel(const float* __restrict_
             // (in-contract positions: lo < size; hi may wrap once -- then every tile is a candidate)
             s = 0x80000000u | (hi >= size ? 0x00FF00u : (((hi >> TILE_LOG2) & 0xFFu) << 8)) | ((lo >> TILE_LOG2) & 0xFFu);
         }
-        sig[(int64_t)l * S + b] = s;
+        sig[(int64_t)l * S + i] = s;
     }
 }
 
 __global__ __launch_bounds__(THREADS) void owner_scatter_kernel(
-    const float* __restrict__ x, const int32_t* __restrict__ perm, const int32_t* __restrict__ slot_off,
-    const uint32_t* __restrict__ sig, int64_t S, const float* __restrict__ dout, const nsx_grid_geom g, const Tiles tiles,
+    const float* __restrict__ x, const int32_t* __restrict__ slot_off,
+    const uint32_t* __restrict__ sig, int64_t S, const float2* __restrict__ ds, const nsx_grid_geom g, const Tiles tiles,
     float2* __restrict__ G2, uint64_t g_total) {
     extern __shared__ float acc[];                         // [TILE][2]
     const int t = blockIdx.x, s = blockIdx.y;
@@ -79,20 +91,29 @@ __global__ __launch_bounds__(THREADS) void owner_scatter_kernel(
     __syncthreads();
     const float scale = g.scale[l];
     const bool hashed = g.hashed[l] != 0;
-    const int L2 = 2 * g.n_levels;
     const uint32_t* sl = sig + (int64_t)l * S;
+    const float2* dl = ds + (int64_t)l * S;
     const int end = slot_off[s + 1];
-    for (int i = slot_off[s] + threadIdx.x; i < end; i += THREADS) {
-        const int b = perm[i];
-        const uint32_t sg = sl[b];
+    for (int i0_ = slot_off[s] + threadIdx.x; i0_ < end; i0_ += 4 * THREADS) {
+      uint32_t sg4[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) sg4[u] = (i0_ + u * THREADS < end) ? sl[i0_ + u * THREADS] : 0xFFFFFFFFu;   // four in flight
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0_ + u * THREADS;
+        if (i >= end) break;
+        const int b = i;
+        const uint32_t sg = sg4[u];
         if (hashed) {
-            const uint32_t m0 = (sg & 31u) == r, m1 = ((sg >> 5) & 31u) == r, m2 = ((sg >> 10) & 31u) == r,
-                           m3 = ((sg >> 15) & 31u) == r;
+            constexpr uint32_t SM = (1u << SB) - 1u;
+            const uint32_t m0 = (sg & SM) == r, m1 = ((sg >> SB) & SM) == r, m2 = ((sg >> (2 * SB)) & SM) == r,
+                           m3 = ((sg >> (3 * SB)) & SM) == r;
             if (!(m0 | m1 | m2 | m3)) continue;
             const float px = x[b * 3], py = x[b * 3 + 1], pz = x[b * 3 + 2];
             uint32_t cx, cy, cz; float wx, wy, wz;
             cell1(scale, px, cx, wx); cell1(scale, py, cy, wy); cell1(scale, pz, cz, wz);
-            const float g0 = dout[(int64_t)b * L2 + 2 * l], g1 = dout[(int64_t)b * L2 + 2 * l + 1];
+            const float2 gg = dl[b];
+            const float g0 = gg.x, g1 = gg.y;
             const uint32_t mask = size - 1u;
             const uint32_t yh[2] = {cy * 2654435761u, (cy + 1u) * 2654435761u};
             const uint32_t zh[2] = {cz * 805459861u, (cz + 1u) * 805459861u};
@@ -113,7 +134,8 @@ __global__ __launch_bounds__(THREADS) void owner_scatter_kernel(
             const float px = x[b * 3], py = x[b * 3 + 1], pz = x[b * 3 + 2];
             uint32_t cx, cy, cz; float wx, wy, wz;
             cell1(scale, px, cx, wx); cell1(scale, py, cy, wy); cell1(scale, pz, cz, wz);
-            const float g0 = dout[(int64_t)b * L2 + 2 * l], g1 = dout[(int64_t)b * L2 + 2 * l + 1];
+            const float2 gg = dl[b];
+            const float g0 = gg.x, g1 = gg.y;
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 uint32_t idx = (cx + (k & 1)) + (cy + ((k >> 1) & 1)) * res + (cz + (k >> 2)) * res * res;
@@ -125,6 +147,7 @@ __global__ __launch_bounds__(THREADS) void owner_scatter_kernel(
                 }
             }
         }
+      }
     }
     __syncthreads();
     float2* dst = G2 + (uint64_t)s * g_total + off + first;
@@ -167,9 +190,9 @@ int main(int argc, char** argv) {
     for (int64_t i = 0; i < S; ++i) hoff[hslot[i] + 1]++;
     for (int s = 0; s < T; ++s) hoff[s + 1] += hoff[s];
     { std::vector<int32_t> cur(hoff.begin(), hoff.end() - 1); for (int64_t i = 0; i < S; ++i) hperm[cur[hslot[i]]++] = (int32_t)i; }
-    float *x, *d, *Ga, *Gb; int32_t *slot, *perm, *off; uint32_t* sig;
+    float *x, *d, *Ga, *Gb, *xs; float2* ds; int32_t *slot, *perm, *off; uint32_t* sig;
     CK(hipMalloc(&x, S * 12)); CK(hipMalloc(&d, S * 128)); CK(hipMalloc(&slot, S * 4)); CK(hipMalloc(&perm, S * 4));
-    CK(hipMalloc(&off, (T + 1) * 4)); CK(hipMalloc(&sig, S * 16 * 4));
+    CK(hipMalloc(&off, (T + 1) * 4)); CK(hipMalloc(&sig, S * 16 * 4)); CK(hipMalloc(&xs, S * 12)); CK(hipMalloc(&ds, S * 16 * 8));
     CK(hipMalloc(&Ga, (size_t)T * total * 8)); CK(hipMalloc(&Gb, (size_t)T * total * 8));
     CK(hipMemcpy(x, hx.data(), S * 12, hipMemcpyHostToDevice)); CK(hipMemcpy(d, hd.data(), S * 128, hipMemcpyHostToDevice));
     CK(hipMemcpy(slot, hslot.data(), S * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(perm, hperm.data(), S * 4, hipMemcpyHostToDevice));
@@ -177,8 +200,8 @@ int main(int argc, char** argv) {
     CK(hipFuncSetAttribute((const void*)owner_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TILE * 8));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     auto owner = [&]() {
-        hipLaunchKernelGGL(signature_kernel, dim3((S + 255) / 256), dim3(256), 0, 0, x, S, g, sig);
-        hipLaunchKernelGGL(owner_scatter_kernel, dim3(tiles.n, T), dim3(THREADS), TILE * 8, 0, x, perm, off, sig, S, d, g, tiles,
+        hipLaunchKernelGGL(signature_kernel, dim3((S + 255) / 256), dim3(256), 0, 0, x, perm, d, S, g, sig, xs, ds);
+        hipLaunchKernelGGL(owner_scatter_kernel, dim3(tiles.n, T), dim3(THREADS), TILE * 8, 0, xs, off, sig, S, ds, g, tiles,
                            reinterpret_cast<float2*>(Gb), total);
     };
     auto atomics = [&]() {
@@ -191,7 +214,7 @@ int main(int argc, char** argv) {
         CK(hipEventRecord(e0)); for (int i = 0; i < 5; ++i) owner(); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
         CK(hipEventElapsedTime(&ms, e0, e1)); printf("owner-computes (signature pre-pass + tile kernel): %.3f ms\n", ms / 5);
         CK(hipEventRecord(e0));
-        for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(signature_kernel, dim3((S + 255) / 256), dim3(256), 0, 0, x, S, g, sig);
+        for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(signature_kernel, dim3((S + 255) / 256), dim3(256), 0, 0, x, perm, d, S, g, sig, xs, ds);
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
         CK(hipEventElapsedTime(&ms, e0, e1)); printf("   of which the signature pre-pass:               %.3f ms\n", ms / 5);
         atomics(); CK(hipDeviceSynchronize());
