@@ -189,6 +189,8 @@ class SE3DeformationField(nn.Module):
             if warp_code is None:
                 return None
             max_chunk = len(positions) if self.max_n_samples_per_batch == -1 else self.max_n_samples_per_batch
+            if not torch.is_grad_enabled():
+                max_chunk = len(positions)            # (nothing is kept for a backward: one launch for the whole pass)
             params, packed = self.ordered_params(), self.packed_params()
             outs = []
             if code_index is None and warp_code.shape[0] == 1 and len(positions) != 1:

@@ -195,7 +195,11 @@ class NeRSembleNeRFactoField(nn.Module):
     def _density_fused(self, positions_world: Tensor, offsets: Optional[Tensor], blended: Tensor) -> Tuple[Tensor, Tensor]:
         """``_density_from_positions`` on the pre-blended grid without gradients: one launch per chunk
         (``nsx_density_fused_fwd``); the hash features are never materialised."""
-        max_chunk = len(positions_world) if self.max_n_samples_per_batch == -1 else self.max_n_samples_per_batch
+        # (round 6: ONE launch for the whole pass.  The reference's ``max_n_samples_per_batch`` -- evaluate_nersemble.py:133-145
+        # walks the field in 2^20-sample pieces -- bounds the memory of activations kept for autograd; this route runs
+        # without gradients and keeps 34 bytes per sample, so the 27 pieces of an evaluation image were 27 launches and two
+        # ``cat`` copies of their outputs for nothing; the result does not depend on the chunking, tests/test_full_size_gpu.py)
+        max_chunk = len(positions_world)
         w16, nh, geom, aabb6 = self.mlp_base.half_weights(), self.mlp_base.n_hidden_mats, self.hash_ensemble.geom, self._aabb6()
         densities, base_outs = [], []
         for pos_c, off_c in chunked(max(max_chunk, 1), positions_world, offsets):
@@ -217,6 +221,8 @@ class NeRSembleNeRFactoField(nn.Module):
             raise AttributeError("Camera indices are not provided.")
         directions = ray_samples.frustums.directions.reshape(-1, 3)
         max_chunk = len(ray_samples) if self.max_n_samples_per_batch == -1 else self.max_n_samples_per_batch
+        if not torch.is_grad_enabled() and directions.is_cuda:
+            max_chunk = len(ray_samples)                  # (no activations are kept: one launch, see _density_fused)
         if base_out is None:
             # generic path (reference signature): rebuild a [S,16] tensor with an empty density column
             base_out = torch.cat([torch.zeros_like(density_embedding[..., :1]), density_embedding], dim=-1)
