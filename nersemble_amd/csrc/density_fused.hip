@@ -145,21 +145,33 @@ int nsx_density_fused_fwd(const float* positions_world, const float* offsets, in
         box.lo[d] = field_aabb_host[d];
         box.ext[d] = field_aabb_host[3 + d] - field_aabb_host[d];
     }
-    const int64_t n_tiles = (S + 31) / 32;
-    int64_t blocks = (n_tiles + MLP_WAVES - 1) / MLP_WAVES;
-    const int64_t cap = (int64_t)num_cus() * 8;
-    if (blocks > cap) blocks = cap;
     hipStream_t st = (hipStream_t)stream;
     const half_t* t = reinterpret_cast<const half_t*>(table);
     const half_t* W = reinterpret_cast<const half_t*>(base_weights);
     half_t* bo = reinterpret_cast<half_t*>(base_out);
-    if (base_hidden_mats == 0)
-        hipLaunchKernelGGL((density_fused_kernel<0>), dim3((unsigned)blocks), dim3(MLP_WAVES * kWave), fused_smem(0), st,
-                           positions_world, offsets, S, box, t, *g, W, bo, base_out_stride, density, n_tiles, n_device);
-    else
-        hipLaunchKernelGGL((density_fused_kernel<1>), dim3((unsigned)blocks), dim3(MLP_WAVES * kWave), fused_smem(1), st,
-                           positions_world, offsets, S, box, t, *g, W, bo, base_out_stride, density, n_tiles, n_device);
-    NSX_LAUNCH_CHECK("nsx_density_fused_fwd launch");
+    // A pass of many million samples (an evaluation image: 6.5 M per 32 768-ray bundle) is enqueued in slices of 2^20: the
+    // blocks of one launch stride through its samples together, and the ray-ordered samples they hold at any moment share
+    // their coarse cells in L2 -- over 25 strides of ONE launch the blocks drift apart and the kernel ran 0.40 ms per 2^20
+    // samples instead of 0.33 (profiles/r06_eval_image.txt).  Slicing needs host-known row counts: a call under a device-side
+    // count is one launch.
+    const int64_t slice = n_device ? S : ((int64_t)1 << 20);
+    for (int64_t s0 = 0; s0 < S; s0 += slice) {
+        const int64_t Sn = S - s0 < slice ? S - s0 : slice;
+        const int64_t n_tiles = (Sn + 31) / 32;
+        int64_t blocks = (n_tiles + MLP_WAVES - 1) / MLP_WAVES;
+        const int64_t cap = (int64_t)num_cus() * 8;
+        if (blocks > cap) blocks = cap;
+        const float* pw = positions_world + s0 * 3;
+        const float* of = offsets ? offsets + s0 * 3 : nullptr;
+        half_t* bos = bo ? bo + s0 * base_out_stride : nullptr;
+        if (base_hidden_mats == 0)
+            hipLaunchKernelGGL((density_fused_kernel<0>), dim3((unsigned)blocks), dim3(MLP_WAVES * kWave), fused_smem(0), st,
+                               pw, of, Sn, box, t, *g, W, bos, base_out_stride, density + s0, n_tiles, n_device);
+        else
+            hipLaunchKernelGGL((density_fused_kernel<1>), dim3((unsigned)blocks), dim3(MLP_WAVES * kWave), fused_smem(1), st,
+                               pw, of, Sn, box, t, *g, W, bos, base_out_stride, density + s0, n_tiles, n_device);
+        NSX_LAUNCH_CHECK("nsx_density_fused_fwd launch");
+    }
     return NSX_OK;
 }
 
