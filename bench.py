@@ -723,6 +723,7 @@ def main():
         local_rank = 0
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("TORCH_NCCL_AVOID_RECORD_STREAMS", "1")     # (persistent buffers: no per-call recordStream)
         torch.cuda.set_device(local_rank)
         if a.backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
@@ -737,6 +738,7 @@ def main():
         os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(s_.getsockname()[1])
         s_.close()
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("TORCH_NCCL_AVOID_RECORD_STREAMS", "1")     # (persistent buffers: no per-call recordStream)
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend=a.backend, rank=0, world_size=1,
                                 **({"device_id": torch.device(f"cuda:{local_rank}")} if a.backend == "nccl" else {}))

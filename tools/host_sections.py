@@ -37,6 +37,7 @@ def main():
         os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(s_.getsockname()[1])
         s_.close()
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("TORCH_NCCL_AVOID_RECORD_STREAMS", "1")     # (persistent buffers: no per-call recordStream)
         torch.cuda.set_device(0)
         dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
         a.window_open, a.full_layout = True, True
