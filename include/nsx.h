@@ -909,6 +909,11 @@ typedef struct nsx_lp_layout {
     int32_t R_cap;
     int32_t H;
     int32_t n2;                 /* feature columns per rank = 2 x owned levels */
+    int32_t level_of[32];   /* (NSX_MAX_LEVELS) global level of (owner j, its i-th level) at [j * n2 / 2 + i]: where block j's columns
+                                           sit in the [S][2 L] feature row.  nsx_lp_layout_make fills the contiguous assignment
+                                           (owner j holds levels [j n2/2, (j+1) n2/2)); a binding that balances the owners'
+                                           work -- the finest levels cost twice the coarsest -- overwrites it with its
+                                           permutation of 0 .. W n2/2 - 1 */
 } nsx_lp_layout;
 int nsx_lp_layout_make(int W, int64_t S_cap, int R_cap, int H, int n2, nsx_lp_layout* out);
 int64_t nsx_lp_sizeof(void);

@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void lp_fwd_unpack_kernel(const uint8_t* __res
         const int rem = (int)(i - s * P);
         const int j = rem / n_own, c = rem - j * n_own;
         const uint32_t* src = reinterpret_cast<const uint32_t*>(recv + (int64_t)j * lay.feat_bytes);
-        feats[i] = src[s * n_own + c];
+        feats[s * P + lay.level_of[rem]] = src[s * n_own + c];
     }
 }
 
@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void lp_bwd_pack_kernel(const float* __restric
         const int64_t s = i / P;
         const int rem = (int)(i - s * P);
         const int j = rem / n_own, c = rem - j * n_own;
-        const float2 v = d2[i];
+        const float2 v = d2[s * P + lay.level_of[rem]];
         uint32_t* dz = reinterpret_cast<uint32_t*>(send + (int64_t)j * lay.bwd_bytes + lay.b_dz);
         dz[s * n_own + c] = as_u32(half2_t{(half_t)v.x, (half_t)v.y});
     }
@@ -166,10 +166,22 @@ static inline int lp_blocks(int64_t work) {
     return (int)b;
 }
 
+static int lp_check_levels(const nsx_lp_layout* lay, const char* who) {
+    const int n = lay->W * (lay->n2 / 2);
+    uint32_t seen = 0;
+    for (int i = 0; i < n; ++i) {
+        NSX_REQUIRE(lay->level_of[i] >= 0 && lay->level_of[i] < n && !((seen >> lay->level_of[i]) & 1u),
+                    "%s: level_of is not a permutation of 0 .. %d", who, n - 1);
+        seen |= 1u << lay->level_of[i];
+    }
+    return NSX_OK;
+}
+
 static int lp_check(const nsx_lp_layout* lay, const char* who) {
     NSX_REQUIRE(lay != nullptr, "%s: layout is NULL", who);
     NSX_REQUIRE(lay->W >= 1 && lay->W <= NSX_MAX_LEVELS && lay->n2 >= 2 && lay->n2 % 2 == 0 && lay->H >= 1 && lay->H <= 32 &&
-                lay->R_cap >= 1 && lay->R_cap <= NSX_MAX_SLOTS && lay->S_cap >= 1 && lay->fwd_bytes > 0,
+                lay->R_cap >= 1 && lay->R_cap <= NSX_MAX_SLOTS && lay->S_cap >= 1 && lay->fwd_bytes > 0 &&
+                lay->W * (lay->n2 / 2) <= NSX_MAX_LEVELS,
                 "%s: not a layout of nsx_lp_layout_make (W=%d n2=%d H=%d R_cap=%d S_cap=%lld)", who, lay->W, lay->n2, lay->H,
                 lay->R_cap, (long long)lay->S_cap);
     return NSX_OK;
@@ -189,7 +201,10 @@ int nsx_lp_layout_make(int W, int64_t S_cap, int R_cap, int H, int n2, nsx_lp_la
     NSX_REQUIRE(H >= 1 && H <= 32, "nsx_lp_layout_make: H=%d not in [1,32]", H);
     NSX_REQUIRE(n2 >= 2 && n2 % 2 == 0 && n2 <= 2 * NSX_MAX_LEVELS, "nsx_lp_layout_make: n2=%d (2 x owned levels)", n2);
     memset(out, 0, sizeof(*out));
+    NSX_REQUIRE(W * (n2 / 2) <= NSX_MAX_LEVELS, "nsx_lp_layout_make: %d ranks x %d levels exceed %d levels", W, n2 / 2,
+                NSX_MAX_LEVELS);
     out->W = W; out->R_cap = R_cap; out->H = H; out->n2 = n2; out->S_cap = S_cap;
+    for (int i = 0; i < W * (n2 / 2); ++i) out->level_of[i] = i;
     int64_t off = 0;
     auto take = [&](int64_t bytes) { const int64_t at = off; off += lp_up256(bytes); return at; };
     out->f_count = take(8);
@@ -266,6 +281,7 @@ int nsx_lp_fwd_unpack(const nsx_lp_layout* lay, const uint8_t* recv, int64_t S, 
                 (long long)lay->S_cap);
     if (S == 0) return NSX_OK;
     NSX_REQUIRE(recv && feats, "nsx_lp_fwd_unpack: NULL argument");
+    if (int rc = lp_check_levels(lay, "nsx_lp_fwd_unpack")) return rc;
     hipLaunchKernelGGL(lp_fwd_unpack_kernel, dim3(lp_blocks(S * lay->W * (lay->n2 / 2))), dim3(256), 0, (hipStream_t)stream,
                        recv, S, n_device, reinterpret_cast<uint32_t*>(feats), *lay);
     NSX_LAUNCH_CHECK("nsx_lp_fwd_unpack");
@@ -278,6 +294,7 @@ int nsx_lp_bwd_pack(const nsx_lp_layout* lay, const float* dout, const float* pn
     NSX_REQUIRE(send && (S == 0 || (dout && pn && slot)), "nsx_lp_bwd_pack: NULL argument");
     NSX_REQUIRE(S >= 0 && S <= lay->S_cap, "nsx_lp_bwd_pack: S=%lld beyond the capacity %lld", (long long)S,
                 (long long)lay->S_cap);
+    if (int rc = lp_check_levels(lay, "nsx_lp_bwd_pack")) return rc;
     hipLaunchKernelGGL(lp_bwd_pack_kernel, dim3(lp_blocks(S * lay->W * (lay->n2 / 2) + lay->W)), dim3(256), 0,
                        (hipStream_t)stream, dout, pn, slot, S, n_device, send, *lay);
     NSX_LAUNCH_CHECK("nsx_lp_bwd_pack");

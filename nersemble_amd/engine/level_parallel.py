@@ -65,6 +65,39 @@ def sub_geometry(g: GridGeom, first_level: int, n_levels: int) -> GridGeom:
     return s
 
 
+def level_assignment(n_levels: int, world_size: int, balanced: bool = True) -> List[List[int]]:
+    """Which levels every rank owns.  ``balanced`` (the default): the levels are dealt to the ranks in snake order -- 0 .. W - 1
+    forward, W .. 2 W - 1 backward, ... -- so that at W = 8 rank r holds levels r and 15 - r.  A level's cost grows with its
+    resolution: the coarse levels' samples share cells (their gathers hit L2, their gradient atomics merge), the finest
+    levels' do not -- measured at 8 ranks with contiguous pairs: forward 1.11 ms (levels 0, 1) against 2.20 (levels 14, 15),
+    backward 2.34 against 4.39 over the benchmark window (profiles/r06_contiguous_levels/) -- and the step waits for the
+    slowest rank.  The snake pairs the cheapest level with the dearest.  ``balanced=False``: contiguous blocks (round 5)."""
+    n_own = n_levels // world_size
+    if not balanced:
+        return [list(range(r * n_own, (r + 1) * n_own)) for r in range(world_size)]
+    own = [[] for _ in range(world_size)]
+    for i in range(n_own):
+        order = range(world_size) if i % 2 == 0 else range(world_size - 1, -1, -1)
+        for k, r in enumerate(order):
+            own[r].append(i * world_size + k)
+    return [sorted(v) for v in own]
+
+
+def sub_geometry_levels(g: GridGeom, levels: List[int]) -> GridGeom:
+    """The geometry of the given levels as a grid of its own, their entries laid out one level after the other from 0: the
+    unchanged kernels run on a rank's COMPACT tables / gradient planes / optimizer state."""
+    s = GridGeom()
+    s.n_levels, s.log2_hashmap_size = len(levels), g.log2_hashmap_size
+    s.base_resolution, s.per_level_scale = g.base_resolution, g.per_level_scale
+    at = 0
+    for i, l in enumerate(levels):
+        s.scale[i], s.res[i], s.size[i], s.hashed[i] = g.scale[l], g.res[l], g.size[l], g.hashed[l]
+        s.offset[i] = at
+        at += int(g.offset[l + 1]) - int(g.offset[l])
+    s.offset[len(levels)] = at
+    return s
+
+
 def _as(t: torch.Tensor, dtype) -> torch.Tensor:
     """``t.detach().to(dtype).contiguous()`` without the three dispatches when there is nothing to do."""
     if t.dtype == dtype and t.is_contiguous() and not t.requires_grad:
@@ -153,7 +186,8 @@ class LevelParallel:
     feature columns of the levels this rank does not own are then copies of its own, so the numbers it trains on are not the
     model's."""
 
-    def __init__(self, he: HashEnsemble, world_size: int, rank: int, group=None, emulate: bool = False, ops=None):
+    def __init__(self, he: HashEnsemble, world_size: int, rank: int, group=None, emulate: bool = False, ops=None,
+                 balanced: bool = True):
         L = int(he.geom.n_levels)
         if world_size < 2 or L % world_size != 0:
             raise ValueError(f"level-parallel tables need a world size that divides the {L} levels (got {world_size})")
@@ -161,13 +195,18 @@ class LevelParallel:
         self.emulate = bool(emulate)
         self.ops = ops or NativeLPOps()
         self.n_own = L // self.world_size
-        self.first_level = self.rank * self.n_own
-        self.geom = sub_geometry(he.geom, self.first_level, self.n_own)
-        self.e0 = int(he.geom.offset[self.first_level])
-        self.e1 = int(he.geom.offset[self.first_level + self.n_own])
-        self.n_entries = self.e1 - self.e0
-        self.entry_ranges = [(int(he.geom.offset[r * self.n_own]), int(he.geom.offset[(r + 1) * self.n_own]))
-                             for r in range(self.world_size)]
+        # who owns which levels (round 6: balanced -- the cheapest level with the dearest; see level_assignment), and where a
+        # rank's levels sit in the full [entry][f][h] tables: one entry range per level.  The rank's CURRENT values of those
+        # entries -- fp16 working tables, fp32 master -- live in compact buffers of their own (the levels one after the
+        # other); the full-size tensors of the HashEnsemble are stale while the mode lasts (``gather_entry_ranges``).
+        self.levels_of = level_assignment(L, self.world_size, balanced)
+        self.levels = self.levels_of[self.rank]
+        self.level_of_flat = [l for lv in self.levels_of for l in lv]
+        self.geom = sub_geometry_levels(he.geom, self.levels)
+        self.ranges_of = [[(int(he.geom.offset[l]), int(he.geom.offset[l + 1])) for l in lv] for lv in self.levels_of]
+        self.ranges = self.ranges_of[self.rank]
+        self.n_entries = sum(b - a for a, b in self.ranges)
+        self.f16 = self.master = None    # compact [n_entries][2][Hp]: made by ``pull`` (the optimizer that owns the mode)
         # sizes travel host-to-host (a device collective would make the host wait for the queue): a gloo group beside RCCL
         backend = dist.get_backend(group)
         self._a2a_native = backend == "nccl"
@@ -227,8 +266,14 @@ class LevelParallel:
         if sum(rws) > MAX_ADAM_SLOTS:
             raise RuntimeError(f"level-parallel HashEnsemble: {sum(rws)} code rows in the job's batch (limit {MAX_ADAM_SLOTS}: "
                                f"NSX_MAX_ADAM_SLOTS gradient planes per optimizer pass)")
-        lay = self.ops.layout(W, max(1, max(sizes)), max(rws), self.he.n_hash_encodings, 2 * self.n_own)
+        lay = self._layout(max(1, max(sizes)), max(rws))
         return Exchange(lay, sizes, rws, self.rank)
+
+    def _layout(self, S_cap: int, R_cap: int):
+        lay = self.ops.layout(self.world_size, S_cap, R_cap, self.he.n_hash_encodings, 2 * self.n_own)
+        for i, l in enumerate(self.level_of_flat):
+            lay.level_of[i] = l
+        return lay
 
     collective_timeout_s = 120.0
 
@@ -283,11 +328,27 @@ class LevelParallel:
             self.shared_inputs = old
 
     # ---- the rank's slice ---------------------------------------------------------------------------------------------
+    def take_local(self, full: torch.Tensor) -> torch.Tensor:
+        """The entries of this rank's levels out of a full ``[entries, ...]`` tensor, one level after the other (a copy)."""
+        return torch.cat([full[a:b] for a, b in self.ranges], dim=0).contiguous()
+
+    @torch.no_grad()
+    def pull(self) -> None:
+        """(Re)build the compact working tables and master from the HashEnsemble's full-size tensors (entering the mode,
+        loading a checkpoint)."""
+        self.he.wait_tables()
+        self.f16 = self.take_local(self.he.half_tables())
+        self.master = self.take_local(self.he.tables.data)
+
     def slice_f16(self) -> torch.Tensor:
-        return self.he.half_tables()[self.e0:self.e1]
+        if self.f16 is None:
+            self.pull()
+        return self.f16
 
     def slice_master(self) -> torch.Tensor:
-        return self.he.tables.data[self.e0:self.e1]
+        if self.master is None:
+            self.pull()
+        return self.master
 
     @staticmethod
     def _bytes(n: int, dev) -> torch.Tensor:
@@ -320,7 +381,7 @@ class LevelParallel:
         ops = self.ops
         self.stats["fwd_calls"] += 1
         if self.shared_inputs:
-            lay = ops.layout(W, max(1, S), 1, H, n2)
+            lay = self._layout(max(1, S), 1)
             cols = self._bytes(lay.feat_bytes, dev)
             if S:
                 ops.shared_columns(x, S, tables, H, self.geom, code, slot, window, cols)
@@ -460,17 +521,20 @@ class LevelParallel:
 
     # ---- the whole table on every rank again (evaluation, checkpoints, leaving the mode) -----------------------------------
     @torch.no_grad()
-    def gather_entry_ranges(self, full: torch.Tensor, mine: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """``full`` [entries, 2, Hp]: every rank's owned entry range is made current everywhere (``mine``: this rank's
-        range if it does not live in ``full`` already).  Collective; the ranges differ in size, so each one is broadcast by
-        its owner.  (An emulated rank has nobody to hear from: its own range is all it can make current.)"""
-        for r, (a, b) in enumerate(self.entry_ranges):
-            piece = full[a:b]
-            if r == self.rank and mine is not None:
-                piece.copy_(mine)
-            if self.emulate:
-                continue
-            dist.broadcast(piece, src=dist.get_global_rank(self.group, r) if self.group is not None else r, group=self.group)
+    def gather_entry_ranges(self, full: torch.Tensor, mine: torch.Tensor) -> torch.Tensor:
+        """``full`` [entries, 2, Hp] made current everywhere: every rank contributes the entries of ITS levels from its
+        compact tensor ``mine`` [own entries, 2, Hp].  Collective; the levels differ in size, so each one is broadcast by its
+        owner.  (An emulated rank has nobody to hear from: its own levels are all it can make current.)"""
+        at = 0
+        for a, b in self.ranges:
+            full[a:b].copy_(mine[at:at + (b - a)])
+            at += b - a
+        if self.emulate:
+            return full
+        for r, ranges in enumerate(self.ranges_of):
+            for a, b in ranges:
+                dist.broadcast(full[a:b], src=dist.get_global_rank(self.group, r) if self.group is not None else r,
+                               group=self.group)
         return full
 
 
@@ -518,18 +582,18 @@ class LevelParallelTableAdam(torch.optim.Optimizer):
         hash_ensemble.level_parallel = self.lp
         hash_ensemble.grad_sink = None                       # (the planes of LevelParallel take the table gradient)
         p = hash_ensemble.tables
-        a, b = self.lp.e0, self.lp.e1
-        shape = (b - a,) + tuple(p.shape[1:])
-        self.exp_avg = torch.zeros(shape, dtype=torch.float32, device=p.device)
-        self.exp_avg_sq = torch.zeros(shape, dtype=torch.float32, device=p.device)
+        shape = (self.lp.n_entries,) + tuple(p.shape[1:])
         if exp_avg is not None:
-            self.exp_avg.copy_(exp_avg[a:b])
-            self.exp_avg_sq.copy_(exp_avg_sq[a:b])
+            self.exp_avg, self.exp_avg_sq = self.lp.take_local(exp_avg), self.lp.take_local(exp_avg_sq)
+        else:
+            self.exp_avg = torch.zeros(shape, dtype=torch.float32, device=p.device)
+            self.exp_avg_sq = torch.zeros(shape, dtype=torch.float32, device=p.device)
         self._step = int(step)
         self.consume_density_limit = 0.5
         self.timing = False
         self._events = []
         hash_ensemble.half_tables()                          # the working copy exists and is current when the mode starts
+        self.lp.pull()                                       # ... and this rank's levels move into their compact tensors
 
     # ---- the trainer's two phases ---------------------------------------------------------------------------------------
     reduced_nonfinite = None        # set by the trainer: the ranks' flags summed in the small gradients' bucket
@@ -647,7 +711,7 @@ class LevelParallelTableAdam(torch.optim.Optimizer):
                 total += open_ev.elapsed_time(e)
                 open_ev = None
         n_adam = max(1, sum(1 for w, _ in self._events if w == "adam_begin"))
-        out = {"exchange": "level_parallel", "world_size": self.world_size, "levels_per_rank": lp.n_own,
+        out = {"exchange": "level_parallel", "world_size": self.world_size, "levels_per_rank": lp.n_own, "levels": list(lp.levels),
                "owned_entries": lp.n_entries, "steps": n, "bytes_per_rank": st["bytes_in"] / n,
                "samples_fwd_per_step": st["samples_fwd"] / n, "samples_bwd_per_step": st["samples_bwd"] / n,
                "fwd_exchanges_per_step": st["fwd_calls"] / n, "shard_adam_ms": total / n_adam, "gradient_planes": lp.planes,
@@ -670,8 +734,8 @@ class LevelParallelTableAdam(torch.optim.Optimizer):
         """The full fp32 master AND the full fp16 working tables on every rank again (collective)."""
         he = self.he
         he.wait_tables()
-        self.lp.gather_entry_ranges(he.tables.data)
-        self.lp.gather_entry_ranges(he.half_tables())
+        self.lp.gather_entry_ranges(he.tables.data, self.lp.slice_master())
+        self.lp.gather_entry_ranges(he.half_tables(), self.lp.slice_f16())
         he.mark_half_synced()
 
     def _gather_moment(self, mine: torch.Tensor) -> torch.Tensor:
@@ -690,10 +754,10 @@ class LevelParallelTableAdam(torch.optim.Optimizer):
         self.he.wait_tables()
         self._step = int(state["step"])
         self.param_groups[0]["lr"] = float(state.get("lr", self.param_groups[0]["lr"]))
-        a, b = self.lp.e0, self.lp.e1
         for key, dst in (("exp_avg", self.exp_avg), ("exp_avg_sq", self.exp_avg_sq)):
             dst.zero_()
             if state.get(key) is not None:
-                dst.copy_(self.he.from_tcnn_layout(state[key])[a:b])
+                dst.copy_(self.lp.take_local(self.he.from_tcnn_layout(state[key])))
         self.he._f16_version = None
         self.he.half_tables()
+        self.lp.pull()                            # (the model parameters were loaded into the full-size tensors)

@@ -569,14 +569,14 @@ class _TorchLPOps:
     gradient planes -- runs over gloo.  The two per-source-rank KERNELS are stand-ins with a closed form the test can
     recompute from the ranks' inputs:
 
-        feature[s][2 i + f]  = fp16( x[s][0] * (l + 1) + code[slot[s]][0] / 2 + f ),  l = first owned level + i
+        feature[s][2 i + f]  = fp16( x[s][0] * (l + 1) + code[slot[s]][0] / 2 + f ),  l = the owner's i-th level
         dx partial[s][d]     = (d + 1) * (owner + 1) * sum_c dz[s][c]
         dcode partial[r][h]  = (h + 1) * sum_{s in row r} sum_c dz[s][c]
         G[plane of (j, r)][0][0] += sum_{s in row r} sum_c dz[s][c]
     """
 
-    def __init__(self, owner_rank, first_level):
-        self.owner, self.first_level = owner_rank, first_level
+    def __init__(self, owner_rank, levels):
+        self.owner, self.levels = owner_rank, list(levels)
 
     @staticmethod
     def layout(W, S_cap, R_cap, H, n2):
@@ -624,20 +624,23 @@ class _TorchLPOps:
             out = self._f16(send[j * lay.feat_bytes:(j + 1) * lay.feat_bytes], 0, n * lay.n2).view(n, n_own, 2)
             for i in range(n_own):
                 for f in range(2):
-                    out[:, i, f] = (x[:, 0] * (self.first_level + i + 1) + codes[sl, 0] / 2 + f).half()
+                    out[:, i, f] = (x[:, 0] * (self.levels[i] + 1) + codes[sl, 0] / 2 + f).half()
 
     def fwd_unpack(self, lay, recv, S, n_dev, feats):
-        n = self._count(S, n_dev)
+        n, n_own = self._count(S, n_dev), lay.n2 // 2
         for j in range(lay.W):
-            blk = recv[j * lay.feat_bytes:(j + 1) * lay.feat_bytes]
-            feats[:n, j * lay.n2:(j + 1) * lay.n2] = self._f16(blk, 0, n * lay.n2).view(n, lay.n2)
+            blk = self._f16(recv[j * lay.feat_bytes:(j + 1) * lay.feat_bytes], 0, n * lay.n2).view(n, n_own, 2)
+            for i in range(n_own):
+                l = lay.level_of[j * n_own + i]              # where owner j's i-th level sits in the feature row
+                feats[:n, 2 * l:2 * l + 2] = blk[:, i]
 
     def bwd_pack(self, lay, dout, pn, slot, S, n_dev, send):
         n = self._count(S, n_dev)
         for j in range(lay.W):
             blk = send[j * lay.bwd_bytes:(j + 1) * lay.bwd_bytes]
             blk[lay.b_count:lay.b_count + 8].view(torch.int64)[0] = n
-            self._f16(blk, lay.b_dz, n * lay.n2).view(n, lay.n2).copy_(dout[:n, j * lay.n2:(j + 1) * lay.n2].half())
+            cols = [c for i in range(lay.n2 // 2) for c in (2 * lay.level_of[j * (lay.n2 // 2) + i], 2 * lay.level_of[j * (lay.n2 // 2) + i] + 1)]
+            self._f16(blk, lay.b_dz, n * lay.n2).view(n, lay.n2).copy_(dout[:n][:, cols].half())
             self._f32(blk, lay.b_pn, n * 3).copy_(pn[:n].reshape(-1))
             self._i32(blk, lay.b_slot, n).copy_(slot[:n])
 
@@ -676,7 +679,7 @@ class _TorchLPOps:
         out = self._f16(cols, 0, S * 2 * n_own).view(S, n_own, 2)
         for i in range(n_own):
             for f in range(2):
-                out[:, i, f] = (x[:, 0] * (self.first_level + i + 1) + code[slot.long(), 0] / 2 + f).half()
+                out[:, i, f] = (x[:, 0] * (self.levels[i] + 1) + code[slot.long(), 0] / 2 + f).half()
 
 
 def _lp_rank_inputs(rank, world, H, L):
@@ -699,24 +702,31 @@ def _lp_plumbing_worker(rank, world, port, out_dir):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from types import SimpleNamespace
     from nersemble_amd import _lib
-    from nersemble_amd.engine.level_parallel import LevelParallel, sub_geometry
+    from nersemble_amd.engine.level_parallel import LevelParallel, level_assignment, sub_geometry_levels
     L, H = (8 if world == 2 else 2 * world), 4
     n_own = L // world
     geom = _lib.grid_geometry(n_levels=L, per_level_scale=1.3, base_resolution=4, log2_hashmap_size=9)
     f16 = torch.zeros((geom.total_entries, 2, H), dtype=torch.float16)
     he = SimpleNamespace(geom=geom, n_hash_encodings=H, wait_tables=lambda: None, half_tables=lambda: f16,
                          tables=SimpleNamespace(data=f16.float()))
-    lp = LevelParallel(he, world, rank, ops=_TorchLPOps(rank, rank * n_own))
-    ok = lp.n_own == n_own and lp.first_level == n_own * rank and lp.e0 == int(geom.offset[n_own * rank])
-    ok &= all(lp.entry_ranges[r][1] == lp.entry_ranges[r + 1][0] for r in range(world - 1))
-    ok &= lp.entry_ranges[-1][1] == geom.total_entries
-    # sub-geometry: the owned levels, offsets re-based to the range's first entry
-    sg = sub_geometry(geom, n_own * rank, n_own)
-    for i in range(n_own):
-        l = n_own * rank + i
+    own = level_assignment(L, world)
+    lp = LevelParallel(he, world, rank, ops=_TorchLPOps(rank, own[rank]))
+    # the balanced assignment: a partition of the levels, the cheapest with the dearest (rank r: levels r and L - 1 - r at two
+    # levels per rank); the contiguous one of round 5 is still there
+    ok = sorted(l for lv in own for l in lv) == list(range(L)) and all(len(lv) == n_own for lv in own)
+    ok &= lp.levels == own[rank] and lp.n_own == n_own
+    if n_own == 2:
+        ok &= own[rank] == sorted([rank, L - 1 - rank])
+    ok &= level_assignment(L, world, balanced=False)[rank] == list(range(rank * n_own, (rank + 1) * n_own))
+    ok &= lp.ranges == [(int(geom.offset[l]), int(geom.offset[l + 1])) for l in own[rank]]
+    # sub-geometry: the owned levels, one after the other from entry 0
+    sg = sub_geometry_levels(geom, own[rank])
+    at = 0
+    for i, l in enumerate(own[rank]):
         ok &= sg.scale[i] == geom.scale[l] and sg.res[i] == geom.res[l] and sg.size[i] == geom.size[l]
-        ok &= sg.hashed[i] == geom.hashed[l] and sg.offset[i] == geom.offset[l] - geom.offset[n_own * rank]
-    ok &= sg.total_entries == lp.n_entries
+        ok &= sg.hashed[i] == geom.hashed[l] and sg.offset[i] == at
+        at += int(geom.offset[l + 1]) - int(geom.offset[l])
+    ok &= sg.total_entries == lp.n_entries == at
     everyone = [_lp_rank_inputs(r, world, H, L) for r in range(world)]
     S, rows, x, slot, code, kept, dout = everyone[rank]
     window = torch.ones((H,))
@@ -738,7 +748,7 @@ def _lp_plumbing_worker(rank, world, port, out_dir):
         # ---- backward under a device-side count: partials summed over the owners, planes in (source rank, row) order
         n_dev = torch.tensor([kept], dtype=torch.int64)
         dx, dcode = lp.backward(x, slot, dout, n_dev=n_dev)
-        colsum = dout[:kept].view(kept, world, 2 * n_own).sum(dim=2)                  # per owner
+        colsum = torch.stack([sum(dout[:kept, 2 * l] + dout[:kept, 2 * l + 1] for l in own[o]) for o in range(world)], dim=1)
         want_dx = torch.stack([(d + 1) * (colsum * torch.arange(1, world + 1)[None, :]).sum(dim=1) for d in range(3)], dim=1)
         ok &= torch.allclose(dx[:kept], want_dx, rtol=1e-5, atol=1e-4)
         per_row = torch.zeros((rows,)).index_add_(0, slot[:kept].long(), dout[:kept].sum(dim=1))
@@ -746,7 +756,7 @@ def _lp_plumbing_worker(rank, world, port, out_dir):
         G = lp.G[:lp.planes * lp.n_entries * 2].view(lp.planes, lp.n_entries, 2)
         plane = 0
         for r, (Sr, rr, _, slr, _, kr, dr) in enumerate(everyone):
-            mine = dr[:kr, rank * 2 * n_own:(rank + 1) * 2 * n_own].sum(dim=1)
+            mine = sum(dr[:kr, 2 * l] + dr[:kr, 2 * l + 1] for l in own[rank])
             wantG = torch.zeros((rr,)).index_add_(0, slr[:kr].long(), mine)
             ok &= torch.allclose(G[plane:plane + rr, 0, 0], wantG, rtol=1e-5, atol=1e-4)
             plane += rr
@@ -776,11 +786,12 @@ def _lp_plumbing_worker(rank, world, port, out_dir):
         lp.backward(x, slot, dout, n_dev=torch.tensor([kept], dtype=torch.int64))
     G = lp.G[:lp.planes * lp.n_entries * 2].view(lp.planes, lp.n_entries, 2)
     ok &= float(G[:everyone[0][1], 0, 0].abs().sum()) == 0.0                        # rank 0's planes: nothing arrived
-    # every rank's entry range becomes current everywhere
-    full = torch.full((geom.total_entries, 2, 4), float(rank + 1))
-    lp.gather_entry_ranges(full)
-    for r, (a, b) in enumerate(lp.entry_ranges):
-        ok &= bool((full[a:b] == r + 1).all())
+    # every rank's levels become current everywhere, from the owners' compact tensors
+    full = torch.zeros((geom.total_entries, 2, 4))
+    lp.gather_entry_ranges(full, torch.full((lp.n_entries, 2, 4), float(rank + 1)))
+    for r in range(world):
+        for a, b in lp.ranges_of[r]:
+            ok &= bool((full[a:b] == r + 1).all())
     ok &= lp.stats["bytes_in"] > 0
     torch.save({"ok": bool(ok)}, os.path.join(out_dir, f"lp{rank}.pt"))
     dist.barrier()

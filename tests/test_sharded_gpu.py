@@ -338,13 +338,14 @@ def _level_worker(rank, world, port, out_dir, workload="p030_h16", per=256):
     assert model._native is not None                            # the step ran through the native drivers, split at the exchange
     grads = {n: p.grad.detach().float().cpu() for n, p in model.named_parameters() if "tables" not in n and p.grad is not None}
     lp = opt.lp
-    own = (lp.e0, lp.e1)
+    own = list(lp.ranges)                                        # one entry range per owned level (balanced assignment)
     stale_before = model.field.hash_ensemble.half_tables().detach().cpu().clone()
+    local_f16 = lp.slice_f16().detach().cpu().clone()            # this rank's CURRENT values: compact, level after level
     trainer.consolidate()
     res = {"loss": loss.item(), "terms": {k: v.item() for k, v in loss_dict.items()}, "grads": grads,
            "tables": model.field.hash_ensemble.tables.detach().cpu(), "f16": model.field.hash_ensemble.half_tables().detach().cpu(),
            "small": torch.cat([p.detach().reshape(-1).cpu() for n, p in model.named_parameters() if "tables" not in n]),
-           "comm": comm, "own": own, "stale_before": stale_before}
+           "comm": comm, "own": own, "stale_before": stale_before, "local_f16": local_f16}
     # two more steps on rank-local rays (weak scaling): the replicas of everything that IS replicated stay identical
     model.global_loss_normalisers = None
     losses = []
@@ -395,9 +396,12 @@ def test_level_parallel_ranks_equal_one_process_on_the_union_batch(cuda, tmp_pat
     # after consolidation both ranks hold the whole table again, identical; before it a rank held only ITS levels current
     assert torch.equal(a["tables"], b["tables"]) and torch.equal(a["small"], b["small"]) and torch.equal(a["f16"], b["f16"])
     assert torch.equal(a["tables"].half(), a["f16"])
-    (a0, a1), (b0, b1) = a["own"], b["own"]
-    assert a0 == 0 and a1 == b0 and b1 == tables.shape[0]
-    assert torch.equal(a["stale_before"][a0:a1], a["f16"][a0:a1]) and not torch.equal(a["stale_before"][b0:b1], a["f16"][b0:b1])
+    _ranges_partition_the_table([a["own"], b["own"]], tables.shape[0])
+    for r in (a, b):
+        # before consolidation a rank's current values live in its compact tensors (the full-size tables are stale); after
+        # it every rank holds them in place
+        assert not torch.equal(r["stale_before"], r["f16"])
+        assert torch.equal(torch.cat([r["f16"][lo:hi] for lo, hi in r["own"]]), r["local_f16"])
     assert np.isclose((a["loss"] + b["loss"]) / 2, loss.item(), rtol=2e-4), (a["loss"], b["loss"], loss.item())
     for k, v in loss_dict.items():
         assert np.isclose((a["terms"][k] + b["terms"][k]) / 2, v.item(), rtol=2e-3, atol=1e-9), k
@@ -455,8 +459,9 @@ def test_four_level_parallel_ranks_with_32_grids_step_through_the_matrix_core_pa
              if "tables" not in n and p.grad is not None}
     moved = (tables - init_tables).abs() > 1e-4
     assert moved.float().mean().item() > 1e-3 and moved[:, :, 16:].any()
-    bounds = [r["own"] for r in rs]
-    assert bounds[0][0] == 0 and bounds[-1][1] == tables.shape[0] and all(bounds[i][1] == bounds[i + 1][0] for i in range(3))
+    bounds = [rng for r in rs for rng in r["own"]]
+    _ranges_partition_the_table([r["own"] for r in rs], tables.shape[0])
+    assert [r["comm"]["levels"] for r in rs] == [[0, 7, 8, 15], [1, 6, 9, 14], [2, 5, 10, 13], [3, 4, 11, 12]]
     for r in rs:
         c = r["comm"]
         assert c["exchange"] == "level_parallel" and c["levels_per_rank"] == 4
@@ -512,8 +517,9 @@ def test_eight_level_parallel_ranks_on_the_p124_model_equal_one_process(cuda, tm
              if "tables" not in n and p.grad is not None}
     moved = (tables - init_tables).abs() > 1e-4
     assert moved.float().mean().item() > 1e-3
-    bounds = [r["own"] for r in rs]
-    assert bounds[0][0] == 0 and bounds[-1][1] == tables.shape[0] and all(bounds[i][1] == bounds[i + 1][0] for i in range(7))
+    bounds = [rng for r in rs for rng in r["own"]]
+    _ranges_partition_the_table([r["own"] for r in rs], tables.shape[0])
+    assert [r["comm"]["levels"] for r in rs] == [[k, 15 - k] for k in range(8)]       # the cheapest level with the dearest
     for r in rs:
         c = r["comm"]
         assert c["exchange"] == "level_parallel" and c["levels_per_rank"] == 2 and c["gradient_planes"] == 192
@@ -535,6 +541,12 @@ def test_eight_level_parallel_ranks_on_the_p124_model_equal_one_process(cuda, tm
         for r in rs:
             err = (r["grads"][name] - g_ref).abs().max().item()
             assert err <= 2e-3 * sc + 1e-9, (name, err, sc)
+
+
+def _ranges_partition_the_table(owns, total):
+    """The ranks' entry ranges (one per owned level) cover [0, total) exactly once."""
+    flat = sorted(rng for own in owns for rng in own)
+    assert flat[0][0] == 0 and flat[-1][1] == total and all(flat[i][1] == flat[i + 1][0] for i in range(len(flat) - 1))
 
 
 def _differences_are_sign_flips(tables, ref, init, lr):
@@ -581,8 +593,11 @@ def test_emulated_level_parallel_rank_through_rccl(cuda, single_rank_group):
     feats = lp.features(x, code, slot, window)
     n2 = 2 * lp.n_own
     assert feats.shape == (B, W * n2)
+    assert lp.levels_of == [[0, 5], [1, 4], [2, 3]] and lp.levels == [1, 4]          # balanced: cheapest with dearest
+    cols = lambda lv: [c for l in lv for c in (2 * l, 2 * l + 1)]
     for j in range(W):
-        assert torch.equal(feats[:, j * n2:(j + 1) * n2], full[:, r * n2:(r + 1) * n2])
+        # replica j's block sits where rank j's levels sit in the feature row and holds THIS rank's levels' columns
+        assert torch.equal(feats[:, cols(lp.levels_of[j])], full[:, cols(lp.levels)])
     assert lp.stats["collectives"] == 2 and lp.stats["host_exchanges"] == 1
     ex = lp.last_exchange
     assert ex.sizes == [B] * W and ex.rows == [T] * W and ex.n_planes == W * T
@@ -590,7 +605,10 @@ def test_emulated_level_parallel_rank_through_rccl(cuda, single_rank_group):
     block = (torch.randn((B, n2), device=cuda, generator=g) * 3).half().float()
     n_dev = torch.tensor([kept], dtype=torch.int64, device=cuda)
     lp.begin_step()
-    dx, dcode = lp.backward(x, slot, block.repeat(1, W), n_dev=n_dev)
+    dout = torch.empty((B, W * n2), device=cuda)
+    for j in range(W):
+        dout[:, cols(lp.levels_of[j])] = block                    # every owner receives the same column block
+    dx, dcode = lp.backward(x, slot, dout, n_dev=n_dev)
     assert lp.stats["collectives"] == 4
     n_e = lp.n_entries
     G_d = torch.zeros((T, n_e, 2), device=cuda)
@@ -610,7 +628,7 @@ def test_emulated_level_parallel_rank_through_rccl(cuda, single_rank_group):
     # rows beyond the device-side count were neither packed nor unpacked
     dx2 = torch.full((B, 3), 7.0, device=cuda)
     lp.begin_step()
-    lp.backward(x, slot, block.repeat(1, W), n_dev=n_dev, dx_out=dx2)
+    lp.backward(x, slot, dout, n_dev=n_dev, dx_out=dx2)
     assert bool((dx2[kept:] == 7.0).all()) and torch.allclose(dx2[:kept], dx[:kept])
 
 
@@ -624,7 +642,7 @@ def test_emulated_rank_7_of_8_trains_through_the_native_step(cuda, single_rank_g
     trainer, data, _ = build_workload("p030_h32", device="cuda:0", small=True, n_rays=512, window_hash=OPEN_WINDOW,
                                       level_parallel_emulation=(8, 7))
     opt = trainer.optimizers[trainer.group_of_tables()]
-    assert isinstance(opt, LevelParallelTableAdam) and opt.lp.emulate and opt.lp.n_own == 2 and opt.lp.first_level == 14
+    assert isinstance(opt, LevelParallelTableAdam) and opt.lp.emulate and opt.lp.n_own == 2 and opt.lp.levels == [7, 8]
     trainer.train_iteration(0, *data.next_train(0))              # (step 0 refreshes the occupancy grid: one more exchange)
     assert opt.lp.stats["collectives"] == 5
     opt.comm_report()
