@@ -109,6 +109,34 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// accumulators -> two packed fp16 fragments (registers 0..7 | 8..15), no activation
+__device__ __forceinline__ void pack16(const f32x16& d, f16x8& lo, f16x8& hi) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { lo[j] = (half_t)d[j]; hi[j] = (half_t)d[8 + j]; }
+}
+// dZ = dA * relu'(a): accumulators masked by the sign of the (packed) activations they belong to
+__device__ __forceinline__ void mask_pack16(const f32x16& d, const f16x8& alo, const f16x8& ahi, f16x8& lo, f16x8& hi) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        lo[j] = ((float)alo[j] > 0.f) ? (half_t)d[j] : (half_t)0.f;
+        hi[j] = ((float)ahi[j] > 0.f) ? (half_t)d[8 + j] : (half_t)0.f;
+    }
+}
+
+// Round 6: no LDS transposes.  The weight gradients are products contracted over the SAMPLES of a tile,
+//   dW[o][i] += sum_s dZ[o][s] * H[i][s],
+// i.e. both MFMA operands are wanted with lane = neuron and the 8 k-elements = samples -- the transpose of what the chained
+// forward / backward hold (lane = sample, elements = neurons).  Rounds 1-5 wrote every dZ and H tile to a per-wave LDS tile
+// element by element (~190 ds_write_b16 per lane and tile, two wave barriers per product) and read it back transposed: 23-28
+// VALU instructions per MFMA at 6-9 % matrix-core duty.  But the transposed tiles are themselves MFMA results of the SAME
+// fragments with the operands swapped: the A fragment (lane = row, 8 k) and the B fragment (lane = column, 8 k) of a
+// 32x32x16 MFMA have the same register layout, so
+//   H^T [sample][neuron] = X^T [sample][k] * W^T [k][neuron]  =  mfma(a = x fragment, b = weight fragment)
+// comes out with lane = neuron and registers = the 16 samples acc_row(r, kb) -- which, packed, ARE the two K-step fragments
+// (samples acc_row(8 tt + j, kb)) of the weight-gradient product.  Any assignment of samples to k-slots is fine as long as both
+// operands use the same one, and every transposed tile here has this one.  The input tile is transposed by a product with
+// an identity fragment (exact: fp16 values times one).  ~2 x the MFMAs of a kernel whose matrix cores were idle, no LDS
+// traffic besides the weight fragments.
 template <int NH>
 __global__ __launch_bounds__(MLP_WAVES * kWave) void mlp_bwd_kernel(
     const half_t* __restrict__ W, MlpIO io, int64_t B, int n_out, int out_act, const half_t* __restrict__ dout,
@@ -120,9 +148,7 @@ __global__ __launch_bounds__(MLP_WAVES * kWave) void mlp_bwd_kernel(
     f16x8* frags = reinterpret_cast<f16x8*>(smem_raw);
     half_t* tbase = reinterpret_cast<half_t*>(smem_raw + (size_t)p.total * kWave * sizeof(f16x8));
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    half_t* Zt = tbase + (size_t)wave * 2 * MLP_W * TP;     // dZ^T tile  [64][TP]
-    half_t* Ht = Zt + MLP_W * TP;                           // H^T  tile  [64][TP]
-    stage_weights<NH>(W, tbase, frags, true);          // (the tile region doubles as the staging buffer: unused until the sync)
+    stage_weights<NH>(W, tbase, frags, true);          // (the region behind the fragments is the staging buffer)
     __syncthreads();
     const int n = lane & 31, kb = lane >> 5;
     const int fast = input_mode(io);
@@ -131,8 +157,13 @@ __global__ __launch_bounds__(MLP_WAVES * kWave) void mlp_bwd_kernel(
     f32x16 gWo[2], gWh[2][2], gW0[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) { gWo[i] = zero16(); gW0[i] = zero16(); gWh[i][0] = zero16(); gWh[i][1] = zero16(); }
+    // identity fragments: B[k-slot][n] = (input feature of the slot == n); K-step t holds features 16 t + 8 kb + j
+    f16x8 idn[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) idn[t][j] = (kmap_natural(t, kb, j) == n) ? (half_t)1.f : (half_t)0.f;
 
-    // (round 6: the next tile's input is requested while this tile's chain runs -- what the forward got in round 5)
     const int64_t tile_step = (int64_t)gridDim.x * MLP_WAVES;
     int64_t tile = (int64_t)blockIdx.x * MLP_WAVES + wave;
     f16x8 xn[2];
@@ -144,9 +175,12 @@ __global__ __launch_bounds__(MLP_WAVES * kWave) void mlp_bwd_kernel(
         const int64_t b_raw = tile * 32 + n;
         const bool valid = b_raw < B;
         const int64_t b = valid ? b_raw : B - 1;
+        // (the weight fragments are re-read from LDS where they are used: hoisted out of the tile loop they alone are 144
+        // registers, and the kernel spilled 104)
+        asm volatile("" ::: "memory");
         f16x8 x[2], h1[4], h2[4];
         x[0] = xn[0]; x[1] = xn[1];
-        if (tile + tile_step < n_tiles) {
+        if (tile + tile_step < n_tiles) {          // the next tile's input is in flight while this tile's chains run
             const int64_t bn = (tile + tile_step) * 32 + n;
             load_input(io, bn < B ? bn : B - 1, kb, fast, xn);
         }
@@ -154,9 +188,36 @@ __global__ __launch_bounds__(MLP_WAVES * kWave) void mlp_bwd_kernel(
 #pragma unroll
             for (int j = 0; j < 8; ++j) { x[0][j] = (half_t)0.f; x[1][j] = (half_t)0.f; }
         }
-        const f32x16 o = forward_tile<NH>(frags, p, lane, x, h1, h2);
-        // dZ_out (rows 0..15 live in regs 0..7)
-        f16x8 dzo;
+        // ---- forward, both orientations -------------------------------------------------------------------------------
+        const f32x16 o = forward_tile<NH>(frags, p, lane, x, h1, h2);          // lane = sample
+        f16x8 h1T[2][2], h2T[2][2];                                           // [neuron tile][K-step]: lane = neuron
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            f32x16 zT = zero16();
+#pragma unroll
+            for (int t = 0; t < 2; ++t) zT = mfma(x[t], frags[(p.w0 + mt * 2 + t) * kWave + lane], zT);
+            relu_pack(zT, h1T[mt][0], h1T[mt][1]);
+        }
+        if constexpr (NH == 1) {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                f32x16 zT = zero16();
+#pragma unroll
+                for (int t = 0; t < 4; ++t) zT = mfma(h1[t], frags[(p.wh + mt * 4 + t) * kWave + lane], zT);
+                relu_pack(zT, h2T[mt][0], h2T[mt][1]);
+            }
+        }
+        const f16x8* hl = (NH == 1) ? h2 : h1;
+        const f16x8 (*hlT)[2] = (NH == 1) ? h2T : h1T;
+        f16x8 xT[2];                                                          // lane = input feature
+        {
+            f32x16 xa = zero16();
+#pragma unroll
+            for (int t = 0; t < 2; ++t) xa = mfma(x[t], idn[t], xa);
+            pack16(xa, xT[0], xT[1]);
+        }
+        // ---- dZ_out, both orientations --------------------------------------------------------------------------------
+        f16x8 dzo;                                                            // lane = sample, rows 0..15 in regs 0..7
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
             const int m = acc_row(r, kb);
@@ -167,80 +228,72 @@ __global__ __launch_bounds__(MLP_WAVES * kWave) void mlp_bwd_kernel(
             }
             dzo[r] = (half_t)gv;
         }
-        const f16x8* hl = (NH == 1) ? h2 : h1;
-        // ---- dWo += dZo * Hl^T ----
-        f16x8 zero8;
+        f16x8 dzoT[2];                                                        // lane = output neuron n, 16 samples
+        {
+            f32x16 oT = zero16();
+            if (out_act == 1) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) zero8[j] = (half_t)0.f;
-        stage_T(Zt, 0, n, kb, dzo, zero8);
-        stage_T(Ht, 0, n, kb, hl[0], hl[1]);
-        stage_T(Ht, 1, n, kb, hl[2], hl[3]);
-        wave_lds_sync();
+                for (int t = 0; t < 4; ++t) oT = mfma(hl[t], frags[(p.wo + t) * kWave + lane], oT);
+            }
+            const int64_t s0 = tile * 32;
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const f16x8 a = read_T(Zt, n, t, kb);                       // rows = out neuron (lane&31)
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt) gWo[nt] = mfma(a, read_T(Ht, 32 * nt + n, t, kb), gWo[nt]);
+            for (int r = 0; r < 16; ++r) {
+                const int64_t bs = s0 + acc_row(r, kb);
+                float gv = 0.f;
+                if (n < n_out && bs < B) {
+                    gv = (float)dout[bs * dout_stride + n];
+                    if (out_act == 1) { const float y = sigmoidf_(oT[r]); gv *= y * (1.0f - y); }
+                }
+                if (r < 8) dzoT[0][r] = (half_t)gv; else dzoT[1][r - 8] = (half_t)gv;
+            }
         }
-        wave_lds_sync();
-        // ---- dHl = Wo^T dZo ; dZl = dHl * relu'(Hl) ----
-        f16x8 dz[4];
+        // ---- dWo += dZo * Hl^T ----------------------------------------------------------------------------------------
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) gWo[nt] = mfma(dzoT[tt], hlT[nt][tt], gWo[nt]);
+        // ---- dHl = Wo^T dZo ; dZl = dHl * relu'(Hl), both orientations --------------------------------------------------
+        f16x8 dz[4], dzT[2][2];
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
-            f32x16 d = mfma(frags[(p.woT + mt) * kWave + lane], dzo, zero16());
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                dz[2 * mt][j] = ((float)hl[2 * mt][j] > 0.f) ? (half_t)d[j] : (half_t)0.f;
-                dz[2 * mt + 1][j] = ((float)hl[2 * mt + 1][j] > 0.f) ? (half_t)d[8 + j] : (half_t)0.f;
-            }
+            const f16x8 wf = frags[(p.woT + mt) * kWave + lane];
+            const f32x16 d = mfma(wf, dzo, zero16());
+            mask_pack16(d, hl[2 * mt], hl[2 * mt + 1], dz[2 * mt], dz[2 * mt + 1]);
+            const f32x16 dT = mfma(dzo, wf, zero16());
+            mask_pack16(dT, hlT[mt][0], hlT[mt][1], dzT[mt][0], dzT[mt][1]);
         }
         if constexpr (NH == 1) {
             // ---- dWh += dZ2 * H1^T ----
-            stage_T(Zt, 0, n, kb, dz[0], dz[1]);
-            stage_T(Zt, 1, n, kb, dz[2], dz[3]);
-            stage_T(Ht, 0, n, kb, h1[0], h1[1]);
-            stage_T(Ht, 1, n, kb, h1[2], h1[3]);
-            wave_lds_sync();
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
+            for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt) {
-                    const f16x8 a = read_T(Zt, 32 * mt + n, t, kb);
+                for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                    for (int nt = 0; nt < 2; ++nt) gWh[mt][nt] = mfma(a, read_T(Ht, 32 * nt + n, t, kb), gWh[mt][nt]);
-                }
-            wave_lds_sync();
-            // ---- dH1 = Wh^T dZ2 ; dZ1 ----
-            f16x8 dz1[4];
+                    for (int nt = 0; nt < 2; ++nt) gWh[mt][nt] = mfma(dzT[mt][tt], h1T[nt][tt], gWh[mt][nt]);
+            // ---- dH1 = Wh^T dZ2 ; dZ1, both orientations ----
+            f16x8 dz1[4], dz1T[2][2];
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) {
-                f32x16 d = zero16();
+                f32x16 d = zero16(), dT = zero16();
 #pragma unroll
-                for (int t = 0; t < 4; ++t) d = mfma(frags[(p.whT + mt * 4 + t) * kWave + lane], dz[t], d);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    dz1[2 * mt][j] = ((float)h1[2 * mt][j] > 0.f) ? (half_t)d[j] : (half_t)0.f;
-                    dz1[2 * mt + 1][j] = ((float)h1[2 * mt + 1][j] > 0.f) ? (half_t)d[8 + j] : (half_t)0.f;
+                for (int t = 0; t < 4; ++t) {
+                    const f16x8 wf = frags[(p.whT + mt * 4 + t) * kWave + lane];
+                    d = mfma(wf, dz[t], d);
+                    dT = mfma(dz[t], wf, dT);
                 }
+                mask_pack16(d, h1[2 * mt], h1[2 * mt + 1], dz1[2 * mt], dz1[2 * mt + 1]);
+                mask_pack16(dT, h1T[mt][0], h1T[mt][1], dz1T[mt][0], dz1T[mt][1]);
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) dz[i] = dz1[i];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) { dzT[mt][0] = dz1T[mt][0]; dzT[mt][1] = dz1T[mt][1]; }
         }
-        // ---- dW0 += dZ1 * X^T  (X is in natural k order: write rows k directly) ----
-        stage_T(Zt, 0, n, kb, dz[0], dz[1]);
-        stage_T(Zt, 1, n, kb, dz[2], dz[3]);
+        // ---- dW0 += dZ1 * X^T ------------------------------------------------------------------------------------------
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) Ht[kmap_natural(t, kb, j) * TP + n] = x[t][j];
-        wave_lds_sync();
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const f16x8 bx = read_T(Ht, n, t, kb);                     // rows = input feature (lane&31)
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt) gW0[mt] = mfma(read_T(Zt, 32 * mt + n, t, kb), bx, gW0[mt]);
-        }
-        wave_lds_sync();
+            for (int mt = 0; mt < 2; ++mt) gW0[mt] = mfma(dzT[mt][tt], xT[tt], gW0[mt]);
         // ---- dX = W0^T dZ1 ----
         if (dA || dBsrc || dB32) {
             f32x16 d = zero16();
