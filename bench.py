@@ -136,7 +136,7 @@ def cpu_baseline(H: int, seconds_budget: float = 30.0):
                           "unit": "ray-samples/s (HashEnsemble forward + mlp_base, PyTorch on the host: oracle/torch_cpu.py)",
                           "threads": threads, "cores_available": cores, "sweep": sweep, "all_cores": all_cores,
                           "note": "`threads` = the intra-op thread count a 4096-sample calibration picked; `all_cores` = the "
-                                  "same encoder on every core (2^16 samples)"}}
+                                  "same encoder on every core (about 3 s of samples)"}}
 
 
 def compute_rooflines(prof, records, tags, kept, H: int, total_entries: int, side_stream: bool, pmc_state=None):

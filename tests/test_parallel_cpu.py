@@ -798,6 +798,18 @@ def _lp_plumbing_worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
+def test_level_assignment_pairs_the_cheapest_level_with_the_dearest():
+    """The balanced (snake) assignment of levels to ranks: a partition, equal counts, ascending within a rank; at two levels per
+    rank, rank r holds levels r and L - 1 - r."""
+    from nersemble_amd.engine.level_parallel import level_assignment
+    for L, W in ((16, 8), (16, 4), (16, 2), (16, 16), (8, 2), (6, 3)):
+        own = level_assignment(L, W)
+        assert sorted(l for lv in own for l in lv) == list(range(L)) and all(len(lv) == L // W and lv == sorted(lv) for lv in own)
+        assert level_assignment(L, W, balanced=False) == [list(range(r * (L // W), (r + 1) * (L // W))) for r in range(W)]
+    assert level_assignment(16, 8) == [[k, 15 - k] for k in range(8)]
+    assert level_assignment(16, 4) == [[0, 7, 8, 15], [1, 6, 9, 14], [2, 5, 10, 13], [3, 4, 11, 12]]
+
+
 @pytest.mark.parametrize("world", [2, 8])
 def test_level_parallel_exchange_plumbing(world, tmp_path):
     """The whole level-parallel exchange on CPU tensors over gloo with the library's own payload layout

@@ -661,6 +661,48 @@ def test_emulated_rank_7_of_8_trains_through_the_native_step(cuda, single_rank_g
     assert c["collectives_per_step"] == 4 and c["host_exchanges_per_step"] == 1 and c["gradient_planes"] == 192
 
 
+def test_a_trained_model_goes_on_as_a_frozen_emulated_rank(cuda, single_rank_group):
+    """``NeRSembleTrainer.become_emulated_level_parallel_rank`` (what ``bench.py --level-parallel-one-rank`` prices in steady
+    state): a single-GPU run continues as rank 3 of 8 with frozen parameters, the replicas' feature columns replaced by the
+    true ones (one full-geometry forward per pass).  The model then sees exactly what it saw before: the loss of a step on a
+    given batch is the loss the un-emulated model has on it, bit for bit, no parameter moves -- while the level-parallel
+    kernels, the 192 gradient planes and the four collectives of the emulated rank run."""
+    from nersemble_amd.engine.level_parallel import LevelParallelTableAdam
+    from nersemble_amd.workloads import build_workload
+
+    def run(emulated):
+        torch.manual_seed(0)
+        trainer, data, _ = build_workload("p030_h32", device="cuda:0", small=True, n_rays=512, window_hash=OPEN_WINDOW,
+                                          compact_first_grid=False)
+        _no_jitter(trainer)
+        for step in range(3):
+            trainer.train_iteration(step, *data.next_train(step))
+        trainer.flush_scheduler_step()
+        if emulated:
+            trainer.become_emulated_level_parallel_rank(8, 3)
+        else:
+            for o in trainer.optimizers.values():
+                for g in o.param_groups:
+                    g["lr"] = 0.0
+        before = torch.cat([p.detach().reshape(-1).float().cpu() for p in trainer.model.parameters()])
+        losses = []
+        for step in range(3, 6):
+            loss, _, metrics = trainer.train_iteration(step, *data.next_train(step))
+            losses.append((loss.item(), int(metrics["num_samples_per_batch"])))
+        trainer.flush_scheduler_step()
+        trainer.consolidate()
+        after = torch.cat([p.detach().reshape(-1).float().cpu() for p in trainer.model.parameters()])
+        return trainer, losses, before, after
+
+    t_e, l_e, b_e, a_e = run(True)
+    opt = t_e.optimizers[t_e.group_of_tables()]
+    assert isinstance(opt, LevelParallelTableAdam) and opt.lp.emulate and opt.lp.shadow_forward and opt.lp.levels == [3, 12]
+    assert opt.lp.stats["bwd_calls"] == 3 and opt.lp.planes == 8 * 24
+    _, l_s, b_s, a_s = run(False)
+    assert l_e == l_s, (l_e, l_s)                       # the same losses and kept-sample counts, bit for bit
+    assert torch.equal(b_e, a_e) and torch.equal(b_s, a_s) and torch.equal(b_e, b_s)
+
+
 def _empty_rank_worker(rank, world, port, out_dir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
