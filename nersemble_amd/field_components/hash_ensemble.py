@@ -313,6 +313,9 @@ class HashEnsemble(nn.Module):
             tc = torch.stack([state_dict.pop(k).reshape(self.geom.total_entries, -1) for k in keys])
             state_dict[prefix + "tables"] = self._permute_from_tcnn_cpu(tc.float().cpu()).to(tc.device)
             self._f16_version = None
+            if self.level_parallel is not None:
+                # (level-parallel run: the rank's compact copies of its levels are cut again from what is loaded)
+                self.level_parallel.f16 = self.level_parallel.master = None
 
     def _permute_to_tcnn_cpu(self, native: torch.Tensor) -> torch.Tensor:
         # host-side restatement of the permutation (used only for CPU state dicts): [e,f,h] -> [c,e,p*2+f]
