@@ -113,9 +113,9 @@ def time_encoder_sweep(H: int, geom, sizes=(1 << 16, 1 << 18, 1 << 20), budget_s
     all_cores = None
     if max_threads != best_t and time.time() - t_begin < 0.5 * budget_s:
         torch.set_num_threads(max_threads)
-        _time_once(1024, tables, params, geom, H, g)
-        probe = 1024 / max(_time_once(1024, tables, params, geom, H, g), 1e-6)   # (hundreds of threads can be 20x slower)
-        S_all = int(max(1024, min(1 << 16, probe * 3.0))) // 1024 * 1024           # ~3 s of work at the probed rate
+        _time_once(256, tables, params, geom, H, g)
+        probe = 256 / max(_time_once(256, tables, params, geom, H, g), 1e-6)      # (256 threads: 153 samples/s on one box)
+        S_all = int(max(256, min(1 << 16, probe * 3.0))) // 256 * 256              # ~3 s of work at the probed rate
         dt = _time_once(S_all, tables, params, geom, H, g)
         all_cores = {"threads": max_threads, "samples": S_all, "seconds": round(dt, 3), "samples_per_s": S_all / dt}
     time_encoder_sweep.all_cores = all_cores
