@@ -670,37 +670,40 @@ def test_a_trained_model_goes_on_as_a_frozen_emulated_rank(cuda, single_rank_gro
     from nersemble_amd.engine.level_parallel import LevelParallelTableAdam
     from nersemble_amd.workloads import build_workload
 
-    def run(emulated):
-        torch.manual_seed(0)
-        trainer, data, _ = build_workload("p030_h32", device="cuda:0", small=True, n_rays=512, window_hash=OPEN_WINDOW,
-                                          compact_first_grid=False)
-        _no_jitter(trainer)
-        for step in range(3):
-            trainer.train_iteration(step, *data.next_train(step))
-        trainer.flush_scheduler_step()
-        if emulated:
-            trainer.become_emulated_level_parallel_rank(8, 3)
-        else:
-            for o in trainer.optimizers.values():
-                for g in o.param_groups:
-                    g["lr"] = 0.0
-        before = torch.cat([p.detach().reshape(-1).float().cpu() for p in trainer.model.parameters()])
-        losses = []
-        for step in range(3, 6):
-            loss, _, metrics = trainer.train_iteration(step, *data.next_train(step))
-            losses.append((loss.item(), int(metrics["num_samples_per_batch"])))
-        trainer.flush_scheduler_step()
-        trainer.consolidate()
-        after = torch.cat([p.detach().reshape(-1).float().cpu() for p in trainer.model.parameters()])
-        return trainer, losses, before, after
+    torch.manual_seed(0)
+    trainer, data, _ = build_workload("p030_h32", device="cuda:0", small=True, n_rays=512, window_hash=OPEN_WINDOW,
+                                      compact_first_grid=False)
+    _no_jitter(trainer)
+    for step in range(3):
+        trainer.train_iteration(step, *data.next_train(step))
+    trainer.flush_scheduler_step()
+    for o in trainer.optimizers.values():               # frozen from here on (two separate trainings would differ by the
+        for g in o.param_groups:                        # order of their gradient atomics: ONE model is stepped twice)
+            g["lr"] = 0.0
+    batches = [data.next_train(step) for step in range(3, 6)]
 
-    t_e, l_e, b_e, a_e = run(True)
-    opt = t_e.optimizers[t_e.group_of_tables()]
+    def steps():
+        out = []
+        for step, (bundle, batch) in zip(range(3, 6), batches):
+            loss, _, metrics = trainer.train_iteration(step, bundle, batch)
+            out.append((loss.item(), int(metrics["num_samples_per_batch"])))
+        trainer.flush_scheduler_step()
+        return out
+
+    def params():
+        trainer.consolidate()
+        return torch.cat([p.detach().reshape(-1).float().cpu() for p in trainer.model.parameters()])
+
+    before = params()
+    l_s = steps()                                        # the single-GPU step on the three batches
+    assert torch.equal(params(), before)
+    trainer.become_emulated_level_parallel_rank(8, 3)
+    opt = trainer.optimizers[trainer.group_of_tables()]
     assert isinstance(opt, LevelParallelTableAdam) and opt.lp.emulate and opt.lp.shadow_forward and opt.lp.levels == [3, 12]
-    assert opt.lp.stats["bwd_calls"] == 3 and opt.lp.planes == 8 * 24
-    _, l_s, b_s, a_s = run(False)
-    assert l_e == l_s, (l_e, l_s)                       # the same losses and kept-sample counts, bit for bit
-    assert torch.equal(b_e, a_e) and torch.equal(b_s, a_s) and torch.equal(b_e, b_s)
+    l_e = steps()                                        # the same batches through the emulated rank
+    assert opt.lp.stats["bwd_calls"] == 3 and opt.lp.planes == 8 * 24 and opt.lp.stats["collectives"] == 12
+    assert l_e == l_s, (l_e, l_s)                        # the same losses and kept-sample counts, bit for bit
+    assert torch.equal(params(), before)
 
 
 def _empty_rank_worker(rank, world, port, out_dir):
