@@ -32,7 +32,7 @@ extern "C" {
 #define NSX_MAX_SLOTS 64
 #define NSX_MAX_ADAM_SLOTS 192   /* gradient planes nsx_adam_hash_factored(_consume) reads (level-parallel runs: one per
                                    (source rank, code row), engine/level_parallel.py) */
-#define NSX_VERSION 122
+#define NSX_VERSION 123
 
 typedef uint16_t nsx_half;
 
@@ -741,6 +741,7 @@ typedef struct nsx_step_plan {
     int64_t b_dx;
     int64_t b_goff;
     int64_t b_csum;             /* block partials of the code sums */
+    int64_t b_plane;            /* int32 [S]: slot % hash_planes (nsx_step_main.hash_planes > 0) */
     int64_t b_deform;           /* nsx_deform_scratch_bytes(S) */
 } nsx_step_plan;
 int nsx_step_plan_make(int64_t S, int64_t R, int n_code_rows, int H, int base_hidden, int head_hidden,
@@ -837,7 +838,8 @@ typedef struct nsx_step_main {
     int32_t use_masked;
     int32_t need_code_grad;          /* the code gradient (window open); 0: nsx_hash_ensemble_bwd_factored without it */
     int32_t scatter_separately;      /* H == 1: the scatter as its own kernel (nsx_hash_ensemble_bwd_scatter) */
-    int32_t reserved;
+    int32_t hash_planes;             /* 0: G has one plane per code row.  P > 0 (only where every code row is the same, the
+                                        compact first-grid phase): G is [P][entries][2], a sample adds to plane slot % P */
     float background;
     float thr;
     float l_alpha;

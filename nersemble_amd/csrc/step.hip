@@ -26,6 +26,17 @@ static inline T* at(uint8_t* base, int64_t off) { return reinterpret_cast<T*>(ba
 template <typename T>
 static inline const T* cat(const uint8_t* base, int64_t off) { return reinterpret_cast<const T*>(base + off); }
 
+// plane[i] = slot[i] % P for the kept samples (nsx_step_main.hash_planes)
+__global__ __launch_bounds__(256) void plane_of_slot_kernel(const int32_t* __restrict__ slot, int64_t S, int P,
+                                                            int32_t* __restrict__ plane, const int64_t* __restrict__ n_dev) {
+    if (n_dev) {
+        const int64_t n = *n_dev;
+        if (n < S) S = n < 0 ? 0 : n;
+    }
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < S; i += (int64_t)gridDim.x * 256)
+        plane[i] = (int32_t)((uint32_t)slot[i] % (uint32_t)P);
+}
+
 #define NSX_TRY(call)                    \
     do {                                 \
         const int rc__ = (call);         \
@@ -177,6 +188,7 @@ int nsx_step_plan_make(int64_t S, int64_t R, int n_code_rows, int H, int base_hi
         p->b_dx = c.take(S * 12);
         p->b_goff = c.take(S * 12);
         p->b_csum = c.take(nsx_hash_codesum_scratch_floats(n_code_rows, H) * 4);
+        p->b_plane = c.take(S * 4);
         p->b_deform = c.take(nsx_deform_scratch_bytes(S));
         p->bwd_bytes = c.off;
     }
@@ -389,9 +401,24 @@ int nsx_step_main_bwd(const nsx_step_main* a, int stage, void* stream) {
     if (stage == 1) {
         // -- HashEnsemble: factored table gradient into G, code gradient summed per code row, position gradient
         float* G_fused = a->G;
+        int hrows = a->n_code_rows;
+        if (a->hash_planes > 0) {
+            // every code row is the same one (compact first-grid phase): the planes only spread the atomics -- P of them
+            // instead of one per row, P / rows of the bytes for the scatter's footprint and for whoever reads G afterwards
+            NSX_REQUIRE(a->hash_planes <= a->n_code_rows && !a->need_code_grad,
+                        "nsx_step_main_bwd: hash_planes %d with %d code rows (code gradient %d)", a->hash_planes,
+                        a->n_code_rows, a->need_code_grad);
+            int32_t* plane = at<int32_t>(wb, p.b_plane);
+            const unsigned blocks = (unsigned)std::min<int64_t>((S + 255) / 256, 4096);
+            hipLaunchKernelGGL(plane_of_slot_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, (hipStream_t)stream, slot, S,
+                               a->hash_planes, plane, n_dev);
+            NSX_LAUNCH_CHECK("plane_of_slot_kernel launch");
+            slot = plane;
+            hrows = a->hash_planes;
+        }
         if (a->scatter_separately && a->G) {
-            NSX_CALL("nsx_hash_ensemble_bwd_scatter", S, a->H, a->n_code_rows, 1,
-                     nsx_hash_ensemble_bwd_scatter(pn, S, a->geom, a->n_code_rows, slot, dout, a->G, a->nonfinite, 8, n_dev,
+            NSX_CALL("nsx_hash_ensemble_bwd_scatter", S, a->H, hrows, 1,
+                     nsx_hash_ensemble_bwd_scatter(pn, S, a->geom, hrows, slot, dout, a->G, a->nonfinite, 8, n_dev,
                                                    stream));
             G_fused = nullptr;
         }
@@ -403,9 +430,9 @@ int nsx_step_main_bwd(const nsx_step_main* a, int stage, void* stream) {
                                                    at<float>(wg, p.g_code_hash), at<float>(wb, p.b_csum), dx, nonfinite,
                                                    n_dev, stream));
         } else {
-            NSX_CALL("nsx_hash_ensemble_bwd_factored", S, a->H, a->n_code_rows, 1,
+            NSX_CALL("nsx_hash_ensemble_bwd_factored", S, a->H, hrows, 1,
                      nsx_hash_ensemble_bwd_factored(pn, S, a->tables, a->H, a->geom, a->code_hash, a->code_hash_stride,
-                                                    a->n_code_rows, slot, a->hash_window, dout, G_fused, nullptr, dx,
+                                                    hrows, slot, a->hash_window, dout, G_fused, nullptr, dx,
                                                     nonfinite, n_dev, stream));
         }
         return NSX_OK;
@@ -499,7 +526,7 @@ int nsx_step_echo(int kind, const void* s, double* out, int capacity) {
         PUT(a->R); PUT(a->S); PUT(a->code_hash_stride); PUT(a->code_deform_stride); PUT(a->max_ray);
         PUT(a->H); PUT(a->n_code_rows); PUT(a->base_hidden); PUT(a->base_out_dim); PUT(a->base_act); PUT(a->head_hidden);
         PUT(a->head_act); PUT(a->geo_dim); PUT(a->use_masked); PUT(a->need_code_grad); PUT(a->scatter_separately);
-        PUT(a->reserved);
+        PUT(a->hash_planes);
         PUT(a->background); PUT(a->thr); PUT(a->l_alpha); PUT(a->l_depth); PUT(a->l_dist); PUT(a->l_empty); PUT(a->l_near);
         PUT(a->eps);
         for (int i = 0; i < 6; ++i) PUT(a->field_aabb[i]);

@@ -71,6 +71,7 @@ class HashTableAdam(torch.optim.Optimizer):
     # the optimizer pass clears the pieces of G it finds non-zero while it reads them (nsx_adam_hash_factored_consume):
     # no 1.6 GB fill in front of the next backward's scatter.  Off (A/B measurements): the backward clears G itself.
     consume_gradient = os.environ.get("NSX_ADAM_CONSUMES_G", "1") == "1"
+    consume_always_below_bytes = 1 << 29     # (compact first-grid phase: a G of a few planes, HashEnsemble.first_grid_planes)
     consume_density_limit = 0.5      # ... while the scatter is expected to touch less than this share of G's sectors
 
     def disarm_early_step(self) -> None:
@@ -178,7 +179,10 @@ class HashTableAdam(torch.optim.Optimizer):
             # 11.7 GB at the reference geometry); the other grids have zero gradient and zero moments -- Adam leaves them
             # where they are
             e, cs = entries[0], self._compact_state
-            sparse = 0 < sink.samples_scattered * 80 < self.consume_density_limit * (e["G"].numel() // 8)
+            # (a G of a few planes -- HashEnsemble.first_grid_planes -- is cleared in passing whatever its density: the pass
+            # is a fraction of a millisecond either way, a separate fill would sit in front of the next scatter)
+            sparse = (0 < sink.samples_scattered * 80 < self.consume_density_limit * (e["G"].numel() // 8)
+                      or e["G"].numel() * 4 <= self.consume_always_below_bytes)
             consume = self.consume_gradient and sparse and sink.is_persistent(e["G"])
             fn = lib().nsx_adam_hash_factored_consume if consume else lib().nsx_adam_hash_factored
             check(fn(ptr(e["G"]), e["n_rows"], ptr(e["code"]), e["code"].stride(0), None, 1, C.byref(he.geom),

@@ -55,7 +55,7 @@ class _LazyView:
 class _StepState:
     """Everything one step's drivers share: the plan, the argument structs, the workspaces (kept alive until the backward
     has been enqueued), the tensors the factored-gradient sink and the optimizer look at afterwards."""
-    __slots__ = ("plan", "sample", "main", "ws_sample", "ws_fwd", "out", "S", "R", "n_rows", "H", "he", "first_grid",
+    __slots__ = ("plan", "sample", "main", "ws_sample", "ws_fwd", "out", "S", "R", "n_rows", "H", "he", "first_grid", "hash_planes",
                  "main_code", "main_window", "keep", "grads", "code_width", "lp", "lp_ex")
 
 
@@ -183,7 +183,12 @@ class _NativeMain(torch.autograd.Function):
         # the factored table gradient of the step (cleared ahead / left clean by the optimizer / cleared here)
         G = None
         if need_tab:
-            G = sink.buffer_for(st.main_code, st.main_window, st.n_rows, st.he.geom.total_entries, n_samples=st.S)
+            if st.hash_planes:
+                # (compact first-grid phase: every row's code is one -- the planes only spread the atomics)
+                G = sink.buffer_for(st.he.first_grid_code(st.hash_planes), None, st.hash_planes, st.he.geom.total_entries,
+                                    n_samples=st.S)
+            else:
+                G = sink.buffer_for(st.main_code, st.main_window, st.n_rows, st.he.geom.total_entries, n_samples=st.S)
         m.G = G.data_ptr() if G is not None else None
         m.nonfinite = sink.nonfinite.data_ptr() if G is not None else None
         m.scatter_separately = 1 if (F.scatter_alone(st.H) and G is not None) else 0
@@ -480,6 +485,8 @@ class NativeStep:
         m.code_hash_stride, m.code_deform_stride = main_code.stride(0), code_d.stride(0)
         m.max_ray = int(cfg.dist_loss_max_rays)
         m.H, m.n_code_rows = Hk, n_rows
+        hash_planes = he.first_grid_planes(n_rows, S) if first else 0
+        m.hash_planes = hash_planes
         m.base_hidden, m.base_out_dim, m.base_act = mb.n_hidden_mats, mb.n_output_dims, mb.out_act
         m.head_hidden, m.head_act, m.geo_dim = mh.n_hidden_mats, mh.out_act, model.field.geo_feat_dim
         m.use_masked = 1 if cfg.use_masked_rgb_loss else 0
@@ -493,7 +500,7 @@ class NativeStep:
         st = _StepState()
         st.plan, st.sample, st.main, st.ws_sample = plan, a, m, ws_sample
         st.S, st.R, st.n_rows, st.H, st.he, st.first_grid = S, R, n_rows, Hk, he, first
-        st.main_code, st.main_window = main_code, main_window
+        st.main_code, st.main_window, st.hash_planes = main_code, main_window, hash_planes
         st.code_width = int(code_hash.shape[1])
         st.lp, st.lp_ex = lp, lp_ex
         deform_params = df.ordered_params()

@@ -154,7 +154,7 @@ class ShardedTableAdam(torch.optim.Optimizer):
         # the reduce-scatter starts inside the backward, as soon as the HashEnsemble's backward has completed G: it
         # then runs beside the deformation field's backward (which comes later in the graph) instead of after it
         self._early = None            # handle of a reduce-scatter already started for this step ("done" = finished)
-        self._comm_stream = None
+        self.comm_stream = None       # the stream it runs on (the trainer hands in its optimizer stream; else one of its own)
         # narrow phases (exchange width W < H): fp32 master and both moments of the W active grids of this rank's entries
         # as CONTIGUOUS [entries][2][W] arrays -- the shard's Adam is then a dense pass over W / H of the bytes instead of
         # one 4 W-byte run per 128-byte line of the full layout (1.65 ms at W = 1 on a half-table shard: as long as the
@@ -416,7 +416,8 @@ class ShardedTableAdam(torch.optim.Optimizer):
         sink = he.grad_sink
         consume = (self.consume_gradient and len(entries) == 1 and self.Hp >= 8 and W <= 16 and entries[0]["G"].is_cuda
                    and sink.is_persistent(entries[0]["G"])
-                   and 0 < sink.samples_scattered * 80 < self.consume_density_limit * (entries[0]["G"].numel() // 8))
+                   and (0 < sink.samples_scattered * 80 < self.consume_density_limit * (entries[0]["G"].numel() // 8)
+                        or entries[0]["G"].numel() * 4 <= self.consume_always_below_bytes))
         handles = []
         for k in range(n_pieces):
             buf = b["buckets"][k % 2][:self.world_size * n_piece]
@@ -443,6 +444,7 @@ class ShardedTableAdam(torch.optim.Optimizer):
 
     consume_gradient = True
     consume_density_limit = 0.5
+    consume_always_below_bytes = 1 << 29          # (a G of a few planes: HashEnsemble.first_grid_planes)
 
     @torch.no_grad()
     def _start_reduce(self) -> None:
@@ -454,9 +456,9 @@ class ShardedTableAdam(torch.optim.Optimizer):
             self._early = "done"
             return
         dev = he.tables.device
-        if self._comm_stream is None:
-            self._comm_stream = torch.cuda.Stream(dev)
-        comm = self._comm_stream
+        if self.comm_stream is None:
+            self.comm_stream = torch.cuda.Stream(dev)
+        comm = self.comm_stream
         comm.wait_stream(torch.cuda.current_stream(dev))         # codes / flags are ready on the backward's stream
         he.grad_sink.wait_scatter(comm)                          # G is complete on the scatter's stream
         with torch.cuda.stream(comm):

@@ -177,6 +177,15 @@ class NeRSembleTrainer:
         # where the table optimizer's streams live in HBM changes the pass by up to 20 % (engine/placement.py)
         self.placement_report = None
         table_opt = self.optimizers.get(self.group_of_tables())
+        if isinstance(table_opt, ShardedTableAdam) and self._opt_stream is not None:
+            # ONE side stream for the expansion + reduce-scatter (from inside the backward) and, later, the shard's Adam +
+            # all-gather: HIP maps its streams onto 4 hardware queues -- with main, ray-march prefetch, optimizer and RCCL's
+            # own stream in use, a fifth stream shared the MAIN stream's queue and its 0.3 ms expansion ran in line with the
+            # backward instead of beside it (profiles/r06_timeline_dp_compact_*.txt)
+            table_opt.comm_stream = self._opt_stream
+            sink = model.field.hash_ensemble.grad_sink
+            if sink is not None:
+                sink._fill_stream = self._opt_stream      # (the clear-ahead of G: that stream is idle while the forward runs)
         if calibrate_table_placement and isinstance(table_opt, HashTableAdam):
             from .placement import calibrate_table_placement as _calibrate
             self.placement_report = _calibrate(model.field.hash_ensemble, table_opt)

@@ -10,6 +10,7 @@ reference's tcnn layout (``hash_encodings.{c}.params``) through a lossless permu
 from collections import defaultdict
 from dataclasses import dataclass, field
 import math
+import os
 from math import ceil
 from typing import Dict, List, Literal, Optional
 
@@ -216,14 +217,29 @@ class HashEnsemble(nn.Module):
         return self.enter_compact(1)
 
     def first_grid_code(self, n_rows: int) -> torch.Tensor:
-        """The phase's code table with ``n_rows`` rows of one: the kernels keep one gradient plane per code row, and the
-        samples of a batch stay spread over their time slots' planes -- with a single plane every sample of the batch adds
-        to the same few thousand coarse-level entries, and the memory-side atomics serialise (measured: hash backward
-        5.5 ms instead of 1.9 at 650 k samples)."""
+        """The phase's code table with ``n_rows`` rows of one (the forward reads it through the samples' slots; the native
+        step's backward keeps ``first_grid_planes`` gradient planes, the per-kernel path one per row.  Round 3 measured a
+        single plane at 5.5 ms instead of 1.9 for the hash backward at 650 k samples -- every sample adding to the same few
+        thousand coarse-level entries; since the scatter merges neighbouring samples' duplicates that no longer holds)."""
         codes = self._compact["codes"]
         if n_rows not in codes:
             codes[n_rows] = torch.ones((n_rows, 1), dtype=torch.float32, device=self._compact["f16"].device)
         return codes[n_rows]
+
+    def first_grid_planes(self, n_rows: int, n_samples: int) -> int:
+        """Gradient planes of a native step in the phase (0: one per code row, as everywhere else).  Every row's code is the
+        same one, so which plane a sample adds to is free: P planes (plane = slot % P) spread the coarse levels' atomics
+        like the rows do, while the scatter's footprint, the clear, and the pass that reads G afterwards (the optimizer's,
+        or the data-parallel expansion, which sits in the step's dependent chain) move P / rows of the bytes.
+        Measured (profiles/r06_first_grid_planes_sweep.txt, 4096 rays, 24 rows; window / steady ms per step): one plane per
+        row 5.06 / 1.45 (data-parallel rank 5.38 / 1.69), P = 1: 4.78 / 1.31 (4.96 / 1.55), **P = 2: 4.76 / 1.27 (5.00 /
+        1.43)**, 4: 4.81 / 1.31 (5.01 / 1.45), 8: 4.85 / 1.32 (5.09 / 1.51); the scatter itself takes 1.83-1.87 ms at 2^20
+        samples whatever P (it merges the duplicates of neighbouring samples before its atomics)."""
+        env = os.environ.get("NSX_FIRST_GRID_PLANES")
+        P = int(env) if env else self.first_grid_planes_default
+        return min(P, n_rows) if 0 < P < n_rows else 0
+
+    first_grid_planes_default = 2
 
     def first_grid_code_full(self, n_rows: int) -> torch.Tensor:
         """The same code as a table over ALL grids -- [n_rows, Hp], one in column 0, zeros elsewhere -- for a consumer that

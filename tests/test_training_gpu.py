@@ -666,13 +666,15 @@ def test_trainer_prefetches_the_next_batch(cuda):
     assert abs(np.mean(losses[-8:]) - np.mean(losses0[-8:])) < 0.25 * np.mean(losses0[-8:])
 
 
-def _compact_run(compact, steps, window_hash=None, seed=31, ramp=True, window_at_step0=None):
+def _compact_run(compact, steps, window_hash=None, seed=31, ramp=True, window_at_step0=None, planes=None):
     from nersemble_amd.workloads import build_workload
     torch.manual_seed(seed)
     trainer, data, _ = build_workload("p030_h16", device="cuda:0", small=True, n_rays=512, compact_first_grid=compact,
                                       window_hash=window_hash)
     he = trainer.model.field.hash_ensemble
     he.compact_window_ramp = ramp
+    if planes is not None:
+        he.first_grid_planes_default = planes
     if window_at_step0 is not None:
         # a schedule whose value at step 0 is `window_at_step0` and that barely moves over a few steps
         sch = trainer.model.sched_window_hash_encodings
@@ -730,6 +732,26 @@ def test_compact_first_grid_phase_is_the_same_training(cuda):
     t_c.model.eval()
     assert he._compact is None
     t_c.model.train()
+
+
+@pytest.mark.parametrize("planes", [1, 4])
+def test_first_grid_phase_with_fewer_gradient_planes_is_the_same_training(planes, cuda):
+    """``HashEnsemble.first_grid_planes``: in the compact first-grid phase every code row is the same one, so the factored
+    gradient may keep P planes (a sample adds to plane ``slot % P``) instead of one per code row -- the sum over the planes,
+    which is all the optimizer reads, is the same up to the order of the additions."""
+    t_p, init, l_p, phase_p, f_p = _compact_run(True, 8, planes=planes)
+    t_r, _, l_r, phase_r, f_r = _compact_run(True, 8, planes=0)
+    assert all(phase_p) and all(phase_r)
+    cache_p, cache_r = t_p.model.field.hash_ensemble.grad_sink._cache, t_r.model.field.hash_ensemble.grad_sink._cache
+    assert list(cache_p) == [planes] and list(cache_r)[0] > 4            # G: [planes][entries][2] against one plane per row
+    tab_p, tab_r = f_p.pop("tables"), f_r.pop("tables")
+    assert f_p == f_r, (f_p, f_r)                                            # the forward does not know about planes
+    d = (tab_p - tab_r).abs()
+    assert (d <= 1e-5).float().mean().item() >= 0.9995
+    assert torch.equal(tab_p[:, :, 1:], init[:, :, 1:])
+    assert (tab_p[:, :, 0] != init[:, :, 0]).any()
+    assert np.allclose(l_p[:5], l_r[:5], rtol=2e-3), (l_p, l_r)
+    assert np.allclose(l_p, l_r, rtol=5e-2), (l_p, l_r)
 
 
 def test_compact_phase_ends_when_the_window_opens(cuda):

@@ -30,11 +30,25 @@ def main():
     ap.add_argument("--compact", action="store_true", help="the trainer's default: compact first-grid phase")
     ap.add_argument("--datamanager", action="store_true",
                     help="draw the batches inside the loop through NeRSembleVanillaDataManager.next_train (bench.py --with-datamanager)")
+    ap.add_argument("--sharded-one-rank", action="store_true",
+                    help="the table step of a data-parallel rank (ShardedTableAdam, collectives through RCCL on a one-rank group)")
     a = ap.parse_args()
     from nersemble_amd.workloads import build_workload
     torch.manual_seed(19980801)
+    if a.sharded_one_rank:
+        import socket
+        import torch.distributed as dist
+        s_ = socket.socket()
+        s_.bind(("127.0.0.1", 0))
+        os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(s_.getsockname()[1])
+        s_.close()
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("TORCH_NCCL_AVOID_RECORD_STREAMS", "1")
+        torch.cuda.set_device(0)
+        dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
     trainer, data, info = build_workload(a.workload, device="cuda:0", compact_first_grid=a.compact,
-                                         window_hash=(0, 1) if a.window_open else None)
+                                         window_hash=(0, 1) if a.window_open else None,
+                                         **({"sharded_table_adam": True} if a.sharded_one_rank else {}))
     dm = None
     if a.datamanager:
         sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

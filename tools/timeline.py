@@ -1,8 +1,9 @@
 """rocprofv3 --kernel-trace CSV -> the device timeline of one training step, averaged over the last steps of the run.
 
-    python tools/timeline.py <dir with *kernel_trace.csv> [n_steps] > timeline.txt
+    python tools/timeline.py <dir with *kernel_trace.csv> [n_steps] [delimiter kernel prefix] > timeline.txt
 
-A step is delimited by the table optimizer (nsx::adam_hash_factored_kernel): step k = (end of Adam k-1, end of Adam k].
+A step is delimited by the table optimizer (nsx::adam_hash_factored_kernel; a data-parallel rank's shard optimizer:
+pass "nsx::adam_f16grad"): step k = (end of Adam k-1, end of Adam k].
 Per kernel position inside the step: mean start offset from the step start, mean duration, mean idle time of the device
 in front of it (no kernel of any queue running), whether it overlapped another kernel.  The totals at the end split the
 step period into "some kernel running" and "device idle" -- the idle part is dependent-launch latency, not work.
@@ -43,7 +44,8 @@ def main():
                 rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]),
                              "memcpy " + r.get("Direction", "?").replace("MEMORY_COPY_", ""), "dma"))
     rows.sort()
-    adam_ends = [e for s, e, n, q in rows if n.startswith("nsx::adam_hash_factored_kernel")]
+    delimiter = sys.argv[3] if len(sys.argv) > 3 else "nsx::adam_hash_factored_kernel"
+    adam_ends = [e for s, e, n, q in rows if n.startswith(delimiter)]
     if len(adam_ends) < n_steps + 1:
         print(f"only {len(adam_ends)} table-optimizer launches in the trace")
         return
