@@ -179,9 +179,11 @@ class NeRSembleTrainer:
         table_opt = self.optimizers.get(self.group_of_tables())
         if isinstance(table_opt, ShardedTableAdam) and self._opt_stream is not None:
             # ONE side stream for the expansion + reduce-scatter (from inside the backward) and, later, the shard's Adam +
-            # all-gather: HIP maps its streams onto 4 hardware queues -- with main, ray-march prefetch, optimizer and RCCL's
-            # own stream in use, a fifth stream shared the MAIN stream's queue and its 0.3 ms expansion ran in line with the
-            # backward instead of beside it (profiles/r06_timeline_dp_compact_*.txt)
+            # all-gather: HIP maps its streams onto 4 hardware queues by default, and main, ray-march prefetch, optimizer and
+            # RCCL's own stream already use them.  (Measured, tools/run_{m,n,o}_r06.sh: whichever side stream is first used
+            # inside the backward lands on the main stream's queue and runs in line with it; with GPU_MAX_HW_QUEUES=8 the
+            # expansion does overlap the deformation backward, which then takes 3.6 x as long -- the two share the CUs -- for
+            # 0.01-0.09 ms per step.  What shortened the rank's step was a smaller G: HashEnsemble.first_grid_planes.)
             table_opt.comm_stream = self._opt_stream
             sink = model.field.hash_ensemble.grad_sink
             if sink is not None:
