@@ -114,10 +114,14 @@ def time_encoder_sweep(H: int, geom, sizes=(1 << 16, 1 << 18, 1 << 20), budget_s
     if max_threads != best_t and time.time() - t_begin < 0.5 * budget_s:
         torch.set_num_threads(max_threads)
         _time_once(256, tables, params, geom, H, g)
-        probe = 256 / max(_time_once(256, tables, params, geom, H, g), 1e-6)      # (256 threads: 153 samples/s on one box)
-        S_all = int(max(256, min(1 << 16, probe * 3.0))) // 256 * 256              # ~3 s of work at the probed rate
-        dt = _time_once(S_all, tables, params, geom, H, g)
-        all_cores = {"threads": max_threads, "samples": S_all, "seconds": round(dt, 3), "samples_per_s": S_all / dt}
+        # batches of 256 samples until ~3 s have passed (at most 16): on a host shared with other jobs hundreds of torch
+        # threads ran anywhere between 27 and 500 samples/s from one call to the next -- a sample count projected from a probe
+        # took 56 s and 428 s on two boxes; a batch count bounded by the clock cannot
+        t_all, n_all = 0.0, 0
+        while t_all < 3.0 and n_all < 16 * 256:
+            t_all += _time_once(256, tables, params, geom, H, g)
+            n_all += 256
+        all_cores = {"threads": max_threads, "samples": n_all, "seconds": round(t_all, 3), "samples_per_s": n_all / max(t_all, 1e-6)}
     time_encoder_sweep.all_cores = all_cores
     torch.set_num_threads(best_t)
     out = []
