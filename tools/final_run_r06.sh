@@ -40,7 +40,7 @@ DPC="python bench.py --gpus 2 --steps 6 --warmup 3 --backend gloo --ranks-share-
 timeout 600 $DPC --compact-first-grid --steady-after 0 > $out/dp2_narrow_compact.json 2> $out/dp2_narrow_compact.err
 timeout 900 $DPC --window-hash 0 1 --steady-after 200 > $out/dp2_level.json 2> $out/dp2_level.err
 # HBM counters of the level-parallel rank's step (the optimizer pass over 192 planes, the per-source-rank backward)
-p=gpurun_out/prof_r06
+p=gpurun_out/prof_r06; mkdir -p $p
 PM="$LP --steady-after 0 --no-kernel-events --steps 6 --warmup 2"
 timeout 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $p/lp_fetch -o lp -- $PM > /dev/null 2> $p/lp_fetch.err
 timeout 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $p/lp_write -o lp -- $PM > /dev/null 2> $p/lp_write.err
