@@ -848,7 +848,7 @@ def main():
                            "nsx_hash_ensemble_bwd_scatter",
                            "nsx_adam_hash_factored", "nsx_adam_hash_factored_consume", "nsx_adam_dense",
                            "nsx_deform_fwd", "nsx_deform_fwd_rows", "nsx_deform_bwd",
-                           "nsx_mlp_fwd", "nsx_mlp_bwd", "nsx_check_finite", "nsx_march_fill",
+                           "nsx_mlp_fwd", "nsx_mlp_bwd", "nsx_check_finite", "nsx_march_fill", "nsx_march_fill_from_stash",
                            "nsx_hash_grad_expand", "nsx_hash_grad_expand_f16", "nsx_adam_dense_f16grad",
                            "nsx_check_finite_f16", "nsx_lp_fwd_run", "nsx_lp_bwd_run"}
     # (the variant of the table optimizer that also clears the gradient pieces it reads is priced as the optimizer pass)

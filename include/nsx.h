@@ -32,7 +32,7 @@ extern "C" {
 #define NSX_MAX_SLOTS 64
 #define NSX_MAX_ADAM_SLOTS 192   /* gradient planes nsx_adam_hash_factored(_consume) reads (level-parallel runs: one per
                                    (source rank, code row), engine/level_parallel.py) */
-#define NSX_VERSION 123
+#define NSX_VERSION 124
 
 typedef uint16_t nsx_half;
 
@@ -366,6 +366,17 @@ int nsx_march_fill(const float* rays_o, const float* rays_d, int64_t R, const fl
                    const uint8_t* binary, int res, const float* near, float far_plane, float step,
                    const int64_t* packed_info, float* t_starts, float* t_ends, int64_t* ray_indices,
                    int32_t* cells /* may be NULL */, void* stream);
+/* The counting pass that also KEEPS what it walks past (round 6): stash [R][stash_cap] fp32 receives the starts of each ray's
+ * first stash_cap samples; *over (device int64, zeroed by the caller) is set when some ray has more.  A counting pass runs a
+ * step ahead on its own stream (OccGridEstimator.prefetch_march): with the stash the step itself no longer walks the grid a
+ * second time -- nsx_march_fill_from_stash copies the starts to their packed places (one wave per ray) and writes the same
+ * t_ends = fl(t_starts + step) and ray indices as nsx_march_fill, bit for bit (tests/test_march_gpu.py).  Replaces the second
+ * traversal of nersemble_volumetric_sampler.py:95-108 / nerfacc's traverse_grids on the step's critical path only. */
+int nsx_march_count_stash(const float* rays_o, const float* rays_d, int64_t R, const float* aabb_host,
+                          const uint8_t* binary, int res, const float* near, float far_plane, float step,
+                          int64_t* counts, float* stash, int stash_cap, int64_t* over, void* stream);
+int nsx_march_fill_from_stash(const float* stash, int stash_cap, int64_t R, float step, const int64_t* packed_info,
+                              float* t_starts, float* t_ends, int64_t* ray_indices, void* stream);
 /* counts[r] += #samples with ray index r (nerfacc.pack_info, nersemble_instant_ngp.py:325); caller zeroes counts. */
 int nsx_ray_histogram(const int64_t* ray_indices, int64_t S, int64_t R, int64_t* counts_zeroed, const int64_t* n_device, void* stream);
 
@@ -775,6 +786,8 @@ typedef struct nsx_step_sample {
     uint8_t* ws;                     /* plan->sample_bytes */
     const nsx_step_plan* plan;
     const void* tables_ready_event;  /* hipEvent_t or NULL: `stream` waits for it right in front of the HashEnsemble */
+    const float* march_stash;        /* [R][march_stash_cap] from nsx_march_count_stash (no ray beyond the cap), or NULL: pass 2
+                                        of the traversal walks the grid again (nsx_march_fill) */
     int64_t R;
     int64_t S;
     int64_t deform_code_stride;
@@ -790,6 +803,7 @@ typedef struct nsx_step_sample {
                                         then arrive through the sample exchange (nsx_lp_*): 1 = everything in front of it
                                         (traversal ... normalised positions m_pn, code slots m_slot), 2 = everything behind
                                         it (mlp_base on m_feat ... the kept samples) */
+    int32_t march_stash_cap;
     float far_plane;
     float step;
     float early_stop_eps;

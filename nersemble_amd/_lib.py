@@ -113,6 +113,10 @@ SIGNATURES = {
                                c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "nsx_march_count": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_void_p, c_float, c_float,
                                 c_void_p, c_void_p]),
+    "nsx_march_count_stash": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_void_p, c_float, c_float,
+                                      c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "nsx_march_fill_from_stash": (c_int, [c_void_p, c_int, c_int64, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
+                                          c_void_p]),
     "nsx_pack_info": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "nsx_copy_to_host_async": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "nsx_march_fill": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_void_p, c_float, c_float,

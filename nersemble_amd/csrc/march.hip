@@ -51,11 +51,13 @@ constexpr int kRaysPerBlock = NSX_MARCH_RPB;   // one partially filled wave per 
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
-template <bool FILL>
+// FILL: 0 = count only; 1 = write every sample's start to t0[n] (and its cell id); 2 = the counting pass that also keeps the
+// starts of its first `cap` samples (nsx_march_count_stash: t0 = the ray's row of the stash)
+template <int FILL>
 __device__ __forceinline__ int64_t march_ray(const float o[3], const float d[3], const Aabb& bb,
                                              const uint8_t* __restrict__ binary, int res, float near_plane,
                                              float far_plane, float step, float* __restrict__ t0,
-                                             float* __restrict__ t1, int32_t* __restrict__ cells) {
+                                             float* __restrict__ t1, int32_t* __restrict__ cells, int cap = 0) {
     const float eps = 1e-6f;
     float tmin, tmax;
     if (!ray_aabb(o, d, bb, tmin, tmax)) return 0;
@@ -143,9 +145,11 @@ __device__ __forceinline__ int64_t march_ray(const float o[3], const float d[3],
                     if (t_last + half_step >= t_trav) break;
                     const float t_next = t_last + step;
                     if (emit) {
-                        if (FILL) {
+                        if (FILL == 1) {
                             t0[n] = t_last;          // t1[n] = t0[n] + step: written by the caller, coalesced
                             if (cells) cells[n] = cell_id[i];
+                        } else if (FILL == 2) {
+                            if (n < cap) t0[n] = t_last;
                         }
                         n++;
                     }
@@ -166,7 +170,7 @@ __global__ __launch_bounds__(64) void march_count_kernel(const float* __restrict
     if (r >= R) return;
     const float o[3] = {rays_o[3 * r], rays_o[3 * r + 1], rays_o[3 * r + 2]};
     const float d[3] = {rays_d[3 * r], rays_d[3 * r + 1], rays_d[3 * r + 2]};
-    counts[r] = march_ray<false>(o, d, bb, binary, res, near[r], far_plane, step, nullptr, nullptr, nullptr);
+    counts[r] = march_ray<0>(o, d, bb, binary, res, near[r], far_plane, step, nullptr, nullptr, nullptr);
 }
 
 __global__ __launch_bounds__(64) void march_fill_kernel(const float* __restrict__ rays_o,
@@ -193,7 +197,7 @@ __global__ __launch_bounds__(64) void march_fill_kernel(const float* __restrict_
     if (has_ray && cnt != 0) {
         const float o[3] = {rays_o[3 * r], rays_o[3 * r + 1], rays_o[3 * r + 2]};
         const float d[3] = {rays_d[3 * r], rays_d[3 * r + 1], rays_d[3 * r + 2]};
-        march_ray<true>(o, d, bb, binary, res, near[r], far_plane, step, t0 + s, t1 + s, cells ? cells + s : nullptr);
+        march_ray<1>(o, d, bb, binary, res, near[r], far_plane, step, t0 + s, t1 + s, cells ? cells + s : nullptr);
     }
     // interval ends: every emitted sample is [t, fl(t + step)] by construction, so the ends are one coalesced
     // read-add-write over the block's run of starts instead of a second scattered store per lattice step
@@ -216,6 +220,44 @@ __global__ __launch_bounds__(64) void march_fill_kernel(const float* __restrict_
             const long long i = base + (long long)u * kWave;
             if (i < run_end) t1[i] = v[u] + step;
         }
+    }
+}
+
+// The counting pass that keeps what it walks past (nsx_march_count_stash): stash[r][0 .. min(count, cap)) = the starts of ray
+// r's samples, *over = 1 if some ray has more than `cap` (its tail is then missing: the caller marches that batch again).
+__global__ __launch_bounds__(64) void march_count_stash_kernel(const float* __restrict__ rays_o,
+                                                               const float* __restrict__ rays_d, int64_t R, Aabb bb,
+                                                               const uint8_t* __restrict__ binary, int res,
+                                                               const float* __restrict__ near, float far_plane, float step,
+                                                               int64_t* __restrict__ counts, float* __restrict__ stash, int cap,
+                                                               int64_t* __restrict__ over) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    const float o[3] = {rays_o[3 * r], rays_o[3 * r + 1], rays_o[3 * r + 2]};
+    const float d[3] = {rays_d[3 * r], rays_d[3 * r + 1], rays_d[3 * r + 2]};
+    const int64_t n = march_ray<2>(o, d, bb, binary, res, near[r], far_plane, step, stash + r * (int64_t)cap, nullptr, nullptr,
+                                   cap);
+    counts[r] = n;
+    if (n > cap) *over = 1;
+}
+
+// Pass 2 from the stash: one wave per ray copies its starts to their place in the packed arrays; ends and ray indices as
+// march_fill_kernel writes them (t1 = fl(t0 + step)).
+__global__ __launch_bounds__(256) void march_fill_from_stash_kernel(const float* __restrict__ stash, int cap, int64_t R, float step,
+                                                                    const int64_t* __restrict__ packed, float* __restrict__ t0,
+                                                                    float* __restrict__ t1, int64_t* __restrict__ ray_idx) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x / kWave);
+    if (r >= R) return;
+    const long long s = packed[2 * r];
+    long long cnt = packed[2 * r + 1];
+    if (cnt > cap) cnt = cap;                        // (never, when the caller honoured *over)
+    const float* src = stash + r * (int64_t)cap;
+    for (long long i = lane; i < cnt; i += kWave) {
+        const float v = src[i];
+        t0[s + i] = v;
+        t1[s + i] = v + step;
+        ray_idx[s + i] = r;
     }
 }
 
@@ -351,6 +393,35 @@ int nsx_march_count(const float* rays_o, const float* rays_d, int64_t R, const f
     hipLaunchKernelGGL(march_count_kernel, dim3((unsigned)((R + kRaysPerBlock - 1) / kRaysPerBlock)), dim3(kRaysPerBlock), 0, (hipStream_t)stream, rays_o,
                        rays_d, R, bb, binary, res, near, far_plane, step, counts);
     NSX_LAUNCH_CHECK("nsx_march_count launch");
+    return NSX_OK;
+}
+
+int nsx_march_count_stash(const float* rays_o, const float* rays_d, int64_t R, const float* aabb_host,
+                          const uint8_t* binary, int res, const float* near, float far_plane, float step,
+                          int64_t* counts, float* stash, int stash_cap, int64_t* over, void* stream) {
+    NSX_REQUIRE(R >= 0, "nsx_march_count_stash: negative ray count");
+    if (R == 0) return NSX_OK;
+    if (int rc = check_march("nsx_march_count_stash", rays_o, rays_d, aabb_host, binary, res, near, step)) return rc;
+    NSX_REQUIRE(counts && stash && over, "nsx_march_count_stash: NULL argument");
+    NSX_REQUIRE(stash_cap >= 1, "nsx_march_count_stash: stash_cap %d", stash_cap);
+    Aabb bb;
+    for (int i = 0; i < 6; ++i) bb.v[i] = aabb_host[i];
+    hipLaunchKernelGGL(march_count_stash_kernel, dim3((unsigned)((R + kRaysPerBlock - 1) / kRaysPerBlock)), dim3(kRaysPerBlock), 0,
+                       (hipStream_t)stream, rays_o, rays_d, R, bb, binary, res, near, far_plane, step, counts, stash, stash_cap,
+                       over);
+    NSX_LAUNCH_CHECK("nsx_march_count_stash launch");
+    return NSX_OK;
+}
+
+int nsx_march_fill_from_stash(const float* stash, int stash_cap, int64_t R, float step, const int64_t* packed_info,
+                              float* t_starts, float* t_ends, int64_t* ray_indices, void* stream) {
+    NSX_REQUIRE(R >= 0, "nsx_march_fill_from_stash: negative ray count");
+    if (R == 0) return NSX_OK;
+    NSX_REQUIRE(stash && packed_info && t_starts && t_ends && ray_indices, "nsx_march_fill_from_stash: NULL argument");
+    NSX_REQUIRE(stash_cap >= 1 && step > 0.f, "nsx_march_fill_from_stash: stash_cap %d, step %g", stash_cap, (double)step);
+    hipLaunchKernelGGL(march_fill_from_stash_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, (hipStream_t)stream, stash,
+                       stash_cap, R, step, packed_info, t_starts, t_ends, ray_indices);
+    NSX_LAUNCH_CHECK("nsx_march_fill_from_stash launch");
     return NSX_OK;
 }
 

@@ -228,9 +228,16 @@ int nsx_step_sample_run(const nsx_step_sample* a, void* stream) {
     const bool front = a->phase != 2, back = a->phase != 1;      // level-parallel runs split at the HashEnsemble
     if (front) {
     // -- pass 2 of the traversal (OccGridEstimator.sampling -> traverse)
-    NSX_CALL("nsx_march_fill", R, 0, 0, 0,
-             nsx_march_fill(a->origins, a->directions, R, a->occ_aabb, a->binaries, a->grid_res, a->near_planes, a->far_plane,
-                            a->step, a->packed_march, m_t0, m_t1, m_ri, nullptr, stream));
+    if (a->march_stash) {
+        // (the counting pass kept the samples' starts: nothing walks the grid on the step's critical path)
+        NSX_CALL("nsx_march_fill_from_stash", R, 0, 0, 0,
+                 nsx_march_fill_from_stash(a->march_stash, a->march_stash_cap, R, a->step, a->packed_march, m_t0, m_t1, m_ri,
+                                           stream));
+    } else {
+        NSX_CALL("nsx_march_fill", R, 0, 0, 0,
+                 nsx_march_fill(a->origins, a->directions, R, a->occ_aabb, a->binaries, a->grid_res, a->near_planes,
+                                a->far_plane, a->step, a->packed_march, m_t0, m_t1, m_ri, nullptr, stream));
+    }
     // -- sigma_fn: density at the marched midpoints (get_sigma_fn -> field_density_fn)
     NSX_TRY(nsx_sample_positions(a->origins, a->directions, m_ri, m_t0, m_t1, nullptr, S, nullptr, m_pos, nullptr, nullptr,
                                  nullptr, stream));
@@ -510,9 +517,10 @@ int nsx_step_echo(int kind, const void* s, double* out, int capacity) {
         PUTP(a->ray_slots); PUTP(a->ray_times); PUTP(a->row_timesteps); PUTP(a->rows_flag); PUTP(a->deform_packed); PUTP(a->deform_codes); PUTP(a->tables);
         PUTP(a->geom); PUTP(a->hash_codes); PUTP(a->hash_window); PUTP(a->base_w16); PUTP(a->alpha_thre_dev);
         PUTP(a->window7_host); PUTP(a->ws); PUTP(a->plan); PUTP(a->tables_ready_event);
+        PUTP(a->march_stash);
         PUT(a->R); PUT(a->S); PUT(a->deform_code_stride); PUT(a->hash_code_stride);
         PUT(a->grid_res); PUT(a->H); PUT(a->base_hidden); PUT(a->base_out_dim); PUT(a->base_act); PUT(a->n_code_rows);
-        PUT(a->n_timesteps); PUT(a->phase);
+        PUT(a->n_timesteps); PUT(a->phase); PUT(a->march_stash_cap);
         PUT(a->far_plane); PUT(a->step); PUT(a->early_stop_eps); PUT(a->reserved_f);
         for (int i = 0; i < 6; ++i) PUT(a->occ_aabb[i]);
         for (int i = 0; i < 6; ++i) PUT(a->deform_aabb[i]);

@@ -426,6 +426,8 @@ class NativeStep:
         a = self._sample_cls()
         a.origins, a.directions, a.near_planes = o.data_ptr(), d.data_ptr(), near_planes.data_ptr()
         a.packed_march, a.binaries = packed_march.data_ptr(), binary.data_ptr()
+        kept = grid.last_march_stash               # the counting pass ran a step ahead and kept the samples' starts
+        a.march_stash, a.march_stash_cap = (kept[0].data_ptr(), kept[1]) if kept is not None else (None, 0)
         a.ray_slots = ray_slots.data_ptr()
         if ray_times is not None:
             a.ray_times, a.row_timesteps, a.rows_flag = ray_times.data_ptr(), uniq.data_ptr(), rows_flag.data_ptr()

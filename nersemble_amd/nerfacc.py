@@ -8,6 +8,8 @@ Call sites in the reference: nersemble_volumetric_sampler.py:95-108, nersemble_i
 update (cell selection, jitter, EMA-max, threshold) are HIP kernels.
 """
 import ctypes as C
+import math
+import os
 from typing import Callable, Optional, Tuple
 
 import torch
@@ -278,8 +280,8 @@ class OccGridEstimator(nn.Module):
         if side is None or side.device != dev:
             side = self._prefetch_stream = torch.cuda.Stream(dev, priority=-1)
             # pinned read-back words + completion events, recycled (three in flight at most: two held + the one being made)
-            self._prefetch_ring = [(torch.empty((1,), dtype=torch.int64, pin_memory=True), torch.cuda.Event())
-                                   for _ in range(4)]
+            self._prefetch_ring = [(torch.empty((2,), dtype=torch.int64, pin_memory=True), torch.cuda.Event())
+                                   for _ in range(4)]           # (total, "a ray has more samples than the stash keeps")
             self._prefetch_turn = 0
         key = self._march_key(rays_o, rays_d, near_plane, far_plane, render_step_size, stratified, t_min)
         binary = self.binaries[0].contiguous().view(torch.uint8)
@@ -288,23 +290,61 @@ class OccGridEstimator(nn.Module):
         # the jitter is drawn on the caller's stream (same generator, same order of draws as marching in place); the two
         # traversal kernels and the read-back are enqueued on the side stream through its raw handle
         near_planes = self._near_planes(rays_o, near_plane, t_min, render_step_size, stratified)
-        work = torch.empty((3 * R + 1,), dtype=torch.int64, device=dev)      # counts [R] | packed_info [R, 2] | total
+        work = torch.empty((3 * R + 2,), dtype=torch.int64, device=dev)      # counts [R] | packed_info [R, 2] | total | over
         counts, packed, total = work[:R], work[R:3 * R].view(R, 2), work[3 * R:]
+        # the pass keeps the samples' starts as it walks past them (nsx_march_count_stash): the step that uses it copies them
+        # into place instead of walking the grid a second time on its critical path
+        cap = self._stash_cap(render_step_size)
+        if cap * R * 4 > self.march_stash_max_bytes:
+            cap = 0
+        stash = torch.empty((R, cap), dtype=torch.float32, device=dev) if cap else None
+        if cap:
+            work[3 * R + 1:].zero_()
         side.wait_stream(main)                               # rays, grid and near planes were written on the caller's stream
         raw = C.c_void_p(side.cuda_stream)
-        check(lib().nsx_march_count(ptr(rays_o), ptr(rays_d), R, self._aabb6(), ptr(binary), self._res,
-                                    ptr(near_planes), float(far_plane), float(render_step_size), ptr(counts), raw),
-              "nsx_march_count")
+        if cap:
+            check(lib().nsx_march_count_stash(ptr(rays_o), ptr(rays_d), R, self._aabb6(), ptr(binary), self._res,
+                                              ptr(near_planes), float(far_plane), float(render_step_size), ptr(counts),
+                                              ptr(stash), cap, ptr(work[3 * R + 1:]), raw), "nsx_march_count_stash")
+        else:
+            check(lib().nsx_march_count(ptr(rays_o), ptr(rays_d), R, self._aabb6(), ptr(binary), self._res,
+                                        ptr(near_planes), float(far_plane), float(render_step_size), ptr(counts), raw),
+                  "nsx_march_count")
         check(lib().nsx_pack_info(ptr(counts), R, ptr(packed), ptr(total), raw), "nsx_pack_info")
-        check(lib().nsx_copy_to_host_async(C.c_void_p(total_host.data_ptr()), ptr(total), 8, raw), "nsx_copy_to_host_async")
+        check(lib().nsx_copy_to_host_async(C.c_void_p(total_host.data_ptr()), ptr(total), 16 if cap else 8, raw),
+              "nsx_copy_to_host_async")
         done.record(side)
         work.record_stream(side)                             # allocated on the caller's stream, written on the side stream
+        if stash is not None:
+            stash.record_stream(side)
         # (two are held at most: the pass for the step whose forward has not run yet, and the one for the step after)
         held = getattr(self, "_prefetched", None) or []
         held.append({"key": key, "rays": (rays_o, rays_d, t_min), "near_planes": near_planes, "packed": packed,
-                     "total_host": total_host, "done": done, "keep": (work, binary)})
+                     "total_host": total_host, "done": done, "keep": (work, binary), "stash": stash, "cap": cap})
         self._prefetched = held[-2:]
         return True
+
+    march_stash = os.environ.get("NSX_MARCH_STASH", "1") == "1"
+    march_stash_max = 2048                 # samples per ray
+    march_stash_max_bytes = 1 << 28        # (a training batch of 4096 rays keeps 11.5 MB)
+
+    def _stash_cap(self, render_step_size: float) -> int:
+        """Samples per ray the prefetched counting pass keeps (0: none).  A ray of unit direction stays inside the box for
+        at most its diagonal; a batch with a longer ray (directions that are not normalised) raises the pass's overflow flag
+        and is marched in place."""
+        if not self.march_stash:
+            return 0
+        a = self._aabb6()
+        diag = math.sqrt(sum((float(a[3 + i]) - float(a[i])) ** 2 for i in range(3)))
+        n = int(diag / float(render_step_size)) + 4
+        return (n + 63) // 64 * 64 if n <= self.march_stash_max else 0
+
+    @staticmethod
+    def _stash_of(counted: Optional[dict]):
+        """(stash, cap) of a prefetched pass whose every ray fits its row (read after ``done``), else None."""
+        if counted is None or counted.get("stash") is None or int(counted["total_host"][1]) != 0:
+            return None
+        return counted["stash"], counted["cap"]
 
     def _take_prefetched(self, key):
         """The prefetched counting pass if it is for exactly this call (it then leaves the estimator); one that is for
@@ -329,9 +369,11 @@ class OccGridEstimator(nn.Module):
             counted = self._take_prefetched(self._march_key(rays_o, rays_d, near_plane, far_plane, render_step_size,
                                                             stratified, t_min))
         self.last_march_prefetched = counted is not None
+        self.last_march_stash = None                          # (stash [R, cap], cap) when the pass kept the samples' starts
         if counted is not None:
             torch.cuda.current_stream(dev).wait_event(counted["done"])
             counted["done"].synchronize()                     # long complete when issued a step ahead
+            self.last_march_stash = self._stash_of(counted)
             return counted["near_planes"], counted["packed"], int(counted["total_host"][0])
         near_planes = self._near_planes(rays_o, near_plane, t_min, render_step_size, stratified)
         binary = self.binaries[0].contiguous().view(torch.uint8)
@@ -372,7 +414,11 @@ class OccGridEstimator(nn.Module):
         t1 = torch.empty((S,), dtype=torch.float32, device=dev)
         ri = torch.empty((S,), dtype=torch.int64, device=dev)
         cells = torch.empty((S,), dtype=torch.int32, device=dev) if want_cells else None
-        if S > 0:
+        kept = None if want_cells else self._stash_of(counted)
+        if S > 0 and kept is not None:
+            check(lib().nsx_march_fill_from_stash(ptr(kept[0]), kept[1], R, float(step), ptr(packed), ptr(t0), ptr(t1), ptr(ri),
+                                                  stream()), "nsx_march_fill_from_stash")
+        elif S > 0:
             check(lib().nsx_march_fill(ptr(rays_o), ptr(rays_d), R, self._aabb6(), ptr(binary), res,
                                        ptr(near_planes), float(far_plane), float(step), ptr(packed), ptr(t0), ptr(t1),
                                        ptr(ri), ptr(cells), stream()), "nsx_march_fill")

@@ -68,6 +68,50 @@ def test_march_bit_exact(kind, aabb, res, cuda):
         assert ri.numel() > 200 * (R - 16)
 
 
+@pytest.mark.parametrize("kind,aabb,res", [("ones", P97, 128), ("shell", P30, 128), ("random", P30, 64), ("empty", P30, 32)])
+def test_prefetched_pass_keeps_the_samples_and_the_step_copies_them(kind, aabb, res, cuda):
+    """``nsx_march_count_stash`` + ``nsx_march_fill_from_stash`` (the counting pass a step ahead keeps the samples' starts; the
+    step copies them into place) against the oracle's march, bit for bit -- through ``prefetch_march`` -> ``traverse(counted=)``
+    and ``counted_march``, the way the per-kernel path and the native step take it."""
+    R = 1024
+    o, d = _rays(R, 3, axis_aligned=True)
+    binary = _grid(res, kind)
+    near = np.full(R, 0.2, np.float32)
+    ri_o, t0_o, t1_o, packed_o = om.march(o, d, aabb, binary, near, 1e3, 0.011)
+    est = _est(aabb, binary, cuda)
+    ot, dt = torch.from_numpy(o).to(cuda), torch.from_numpy(d).to(cuda)
+    args = dict(near_plane=0.2, far_plane=1e3, render_step_size=0.011, stratified=False)
+    assert est.prefetch_march(ot, dt, **args)
+    pre = est._take_prefetched(est._march_key(ot, dt, 0.2, 1e3, 0.011, False, None))
+    assert pre is not None and pre["stash"] is not None and pre["cap"] % 64 == 0
+    ri, t0, t1, packed, _ = est.traverse(ot, dt, pre["near_planes"], 1e3, 0.011, counted=pre)
+    assert est._stash_of(pre) is not None and int(pre["total_host"][0]) == ri_o.shape[0]
+    assert np.array_equal(packed.cpu().numpy(), packed_o)
+    assert np.array_equal(ri.cpu().numpy(), ri_o)
+    assert np.array_equal(t0.cpu().numpy().view(np.uint32), t0_o.view(np.uint32))
+    assert np.array_equal(t1.cpu().numpy().view(np.uint32), t1_o.view(np.uint32))
+    # the native step's entry: counted_march hands the stash on
+    assert est.prefetch_march(ot, dt, **args)
+    near_t, packed2, S = est.counted_march(ot, dt, 0.2, 1e3, 0.011, False)
+    assert est.last_march_prefetched and S == ri_o.shape[0] and torch.equal(packed2, packed)
+    assert (est.last_march_stash is not None) and est.last_march_stash[1] == pre["cap"]
+    if S:
+        stash = est.last_march_stash[0]
+        n0 = int(packed_o[np.argmax(packed_o[:, 1]), 1])
+        r0 = int(np.argmax(packed_o[:, 1]))
+        assert np.array_equal(stash[r0, :n0].cpu().numpy().view(np.uint32), t0_o[packed_o[r0, 0]:packed_o[r0, 0] + n0].view(np.uint32))
+    # a stash too short for some ray: the pass says so, and the step marches in place (same result)
+    est.march_stash_max = 10 ** 6
+    est._stash_cap = lambda step: 64
+    assert est.prefetch_march(ot, dt, **args)
+    pre = est._take_prefetched(est._march_key(ot, dt, 0.2, 1e3, 0.011, False, None))
+    ri3, t03, t13, packed3, _ = est.traverse(ot, dt, pre["near_planes"], 1e3, 0.011, counted=pre)
+    longest = int(packed_o[:, 1].max()) if R else 0
+    assert (est._stash_of(pre) is None) == (longest > 64)
+    assert np.array_equal(ri3.cpu().numpy(), ri_o) and np.array_equal(t03.cpu().numpy().view(np.uint32), t0_o.view(np.uint32))
+    assert np.array_equal(t13.cpu().numpy().view(np.uint32), t1_o.view(np.uint32))
+
+
 def test_sampling_contract_and_visibility(cuda):
     """OccGridEstimator.sampling: sigma_fn filtering == oracle transmittance/alpha thresholds."""
     R = 512
