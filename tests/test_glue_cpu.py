@@ -250,3 +250,36 @@ def test_prefetched_march_bookkeeping():
     k1 = grid._march_key(o, o, 0.2, 1e3, 0.01, True, None)
     torch.autograd.graph.increment_version(grid.binaries)                        # what the native grid update does
     assert grid._march_key(o, o, 0.2, 1e3, 0.01, True, None) != k1
+
+
+def test_march_stash_capacity_and_validity():
+    """The prefetched counting pass keeps the samples' starts (``nsx_march_count_stash``): how many per ray, and when the step
+    may use them (every ray fits: the overflow word that travels with the total is zero)."""
+    import torch
+    from nersemble_amd.nerfacc import OccGridEstimator
+    grid = OccGridEstimator(roi_aabb=torch.tensor([-2.5, -1.8, -2.5, 2.2, 1.8, 2.0]), resolution=16, levels=1)
+    diag = (4.7 ** 2 + 3.6 ** 2 + 4.5 ** 2) ** 0.5
+    cap = grid._stash_cap(0.011)
+    assert cap % 64 == 0 and diag / 0.011 + 4 <= cap < diag / 0.011 + 4 + 64          # the box diagonal bounds a unit ray
+    assert grid._stash_cap(1e-4) == 0                                                 # beyond march_stash_max: no stash
+    grid.march_stash = False
+    assert grid._stash_cap(0.011) == 0
+    stash = torch.zeros((4, 64))
+    ok = {"stash": stash, "cap": 64, "total_host": torch.tensor([10, 0])}
+    assert OccGridEstimator._stash_of(ok) == (stash, 64)
+    assert OccGridEstimator._stash_of(dict(ok, total_host=torch.tensor([10, 1]))) is None   # some ray has more than cap
+    assert OccGridEstimator._stash_of(dict(ok, stash=None)) is None and OccGridEstimator._stash_of(None) is None
+
+
+def test_first_grid_planes_policy(monkeypatch):
+    """``HashEnsemble.first_grid_planes``: P planes when the batch has more code rows than that, else one per row (0)."""
+    from nersemble_amd.field_components.hash_ensemble import HashEnsemble
+    fgp = HashEnsemble.first_grid_planes
+    he = type("H", (), {"first_grid_planes_default": HashEnsemble.first_grid_planes_default})()
+    monkeypatch.delenv("NSX_FIRST_GRID_PLANES", raising=False)
+    assert HashEnsemble.first_grid_planes_default == 2
+    assert fgp(he, 24, 100000) == 2 and fgp(he, 2, 100000) == 0 and fgp(he, 1, 5) == 0
+    he.first_grid_planes_default = 0
+    assert fgp(he, 24, 100000) == 0
+    monkeypatch.setenv("NSX_FIRST_GRID_PLANES", "4")
+    assert fgp(he, 24, 100000) == 4 and fgp(he, 3, 100000) == 0
