@@ -32,10 +32,15 @@ def main():
                     help="draw the batches inside the loop through NeRSembleVanillaDataManager.next_train (bench.py --with-datamanager)")
     ap.add_argument("--sharded-one-rank", action="store_true",
                     help="the table step of a data-parallel rank (ShardedTableAdam, collectives through RCCL on a one-rank group)")
+    ap.add_argument("--level-parallel-one-rank", type=int, default=0, metavar="N",
+                    help="after settling: go on as rank --rank of an N-rank level-parallel job (emulated, frozen; window open)")
+    ap.add_argument("--rank", type=int, default=None)
     a = ap.parse_args()
     from nersemble_amd.workloads import build_workload
     torch.manual_seed(19980801)
-    if a.sharded_one_rank:
+    if a.level_parallel_one_rank:
+        a.window_open, a.compact = True, False
+    if a.sharded_one_rank or a.level_parallel_one_rank:
         import socket
         import torch.distributed as dist
         s_ = socket.socket()
@@ -60,6 +65,13 @@ def main():
     while step < a.settle_at:
         trainer.train_iteration(step, *data.next_train(step))
         step += 1
+    if a.level_parallel_one_rank:
+        trainer.flush_scheduler_step()
+        N = a.level_parallel_one_rank
+        trainer.become_emulated_level_parallel_rank(N, N - 1 if a.rank is None else a.rank)
+        for _ in range(8):
+            trainer.train_iteration(step, *data.next_train(step))
+            step += 1
     n = a.steps
     batches = [data.next_train(step + i) for i in range(3 * n + 1)] if dm is None else None
     gc.collect()
