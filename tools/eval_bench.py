@@ -66,11 +66,11 @@ if "--price" in sys.argv:
     native = sum(v["total_ms"] for _, v in rows)
     # what bounds the dominant kernel: not HBM bytes -- 572 algorithmic bytes per sample at the measured rate
     # are ~1.8 TB/s -- and not the matrix cores (8 MFMAs per 32 samples).  The counter passes of this very command
-    # (profiles/pmc/r06_density_fused_counters.json: rocprofv3 --pmc TCC_HIT / TCC_MISS, SQ_WAVE_CYCLES / SQ_WAIT_*) say:
-    # L2 hit rate 0.41 -- the 25 MB pre-blended table does not fit the 4 MB L2 of an XCD, the eleven 2 MB hashed levels are
-    # served by the Infinity Cache --, 13.6 L2 misses per sample, and the waves spend 66 % of their cycles parked on
-    # s_waitcnt with 13 % issuing: the kernel is bound by the LATENCY of random 64-byte lines that miss L2, at the
-    # memory-level parallelism 2 blocks x 4 waves per CU can hold.
+    # (profiles/pmc/r06_density_fused_counters.json: L2 hit rate 0.41, 13.6 L2 misses per sample, waves parked on s_waitcnt 66 % of
+    # their cycles) read like a latency bound; five experiments (profiles/r06_eval_lookup_bound_experiments.txt)
+    # say otherwise: more waves per SIMD, merged 8-byte reads, a level-major order that keeps each level in L2 and the pair's
+    # lanes side by side all leave the time where it is, and ONE level costs 17-23 us per 2^20 samples whether its table is
+    # 16 KB or 2 MB.  The cost is per dword gathered: 128 per sample at ~0.6 per clock and CU.
     dens = dict(rows).get("nsx_density_fused_fwd")
     roofline = None
     if dens is not None:
@@ -81,10 +81,12 @@ if "--price" in sys.argv:
             c = json.load(open(pmc))
             l2_hit, wait = c["derived"].get("l2_hit_rate"), c["derived"].get("SQ_WAIT_ANY_frac_of_wave_cycles")
             miss_per_sample = c["counters"]["TCC_MISS_sum"]["sum_last_render"] / 25881293.0
-        roofline = {"kernel": "nsx_density_fused_fwd", "bound": "latency of L2-missing random 64-byte lines (Infinity Cache)",
+        roofline = {"kernel": "nsx_density_fused_fwd", "bound": "the CU's gather rate: 128 divergent dword reads per sample at ~0.6 per clock and CU (DESIGN.md 7b)",
                     "ms_per_2^20_samples": round(dens["total_ms"] / samples * 2 ** 20, 4),
                     "achieved": round(samples * 64 / (dens["total_ms"] * 1e-3) / 1e9, 1), "unit": "G line requests/s (16 levels x 4 "
-                    "(y, z) corner pairs per sample)", "peak": None, "frac": None,
+                    "(y, z) corner pairs per sample)",
+                    "dword_reads_per_clock_per_cu": round(samples * 128 / (dens["total_ms"] * 1e-3) / 256 / 2.4e9, 3),
+                    "peak": None, "frac": None,
                     "hbm_view": {"algorithmic_bytes_per_sample": 572, "achieved_GBps": round(samples * 572 / (dens["total_ms"] * 1e-3) / 1e9, 1),
                                  "frac_of_8_TBps": round(samples * 572 / (dens["total_ms"] * 1e-3) / 8e12, 3)},
                     "counters": {"l2_hit_rate": l2_hit, "l2_misses_per_sample": miss_per_sample,
