@@ -128,6 +128,37 @@ def test_native_step_with_the_march_counted_a_step_ahead(cuda):
     assert np.allclose(a[:, 0], b[:, 0], rtol=0.1) and np.allclose(a[:, 1], b[:, 1], rtol=0.1)
 
 
+@pytest.mark.parametrize("phase", ["compact", "open"])
+def test_the_stash_of_the_counting_pass_is_the_second_march(phase, cuda):
+    """``OccGridEstimator.march_stash``: the counting pass a step ahead keeps the samples' starts and the native sampler copies
+    them (``nsx_step_sample.march_stash`` -> ``nsx_march_fill_from_stash``) instead of marching a second time -- the step sees the
+    same samples (``tests/test_march_gpu.py`` holds the copy to the oracle's march bit for bit): the runs agree as two runs of one
+    configuration do (from step 1 on they differ by the order of the gradient atomics of the steps before)."""
+    from nersemble_amd.nerfacc import OccGridEstimator
+    runs = {}
+    for stash in (False, True):
+        trainer, data, model = _build(phase, True, seed=13)
+        grid = model.occupancy_grid
+        grid.march_stash = stash
+        batches = [data.next_train(s) for s in range(6)]
+        rec, used, kept = [], [], []
+        for step in range(5):
+            torch.manual_seed(900 + step)
+            loss, loss_dict, metrics = trainer.train_iteration(step, *batches[step], next_ray_bundle=batches[step + 1][0])
+            rec.append((loss.item(), int(metrics["num_samples_per_batch"])))
+            used.append(bool(grid.last_march_prefetched))
+            kept.append(grid.last_march_stash is not None)
+        trainer.flush_scheduler_step()
+        runs[stash] = (rec, used, kept)
+    assert runs[False][1] == runs[True][1] and sum(runs[True][1]) >= 3
+    assert not any(runs[False][2])
+    assert runs[True][2] == runs[True][1]                     # every prefetched pass handed its stash on (no ray beyond the cap)
+    assert runs[True][0][0] == runs[False][0][0]                  # step 0 marches in place on both sides: bit for bit
+    a, b = np.array(runs[False][0]), np.array(runs[True][0])
+    assert np.allclose(a[:, 0], b[:, 0], rtol=5e-2) and np.allclose(a[:, 1], b[:, 1], rtol=2e-2)
+    assert OccGridEstimator.march_stash is True                    # (the class default: on)
+
+
 def test_native_step_falls_back_outside_its_configuration(cuda):
     """Dense configuration (occupancy grid off: nothing to reuse from a sigma pass) and per-sample-count read-backs stay on
     the per-kernel path; the step still runs."""
