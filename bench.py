@@ -694,6 +694,9 @@ def main():
                          "numbers it trains on are not the model's).  Implies --window-hash 0 1")
     ap.add_argument("--rank", type=int, default=-1, help="the emulated rank of --level-parallel-one-rank (default N - 1: the "
                                                          "finest levels' owner, the slowest rank)")
+    ap.add_argument("--lp-launch-per-source", action="store_true",
+                    help="level-parallel runs: one HashEnsemble launch per source rank (NSX_OPT_LP_ONE_LAUNCH = 0) instead of "
+                         "all source ranks in one launch -- the A/B switch of that change")
     ap.add_argument("--no-kernels-alone", action="store_true", help="skip the stand-alone kernel timings after the run")
     ap.add_argument("--with-datamanager", action="store_true",
                     help="draw every batch INSIDE the timed loop through NeRSembleVanillaDataManager.next_train (24-image "
@@ -715,6 +718,9 @@ def main():
         a.no_first_grid_phase = a.no_open_window = a.no_with_datamanager = True
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(a, sys.argv[1:]))
+    if a.lp_launch_per_source:
+        from nersemble_amd import _lib
+        _lib.check(_lib.lib().nsx_set_option(_lib.NSX_OPT_LP_ONE_LAUNCH, 0), "nsx_set_option")
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

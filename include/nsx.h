@@ -32,7 +32,7 @@ extern "C" {
 #define NSX_MAX_SLOTS 64
 #define NSX_MAX_ADAM_SLOTS 192   /* gradient planes nsx_adam_hash_factored(_consume) reads (level-parallel runs: one per
                                    (source rank, code row), engine/level_parallel.py) */
-#define NSX_VERSION 124
+#define NSX_VERSION 125
 
 typedef uint16_t nsx_half;
 
@@ -61,7 +61,9 @@ const char* nsx_last_error(void);
 #define NSX_OPT_ADAM_BLOCKS_PER_CU 0           /* nsx_adam_hash_factored(_consume): 1..8, default 5 */
 #define NSX_OPT_MLP_BWD_HALF_BLOCKS_PER_CU 1   /* nsx_mlp_bwd with a hidden matrix: blocks per CU x 2, 1..8, default 2 */
 #define NSX_OPT_MLP_BWD0_HALF_BLOCKS_PER_CU 2  /* nsx_mlp_bwd without one: blocks per CU x 2, 1..8, default 2 */
-#define NSX_OPT_COUNT 3
+#define NSX_OPT_LP_ONE_LAUNCH 3                /* nsx_lp_fwd_run / nsx_lp_bwd_run: 1 (default) = all source ranks in ONE launch
+                                                  (grid.y = source rank), 0 = one launch per source rank */
+#define NSX_OPT_COUNT 4
 int nsx_set_option(int option, int value);
 int nsx_get_option(int option);                /* the current value, or NSX_ERR_INVALID */
 

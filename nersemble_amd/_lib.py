@@ -11,6 +11,7 @@ NSX_MAX_SLOTS = 64
 NSX_MAX_GATHER = 8
 NSX_MAX_ADAM_SLOTS = 192
 NSX_OPT_ADAM_BLOCKS_PER_CU, NSX_OPT_MLP_BWD_HALF_BLOCKS_PER_CU, NSX_OPT_MLP_BWD0_HALF_BLOCKS_PER_CU = 0, 1, 2
+NSX_OPT_LP_ONE_LAUNCH = 3
 
 c_void_p, c_int, c_int64, c_float = C.c_void_p, C.c_int, C.c_int64, C.c_float
 

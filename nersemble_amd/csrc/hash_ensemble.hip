@@ -142,8 +142,8 @@ __device__ __forceinline__ void load_code(const float* __restrict__ row, const f
 // forward
 // ------------------------------------------------------------------------------------------------
 template <int H, int WAVES>
-__global__ __launch_bounds__(WAVES * kWave) void ens_fwd_kernel(
-    const float* __restrict__ x, int64_t B, const uint8_t* __restrict__ tab, const nsx_grid_geom g,
+__device__ __forceinline__ void ens_fwd_body(
+    const float* __restrict__ x, int64_t B, const uint8_t* __restrict__ tab, const nsx_grid_geom& g,
     const float* __restrict__ code, int64_t code_stride, const int32_t* __restrict__ code_index,
     const float* __restrict__ window, int Hreal, uint32_t* __restrict__ out, int64_t n_tiles,
     const int64_t* __restrict__ n_dev) {
@@ -234,6 +234,35 @@ __global__ __launch_bounds__(WAVES * kWave) void ens_fwd_kernel(
     }
 }
 
+template <int H, int WAVES>
+__global__ __launch_bounds__(WAVES * kWave) void ens_fwd_kernel(
+    const float* __restrict__ x, int64_t B, const uint8_t* __restrict__ tab, const nsx_grid_geom g,
+    const float* __restrict__ code, int64_t code_stride, const int32_t* __restrict__ code_index,
+    const float* __restrict__ window, int Hreal, uint32_t* __restrict__ out, int64_t n_tiles,
+    const int64_t* __restrict__ n_dev) {
+    ens_fwd_body<H, WAVES>(x, B, tab, g, code, code_stride, code_index, window, Hreal, out, n_tiles, n_dev);
+}
+
+// Several sample sets ("sources": the ranks of a level-parallel job, level_parallel.hip) in ONE launch: blockIdx.y is the
+// source, whose arrays sit at fixed byte strides from source 0's; a block works on one source only, so nothing about
+// the tile, the code slots or the duplicate-merging keys changes.  One source's ~90 k samples on two levels are one or
+// two tiles per wave -- a launch of its own is mostly its own latency.
+template <int H, int WAVES>
+__global__ __launch_bounds__(WAVES * kWave) void ens_fwd_sources_kernel(
+    const uint8_t* __restrict__ x, const uint8_t* __restrict__ tab, const nsx_grid_geom g,
+    const uint8_t* __restrict__ code, int64_t code_stride, const uint8_t* __restrict__ code_index,
+    const float* __restrict__ window, int Hreal, uint8_t* __restrict__ out, const uint8_t* __restrict__ n_dev,
+    const EnsSources src) {
+    using C = EnsCfg<H>;
+    const int j = blockIdx.y;
+    const int64_t B = src.B[j];
+    ens_fwd_body<H, WAVES>(reinterpret_cast<const float*>(x + j * src.x_stride), B, tab, g,
+                           reinterpret_cast<const float*>(code + j * src.code_stride), code_stride,
+                           reinterpret_cast<const int32_t*>(code_index + j * src.slot_stride), window, Hreal,
+                           reinterpret_cast<uint32_t*>(out + j * src.out_stride), (B + C::SPW - 1) / C::SPW,
+                           reinterpret_cast<const int64_t*>(n_dev + j * src.count_stride));
+}
+
 // DPP row_shl:J -- lane i receives the value of lane i+J of its 16-lane row (0 when out of the row)
 template <int J>
 __device__ __forceinline__ int dpp_row_shl(int x) { return __builtin_amdgcn_update_dpp(0, x, 0x100 + J, 0xf, 0xf, true); }
@@ -285,8 +314,8 @@ __device__ __forceinline__ float run_sum(float val, const RunLinks& r) {
 // BWD_GATHER (dL/dcode and dL/dx only: the table gradient is scattered by ens_scatter_kernel on another stream).
 constexpr int BWD_DENSE = 0, BWD_FACTORED = 1, BWD_GATHER = 2;
 template <int H, int WAVES, int MODE, bool DCODE>
-__global__ __launch_bounds__(WAVES * kWave) void ens_bwd_kernel(
-    const float* __restrict__ x, int64_t B, const uint8_t* __restrict__ tab, const nsx_grid_geom g,
+__device__ __forceinline__ void ens_bwd_body(
+    const float* __restrict__ x, int64_t B, const uint8_t* __restrict__ tab, const nsx_grid_geom& g,
     const float* __restrict__ code, int64_t code_stride, const int32_t* __restrict__ code_index,
     const float* __restrict__ window, int Hreal, const float* __restrict__ dout,
     float* __restrict__ dtab, float* __restrict__ dcode, float* __restrict__ dx, int64_t n_tiles,
@@ -543,15 +572,52 @@ __global__ __launch_bounds__(WAVES * kWave) void ens_bwd_kernel(
     }
 }
 
+template <int H, int WAVES, int MODE, bool DCODE>
+__global__ __launch_bounds__(WAVES * kWave) void ens_bwd_kernel(
+    const float* __restrict__ x, int64_t B, const uint8_t* __restrict__ tab, const nsx_grid_geom g,
+    const float* __restrict__ code, int64_t code_stride, const int32_t* __restrict__ code_index,
+    const float* __restrict__ window, int Hreal, const float* __restrict__ dout,
+    float* __restrict__ dtab, float* __restrict__ dcode, float* __restrict__ dx, int64_t n_tiles,
+    int n_slots, float* __restrict__ nonfinite, const int64_t* __restrict__ n_dev,
+    float* __restrict__ csum_part) {
+    ens_bwd_body<H, WAVES, MODE, DCODE>(x, B, tab, g, code, code_stride, code_index, window, Hreal, dout, dtab, dcode, dx,
+                                        n_tiles, n_slots, nonfinite, n_dev, csum_part);
+}
+
+// The factored backward with in-kernel code-row sums over several sources in one launch (see ens_fwd_sources_kernel):
+// source j adds to ITS gradient planes (src.plane_base[j] ...), has its own code rows (src.rows[j] of them), its own
+// block partials of the code sums and its own dL/dx rows.
+template <int H, int WAVES, bool TABLE_GRAD>
+__global__ __launch_bounds__(WAVES * kWave) void ens_bwd_sources_kernel(
+    const uint8_t* __restrict__ x, const uint8_t* __restrict__ tab, const nsx_grid_geom g,
+    const uint8_t* __restrict__ code, int64_t code_stride, const uint8_t* __restrict__ code_index,
+    const float* __restrict__ window, int Hreal, const uint8_t* __restrict__ dout, float* __restrict__ G,
+    uint8_t* __restrict__ dx, float* __restrict__ nonfinite, const uint8_t* __restrict__ n_dev,
+    float* __restrict__ csum_part, const EnsSources src) {
+    using C = EnsCfg<H>;
+    const int j = blockIdx.y;
+    const int64_t B = src.B[j];
+    const int rows = src.plane_base[j + 1] - src.plane_base[j];
+    float* planes = TABLE_GRAD ? G + (size_t)src.plane_base[j] * (size_t)g.offset[g.n_levels] * 2 : nullptr;
+    ens_bwd_body<H, WAVES, TABLE_GRAD ? BWD_FACTORED : BWD_GATHER, true>(
+        reinterpret_cast<const float*>(x + j * src.x_stride), B, tab, g,
+        reinterpret_cast<const float*>(code + j * src.code_stride), code_stride,
+        reinterpret_cast<const int32_t*>(code_index + j * src.slot_stride), window, Hreal,
+        reinterpret_cast<const float*>(dout + j * src.dout_stride), planes, nullptr,
+        reinterpret_cast<float*>(dx + j * src.dx_stride), (B + C::SPW - 1) / C::SPW, rows,
+        TABLE_GRAD ? nonfinite : nullptr, reinterpret_cast<const int64_t*>(n_dev + j * src.count_stride),
+        csum_part + (size_t)j * src.csum_floats);
+}
+
 // dcode_rows[row][h] = window[h] * sum_blocks part[block][row][h]: the second stage of the in-kernel code-gradient sums
 // (the chain rule through code' = code * window, hash_ensemble.py:133-138, folded in).  One block per code row; 1024 / H
 // groups of H threads walk the ~2000 block partials with four loads in flight each (the walk is latency-bound: 256
 // dependent rounds of 256 threads took 0.1 ms per step), then a tree over the groups.  Fixed order: deterministic sums.
 constexpr int kCodeSumThreads = 1024;
 template <int H>
-__global__ __launch_bounds__(kCodeSumThreads) void code_sums_reduce_kernel(const float* __restrict__ part, int n_blocks,
-                                                                           int n_slots, const float* __restrict__ window,
-                                                                           int Hreal, float* __restrict__ dcode_rows) {
+__device__ __forceinline__ void code_sums_reduce_body(const float* __restrict__ part, int n_blocks, int n_slots,
+                                                      const float* __restrict__ window, int Hreal,
+                                                      float* __restrict__ dcode_rows) {
     __shared__ float red[kCodeSumThreads];
     const int row = blockIdx.x;
     constexpr int G = kCodeSumThreads / H;             // block-partials walked in parallel
@@ -575,6 +641,25 @@ __global__ __launch_bounds__(kCodeSumThreads) void code_sums_reduce_kernel(const
         __syncthreads();
     }
     if (grp == 0 && h < Hreal) dcode_rows[(size_t)row * Hreal + h] = red[h] * (window ? window[h] : 1.0f);
+}
+
+template <int H>
+__global__ __launch_bounds__(kCodeSumThreads) void code_sums_reduce_kernel(const float* __restrict__ part, int n_blocks,
+                                                                           int n_slots, const float* __restrict__ window,
+                                                                           int Hreal, float* __restrict__ dcode_rows) {
+    code_sums_reduce_body<H>(part, n_blocks, n_slots, window, Hreal, dcode_rows);
+}
+
+// grid (most rows of a source, sources): the second stage of ens_bwd_sources_kernel's code sums
+template <int H>
+__global__ __launch_bounds__(kCodeSumThreads) void code_sums_reduce_sources_kernel(
+    const float* __restrict__ part, int n_blocks, const float* __restrict__ window, int Hreal,
+    uint8_t* __restrict__ dcode_rows, const EnsSources src) {
+    const int j = blockIdx.y;
+    const int rows = src.plane_base[j + 1] - src.plane_base[j];
+    if ((int)blockIdx.x >= rows) return;
+    code_sums_reduce_body<H>(part + (size_t)j * src.csum_floats, n_blocks, rows, window, Hreal,
+                             reinterpret_cast<float*>(dcode_rows + j * src.rows_stride));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -842,6 +927,67 @@ static int launch_bwd(const float* x, int64_t B, const nsx_half* tables, int Hre
     return NSX_OK;
 }
 
+template <int H>
+static int launch_fwd_sources(int W, const EnsSources& src, const void* x, const nsx_half* tables, int Hreal,
+                              const nsx_grid_geom* g, const void* code, int64_t code_row_stride, const void* code_slot,
+                              const float* window, void* out, const void* n_dev, hipStream_t st) {
+    using C = EnsCfg<H>;
+    constexpr int WAVES = 4;
+    int64_t most = 0;
+    for (int j = 0; j < W; ++j) most = src.B[j] > most ? src.B[j] : most;
+    if (most == 0) return NSX_OK;
+    int64_t blocks = ((most + C::SPW - 1) / C::SPW + WAVES - 1) / WAVES;
+    int64_t cap = (int64_t)num_cus() * 8 / W;
+    if (cap < 1) cap = 1;
+    if (blocks > cap) blocks = cap;
+    const size_t smem = (size_t)WAVES * C::SPW * (g->n_levels + 4) * sizeof(uint32_t);
+    hipLaunchKernelGGL((ens_fwd_sources_kernel<H, WAVES>), dim3((unsigned)blocks, (unsigned)W), dim3(WAVES * kWave), smem, st,
+                       reinterpret_cast<const uint8_t*>(x), reinterpret_cast<const uint8_t*>(tables), *g,
+                       reinterpret_cast<const uint8_t*>(code), code_row_stride, reinterpret_cast<const uint8_t*>(code_slot),
+                       window, Hreal, reinterpret_cast<uint8_t*>(out), reinterpret_cast<const uint8_t*>(n_dev), src);
+    NSX_LAUNCH_CHECK("ens_fwd_sources launch");
+    return NSX_OK;
+}
+
+template <int H>
+static int launch_bwd_sources(int W, EnsSources& src, const void* x, const nsx_half* tables, int Hreal,
+                              const nsx_grid_geom* g, const void* code, int64_t code_row_stride, const void* code_slot,
+                              const float* window, const void* dout, float* G, void* dx, float* nonfinite, const void* n_dev,
+                              float* csum_part, int64_t csum_capacity, void* dcode_rows, hipStream_t st) {
+    using C = EnsCfg<H>;
+    constexpr int WAVES = 4;
+    int64_t most = 0;
+    int most_rows = 1;
+    for (int j = 0; j < W; ++j) {
+        most = src.B[j] > most ? src.B[j] : most;
+        const int rows = src.plane_base[j + 1] - src.plane_base[j];
+        most_rows = rows > most_rows ? rows : most_rows;
+    }
+    int64_t blocks = ((most + C::SPW - 1) / C::SPW + WAVES - 1) / WAVES;
+    int64_t cap = (int64_t)num_cus() * 8 / W;
+    if (cap < 1) cap = 1;
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;                     // sources without samples still get their (zero) code sums written
+    src.csum_floats = blocks * most_rows * H;
+    NSX_REQUIRE(src.csum_floats * W <= csum_capacity, "ens_bwd_sources: the code-sum scratch holds %lld floats, %lld needed",
+                (long long)csum_capacity, (long long)(src.csum_floats * W));
+    const size_t smem = (size_t)(C::SPW == 8 ? WAVES : 1) * most_rows * H * sizeof(float);
+#define NSX_BWD_SOURCES(TG)                                                                                                \
+    hipLaunchKernelGGL((ens_bwd_sources_kernel<H, WAVES, TG>), dim3((unsigned)blocks, (unsigned)W), dim3(WAVES * kWave), smem, \
+                       st, reinterpret_cast<const uint8_t*>(x), reinterpret_cast<const uint8_t*>(tables), *g,              \
+                       reinterpret_cast<const uint8_t*>(code), code_row_stride, reinterpret_cast<const uint8_t*>(code_slot), \
+                       window, Hreal, reinterpret_cast<const uint8_t*>(dout), G, reinterpret_cast<uint8_t*>(dx), nonfinite, \
+                       reinterpret_cast<const uint8_t*>(n_dev), csum_part, src)
+    if (G) NSX_BWD_SOURCES(true);
+    else NSX_BWD_SOURCES(false);
+#undef NSX_BWD_SOURCES
+    NSX_LAUNCH_CHECK("ens_bwd_sources launch");
+    hipLaunchKernelGGL((code_sums_reduce_sources_kernel<H>), dim3((unsigned)most_rows, (unsigned)W), dim3(kCodeSumThreads),
+                       0, st, csum_part, (int)blocks, window, Hreal, reinterpret_cast<uint8_t*>(dcode_rows), src);
+    NSX_LAUNCH_CHECK("ens_bwd_sources reduce launch");
+    return NSX_OK;
+}
+
 static int check_geom(const nsx_grid_geom* g, int Hp, const char* who) {
     NSX_REQUIRE(g != nullptr, "%s: geometry is NULL", who);
     NSX_REQUIRE(g->n_levels >= 1 && g->n_levels <= NSX_MAX_LEVELS, "%s: bad n_levels %d", who, g->n_levels);
@@ -858,6 +1004,53 @@ static int launch_expand(const float* G, int n_slots, const float* code, int64_t
                        code_stride, window, H, total, dtables, accumulate);
     NSX_LAUNCH_CHECK("nsx_hash_grad_expand launch");
     return NSX_OK;
+}
+
+static int check_sources(int W, const EnsSources& src, const nsx_grid_geom* g, int H, const char* who) {
+    NSX_REQUIRE(W >= 1 && W <= NSX_MAX_LEVELS, "%s: %d sources not in [1,%d]", who, W, NSX_MAX_LEVELS);
+    NSX_REQUIRE(H >= 1 && H <= 32, "%s: H=%d not in [1,32]", who, H);
+    if (int rc = check_geom(g, nsx_padded_grids(H), who)) return rc;
+    for (int j = 0; j < W; ++j) {
+        const int rows = src.plane_base[j + 1] - src.plane_base[j];
+        NSX_REQUIRE(src.B[j] >= 0 && rows >= 1 && rows <= NSX_MAX_SLOTS, "%s: source %d brings %lld samples, %d code rows",
+                    who, j, (long long)src.B[j], rows);
+    }
+    return NSX_OK;
+}
+
+int ens_fwd_sources(int W, const EnsSources& src, const void* x, const nsx_half* tables, int H, const nsx_grid_geom* g,
+                    const void* code, int64_t code_row_stride, const void* code_slot, const float* window, void* out,
+                    const void* n_dev, hipStream_t st) {
+    if (int rc = check_sources(W, src, g, H, "ens_fwd_sources")) return rc;
+    NSX_REQUIRE(x && tables && code && code_slot && out && n_dev, "ens_fwd_sources: NULL argument");
+    switch (nsx_padded_grids(H)) {
+#define NSX_FS_CASE(HP) case HP: return launch_fwd_sources<HP>(W, src, x, tables, H, g, code, code_row_stride, code_slot, \
+                                                               window, out, n_dev, st);
+        NSX_FS_CASE(1) NSX_FS_CASE(2) NSX_FS_CASE(4) NSX_FS_CASE(8) NSX_FS_CASE(16) NSX_FS_CASE(32)
+#undef NSX_FS_CASE
+    }
+    set_error("ens_fwd_sources: unsupported H=%d", H);
+    return NSX_ERR_UNSUPPORTED;
+}
+
+int ens_bwd_sources(int W, EnsSources& src, const void* x, const nsx_half* tables, int H, const nsx_grid_geom* g,
+                    const void* code, int64_t code_row_stride, const void* code_slot, const float* window, const void* dout,
+                    float* G, void* dx, float* nonfinite, const void* n_dev, float* csum_part, int64_t csum_capacity,
+                    void* dcode_rows, hipStream_t st) {
+    if (int rc = check_sources(W, src, g, H, "ens_bwd_sources")) return rc;
+    NSX_REQUIRE(x && tables && code && code_slot && dout && dx && n_dev && csum_part && dcode_rows,
+                "ens_bwd_sources: NULL argument");
+    // the duplicate-merging key packs (entry, slot) into 32 bits: ((offset + index) << 6) | slot
+    NSX_REQUIRE(!G || g->offset[g->n_levels] < (1u << 26), "ens_bwd_sources: more than 2^26 entries");
+    switch (nsx_padded_grids(H)) {
+#define NSX_BS_CASE(HP) case HP: return launch_bwd_sources<HP>(W, src, x, tables, H, g, code, code_row_stride, code_slot, \
+                                                               window, dout, G, dx, nonfinite, n_dev, csum_part,         \
+                                                               csum_capacity, dcode_rows, st);
+        NSX_BS_CASE(1) NSX_BS_CASE(2) NSX_BS_CASE(4) NSX_BS_CASE(8) NSX_BS_CASE(16) NSX_BS_CASE(32)
+#undef NSX_BS_CASE
+    }
+    set_error("ens_bwd_sources: unsupported H=%d", H);
+    return NSX_ERR_UNSUPPORTED;
 }
 
 }  // namespace nsx

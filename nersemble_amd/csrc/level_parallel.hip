@@ -261,6 +261,17 @@ int nsx_lp_fwd_run(const nsx_lp_layout* lay, const uint8_t* gathered, const int6
                            codes_packed);
         NSX_LAUNCH_CHECK("nsx_lp_fwd_run (codes)");
     }
+    if (option(NSX_OPT_LP_ONE_LAUNCH)) {
+        // every source rank's samples in ONE launch (grid.y = source rank): a source's samples on the few owned levels are
+        // one or two tiles per wave, W launches of their own are W launch latencies back to back
+        EnsSources src{};
+        src.x_stride = src.slot_stride = src.count_stride = src.code_stride = lay->fwd_bytes;
+        src.out_stride = lay->feat_bytes;
+        for (int j = 0; j < lay->W; ++j) { src.B[j] = sizes_host[j]; src.plane_base[j] = pre.base[j]; }
+        src.plane_base[lay->W] = pre.base[lay->W];
+        return ens_fwd_sources(lay->W, src, gathered + lay->f_pn, tables, lay->H, sub_geom, gathered + lay->f_codes, lay->H,
+                               gathered + lay->f_slot, window, send, gathered + lay->f_count, (hipStream_t)stream);
+    }
     for (int j = 0; j < lay->W; ++j) {
         if (sizes_host[j] == 0) continue;
         const uint8_t* blk = gathered + (int64_t)j * lay->fwd_bytes;
@@ -313,6 +324,27 @@ int nsx_lp_bwd_run(const nsx_lp_layout* lay, const uint8_t* recv, const uint8_t*
                        (hipStream_t)stream, recv, dz_scratch, ret, *lay);
     NSX_LAUNCH_CHECK("nsx_lp_bwd_run (arrive)");
     const int64_t entries = sub_geom->offset[sub_geom->n_levels];
+    if (option(NSX_OPT_LP_ONE_LAUNCH)) {
+        EnsSources src{};
+        src.x_stride = src.slot_stride = src.count_stride = lay->bwd_bytes;
+        src.code_stride = lay->fwd_bytes;
+        src.dout_stride = lay->S_cap * lay->n2 * (int64_t)sizeof(float);
+        src.dx_stride = src.rows_stride = lay->ret_bytes;
+        src.plane_base[0] = 0;
+        for (int j = 0; j < lay->W; ++j) {
+            NSX_REQUIRE(sizes_host[j] >= 0 && sizes_host[j] <= lay->S_cap && rows_host[j] >= 1 && rows_host[j] <= lay->R_cap,
+                        "nsx_lp_bwd_run: rank %d brings S=%lld rows=%d beyond the layout's capacities", j,
+                        (long long)sizes_host[j], rows_host[j]);
+            src.B[j] = sizes_host[j];
+            src.plane_base[j + 1] = src.plane_base[j] + rows_host[j];
+        }
+        NSX_REQUIRE(src.plane_base[lay->W] <= NSX_MAX_ADAM_SLOTS, "nsx_lp_bwd_run: %d code rows in the job's batch (limit %d)",
+                    src.plane_base[lay->W], NSX_MAX_ADAM_SLOTS);
+        return ens_bwd_sources(lay->W, src, recv + lay->b_pn, tables, lay->H, sub_geom, gathered + lay->f_codes, lay->H,
+                               recv + lay->b_slot, window, dz_scratch, G, ret + lay->r_dx, G ? nonfinite : nullptr,
+                               recv + lay->b_count, csum_scratch, nsx_hash_codesum_scratch_floats(lay->R_cap, lay->H),
+                               ret + lay->r_dcode, (hipStream_t)stream);
+    }
     int plane = 0;
     for (int j = 0; j < lay->W; ++j) {
         const int rows = rows_host[j];

@@ -57,6 +57,24 @@ __device__ __forceinline__ uint32_t umod(uint32_t idx, uint32_t size, float inv_
     return (uint32_t)r;
 }
 
+// Several sample sets in one launch of the HashEnsemble kernels (hash_ensemble.hip: ens_*_sources_kernel; the caller is
+// level_parallel.hip).  Source j's arrays start j * stride BYTES behind source 0's; B[j] is its capacity (the valid count
+// is read from its device counter), plane_base[j] its first gradient plane, plane_base[j + 1] - plane_base[j] its code rows.
+struct EnsSources {
+    int64_t x_stride, slot_stride, count_stride, code_stride, out_stride, dout_stride, dx_stride, rows_stride;
+    int64_t csum_floats;                        // block partials of the code sums per source (set by the launcher)
+    int64_t B[NSX_MAX_LEVELS];
+    int32_t plane_base[NSX_MAX_LEVELS + 1];
+};
+int ens_fwd_sources(int n_sources, const EnsSources& src, const void* x, const nsx_half* tables, int H, const nsx_grid_geom* g,
+                    const void* code, int64_t code_row_stride, const void* code_slot, const float* window, void* out,
+                    const void* n_dev, hipStream_t st);
+// G may be NULL (no table gradient: the gather half alone); csum_part holds csum_capacity floats
+int ens_bwd_sources(int n_sources, EnsSources& src, const void* x, const nsx_half* tables, int H, const nsx_grid_geom* g,
+                    const void* code, int64_t code_row_stride, const void* code_slot, const float* window, const void* dout,
+                    float* G, void* dx, float* nonfinite, const void* n_dev, float* csum_part, int64_t csum_capacity,
+                    void* dcode_rows, hipStream_t st);
+
 inline int num_cus() {
     static int cus = 0;
     if (!cus) {

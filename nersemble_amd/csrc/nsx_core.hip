@@ -9,8 +9,8 @@
 namespace nsx {
 
 // launch-shape options (include/nsx.h): value, lowest and highest admissible value
-static std::atomic<int> g_opt[NSX_OPT_COUNT] = {{5}, {2}, {2}};
-static const int g_opt_lo[NSX_OPT_COUNT] = {1, 1, 1}, g_opt_hi[NSX_OPT_COUNT] = {8, 8, 8};
+static std::atomic<int> g_opt[NSX_OPT_COUNT] = {{5}, {2}, {2}, {1}};
+static const int g_opt_lo[NSX_OPT_COUNT] = {1, 1, 1, 0}, g_opt_hi[NSX_OPT_COUNT] = {8, 8, 8, 1};
 
 int option(int which) { return g_opt[which].load(std::memory_order_relaxed); }
 

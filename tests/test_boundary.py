@@ -59,6 +59,11 @@ def test_launch_shape_options_are_explicit_and_checked():
         assert L.nsx_set_option(opt, 0) != 0 and b"takes" in L.nsx_last_error()       # out of range: refused, value kept
         assert L.nsx_set_option(opt, 9) != 0 and L.nsx_get_option(opt) == 4
         assert L.nsx_set_option(opt, dflt) == 0
+    opt = _lib.NSX_OPT_LP_ONE_LAUNCH                       # a switch: 0 / 1, on by default
+    assert L.nsx_get_option(opt) == 1
+    assert L.nsx_set_option(opt, 0) == 0 and L.nsx_get_option(opt) == 0
+    assert L.nsx_set_option(opt, 2) != 0 and L.nsx_set_option(opt, -1) != 0 and L.nsx_get_option(opt) == 0
+    assert L.nsx_set_option(opt, 1) == 0
     assert L.nsx_set_option(99, 1) != 0 and L.nsx_get_option(99) < 0
 
 

@@ -632,6 +632,102 @@ def test_emulated_level_parallel_rank_through_rccl(cuda, single_rank_group):
     assert bool((dx2[kept:] == 7.0).all()) and torch.allclose(dx2[:kept], dx[:kept])
 
 
+@pytest.mark.parametrize("H,table_grad", [(32, True), (8, True), (32, False)])
+def test_all_source_ranks_in_one_launch_equal_one_launch_per_source_rank(H, table_grad, cuda):
+    """``nsx_lp_fwd_run`` / ``nsx_lp_bwd_run`` with NSX_OPT_LP_ONE_LAUNCH (grid.y = source rank) against the per-source-rank
+    launches of the unchanged kernels, on RAGGED sources: different sample counts, device-side counts below the capacity,
+    different numbers of code rows, one source without samples.  Forward columns bit for bit; gradient planes, dL/dx and
+    code-row gradients up to the order of the additions."""
+    import ctypes as C
+    from nersemble_amd import _lib, functional as F
+    from nersemble_amd._lib import check, lib, ptr, stream
+    from nersemble_amd.engine.level_parallel import NativeLPOps, sub_geometry_levels
+    he = _he(H, cuda)
+    levels = [1, 4]
+    geom = sub_geometry_levels(he.geom, levels)
+    n_e = int(geom.offset[2])
+    n2 = 4
+    cut = torch.cat([he.half_tables()[int(he.geom.offset[l]):int(he.geom.offset[l + 1])] for l in levels]).contiguous()
+    assert cut.shape[0] == n_e
+    W, R_cap = 5, 7
+    sizes = [2900, 0, 3001, 17, 1500]              # capacities (the marcher's counts)
+    counts = [2500, 0, 3001, 9, 1]                 # valid rows on the device
+    rows = [5, 1, 7, 2, 3]
+    S_cap = max(sizes)
+    lay = NativeLPOps.layout(W, S_cap, R_cap, H, n2)
+    g = torch.Generator(device=cuda).manual_seed(11)
+    window = torch.rand((H,), device=cuda, generator=g)
+    gathered = torch.zeros((W * lay.fwd_bytes,), dtype=torch.uint8, device=cuda)
+    recv = torch.zeros((W * lay.bwd_bytes,), dtype=torch.uint8, device=cuda)
+    tmp = torch.zeros((W * lay.bwd_bytes,), dtype=torch.uint8, device=cuda)
+    src = []
+    for j in range(W):
+        S = sizes[j]
+        x = torch.rand((max(S, 1), 3), device=cuda, generator=g)
+        x[: S // 2] = x[:1] + 1e-3 * torch.rand((S // 2, 3), device=cuda, generator=g)     # neighbours share cells
+        x.clamp_(0, 0.999)
+        slot = torch.randint(0, rows[j], (max(S, 1),), device=cuda, generator=g, dtype=torch.int32)
+        code = torch.randn((rows[j], H), device=cuda, generator=g)
+        dout = (torch.randn((max(S, 1), W * n2), device=cuda, generator=g) * 3).half().float()
+        n_dev = torch.tensor([counts[j]], dtype=torch.int64, device=cuda)
+        NativeLPOps.fwd_pack(lay, x, slot, S, n_dev, code, rows[j], gathered[j * lay.fwd_bytes:])
+        NativeLPOps.bwd_pack(lay, dout, x, slot, S, n_dev, tmp)              # block 0 of `tmp`: what owner 0 receives
+        recv[j * lay.bwd_bytes:(j + 1) * lay.bwd_bytes] = tmp[:lay.bwd_bytes]
+        src.append((x, slot, code, dout, n_dev))
+
+    class Ex:
+        sizes_host = (C.c_int64 * W)(*sizes)
+        rows_host = (C.c_int32 * W)(*rows)
+    planes = sum(rows)
+
+    def run(one_launch):
+        check(lib().nsx_set_option(_lib.NSX_OPT_LP_ONE_LAUNCH, one_launch), "option")
+        try:
+            send = torch.full((W * lay.feat_bytes,), 0x5A, dtype=torch.uint8, device=cuda)
+            codes_packed = torch.zeros((planes, H), device=cuda)
+            NativeLPOps.fwd_run(lay, gathered, Ex, cut, geom, window, send, codes_packed)
+            G = torch.zeros((planes, n_e, 2), device=cuda) if table_grad else None
+            ret = torch.full((W * lay.ret_bytes,), 0x5A, dtype=torch.uint8, device=cuda)
+            nonfinite = torch.zeros((1,), device=cuda)
+            dz = torch.zeros((W * S_cap * n2,), device=cuda)
+            NativeLPOps.bwd_run(lay, recv, gathered, Ex, cut, geom, window, G, ret, nonfinite, dz)
+            torch.cuda.synchronize()
+            return send, codes_packed, G, ret
+        finally:
+            check(lib().nsx_set_option(_lib.NSX_OPT_LP_ONE_LAUNCH, 1), "option")
+
+    send1, cp1, G1, ret1 = run(1)
+    send0, cp0, G0, ret0 = run(0)
+    assert torch.equal(cp1, cp0)
+    at = 0
+    for j in range(W):
+        n = counts[j]
+        f1 = send1[j * lay.feat_bytes:(j + 1) * lay.feat_bytes].view(torch.float16)[: n * n2]
+        f0 = send0[j * lay.feat_bytes:(j + 1) * lay.feat_bytes].view(torch.float16)[: n * n2]
+        assert torch.equal(f1, f0), f"forward columns of source {j}"
+        if n:
+            x, slot, code, dout, n_dev = src[j]
+            want = F._hash_ensemble_fwd_raw(x[:n], cut, H, geom, code, slot[:n], window)
+            assert torch.equal(f1.view(n, n2), want)
+        r1 = ret1[j * lay.ret_bytes:(j + 1) * lay.ret_bytes]
+        r0 = ret0[j * lay.ret_bytes:(j + 1) * lay.ret_bytes]
+        dx1 = r1[lay.r_dx:lay.r_dx + n * 12].view(torch.float32)
+        dx0 = r0[lay.r_dx:lay.r_dx + n * 12].view(torch.float32)
+        dc1 = r1[lay.r_dcode:lay.r_dcode + rows[j] * H * 4].view(torch.float32)
+        dc0 = r0[lay.r_dcode:lay.r_dcode + rows[j] * H * 4].view(torch.float32)
+        if n:
+            assert torch.allclose(dx1, dx0, rtol=1e-5, atol=1e-6 * float(dx0.abs().max()))
+            assert torch.allclose(dc1, dc0, rtol=1e-4, atol=2e-6 * float(dc0.abs().max()) + 1e-30)
+            assert float(dc0.abs().max()) > 0
+        else:
+            assert float(dc1.abs().max()) == 0 and float(dc0.abs().max()) == 0
+        if table_grad:
+            a, b = G1[at:at + rows[j]], G0[at:at + rows[j]]
+            assert float((a - b).abs().max()) <= 2e-5 * max(float(b.abs().max()), 1e-30)
+            assert (n == 0) == (float(b.abs().max()) == 0)
+        at += rows[j]
+
+
 def test_emulated_rank_7_of_8_trains_through_the_native_step(cuda, single_rank_group):
     """``NeRSembleTrainer(level_parallel_emulation=(8, 7))``: the training step of the finest levels' owner of an 8-rank job on
     one GPU -- native step drivers split at the exchange, four device collectives + one host-side size exchange per step on
