@@ -697,6 +697,10 @@ def main():
     ap.add_argument("--lp-launch-per-source", action="store_true",
                     help="level-parallel runs: one HashEnsemble launch per source rank (NSX_OPT_LP_ONE_LAUNCH = 0) instead of "
                          "all source ranks in one launch -- the A/B switch of that change")
+    ap.add_argument("--lp-torch-collectives", action="store_true",
+                    help="level-parallel runs: the exchange's collectives through torch.distributed (five calls per step with "
+                         "Python in between) instead of the library's own RCCL communicator (one C call per direction) -- "
+                         "the A/B switch of that change")
     ap.add_argument("--no-kernels-alone", action="store_true", help="skip the stand-alone kernel timings after the run")
     ap.add_argument("--with-datamanager", action="store_true",
                     help="draw every batch INSIDE the timed loop through NeRSembleVanillaDataManager.next_train (24-image "
@@ -718,6 +722,9 @@ def main():
         a.no_first_grid_phase = a.no_open_window = a.no_with_datamanager = True
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(a, sys.argv[1:]))
+    if a.lp_torch_collectives:
+        from nersemble_amd.engine import level_parallel as _lpm
+        _lpm.NATIVE_COLLECTIVES = False
     if a.lp_launch_per_source:
         from nersemble_amd import _lib
         _lib.check(_lib.lib().nsx_set_option(_lib.NSX_OPT_LP_ONE_LAUNCH, 0), "nsx_set_option")

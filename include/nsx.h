@@ -32,7 +32,7 @@ extern "C" {
 #define NSX_MAX_SLOTS 64
 #define NSX_MAX_ADAM_SLOTS 192   /* gradient planes nsx_adam_hash_factored(_consume) reads (level-parallel runs: one per
                                    (source rank, code row), engine/level_parallel.py) */
-#define NSX_VERSION 125
+#define NSX_VERSION 126
 
 typedef uint16_t nsx_half;
 
@@ -891,16 +891,18 @@ int nsx_step_echo(int kind, const void* s, double* out, int capacity);
  * rank r of W owns levels [r L / W, (r + 1) L / W) of all H grids -- a contiguous entry range of the [entry][f][h] tables --
  * and evaluates / differentiates them for EVERY rank's samples.  The columns out[:, 2 l + f] of HashEnsemble.forward
  * (hash_ensemble.py:93-158) depend on level l's entries only, so samples travel and parameters do not.  The binding issues
- * four collectives per step on byte buffers whose layout nsx_lp_layout_make fixes; everything in between is enqueued by the
- * entry points below (the per-source-rank kernels are the UNCHANGED nsx_hash_ensemble_fwd / _bwd_codesum on a sub-geometry).
+ * four collectives per step on byte buffers whose layout nsx_lp_layout_make fixes (or lets the library issue them:
+ * nsx_lp_forward / nsx_lp_backward below); everything in between is enqueued by the entry points below (the per-source-rank
+ * work is the UNCHANGED nsx_hash_ensemble_fwd / _bwd_codesum kernel body on a sub-geometry).
  *
  *   1. nsx_lp_fwd_pack    this rank's [count | positions | code slots | conditioned code rows]   -> ALL-GATHER (fwd_bytes)
- *   2. nsx_lp_fwd_run     W launches: the owned levels for the samples of source rank j -> block j of `send`
+ *   2. nsx_lp_fwd_run     ONE launch over all W source ranks (grid.y = source rank; NSX_OPT_LP_ONE_LAUNCH = 0: W launches):
+ *                         the owned levels for the samples of source rank j -> block j of `send`
  *                                                                                               -> ALL-TO-ALL (feat_bytes)
  *   3. nsx_lp_fwd_unpack  column blocks -> features [S][2 L] fp16
  *   4. nsx_lp_bwd_pack    [count | dL/dfeatures column block fp16 | positions | slots] for every owner
  *                                                                                               -> ALL-TO-ALL (bwd_bytes)
- *   5. nsx_lp_bwd_run     W launches: factored table gradient of the owned entries into the planes of source rank j
+ *   5. nsx_lp_bwd_run     one launch (as 2.): factored table gradient of the owned entries into the planes of source rank j
  *                         (plane = sum of the code rows of ranks < j, + code row), partial dL/dx and partial code-row
  *                         gradient into block j of `ret`                                        -> ALL-TO-ALL (ret_bytes)
  *   6. nsx_lp_bwd_unpack  partials summed over the owners (fixed order) -> dL/dx [S][3], dL/dcode [rows][H]
@@ -955,6 +957,40 @@ int nsx_lp_bwd_run(const nsx_lp_layout* lay, const uint8_t* recv, const uint8_t*
                    float* G, float* dz_scratch, float* csum_scratch, uint8_t* ret, float* nonfinite, void* stream);
 int nsx_lp_bwd_unpack(const nsx_lp_layout* lay, const uint8_t* ret_recv, int64_t S, const int64_t* n_device, int rows,
                       float* dx, float* dcode, void* stream);
+
+/* ---- collectives issued by the library (csrc/comm.hip) --------------------------------------------------------------------
+ * The level-parallel exchange above with its collectives enqueued from C: one call per direction puts
+ * pack -> collective -> kernels -> collective -> unpack on the caller's stream (the binding otherwise pays five
+ * torch.distributed calls and the Python between them per step -- on a rank whose step takes ~2 ms that was what it waited
+ * for).  An nsx_comm is an RCCL communicator owned by the library: rank 0 of the job draws nsx_comm_unique_id, the binding
+ * carries the NSX_COMM_ID_BYTES bytes to every process (any host-side channel), every process calls nsx_comm_create with the
+ * HIP device current that it computes on (collective: returns when all ranks have joined).  RCCL is resolved at run time from
+ * the librccl.so.1 the process already holds (PyTorch's); nsx_comm_library names another file, before first use.
+ * nsx_lp_forward / nsx_lp_backward take the arguments of the six nsx_lp_* calls they chain (same buffers, same layouts) plus
+ * the receive buffers; emulate_rank >= 0: the communicator has ONE rank and this process plays rank emulate_rank of lay->W
+ * whose other ranks are replicas of it (what a rank of a W-GPU job computes and issues, on one GPU); -1: a real job. */
+#define NSX_COMM_ID_BYTES 128
+typedef struct nsx_comm nsx_comm;
+int nsx_comm_library(const char* path);
+int nsx_comm_unique_id(uint8_t* id128);
+int nsx_comm_create(const uint8_t* id128, int world_size, int rank, nsx_comm** out);
+int nsx_comm_destroy(nsx_comm* comm);
+int nsx_comm_world_size(const nsx_comm* comm);
+int nsx_comm_rank(const nsx_comm* comm);
+/* in-place sum over the ranks of `count` floats (the bucket of the small gradients, engine/parallel.py) */
+int nsx_comm_all_reduce_sum(nsx_comm* comm, float* data, int64_t count, void* stream);
+/* payload: [fwd_bytes]; gathered: [W][fwd_bytes] (kept until the backward); send, recv: [W][feat_bytes]; feats: fp16 [S][2 L] */
+int nsx_lp_forward(const nsx_lp_layout* lay, nsx_comm* comm, int emulate_rank, const float* pn, const int32_t* slot, int64_t S,
+                   const int64_t* n_device, const float* codes, int64_t code_stride, int rows, uint8_t* payload,
+                   uint8_t* gathered, const int64_t* sizes_host, const int32_t* rows_host, const nsx_half* tables,
+                   const nsx_grid_geom* sub_geom, const float* window, uint8_t* send, float* codes_packed, uint8_t* recv,
+                   nsx_half* feats, void* stream);
+/* send, recv: [W][bwd_bytes]; ret, ret_recv: [W][ret_bytes]; the rest as nsx_lp_bwd_pack / _run / _unpack */
+int nsx_lp_backward(const nsx_lp_layout* lay, nsx_comm* comm, int emulate_rank, const float* dout, const float* pn,
+                    const int32_t* slot, int64_t S, const int64_t* n_device, uint8_t* send, uint8_t* recv,
+                    const uint8_t* gathered, const int64_t* sizes_host, const int32_t* rows_host, const nsx_half* tables,
+                    const nsx_grid_geom* sub_geom, const float* window, float* G, float* dz_scratch, float* csum_scratch,
+                    uint8_t* ret, uint8_t* ret_recv, float* nonfinite, int rows, float* dx, float* dcode, void* stream);
 
 #ifdef __cplusplus
 }

@@ -12,6 +12,7 @@ NSX_MAX_GATHER = 8
 NSX_MAX_ADAM_SLOTS = 192
 NSX_OPT_ADAM_BLOCKS_PER_CU, NSX_OPT_MLP_BWD_HALF_BLOCKS_PER_CU, NSX_OPT_MLP_BWD0_HALF_BLOCKS_PER_CU = 0, 1, 2
 NSX_OPT_LP_ONE_LAUNCH = 3
+NSX_COMM_ID_BYTES = 128
 
 c_void_p, c_int, c_int64, c_float = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
@@ -211,6 +212,20 @@ SIGNATURES = {
     "nsx_lp_bwd_run": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, _GEOM_P, c_void_p, c_void_p,
                                c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "nsx_lp_bwd_unpack": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    # collectives issued by the library (csrc/comm.hip)
+    "nsx_comm_library": (c_int, [C.c_char_p]),
+    "nsx_comm_unique_id": (c_int, [c_void_p]),
+    "nsx_comm_create": (c_int, [c_void_p, c_int, c_int, C.POINTER(c_void_p)]),
+    "nsx_comm_destroy": (c_int, [c_void_p]),
+    "nsx_comm_world_size": (c_int, [c_void_p]),
+    "nsx_comm_rank": (c_int, [c_void_p]),
+    "nsx_comm_all_reduce_sum": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "nsx_lp_forward": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int,
+                               c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, _GEOM_P, c_void_p, c_void_p, c_void_p,
+                               c_void_p, c_void_p, c_void_p]),
+    "nsx_lp_backward": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p,
+                                c_void_p, c_void_p, c_void_p, c_void_p, _GEOM_P, c_void_p, c_void_p, c_void_p, c_void_p,
+                                c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
 }
 
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "nsx.h")

@@ -105,6 +105,10 @@ def _as(t: torch.Tensor, dtype) -> torch.Tensor:
     return t.detach().to(dtype).contiguous()
 
 
+NATIVE_COLLECTIVES: Optional[bool] = None     # None: the library's own collectives wherever the group is an RCCL one; False:
+#                                               torch.distributed everywhere (bench.py --lp-torch-collectives, the A/B switch)
+
+
 class NativeLPOps:
     """The device side of the exchange: csrc/level_parallel.hip through the C ABI (include/nsx.h, "level-parallel exchange").
     Tests substitute a torch restatement to run the collectives' plumbing on CPU over gloo (tests/test_parallel_cpu.py)."""
@@ -145,6 +149,25 @@ class NativeLPOps:
     def bwd_unpack(lay, ret_recv, S, n_dev, rows, dx, dcode) -> None:
         check(lib().nsx_lp_bwd_unpack(C.byref(lay), ptr(ret_recv), int(S), ptr(n_dev), int(rows), ptr(dx), ptr(dcode),
                                       stream()), "nsx_lp_bwd_unpack")
+
+    # the same six steps with their collectives issued from C (csrc/comm.hip): one call per direction
+    @staticmethod
+    def forward(lay, comm, emulate_rank, x, slot, S, n_dev, codes, rows, payload, gathered, ex, tables, geom, window, send,
+                codes_packed, recv, feats) -> None:
+        check(lib().nsx_lp_forward(C.byref(lay), comm, int(emulate_rank), ptr(x), ptr(slot), int(S), ptr(n_dev), ptr(codes),
+                                   codes.stride(0), int(rows), ptr(payload), ptr(gathered), ex.sizes_host, ex.rows_host,
+                                   ptr(tables), C.byref(geom), ptr(window), ptr(send), ptr(codes_packed), ptr(recv), ptr(feats),
+                                   stream()), "nsx_lp_forward")
+
+    @staticmethod
+    def backward(lay, comm, emulate_rank, dout, x, slot, S, n_dev, send, recv, gathered, ex, tables, geom, window, G, dz, ret,
+                 ret_recv, nonfinite, rows, dx, dcode) -> None:
+        dev = recv.device
+        check(lib().nsx_lp_backward(C.byref(lay), comm, int(emulate_rank), ptr(dout), ptr(x), ptr(slot), int(S), ptr(n_dev),
+                                    ptr(send), ptr(recv), ptr(gathered), ex.sizes_host, ex.rows_host, ptr(tables),
+                                    C.byref(geom), ptr(window), ptr(G), ptr(dz), ptr(F.codesum_scratch(lay.R_cap, lay.H, dev)),
+                                    ptr(ret), ptr(ret_recv), ptr(nonfinite), int(rows), ptr(dx), ptr(dcode), stream()),
+              "nsx_lp_backward")
 
     @staticmethod
     def shared_columns(x, S, tables, H, geom, code, slot, window, cols) -> None:
@@ -187,7 +210,7 @@ class LevelParallel:
     model's."""
 
     def __init__(self, he: HashEnsemble, world_size: int, rank: int, group=None, emulate: bool = False, ops=None,
-                 balanced: bool = True):
+                 balanced: bool = True, native_collectives: Optional[bool] = None):
         L = int(he.geom.n_levels)
         if world_size < 2 or L % world_size != 0:
             raise ValueError(f"level-parallel tables need a world size that divides the {L} levels (got {world_size})")
@@ -213,6 +236,19 @@ class LevelParallel:
         self.cpu_group = group if backend == "gloo" else dist.new_group(backend="gloo")
         if self.emulate and dist.get_world_size(group) != 1:
             raise ValueError("an emulated rank runs on a one-rank process group")
+        # RCCL runs: the exchange's collectives are issued by the library itself (csrc/comm.hip: an RCCL communicator of its
+        # own, one C call per direction that enqueues pack -> collective -> kernels -> collective -> unpack) instead of five
+        # torch.distributed calls per step with Python in between -- ~0.35 ms of host time on a rank whose step takes ~2 ms.
+        # ``native_collectives=False`` keeps the torch.distributed route (the only one on gloo, where the tests' CPU ops run).
+        self.comm = None
+        if native_collectives is None:
+            native_collectives = NATIVE_COLLECTIVES
+        if native_collectives is None:
+            native_collectives = backend == "nccl" and ops is None and he.tables.is_cuda
+        if native_collectives:
+            if backend != "nccl":
+                raise ValueError("the library's own collectives are RCCL's: the process group must be an nccl one")
+            self.comm = self._make_comm(he.tables.device)
         # emulated rank only: after the exchange, ONE launch of the full-geometry forward on this rank's own samples writes
         # the TRUE feature columns of all levels over the replicas' copies (this process holds the whole table): the model
         # then sees what the real job's ranks would have delivered, and -- with its parameters frozen -- the sample counts
@@ -235,6 +271,35 @@ class LevelParallel:
         self._g_clean = None             # event: the optimizer pass left G all zeros (nsx_adam_hash_factored_consume)
         self.stats = {"bytes_in": 0, "samples_fwd": 0, "samples_bwd": 0, "fwd_calls": 0, "bwd_calls": 0, "collectives": 0,
                       "host_exchanges": 0}
+
+    def _make_comm(self, dev):
+        """The library's RCCL communicator over the ranks of ``group``: rank 0 draws the unique id, the gloo side group
+        carries it, every rank joins (collective) with its device current."""
+        n, r = dist.get_world_size(self.group), dist.get_rank(self.group)
+        ident = torch.zeros((_lib.NSX_COMM_ID_BYTES,), dtype=torch.uint8)
+        if r == 0:
+            check(lib().nsx_comm_unique_id(ident.data_ptr()), "nsx_comm_unique_id")
+        if n > 1:
+            dist.broadcast(ident, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0,
+                           group=self.cpu_group)
+        comm = C.c_void_p()
+        with torch.cuda.device(dev):
+            check(lib().nsx_comm_create(ident.data_ptr(), n, r, C.byref(comm)), "nsx_comm_create")
+        return comm
+
+    def close(self) -> None:
+        comm, self.comm = self.comm, None
+        if comm is not None:
+            lib().nsx_comm_destroy(comm)
+
+    def __del__(self):
+        # (not while the interpreter shuts down: the HIP runtime may be gone, and the process' exit frees the communicator)
+        try:
+            import sys
+            if not sys.is_finalizing():
+                self.close()
+        except Exception:
+            pass
 
     # ---- collectives -------------------------------------------------------------------------------------------------
     def exchange_sizes_begin(self, S: int, rows: int):
@@ -399,17 +464,23 @@ class LevelParallel:
                                f"exchanged for it say {ex.S} / <= {ex.R_cap}")
         lay = ex.lay
         payload = self._buf("fwd_payload", lay.fwd_bytes, dev)
-        ops.fwd_pack(lay, x, slot, S, n_dev, code, int(code.shape[0]), payload)
         ex.gathered = self._bytes(W * lay.fwd_bytes, dev)
-        self._all_gather(ex.gathered, payload)
         send = self._buf("feat_send", W * lay.feat_bytes, dev)
         ex.codes_packed = torch.empty((ex.n_planes, H), dtype=torch.float32, device=dev)
         ex.window = window
-        ops.fwd_run(lay, ex.gathered, ex, tables, self.geom, window, send, ex.codes_packed)
         recv = self._buf("feat_recv", W * lay.feat_bytes, dev)
-        self._all_to_all(recv, send)
         feats = out if out is not None else torch.empty((S, W * n2), dtype=torch.float16, device=dev)
-        ops.fwd_unpack(lay, recv, S, n_dev, feats)
+        if self.comm is not None:
+            ops.forward(lay, self.comm, self.rank if self.emulate else -1, x, slot, S, n_dev, code, int(code.shape[0]), payload,
+                        ex.gathered, ex, tables, self.geom, window, send, ex.codes_packed, recv, feats)
+            self.stats["bytes_in"] += (W - 1) * (lay.fwd_bytes + lay.feat_bytes)
+            self.stats["collectives"] += 2
+        else:
+            ops.fwd_pack(lay, x, slot, S, n_dev, code, int(code.shape[0]), payload)
+            self._all_gather(ex.gathered, payload)
+            ops.fwd_run(lay, ex.gathered, ex, tables, self.geom, window, send, ex.codes_packed)
+            self._all_to_all(recv, send)
+            ops.fwd_unpack(lay, recv, S, n_dev, feats)
         self.stats["samples_fwd"] += sum(ex.sizes)
         self.last_exchange = ex
         self._shadow(x, code, slot, window, n_dev, feats)
@@ -481,15 +552,29 @@ class LevelParallel:
             raise RuntimeError(f"level-parallel HashEnsemble: {S} samples in the backward of a forward exchange of capacity {ex.S_cap}")
         lay, ops = ex.lay, self.ops
         send = self._buf("bwd_send", W * lay.bwd_bytes, dev)
-        ops.bwd_pack(lay, dout, x, slot, S, n_dev, send)
         recv = self._buf("bwd_recv", W * lay.bwd_bytes, dev)
-        self._all_to_all(recv, send)
+        ret = self._buf("ret_send", W * lay.ret_bytes, dev)
+        ret_recv = self._buf("ret_recv", W * lay.ret_bytes, dev)
+        dz = self._buf("dz", 4 * W * lay.S_cap * lay.n2, dev)
+        dx = dx_out if dx_out is not None else torch.empty((S, 3), dtype=torch.float32, device=dev)
+        dcode = dcode_out if dcode_out is not None else torch.empty((ex.n_rows, H), dtype=torch.float32, device=dev)
+        native = self.comm is not None
+        if not native:
+            ops.bwd_pack(lay, dout, x, slot, S, n_dev, send)
+            self._all_to_all(recv, send)
         G = self._planes(ex.n_planes, dev) if need_table else None
         if self.nonfinite is None or self.nonfinite.device != dev:
             self.nonfinite = torch.zeros((1,), dtype=torch.float32, device=dev)
-        ret = self._buf("ret_send", W * lay.ret_bytes, dev)
-        ops.bwd_run(lay, recv, ex.gathered, ex, self.slice_f16(), self.geom, ex.window, G, ret, self.nonfinite,
-                    self._buf("dz", 4 * W * lay.S_cap * lay.n2, dev))
+        if native:
+            ops.backward(lay, self.comm, self.rank if self.emulate else -1, dout, x, slot, S, n_dev, send, recv, ex.gathered, ex,
+                         self.slice_f16(), self.geom, ex.window, G, dz, ret, ret_recv, self.nonfinite, ex.n_rows, dx, dcode)
+            self.stats["bytes_in"] += (W - 1) * (lay.bwd_bytes + lay.ret_bytes)
+            self.stats["collectives"] += 2
+        else:
+            ops.bwd_run(lay, recv, ex.gathered, ex, self.slice_f16(), self.geom, ex.window, G, ret, self.nonfinite, dz)
+            # partial dL/dx and partial code-row gradients back to the samples' owners, summed over the level owners
+            self._all_to_all(ret_recv, ret)
+            ops.bwd_unpack(lay, ret_recv, S, n_dev, ex.n_rows, dx, dcode)
         if self.backward_calls == 0 or self.codes_packed is None:
             self.codes_packed, self.window = ex.codes_packed, ex.window
         self.backward_calls += 1
@@ -497,12 +582,6 @@ class LevelParallel:
         self.samples_scattered += n_job
         self.stats["bwd_calls"] += 1
         self.stats["samples_bwd"] += n_job
-        # partial dL/dx and partial code-row gradients back to the samples' owners, summed over the level owners
-        ret_recv = self._buf("ret_recv", W * lay.ret_bytes, dev)
-        self._all_to_all(ret_recv, ret)
-        dx = dx_out if dx_out is not None else torch.empty((S, 3), dtype=torch.float32, device=dev)
-        dcode = dcode_out if dcode_out is not None else torch.empty((ex.n_rows, H), dtype=torch.float32, device=dev)
-        ops.bwd_unpack(lay, ret_recv, S, n_dev, ex.n_rows, dx, dcode)
         ex.backward_done = True
         return dx, dcode
 

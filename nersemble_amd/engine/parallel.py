@@ -15,7 +15,7 @@ SMALL_BUCKET_ELEMS = 1 << 22
 
 def all_reduce_gradients(params: Iterable[torch.nn.Parameter], world_size: int, group=None,
                          takes_part: Optional[Sequence[bool]] = None, force: bool = False, arena=None,
-                         extra_flags: Optional[torch.Tensor] = None):
+                         extra_flags: Optional[torch.Tensor] = None, native_comm=None):
     """In-place average of ``p.grad`` over all ranks.  A parameter without a gradient on this rank contributes zeros
     (every rank must join every collective).  What it is left with afterwards follows from whether the parameter took
     part in the step on ANY rank:
@@ -46,6 +46,10 @@ def all_reduce_gradients(params: Iterable[torch.nn.Parameter], world_size: int, 
     path the host paces).  A rank whose step did not run the native drivers (nothing marched: the per-kernel path) copies its
     gradients into their slots first.  Every rank must pass an arena of the same model, or none (the trainer decides from
     the configuration): without one the small gradients are flattened into one bucket as before.
+
+    ``native_comm``: an ``nsx_comm`` over the ranks of ``group`` (the level-parallel exchange's, csrc/comm.hip): the arena's
+    bucket is then summed by the library on the current stream (``nsx_comm_all_reduce_sum``) -- no work object, no side
+    stream to wait for.
 
     ``extra_flags``: a small fp32 device tensor summed over the ranks in the same bucket (the level-parallel optimizer's
     non-finite flag: a step is skipped on every rank or on none) -- returned as the third value.
@@ -104,7 +108,11 @@ def all_reduce_gradients(params: Iterable[torch.nn.Parameter], world_size: int, 
             flat[off:off + n_flags].copy_(extra_flags.reshape(-1).to(torch.float32))
             off += n_flags
         span = flat[:off]
-        handles.append(dist.all_reduce(span, op=dist.ReduceOp.SUM, group=group, async_op=True))
+        if native_comm is not None:
+            from .._lib import check, lib, stream
+            check(lib().nsx_comm_all_reduce_sum(native_comm, span.data_ptr(), off, stream()), "nsx_comm_all_reduce_sum")
+        else:
+            handles.append(dist.all_reduce(span, op=dist.ReduceOp.SUM, group=group, async_op=True))
         for h in handles:
             h.wait()
         aux = flat[n_grad:off]                                   # counts (+ flags): not averaged; views of the arena -- their

@@ -307,12 +307,13 @@ class NeRSembleTrainer:
         # level-parallel tables: the owners' non-finite flags ride in the same bucket (a step is skipped on every rank or on
         # none); every other flag is computed from the REDUCED gradients, identical on all ranks -- no collective of its own
         table_opt = self.optimizers.get(self.group_of_tables() or "")
-        lp_flag = None
+        lp_flag = native_comm = None
         if isinstance(table_opt, LevelParallelTableAdam):
             lp_flag = table_opt.local_nonfinite()
+            native_comm = table_opt.lp.comm           # (the exchange's own RCCL communicator spans the same ranks)
         self._presence, flags = all_reduce_gradients(params, self.world_size, takes_part=self._took_part,
                                                      force=self.level_parallel_emulation is not None, arena=arena,
-                                                     extra_flags=lp_flag)
+                                                     extra_flags=lp_flag, native_comm=native_comm)
         if isinstance(table_opt, LevelParallelTableAdam):
             table_opt.reduced_nonfinite = flags
 

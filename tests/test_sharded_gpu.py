@@ -632,6 +632,50 @@ def test_emulated_level_parallel_rank_through_rccl(cuda, single_rank_group):
     assert bool((dx2[kept:] == 7.0).all()) and torch.allclose(dx2[:kept], dx[:kept])
 
 
+def test_collectives_issued_by_the_library_equal_the_torch_distributed_route(cuda, single_rank_group):
+    """``LevelParallel`` on an RCCL group issues the exchange's collectives from C (csrc/comm.hip: ``nsx_lp_forward`` /
+    ``nsx_lp_backward`` on the library's own communicator, one call per direction); ``native_collectives=False`` keeps the five
+    torch.distributed calls.  Same feature rows bit for bit, same planes / dL/dx / code gradients up to the order of the
+    atomics, same collective count; the communicator reports the group's size."""
+    from nersemble_amd._lib import lib
+    from nersemble_amd.engine.level_parallel import LevelParallel
+    H, B, T, kept = 32, 2777, 6, 2100
+    he2 = _he(H, cuda)
+    he2.train()
+    g = torch.Generator(device=cuda).manual_seed(5)
+    x = torch.rand((B, 3), device=cuda, generator=g)
+    code = torch.randn((T, H), device=cuda, generator=g)
+    slot = torch.randint(0, T, (B,), device=cuda, generator=g, dtype=torch.int32)
+    window = torch.rand((H,), device=cuda, generator=g)
+    n_dev = torch.tensor([kept], dtype=torch.int64, device=cuda)
+    # (six levels in the test model: 2 and 3 ranks divide them)
+    for W, r in ((3, 1), (2, 0)):
+        res = []
+        for native in (True, False):
+            lp = LevelParallel(he2, W, r, emulate=True, native_collectives=native)
+            assert (lp.comm is not None) == native
+            if native:
+                assert lib().nsx_comm_world_size(lp.comm) == 1 and lib().nsx_comm_rank(lp.comm) == 0
+            feats = lp.features(x, code, slot, window, n_dev=n_dev)
+            assert lp.stats["collectives"] == 2 and lp.stats["host_exchanges"] == 1
+            n2 = 2 * lp.n_own
+            dout = (torch.randn((B, W * n2), device=cuda, generator=torch.Generator(device=cuda).manual_seed(9)) * 3).half().float()
+            lp.begin_step()
+            dx, dcode = lp.backward(x, slot, dout, n_dev=n_dev)
+            assert lp.stats["collectives"] == 4
+            torch.cuda.synchronize()
+            res.append((feats[:kept].clone(), dx[:kept].clone(), dcode.clone(),
+                        lp.G[:W * T * lp.n_entries * 2].clone(), dict(lp.stats)))
+            lp.close()
+            assert lp.comm is None
+        (f1, dx1, dc1, G1, st1), (f0, dx0, dc0, G0, st0) = res
+        assert torch.equal(f1, f0)
+        assert float(G0.abs().max()) > 0 and float((G1 - G0).abs().max()) <= 2e-5 * float(G0.abs().max())
+        assert torch.allclose(dx1, dx0, rtol=1e-5, atol=1e-6 * float(dx0.abs().max()))
+        assert torch.allclose(dc1, dc0, rtol=1e-4, atol=2e-6 * float(dc0.abs().max()))
+        assert st1["bytes_in"] == st0["bytes_in"] and st1["samples_bwd"] == st0["samples_bwd"]
+
+
 @pytest.mark.parametrize("H,table_grad", [(32, True), (8, True), (32, False)])
 def test_all_source_ranks_in_one_launch_equal_one_launch_per_source_rank(H, table_grad, cuda):
     """``nsx_lp_fwd_run`` / ``nsx_lp_bwd_run`` with NSX_OPT_LP_ONE_LAUNCH (grid.y = source rank) against the per-source-rank
