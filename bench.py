@@ -863,7 +863,9 @@ def main():
                            "nsx_deform_fwd", "nsx_deform_fwd_rows", "nsx_deform_bwd",
                            "nsx_mlp_fwd", "nsx_mlp_bwd", "nsx_check_finite", "nsx_march_fill", "nsx_march_fill_from_stash",
                            "nsx_hash_grad_expand", "nsx_hash_grad_expand_f16", "nsx_adam_dense_f16grad",
-                           "nsx_check_finite_f16", "nsx_lp_fwd_run", "nsx_lp_bwd_run"}
+                           "nsx_check_finite_f16", "nsx_lp_fwd_run", "nsx_lp_bwd_run",
+                           # (the same two with their collectives, issued by the library: csrc/comm.hip)
+                           "nsx_lp_forward", "nsx_lp_backward"}
     # (the variant of the table optimizer that also clears the gradient pieces it reads is priced as the optimizer pass)
     _lib.profiler.alias = {"nsx_adam_hash_factored_consume": "nsx_adam_hash_factored"}
     if not a.no_kernel_events:

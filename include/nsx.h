@@ -32,7 +32,7 @@ extern "C" {
 #define NSX_MAX_SLOTS 64
 #define NSX_MAX_ADAM_SLOTS 192   /* gradient planes nsx_adam_hash_factored(_consume) reads (level-parallel runs: one per
                                    (source rank, code row), engine/level_parallel.py) */
-#define NSX_VERSION 126
+#define NSX_VERSION 127
 
 typedef uint16_t nsx_half;
 
@@ -599,6 +599,15 @@ int nsx_multi_unscale_check(const nsx_tensor_ref* tensors_host, int n_tensors, i
                             float* found_inf /* [n_groups] */, void* stream);
 int nsx_multi_adam(const nsx_tensor_ref* tensors_host, int n_tensors, const nsx_adam_group* groups_host, int n_groups,
                    const float* found_inf /* [n_groups], may be NULL */, void* stream);
+/* nsx_multi_adam for a data-parallel rank.  torch.optim.Adam leaves a parameter without a gradient alone (no moment decay, no
+ * `step`): with several ranks every rank joins the gradient all-reduce with zeros for such a parameter, and WHETHER any rank
+ * had a gradient is known on the device only (the counts travel in the same bucket).  present: fp32 device vector [n_present]
+ * of those counts; present_index_host [n_tensors]: tensor i's element of it (-1: not subject to the rule).  A tensor whose count
+ * is 0 is skipped exactly like one whose grad is NULL; the caller takes its host-side step count back when the counts have
+ * reached the host (as it does for found_inf).  present NULL: nsx_multi_adam. */
+int nsx_multi_adam_present(const nsx_tensor_ref* tensors_host, int n_tensors, const nsx_adam_group* groups_host, int n_groups,
+                           const float* found_inf, const float* present, const int32_t* present_index_host, int n_present,
+                           void* stream);
 
 /* torch.amp.GradScaler.update() for the step's found_inf flags (nersemble_trainer.py:186-203: one scale update from all
  * optimizer groups) in ONE launch: total = sum(found_inf[0..n_groups)); the scale backs off when total != 0, grows after

@@ -706,11 +706,19 @@ __global__ void grad_scaler_update_kernel(const float* found_inf, int n_groups, 
     for (int k = 0; k < M.n; ++k) M.p[k][0] = s;
 }
 
-__global__ __launch_bounds__(256) void multi_adam_kernel(TensorTable T, GroupHyper H, const float* __restrict__ found_inf) {
+struct PresentIndex {
+    int16_t at[NSX_MAX_TENSORS];      // tensor i's element of `present`, -1: always present
+};
+
+__global__ __launch_bounds__(256) void multi_adam_kernel(TensorTable T, GroupHyper H, const float* __restrict__ found_inf,
+                                                         const float* __restrict__ present, PresentIndex P) {
     const nsx_tensor_ref r = T.t[blockIdx.y];
     const float* g = reinterpret_cast<const float*>(r.grad);
     if (!g) return;                                          // no gradient this step: torch skips the parameter
     if (found_inf && found_inf[r.group] != 0.f) return;      // GradScaler: the whole group's step is skipped
+    // data-parallel runs: NO rank had a gradient for this tensor (the all-reduced `gradient` is the zeros the ranks put in to
+    // join the collective): a single process leaves such a parameter alone, so does every rank (nsx_multi_adam_present)
+    if (present && P.at[blockIdx.y] >= 0 && present[P.at[blockIdx.y]] == 0.f) return;
     AdamHyper hy = H.h[r.group];
     if (r.step > 0) {                                        // the tensor's own step count (torch: state[p]["step"])
         hy.bc1 = (float)(1.0 - pow((double)hy.beta1, (double)r.step));
@@ -1023,7 +1031,25 @@ int nsx_multi_unscale_check(const nsx_tensor_ref* tensors_host, int n_tensors, i
 
 int nsx_multi_adam(const nsx_tensor_ref* tensors_host, int n_tensors, const nsx_adam_group* groups_host, int n_groups,
                    const float* found_inf, void* stream) {
+    return nsx_multi_adam_present(tensors_host, n_tensors, groups_host, n_groups, found_inf, nullptr, nullptr, 0, stream);
+}
+
+int nsx_multi_adam_present(const nsx_tensor_ref* tensors_host, int n_tensors, const nsx_adam_group* groups_host, int n_groups,
+                           const float* found_inf, const float* present, const int32_t* present_index_host, int n_present,
+                           void* stream) {
     NSX_REQUIRE(groups_host, "nsx_multi_adam: NULL groups");
+    NSX_REQUIRE(!present || (present_index_host && n_present >= 1 && n_present <= 32767),
+                "nsx_multi_adam_present: a presence vector needs the tensors' indices into it (n_present=%d)", n_present);
+    PresentIndex P;
+    for (int i = 0; i < NSX_MAX_TENSORS; ++i) P.at[i] = -1;
+    if (present) {
+        for (int i = 0; i < n_tensors && i < NSX_MAX_TENSORS; ++i) {
+            NSX_REQUIRE(present_index_host[i] >= -1 && present_index_host[i] < n_present,
+                        "nsx_multi_adam_present: tensor %d: index %d outside the presence vector [0,%d)", i,
+                        present_index_host[i], n_present);
+            P.at[i] = (int16_t)present_index_host[i];
+        }
+    }
     TensorTable T;
     int64_t n_max = 0;
     if (int rc = fill_table(tensors_host, n_tensors, n_groups, T, n_max, "nsx_multi_adam")) return rc;
@@ -1040,7 +1066,7 @@ int nsx_multi_adam(const nsx_tensor_ref* tensors_host, int n_tensors, const nsx_
     int64_t bx = (n_max + 1023) / 1024;
     if (bx > 64) bx = 64;
     hipLaunchKernelGGL(multi_adam_kernel, dim3((unsigned)bx, (unsigned)n_tensors), dim3(256), 0, (hipStream_t)stream, T, H,
-                       found_inf);
+                       found_inf, present, P);
     NSX_LAUNCH_CHECK("nsx_multi_adam launch");
     return NSX_OK;
 }

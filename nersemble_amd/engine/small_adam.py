@@ -15,6 +15,8 @@ Semantics are torch.optim.Adam's (no amsgrad, no weight decay); parameters witho
 """
 from typing import Dict, List, Optional, Sequence
 
+import ctypes as C
+
 import torch
 
 from .._lib import AdamGroup, NSX_MAX_GROUPS, NSX_MAX_TENSORS, TensorRef, check, lib, ptr, stream
@@ -67,6 +69,19 @@ class SmallGroupAdam(torch.optim.Optimizer):
         for p in self._last_stepped:
             self.steps[p] = max(0, self.steps.get(p, 0) - 1)
         self._last_stepped = []
+
+    def rollback_params(self, params) -> None:
+        """The last step left these tensors alone on the device (data-parallel run: no rank had a gradient for them --
+        ``nsx_multi_adam_present``): their step does not count.  They leave ``_last_stepped``, so a ``rollback_step`` of the
+        same step does not take a second count from them."""
+        gone = {id(p) for p in params}
+        keep = []
+        for p in self._last_stepped:
+            if id(p) in gone:
+                self.steps[p] = max(0, self.steps.get(p, 0) - 1)
+            else:
+                keep.append(p)
+        self._last_stepped = keep
 
     def step(self, closure=None):             # pragma: no cover - the trainer steps all groups together
         raise RuntimeError("SmallGroupAdam steps through step_groups([...]) (all groups in one launch)")
@@ -155,7 +170,11 @@ def unscale_and_check_groups(optimizers: Sequence[SmallGroupAdam], group_of: Seq
 
 
 def adam_groups(optimizers: Sequence[SmallGroupAdam], group_of: Sequence[int], n_groups: int, table,
-                found_inf: Optional[torch.Tensor]) -> None:
+                found_inf: Optional[torch.Tensor], present: Optional[torch.Tensor] = None, present_index=None) -> None:
+    """``present`` / ``present_index`` (data-parallel runs): the device vector of how many ranks held a gradient per parameter
+    (``all_reduce_gradients``' counts[0]) and ``{id(parameter): its element}`` -- a parameter nobody had a gradient for is
+    left alone by the kernel although every rank carries the zeros it joined the all-reduce with; the trainer takes the
+    host-side count back when the counts arrive (``SmallGroupAdam.rollback_params``)."""
     refs, n, owners = table
     if not n:
         return
@@ -175,7 +194,12 @@ def adam_groups(optimizers: Sequence[SmallGroupAdam], group_of: Sequence[int], n
     for k in range(n_groups):
         if k not in seen:
             groups[k].step = 1
-    check(lib().nsx_multi_adam(refs, n, groups, n_groups, ptr(found_inf), stream()), "nsx_multi_adam")
+    if present is not None and present_index:
+        at = (C.c_int32 * n)(*[present_index.get(id(p), -1) for _, p in owners])
+        check(lib().nsx_multi_adam_present(refs, n, groups, n_groups, ptr(found_inf), ptr(present), at, int(present.numel()),
+                                           stream()), "nsx_multi_adam_present")
+    else:
+        check(lib().nsx_multi_adam(refs, n, groups, n_groups, ptr(found_inf), stream()), "nsx_multi_adam")
     # what torch's optimizer-step hooks would have announced: cached parameter packs (deformation MFMA fragments, the
     # evaluation pre-blend) are stale now
     from ..field_components.deformation_field import _OPTIMIZER_STEPS

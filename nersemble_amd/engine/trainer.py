@@ -171,6 +171,7 @@ class NeRSembleTrainer:
         self._flag_state = None       # persistent found_inf flags of the native scale update
         self._presence, self._presence_host = None, None      # data-parallel: ranks per parameter that held a gradient
         self._took_part = None                                # ... > 0 in the previous step (engine/parallel.py)
+        self._presence_params = self._presence_params_late = None   # the parameters those counts are about (this / the read-back step)
         # the table optimizer's 12 GB pass runs beside the rest of the step's tail and the next step's ray marching
         self._opt_stream = torch.cuda.Stream(device) if (overlap_table_adam and device.type == "cuda") else None
         self._found_groups = []
@@ -314,6 +315,8 @@ class NeRSembleTrainer:
         self._presence, flags = all_reduce_gradients(params, self.world_size, takes_part=self._took_part,
                                                      force=self.level_parallel_emulation is not None, arena=arena,
                                                      extra_flags=lp_flag, native_comm=native_comm)
+        # (the counts' order: the parameters that take gradients, as all_reduce_gradients lists them)
+        self._presence_params = [p for p in params if p.requires_grad] if self._presence is not None else None
         if isinstance(table_opt, LevelParallelTableAdam):
             table_opt.reduced_nonfinite = flags
 
@@ -415,7 +418,14 @@ class NeRSembleTrainer:
                 elif f.item() == 0:
                     opt.step()
         if native_small:
-            adam_groups([o for _, o in native_small], small_groups, len(groups), table, found_all)
+            # data-parallel: a parameter NO rank had a gradient for this step is left alone on the device (its count in the
+            # all-reduced bucket is 0), although every rank holds the zeros it joined the all-reduce with (advisor, round 5:
+            # Adam stepped it with g = 0 -- momentum drift and a step count a single process does not take)
+            present = index = None
+            if self._presence is not None and self._presence_params:
+                present = self._presence[0]
+                index = {id(p): i for i, p in enumerate(self._presence_params)}
+            adam_groups([o for _, o in native_small], small_groups, len(groups), table, found_all, present, index)
             # the fused MLPs' fp16 weight copies for the NEXT step, now: two small launches that would otherwise sit in
             # the dependent chain behind the table optimizer (tcnn.Network.half_weights is lazy) run beside it instead
             field = getattr(self.model, "field", None)
@@ -483,6 +493,7 @@ class NeRSembleTrainer:
 
     def _defer_scheduler_step(self, found_all: torch.Tensor) -> None:
         """found_all: one inf/NaN flag per parameter group (device)."""
+        self._presence_params_late = self._presence_params if self._presence is not None else None
         if not found_all.is_cuda:
             self._pending = ("host", found_all.clone())
             self._presence_host, self._presence = (self._presence.clone() if self._presence is not None else None), None
@@ -578,6 +589,13 @@ class NeRSembleTrainer:
             counts = self._presence_host.tolist()
             check_gradient_presence(counts, self.world_size)
             self._took_part = [c > 0 for c in counts[0]]
+            # tensors the device left alone in that step (nobody had a gradient): their host-side step count goes back
+            listed = self._presence_params_late or []
+            idle = [p for p, c in zip(listed, counts[0]) if c == 0]
+            if idle:
+                for opt in self.optimizers.values():
+                    if isinstance(opt, SmallGroupAdam):
+                        opt.rollback_params(idle)
         # the native table optimizers count their step on the host before the device decides to skip it: take the
         # count back for the groups that skipped (torch's fused Adam does the same with _foreach_sub_(steps, found_inf))
         for key, opt in self.optimizers.items():

@@ -232,6 +232,50 @@ def test_small_group_adam_equals_torch_adam_with_gradscaler_semantics(cuda):
     assert [again.steps[p] for p in again._params()] == [4, 2]
 
 
+def test_a_parameter_no_rank_had_a_gradient_for_is_left_alone(cuda):
+    """Data-parallel rule of ``nsx_multi_adam_present`` (advisor, round 5): every rank joins the gradient all-reduce with zeros
+    for a parameter it has no gradient for; when NO rank had one, the averaged `gradient` is those zeros and a single process
+    (torch.optim.Adam: ``grad is None``) leaves the parameter, its moments and its step count alone.  The counts are on the
+    device: the kernel skips the tensor, the host takes the step count back when the counts arrive."""
+    from nersemble_amd.engine.small_adam import SmallGroupAdam, adam_groups, unscale_and_check_groups
+    g = torch.Generator(device=cuda).manual_seed(2)
+    shapes = [(64, 32), (16,), (33, 7)]
+
+    def make():
+        gg = torch.Generator(device=cuda).manual_seed(3)
+        return [torch.nn.Parameter(torch.randn(s, device=cuda, generator=gg)) for s in shapes]
+
+    ref, nat = make(), make()
+    ref_opt, nat_opt = torch.optim.Adam(ref, lr=1e-2, eps=1e-15), SmallGroupAdam(nat, lr=1e-2, eps=1e-15)
+    index = {id(p): i for i, p in enumerate(nat)}
+    for it in range(4):
+        idle = 1 if it in (1, 2) else -1                       # tensor 1: a gradient in step 0, none anywhere in steps 1, 2
+        counts = torch.tensor([0.0 if i == idle else 2.0 for i in range(3)], device=cuda)
+        for i, (a, b) in enumerate(zip(ref, nat)):
+            grad = torch.randn(a.shape, device=cuda, generator=g)
+            a.grad = None if i == idle else grad.clone()
+            b.grad = torch.zeros_like(b) if i == idle else grad.clone()      # (the zeros the ranks joined the collective with)
+        found = torch.zeros(1, device=cuda)
+        table = unscale_and_check_groups([nat_opt], [0], 1, found, None)
+        adam_groups([nat_opt], [0], 1, table, found, counts, index)
+        ref_opt.step()
+        if idle >= 0:
+            nat_opt.rollback_params([nat[idle]])                # (the trainer, once the counts have reached the host)
+        for a, b in zip(ref, nat):
+            assert torch.allclose(a, b, rtol=1e-5, atol=1e-7)
+    assert [nat_opt.steps[p] for p in nat] == [4, 2, 4]
+    assert [int(ref_opt.state[p]["step"]) for p in ref] == [4, 2, 4]
+    for a, b in zip(ref, nat):
+        assert torch.allclose(ref_opt.state[a]["exp_avg"], nat_opt.state[b]["exp_avg"], rtol=1e-5, atol=1e-7)
+        assert torch.allclose(ref_opt.state[a]["exp_avg_sq"], nat_opt.state[b]["exp_avg_sq"], rtol=1e-5, atol=1e-8)
+    # without the presence vector the same call steps the tensor with g = 0 (what the rule exists to prevent)
+    before = nat[1].detach().clone()
+    nat[1].grad = torch.zeros_like(nat[1])
+    found = torch.zeros(1, device=cuda)
+    adam_groups([nat_opt], [0], 1, unscale_and_check_groups([nat_opt], [0], 1, found, None), found)
+    assert not torch.equal(nat[1].detach(), before)
+
+
 def test_optimizer_pass_consumes_the_factored_gradient(cuda):
     """nsx_adam_hash_factored_consume: same update as nsx_adam_hash_factored, G all zeros afterwards -- also when the
     step is skipped -- and the next backward adds to that buffer without a fill of its own."""

@@ -283,3 +283,23 @@ def test_first_grid_planes_policy(monkeypatch):
     assert fgp(he, 24, 100000) == 0
     monkeypatch.setenv("NSX_FIRST_GRID_PLANES", "4")
     assert fgp(he, 24, 100000) == 4 and fgp(he, 3, 100000) == 0
+
+
+def test_small_group_adam_takes_the_count_back_for_tensors_the_device_left_alone():
+    """``SmallGroupAdam.rollback_params`` (host side of ``nsx_multi_adam_present``): only the named tensors lose the step, and
+    a ``rollback_step`` of the same step (inf / NaN found as well) does not take a second count from them."""
+    import torch
+    from nersemble_amd.engine.small_adam import SmallGroupAdam
+    ps = [torch.nn.Parameter(torch.zeros(3)) for _ in range(3)]
+    opt = SmallGroupAdam(ps)
+    for _ in range(2):
+        opt._last_stepped = []
+        for p in ps:
+            opt.advance(p)
+    assert [opt.steps[p] for p in ps] == [2, 2, 2]
+    opt.rollback_params([ps[1]])
+    assert [opt.steps[p] for p in ps] == [2, 1, 2]
+    opt.rollback_step()
+    assert [opt.steps[p] for p in ps] == [1, 1, 1]
+    opt.rollback_params([ps[0]])                              # nothing stepped since: nothing to take back
+    assert [opt.steps[p] for p in ps] == [1, 1, 1]

@@ -1,22 +1,23 @@
 #!/bin/bash
 # Round 6, run I: every rank of an 8-rank level-parallel job, one after the other, emulated on ONE GPU (same box) + the new test
 set -u
-out=gpurun_out/r06_i; mkdir -p $out
+out=gpurun_out/${RUN_I_OUT:-r06_i}; mkdir -p $out
 export TMPDIR=/tmp
-timeout 600 python -m pytest tests/test_sharded_gpu.py -q -m gpu -k "frozen_emulated or emulated" 2>&1 | grep -v "amdgpu.ids\|socket.cpp\|Gloo" | tail -5
+[ -n "${RUN_I_SKIP_TESTS:-}" ] || timeout 600 python -m pytest tests/test_sharded_gpu.py -q -m gpu -k "frozen_emulated or emulated" 2>&1 | grep -v "amdgpu.ids\|socket.cpp\|Gloo" | tail -5
 LP="python bench.py --level-parallel-one-rank 8 --steps 20 --warmup 5 --no-cpu-baseline --no-kernels-alone"
 for r in 0 1 2 3 4 5 6 7; do timeout 400 $LP --rank $r > $out/lp8_rank$r.json 2> $out/lp8_rank$r.err; done
 python - <<'P'
-import json
+import json, os
+OUT = os.environ.get("RUN_I_OUT", "r06_i")
 rows = []
 for r in range(8):
     try:
-        d = json.loads([l for l in open(f"gpurun_out/r06_i/lp8_rank{r}.json") if l.startswith("{")][-1])
+        d = json.loads([l for l in open(f"gpurun_out/{OUT}/lp8_rank{r}.json") if l.startswith("{")][-1])
         ss = d.get("steady_state") or {}
         c = ss.get("comm") or {}
         k = d["native_kernel_ms"]
         rows.append({"rank": r, "levels": c.get("levels"), "window_ms_per_step": round(d["ms_per_step"], 3),
-                     "window_fwd_run_ms": k.get("nsx_lp_fwd_run", {}).get("avg_ms"), "window_bwd_run_ms": k.get("nsx_lp_bwd_run", {}).get("avg_ms"),
+                     "window_fwd_run_ms": (k.get("nsx_lp_fwd_run") or k.get("nsx_lp_forward") or {}).get("avg_ms"), "window_bwd_run_ms": (k.get("nsx_lp_bwd_run") or k.get("nsx_lp_backward") or {}).get("avg_ms"),
                      "window_adam_ms": k.get("nsx_adam_hash_factored", {}).get("avg_ms"),
                      "steady_ms_per_step": round(ss.get("ms_per_step", 0), 3), "steady_shadow_fwd_ms": round(c.get("shadow_fwd_ms", 0), 3),
                      "steady_adam_ms": round(c.get("shard_adam_ms", 0), 3), "host_issue_ms": round(ss.get("host_issue_ms_per_step", 0), 3),
@@ -33,7 +34,7 @@ if ok:
     w = [x["window_ms_per_step"] for x in ok]; s = [x["steady_ms_per_step"] for x in ok]
     doc["window_max_over_min"] = round(max(w) / min(w), 3); doc["steady_max_over_min"] = round(max(s) / min(s), 3)
     doc["window_max_ms"], doc["steady_max_ms"] = max(w), max(s)
-json.dump(doc, open("gpurun_out/r06_i/r06_level_parallel_all_ranks.json", "w"), indent=1)
+json.dump(doc, open(f"gpurun_out/{OUT}/r06_level_parallel_all_ranks.json", "w"), indent=1)
 for x in rows: print(x)
 print({k: v for k, v in doc.items() if k not in ("ranks", "what")})
 P
