@@ -267,7 +267,7 @@ def test_a_parameter_no_rank_had_a_gradient_for_is_left_alone(cuda):
     assert [int(ref_opt.state[p]["step"]) for p in ref] == [4, 2, 4]
     for a, b in zip(ref, nat):
         assert torch.allclose(ref_opt.state[a]["exp_avg"], nat_opt.state[b]["exp_avg"], rtol=1e-5, atol=1e-7)
-        assert torch.allclose(ref_opt.state[a]["exp_avg_sq"], nat_opt.state[b]["exp_avg_sq"], rtol=1e-5, atol=1e-8)
+        assert torch.allclose(ref_opt.state[a]["exp_avg_sq"], nat_opt.state[b]["exp_avg_sq"], rtol=1e-5, atol=1e-7)
     # without the presence vector the same call steps the tensor with g = 0 (what the rule exists to prevent)
     before = nat[1].detach().clone()
     nat[1].grad = torch.zeros_like(nat[1])
