@@ -2,7 +2,7 @@
 # Round 6, run V: after "all source ranks in one launch": device timeline of the emulated level-parallel rank's steady-state step
 # (rank 7 of 8) and the host's issue time by section
 set -u
-out=gpurun_out/r06_v; mkdir -p $out
+out=gpurun_out/${RUN_V_OUT:-r06_v}; mkdir -p $out
 export TMPDIR=/tmp
 cd /tmp
 timeout 500 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $GRAFT_REPO_ROOT/$out/lp -o tl -- python $GRAFT_REPO_ROOT/tools/host_profile.py --plain --steps 30 --level-parallel-one-rank 8 > $GRAFT_REPO_ROOT/$out/lp.out 2> $GRAFT_REPO_ROOT/$out/lp.err
