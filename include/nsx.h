@@ -599,7 +599,8 @@ int nsx_multi_unscale_check(const nsx_tensor_ref* tensors_host, int n_tensors, i
                             float* found_inf /* [n_groups] */, void* stream);
 int nsx_multi_adam(const nsx_tensor_ref* tensors_host, int n_tensors, const nsx_adam_group* groups_host, int n_groups,
                    const float* found_inf /* [n_groups], may be NULL */, void* stream);
-/* nsx_multi_adam for a data-parallel rank.  torch.optim.Adam leaves a parameter without a gradient alone (no moment decay, no
+/* nsx_multi_adam for a data-parallel rank (the optimizer step of nersemble_trainer.py:185-203 when several processes share
+ * it).  torch.optim.Adam leaves a parameter without a gradient alone (no moment decay, no
  * `step`): with several ranks every rank joins the gradient all-reduce with zeros for such a parameter, and WHETHER any rank
  * had a gradient is known on the device only (the counts travel in the same bucket).  present: fp32 device vector [n_present]
  * of those counts; present_index_host [n_tensors]: tensor i's element of it (-1: not subject to the rule).  A tensor whose count
@@ -968,6 +969,8 @@ int nsx_lp_bwd_unpack(const nsx_lp_layout* lay, const uint8_t* ret_recv, int64_t
                       float* dx, float* dcode, void* stream);
 
 /* ---- collectives issued by the library (csrc/comm.hip) --------------------------------------------------------------------
+ * (No reference counterpart: scripts/train/train_nersemble.py:272-274 hard-codes one process; the training step whose
+ * HashEnsemble calls these surround is nersemble_trainer.py:169-206.)
  * The level-parallel exchange above with its collectives enqueued from C: one call per direction puts
  * pack -> collective -> kernels -> collective -> unpack on the caller's stream (the binding otherwise pays five
  * torch.distributed calls and the Python between them per step -- on a rank whose step takes ~2 ms that was what it waited
