@@ -67,6 +67,27 @@ def test_launch_shape_options_are_explicit_and_checked():
     assert L.nsx_set_option(99, 1) != 0 and L.nsx_get_option(99) < 0
 
 
+def test_library_collectives_refuse_bad_arguments_before_touching_rccl():
+    """csrc/comm.hip: argument errors are reported through the C ABI's error state, without a GPU and without a communicator."""
+    from nersemble_amd import _lib
+    L = _lib.lib()
+    ident = (ctypes.c_uint8 * _lib.NSX_COMM_ID_BYTES)()
+    comm = ctypes.c_void_p()
+    assert L.nsx_comm_create(ident, 2, 5, ctypes.byref(comm)) != 0 and b"rank 5 of 2" in L.nsx_last_error()
+    assert L.nsx_comm_create(None, 1, 0, ctypes.byref(comm)) != 0 and b"NULL" in L.nsx_last_error()
+    assert comm.value is None
+    assert L.nsx_comm_destroy(None) == 0                       # destroying nothing is fine
+    assert L.nsx_comm_world_size(None) < 0 and L.nsx_comm_rank(None) < 0
+    assert L.nsx_comm_all_reduce_sum(None, None, 4, None) != 0 and b"nsx_comm_all_reduce_sum" in L.nsx_last_error()
+    lay = _lib.step_struct("nsx_lp_layout")()
+    assert L.nsx_lp_layout_make(4, 1000, 8, 32, 8, ctypes.byref(lay)) == 0
+    g = _lib.GridGeom()
+    args_f = [ctypes.byref(lay), None, -1] + [None, None, 0, None, None, 0, 1] + [None] * 5 + [ctypes.byref(g)] + [None] * 6
+    assert L.nsx_lp_forward(*args_f) != 0 and b"NULL communicator" in L.nsx_last_error()
+    args_b = [ctypes.byref(lay), None, -1] + [None, None, None, 0] + [None] * 7 + [ctypes.byref(g)] + [None] * 7 + [1, None, None, None]
+    assert L.nsx_lp_backward(*args_b) != 0 and b"NULL communicator" in L.nsx_last_error()
+
+
 def test_error_reporting_across_abi():
     from nersemble_amd import _lib
     g = _lib.GridGeom()

@@ -637,7 +637,8 @@ def test_collectives_issued_by_the_library_equal_the_torch_distributed_route(cud
     ``nsx_lp_backward`` on the library's own communicator, one call per direction); ``native_collectives=False`` keeps the five
     torch.distributed calls.  Same feature rows bit for bit, same planes / dL/dx / code gradients up to the order of the
     atomics, same collective count; the communicator reports the group's size."""
-    from nersemble_amd._lib import lib
+    import ctypes as C
+    from nersemble_amd._lib import check, lib, ptr, stream
     from nersemble_amd.engine.level_parallel import LevelParallel
     H, B, T, kept = 32, 2777, 6, 2100
     he2 = _he(H, cuda)
@@ -656,6 +657,15 @@ def test_collectives_issued_by_the_library_equal_the_torch_distributed_route(cud
             assert (lp.comm is not None) == native
             if native:
                 assert lib().nsx_comm_world_size(lp.comm) == 1 and lib().nsx_comm_rank(lp.comm) == 0
+                # the sum over ONE rank is the identity; a W-rank layout on a one-rank communicator is refused unless the
+                # call says it emulates (block counts would not match the peers)
+                v = torch.arange(7, dtype=torch.float32, device=cuda)
+                check(lib().nsx_comm_all_reduce_sum(lp.comm, ptr(v), 7, stream()), "nsx_comm_all_reduce_sum")
+                assert torch.equal(v, torch.arange(7, dtype=torch.float32, device=cuda))
+                lay = lp._layout(B, T)
+                rc = lib().nsx_lp_forward(C.byref(lay), lp.comm, -1, *([None] * 2), 0, *([None] * 2), 0, 1, *([None] * 5),
+                                          C.byref(lp.geom), *([None] * 6))
+                assert rc != 0 and b"the communicator has 1" in lib().nsx_last_error()
             feats = lp.features(x, code, slot, window, n_dev=n_dev)
             assert lp.stats["collectives"] == 2 and lp.stats["host_exchanges"] == 1
             n2 = 2 * lp.n_own

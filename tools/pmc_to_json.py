@@ -16,6 +16,8 @@ ENTRY_OF = {            # kernel-name prefix -> C-ABI entry point it belongs to
     "nsx::ens_fwd_kernel": "nsx_hash_ensemble_fwd",
     "nsx::ens_bwd_kernel": "nsx_hash_ensemble_bwd_factored",
     "nsx::ens_scatter_kernel": "nsx_hash_ensemble_bwd_scatter",
+    "nsx::ens_fwd_sources_kernel": "nsx_lp_fwd_run (all source ranks in one launch)",
+    "nsx::ens_bwd_sources_kernel": "nsx_lp_bwd_run (all source ranks in one launch)",
     "nsx::adam_hash_factored_kernel": "nsx_adam_hash_factored",
     "nsx::adam_hash_factored_mfma_kernel": "nsx_adam_hash_factored (> 64 planes: matrix-core expansion)",
     "nsx::deform_bwd_kernel": "nsx_deform_bwd",

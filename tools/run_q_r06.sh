@@ -2,7 +2,7 @@
 # Round 6, run Q: HBM counters of an emulated level-parallel rank's step (the part of final run B that lacked its directory)
 set -u
 export TMPDIR=/tmp
-p=gpurun_out/prof_r06; mkdir -p $p
+p=gpurun_out/${RUN_Q_OUT:-prof_r06}; mkdir -p $p
 LP="python bench.py --level-parallel-one-rank 8 --steps 20 --warmup 5 --no-cpu-baseline --no-kernels-alone"
 PM="$LP --steady-after 0 --no-kernel-events --steps 6 --warmup 2"
 timeout 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $p/lp_fetch -o lp -- $PM > /dev/null 2> $p/lp_fetch.err
