@@ -701,6 +701,9 @@ def main():
                     help="level-parallel runs: the exchange's collectives through torch.distributed (five calls per step with "
                          "Python in between) instead of the library's own RCCL communicator (one C call per direction) -- "
                          "the A/B switch of that change")
+    ap.add_argument("--bucket-tail-copies", action="store_true",
+                    help="data-parallel / level-parallel runs: the tail of the small gradients' bucket by one copy per piece "
+                         "(torch) instead of nsx_bucket_pack / _unpack -- the A/B switch of that change")
     ap.add_argument("--no-kernels-alone", action="store_true", help="skip the stand-alone kernel timings after the run")
     ap.add_argument("--with-datamanager", action="store_true",
                     help="draw every batch INSIDE the timed loop through NeRSembleVanillaDataManager.next_train (24-image "
@@ -722,6 +725,9 @@ def main():
         a.no_first_grid_phase = a.no_open_window = a.no_with_datamanager = True
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(a, sys.argv[1:]))
+    if a.bucket_tail_copies:
+        from nersemble_amd.engine import parallel as _par
+        _par._NATIVE_PIECES = 0
     if a.lp_torch_collectives:
         from nersemble_amd.engine import level_parallel as _lpm
         _lpm.NATIVE_COLLECTIVES = False

@@ -32,7 +32,7 @@ extern "C" {
 #define NSX_MAX_SLOTS 64
 #define NSX_MAX_ADAM_SLOTS 192   /* gradient planes nsx_adam_hash_factored(_consume) reads (level-parallel runs: one per
                                    (source rank, code row), engine/level_parallel.py) */
-#define NSX_VERSION 127
+#define NSX_VERSION 128
 
 typedef uint16_t nsx_half;
 
@@ -609,6 +609,17 @@ int nsx_multi_adam(const nsx_tensor_ref* tensors_host, int n_tensors, const nsx_
 int nsx_multi_adam_present(const nsx_tensor_ref* tensors_host, int n_tensors, const nsx_adam_group* groups_host, int n_groups,
                            const float* found_inf, const float* present, const int32_t* present_index_host, int n_present,
                            void* stream);
+
+/* The tail of a data-parallel gradient bucket (the reference is single-process, train_nersemble.py:272-274; the gradients are
+ * those of nersemble_trainer.py:183-184's backward): n_pieces <= NSX_MAX_BUCKET_PIECES small fp32 device arrays -- the
+ * gradients that do not live in the step's gradient buffer, the presence counts, the flags -- copied one after the other to
+ * flat_at in ONE launch (nsx_bucket_pack), and after the all-reduce (nsx_bucket_unpack) piece k = scale x its section of
+ * flat_at, flat[0 .. n_scale) *= scale (the average over the ranks; scale = 1: untouched).  HOST arrays of device pointers /
+ * element counts. */
+#define NSX_MAX_BUCKET_PIECES 16
+int nsx_bucket_pack(float* flat_at, const float* const* pieces_host, const int64_t* sizes_host, int n_pieces, void* stream);
+int nsx_bucket_unpack(float* flat, int64_t n_scale, float scale, const float* flat_at, float* const* pieces_host,
+                      const int64_t* sizes_host, int n_pieces, void* stream);
 
 /* torch.amp.GradScaler.update() for the step's found_inf flags (nersemble_trainer.py:186-203: one scale update from all
  * optimizer groups) in ONE launch: total = sum(found_inf[0..n_groups)); the scale backs off when total != 0, grows after

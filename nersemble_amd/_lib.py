@@ -182,6 +182,8 @@ SIGNATURES = {
     "nsx_hash_indices": (c_int, [c_void_p, c_int64, _GEOM_P, c_void_p, c_void_p]),
     "nsx_multi_unscale_check": (c_int, [C.POINTER(TensorRef), c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "nsx_multi_adam": (c_int, [C.POINTER(TensorRef), c_int, C.POINTER(AdamGroup), c_int, c_void_p, c_void_p]),
+    "nsx_bucket_pack": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "nsx_bucket_unpack": (c_int, [c_void_p, c_int64, c_float, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "nsx_multi_adam_present": (c_int, [C.POINTER(TensorRef), c_int, C.POINTER(AdamGroup), c_int, c_void_p, c_void_p,
                                        c_void_p, c_int, c_void_p]),
     "nsx_occ_scratch_bytes": (c_int64, [c_int64]),

@@ -802,6 +802,51 @@ static int adam_hash_factored_entry(float* G, int n_slots, const float* code_tab
     return NSX_ERR_UNSUPPORTED;
 }
 
+// The tail of a data-parallel gradient bucket (engine/parallel.py): a few small fp32 arrays -- the gradients that do not live
+// in the step's gradient buffer (the two embeddings'), the presence counts, the flags -- copied behind the buffer's fixed part
+// in ONE launch, and back (averaged) after the all-reduce.  blockIdx.y = piece.
+struct BucketPieces {
+    float* p[NSX_MAX_BUCKET_PIECES];
+    int64_t n[NSX_MAX_BUCKET_PIECES];
+    int64_t at[NSX_MAX_BUCKET_PIECES];     // element offset of the piece behind `flat_at`
+};
+__global__ __launch_bounds__(256) void bucket_pack_kernel(float* __restrict__ flat_at, BucketPieces P) {
+    const int k = blockIdx.y;
+    const float* src = P.p[k];
+    float* dst = flat_at + P.at[k];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P.n[k]; i += (int64_t)gridDim.x * blockDim.x)
+        dst[i] = src[i];
+}
+// blockIdx.y < n_pieces: piece k = flat_at[at_k ..] * scale; blockIdx.y == n_pieces: flat[0 .. n_scale) *= scale
+__global__ __launch_bounds__(256) void bucket_unpack_kernel(float* __restrict__ flat, int64_t n_scale, float scale,
+                                                            const float* __restrict__ flat_at, BucketPieces P, int n_pieces) {
+    const int k = blockIdx.y;
+    const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, step = (int64_t)gridDim.x * blockDim.x;
+    if (k == n_pieces) {
+        if (scale != 1.0f)
+            for (int64_t i = i0; i < n_scale; i += step) flat[i] *= scale;
+        return;
+    }
+    const float* src = flat_at + P.at[k];
+    float* dst = P.p[k];
+    for (int64_t i = i0; i < P.n[k]; i += step) dst[i] = src[i] * scale;
+}
+
+static int fill_pieces(float* const* pieces_host, const int64_t* sizes_host, int n_pieces, BucketPieces& P, int64_t& most,
+                       int64_t& total, const char* who) {
+    NSX_REQUIRE(n_pieces >= 0 && n_pieces <= NSX_MAX_BUCKET_PIECES && (n_pieces == 0 || (pieces_host && sizes_host)),
+                "%s: %d pieces (limit %d)", who, n_pieces, NSX_MAX_BUCKET_PIECES);
+    most = 0; total = 0;
+    for (int k = 0; k < NSX_MAX_BUCKET_PIECES; ++k) { P.p[k] = nullptr; P.n[k] = 0; P.at[k] = 0; }
+    for (int k = 0; k < n_pieces; ++k) {
+        NSX_REQUIRE(sizes_host[k] >= 0 && (sizes_host[k] == 0 || pieces_host[k]), "%s: piece %d: bad size or NULL", who, k);
+        P.p[k] = pieces_host[k]; P.n[k] = sizes_host[k]; P.at[k] = total;
+        total += sizes_host[k];
+        if (sizes_host[k] > most) most = sizes_host[k];
+    }
+    return NSX_OK;
+}
+
 }  // namespace nsx
 
 using namespace nsx;
@@ -1068,6 +1113,37 @@ int nsx_multi_adam_present(const nsx_tensor_ref* tensors_host, int n_tensors, co
     hipLaunchKernelGGL(multi_adam_kernel, dim3((unsigned)bx, (unsigned)n_tensors), dim3(256), 0, (hipStream_t)stream, T, H,
                        found_inf, present, P);
     NSX_LAUNCH_CHECK("nsx_multi_adam launch");
+    return NSX_OK;
+}
+
+int nsx_bucket_pack(float* flat_at, const float* const* pieces_host, const int64_t* sizes_host, int n_pieces, void* stream) {
+    BucketPieces P;
+    int64_t most, total;
+    if (int rc = fill_pieces(const_cast<float* const*>(reinterpret_cast<const float* const*>(pieces_host)), sizes_host, n_pieces, P,
+                             most, total, "nsx_bucket_pack"))
+        return rc;
+    if (total == 0) return NSX_OK;
+    NSX_REQUIRE(flat_at, "nsx_bucket_pack: NULL destination");
+    int64_t bx = (most + 1023) / 1024;
+    if (bx > 64) bx = 64;
+    hipLaunchKernelGGL(bucket_pack_kernel, dim3((unsigned)bx, (unsigned)n_pieces), dim3(256), 0, (hipStream_t)stream, flat_at, P);
+    NSX_LAUNCH_CHECK("nsx_bucket_pack launch");
+    return NSX_OK;
+}
+
+int nsx_bucket_unpack(float* flat, int64_t n_scale, float scale, const float* flat_at, float* const* pieces_host,
+                      const int64_t* sizes_host, int n_pieces, void* stream) {
+    BucketPieces P;
+    int64_t most, total;
+    if (int rc = fill_pieces(pieces_host, sizes_host, n_pieces, P, most, total, "nsx_bucket_unpack")) return rc;
+    NSX_REQUIRE(n_scale >= 0 && (n_scale == 0 || flat) && (total == 0 || flat_at), "nsx_bucket_unpack: NULL buffer");
+    if (n_scale > most) most = n_scale;
+    if (most == 0) return NSX_OK;
+    int64_t bx = (most + 1023) / 1024;
+    if (bx > 64) bx = 64;
+    hipLaunchKernelGGL(bucket_unpack_kernel, dim3((unsigned)bx, (unsigned)(n_pieces + 1)), dim3(256), 0, (hipStream_t)stream, flat,
+                       n_scale, scale, flat_at, P, n_pieces);
+    NSX_LAUNCH_CHECK("nsx_bucket_unpack launch");
     return NSX_OK;
 }
 

@@ -11,6 +11,7 @@ import torch
 import torch.distributed as dist
 
 SMALL_BUCKET_ELEMS = 1 << 22
+_NATIVE_PIECES = 16          # NSX_MAX_BUCKET_PIECES (include/nsx.h)
 
 
 def all_reduce_gradients(params: Iterable[torch.nn.Parameter], world_size: int, group=None,
@@ -96,17 +97,33 @@ def all_reduce_gradients(params: Iterable[torch.nn.Parameter], world_size: int, 
                 p.grad = sl.view(p.shape)
     if arena is not None:
         flat = arena.flat
-        off = int(arena.fixed)
-        for p in outside:                                        # (two embeddings' gradients, typically)
-            k = p.grad.numel()
-            flat[off:off + k].copy_(p.grad.reshape(-1))
-            off += k
-        n_grad = off
-        flat[off:off + 2 * n].copy_(tail)
-        off += 2 * n
-        if n_flags:
-            flat[off:off + n_flags].copy_(extra_flags.reshape(-1).to(torch.float32))
-            off += n_flags
+        fixed = int(arena.fixed)
+        # on the device the bucket's tail is written, and read back, by ONE launch each (nsx_bucket_pack / _unpack) instead of a
+        # copy per piece: ~7 launches fewer on a step the host paces (the CPU route below is what the gloo tests hold it to)
+        native = (flat.is_cuda and len(outside) + 2 <= _NATIVE_PIECES and all(p.grad.is_contiguous() and
+                  p.grad.dtype == torch.float32 for p in outside)
+                  and (extra_flags is None or (extra_flags.is_contiguous() and extra_flags.dtype == torch.float32)))
+        off = fixed
+        if native:
+            import ctypes as C
+            from .._lib import check, lib, stream
+            pieces = [p.grad for p in outside] + [tail] + ([extra_flags] if n_flags else [])
+            ptrs = (C.c_void_p * len(pieces))(*[t.data_ptr() for t in pieces])
+            sizes = (C.c_int64 * len(pieces))(*[t.numel() for t in pieces])
+            check(lib().nsx_bucket_pack(flat.data_ptr() + 4 * fixed, ptrs, sizes, len(pieces), stream()), "nsx_bucket_pack")
+            n_grad = fixed + sum(p.grad.numel() for p in outside)
+            off = n_grad + 2 * n + n_flags
+        else:
+            for p in outside:                                        # (two embeddings' gradients, typically)
+                k = p.grad.numel()
+                flat[off:off + k].copy_(p.grad.reshape(-1))
+                off += k
+            n_grad = off
+            flat[off:off + 2 * n].copy_(tail)
+            off += 2 * n
+            if n_flags:
+                flat[off:off + n_flags].copy_(extra_flags.reshape(-1).to(torch.float32))
+                off += n_flags
         span = flat[:off]
         if native_comm is not None:
             from .._lib import check, lib, stream
@@ -120,13 +137,18 @@ def all_reduce_gradients(params: Iterable[torch.nn.Parameter], world_size: int, 
         counts = aux[:2 * n].view(2, n)
         if n_flags:
             flags = aux[2 * n:]
-        if inv != 1.0:
-            flat[:n_grad].mul_(inv)
-        off = int(arena.fixed)
-        for p in outside:
-            k = p.grad.numel()
-            p.grad.copy_(flat[off:off + k].view_as(p.grad))
-            off += k
+        if native:
+            m = len(outside)
+            check(lib().nsx_bucket_unpack(flat.data_ptr(), fixed, float(inv), flat.data_ptr() + 4 * fixed, ptrs, sizes, m,
+                                          stream()), "nsx_bucket_unpack")
+        else:
+            if inv != 1.0:
+                flat[:n_grad].mul_(inv)
+            off = fixed
+            for p in outside:
+                k = p.grad.numel()
+                p.grad.copy_(flat[off:off + k].view_as(p.grad))
+                off += k
     else:
         pieces = [p.grad.reshape(-1).float() for p in small] + [tail]
         if n_flags:

@@ -632,6 +632,61 @@ def test_emulated_level_parallel_rank_through_rccl(cuda, single_rank_group):
     assert bool((dx2[kept:] == 7.0).all()) and torch.allclose(dx2[:kept], dx[:kept])
 
 
+def test_bucket_tail_in_one_launch_equals_the_copies(cuda, single_rank_group):
+    """``all_reduce_gradients`` with the step's gradient arena on the device: the bucket's tail (gradients without a slot, presence
+    counts, flags) goes in and comes back by ``nsx_bucket_pack`` / ``nsx_bucket_unpack`` -- one launch each -- instead of a copy
+    per piece (the route the gloo CPU tests hold).  Same gradients, counts and flags; the averaging factor of a W-rank job is
+    applied once to the buffer's fixed part and once to every returned piece; also through the library's own communicator."""
+    from nersemble_amd.engine import parallel
+    from nersemble_amd.engine.level_parallel import LevelParallel
+
+    def run(native, world, comm=None):
+        flat = torch.zeros((64 + 256,), device=cuda)
+        a1, a2 = torch.nn.Parameter(torch.zeros((4, 5), device=cuda)), torch.nn.Parameter(torch.zeros((9,), device=cuda))
+        out1, out2 = torch.nn.Parameter(torch.zeros((6,), device=cuda)), torch.nn.Parameter(torch.zeros((3, 7), device=cuda))
+        absent = torch.nn.Parameter(torch.zeros((5,), device=cuda))
+        slots = {id(a1): flat[3:23].view(4, 5), id(a2): flat[30:39]}
+
+        class _Arena:
+            fixed, slack = 40, 256
+
+            def __init__(self):
+                self.flat = flat
+
+            def slot_of(self, p):
+                return slots.get(id(p))
+
+        flat[23:30] = 99.0
+        flat[3:23] = torch.arange(20., device=cuda)
+        flat[30:39] = 2.0
+        a1.grad, a2.grad = slots[id(a1)], slots[id(a2)]
+        out1.grad = torch.full((6,), 3.0, device=cuda)
+        out2.grad = torch.arange(21., device=cuda).view(3, 7)
+        old = parallel._NATIVE_PIECES
+        parallel._NATIVE_PIECES = old if native else 0
+        try:
+            cnt, fl = parallel.all_reduce_gradients([a1, a2, out1, out2, absent], world, force=True, arena=_Arena(),
+                                                    extra_flags=torch.tensor([1.0, 0.0], device=cuda), native_comm=comm)
+        finally:
+            parallel._NATIVE_PIECES = old
+        torch.cuda.synchronize()
+        assert a1.grad.data_ptr() == flat[3:23].data_ptr() and absent.grad is None
+        return [a1.grad.clone(), a2.grad.clone(), out1.grad.clone(), out2.grad.clone(), cnt.clone(), fl.clone(), flat[23:30].clone()]
+
+    lp = LevelParallel(_he(8, cuda), 2, 0, emulate=True)          # (its communicator: the bucket's sum through the library)
+    try:
+        for world in (1, 4):
+            want = run(False, world)
+            for got in (run(True, world), run(True, world, lp.comm)):
+                for a, b in zip(got, want):
+                    assert torch.equal(a, b)
+            assert torch.equal(want[2], torch.full((6,), 3.0 / world, device=cuda))
+            assert want[4].tolist() == [[1.0, 1.0, 1.0, 1.0, 0.0], [0.0] * 5] and want[5].tolist() == [1.0, 0.0]
+            assert bool((want[6] == 99.0 / world).all())             # (a region of the fixed part that is nobody's is averaged with it)
+    finally:
+        lp.close()
+
+
 def test_collectives_issued_by_the_library_equal_the_torch_distributed_route(cuda, single_rank_group):
     """``LevelParallel`` on an RCCL group issues the exchange's collectives from C (csrc/comm.hip: ``nsx_lp_forward`` /
     ``nsx_lp_backward`` on the library's own communicator, one call per direction); ``native_collectives=False`` keeps the five
