@@ -88,6 +88,18 @@ def test_library_collectives_refuse_bad_arguments_before_touching_rccl():
     assert L.nsx_lp_backward(*args_b) != 0 and b"NULL communicator" in L.nsx_last_error()
 
 
+def test_bucket_tail_calls_check_their_arguments():
+    from nersemble_amd import _lib
+    L = _lib.lib()
+    sizes = (ctypes.c_int64 * 17)(*([1] * 17))
+    ptrs = (ctypes.c_void_p * 17)()
+    assert L.nsx_bucket_pack(None, ptrs, sizes, 17, None) != 0 and b"17 pieces (limit 16)" in L.nsx_last_error()
+    assert L.nsx_bucket_pack(None, ptrs, sizes, 2, None) != 0 and b"piece 0" in L.nsx_last_error()        # NULL piece of size 1
+    assert L.nsx_bucket_pack(None, None, None, 0, None) == 0                                              # nothing to do
+    assert L.nsx_bucket_unpack(None, 5, 0.5, None, None, None, 0, None) != 0 and b"NULL buffer" in L.nsx_last_error()
+    assert L.nsx_bucket_unpack(None, 0, 0.5, None, None, None, 0, None) == 0
+
+
 def test_error_reporting_across_abi():
     from nersemble_amd import _lib
     g = _lib.GridGeom()
