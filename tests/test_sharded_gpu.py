@@ -866,6 +866,52 @@ def test_emulated_rank_7_of_8_trains_through_the_native_step(cuda, single_rank_g
     assert c["collectives_per_step"] == 4 and c["host_exchanges_per_step"] == 1 and c["gradient_planes"] == 192
 
 
+def test_level_parallel_step_keeps_gradscaler_skip_semantics(cuda, single_rank_group):
+    """The level-parallel twin of ``test_early_table_step_keeps_gradscaler_skip_semantics``: an emulated rank of 8 through the native
+    step and the library's collectives; the owners' non-finite flags ride in the small gradients' bucket.  When the scaled
+    gradients overflow the step is skipped as a whole -- the owned levels' master / working tables and moments, the fused MLPs,
+    the deformation field and every step count untouched, the scale halves -- and the next (finite) step goes through."""
+    from nersemble_amd.engine.level_parallel import LevelParallelTableAdam
+    from nersemble_amd.workloads import build_workload
+    torch.manual_seed(4)
+    trainer, data, _ = build_workload("p030_h32", device="cuda:0", small=True, n_rays=512, window_hash=OPEN_WINDOW,
+                                      level_parallel_emulation=(8, 7))
+    model = trainer.model
+    opt = trainer.optimizers[trainer.group_of_tables()]
+    assert isinstance(opt, LevelParallelTableAdam) and opt.lp.comm is not None
+    small = trainer.optimizers["fields"]
+    trainer.train_iteration(0, *data.next_train(0))                     # a normal step first (moments exist)
+    trainer.flush_scheduler_step()
+    torch.cuda.synchronize()
+    model.field.hash_ensemble.wait_tables()
+    snap = lambda: {"master": opt.lp.slice_master().detach().clone(), "f16": opt.lp.slice_f16().clone(),
+                    "m": opt.exp_avg.clone(), "v": opt.exp_avg_sq.clone(),
+                    "base": model.field.mlp_base.params.detach().clone(),
+                    "deform": model.deformation_field.se3_field.mlp_stem.layers[0].weight.detach().clone(),
+                    "emb": model.time_embedding.weight.detach().clone()}
+    before = snap()
+    assert opt._step == 1 and small.step_count == 1
+    trainer.grad_scaler._scale.fill_(2.0 ** 60)                          # every fp16 gradient overflows
+    trainer.train_iteration(1, *data.next_train(1))
+    trainer.flush_scheduler_step()
+    torch.cuda.synchronize()
+    model.field.hash_ensemble.wait_tables()
+    after = snap()
+    for k in before:
+        assert torch.equal(after[k], before[k]), k
+    assert opt._step == 1 and small.step_count == 1
+    assert trainer.grad_scaler.get_scale() == 2.0 ** 59
+    trainer.grad_scaler._scale.fill_(65536.0)
+    trainer.train_iteration(2, *data.next_train(2))
+    trainer.flush_scheduler_step()
+    torch.cuda.synchronize()
+    model.field.hash_ensemble.wait_tables()
+    moved = snap()
+    assert opt._step == 2 and small.step_count == 2
+    for k in ("master", "f16", "m", "base", "deform"):
+        assert not torch.equal(moved[k], before[k]), k
+
+
 def test_a_trained_model_goes_on_as_a_frozen_emulated_rank(cuda, single_rank_group):
     """``NeRSembleTrainer.become_emulated_level_parallel_rank`` (what ``bench.py --level-parallel-one-rank`` prices in steady
     state): a single-GPU run continues as rank 3 of 8 with frozen parameters, the replicas' feature columns replaced by the
