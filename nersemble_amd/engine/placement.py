@@ -44,8 +44,15 @@ def _time_adam(he, master, m, v, f16, G, code, iters: int) -> float:
     return sorted(times)[len(times) // 2]
 
 
+DEFAULT_CANDIDATES = 14
+# Round 6, last session: over four benchmark runs of the round (24 candidates) a quarter of the placements were "fast" (1.76-1.93 ms
+# for the 12 GB pass) and the rest 2.03-2.19; with six candidates a run draws no fast one with probability 0.75^6 = 18 % -- the
+# final check's box did (best of six: 2.05 ms, headline 7.49 instead of 7.2-7.3 ms per step).  Fourteen candidates: 2 %.  They are
+# held at once (a freed set would be handed out again): 14 x 5.6 GB transient of 288 GB, ~0.2 s once per run.
+
+
 @torch.no_grad()
-def calibrate_table_placement(he, optimizer, candidates: int = 6, iters: int = 3,
+def calibrate_table_placement(he, optimizer, candidates: int = DEFAULT_CANDIDATES, iters: int = 3,
                               min_params: int = MIN_PARAMS) -> Optional[Dict[str, object]]:
     """Re-homes ``he.tables`` (fp32 master), ``he.tables_f16`` and the Adam moments of ``optimizer`` (a
     ``HashTableAdam`` that has not stepped yet) into the fastest of ``candidates`` placements.  Returns a report
